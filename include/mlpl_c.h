@@ -1,0 +1,177 @@
+/*
+ * mlpl_c.h -- C ABI of the MI355X-native (gfx950) descriptor-matching + robust-pose hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  The reference
+ * (josefmaierfl/matchinglib_poselib) has no FFI of its own for this path -- the path sits behind exported
+ * C++ functions -- so each entry point below names the reference code it replaces.  Paths are relative to
+ * /root/reference/matchinglib_poselib/source/ (M/ = matchinglib/, P/ = poselib/).
+ *
+ * Conventions
+ *   - return value: 0 = ok, negative = error.  Codes -1..-4 keep the meaning of the reference's getMatches
+ *     (M/source/matchers.cpp:109-114); MLPL_E_* below are this library's own.
+ *   - no exceptions, no exit(), no stdout.  mlpl_last_error() returns a thread-local message.
+ *   - the caller owns every buffer; outputs are caller-allocated.
+ *   - `*_dev` entry points take DEVICE pointers plus a hipStream_t (as void*), enqueue work and return
+ *     without synchronising; the plain entry points take HOST pointers, copy in/out and synchronise.
+ *   - a context (mlpl_ctx) owns the device workspace and a private stream; use one per host thread.
+ *   - there is NO CPU fallback: every compute entry point fails with MLPL_E_NO_DEVICE when no gfx950
+ *     device is usable.
+ */
+#ifndef MLPL_C_H
+#define MLPL_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLPL_OK 0
+#define MLPL_E_BAD_INPUT (-1)     /* getMatches: "Wrong input data"        (matchers.cpp:110) */
+#define MLPL_E_UNSUPPORTED (-2)   /* getMatches: "Matcher not supported"   (matchers.cpp:111) */
+#define MLPL_E_FAILED (-3)        /* getMatches: "Matching algorithm failed" / < 2 matches (matchers.cpp:112,709-713) */
+#define MLPL_E_FEW_KEYPOINTS (-4) /* getMatches: "Too less keypoits"       (matchers.cpp:113,123-127) */
+#define MLPL_E_NO_DEVICE (-100)
+#define MLPL_E_HIP (-101)
+#define MLPL_E_NOMEM (-102)
+
+/* cv::DMatch layout {int queryIdx; int trainIdx; int imgIdx; float distance;} -- 16 bytes. */
+typedef struct mlpl_dmatch {
+    int32_t queryIdx;
+    int32_t trainIdx;
+    int32_t imgIdx;
+    float distance;
+} mlpl_dmatch;
+
+typedef struct mlpl_ctx mlpl_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------------ */
+int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out);
+void mlpl_ctx_destroy(mlpl_ctx *ctx);
+const char *mlpl_last_error(void);
+const char *mlpl_version(void);
+/* Number of visible HIP devices (0 when none); does not create a context. */
+int mlpl_device_count(void);
+/* The context's private stream (hipStream_t) and device ordinal. */
+void *mlpl_ctx_stream(mlpl_ctx *ctx);
+int mlpl_ctx_device(mlpl_ctx *ctx);
+int mlpl_ctx_synchronize(mlpl_ctx *ctx);
+
+/* ---- in-library kernel timing (for roofline accounting) ------------------------------------------------------
+ * When enabled, the launches of the dominant kernel of each path are bracketed with hipEvents on the stream
+ * they run on.  mlpl_profile_read() synchronises those events and returns the summed duration and the
+ * launch count since the last reset.  kernel_id: 0 = knn_hamming_partial, 1 = knn_l2 (exact or MFMA),
+ * 2 = 5-point solver, 3 = Sampson scoring, 4 = recover_pose. */
+#define MLPL_PROF_KNN_HAMMING 0
+#define MLPL_PROF_KNN_L2 1
+#define MLPL_PROF_SOLVE_5PT 2
+#define MLPL_PROF_SCORE 3
+#define MLPL_PROF_RECOVER_POSE 4
+#define MLPL_PROF_NUM 5
+int mlpl_profile_enable(mlpl_ctx *ctx, int on);
+int mlpl_profile_reset(mlpl_ctx *ctx);
+int mlpl_profile_read(mlpl_ctx *ctx, int kernel_id, double *total_ms, int *launches);
+
+/* ---- brute-force k-NN (k = 1 or 2) ---------------------------------------------------------------------
+ * Replaces cvflann::Index<HammingLUT>(dataset, LinearIndexParams()).knnSearch(query, indices, dists, nn, ...)
+ * at M/source/matchers.cpp:567-588 (CV_8U) and cvflann::Index<L2<float>> at :634-664 (CV_32F).
+ * q = descriptors1 (query, nq rows), t = descriptors2 (train, nt rows).  Strides are in BYTES for the
+ * Hamming entry and in ELEMENTS for the float entry.  idx/dist are nq*k row-major.
+ * Result = the k lexicographically smallest (distance, trainIdx) pairs, ascending (cvflann
+ * KNNUniqueResultSet semantics).  Hamming distances are exact integers; L2 is SQUARED, summed in fp32 in
+ * the reference's order (4 differences per step), so both are bit-exact against the CPU path.
+ * Requires nt >= k, nbytes in [1,256] / dim in [1,1024].
+ */
+int mlpl_knn2_hamming(mlpl_ctx *ctx, const uint8_t *q, int nq, size_t q_stride, const uint8_t *t, int nt,
+                      size_t t_stride, int nbytes, int k, int32_t *idx, int32_t *dist);
+int mlpl_knn2_l2sq_f32(mlpl_ctx *ctx, const float *q, int nq, size_t q_stride, const float *t, int nt,
+                       size_t t_stride, int dim, int k, int32_t *idx, float *dist);
+
+/* Device-pointer, batched forms.  `batch` independent problems of identical shape; problem b reads
+ * q + b*q_batch_stride (bytes for Hamming / elements for float), writes idx + b*nq*k etc. */
+int mlpl_knn2_hamming_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_stride, size_t q_batch_stride,
+                          const uint8_t *d_t, int nt, size_t t_stride, size_t t_batch_stride, int nbytes, int k,
+                          int batch, int32_t *d_idx, int32_t *d_dist, void *stream);
+int mlpl_knn2_l2sq_f32_dev(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_batch_stride,
+                           const float *d_t, int nt, size_t t_stride, size_t t_batch_stride, int dim, int k,
+                           int batch, int32_t *d_idx, float *d_dist, void *stream);
+/* L2 fast path selector for the *_dev/host float entries: 0 = auto (fp16 MFMA distance-GEMM when every
+ * element is an integer in [0,255], else the exact fp32 VALU kernel), 1 = force exact fp32 VALU,
+ * 2 = force MFMA (MLPL_E_BAD_INPUT if the data are not integer-valued 0..255). */
+int mlpl_set_l2_path(mlpl_ctx *ctx, int mode);
+
+/* ---- ratio test + DMatch emission ----------------------------------------------------------------------
+ * Replaces the loops at M/source/matchers.cpp:601-625 (int distances) and :677-701 (float distances):
+ * k==2: keep q iff (float)d0 < ratio*(float)d1 (reference ratio = 0.75f); k==1: keep every q.
+ * Matches are emitted in ascending queryIdx, imgIdx = -1, distance = (float)d0.
+ * out must hold nq entries (per batch item); *n_out receives the count.
+ */
+int mlpl_ratio_compact_i32(mlpl_ctx *ctx, const int32_t *idx, const int32_t *dist, int nq, int k, float ratio,
+                           mlpl_dmatch *out, int *n_out);
+int mlpl_ratio_compact_f32(mlpl_ctx *ctx, const int32_t *idx, const float *dist, int nq, int k, float ratio,
+                           mlpl_dmatch *out, int *n_out);
+int mlpl_ratio_compact_i32_dev(mlpl_ctx *ctx, const int32_t *d_idx, const int32_t *d_dist, int nq, int k,
+                               int batch, float ratio, mlpl_dmatch *d_out, int32_t *d_n_out, void *stream);
+int mlpl_ratio_compact_f32_dev(mlpl_ctx *ctx, const int32_t *d_idx, const float *d_dist, int nq, int k,
+                               int batch, float ratio, mlpl_dmatch *d_out, int32_t *d_n_out, void *stream);
+
+/* ---- getMatches(..., "LINEAR", ...) in one call ---------------------------------------------------------
+ * Replaces the whole LINEAR branch, M/source/matchers.cpp:115-135 + 525-714.  desc_type: 0 = CV_8U
+ * (cols bytes per row), 5 = CV_32F (cols floats per row); step1/step2 = cv::Mat::step in bytes.
+ * Returns the reference's codes (0, -1, -3, -4).  out must hold rows1 entries.
+ */
+int mlpl_get_matches_linear(mlpl_ctx *ctx, int n_keypoints1, int n_keypoints2, const void *desc1, int rows1,
+                            size_t step1, const void *desc2, int rows2, size_t step2, int cols, int desc_type,
+                            int ratio_test, mlpl_dmatch *out, int *n_out);
+/* Device-resident, batched: knn + ratio + compaction, nothing leaves the device. */
+int mlpl_match_hamming_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_stride, size_t q_batch_stride,
+                           const uint8_t *d_t, int nt, size_t t_stride, size_t t_batch_stride, int nbytes,
+                           int ratio_test, float ratio, int batch, int32_t *d_idx, int32_t *d_dist,
+                           mlpl_dmatch *d_out, int32_t *d_n_out, void *stream);
+
+/* ---- robust essential matrix ----------------------------------------------------------------------------
+ * Replaces poselib::estimateEssentialMat(E,p1,p2,"RANSAC",th,refine,mask) (P/source/pose_estim.cpp:857-890)
+ * = findEssentialMat (P/source/five-point-nister/five-point.cpp:69-148) = CvModelEstimator3::runRANSAC
+ * (modelest.cpp:343-474) with the Nister solver CvEMEstimator::run5Point (five-point.cpp:366-471) and
+ * Sampson scoring computeReprojError3 (five-point.cpp:476-503).
+ * p1,p2: n x 2 doubles (camera-normalised).  The reference hard-codes max_iters=1000, confidence=0.999
+ * and seeds std::srand(time) (modelest.cpp:58); here they are parameters, and `seed` reproduces the glibc
+ * srand(seed)/rand() sample stream so that a fixed seed gives the CPU path's hypotheses.
+ * refit != 0 = the reference's `lesqu` least-squares step on all inliers (modelest.cpp:420-464).
+ * mask: n bytes, 1 = inlier.  Returns 0 on success, MLPL_E_FAILED when no model was found
+ * (reference returns false), -1 on bad input.
+ */
+int mlpl_ransac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n, double thresh,
+                          double confidence, int max_iters, int refit, uint32_t seed, double E[9],
+                          uint8_t *mask, int *n_inliers, int *iters_used);
+/* Device-resident points; E/mask/n_inliers/iters_used are HOST outputs (the replay of the sequential
+ * best/niters logic needs one device->host hop).  d_p1/d_p2: n x 2 doubles on the device. */
+int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thresh,
+                              double confidence, int max_iters, int refit, uint32_t seed, double E[9],
+                              uint8_t *d_mask, int *n_inliers, int *iters_used, void *stream);
+
+/* Building blocks, exposed for parity tests and for callers that schedule the phases themselves. */
+/* 5-point minimal solver, one wavefront per sample: samples = n_samples x 5 indices into p1/p2 (host).
+ * E_out: n_samples x 10 x 9 doubles, n_models: n_samples ints (host). Replaces run5Point (five-point.cpp:366-471). */
+int mlpl_solve_5pt(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const int32_t *samples, int n_samples,
+                   double *E_out, int32_t *n_models);
+/* Sampson scoring of n_models 3x3 matrices against n correspondences: count[i] = #{err <= thresh^2},
+ * err_sum[i] = sum of the float-rounded errors (findInliers + cv::sum(err), modelest.cpp:69-83,407). */
+int mlpl_score_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const double *E, int n_models,
+                      double thresh, int32_t *count, double *err_sum);
+
+/* ---- cheirality / pose recovery --------------------------------------------------------------------------
+ * Replaces poselib::getPoseTriangPts (P/source/pose_estim.cpp:913-946) = recoverPose
+ * (five-point.cpp:150-338) with t_only empty: decomposeEssentialMat (:340-352), four triangulations,
+ * masks z*w>0, (P*Q)z*w>0, z<dist, AND with mask_inout (NULL = all ones), candidate choice by the
+ * reference's if-chain.  R: 9, t: 3, Q: n x 3 doubles, mask_inout: n bytes (nonzero = keep; rewritten as
+ * 0/255 like the reference's comparison masks).  Returns the number of good points (>=0) or a negative error.
+ */
+int mlpl_recover_pose(mlpl_ctx *ctx, const double E[9], const double *p1, const double *p2, int n, double dist,
+                      double R[9], double t[3], double *Q, uint8_t *mask_inout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLPL_C_H */

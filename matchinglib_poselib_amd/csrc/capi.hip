@@ -1,0 +1,375 @@
+// capi.hip -- context management and the host-pointer entry points of the C ABI (include/mlpl_c.h).
+// Every compute path here ends in a HIP kernel launch; there is no CPU fallback.
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "mlpl_internal.h"
+
+namespace mlpl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ws_get(mlpl_ctx *ctx, WsSlot slot, size_t bytes, void **out) {
+    if (bytes == 0) bytes = 16;
+    if (ctx->ws_bytes[slot] < bytes) {
+        // growing: make sure nothing in flight still uses the old buffer
+        MLPL_HIP_TRY(hipDeviceSynchronize());
+        if (ctx->ws[slot]) MLPL_HIP_TRY(hipFree(ctx->ws[slot]));
+        ctx->ws[slot] = nullptr;
+        ctx->ws_bytes[slot] = 0;
+        size_t want = bytes + bytes / 4;
+        want = (want + 255) & ~size_t(255);
+        hipError_t e = hipMalloc(&ctx->ws[slot], want);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            return MLPL_E_NOMEM;
+        }
+        ctx->ws_bytes[slot] = want;
+    }
+    *out = ctx->ws[slot];
+    return MLPL_OK;
+}
+
+int pinned_get(mlpl_ctx *ctx, size_t bytes, void **out) {
+    if (ctx->pinned_bytes < bytes) {
+        MLPL_HIP_TRY(hipDeviceSynchronize());
+        if (ctx->pinned) MLPL_HIP_TRY(hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+        size_t want = std::max<size_t>(bytes * 2, 4096);
+        hipError_t e = hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            return MLPL_E_NOMEM;
+        }
+        ctx->pinned_bytes = want;
+    }
+    *out = ctx->pinned;
+    return MLPL_OK;
+}
+
+void prof_mark(mlpl_ctx *ctx, int id, int phase, hipStream_t s) {
+    if (!ctx->prof_on) return;
+    if (!ctx->prof_ev[id]) {
+        ctx->prof_ev[id] = new hipEvent_t[2 * kProfMaxLaunches];
+        for (int i = 0; i < 2 * kProfMaxLaunches; ++i) (void)hipEventCreate(&ctx->prof_ev[id][i]);
+    }
+    if (ctx->prof_n[id] >= kProfMaxLaunches) return;
+    (void)hipEventRecord(ctx->prof_ev[id][2 * ctx->prof_n[id] + phase], s);
+    if (phase == 1) ctx->prof_n[id]++;
+}
+
+}  // namespace mlpl
+
+using namespace mlpl;
+
+extern "C" {
+
+const char *mlpl_last_error(void) { return g_err; }
+const char *mlpl_version(void) { return "mlpl-hip 0.1 (gfx950)"; }
+
+int mlpl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
+    if (!out) return MLPL_E_BAD_INPUT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device visible: this library has no CPU fallback");
+        return MLPL_E_NO_DEVICE;
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) {
+        set_error("device ordinal %d out of range [0,%d)", device_ordinal, n);
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    MLPL_HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library carries gfx950 code objects only", device_ordinal, prop.gcnArchName);
+        return MLPL_E_NO_DEVICE;
+    }
+    mlpl_ctx *ctx = new (std::nothrow) mlpl_ctx();
+    if (!ctx) return MLPL_E_NOMEM;
+    std::memset(ctx, 0, sizeof(*ctx));
+    ctx->device = device_ordinal;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return MLPL_E_HIP;
+    }
+    *out = ctx;
+    return MLPL_OK;
+}
+
+void mlpl_ctx_destroy(mlpl_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < WS_NUM_SLOTS; ++i)
+        if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    for (int k = 0; k < MLPL_PROF_NUM; ++k) {
+        if (!ctx->prof_ev[k]) continue;
+        for (int i = 0; i < 2 * kProfMaxLaunches; ++i) (void)hipEventDestroy(ctx->prof_ev[k][i]);
+        delete[] ctx->prof_ev[k];
+    }
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void *mlpl_ctx_stream(mlpl_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int mlpl_ctx_device(mlpl_ctx *ctx) { return ctx ? ctx->device : -1; }
+int mlpl_ctx_synchronize(mlpl_ctx *ctx) {
+    if (!ctx) return MLPL_E_BAD_INPUT;
+    MLPL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MLPL_OK;
+}
+
+int mlpl_profile_enable(mlpl_ctx *ctx, int on) {
+    if (!ctx) return MLPL_E_BAD_INPUT;
+    ctx->prof_on = on ? 1 : 0;
+    return MLPL_OK;
+}
+
+int mlpl_profile_reset(mlpl_ctx *ctx) {
+    if (!ctx) return MLPL_E_BAD_INPUT;
+    MLPL_HIP_TRY(hipDeviceSynchronize());
+    for (int k = 0; k < MLPL_PROF_NUM; ++k) ctx->prof_n[k] = 0;
+    return MLPL_OK;
+}
+
+int mlpl_profile_read(mlpl_ctx *ctx, int kernel_id, double *total_ms, int *launches) {
+    if (!ctx || kernel_id < 0 || kernel_id >= MLPL_PROF_NUM || !total_ms || !launches) return MLPL_E_BAD_INPUT;
+    double tot = 0.0;
+    const int n = ctx->prof_n[kernel_id];
+    for (int i = 0; i < n; ++i) {
+        MLPL_HIP_TRY(hipEventSynchronize(ctx->prof_ev[kernel_id][2 * i + 1]));
+        float ms = 0.f;
+        MLPL_HIP_TRY(hipEventElapsedTime(&ms, ctx->prof_ev[kernel_id][2 * i], ctx->prof_ev[kernel_id][2 * i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = n;
+    return MLPL_OK;
+}
+
+int mlpl_set_l2_path(mlpl_ctx *ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 2) return MLPL_E_BAD_INPUT;
+    ctx->l2_mode = mode;
+    return MLPL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// device-pointer entry points
+// ---------------------------------------------------------------------------------------------------------
+
+int mlpl_knn2_hamming_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_stride, size_t q_batch_stride,
+                          const uint8_t *d_t, int nt, size_t t_stride, size_t t_batch_stride, int nbytes, int k,
+                          int batch, int32_t *d_idx, int32_t *d_dist, void *stream) {
+    if (!ctx) return MLPL_E_BAD_INPUT;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_knn_hamming(ctx, d_q, nq, q_stride, q_batch_stride, d_t, nt, t_stride, t_batch_stride, nbytes, k,
+                              batch, d_idx, d_dist, pick_stream(ctx, stream));
+}
+
+int mlpl_knn2_l2sq_f32_dev(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_batch_stride,
+                           const float *d_t, int nt, size_t t_stride, size_t t_batch_stride, int dim, int k, int batch,
+                           int32_t *d_idx, float *d_dist, void *stream) {
+    if (!ctx) return MLPL_E_BAD_INPUT;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_knn_l2(ctx, d_q, nq, q_stride, q_batch_stride, d_t, nt, t_stride, t_batch_stride, dim, k, batch,
+                         d_idx, d_dist, pick_stream(ctx, stream));
+}
+
+int mlpl_ratio_compact_i32_dev(mlpl_ctx *ctx, const int32_t *d_idx, const int32_t *d_dist, int nq, int k, int batch,
+                               float ratio, mlpl_dmatch *d_out, int32_t *d_n_out, void *stream) {
+    if (!ctx) return MLPL_E_BAD_INPUT;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_ratio_compact(ctx, d_idx, d_dist, 0, nq, k, batch, ratio, d_out, d_n_out, pick_stream(ctx, stream));
+}
+
+int mlpl_ratio_compact_f32_dev(mlpl_ctx *ctx, const int32_t *d_idx, const float *d_dist, int nq, int k, int batch,
+                               float ratio, mlpl_dmatch *d_out, int32_t *d_n_out, void *stream) {
+    if (!ctx) return MLPL_E_BAD_INPUT;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_ratio_compact(ctx, d_idx, d_dist, 1, nq, k, batch, ratio, d_out, d_n_out, pick_stream(ctx, stream));
+}
+
+int mlpl_match_hamming_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_stride, size_t q_batch_stride,
+                           const uint8_t *d_t, int nt, size_t t_stride, size_t t_batch_stride, int nbytes,
+                           int ratio_test, float ratio, int batch, int32_t *d_idx, int32_t *d_dist, mlpl_dmatch *d_out,
+                           int32_t *d_n_out, void *stream) {
+    if (!ctx) return MLPL_E_BAD_INPUT;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = pick_stream(ctx, stream);
+    const int k = ratio_test ? 2 : 1;
+    int rc = launch_knn_hamming(ctx, d_q, nq, q_stride, q_batch_stride, d_t, nt, t_stride, t_batch_stride, nbytes, k,
+                                batch, d_idx, d_dist, s);
+    if (rc) return rc;
+    return launch_ratio_compact(ctx, d_idx, d_dist, 0, nq, k, batch, ratio, d_out, d_n_out, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-pointer entry points: stage through the context workspace, run the device path, copy back
+// ---------------------------------------------------------------------------------------------------------
+
+namespace {
+
+// Copies `rows` rows of `row_bytes` bytes (host stride `stride`) into a dense device buffer.
+int upload_rows(mlpl_ctx *ctx, WsSlot slot, const void *host, int rows, size_t row_bytes, size_t stride, void **dev) {
+    int rc = ws_get(ctx, slot, (size_t)rows * row_bytes, dev);
+    if (rc) return rc;
+    if (rows == 0) return MLPL_OK;
+    MLPL_HIP_TRY(hipMemcpy2DAsync(*dev, row_bytes, host, stride, row_bytes, rows, hipMemcpyHostToDevice, ctx->stream));
+    return MLPL_OK;
+}
+
+}  // namespace
+
+int mlpl_knn2_hamming(mlpl_ctx *ctx, const uint8_t *q, int nq, size_t q_stride, const uint8_t *t, int nt, size_t t_stride,
+                      int nbytes, int k, int32_t *idx, int32_t *dist) {
+    if (!ctx || !q || !t || !idx || !dist || nq < 0 || nt < 0 || nbytes < 1 || q_stride < (size_t)nbytes ||
+        t_stride < (size_t)nbytes || (k != 1 && k != 2) || nt < k) {
+        set_error("mlpl_knn2_hamming: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    if (nq == 0) return MLPL_OK;
+    void *dq, *dt, *didx, *ddist;
+    int rc;
+    if ((rc = upload_rows(ctx, WS_AUX0, q, nq, nbytes, q_stride, &dq))) return rc;
+    if ((rc = upload_rows(ctx, WS_AUX1, t, nt, nbytes, t_stride, &dt))) return rc;
+    if ((rc = ws_get(ctx, WS_IDX, (size_t)nq * k * 4, &didx))) return rc;
+    if ((rc = ws_get(ctx, WS_DIST, (size_t)nq * k * 4, &ddist))) return rc;
+    rc = launch_knn_hamming(ctx, (const uint8_t *)dq, nq, nbytes, 0, (const uint8_t *)dt, nt, nbytes, 0, nbytes, k, 1,
+                            (int32_t *)didx, (int32_t *)ddist, ctx->stream);
+    if (rc) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(idx, didx, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MLPL_HIP_TRY(hipMemcpyAsync(dist, ddist, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MLPL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MLPL_OK;
+}
+
+int mlpl_knn2_l2sq_f32(mlpl_ctx *ctx, const float *q, int nq, size_t q_stride, const float *t, int nt, size_t t_stride,
+                       int dim, int k, int32_t *idx, float *dist) {
+    if (!ctx || !q || !t || !idx || !dist || nq < 0 || nt < 0 || dim < 1 || q_stride < (size_t)dim ||
+        t_stride < (size_t)dim || (k != 1 && k != 2) || nt < k) {
+        set_error("mlpl_knn2_l2sq_f32: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    if (nq == 0) return MLPL_OK;
+    void *dq, *dt, *didx, *ddist;
+    int rc;
+    if ((rc = upload_rows(ctx, WS_AUX0, q, nq, (size_t)dim * 4, q_stride * 4, &dq))) return rc;
+    if ((rc = upload_rows(ctx, WS_AUX1, t, nt, (size_t)dim * 4, t_stride * 4, &dt))) return rc;
+    if ((rc = ws_get(ctx, WS_IDX, (size_t)nq * k * 4, &didx))) return rc;
+    if ((rc = ws_get(ctx, WS_DIST, (size_t)nq * k * 4, &ddist))) return rc;
+    rc = launch_knn_l2(ctx, (const float *)dq, nq, dim, 0, (const float *)dt, nt, dim, 0, dim, k, 1, (int32_t *)didx,
+                       (float *)ddist, ctx->stream);
+    if (rc) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(idx, didx, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MLPL_HIP_TRY(hipMemcpyAsync(dist, ddist, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MLPL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MLPL_OK;
+}
+
+static int ratio_compact_host(mlpl_ctx *ctx, const int32_t *idx, const void *dist, int is_float, int nq, int k,
+                              float ratio, mlpl_dmatch *out, int *n_out) {
+    if (!ctx || !idx || !dist || !out || !n_out || nq < 0 || (k != 1 && k != 2)) {
+        set_error("mlpl_ratio_compact: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    *n_out = 0;
+    if (nq == 0) return MLPL_OK;
+    void *didx, *ddist, *dout, *dcnt;
+    int rc;
+    if ((rc = ws_get(ctx, WS_IDX, (size_t)nq * k * 4, &didx))) return rc;
+    if ((rc = ws_get(ctx, WS_DIST, (size_t)nq * k * 4, &ddist))) return rc;
+    if ((rc = ws_get(ctx, WS_MATCH, (size_t)nq * sizeof(mlpl_dmatch), &dout))) return rc;
+    if ((rc = ws_get(ctx, WS_COUNT, 64, &dcnt))) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(didx, idx, (size_t)nq * k * 4, hipMemcpyHostToDevice, ctx->stream));
+    MLPL_HIP_TRY(hipMemcpyAsync(ddist, dist, (size_t)nq * k * 4, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_ratio_compact(ctx, (const int32_t *)didx, ddist, is_float, nq, k, 1, ratio, (mlpl_dmatch *)dout,
+                              (int32_t *)dcnt, ctx->stream);
+    if (rc) return rc;
+    int32_t cnt = 0;
+    MLPL_HIP_TRY(hipMemcpyAsync(&cnt, dcnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MLPL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (cnt > 0) MLPL_HIP_TRY(hipMemcpy(out, dout, (size_t)cnt * sizeof(mlpl_dmatch), hipMemcpyDeviceToHost));
+    *n_out = cnt;
+    return MLPL_OK;
+}
+
+int mlpl_ratio_compact_i32(mlpl_ctx *ctx, const int32_t *idx, const int32_t *dist, int nq, int k, float ratio,
+                           mlpl_dmatch *out, int *n_out) {
+    return ratio_compact_host(ctx, idx, dist, 0, nq, k, ratio, out, n_out);
+}
+
+int mlpl_ratio_compact_f32(mlpl_ctx *ctx, const int32_t *idx, const float *dist, int nq, int k, float ratio,
+                           mlpl_dmatch *out, int *n_out) {
+    return ratio_compact_host(ctx, idx, dist, 1, nq, k, ratio, out, n_out);
+}
+
+int mlpl_get_matches_linear(mlpl_ctx *ctx, int n_keypoints1, int n_keypoints2, const void *desc1, int rows1, size_t step1,
+                            const void *desc2, int rows2, size_t step2, int cols, int desc_type, int ratio_test,
+                            mlpl_dmatch *out, int *n_out) {
+    if (!ctx || !n_out) return MLPL_E_BAD_INPUT;
+    *n_out = 0;
+    // reference matchers.cpp:123-133
+    if (n_keypoints1 < 15 || n_keypoints2 < 15) return MLPL_E_FEW_KEYPOINTS;
+    if (n_keypoints1 != rows1 || n_keypoints2 != rows2) return MLPL_E_BAD_INPUT;
+    // reference matchers.cpp:540-547
+    if (desc_type != 0 && desc_type != 5) return MLPL_E_BAD_INPUT;
+    if (!desc1 || !desc2 || !out || cols < 1) return MLPL_E_BAD_INPUT;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    const int k = ratio_test ? 2 : 1;  // matchers.cpp:529-538
+    const size_t elem = desc_type == 0 ? 1 : 4;
+    if (step1 < (size_t)cols * elem || step2 < (size_t)cols * elem) return MLPL_E_BAD_INPUT;
+    void *dq, *dt, *didx, *ddist, *dout, *dcnt;
+    int rc;
+    if ((rc = upload_rows(ctx, WS_AUX0, desc1, rows1, (size_t)cols * elem, step1, &dq))) return rc;
+    if ((rc = upload_rows(ctx, WS_AUX1, desc2, rows2, (size_t)cols * elem, step2, &dt))) return rc;
+    if ((rc = ws_get(ctx, WS_IDX, (size_t)rows1 * k * 4, &didx))) return rc;
+    if ((rc = ws_get(ctx, WS_DIST, (size_t)rows1 * k * 4, &ddist))) return rc;
+    if ((rc = ws_get(ctx, WS_MATCH, (size_t)rows1 * sizeof(mlpl_dmatch), &dout))) return rc;
+    if ((rc = ws_get(ctx, WS_COUNT, 64, &dcnt))) return rc;
+    if (desc_type == 0) {
+        rc = launch_knn_hamming(ctx, (const uint8_t *)dq, rows1, cols, 0, (const uint8_t *)dt, rows2, cols, 0, cols, k, 1,
+                                (int32_t *)didx, (int32_t *)ddist, ctx->stream);
+    } else {
+        rc = launch_knn_l2(ctx, (const float *)dq, rows1, cols, 0, (const float *)dt, rows2, cols, 0, cols, k, 1,
+                           (int32_t *)didx, (float *)ddist, ctx->stream);
+    }
+    if (rc) return rc == MLPL_E_BAD_INPUT ? MLPL_E_BAD_INPUT : rc;
+    rc = launch_ratio_compact(ctx, (const int32_t *)didx, ddist, desc_type == 5, rows1, k, 1, 0.75f, (mlpl_dmatch *)dout,
+                              (int32_t *)dcnt, ctx->stream);
+    if (rc) return rc;
+    int32_t cnt = 0;
+    MLPL_HIP_TRY(hipMemcpyAsync(&cnt, dcnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MLPL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (cnt > 0) MLPL_HIP_TRY(hipMemcpy(out, dout, (size_t)cnt * sizeof(mlpl_dmatch), hipMemcpyDeviceToHost));
+    *n_out = cnt;
+    if (cnt < 2) return MLPL_E_FAILED;  // matchers.cpp:709-713 (MIN_FINAL_MATCHES = 2)
+    return MLPL_OK;
+}
+
+}  // extern "C"

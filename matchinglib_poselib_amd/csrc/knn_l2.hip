@@ -1,0 +1,189 @@
+// knn_l2.hip -- exact brute-force 2-NN under squared L2 distance on float descriptors (gfx950).
+//
+// Replaces cvflann::Index<L2<float>>(LinearIndexParams).knnSearch as called by
+// matchinglib::getMatches(...,"LINEAR",...) -- reference matchinglib/source/matchers.cpp:634-664.
+//
+// Two device paths, both bit-exact against the CPU path:
+//   (1) knn_l2_exact_kernel  -- fp32 VALU, reproduces cvflann::L2<float>'s summation order
+//       (per 4 elements: result += ((d0*d0 + d1*d1) + d2*d2) + d3*d3, then a scalar tail) with explicit
+//       round-to-nearest mul/add (no FMA contraction: the reference is built -msse4.2, no FMA).
+//   (2) knn_l2_mfma_*        -- fp16 MFMA distance-GEMM  |a|^2 + |b|^2 - 2 a.b  with fused top-2, used only
+//       when every element is an integer in [0,255] (OpenCV SIFT layout): then every product, every partial
+//       sum and d^2 are integers < 2^24, exact in the fp32 accumulator AND in the reference's fp32 sum, so
+//       the distances are identical.  See knn_l2_mfma.hip.
+// Keys are 64-bit (float_bits(d2) << 32 | trainIdx): non-negative floats order like unsigned ints, so the
+// running top-2 is a lexicographic (distance, trainIdx) min exactly like cvflann's KNNUniqueResultSet.
+
+#include "mlpl_internal.h"
+
+namespace mlpl {
+
+int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t, int nt,
+                       size_t t_stride, size_t t_bstride, int dim, int k, int batch, int32_t *d_idx, float *d_dist,
+                       hipStream_t s, int force);
+
+namespace {
+
+constexpr int kQPB = 256;   // queries per block, one per lane
+constexpr int kMaxTileRows = 32;
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void top2_update(u64 &k0, u64 &k1, u64 key) {
+    const bool lt0 = key < k0;
+    const bool lt1 = key < k1;
+    k1 = lt0 ? k0 : (lt1 ? key : k1);
+    k0 = lt0 ? key : k0;
+}
+
+// cvflann::L2<float>::operator() restated for one 4-group.
+__device__ __forceinline__ float l2_group4(float result, float4 a, float4 b) {
+    const float d0 = __fsub_rn(a.x, b.x), d1 = __fsub_rn(a.y, b.y), d2 = __fsub_rn(a.z, b.z), d3 = __fsub_rn(a.w, b.w);
+    float s = __fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1));
+    s = __fadd_rn(s, __fmul_rn(d2, d2));
+    s = __fadd_rn(s, __fmul_rn(d3, d3));
+    return __fadd_rn(result, s);
+}
+
+// DIM4 = number of float4 groups held in registers per query (dim = 4*DIM4 + tail, tail < 4 handled via LDS/global).
+// Generic variant (DIM4 == 0) keeps the query in LDS as well.
+template <int DIM4>
+__global__ __launch_bounds__(kQPB) void knn_l2_exact_kernel(const float *__restrict__ q, size_t q_stride, size_t q_bstride,
+                                                            const float *__restrict__ t, size_t t_stride, size_t t_bstride,
+                                                            int nq, int nt, int dim, int rows_per_split, int nsplit, int tile_rows,
+                                                            ulonglong2 *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [tile_rows][dim_pad]
+    const int dim_pad = (dim + 3) & ~3;
+    const int tid = threadIdx.x;
+    const int split = blockIdx.y, b = blockIdx.z;
+    const int qi = blockIdx.x * kQPB + tid;
+    q += (size_t)b * q_bstride;
+    t += (size_t)b * t_bstride;
+    const int ngroups = dim / 4;
+    const int tail = dim - ngroups * 4;
+
+    float4 qa[DIM4 > 0 ? DIM4 : 1];
+    float qtail[3] = {0.f, 0.f, 0.f};
+    const float *qrow = q + (size_t)(qi < nq ? qi : 0) * q_stride;
+    if constexpr (DIM4 > 0) {
+#pragma unroll
+        for (int g = 0; g < DIM4; ++g) qa[g] = make_float4(qrow[4 * g], qrow[4 * g + 1], qrow[4 * g + 2], qrow[4 * g + 3]);
+    }
+    for (int j = 0; j < tail; ++j) qtail[j] = qrow[ngroups * 4 + j];
+
+    u64 k0 = ~0ull, k1 = ~0ull;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(nt, r_begin + rows_per_split);
+    for (int base = r_begin; base < r_end; base += tile_rows) {
+        const int rows = min(tile_rows, r_end - base);
+        __syncthreads();
+        for (int i = tid; i < rows * dim_pad; i += kQPB) {
+            const int r = i / dim_pad, c = i - r * dim_pad;
+            smem[i] = (c < dim) ? t[(size_t)(base + r) * t_stride + c] : 0.f;
+        }
+        __syncthreads();
+        for (int r = 0; r < rows; ++r) {
+            const float4 *trow = reinterpret_cast<const float4 *>(smem + (size_t)r * dim_pad);
+            float res = 0.f;
+            if constexpr (DIM4 > 0) {
+#pragma unroll
+                for (int g = 0; g < DIM4; ++g) res = l2_group4(res, trow[g], qa[g]);
+            } else {
+                for (int g = 0; g < ngroups; ++g) {
+                    const float4 qv = make_float4(qrow[4 * g], qrow[4 * g + 1], qrow[4 * g + 2], qrow[4 * g + 3]);
+                    res = l2_group4(res, trow[g], qv);
+                }
+            }
+            // scalar tail: result += diff*diff, one element at a time
+            const float *tt = smem + (size_t)r * dim_pad + ngroups * 4;
+            for (int j = 0; j < tail; ++j) {
+                const float d = __fsub_rn(tt[j], qtail[j]);
+                res = __fadd_rn(res, __fmul_rn(d, d));
+            }
+            const u64 key = ((u64)__float_as_uint(res) << 32) | (u64)(uint32_t)(base + r);
+            top2_update(k0, k1, key);
+        }
+    }
+    if (qi < nq) part[((size_t)b * nsplit + split) * nq + qi] = make_ulonglong2(k0, k1);
+}
+
+__global__ void knn_l2_merge_kernel(const ulonglong2 *__restrict__ part, int nq, int nsplit, int k,
+                                    int32_t *__restrict__ idx, float *__restrict__ dist) {
+    const int b = blockIdx.y;
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    u64 b0 = ~0ull, b1 = ~0ull;
+    for (int s = 0; s < nsplit; ++s) {
+        const ulonglong2 p = part[((size_t)b * nsplit + s) * nq + qi];
+        if (p.x != ~0ull) top2_update(b0, b1, p.x);
+        if (p.y != ~0ull) top2_update(b0, b1, p.y);
+    }
+    const size_t o = ((size_t)b * nq + qi) * k;
+    idx[o] = (int32_t)(b0 & 0xFFFFFFFFull);
+    dist[o] = __uint_as_float((uint32_t)(b0 >> 32));
+    if (k == 2) {
+        idx[o + 1] = (int32_t)(b1 & 0xFFFFFFFFull);
+        dist[o + 1] = __uint_as_float((uint32_t)(b1 >> 32));
+    }
+}
+
+}  // namespace
+
+void launch_knn_l2_merge(const void *part, int nq, int nsplit, int k, int batch, int32_t *d_idx, float *d_dist,
+                         hipStream_t s) {
+    dim3 mgrid((nq + 255) / 256, batch);
+    hipLaunchKernelGGL(knn_l2_merge_kernel, mgrid, dim3(256), 0, s, (const ulonglong2 *)part, nq, nsplit, k, d_idx, d_dist);
+}
+
+int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t, int nt,
+                  size_t t_stride, size_t t_bstride, int dim, int k, int batch, int32_t *d_idx, float *d_dist,
+                  hipStream_t s) {
+    if (!d_q || !d_t || !d_idx || !d_dist || nq < 0 || batch < 1 || batch > 65535 || (k != 1 && k != 2) || nt < k ||
+        dim < 1 || dim > 1024 || q_stride < (size_t)dim || t_stride < (size_t)dim) {
+        set_error("knn_l2: bad arguments (nq=%d nt=%d dim=%d k=%d batch=%d)", nq, nt, dim, k, batch);
+        return MLPL_E_BAD_INPUT;
+    }
+    if (nq == 0) return MLPL_OK;
+
+    if (ctx->l2_mode != 1) {
+        // fp16 MFMA distance-GEMM when the data qualify (auto) or when forced
+        int rc = launch_knn_l2_mfma(ctx, d_q, nq, q_stride, q_bstride, d_t, nt, t_stride, t_bstride, dim, k, batch, d_idx,
+                                    d_dist, s, ctx->l2_mode == 2);
+        if (rc != 1) return rc;  // 1 = "not applicable, use the exact kernel"
+    }
+
+    const int dim_pad = (dim + 3) & ~3;
+    const int kTileRows = std::max(1, std::min(kMaxTileRows, 8192 / dim_pad));  // <= 32 KiB of LDS per block
+    const int qtiles = (nq + kQPB - 1) / kQPB;
+    const long long target_blocks = 8LL * ctx->num_cus;
+    const int max_split = (nt + kTileRows - 1) / kTileRows;
+    long long want = (target_blocks + (long long)qtiles * batch - 1) / ((long long)qtiles * batch);
+    int nsplit = (int)std::max<long long>(1, std::min<long long>(want, max_split));
+    int rps = (nt + nsplit - 1) / nsplit;
+    rps = ((rps + kTileRows - 1) / kTileRows) * kTileRows;
+    nsplit = (nt + rps - 1) / rps;
+    if (nsplit > 65535) {
+        rps = ((nt + 65534) / 65535 + kTileRows - 1) / kTileRows * kTileRows;
+        nsplit = (nt + rps - 1) / rps;
+    }
+    void *part = nullptr;
+    int rc = ws_get(ctx, WS_PARTIAL, (size_t)batch * nsplit * nq * sizeof(ulonglong2), &part);
+    if (rc) return rc;
+
+    const size_t shmem = (size_t)kTileRows * dim_pad * sizeof(float);
+    dim3 grid(qtiles, nsplit, batch);
+#define MLPL_L2_LAUNCH(D4)                                                                                          \
+    hipLaunchKernelGGL(knn_l2_exact_kernel<D4>, grid, dim3(kQPB), shmem, s, d_q, q_stride, q_bstride, d_t, t_stride, \
+                       t_bstride, nq, nt, dim, rps, nsplit, kTileRows, (ulonglong2 *)part)
+    const int g4 = dim / 4;
+    if (g4 == 32) MLPL_L2_LAUNCH(32);
+    else if (g4 == 16) MLPL_L2_LAUNCH(16);
+    else if (g4 == 8) MLPL_L2_LAUNCH(8);
+    else MLPL_L2_LAUNCH(0);
+#undef MLPL_L2_LAUNCH
+    launch_knn_l2_merge(part, nq, nsplit, k, batch, d_idx, d_dist, s);
+    MLPL_HIP_TRY(hipGetLastError());
+    return MLPL_OK;
+}
+
+}  // namespace mlpl

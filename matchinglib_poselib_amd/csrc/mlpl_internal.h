@@ -1,0 +1,87 @@
+// mlpl_internal.h -- shared by the HIP translation units of libmlpl_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+
+#include "mlpl_c.h"
+
+namespace mlpl {
+
+void set_error(const char *fmt, ...);
+
+#define MLPL_HIP_TRY(expr)                                                                                  \
+    do {                                                                                                    \
+        hipError_t e__ = (expr);                                                                            \
+        if (e__ != hipSuccess) {                                                                            \
+            ::mlpl::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__));        \
+            return MLPL_E_HIP;                                                                              \
+        }                                                                                                   \
+    } while (0)
+
+// Workspace slots: each grows monotonically and is reused across calls (no hipMalloc on the steady path).
+enum WsSlot {
+    WS_PACK_Q = 0,
+    WS_PACK_T,
+    WS_PARTIAL,
+    WS_IDX,
+    WS_DIST,
+    WS_MATCH,
+    WS_COUNT,
+    WS_AUX0,
+    WS_AUX1,
+    WS_AUX2,
+    WS_AUX3,
+    WS_AUX4,
+    WS_AUX5,
+    WS_AUX6,
+    WS_AUX7,
+    WS_NUM_SLOTS
+};
+
+}  // namespace mlpl
+
+struct mlpl_ctx {
+    int device;
+    hipStream_t stream;
+    void *ws[mlpl::WS_NUM_SLOTS];
+    size_t ws_bytes[mlpl::WS_NUM_SLOTS];
+    void *pinned;  // small pinned host scratch for async result readback
+    size_t pinned_bytes;
+    int l2_mode;
+    int num_cus;
+    // optional per-kernel hipEvent bracketing (mlpl_profile_*)
+    int prof_on;
+    hipEvent_t *prof_ev[MLPL_PROF_NUM];  // pairs: [2*i] start, [2*i+1] stop
+    int prof_n[MLPL_PROF_NUM];
+};
+
+namespace mlpl {
+
+// Returns a device buffer of at least `bytes` for `slot`, growing it if needed (grow = sync + realloc).
+int ws_get(mlpl_ctx *ctx, WsSlot slot, size_t bytes, void **out);
+int pinned_get(mlpl_ctx *ctx, size_t bytes, void **out);
+
+constexpr int kProfMaxLaunches = 8192;
+// Records the start (phase 0) / stop (phase 1) event of one launch of kernel `id` on stream s when profiling is on.
+void prof_mark(mlpl_ctx *ctx, int id, int phase, hipStream_t s);
+
+inline hipStream_t pick_stream(mlpl_ctx *ctx, void *stream) {
+    return stream ? reinterpret_cast<hipStream_t>(stream) : ctx->stream;
+}
+
+// ---- kernel launchers (defined in the .hip files) ----
+int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_stride, size_t q_bstride,
+                       const uint8_t *d_t, int nt, size_t t_stride, size_t t_bstride, int nbytes, int k, int batch,
+                       int32_t *d_idx, int32_t *d_dist, hipStream_t s);
+int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t,
+                  int nt, size_t t_stride, size_t t_bstride, int dim, int k, int batch, int32_t *d_idx,
+                  float *d_dist, hipStream_t s);
+int launch_ratio_compact(mlpl_ctx *ctx, const int32_t *d_idx, const void *d_dist, int dist_is_float, int nq, int k,
+                         int batch, float ratio, mlpl_dmatch *d_out, int32_t *d_n_out, hipStream_t s);
+
+}  // namespace mlpl

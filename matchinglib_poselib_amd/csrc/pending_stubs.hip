@@ -1,0 +1,40 @@
+// pending_stubs.hip -- entry points whose kernels have not landed yet.  They fail loudly
+// (MLPL_E_UNSUPPORTED); nothing here computes on the host.  Entries move out of this file as they land.
+#include "mlpl_internal.h"
+
+namespace mlpl {
+int launch_knn_l2_mfma(mlpl_ctx *, const float *, int, size_t, size_t, const float *, int, size_t, size_t, int, int, int,
+                       int32_t *, float *, hipStream_t, int force) {
+    if (force) {
+        set_error("fp16 MFMA L2 path not built yet");
+        return MLPL_E_UNSUPPORTED;
+    }
+    return 1;
+}
+}  // namespace mlpl
+
+extern "C" {
+int mlpl_ransac_essential(mlpl_ctx *, const double *, const double *, int, double, double, int, int, uint32_t, double *,
+                          uint8_t *, int *, int *) {
+    mlpl::set_error("mlpl_ransac_essential: not built yet");
+    return MLPL_E_UNSUPPORTED;
+}
+int mlpl_ransac_essential_dev(mlpl_ctx *, const double *, const double *, int, double, double, int, int, uint32_t,
+                              double *, uint8_t *, int *, int *, void *) {
+    mlpl::set_error("mlpl_ransac_essential_dev: not built yet");
+    return MLPL_E_UNSUPPORTED;
+}
+int mlpl_solve_5pt(mlpl_ctx *, const double *, const double *, int, const int32_t *, int, double *, int32_t *) {
+    mlpl::set_error("mlpl_solve_5pt: not built yet");
+    return MLPL_E_UNSUPPORTED;
+}
+int mlpl_score_models(mlpl_ctx *, const double *, const double *, int, const double *, int, double, int32_t *, double *) {
+    mlpl::set_error("mlpl_score_models: not built yet");
+    return MLPL_E_UNSUPPORTED;
+}
+int mlpl_recover_pose(mlpl_ctx *, const double *, const double *, const double *, int, double, double *, double *, double *,
+                      uint8_t *) {
+    mlpl::set_error("mlpl_recover_pose: not built yet");
+    return MLPL_E_UNSUPPORTED;
+}
+}

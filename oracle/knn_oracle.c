@@ -1,0 +1,201 @@
+/*
+ * knn_oracle.c -- CPU restatement of matchinglib::getMatches(..., "LINEAR", ...).
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  Plain C, single thread, no dependencies.
+ *
+ * Follows /root/reference/matchinglib_poselib/source/matchinglib/source/matchers.cpp:
+ *   :115-135  input validation and return codes
+ *   :525-547  nn = ratioTest ? 2 : 1 ; dtype check (CV_8U / CV_32F)
+ *   :565-631  CV_8U: cvflann::Index<HammingLUT>(LinearIndexParams) + knnSearch + ratio loop
+ *   :632-707  CV_32F: cvflann::Index<L2<float>>(LinearIndexParams) + knnSearch + ratio loop
+ *   :709-713  < MIN_FINAL_MATCHES(2) matches -> -3   (match_statOptFlow.h:68)
+ *
+ * The callee cvflann (OpenCV 4.2.0 modules/flann, pinned by ci/make_opencv.sh:6) is not vendored in
+ * the reference tree.  Its published behaviour, restated here:
+ *   - NNIndex::knnSearch loops queries serially with a KNNUniqueResultSet(knn): an ordered set of
+ *     (dist, index) pairs; addPoint() drops a candidate when dist >= worst_distance once the set is
+ *     full, otherwise inserts and evicts the largest pair.  LinearIndex::findNeighbors visits train
+ *     rows in ascending order.  Net effect: the k lexicographically smallest (dist, trainIdx) pairs,
+ *     sorted ascending.
+ *   - HammingLUT: per-byte popcount lookup table summed over the descriptor bytes (int result).
+ *   - L2<float>: squared Euclidean distance, four differences per step:
+ *         result += d0*d0 + d1*d1 + d2*d2 + d3*d3      (left to right, float)
+ *     then a scalar tail; no early exit because worst_dist defaults to -1.
+ */
+#include "oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+static uint8_t g_lut[256];
+static int g_lut_ready = 0;
+
+static void lut_init(void) {
+    if (g_lut_ready) return;
+    for (int v = 0; v < 256; ++v) {
+        int c = 0;
+        for (int b = 0; b < 8; ++b) c += (v >> b) & 1;
+        g_lut[v] = (uint8_t)c;
+    }
+    g_lut_ready = 1;
+}
+
+/* KNNUniqueResultSet for k <= 2 kept as a tiny sorted array. */
+typedef struct {
+    int cap, size, full;
+    double worst; /* DistanceType max until full */
+    double d[3];
+    int i[3];
+} result_set;
+
+static void rs_clear(result_set *rs, int cap) {
+    rs->cap = cap;
+    rs->size = 0;
+    rs->full = 0;
+    rs->worst = 1.0e300;
+}
+
+static void rs_add(result_set *rs, double dist, int index) {
+    if (dist >= rs->worst) return;
+    /* insert keeping (dist, index) ascending */
+    int pos = rs->size;
+    while (pos > 0 && (rs->d[pos - 1] > dist || (rs->d[pos - 1] == dist && rs->i[pos - 1] > index))) {
+        rs->d[pos] = rs->d[pos - 1];
+        rs->i[pos] = rs->i[pos - 1];
+        --pos;
+    }
+    rs->d[pos] = dist;
+    rs->i[pos] = index;
+    rs->size++;
+    if (rs->full) {
+        if (rs->size > rs->cap) {
+            rs->size--; /* erase the largest */
+            rs->worst = rs->d[rs->size - 1];
+        }
+    } else if (rs->size == rs->cap) {
+        rs->full = 1;
+        rs->worst = rs->d[rs->size - 1];
+    }
+}
+
+int oracle_knn_hamming(const uint8_t *q, int nq, size_t q_stride, const uint8_t *t, int nt, size_t t_stride,
+                       int nbytes, int k, int32_t *idx, int32_t *dist) {
+    if (!q || !t || !idx || !dist || nq < 0 || nt < k || nbytes <= 0 || (k != 1 && k != 2)) return -1;
+    lut_init();
+    result_set rs;
+    for (int qi = 0; qi < nq; ++qi) {
+        const uint8_t *a = q + (size_t)qi * q_stride;
+        rs_clear(&rs, k);
+        for (int ti = 0; ti < nt; ++ti) {
+            const uint8_t *b = t + (size_t)ti * t_stride;
+            int d = 0;
+            for (int j = 0; j < nbytes; ++j) d += g_lut[a[j] ^ b[j]];
+            rs_add(&rs, (double)d, ti);
+        }
+        for (int j = 0; j < k; ++j) {
+            idx[(size_t)qi * k + j] = rs.i[j];
+            dist[(size_t)qi * k + j] = (int32_t)rs.d[j];
+        }
+    }
+    return 0;
+}
+
+static float l2sq_f32(const float *a, const float *b, int size) {
+    float result = 0.0f;
+    float diff0, diff1, diff2, diff3;
+    const float *last = a + size;
+    const float *lastgroup = last - 3;
+    while (a < lastgroup) {
+        diff0 = a[0] - b[0];
+        diff1 = a[1] - b[1];
+        diff2 = a[2] - b[2];
+        diff3 = a[3] - b[3];
+        result += diff0 * diff0 + diff1 * diff1 + diff2 * diff2 + diff3 * diff3;
+        a += 4;
+        b += 4;
+    }
+    while (a < last) {
+        diff0 = *a++ - *b++;
+        result += diff0 * diff0;
+    }
+    return result;
+}
+
+int oracle_knn_l2sq_f32(const float *q, int nq, size_t q_stride, const float *t, int nt, size_t t_stride, int dim,
+                        int k, int32_t *idx, float *dist) {
+    if (!q || !t || !idx || !dist || nq < 0 || nt < k || dim <= 0 || (k != 1 && k != 2)) return -1;
+    result_set rs;
+    for (int qi = 0; qi < nq; ++qi) {
+        const float *a = q + (size_t)qi * q_stride;
+        rs_clear(&rs, k);
+        for (int ti = 0; ti < nt; ++ti) {
+            /* LinearIndex::findNeighbors calls distance_(data_row, query_vec, cols) */
+            float d = l2sq_f32(t + (size_t)ti * t_stride, a, dim);
+            rs_add(&rs, (double)d, ti);
+        }
+        for (int j = 0; j < k; ++j) {
+            idx[(size_t)qi * k + j] = rs.i[j];
+            dist[(size_t)qi * k + j] = (float)rs.d[j];
+        }
+    }
+    return 0;
+}
+
+int oracle_ratio_filter_i32(const int32_t *idx, const int32_t *dist, int nq, int k, oracle_dmatch *out) {
+    int n = 0;
+    for (int qi = 0; qi < nq; ++qi) {
+        if (k == 2) {
+            /* matchers.cpp:605  if(dists[q][0] < (0.75f * dists[q][1]))  -- int vs float compare */
+            if (!((float)dist[2 * qi] < (0.75f * (float)dist[2 * qi + 1]))) continue;
+        }
+        out[n].distance = (float)dist[(size_t)k * qi];
+        out[n].queryIdx = qi;
+        out[n].trainIdx = idx[(size_t)k * qi];
+        out[n].imgIdx = -1;
+        ++n;
+    }
+    return n;
+}
+
+int oracle_ratio_filter_f32(const int32_t *idx, const float *dist, int nq, int k, oracle_dmatch *out) {
+    int n = 0;
+    for (int qi = 0; qi < nq; ++qi) {
+        if (k == 2) {
+            /* matchers.cpp:681 -- applied to SQUARED distances */
+            if (!(dist[2 * qi] < (0.75f * dist[2 * qi + 1]))) continue;
+        }
+        out[n].distance = dist[(size_t)k * qi];
+        out[n].queryIdx = qi;
+        out[n].trainIdx = idx[(size_t)k * qi];
+        out[n].imgIdx = -1;
+        ++n;
+    }
+    return n;
+}
+
+int oracle_get_matches_linear(int n_kp1, int n_kp2, const void *desc1, int rows1, const void *desc2, int rows2,
+                              int cols, int desc_type, int ratio_test, oracle_dmatch *out, int *n_out) {
+    *n_out = 0;
+    if (n_kp1 < 15 || n_kp2 < 15) return -4;             /* matchers.cpp:123-127 */
+    if (n_kp1 != rows1 || n_kp2 != rows2) return -1;     /* matchers.cpp:129-133 */
+    if (desc_type != 0 && desc_type != 5) return -1;     /* matchers.cpp:540-547 */
+    const int nn = ratio_test ? 2 : 1;                   /* matchers.cpp:529-538 */
+    int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)rows1 * nn);
+    int rc = 0;
+    if (desc_type == 0) {
+        int32_t *dist = (int32_t *)malloc(sizeof(int32_t) * (size_t)rows1 * nn);
+        rc = oracle_knn_hamming((const uint8_t *)desc1, rows1, (size_t)cols, (const uint8_t *)desc2, rows2,
+                                (size_t)cols, cols, nn, idx, dist);
+        if (rc == 0) *n_out = oracle_ratio_filter_i32(idx, dist, rows1, nn, out);
+        free(dist);
+    } else {
+        float *dist = (float *)malloc(sizeof(float) * (size_t)rows1 * nn);
+        rc = oracle_knn_l2sq_f32((const float *)desc1, rows1, (size_t)cols, (const float *)desc2, rows2,
+                                 (size_t)cols, cols, nn, idx, dist);
+        if (rc == 0) *n_out = oracle_ratio_filter_f32(idx, dist, rows1, nn, out);
+        free(dist);
+    }
+    free(idx);
+    if (rc != 0) return -1;
+    if (*n_out < 2) return -3;                           /* matchers.cpp:709-713 */
+    return 0;
+}

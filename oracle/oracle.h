@@ -1,0 +1,131 @@
+/*
+ * oracle.h -- CPU restatement of the reference's descriptor-matching + robust-pose hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ * Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load or call it,
+ * and there only as the checker / the timed CPU baseline.  Nothing under matchinglib_poselib_amd/
+ * or include/ may include, link or dlopen anything from oracle/.
+ *
+ * Parity pinning status (see DESIGN.md "Oracle"):
+ *   - matching (knn/ratio): pinned against the reference's vendored NMSLIB seq_search built from
+ *     /root/reference by oracle/Makefile into oracle/_ref/ (distances and tie-free indices) and
+ *     against numpy brute force; the reference ships no golden vectors of its own for this path.
+ *   - 5-point solver: pinned against the reference's vendored OpenGV fivept_nister built into
+ *     oracle/_ref/ (E-sets up to sign).
+ *   - The arithmetic of cvflann::LinearIndex / cv::SVD / cv::solvePoly / cv::triangulatePoints lives in
+ *     OpenCV 4.2.0 (pinned in ci/make_opencv.sh:6), which is NOT vendored under /root/reference and is
+ *     not installed here; those steps restate the published algorithms and are "parity unpinned" at
+ *     that boundary (no reference test holds a vector for them).
+ *
+ * Citations are relative to /root/reference/matchinglib_poselib/source/ :
+ *   M/ = matchinglib/   P/ = poselib/
+ */
+#ifndef MLPL_ORACLE_H
+#define MLPL_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cv::DMatch layout (OpenCV core/types.hpp): 16 bytes. */
+typedef struct {
+    int32_t queryIdx;
+    int32_t trainIdx;
+    int32_t imgIdx;
+    float distance;
+} oracle_dmatch;
+
+/* ---- matching: M/source/matchers.cpp:525-714 (LINEAR branch) ---------------------------------- */
+
+/* cvflann::Index<HammingLUT>(LinearIndexParams).knnSearch (matchers.cpp:584-588).
+ * idx/dist are nq*k int32, row-major; k in {1,2}.  Returns 0, or -1 on bad arguments. */
+int oracle_knn_hamming(const uint8_t *q, int nq, size_t q_stride, const uint8_t *t, int nt, size_t t_stride,
+                       int nbytes, int k, int32_t *idx, int32_t *dist);
+
+/* cvflann::Index<L2<float>>(LinearIndexParams).knnSearch (matchers.cpp:660-664): squared L2. */
+int oracle_knn_l2sq_f32(const float *q, int nq, size_t q_stride_elems, const float *t, int nt,
+                        size_t t_stride_elems, int dim, int k, int32_t *idx, float *dist);
+
+/* Ratio / emit loop (matchers.cpp:601-625 int distances, :677-701 float distances).
+ * k==2: keep q iff d0 < 0.75f*d1; k==1: keep all.  out must hold nq entries.  Returns #matches. */
+int oracle_ratio_filter_i32(const int32_t *idx, const int32_t *dist, int nq, int k, oracle_dmatch *out);
+int oracle_ratio_filter_f32(const int32_t *idx, const float *dist, int nq, int k, oracle_dmatch *out);
+
+/* getMatches(...,"LINEAR",...) end to end (matchers.cpp:115-135, 525-714): return codes 0/-1/-3/-4.
+ * desc_type: 0 = CV_8U (cols = bytes), 5 = CV_32F (cols = floats).  n_kp1/n_kp2 = keypoint counts. */
+int oracle_get_matches_linear(int n_kp1, int n_kp2, const void *desc1, int rows1, const void *desc2, int rows2,
+                              int cols, int desc_type, int ratio_test, oracle_dmatch *out, int *n_out);
+
+/* ---- robust pose: P/source/five-point-nister/{five-point,modelest}.cpp, P/source/pose_estim.cpp -- */
+
+/* glibc srand/rand (TYPE_3 additive feedback generator) restated, so that sampling is reproducible
+ * without touching the process-global stream (modelest.cpp:58,585 use std::srand/std::rand). */
+typedef struct {
+    int32_t r[34];
+    int f, b; /* front/rear indices */
+} oracle_glibc_rand;
+void oracle_srand(oracle_glibc_rand *st, unsigned seed);
+int oracle_rand(oracle_glibc_rand *st);
+
+/* CvModelEstimator3::getSubset (modelest.cpp:567-610) + checkSubset (:613-650).
+ * p1,p2: n x 2 doubles.  idx5 receives the 5 sample indices.  Returns 1 if found. */
+int oracle_get_subset(oracle_glibc_rand *st, const double *p1, const double *p2, int n, int max_attempts,
+                      int *idx5);
+
+/* CvEMEstimator::run5Point (five-point.cpp:366-471).  q1,q2: n x 2 doubles (n>=5).
+ * E_out: up to 10 row-major 3x3 matrices.  Returns the number of solutions. */
+int oracle_run5point(const double *q1, const double *q2, int n, double *E_out);
+
+/* computeReprojError3 (five-point.cpp:476-503): Sampson error in fp64 stored as float. */
+void oracle_sampson_err(const double *p1, const double *p2, int n, const double *E, float *err);
+
+/* findInliers (modelest.cpp:69-83): mask[i] = err[i] <= thresh^2; returns count; *err_sum = cv::sum(err). */
+int oracle_find_inliers(const double *p1, const double *p2, int n, const double *E, double thresh,
+                        float *err, uint8_t *mask, double *err_sum);
+
+/* cvRANSACUpdateNumIters1 (modelest.cpp:86-109). */
+int oracle_ransac_update_num_iters(double p, double ep, int model_points, int max_iters);
+
+/* Optional per-iteration trace of runRANSAC. */
+typedef struct {
+    int32_t idx[5];
+    int32_t nmodels;
+    int32_t good[10];
+    double err_sum[10];
+    int32_t niters_after; /* niters after processing this iteration */
+    int32_t best_taken;   /* index of the model taken as new best in this iteration, or -1 */
+} oracle_ransac_trace;
+
+/* CvModelEstimator3::runRANSAC (modelest.cpp:343-474) driven as findEssentialMat does
+ * (five-point.cpp:69-148) but with seed / confidence / max_iters exposed.
+ * mask: n bytes (0/1).  trace may be NULL; if not, it must hold max_iters entries.
+ * Returns 1 on success, 0 on failure.  *iters_run = iterations actually executed. */
+int oracle_ransac_essential(const double *p1, const double *p2, int n, double thresh, double confidence,
+                            int max_iters, int lesqu, unsigned seed, double *E, uint8_t *mask,
+                            int *n_inliers, int *iters_run, oracle_ransac_trace *trace);
+
+/* decomposeEssentialMat (five-point.cpp:340-352). */
+void oracle_decompose_essential(const double *E, double *R1, double *R2, double *t);
+
+/* recoverPose / getPoseTriangPts (five-point.cpp:150-338, pose_estim.cpp:913-946) with t_only empty.
+ * mask_inout: n bytes, nonzero = use (may be NULL = all ones).  Q: n x 3.  Returns #good points. */
+int oracle_recover_pose(const double *E, const double *p1, const double *p2, int n, double dist, double *R,
+                        double *t, double *Q, uint8_t *mask_inout);
+
+/* cv::triangulatePoints for one correspondence with P0=[I|0], P1=[R|t] (unit-norm homogeneous X). */
+void oracle_triangulate_point(const double *P0, const double *P1, const double *x1, const double *x2, double *X4);
+
+/* one-sided Jacobi SVD helper exposed for tests: A is m x n row-major (m may be < n).
+ * On return w[n] (descending) and V (n x n row-major, columns = right singular vectors). */
+void oracle_jacobi_svd(const double *A, int m, int n, double *w, double *V);
+
+/* Durand-Kerner as cv::solvePoly; coeffs[0..deg] ascending powers; roots as (re,im) pairs. Returns #roots. */
+int oracle_solve_poly(const double *coeffs, int deg, double *roots_re_im, int max_iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,177 @@
+"""GPU parity tests for the matching path: HIP kernels (through the C ABI) vs the CPU oracle, bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import matchinglib_poselib_amd as mpa
+import oracle_lib
+from matchinglib_poselib_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name", ["hamming_257x263", "hamming_ties_96x80", "hamming_c1_2048"])
+def test_hamming_golden(ctx, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    idx, dist = mpa.knn_hamming(g["q"], g["t"], ctx=ctx)
+    assert np.array_equal(dist, g["dist"])
+    assert np.array_equal(idx, g["idx"])
+    m = mpa.ratio_compact(idx, dist, ctx=ctx)
+    assert np.array_equal(m["queryIdx"], g["match_q"]) and np.array_equal(m["trainIdx"], g["match_t"])
+    assert np.all(m["imgIdx"] == -1)
+    assert np.array_equal(m["distance"], dist[g["match_q"], 0].astype(np.float32))
+
+
+@pytest.mark.parametrize("nq,nt,nbytes,k", [
+    (1, 2, 32, 2), (15, 15, 32, 2), (64, 1000, 32, 1), (300, 129, 32, 2), (1000, 5000, 32, 2),
+    (77, 333, 64, 2), (50, 200, 16, 2), (40, 90, 61, 2), (33, 70, 24, 2), (20, 40, 1, 2), (10, 600, 128, 2),
+])
+def test_hamming_shapes_vs_oracle(ctx, oracle, nq, nt, nbytes, k):
+    q, t = synth.orb_pair(nq, nt, nbytes=nbytes, seed=1000 + nq + nt + nbytes)
+    idx, dist = mpa.knn_hamming(q, t, k=k, ctx=ctx)
+    oi, od = oracle.knn_hamming(q, t, k=k)
+    assert np.array_equal(dist, od)
+    assert np.array_equal(idx, oi)
+
+
+def test_hamming_strided_rows(ctx, oracle):
+    # cv::Mat with step > cols (ROI of a wider matrix)
+    big_q = np.random.default_rng(1).integers(0, 256, (100, 48), dtype=np.uint8)
+    big_t = np.random.default_rng(2).integers(0, 256, (150, 40), dtype=np.uint8)
+    q, t = big_q[:, :32], big_t[:, :32]
+    idx, dist = mpa.knn_hamming(q, t, ctx=ctx)
+    oi, od = oracle.knn_hamming(np.ascontiguousarray(q), np.ascontiguousarray(t))
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+
+
+def test_hamming_heavy_ties(ctx, oracle):
+    # few distinct descriptors -> ties everywhere; the packed-key min must give the smaller train index
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 256, (5, 32), dtype=np.uint8)
+    t = base[rng.integers(0, 5, 3000)]
+    q = base[rng.integers(0, 5, 500)]
+    idx, dist = mpa.knn_hamming(q, t, ctx=ctx)
+    oi, od = oracle.knn_hamming(q, t)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert (dist[:, 0] == 0).all() and (dist[:, 1] == 0).all()
+
+
+def test_c2_full_size_properties(ctx, oracle):
+    """BASELINE config C2 (8192 x 8192 ORB-256): size-independent properties + oracle on a sample of rows."""
+    q, t = synth.orb_pair(8192, 8192, seed=20260102)
+    idx, dist = mpa.knn_hamming(q, t, ctx=ctx)
+    lut = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    # (1) reported distances are the true distances of the reported indices
+    for j in range(2):
+        d = lut[np.bitwise_xor(q, t[idx[:, j]])].sum(axis=1)
+        assert np.array_equal(d, dist[:, j])
+    # (2) sorted, distinct neighbours
+    assert (dist[:, 0] <= dist[:, 1]).all() and (idx[:, 0] != idx[:, 1]).all()
+    tie = dist[:, 0] == dist[:, 1]
+    assert (idx[tie, 0] < idx[tie, 1]).all()
+    # (3) permuting the train rows permutes the indices and keeps the distances (tie-free rows)
+    perm = np.random.default_rng(0).permutation(8192)
+    idx_p, dist_p = mpa.knn_hamming(q, t[perm], ctx=ctx)
+    assert np.array_equal(dist_p, dist)
+    sub = np.arange(0, 8192, 37)
+    oi, od = oracle.knn_hamming(q[sub], t)
+    assert np.array_equal(idx[sub], oi) and np.array_equal(dist[sub], od)
+    # (4) query == train: nearest neighbour of row i is i at distance 0
+    idx_s, dist_s = mpa.knn_hamming(t, t, ctx=ctx)
+    assert (dist_s[:, 0] == 0).all()
+    assert np.array_equal(idx_s[:, 0], np.arange(8192)) or (dist_s[:, 1] == 0).any()
+
+
+def test_ratio_compact_edge_cases(ctx, oracle):
+    idx = np.array([[1, 2], [3, 4], [5, 6], [7, 8]], np.int32)
+    dist = np.array([[3, 4], [0, 0], [74, 100], [75, 100]], np.int32)
+    m = mpa.ratio_compact(idx, dist, ctx=ctx)
+    o = oracle.ratio_filter(idx, dist)
+    assert m.tobytes() == o.tobytes()
+    # nothing passes
+    m = mpa.ratio_compact(idx[:2], dist[:2], ctx=ctx)
+    assert len(m) == 0
+    # k = 1: everything is emitted
+    m = mpa.ratio_compact(idx[:, :1].copy(), dist[:, :1].copy(), ctx=ctx)
+    assert m["queryIdx"].tolist() == [0, 1, 2, 3]
+    # long input crossing many 1024-chunks
+    rng = np.random.default_rng(4)
+    dist = np.sort(rng.integers(0, 256, (50000, 2)), axis=1).astype(np.int32)
+    idx = rng.integers(0, 1 << 20, (50000, 2)).astype(np.int32)
+    m = mpa.ratio_compact(idx, dist, ctx=ctx)
+    o = oracle.ratio_filter(idx, dist)
+    assert m.tobytes() == o.tobytes()
+
+
+def test_get_matches_linear_u8(ctx, oracle):
+    q, t = synth.orb_pair(2048, 2048, seed=20260101)
+    kp1, kp2 = [None] * 2048, [None] * 2048
+    err, m = mpa.getMatches(kp1, kp2, q, t, matcher_name="LINEAR", ctx=ctx)
+    rc, o = oracle.get_matches_linear(2048, 2048, q, t)
+    assert err == rc == 0
+    assert m.tobytes() == o.tobytes()
+    err, m = mpa.getMatches(kp1, kp2, q, t, matcher_name="LINEAR", ratioTest=False, ctx=ctx)
+    rc, o = oracle.get_matches_linear(2048, 2048, q, t, ratio_test=False)
+    assert err == rc == 0 and len(m) == 2048 and m.tobytes() == o.tobytes()
+
+
+def test_get_matches_error_codes(ctx):
+    q, t = synth.orb_pair(40, 50, seed=2)
+    kp = lambda n: [None] * n  # noqa: E731
+    assert mpa.getMatches(kp(14), kp(50), q[:14], t, matcher_name="LINEAR", ctx=ctx)[0] == -4
+    assert mpa.getMatches(kp(41), kp(50), q, t, matcher_name="LINEAR", ctx=ctx)[0] == -1
+    assert mpa.getMatches(kp(40), kp(50), q, t, ctx=ctx)[0] == -2           # default GMBSOF: not built here
+    assert mpa.getMatches(kp(40), kp(50), q, t, matcher_name="NOPE", ctx=ctx)[0] == -2
+    assert mpa.getMatches(kp(40), kp(50), q.astype(np.int16), t.astype(np.int16), matcher_name="LINEAR", ctx=ctx)[0] == -1
+    with pytest.raises(ValueError):
+        mpa.getMatches(kp(40), kp(50), q, t.astype(np.float32), matcher_name="LINEAR", ctx=ctx)
+    # all queries identical to all trains -> d1 == 0 for everyone -> no match -> -3
+    z = np.zeros((20, 32), np.uint8)
+    assert mpa.getMatches(kp(20), kp(20), z, z, matcher_name="LINEAR", ctx=ctx)[0] == -3
+
+
+def test_l2_exact_integer_and_fractional(ctx, oracle):
+    from matchinglib_poselib_amd import _lib
+    q, t = synth.sift_pair(300, 1000, seed=5)
+    _lib.check(ctx.lib.mlpl_set_l2_path(ctx.handle, 1), "set_l2_path")   # exact fp32 VALU kernel
+    idx, dist = mpa.knn_l2sq(q, t, ctx=ctx)
+    oi, od = oracle.knn_l2sq(q, t)
+    assert np.array_equal(idx, oi) and dist.tobytes() == od.tobytes()
+    # non-integer descriptors: same fp32 summation order as cvflann::L2<float> -> still bit-exact
+    rng = np.random.default_rng(6)
+    q = rng.normal(size=(200, 128)).astype(np.float32)
+    t = rng.normal(size=(700, 128)).astype(np.float32)
+    idx, dist = mpa.knn_l2sq(q, t, ctx=ctx)
+    oi, od = oracle.knn_l2sq(q, t)
+    assert np.array_equal(idx, oi) and dist.tobytes() == od.tobytes()
+    for dim in (64, 32, 30, 7, 130):
+        q = rng.normal(size=(50, dim)).astype(np.float32)
+        t = rng.normal(size=(90, dim)).astype(np.float32)
+        idx, dist = mpa.knn_l2sq(q, t, ctx=ctx)
+        oi, od = oracle.knn_l2sq(q, t)
+        assert np.array_equal(idx, oi) and dist.tobytes() == od.tobytes(), dim
+    _lib.check(ctx.lib.mlpl_set_l2_path(ctx.handle, 0), "set_l2_path")
+
+
+def test_device_batched_match(ctx, oracle):
+    import torch
+    from matchinglib_poselib_amd.matching import match_hamming_device
+    B = 3
+    qs, ts = zip(*[synth.orb_pair(500, 700, seed=40 + b) for b in range(B)])
+    q = torch.from_numpy(np.stack(qs)).cuda()
+    t = torch.from_numpy(np.stack(ts)).cuda()
+    out = match_hamming_device(q, t, ctx=ctx)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    for b in range(B):
+        oi, od = oracle.knn_hamming(qs[b], ts[b])
+        assert np.array_equal(out["idx"][b].cpu().numpy(), oi)
+        assert np.array_equal(out["dist"][b].cpu().numpy(), od)
+        o = oracle.ratio_filter(oi, od)
+        n = int(out["count"][b])
+        assert n == len(o)
+        m = out["matches"][b, :n].cpu().numpy()
+        assert np.array_equal(m[:, 0], o["queryIdx"]) and np.array_equal(m[:, 1], o["trainIdx"])
+        assert np.array_equal(m[:, 3].view(np.float32), o["distance"])
