@@ -11,8 +11,9 @@
  *     (M/source/matchers.cpp:109-114); MLPL_E_* below are this library's own.
  *   - no exceptions, no exit(), no stdout.  mlpl_last_error() returns a thread-local message.
  *   - the caller owns every buffer; outputs are caller-allocated.
- *   - `*_dev` entry points take DEVICE pointers plus a hipStream_t (as void*), enqueue work and return
- *     without synchronising; the plain entry points take HOST pointers, copy in/out and synchronise.
+ *   - `*_dev` entry points take DEVICE pointers plus a hipStream_t (as void*; NULL = HIP's null stream, use
+ *     mlpl_ctx_stream() for the context's own), enqueue work and return without synchronising; the plain
+ *     entry points take HOST pointers, copy in/out on the context's stream and synchronise.
  *   - a context (mlpl_ctx) owns the device workspace and a private stream; use one per host thread.
  *   - there is NO CPU fallback: every compute entry point fails with MLPL_E_NO_DEVICE when no gfx950
  *     device is usable.
@@ -57,6 +58,10 @@ int mlpl_device_count(void);
 void *mlpl_ctx_stream(mlpl_ctx *ctx);
 int mlpl_ctx_device(mlpl_ctx *ctx);
 int mlpl_ctx_synchronize(mlpl_ctx *ctx);
+
+/* Tuning knobs (performance only, never results): "hamming_variant" 0 = LDS-tiled broadcast reads, 1 = scalar-load
+ * kernel (default); "hamming_qpl" queries per lane 1|2; "hamming_blocks_per_cu" grid sizing target. */
+int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value);
 
 /* ---- in-library kernel timing (for roofline accounting) ------------------------------------------------------
  * When enabled, the launches of the dominant kernel of each path are bracketed with hipEvents on the stream

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "mlpl_ctx_stream": (c_void_p, [c_void_p]),
     "mlpl_ctx_device": (c_int, [c_void_p]),
     "mlpl_ctx_synchronize": (c_int, [c_void_p]),
+    "mlpl_set_option": (c_int, [c_void_p, C.c_char_p, c_int]),
     "mlpl_profile_enable": (c_int, [c_void_p, c_int]),
     "mlpl_profile_reset": (c_int, [c_void_p]),
     "mlpl_profile_read": (c_int, [c_void_p, c_int, C.POINTER(c_double), C.POINTER(c_int)]),
@@ -84,6 +85,24 @@ _SIGNATURES = {
 }
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm wheels carry their own libamdhip64.so (SONAME libamdhip64.so.7).
+    If ours (/opt/rocm) were loaded first, torch would later load a second copy and find "No HIP GPUs"; device
+    pointers and streams could not be shared either.  So when torch is installed, map its runtime first; our
+    library's NEEDED libamdhip64.so.7 then resolves to that same object."""
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load_library():
     """dlopen libmlpl_hip.so and bind every entry point. Raises if the library has not been built."""
     global _lib
@@ -97,6 +116,7 @@ def load_library():
                 f"{_LIB_PATH} not found -- build it with `python -m matchinglib_poselib_amd.build`; "
                 "there is no CPU fallback",
             )
+        _preload_torch_hip_runtime()
         lib = C.CDLL(_LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError = symbol missing: fail loudly

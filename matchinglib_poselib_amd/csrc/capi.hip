@@ -108,6 +108,9 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     std::memset(ctx, 0, sizeof(*ctx));
     ctx->device = device_ordinal;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->opt_hamming_variant = 0;
+    ctx->opt_hamming_qpl = 1;
+    ctx->opt_hamming_blocks_per_cu = 8;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -139,6 +142,18 @@ int mlpl_ctx_device(mlpl_ctx *ctx) { return ctx ? ctx->device : -1; }
 int mlpl_ctx_synchronize(mlpl_ctx *ctx) {
     if (!ctx) return MLPL_E_BAD_INPUT;
     MLPL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MLPL_OK;
+}
+
+int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
+    if (!ctx || !name) return MLPL_E_BAD_INPUT;
+    if (!std::strcmp(name, "hamming_variant") && (value == 0 || value == 1)) ctx->opt_hamming_variant = value;
+    else if (!std::strcmp(name, "hamming_qpl") && (value == 1 || value == 2)) ctx->opt_hamming_qpl = value;
+    else if (!std::strcmp(name, "hamming_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_blocks_per_cu = value;
+    else {
+        set_error("mlpl_set_option: unknown option or bad value: %s=%d", name, value);
+        return MLPL_E_BAD_INPUT;
+    }
     return MLPL_OK;
 }
 
@@ -220,10 +235,14 @@ int mlpl_match_hamming_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_s
     MLPL_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = pick_stream(ctx, stream);
     const int k = ratio_test ? 2 : 1;
-    int rc = launch_knn_hamming(ctx, d_q, nq, q_stride, q_batch_stride, d_t, nt, t_stride, t_batch_stride, nbytes, k,
-                                batch, d_idx, d_dist, s);
+    void *gc = nullptr;
+    const int ncnt = (nq + kCountGroup - 1) / kCountGroup;
+    int rc = ws_get(ctx, WS_COUNT, (size_t)batch * std::max(ncnt, 1) * sizeof(int32_t), &gc);
     if (rc) return rc;
-    return launch_ratio_compact(ctx, d_idx, d_dist, 0, nq, k, batch, ratio, d_out, d_n_out, s);
+    rc = launch_knn_hamming(ctx, d_q, nq, q_stride, q_batch_stride, d_t, nt, t_stride, t_batch_stride, nbytes, k, batch,
+                            d_idx, d_dist, s, ratio, (int32_t *)gc);
+    if (rc) return rc;
+    return launch_ratio_compact(ctx, d_idx, d_dist, 0, nq, k, batch, ratio, d_out, d_n_out, s, (int32_t *)gc);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -305,7 +324,7 @@ static int ratio_compact_host(mlpl_ctx *ctx, const int32_t *idx, const void *dis
     if ((rc = ws_get(ctx, WS_IDX, (size_t)nq * k * 4, &didx))) return rc;
     if ((rc = ws_get(ctx, WS_DIST, (size_t)nq * k * 4, &ddist))) return rc;
     if ((rc = ws_get(ctx, WS_MATCH, (size_t)nq * sizeof(mlpl_dmatch), &dout))) return rc;
-    if ((rc = ws_get(ctx, WS_COUNT, 64, &dcnt))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX2, 64, &dcnt))) return rc;
     MLPL_HIP_TRY(hipMemcpyAsync(didx, idx, (size_t)nq * k * 4, hipMemcpyHostToDevice, ctx->stream));
     MLPL_HIP_TRY(hipMemcpyAsync(ddist, dist, (size_t)nq * k * 4, hipMemcpyHostToDevice, ctx->stream));
     rc = launch_ratio_compact(ctx, (const int32_t *)didx, ddist, is_float, nq, k, 1, ratio, (mlpl_dmatch *)dout,
@@ -351,7 +370,7 @@ int mlpl_get_matches_linear(mlpl_ctx *ctx, int n_keypoints1, int n_keypoints2, c
     if ((rc = ws_get(ctx, WS_IDX, (size_t)rows1 * k * 4, &didx))) return rc;
     if ((rc = ws_get(ctx, WS_DIST, (size_t)rows1 * k * 4, &ddist))) return rc;
     if ((rc = ws_get(ctx, WS_MATCH, (size_t)rows1 * sizeof(mlpl_dmatch), &dout))) return rc;
-    if ((rc = ws_get(ctx, WS_COUNT, 64, &dcnt))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX2, 64, &dcnt))) return rc;
     if (desc_type == 0) {
         rc = launch_knn_hamming(ctx, (const uint8_t *)dq, rows1, cols, 0, (const uint8_t *)dt, rows2, cols, 0, cols, k, 1,
                                 (int32_t *)didx, (int32_t *)ddist, ctx->stream);

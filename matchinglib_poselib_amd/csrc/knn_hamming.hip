@@ -25,6 +25,9 @@ namespace {
 
 constexpr int kQueriesPerBlock = 256;
 constexpr int kTileRows = 128;
+constexpr int kMergeLanes = 16;                    // lanes cooperating on one query in the merge kernel
+constexpr int kMergeGroup = 1024 / kMergeLanes;    // queries per merge block (= kCountGroup of ratio_write_kernel)
+static_assert(kMergeGroup == kCountGroup, "merge kernel and ratio_write_kernel disagree on the count granularity");
 
 // bits needed for a distance in [0, 32*nw]
 constexpr int dist_bits(int nw) {
@@ -157,51 +160,170 @@ __global__ __launch_bounds__(kQueriesPerBlock) void knn_hamming_partial_kernel(
     if (qi < nq) part[((size_t)b * nsplit + split) * nq + qi] = make_uint2(k0, k1);
 }
 
-__global__ void knn_hamming_merge_kernel(const uint2 *__restrict__ part, int nq, int nsplit, int rows_per_split,
-                                         int dshift, int k, int32_t *__restrict__ idx, int32_t *__restrict__ dist) {
-    const int b = blockIdx.y;
-    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi >= nq) return;
-    const uint32_t lmask = (1u << dshift) - 1u;
-    unsigned long long b0 = ~0ull, b1 = ~0ull;
-    for (int s = 0; s < nsplit; ++s) {
-        const uint2 p = part[((size_t)b * nsplit + s) * nq + qi];
-        const uint32_t keys[2] = {p.x, p.y};
+// Variant B: the train rows are wave-uniform operands, so they are fetched with SCALAR loads (s_load_dwordx8 through
+// the scalar data cache) straight into SGPRs and fed to v_xor_b32 as the scalar source: no LDS traffic, no barriers.
+// (A broadcast ds_read_b128 delivers 1 KiB per wave-instruction for 16 useful bytes and saturates the CU's LDS at
+// ~84 % with four SIMDs issuing; the scalar path leaves the VALU as the only bound.)  Q queries per lane.
+template <int NW, int Q>
+__global__ __launch_bounds__(kQueriesPerBlock) void knn_hamming_partial_sgpr_kernel(
+    const uint32_t *__restrict__ q, size_t q_bstride_w, const uint32_t *__restrict__ t, size_t t_bstride_w, int nq,
+    int nt, int rows_per_split, int nsplit, uint2 *__restrict__ part) {
+    constexpr int dshift = 32 - dist_bits(NW);
+    constexpr int RB = (NW <= 8) ? 4 : ((NW <= 16) ? 2 : 1);  // rows per scalar-load batch (<= 32 SGPRs)
+    const int tid = threadIdx.x;
+    const int split = blockIdx.y;
+    const int b = blockIdx.z;
+    q += (size_t)b * q_bstride_w;
+
+    uint32_t qa[Q][NW];
+    int qidx[Q];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (keys[j] == 0xFFFFFFFFu) continue;
-            const unsigned long long d = keys[j] >> dshift;
-            const unsigned long long row = (unsigned long long)s * rows_per_split + (keys[j] & lmask);
-            const unsigned long long g = (d << 32) | row;
-            if (g < b0) {
-                b1 = b0;
-                b0 = g;
-            } else if (g < b1) {
-                b1 = g;
+    for (int j = 0; j < Q; ++j) {
+        qidx[j] = (blockIdx.x * Q + j) * kQueriesPerBlock + tid;
+        if (qidx[j] < nq) {
+            const uint32_t *qp = q + (size_t)qidx[j] * NW;
+            if constexpr (NW % 4 == 0) {
+#pragma unroll
+                for (int w = 0; w < NW; w += 4) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(qp + w);
+                    qa[j][w] = v.x, qa[j][w + 1] = v.y, qa[j][w + 2] = v.z, qa[j][w + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) qa[j][w] = qp[w];
             }
+        } else {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) qa[j][w] = 0;
         }
     }
-    const size_t o = ((size_t)b * nq + qi) * k;
-    idx[o] = (int32_t)(b0 & 0xFFFFFFFFull);
-    dist[o] = (int32_t)(b0 >> 32);
-    if (k == 2) {
-        idx[o + 1] = (int32_t)(b1 & 0xFFFFFFFFull);
-        dist[o + 1] = (int32_t)(b1 >> 32);
+    uint32_t k0[Q], k1[Q];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) k0[j] = k1[j] = 0xFFFFFFFFu;
+
+    const int r_begin = split * rows_per_split;
+    const int rows = min(nt, r_begin + rows_per_split) - r_begin;
+    const uint32_t *__restrict__ tp = t + (size_t)b * t_bstride_w + (size_t)r_begin * NW;  // wave-uniform
+
+    auto score_row = [&](const uint32_t(&tw)[NW], uint32_t lrow) {
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            uint32_t d = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) d = bcnt_acc(qa[j][w] ^ tw[w], d);
+            const uint32_t key = (d << dshift) | lrow;
+            k1[j] = umed3(k0[j], k1[j], key);
+            k0[j] = min(k0[j], key);
+        }
+    };
+
+    int r = 0;
+    for (; r + RB <= rows; r += RB) {
+        uint32_t tw[RB][NW];
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tw[i][w] = tp[(size_t)(r + i) * NW + w];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) score_row(tw[i], (uint32_t)(r + i));
+    }
+    for (; r < rows; ++r) {
+        uint32_t tw[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tw[w] = tp[(size_t)r * NW + w];
+        score_row(tw, (uint32_t)r);
+    }
+#pragma unroll
+    for (int j = 0; j < Q; ++j)
+        if (qidx[j] < nq) part[((size_t)b * nsplit + split) * nq + qidx[j]] = make_uint2(k0[j], k1[j]);
+}
+
+// Merge of the per-split partial top-2 lists, kMergeLanes lanes per query (each lane folds every kMergeLanes-th
+// split, then xor-shuffles combine the lanes), on 64-bit (dist << 32 | global row) keys.  Also evaluates the ratio predicate and
+// leaves the number of passing queries of this 256-query group in group_counts (consumed by ratio_write_kernel), so
+// the fused getMatches path needs no separate counting pass.
+__global__ __launch_bounds__(1024) void knn_hamming_merge_kernel(const uint2 *__restrict__ part, int nq, int nsplit,
+                                                                 int rows_per_split, int dshift, int k, float ratio,
+                                                                 int32_t *__restrict__ idx, int32_t *__restrict__ dist,
+                                                                 int32_t *__restrict__ group_counts) {
+    __shared__ int wave_tot[16];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int sub = tid & (kMergeLanes - 1);
+    const int qi = blockIdx.x * kMergeGroup + tid / kMergeLanes;
+    const uint32_t lmask = (1u << dshift) - 1u;
+    unsigned long long b0 = ~0ull, b1 = ~0ull;
+    auto upd = [&](unsigned long long g) {
+        const bool lt0 = g < b0, lt1 = g < b1;
+        b1 = lt0 ? b0 : (lt1 ? g : b1);
+        b0 = lt0 ? g : b0;
+    };
+    if (qi < nq) {
+        for (int s = sub; s < nsplit; s += kMergeLanes) {
+            const uint2 p = part[((size_t)b * nsplit + s) * nq + qi];
+            const unsigned long long base = (unsigned long long)s * rows_per_split;
+            if (p.x != 0xFFFFFFFFu) upd(((unsigned long long)(p.x >> dshift) << 32) | (base + (p.x & lmask)));
+            if (p.y != 0xFFFFFFFFu) upd(((unsigned long long)(p.y >> dshift) << 32) | (base + (p.y & lmask)));
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < kMergeLanes; off <<= 1) {
+        const unsigned long long o0 = __shfl_xor(b0, off), o1 = __shfl_xor(b1, off);
+        upd(o0);
+        upd(o1);
+    }
+    bool pass = false;
+    if (sub == 0 && qi < nq) {
+        const size_t o = ((size_t)b * nq + qi) * k;
+        const int d0 = (int32_t)(b0 >> 32);
+        idx[o] = (int32_t)(b0 & 0xFFFFFFFFull);
+        dist[o] = d0;
+        if (k == 2) {
+            const int d1 = (int32_t)(b1 >> 32);
+            idx[o + 1] = (int32_t)(b1 & 0xFFFFFFFFull);
+            dist[o + 1] = d1;
+            pass = (float)d0 < __fmul_rn(ratio, (float)d1);
+        } else {
+            pass = true;
+        }
+    }
+    if (group_counts) {
+        const unsigned long long bal = __ballot(pass);
+        if ((tid & 63) == 0) wave_tot[tid >> 6] = __popcll(bal);
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) tot += wave_tot[w];
+            group_counts[(size_t)b * gridDim.x + blockIdx.x] = tot;
+        }
     }
 }
 
 template <int NW>
-void launch_partial(dim3 grid, hipStream_t s, const uint32_t *q, size_t qbw, const uint32_t *t, size_t tbw, int nq, int nt,
-                    int rps, int nsplit, uint2 *part) {
-    hipLaunchKernelGGL(knn_hamming_partial_kernel<NW>, grid, dim3(kQueriesPerBlock), 0, s, q, qbw, t, tbw, nq, nt, rps,
-                       nsplit, part);
+void launch_partial(int variant, int qpl, dim3 grid, hipStream_t s, const uint32_t *q, size_t qbw, const uint32_t *t,
+                    size_t tbw, int nq, int nt, int rps, int nsplit, uint2 *part) {
+    if (variant == 0) {
+        hipLaunchKernelGGL(knn_hamming_partial_kernel<NW>, grid, dim3(kQueriesPerBlock), 0, s, q, qbw, t, tbw, nq, nt, rps,
+                           nsplit, part);
+    } else if constexpr (NW <= 16) {
+        if (qpl == 2)
+            hipLaunchKernelGGL((knn_hamming_partial_sgpr_kernel<NW, 2>), grid, dim3(kQueriesPerBlock), 0, s, q, qbw, t, tbw,
+                               nq, nt, rps, nsplit, part);
+        else
+            hipLaunchKernelGGL((knn_hamming_partial_sgpr_kernel<NW, 1>), grid, dim3(kQueriesPerBlock), 0, s, q, qbw, t, tbw,
+                               nq, nt, rps, nsplit, part);
+    } else {
+        hipLaunchKernelGGL((knn_hamming_partial_sgpr_kernel<NW, 1>), grid, dim3(kQueriesPerBlock), 0, s, q, qbw, t, tbw, nq,
+                           nt, rps, nsplit, part);
+    }
 }
 
 }  // namespace
 
 int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_stride, size_t q_bstride,
                        const uint8_t *d_t, int nt, size_t t_stride, size_t t_bstride, int nbytes, int k, int batch,
-                       int32_t *d_idx, int32_t *d_dist, hipStream_t s) {
+                       int32_t *d_idx, int32_t *d_dist, hipStream_t s, float ratio, int32_t *d_group_counts) {
     if (!d_q || !d_t || !d_idx || !d_dist || nq < 0 || batch < 1 || batch > 65535 || (k != 1 && k != 2) || nt < k ||
         nbytes < 1 || nbytes > 256 || q_stride < (size_t)nbytes || t_stride < (size_t)nbytes) {
         set_error("knn_hamming: bad arguments (nq=%d nt=%d nbytes=%d k=%d batch=%d)", nq, nt, nbytes, k, batch);
@@ -250,9 +372,12 @@ int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_strid
         tbw = (size_t)nt * nw;
     }
 
-    // split the train rows so that the grid holds ~8 blocks per CU
-    const int qtiles = (nq + kQueriesPerBlock - 1) / kQueriesPerBlock;
-    const long long target_blocks = 8LL * ctx->num_cus;
+    // split the train rows so that the grid holds ~tune_blocks_per_cu blocks per CU
+    const int variant = ctx->opt_hamming_variant;
+    int qpl = (variant == 1 && nw <= 16) ? ctx->opt_hamming_qpl : 1;  // queries per lane
+    if (qpl == 2 && nq <= kQueriesPerBlock * 32) qpl = 1;                // too few queries to afford it
+    const int qtiles = (nq + kQueriesPerBlock * qpl - 1) / (kQueriesPerBlock * qpl);
+    const long long target_blocks = (long long)ctx->opt_hamming_blocks_per_cu * ctx->num_cus;
     const int max_split = (nt + kTileRows - 1) / kTileRows;
     long long want = (target_blocks + (long long)qtiles * batch - 1) / ((long long)qtiles * batch);
     int nsplit = (int)std::max<long long>(1, std::min<long long>(want, max_split));
@@ -273,19 +398,19 @@ int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_strid
     dim3 grid(qtiles, nsplit, batch);
     prof_mark(ctx, MLPL_PROF_KNN_HAMMING, 0, s);
     switch (nw) {
-        case 1: launch_partial<1>(grid, s, qw, qbw, tw, tbw, nq, nt, rps, nsplit, (uint2 *)part); break;
-        case 2: launch_partial<2>(grid, s, qw, qbw, tw, tbw, nq, nt, rps, nsplit, (uint2 *)part); break;
-        case 4: launch_partial<4>(grid, s, qw, qbw, tw, tbw, nq, nt, rps, nsplit, (uint2 *)part); break;
-        case 8: launch_partial<8>(grid, s, qw, qbw, tw, tbw, nq, nt, rps, nsplit, (uint2 *)part); break;
-        case 16: launch_partial<16>(grid, s, qw, qbw, tw, tbw, nq, nt, rps, nsplit, (uint2 *)part); break;
-        case 32: launch_partial<32>(grid, s, qw, qbw, tw, tbw, nq, nt, rps, nsplit, (uint2 *)part); break;
-        case 64: launch_partial<64>(grid, s, qw, qbw, tw, tbw, nq, nt, rps, nsplit, (uint2 *)part); break;
+        case 1: launch_partial<1>(variant, qpl, grid, s, qw, qbw, tw, tbw, nq, nt, rps, nsplit, (uint2 *)part); break;
+        case 2: launch_partial<2>(variant, qpl, grid, s, qw, qbw, tw, tbw, nq, nt, rps, nsplit, (uint2 *)part); break;
+        case 4: launch_partial<4>(variant, qpl, grid, s, qw, qbw, tw, tbw, nq, nt, rps, nsplit, (uint2 *)part); break;
+        case 8: launch_partial<8>(variant, qpl, grid, s, qw, qbw, tw, tbw, nq, nt, rps, nsplit, (uint2 *)part); break;
+        case 16: launch_partial<16>(variant, qpl, grid, s, qw, qbw, tw, tbw, nq, nt, rps, nsplit, (uint2 *)part); break;
+        case 32: launch_partial<32>(variant, qpl, grid, s, qw, qbw, tw, tbw, nq, nt, rps, nsplit, (uint2 *)part); break;
+        case 64: launch_partial<64>(variant, qpl, grid, s, qw, qbw, tw, tbw, nq, nt, rps, nsplit, (uint2 *)part); break;
         default: set_error("knn_hamming: unsupported descriptor width %d bytes", nbytes); return MLPL_E_BAD_INPUT;
     }
     prof_mark(ctx, MLPL_PROF_KNN_HAMMING, 1, s);
-    dim3 mgrid((nq + 255) / 256, batch);
-    hipLaunchKernelGGL(knn_hamming_merge_kernel, mgrid, dim3(256), 0, s, (const uint2 *)part, nq, nsplit, rps, dshift, k,
-                       d_idx, d_dist);
+    dim3 mgrid((nq + kMergeGroup - 1) / kMergeGroup, batch);
+    hipLaunchKernelGGL(knn_hamming_merge_kernel, mgrid, dim3(1024), 0, s, (const uint2 *)part, nq, nsplit, rps, dshift, k,
+                       ratio, d_idx, d_dist, d_group_counts);
     MLPL_HIP_TRY(hipGetLastError());
     return MLPL_OK;
 }

@@ -54,6 +54,10 @@ struct mlpl_ctx {
     size_t pinned_bytes;
     int l2_mode;
     int num_cus;
+    // tuning knobs (mlpl_set_option)
+    int opt_hamming_variant;        // 0 = LDS-tiled broadcast reads, 1 = scalar-load (SGPR operand) kernel
+    int opt_hamming_qpl;            // queries per lane for variant 1 (1 or 2)
+    int opt_hamming_blocks_per_cu;  // grid sizing target
     // optional per-kernel hipEvent bracketing (mlpl_profile_*)
     int prof_on;
     hipEvent_t *prof_ev[MLPL_PROF_NUM];  // pairs: [2*i] start, [2*i+1] stop
@@ -70,18 +74,24 @@ constexpr int kProfMaxLaunches = 8192;
 // Records the start (phase 0) / stop (phase 1) event of one launch of kernel `id` on stream s when profiling is on.
 void prof_mark(mlpl_ctx *ctx, int id, int phase, hipStream_t s);
 
-inline hipStream_t pick_stream(mlpl_ctx *ctx, void *stream) {
-    return stream ? reinterpret_cast<hipStream_t>(stream) : ctx->stream;
-}
+// `stream` of the *_dev entry points is a hipStream_t; NULL is HIP's null (legacy default) stream, as everywhere
+// in HIP.  The context's private stream is only used by the host-pointer entry points.
+inline hipStream_t pick_stream(mlpl_ctx *, void *stream) { return reinterpret_cast<hipStream_t>(stream); }
 
 // ---- kernel launchers (defined in the .hip files) ----
 int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_stride, size_t q_bstride,
                        const uint8_t *d_t, int nt, size_t t_stride, size_t t_bstride, int nbytes, int k, int batch,
-                       int32_t *d_idx, int32_t *d_dist, hipStream_t s);
+                       int32_t *d_idx, int32_t *d_dist, hipStream_t s, float ratio = 0.75f,
+                       int32_t *d_group_counts = nullptr);
 int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t,
                   int nt, size_t t_stride, size_t t_bstride, int dim, int k, int batch, int32_t *d_idx,
                   float *d_dist, hipStream_t s);
+// group_counts_ready: d_group_counts (one int per kCountGroup queries per batch item, in the context workspace slot
+// WS_COUNT) was already filled by knn_hamming_merge_kernel; otherwise a counting pass runs first.
+constexpr int kRatioGroup = 256;  // queries per ratio_write block
+constexpr int kCountGroup = 64;   // queries per entry of the pass-count table
 int launch_ratio_compact(mlpl_ctx *ctx, const int32_t *d_idx, const void *d_dist, int dist_is_float, int nq, int k,
-                         int batch, float ratio, mlpl_dmatch *d_out, int32_t *d_n_out, hipStream_t s);
+                         int batch, float ratio, mlpl_dmatch *d_out, int32_t *d_n_out, hipStream_t s,
+                         int32_t *d_group_counts_ready = nullptr);
 
 }  // namespace mlpl

@@ -3,9 +3,10 @@
 // Replaces the loops at reference matchinglib/source/matchers.cpp:601-625 (int Hamming distances) and
 // :677-701 (float squared-L2 distances):
 //     if (dists[q][0] < (0.75f * dists[q][1])) push_back(DMatch{distance=(float)d0, queryIdx=q, trainIdx=idx0})
-// Matches must come out in ascending query order (push_back order), so compaction is a stable block scan:
-// one 1024-thread block per batch item walks the queries in chunks of 1024, ballot + popcount inside each
-// wave, a 16-entry LDS prefix across waves and a running base across chunks.
+// Matches must come out in ascending query order (push_back order), so compaction is a stable two-level scan over
+// groups of 256 queries: (1) per-group pass counts (ratio_count_kernel, or for Hamming the merge kernel's by-product),
+// (2) ratio_write_kernel: each group sums the counts of the groups before it, ballot/popcount-scans its own 256
+// predicates and writes its DMatch rows at the right offset; the last group stores the total.
 
 #include "mlpl_internal.h"
 
@@ -13,79 +14,113 @@ namespace mlpl {
 
 namespace {
 
-constexpr int kThreads = 1024;
+template <bool kFloat>
+__device__ __forceinline__ bool ratio_pred(const void *dist_v, size_t qi, int k, float ratio, float &d0) {
+    float d1 = 0.f;
+    if constexpr (kFloat) {
+        const float *df = reinterpret_cast<const float *>(dist_v);
+        d0 = df[qi * k];
+        if (k == 2) d1 = df[qi * k + 1];
+    } else {
+        const int32_t *di = reinterpret_cast<const int32_t *>(dist_v);
+        d0 = (float)di[qi * k];
+        if (k == 2) d1 = (float)di[qi * k + 1];
+    }
+    return (k == 2) ? (d0 < __fmul_rn(ratio, d1)) : true;
+}
 
 template <bool kFloat>
-__global__ __launch_bounds__(kThreads) void ratio_compact_kernel(const int32_t *__restrict__ idx,
-                                                                  const void *__restrict__ dist_v, int nq, int k,
+__global__ __launch_bounds__(kCountGroup) void ratio_count_kernel(const void *__restrict__ dist_v, int nq, int k, float ratio,
+                                                                  int32_t *__restrict__ group_counts) {
+    static_assert(kCountGroup == 64, "one wave per count group");
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int qi = blockIdx.x * kCountGroup + tid;
+    bool pass = false;
+    float d0;
+    if (qi < nq) pass = ratio_pred<kFloat>(dist_v, (size_t)b * nq + qi, k, ratio, d0);
+    const unsigned long long bal = __ballot(pass);
+    if (tid == 0) group_counts[(size_t)b * gridDim.x + blockIdx.x] = __popcll(bal);
+}
+
+template <bool kFloat>
+__global__ __launch_bounds__(kRatioGroup) void ratio_write_kernel(const int32_t *__restrict__ idx, const void *__restrict__ dist_v,
+                                                                  const int32_t *__restrict__ group_counts, int nq, int k,
                                                                   float ratio, mlpl_dmatch *__restrict__ out,
                                                                   int32_t *__restrict__ n_out) {
-    __shared__ int wave_tot[kThreads / 64];
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    idx += (size_t)b * nq * k;
-    out += (size_t)b * nq;
-    const int32_t *di = reinterpret_cast<const int32_t *>(dist_v) + (size_t)b * nq * k;
-    const float *df = reinterpret_cast<const float *>(dist_v) + (size_t)b * nq * k;
-
-    int running = 0;
-    for (int base = 0; base < nq; base += kThreads) {
-        const int qi = base + tid;
-        bool pass = false;
-        float d0 = 0.f;
-        int i0 = 0;
-        if (qi < nq) {
-            float d1 = 0.f;
-            if constexpr (kFloat) {
-                d0 = df[(size_t)qi * k];
-                if (k == 2) d1 = df[(size_t)qi * k + 1];
-            } else {
-                d0 = (float)di[(size_t)qi * k];
-                if (k == 2) d1 = (float)di[(size_t)qi * k + 1];
-            }
-            i0 = idx[(size_t)qi * k];
-            pass = (k == 2) ? (d0 < __fmul_rn(ratio, d1)) : true;
-        }
-        const unsigned long long bal = __ballot(pass);
-        const int lane_prefix = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[wave] = __popcll(bal);
-        __syncthreads();
-        int wave_prefix = 0, chunk_total = 0;
+    __shared__ int red[kRatioGroup / 64];
+    __shared__ int wave_tot[kRatioGroup / 64];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = blockIdx.x, ngrp = gridDim.x;
+    const int ncnt = (nq + kCountGroup - 1) / kCountGroup;
+    const int32_t *gc = group_counts + (size_t)b * ncnt;
+    // exclusive prefix: pass counts of all count-groups before this block's first query
+    int part = 0;
+    for (int j = tid; j < grp * (kRatioGroup / kCountGroup); j += kRatioGroup) part += gc[j];
 #pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) {
-            const int c = wave_tot[w];
-            if (w < wave) wave_prefix += c;
-            chunk_total += c;
-        }
-        if (pass) {
-            mlpl_dmatch m;
-            m.queryIdx = qi;
-            m.trainIdx = i0;
-            m.imgIdx = -1;
-            m.distance = d0;
-            out[running + wave_prefix + lane_prefix] = m;
-        }
-        running += chunk_total;
-        __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) red[wave] = part;
+
+    const int qi = grp * kRatioGroup + tid;
+    bool pass = false;
+    float d0 = 0.f;
+    if (qi < nq) pass = ratio_pred<kFloat>(dist_v, (size_t)b * nq + qi, k, ratio, d0);
+    const unsigned long long bal = __ballot(pass);
+    const int lane_prefix = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(bal);
+    __syncthreads();
+    int base = 0, wave_prefix = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kRatioGroup / 64; ++w) {
+        base += red[w];
+        const int c = wave_tot[w];
+        if (w < wave) wave_prefix += c;
+        total += c;
     }
-    if (tid == 0) n_out[b] = running;
+    if (pass) {
+        mlpl_dmatch m;
+        m.queryIdx = qi;
+        m.trainIdx = idx[((size_t)b * nq + qi) * k];
+        m.imgIdx = -1;
+        m.distance = d0;
+        out[(size_t)b * nq + base + wave_prefix + lane_prefix] = m;
+    }
+    if (grp == ngrp - 1 && tid == 0) n_out[b] = base + total;
 }
 
 }  // namespace
 
 int launch_ratio_compact(mlpl_ctx *ctx, const int32_t *d_idx, const void *d_dist, int dist_is_float, int nq, int k,
-                         int batch, float ratio, mlpl_dmatch *d_out, int32_t *d_n_out, hipStream_t s) {
-    (void)ctx;
-    if (!d_idx || !d_dist || !d_out || !d_n_out || nq < 0 || batch < 1 || (k != 1 && k != 2)) {
+                         int batch, float ratio, mlpl_dmatch *d_out, int32_t *d_n_out, hipStream_t s,
+                         int32_t *d_group_counts_ready) {
+    if (!d_idx || !d_dist || !d_out || !d_n_out || nq < 0 || batch < 1 || batch > 65535 || (k != 1 && k != 2)) {
         set_error("ratio_compact: bad arguments");
         return MLPL_E_BAD_INPUT;
     }
+    if (nq == 0) {
+        MLPL_HIP_TRY(hipMemsetAsync(d_n_out, 0, sizeof(int32_t) * batch, s));
+        return MLPL_OK;
+    }
+    const int ngrp = (nq + kRatioGroup - 1) / kRatioGroup;
+    const int ncnt = (nq + kCountGroup - 1) / kCountGroup;
+    dim3 grid(ngrp, batch);
+    int32_t *gc = d_group_counts_ready;
+    if (!gc) {
+        void *buf = nullptr;
+        int rc = ws_get(ctx, WS_COUNT, (size_t)batch * ncnt * sizeof(int32_t), &buf);
+        if (rc) return rc;
+        gc = (int32_t *)buf;
+        dim3 cgrid(ncnt, batch);
+        if (dist_is_float)
+            hipLaunchKernelGGL(ratio_count_kernel<true>, cgrid, dim3(kCountGroup), 0, s, d_dist, nq, k, ratio, gc);
+        else
+            hipLaunchKernelGGL(ratio_count_kernel<false>, cgrid, dim3(kCountGroup), 0, s, d_dist, nq, k, ratio, gc);
+    }
     if (dist_is_float)
-        hipLaunchKernelGGL(ratio_compact_kernel<true>, dim3(batch), dim3(kThreads), 0, s, d_idx, d_dist, nq, k, ratio,
-                           d_out, d_n_out);
+        hipLaunchKernelGGL(ratio_write_kernel<true>, grid, dim3(kRatioGroup), 0, s, d_idx, d_dist, gc, nq, k, ratio, d_out,
+                           d_n_out);
     else
-        hipLaunchKernelGGL(ratio_compact_kernel<false>, dim3(batch), dim3(kThreads), 0, s, d_idx, d_dist, nq, k, ratio,
-                           d_out, d_n_out);
+        hipLaunchKernelGGL(ratio_write_kernel<false>, grid, dim3(kRatioGroup), 0, s, d_idx, d_dist, gc, nq, k, ratio, d_out,
+                           d_n_out);
     MLPL_HIP_TRY(hipGetLastError());
     return MLPL_OK;
 }

@@ -152,12 +152,13 @@ def getMatches(
 # ---- device-resident (torch) entry: nothing leaves HBM -------------------------------------------------------
 
 def match_hamming_device(q, t, ratio_test: bool = True, ratio: float = 0.75, ctx: Optional[Context] = None, out=None,
-                         stream: int = 0):
+                         stream: Optional[int] = None):
     """Batched knn(+ratio+compaction) on CUDA/HIP torch tensors.
 
     q: uint8 [B, nq, nbytes] (or [nq, nbytes]), t: uint8 [B, nt, nbytes]; returns dict of torch tensors
     idx [B,nq,k] int32, dist [B,nq,k] int32, matches [B,nq,4] int32 (DMatch rows, .distance bit-cast),
-    count [B] int32.  Enqueues on `stream` (0 = the context's stream) without synchronising.
+    count [B] int32.  Enqueues on `stream` (a hipStream_t handle; None = torch's current stream) without
+    synchronising.
     """
     import torch
 
@@ -181,6 +182,6 @@ def match_hamming_device(q, t, ratio_test: bool = True, ratio: float = 0.75, ctx
     rc = ctx.lib.mlpl_match_hamming_dev(
         ctx.handle, q.data_ptr(), nq, q.stride(1), q.stride(0), t.data_ptr(), nt, t.stride(1), t.stride(0), nbytes,
         1 if ratio_test else 0, ratio, B, out["idx"].data_ptr(), out["dist"].data_ptr(), out["matches"].data_ptr(),
-        out["count"].data_ptr(), stream or None)
+        out["count"].data_ptr(), torch.cuda.current_stream(q.device).cuda_stream if stream is None else stream)
     check(rc, "mlpl_match_hamming_dev")
     return out
