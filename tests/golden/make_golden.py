@@ -75,5 +75,39 @@ def main():
     hamming_case("hamming_c1_2048", q, t)
 
 
+
+
+# ---- 5-point solver vectors: inputs + E-sets of the reference's vendored OpenGV fivept_nister ----------------
+def run_opengv(pts):
+    tool = oracle_lib.ref_tool("opengv_5pt")
+    assert tool, "build oracle/_ref first: make -C oracle ref"
+    ns, npts = pts.shape[:2]
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            np.array([ns, npts], np.int32).tofile(f)
+            np.ascontiguousarray(pts, np.float64).tofile(f)
+        subprocess.run([tool, fin, fout], check=True)
+        raw = np.fromfile(fout, np.uint8).reshape(ns, 4 + 720)
+    cnt = raw[:, :4].copy().view(np.int32)[:, 0]
+    Es = raw[:, 4:].copy().view(np.float64).reshape(ns, 10, 3, 3)
+    return cnt, Es
+
+
+def fivept_case():
+    p1, p2, R, t, mask, th = synth.pose_scene(5000, seed=20260103)
+    rng = np.random.default_rng(20260113)
+    ns = 120
+    samples = np.stack([rng.choice(5000, 5, replace=False) for _ in range(ns)]).astype(np.int32)
+    pts = np.concatenate([p1[samples], p2[samples]], axis=2)  # ns x 5 x (x1,y1,x2,y2)
+    cnt, Es = run_opengv(pts)
+    np.savez_compressed(os.path.join(HERE, "fivept_opengv_120.npz"), pts=pts, count=cnt, E=Es)
+    print("fivept_opengv_120: mean #solutions", cnt.mean())
+
+
 if __name__ == "__main__":
-    main()
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("all", "matching"):
+        main()
+    if what in ("all", "pose"):
+        fivept_case()

@@ -31,6 +31,108 @@ class Oracle:
         lib.oracle_ratio_filter_i32.argtypes = [vp, vp, ci, ci, vp]
         lib.oracle_ratio_filter_f32.argtypes = [vp, vp, ci, ci, vp]
         lib.oracle_get_matches_linear.argtypes = [ci, ci, vp, ci, vp, ci, ci, ci, ci, vp, C.POINTER(ci)]
+        self._bind_pose()
+
+    def _bind_pose(self):
+        lib = self.lib
+        vp, ci, cd, cu = C.c_void_p, C.c_int, C.c_double, C.c_uint
+        lib.oracle_srand.argtypes = [C.POINTER(GlibcRand), cu]
+        lib.oracle_rand.argtypes = [C.POINTER(GlibcRand)]
+        lib.oracle_rand.restype = ci
+        lib.oracle_get_subset.argtypes = [C.POINTER(GlibcRand), vp, vp, ci, ci, vp]
+        lib.oracle_run5point.argtypes = [vp, vp, ci, vp]
+        lib.oracle_sampson_err.argtypes = [vp, vp, ci, vp, vp]
+        lib.oracle_find_inliers.argtypes = [vp, vp, ci, vp, cd, vp, vp, C.POINTER(cd)]
+        lib.oracle_ransac_update_num_iters.argtypes = [cd, cd, ci, ci]
+        lib.oracle_ransac_essential.argtypes = [vp, vp, ci, cd, cd, ci, ci, cu, vp, vp, C.POINTER(ci), C.POINTER(ci), vp]
+        lib.oracle_decompose_essential.argtypes = [vp, vp, vp, vp]
+        lib.oracle_recover_pose.argtypes = [vp, vp, vp, ci, cd, vp, vp, vp, vp]
+        lib.oracle_triangulate_point.argtypes = [vp, vp, vp, vp, vp]
+        lib.oracle_jacobi_svd.argtypes = [vp, ci, ci, vp, vp]
+        lib.oracle_solve_poly.argtypes = [vp, ci, vp, ci]
+
+    # ---- pose ----
+    def rand_stream(self, seed, count):
+        st = GlibcRand()
+        self.lib.oracle_srand(C.byref(st), seed)
+        return np.array([self.lib.oracle_rand(C.byref(st)) for _ in range(count)], np.int64)
+
+    def sample_table(self, seed, p1, p2, iters):
+        """The first `iters` 5-point samples getSubset would draw for this seed (no early exit)."""
+        p1 = np.ascontiguousarray(p1, np.float64)
+        p2 = np.ascontiguousarray(p2, np.float64)
+        st = GlibcRand()
+        self.lib.oracle_srand(C.byref(st), seed)
+        out = np.empty((iters, 5), np.int32)
+        tmp = np.empty(5, np.int32)
+        for i in range(iters):
+            ok = self.lib.oracle_get_subset(C.byref(st), p1.ctypes.data, p2.ctypes.data, p1.shape[0], 300, tmp.ctypes.data)
+            assert ok
+            out[i] = tmp
+        return out
+
+    def run5point(self, q1, q2):
+        q1 = np.ascontiguousarray(q1, np.float64)
+        q2 = np.ascontiguousarray(q2, np.float64)
+        E = np.zeros((10, 3, 3))
+        n = self.lib.oracle_run5point(q1.ctypes.data, q2.ctypes.data, q1.shape[0], E.ctypes.data)
+        return E[:n].copy()
+
+    def find_inliers(self, p1, p2, E, thresh):
+        p1 = np.ascontiguousarray(p1, np.float64)
+        p2 = np.ascontiguousarray(p2, np.float64)
+        E = np.ascontiguousarray(E, np.float64)
+        n = p1.shape[0]
+        err = np.empty(n, np.float32)
+        mask = np.empty(n, np.uint8)
+        s = C.c_double(0)
+        good = self.lib.oracle_find_inliers(p1.ctypes.data, p2.ctypes.data, n, E.ctypes.data, thresh, err.ctypes.data,
+                                            mask.ctypes.data, C.byref(s))
+        return good, s.value, err, mask
+
+    def ransac_essential(self, p1, p2, thresh, confidence=0.999, max_iters=1000, lesqu=False, seed=12345, trace=False):
+        p1 = np.ascontiguousarray(p1, np.float64)
+        p2 = np.ascontiguousarray(p2, np.float64)
+        n = p1.shape[0]
+        E = np.zeros((3, 3))
+        mask = np.zeros(n, np.uint8)
+        ninl, iters = C.c_int(0), C.c_int(0)
+        tr = (TraceRec * max_iters)() if trace else None
+        ok = self.lib.oracle_ransac_essential(p1.ctypes.data, p2.ctypes.data, n, thresh, confidence, max_iters,
+                                              int(lesqu), seed, E.ctypes.data, mask.ctypes.data, C.byref(ninl),
+                                              C.byref(iters), C.addressof(tr) if trace else None)
+        return dict(ok=bool(ok), E=E, mask=mask, n_inliers=ninl.value, iters=iters.value, trace=tr)
+
+    def recover_pose(self, E, p1, p2, dist=50.0, mask=None):
+        p1 = np.ascontiguousarray(p1, np.float64)
+        p2 = np.ascontiguousarray(p2, np.float64)
+        E = np.ascontiguousarray(E, np.float64)
+        n = p1.shape[0]
+        R, t, Q = np.zeros((3, 3)), np.zeros(3), np.zeros((n, 3))
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).copy()
+        good = self.lib.oracle_recover_pose(E.ctypes.data, p1.ctypes.data, p2.ctypes.data, n, dist, R.ctypes.data,
+                                            t.ctypes.data, Q.ctypes.data, None if m is None else m.ctypes.data)
+        return good, R, t, Q, m
+
+    def decompose_essential(self, E):
+        E = np.ascontiguousarray(E, np.float64)
+        R1, R2, t = np.zeros((3, 3)), np.zeros((3, 3)), np.zeros(3)
+        self.lib.oracle_decompose_essential(E.ctypes.data, R1.ctypes.data, R2.ctypes.data, t.ctypes.data)
+        return R1, R2, t
+
+    def jacobi_svd(self, A):
+        A = np.ascontiguousarray(A, np.float64)
+        m, n = A.shape
+        w, V = np.zeros(n), np.zeros((n, n))
+        self.lib.oracle_jacobi_svd(A.ctypes.data, m, n, w.ctypes.data, V.ctypes.data)
+        return w, V
+
+    def solve_poly(self, coeffs):
+        c = np.ascontiguousarray(coeffs, np.float64)
+        deg = len(c) - 1
+        r = np.zeros((deg, 2))
+        self.lib.oracle_solve_poly(c.ctypes.data, deg, r.ctypes.data, 0)
+        return r[:, 0] + 1j * r[:, 1]
 
     # ---- matching ----
     def knn_hamming(self, q, t, k=2):
@@ -83,7 +185,8 @@ _cached = None
 def load() -> Oracle:
     global _cached
     if _cached is None:
-        if not os.path.exists(LIB):
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith(("_oracle.c", ".h"))]
+        if not os.path.exists(LIB) or any(os.path.getmtime(f) > os.path.getmtime(LIB) for f in srcs):
             subprocess.run(["make", "-C", ORACLE_DIR], check=True, stdout=subprocess.DEVNULL)
         _cached = Oracle(C.CDLL(LIB))
     return _cached
