@@ -14,24 +14,6 @@ int launch_knn_l2_mfma(mlpl_ctx *, const float *, int, size_t, size_t, const flo
 }  // namespace mlpl
 
 extern "C" {
-int mlpl_ransac_essential(mlpl_ctx *, const double *, const double *, int, double, double, int, int, uint32_t, double *,
-                          uint8_t *, int *, int *) {
-    mlpl::set_error("mlpl_ransac_essential: not built yet");
-    return MLPL_E_UNSUPPORTED;
-}
-int mlpl_ransac_essential_dev(mlpl_ctx *, const double *, const double *, int, double, double, int, int, uint32_t,
-                              double *, uint8_t *, int *, int *, void *) {
-    mlpl::set_error("mlpl_ransac_essential_dev: not built yet");
-    return MLPL_E_UNSUPPORTED;
-}
-int mlpl_solve_5pt(mlpl_ctx *, const double *, const double *, int, const int32_t *, int, double *, int32_t *) {
-    mlpl::set_error("mlpl_solve_5pt: not built yet");
-    return MLPL_E_UNSUPPORTED;
-}
-int mlpl_score_models(mlpl_ctx *, const double *, const double *, int, const double *, int, double, int32_t *, double *) {
-    mlpl::set_error("mlpl_score_models: not built yet");
-    return MLPL_E_UNSUPPORTED;
-}
 int mlpl_recover_pose(mlpl_ctx *, const double *, const double *, const double *, int, double, double *, double *, double *,
                       uint8_t *) {
     mlpl::set_error("mlpl_recover_pose: not built yet");

@@ -1,0 +1,969 @@
+// ransac_5pt.hip -- RANSAC for the essential matrix on gfx950: one 5-point Nister solve per wavefront, thread-per-model
+// Sampson scoring, host replay of the reference's sequential best/niters logic.
+//
+// Replaces, under reference poselib/source/five-point-nister/ :
+//   modelest.cpp:343-474  CvModelEstimator3::runRANSAC        (driver; replayed exactly on the host from device tables)
+//   modelest.cpp:567-650  getSubset / checkSubset             (sample table from the glibc rand() stream, host)
+//   five-point.cpp:366-471 CvEMEstimator::run5Point           (solve5pt_kernel, one hypothesis per wave)
+//   five-point.cpp:476-503 computeReprojError3 + modelest.cpp:69-83 findInliers (score_models_kernel)
+//
+// solve5pt_kernel (64 threads = one wave per sample; all cross-lane traffic goes through ~7 KiB of LDS):
+//   1. the 5x9 epipolar matrix; its 4-dim null space by Householder QR of the 9x5 transpose (orthonormal basis, like the
+//      reference's SVD basis; any orthonormal basis yields the same set of essential matrices);
+//   2. the ten cubic constraints det(E)=0, E E^T E - 1/2 tr(E E^T) E = 0 for E = x E0 + y E1 + z E2 + E3: lane (i,j,k) of the
+//      64 = 4^3 lanes evaluates the trilinear coefficient tensor, 20 lanes symmetrise it into the 10x20 matrix in the
+//      reference's monomial order (five-point.cpp:813-823);
+//   3. Gauss-Jordan with partial pivoting on the 10x20 system, 200 elements spread over the wave;
+//   4. B(z) (3x13) and the degree-10 determinant polynomial, one coefficient per lane;
+//   5. all complex roots by Durand-Kerner, one root per lane, start values (1+i)^k as cv::solvePoly, Jacobi-style sweeps
+//      until the corrections vanish to rounding; a root is real iff |imag| <= 1e-10 (five-point.cpp:438);
+//   6. per real root: null vector of Bz (3x3 one-sided Jacobi SVD in registers), reject |xy1[2]| < 1e-10 (:457),
+//      E = x E0 + y E1 + z E2 + E3, Frobenius-normalised; ballot-compacted into the output.
+// score_models_kernel: one thread per model, sequential loop over the correspondences (wave-uniform operands through the
+//   scalar cache), fp64 Sampson error rounded to float exactly as the reference stores it, `err <= thresh^2` count and
+//   the in-order double sum of the float errors -- bit-identical to the CPU path for the same E (no FMA contraction:
+//   this file is compiled with -ffp-contract=off like the reference's -msse4.2 build).
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "mlpl_internal.h"
+
+namespace mlpl {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------------------------
+
+// monomial order of the reference's coefficient matrix: exponents of (x, y, z); the 4th variable w = 1 takes the rest.
+__constant__ int8_t kMonoVars[20][3] = {
+    // as variable indices of the three factors (0=x,1=y,2=z,3=w), sorted
+    {0, 0, 0}, {1, 1, 1}, {0, 0, 1}, {0, 1, 1}, {0, 0, 2}, {0, 0, 3}, {1, 1, 2}, {1, 1, 3}, {0, 1, 2}, {0, 1, 3},
+    {0, 2, 2}, {0, 2, 3}, {0, 3, 3}, {1, 2, 2}, {1, 2, 3}, {1, 3, 3}, {2, 2, 2}, {2, 2, 3}, {2, 3, 3}, {3, 3, 3}};
+
+struct SolveLds {
+    double Q[5][9];     // epipolar rows; overwritten by the QR (as its transpose M[r][c] = Q[c][r])
+    double V[5][9];     // Householder vectors
+    double vn2[5];      // their squared norms
+    double EE[4][9];    // null-space basis
+    double F[10][64];   // trilinear tensors
+    double A[10][20];   // constraint matrix
+    double b[3][13];    // B(z)
+    double c[11];       // determinant polynomial, ascending
+    double rr[10], ri[10];
+};
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+
+// One-sided Jacobi SVD of a 3x3 (row-major a[9]); returns the right singular vector of the smallest singular value.
+__device__ __forceinline__ void null_vector_3x3(const double *a, double *nv) {
+    double G[3][3], V[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            G[i][j] = a[i * 3 + j];
+            V[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+    const double eps = DBL_EPSILON * 2;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    alpha += G[i][p] * G[i][p];
+                    beta += G[i][q] * G[i][q];
+                    gamma += G[i][p] * G[i][q];
+                }
+                if (fabs(gamma) <= eps * sqrt(alpha * beta) || gamma == 0.0) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const double gp = G[i][p], gq = G[i][q];
+                    G[i][p] = c * gp - s * gq;
+                    G[i][q] = s * gp + c * gq;
+                    const double vp = V[i][p], vq = V[i][q];
+                    V[i][p] = c * vp - s * vq;
+                    V[i][q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double w[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) w[j] = G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j];
+    int m = 0;
+    if (w[1] < w[m]) m = 1;
+    if (w[2] < w[m]) m = 2;
+    nv[0] = (m == 0) ? V[0][0] : (m == 1 ? V[0][1] : V[0][2]);
+    nv[1] = (m == 0) ? V[1][0] : (m == 1 ? V[1][1] : V[1][2]);
+    nv[2] = (m == 0) ? V[2][0] : (m == 1 ? V[2][1] : V[2][2]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Steps 2..6 of the solver, shared by the minimal (5-point) kernel and the refit kernel: EE basis in LDS ->
+// essential matrices.  Returns (per lane) whether this lane holds a valid model in Eout[9].
+// ---------------------------------------------------------------------------------------------------------------
+__device__ bool solve_from_basis(SolveLds &L, int lane, double *Eout) {
+    // ---- 2. trilinear coefficient tensors F[row][lane], lane = (i,j,k) ----
+    {
+        const int i = lane >> 4, j = (lane >> 2) & 3, k = lane & 3;
+        const double *Ei = L.EE[i], *Ej = L.EE[j], *Ek = L.EE[k];
+        // det: rows 0,1,2 of E taken from basis i,j,k
+        const double det = Ei[0] * (Ej[4] * Ek[8] - Ej[5] * Ek[7]) - Ei[1] * (Ej[3] * Ek[8] - Ej[5] * Ek[6]) +
+                           Ei[2] * (Ej[3] * Ek[7] - Ej[4] * Ek[6]);
+        L.F[0][lane] = det;
+        // P = Ei * Ej^T, tr = trace(P);  C = P * Ek - 1/2 tr * Ek
+        double P[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) P[r][b] = Ei[r * 3] * Ej[b * 3] + Ei[r * 3 + 1] * Ej[b * 3 + 1] + Ei[r * 3 + 2] * Ej[b * 3 + 2];
+        const double htr = 0.5 * (P[0][0] + P[1][1] + P[2][2]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                L.F[1 + r * 3 + c][lane] = P[r][0] * Ek[c] + P[r][1] * Ek[3 + c] + P[r][2] * Ek[6 + c] - htr * Ek[r * 3 + c];
+    }
+    __syncthreads();
+    // ---- symmetrise: A[row][m] = sum over the distinct orderings of monomial m ----
+    if (lane < 20) {
+        const int a = kMonoVars[lane][0], b = kMonoVars[lane][1], c = kMonoVars[lane][2];
+        int perm[6];
+        int np = 0;
+        const int cand[6] = {a * 16 + b * 4 + c, a * 16 + c * 4 + b, b * 16 + a * 4 + c,
+                             b * 16 + c * 4 + a, c * 16 + a * 4 + b, c * 16 + b * 4 + a};
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            bool dup = false;
+            for (int u = 0; u < np; ++u) dup = dup || (perm[u] == cand[t]);
+            if (!dup) perm[np++] = cand[t];
+        }
+        for (int row = 0; row < 10; ++row) {
+            double s = 0;
+            for (int u = 0; u < np; ++u) s += L.F[row][perm[u]];
+            L.A[row][lane] = s;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. Gauss-Jordan with partial pivoting: A <- [I | inv(A1) A2] ----
+    bool singular = false;
+    for (int col = 0; col < 10; ++col) {
+        int piv = col;
+        double pmax = fabs(L.A[col][col]);
+        for (int r = col + 1; r < 10; ++r) {
+            const double v = fabs(L.A[r][col]);
+            if (v > pmax) {
+                pmax = v;
+                piv = r;
+            }
+        }
+        if (pmax < DBL_EPSILON * 1e-3) {
+            singular = true;
+            break;
+        }
+        __syncthreads();
+        if (piv != col && lane < 20) {
+            const double t = L.A[col][lane];
+            L.A[col][lane] = L.A[piv][lane];
+            L.A[piv][lane] = t;
+        }
+        __syncthreads();
+        const double inv = 1.0 / L.A[col][col];
+        __syncthreads();
+        if (lane < 20) L.A[col][lane] *= inv;
+        __syncthreads();
+        double nv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = lane + 64 * t;
+            if (e < 200) {
+                const int r = e / 20, j = e - r * 20;
+                nv[t] = (r == col) ? L.A[r][j] : (L.A[r][j] - L.A[r][col] * L.A[col][j]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = lane + 64 * t;
+            if (e < 200) {
+                const int r = e / 20, j = e - r * 20;
+                L.A[r][j] = nv[t];
+            }
+        }
+        __syncthreads();
+    }
+    if (singular) return false;  // wave-uniform
+
+    // ---- 4. B(z) rows and the determinant polynomial ----
+    if (lane < 39) {
+        const int i = lane / 13, j = lane - i * 13;
+        const double *r1 = &L.A[2 * i + 4][10];
+        const double *r2 = &L.A[2 * i + 5][10];
+        double v1 = 0, v2 = 0;
+        // row1: [1..3] <- r1[0..2], [5..7] <- r1[3..5], [9..12] <- r1[6..9];  row2: [0..2] <- r2[0..2], [4..6] <- r2[3..5], [8..11] <- r2[6..9]
+        if (j >= 1 && j <= 3) v1 = r1[j - 1];
+        else if (j >= 5 && j <= 7) v1 = r1[j - 2];
+        else if (j >= 9) v1 = r1[j - 3];
+        if (j <= 2) v2 = r2[j];
+        else if (j >= 4 && j <= 6) v2 = r2[j - 1];
+        else if (j >= 8 && j <= 11) v2 = r2[j - 2];
+        L.b[i][j] = v1 - v2;
+    }
+    __syncthreads();
+    if (lane < 11) {
+        // entries of B as ascending polynomials: P[i][0] = b[i][3-k] (deg 3), P[i][1] = b[i][7-k] (deg 3), P[i][2] = b[i][12-k] (deg 4)
+        auto coef = [&](int row, int colm, int k) -> double {
+            if (colm == 0) return (k <= 3) ? L.b[row][3 - k] : 0.0;
+            if (colm == 1) return (k <= 3) ? L.b[row][7 - k] : 0.0;
+            return (k <= 4) ? L.b[row][12 - k] : 0.0;
+        };
+        const int perms[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
+        const double sgn[6] = {1, 1, 1, -1, -1, -1};
+        double ck = 0;
+        for (int pi = 0; pi < 6; ++pi) {
+            const int p0 = perms[pi][0], p1 = perms[pi][1], p2 = perms[pi][2];
+            double s = 0;
+            for (int i0 = 0; i0 <= 4; ++i0)
+                for (int i1 = 0; i1 <= 4 && i0 + i1 <= lane; ++i1) {
+                    const int i2 = lane - i0 - i1;
+                    if (i2 > 4) continue;
+                    s += coef(0, p0, i0) * coef(1, p1, i1) * coef(2, p2, i2);
+                }
+            ck += sgn[pi] * s;
+        }
+        L.c[lane] = ck;
+    }
+    __syncthreads();
+
+    // ---- 5. Durand-Kerner on up to 10 lanes ----
+    int n = 10;
+    for (; n > 1; n--)
+        if (fabs(L.c[n]) > DBL_EPSILON) break;  // cv::solvePoly trims vanishing leading coefficients
+    double pr, pim;
+    {
+        // (1+i)^lane for lane 0..9
+        const double tr[10] = {1, 1, 0, -2, -4, -4, 0, 8, 16, 16};
+        const double ti[10] = {0, 1, 2, 2, 0, -4, -8, -8, 0, 16};
+        const int l = lane < 10 ? lane : 0;
+        pr = tr[l];
+        pim = ti[l];
+    }
+    const bool active = lane < n;
+    int settle = 0;
+    for (int iter = 0; iter < 400; ++iter) {
+        if (lane < 10) {
+            L.rr[lane] = pr;
+            L.ri[lane] = pim;
+        }
+        __syncthreads();
+        double dr = 0, di = 0;
+        if (active) {
+            double nr = L.c[n], ni = 0, der = L.c[n], dei = 0;
+            for (int j = 0; j < n; ++j) {
+                // num = num * p + c[n-1-j]
+                const double t = nr * pr - ni * pim;
+                ni = nr * pim + ni * pr;
+                nr = t + L.c[n - 1 - j];
+                if (j != lane) {
+                    const double xr = pr - L.rr[j], xi = pim - L.ri[j];
+                    if (xr != 0 || xi != 0) {
+                        const double u = der * xr - dei * xi;
+                        dei = der * xi + dei * xr;
+                        der = u;
+                    }
+                }
+            }
+            const double tt = 1.0 / (der * der + dei * dei);
+            dr = (nr * der + ni * dei) * tt;
+            di = (-nr * dei + ni * der) * tt;
+            pr -= dr;
+            pim -= di;
+        }
+        const double mag = active ? sqrt(dr * dr + di * di) : 0.0;
+        const double scale = active ? (1.0 + sqrt(pr * pr + pim * pim)) : 1.0;
+        const double rel = wave_max(mag / scale);
+        __syncthreads();
+        // quadratic convergence: once every correction is below 1e-9 (relative) two more sweeps reach rounding level
+        if (!(rel > 1e-9)) {
+            if (++settle >= 3) break;
+        } else {
+            settle = 0;
+        }
+        if (rel != rel) break;  // NaN: degenerate polynomial
+    }
+
+    // ---- 6. real roots -> essential matrices ----
+    bool valid = false;
+    if (active && fabs(pim) <= 1e-10 && pr == pr) {
+        const double z1 = pr, z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+        double bz[9];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double *br = L.b[j];
+            bz[j * 3 + 0] = br[0] * z3 + br[1] * z2 + br[2] * z1 + br[3];
+            bz[j * 3 + 1] = br[4] * z3 + br[5] * z2 + br[6] * z1 + br[7];
+            bz[j * 3 + 2] = br[8] * z4 + br[9] * z3 + br[10] * z2 + br[11] * z1 + br[12];
+        }
+        double xy1[3];
+        null_vector_3x3(bz, xy1);
+        if (!(fabs(xy1[2]) < 1e-10)) {
+            const double x = xy1[0] / xy1[2], y = xy1[1] / xy1[2];
+            double nrm = 0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                Eout[k] = L.EE[0][k] * x + L.EE[1][k] * y + L.EE[2][k] * z1 + L.EE[3][k];
+                nrm += Eout[k] * Eout[k];
+            }
+            nrm = sqrt(nrm);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Eout[k] /= nrm;
+            valid = (nrm == nrm) && nrm > 0;
+        }
+    }
+    return valid;
+}
+
+// Writes the wave's valid models: per-sample table (E_tab[sample][10][9], n_models[sample]) and, if dense != nullptr,
+// the dense list used by the scoring kernel (dense_E[total][9], dense_id[total] = sample*10 + slot).
+__device__ void emit_models(bool valid, const double *E, int lane, int sample, double *E_tab, int32_t *n_models,
+                            double *dense_E, int32_t *dense_id, int32_t *dense_total) {
+    const unsigned long long bal = __ballot(valid);
+    const int cnt = __popcll(bal);
+    const int slot = __popcll(bal & ((1ull << lane) - 1ull));
+    int base = 0;
+    if (dense_total) {
+        if (lane == 0 && cnt > 0) base = atomicAdd(dense_total, cnt);
+        base = __shfl(base, 0);
+    }
+    if (valid) {
+        double *dst = E_tab + ((size_t)sample * 10 + slot) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dst[k] = E[k];
+        if (dense_E) {
+            double *dd = dense_E + (size_t)(base + slot) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dd[k] = E[k];
+            dense_id[base + slot] = sample * 10 + slot;
+        }
+    }
+    if (lane == 0) n_models[sample] = cnt;
+}
+
+__global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
+                                                      const int32_t *__restrict__ samples, int n_samples,
+                                                      double *__restrict__ E_tab, int32_t *__restrict__ n_models,
+                                                      double *__restrict__ dense_E, int32_t *__restrict__ dense_id,
+                                                      int32_t *__restrict__ dense_total) {
+    __shared__ SolveLds L;
+    const int lane = threadIdx.x;
+    const int sample = blockIdx.x;
+    if (sample >= n_samples) return;
+
+    // ---- 1a. epipolar rows Q[i] = [x1x2, y1x2, x2, x1y2, y1y2, y2, x1, y1, 1]  (five-point.cpp:375-383) ----
+    if (lane < 5) {
+        const int idx = samples[sample * 5 + lane];
+        const double x1 = p1[2 * idx], y1 = p1[2 * idx + 1], x2 = p2[2 * idx], y2 = p2[2 * idx + 1];
+        double *r = L.Q[lane];
+        r[0] = x1 * x2, r[1] = y1 * x2, r[2] = x2, r[3] = x1 * y2, r[4] = y1 * y2, r[5] = y2, r[6] = x1, r[7] = y1, r[8] = 1.0;
+    }
+    __syncthreads();
+    // ---- 1b. Householder QR of M = Q^T (9x5): M[r][c] = L.Q[c][r] ----
+    for (int k = 0; k < 5; ++k) {
+        double nrm2 = 0;
+        for (int r = k; r < 9; ++r) nrm2 += L.Q[k][r] * L.Q[k][r];
+        const double x0 = L.Q[k][k];
+        const double alpha = (x0 >= 0 ? -1.0 : 1.0) * sqrt(nrm2);
+        // v = x - alpha e_k ; |v|^2 = 2 (nrm2 - alpha x0)
+        const double vn2 = 2.0 * (nrm2 - alpha * x0);
+        __syncthreads();
+        if (lane < 9) L.V[k][lane] = (lane < k) ? 0.0 : ((lane == k) ? (x0 - alpha) : L.Q[k][lane]);
+        if (lane == 0) L.vn2[k] = vn2;
+        __syncthreads();
+        // apply H_k to the remaining columns c > k
+        double upd = 0;
+        bool doit = false;
+        if (lane < 45) {
+            const int c = lane / 9, r = lane - c * 9;
+            doit = (c > k && r >= k && vn2 > 0);
+            if (doit) {
+                double dot = 0;
+                for (int rr = k; rr < 9; ++rr) dot += L.V[k][rr] * L.Q[c][rr];
+                upd = L.Q[c][r] - 2.0 * L.V[k][r] * dot / vn2;
+            }
+        }
+        __syncthreads();
+        if (doit) L.Q[lane / 9][lane % 9] = upd;
+        __syncthreads();
+    }
+    // ---- 1c. null space: n_j = H_0 H_1 ... H_4 e_{5+j} ----
+    if (lane < 36) {
+        const int j = lane / 9, r = lane - j * 9;
+        L.EE[j][r] = (r == 5 + j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int k = 4; k >= 0; --k) {
+        double upd = 0;
+        const int j = lane / 9, r = lane - j * 9;
+        const double vn2 = L.vn2[k];
+        if (lane < 36) {
+            double dot = 0;
+            for (int rr = k; rr < 9; ++rr) dot += L.V[k][rr] * L.EE[j][rr];
+            upd = (vn2 > 0) ? (L.EE[j][r] - 2.0 * L.V[k][r] * dot / vn2) : L.EE[j][r];
+        }
+        __syncthreads();
+        if (lane < 36) L.EE[j][r] = upd;
+        __syncthreads();
+    }
+
+    double E[9];
+    const bool valid = solve_from_basis(L, lane, E);
+    emit_models(valid, E, lane, sample, E_tab, n_models, dense_E, dense_id, dense_total);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sampson scoring: one thread per model.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void pack_points_kernel(const double *__restrict__ p1, const double *__restrict__ p2, int n, double4 *__restrict__ pts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pts[i] = make_double4(p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+}
+
+__device__ __forceinline__ float sampson_err_f32(const double *e, double x1, double y1, double x2, double y2) {
+    // computeReprojError3 (five-point.cpp:490-502): k-ordered 3-term sums, no contraction, double -> float
+    const double Ex1_0 = __dadd_rn(__dadd_rn(__dmul_rn(e[0], x1), __dmul_rn(e[1], y1)), e[2]);
+    const double Ex1_1 = __dadd_rn(__dadd_rn(__dmul_rn(e[3], x1), __dmul_rn(e[4], y1)), e[5]);
+    const double Ex1_2 = __dadd_rn(__dadd_rn(__dmul_rn(e[6], x1), __dmul_rn(e[7], y1)), e[8]);
+    const double x2tEx1 = __dadd_rn(__dadd_rn(__dmul_rn(x2, Ex1_0), __dmul_rn(y2, Ex1_1)), Ex1_2);
+    const double Etx2_0 = __dadd_rn(__dadd_rn(__dmul_rn(e[0], x2), __dmul_rn(e[3], y2)), e[6]);
+    const double Etx2_1 = __dadd_rn(__dadd_rn(__dmul_rn(e[1], x2), __dmul_rn(e[4], y2)), e[7]);
+    const double a = __dmul_rn(Ex1_0, Ex1_0), b = __dmul_rn(Ex1_1, Ex1_1), c = __dmul_rn(Etx2_0, Etx2_0), d = __dmul_rn(Etx2_1, Etx2_1);
+    const double den = __dadd_rn(__dadd_rn(__dadd_rn(a, b), c), d);
+    return (float)__ddiv_rn(__dmul_rn(x2tEx1, x2tEx1), den);
+}
+
+__global__ __launch_bounds__(64) void score_models_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
+                                                          const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
+                                                          int total_host, double thresh2, int32_t *__restrict__ good,
+                                                          double *__restrict__ esum) {
+    const int total = total_ptr ? *total_ptr : total_host;
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= total) return;
+    double e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = E_list[(size_t)m * 9 + k];
+    int cnt = 0;
+    double s = 0.0;
+    // Points are wave-uniform operands: they arrive through the scalar cache (s_load_dwordx8) into SGPRs.  Batches of 4
+    // are fetched one batch ahead so that the scalar-load latency hides under the ~200 fp64 VALU cycles per point.
+    constexpr int PB = 4;
+    double4 cur[PB], nxt[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) cur[j] = pts[min(j, n - 1)];
+    for (int i = 0; i < n; i += PB) {
+#pragma unroll
+        for (int j = 0; j < PB; ++j) nxt[j] = pts[min(i + PB + j, n - 1)];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const float err = sampson_err_f32(e, cur[j].x, cur[j].y, cur[j].z, cur[j].w);
+            if (i + j < n) {  // wave-uniform
+                cnt += ((double)err <= thresh2) ? 1 : 0;
+                s = __dadd_rn(s, (double)err);  // in index order, like cv::sum over the float errors
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) cur[j] = nxt[j];
+    }
+    const int o = ids ? ids[m] : m;
+    good[o] = cnt;
+    esum[o] = s;
+}
+
+__global__ void inlier_mask_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E, double thresh2,
+                                   uint8_t *__restrict__ mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = E[k];
+    const double4 p = pts[i];
+    const float err = sampson_err_f32(e, p.x, p.y, p.z, p.w);
+    mask[i] = ((double)err <= thresh2) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Refit on all inliers (the reference's `lesqu`, modelest.cpp:420-464): Gram matrix of the masked epipolar rows,
+// its 4 smallest eigenvectors (cyclic Jacobi, one wave), then the same solver tail.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gram_kernel(const double4 *__restrict__ pts, const uint8_t *__restrict__ mask, int n,
+                                                   double *__restrict__ gram_part /* [gridDim.x][45] */) {
+    __shared__ double red[4][45];
+    double acc[45];
+#pragma unroll
+    for (int k = 0; k < 45; ++k) acc[k] = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (!mask[i]) continue;
+        const double4 p = pts[i];
+        const double q[9] = {p.x * p.z, p.y * p.z, p.z, p.x * p.w, p.y * p.w, p.w, p.x, p.y, 1.0};
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < 9; ++a)
+#pragma unroll
+            for (int b = a; b < 9; ++b) acc[t++] += q[a] * q[b];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 45; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 45)
+        gram_part[(size_t)blockIdx.x * 45 + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restrict__ gram_part, int nparts,
+                                                         double *__restrict__ E_tab, int32_t *__restrict__ n_models) {
+    __shared__ SolveLds L;
+    __shared__ double G[9][9], Vv[9][9], gsum[45];
+    const int lane = threadIdx.x;
+    if (lane < 45) {  // fixed summation order over the blocks: run-to-run deterministic
+        double sacc = 0;
+        for (int pblk = 0; pblk < nparts; ++pblk) sacc += gram_part[(size_t)pblk * 45 + lane];
+        gsum[lane] = sacc;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int t = 0;
+        for (int a = 0; a < 9; ++a)
+            for (int b = a; b < 9; ++b) {
+                G[a][b] = gsum[t];
+                G[b][a] = gsum[t];
+                ++t;
+            }
+        for (int a = 0; a < 9; ++a)
+            for (int b = 0; b < 9; ++b) Vv[a][b] = (a == b) ? 1.0 : 0.0;
+        // cyclic Jacobi eigenvalue iteration on the symmetric 9x9 (sequential: once per RANSAC call)
+        for (int sweep = 0; sweep < 60; ++sweep) {
+            double off = 0, diag = 0;
+            for (int a = 0; a < 9; ++a) {
+                diag += G[a][a] * G[a][a];
+                for (int b = a + 1; b < 9; ++b) off += G[a][b] * G[a][b];
+            }
+            if (off <= 1e-32 * diag) break;
+            for (int p = 0; p < 8; ++p)
+                for (int q = p + 1; q < 9; ++q) {
+                    const double apq = G[p][q];
+                    if (apq == 0.0) continue;
+                    const double theta = (G[q][q] - G[p][p]) / (2.0 * apq);
+                    const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+                    for (int k = 0; k < 9; ++k) {
+                        const double gkp = G[k][p], gkq = G[k][q];
+                        G[k][p] = c * gkp - s * gkq;
+                        G[k][q] = s * gkp + c * gkq;
+                    }
+                    for (int k = 0; k < 9; ++k) {
+                        const double gpk = G[p][k], gqk = G[q][k];
+                        G[p][k] = c * gpk - s * gqk;
+                        G[q][k] = s * gpk + c * gqk;
+                    }
+                    for (int k = 0; k < 9; ++k) {
+                        const double vkp = Vv[k][p], vkq = Vv[k][q];
+                        Vv[k][p] = c * vkp - s * vkq;
+                        Vv[k][q] = s * vkp + c * vkq;
+                    }
+                }
+        }
+        // order eigenvalues descending; EE = eigenvectors of the 4 smallest, in descending order (five-point.cpp:388)
+        int order[9];
+        for (int a = 0; a < 9; ++a) order[a] = a;
+        for (int a = 0; a < 8; ++a) {
+            int best = a;
+            for (int b = a + 1; b < 9; ++b)
+                if (G[order[b]][order[b]] > G[order[best]][order[best]]) best = b;
+            const int t2 = order[a];
+            order[a] = order[best];
+            order[best] = t2;
+        }
+        for (int j = 0; j < 4; ++j)
+            for (int r = 0; r < 9; ++r) L.EE[j][r] = Vv[r][order[5 + j]];
+    }
+    __syncthreads();
+    double E[9];
+    const bool valid = solve_from_basis(L, lane, E);
+    emit_models(valid, E, lane, 0, E_tab, n_models, nullptr, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+
+// glibc srand()/rand() (TYPE_3 additive feedback), so that a seed reproduces the reference's sample stream
+struct GlibcRand {
+    int32_t r[34];
+    int f, b;
+    void seed(unsigned s) {
+        if (s == 0) s = 1;
+        r[0] = (int32_t)s;
+        for (int i = 1; i < 31; ++i) {
+            const long hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+            long w = 16807 * lo - 2836 * hi;
+            if (w < 0) w += 2147483647;
+            r[i] = (int32_t)w;
+        }
+        f = 3;
+        b = 0;
+        for (int i = 0; i < 310; ++i) (void)next();
+    }
+    int next() {
+        uint32_t *u = reinterpret_cast<uint32_t *>(r);
+        u[f] += u[b];
+        const uint32_t res = u[f] >> 1;
+        if (++f >= 31) f = 0;
+        if (++b >= 31) b = 0;
+        return (int)res;
+    }
+};
+
+// getSubset (modelest.cpp:567-610): 5 distinct indices, duplicates redrawn.  checkSubset (:613-650) returns
+// `i >= i1` with i0 == i1, i.e. true for every input, so no geometric rejection ever happens in the reference.
+void draw_sample(GlibcRand &g, int n, int32_t *idx) {
+    for (int i = 0; i < 5;) {
+        const int v = g.next() % n;
+        bool dup = false;
+        for (int j = 0; j < i; ++j) dup = dup || (idx[j] == v);
+        if (dup) continue;
+        idx[i++] = v;
+    }
+}
+
+// cvRANSACUpdateNumIters1 (modelest.cpp:86-109)
+int update_num_iters(double p, double ep, int model_points, int max_iters) {
+    p = std::max(p, 0.);
+    p = std::min(p, 1.);
+    ep = std::max(ep, 0.);
+    ep = std::min(ep, 1.);
+    double num = std::max(1. - p, DBL_MIN);
+    double denom = 1. - std::pow(1. - ep, model_points);
+    if (denom < DBL_MIN) return 0;
+    num = std::log(num);
+    denom = std::log(denom);
+    return denom >= 0 || -num >= (double)max_iters * (-denom) ? max_iters : (int)std::round(num / denom);
+}
+
+}  // namespace
+
+// Launchers used by the C ABI ------------------------------------------------------------------------------------
+
+static int pack_points(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double4 **d_pts, hipStream_t s) {
+    void *buf = nullptr;
+    int rc = ws_get(ctx, WS_AUX3, (size_t)n * sizeof(double4), &buf);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_p1, d_p2, n, (double4 *)buf);
+    *d_pts = (double4 *)buf;
+    return MLPL_OK;
+}
+
+struct RansacBuffers {
+    int32_t *samples;   // [chunk][5]
+    double *E_tab;      // [chunk][10][9]
+    int32_t *n_models;  // [chunk]
+    double *dense_E;    // [chunk*10][9]
+    int32_t *dense_id;  // [chunk*10]
+    int32_t *good;      // [chunk*10]
+    double *esum;       // [chunk*10]
+    int32_t *total;     // [1]
+};
+
+static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
+    void *p;
+    int rc;
+    if ((rc = ws_get(ctx, WS_AUX4, (size_t)chunk * 5 * 4, &p))) return rc;
+    B.samples = (int32_t *)p;
+    if ((rc = ws_get(ctx, WS_AUX5, (size_t)chunk * 90 * 8, &p))) return rc;
+    B.E_tab = (double *)p;
+    if ((rc = ws_get(ctx, WS_AUX6, (size_t)chunk * 90 * 8, &p))) return rc;
+    B.dense_E = (double *)p;
+    // one slot for the small integer/double tables: [n_models | dense_id | good | total] + esum
+    const size_t ints = (size_t)chunk * (1 + 10 + 10) + 16;
+    if ((rc = ws_get(ctx, WS_AUX7, ints * 4 + (size_t)chunk * 10 * 8 + 64, &p))) return rc;
+    B.esum = (double *)p;
+    B.n_models = (int32_t *)(B.esum + (size_t)chunk * 10);
+    B.dense_id = B.n_models + chunk;
+    B.good = B.dense_id + (size_t)chunk * 10;
+    B.total = B.good + (size_t)chunk * 10;
+    return MLPL_OK;
+}
+
+}  // namespace mlpl
+
+using namespace mlpl;
+
+extern "C" {
+
+int mlpl_solve_5pt(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const int32_t *samples, int n_samples,
+                   double *E_out, int32_t *n_models) {
+    if (!ctx || !p1 || !p2 || !samples || !E_out || !n_models || n < 5 || n_samples < 0) {
+        set_error("mlpl_solve_5pt: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    for (long long i = 0; i < (long long)n_samples * 5; ++i)
+        if (samples[i] < 0 || samples[i] >= n) {
+            set_error("mlpl_solve_5pt: sample index out of range");
+            return MLPL_E_BAD_INPUT;
+        }
+    if (n_samples == 0) return MLPL_OK;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    void *dp1, *dp2;
+    int rc;
+    if ((rc = ws_get(ctx, WS_AUX0, (size_t)n * 16, &dp1))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX1, (size_t)n * 16, &dp2))) return rc;
+    RansacBuffers B;
+    if ((rc = alloc_ransac(ctx, n_samples, B))) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(dp1, p1, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(dp2, p2, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(B.samples, samples, (size_t)n_samples * 20, hipMemcpyHostToDevice, s));
+    MLPL_HIP_TRY(hipMemsetAsync(B.E_tab, 0, (size_t)n_samples * 720, s));
+    prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
+    hipLaunchKernelGGL(solve5pt_kernel, dim3(n_samples), dim3(64), 0, s, (const double *)dp1, (const double *)dp2, B.samples,
+                       n_samples, B.E_tab, B.n_models, (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+    prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
+    MLPL_HIP_TRY(hipGetLastError());
+    MLPL_HIP_TRY(hipMemcpyAsync(E_out, B.E_tab, (size_t)n_samples * 720, hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(n_models, B.n_models, (size_t)n_samples * 4, hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipStreamSynchronize(s));
+    return MLPL_OK;
+}
+
+int mlpl_score_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const double *E, int n_models, double thresh,
+                      int32_t *count, double *err_sum) {
+    if (!ctx || !p1 || !p2 || !E || !count || !err_sum || n < 1 || n_models < 0) {
+        set_error("mlpl_score_models: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    if (n_models == 0) return MLPL_OK;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    void *dp1, *dp2, *dE, *dgood, *dsum;
+    int rc;
+    if ((rc = ws_get(ctx, WS_AUX0, (size_t)n * 16, &dp1))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX1, (size_t)n * 16, &dp2))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX5, (size_t)n_models * 72, &dE))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX6, (size_t)n_models * 8, &dsum))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX7, (size_t)n_models * 4, &dgood))) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(dp1, p1, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(dp2, p2, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(dE, E, (size_t)n_models * 72, hipMemcpyHostToDevice, s));
+    double4 *pts;
+    if ((rc = pack_points(ctx, (const double *)dp1, (const double *)dp2, n, &pts, s))) return rc;
+    prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
+    hipLaunchKernelGGL(score_models_kernel, dim3((n_models + 63) / 64), dim3(64), 0, s, (const double4 *)pts, n,
+                       (const double *)dE, (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, thresh * thresh,
+                       (int32_t *)dgood, (double *)dsum);
+    prof_mark(ctx, MLPL_PROF_SCORE, 1, s);
+    MLPL_HIP_TRY(hipGetLastError());
+    MLPL_HIP_TRY(hipMemcpyAsync(count, dgood, (size_t)n_models * 4, hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(err_sum, dsum, (size_t)n_models * 8, hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipStreamSynchronize(s));
+    return MLPL_OK;
+}
+
+int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thresh, double confidence,
+                              int max_iters, int refit, uint32_t seed, double E[9], uint8_t *d_mask, int *n_inliers,
+                              int *iters_used, void *stream) {
+    if (!ctx || !d_p1 || !d_p2 || !E || !d_mask || n < 6 || max_iters < 1 || !(thresh > 0)) {
+        set_error("mlpl_ransac_essential: bad arguments (n=%d max_iters=%d); n must exceed the 5 model points", n, max_iters);
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = pick_stream(ctx, stream);
+    if (n_inliers) *n_inliers = 0;
+    if (iters_used) *iters_used = 0;
+    const double thresh2 = thresh * thresh;  // modelest.cpp:79
+
+    double4 *pts;
+    int rc = pack_points(ctx, d_p1, d_p2, n, &pts, s);
+    if (rc) return rc;
+
+    const int kChunk = 32768;
+    const int chunk_cap = std::min(max_iters, kChunk);
+    RansacBuffers B;
+    if ((rc = alloc_ransac(ctx, chunk_cap, B))) return rc;
+
+    // host tables for the replay
+    std::vector<int32_t> h_samples((size_t)chunk_cap * 5), h_nm(chunk_cap), h_good((size_t)chunk_cap * 10);
+    std::vector<double> h_esum((size_t)chunk_cap * 10);
+
+    GlibcRand rng;
+    rng.seed(seed);
+
+    // replay state (modelest.cpp:352-416)
+    int niters = max_iters, maxGood = 0;
+    double errminsum = DBL_MAX;
+    long long best_global = -1;  // iter*10 + slot of the model currently held
+    double bestE[9] = {0};
+    int iter = 0;
+    bool stop = false;
+
+    for (int base = 0; base < max_iters && !stop; base += chunk_cap) {
+        const int cnt = std::min(chunk_cap, std::min(max_iters, niters) - base);
+        if (cnt <= 0) break;
+        for (int i = 0; i < cnt; ++i) draw_sample(rng, n, &h_samples[(size_t)i * 5]);
+        MLPL_HIP_TRY(hipMemcpyAsync(B.samples, h_samples.data(), (size_t)cnt * 20, hipMemcpyHostToDevice, s));
+        MLPL_HIP_TRY(hipMemsetAsync(B.total, 0, 4, s));
+        prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
+        hipLaunchKernelGGL(solve5pt_kernel, dim3(cnt), dim3(64), 0, s, d_p1, d_p2, B.samples, cnt, B.E_tab, B.n_models,
+                           B.dense_E, B.dense_id, B.total);
+        prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
+        prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
+        hipLaunchKernelGGL(score_models_kernel, dim3((cnt * 10 + 63) / 64), dim3(64), 0, s, (const double4 *)pts, n,
+                           (const double *)B.dense_E, (const int32_t *)B.dense_id, (const int32_t *)B.total, 0, thresh2,
+                           B.good, B.esum);
+        prof_mark(ctx, MLPL_PROF_SCORE, 1, s);
+        MLPL_HIP_TRY(hipGetLastError());
+        MLPL_HIP_TRY(hipMemcpyAsync(h_nm.data(), B.n_models, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipMemcpyAsync(h_good.data(), B.good, (size_t)cnt * 40, hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipMemcpyAsync(h_esum.data(), B.esum, (size_t)cnt * 80, hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipStreamSynchronize(s));
+
+        // sequential replay of runRANSAC's update rule over this chunk
+        int best_local = -1;
+        for (int i = 0; i < cnt; ++i) {
+            if (iter >= niters) {
+                stop = true;
+                break;
+            }
+            const int nm = h_nm[i];
+            for (int m = 0; m < nm; ++m) {
+                const int good = h_good[(size_t)i * 10 + m];
+                const double es = h_esum[(size_t)i * 10 + m];
+                if (good > std::max(maxGood, 4)) {  // modelest.cpp:400
+                    maxGood = good;
+                    niters = update_num_iters(confidence, (double)(n - good) / n, 5, niters);
+                    errminsum = es;
+                    best_local = i * 10 + m;
+                } else if (good == std::max(maxGood, 5) && errminsum < DBL_MAX && errminsum > es) {  // :408
+                    errminsum = es;
+                    best_local = i * 10 + m;
+                }
+            }
+            ++iter;
+        }
+        if (best_local >= 0) {
+            best_global = (long long)base * 10 + best_local;
+            MLPL_HIP_TRY(hipMemcpy(bestE, B.E_tab + (size_t)best_local * 9, 72, hipMemcpyDeviceToHost));
+        }
+        if (iter >= niters) stop = true;
+    }
+    if (iters_used) *iters_used = iter;
+    (void)best_global;
+    if (maxGood <= 0) {
+        set_error("mlpl_ransac_essential: no model found");
+        return MLPL_E_FAILED;
+    }
+
+    // mask of the best model
+    void *dE;
+    if ((rc = ws_get(ctx, WS_AUX2, (144 + 256 * 45) * sizeof(double), &dE))) return rc;
+    double *dEd = (double *)dE;
+    MLPL_HIP_TRY(hipMemcpyAsync(dEd, bestE, 72, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(inlier_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double4 *)pts, n, (const double *)dEd,
+                       thresh2, d_mask);
+
+    if (refit) {
+        // modelest.cpp:420-464: solve on all inliers, keep a refit model if it has more inliers (or equal and smaller sum)
+        double *d_Etab = dEd + 16;            // 90 doubles
+        int32_t *d_nm = (int32_t *)(dEd + 112);
+        int32_t *d_good = d_nm + 4;           // 10 ints
+        double *d_es = dEd + 128;             // 10 doubles
+        double *d_gram = dEd + 144;           // [gblocks][45]
+        const int gblocks = std::max(1, std::min(256, (n + 255) / 256));
+        hipLaunchKernelGGL(gram_kernel, dim3(gblocks), dim3(256), 0, s, (const double4 *)pts, (const uint8_t *)d_mask, n, d_gram);
+        hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, s, (const double *)d_gram, gblocks, d_Etab, d_nm);
+        int32_t nm = 0;
+        MLPL_HIP_TRY(hipMemcpyAsync(&nm, d_nm, 4, hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipStreamSynchronize(s));
+        if (nm <= 0) {
+            // the reference returns `result` (still false) here: modelest.cpp:442-443
+            set_error("mlpl_ransac_essential: refit produced no model (reference returns false here)");
+            return MLPL_E_FAILED;
+        }
+        hipLaunchKernelGGL(score_models_kernel, dim3(1), dim3(64), 0, s, (const double4 *)pts, n, (const double *)d_Etab,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr, nm, thresh2, d_good, d_es);
+        int32_t hg[10];
+        double hs[10], hE[90];
+        MLPL_HIP_TRY(hipMemcpyAsync(hg, d_good, nm * 4, hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipMemcpyAsync(hs, d_es, nm * 8, hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipMemcpyAsync(hE, d_Etab, nm * 72, hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipStreamSynchronize(s));
+        int taken = -1;
+        for (int m = 0; m < nm; ++m) {
+            if (hg[m] > std::max(maxGood, 4)) {
+                maxGood = hg[m];
+                errminsum = hs[m];
+                taken = m;
+            } else if (hg[m] == maxGood && errminsum < DBL_MAX && errminsum > hs[m]) {
+                errminsum = hs[m];
+                taken = m;
+            }
+        }
+        if (taken >= 0) {
+            std::memcpy(bestE, hE + taken * 9, 72);
+            MLPL_HIP_TRY(hipMemcpyAsync(dEd, bestE, 72, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(inlier_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double4 *)pts, n,
+                               (const double *)dEd, thresh2, d_mask);
+        }
+    }
+    MLPL_HIP_TRY(hipGetLastError());
+    MLPL_HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(E, bestE, 72);
+    if (n_inliers) *n_inliers = maxGood;
+    return MLPL_OK;
+}
+
+int mlpl_ransac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n, double thresh, double confidence,
+                          int max_iters, int refit, uint32_t seed, double E[9], uint8_t *mask, int *n_inliers,
+                          int *iters_used) {
+    if (!ctx || !p1 || !p2 || !E || !mask || n < 6) {
+        set_error("mlpl_ransac_essential: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    void *dp1, *dp2, *dmask;
+    int rc;
+    if ((rc = ws_get(ctx, WS_AUX0, (size_t)n * 16, &dp1))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX1, (size_t)n * 16, &dp2))) return rc;
+    if ((rc = ws_get(ctx, WS_MATCH, (size_t)n, &dmask))) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(dp1, p1, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    MLPL_HIP_TRY(hipMemcpyAsync(dp2, p2, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    rc = mlpl_ransac_essential_dev(ctx, (const double *)dp1, (const double *)dp2, n, thresh, confidence, max_iters, refit,
+                                   seed, E, (uint8_t *)dmask, n_inliers, iters_used, ctx->stream);
+    if (rc) return rc;
+    MLPL_HIP_TRY(hipMemcpy(mask, dmask, (size_t)n, hipMemcpyDeviceToHost));
+    return MLPL_OK;
+}
+
+}  // extern "C"

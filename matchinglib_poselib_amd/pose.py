@@ -1,0 +1,120 @@
+"""Host-side mirror of poselib's robust relative-pose entry points (RANSAC path).
+
+Reference interface: poselib/include/poselib/pose_estim.h:192-210 (getPoseTriangPts, estimateEssentialMat),
+implementation poselib/source/pose_estim.cpp:857-946 over poselib/source/five-point-nister/*.  Same argument meaning
+and failure behaviour; the arithmetic runs in libmlpl_hip.so (HIP, gfx950).  Nothing here computes on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import Context, MlplError, check, default_context
+
+PIX_MIN_GOOD_TH = 0.8  # pose_estim.h:56
+
+
+def _pts(p) -> np.ndarray:
+    a = np.ascontiguousarray(p, dtype=np.float64)
+    if a.ndim != 2 or a.shape[1] != 2:
+        raise ValueError("points must be an n x 2 array")
+    return a
+
+
+def solve_5pt(p1, p2, samples, ctx: Optional[Context] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Nister 5-point solver on `samples` (n_samples x 5 indices into p1/p2) -> (E [n_samples,10,3,3], n_models).
+    Replaces CvEMEstimator::run5Point (five-point.cpp:366-471)."""
+    ctx = ctx or default_context()
+    p1, p2 = _pts(p1), _pts(p2)
+    samples = np.ascontiguousarray(samples, np.int32)
+    ns = samples.shape[0]
+    E = np.zeros((ns, 10, 3, 3))
+    nm = np.zeros(ns, np.int32)
+    check(ctx.lib.mlpl_solve_5pt(ctx.handle, p1.ctypes.data, p2.ctypes.data, p1.shape[0], samples.ctypes.data, ns,
+                                 E.ctypes.data, nm.ctypes.data), "mlpl_solve_5pt")
+    return E, nm
+
+
+def score_models(p1, p2, E, thresh: float, ctx: Optional[Context] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Sampson inlier count and float-error sum per model (findInliers + cv::sum(err), modelest.cpp:69-83,407)."""
+    ctx = ctx or default_context()
+    p1, p2 = _pts(p1), _pts(p2)
+    E = np.ascontiguousarray(E, np.float64).reshape(-1, 9)
+    good = np.zeros(E.shape[0], np.int32)
+    esum = np.zeros(E.shape[0], np.float64)
+    check(ctx.lib.mlpl_score_models(ctx.handle, p1.ctypes.data, p2.ctypes.data, p1.shape[0], E.ctypes.data, E.shape[0],
+                                    float(thresh), good.ctypes.data, esum.ctypes.data), "mlpl_score_models")
+    return good, esum
+
+
+def ransac_essential(p1, p2, thresh: float, confidence: float = 0.999, max_iters: int = 1000, refit: bool = True,
+                     seed: int = 0, ctx: Optional[Context] = None) -> dict:
+    """CvModelEstimator3::runRANSAC with the 5-point kernel (modelest.cpp:343-474); parameters the reference
+    hard-codes (1000 iterations, p = 0.999, srand(time)) are explicit here."""
+    ctx = ctx or default_context()
+    p1, p2 = _pts(p1), _pts(p2)
+    n = p1.shape[0]
+    E = np.zeros((3, 3))
+    mask = np.zeros(n, np.uint8)
+    ninl, iters = C.c_int(0), C.c_int(0)
+    rc = ctx.lib.mlpl_ransac_essential(ctx.handle, p1.ctypes.data, p2.ctypes.data, n, float(thresh), float(confidence),
+                                       int(max_iters), 1 if refit else 0, int(seed) & 0xFFFFFFFF, E.ctypes.data,
+                                       mask.ctypes.data, C.byref(ninl), C.byref(iters))
+    if rc not in (0, _lib.MLPL_E_FAILED):
+        raise MlplError(rc, "mlpl_ransac_essential", _lib.last_error())
+    return dict(ok=(rc == 0), E=E, mask=mask, n_inliers=ninl.value, iters=iters.value)
+
+
+def estimateEssentialMat(p1, p2, method: str = "ARRSAC", threshold: float = PIX_MIN_GOOD_TH, refine: bool = True,
+                         seed: Optional[int] = None, ctx: Optional[Context] = None):
+    """poselib::estimateEssentialMat (pose_estim.h:204-210, pose_estim.cpp:857-890) -> (ok, E, mask).
+
+    Only method == "RANSAC" is built in this library (the hot path).  Like the reference, "USAC" and unknown method
+    names are fatal (the reference prints and calls exit(1), pose_estim.cpp:878-887): SystemExit(1) is raised.
+    "ARRSAC" (the reference's default) and "LMEDS" are outside the hot path: NotImplementedError.
+    `seed` = None mirrors the reference's std::srand(std::time(nullptr)) (modelest.cpp:58)."""
+    if method == "RANSAC":
+        import time
+
+        s = int(time.time()) if seed is None else seed
+        r = ransac_essential(p1, p2, threshold, confidence=0.999, max_iters=1000, refit=refine, seed=s, ctx=ctx)
+        return r["ok"], r["E"], r["mask"]
+    if method in ("ARRSAC", "LMEDS"):
+        raise NotImplementedError(f"{method} is outside the RANSAC hot path built here")
+    if method == "USAC":
+        print("USAC must be executed by function estimateEssentialOrPoseUSAC as it needs additional paramters! Exiting.")
+    else:
+        print("Either there is a typo in the specified robust estimation method or the method is not supported. Exiting.")
+    raise SystemExit(1)
+
+
+def getPoseTriangPts(E, p1, p2, mask=None, dist: float = 50.0, translatE: bool = False,
+                     ctx: Optional[Context] = None):
+    """poselib::getPoseTriangPts (pose_estim.h:192-200, pose_estim.cpp:913-946) -> (n_good, R, t, Q, mask)."""
+    if translatE:
+        raise NotImplementedError("translational essential matrices (translatE=true) are outside the hot path")
+    ctx = ctx or default_context()
+    p1, p2 = _pts(p1), _pts(p2)
+    E = np.ascontiguousarray(E, np.float64).reshape(3, 3)
+    n = p1.shape[0]
+    R, t, Q = np.zeros((3, 3)), np.zeros((3, 1)), np.zeros((n, 3))
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(-1).copy()
+    rc = ctx.lib.mlpl_recover_pose(ctx.handle, E.ctypes.data, p1.ctypes.data, p2.ctypes.data, n, float(dist),
+                                   R.ctypes.data, t.ctypes.data, Q.ctypes.data, None if m is None else m.ctypes.data)
+    if rc < 0:
+        raise MlplError(rc, "mlpl_recover_pose", _lib.last_error())
+    return rc, R, t, Q, m
+
+
+def estimateRelativePose(p1, p2, threshold: float = PIX_MIN_GOOD_TH, refine: bool = True, dist: float = 50.0,
+                         seed: Optional[int] = None, ctx: Optional[Context] = None):
+    """Convenience named in BASELINE.json: estimateEssentialMat("RANSAC") followed by getPoseTriangPts, as the
+    reference's README and harness do (README.md:497-521, tests/poselib-test/main.cpp:1717,1827)."""
+    ok, E, mask = estimateEssentialMat(p1, p2, "RANSAC", threshold, refine, seed=seed, ctx=ctx)
+    if not ok:
+        return False, E, None, None, None, mask
+    n_good, R, t, Q, mask2 = getPoseTriangPts(E, p1, p2, mask, dist, ctx=ctx)
+    return True, E, R, t, Q, mask2
