@@ -13,10 +13,3 @@ int launch_knn_l2_mfma(mlpl_ctx *, const float *, int, size_t, size_t, const flo
 }
 }  // namespace mlpl
 
-extern "C" {
-int mlpl_recover_pose(mlpl_ctx *, const double *, const double *, const double *, int, double, double *, double *, double *,
-                      uint8_t *) {
-    mlpl::set_error("mlpl_recover_pose: not built yet");
-    return MLPL_E_UNSUPPORTED;
-}
-}

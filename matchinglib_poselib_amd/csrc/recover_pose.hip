@@ -1,0 +1,257 @@
+// recover_pose.hip -- cheirality check / pose recovery on gfx950.
+//
+// Replaces poselib::getPoseTriangPts (reference poselib/source/pose_estim.cpp:913-946) = recoverPose
+// (poselib/source/five-point-nister/five-point.cpp:150-338) with t_only empty:
+//   decomposeEssentialMat (:340-352): SVD(E), det fixes, R1 = U W Vt, R2 = U W^T Vt, t = U[:,2]   -> decompose_kernel
+//   four cv::triangulatePoints calls against P0 = [I|0] (:200-268)                               -> triangulate_kernel
+//   masks  z*w > 0,  (P*Q)z*w > 0,  z/w < dist,  AND with the incoming mask, countNonZero        -> triangulate_kernel
+//   candidate choice by the if-chain (:299-336)                                                   -> host, from 4 counts
+// One thread per (candidate, correspondence): the 4x4 DLT system [x*P(2,:)-P(0,:); y*P(2,:)-P(1,:)] of both views,
+// its smallest right singular vector by a one-sided Jacobi SVD held entirely in registers (the algorithm of OpenCV's
+// JacobiSVDImpl_, which the un-vendored cv::triangulatePoints ends in), then the three predicates.
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "mlpl_internal.h"
+
+namespace mlpl {
+
+namespace {
+
+template <int N>
+__device__ __forceinline__ void jacobi_right_vectors(double (&G)[N][N], double (&V)[N][N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    const double eps = DBL_EPSILON * 2;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < N - 1; ++p)
+#pragma unroll
+            for (int q = p + 1; q < N; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    alpha += G[i][p] * G[i][p];
+                    beta += G[i][q] * G[i][q];
+                    gamma += G[i][p] * G[i][q];
+                }
+                if (fabs(gamma) <= eps * sqrt(alpha * beta) || gamma == 0.0) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const double gp = G[i][p], gq = G[i][q];
+                    G[i][p] = c * gp - s * gq;
+                    G[i][q] = s * gp + c * gq;
+                    const double vp = V[i][p], vq = V[i][q];
+                    V[i][p] = c * vp - s * vq;
+                    V[i][q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+}
+
+__device__ __forceinline__ double det3(const double *M) {
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+__device__ __forceinline__ void mat3_mul(const double *A, const double *B, double *C) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C[r * 3 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c];
+}
+
+// out: P[4][12] candidate projection matrices, Rt[2][9] = R1,R2 and t[3] appended (42 + 18 + 3 doubles)
+__global__ void decompose_kernel(const double *__restrict__ E, double *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double G[3][3], V[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) G[i][j] = E[i * 3 + j];
+    jacobi_right_vectors<3>(G, V);
+    double w[3];
+    for (int j = 0; j < 3; ++j) w[j] = sqrt(G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j]);
+    // descending order (selection sort on indices, first maximum wins on ties)
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; ++a) {
+        int best = a;
+        for (int b = a + 1; b < 3; ++b)
+            if (w[ord[b]] > w[ord[best]]) best = b;
+        const int t = ord[a];
+        ord[a] = ord[best];
+        ord[best] = t;
+    }
+    double U[9], Vt[9], ws[3];
+    for (int j = 0; j < 3; ++j) {
+        ws[j] = w[ord[j]];
+        for (int i = 0; i < 3; ++i) {
+            U[i * 3 + j] = (ws[j] > 0) ? G[i][ord[j]] / ws[j] : 0.0;
+            Vt[j * 3 + i] = V[i][ord[j]];
+        }
+    }
+    if (!(ws[2] > 1e-12 * ws[0])) {  // rank-2 E: complete U with u1 x u2
+        U[0 * 3 + 2] = U[1 * 3 + 0] * U[2 * 3 + 1] - U[2 * 3 + 0] * U[1 * 3 + 1];
+        U[1 * 3 + 2] = U[2 * 3 + 0] * U[0 * 3 + 1] - U[0 * 3 + 0] * U[2 * 3 + 1];
+        U[2 * 3 + 2] = U[0 * 3 + 0] * U[1 * 3 + 1] - U[1 * 3 + 0] * U[0 * 3 + 1];
+    }
+    if (det3(U) < 0)
+        for (int i = 0; i < 9; ++i) U[i] = -U[i];
+    if (det3(Vt) < 0)
+        for (int i = 0; i < 9; ++i) Vt[i] = -Vt[i];
+    const double W[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
+    const double Wt[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};
+    double T[9], R1[9], R2[9];
+    mat3_mul(U, W, T);
+    mat3_mul(T, Vt, R1);
+    mat3_mul(U, Wt, T);
+    mat3_mul(T, Vt, R2);
+    const double tv[3] = {U[2], U[5], U[8]};
+    // P1=[R1|t] P2=[R2|t] P3=[R1|-t] P4=[R2|-t]   (five-point.cpp:185-193)
+    for (int c = 0; c < 4; ++c) {
+        const double *R = (c & 1) ? R2 : R1;
+        const double sg = (c < 2) ? 1.0 : -1.0;
+        for (int r = 0; r < 3; ++r) {
+            for (int k = 0; k < 3; ++k) out[c * 12 + r * 4 + k] = R[r * 3 + k];
+            out[c * 12 + r * 4 + 3] = sg * tv[r];
+        }
+    }
+    for (int i = 0; i < 9; ++i) {
+        out[48 + i] = R1[i];
+        out[57 + i] = R2[i];
+    }
+    for (int i = 0; i < 3; ++i) out[66 + i] = tv[i];
+}
+
+__global__ __launch_bounds__(256) void triangulate_kernel(const double *__restrict__ P /*[4][12]*/, const double *__restrict__ p1,
+                                                          const double *__restrict__ p2, int n, double dist,
+                                                          const uint8_t *__restrict__ mask_in, double *__restrict__ Q /*[4][n][3]*/,
+                                                          uint8_t *__restrict__ mask_out /*[4][n]*/, int32_t *__restrict__ counts) {
+    __shared__ int wave_cnt[4];
+    const int c = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool good = false;
+    if (i < n) {
+        const double *Pc = P + c * 12;
+        const double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
+        double G[4][4], V[4][4];
+        // view 1: P0 = [I|0]
+        const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            G[0][k] = x1 * P0[8 + k] - P0[k];
+            G[1][k] = y1 * P0[8 + k] - P0[4 + k];
+            G[2][k] = x2 * Pc[8 + k] - Pc[k];
+            G[3][k] = y2 * Pc[8 + k] - Pc[4 + k];
+        }
+        jacobi_right_vectors<4>(G, V);
+        double w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j] + G[3][j] * G[3][j];
+        int m = 0;
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+            if (w[j] < w[m]) m = j;
+        double X[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X[k] = (m == 0) ? V[k][0] : (m == 1 ? V[k][1] : (m == 2 ? V[k][2] : V[k][3]));
+        bool mk = (X[2] * X[3] > 0);
+        const double qz = Pc[8] * X[0] + Pc[9] * X[1] + Pc[10] * X[2] + Pc[11] * X[3];
+        mk = mk && (qz * X[3] > 0);
+        const double qx = X[0] / X[3], qy = X[1] / X[3], qzz = X[2] / X[3];
+        mk = mk && (qzz < dist);
+        double *q = Q + ((size_t)c * n + i) * 3;
+        q[0] = qx, q[1] = qy, q[2] = qzz;
+        uint8_t mv = mk ? 255 : 0;
+        if (mask_in) mv &= mask_in[i];
+        mask_out[(size_t)c * n + i] = mv;
+        good = (mv != 0);
+    }
+    const unsigned long long bal = __ballot(good);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&counts[c], wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
+}
+
+}  // namespace
+}  // namespace mlpl
+
+using namespace mlpl;
+
+extern "C" int mlpl_recover_pose(mlpl_ctx *ctx, const double E[9], const double *p1, const double *p2, int n, double dist,
+                                 double R[9], double t[3], double *Q, uint8_t *mask_inout) {
+    if (!ctx || !E || !p1 || !p2 || !R || !t || !Q || n < 0) {
+        set_error("mlpl_recover_pose: R, t and Q are mandatory outputs");  // pose_estim.cpp:925-926 returns -1
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    void *dp1, *dp2, *dQ, *dmask, *dsmall;
+    int rc;
+    const size_t nn = (size_t)std::max(n, 1);
+    if ((rc = ws_get(ctx, WS_AUX0, nn * 16, &dp1))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX1, nn * 16, &dp2))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX5, nn * 4 * 3 * 8, &dQ))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX6, nn * 5, &dmask))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX2, 4096, &dsmall))) return rc;
+    double *dE = (double *)dsmall;         // 9
+    double *dP = dE + 16;                  // 69
+    int32_t *dcnt = (int32_t *)(dE + 96);  // 4
+    uint8_t *dmask_in = (uint8_t *)dmask + nn * 4;
+    MLPL_HIP_TRY(hipMemcpyAsync(dE, E, 72, hipMemcpyHostToDevice, s));
+    MLPL_HIP_TRY(hipMemsetAsync(dcnt, 0, 16, s));
+    if (n > 0) {
+        MLPL_HIP_TRY(hipMemcpyAsync(dp1, p1, (size_t)n * 16, hipMemcpyHostToDevice, s));
+        MLPL_HIP_TRY(hipMemcpyAsync(dp2, p2, (size_t)n * 16, hipMemcpyHostToDevice, s));
+        if (mask_inout) MLPL_HIP_TRY(hipMemcpyAsync(dmask_in, mask_inout, (size_t)n, hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(decompose_kernel, dim3(1), dim3(64), 0, s, (const double *)dE, dP);
+    if (n > 0) {
+        prof_mark(ctx, MLPL_PROF_RECOVER_POSE, 0, s);
+        hipLaunchKernelGGL(triangulate_kernel, dim3((n + 255) / 256, 4), dim3(256), 0, s, (const double *)dP, (const double *)dp1,
+                           (const double *)dp2, n, dist, mask_inout ? (const uint8_t *)dmask_in : (const uint8_t *)nullptr,
+                           (double *)dQ, (uint8_t *)dmask, dcnt);
+        prof_mark(ctx, MLPL_PROF_RECOVER_POSE, 1, s);
+    }
+    MLPL_HIP_TRY(hipGetLastError());
+    int32_t cnt[4];
+    double hP[69];
+    MLPL_HIP_TRY(hipMemcpyAsync(cnt, dcnt, 16, hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(hP, dP, sizeof(hP), hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipStreamSynchronize(s));
+    const int good1 = cnt[0], good2 = cnt[1], good3 = cnt[2], good4 = cnt[3];
+    // five-point.cpp:299-336
+    int pick, ret;
+    if (good1 >= good2 && good1 >= good3 && good1 >= good4) {
+        pick = 0, ret = good1;
+    } else if (good2 && good2 >= good1 && good2 >= good3 && good2 >= good4) {
+        pick = 1, ret = good2;
+    } else if (good3 >= good1 && good3 >= good2 && good3 >= good4) {
+        pick = 2, ret = good3;
+    } else {
+        ret = good4;
+        pick = good4 ? 3 : -1;
+    }
+    if (pick >= 0) {
+        std::memcpy(R, hP + ((pick & 1) ? 57 : 48), 72);
+        const double sg = (pick < 2) ? 1.0 : -1.0;
+        for (int i = 0; i < 3; ++i) t[i] = sg * hP[66 + i];
+        if (n > 0) {
+            MLPL_HIP_TRY(hipMemcpy(Q, (double *)dQ + (size_t)pick * n * 3, (size_t)n * 24, hipMemcpyDeviceToHost));
+            if (mask_inout) MLPL_HIP_TRY(hipMemcpy(mask_inout, (uint8_t *)dmask + (size_t)pick * n, (size_t)n, hipMemcpyDeviceToHost));
+        }
+    } else {
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        std::memcpy(R, I, 72);
+        t[0] = t[1] = t[2] = 0;
+        std::memset(Q, 0, (size_t)n * 24);
+        if (mask_inout) std::memset(mask_inout, 0, (size_t)n);
+    }
+    return ret;
+}

@@ -118,3 +118,19 @@ def estimateRelativePose(p1, p2, threshold: float = PIX_MIN_GOOD_TH, refine: boo
         return False, E, None, None, None, mask
     n_good, R, t, Q, mask2 = getPoseTriangPts(E, p1, p2, mask, dist, ctx=ctx)
     return True, E, R, t, Q, mask2
+
+
+def smoke_check(ctx, oracle) -> None:
+    """Used by __graft_entry__.smoke(): one small RANSAC + pose recovery on the GPU, checked against the CPU oracle."""
+    from . import synth
+
+    p1, p2, R, t, mask, th = synth.pose_scene(600, seed=3)
+    g = ransac_essential(p1, p2, th, confidence=0.999, max_iters=300, refit=False, seed=99, ctx=ctx)
+    o = oracle.ransac_essential(p1, p2, th, confidence=0.999, max_iters=300, lesqu=False, seed=99)
+    assert g["ok"] and g["iters"] == o["iters"] and g["n_inliers"] == o["n_inliers"], "RANSAC differs from the oracle"
+    d = min(np.abs(g["E"] - o["E"]).max(), np.abs(g["E"] + o["E"]).max())
+    assert d < 1e-8, f"essential matrix differs from the oracle by {d}"
+    n_good, Rg, tg, Q, m = getPoseTriangPts(g["E"], p1, p2, g["mask"], 50.0, ctx=ctx)
+    go, Ro, to, Qo, mo = oracle.recover_pose(o["E"], p1, p2, 50.0, o["mask"])
+    assert n_good == go and np.abs(Rg - Ro).max() < 1e-6 and np.abs(tg.ravel() - to).max() < 1e-6
+    print(f"smoke: RANSAC 5pt {g['iters']} iters -> {g['n_inliers']} inliers, pose within 1e-6 of the oracle")

@@ -102,3 +102,45 @@ def test_ransac_failure_and_bad_input(ctx):
         pose.estimateEssentialMat(p, p, "USAC", ctx=ctx)
     with pytest.raises(SystemExit):
         pose.estimateEssentialMat(p, p, "NOPE", ctx=ctx)
+
+
+def essential_from(R, t):
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    E = tx @ R
+    return E / np.linalg.norm(E)
+
+
+def test_recover_pose_vs_oracle(ctx, oracle):
+    p1, p2, R, t, mask, th = synth.pose_scene(3000, seed=20260103)
+    o = oracle.ransac_essential(p1, p2, th, max_iters=400, seed=5)
+    for E, m_in, dist in [(o["E"], o["mask"], 50.0), (-o["E"], None, 50.0), (2.5 * o["E"], o["mask"], 9.0),
+                          (essential_from(R, t), None, 50.0)]:
+        go, Ro, to, Qo, mo = oracle.recover_pose(E, p1, p2, dist, m_in)
+        gg, Rg, tg, Qg, mg = pose.getPoseTriangPts(E, p1, p2, m_in, dist, ctx=ctx)
+        assert gg == go
+        assert np.abs(Rg - Ro).max() < 1e-12 and np.abs(tg.ravel() - to).max() < 1e-12
+        if m_in is not None:
+            assert np.array_equal(mg, mo)
+        fin = np.isfinite(Qo).all(axis=1) & (np.abs(Qo).max(axis=1) < 1e6)
+        assert np.allclose(Qg[fin], Qo[fin], rtol=1e-9, atol=1e-9)
+    # R,t close to the ground truth on this scene
+    gg, Rg, tg, Qg, mg = pose.getPoseTriangPts(o["E"], p1, p2, o["mask"], 50.0, ctx=ctx)
+    assert np.abs(Rg - R).max() < 2e-2 and np.abs(tg.ravel() - t).max() < 2e-2
+
+
+def test_recover_pose_all_behind(ctx, oracle):
+    """Degenerate input: identical points in both views -> whatever the oracle returns, the GPU returns the same."""
+    rng = np.random.default_rng(3)
+    p = rng.normal(size=(50, 2))
+    E = np.array([[0, -1, 0.2], [1, 0, -0.3], [-0.2, 0.3, 0.0]])
+    go, Ro, to, Qo, mo = oracle.recover_pose(E, p, p + 0.01, 50.0, None)
+    gg, Rg, tg, Qg, mg = pose.getPoseTriangPts(E, p, p + 0.01, None, 50.0, ctx=ctx)
+    assert gg == go and np.abs(Rg - Ro).max() < 1e-12 and np.abs(tg.ravel() - to).max() < 1e-12
+
+
+def test_estimate_relative_pose_end_to_end(ctx):
+    p1, p2, R, t, mask, th = synth.pose_scene(4000, seed=77)
+    ok, E, Rg, tg, Q, m = pose.estimateRelativePose(p1, p2, threshold=th, refine=True, seed=4242, ctx=ctx)
+    assert ok
+    assert np.abs(Rg - R).max() < 5e-3 and np.abs(tg.ravel() - t).max() < 2e-2
+    assert (m != 0).sum() > 1700
