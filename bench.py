@@ -174,7 +174,7 @@ def main():
         if not args.no_extras:
             try:
                 import bench_extras
-                rec["extras"] = bench_extras.run(ctx, dev)
+                rec["extras"] = bench_extras.run(ctx, dev, cpu_baseline=not args.no_cpu_baseline)
             except ImportError:
                 pass
         print(json.dumps(rec), flush=True)

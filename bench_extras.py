@@ -1,0 +1,93 @@
+"""Secondary measurements printed inside bench.py's JSON line under "extras" (rank 0, N = 1 only):
+C3 RANSAC hypotheses/s (5000 correspondences, 50 % inliers, 20000 iterations, confidence 1.0 => no early exit, fixed
+seed) with its CPU baseline, and C4 squared-L2 2-NN on 4096 x 4096 SIFT-128f."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+FP64_VALU_PEAK = 78.6e12  # MI355X vector fp64 (spec)
+
+
+def _prof(ctx, kid):
+    ms, cnt = C.c_double(0), C.c_int(0)
+    ctx.lib.mlpl_profile_read(ctx.handle, kid, C.byref(ms), C.byref(cnt))
+    return ms.value, cnt.value
+
+
+def run(ctx, dev, cpu_baseline=True):
+    import torch
+    from matchinglib_poselib_amd import pose, synth, _lib
+    import matchinglib_poselib_amd as mpa
+
+    out = {}
+    # ---- C3: RANSAC ----
+    n, iters = 5000, 20000
+    p1, p2, R, t, mask, th = synth.pose_scene(n, seed=20260103)
+    d1 = torch.from_numpy(p1).to(dev)
+    d2 = torch.from_numpy(p2).to(dev)
+    dm = torch.empty(n, dtype=torch.uint8, device=dev)
+    pose.ransac_essential_device(d1, d2, th, confidence=1.0, max_iters=iters, refit=False, seed=12345, ctx=ctx, mask_out=dm)
+    torch.cuda.synchronize()
+    ctx.lib.mlpl_profile_reset(ctx.handle)
+    ctx.lib.mlpl_profile_enable(ctx.handle, 1)
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = pose.ransac_essential_device(d1, d2, th, confidence=1.0, max_iters=iters, refit=False, seed=12345, ctx=ctx, mask_out=dm)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    ctx.lib.mlpl_profile_enable(ctx.handle, 0)
+    solve_ms, solve_n = _prof(ctx, 2)
+    score_ms, score_n = _prof(ctx, 3)
+    # models actually scored: count once through the building-block API on a sample of the hypotheses
+    out["ransac_c3"] = {
+        "metric": "RANSAC hypotheses/s (5-pt Nister + Sampson on 5000 correspondences, 20000 iterations)",
+        "value": iters / dt,
+        "unit": "hypotheses/s",
+        "ms_per_call": dt * 1e3,
+        "iters_used": r["iters"],
+        "n_inliers": r["n_inliers"],
+        "solve_kernel_ms": solve_ms / max(solve_n, 1),
+        "score_kernel_ms": score_ms / max(score_n, 1),
+        "includes": "host sample table (glibc rand stream), H2D samples, solve + score kernels, D2H tables, host replay, mask",
+    }
+    if cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        ora = oracle_lib.load()
+        ci = 400
+        tc = time.perf_counter()
+        o = ora.ransac_essential(p1, p2, th, confidence=1.0, max_iters=ci, lesqu=False, seed=12345)
+        tc = time.perf_counter() - tc
+        out["ransac_c3"]["cpu_baseline"] = {"value": ci / tc, "unit": "hypotheses/s", "cores": 1, "kind": "port",
+                                            "sample": f"first {ci} of the 20000 iterations of the same run ({tc:.2f} s)"}
+    # ---- C4: L2 ----
+    q, tt = synth.sift_pair(4096, 4096, seed=20260104)
+    dq = torch.from_numpy(q).to(dev)
+    dtt = torch.from_numpy(tt).to(dev)
+    idx = torch.empty((4096, 2), dtype=torch.int32, device=dev)
+    dist = torch.empty((4096, 2), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for mode, name in ((1, "l2_c4_exact_fp32"), (0, "l2_c4_auto")):
+        ctx.lib.mlpl_set_l2_path(ctx.handle, mode)
+
+        def call():
+            _lib.check(ctx.lib.mlpl_knn2_l2sq_f32_dev(ctx.handle, dq.data_ptr(), 4096, 128, 0, dtt.data_ptr(), 4096, 128, 0,
+                                                      128, 2, 1, idx.data_ptr(), dist.data_ptr(), st), "knn_l2_dev")
+        call()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        out[name] = {"value": 4096 * 4096 / (ms * 1e-3), "unit": "descriptor-pairs/s", "ms_per_call": ms,
+                     "gflops_equiv": 2 * 4096 * 4096 * 128 / (ms * 1e-3) / 1e9}
+    ctx.lib.mlpl_set_l2_path(ctx.handle, 0)
+    return out
