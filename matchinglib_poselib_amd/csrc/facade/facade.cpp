@@ -1,0 +1,250 @@
+// facade.cpp -- C++ drop-in facade (reference signatures) over the C ABI of libmlpl_hip.so.  Host glue only: argument
+// checks, cv::Mat <-> pointer plumbing and the reference's error behaviour (return codes, cv::Exception, exit(1)).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
+#include <iostream>
+
+#include "matchinglib_poselib/matchinglib_matchers.h"
+#include "matchinglib_poselib/pose_estim.h"
+#include "matchinglib_poselib/stereo_pose_refinement.h"
+#include "mlpl_c.h"
+
+namespace {
+
+struct CtxHolder {
+    mlpl_ctx *ctx = nullptr;
+    ~CtxHolder() {
+        if (ctx) mlpl_ctx_destroy(ctx);
+    }
+};
+
+mlpl_ctx *default_ctx() {
+    static thread_local CtxHolder h;
+    if (!h.ctx) {
+        int dev = 0;
+        if (const char *e = std::getenv("MLPL_DEVICE")) dev = std::atoi(e);
+        if (mlpl_ctx_create(dev, &h.ctx) != MLPL_OK) {
+            // no CPU fallback: the drop-in fails loudly when the GPU path is unavailable
+            throw cv::Exception(std::string("mlpl_ctx_create failed: ") + mlpl_last_error());
+        }
+    }
+    return h.ctx;
+}
+
+thread_local bool g_seed_fixed = false;
+thread_local unsigned g_seed = 0;
+
+// contiguous n x 2 CV_64F copy of a point matrix (the reference converts with convertTo(CV_64F))
+std::vector<double> points64(const cv::Mat &p, int &n) {
+    CV_Assert(p.cols == 2 && (p.type() == CV_64F || p.type() == CV_32F));
+    n = p.rows;
+    std::vector<double> out((size_t)n * 2);
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 2; ++c) out[2 * i + c] = p.type() == CV_64F ? p.at<double>(i, c) : (double)p.at<float>(i, c);
+    return out;
+}
+
+}  // namespace
+
+namespace matchinglib {
+
+int getMatches(const std::vector<cv::KeyPoint> &keypoints1, const std::vector<cv::KeyPoint> &keypoints2,
+               cv::Mat const &descriptors1, cv::Mat const &descriptors2, cv::Size /*imgSi*/,
+               std::vector<cv::DMatch> &finalMatches, std::string const &matcher_name, bool VFCrefine, bool ratioTest,
+               std::string const & /*descriptor_name*/, std::string /*idxPars_NMSLIB*/, std::string /*queryPars_NMSLIB*/,
+               const size_t /*nr_threads*/) {
+    CV_Assert(descriptors1.type() == descriptors2.type());  // matchers.cpp:119
+    if (keypoints1.size() < 15 || keypoints2.size() < 15) {
+        std::cout << "Too less keypoits!" << std::endl;
+        return -4;
+    }
+    if ((int)keypoints1.size() != descriptors1.rows || (int)keypoints2.size() != descriptors2.rows) {
+        std::cout << "Number of descriptors must be equal to the number of keypoints!" << std::endl;
+        return -1;
+    }
+    finalMatches.clear();
+    if (matcher_name != "LINEAR") {
+        std::cout << "Matcher " << matcher_name << " is not supported." << std::endl;
+        return -2;
+    }
+    if (descriptors1.type() != CV_32F && descriptors1.type() != CV_8U) {
+        std::cout << "Format of descriptors not supported!" << std::endl;
+        return -1;
+    }
+    if (descriptors1.cols != descriptors2.cols) return -1;
+    if (VFCrefine) {
+        std::cout << "VFC refinement is not part of the MI355X hot path." << std::endl;
+        return -2;
+    }
+    std::vector<mlpl_dmatch> out((size_t)descriptors1.rows);
+    int n_out = 0;
+    // cv::Mat::step is honoured, so non-continuous Mats (ROIs) are handled (the reference silently mis-reads them,
+    // matchers.cpp:567-568 uses .data with rows x cols)
+    const int rc = mlpl_get_matches_linear(default_ctx(), (int)keypoints1.size(), (int)keypoints2.size(), descriptors1.data,
+                                           descriptors1.rows, descriptors1.step, descriptors2.data, descriptors2.rows,
+                                           descriptors2.step, descriptors1.cols, descriptors1.type(), ratioTest ? 1 : 0,
+                                           out.data(), &n_out);
+    if (rc != 0 && rc != -3) {
+        if (rc == -1 || rc == -4) return rc;
+        throw cv::Exception(std::string("mlpl_get_matches_linear: ") + mlpl_last_error());
+    }
+    finalMatches.resize((size_t)n_out);
+    static_assert(sizeof(cv::DMatch) == sizeof(mlpl_dmatch), "DMatch layout");
+    if (n_out) std::memcpy((void *)finalMatches.data(), out.data(), (size_t)n_out * sizeof(mlpl_dmatch));
+    if (rc == -3) std::cout << "Too less remaining matches using the " << matcher_name << " matcher." << std::endl;
+    return rc;
+}
+
+}  // namespace matchinglib
+
+namespace poselib {
+
+void setRansacSeed(unsigned seed) {
+    g_seed_fixed = true;
+    g_seed = seed;
+}
+void clearRansacSeed() { g_seed_fixed = false; }
+
+bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p2, const std::string &method,
+                          double threshold, bool refine, cv::OutputArray mask) {
+    if (method == "RANSAC") {
+        if (!cv::needed(E)) return false;  // five-point.cpp:143-144
+        int n1 = 0, n2 = 0;
+        std::vector<double> a = points64(p1, n1), b = points64(p2, n2);
+        CV_Assert(n1 >= 5 && n1 == n2);  // five-point.cpp:81
+        if (n1 == 5) {
+            std::cout << "estimateEssentialMat: exactly 5 correspondences (minimal case) is served by mlpl_solve_5pt, not by "
+                         "the RANSAC entry."
+                      << std::endl;
+            return false;
+        }
+        double Ev[9];
+        std::vector<uint8_t> m((size_t)n1);
+        int ninl = 0, iters = 0;
+        const unsigned seed = g_seed_fixed ? g_seed : (unsigned)std::time(nullptr);  // modelest.cpp:58
+        const int rc = mlpl_ransac_essential(default_ctx(), a.data(), b.data(), n1, threshold, 0.999, 1000, refine ? 1 : 0, seed,
+                                             Ev, m.data(), &ninl, &iters);
+        if (rc == MLPL_E_FAILED) return false;
+        if (rc != MLPL_OK) throw cv::Exception(std::string("mlpl_ransac_essential: ") + mlpl_last_error());
+        if (cv::needed(mask)) {
+            mask.create(1, n1, CV_8U);
+            std::memcpy(mask.data, m.data(), (size_t)n1);
+        }
+        E.create(3, 3, CV_64F);
+        for (int i = 0; i < 9; ++i) E.at<double>(i / 3, i % 3) = Ev[i];
+        return true;
+    }
+    if (method == "USAC") {
+        std::cout << "USAC must be executed by function estimateEssentialOrPoseUSAC as it needs additional paramters! Exiting."
+                  << std::endl;
+        std::exit(1);  // pose_estim.cpp:878-882
+    }
+    if (method == "ARRSAC" || method == "LMEDS") {
+        std::cout << method << " is not built in the MI355X hot-path library (RANSAC only). Exiting." << std::endl;
+        std::exit(1);
+    }
+    std::cout << "Either there is a typo in the specified robust estimation method or the method is not supported. Exiting."
+              << std::endl;
+    std::exit(1);  // pose_estim.cpp:883-887
+}
+
+int getPoseTriangPts(cv::InputArray E, cv::InputArray p1, cv::InputArray p2, cv::OutputArray R, cv::OutputArray t,
+                     cv::OutputArray Q, cv::InputOutputArray mask, const double dist, bool translatE) {
+    if (!cv::needed(R) || !cv::needed(t) || !cv::needed(Q)) return -1;  // pose_estim.cpp:925-926
+    if (translatE) return -1;
+    CV_Assert(E.rows == 3 && E.cols == 3 && E.type() == CV_64F);
+    int n1 = 0, n2 = 0;
+    std::vector<double> a = points64(p1, n1), b = points64(p2, n2);
+    CV_Assert(n1 == n2);
+    double Ev[9], Rv[9], tv[3];
+    for (int i = 0; i < 9; ++i) Ev[i] = E.at<double>(i / 3, i % 3);
+    std::vector<double> Qv((size_t)std::max(n1, 1) * 3);
+    std::vector<uint8_t> m;
+    const bool use_mask = cv::needed(mask);
+    if (use_mask) {
+        m.assign((size_t)n1, 1);  // an empty mask is created as all ones (five-point.cpp:275-280)
+        if (!mask.empty()) {
+            CV_Assert(mask.rows * mask.cols == n1 && mask.type() == CV_8U);
+            for (int i = 0; i < n1; ++i) m[i] = mask.rows == 1 ? mask.at<uint8_t>(0, i) : mask.at<uint8_t>(i, 0);
+        }
+    }
+    const int rc = mlpl_recover_pose(default_ctx(), Ev, a.data(), b.data(), n1, dist, Rv, tv, Qv.data(), use_mask ? m.data() : nullptr);
+    if (rc < 0) throw cv::Exception(std::string("mlpl_recover_pose: ") + mlpl_last_error());
+    R.create(3, 3, CV_64F);
+    t.create(3, 1, CV_64F);
+    Q.create(n1, 3, CV_64F);
+    for (int i = 0; i < 9; ++i) R.at<double>(i / 3, i % 3) = Rv[i];
+    for (int i = 0; i < 3; ++i) t.at<double>(i, 0) = tv[i];
+    for (int i = 0; i < n1; ++i)
+        for (int c = 0; c < 3; ++c) Q.at<double>(i, c) = Qv[(size_t)i * 3 + c];
+    if (use_mask) {
+        mask.create(1, n1, CV_8U);
+        std::memcpy(mask.data, m.data(), (size_t)n1);
+    }
+    return rc;
+}
+
+bool estimateRelativePose(cv::InputArray p1, cv::InputArray p2, cv::OutputArray E, cv::OutputArray R, cv::OutputArray t,
+                          cv::OutputArray Q, cv::OutputArray mask, double threshold, bool refine, double dist) {
+    if (!estimateEssentialMat(E, p1, p2, "RANSAC", threshold, refine, mask)) return false;
+    return getPoseTriangPts(E, p1, p2, R, t, Q, mask, dist, false) >= 0;
+}
+
+// ---- StereoRefine (hot-path slice) -------------------------------------------------------------------------
+
+StereoRefine::StereoRefine(ConfigPoseEstimation cfg_pose_, bool verbose_) : cfg_pose(cfg_pose_), verbose(verbose_) { init(); }
+
+void StereoRefine::setNewParameters(ConfigPoseEstimation cfg_pose_) {
+    cfg_pose = cfg_pose_;
+    init();
+}
+
+void StereoRefine::init() {
+    CV_Assert(cfg_pose.K0 != nullptr && cfg_pose.K1 != nullptr);
+    for (cv::Mat *d : {cfg_pose.dist0_8, cfg_pose.dist1_8})
+        if (d && !d->empty())
+            for (int r = 0; r < d->rows; ++r)
+                for (int c = 0; c < d->cols; ++c) CV_Assert(d->at<double>(r, c) == 0.0);  // undistortion is not built here
+    // stereo_pose_refinement.h:280-286
+    pixToCamFact = 4.0 / (std::sqrt(2.0) * (cfg_pose.K0->at<double>(0, 0) + cfg_pose.K0->at<double>(1, 1) +
+                                            cfg_pose.K1->at<double>(0, 0) + cfg_pose.K1->at<double>(1, 1)));
+    th = cfg_pose.th_pix_user * pixToCamFact;
+}
+
+int StereoRefine::addNewCorrespondences(std::vector<cv::DMatch> matches, std::vector<cv::KeyPoint> kp1,
+                                        std::vector<cv::KeyPoint> kp2, const poselib::ConfigUSAC &) {
+    if (cfg_pose.RobMethod != "RANSAC") {
+        std::cout << "StereoRefine (MI355X slice): only RobMethod == \"RANSAC\" is built." << std::endl;
+        return -1;
+    }
+    const int n = (int)matches.size();
+    nr_corrs_new = (size_t)n;
+    if (n < 16) return -1;
+    // stereo_pose_refinement.cpp:428-455: gather, ImgToCamCoordTrans (float result of a double op), to CV_64F n x 2
+    cv::Mat p1(n, 2, CV_64F), p2(n, 2, CV_64F);
+    const cv::Mat &K0 = *cfg_pose.K0, &K1 = *cfg_pose.K1;
+    for (int i = 0; i < n; ++i) {
+        const cv::Point2f a = kp1[(size_t)matches[i].queryIdx].pt, b = kp2[(size_t)matches[i].trainIdx].pt;
+        p1.at<double>(i, 0) = (double)(float)(((double)a.x - K0.at<double>(0, 2)) / K0.at<double>(0, 0));
+        p1.at<double>(i, 1) = (double)(float)(((double)a.y - K0.at<double>(1, 2)) / K0.at<double>(1, 1));
+        p2.at<double>(i, 0) = (double)(float)(((double)b.x - K1.at<double>(0, 2)) / K1.at<double>(0, 0));
+        p2.at<double>(i, 1) = (double)(float)(((double)b.y - K1.at<double>(1, 2)) / K1.at<double>(1, 1));
+    }
+    cv::Mat E, mask;
+    if (!estimateEssentialMat(E, p1, p2, cfg_pose.RobMethod, th, cfg_pose.refineRTold, mask)) return -2;
+    mask_E_new = mask.clone();
+    size_t ninl = 0;
+    for (int i = 0; i < n; ++i) ninl += mask.at<uint8_t>(0, i) != 0;
+    nr_inliers_new = ninl;
+    cv::Mat R, t, Q3;
+    cv::Mat mq = mask.clone();
+    if (getPoseTriangPts(E, p1, p2, R, t, Q3, mq, cfg_pose.maxDist3DPtsZ) < 0) return -2;  // stereo_pose_refinement.cpp:1557
+    mask_Q_new = mq;
+    E_new = E, R_new = R, t_new = t, Q = Q3;
+    E_mostLikely = E, R_mostLikely = R, t_mostLikely = t;
+    return 0;
+}
+
+}  // namespace poselib

@@ -1,0 +1,78 @@
+// facade_check.cpp -- drives the C++ drop-in facade exactly as a user of the reference would; the pytest wrapper
+// (tests/test_gpu_facade.py) compares what it writes against the CPU oracle.
+//   in : int32 nq, nt, nbytes ; q bytes ; t bytes ; int32 n ; p1 (n x 2 f64) ; p2 (n x 2 f64) ; f64 thresh ; uint32 seed
+//   out: int32 err ; int32 n_matches ; DMatch[n_matches] ; int32 ok ; E[9] ; mask[n] ; int32 n_good ; R[9] ; t[3] ;
+//        int32 sr_rc ; sr_E[9] ; int32 sr_inliers
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "matchinglib_poselib/matchinglib_matchers.h"
+#include "matchinglib_poselib/pose_estim.h"
+#include "matchinglib_poselib/stereo_pose_refinement.h"
+
+int main(int argc, char **argv) {
+    if (argc != 3) return 2;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    int32_t hdr[3];
+    if (fread(hdr, 4, 3, f) != 3) return 2;
+    const int nq = hdr[0], nt = hdr[1], nb = hdr[2];
+    cv::Mat d1(nq, nb, CV_8U), d2(nt, nb, CV_8U);
+    if (fread(d1.data, 1, (size_t)nq * nb, f) != (size_t)nq * nb) return 2;
+    if (fread(d2.data, 1, (size_t)nt * nb, f) != (size_t)nt * nb) return 2;
+    int32_t n;
+    if (fread(&n, 4, 1, f) != 1) return 2;
+    cv::Mat p1(n, 2, CV_64F), p2(n, 2, CV_64F);
+    if (fread(p1.data, 8, (size_t)n * 2, f) != (size_t)n * 2) return 2;
+    if (fread(p2.data, 8, (size_t)n * 2, f) != (size_t)n * 2) return 2;
+    double th;
+    uint32_t seed;
+    if (fread(&th, 8, 1, f) != 1 || fread(&seed, 4, 1, f) != 1) return 2;
+    fclose(f);
+
+    FILE *o = fopen(argv[2], "wb");
+    std::vector<cv::KeyPoint> kp1((size_t)nq), kp2((size_t)nt);
+    std::vector<cv::DMatch> matches;
+    int32_t err = matchinglib::getMatches(kp1, kp2, d1, d2, cv::Size(640, 480), matches, "LINEAR", false, true);
+    int32_t nm = (int32_t)matches.size();
+    fwrite(&err, 4, 1, o);
+    fwrite(&nm, 4, 1, o);
+    fwrite(matches.data(), sizeof(cv::DMatch), matches.size(), o);
+
+    poselib::setRansacSeed(seed);
+    cv::Mat E, mask;
+    int32_t ok = poselib::estimateEssentialMat(E, p1, p2, "RANSAC", th, false, mask) ? 1 : 0;
+    fwrite(&ok, 4, 1, o);
+    fwrite(E.data, 8, 9, o);
+    fwrite(mask.data, 1, (size_t)n, o);
+    cv::Mat R, t, Q;
+    int32_t ng = poselib::getPoseTriangPts(E, p1, p2, R, t, Q, mask, 50.0);
+    fwrite(&ng, 4, 1, o);
+    fwrite(R.data, 8, 9, o);
+    fwrite(t.data, 8, 3, o);
+
+    // StereoRefine on pixel keypoints: K = [[800,0,320],[0,800,240],[0,0,1]] both cameras
+    cv::Mat K = cv::Mat::zeros(3, 3, CV_64F);
+    K.at<double>(0, 0) = 800, K.at<double>(1, 1) = 800, K.at<double>(0, 2) = 320, K.at<double>(1, 2) = 240, K.at<double>(2, 2) = 1;
+    poselib::ConfigPoseEstimation cfg;
+    cfg.K0 = &K, cfg.K1 = &K;
+    cfg.RobMethod = "RANSAC";
+    poselib::StereoRefine sr(cfg);
+    std::vector<cv::KeyPoint> a((size_t)n), b((size_t)n);
+    std::vector<cv::DMatch> mm((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        a[i].pt = cv::Point2f((float)(p1.at<double>(i, 0) * 800 + 320), (float)(p1.at<double>(i, 1) * 800 + 240));
+        b[i].pt = cv::Point2f((float)(p2.at<double>(i, 0) * 800 + 320), (float)(p2.at<double>(i, 1) * 800 + 240));
+        mm[i].queryIdx = i, mm[i].trainIdx = i;
+    }
+    poselib::setRansacSeed(seed);
+    int32_t rc = sr.addNewCorrespondences(mm, a, b, poselib::ConfigUSAC());
+    int32_t inl = (int32_t)sr.nr_inliers_new;
+    double zero[9] = {0};
+    fwrite(&rc, 4, 1, o);
+    fwrite(rc == 0 ? (const void *)sr.E_new.data : (const void *)zero, 8, 9, o);
+    fwrite(&inl, 4, 1, o);
+    fclose(o);
+    return 0;
+}
