@@ -135,6 +135,14 @@ int mlpl_match_hamming_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_s
                            int ratio_test, float ratio, int batch, int32_t *d_idx, int32_t *d_dist,
                            mlpl_dmatch *d_out, int32_t *d_n_out, void *stream);
 
+/* ---- correspondence gather (pre-step of the pose path) -------------------------------------------------------
+ * Replaces the gather + ImgToCamCoordTrans of StereoRefine::addNewCorrespondences (P/source/stereo_pose_refinement.cpp:
+ * 428-455, P/source/pose_helper.cpp:1100-1109): p1[i] = ((double)kp1[m.queryIdx] - c0) / f0 rounded to float and widened
+ * to double, p2 likewise with kp2[m.trainIdx].  kp1/kp2: device arrays of (x,y) float pairs; K = {fx, fy, cx, cy}.
+ * All pointers are device pointers; n = number of matches (known to the host). */
+int mlpl_gather_match_points_dev(mlpl_ctx *ctx, const mlpl_dmatch *d_matches, int n, const float *d_kp1, const float *d_kp2,
+                                 const double K0[4], const double K1[4], double *d_p1, double *d_p2, void *stream);
+
 /* ---- robust essential matrix ----------------------------------------------------------------------------
  * Replaces poselib::estimateEssentialMat(E,p1,p2,"RANSAC",th,refine,mask) (P/source/pose_estim.cpp:857-890)
  * = findEssentialMat (P/source/five-point-nister/five-point.cpp:69-148) = CvModelEstimator3::runRANSAC

@@ -73,6 +73,8 @@ _SIGNATURES = {
     "mlpl_match_hamming_dev": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_size_t, c_void_p, c_int, c_size_t,
                                        c_size_t, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
+    "mlpl_gather_match_points_dev": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p]),
     "mlpl_ransac_essential": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int, c_int, c_u32,
                                       c_void_p, c_void_p, C.POINTER(c_int), C.POINTER(c_int)]),
     "mlpl_ransac_essential_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int, c_int,

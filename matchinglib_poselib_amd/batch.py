@@ -1,0 +1,98 @@
+"""Batches of independent image pairs sharded over the GPUs of one node (BASELINE config C5).
+
+Every image pair is an independent unit (reference harness loop, tests/poselib-test/main.cpp:1440-2072), so pairs are
+dealt to ranks in contiguous blocks, each rank runs match -> gather -> RANSAC -> pose on its own GPU with no data-path
+collective, and the fixed-size per-pair result records are gathered once (torch.distributed all_gather: RCCL over xGMI
+on GPUs, gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from ._lib import Context, check
+
+# {pair_id, n_matches, n_inliers, status, E[9], R[9], t[3]} = 184 bytes
+RECORD_DTYPE = np.dtype([("pair_id", np.int32), ("n_matches", np.int32), ("n_inliers", np.int32), ("status", np.int32),
+                         ("E", np.float64, (9,)), ("R", np.float64, (9,)), ("t", np.float64, (3,))])
+assert RECORD_DTYPE.itemsize == 184
+
+
+def pair_shard(num_pairs: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [begin, end) of pair ids owned by `rank`; sizes differ by at most one."""
+    base, rem = divmod(num_pairs, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def shard_capacity(num_pairs: int, world: int) -> int:
+    return (num_pairs + world - 1) // world
+
+
+def gather_records(local: np.ndarray, num_pairs: int, rank: int, world: int, device=None, group=None) -> Optional[np.ndarray]:
+    """All-gathers the ranks' record blocks (padded to equal size) and returns the num_pairs records in pair order on
+    every rank.  `device` = torch device the collective runs on (cuda for RCCL, cpu for gloo)."""
+    import torch
+    import torch.distributed as dist
+
+    cap = shard_capacity(num_pairs, world)
+    buf = np.zeros(cap, RECORD_DTYPE)
+    buf["pair_id"] = -1
+    buf[: len(local)] = local
+    t = torch.from_numpy(buf.view(np.uint8).reshape(cap, RECORD_DTYPE.itemsize).copy())
+    if device is not None:
+        t = t.to(device)
+    if world == 1:
+        allr = t.cpu().numpy()
+    else:
+        out = torch.empty((world * cap, RECORD_DTYPE.itemsize), dtype=torch.uint8, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=group)
+        allr = out.cpu().numpy()
+    rec = np.ascontiguousarray(allr).view(RECORD_DTYPE).reshape(-1)
+    rec = rec[rec["pair_id"] >= 0]
+    order = np.argsort(rec["pair_id"], kind="stable")
+    rec = rec[order]
+    assert len(rec) == num_pairs and np.array_equal(rec["pair_id"], np.arange(num_pairs)), "lost or duplicated pairs"
+    return rec
+
+
+def process_pair_on_device(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, th_pix: float = 0.8, max_iters: int = 1000,
+                           confidence: float = 0.999, refit: bool = False, seed: int = 0, dist: float = 50.0, pair_id: int = 0,
+                           scratch: Optional[dict] = None) -> np.ndarray:
+    """One image pair, device-resident inputs (torch CUDA tensors): Hamming 2-NN + ratio -> gather matched keypoints
+    (ImgToCamCoordTrans) -> RANSAC essential matrix -> cheirality.  Returns one RECORD_DTYPE record."""
+    import torch
+    from .matching import match_hamming_device
+    from . import pose
+
+    rec = np.zeros(1, RECORD_DTYPE)
+    rec["pair_id"] = pair_id
+    out = match_hamming_device(d_q, d_t, ctx=ctx, out=None if scratch is None else scratch.get("match"))
+    if scratch is not None:
+        scratch["match"] = out
+    n = int(out["count"][0].item())  # the only host hop before RANSAC: the match count sizes the next launches
+    rec["n_matches"] = n
+    if n < 16:
+        rec["status"] = -1
+        return rec
+    dev = d_q.device
+    p1 = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    p2 = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    k0 = (C.c_double * 4)(*K0)
+    k1 = (C.c_double * 4)(*K1)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    check(ctx.lib.mlpl_gather_match_points_dev(ctx.handle, out["matches"].data_ptr(), n, d_kp1.data_ptr(), d_kp2.data_ptr(),
+                                               k0, k1, p1.data_ptr(), p2.data_ptr(), st), "mlpl_gather_match_points_dev")
+    th = th_pix * 4.0 / (np.sqrt(2.0) * (K0[0] + K0[1] + K1[0] + K1[1]))  # stereo_pose_refinement.h:280-286
+    r = pose.ransac_essential_device(p1, p2, th, confidence=confidence, max_iters=max_iters, refit=refit, seed=seed, ctx=ctx)
+    if not r["ok"]:
+        rec["status"] = -2
+        return rec
+    rec["n_inliers"] = r["n_inliers"]
+    rec["E"] = r["E"].reshape(-1)
+    n_good, R, t, Q, m = pose.getPoseTriangPts(r["E"], p1.cpu().numpy(), p2.cpu().numpy(), r["mask"].cpu().numpy(), dist, ctx=ctx)
+    rec["R"] = R.reshape(-1)
+    rec["t"] = t.reshape(-1)
+    return rec

@@ -227,6 +227,16 @@ int mlpl_ratio_compact_f32_dev(mlpl_ctx *ctx, const int32_t *d_idx, const float 
     return launch_ratio_compact(ctx, d_idx, d_dist, 1, nq, k, batch, ratio, d_out, d_n_out, pick_stream(ctx, stream));
 }
 
+int mlpl_gather_match_points_dev(mlpl_ctx *ctx, const mlpl_dmatch *d_matches, int n, const float *d_kp1, const float *d_kp2,
+                                 const double K0[4], const double K1[4], double *d_p1, double *d_p2, void *stream) {
+    if (!ctx || !d_matches || !d_kp1 || !d_kp2 || !K0 || !K1 || !d_p1 || !d_p2 || n < 0) {
+        set_error("mlpl_gather_match_points_dev: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_gather_match_points(d_matches, n, d_kp1, d_kp2, K0, K1, d_p1, d_p2, pick_stream(ctx, stream));
+}
+
 int mlpl_match_hamming_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_stride, size_t q_batch_stride,
                            const uint8_t *d_t, int nt, size_t t_stride, size_t t_batch_stride, int nbytes,
                            int ratio_test, float ratio, int batch, int32_t *d_idx, int32_t *d_dist, mlpl_dmatch *d_out,

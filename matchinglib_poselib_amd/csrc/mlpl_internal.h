@@ -43,6 +43,9 @@ enum WsSlot {
     WS_NUM_SLOTS
 };
 
+int launch_gather_match_points(const mlpl_dmatch *d_matches, int n, const float *d_kp1, const float *d_kp2, const double K0[4],
+                               const double K1[4], double *d_p1, double *d_p2, hipStream_t s);
+
 }  // namespace mlpl
 
 struct mlpl_ctx {
@@ -93,5 +96,8 @@ constexpr int kCountGroup = 64;   // queries per entry of the pass-count table
 int launch_ratio_compact(mlpl_ctx *ctx, const int32_t *d_idx, const void *d_dist, int dist_is_float, int nq, int k,
                          int batch, float ratio, mlpl_dmatch *d_out, int32_t *d_n_out, hipStream_t s,
                          int32_t *d_group_counts_ready = nullptr);
+
+int launch_gather_match_points(const mlpl_dmatch *d_matches, int n, const float *d_kp1, const float *d_kp2, const double K0[4],
+                               const double K1[4], double *d_p1, double *d_p2, hipStream_t s);
 
 }  // namespace mlpl

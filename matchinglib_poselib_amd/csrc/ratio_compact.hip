@@ -87,7 +87,33 @@ __global__ __launch_bounds__(kRatioGroup) void ratio_write_kernel(const int32_t 
     if (grp == ngrp - 1 && tid == 0) n_out[b] = base + total;
 }
 
+// Correspondence gather with the reference's ImgToCamCoordTrans fused in (poselib/source/pose_helper.cpp:1100-1109:
+// float result of a double operation), as StereoRefine::addNewCorrespondences does (stereo_pose_refinement.cpp:428-455).
+__global__ void gather_match_points_kernel(const mlpl_dmatch *__restrict__ matches, int n, const float *__restrict__ kp1,
+                                           const float *__restrict__ kp2, double fx0, double fy0, double cx0, double cy0,
+                                           double fx1, double fy1, double cx1, double cy1, double *__restrict__ p1,
+                                           double *__restrict__ p2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const mlpl_dmatch m = matches[i];
+    const float ax = kp1[2 * m.queryIdx], ay = kp1[2 * m.queryIdx + 1];
+    const float bx = kp2[2 * m.trainIdx], by = kp2[2 * m.trainIdx + 1];
+    p1[2 * i] = (double)(float)(((double)ax - cx0) / fx0);
+    p1[2 * i + 1] = (double)(float)(((double)ay - cy0) / fy0);
+    p2[2 * i] = (double)(float)(((double)bx - cx1) / fx1);
+    p2[2 * i + 1] = (double)(float)(((double)by - cy1) / fy1);
+}
+
 }  // namespace
+
+int launch_gather_match_points(const mlpl_dmatch *d_matches, int n, const float *d_kp1, const float *d_kp2, const double K0[4],
+                               const double K1[4], double *d_p1, double *d_p2, hipStream_t s) {
+    if (n <= 0) return MLPL_OK;
+    hipLaunchKernelGGL(gather_match_points_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_matches, n, d_kp1, d_kp2, K0[0],
+                       K0[1], K0[2], K0[3], K1[0], K1[1], K1[2], K1[3], d_p1, d_p2);
+    MLPL_HIP_TRY(hipGetLastError());
+    return MLPL_OK;
+}
 
 int launch_ratio_compact(mlpl_ctx *ctx, const int32_t *d_idx, const void *d_dist, int dist_is_float, int nq, int k,
                          int batch, float ratio, mlpl_dmatch *d_out, int32_t *d_n_out, hipStream_t s,

@@ -78,3 +78,22 @@ def pose_scene(n: int = 5000, inlier_frac: float = 0.5, seed: int = 20260103, no
     mask = np.concatenate([np.ones(n_in, bool), np.zeros(n_out, bool)])
     perm = rng.permutation(n)
     return (np.ascontiguousarray(p1[perm]), np.ascontiguousarray(p2[perm]), R, t, mask[perm], 0.8 * PIX_TO_CAM)
+
+
+def stereo_pair(n: int = 2000, seed: int = 20260200, inlier_frac: float = 0.5, f: float = 800.0, cx: float = 320.0,
+                cy: float = 240.0, nbytes: int = 32, flip_p: float = 0.04):
+    """One synthetic image pair for the whole pipeline (C5 unit): keypoints in pixels (float32), binary descriptors whose
+    nearest neighbours are the true correspondences (train side shuffled), and the ground-truth pose.
+    Returns dict(desc1, desc2, kp1, kp2, K, R, t, train_of_query)."""
+    p1, p2, R, t, mask, th = pose_scene(n, inlier_frac=inlier_frac, seed=seed)
+    rng = np.random.default_rng(seed + 7)
+    perm = rng.permutation(n)                      # train row perm[i] belongs to query i
+    kp1 = (p1 * f + np.array([cx, cy])).astype(np.float32)
+    kp2_q = (p2 * f + np.array([cx, cy])).astype(np.float32)
+    kp2 = np.empty_like(kp2_q)
+    kp2[perm] = kp2_q
+    d2 = rng.integers(0, 256, size=(n, nbytes), dtype=np.uint8)
+    flips = np.packbits(rng.random((n, nbytes * 8)) < flip_p, axis=1, bitorder="little")
+    d1 = d2[perm] ^ flips
+    K = np.array([f, f, cx, cy], np.float64)
+    return dict(desc1=d1, desc2=d2, kp1=kp1, kp2=kp2, K=K, R=R, t=t, train_of_query=perm.astype(np.int32))
