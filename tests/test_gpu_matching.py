@@ -175,3 +175,60 @@ def test_device_batched_match(ctx, oracle):
         m = out["matches"][b, :n].cpu().numpy()
         assert np.array_equal(m[:, 0], o["queryIdx"]) and np.array_equal(m[:, 1], o["trainIdx"])
         assert np.array_equal(m[:, 3].view(np.float32), o["distance"])
+
+
+def _set_l2(ctx, mode):
+    from matchinglib_poselib_amd import _lib
+    _lib.check(ctx.lib.mlpl_set_l2_path(ctx.handle, mode), "set_l2_path")
+
+
+@pytest.mark.parametrize("nq,nt,dim", [(4096, 4096, 128), (300, 1000, 128), (33, 65, 64), (100, 257, 32), (64, 64, 100),
+                                       (50, 700, 256), (31, 40, 16)])
+def test_l2_mfma_integer_descriptors_bit_exact(ctx, oracle, nq, nt, dim):
+    """fp16 MFMA distance-GEMM path on integer-valued 0..255 descriptors (OpenCV SIFT layout): bit-exact vs cvflann order."""
+    q, t = synth.sift_pair(nq, nt, dim=dim, seed=900 + nq + dim)
+    if nt > 10:
+        t[7] = t[3]            # duplicated train rows -> exact distance ties -> smaller index must win
+        q[0] = t[3]
+    _set_l2(ctx, 2)            # force MFMA
+    try:
+        idx, dist = mpa.knn_l2sq(q, t, ctx=ctx)
+    finally:
+        _set_l2(ctx, 0)
+    if nq * nt <= 300 * 1000:
+        oi, od = oracle.knn_l2sq(q, t)
+    else:
+        sub = np.arange(0, nq, 41)
+        oi, od = oracle.knn_l2sq(q[sub], t)
+        idx, dist = idx[sub], dist[sub]
+    assert np.array_equal(idx, oi)
+    assert dist.tobytes() == od.tobytes()
+
+
+def test_l2_auto_path_selection(ctx, oracle):
+    import matchinglib_poselib_amd as m
+    rng = np.random.default_rng(12)
+    q = rng.normal(size=(70, 128)).astype(np.float32)
+    t = rng.normal(size=(200, 128)).astype(np.float32)
+    idx, dist = mpa.knn_l2sq(q, t, ctx=ctx)      # auto: fractional data -> exact fp32 kernel
+    oi, od = oracle.knn_l2sq(q, t)
+    assert np.array_equal(idx, oi) and dist.tobytes() == od.tobytes()
+    _set_l2(ctx, 2)
+    try:
+        with pytest.raises(m.MlplError):
+            mpa.knn_l2sq(q, t, ctx=ctx)          # forcing MFMA on non-integer data is an error, never a wrong answer
+    finally:
+        _set_l2(ctx, 0)
+    qi, ti = synth.sift_pair(200, 300, seed=77)
+    ti[5, 3] = 256.0                              # one value out of range -> auto must fall back and still be exact
+    idx, dist = mpa.knn_l2sq(qi, ti, ctx=ctx)
+    oi, od = oracle.knn_l2sq(qi, ti)
+    assert np.array_equal(idx, oi) and dist.tobytes() == od.tobytes()
+
+
+def test_get_matches_linear_f32(ctx, oracle):
+    q, t = synth.sift_pair(1500, 1800, seed=20260104)
+    kp1, kp2 = [None] * 1500, [None] * 1800
+    err, m = mpa.getMatches(kp1, kp2, q, t, matcher_name="LINEAR", ctx=ctx)
+    rc, o = oracle.get_matches_linear(1500, 1800, q, t)
+    assert err == rc == 0 and m.tobytes() == o.tobytes()
