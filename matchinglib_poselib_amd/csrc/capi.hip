@@ -47,7 +47,7 @@ int pinned_get(mlpl_ctx *ctx, size_t bytes, void **out) {
         ctx->pinned = nullptr;
         ctx->pinned_bytes = 0;
         size_t want = std::max<size_t>(bytes * 2, 4096);
-        hipError_t e = hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&ctx->pinned, want, hipHostMallocMapped);
         if (e != hipSuccess) {
             set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
             return MLPL_E_NOMEM;
@@ -133,6 +133,7 @@ void mlpl_ctx_destroy(mlpl_ctx *ctx) {
         delete[] ctx->prof_ev[k];
     }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    delete[] ctx->ransac_T_host;
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -20,7 +20,7 @@ namespace mlpl {
 
 int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t, int nt,
                        size_t t_stride, size_t t_bstride, int dim, int k, int batch, int32_t *d_idx, float *d_dist,
-                       hipStream_t s, int force);
+                       hipStream_t s, int force, const int **gate_out);
 
 namespace {
 
@@ -51,7 +51,8 @@ template <int DIM4>
 __global__ __launch_bounds__(kQPB) void knn_l2_exact_kernel(const float *__restrict__ q, size_t q_stride, size_t q_bstride,
                                                             const float *__restrict__ t, size_t t_stride, size_t t_bstride,
                                                             int nq, int nt, int dim, int rows_per_split, int nsplit, int tile_rows,
-                                                            ulonglong2 *__restrict__ part) {
+                                                            ulonglong2 *__restrict__ part, const int *__restrict__ gate) {
+    if (gate && *gate == 0) return;  // auto mode: the MFMA pipeline already produced the (identical) result
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [tile_rows][dim_pad]
     const int dim_pad = (dim + 3) & ~3;
     const int tid = threadIdx.x;
@@ -108,7 +109,9 @@ __global__ __launch_bounds__(kQPB) void knn_l2_exact_kernel(const float *__restr
 }
 
 __global__ void knn_l2_merge_kernel(const ulonglong2 *__restrict__ part, int nq, int nsplit, int k,
-                                    int32_t *__restrict__ idx, float *__restrict__ dist) {
+                                    int32_t *__restrict__ idx, float *__restrict__ dist, const int *__restrict__ gate,
+                                    int gate_want) {
+    if (gate && ((*gate != 0) ? 1 : 0) != gate_want) return;
     const int b = blockIdx.y;
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
@@ -130,9 +133,10 @@ __global__ void knn_l2_merge_kernel(const ulonglong2 *__restrict__ part, int nq,
 }  // namespace
 
 void launch_knn_l2_merge(const void *part, int nq, int nsplit, int k, int batch, int32_t *d_idx, float *d_dist,
-                         hipStream_t s) {
+                         hipStream_t s, const int *gate, int gate_want) {
     dim3 mgrid((nq + 255) / 256, batch);
-    hipLaunchKernelGGL(knn_l2_merge_kernel, mgrid, dim3(256), 0, s, (const ulonglong2 *)part, nq, nsplit, k, d_idx, d_dist);
+    hipLaunchKernelGGL(knn_l2_merge_kernel, mgrid, dim3(256), 0, s, (const ulonglong2 *)part, nq, nsplit, k, d_idx, d_dist, gate,
+                       gate_want);
 }
 
 int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t, int nt,
@@ -145,11 +149,15 @@ int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size
     }
     if (nq == 0) return MLPL_OK;
 
+    const int *gate = nullptr;
     if (ctx->l2_mode != 1) {
-        // fp16 MFMA distance-GEMM when the data qualify (auto) or when forced
+        // fp16 MFMA distance-GEMM when the data qualify (auto) or when forced.  In auto mode both pipelines are enqueued and a
+        // device flag written by the operand-preparation kernel decides which one does the work: no host round trip.
         int rc = launch_knn_l2_mfma(ctx, d_q, nq, q_stride, q_bstride, d_t, nt, t_stride, t_bstride, dim, k, batch, d_idx,
-                                    d_dist, s, ctx->l2_mode == 2);
-        if (rc != 1) return rc;  // 1 = "not applicable, use the exact kernel"
+                                    d_dist, s, ctx->l2_mode == 2, &gate);
+        if (rc < 0) return rc;
+        if (rc == 0 && ctx->l2_mode == 2) return MLPL_OK;
+        if (rc == 1) gate = nullptr;  // MFMA path not applicable at all: run the exact kernel unconditionally
     }
 
     const int dim_pad = (dim + 3) & ~3;
@@ -174,14 +182,14 @@ int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size
     dim3 grid(qtiles, nsplit, batch);
 #define MLPL_L2_LAUNCH(D4)                                                                                          \
     hipLaunchKernelGGL(knn_l2_exact_kernel<D4>, grid, dim3(kQPB), shmem, s, d_q, q_stride, q_bstride, d_t, t_stride, \
-                       t_bstride, nq, nt, dim, rps, nsplit, kTileRows, (ulonglong2 *)part)
+                       t_bstride, nq, nt, dim, rps, nsplit, kTileRows, (ulonglong2 *)part, gate)
     const int g4 = dim / 4;
     if (g4 == 32) MLPL_L2_LAUNCH(32);
     else if (g4 == 16) MLPL_L2_LAUNCH(16);
     else if (g4 == 8) MLPL_L2_LAUNCH(8);
     else MLPL_L2_LAUNCH(0);
 #undef MLPL_L2_LAUNCH
-    launch_knn_l2_merge(part, nq, nsplit, k, batch, d_idx, d_dist, s);
+    launch_knn_l2_merge(part, nq, nsplit, k, batch, d_idx, d_dist, s, gate, 1);
     MLPL_HIP_TRY(hipGetLastError());
     return MLPL_OK;
 }

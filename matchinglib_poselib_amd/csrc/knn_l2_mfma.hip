@@ -20,7 +20,8 @@
 
 namespace mlpl {
 
-void launch_knn_l2_merge(const void *part, int nq, int nsplit, int k, int batch, int32_t *d_idx, float *d_dist, hipStream_t s);
+void launch_knn_l2_merge(const void *part, int nq, int nsplit, int k, int batch, int32_t *d_idx, float *d_dist, hipStream_t s,
+                         const int *gate, int gate_want);
 
 namespace {
 
@@ -62,17 +63,26 @@ __global__ void l2_prep_kernel(const float *__restrict__ X, size_t stride, size_
     frag[(size_t)b * total + g] = *reinterpret_cast<uint4 *>(&h);
 }
 
-__global__ void l2_norm_kernel(const float *__restrict__ X, size_t stride, size_t bstride, int n, int dim, int npad,
-                               float *__restrict__ norms) {
+// Squared norms of the rows of both sets in one launch: 8 lanes per row (coalesced 32-byte segments), xor-shuffle sum.
+// Any summation order is exact here (integer data, sums < 2^24); when the data do not qualify the result is unused.
+__global__ void l2_norm_kernel(const float *__restrict__ Xq, size_t q_stride, size_t q_bstride, int nq, int nq_pad,
+                               const float *__restrict__ Xt, size_t t_stride, size_t t_bstride, int nt, int nt_pad, int dim,
+                               float *__restrict__ qnorm, float *__restrict__ tnorm) {
     const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npad) return;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row_all = g >> 3, sub = g & 7;
+    const bool is_t = row_all >= nq_pad;
+    const int i = is_t ? row_all - nq_pad : row_all;
+    const int n = is_t ? nt : nq, npad = is_t ? nt_pad : nq_pad;
     float s = 0.f;
     if (i < n) {
-        const float *r = X + (size_t)b * bstride + (size_t)i * stride;
-        for (int c = 0; c < dim; ++c) s = __fadd_rn(s, __fmul_rn(r[c], r[c]));  // exact for integer data
+        const float *r = is_t ? Xt + (size_t)b * t_bstride + (size_t)i * t_stride : Xq + (size_t)b * q_bstride + (size_t)i * q_stride;
+        for (int c = sub; c < dim; c += 8) s += r[c] * r[c];
     }
-    norms[(size_t)b * npad + i] = s;
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    if (sub == 0 && i < npad) (is_t ? tnorm : qnorm)[(size_t)b * npad + i] = s;
 }
 
 template <int KS>
@@ -80,7 +90,8 @@ __global__ __launch_bounds__(256) void knn_l2_mfma_kernel(const uint4 *__restric
                                                           const uint4 *__restrict__ tfrag, const float *__restrict__ tnorm,
                                                           int nq, int nt, int nq_tiles, int nt_tiles, int nq_pad, int nt_pad,
                                                           int tiles_per_split, int nsplit, int ib,
-                                                          ulonglong2 *__restrict__ part) {
+                                                          ulonglong2 *__restrict__ part, const int *__restrict__ gate) {
+    if (*gate != 0) return;  // some element is not an integer in [0,255]: the exact kernel (gated the other way) runs instead
     __shared__ __attribute__((aligned(16))) uint4 tileA[2][KS * 64];
     __shared__ float tileN[2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -167,10 +178,13 @@ __global__ __launch_bounds__(256) void knn_l2_mfma_kernel(const uint4 *__restric
 
 }  // namespace
 
-// Returns 1 when the MFMA path does not apply (caller falls back to the exact kernel), 0 on success, < 0 on error.
+// Returns 1 when the MFMA path cannot apply at all (caller runs the exact kernel ungated), 0 when the MFMA pipeline was
+// enqueued (in auto mode *gate_out then points at the device flag: 0 = the data qualified and the results are final,
+// nonzero = the MFMA kernels exited early and the caller's exact kernels, gated on nonzero, produce the results), < 0 on error.
+// Nothing here synchronises in auto mode, so the *_dev entry points stay asynchronous.
 int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t, int nt,
                        size_t t_stride, size_t t_bstride, int dim, int k, int batch, int32_t *d_idx, float *d_dist,
-                       hipStream_t s, int force) {
+                       hipStream_t s, int force, const int **gate_out) {
     const int KS = (dim + 15) / 16;
     int ksel = 0;
     for (int c : {1, 2, 4, 8, 16})
@@ -208,21 +222,20 @@ int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride,
                            dim, ksel, nq_tiles, (uint4 *)qf, dflag);
         hipLaunchKernelGGL(l2_prep_kernel, dim3((unsigned)((tt + 255) / 256), batch), dim3(256), 0, s, d_t, t_stride, t_bstride, nt,
                            dim, ksel, nt_tiles, (uint4 *)tf, dflag);
-        hipLaunchKernelGGL(l2_norm_kernel, dim3((nq_pad + 255) / 256, batch), dim3(256), 0, s, d_q, q_stride, q_bstride, nq, dim,
-                           nq_pad, qn);
-        hipLaunchKernelGGL(l2_norm_kernel, dim3((nt_pad + 255) / 256, batch), dim3(256), 0, s, d_t, t_stride, t_bstride, nt, dim,
-                           nt_pad, tn);
+        const long long rows8 = (long long)(nq_pad + nt_pad) * 8;
+        hipLaunchKernelGGL(l2_norm_kernel, dim3((unsigned)((rows8 + 255) / 256), batch), dim3(256), 0, s, d_q, q_stride, q_bstride,
+                           nq, nq_pad, d_t, t_stride, t_bstride, nt, nt_pad, dim, qn, tn);
     }
-    int hflag = 0;
-    MLPL_HIP_TRY(hipMemcpyAsync(&hflag, dflag, 4, hipMemcpyDeviceToHost, s));
-    MLPL_HIP_TRY(hipStreamSynchronize(s));
-    if (hflag) {
-        if (force) {
+    if (force) {  // forcing is a test/diagnostic mode: report non-qualifying data as an error (one host hop)
+        int hflag = 0;
+        MLPL_HIP_TRY(hipMemcpyAsync(&hflag, dflag, 4, hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipStreamSynchronize(s));
+        if (hflag) {
             set_error("knn_l2 (MFMA): descriptors are not integer-valued in [0,255]");
             return MLPL_E_BAD_INPUT;
         }
-        return 1;
     }
+    if (gate_out) *gate_out = dflag;
 
     // train tiles per split: one split must fit the local-row field and the grid should hold >= 2 waves per SIMD
     const int qblocks = (nq_tiles + 3) / 4;
@@ -237,13 +250,14 @@ int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride,
         if (nsplit > 65535) return force ? MLPL_E_BAD_INPUT : 1;
     }
     void *part = nullptr;
-    if ((rc = ws_get(ctx, WS_PARTIAL, (size_t)batch * nsplit * nq * sizeof(ulonglong2), &part))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX4, (size_t)batch * nsplit * nq * sizeof(ulonglong2), &part))) return rc;
 
     dim3 grid(qblocks, nsplit, batch);
     prof_mark(ctx, MLPL_PROF_KNN_L2, 0, s);
 #define MLPL_MFMA_LAUNCH(K)                                                                                                  \
     hipLaunchKernelGGL(knn_l2_mfma_kernel<K>, grid, dim3(256), 0, s, (const uint4 *)qf, (const float *)qn, (const uint4 *)tf, \
-                       (const float *)tn, nq, nt, nq_tiles, nt_tiles, nq_pad, nt_pad, tps, nsplit, ib, (ulonglong2 *)part)
+                       (const float *)tn, nq, nt, nq_tiles, nt_tiles, nq_pad, nt_pad, tps, nsplit, ib, (ulonglong2 *)part, \
+                       (const int *)dflag)
     switch (ksel) {
         case 1: MLPL_MFMA_LAUNCH(1); break;
         case 2: MLPL_MFMA_LAUNCH(2); break;
@@ -253,7 +267,7 @@ int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride,
     }
 #undef MLPL_MFMA_LAUNCH
     prof_mark(ctx, MLPL_PROF_KNN_L2, 1, s);
-    launch_knn_l2_merge(part, nq, nsplit, k, batch, d_idx, d_dist, s);
+    launch_knn_l2_merge(part, nq, nsplit, k, batch, d_idx, d_dist, s, dflag, 0);
     MLPL_HIP_TRY(hipGetLastError());
     return MLPL_OK;
 }

@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -369,13 +370,13 @@ __device__ void emit_models(bool valid, const double *E, int lane, int sample, d
 }
 
 __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
-                                                      const int32_t *__restrict__ samples, int n_samples,
+                                                      const int32_t *__restrict__ samples, int sample_offset, int n_samples,
                                                       double *__restrict__ E_tab, int32_t *__restrict__ n_models,
                                                       double *__restrict__ dense_E, int32_t *__restrict__ dense_id,
                                                       int32_t *__restrict__ dense_total) {
     __shared__ SolveLds L;
     const int lane = threadIdx.x;
-    const int sample = blockIdx.x;
+    const int sample = sample_offset + blockIdx.x;
     if (sample >= n_samples) return;
 
     // ---- 1a. epipolar rows Q[i] = [x1x2, y1x2, x2, x1y2, y1y2, y2, x1, y1, 1]  (five-point.cpp:375-383) ----
@@ -617,6 +618,170 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Device-side replay of CvModelEstimator3::runRANSAC's sequential update rule (modelest.cpp:377-416) over the score
+// tables of one chunk of hypotheses.  The rule is a running arg-max under the total order (good desc, error sum asc,
+// earlier first) restricted to good >= 5, and `niters` after an iteration is min(niters, T[best good so far]) where
+// T[g] = cvRANSACUpdateNumIters1(confidence, (n-g)/n, 5, +inf) is tabulated on the HOST (glibc log/pow, so the values are
+// the CPU path's).  So the loop's stopping point and winner are a prefix-max scan, a find-first and an arg-max reduction.
+// ---------------------------------------------------------------------------------------------------------------
+struct ReplayState {
+    int32_t maxGood;      // best inlier count so far (0 = none)
+    int32_t niters;       // current iteration bound
+    int32_t iter;         // iterations executed so far
+    int32_t stop;         // 1 once iter >= niters
+    double errminsum;     // error sum of the model held
+    long long best;       // global index iteration*10 + slot of the model held, -1 = none
+    double E[9];          // the model held
+    int32_t refit_models; // models produced by the refit step (-1 = refit not run)
+    int32_t refit_taken;  // slot of the refit model taken, -1 = none
+};
+
+// Per-hypothesis arg-max under (good desc, error sum asc, slot asc): the only model of a hypothesis that can ever be taken.
+__global__ void hyp_best_kernel(const int32_t *__restrict__ n_models, const int32_t *__restrict__ good,
+                                const double *__restrict__ esum, int cnt, int32_t *__restrict__ hgood, double *__restrict__ hsum,
+                                int32_t *__restrict__ hslot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const int nm = n_models[i];
+    int bg = 0, bs = -1;
+    double be = 0;
+    for (int m = 0; m < nm; ++m) {
+        const int g = good[(size_t)i * 10 + m];
+        const double e = esum[(size_t)i * 10 + m];
+        if (bs < 0 || g > bg || (g == bg && e < be)) {
+            bg = g;
+            be = e;
+            bs = m;
+        }
+    }
+    hgood[i] = bg;
+    hsum[i] = be;
+    hslot[i] = bs;
+}
+
+__global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict__ hgood, const double *__restrict__ hsum,
+                                                      const int32_t *__restrict__ hslot, const double *__restrict__ E_tab, int cnt,
+                                                      const int32_t *__restrict__ Ttab, int npts, long long base_index,
+                                                      ReplayState *__restrict__ st) {
+    __shared__ int wave_max_s[16];
+    __shared__ int stop_idx;
+    __shared__ int s_best_good[1024];
+    __shared__ double s_best_sum[1024];
+    __shared__ int s_best_idx[1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int maxGood0 = st->maxGood, niters0 = st->niters, iter0 = st->iter;
+    if (tid == 0) stop_idx = cnt;  // "no stop inside this chunk"
+    __syncthreads();
+
+    // pass 1: running best count (inclusive prefix max in iteration order), niters after each iteration, first iteration
+    // after which the loop ends.  1024 iterations per step, coalesced.
+    int carry = maxGood0;
+    for (int base = 0; base < cnt; base += 1024) {
+        const int i = base + tid;
+        int v = (i < cnt) ? hgood[i] : 0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {  // inclusive max-scan inside the wave
+            const int o = __shfl_up(v, off);
+            if (lane >= off) v = max(v, o);
+        }
+        if (lane == 63) wave_max_s[wave] = v;
+        __syncthreads();
+        int pre = carry, tot = carry;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = wave_max_s[w];
+            if (w < wave) pre = max(pre, c);
+            tot = max(tot, c);
+        }
+        const int running = max(pre, v);
+        if (i < cnt) {
+            const int nit = (running >= 5) ? min(niters0, Ttab[min(running, npts)]) : niters0;
+            if (iter0 + i + 1 >= nit) atomicMin(&stop_idx, i);
+        }
+        carry = tot;
+        __syncthreads();
+        if (stop_idx < cnt) break;  // block-uniform after the barrier
+    }
+    __syncthreads();
+    const int processed = min(cnt, stop_idx + 1);
+
+    // pass 2: arg-max over the processed iterations (good desc, sum asc, earlier first), only counts >= 5 qualify
+    int bg = 0, bi = -1;
+    double bs = 0;
+    for (int i = tid; i < processed; i += 1024) {
+        const int g = hgood[i];
+        if (g < 5) continue;
+        const double e = hsum[i];
+        if (bi < 0 || g > bg || (g == bg && e < bs)) {  // i increases per thread: strict comparisons keep the earlier one
+            bg = g;
+            bs = e;
+            bi = i;
+        }
+    }
+    s_best_good[tid] = bg;
+    s_best_sum[tid] = bs;
+    s_best_idx[tid] = bi;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) {
+            const int g2 = s_best_good[tid + off], i2 = s_best_idx[tid + off];
+            const double e2 = s_best_sum[tid + off];
+            const int g1 = s_best_good[tid], i1b = s_best_idx[tid];
+            const double e1 = s_best_sum[tid];
+            // exact ties go to the earlier iteration, as in the sequential loop
+            const bool take2 = (i2 >= 0) && (i1b < 0 || g2 > g1 || (g2 == g1 && (e2 < e1 || (e2 == e1 && i2 < i1b))));
+            if (take2) {
+                s_best_good[tid] = g2;
+                s_best_sum[tid] = e2;
+                s_best_idx[tid] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int g = s_best_good[0], hyp = s_best_idx[0];
+        const double e = s_best_sum[0];
+        int newMax = maxGood0;
+        if (hyp >= 0 && (g > max(maxGood0, 4) || (g == max(maxGood0, 5) && st->errminsum > e))) {
+            // (for g == maxGood0 the carried model is earlier and keeps the tie unless the sum is strictly smaller)
+            const int idx = hyp * 10 + hslot[hyp];
+            newMax = g;
+            st->errminsum = e;
+            st->best = base_index + idx;
+            for (int k = 0; k < 9; ++k) st->E[k] = E_tab[(size_t)idx * 9 + k];
+        }
+        st->maxGood = newMax;
+        const int nit = (newMax >= 5) ? min(niters0, Ttab[min(newMax, npts)]) : niters0;
+        st->niters = nit;
+        st->iter = iter0 + processed;
+        st->stop = (iter0 + processed >= nit) ? 1 : 0;
+    }
+}
+
+// modelest.cpp:444-463: keep a refit model if it has more inliers, or as many and a smaller error sum.
+__global__ void refit_decide_kernel(const int32_t *__restrict__ n_models, const int32_t *__restrict__ good,
+                                    const double *__restrict__ esum, const double *__restrict__ E_tab, ReplayState *__restrict__ st) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int nm = n_models[0];
+    st->refit_models = nm;
+    st->refit_taken = -1;
+    for (int m = 0; m < nm; ++m) {
+        const int g = good[m];
+        const double e = esum[m];
+        if (g > max(st->maxGood, 4)) {
+            st->maxGood = g;
+            st->errminsum = e;
+            st->refit_taken = m;
+        } else if (g == st->maxGood && st->errminsum > e) {
+            st->errminsum = e;
+            st->refit_taken = m;
+        }
+    }
+    if (st->refit_taken >= 0)
+        for (int k = 0; k < 9; ++k) st->E[k] = E_tab[(size_t)st->refit_taken * 9 + k];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 
@@ -695,6 +860,9 @@ struct RansacBuffers {
     int32_t *good;      // [chunk*10]
     double *esum;       // [chunk*10]
     int32_t *total;     // [1]
+    int32_t *hgood;     // [chunk]  per-hypothesis best count
+    int32_t *hslot;     // [chunk]
+    double *hsum;       // [chunk]
 };
 
 static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
@@ -707,13 +875,16 @@ static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
     if ((rc = ws_get(ctx, WS_AUX6, (size_t)chunk * 90 * 8, &p))) return rc;
     B.dense_E = (double *)p;
     // one slot for the small integer/double tables: [n_models | dense_id | good | total] + esum
-    const size_t ints = (size_t)chunk * (1 + 10 + 10) + 16;
-    if ((rc = ws_get(ctx, WS_AUX7, ints * 4 + (size_t)chunk * 10 * 8 + 64, &p))) return rc;
+    const size_t ints = (size_t)chunk * (1 + 10 + 10 + 2) + 16;
+    if ((rc = ws_get(ctx, WS_AUX7, ints * 4 + (size_t)chunk * 11 * 8 + 64, &p))) return rc;
     B.esum = (double *)p;
-    B.n_models = (int32_t *)(B.esum + (size_t)chunk * 10);
+    B.hsum = B.esum + (size_t)chunk * 10;
+    B.n_models = (int32_t *)(B.hsum + chunk);
     B.dense_id = B.n_models + chunk;
     B.good = B.dense_id + (size_t)chunk * 10;
-    B.total = B.good + (size_t)chunk * 10;
+    B.hgood = B.good + (size_t)chunk * 10;
+    B.hslot = B.hgood + chunk;
+    B.total = B.hslot + chunk;
     return MLPL_OK;
 }
 
@@ -748,7 +919,7 @@ int mlpl_solve_5pt(mlpl_ctx *ctx, const double *p1, const double *p2, int n, con
     MLPL_HIP_TRY(hipMemcpyAsync(B.samples, samples, (size_t)n_samples * 20, hipMemcpyHostToDevice, s));
     MLPL_HIP_TRY(hipMemsetAsync(B.E_tab, 0, (size_t)n_samples * 720, s));
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
-    hipLaunchKernelGGL(solve5pt_kernel, dim3(n_samples), dim3(64), 0, s, (const double *)dp1, (const double *)dp2, B.samples,
+    hipLaunchKernelGGL(solve5pt_kernel, dim3(n_samples), dim3(64), 0, s, (const double *)dp1, (const double *)dp2, B.samples, 0,
                        n_samples, B.E_tab, B.n_models, (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
     MLPL_HIP_TRY(hipGetLastError());
@@ -813,134 +984,120 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     RansacBuffers B;
     if ((rc = alloc_ransac(ctx, chunk_cap, B))) return rc;
 
-    // host tables for the replay
-    std::vector<int32_t> h_samples((size_t)chunk_cap * 5), h_nm(chunk_cap), h_good((size_t)chunk_cap * 10);
-    std::vector<double> h_esum((size_t)chunk_cap * 10);
+    // small device block: replay state | niters table | refit scratch
+    const int gblocks = std::max(1, std::min(256, (n + 255) / 256));
+    void *dsm;
+    const size_t off_T = 256, off_refit = off_T + ((size_t)(n + 1) * 4 + 255) / 256 * 256;
+    if ((rc = ws_get(ctx, WS_AUX2, off_refit + (144 + (size_t)gblocks * 45) * 8, &dsm))) return rc;
+    ReplayState *d_st = (ReplayState *)dsm;
+    int32_t *d_T = (int32_t *)((char *)dsm + off_T);
+    double *d_rf = (double *)((char *)dsm + off_refit);
+
+    // pinned staging: samples up, state down
+    void *pin;
+    if ((rc = pinned_get(ctx, (size_t)chunk_cap * 20 + (size_t)(n + 1) * 4 + 1024, &pin))) return rc;
+    ReplayState *h_st = (ReplayState *)pin;
+    int32_t *h_T = (int32_t *)((char *)pin + 512);
+    int32_t *h_samples = h_T + (n + 1);
+    int32_t *d_samples_mapped = nullptr;  // device view of the pinned sample table
+    MLPL_HIP_TRY(hipHostGetDevicePointer((void **)&d_samples_mapped, h_samples, 0));
+
+    // T[g] = cvRANSACUpdateNumIters1(confidence, (n-g)/n, 5, "infinity")  (modelest.cpp:86-109, host libm)
+    if (ctx->ransac_T_n != n || ctx->ransac_T_conf != confidence || !ctx->ransac_T_host) {
+        delete[] ctx->ransac_T_host;
+        ctx->ransac_T_host = new int32_t[(size_t)n + 1];
+        for (int g = 0; g <= n; ++g) ctx->ransac_T_host[g] = update_num_iters(confidence, (double)(n - g) / n, 5, INT32_MAX);
+        ctx->ransac_T_n = n;
+        ctx->ransac_T_conf = confidence;
+    }
+    std::memcpy(h_T, ctx->ransac_T_host, (size_t)(n + 1) * 4);
+    ReplayState init;
+    std::memset(&init, 0, sizeof(init));
+    init.niters = max_iters;
+    init.errminsum = DBL_MAX;
+    init.best = -1;
+    init.refit_models = -1;
+    init.refit_taken = -1;
+    *h_st = init;
+    MLPL_HIP_TRY(hipMemcpyAsync(d_st, h_st, sizeof(ReplayState), hipMemcpyHostToDevice, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(d_T, h_T, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
 
     GlibcRand rng;
     rng.seed(seed);
-
-    // replay state (modelest.cpp:352-416)
-    int niters = max_iters, maxGood = 0;
-    double errminsum = DBL_MAX;
-    long long best_global = -1;  // iter*10 + slot of the model currently held
-    double bestE[9] = {0};
-    int iter = 0;
-    bool stop = false;
-
-    for (int base = 0; base < max_iters && !stop; base += chunk_cap) {
-        const int cnt = std::min(chunk_cap, std::min(max_iters, niters) - base);
+    ReplayState cur = init;
+    for (int base = 0; base < max_iters; base += chunk_cap) {
+        const int cnt = std::min(chunk_cap, std::min(max_iters, cur.niters) - base);
         if (cnt <= 0) break;
-        for (int i = 0; i < cnt; ++i) draw_sample(rng, n, &h_samples[(size_t)i * 5]);
-        MLPL_HIP_TRY(hipMemcpyAsync(B.samples, h_samples.data(), (size_t)cnt * 20, hipMemcpyHostToDevice, s));
+        if (base > 0) MLPL_HIP_TRY(hipStreamSynchronize(s));  // the pinned sample buffer is being reused
         MLPL_HIP_TRY(hipMemsetAsync(B.total, 0, 4, s));
-        prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
-        hipLaunchKernelGGL(solve5pt_kernel, dim3(cnt), dim3(64), 0, s, d_p1, d_p2, B.samples, cnt, B.E_tab, B.n_models,
-                           B.dense_E, B.dense_id, B.total);
-        prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
+        // The glibc-stream sample table is drawn on the host into pinned, device-mapped memory that the solver reads in place
+        // (20 bytes per wave over PCIe, no staging copy in the stream).  Two slices: the device solves the first while the
+        // host draws the rest.
+        const int first = std::min(cnt, 4096);
+        for (int off = 0; off < cnt;) {
+            const int m = (off == 0) ? first : cnt - off;
+            for (int i = off; i < off + m; ++i) draw_sample(rng, n, &h_samples[(size_t)i * 5]);
+            prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
+            hipLaunchKernelGGL(solve5pt_kernel, dim3(m), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, off, cnt,
+                               B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total);
+            prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
+            off += m;
+        }
         prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
         hipLaunchKernelGGL(score_models_kernel, dim3((cnt * 10 + 63) / 64), dim3(64), 0, s, (const double4 *)pts, n,
                            (const double *)B.dense_E, (const int32_t *)B.dense_id, (const int32_t *)B.total, 0, thresh2,
                            B.good, B.esum);
         prof_mark(ctx, MLPL_PROF_SCORE, 1, s);
+        hipLaunchKernelGGL(hyp_best_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, (const int32_t *)B.n_models,
+                           (const int32_t *)B.good, (const double *)B.esum, cnt, B.hgood, B.hsum, B.hslot);
+        hipLaunchKernelGGL(replay_kernel, dim3(1), dim3(1024), 0, s, (const int32_t *)B.hgood, (const double *)B.hsum,
+                           (const int32_t *)B.hslot, (const double *)B.E_tab, cnt, (const int32_t *)d_T, n, (long long)base * 10,
+                           d_st);
         MLPL_HIP_TRY(hipGetLastError());
-        MLPL_HIP_TRY(hipMemcpyAsync(h_nm.data(), B.n_models, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
-        MLPL_HIP_TRY(hipMemcpyAsync(h_good.data(), B.good, (size_t)cnt * 40, hipMemcpyDeviceToHost, s));
-        MLPL_HIP_TRY(hipMemcpyAsync(h_esum.data(), B.esum, (size_t)cnt * 80, hipMemcpyDeviceToHost, s));
-        MLPL_HIP_TRY(hipStreamSynchronize(s));
-
-        // sequential replay of runRANSAC's update rule over this chunk
-        int best_local = -1;
-        for (int i = 0; i < cnt; ++i) {
-            if (iter >= niters) {
-                stop = true;
-                break;
-            }
-            const int nm = h_nm[i];
-            for (int m = 0; m < nm; ++m) {
-                const int good = h_good[(size_t)i * 10 + m];
-                const double es = h_esum[(size_t)i * 10 + m];
-                if (good > std::max(maxGood, 4)) {  // modelest.cpp:400
-                    maxGood = good;
-                    niters = update_num_iters(confidence, (double)(n - good) / n, 5, niters);
-                    errminsum = es;
-                    best_local = i * 10 + m;
-                } else if (good == std::max(maxGood, 5) && errminsum < DBL_MAX && errminsum > es) {  // :408
-                    errminsum = es;
-                    best_local = i * 10 + m;
-                }
-            }
-            ++iter;
+        if (base + chunk_cap < max_iters) {  // more chunks may follow: the host needs niters / stop to size the next one
+            MLPL_HIP_TRY(hipMemcpyAsync(h_st, d_st, sizeof(ReplayState), hipMemcpyDeviceToHost, s));
+            MLPL_HIP_TRY(hipStreamSynchronize(s));
+            cur = *h_st;
+            if (cur.stop) break;
         }
-        if (best_local >= 0) {
-            best_global = (long long)base * 10 + best_local;
-            MLPL_HIP_TRY(hipMemcpy(bestE, B.E_tab + (size_t)best_local * 9, 72, hipMemcpyDeviceToHost));
-        }
-        if (iter >= niters) stop = true;
     }
-    if (iters_used) *iters_used = iter;
-    (void)best_global;
-    if (maxGood <= 0) {
+
+    // mask of the model held (no-op result when none was found; checked below)
+    hipLaunchKernelGGL(inlier_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double4 *)pts, n,
+                       (const double *)d_st->E, thresh2, d_mask);
+    if (refit) {
+        // modelest.cpp:420-464: solve on all inliers, keep a refit model if it scores better
+        double *d_Etab = d_rf;                       // 90 doubles
+        int32_t *d_nm = (int32_t *)(d_rf + 96);      // 1 int
+        int32_t *d_good = d_nm + 4;                  // 10 ints
+        double *d_es = d_rf + 112;                   // 10 doubles
+        double *d_gram = d_rf + 144;                 // [gblocks][45]
+        hipLaunchKernelGGL(gram_kernel, dim3(gblocks), dim3(256), 0, s, (const double4 *)pts, (const uint8_t *)d_mask, n, d_gram);
+        hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, s, (const double *)d_gram, gblocks, d_Etab, d_nm);
+        hipLaunchKernelGGL(score_models_kernel, dim3(1), dim3(64), 0, s, (const double4 *)pts, n, (const double *)d_Etab,
+                           (const int32_t *)nullptr, (const int32_t *)d_nm, 0, thresh2, d_good, d_es);
+        hipLaunchKernelGGL(refit_decide_kernel, dim3(1), dim3(64), 0, s, (const int32_t *)d_nm, (const int32_t *)d_good,
+                           (const double *)d_es, (const double *)d_Etab, d_st);
+        // re-evaluating the mask with the (possibly unchanged) model held is idempotent
+        hipLaunchKernelGGL(inlier_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double4 *)pts, n,
+                           (const double *)d_st->E, thresh2, d_mask);
+    }
+    MLPL_HIP_TRY(hipGetLastError());
+    MLPL_HIP_TRY(hipMemcpyAsync(h_st, d_st, sizeof(ReplayState), hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipStreamSynchronize(s));  // the single host hop of the call (per 32768-iteration chunk)
+    const ReplayState fin = *h_st;
+    if (iters_used) *iters_used = fin.iter;
+    if (fin.maxGood <= 0) {
         set_error("mlpl_ransac_essential: no model found");
         return MLPL_E_FAILED;
     }
-
-    // mask of the best model
-    void *dE;
-    if ((rc = ws_get(ctx, WS_AUX2, (144 + 256 * 45) * sizeof(double), &dE))) return rc;
-    double *dEd = (double *)dE;
-    MLPL_HIP_TRY(hipMemcpyAsync(dEd, bestE, 72, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(inlier_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double4 *)pts, n, (const double *)dEd,
-                       thresh2, d_mask);
-
-    if (refit) {
-        // modelest.cpp:420-464: solve on all inliers, keep a refit model if it has more inliers (or equal and smaller sum)
-        double *d_Etab = dEd + 16;            // 90 doubles
-        int32_t *d_nm = (int32_t *)(dEd + 112);
-        int32_t *d_good = d_nm + 4;           // 10 ints
-        double *d_es = dEd + 128;             // 10 doubles
-        double *d_gram = dEd + 144;           // [gblocks][45]
-        const int gblocks = std::max(1, std::min(256, (n + 255) / 256));
-        hipLaunchKernelGGL(gram_kernel, dim3(gblocks), dim3(256), 0, s, (const double4 *)pts, (const uint8_t *)d_mask, n, d_gram);
-        hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, s, (const double *)d_gram, gblocks, d_Etab, d_nm);
-        int32_t nm = 0;
-        MLPL_HIP_TRY(hipMemcpyAsync(&nm, d_nm, 4, hipMemcpyDeviceToHost, s));
-        MLPL_HIP_TRY(hipStreamSynchronize(s));
-        if (nm <= 0) {
-            // the reference returns `result` (still false) here: modelest.cpp:442-443
-            set_error("mlpl_ransac_essential: refit produced no model (reference returns false here)");
-            return MLPL_E_FAILED;
-        }
-        hipLaunchKernelGGL(score_models_kernel, dim3(1), dim3(64), 0, s, (const double4 *)pts, n, (const double *)d_Etab,
-                           (const int32_t *)nullptr, (const int32_t *)nullptr, nm, thresh2, d_good, d_es);
-        int32_t hg[10];
-        double hs[10], hE[90];
-        MLPL_HIP_TRY(hipMemcpyAsync(hg, d_good, nm * 4, hipMemcpyDeviceToHost, s));
-        MLPL_HIP_TRY(hipMemcpyAsync(hs, d_es, nm * 8, hipMemcpyDeviceToHost, s));
-        MLPL_HIP_TRY(hipMemcpyAsync(hE, d_Etab, nm * 72, hipMemcpyDeviceToHost, s));
-        MLPL_HIP_TRY(hipStreamSynchronize(s));
-        int taken = -1;
-        for (int m = 0; m < nm; ++m) {
-            if (hg[m] > std::max(maxGood, 4)) {
-                maxGood = hg[m];
-                errminsum = hs[m];
-                taken = m;
-            } else if (hg[m] == maxGood && errminsum < DBL_MAX && errminsum > hs[m]) {
-                errminsum = hs[m];
-                taken = m;
-            }
-        }
-        if (taken >= 0) {
-            std::memcpy(bestE, hE + taken * 9, 72);
-            MLPL_HIP_TRY(hipMemcpyAsync(dEd, bestE, 72, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(inlier_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double4 *)pts, n,
-                               (const double *)dEd, thresh2, d_mask);
-        }
+    if (refit && fin.refit_models <= 0) {
+        // the reference returns `result` (still false) when the refit kernel yields no model: modelest.cpp:442-443
+        set_error("mlpl_ransac_essential: refit produced no model (reference returns false here)");
+        return MLPL_E_FAILED;
     }
-    MLPL_HIP_TRY(hipGetLastError());
-    MLPL_HIP_TRY(hipStreamSynchronize(s));
-    std::memcpy(E, bestE, 72);
-    if (n_inliers) *n_inliers = maxGood;
+    std::memcpy(E, fin.E, 72);
+    if (n_inliers) *n_inliers = fin.maxGood;
     return MLPL_OK;
 }
 
