@@ -19,10 +19,10 @@
 //      until the corrections vanish to rounding; a root is real iff |imag| <= 1e-10 (five-point.cpp:438);
 //   6. per real root: null vector of Bz (3x3 one-sided Jacobi SVD in registers), reject |xy1[2]| < 1e-10 (:457),
 //      E = x E0 + y E1 + z E2 + E3, Frobenius-normalised; ballot-compacted into the output.
-// score_models_kernel: one thread per model, sequential loop over the correspondences (wave-uniform operands through the
-//   scalar cache), fp64 Sampson error rounded to float exactly as the reference stores it, `err <= thresh^2` count and
-//   the in-order double sum of the float errors -- bit-identical to the CPU path for the same E (no FMA contraction:
-//   this file is compiled with -ffp-contract=off like the reference's -msse4.2 build).
+// score_models_kernel: 4 lanes per model over interleaved correspondences staged through LDS, fp64 Sampson error rounded to
+//   float exactly as the reference stores it, `err <= thresh^2` count and the 4-accumulator double sum of the float
+//   errors -- bit-identical to the CPU path for the same E (no FMA contraction: this file is compiled with
+//   -ffp-contract=off like the reference's -msse4.2 build).
 
 #include <algorithm>
 #include <cfloat>
@@ -461,41 +461,51 @@ __device__ __forceinline__ float sampson_err_f32(const double *e, double x1, dou
     return (float)__ddiv_rn(__dmul_rn(x2tEx1, x2tEx1), den);
 }
 
-__global__ __launch_bounds__(64) void score_models_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
-                                                          const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
-                                                          int total_host, double thresh2, int32_t *__restrict__ good,
-                                                          double *__restrict__ esum) {
+// 4 lanes per model (lane j takes the correspondences i = j mod 4, in order), 64 models per 256-thread block; the
+// correspondences go through LDS in tiles of 512.  The float errors are accumulated in double per lane and combined as
+// (s0 + s2) + (s1 + s3): four interleaved accumulators, the shape of an SSE2 cv::sum over CV_32F.
+constexpr int kScoreTile = 512;
+__global__ __launch_bounds__(256) void score_models_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
+                                                           const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
+                                                           int total_host, double thresh2, int32_t *__restrict__ good,
+                                                           double *__restrict__ esum) {
+    __shared__ double4 tile[kScoreTile];
     const int total = total_ptr ? *total_ptr : total_host;
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= total) return;
+    if (blockIdx.x * 64 >= total) return;  // block-uniform
+    const int tid = threadIdx.x;
+    const int j = tid & 3;
+    const int m = blockIdx.x * 64 + (tid >> 2);
+    const bool live = m < total;
     double e[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) e[k] = E_list[(size_t)m * 9 + k];
+    for (int k = 0; k < 9; ++k) e[k] = live ? E_list[(size_t)m * 9 + k] : 0.0;
     int cnt = 0;
     double s = 0.0;
-    // Points are wave-uniform operands: they arrive through the scalar cache (s_load_dwordx8) into SGPRs.  Batches of 4
-    // are fetched one batch ahead so that the scalar-load latency hides under the ~200 fp64 VALU cycles per point.
-    constexpr int PB = 4;
-    double4 cur[PB], nxt[PB];
-#pragma unroll
-    for (int j = 0; j < PB; ++j) cur[j] = pts[min(j, n - 1)];
-    for (int i = 0; i < n; i += PB) {
-#pragma unroll
-        for (int j = 0; j < PB; ++j) nxt[j] = pts[min(i + PB + j, n - 1)];
-#pragma unroll
-        for (int j = 0; j < PB; ++j) {
-            const float err = sampson_err_f32(e, cur[j].x, cur[j].y, cur[j].z, cur[j].w);
-            if (i + j < n) {  // wave-uniform
+    for (int base = 0; base < n; base += kScoreTile) {
+        const int rows = min(kScoreTile, n - base);
+        __syncthreads();
+        for (int i = tid; i < rows; i += 256) tile[i] = pts[base + i];
+        __syncthreads();
+        if (live) {
+#pragma unroll 4
+            for (int i = j; i < rows; i += 4) {
+                const double4 p = tile[i];
+                const float err = sampson_err_f32(e, p.x, p.y, p.z, p.w);
                 cnt += ((double)err <= thresh2) ? 1 : 0;
-                s = __dadd_rn(s, (double)err);  // in index order, like cv::sum over the float errors
+                s = __dadd_rn(s, (double)err);
             }
         }
-#pragma unroll
-        for (int j = 0; j < PB; ++j) cur[j] = nxt[j];
     }
-    const int o = ids ? ids[m] : m;
-    good[o] = cnt;
-    esum[o] = s;
+    // combine the 4 lanes of a model: counts add up, sums as (s0 + s2) + (s1 + s3)
+    const int lane = tid & 63, gb = lane & ~3;
+    const double s0 = __shfl(s, gb), s1 = __shfl(s, gb + 1), s2 = __shfl(s, gb + 2), s3 = __shfl(s, gb + 3);
+    cnt += __shfl_xor(cnt, 1);
+    cnt += __shfl_xor(cnt, 2);
+    if (live && j == 0) {
+        const int o = ids ? ids[m] : m;
+        good[o] = cnt;
+        esum[o] = __dadd_rn(__dadd_rn(s0, s2), __dadd_rn(s1, s3));
+    }
 }
 
 __global__ void inlier_mask_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E, double thresh2,
@@ -951,7 +961,7 @@ int mlpl_score_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, 
     double4 *pts;
     if ((rc = pack_points(ctx, (const double *)dp1, (const double *)dp2, n, &pts, s))) return rc;
     prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
-    hipLaunchKernelGGL(score_models_kernel, dim3((n_models + 63) / 64), dim3(64), 0, s, (const double4 *)pts, n,
+    hipLaunchKernelGGL(score_models_kernel, dim3((n_models + 63) / 64), dim3(256), 0, s, (const double4 *)pts, n,
                        (const double *)dE, (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, thresh * thresh,
                        (int32_t *)dgood, (double *)dsum);
     prof_mark(ctx, MLPL_PROF_SCORE, 1, s);
@@ -1044,7 +1054,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
             off += m;
         }
         prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
-        hipLaunchKernelGGL(score_models_kernel, dim3((cnt * 10 + 63) / 64), dim3(64), 0, s, (const double4 *)pts, n,
+        hipLaunchKernelGGL(score_models_kernel, dim3((cnt * 10 + 63) / 64), dim3(256), 0, s, (const double4 *)pts, n,
                            (const double *)B.dense_E, (const int32_t *)B.dense_id, (const int32_t *)B.total, 0, thresh2,
                            B.good, B.esum);
         prof_mark(ctx, MLPL_PROF_SCORE, 1, s);
@@ -1074,7 +1084,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         double *d_gram = d_rf + 144;                 // [gblocks][45]
         hipLaunchKernelGGL(gram_kernel, dim3(gblocks), dim3(256), 0, s, (const double4 *)pts, (const uint8_t *)d_mask, n, d_gram);
         hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, s, (const double *)d_gram, gblocks, d_Etab, d_nm);
-        hipLaunchKernelGGL(score_models_kernel, dim3(1), dim3(64), 0, s, (const double4 *)pts, n, (const double *)d_Etab,
+        hipLaunchKernelGGL(score_models_kernel, dim3(1), dim3(256), 0, s, (const double4 *)pts, n, (const double *)d_Etab,
                            (const int32_t *)nullptr, (const int32_t *)d_nm, 0, thresh2, d_good, d_es);
         hipLaunchKernelGGL(refit_decide_kernel, dim3(1), dim3(64), 0, s, (const int32_t *)d_nm, (const int32_t *)d_good,
                            (const double *)d_es, (const double *)d_Etab, d_st);

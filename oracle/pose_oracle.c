@@ -26,7 +26,11 @@
  *   cv::SVD::solveZ   -> right singular vector of the smallest singular value.
  *   cv::triangulatePoints -> per point the 4x4 DLT system  [x*P(2,:) - P(0,:); y*P(2,:) - P(1,:)] (both views),
  *                        solution = right singular vector of the smallest singular value.
- *   cv::sum(err)      -> double accumulation of the float errors, here in index order.
+ *   cv::sum(err)      -> double accumulation of the float errors.  OpenCV's sum kernel for CV_32F widens to double and keeps
+ *                        SIMD-lane accumulators; restated here as the SSE2 form: four interleaved double accumulators
+ *                        (element i goes to accumulator i mod 4), combined as (s0 + s2) + (s1 + s3).  The exact lane
+ *                        count/tail handling of the reference's OpenCV build is not knowable (it only matters for the
+ *                        equal-inlier-count tie-break, modelest.cpp:408-414).
  *
  * The constraint matrix of five-point.cpp:603-824 is 200 machine-generated expressions; it is NOT copied here.
  * It is re-derived from its definition: with E = x*E0 + y*E1 + z*E2 + E3 the ten cubic constraints
@@ -470,13 +474,13 @@ int oracle_find_inliers(const double *p1, const double *p2, int n, const double 
     oracle_sampson_err(p1, p2, n, E, err);
     const double t = thresh * thresh; /* modelest.cpp:79 */
     int good = 0;
-    double s = 0;
+    double s[4] = {0, 0, 0, 0};
     for (int i = 0; i < n; ++i) {
         mask[i] = (uint8_t)((double)err[i] <= t);
         good += mask[i];
-        s += (double)err[i];
+        s[i & 3] += (double)err[i];
     }
-    if (err_sum) *err_sum = s;
+    if (err_sum) *err_sum = (s[0] + s[2]) + (s[1] + s[3]);
     return good;
 }
 
