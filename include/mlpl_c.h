@@ -174,6 +174,10 @@ int mlpl_solve_5pt(mlpl_ctx *ctx, const double *p1, const double *p2, int n, con
 int mlpl_score_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const double *E, int n_models,
                       double thresh, int32_t *count, double *err_sum);
 
+/* Diagnostics: Durand-Kerner sweep statistics of the solver since the last call ({sum, solves, max}); enable != 0 turns
+ * the (atomic) bookkeeping on.  Not for production use. */
+int mlpl_debug_dk_stats(mlpl_ctx *ctx, int enable, int stats[3]);
+
 /* ---- cheirality / pose recovery --------------------------------------------------------------------------
  * Replaces poselib::getPoseTriangPts (P/source/pose_estim.cpp:913-946) = recoverPose
  * (five-point.cpp:150-338) with t_only empty: decomposeEssentialMat (:340-352), four triangulations,

@@ -52,7 +52,7 @@ struct SolveLds {
     double V[5][9];     // Householder vectors
     double vn2[5];      // their squared norms
     double EE[4][9];    // null-space basis
-    double F[10][64];   // trilinear tensors
+    double F[5][64];    // trilinear tensors, five constraint rows at a time
     double A[10][20];   // constraint matrix
     double b[3][13];    // B(z)
     double c[11];       // determinant polynomial, ascending
@@ -121,15 +121,17 @@ __device__ __forceinline__ void null_vector_3x3(const double *a, double *nv) {
 // Steps 2..6 of the solver, shared by the minimal (5-point) kernel and the refit kernel: EE basis in LDS ->
 // essential matrices.  Returns (per lane) whether this lane holds a valid model in Eout[9].
 // ---------------------------------------------------------------------------------------------------------------
+__device__ int g_dk_iters_dbg[4] = {0, 0, 0, 0};  // [sum, count, max, enabled] -- diagnostics only (tools/)
+
 __device__ bool solve_from_basis(SolveLds &L, int lane, double *Eout) {
-    // ---- 2. trilinear coefficient tensors F[row][lane], lane = (i,j,k) ----
+    // ---- 2. trilinear coefficient tensors (lane = ordered index triple (i,j,k)), symmetrised into A ----
     {
         const int i = lane >> 4, j = (lane >> 2) & 3, k = lane & 3;
         const double *Ei = L.EE[i], *Ej = L.EE[j], *Ek = L.EE[k];
+        double T[10];
         // det: rows 0,1,2 of E taken from basis i,j,k
-        const double det = Ei[0] * (Ej[4] * Ek[8] - Ej[5] * Ek[7]) - Ei[1] * (Ej[3] * Ek[8] - Ej[5] * Ek[6]) +
-                           Ei[2] * (Ej[3] * Ek[7] - Ej[4] * Ek[6]);
-        L.F[0][lane] = det;
+        T[0] = Ei[0] * (Ej[4] * Ek[8] - Ej[5] * Ek[7]) - Ei[1] * (Ej[3] * Ek[8] - Ej[5] * Ek[6]) +
+               Ei[2] * (Ej[3] * Ek[7] - Ej[4] * Ek[6]);
         // P = Ei * Ej^T, tr = trace(P);  C = P * Ek - 1/2 tr * Ek
         double P[3][3];
 #pragma unroll
@@ -141,26 +143,44 @@ __device__ bool solve_from_basis(SolveLds &L, int lane, double *Eout) {
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                L.F[1 + r * 3 + c][lane] = P[r][0] * Ek[c] + P[r][1] * Ek[3 + c] + P[r][2] * Ek[6 + c] - htr * Ek[r * 3 + c];
-    }
-    __syncthreads();
-    // ---- symmetrise: A[row][m] = sum over the distinct orderings of monomial m ----
-    if (lane < 20) {
-        const int a = kMonoVars[lane][0], b = kMonoVars[lane][1], c = kMonoVars[lane][2];
+                T[1 + r * 3 + c] = P[r][0] * Ek[c] + P[r][1] * Ek[3 + c] + P[r][2] * Ek[6 + c] - htr * Ek[r * 3 + c];
+
+        // the distinct orderings of this lane's monomial (lanes 0..19)
         int perm[6];
         int np = 0;
-        const int cand[6] = {a * 16 + b * 4 + c, a * 16 + c * 4 + b, b * 16 + a * 4 + c,
-                             b * 16 + c * 4 + a, c * 16 + a * 4 + b, c * 16 + b * 4 + a};
+        if (lane < 20) {
+            const int a = kMonoVars[lane][0], b = kMonoVars[lane][1], c = kMonoVars[lane][2];
+            const int cand[6] = {a * 16 + b * 4 + c, a * 16 + c * 4 + b, b * 16 + a * 4 + c,
+                                 b * 16 + c * 4 + a, c * 16 + a * 4 + b, c * 16 + b * 4 + a};
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            bool dup = false;
-            for (int u = 0; u < np; ++u) dup = dup || (perm[u] == cand[t]);
-            if (!dup) perm[np++] = cand[t];
+            for (int t = 0; t < 6; ++t) {
+                bool dup = false;
+#pragma unroll
+                for (int u = 0; u < 6; ++u) dup = dup || (u < np && perm[u] == cand[t]);
+                if (!dup) {
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+                        if (u == np) perm[u] = cand[t];
+                    ++np;
+                }
+            }
         }
-        for (int row = 0; row < 10; ++row) {
-            double s = 0;
-            for (int u = 0; u < np; ++u) s += L.F[row][perm[u]];
-            L.A[row][lane] = s;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 5; ++r) L.F[r][lane] = T[half * 5 + r];
+            __syncthreads();
+            if (lane < 20) {
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    double sacc = 0;
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+                        if (u < np) sacc += L.F[r][perm[u]];
+                    L.A[half * 5 + r][lane] = sacc;
+                }
+            }
         }
     }
     __syncthreads();
@@ -269,8 +289,9 @@ __device__ bool solve_from_basis(SolveLds &L, int lane, double *Eout) {
         pim = ti[l];
     }
     const bool active = lane < n;
-    int settle = 0;
+    int settle = 0, dk_sweeps = 0;
     for (int iter = 0; iter < 400; ++iter) {
+        dk_sweeps = iter + 1;
         if (lane < 10) {
             L.rr[lane] = pr;
             L.ri[lane] = pim;
@@ -310,6 +331,11 @@ __device__ bool solve_from_basis(SolveLds &L, int lane, double *Eout) {
             settle = 0;
         }
         if (rel != rel) break;  // NaN: degenerate polynomial
+    }
+    if (g_dk_iters_dbg[3] && lane == 0) {
+        atomicAdd(&g_dk_iters_dbg[0], dk_sweeps);
+        atomicAdd(&g_dk_iters_dbg[1], 1);
+        atomicMax(&g_dk_iters_dbg[2], dk_sweeps);
     }
 
     // ---- 6. real roots -> essential matrices ----
@@ -903,6 +929,18 @@ static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
 using namespace mlpl;
 
 extern "C" {
+
+int mlpl_debug_dk_stats(mlpl_ctx *ctx, int enable, int stats[3]) {
+    if (!ctx) return MLPL_E_BAD_INPUT;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    MLPL_HIP_TRY(hipDeviceSynchronize());
+    int h[4] = {0, 0, 0, 0};
+    MLPL_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dk_iters_dbg), sizeof(h)));
+    if (stats) stats[0] = h[0], stats[1] = h[1], stats[2] = h[2];
+    const int z[4] = {0, 0, 0, enable ? 1 : 0};
+    MLPL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dk_iters_dbg), z, sizeof(z)));
+    return MLPL_OK;
+}
 
 int mlpl_solve_5pt(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const int32_t *samples, int n_samples,
                    double *E_out, int32_t *n_models) {
