@@ -2,9 +2,9 @@
 // (poselib/include/poselib/stereo_pose_refinement.h:100-313, poselib/source/stereo_pose_refinement.cpp:416-478,
 // 1272-1579).  What is kept: construction from ConfigPoseEstimation (K0, K1 mandatory), the pixel -> camera threshold
 // (th = th_pix_user * 4/(sqrt(2)(fx0+fy0+fx1+fy1))), addNewCorrespondences() = gather matched keypoints ->
-// ImgToCamCoordTrans (pose_helper.cpp:1100-1109, float result of a double operation) -> robust estimation with the
+// ImgToCamCoordTrans + Remove_LensDist (pose_helper.cpp:1100-1109, 1169-1279; both on the GPU) -> robust estimation with the
 // non-USAC branch (estimateEssentialMat(RobMethod, th, refineRTold) + getPoseTriangPts(maxDist3DPtsZ)) on the GPU.
-// What is NOT built ("next"): lens undistortion, the correspondence pool, pose history and
+// What is NOT built ("next"): the correspondence pool, pose history and
 // stability logic, refinement/BA; every call is a fresh robust estimation (the reference's first-call path).
 #pragma once
 #include <string>
@@ -16,7 +16,7 @@
 namespace poselib {
 
 struct ConfigPoseEstimation {
-    cv::Mat *dist0_8 = nullptr;  // accepted for signature compatibility; must be null or all-zero (no undistortion here)
+    cv::Mat *dist0_8 = nullptr;  // 8 OpenCV-ordered distortion coefficients (CV_64F), null/empty = none
     cv::Mat *dist1_8 = nullptr;
     cv::Mat *K0 = nullptr;  // 3x3 CV_64F camera matrices
     cv::Mat *K1 = nullptr;

@@ -143,6 +143,22 @@ int mlpl_match_hamming_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_s
 int mlpl_gather_match_points_dev(mlpl_ctx *ctx, const mlpl_dmatch *d_matches, int n, const float *d_kp1, const float *d_kp2,
                                  const double K0[4], const double K1[4], double *d_p1, double *d_p2, void *stream);
 
+/* ---- pre/post steps of the pose path (host-pointer forms) ----------------------------------------------------------
+ * mlpl_img_to_cam: ImgToCamCoordTrans (P/source/pose_helper.cpp:1100-1109), pts = n x (x,y) floats rewritten in place,
+ *   K = {fx, fy, cx, cy}.
+ * mlpl_remove_lens_dist: Remove_LensDist + LensDist_Oulu (pose_helper.cpp:1169-1279): 10 fixed-point iterations per
+ *   point and view, correspondences failing the 0.25 proof gate are dropped (order kept), points rewritten in place,
+ *   *n_out = remaining count.  No-op when both coefficient sums are within 1e-3 of zero.  MLPL_E_FAILED (-3) = the
+ *   reference's `false` (fewer than 16 correspondences left).
+ * mlpl_get_inliers_strict: computeReprojError2 + getInlierMask (pose_helper.cpp:639-664, 3030-3045) as used by
+ *   StereoRefine::getInliers (stereo_pose_refinement.cpp:2085-2090): err[i] = fp64 Sampson error (kept double),
+ *   mask[i] = err[i] < th2 (STRICT, unlike RANSAC's <=).  Returns the inlier count (>= 0) or a negative error. */
+int mlpl_img_to_cam(mlpl_ctx *ctx, float *pts, int n, const double K[4]);
+int mlpl_remove_lens_dist(mlpl_ctx *ctx, float *points1, float *points2, int n, const double dist1[8], const double dist2[8],
+                          int *n_out);
+int mlpl_get_inliers_strict(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const double E[9], double th2, double *err,
+                            uint8_t *mask);
+
 /* ---- robust essential matrix ----------------------------------------------------------------------------
  * Replaces poselib::estimateEssentialMat(E,p1,p2,"RANSAC",th,refine,mask) (P/source/pose_estim.cpp:857-890)
  * = findEssentialMat (P/source/five-point-nister/five-point.cpp:69-148) = CvModelEstimator3::runRANSAC

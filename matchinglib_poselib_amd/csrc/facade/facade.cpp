@@ -203,10 +203,6 @@ void StereoRefine::setNewParameters(ConfigPoseEstimation cfg_pose_) {
 
 void StereoRefine::init() {
     CV_Assert(cfg_pose.K0 != nullptr && cfg_pose.K1 != nullptr);
-    for (cv::Mat *d : {cfg_pose.dist0_8, cfg_pose.dist1_8})
-        if (d && !d->empty())
-            for (int r = 0; r < d->rows; ++r)
-                for (int c = 0; c < d->cols; ++c) CV_Assert(d->at<double>(r, c) == 0.0);  // undistortion is not built here
     // stereo_pose_refinement.h:280-286
     pixToCamFact = 4.0 / (std::sqrt(2.0) * (cfg_pose.K0->at<double>(0, 0) + cfg_pose.K0->at<double>(1, 1) +
                                             cfg_pose.K1->at<double>(0, 0) + cfg_pose.K1->at<double>(1, 1)));
@@ -219,18 +215,39 @@ int StereoRefine::addNewCorrespondences(std::vector<cv::DMatch> matches, std::ve
         std::cout << "StereoRefine (MI355X slice): only RobMethod == \"RANSAC\" is built." << std::endl;
         return -1;
     }
-    const int n = (int)matches.size();
+    int n = (int)matches.size();
     nr_corrs_new = (size_t)n;
     if (n < 16) return -1;
-    // stereo_pose_refinement.cpp:428-455: gather, ImgToCamCoordTrans (float result of a double op), to CV_64F n x 2
-    cv::Mat p1(n, 2, CV_64F), p2(n, 2, CV_64F);
-    const cv::Mat &K0 = *cfg_pose.K0, &K1 = *cfg_pose.K1;
+    // stereo_pose_refinement.cpp:428-455: gather the matched keypoints, ImgToCamCoordTrans on both sets, Remove_LensDist
+    // (drops correspondences whose undistortion fails; `false` when fewer than 16 remain), then CV_64F n x 2
+    std::vector<float> a((size_t)n * 2), b((size_t)n * 2);
     for (int i = 0; i < n; ++i) {
-        const cv::Point2f a = kp1[(size_t)matches[i].queryIdx].pt, b = kp2[(size_t)matches[i].trainIdx].pt;
-        p1.at<double>(i, 0) = (double)(float)(((double)a.x - K0.at<double>(0, 2)) / K0.at<double>(0, 0));
-        p1.at<double>(i, 1) = (double)(float)(((double)a.y - K0.at<double>(1, 2)) / K0.at<double>(1, 1));
-        p2.at<double>(i, 0) = (double)(float)(((double)b.x - K1.at<double>(0, 2)) / K1.at<double>(0, 0));
-        p2.at<double>(i, 1) = (double)(float)(((double)b.y - K1.at<double>(1, 2)) / K1.at<double>(1, 1));
+        const cv::Point2f pa = kp1[(size_t)matches[i].queryIdx].pt, pb = kp2[(size_t)matches[i].trainIdx].pt;
+        a[2 * i] = pa.x, a[2 * i + 1] = pa.y, b[2 * i] = pb.x, b[2 * i + 1] = pb.y;
+    }
+    const cv::Mat &K0 = *cfg_pose.K0, &K1 = *cfg_pose.K1;
+    const double k0[4] = {K0.at<double>(0, 0), K0.at<double>(1, 1), K0.at<double>(0, 2), K0.at<double>(1, 2)};
+    const double k1[4] = {K1.at<double>(0, 0), K1.at<double>(1, 1), K1.at<double>(0, 2), K1.at<double>(1, 2)};
+    mlpl_ctx *ctx = default_ctx();
+    if (mlpl_img_to_cam(ctx, a.data(), n, k0) != MLPL_OK || mlpl_img_to_cam(ctx, b.data(), n, k1) != MLPL_OK)
+        throw cv::Exception(std::string("mlpl_img_to_cam: ") + mlpl_last_error());
+    double d0[8] = {0}, d1[8] = {0};
+    auto read_dist = [](const cv::Mat *m, double *out) {
+        if (!m || m->empty()) return;
+        CV_Assert(m->rows * m->cols == 8 && m->type() == CV_64F);
+        for (int i = 0; i < 8; ++i) out[i] = m->rows == 1 ? m->at<double>(0, i) : m->at<double>(i, 0);
+    };
+    read_dist(cfg_pose.dist0_8, d0);
+    read_dist(cfg_pose.dist1_8, d1);
+    int n_left = n;
+    const int rcd = mlpl_remove_lens_dist(ctx, a.data(), b.data(), n, d0, d1, &n_left);
+    if (rcd == MLPL_E_FAILED) return -1;  // "Undistortion failed"
+    if (rcd != MLPL_OK) throw cv::Exception(std::string("mlpl_remove_lens_dist: ") + mlpl_last_error());
+    n = n_left;
+    cv::Mat p1(n, 2, CV_64F), p2(n, 2, CV_64F);
+    for (int i = 0; i < n; ++i) {
+        p1.at<double>(i, 0) = (double)a[2 * i], p1.at<double>(i, 1) = (double)a[2 * i + 1];
+        p2.at<double>(i, 0) = (double)b[2 * i], p2.at<double>(i, 1) = (double)b[2 * i + 1];
     }
     cv::Mat E, mask;
     if (!estimateEssentialMat(E, p1, p2, cfg_pose.RobMethod, th, cfg_pose.refineRTold, mask)) return -2;

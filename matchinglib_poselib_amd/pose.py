@@ -130,6 +130,47 @@ def getPoseTriangPts(E, p1, p2, mask=None, dist: float = 50.0, translatE: bool =
     return rc, R, t, Q, m
 
 
+def ImgToCamCoordTrans(points, K, ctx: Optional[Context] = None) -> np.ndarray:
+    """poselib::ImgToCamCoordTrans (pose_helper.cpp:1100-1109): float32 n x 2 pixel points -> camera coordinates."""
+    ctx = ctx or default_context()
+    pts = np.ascontiguousarray(points, np.float32).copy()
+    K = np.asarray(K, np.float64)
+    k4 = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]]) if K.shape == (3, 3) else K.astype(np.float64)
+    check(ctx.lib.mlpl_img_to_cam(ctx.handle, pts.ctypes.data, pts.shape[0], k4.ctypes.data), "mlpl_img_to_cam")
+    return pts
+
+
+def Remove_LensDist(points1, points2, dist1, dist2, ctx: Optional[Context] = None):
+    """poselib::Remove_LensDist (pose_helper.cpp:1169-1223) -> (ok, points1, points2) with failing pairs dropped."""
+    ctx = ctx or default_context()
+    a = np.ascontiguousarray(points1, np.float32).copy()
+    b = np.ascontiguousarray(points2, np.float32).copy()
+    d1 = np.ascontiguousarray(np.asarray(dist1, np.float64).reshape(-1))
+    d2 = np.ascontiguousarray(np.asarray(dist2, np.float64).reshape(-1))
+    assert d1.size == 8 and d2.size == 8 and a.shape == b.shape
+    n_out = C.c_int(0)
+    rc = ctx.lib.mlpl_remove_lens_dist(ctx.handle, a.ctypes.data, b.ctypes.data, a.shape[0], d1.ctypes.data, d2.ctypes.data,
+                                       C.byref(n_out))
+    if rc not in (0, _lib.MLPL_E_FAILED):
+        raise MlplError(rc, "mlpl_remove_lens_dist", _lib.last_error())
+    return rc == 0, a[: n_out.value], b[: n_out.value]
+
+
+def getInliers(E, p1, p2, th2: float, ctx: Optional[Context] = None):
+    """StereoRefine::getInliers (stereo_pose_refinement.cpp:2085-2090) -> (n_inliers, mask, error); strict `<`."""
+    ctx = ctx or default_context()
+    p1, p2 = _pts(p1), _pts(p2)
+    E = np.ascontiguousarray(E, np.float64).reshape(3, 3)
+    n = p1.shape[0]
+    err = np.zeros(n)
+    mask = np.zeros(n, np.uint8)
+    rc = ctx.lib.mlpl_get_inliers_strict(ctx.handle, p1.ctypes.data, p2.ctypes.data, n, E.ctypes.data, float(th2),
+                                         err.ctypes.data, mask.ctypes.data)
+    if rc < 0:
+        raise MlplError(rc, "mlpl_get_inliers_strict", _lib.last_error())
+    return rc, mask, err
+
+
 def estimateRelativePose(p1, p2, threshold: float = PIX_MIN_GOOD_TH, refine: bool = True, dist: float = 50.0,
                          seed: Optional[int] = None, ctx: Optional[Context] = None):
     """Convenience named in BASELINE.json: estimateEssentialMat("RANSAC") followed by getPoseTriangPts, as the

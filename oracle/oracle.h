@@ -125,6 +125,12 @@ void oracle_jacobi_svd(const double *A, int m, int n, double *w, double *V);
 /* Durand-Kerner as cv::solvePoly; coeffs[0..deg] ascending powers; roots as (re,im) pairs. Returns #roots. */
 int oracle_solve_poly(const double *coeffs, int deg, double *roots_re_im, int max_iters);
 
+/* ---- pre/post steps: P/source/pose_helper.cpp:1100-1109, 1169-1279, 639-664, 3030-3045 -------- */
+void oracle_img_to_cam(float *pts, int n, const double K[4]);
+int oracle_remove_lens_dist(float *points1, float *points2, int n, const double dist1[8], const double dist2[8], int *n_out);
+int oracle_get_inliers_strict(const double *p1, const double *p2, int n, const double *E, double th2, double *err,
+                              unsigned char *mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,6 +120,35 @@ class Oracle:
         self.lib.oracle_decompose_essential(E.ctypes.data, R1.ctypes.data, R2.ctypes.data, t.ctypes.data)
         return R1, R2, t
 
+    def img_to_cam(self, pts, K4):
+        a = np.ascontiguousarray(pts, np.float32).copy()
+        k = np.ascontiguousarray(K4, np.float64)
+        self.lib.oracle_img_to_cam.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self.lib.oracle_img_to_cam(a.ctypes.data, a.shape[0], k.ctypes.data)
+        return a
+
+    def remove_lens_dist(self, p1, p2, d1, d2):
+        a = np.ascontiguousarray(p1, np.float32).copy()
+        b = np.ascontiguousarray(p2, np.float32).copy()
+        d1 = np.ascontiguousarray(d1, np.float64)
+        d2 = np.ascontiguousarray(d2, np.float64)
+        n_out = C.c_int(0)
+        self.lib.oracle_remove_lens_dist.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        ok = self.lib.oracle_remove_lens_dist(a.ctypes.data, b.ctypes.data, a.shape[0], d1.ctypes.data, d2.ctypes.data,
+                                              C.byref(n_out))
+        return bool(ok), a[: n_out.value], b[: n_out.value]
+
+    def get_inliers_strict(self, p1, p2, E, th2):
+        p1 = np.ascontiguousarray(p1, np.float64)
+        p2 = np.ascontiguousarray(p2, np.float64)
+        E = np.ascontiguousarray(E, np.float64)
+        n = p1.shape[0]
+        err, mask = np.zeros(n), np.zeros(n, np.uint8)
+        self.lib.oracle_get_inliers_strict.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+        cnt = self.lib.oracle_get_inliers_strict(p1.ctypes.data, p2.ctypes.data, n, E.ctypes.data, th2, err.ctypes.data,
+                                                 mask.ctypes.data)
+        return cnt, mask, err
+
     def jacobi_svd(self, A):
         A = np.ascontiguousarray(A, np.float64)
         m, n = A.shape
