@@ -20,9 +20,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
-VALU_PEAK_INT32_OPS = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz = 78.6 Tops/s
 BYTES_PER_PAIR = 64              # streaming-equivalent algorithmic bytes: two 32-byte operands
-OPS_PER_PAIR = 19                # 8 xor + 8 bcnt-acc + lshl_or + med3 + min
+OPS_PER_PAIR = 19                # 8 v_xor + 8 v_bcnt(acc) + v_lshl_or + v_med3 + v_min per descriptor pair (ORB-256)
+# Issue cost of that instruction mix per wave and train row, from tools/valu_peak.hip on this pool (8 waves/SIMD, cycles per
+# wave-instruction per SIMD at 2.4 GHz): v_xor 3.24, v_bcnt 4.73, v_lshl_or/v_med3 4.8, v_min 3.24
+MIX_CYCLES_PER_WAVE_ROW = 8 * 3.24 + 8 * 4.73 + 4.8 + 4.8 + 3.24
+N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
 
 
 def main():
@@ -149,9 +152,12 @@ def main():
                 "kernel_ms_avg": kern_ms,
                 "launches_timed": launches.value,
                 "note": "streaming-equivalent bytes (64 B per descriptor pair, SURVEY 8(d)); operands are LDS/L2-"
-                        "resident so the kernel is integer-VALU bound: see valu_frac",
+                        "resident so the kernel is integer-VALU bound: valu_frac = measured instruction-issue floor of the xor/bcnt/"
+                        "med3 mix (tools/valu_peak.hip) / kernel time",
                 "valu_ops_per_pair": OPS_PER_PAIR,
-                "valu_frac": pairs_per_step_rank * OPS_PER_PAIR / (kern_ms * 1e-3) / VALU_PEAK_INT32_OPS,
+                "valu_achieved_Tops": pairs_per_step_rank * OPS_PER_PAIR / (kern_ms * 1e-3) / 1e12,
+                "valu_issue_floor_ms": pairs_per_step_rank / 64 * MIX_CYCLES_PER_WAVE_ROW / N_SIMD / CLOCK_HZ * 1e3,
+                "valu_frac": (pairs_per_step_rank / 64 * MIX_CYCLES_PER_WAVE_ROW / N_SIMD / CLOCK_HZ * 1e3) / kern_ms,
             },
         }
         if not args.no_cpu_baseline:
