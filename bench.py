@@ -2,8 +2,8 @@
 """bench.py -- descriptor-pairs/s of the brute-force Hamming 2-NN + ratio hot path on MI355X.
 
 A step = one pass of getMatches("LINEAR") device path (knn2_hamming partial + merge + ratio/compaction) over one
-batch of `--pairs-per-gpu` synthetic image pairs of BASELINE config C2 (8192 x 8192 ORB-256), inputs resident in
-HBM.  One process per GPU; image pairs shard across ranks with no data-path collective (weak scaling); with N > 1
+batch of `--pairs-per-gpu` (default 8) synthetic image pairs of BASELINE config C2 (8192 x 8192 ORB-256 each), one batched
+launch per kernel, inputs resident in HBM.  The single-pair (latency) figure is reported under extras.  One process per GPU; image pairs shard across ranks with no data-path collective (weak scaling); with N > 1
 each step ends with one RCCL all_gather of the fixed-size per-pair result records (match counts).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured live with HIP events inside the library,
@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--pairs-per-gpu", type=int, default=1, help="image pairs per rank per step")
+    ap.add_argument("--pairs-per-gpu", type=int, default=8, help="image pairs per rank per step (one batched launch)")
     ap.add_argument("--n", type=int, default=8192, help="descriptors per image")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-queries", type=int, default=8192)

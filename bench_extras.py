@@ -90,4 +90,21 @@ def run(ctx, dev, cpu_baseline=True):
         out[name] = {"value": 4096 * 4096 / (ms * 1e-3), "unit": "descriptor-pairs/s", "ms_per_call": ms,
                      "gflops_equiv": 2 * 4096 * 4096 * 128 / (ms * 1e-3) / 1e9}
     ctx.lib.mlpl_set_l2_path(ctx.handle, 0)
+    # ---- C2 as ONE image pair per launch (latency shape; the headline step batches 8 pairs per launch) ----
+    from matchinglib_poselib_amd.matching import match_hamming_device
+    B = 1
+    qs, ts = zip(*[synth.orb_pair(8192, 8192, seed=20260300 + b) for b in range(B)])
+    bq = torch.from_numpy(np.stack(qs)).to(dev)
+    bt = torch.from_numpy(np.stack(ts)).to(dev)
+    res = match_hamming_device(bq, bt, ctx=ctx)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        res = match_hamming_device(bq, bt, ctx=ctx, out=res)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    out["hamming_c2_single_pair"] = {"value": B * 8192 * 8192 / (ms * 1e-3), "unit": "descriptor-pairs/s",
+                                     "ms_per_call": ms, "pairs_per_call": B}
     return out
