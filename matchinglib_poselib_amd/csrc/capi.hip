@@ -110,7 +110,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->opt_hamming_variant = 0;
     ctx->opt_hamming_qpl = 1;
-    ctx->opt_hamming_blocks_per_cu = 8;
+    ctx->opt_hamming_blocks_per_cu = 32;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(e));

@@ -12,11 +12,12 @@ from matchinglib_poselib_amd.matching import match_hamming_device
 ctx = mpa.Context(0)
 lib = ctx.lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-q, t = synth.orb_pair(n, n, seed=20260102)
-dq = torch.from_numpy(q).cuda()[None]
-dt = torch.from_numpy(t).cuda()[None]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+qs, ts = zip(*[synth.orb_pair(n, n, seed=20260102 + b) for b in range(B)])
+dq = torch.from_numpy(np.stack(qs)).cuda()
+dt = torch.from_numpy(np.stack(ts)).cuda()
 stream = None
-configs = [(0, 1, 8), (0, 1, 4), (1, 1, 2), (1, 1, 4), (1, 1, 8), (1, 1, 16), (1, 2, 4), (1, 2, 8), (1, 2, 16)]
+configs = [(0, 1, 16), (0, 1, 32), (0, 1, 48), (0, 1, 64)]
 res = {c: [] for c in configs}
 ref = None
 for rnd in range(5):
