@@ -129,6 +129,15 @@ int mlpl_ratio_compact_f32_dev(mlpl_ctx *ctx, const int32_t *d_idx, const float 
 int mlpl_get_matches_linear(mlpl_ctx *ctx, int n_keypoints1, int n_keypoints2, const void *desc1, int rows1,
                             size_t step1, const void *desc2, int rows2, size_t step2, int cols, int desc_type,
                             int ratio_test, mlpl_dmatch *out, int *n_out);
+/* getMatches(..., "BRUTEFORCENMS", ...): M/source/matchers.cpp:476-519 -> nmslibMatching<dist_t>(..., "seq_search",
+ * "bit_hamming" | "l2") (M/include/nmslib/nmslib_matchers.h:159-424) on the vendored NMSLIB, including its quirks:
+ * CV_8U rows are compared WITHOUT their last two bytes (one for odd widths; the wrapper omits the length word that
+ * SpaceBitHamming::HiddenDistance strips), CV_32F uses the TRUE L2 distance sqrt(sum) summed in NMSLIB's 4-lane order and
+ * the ratio test runs on those, K = 2 always, without ratio test ties emit the larger train id, and there is no
+ * minimum-match check.  desc_type 0 = CV_8U, 5 = CV_32F (CV_64F: MLPL_E_UNSUPPORTED). */
+int mlpl_get_matches_bruteforce_nms(mlpl_ctx *ctx, int n_keypoints1, int n_keypoints2, const void *desc1, int rows1,
+                                    size_t step1, const void *desc2, int rows2, size_t step2, int cols, int desc_type,
+                                    int ratio_test, mlpl_dmatch *out, int *n_out);
 /* Device-resident, batched: knn + ratio + compaction, nothing leaves the device. */
 int mlpl_match_hamming_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_stride, size_t q_batch_stride,
                            const uint8_t *d_t, int nt, size_t t_stride, size_t t_batch_stride, int nbytes,

@@ -70,6 +70,8 @@ _SIGNATURES = {
                                            c_void_p, c_void_p]),
     "mlpl_get_matches_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_size_t, c_void_p, c_int, c_size_t,
                                         c_int, c_int, c_int, c_void_p, C.POINTER(c_int)]),
+    "mlpl_get_matches_bruteforce_nms": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_size_t, c_void_p, c_int,
+                                                c_size_t, c_int, c_int, c_int, c_void_p, C.POINTER(c_int)]),
     "mlpl_match_hamming_dev": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_size_t, c_void_p, c_int, c_size_t,
                                        c_size_t, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),

@@ -402,4 +402,50 @@ int mlpl_get_matches_linear(mlpl_ctx *ctx, int n_keypoints1, int n_keypoints2, c
     return MLPL_OK;
 }
 
+int mlpl_get_matches_bruteforce_nms(mlpl_ctx *ctx, int n_keypoints1, int n_keypoints2, const void *desc1, int rows1,
+                                    size_t step1, const void *desc2, int rows2, size_t step2, int cols, int desc_type,
+                                    int ratio_test, mlpl_dmatch *out, int *n_out) {
+    if (!ctx || !n_out) return MLPL_E_BAD_INPUT;
+    *n_out = 0;
+    if (n_keypoints1 < 15 || n_keypoints2 < 15) return MLPL_E_FEW_KEYPOINTS;                 // matchers.cpp:123-127
+    if (n_keypoints1 != rows1 || n_keypoints2 != rows2) return MLPL_E_BAD_INPUT;             // matchers.cpp:129-133
+    if (desc_type != 0 && desc_type != 5) {
+        set_error("BRUTEFORCENMS: CV_8U and CV_32F descriptors are built (the reference also takes CV_64F)");
+        return desc_type == 6 ? MLPL_E_UNSUPPORTED : MLPL_E_BAD_INPUT;                       // matchers.cpp:514-518
+    }
+    if (!desc1 || !desc2 || !out || cols < 1 || rows2 < 2) return MLPL_E_BAD_INPUT;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    const size_t elem = desc_type == 0 ? 1 : 4;
+    if (step1 < (size_t)cols * elem || step2 < (size_t)cols * elem) return MLPL_E_BAD_INPUT;
+    const int k = 2;  // K = 2 always (nmslib_matchers.h:182)
+    void *dq, *dt, *didx, *ddist, *dout, *dcnt;
+    int rc;
+    if ((rc = upload_rows(ctx, WS_AUX0, desc1, rows1, (size_t)cols * elem, step1, &dq))) return rc;
+    if ((rc = upload_rows(ctx, WS_AUX1, desc2, rows2, (size_t)cols * elem, step2, &dt))) return rc;
+    if ((rc = ws_get(ctx, WS_IDX, (size_t)rows1 * k * 4, &didx))) return rc;
+    if ((rc = ws_get(ctx, WS_DIST, (size_t)rows1 * k * 4, &ddist))) return rc;
+    if ((rc = ws_get(ctx, WS_MATCH, (size_t)rows1 * sizeof(mlpl_dmatch), &dout))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX2, 64, &dcnt))) return rc;
+    if (desc_type == 0) {
+        // two bytes per int, last int dropped by SpaceBitHamming::HiddenDistance: the last 2 bytes (1 for odd widths) are ignored
+        const int eff = (cols % 2 == 0) ? cols - 2 : cols - 1;
+        if (eff < 1) return MLPL_E_BAD_INPUT;
+        rc = launch_knn_hamming(ctx, (const uint8_t *)dq, rows1, cols, 0, (const uint8_t *)dt, rows2, cols, 0, eff, k, 1,
+                                (int32_t *)didx, (int32_t *)ddist, ctx->stream);
+    } else {
+        rc = launch_knn_l2(ctx, (const float *)dq, rows1, cols, 0, (const float *)dt, rows2, cols, 0, cols, k, 1,
+                           (int32_t *)didx, (float *)ddist, ctx->stream, /*nms_order=*/1);
+    }
+    if (rc) return rc;
+    rc = launch_ratio_compact(ctx, (const int32_t *)didx, ddist, desc_type == 5, rows1, k, 1, 0.75f, (mlpl_dmatch *)dout,
+                              (int32_t *)dcnt, ctx->stream, nullptr, ratio_test ? 1 : 2);
+    if (rc) return rc;
+    int32_t cnt = 0;
+    MLPL_HIP_TRY(hipMemcpyAsync(&cnt, dcnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MLPL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (cnt > 0) MLPL_HIP_TRY(hipMemcpy(out, dout, (size_t)cnt * sizeof(mlpl_dmatch), hipMemcpyDeviceToHost));
+    *n_out = cnt;
+    return MLPL_OK;  // no minimum-match check on this branch of getMatches
+}
+
 }  // extern "C"

@@ -65,12 +65,15 @@ int getMatches(const std::vector<cv::KeyPoint> &keypoints1, const std::vector<cv
         return -1;
     }
     finalMatches.clear();
-    if (matcher_name != "LINEAR") {
+    const bool nms = matcher_name == "BRUTEFORCENMS";
+    if (matcher_name != "LINEAR" && !nms) {
         std::cout << "Matcher " << matcher_name << " is not supported." << std::endl;
         return -2;
     }
     if (descriptors1.type() != CV_32F && descriptors1.type() != CV_8U) {
-        std::cout << "Format of descriptors not supported!" << std::endl;
+        std::cout << (nms ? "Wrong descriptor data type for BRUTEFORCENMS! Must be 32bit float or 8bit unsigned char here."
+                          : "Format of descriptors not supported!")
+                  << std::endl;
         return -1;
     }
     if (descriptors1.cols != descriptors2.cols) return -1;
@@ -82,10 +85,10 @@ int getMatches(const std::vector<cv::KeyPoint> &keypoints1, const std::vector<cv
     int n_out = 0;
     // cv::Mat::step is honoured, so non-continuous Mats (ROIs) are handled (the reference silently mis-reads them,
     // matchers.cpp:567-568 uses .data with rows x cols)
-    const int rc = mlpl_get_matches_linear(default_ctx(), (int)keypoints1.size(), (int)keypoints2.size(), descriptors1.data,
-                                           descriptors1.rows, descriptors1.step, descriptors2.data, descriptors2.rows,
-                                           descriptors2.step, descriptors1.cols, descriptors1.type(), ratioTest ? 1 : 0,
-                                           out.data(), &n_out);
+    const int rc = (nms ? mlpl_get_matches_bruteforce_nms : mlpl_get_matches_linear)(
+        default_ctx(), (int)keypoints1.size(), (int)keypoints2.size(), descriptors1.data, descriptors1.rows, descriptors1.step,
+        descriptors2.data, descriptors2.rows, descriptors2.step, descriptors1.cols, descriptors1.type(), ratioTest ? 1 : 0,
+        out.data(), &n_out);
     if (rc != 0 && rc != -3) {
         if (rc == -1 || rc == -4) return rc;
         throw cv::Exception(std::string("mlpl_get_matches_linear: ") + mlpl_last_error());

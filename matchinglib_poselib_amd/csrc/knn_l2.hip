@@ -47,7 +47,18 @@ __device__ __forceinline__ float l2_group4(float result, float4 a, float4 b) {
 
 // DIM4 = number of float4 groups held in registers per query (dim = 4*DIM4 + tail, tail < 4 handled via LDS/global).
 // Generic variant (DIM4 == 0) keeps the query in LDS as well.
-template <int DIM4>
+// NMSLIB's L2SqrSIMD (similarity_search/src/distcomp_lp.cc:399-451) restated for one 4-chunk: four lane accumulators.
+__device__ __forceinline__ void l2_group4_nms(float4 &t, float4 a, float4 b) {
+    const float d0 = __fsub_rn(a.x, b.x), d1 = __fsub_rn(a.y, b.y), d2 = __fsub_rn(a.z, b.z), d3 = __fsub_rn(a.w, b.w);
+    t.x = __fadd_rn(t.x, __fmul_rn(d0, d0));
+    t.y = __fadd_rn(t.y, __fmul_rn(d1, d1));
+    t.z = __fadd_rn(t.z, __fmul_rn(d2, d2));
+    t.w = __fadd_rn(t.w, __fmul_rn(d3, d3));
+}
+
+// NMS = false: cvflann::L2<float> order, squared distance (LINEAR).  NMS = true: NMSLIB "l2" space order and TRUE distance
+// sqrt(sum) (BRUTEFORCENMS, reference matchers.cpp:476-519); there the query is the first operand (x - y with x = query).
+template <int DIM4, bool NMS>
 __global__ __launch_bounds__(kQPB) void knn_l2_exact_kernel(const float *__restrict__ q, size_t q_stride, size_t q_bstride,
                                                             const float *__restrict__ t, size_t t_stride, size_t t_bstride,
                                                             int nq, int nt, int dim, int rows_per_split, int nsplit, int tile_rows,
@@ -86,7 +97,19 @@ __global__ __launch_bounds__(kQPB) void knn_l2_exact_kernel(const float *__restr
         for (int r = 0; r < rows; ++r) {
             const float4 *trow = reinterpret_cast<const float4 *>(smem + (size_t)r * dim_pad);
             float res = 0.f;
-            if constexpr (DIM4 > 0) {
+            if constexpr (NMS) {
+                float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (DIM4 > 0) {
+#pragma unroll
+                    for (int g = 0; g < DIM4; ++g) l2_group4_nms(acc4, qa[g], trow[g]);
+                } else {
+                    for (int g = 0; g < ngroups; ++g) {
+                        const float4 qv = make_float4(qrow[4 * g], qrow[4 * g + 1], qrow[4 * g + 2], qrow[4 * g + 3]);
+                        l2_group4_nms(acc4, qv, trow[g]);
+                    }
+                }
+                res = __fadd_rn(__fadd_rn(__fadd_rn(acc4.x, acc4.y), acc4.z), acc4.w);
+            } else if constexpr (DIM4 > 0) {
 #pragma unroll
                 for (int g = 0; g < DIM4; ++g) res = l2_group4(res, trow[g], qa[g]);
             } else {
@@ -98,9 +121,10 @@ __global__ __launch_bounds__(kQPB) void knn_l2_exact_kernel(const float *__restr
             // scalar tail: result += diff*diff, one element at a time
             const float *tt = smem + (size_t)r * dim_pad + ngroups * 4;
             for (int j = 0; j < tail; ++j) {
-                const float d = __fsub_rn(tt[j], qtail[j]);
+                const float d = NMS ? __fsub_rn(qtail[j], tt[j]) : __fsub_rn(tt[j], qtail[j]);
                 res = __fadd_rn(res, __fmul_rn(d, d));
             }
+            if constexpr (NMS) res = sqrtf(res);
             const u64 key = ((u64)__float_as_uint(res) << 32) | (u64)(uint32_t)(base + r);
             top2_update(k0, k1, key);
         }
@@ -141,7 +165,7 @@ void launch_knn_l2_merge(const void *part, int nq, int nsplit, int k, int batch,
 
 int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t, int nt,
                   size_t t_stride, size_t t_bstride, int dim, int k, int batch, int32_t *d_idx, float *d_dist,
-                  hipStream_t s) {
+                  hipStream_t s, int nms_order) {
     if (!d_q || !d_t || !d_idx || !d_dist || nq < 0 || batch < 1 || batch > 65535 || (k != 1 && k != 2) || nt < k ||
         dim < 1 || dim > 1024 || q_stride < (size_t)dim || t_stride < (size_t)dim) {
         set_error("knn_l2: bad arguments (nq=%d nt=%d dim=%d k=%d batch=%d)", nq, nt, dim, k, batch);
@@ -150,7 +174,7 @@ int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size
     if (nq == 0) return MLPL_OK;
 
     const int *gate = nullptr;
-    if (ctx->l2_mode != 1) {
+    if (ctx->l2_mode != 1 && !nms_order) {
         // fp16 MFMA distance-GEMM when the data qualify (auto) or when forced.  In auto mode both pipelines are enqueued and a
         // device flag written by the operand-preparation kernel decides which one does the work: no host round trip.
         int rc = launch_knn_l2_mfma(ctx, d_q, nq, q_stride, q_bstride, d_t, nt, t_stride, t_bstride, dim, k, batch, d_idx,
@@ -180,8 +204,12 @@ int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size
 
     const size_t shmem = (size_t)kTileRows * dim_pad * sizeof(float);
     dim3 grid(qtiles, nsplit, batch);
-#define MLPL_L2_LAUNCH(D4)                                                                                          \
-    hipLaunchKernelGGL(knn_l2_exact_kernel<D4>, grid, dim3(kQPB), shmem, s, d_q, q_stride, q_bstride, d_t, t_stride, \
+#define MLPL_L2_LAUNCH(D4)                                                                                                  \
+    if (nms_order)                                                                                                          \
+        hipLaunchKernelGGL((knn_l2_exact_kernel<D4, true>), grid, dim3(kQPB), shmem, s, d_q, q_stride, q_bstride, d_t,     \
+                           t_stride, t_bstride, nq, nt, dim, rps, nsplit, kTileRows, (ulonglong2 *)part, gate);            \
+    else                                                                                                                    \
+        hipLaunchKernelGGL((knn_l2_exact_kernel<D4, false>), grid, dim3(kQPB), shmem, s, d_q, q_stride, q_bstride, d_t, t_stride, \
                        t_bstride, nq, nt, dim, rps, nsplit, kTileRows, (ulonglong2 *)part, gate)
     const int g4 = dim / 4;
     if (g4 == 32) MLPL_L2_LAUNCH(32);

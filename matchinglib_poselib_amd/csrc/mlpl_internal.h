@@ -92,14 +92,14 @@ int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_strid
                        int32_t *d_group_counts = nullptr);
 int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t,
                   int nt, size_t t_stride, size_t t_bstride, int dim, int k, int batch, int32_t *d_idx,
-                  float *d_dist, hipStream_t s);
+                  float *d_dist, hipStream_t s, int nms_order = 0);
 // group_counts_ready: d_group_counts (one int per kCountGroup queries per batch item, in the context workspace slot
 // WS_COUNT) was already filled by knn_hamming_merge_kernel; otherwise a counting pass runs first.
 constexpr int kRatioGroup = 256;  // queries per ratio_write block
 constexpr int kCountGroup = 64;   // queries per entry of the pass-count table
 int launch_ratio_compact(mlpl_ctx *ctx, const int32_t *d_idx, const void *d_dist, int dist_is_float, int nq, int k,
                          int batch, float ratio, mlpl_dmatch *d_out, int32_t *d_n_out, hipStream_t s,
-                         int32_t *d_group_counts_ready = nullptr);
+                         int32_t *d_group_counts_ready = nullptr, int nms_emit = 0);
 
 int launch_gather_match_points(const mlpl_dmatch *d_matches, int n, const float *d_kp1, const float *d_kp2, const double K0[4],
                                const double K1[4], double *d_p1, double *d_p2, hipStream_t s);

@@ -45,7 +45,7 @@ __device__ __forceinline__ bool lens_dist_oulu(float dx, float dy, float &cx, fl
     oulu_terms(cx, cy, D, rc, d0, d1);
     const float px = (float)__dsub_rn(__dadd_rn(__dmul_rn((double)cx, rc), d0), (double)dx);
     const float py = (float)__dsub_rn(__dadd_rn(__dmul_rn((double)cy, rc), d1), (double)dy);
-    return !(__fsqrt_rn(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py))) > 0.25f);
+    return !(sqrtf(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py))) > 0.25f);
 }
 
 __global__ void undistort_kernel(float *__restrict__ p1, float *__restrict__ p2, int n, Dist8 D1, Dist8 D2,

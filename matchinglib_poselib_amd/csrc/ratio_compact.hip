@@ -14,8 +14,12 @@ namespace mlpl {
 
 namespace {
 
+// nms_emit (BRUTEFORCENMS, nmslib_matchers.h:360-414): with k == 2 and NO ratio test every query is emitted and, when the two
+// distances tie, NMSLIB's sorted list starts with the LARGER id (heap pop order kept by std::sort); with the ratio test the
+// predicate is the same d0 < ratio*d1.  nms_emit: 0 = LINEAR semantics, 1 = NMS with ratio test, 2 = NMS without.
 template <bool kFloat>
-__device__ __forceinline__ bool ratio_pred(const void *dist_v, size_t qi, int k, float ratio, float &d0) {
+__device__ __forceinline__ bool ratio_pred(const void *dist_v, size_t qi, int k, float ratio, float &d0, int nms_emit = 0,
+                                           bool *tie = nullptr) {
     float d1 = 0.f;
     if constexpr (kFloat) {
         const float *df = reinterpret_cast<const float *>(dist_v);
@@ -26,18 +30,20 @@ __device__ __forceinline__ bool ratio_pred(const void *dist_v, size_t qi, int k,
         d0 = (float)di[qi * k];
         if (k == 2) d1 = (float)di[qi * k + 1];
     }
+    if (tie) *tie = (k == 2) && (d0 == d1);
+    if (nms_emit == 2) return true;
     return (k == 2) ? (d0 < __fmul_rn(ratio, d1)) : true;
 }
 
 template <bool kFloat>
 __global__ __launch_bounds__(kCountGroup) void ratio_count_kernel(const void *__restrict__ dist_v, int nq, int k, float ratio,
-                                                                  int32_t *__restrict__ group_counts) {
+                                                                  int32_t *__restrict__ group_counts, int nms_emit) {
     static_assert(kCountGroup == 64, "one wave per count group");
     const int b = blockIdx.y, tid = threadIdx.x;
     const int qi = blockIdx.x * kCountGroup + tid;
     bool pass = false;
     float d0;
-    if (qi < nq) pass = ratio_pred<kFloat>(dist_v, (size_t)b * nq + qi, k, ratio, d0);
+    if (qi < nq) pass = ratio_pred<kFloat>(dist_v, (size_t)b * nq + qi, k, ratio, d0, nms_emit);
     const unsigned long long bal = __ballot(pass);
     if (tid == 0) group_counts[(size_t)b * gridDim.x + blockIdx.x] = __popcll(bal);
 }
@@ -46,7 +52,7 @@ template <bool kFloat>
 __global__ __launch_bounds__(kRatioGroup) void ratio_write_kernel(const int32_t *__restrict__ idx, const void *__restrict__ dist_v,
                                                                   const int32_t *__restrict__ group_counts, int nq, int k,
                                                                   float ratio, mlpl_dmatch *__restrict__ out,
-                                                                  int32_t *__restrict__ n_out) {
+                                                                  int32_t *__restrict__ n_out, int nms_emit) {
     __shared__ int red[kRatioGroup / 64];
     __shared__ int wave_tot[kRatioGroup / 64];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -61,9 +67,9 @@ __global__ __launch_bounds__(kRatioGroup) void ratio_write_kernel(const int32_t 
     if (lane == 0) red[wave] = part;
 
     const int qi = grp * kRatioGroup + tid;
-    bool pass = false;
+    bool pass = false, tie = false;
     float d0 = 0.f;
-    if (qi < nq) pass = ratio_pred<kFloat>(dist_v, (size_t)b * nq + qi, k, ratio, d0);
+    if (qi < nq) pass = ratio_pred<kFloat>(dist_v, (size_t)b * nq + qi, k, ratio, d0, nms_emit, &tie);
     const unsigned long long bal = __ballot(pass);
     const int lane_prefix = __popcll(bal & ((1ull << lane) - 1ull));
     if (lane == 0) wave_tot[wave] = __popcll(bal);
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(kRatioGroup) void ratio_write_kernel(const int32_t 
     if (pass) {
         mlpl_dmatch m;
         m.queryIdx = qi;
-        m.trainIdx = idx[((size_t)b * nq + qi) * k];
+        m.trainIdx = idx[((size_t)b * nq + qi) * k + ((nms_emit == 2 && tie) ? 1 : 0)];
         m.imgIdx = -1;
         m.distance = d0;
         out[(size_t)b * nq + base + wave_prefix + lane_prefix] = m;
@@ -117,7 +123,7 @@ int launch_gather_match_points(const mlpl_dmatch *d_matches, int n, const float 
 
 int launch_ratio_compact(mlpl_ctx *ctx, const int32_t *d_idx, const void *d_dist, int dist_is_float, int nq, int k,
                          int batch, float ratio, mlpl_dmatch *d_out, int32_t *d_n_out, hipStream_t s,
-                         int32_t *d_group_counts_ready) {
+                         int32_t *d_group_counts_ready, int nms_emit) {
     if (!d_idx || !d_dist || !d_out || !d_n_out || nq < 0 || batch < 1 || batch > 65535 || (k != 1 && k != 2)) {
         set_error("ratio_compact: bad arguments");
         return MLPL_E_BAD_INPUT;
@@ -137,16 +143,16 @@ int launch_ratio_compact(mlpl_ctx *ctx, const int32_t *d_idx, const void *d_dist
         gc = (int32_t *)buf;
         dim3 cgrid(ncnt, batch);
         if (dist_is_float)
-            hipLaunchKernelGGL(ratio_count_kernel<true>, cgrid, dim3(kCountGroup), 0, s, d_dist, nq, k, ratio, gc);
+            hipLaunchKernelGGL(ratio_count_kernel<true>, cgrid, dim3(kCountGroup), 0, s, d_dist, nq, k, ratio, gc, nms_emit);
         else
-            hipLaunchKernelGGL(ratio_count_kernel<false>, cgrid, dim3(kCountGroup), 0, s, d_dist, nq, k, ratio, gc);
+            hipLaunchKernelGGL(ratio_count_kernel<false>, cgrid, dim3(kCountGroup), 0, s, d_dist, nq, k, ratio, gc, nms_emit);
     }
     if (dist_is_float)
         hipLaunchKernelGGL(ratio_write_kernel<true>, grid, dim3(kRatioGroup), 0, s, d_idx, d_dist, gc, nq, k, ratio, d_out,
-                           d_n_out);
+                           d_n_out, nms_emit);
     else
         hipLaunchKernelGGL(ratio_write_kernel<false>, grid, dim3(kRatioGroup), 0, s, d_idx, d_dist, gc, nq, k, ratio, d_out,
-                           d_n_out);
+                           d_n_out, nms_emit);
     MLPL_HIP_TRY(hipGetLastError());
     return MLPL_OK;
 }

@@ -108,8 +108,9 @@ def getMatches(
     """matchinglib::getMatches (matchinglib_matchers.h:61-64).  Returns (err, finalMatches).
 
     err: 0 ok, -1 wrong input data, -2 matcher not supported, -3 matching failed (< 2 matches),
-    -4 too few keypoints (matchers.cpp:109-114).  Only matcher_name == "LINEAR" is built in this library
-    (the brute-force hot path); every other name -- including the reference's default "GMBSOF" -- yields -2.
+    -4 too few keypoints (matchers.cpp:109-114).  matcher_name "LINEAR" (cvflann brute force, matchers.cpp:525-714) and
+    "BRUTEFORCENMS" (NMSLIB seq_search, matchers.cpp:476-519, with its 240-bit / sqrt-L2 semantics) are built in this
+    library; every other name -- including the reference's default "GMBSOF" -- yields -2.
     A dtype mismatch raises ValueError where the reference's CV_Assert throws cv::Exception (matchers.cpp:119).
     """
     d1 = np.asarray(descriptors1)
@@ -122,7 +123,7 @@ def getMatches(
         return -4, empty
     if d1.ndim != 2 or d2.ndim != 2 or n1 != d1.shape[0] or n2 != d2.shape[0]:
         return -1, empty
-    if matcher_name != "LINEAR":
+    if matcher_name not in ("LINEAR", "BRUTEFORCENMS"):
         return -2, empty
     if VFCrefine:
         raise NotImplementedError("VFC refinement (matchers.cpp:722-733) is outside the hot path built here")
@@ -139,7 +140,8 @@ def getMatches(
     d2 = _rows_2d(d2, d2.dtype)
     out = np.empty(max(n1, 1), DMATCH_DTYPE)
     n = C.c_int(0)
-    rc = ctx.lib.mlpl_get_matches_linear(
+    entry = ctx.lib.mlpl_get_matches_linear if matcher_name == "LINEAR" else ctx.lib.mlpl_get_matches_bruteforce_nms
+    rc = entry(
         ctx.handle, n1, n2, d1.ctypes.data, d1.shape[0], d1.strides[0], d2.ctypes.data, d2.shape[0], d2.strides[0],
         d1.shape[1], desc_type, 1 if ratioTest else 0, out.ctypes.data, C.byref(n))
     if rc in (0, -3):

@@ -199,3 +199,87 @@ int oracle_get_matches_linear(int n_kp1, int n_kp2, const void *desc1, int rows1
     if (*n_out < 2) return -3;                           /* matchers.cpp:709-713 */
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * BRUTEFORCENMS: matchers.cpp:476-519 -> nmslibMatching<dist_t>(..., "seq_search", "bit_hamming"|"l2")
+ * (M/include/nmslib/nmslib_matchers.h:159-424) on the vendored NMSLIB.  Restated from the vendored sources:
+ *   - CV_8U rows are packed two bytes per int and handed to NMSLIB without the trailing length word, and
+ *     SpaceBitHamming::HiddenDistance uses datalength/4 - 1 words (similarity_search/src/space/space_bit_hamming.cc:33-42):
+ *     the LAST int is ignored, i.e. the last two bytes (one byte for odd widths) never take part -- ORB-256 is compared on
+ *     240 bits;
+ *   - CV_32F: SpaceLp<float>(2) = L2NormSIMD = sqrt(L2SqrSIMD) (src/distcomp_lp.cc:399-457): four lane accumulators over
+ *     4-float chunks, res = ((t0+t1)+t2)+t3, scalar tail, then sqrtf -- TRUE distances, not squared;
+ *   - K = 2 always; KNNQueue keeps a candidate only if dist < current worst (include/knnqueue.h:57-66), i.e. the two
+ *     lexicographically smallest (dist, id) for sequentially allocated objects; results are sorted by distance with the
+ *     heap's pop order kept on ties (larger id first), nmslib_matchers.h:360-385;
+ *   - ratio test on the true distances d0 < 0.75f*d1 (:397-406); without ratio test the first sorted entry is emitted;
+ *     matches sorted by queryIdx (:416-420); getMatches applies no minimum-match check on this branch.
+ * The reference builds NMSLIB with -Ofast -march=native (similarity_search/CMakeLists.txt), so its float sums may be
+ * contracted/reassociated on the build machine; this restates the source as written and is pinned against oracle/_ref
+ * (built -O2 -msse4.2, no fast-math).
+ * ---------------------------------------------------------------------------------------------------------------- */
+#include <math.h>
+
+static int nms_eff_bytes(int cols) { return (cols % 2 == 0) ? cols - 2 : cols - 1; }
+
+static float nms_l2(const float *a, const float *b, int qty) {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    const int q4 = qty / 4;
+    for (int c = 0; c < q4; ++c)
+        for (int l = 0; l < 4; ++l) {
+            const float d = a[4 * c + l] - b[4 * c + l];
+            t[l] = t[l] + d * d;
+        }
+    float res = t[0] + t[1] + t[2] + t[3];
+    for (int i = 4 * q4; i < qty; ++i) {
+        const float d = a[i] - b[i];
+        res += d * d;
+    }
+    return sqrtf(res);
+}
+
+/* desc_type 0 = CV_8U, 5 = CV_32F.  out must hold rows1 entries.  Returns the wrapper's code (0). */
+int oracle_get_matches_bruteforce_nms(const void *desc1, int rows1, const void *desc2, int rows2, int cols, int desc_type,
+                                      int ratio_test, oracle_dmatch *out, int *n_out) {
+    *n_out = 0;
+    if (desc_type != 0 && desc_type != 5) return -1;
+    if (rows2 < 2) return -1;
+    lut_init();
+    const int eb = nms_eff_bytes(cols);
+    int n = 0;
+    for (int q = 0; q < rows1; ++q) {
+        double d0 = 1e300, d1 = 1e300; /* two lexicographically smallest (dist, id) */
+        int i0 = -1, i1 = -1;
+        for (int t = 0; t < rows2; ++t) {
+            double d;
+            if (desc_type == 0) {
+                const uint8_t *a = (const uint8_t *)desc1 + (size_t)q * cols, *b = (const uint8_t *)desc2 + (size_t)t * cols;
+                int h = 0;
+                for (int j = 0; j < eb; ++j) h += g_lut[a[j] ^ b[j]];
+                d = (double)h;
+            } else {
+                d = (double)nms_l2((const float *)desc1 + (size_t)q * cols, (const float *)desc2 + (size_t)t * cols, cols);
+            }
+            if (i1 < 0 || d < d1) { /* queue not full, or strictly better than the current worst */
+                if (i0 < 0 || d < d0) {
+                    d1 = d0, i1 = i0;
+                    d0 = d, i0 = t;
+                } else {
+                    d1 = d, i1 = t;
+                }
+            }
+        }
+        /* sorted by distance; on a tie the heap pops the larger id first and std::sort keeps that order */
+        int first = i0;
+        const double fd = d0;
+        if (d0 == d1) first = i1;
+        if (ratio_test && !((float)d0 < 0.75f * (float)d1)) continue;
+        out[n].queryIdx = q;
+        out[n].trainIdx = first;
+        out[n].imgIdx = -1;
+        out[n].distance = (float)fd;
+        ++n;
+    }
+    *n_out = n;
+    return 0;
+}

@@ -59,6 +59,11 @@ int oracle_ratio_filter_f32(const int32_t *idx, const float *dist, int nq, int k
 int oracle_get_matches_linear(int n_kp1, int n_kp2, const void *desc1, int rows1, const void *desc2, int rows2,
                               int cols, int desc_type, int ratio_test, oracle_dmatch *out, int *n_out);
 
+/* getMatches(...,"BRUTEFORCENMS",...) (matchers.cpp:476-519 -> nmslib_matchers.h:159-424), incl. the 240-bit quirk for
+ * CV_8U and true (sqrt) L2 for CV_32F.  desc_type 0/5, dense rows of `cols` elements. */
+int oracle_get_matches_bruteforce_nms(const void *desc1, int rows1, const void *desc2, int rows2, int cols, int desc_type,
+                                      int ratio_test, oracle_dmatch *out, int *n_out);
+
 /* ---- robust pose: P/source/five-point-nister/{five-point,modelest}.cpp, P/source/pose_estim.cpp -- */
 
 /* glibc srand/rand (TYPE_3 additive feedback generator) restated, so that sampling is reproducible

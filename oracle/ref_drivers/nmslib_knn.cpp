@@ -4,7 +4,10 @@
 // NMSLIB sources where they lie; used to pin the CPU restatement (oracle/knn_oracle.c) and to generate the
 // golden vectors under tests/golden/.  This file is ours; it contains no reference source.
 //
-// usage: nmslib_knn <hamming|l2> <in.bin> <out.bin>
+// usage: nmslib_knn <hamming|hamming_wrapper|l2> <in.bin> <out.bin>
+//   hamming_wrapper packs the descriptors exactly like the reference's wrapper (nmslib_matchers.h:214-231): two bytes per
+//   int (b[j] << 8 | b[j+1], an odd last byte alone), Object created WITHOUT the trailing length word, so that
+//   SpaceBitHamming::HiddenDistance (length = datalength/4 - 1) drops the last int -- the 240-bit quirk of BRUTEFORCENMS.
 //   in.bin : int32 nq, nt, width ; then nq*width and nt*width elements (uint8 for hamming, float32 for l2)
 //   out.bin: int32 idx[nq][2] ; then dist[nq][2] (int32 for hamming; float32 = NMSLIB's sqrt L2 for l2)
 // Unlike the matchinglib wrapper (which packs 2 bytes per int and omits the trailing length word, so the last
@@ -66,7 +69,9 @@ int main(int argc, char **argv) {
         fprintf(stderr, "usage: %s <hamming|l2> in.bin out.bin\n", argv[0]);
         return 1;
     }
-    const bool hamming = std::string(argv[1]) == "hamming";
+    const std::string mode = argv[1];
+    const bool wrapper = mode == "hamming_wrapper";
+    const bool hamming = mode == "hamming" || wrapper;
     FILE *f = fopen(argv[2], "rb");
     if (!f) return 2;
     int32_t hdr[3];
@@ -82,7 +87,13 @@ int main(int argc, char **argv) {
         std::unique_ptr<Space<int>> space(SpaceFactoryRegistry<int>::Instance().CreateSpace("bit_hamming", empty));
         SpaceBitHamming *bh = dynamic_cast<SpaceBitHamming *>(space.get());
         const int nw = (width + 3) / 4;
-        auto make = [&](const uint8_t *row, int id) {
+        auto make = [&](const uint8_t *row, int id) -> Object * {
+            if (wrapper) {
+                std::vector<int> v;
+                for (int j = 0; j < width - 1; j += 2) v.push_back(((int)row[j] << 8) | (int)row[j + 1]);
+                if (width % 2) v.push_back((int)row[width - 1]);
+                return new Object(id, 0, v.size() * sizeof(int), &v[0]);
+            }
             std::vector<uint32_t> w(nw, 0u);
             memcpy(w.data(), row, width);
             return bh->CreateObjFromVect(id, 0, w);  // appends the length word

@@ -34,7 +34,7 @@ def run_nmslib(mode, q, t):
             t.tofile(f)
         subprocess.run([tool, mode, fin, fout], check=True)
         n = q.shape[0] * 2
-        if mode == "hamming":
+        if mode.startswith("hamming"):
             raw = np.fromfile(fout, np.int32)
             return raw[:n].reshape(-1, 2), raw[n:].reshape(-1, 2)
         idx = np.fromfile(fout, np.int32, count=n).reshape(-1, 2)
@@ -105,8 +105,28 @@ def fivept_case():
     print("fivept_opengv_120: mean #solutions", cnt.mean())
 
 
+def nms_wrapper_case():
+    """BRUTEFORCENMS: expected (idx, dist) straight from the reference's vendored NMSLIB driven with the reference
+    wrapper's own packing (2 bytes per int, no length word => last 2 bytes ignored) and its 'l2' space (sqrt distances)."""
+    out = {}
+    for nb in (32, 31):
+        q, t = synth.orb_pair(200, 260, nbytes=nb, seed=20260120 + nb)
+        idx, dist = run_nmslib("hamming_wrapper", q, t)
+        out[f"u8_{nb}_q"], out[f"u8_{nb}_t"], out[f"u8_{nb}_idx"], out[f"u8_{nb}_dist"] = q, t, idx, dist
+    rng = np.random.default_rng(20260121)
+    t = rng.normal(size=(260, 64)).astype(np.float32)
+    q = rng.normal(size=(200, 64)).astype(np.float32)
+    q[:60] = t[:60] + rng.normal(size=(60, 64)).astype(np.float32) * 0.05
+    idx, dist = run_nmslib("l2", q, t)
+    out["f32_q"], out["f32_t"], out["f32_idx"], out["f32_dist"] = q, t, idx, dist
+    np.savez_compressed(os.path.join(HERE, "bruteforce_nms.npz"), **out)
+    print("bruteforce_nms: ok")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("all", "nms"):
+        nms_wrapper_case()
     if what in ("all", "matching"):
         main()
     if what in ("all", "pose"):

@@ -208,6 +208,21 @@ class Oracle:
         return rc, out[: n.value].copy()
 
 
+def _nms(self, d1, d2, ratio_test=True):
+    d1 = np.ascontiguousarray(d1)
+    d2 = np.ascontiguousarray(d2)
+    dt = 0 if d1.dtype == np.uint8 else 5
+    out = np.empty(max(d1.shape[0], 1), DMATCH)
+    n = C.c_int(0)
+    self.lib.oracle_get_matches_bruteforce_nms.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                           C.c_void_p, C.POINTER(C.c_int)]
+    rc = self.lib.oracle_get_matches_bruteforce_nms(d1.ctypes.data, d1.shape[0], d2.ctypes.data, d2.shape[0], d1.shape[1], dt,
+                                                    int(ratio_test), out.ctypes.data, C.byref(n))
+    return rc, out[: n.value].copy()
+
+
+Oracle.get_matches_bruteforce_nms = _nms
+
 _cached = None
 
 

@@ -232,3 +232,35 @@ def test_get_matches_linear_f32(ctx, oracle):
     err, m = mpa.getMatches(kp1, kp2, q, t, matcher_name="LINEAR", ctx=ctx)
     rc, o = oracle.get_matches_linear(1500, 1800, q, t)
     assert err == rc == 0 and m.tobytes() == o.tobytes()
+
+
+@pytest.mark.parametrize("nb", [32, 31, 16, 64, 3])
+@pytest.mark.parametrize("ratio", [True, False])
+def test_bruteforce_nms_u8(ctx, oracle, nb, ratio):
+    q, t = synth.orb_pair(400, 700, nbytes=nb, seed=600 + nb)
+    if nb > 3:
+        t[9] = t[4]
+        q[3] = t[4]          # exact tie between two train rows: without ratio test NMSLIB emits the larger id
+    kp = lambda n: [None] * n  # noqa: E731
+    err, m = mpa.getMatches(kp(400), kp(700), q, t, matcher_name="BRUTEFORCENMS", ratioTest=ratio, ctx=ctx)
+    rc, o = oracle.get_matches_bruteforce_nms(q, t, ratio_test=ratio)
+    assert err == rc == 0
+    assert m.tobytes() == o.tobytes()
+    if not ratio and nb > 3:
+        assert m["trainIdx"][3] == 9
+
+
+@pytest.mark.parametrize("dim", [128, 64, 30, 7])
+@pytest.mark.parametrize("ratio", [True, False])
+def test_bruteforce_nms_f32(ctx, oracle, dim, ratio):
+    rng = np.random.default_rng(70 + dim)
+    t = rng.normal(size=(500, dim)).astype(np.float32)
+    q = rng.normal(size=(300, dim)).astype(np.float32)
+    q[:100] = t[:100] + rng.normal(size=(100, dim)).astype(np.float32) * 0.05
+    kp = lambda n: [None] * n  # noqa: E731
+    err, m = mpa.getMatches(kp(300), kp(500), q, t, matcher_name="BRUTEFORCENMS", ratioTest=ratio, ctx=ctx)
+    rc, o = oracle.get_matches_bruteforce_nms(q, t, ratio_test=ratio)
+    assert err == rc == 0
+    assert m.tobytes() == o.tobytes()
+    if ratio:
+        assert len(m) >= 90   # sqrt distances: the ratio test is applied to TRUE distances here
