@@ -60,7 +60,8 @@ int mlpl_ctx_device(mlpl_ctx *ctx);
 int mlpl_ctx_synchronize(mlpl_ctx *ctx);
 
 /* Tuning knobs (performance only, never results): "hamming_variant" 0 = LDS-tiled broadcast reads, 1 = scalar-load
- * kernel (default); "hamming_qpl" queries per lane 1|2; "hamming_blocks_per_cu" grid sizing target. */
+ * kernel; "hamming_qpl" queries per lane 1|2; "hamming_blocks_per_cu" grid sizing target; "ransac_chunk" hypotheses per
+ * device pass (0 = 32768; the sequential best/niters rule is replayed across passes). */
 int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value);
 
 /* ---- in-library kernel timing (for roofline accounting) ------------------------------------------------------

@@ -61,6 +61,7 @@ struct mlpl_ctx {
     int opt_hamming_variant;        // 0 = LDS-tiled broadcast reads, 1 = scalar-load (SGPR operand) kernel
     int opt_hamming_qpl;            // queries per lane for variant 1 (1 or 2)
     int opt_hamming_blocks_per_cu;  // grid sizing target
+    int opt_ransac_chunk;           // hypotheses per device pass (0 = 32768)
     // cached table T[g] = cvRANSACUpdateNumIters1(conf, (n-g)/n, 5, inf) for the last (n, conf) (host libm values)
     int32_t *ransac_T_host;
     int ransac_T_n;

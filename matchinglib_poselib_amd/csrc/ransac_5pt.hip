@@ -1027,7 +1027,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     int rc = pack_points(ctx, d_p1, d_p2, n, &pts, s);
     if (rc) return rc;
 
-    const int kChunk = 32768;
+    const int kChunk = ctx->opt_ransac_chunk > 0 ? ctx->opt_ransac_chunk : 32768;
     const int chunk_cap = std::min(max_iters, kChunk);
     RansacBuffers B;
     if ((rc = alloc_ransac(ctx, chunk_cap, B))) return rc;

@@ -144,3 +144,36 @@ def test_estimate_relative_pose_end_to_end(ctx):
     assert ok
     assert np.abs(Rg - R).max() < 5e-3 and np.abs(tg.ravel() - t).max() < 2e-2
     assert (m != 0).sum() > 1700
+
+
+def test_ransac_multi_chunk_replay(ctx, oracle):
+    """max_iters above the per-pass capacity: the replay state (best model, niters, iteration count) is carried across
+    device passes.  A small pass size forces many passes; results must not depend on it."""
+    from matchinglib_poselib_amd import _lib
+    p1, p2, R, t, mask, th = synth.pose_scene(1500, seed=41)
+    o = oracle.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, lesqu=True, seed=9)
+    o1 = oracle.ransac_essential(p1, p2, th, confidence=1.0, max_iters=700, lesqu=False, seed=10)
+    for chunk in (64, 100, 0):
+        _lib.check(ctx.lib.mlpl_set_option(ctx.handle, b"ransac_chunk", chunk), "set_option")
+        g = pose.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, refit=True, seed=9, ctx=ctx)
+        assert g["iters"] == o["iters"] and g["n_inliers"] == o["n_inliers"], chunk
+        assert e_dist(g["E"], o["E"]) < 1e-7
+        g1 = pose.ransac_essential(p1, p2, th, confidence=1.0, max_iters=700, refit=False, seed=10, ctx=ctx)
+        assert g1["iters"] == 700 and g1["n_inliers"] == o1["n_inliers"] and e_dist(g1["E"], o1["E"]) < 1e-8
+        assert np.array_equal(g1["mask"], o1["mask"])
+    _lib.check(ctx.lib.mlpl_set_option(ctx.handle, b"ransac_chunk", 0), "set_option")
+
+
+def test_large_shapes_sampled(ctx, oracle):
+    """Bigger-than-C2 shapes (many splits, several LDS tiles per block): sampled rows against the oracle."""
+    import matchinglib_poselib_amd as mpa
+    q, t = synth.orb_pair(20000, 50000, seed=123)
+    idx, dist = mpa.knn_hamming(q, t, ctx=ctx)
+    sub = np.arange(0, 20000, 397)
+    oi, od = oracle.knn_hamming(q[sub], t)
+    assert np.array_equal(idx[sub], oi) and np.array_equal(dist[sub], od)
+    qf, tf = synth.sift_pair(5000, 20000, seed=124)
+    idx, dist = mpa.knn_l2sq(qf, tf, ctx=ctx)
+    sub = np.arange(0, 5000, 211)
+    oi, od = oracle.knn_l2sq(qf[sub], tf)
+    assert np.array_equal(idx[sub], oi) and dist[sub].tobytes() == od.tobytes()
