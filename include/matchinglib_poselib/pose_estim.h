@@ -26,7 +26,7 @@ bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p
                           double threshold = PIX_MIN_GOOD_TH, bool refine = true, cv::OutputArray mask = cv::noArray());
 
 // poselib::getPoseTriangPts (pose_estim.h:192-200, pose_estim.cpp:913-946).  Returns the number of valid 3-D points,
-// or -1 when R, t or Q is cv::noArray().  translatE = true is not supported (returns -1).
+// or -1 when R, t or Q is cv::noArray().  translatE = true: E is a translational essential matrix, R = I.
 int getPoseTriangPts(cv::InputArray E, cv::InputArray p1, cv::InputArray p2, cv::OutputArray R, cv::OutputArray t,
                      cv::OutputArray Q, cv::InputOutputArray mask = cv::noArray(), const double dist = 50.0,
                      bool translatE = false);

@@ -213,6 +213,10 @@ int mlpl_debug_dk_stats(mlpl_ctx *ctx, int enable, int stats[3]);
  */
 int mlpl_recover_pose(mlpl_ctx *ctx, const double E[9], const double *p1, const double *p2, int n, double dist,
                       double R[9], double t[3], double *Q, uint8_t *mask_inout);
+/* The same with `t_only` given (getPoseTriangPts(..., translatE = true), five-point.cpp:178-193): R = I and only the two
+ * candidates [I|t], [I|-t] compete.  t_only = getTfromTransEssential(E) (P/source/pose_helper.cpp:422-433). */
+int mlpl_recover_pose_translation(mlpl_ctx *ctx, const double t_only[3], const double *p1, const double *p2, int n,
+                                  double dist, double R[9], double t[3], double *Q, uint8_t *mask_inout);
 
 #ifdef __cplusplus
 }

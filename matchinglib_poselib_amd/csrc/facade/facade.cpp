@@ -118,10 +118,19 @@ bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p
         std::vector<double> a = points64(p1, n1), b = points64(p2, n2);
         CV_Assert(n1 >= 5 && n1 == n2);  // five-point.cpp:81
         if (n1 == 5) {
-            std::cout << "estimateEssentialMat: exactly 5 correspondences (minimal case) is served by mlpl_solve_5pt, not by "
-                         "the RANSAC entry."
-                      << std::endl;
-            return false;
+            // five-point.cpp:108-114: the minimal case runs the solver once and returns up to 10 stacked 3x3 matrices
+            const int32_t samples[5] = {0, 1, 2, 3, 4};
+            double Es[90];
+            int32_t nm = 0;
+            if (mlpl_solve_5pt(default_ctx(), a.data(), b.data(), 5, samples, 1, Es, &nm) != MLPL_OK)
+                throw cv::Exception(std::string("mlpl_solve_5pt: ") + mlpl_last_error());
+            E.create(3 * nm, 3, CV_64F);
+            for (int i = 0; i < 9 * nm; ++i) E.at<double>(i / 3, i % 3) = Es[i];
+            if (cv::needed(mask)) {
+                mask.create(1, 5, CV_8U);
+                std::memset(mask.data, 1, 5);
+            }
+            return true;
         }
         double Ev[9];
         std::vector<uint8_t> m((size_t)n1);
@@ -156,7 +165,6 @@ bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p
 int getPoseTriangPts(cv::InputArray E, cv::InputArray p1, cv::InputArray p2, cv::OutputArray R, cv::OutputArray t,
                      cv::OutputArray Q, cv::InputOutputArray mask, const double dist, bool translatE) {
     if (!cv::needed(R) || !cv::needed(t) || !cv::needed(Q)) return -1;  // pose_estim.cpp:925-926
-    if (translatE) return -1;
     CV_Assert(E.rows == 3 && E.cols == 3 && E.type() == CV_64F);
     int n1 = 0, n2 = 0;
     std::vector<double> a = points64(p1, n1), b = points64(p2, n2);
@@ -173,7 +181,18 @@ int getPoseTriangPts(cv::InputArray E, cv::InputArray p1, cv::InputArray p2, cv:
             for (int i = 0; i < n1; ++i) m[i] = mask.rows == 1 ? mask.at<uint8_t>(0, i) : mask.at<uint8_t>(i, 0);
         }
     }
-    const int rc = mlpl_recover_pose(default_ctx(), Ev, a.data(), b.data(), n1, dist, Rv, tv, Qv.data(), use_mask ? m.data() : nullptr);
+    int rc;
+    if (translatE) {
+        // getTfromTransEssential (pose_helper.cpp:422-433)
+        double t0[3] = {E.at<double>(1, 2), E.at<double>(2, 0), E.at<double>(0, 1)};
+        const double nrm = std::sqrt(t0[0] * t0[0] + t0[1] * t0[1] + t0[2] * t0[2]);
+        if (std::abs(nrm - 1.0) > 1e-3)
+            for (double &v : t0) v /= nrm;
+        rc = mlpl_recover_pose_translation(default_ctx(), t0, a.data(), b.data(), n1, dist, Rv, tv, Qv.data(),
+                                           use_mask ? m.data() : nullptr);
+    } else {
+        rc = mlpl_recover_pose(default_ctx(), Ev, a.data(), b.data(), n1, dist, Rv, tv, Qv.data(), use_mask ? m.data() : nullptr);
+    }
     if (rc < 0) throw cv::Exception(std::string("mlpl_recover_pose: ") + mlpl_last_error());
     R.create(3, 3, CV_64F);
     t.create(3, 1, CV_64F);

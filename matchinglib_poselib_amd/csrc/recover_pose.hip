@@ -184,9 +184,30 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const double *__restri
 
 using namespace mlpl;
 
+static int recover_pose_impl(mlpl_ctx *ctx, const double *E, const double *t_only, const double *p1, const double *p2, int n,
+                             double dist, double *R, double *t, double *Q, uint8_t *mask_inout);
+
 extern "C" int mlpl_recover_pose(mlpl_ctx *ctx, const double E[9], const double *p1, const double *p2, int n, double dist,
                                  double R[9], double t[3], double *Q, uint8_t *mask_inout) {
-    if (!ctx || !E || !p1 || !p2 || !R || !t || !Q || n < 0) {
+    if (!E) {
+        set_error("mlpl_recover_pose: E is mandatory");
+        return MLPL_E_BAD_INPUT;
+    }
+    return recover_pose_impl(ctx, E, nullptr, p1, p2, n, dist, R, t, Q, mask_inout);
+}
+
+extern "C" int mlpl_recover_pose_translation(mlpl_ctx *ctx, const double t_only[3], const double *p1, const double *p2, int n,
+                                             double dist, double R[9], double t[3], double *Q, uint8_t *mask_inout) {
+    if (!t_only) {
+        set_error("mlpl_recover_pose_translation: t_only is mandatory");
+        return MLPL_E_BAD_INPUT;
+    }
+    return recover_pose_impl(ctx, nullptr, t_only, p1, p2, n, dist, R, t, Q, mask_inout);
+}
+
+static int recover_pose_impl(mlpl_ctx *ctx, const double *E, const double *t_only, const double *p1, const double *p2, int n,
+                             double dist, double *R, double *t, double *Q, uint8_t *mask_inout) {
+    if (!ctx || !p1 || !p2 || !R || !t || !Q || n < 0) {
         set_error("mlpl_recover_pose: R, t and Q are mandatory outputs");  // pose_estim.cpp:925-926 returns -1
         return MLPL_E_BAD_INPUT;
     }
@@ -204,14 +225,29 @@ extern "C" int mlpl_recover_pose(mlpl_ctx *ctx, const double E[9], const double 
     double *dP = dE + 16;                  // 69
     int32_t *dcnt = (int32_t *)(dE + 96);  // 4
     uint8_t *dmask_in = (uint8_t *)dmask + nn * 4;
-    MLPL_HIP_TRY(hipMemcpyAsync(dE, E, 72, hipMemcpyHostToDevice, s));
+    double hPt[69];
+    if (E) {
+        MLPL_HIP_TRY(hipMemcpyAsync(dE, E, 72, hipMemcpyHostToDevice, s));
+    } else {
+        // five-point.cpp:180-193 with t_only given: R1 = I, P1 = [I|t], P3 = [I|-t]; the R2 candidates do not exist
+        // (their slots repeat P1/P3 and their counts are forced to 0 below)
+        const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 3; ++r) {
+                for (int k = 0; k < 3; ++k) hPt[c * 12 + r * 4 + k] = I3[r * 3 + k];
+                hPt[c * 12 + r * 4 + 3] = (c < 2 ? 1.0 : -1.0) * t_only[r];
+            }
+        for (int i = 0; i < 9; ++i) hPt[48 + i] = hPt[57 + i] = I3[i];
+        for (int i = 0; i < 3; ++i) hPt[66 + i] = t_only[i];
+        MLPL_HIP_TRY(hipMemcpyAsync(dP, hPt, sizeof(hPt), hipMemcpyHostToDevice, s));
+    }
     MLPL_HIP_TRY(hipMemsetAsync(dcnt, 0, 16, s));
     if (n > 0) {
         MLPL_HIP_TRY(hipMemcpyAsync(dp1, p1, (size_t)n * 16, hipMemcpyHostToDevice, s));
         MLPL_HIP_TRY(hipMemcpyAsync(dp2, p2, (size_t)n * 16, hipMemcpyHostToDevice, s));
         if (mask_inout) MLPL_HIP_TRY(hipMemcpyAsync(dmask_in, mask_inout, (size_t)n, hipMemcpyHostToDevice, s));
     }
-    hipLaunchKernelGGL(decompose_kernel, dim3(1), dim3(64), 0, s, (const double *)dE, dP);
+    if (E) hipLaunchKernelGGL(decompose_kernel, dim3(1), dim3(64), 0, s, (const double *)dE, dP);
     if (n > 0) {
         prof_mark(ctx, MLPL_PROF_RECOVER_POSE, 0, s);
         hipLaunchKernelGGL(triangulate_kernel, dim3((n + 255) / 256, 4), dim3(256), 0, s, (const double *)dP, (const double *)dp1,
@@ -225,7 +261,7 @@ extern "C" int mlpl_recover_pose(mlpl_ctx *ctx, const double E[9], const double 
     MLPL_HIP_TRY(hipMemcpyAsync(cnt, dcnt, 16, hipMemcpyDeviceToHost, s));
     MLPL_HIP_TRY(hipMemcpyAsync(hP, dP, sizeof(hP), hipMemcpyDeviceToHost, s));
     MLPL_HIP_TRY(hipStreamSynchronize(s));
-    const int good1 = cnt[0], good2 = cnt[1], good3 = cnt[2], good4 = cnt[3];
+    const int good1 = cnt[0], good2 = E ? cnt[1] : 0, good3 = cnt[2], good4 = E ? cnt[3] : 0;
     // five-point.cpp:299-336
     int pick, ret;
     if (good1 >= good2 && good1 >= good3 && good1 >= good4) {

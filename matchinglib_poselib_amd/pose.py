@@ -100,6 +100,12 @@ def estimateEssentialMat(p1, p2, method: str = "ARRSAC", threshold: float = PIX_
     if method == "RANSAC":
         import time
 
+        a, b = _pts(p1), _pts(p2)
+        if a.shape[0] == 5:
+            # findEssentialMat's minimal case (five-point.cpp:108-114): one solver call, up to 10 stacked 3x3 matrices,
+            # mask all true
+            Es, nm = solve_5pt(a, b, np.arange(5, dtype=np.int32)[None, :], ctx=ctx)
+            return True, Es[0, : nm[0]].reshape(-1, 3).copy(), np.ones(5, np.uint8)
         s = int(time.time()) if seed is None else seed
         r = ransac_essential(p1, p2, threshold, confidence=0.999, max_iters=1000, refit=refine, seed=s, ctx=ctx)
         return r["ok"], r["E"], r["mask"]
@@ -115,16 +121,25 @@ def estimateEssentialMat(p1, p2, method: str = "ARRSAC", threshold: float = PIX_
 def getPoseTriangPts(E, p1, p2, mask=None, dist: float = 50.0, translatE: bool = False,
                      ctx: Optional[Context] = None):
     """poselib::getPoseTriangPts (pose_estim.h:192-200, pose_estim.cpp:913-946) -> (n_good, R, t, Q, mask)."""
-    if translatE:
-        raise NotImplementedError("translational essential matrices (translatE=true) are outside the hot path")
     ctx = ctx or default_context()
     p1, p2 = _pts(p1), _pts(p2)
     E = np.ascontiguousarray(E, np.float64).reshape(3, 3)
     n = p1.shape[0]
     R, t, Q = np.zeros((3, 3)), np.zeros((3, 1)), np.zeros((n, 3))
     m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(-1).copy()
-    rc = ctx.lib.mlpl_recover_pose(ctx.handle, E.ctypes.data, p1.ctypes.data, p2.ctypes.data, n, float(dist),
-                                   R.ctypes.data, t.ctypes.data, Q.ctypes.data, None if m is None else m.ctypes.data)
+    if translatE:
+        # getTfromTransEssential (pose_helper.cpp:422-433): t = (E12, E20, E01), normalised unless already unit
+        tv = np.array([E[1, 2], E[2, 0], E[0, 1]])
+        nrm = float(np.sqrt(tv[0] * tv[0] + tv[1] * tv[1] + tv[2] * tv[2]))
+        if abs(nrm - 1.0) > 1e-3:
+            tv = tv / nrm
+        tv = np.ascontiguousarray(tv)
+        rc = ctx.lib.mlpl_recover_pose_translation(ctx.handle, tv.ctypes.data, p1.ctypes.data, p2.ctypes.data, n, float(dist),
+                                                   R.ctypes.data, t.ctypes.data, Q.ctypes.data,
+                                                   None if m is None else m.ctypes.data)
+    else:
+        rc = ctx.lib.mlpl_recover_pose(ctx.handle, E.ctypes.data, p1.ctypes.data, p2.ctypes.data, n, float(dist),
+                                       R.ctypes.data, t.ctypes.data, Q.ctypes.data, None if m is None else m.ctypes.data)
     if rc < 0:
         raise MlplError(rc, "mlpl_recover_pose", _lib.last_error())
     return rc, R, t, Q, m

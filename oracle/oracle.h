@@ -120,6 +120,9 @@ void oracle_decompose_essential(const double *E, double *R1, double *R2, double 
 int oracle_recover_pose(const double *E, const double *p1, const double *p2, int n, double dist, double *R,
                         double *t, double *Q, uint8_t *mask_inout);
 
+int oracle_recover_pose_translation(const double *Et, const double *p1, const double *p2, int n, double dist, double *R,
+                                    double *t, double *Q, uint8_t *mask_inout);
+
 /* cv::triangulatePoints for one correspondence with P0=[I|0], P1=[R|t] (unit-norm homogeneous X). */
 void oracle_triangulate_point(const double *P0, const double *P1, const double *x1, const double *x2, double *X4);
 

@@ -712,10 +712,36 @@ void oracle_triangulate_point(const double *P0, const double *P1, const double *
     for (int k = 0; k < 4; ++k) X4[k] = V[k * 4 + 3];
 }
 
+static int recover_pose_impl(const double *E, const double *t_only, const double *p1, const double *p2, int n, double dist,
+                             double *R, double *t, double *Q, uint8_t *mask_inout);
+
 int oracle_recover_pose(const double *E, const double *p1, const double *p2, int n, double dist, double *R, double *t,
                         double *Q, uint8_t *mask_inout) {
+    return recover_pose_impl(E, NULL, p1, p2, n, dist, R, t, Q, mask_inout);
+}
+
+/* getTfromTransEssential (pose_helper.cpp:422-433) + recoverPose with t_only (five-point.cpp:178-193): R1 = I, only
+ * [I|t] and [I|-t] are tested (good2 = good4 = 0). */
+int oracle_recover_pose_translation(const double *Et, const double *p1, const double *p2, int n, double dist, double *R,
+                                    double *t, double *Q, uint8_t *mask_inout) {
+    double tv[3] = {Et[1 * 3 + 2], Et[2 * 3 + 0], Et[0 * 3 + 1]};
+    const double nrm = sqrt(tv[0] * tv[0] + tv[1] * tv[1] + tv[2] * tv[2]);
+    if (fabs(nrm - 1.0) > 1e-3)
+        for (int i = 0; i < 3; ++i) tv[i] /= nrm;
+    return recover_pose_impl(NULL, tv, p1, p2, n, dist, R, t, Q, mask_inout);
+}
+
+static int recover_pose_impl(const double *E, const double *t_only, const double *p1, const double *p2, int n, double dist,
+                             double *R, double *t, double *Q, uint8_t *mask_inout) {
     double R1[9], R2[9], tv[3];
-    oracle_decompose_essential(E, R1, R2, tv);
+    if (E) {
+        oracle_decompose_essential(E, R1, R2, tv);
+    } else {
+        const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        memcpy(R1, I3, sizeof(I3));
+        memcpy(R2, I3, sizeof(I3));
+        memcpy(tv, t_only, sizeof(tv));
+    }
     const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     double P[4][12];
     const double *Rs[4] = {R1, R2, R1, R2};
@@ -746,7 +772,7 @@ int oracle_recover_pose(const double *E, const double *p1, const double *p2, int
             good[c] += (mv != 0);
         }
     }
-    const int good1 = good[0], good2 = good[1], good3 = good[2], good4 = good[3];
+    const int good1 = good[0], good2 = E ? good[1] : 0, good3 = good[2], good4 = E ? good[3] : 0;
     int pick = -1, ret;
     if (good1 >= good2 && good1 >= good3 && good1 >= good4) {
         pick = 0;

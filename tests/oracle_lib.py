@@ -114,6 +114,18 @@ class Oracle:
                                             t.ctypes.data, Q.ctypes.data, None if m is None else m.ctypes.data)
         return good, R, t, Q, m
 
+    def recover_pose_translation(self, Et, p1, p2, dist=50.0, mask=None):
+        p1 = np.ascontiguousarray(p1, np.float64)
+        p2 = np.ascontiguousarray(p2, np.float64)
+        Et = np.ascontiguousarray(Et, np.float64)
+        n = p1.shape[0]
+        R, t, Q = np.zeros((3, 3)), np.zeros(3), np.zeros((n, 3))
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).copy()
+        self.lib.oracle_recover_pose_translation.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_double] + [C.c_void_p] * 4
+        good = self.lib.oracle_recover_pose_translation(Et.ctypes.data, p1.ctypes.data, p2.ctypes.data, n, dist, R.ctypes.data,
+                                                        t.ctypes.data, Q.ctypes.data, None if m is None else m.ctypes.data)
+        return good, R, t, Q, m
+
     def decompose_essential(self, E):
         E = np.ascontiguousarray(E, np.float64)
         R1, R2, t = np.zeros((3, 3)), np.zeros((3, 3)), np.zeros(3)

@@ -177,3 +177,29 @@ def test_large_shapes_sampled(ctx, oracle):
     sub = np.arange(0, 5000, 211)
     oi, od = oracle.knn_l2sq(qf[sub], tf)
     assert np.array_equal(idx[sub], oi) and dist[sub].tobytes() == od.tobytes()
+
+
+def test_recover_pose_translation_only(ctx, oracle):
+    """getPoseTriangPts(..., translatE=true): R = I, candidates [I|t] and [I|-t] only (five-point.cpp:178-193)."""
+    rng = np.random.default_rng(8)
+    tt = np.array([0.9, -0.1, 0.3])
+    tt /= np.linalg.norm(tt)
+    X = np.stack([rng.uniform(-2, 2, 400), rng.uniform(-2, 2, 400), rng.uniform(4, 12, 400)], axis=1)
+    p1 = X[:, :2] / X[:, 2:3]
+    X2 = X + tt
+    p2 = X2[:, :2] / X2[:, 2:3]
+    Et = np.array([[0, -tt[2], tt[1]], [tt[2], 0, -tt[0]], [-tt[1], tt[0], 0]])
+    for Ein in (Et, -Et, 2.0 * Et):
+        go, Ro, to, Qo, mo = oracle.recover_pose_translation(Ein, p1, p2, 50.0, None)
+        gg, Rg, tg, Qg, mg = pose.getPoseTriangPts(Ein, p1, p2, None, 50.0, translatE=True, ctx=ctx)
+        assert gg == go == 400
+        assert np.array_equal(Rg, np.eye(3)) and np.abs(tg.ravel() - to).max() < 1e-15 and np.abs(tg.ravel() - tt).max() < 1e-12
+        assert np.allclose(Qg, Qo, rtol=1e-9, atol=1e-9)
+
+
+def test_estimate_essential_minimal_five_points(ctx, oracle):
+    p1, p2, R, t, mask, th = synth.pose_scene(50, inlier_frac=1.0, seed=2, noise_px=0.0)
+    ok, Es, m = pose.estimateEssentialMat(p1[:5], p2[:5], "RANSAC", th, ctx=ctx)
+    Eo = oracle.run5point(p1[:5], p2[:5])
+    assert ok and Es.shape == (3 * len(Eo), 3) and m.tolist() == [1] * 5
+    assert match_sets(Es.reshape(-1, 3, 3), Eo, 1e-7)
