@@ -30,19 +30,27 @@ def run(ctx, dev, cpu_baseline=True):
     d1 = torch.from_numpy(p1).to(dev)
     d2 = torch.from_numpy(p2).to(dev)
     dm = torch.empty(n, dtype=torch.uint8, device=dev)
-    pose.ransac_essential_device(d1, d2, th, confidence=1.0, max_iters=iters, refit=False, seed=12345, ctx=ctx, mask_out=dm)
+    call = lambda: pose.ransac_essential_device(d1, d2, th, confidence=1.0, max_iters=iters, refit=False, seed=12345, ctx=ctx,  # noqa: E731
+                                                mask_out=dm)
+    call()
     torch.cuda.synchronize()
-    ctx.lib.mlpl_profile_reset(ctx.handle)
-    ctx.lib.mlpl_profile_enable(ctx.handle, 1)
-    reps = 5
+    reps = 10
+    ctx.lib.mlpl_profile_enable(ctx.handle, 0)
     t0 = time.perf_counter()
     for _ in range(reps):
-        r = pose.ransac_essential_device(d1, d2, th, confidence=1.0, max_iters=iters, refit=False, seed=12345, ctx=ctx, mask_out=dm)
+        r = call()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    dt = (time.perf_counter() - t0) / reps          # the reported rate: no per-kernel event bracketing
+    ctx.lib.mlpl_profile_reset(ctx.handle)
+    ctx.lib.mlpl_profile_enable(ctx.handle, 1)
+    for _ in range(3):
+        call()                                       # second pass only to attribute time to the two kernels
+    torch.cuda.synchronize()
     ctx.lib.mlpl_profile_enable(ctx.handle, 0)
     solve_ms, solve_n = _prof(ctx, 2)
     score_ms, score_n = _prof(ctx, 3)
+    solve_ms, score_ms = solve_ms / 3 * max(solve_n, 1) / max(solve_n, 1), score_ms / 3 * max(score_n, 1) / max(score_n, 1)
+    solve_n = score_n = 1
     # models actually scored: count once through the building-block API on a sample of the hypotheses
     out["ransac_c3"] = {
         "metric": "RANSAC hypotheses/s (5-pt Nister + Sampson on 5000 correspondences, 20000 iterations)",
@@ -51,9 +59,11 @@ def run(ctx, dev, cpu_baseline=True):
         "ms_per_call": dt * 1e3,
         "iters_used": r["iters"],
         "n_inliers": r["n_inliers"],
-        "solve_kernel_ms": solve_ms / max(solve_n, 1),
-        "score_kernel_ms": score_ms / max(score_n, 1),
-        "includes": "host sample table (glibc rand stream), H2D samples, solve + score kernels, D2H tables, host replay, mask",
+        "solve_kernels_ms_per_call": solve_ms,
+        "score_kernel_ms_per_call": score_ms,
+        "score_fp64_tflops_algorithmic": None,
+        "includes": "host sample table (glibc rand stream, pinned/mapped), solve + score + replay + mask kernels, one 200-byte "
+                    "state readback",
     }
     if cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

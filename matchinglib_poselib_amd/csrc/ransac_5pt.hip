@@ -123,7 +123,18 @@ __device__ __forceinline__ void null_vector_3x3(const double *a, double *nv) {
 // ---------------------------------------------------------------------------------------------------------------
 __device__ int g_dk_iters_dbg[4] = {0, 0, 0, 0};  // [sum, count, max, enabled] -- diagnostics only (tools/)
 
-__device__ bool solve_from_basis(SolveLds &L, int lane, double *Eout) {
+// What the per-hypothesis wave hands to the root-finding kernel: the degree-10 polynomial, B(z) and the null-space basis.
+struct PolyRec {
+    double c[11];
+    double b[39];
+    double EE[36];
+    double ok;  // 0 = singular system, no models
+    double pad;
+};
+static_assert(sizeof(PolyRec) == 88 * 8, "PolyRec layout");
+
+// Steps 2..4 of the solver (one wave): EE basis in LDS -> PolyRec in global memory.
+__device__ void solve_from_basis(SolveLds &L, int lane, PolyRec *__restrict__ rec) {
     // ---- 2. trilinear coefficient tensors (lane = ordered index triple (i,j,k)), symmetrised into A ----
     {
         const int i = lane >> 4, j = (lane >> 2) & 3, k = lane & 3;
@@ -232,7 +243,10 @@ __device__ bool solve_from_basis(SolveLds &L, int lane, double *Eout) {
         }
         __syncthreads();
     }
-    if (singular) return false;  // wave-uniform
+    if (singular) {  // wave-uniform
+        if (lane == 0) rec->ok = 0.0;
+        return;
+    }
 
     // ---- 4. B(z) rows and the determinant polynomial ----
     if (lane < 39) {
@@ -275,77 +289,136 @@ __device__ bool solve_from_basis(SolveLds &L, int lane, double *Eout) {
     }
     __syncthreads();
 
-    // ---- 5. Durand-Kerner on up to 10 lanes ----
+    // ---- hand over to roots_kernel ----
+    if (lane < 11) rec->c[lane] = L.c[lane];
+    if (lane < 39) rec->b[lane] = L.b[lane / 13][lane % 13];
+    if (lane < 36) rec->EE[lane] = L.EE[lane / 9][lane % 9];
+    if (lane == 0) rec->ok = 1.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Steps 5..6: roots and models.  Durand-Kerner needs one lane per root, i.e. 10 lanes per hypothesis, so SIX hypotheses
+// share a wave here (lane = 10*h + r) instead of idling 54 lanes of the solver wave.  All complex roots are found
+// simultaneously from cv::solvePoly's start values (1+i)^k; the iteration is Ehrlich-Aberth (cubically convergent) rather
+// than solvePoly's Durand-Kerner -- the roots a converged simultaneous iteration delivers are the same to rounding, only
+// the sweep count differs (8 vs 27 on average); each hypothesis stops on its own once its corrections vanish to rounding;
+// a root is real iff |imag| <= 1e-10 (five-point.cpp:438); per real root the null vector of Bz (3x3 one-sided Jacobi in
+// registers), reject |xy1[2]| < 1e-10 (:457), E = x E0 + y E1 + z E2 + E3, Frobenius-normalised.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kHypPerWave = 6;
+__global__ __launch_bounds__(64) void roots_kernel(const PolyRec *__restrict__ recs, int sample_offset, int n_samples,
+                                                   double *__restrict__ E_tab, int32_t *__restrict__ n_models,
+                                                   double *__restrict__ dense_E, int32_t *__restrict__ dense_id,
+                                                   int32_t *__restrict__ dense_total) {
+    __shared__ double R[kHypPerWave][88];
+    __shared__ double rr[64], ri[64], relbuf[64];
+    const int lane = threadIdx.x;
+    const int h = lane / 10, r = lane - h * 10;
+    const int sample0 = sample_offset + blockIdx.x * kHypPerWave;
+    // cooperative load of the six records
+    for (int i = lane; i < kHypPerWave * 88; i += 64) {
+        const int hh = i / 88, k = i - hh * 88;
+        const int smp = sample0 + hh;
+        R[hh][k] = (smp < n_samples) ? reinterpret_cast<const double *>(recs + (smp - sample_offset))[k] : 0.0;
+    }
+    __syncthreads();
+    const bool lane_ok = (h < kHypPerWave) && (sample0 + h < n_samples) && (R[h < kHypPerWave ? h : 0][86] != 0.0);
+    const int hs = h < kHypPerWave ? h : 0;
+    const double *c = &R[hs][0];
+    const double *b = &R[hs][11];
+    const double *EE = &R[hs][50];
     int n = 10;
     for (; n > 1; n--)
-        if (fabs(L.c[n]) > DBL_EPSILON) break;  // cv::solvePoly trims vanishing leading coefficients
+        if (fabs(c[n]) > DBL_EPSILON) break;  // cv::solvePoly trims vanishing leading coefficients
     double pr, pim;
     {
-        // (1+i)^lane for lane 0..9
-        const double tr[10] = {1, 1, 0, -2, -4, -4, 0, 8, 16, 16};
+        const double tr[10] = {1, 1, 0, -2, -4, -4, 0, 8, 16, 16};  // (1+i)^r
         const double ti[10] = {0, 1, 2, 2, 0, -4, -8, -8, 0, 16};
-        const int l = lane < 10 ? lane : 0;
-        pr = tr[l];
-        pim = ti[l];
+        pr = tr[r];
+        pim = ti[r];
     }
-    const bool active = lane < n;
+    const bool active = lane_ok && r < n;
+    bool done = !lane_ok;  // identical for the 10 lanes of a hypothesis
     int settle = 0, dk_sweeps = 0;
     for (int iter = 0; iter < 400; ++iter) {
-        dk_sweeps = iter + 1;
-        if (lane < 10) {
-            L.rr[lane] = pr;
-            L.ri[lane] = pim;
-        }
+        rr[lane] = pr;
+        ri[lane] = pim;
         __syncthreads();
         double dr = 0, di = 0;
-        if (active) {
-            double nr = L.c[n], ni = 0, der = L.c[n], dei = 0;
+        if (active && !done) {
+            // Ehrlich-Aberth step: w = (p/p') / (1 - (p/p') * sum_{j != r} 1/(z - z_j));  p, p' by one Horner pass
+            double fr = c[n], fi = 0, gr = 0, gi = 0;  // f = p(z), g = p'(z)
+            for (int j = n - 1; j >= 0; --j) {
+                const double t0 = gr * pr - gi * pim + fr;
+                gi = gr * pim + gi * pr + fi;
+                gr = t0;
+                const double t1 = fr * pr - fi * pim + c[j];
+                fi = fr * pim + fi * pr;
+                fr = t1;
+            }
+            double sr = 0, si = 0;
             for (int j = 0; j < n; ++j) {
-                // num = num * p + c[n-1-j]
-                const double t = nr * pr - ni * pim;
-                ni = nr * pim + ni * pr;
-                nr = t + L.c[n - 1 - j];
-                if (j != lane) {
-                    const double xr = pr - L.rr[j], xi = pim - L.ri[j];
-                    if (xr != 0 || xi != 0) {
-                        const double u = der * xr - dei * xi;
-                        dei = der * xi + dei * xr;
-                        der = u;
-                    }
+                if (j == r) continue;
+                const double xr = pr - rr[h * 10 + j], xi = pim - ri[h * 10 + j];
+                const double m2 = xr * xr + xi * xi;
+                if (m2 > 0) {
+                    const double inv = 1.0 / m2;
+                    sr += xr * inv;
+                    si -= xi * inv;
                 }
             }
-            const double tt = 1.0 / (der * der + dei * dei);
-            dr = (nr * der + ni * dei) * tt;
-            di = (-nr * dei + ni * der) * tt;
+            const double g2 = gr * gr + gi * gi;
+            if (g2 > 0) {
+                const double ig = 1.0 / g2;
+                const double qr = (fr * gr + fi * gi) * ig, qi = (fi * gr - fr * gi) * ig;  // q = p/p'
+                const double ur = 1.0 - (qr * sr - qi * si), ui = -(qr * si + qi * sr);     // 1 - q*S
+                const double u2 = ur * ur + ui * ui;
+                if (u2 > 0) {
+                    const double iu = 1.0 / u2;
+                    dr = (qr * ur + qi * ui) * iu;
+                    di = (qi * ur - qr * ui) * iu;
+                } else {
+                    dr = qr, di = qi;
+                }
+            } else {
+                dr = 1e-3 * (1.0 + fabs(pr)), di = 1e-3;  // stationary point of p: nudge off it
+            }
             pr -= dr;
             pim -= di;
         }
-        const double mag = active ? sqrt(dr * dr + di * di) : 0.0;
-        const double scale = active ? (1.0 + sqrt(pr * pr + pim * pim)) : 1.0;
-        const double rel = wave_max(mag / scale);
+        relbuf[lane] = (active && !done) ? sqrt(dr * dr + di * di) / (1.0 + sqrt(pr * pr + pim * pim)) : 0.0;
         __syncthreads();
-        // quadratic convergence: once every correction is below 1e-9 (relative) two more sweeps reach rounding level
-        if (!(rel > 1e-9)) {
-            if (++settle >= 3) break;
-        } else {
-            settle = 0;
+        if (!done) {
+            double rel = 0;
+            bool nan = false;
+            for (int j = 0; j < 10; ++j) {
+                const double v = relbuf[hs * 10 + j];
+                nan = nan || (v != v);
+                rel = fmax(rel, v);
+            }
+            dk_sweeps = iter + 1;
+            // cubic convergence: once every correction is below 1e-9 (relative) one more sweep reaches rounding level
+            if (nan) done = true;
+            else if (!(rel > 1e-9)) done = (++settle >= 2);
+            else settle = 0;
         }
-        if (rel != rel) break;  // NaN: degenerate polynomial
+        if (!__any(!done)) break;
     }
-    if (g_dk_iters_dbg[3] && lane == 0) {
+    if (g_dk_iters_dbg[3] && lane_ok && r == 0) {
         atomicAdd(&g_dk_iters_dbg[0], dk_sweeps);
         atomicAdd(&g_dk_iters_dbg[1], 1);
         atomicMax(&g_dk_iters_dbg[2], dk_sweeps);
     }
 
-    // ---- 6. real roots -> essential matrices ----
+    // real roots -> essential matrices
     bool valid = false;
+    double E[9];
     if (active && fabs(pim) <= 1e-10 && pr == pr) {
         const double z1 = pr, z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
         double bz[9];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const double *br = L.b[j];
+            const double *br = b + j * 13;
             bz[j * 3 + 0] = br[0] * z3 + br[1] * z2 + br[2] * z1 + br[3];
             bz[j * 3 + 1] = br[4] * z3 + br[5] * z2 + br[6] * z1 + br[7];
             bz[j * 3 + 2] = br[8] * z4 + br[9] * z3 + br[10] * z2 + br[11] * z1 + br[12];
@@ -357,49 +430,46 @@ __device__ bool solve_from_basis(SolveLds &L, int lane, double *Eout) {
             double nrm = 0;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                Eout[k] = L.EE[0][k] * x + L.EE[1][k] * y + L.EE[2][k] * z1 + L.EE[3][k];
-                nrm += Eout[k] * Eout[k];
+                E[k] = EE[k] * x + EE[9 + k] * y + EE[18 + k] * z1 + EE[27 + k];
+                nrm += E[k] * E[k];
             }
             nrm = sqrt(nrm);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) Eout[k] /= nrm;
+            for (int k = 0; k < 9; ++k) E[k] /= nrm;
             valid = (nrm == nrm) && nrm > 0;
         }
     }
-    return valid;
-}
-
-// Writes the wave's valid models: per-sample table (E_tab[sample][10][9], n_models[sample]) and, if dense != nullptr,
-// the dense list used by the scoring kernel (dense_E[total][9], dense_id[total] = sample*10 + slot).
-__device__ void emit_models(bool valid, const double *E, int lane, int sample, double *E_tab, int32_t *n_models,
-                            double *dense_E, int32_t *dense_id, int32_t *dense_total) {
+    // per-hypothesis compaction (slot = rank of this lane among the valid lanes of its hypothesis) + dense list
     const unsigned long long bal = __ballot(valid);
-    const int cnt = __popcll(bal);
-    const int slot = __popcll(bal & ((1ull << lane) - 1ull));
+    const int total = __popcll(bal);
+    const unsigned long long below = bal & ((1ull << lane) - 1ull);
+    const unsigned long long hmask = (h < kHypPerWave) ? (((1ull << 10) - 1ull) << (h * 10)) : 0ull;
+    const int slot = __popcll(below & hmask);
+    const int cnt_h = __popcll(bal & hmask);
     int base = 0;
     if (dense_total) {
-        if (lane == 0 && cnt > 0) base = atomicAdd(dense_total, cnt);
+        if (lane == 0 && total > 0) base = atomicAdd(dense_total, total);
         base = __shfl(base, 0);
     }
+    const int sample = sample0 + h;
     if (valid) {
         double *dst = E_tab + ((size_t)sample * 10 + slot) * 9;
 #pragma unroll
         for (int k = 0; k < 9; ++k) dst[k] = E[k];
         if (dense_E) {
-            double *dd = dense_E + (size_t)(base + slot) * 9;
+            const int pos = base + __popcll(below);
+            double *dd = dense_E + (size_t)pos * 9;
 #pragma unroll
             for (int k = 0; k < 9; ++k) dd[k] = E[k];
-            dense_id[base + slot] = sample * 10 + slot;
+            dense_id[pos] = sample * 10 + slot;
         }
     }
-    if (lane == 0) n_models[sample] = cnt;
+    if (h < kHypPerWave && r == 0 && sample < n_samples) n_models[sample] = cnt_h;
 }
 
 __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
                                                       const int32_t *__restrict__ samples, int sample_offset, int n_samples,
-                                                      double *__restrict__ E_tab, int32_t *__restrict__ n_models,
-                                                      double *__restrict__ dense_E, int32_t *__restrict__ dense_id,
-                                                      int32_t *__restrict__ dense_total) {
+                                                      PolyRec *__restrict__ recs /* indexed from sample_offset */) {
     __shared__ SolveLds L;
     const int lane = threadIdx.x;
     const int sample = sample_offset + blockIdx.x;
@@ -461,9 +531,7 @@ __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__
         __syncthreads();
     }
 
-    double E[9];
-    const bool valid = solve_from_basis(L, lane, E);
-    emit_models(valid, E, lane, sample, E_tab, n_models, dense_E, dense_id, dense_total);
+    solve_from_basis(L, lane, recs + (sample - sample_offset));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -581,7 +649,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const double4 *__restrict__ p
 }
 
 __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restrict__ gram_part, int nparts,
-                                                         double *__restrict__ E_tab, int32_t *__restrict__ n_models) {
+                                                         PolyRec *__restrict__ rec) {
     __shared__ SolveLds L;
     __shared__ double G[9][9], Vv[9][9], gsum[45];
     const int lane = threadIdx.x;
@@ -648,9 +716,7 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
             for (int r = 0; r < 9; ++r) L.EE[j][r] = Vv[r][order[5 + j]];
     }
     __syncthreads();
-    double E[9];
-    const bool valid = solve_from_basis(L, lane, E);
-    emit_models(valid, E, lane, 0, E_tab, n_models, nullptr, nullptr, nullptr);
+    solve_from_basis(L, lane, rec);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -899,6 +965,7 @@ struct RansacBuffers {
     int32_t *hgood;     // [chunk]  per-hypothesis best count
     int32_t *hslot;     // [chunk]
     double *hsum;       // [chunk]
+    PolyRec *recs;      // [chunk]  solver -> roots hand-over
 };
 
 static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
@@ -910,6 +977,8 @@ static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
     B.E_tab = (double *)p;
     if ((rc = ws_get(ctx, WS_AUX6, (size_t)chunk * 90 * 8, &p))) return rc;
     B.dense_E = (double *)p;
+    if ((rc = ws_get(ctx, WS_PARTIAL, (size_t)chunk * sizeof(PolyRec), &p))) return rc;
+    B.recs = (PolyRec *)p;
     // one slot for the small integer/double tables: [n_models | dense_id | good | total] + esum
     const size_t ints = (size_t)chunk * (1 + 10 + 10 + 2) + 16;
     if ((rc = ws_get(ctx, WS_AUX7, ints * 4 + (size_t)chunk * 11 * 8 + 64, &p))) return rc;
@@ -968,6 +1037,8 @@ int mlpl_solve_5pt(mlpl_ctx *ctx, const double *p1, const double *p2, int n, con
     MLPL_HIP_TRY(hipMemsetAsync(B.E_tab, 0, (size_t)n_samples * 720, s));
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
     hipLaunchKernelGGL(solve5pt_kernel, dim3(n_samples), dim3(64), 0, s, (const double *)dp1, (const double *)dp2, B.samples, 0,
+                       n_samples, B.recs);
+    hipLaunchKernelGGL(roots_kernel, dim3((n_samples + kHypPerWave - 1) / kHypPerWave), dim3(64), 0, s, (const PolyRec *)B.recs, 0,
                        n_samples, B.E_tab, B.n_models, (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
     MLPL_HIP_TRY(hipGetLastError());
@@ -1086,8 +1157,10 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
             const int m = (off == 0) ? first : cnt - off;
             for (int i = off; i < off + m; ++i) draw_sample(rng, n, &h_samples[(size_t)i * 5]);
             prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
-            hipLaunchKernelGGL(solve5pt_kernel, dim3(m), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, off, cnt,
-                               B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total);
+            hipLaunchKernelGGL(solve5pt_kernel, dim3(m), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, off, off + m,
+                               B.recs);
+            hipLaunchKernelGGL(roots_kernel, dim3((m + kHypPerWave - 1) / kHypPerWave), dim3(64), 0, s, (const PolyRec *)B.recs,
+                               off, off + m, B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total);
             prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
             off += m;
         }
@@ -1121,7 +1194,9 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         double *d_es = d_rf + 112;                   // 10 doubles
         double *d_gram = d_rf + 144;                 // [gblocks][45]
         hipLaunchKernelGGL(gram_kernel, dim3(gblocks), dim3(256), 0, s, (const double4 *)pts, (const uint8_t *)d_mask, n, d_gram);
-        hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, s, (const double *)d_gram, gblocks, d_Etab, d_nm);
+        hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, s, (const double *)d_gram, gblocks, B.recs);
+        hipLaunchKernelGGL(roots_kernel, dim3(1), dim3(64), 0, s, (const PolyRec *)B.recs, 0, 1, d_Etab, d_nm, (double *)nullptr,
+                           (int32_t *)nullptr, (int32_t *)nullptr);
         hipLaunchKernelGGL(score_models_kernel, dim3(1), dim3(256), 0, s, (const double4 *)pts, n, (const double *)d_Etab,
                            (const int32_t *)nullptr, (const int32_t *)d_nm, 0, thresh2, d_good, d_es);
         hipLaunchKernelGGL(refit_decide_kernel, dim3(1), dim3(64), 0, s, (const int32_t *)d_nm, (const int32_t *)d_good,
