@@ -20,7 +20,7 @@ void set_error(const char *fmt, ...) {
 }
 
 int ws_get(mlpl_ctx *ctx, WsSlot slot, size_t bytes, void **out) {
-    if (bytes == 0) bytes = 16;
+    if (bytes < 4096) bytes = 4096;  // small requests share one minimum size, so they never trigger a regrow
     if (ctx->ws_bytes[slot] < bytes) {
         // growing: make sure nothing in flight still uses the old buffer
         MLPL_HIP_TRY(hipDeviceSynchronize());
@@ -336,7 +336,7 @@ static int ratio_compact_host(mlpl_ctx *ctx, const int32_t *idx, const void *dis
     if ((rc = ws_get(ctx, WS_IDX, (size_t)nq * k * 4, &didx))) return rc;
     if ((rc = ws_get(ctx, WS_DIST, (size_t)nq * k * 4, &ddist))) return rc;
     if ((rc = ws_get(ctx, WS_MATCH, (size_t)nq * sizeof(mlpl_dmatch), &dout))) return rc;
-    if ((rc = ws_get(ctx, WS_AUX2, 64, &dcnt))) return rc;
+    if ((rc = ws_get(ctx, WS_SCALARS, 64, &dcnt))) return rc;
     MLPL_HIP_TRY(hipMemcpyAsync(didx, idx, (size_t)nq * k * 4, hipMemcpyHostToDevice, ctx->stream));
     MLPL_HIP_TRY(hipMemcpyAsync(ddist, dist, (size_t)nq * k * 4, hipMemcpyHostToDevice, ctx->stream));
     rc = launch_ratio_compact(ctx, (const int32_t *)didx, ddist, is_float, nq, k, 1, ratio, (mlpl_dmatch *)dout,
@@ -382,7 +382,7 @@ int mlpl_get_matches_linear(mlpl_ctx *ctx, int n_keypoints1, int n_keypoints2, c
     if ((rc = ws_get(ctx, WS_IDX, (size_t)rows1 * k * 4, &didx))) return rc;
     if ((rc = ws_get(ctx, WS_DIST, (size_t)rows1 * k * 4, &ddist))) return rc;
     if ((rc = ws_get(ctx, WS_MATCH, (size_t)rows1 * sizeof(mlpl_dmatch), &dout))) return rc;
-    if ((rc = ws_get(ctx, WS_AUX2, 64, &dcnt))) return rc;
+    if ((rc = ws_get(ctx, WS_SCALARS, 64, &dcnt))) return rc;
     if (desc_type == 0) {
         rc = launch_knn_hamming(ctx, (const uint8_t *)dq, rows1, cols, 0, (const uint8_t *)dt, rows2, cols, 0, cols, k, 1,
                                 (int32_t *)didx, (int32_t *)ddist, ctx->stream);
@@ -426,7 +426,7 @@ int mlpl_get_matches_bruteforce_nms(mlpl_ctx *ctx, int n_keypoints1, int n_keypo
     if ((rc = ws_get(ctx, WS_IDX, (size_t)rows1 * k * 4, &didx))) return rc;
     if ((rc = ws_get(ctx, WS_DIST, (size_t)rows1 * k * 4, &ddist))) return rc;
     if ((rc = ws_get(ctx, WS_MATCH, (size_t)rows1 * sizeof(mlpl_dmatch), &dout))) return rc;
-    if ((rc = ws_get(ctx, WS_AUX2, 64, &dcnt))) return rc;
+    if ((rc = ws_get(ctx, WS_SCALARS, 64, &dcnt))) return rc;
     if (desc_type == 0) {
         // two bytes per int, last int dropped by SpaceBitHamming::HiddenDistance: the last 2 bytes (1 for odd widths) are ignored
         const int eff = (cols % 2 == 0) ? cols - 2 : cols - 1;

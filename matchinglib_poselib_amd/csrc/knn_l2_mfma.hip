@@ -212,9 +212,9 @@ int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride,
     if ((rc = ws_get(ctx, WS_PACK_Q, (size_t)batch * nq_tiles * ksel * 64 * 16, &qf))) return rc;
     if ((rc = ws_get(ctx, WS_PACK_T, (size_t)batch * nt_tiles * ksel * 64 * 16, &tf))) return rc;
     if ((rc = ws_get(ctx, WS_AUX3, (size_t)batch * (nq_pad + nt_pad) * 4 + 64, &nrm))) return rc;
-    if ((rc = ws_get(ctx, WS_AUX2, 4096, &flag))) return rc;
+    if ((rc = ws_get(ctx, WS_L2_FLAG, 4096, &flag))) return rc;
     float *qn = (float *)nrm, *tn = qn + (size_t)batch * nq_pad;
-    int *dflag = (int *)flag + 512;  // away from the small doubles other paths keep at the start of this slot
+    int *dflag = (int *)flag;
     MLPL_HIP_TRY(hipMemsetAsync(dflag, 0, 4, s));
     {
         const long long tq = (long long)nq_tiles * ksel * 64, tt = (long long)nt_tiles * ksel * 64;

@@ -40,6 +40,8 @@ enum WsSlot {
     WS_AUX5,
     WS_AUX6,
     WS_AUX7,
+    WS_SCALARS,   // small host-readable outputs of the host-pointer entry points (match counts)
+    WS_L2_FLAG,   // device gate flag of the L2 auto path
     WS_NUM_SLOTS
 };
 
@@ -74,7 +76,9 @@ struct mlpl_ctx {
 
 namespace mlpl {
 
-// Returns a device buffer of at least `bytes` for `slot`, growing it if needed (grow = sync + realloc).
+// Returns a device buffer of at least `bytes` for `slot`, growing it if needed (grow = sync + realloc).  A slot must not
+// be requested twice with different sizes inside one entry point while the first pointer is still in use: every purpose
+// that can coexist in a call has its own slot (see the WsSlot comments and the call sites).
 int ws_get(mlpl_ctx *ctx, WsSlot slot, size_t bytes, void **out);
 int pinned_get(mlpl_ctx *ctx, size_t bytes, void **out);
 
