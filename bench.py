@@ -177,6 +177,13 @@ def main():
                           f"{tc:.2f} s)",
                 "host_cores_available": os.cpu_count(),
             }
+            # BASELINE.md "CPU-best" tier: same results with hardware popcount + OpenMP on the host cores we may use
+            nthreads = min(16, os.cpu_count() or 1)
+            tb = time.perf_counter()
+            _, _, used = ora.knn_hamming_fast(qs[0], ts[0], threads=nthreads)
+            tb = time.perf_counter() - tb
+            rec["cpu_best"] = {"value": n * n / tb, "unit": "descriptor-pairs/s", "cores": used, "kind": "port",
+                               "sample": f"one full C2 pair, popcnt64 + OpenMP ({tb:.3f} s)"}
         if not args.no_extras:
             try:
                 import bench_extras

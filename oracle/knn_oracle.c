@@ -283,3 +283,50 @@ int oracle_get_matches_bruteforce_nms(const void *desc1, int rows1, const void *
     *n_out = n;
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * "CPU-best" tier of BASELINE.md section 3: same results as oracle_knn_hamming, but hardware popcount on 64-bit words
+ * and OpenMP over the queries -- a fair upper bound for the host, timed beside the faithful single-thread LUT port.
+ * nbytes must be a multiple of 8 here.  Returns the number of threads used, or -1.
+ * ---------------------------------------------------------------------------------------------------------------- */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int oracle_knn_hamming_fast(const uint8_t *q, int nq, size_t q_stride, const uint8_t *t, int nt, size_t t_stride, int nbytes,
+                            int32_t *idx, int32_t *dist, int threads) {
+    if (!q || !t || !idx || !dist || nt < 2 || nbytes <= 0 || nbytes % 8) return -1;
+    const int nw = nbytes / 8;
+    int used = 1;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+    }
+#pragma omp parallel for schedule(static)
+#endif
+    for (int qi = 0; qi < nq; ++qi) {
+        uint64_t a[32];
+        memcpy(a, q + (size_t)qi * q_stride, (size_t)nbytes);
+        uint64_t k0 = ~0ull, k1 = ~0ull; /* (dist << 32 | idx): lexicographic (dist, idx) */
+        for (int ti = 0; ti < nt; ++ti) {
+            uint64_t b[32];
+            memcpy(b, t + (size_t)ti * t_stride, (size_t)nbytes);
+            unsigned d = 0;
+            for (int w = 0; w < nw; ++w) d += (unsigned)__builtin_popcountll(a[w] ^ b[w]);
+            const uint64_t key = ((uint64_t)d << 32) | (uint32_t)ti;
+            if (key < k0) {
+                k1 = k0;
+                k0 = key;
+            } else if (key < k1) {
+                k1 = key;
+            }
+        }
+        idx[2 * qi] = (int32_t)(k0 & 0xffffffffu);
+        dist[2 * qi] = (int32_t)(k0 >> 32);
+        idx[2 * qi + 1] = (int32_t)(k1 & 0xffffffffu);
+        dist[2 * qi + 1] = (int32_t)(k1 >> 32);
+    }
+    return used;
+}

@@ -64,6 +64,11 @@ int oracle_get_matches_linear(int n_kp1, int n_kp2, const void *desc1, int rows1
 int oracle_get_matches_bruteforce_nms(const void *desc1, int rows1, const void *desc2, int rows2, int cols, int desc_type,
                                       int ratio_test, oracle_dmatch *out, int *n_out);
 
+/* BASELINE.md "CPU-best" tier: identical results, hardware popcount + OpenMP over queries (k = 2, nbytes % 8 == 0).
+ * Returns the number of threads used. */
+int oracle_knn_hamming_fast(const uint8_t *q, int nq, size_t q_stride, const uint8_t *t, int nt, size_t t_stride, int nbytes,
+                            int32_t *idx, int32_t *dist, int threads);
+
 /* ---- robust pose: P/source/five-point-nister/{five-point,modelest}.cpp, P/source/pose_estim.cpp -- */
 
 /* glibc srand/rand (TYPE_3 additive feedback generator) restated, so that sampling is reproducible

@@ -186,6 +186,18 @@ class Oracle:
         assert rc == 0
         return idx, dist
 
+    def knn_hamming_fast(self, q, t, threads=0):
+        q = np.ascontiguousarray(q, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        idx = np.empty((q.shape[0], 2), np.int32)
+        dist = np.empty((q.shape[0], 2), np.int32)
+        self.lib.oracle_knn_hamming_fast.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_int,
+                                                     C.c_void_p, C.c_void_p, C.c_int]
+        used = self.lib.oracle_knn_hamming_fast(q.ctypes.data, q.shape[0], q.strides[0], t.ctypes.data, t.shape[0], t.strides[0],
+                                                q.shape[1], idx.ctypes.data, dist.ctypes.data, threads)
+        assert used >= 1
+        return idx, dist, used
+
     def knn_l2sq(self, q, t, k=2):
         q = np.ascontiguousarray(q, np.float32)
         t = np.ascontiguousarray(t, np.float32)
