@@ -264,3 +264,57 @@ def test_bruteforce_nms_f32(ctx, oracle, dim, ratio):
     assert m.tobytes() == o.tobytes()
     if ratio:
         assert len(m) >= 90   # sqrt distances: the ratio test is applied to TRUE distances here
+
+
+def test_edge_cases_small_and_empty(ctx, oracle):
+    import matchinglib_poselib_amd as m
+    rng = np.random.default_rng(33)
+    t = rng.integers(0, 256, (2, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (3, 32), dtype=np.uint8)
+    idx, dist = mpa.knn_hamming(q, t, ctx=ctx)               # nt == k
+    oi, od = oracle.knn_hamming(q, t)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    idx, dist = mpa.knn_hamming(q[:0], t, ctx=ctx)            # no queries
+    assert idx.shape == (0, 2)
+    with pytest.raises(m.MlplError):
+        mpa.knn_hamming(q, t[:1], ctx=ctx)                    # nt < k
+    # L2: k = 1, strided rows, tiny train set, both paths
+    qf, tf = synth.sift_pair(70, 90, dim=128, seed=8)
+    big = np.zeros((70, 160), np.float32)
+    big[:, :128] = qf
+    for mode in (1, 0):
+        _set_l2(ctx, mode)
+        idx, dist = mpa.knn_l2sq(big[:, :128], tf, k=1, ctx=ctx)
+        oi, od = oracle.knn_l2sq(qf, tf, k=1)
+        assert np.array_equal(idx, oi) and dist.tobytes() == od.tobytes(), mode
+        idx, dist = mpa.knn_l2sq(qf, tf[:2], ctx=ctx)
+        oi, od = oracle.knn_l2sq(qf, tf[:2])
+        assert np.array_equal(idx, oi) and dist.tobytes() == od.tobytes(), mode
+    _set_l2(ctx, 0)
+
+
+def test_l2_device_batched(ctx, oracle):
+    import torch
+    from matchinglib_poselib_amd import _lib
+    B = 3
+    pairs = [synth.sift_pair(200, 333, dim=64, seed=50 + b) for b in range(B)]
+    pairs[1][1][7, 3] = 0.5                                    # batch item 1 is not integer-valued -> whole call goes exact
+    dq = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda()
+    dt = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    idx = torch.empty((B, 200, 2), dtype=torch.int32, device="cuda")
+    dist = torch.empty((B, 200, 2), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(ctx.lib.mlpl_knn2_l2sq_f32_dev(ctx.handle, dq.data_ptr(), 200, 64, 200 * 64, dt.data_ptr(), 333, 64, 333 * 64, 64,
+                                              2, B, idx.data_ptr(), dist.data_ptr(), st), "knn_l2_dev")
+    torch.cuda.synchronize()
+    for b in range(B):
+        oi, od = oracle.knn_l2sq(pairs[b][0], pairs[b][1])
+        assert np.array_equal(idx[b].cpu().numpy(), oi) and dist[b].cpu().numpy().tobytes() == od.tobytes(), b
+    pairs[1][1][7, 3] = 1.0                                    # now all integer-valued -> MFMA path, same results
+    dt = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
+    _lib.check(ctx.lib.mlpl_knn2_l2sq_f32_dev(ctx.handle, dq.data_ptr(), 200, 64, 200 * 64, dt.data_ptr(), 333, 64, 333 * 64, 64,
+                                              2, B, idx.data_ptr(), dist.data_ptr(), st), "knn_l2_dev")
+    torch.cuda.synchronize()
+    for b in range(B):
+        oi, od = oracle.knn_l2sq(pairs[b][0], pairs[b][1])
+        assert np.array_equal(idx[b].cpu().numpy(), oi) and dist[b].cpu().numpy().tobytes() == od.tobytes(), b
