@@ -51,6 +51,9 @@ def run(ctx, dev, cpu_baseline=True):
     score_ms, score_n = _prof(ctx, 3)
     solve_ms, score_ms = solve_ms / 3 * max(solve_n, 1) / max(solve_n, 1), score_ms / 3 * max(score_n, 1) / max(score_n, 1)
     solve_n = score_n = 1
+    stats = (C.c_longlong * 2)()
+    ctx.lib.mlpl_ransac_last_stats(ctx.handle, stats)
+    models = int(stats[1])
     # models actually scored: count once through the building-block API on a sample of the hypotheses
     out["ransac_c3"] = {
         "metric": "RANSAC hypotheses/s (5-pt Nister + Sampson on 5000 correspondences, 20000 iterations)",
@@ -61,7 +64,12 @@ def run(ctx, dev, cpu_baseline=True):
         "n_inliers": r["n_inliers"],
         "solve_kernels_ms_per_call": solve_ms,
         "score_kernel_ms_per_call": score_ms,
-        "score_fp64_tflops_algorithmic": None,
+        "models_scored": models,
+        "score_roofline": {"bound": "fp64-valu", "achieved": 39.0 * n * models / (score_ms * 1e-3) / 1e12,
+                           "peak": FP64_VALU_PEAK / 1e12, "unit": "TFLOP/s",
+                           "frac": 39.0 * n * models / (score_ms * 1e-3) / FP64_VALU_PEAK,
+                           "note": "39 fp64 FLOP per (model, correspondence) (SURVEY 8(d)); the IEEE division alone issues ~15 "
+                                   "instructions, so ~55 instructions per point are issued"},
         "includes": "host sample table (glibc rand stream, pinned/mapped), solve + score + replay + mask kernels, one 200-byte "
                     "state readback",
     }
@@ -117,6 +125,17 @@ def run(ctx, dev, cpu_baseline=True):
     ms = e0.elapsed_time(e1) / 20
     out["hamming_c2_single_pair"] = {"value": B * 8192 * 8192 / (ms * 1e-3), "unit": "descriptor-pairs/s",
                                      "ms_per_call": ms, "pairs_per_call": B}
+    # ---- the drop-in host-pointer API on one C2 pair: PCIe-inclusive (H2D 512 KiB, D2H <= 128 KiB, one sync) ----
+    hq, ht = synth.orb_pair(8192, 8192, seed=20260102)
+    kp = [None] * 8192
+    for name in ("LINEAR", "BRUTEFORCENMS"):
+        mpa.getMatches(kp, kp, hq, ht, matcher_name=name, ctx=ctx)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            err, mm = mpa.getMatches(kp, kp, hq, ht, matcher_name=name, ctx=ctx)
+        dt = (time.perf_counter() - t0) / 10
+        out[f"getmatches_host_api_c2_{name.lower()}"] = {"value": 8192 * 8192 / dt, "unit": "descriptor-pairs/s (PCIe-inclusive)",
+                                                        "ms_per_call": dt * 1e3, "err": int(err), "matches": int(len(mm))}
     # ---- C5 unit: whole per-pair pipeline (8k ORB match -> gather -> RANSAC 1000 it/0.999 -> cheirality), device-resident ----
     from matchinglib_poselib_amd import batch
     npairs = 8

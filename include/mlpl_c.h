@@ -200,7 +200,11 @@ int mlpl_solve_5pt(mlpl_ctx *ctx, const double *p1, const double *p2, int n, con
 int mlpl_score_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const double *E, int n_models,
                       double thresh, int32_t *count, double *err_sum);
 
-/* Diagnostics: Durand-Kerner sweep statistics of the solver since the last call ({sum, solves, max}); enable != 0 turns
+/* Statistics of the last mlpl_ransac_essential[_dev] call on this context: {iterations executed, essential matrices
+ * scored}.  Used by bench.py to turn the scoring kernel's time into algorithmic FLOP/s. */
+int mlpl_ransac_last_stats(mlpl_ctx *ctx, long long stats[2]);
+
+/* Diagnostics: root-iteration (Ehrlich-Aberth) sweep statistics of the solver since the last call ({sum, solves, max}); enable != 0 turns
  * the (atomic) bookkeeping on.  Not for production use. */
 int mlpl_debug_dk_stats(mlpl_ctx *ctx, int enable, int stats[3]);
 

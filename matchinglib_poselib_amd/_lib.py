@@ -87,6 +87,7 @@ _SIGNATURES = {
     "mlpl_solve_5pt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "mlpl_score_models": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_double, c_void_p,
                                   c_void_p]),
+    "mlpl_ransac_last_stats": (c_int, [c_void_p, c_void_p]),
     "mlpl_debug_dk_stats": (c_int, [c_void_p, c_int, c_void_p]),
     "mlpl_recover_pose_translation": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p,
                                               c_void_p, c_void_p]),

@@ -68,6 +68,7 @@ struct mlpl_ctx {
     int32_t *ransac_T_host;
     int ransac_T_n;
     double ransac_T_conf;
+    long long last_ransac_models, last_ransac_iters;  // statistics of the last mlpl_ransac_essential* call
     // optional per-kernel hipEvent bracketing (mlpl_profile_*)
     int prof_on;
     hipEvent_t *prof_ev[MLPL_PROF_NUM];  // pairs: [2*i] start, [2*i+1] stop

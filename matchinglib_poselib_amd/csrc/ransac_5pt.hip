@@ -736,6 +736,7 @@ struct ReplayState {
     double E[9];          // the model held
     int32_t refit_models; // models produced by the refit step (-1 = refit not run)
     int32_t refit_taken;  // slot of the refit model taken, -1 = none
+    long long models_scored;  // essential matrices scored over all passes (statistics)
 };
 
 // Per-hypothesis arg-max under (good desc, error sum asc, slot asc): the only model of a hypothesis that can ever be taken.
@@ -764,7 +765,7 @@ __global__ void hyp_best_kernel(const int32_t *__restrict__ n_models, const int3
 __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict__ hgood, const double *__restrict__ hsum,
                                                       const int32_t *__restrict__ hslot, const double *__restrict__ E_tab, int cnt,
                                                       const int32_t *__restrict__ Ttab, int npts, long long base_index,
-                                                      ReplayState *__restrict__ st) {
+                                                      const int32_t *__restrict__ dense_total, ReplayState *__restrict__ st) {
     __shared__ int wave_max_s[16];
     __shared__ int stop_idx;
     __shared__ int s_best_good[1024];
@@ -857,6 +858,7 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
         st->niters = nit;
         st->iter = iter0 + processed;
         st->stop = (iter0 + processed >= nit) ? 1 : 0;
+        st->models_scored += *dense_total;
     }
 }
 
@@ -998,6 +1000,13 @@ static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
 using namespace mlpl;
 
 extern "C" {
+
+int mlpl_ransac_last_stats(mlpl_ctx *ctx, long long stats[2]) {
+    if (!ctx || !stats) return MLPL_E_BAD_INPUT;
+    stats[0] = ctx->last_ransac_iters;
+    stats[1] = ctx->last_ransac_models;
+    return MLPL_OK;
+}
 
 int mlpl_debug_dk_stats(mlpl_ctx *ctx, int enable, int stats[3]) {
     if (!ctx) return MLPL_E_BAD_INPUT;
@@ -1173,7 +1182,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
                            (const int32_t *)B.good, (const double *)B.esum, cnt, B.hgood, B.hsum, B.hslot);
         hipLaunchKernelGGL(replay_kernel, dim3(1), dim3(1024), 0, s, (const int32_t *)B.hgood, (const double *)B.hsum,
                            (const int32_t *)B.hslot, (const double *)B.E_tab, cnt, (const int32_t *)d_T, n, (long long)base * 10,
-                           d_st);
+                           (const int32_t *)B.total, d_st);
         MLPL_HIP_TRY(hipGetLastError());
         if (base + chunk_cap < max_iters) {  // more chunks may follow: the host needs niters / stop to size the next one
             MLPL_HIP_TRY(hipMemcpyAsync(h_st, d_st, sizeof(ReplayState), hipMemcpyDeviceToHost, s));
@@ -1209,6 +1218,8 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     MLPL_HIP_TRY(hipMemcpyAsync(h_st, d_st, sizeof(ReplayState), hipMemcpyDeviceToHost, s));
     MLPL_HIP_TRY(hipStreamSynchronize(s));  // the single host hop of the call (per 32768-iteration chunk)
     const ReplayState fin = *h_st;
+    ctx->last_ransac_models = fin.models_scored;
+    ctx->last_ransac_iters = fin.iter;
     if (iters_used) *iters_used = fin.iter;
     if (fin.maxGood <= 0) {
         set_error("mlpl_ransac_essential: no model found");
