@@ -164,8 +164,8 @@ __global__ __launch_bounds__(kQueriesPerBlock) void knn_hamming_partial_kernel(
 // the scalar data cache) straight into SGPRs and fed to v_xor_b32 as the scalar source: no LDS traffic, no barriers.
 // (A broadcast ds_read_b128 delivers 1 KiB per wave-instruction for 16 useful bytes and saturates the CU's LDS at
 // ~84 % with four SIMDs issuing; the scalar path leaves the VALU as the only bound.)  Q queries per lane.
-template <int NW, int Q>
-__global__ __launch_bounds__(kQueriesPerBlock) void knn_hamming_partial_sgpr_kernel(
+template <int NW, int Q, int BT>
+__global__ __launch_bounds__(BT) void knn_hamming_partial_sgpr_kernel(
     const uint32_t *__restrict__ q, size_t q_bstride_w, const uint32_t *__restrict__ t, size_t t_bstride_w, int nq,
     int nt, int rows_per_split, int nsplit, uint2 *__restrict__ part) {
     constexpr int dshift = 32 - dist_bits(NW);
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kQueriesPerBlock) void knn_hamming_partial_sgpr_ker
     int qidx[Q];
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
-        qidx[j] = (blockIdx.x * Q + j) * kQueriesPerBlock + tid;
+        qidx[j] = (blockIdx.x * Q + j) * BT + tid;
         if (qidx[j] < nq) {
             const uint32_t *qp = q + (size_t)qidx[j] * NW;
             if constexpr (NW % 4 == 0) {
@@ -306,16 +306,19 @@ void launch_partial(int variant, int qpl, dim3 grid, hipStream_t s, const uint32
     if (variant == 0) {
         hipLaunchKernelGGL(knn_hamming_partial_kernel<NW>, grid, dim3(kQueriesPerBlock), 0, s, q, qbw, t, tbw, nq, nt, rps,
                            nsplit, part);
+    } else if (variant == 2) {  // one wave per block: finer scheduling, no co-resident waves needed per block
+        hipLaunchKernelGGL((knn_hamming_partial_sgpr_kernel<NW, 1, 64>), grid, dim3(64), 0, s, q, qbw, t, tbw, nq, nt, rps,
+                           nsplit, part);
     } else if constexpr (NW <= 16) {
         if (qpl == 2)
-            hipLaunchKernelGGL((knn_hamming_partial_sgpr_kernel<NW, 2>), grid, dim3(kQueriesPerBlock), 0, s, q, qbw, t, tbw,
-                               nq, nt, rps, nsplit, part);
+            hipLaunchKernelGGL((knn_hamming_partial_sgpr_kernel<NW, 2, kQueriesPerBlock>), grid, dim3(kQueriesPerBlock), 0, s, q,
+                               qbw, t, tbw, nq, nt, rps, nsplit, part);
         else
-            hipLaunchKernelGGL((knn_hamming_partial_sgpr_kernel<NW, 1>), grid, dim3(kQueriesPerBlock), 0, s, q, qbw, t, tbw,
-                               nq, nt, rps, nsplit, part);
+            hipLaunchKernelGGL((knn_hamming_partial_sgpr_kernel<NW, 1, kQueriesPerBlock>), grid, dim3(kQueriesPerBlock), 0, s, q,
+                               qbw, t, tbw, nq, nt, rps, nsplit, part);
     } else {
-        hipLaunchKernelGGL((knn_hamming_partial_sgpr_kernel<NW, 1>), grid, dim3(kQueriesPerBlock), 0, s, q, qbw, t, tbw, nq,
-                           nt, rps, nsplit, part);
+        hipLaunchKernelGGL((knn_hamming_partial_sgpr_kernel<NW, 1, kQueriesPerBlock>), grid, dim3(kQueriesPerBlock), 0, s, q, qbw,
+                           t, tbw, nq, nt, rps, nsplit, part);
     }
 }
 
@@ -376,7 +379,8 @@ int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_strid
     const int variant = ctx->opt_hamming_variant;
     int qpl = (variant == 1 && nw <= 16) ? ctx->opt_hamming_qpl : 1;  // queries per lane
     if (qpl == 2 && nq <= kQueriesPerBlock * 32) qpl = 1;                // too few queries to afford it
-    const int qtiles = (nq + kQueriesPerBlock * qpl - 1) / (kQueriesPerBlock * qpl);
+    const int qpb = (variant == 2) ? 64 : kQueriesPerBlock * qpl;  // queries per block
+    const int qtiles = (nq + qpb - 1) / qpb;
     const long long target_blocks = (long long)ctx->opt_hamming_blocks_per_cu * ctx->num_cus;
     const int max_split = (nt + kTileRows - 1) / kTileRows;
     long long want = (target_blocks + (long long)qtiles * batch - 1) / ((long long)qtiles * batch);

@@ -17,7 +17,7 @@ qs, ts = zip(*[synth.orb_pair(n, n, seed=20260102 + b) for b in range(B)])
 dq = torch.from_numpy(np.stack(qs)).cuda()
 dt = torch.from_numpy(np.stack(ts)).cuda()
 stream = None
-configs = [(0, 1, 16), (0, 1, 32), (0, 1, 48), (0, 1, 64)]
+configs = [(0, 1, 32), (2, 1, 4), (2, 1, 8), (2, 1, 16), (2, 1, 32), (2, 1, 64)]
 res = {c: [] for c in configs}
 ref = None
 for rnd in range(5):
