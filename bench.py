@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-queries", type=int, default=8192)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with HIP events")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (RANSAC / L2) measurements")
     args = ap.parse_args()
 
@@ -49,11 +51,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import matchinglib_poselib_amd as mpa
     from matchinglib_poselib_amd import _lib, synth
@@ -70,17 +77,32 @@ def main():
         ts.append(t)
     d_q = torch.from_numpy(np.stack(qs)).to(dev)
     d_t = torch.from_numpy(np.stack(ts)).to(dev)
-    out = None
     stream = None  # = torch's current stream, so torch/RCCL work is ordered after our kernels
-    gathered = torch.empty((world, P), dtype=torch.int32, device=dev) if world > 1 else None
+    # Two result buffers: the gather of step k (fixed-size per-pair records, here the match counts) runs asynchronously on
+    # RCCL's stream and overlaps the kernels of step k+1; a buffer is reused only after its gather has completed.
+    outs = [None, None]
+    gathered = [torch.empty((world * P,), dtype=torch.int32, device=dev) for _ in range(2)] if world > 1 else None
+    pending = [None, None]
+    step_no = 0
+    out = None
 
     def step():
-        nonlocal out
-        out = match_hamming_device(d_q, d_t, ratio_test=True, ratio=0.75, ctx=ctx, out=out, stream=stream)
+        nonlocal out, step_no
+        slot = step_no & 1
+        if pending[slot] is not None:
+            pending[slot].wait()
+            pending[slot] = None
+        outs[slot] = match_hamming_device(d_q, d_t, ratio_test=True, ratio=0.75, ctx=ctx, out=outs[slot], stream=stream)
+        out = outs[slot]
         if world > 1:
-            dist.all_gather_into_tensor(gathered, out["count"])
+            pending[slot] = dist.all_gather_into_tensor(gathered[slot], out["count"], async_op=True)
+        step_no += 1
 
     def barrier():
+        for i in (0, 1):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -109,6 +131,9 @@ def main():
     pairs_per_step_rank = P * n * n
     value = world * pairs_per_step_rank * args.steps / elapsed
     counts = out["count"].cpu().numpy().tolist()
+    if world > 1:  # every rank must hold every rank's records after the last gather
+        g = gathered[(step_no - 1) & 1].cpu().numpy().reshape(world, P)
+        assert g.shape == (world, P) and (g[rank] == np.array(counts)).all() and (g > 0).all(), "gathered records are wrong"
 
     if rank == 0:
         alg_bytes = pairs_per_step_rank * BYTES_PER_PAIR           # per launch of the dominant kernel
