@@ -20,8 +20,9 @@ void clearRansacSeed();
 
 // poselib::estimateEssentialMat (pose_estim.h:204-210, pose_estim.cpp:857-890).  p1, p2: n x 2 CV_64F camera
 // coordinates.  method "RANSAC" runs on the GPU (1000 iterations, confidence 0.999, `refine` = least-squares refit on
-// the inliers).  "USAC" / unknown method: prints the reference's message and calls exit(1), like the reference.
-// "ARRSAC" (the reference's default argument) and "LMEDS" are not part of this library: they also exit(1) with a message.
+// the inliers); "LMEDS" runs on the GPU as well (2000 iterations, no refit; `threshold` unused, as in the reference).
+// "USAC" / unknown method: prints the reference's message and calls exit(1), like the reference.
+// "ARRSAC" (the reference's default argument) is not part of this library: it also exits(1) with a message.
 bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p2, const std::string &method = "ARRSAC",
                           double threshold = PIX_MIN_GOOD_TH, bool refine = true, cv::OutputArray mask = cv::noArray());
 

@@ -190,6 +190,20 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
                               double confidence, int max_iters, int refit, uint32_t seed, double E[9],
                               uint8_t *d_mask, int *n_inliers, int *iters_used, void *stream);
 
+/*
+ * CvModelEstimator3::runLMeDS (modelest.cpp:483-564) as findEssentialMat drives it for method LMEDS (five-point.cpp:125-129;
+ * estimateEssentialMat passes prob = 0.999, pose_estim.cpp:874-877, findEssentialMat maxIters = 2000):
+ * niters = clamp(round(log(1-confidence)/log(1-0.55^5)), 3, max_iters) samples from the same glibc stream as RANSAC, the 5-point
+ * solver on each, the MEDIAN of the float Sampson errors per model (exact radix select over the bit patterns, the order the
+ * reference's int sort gives), the first model with the smallest median, sigma = max(2.5*1.4826*(1+5/(n-5))*sqrt(median), 0.001),
+ * mask = err <= sigma^2.  Returns 0, MLPL_E_FAILED when no model was found or fewer than 5 correspondences pass (the mask and
+ * *n_inliers are still written in the latter case), -1 on bad input (n must exceed 5).  *min_median may be NULL.
+ */
+int mlpl_lmeds_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n, double confidence, int max_iters,
+                         uint32_t seed, double E[9], uint8_t *mask, int *n_inliers, double *min_median);
+int mlpl_lmeds_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double confidence, int max_iters,
+                             uint32_t seed, double E[9], uint8_t *d_mask, int *n_inliers, double *min_median, void *stream);
+
 /* Building blocks, exposed for parity tests and for callers that schedule the phases themselves. */
 /* 5-point minimal solver, one wavefront per sample: samples = n_samples x 5 indices into p1/p2 (host).
  * E_out: n_samples x 10 x 9 doubles, n_models: n_samples ints (host). Replaces run5Point (five-point.cpp:366-471). */
@@ -199,6 +213,10 @@ int mlpl_solve_5pt(mlpl_ctx *ctx, const double *p1, const double *p2, int n, con
  * err_sum[i] = sum of the float-rounded errors (findInliers + cv::sum(err), modelest.cpp:69-83,407). */
 int mlpl_score_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const double *E, int n_models,
                       double thresh, int32_t *count, double *err_sum);
+
+/* Median of the float Sampson errors per model, as runLMeDS takes it (modelest.cpp:540-544: errors sorted as int bit patterns;
+ * even n: float sum of the two middle values * 0.5).  median: n_models doubles (host). */
+int mlpl_median_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const double *E, int n_models, double *median);
 
 /* Statistics of the last mlpl_ransac_essential[_dev] call on this context: {iterations executed, essential matrices
  * scored}.  Used by bench.py to turn the scoring kernel's time into algorithmic FLOP/s. */

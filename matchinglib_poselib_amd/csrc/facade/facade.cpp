@@ -112,7 +112,7 @@ void clearRansacSeed() { g_seed_fixed = false; }
 
 bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p2, const std::string &method,
                           double threshold, bool refine, cv::OutputArray mask) {
-    if (method == "RANSAC") {
+    if (method == "RANSAC" || method == "LMEDS") {
         if (!cv::needed(E)) return false;  // five-point.cpp:143-144
         int n1 = 0, n2 = 0;
         std::vector<double> a = points64(p1, n1), b = points64(p2, n2);
@@ -136,10 +136,14 @@ bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p
         std::vector<uint8_t> m((size_t)n1);
         int ninl = 0, iters = 0;
         const unsigned seed = g_seed_fixed ? g_seed : (unsigned)std::time(nullptr);  // modelest.cpp:58
-        const int rc = mlpl_ransac_essential(default_ctx(), a.data(), b.data(), n1, threshold, 0.999, 1000, refine ? 1 : 0, seed,
-                                             Ev, m.data(), &ninl, &iters);
+        // RANSAC: 1000 iterations + optional refit (pose_estim.cpp:870-873); LMEDS: 2000 iterations, no refit (:874-877,
+        // five-point.cpp:125-129)
+        const int rc = method == "LMEDS"
+                           ? mlpl_lmeds_essential(default_ctx(), a.data(), b.data(), n1, 0.999, 2000, seed, Ev, m.data(), &ninl, nullptr)
+                           : mlpl_ransac_essential(default_ctx(), a.data(), b.data(), n1, threshold, 0.999, 1000, refine ? 1 : 0,
+                                                   seed, Ev, m.data(), &ninl, &iters);
         if (rc == MLPL_E_FAILED) return false;
-        if (rc != MLPL_OK) throw cv::Exception(std::string("mlpl_ransac_essential: ") + mlpl_last_error());
+        if (rc != MLPL_OK) throw cv::Exception(std::string("estimateEssentialMat: ") + mlpl_last_error());
         if (cv::needed(mask)) {
             mask.create(1, n1, CV_8U);
             std::memcpy(mask.data, m.data(), (size_t)n1);
@@ -153,8 +157,8 @@ bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p
                   << std::endl;
         std::exit(1);  // pose_estim.cpp:878-882
     }
-    if (method == "ARRSAC" || method == "LMEDS") {
-        std::cout << method << " is not built in the MI355X hot-path library (RANSAC only). Exiting." << std::endl;
+    if (method == "ARRSAC") {
+        std::cout << method << " is not built in the MI355X hot-path library (RANSAC and LMEDS only). Exiting." << std::endl;
         std::exit(1);
     }
     std::cout << "Either there is a typo in the specified robust estimation method or the method is not supported. Exiting."

@@ -615,6 +615,166 @@ __global__ void inlier_mask_kernel(const double4 *__restrict__ pts, int n, const
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// LMedS (CvModelEstimator3::runLMeDS, modelest.cpp:483-564): per-model median of the Sampson errors by an exact
+// 4-pass byte radix select over the float bit patterns (the reference sorts them as ints, :541), one block per model.
+// The errors are recomputed in every pass (55 fp64 instructions) instead of being stored: a model's error vector would
+// be 4n bytes of HBM round trip per pass, the recompute is free next to it.
+// ---------------------------------------------------------------------------------------------------------------
+struct LmedsState {
+    double minMedian;
+    long long best;  // iteration*10 + slot, -1 = none
+    double E[9];
+    int32_t inliers;
+    int32_t pad;
+};
+
+__device__ __forceinline__ uint32_t lmeds_key(float err) { return __float_as_uint(err) ^ 0x80000000u; }  // signed-int order
+
+__global__ __launch_bounds__(256) void median_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ dense_E,
+                                                     const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
+                                                     int total_host, double *__restrict__ median_out) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_bin, s_below;
+    __shared__ uint32_t s_cnt_lt, s_max_lt;
+    const int m = blockIdx.x;
+    if (m >= (total_ptr ? *total_ptr : total_host)) return;  // block-uniform
+    const int tid = threadIdx.x;
+    double e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = dense_E[(size_t)m * 9 + k];
+    uint32_t k = (uint32_t)(n / 2);  // upper middle (the median itself for odd n)
+    uint32_t prefix = 0, care = 0;
+    for (int pass = 3; pass >= 0; --pass) {
+        hist[tid] = 0;
+        __syncthreads();
+        const int sh = pass * 8;
+        for (int i = tid; i < n; i += 256) {
+            const double4 p = pts[i];
+            const uint32_t v = lmeds_key(sampson_err_f32(e, p.x, p.y, p.z, p.w));
+            if ((v & care) == prefix) atomicAdd(&hist[(v >> sh) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // lane l owns bins 4l..4l+3; wave-wide inclusive scan of the lane sums, then the crossing bin
+            const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const uint32_t mine = h0 + h1 + h2 + h3;
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (tid >= d) incl += o;
+            }
+            const uint32_t excl = incl - mine;
+            if (excl <= k && k < incl) {  // exactly one lane
+                uint32_t c = excl, b = 4 * tid;
+                if (k >= c + h0) {
+                    c += h0;
+                    ++b;
+                    if (k >= c + h1) {
+                        c += h1;
+                        ++b;
+                        if (k >= c + h2) {
+                            c += h2;
+                            ++b;
+                        }
+                    }
+                }
+                s_bin = b;
+                s_below = c;
+            }
+        }
+        __syncthreads();
+        prefix |= s_bin << sh;
+        care |= 255u << sh;
+        k -= s_below;
+        __syncthreads();
+    }
+    const uint32_t key_hi = prefix;
+    float f_hi = __uint_as_float(key_hi ^ 0x80000000u);
+    double med;
+    if (n & 1) {
+        med = (double)f_hi;
+    } else {
+        // lower middle: the largest key below key_hi if exactly n/2 keys are below it, else key_hi again (duplicates)
+        if (tid == 0) {
+            s_cnt_lt = 0;
+            s_max_lt = 0;
+        }
+        __syncthreads();
+        uint32_t c = 0, mx = 0;
+        for (int i = tid; i < n; i += 256) {
+            const double4 p = pts[i];
+            const uint32_t v = lmeds_key(sampson_err_f32(e, p.x, p.y, p.z, p.w));
+            if (v < key_hi) {
+                ++c;
+                mx = max(mx, v);
+            }
+        }
+        atomicAdd(&s_cnt_lt, c);
+        atomicMax(&s_max_lt, mx);
+        __syncthreads();
+        const float f_lo = (s_cnt_lt == (uint32_t)(n / 2)) ? __uint_as_float(s_max_lt ^ 0x80000000u) : f_hi;
+        med = __dmul_rn((double)__fadd_rn(f_lo, f_hi), 0.5);  // modelest.cpp:544: float sum, then * 0.5 in double
+    }
+    if (tid == 0) median_out[ids ? ids[m] : m] = med;
+}
+
+// `if (median < minMedian)` in iteration then slot order (modelest.cpp:546-551) == the first minimum under (median, id).
+__global__ __launch_bounds__(1024) void lmeds_argmin_kernel(const int32_t *__restrict__ n_models, const double *__restrict__ medians,
+                                                            const double *__restrict__ E_tab, int cnt, LmedsState *__restrict__ st) {
+    __shared__ double s_med[1024];
+    __shared__ int s_id[1024];
+    const int tid = threadIdx.x;
+    double bm = DBL_MAX;
+    int bi = -1;
+    for (int id = tid; id < cnt * 10; id += 1024) {
+        if ((id % 10) >= n_models[id / 10]) continue;
+        const double v = medians[id];
+        if (v < bm) {  // ids rise within a thread: ties keep the earlier one
+            bm = v;
+            bi = id;
+        }
+    }
+    s_med[tid] = bm;
+    s_id[tid] = bi;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (tid < w) {
+            const double om = s_med[tid + w];
+            const int oi = s_id[tid + w];
+            if (oi >= 0 && (s_id[tid] < 0 || om < s_med[tid] || (om == s_med[tid] && oi < s_id[tid]))) {
+                s_med[tid] = om;
+                s_id[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        st->minMedian = s_med[0];
+        st->best = s_id[0];
+        st->inliers = 0;
+        if (s_id[0] >= 0)
+            for (int k = 0; k < 9; ++k) st->E[k] = E_tab[(size_t)s_id[0] * 9 + k];
+    }
+}
+
+__global__ void inlier_mask_count_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E, double thresh2,
+                                         uint8_t *__restrict__ mask, int32_t *__restrict__ count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool in = false;
+    if (i < n) {
+        double e[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) e[k] = E[k];
+        const double4 p = pts[i];
+        in = (double)sampson_err_f32(e, p.x, p.y, p.z, p.w) <= thresh2;
+        mask[i] = in ? 1 : 0;
+    }
+    const unsigned long long b = __ballot(in);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, __popcll(b));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Refit on all inliers (the reference's `lesqu`, modelest.cpp:420-464): Gram matrix of the masked epipolar rows,
 // its 4 smallest eigenvectors (cyclic Jacobi, one wave), then the same solver tail.
 // ---------------------------------------------------------------------------------------------------------------
@@ -1255,6 +1415,128 @@ int mlpl_ransac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int
     if (rc) return rc;
     MLPL_HIP_TRY(hipMemcpy(mask, dmask, (size_t)n, hipMemcpyDeviceToHost));
     return MLPL_OK;
+}
+
+int mlpl_median_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const double *E, int n_models, double *median) {
+    if (!ctx || !p1 || !p2 || !E || !median || n < 1 || n_models < 0) {
+        set_error("mlpl_median_models: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    if (n_models == 0) return MLPL_OK;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    void *dp1, *dp2, *dE, *dmed;
+    int rc;
+    if ((rc = ws_get(ctx, WS_AUX0, (size_t)n * 16, &dp1))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX1, (size_t)n * 16, &dp2))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX5, (size_t)n_models * 72, &dE))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX6, (size_t)n_models * 8, &dmed))) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(dp1, p1, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(dp2, p2, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(dE, E, (size_t)n_models * 72, hipMemcpyHostToDevice, s));
+    double4 *pts;
+    if ((rc = pack_points(ctx, (const double *)dp1, (const double *)dp2, n, &pts, s))) return rc;
+    hipLaunchKernelGGL(median_kernel, dim3(n_models), dim3(256), 0, s, (const double4 *)pts, n, (const double *)dE,
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, (double *)dmed);
+    MLPL_HIP_TRY(hipGetLastError());
+    MLPL_HIP_TRY(hipMemcpyAsync(median, dmed, (size_t)n_models * 8, hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipStreamSynchronize(s));
+    return MLPL_OK;
+}
+
+int mlpl_lmeds_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double confidence, int max_iters,
+                             uint32_t seed, double E[9], uint8_t *d_mask, int *n_inliers, double *min_median, void *stream) {
+    if (!ctx || !d_p1 || !d_p2 || !E || !d_mask || n < 6 || max_iters < 1 || !(confidence > 0 && confidence < 1)) {
+        set_error("mlpl_lmeds_essential: bad arguments (n=%d max_iters=%d); n must exceed the 5 model points", n, max_iters);
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = pick_stream(ctx, stream);
+    if (n_inliers) *n_inliers = 0;
+    if (min_median) *min_median = DBL_MAX;
+
+    // modelest.cpp:506-508 (host libm, as the reference)
+    const double outlierRatio = 0.45;
+    int niters = (int)std::round(std::log(1. - confidence) / std::log(1. - std::pow(1. - outlierRatio, 5.0)));
+    niters = std::min(std::max(niters, 3), max_iters);
+
+    double4 *pts;
+    int rc = pack_points(ctx, d_p1, d_p2, n, &pts, s);
+    if (rc) return rc;
+    RansacBuffers B;
+    if ((rc = alloc_ransac(ctx, niters, B))) return rc;
+    void *dsm;
+    if ((rc = ws_get(ctx, WS_AUX2, 4096, &dsm))) return rc;
+    LmedsState *d_st = (LmedsState *)dsm;
+    void *pin;
+    if ((rc = pinned_get(ctx, (size_t)niters * 20 + 1024, &pin))) return rc;
+    LmedsState *h_st = (LmedsState *)pin;
+    int32_t *h_samples = (int32_t *)((char *)pin + 512);
+    int32_t *d_samples_mapped = nullptr;
+    MLPL_HIP_TRY(hipHostGetDevicePointer((void **)&d_samples_mapped, h_samples, 0));
+
+    GlibcRand rng;
+    rng.seed(seed);
+    for (int i = 0; i < niters; ++i) draw_sample(rng, n, &h_samples[(size_t)i * 5]);
+    MLPL_HIP_TRY(hipMemsetAsync(B.total, 0, 4, s));
+    prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
+    hipLaunchKernelGGL(solve5pt_kernel, dim3(niters), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, 0, niters, B.recs);
+    hipLaunchKernelGGL(roots_kernel, dim3((niters + kHypPerWave - 1) / kHypPerWave), dim3(64), 0, s, (const PolyRec *)B.recs, 0,
+                       niters, B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total);
+    prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
+    prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
+    hipLaunchKernelGGL(median_kernel, dim3(niters * 10), dim3(256), 0, s, (const double4 *)pts, n, (const double *)B.dense_E,
+                       (const int32_t *)B.dense_id, (const int32_t *)B.total, 0, B.esum);
+    prof_mark(ctx, MLPL_PROF_SCORE, 1, s);
+    hipLaunchKernelGGL(lmeds_argmin_kernel, dim3(1), dim3(1024), 0, s, (const int32_t *)B.n_models, (const double *)B.esum,
+                       (const double *)B.E_tab, niters, d_st);
+    MLPL_HIP_TRY(hipGetLastError());
+    MLPL_HIP_TRY(hipMemcpyAsync(h_st, d_st, sizeof(LmedsState), hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipStreamSynchronize(s));
+    ctx->last_ransac_iters = niters;
+    if (h_st->best < 0 || !(h_st->minMedian < DBL_MAX)) {
+        set_error("mlpl_lmeds_essential: no model found");
+        return MLPL_E_FAILED;
+    }
+    const double minMedian = h_st->minMedian;
+    // modelest.cpp:555-559
+    double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 5)) * std::sqrt(minMedian);
+    sigma = std::max(sigma, 0.001);
+    hipLaunchKernelGGL(inlier_mask_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double4 *)pts, n,
+                       (const double *)d_st->E, sigma * sigma, d_mask, &d_st->inliers);
+    MLPL_HIP_TRY(hipGetLastError());
+    std::memcpy(E, h_st->E, 72);
+    if (min_median) *min_median = minMedian;
+    MLPL_HIP_TRY(hipMemcpyAsync(h_st, d_st, sizeof(LmedsState), hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipStreamSynchronize(s));
+    if (n_inliers) *n_inliers = h_st->inliers;
+    if (h_st->inliers < 5) {  // modelest.cpp:561: result = count >= modelPoints
+        set_error("mlpl_lmeds_essential: fewer than 5 inliers under the LMedS sigma");
+        return MLPL_E_FAILED;
+    }
+    return MLPL_OK;
+}
+
+int mlpl_lmeds_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n, double confidence, int max_iters,
+                         uint32_t seed, double E[9], uint8_t *mask, int *n_inliers, double *min_median) {
+    if (!ctx || !p1 || !p2 || !E || !mask || n < 6) {
+        set_error("mlpl_lmeds_essential: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    void *dp1, *dp2, *dmask;
+    int rc;
+    if ((rc = ws_get(ctx, WS_AUX0, (size_t)n * 16, &dp1))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX1, (size_t)n * 16, &dp2))) return rc;
+    if ((rc = ws_get(ctx, WS_MATCH, (size_t)n, &dmask))) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(dp1, p1, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    MLPL_HIP_TRY(hipMemcpyAsync(dp2, p2, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    rc = mlpl_lmeds_essential_dev(ctx, (const double *)dp1, (const double *)dp2, n, confidence, max_iters, seed, E,
+                                  (uint8_t *)dmask, n_inliers, min_median, ctx->stream);
+    // the mask is meaningful whenever a model was found, also when the inlier count fails the final test
+    if (rc && rc != MLPL_E_FAILED) return rc;
+    MLPL_HIP_TRY(hipMemcpy(mask, dmask, (size_t)n, hipMemcpyDeviceToHost));
+    return rc;
 }
 
 }  // extern "C"

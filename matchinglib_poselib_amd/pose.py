@@ -50,6 +50,17 @@ def score_models(p1, p2, E, thresh: float, ctx: Optional[Context] = None) -> Tup
     return good, esum
 
 
+def median_models(p1, p2, E, ctx: Optional[Context] = None) -> np.ndarray:
+    """Median Sampson error per model as runLMeDS takes it (modelest.cpp:540-544)."""
+    ctx = ctx or default_context()
+    p1, p2 = _pts(p1), _pts(p2)
+    E = np.ascontiguousarray(E, np.float64).reshape(-1, 9)
+    med = np.zeros(E.shape[0], np.float64)
+    check(ctx.lib.mlpl_median_models(ctx.handle, p1.ctypes.data, p2.ctypes.data, p1.shape[0], E.ctypes.data, E.shape[0],
+                                     med.ctypes.data), "mlpl_median_models")
+    return med
+
+
 def ransac_essential(p1, p2, thresh: float, confidence: float = 0.999, max_iters: int = 1000, refit: bool = True,
                      seed: int = 0, ctx: Optional[Context] = None) -> dict:
     """CvModelEstimator3::runRANSAC with the 5-point kernel (modelest.cpp:343-474); parameters the reference
@@ -66,6 +77,24 @@ def ransac_essential(p1, p2, thresh: float, confidence: float = 0.999, max_iters
     if rc not in (0, _lib.MLPL_E_FAILED):
         raise MlplError(rc, "mlpl_ransac_essential", _lib.last_error())
     return dict(ok=(rc == 0), E=E, mask=mask, n_inliers=ninl.value, iters=iters.value)
+
+
+def lmeds_essential(p1, p2, confidence: float = 0.999, max_iters: int = 2000, seed: int = 0,
+                    ctx: Optional[Context] = None) -> dict:
+    """CvModelEstimator3::runLMeDS with the 5-point kernel (modelest.cpp:483-564; findEssentialMat passes 2000 iterations,
+    five-point.cpp:127)."""
+    ctx = ctx or default_context()
+    p1, p2 = _pts(p1), _pts(p2)
+    n = p1.shape[0]
+    E = np.zeros((3, 3))
+    mask = np.zeros(n, np.uint8)
+    ninl, med = C.c_int(0), C.c_double(0)
+    rc = ctx.lib.mlpl_lmeds_essential(ctx.handle, p1.ctypes.data, p2.ctypes.data, n, float(confidence), int(max_iters),
+                                      int(seed) & 0xFFFFFFFF, E.ctypes.data, mask.ctypes.data, C.addressof(ninl),
+                                      C.addressof(med))
+    if rc not in (0, _lib.MLPL_E_FAILED):
+        raise MlplError(rc, "mlpl_lmeds_essential", _lib.last_error())
+    return dict(ok=(rc == 0), E=E, mask=mask, n_inliers=ninl.value, min_median=med.value)
 
 
 def ransac_essential_device(p1, p2, thresh: float, confidence: float = 0.999, max_iters: int = 1000, refit: bool = True,
@@ -93,11 +122,11 @@ def estimateEssentialMat(p1, p2, method: str = "ARRSAC", threshold: float = PIX_
                          seed: Optional[int] = None, ctx: Optional[Context] = None):
     """poselib::estimateEssentialMat (pose_estim.h:204-210, pose_estim.cpp:857-890) -> (ok, E, mask).
 
-    Only method == "RANSAC" is built in this library (the hot path).  Like the reference, "USAC" and unknown method
+    "RANSAC" (the hot path) and "LMEDS" are built in this library.  Like the reference, "USAC" and unknown method
     names are fatal (the reference prints and calls exit(1), pose_estim.cpp:878-887): SystemExit(1) is raised.
-    "ARRSAC" (the reference's default) and "LMEDS" are outside the hot path: NotImplementedError.
+    "ARRSAC" (the reference's default) is outside the hot path: NotImplementedError.
     `seed` = None mirrors the reference's std::srand(std::time(nullptr)) (modelest.cpp:58)."""
-    if method == "RANSAC":
+    if method in ("RANSAC", "LMEDS"):
         import time
 
         a, b = _pts(p1), _pts(p2)
@@ -107,9 +136,12 @@ def estimateEssentialMat(p1, p2, method: str = "ARRSAC", threshold: float = PIX_
             Es, nm = solve_5pt(a, b, np.arange(5, dtype=np.int32)[None, :], ctx=ctx)
             return True, Es[0, : nm[0]].reshape(-1, 3).copy(), np.ones(5, np.uint8)
         s = int(time.time()) if seed is None else seed
-        r = ransac_essential(p1, p2, threshold, confidence=0.999, max_iters=1000, refit=refine, seed=s, ctx=ctx)
+        if method == "LMEDS":  # no least-squares refit on this branch (pose_estim.cpp:874-877)
+            r = lmeds_essential(p1, p2, confidence=0.999, max_iters=2000, seed=s, ctx=ctx)
+        else:
+            r = ransac_essential(p1, p2, threshold, confidence=0.999, max_iters=1000, refit=refine, seed=s, ctx=ctx)
         return r["ok"], r["E"], r["mask"]
-    if method in ("ARRSAC", "LMEDS"):
+    if method == "ARRSAC":
         raise NotImplementedError(f"{method} is outside the RANSAC hot path built here")
     if method == "USAC":
         print("USAC must be executed by function estimateEssentialOrPoseUSAC as it needs additional paramters! Exiting.")

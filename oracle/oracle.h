@@ -117,6 +117,10 @@ int oracle_ransac_essential(const double *p1, const double *p2, int n, double th
                             int max_iters, int lesqu, unsigned seed, double *E, uint8_t *mask,
                             int *n_inliers, int *iters_run, oracle_ransac_trace *trace);
 
+/* CvModelEstimator3::runLMeDS (modelest.cpp:483-564) with the 5-point kernel; returns 1 on success. */
+int oracle_lmeds_essential(const double *p1, const double *p2, int n, double confidence, int max_iters, unsigned seed,
+                           double *E, uint8_t *mask, int *n_inliers, double *min_median);
+
 /* decomposeEssentialMat (five-point.cpp:340-352). */
 void oracle_decompose_essential(const double *E, double *R1, double *R2, double *t);
 

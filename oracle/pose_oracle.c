@@ -654,6 +654,69 @@ done:
 }
 
 /* ------------------------------------------------------------------------------------------------------------
+ * CvModelEstimator3::runLMeDS (modelest.cpp:483-564) as findEssentialMat drives it for method == LMEDS
+ * (five-point.cpp:125-129: confidence = prob, maxIters = 2000; pose_estim.cpp:874-877 passes 0.999).
+ * The error vector is sorted as int bit patterns (icvSortDistances on (int*)err.data, :541) -- for the non-negative
+ * Sampson errors that is the float order; the median of an even count is the FLOAT sum of the two middle values times 0.5.
+ * ---------------------------------------------------------------------------------------------------------- */
+static int cmp_i32(const void *a, const void *b) {
+    const int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return (x > y) - (x < y);
+}
+
+int oracle_lmeds_essential(const double *p1, const double *p2, int n, double confidence, int max_iters, unsigned seed,
+                           double *E, uint8_t *mask, int *n_inliers, double *min_median) {
+    if (n_inliers) *n_inliers = 0;
+    if (n < 6) return 0;
+    const double outlierRatio = 0.45;
+    oracle_glibc_rand st;
+    oracle_srand(&st, seed);
+    float *err = (float *)malloc(sizeof(float) * (size_t)n);
+    double models[90], ms1[10], ms2[10];
+    double minMedian = DBL_MAX;
+    int niters = (int)round(log(1. - confidence) / log(1. - pow(1. - outlierRatio, 5.0)));
+    niters = niters > 3 ? niters : 3;
+    niters = niters < max_iters ? niters : max_iters;
+    for (int iter = 0; iter < niters; iter++) {
+        int idx[5];
+        if (!oracle_get_subset(&st, p1, p2, n, 300, idx)) {
+            if (iter == 0) {
+                free(err);
+                return 0;
+            }
+            break;
+        }
+        for (int i = 0; i < 5; ++i) {
+            ms1[2 * i] = p1[2 * idx[i]];
+            ms1[2 * i + 1] = p1[2 * idx[i] + 1];
+            ms2[2 * i] = p2[2 * idx[i]];
+            ms2[2 * i + 1] = p2[2 * idx[i] + 1];
+        }
+        const int nmodels = oracle_run5point(ms1, ms2, 5, models);
+        for (int i = 0; i < nmodels; ++i) {
+            oracle_sampson_err(p1, p2, n, models + 9 * i, err);
+            qsort(err, (size_t)n, sizeof(float), cmp_i32);
+            const double median = (n % 2 != 0) ? (double)err[n / 2] : (double)(err[n / 2 - 1] + err[n / 2]) * 0.5;
+            if (median < minMedian) {
+                minMedian = median;
+                memcpy(E, models + 9 * i, sizeof(double) * 9);
+            }
+        }
+    }
+    int result = 0;
+    if (minMedian < DBL_MAX) {
+        double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 5)) * sqrt(minMedian);
+        sigma = sigma > 0.001 ? sigma : 0.001;
+        const int cnt = oracle_find_inliers(p1, p2, n, E, sigma, err, mask, NULL);
+        if (n_inliers) *n_inliers = cnt;
+        result = cnt >= 5;
+    }
+    if (min_median) *min_median = minMedian;
+    free(err);
+    return result;
+}
+
+/* ------------------------------------------------------------------------------------------------------------
  * Pose recovery
  * ---------------------------------------------------------------------------------------------------------- */
 static double det3(const double *M) {

@@ -90,6 +90,9 @@ class Oracle:
                                             mask.ctypes.data, C.byref(s))
         return good, s.value, err, mask
 
+    def sampson_err(self, p1, p2, E):
+        return self.find_inliers(p1, p2, E, 1.0)[2]
+
     def ransac_essential(self, p1, p2, thresh, confidence=0.999, max_iters=1000, lesqu=False, seed=12345, trace=False):
         p1 = np.ascontiguousarray(p1, np.float64)
         p2 = np.ascontiguousarray(p2, np.float64)
@@ -102,6 +105,19 @@ class Oracle:
                                               int(lesqu), seed, E.ctypes.data, mask.ctypes.data, C.byref(ninl),
                                               C.byref(iters), C.addressof(tr) if trace else None)
         return dict(ok=bool(ok), E=E, mask=mask, n_inliers=ninl.value, iters=iters.value, trace=tr)
+
+    def lmeds_essential(self, p1, p2, confidence=0.999, max_iters=2000, seed=12345):
+        p1 = np.ascontiguousarray(p1, np.float64)
+        p2 = np.ascontiguousarray(p2, np.float64)
+        n = p1.shape[0]
+        E = np.zeros((3, 3))
+        mask = np.zeros(n, np.uint8)
+        ninl, med = C.c_int(0), C.c_double(0)
+        self.lib.oracle_lmeds_essential.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_uint, C.c_void_p,
+                                                    C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        ok = self.lib.oracle_lmeds_essential(p1.ctypes.data, p2.ctypes.data, n, confidence, max_iters, seed, E.ctypes.data,
+                                             mask.ctypes.data, C.byref(ninl), C.byref(med))
+        return dict(ok=bool(ok), E=E, mask=mask, n_inliers=ninl.value, min_median=med.value)
 
     def recover_pose(self, E, p1, p2, dist=50.0, mask=None):
         p1 = np.ascontiguousarray(p1, np.float64)

@@ -176,3 +176,20 @@ def test_decompose_essential(oracle):
         assert np.abs(Rx @ Rx.T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(Rx) - 1) < 1e-12
     assert min(np.abs(R1 - R).max(), np.abs(R2 - R).max()) < 1e-10
     assert min(np.abs(tv - t).max(), np.abs(tv + t).max()) < 1e-10
+
+
+def test_lmeds_recovers_pose(oracle):
+    """runLMeDS (modelest.cpp:483-564): 134 samples at confidence 0.999, no threshold argument."""
+    p1, p2, R, t, mask, th = synth.pose_scene(1500, inlier_frac=0.7, seed=23)
+    r = oracle.lmeds_essential(p1, p2, seed=12345)
+    assert r["ok"] and int(r["mask"].sum()) == r["n_inliers"]
+    assert (r["mask"].astype(bool) == mask).mean() > 0.97
+    good, Rr, tr_, Q, m = oracle.recover_pose(r["E"], p1, p2, 50.0, r["mask"])
+    assert np.abs(Rr - R).max() < 2e-2 and np.abs(tr_ - t).max() < 2e-2
+    # same seed, same answer; the sample stream is RANSAC's
+    r2 = oracle.lmeds_essential(p1, p2, seed=12345)
+    assert np.array_equal(r["E"], r2["E"]) and r["min_median"] == r2["min_median"]
+    # breakdown point: with fewer than half inliers the median is an outlier error and the mask degenerates
+    p1b, p2b, *_ , maskb, thb = synth.pose_scene(1500, inlier_frac=0.3, seed=23)
+    rb = oracle.lmeds_essential(p1b, p2b, seed=12345)
+    assert rb["min_median"] > 100 * r["min_median"]
