@@ -83,6 +83,23 @@ def run(ctx, dev, cpu_baseline=True):
         tc = time.perf_counter() - tc
         out["ransac_c3"]["cpu_baseline"] = {"value": ci / tc, "unit": "hypotheses/s", "cores": 1, "kind": "port",
                                             "sample": f"first {ci} of the 20000 iterations of the same run ({tc:.2f} s)"}
+    # ---- LMedS on the C3 scene: the reference's LMEDS settings (134 samples at confidence 0.999) and the largest sample count a double confidence reaches (711) ----
+    for conf, name in ((0.999, "lmeds_reference_settings"), (1.0 - 1e-16, "lmeds_711_samples")):
+        lc = lambda: pose.lmeds_essential(p1, p2, confidence=conf, max_iters=2000, seed=12345, ctx=ctx)  # noqa: E731
+        lr = lc()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            lc()
+        dt = (time.perf_counter() - t0) / 5
+        out[name] = {"metric": "LMedS essential matrix, host points in / E + mask out (5000 correspondences)",
+                     "ms_per_call": dt * 1e3, "n_inliers": lr["n_inliers"], "min_median": lr["min_median"],
+                     "includes": "H2D of the points, host sample table, solve + median (radix select) + arg-min kernels, sigma mask, "
+                                 "two small readbacks, D2H of the mask"}
+    if cpu_baseline:
+        tc = time.perf_counter()
+        ora.lmeds_essential(p1, p2, seed=12345)
+        out["lmeds_reference_settings"]["cpu_baseline"] = {"ms_per_call": (time.perf_counter() - tc) * 1e3, "cores": 1,
+                                                           "kind": "port", "sample": "the same call"}
     # ---- C4: L2 ----
     q, tt = synth.sift_pair(4096, 4096, seed=20260104)
     dq = torch.from_numpy(q).to(dev)

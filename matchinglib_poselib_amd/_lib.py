@@ -178,6 +178,10 @@ class Context:
     def synchronize(self):
         check(self._lib.mlpl_ctx_synchronize(self._h), "mlpl_ctx_synchronize")
 
+    def set_option(self, name: str, value: int):
+        """mlpl_set_option (include/mlpl_c.h): kernel selection / tuning knobs of this context."""
+        check(self._lib.mlpl_set_option(self._h, name.encode(), int(value)), "mlpl_set_option")
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.mlpl_ctx_destroy(self._h)

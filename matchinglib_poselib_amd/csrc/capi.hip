@@ -111,6 +111,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_hamming_variant = 0;
     ctx->opt_hamming_qpl = 1;
     ctx->opt_hamming_blocks_per_cu = 32;
+    ctx->opt_hamming_mfma_blocks_per_cu = 2;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -148,7 +149,8 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx) {
 
 int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     if (!ctx || !name) return MLPL_E_BAD_INPUT;
-    if (!std::strcmp(name, "hamming_variant") && value >= 0 && value <= 2) ctx->opt_hamming_variant = value;
+    if (!std::strcmp(name, "hamming_variant") && value >= 0 && value <= 3) ctx->opt_hamming_variant = value;
+    else if (!std::strcmp(name, "hamming_mfma_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_mfma_blocks_per_cu = value;
     else if (!std::strcmp(name, "hamming_qpl") && (value == 1 || value == 2)) ctx->opt_hamming_qpl = value;
     else if (!std::strcmp(name, "hamming_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_blocks_per_cu = value;
     else if (!std::strcmp(name, "ransac_chunk") && value >= 0 && value <= (1 << 20)) ctx->opt_ransac_chunk = value;

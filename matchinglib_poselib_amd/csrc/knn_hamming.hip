@@ -324,6 +324,10 @@ void launch_partial(int variant, int qpl, dim3 grid, hipStream_t s, const uint32
 
 }  // namespace
 
+int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_words, const uint32_t *tw, size_t t_batch_words,
+                            int nq, int nt, int nw, int batch, int dshift, hipStream_t s, int *rps_out, int *nsplit_out,
+                            uint2 **part_out);
+
 int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_stride, size_t q_bstride,
                        const uint8_t *d_t, int nt, size_t t_stride, size_t t_bstride, int nbytes, int k, int batch,
                        int32_t *d_idx, int32_t *d_dist, hipStream_t s, float ratio, int32_t *d_group_counts) {
@@ -375,8 +379,20 @@ int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_strid
         tbw = (size_t)nt * nw;
     }
 
-    // split the train rows so that the grid holds ~tune_blocks_per_cu blocks per CU
     const int variant = ctx->opt_hamming_variant;
+    if (variant == 3 && nw <= 16) {  // matrix-core kernel (knn_hamming_mfma.hip); wider descriptors take the VALU kernels
+        int rps = 0, nsplit = 0;
+        uint2 *part = nullptr;
+        int rc = launch_knn_hamming_mfma(ctx, qw, qbw, tw, tbw, nq, nt, nw, batch, dshift, s, &rps, &nsplit, &part);
+        if (rc) return rc;
+        dim3 mgrid((nq + kMergeGroup - 1) / kMergeGroup, batch);
+        hipLaunchKernelGGL(knn_hamming_merge_kernel, mgrid, dim3(1024), 0, s, (const uint2 *)part, nq, nsplit, rps, dshift, k,
+                           ratio, d_idx, d_dist, d_group_counts);
+        MLPL_HIP_TRY(hipGetLastError());
+        return MLPL_OK;
+    }
+
+    // split the train rows so that the grid holds ~tune_blocks_per_cu blocks per CU
     int qpl = (variant == 1 && nw <= 16) ? ctx->opt_hamming_qpl : 1;  // queries per lane
     if (qpl == 2 && nq <= kQueriesPerBlock * 32) qpl = 1;                // too few queries to afford it
     const int qpb = (variant == 2) ? 64 : kQueriesPerBlock * qpl;  // queries per block

@@ -1,0 +1,271 @@
+// knn_hamming_mfma.hip -- exact brute-force 2-NN under bit-Hamming distance on the gfx950 matrix cores.
+//
+// Same contract as knn_hamming.hip (cvflann::Index<HammingLUT>(LinearIndexParams).knnSearch of
+// matchinglib/source/matchers.cpp:567-588: the two lexicographically smallest (distance, trainIdx) pairs per query,
+// bit-exact), different arithmetic: every descriptor bit b becomes the fp4 (E2M1) value 2b-1 in {-1,+1}, so that
+//     sum_k a'_k b'_k = (#equal bits) - (#different bits) = nbits - 2 * hamming(a, b),
+// an all-pairs distance table is a dense +-1 GEMM, and v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 x fp4, unit scales, fp32
+// accumulate) produces 32x32 of them per K=64 step.  All sums are small integers: exact in fp32.
+//
+// The VALU kernels of knn_hamming.hip spend 2*NW+3 issue slots per descriptor pair (76 cycles per 64 pairs at NW = 8,
+// measured issue floor); here a pair costs KS/1024 MFMAs plus TWO vector instructions:
+//   * queries sit on the lanes (B operand, column = lane & 31), a 32-row train tile is the A operand, so after the K loop
+//     a lane holds 16 distances of ITS query to 16 train rows;
+//   * the row index rides in the accumulator: the first MFMA of a tile reads C = -(local row) * 2^-14 from 16 constant
+//     registers, so v = (nbits - 2 d) - row * eps orders candidates by (distance asc, row asc) as a plain float, and the
+//     running top-2 per lane is  m2 = med3(m1, m2, v); m1 = max(m1, v)  -- two VALU ops per pair, no key packing;
+//   * between tiles the running pair is re-based by +32 eps (two adds per 512 pairs) instead of re-building the 16
+//     constants; values stay exactly representable (|int| <= 512, fraction a multiple of 2^-14 below 1/4);
+//   * operands are pre-expanded once per call into MFMA fragment order ([tile][kstep][lane] x 16 B), so a wave fetches a
+//     train tile's fragment with KS perfectly coalesced 1 KiB loads straight from L2 (the expanded train set of a C2
+//     image is 1 MiB) -- no LDS, no barriers; the query fragments stay in registers for the whole kernel.
+// Output: the same [batch][split][nq] uint2 table of packed (dist << dshift | local row) keys the VALU kernels write,
+// merged by knn_hamming_merge_kernel.
+
+#include "mlpl_internal.h"
+
+namespace mlpl {
+
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr float kEps = 1.0f / 16384.0f;  // 2^-14: row weight in the accumulator
+constexpr int kMaxRowsPerSplit = 4096;   // keeps the re-based fraction below 1/4
+
+__device__ __forceinline__ float fmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fmed3_raw(float a, float b, float c) {
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// 8 bits -> 8 fp4 nibbles (bit i -> nibble i): 1 -> 0x2 (+1.0), 0 -> 0xA (-1.0)
+__device__ __forceinline__ uint32_t expand_byte(uint32_t x) {
+    uint32_t t = (x | (x << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    t = (t | (t << 3)) & 0x11111111u;
+    return 0xAAAAAAAAu ^ (t << 3);
+}
+
+// Rows of `nw` 32-bit words (word rows as the VALU path uses them) -> fragment order.  Lane (r = l & 31, h = l >> 5) of
+// K-step s holds bits [64 s + 32 h, 64 s + 32 h + 32) of row 32 * tile + r: word 2 s + h.  Rows >= n and words >= nw read
+// as zero bits (the same in both operands, so they add nothing to a distance).  `tiles` covers the padded row count.
+__global__ void hamming_expand_kernel(const uint32_t *__restrict__ src, size_t src_batch_words, int n, int nw, int ks, int tiles,
+                                      uint4 *__restrict__ dst) {
+    const int b = blockIdx.y;
+    const long long total = (long long)tiles * ks * 64;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int l = (int)(i & 63);
+        const long long ts = i >> 6;
+        const int s = (int)(ts % ks);
+        const int tile = (int)(ts / ks);
+        const int row = tile * 32 + (l & 31);
+        const int w = 2 * s + (l >> 5);
+        const uint32_t v = (row < n && w < nw) ? src[(size_t)b * src_batch_words + (size_t)row * nw + w] : 0u;
+        dst[(size_t)b * total + i] =
+            make_uint4(expand_byte(v & 255u), expand_byte((v >> 8) & 255u), expand_byte((v >> 16) & 255u), expand_byte(v >> 24));
+    }
+}
+
+__device__ __forceinline__ v16f mfma_fp4(uint4 a, uint4 b, v16f c) {
+    const v8i av = {(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
+    const v8i bv = {(int)b.x, (int)b.y, (int)b.z, (int)b.w, 0, 0, 0, 0};
+    // cbsz = blgp = 4: fp4 operands (4 registers each); E8M0 scale 0x7F = 2^0 for both
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
+// KS K-steps of 64 bits, QT query tiles (32 queries each) per wave; 4 waves per block share a train range.
+template <int KS, int QT>
+__global__ __launch_bounds__(256, 2) void knn_hamming_mfma_kernel(const uint4 *__restrict__ qfrag, size_t q_batch_u4,
+                                                               const uint4 *__restrict__ tfrag, size_t t_batch_u4, int nq, int nt,
+                                                               int rows_per_split, int nsplit, int dshift,
+                                                               uint2 *__restrict__ part) {
+    const int l = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int b = blockIdx.z;
+    const int split = blockIdx.y;
+    const int qt0 = (blockIdx.x * 4 + w) * QT;  // first query tile of this wave (the fragment buffer is padded to whole blocks)
+    if (qt0 * 32 >= nq) return;                 // wave-uniform; the kernel has no barriers
+    const uint4 *qf = qfrag + (size_t)b * q_batch_u4 + (size_t)qt0 * KS * 64 + l;
+    const uint4 *tf = tfrag + (size_t)b * t_batch_u4 + l;
+
+    uint4 bq[QT][KS];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bq[t][s] = qf[(size_t)(t * KS + s) * 64];
+
+    // C of the first MFMA of every tile: minus the local row of accumulator register `reg` in this lane, times eps
+    const int h = l >> 5;
+    v16f cinit;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) cinit[reg] = -(float)((reg & 3) + 8 * (reg >> 2) + 4 * h) * kEps;
+
+    const int row0 = split * rows_per_split;
+    const int row1 = min(nt, row0 + rows_per_split);
+    const int tile0 = row0 >> 5;
+    const int ntiles = (row1 - row0 + 31) >> 5;  // >= 1: the host never launches an empty split
+
+    float m1[QT], m2[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) m1[t] = m2[t] = -INFINITY;
+
+    uint4 a[KS], an[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) a[s] = tf[(size_t)(tile0 * KS + s) * 64];
+
+    // one train tile against the wave's QT query tiles: KS MFMAs + 34 VALU ops per query tile
+    auto tile_body = [&](const v16f &c0) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            v16f acc = mfma_fp4(a[0], bq[t][0], c0);
+#pragma unroll
+            for (int s = 1; s < KS; ++s) acc = mfma_fp4(a[s], bq[t][s], acc);
+            // re-base the running pair to this tile's row origin (exact; -inf stays -inf)
+            m1[t] += 32.0f * kEps;
+            m2[t] += 32.0f * kEps;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float v = acc[reg];
+                m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], v);
+                m1[t] = __builtin_fmaxf(m1[t], v);
+            }
+        }
+    };
+
+    // only the last tile of the train set can be ragged; it gets its own C (rows >= nt start at -inf and stay there)
+    const bool ragged = row0 + ntiles * 32 > nt;
+    const int nfull = ragged ? ntiles - 1 : ntiles;
+    for (int it = 0; it < nfull; ++it) {
+        const int nxt = min(it + 1, ntiles - 1);  // the last iteration re-reads its own tile: harmless, branch-free
+#pragma unroll
+        for (int s = 0; s < KS; ++s) an[s] = tf[(size_t)((tile0 + nxt) * KS + s) * 64];
+        tile_body(cinit);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[s] = an[s];
+    }
+    if (ragged) {
+        const int tile_row0 = row0 + nfull * 32;
+        v16f cl;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int lr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            cl[reg] = (tile_row0 + lr < nt) ? -(float)lr * kEps : -INFINITY;
+        }
+        tile_body(cl);
+    }
+
+    // decode (frame = last tile): v = (64 KS - 2 d) + (32 (ntiles - 1) - local_row) * eps
+    const float frame = (float)(32 * (ntiles - 1));
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        uint32_t k[2];
+        const float mm[2] = {m1[t], m2[t]};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (mm[j] == -INFINITY) {
+                k[j] = 0xFFFFFFFFu;
+            } else {
+                const float ip = rintf(mm[j]);
+                const int d = (64 * KS - (int)ip) >> 1;
+                const int lrow = (int)(frame - (mm[j] - ip) * 16384.0f);
+                k[j] = ((uint32_t)d << dshift) | (uint32_t)lrow;
+            }
+        }
+        // the two lane halves hold disjoint rows of the same query: top-2 of the four keys
+        const uint32_t o0 = __shfl_xor(k[0], 32), o1 = __shfl_xor(k[1], 32);
+        uint32_t k0 = k[0], k1 = k[1];
+        k1 = umed3(k0, k1, o0);
+        k0 = min(k0, o0);
+        k1 = umed3(k0, k1, o1);
+        k0 = min(k0, o1);
+        const int q = (qt0 + t) * 32 + (l & 31);
+        if (h == 0 && q < nq) part[((size_t)b * nsplit + split) * nq + q] = make_uint2(k0, k1);
+    }
+}
+
+template <int KS>
+void launch_mfma(int qt, dim3 grid, hipStream_t s, const uint4 *qf, size_t qb, const uint4 *tf, size_t tb, int nq, int nt, int rps,
+                 int nsplit, int dshift, uint2 *part) {
+    if constexpr (KS <= 4) {
+        if (qt == 4) {
+            hipLaunchKernelGGL((knn_hamming_mfma_kernel<KS, 4>), grid, dim3(256), 0, s, qf, qb, tf, tb, nq, nt, rps, nsplit, dshift, part);
+            return;
+        }
+    }
+    if (qt >= 2)
+        hipLaunchKernelGGL((knn_hamming_mfma_kernel<KS, 2>), grid, dim3(256), 0, s, qf, qb, tf, tb, nq, nt, rps, nsplit, dshift, part);
+    else
+        hipLaunchKernelGGL((knn_hamming_mfma_kernel<KS, 1>), grid, dim3(256), 0, s, qf, qb, tf, tb, nq, nt, rps, nsplit, dshift, part);
+}
+
+}  // namespace
+
+// Called by launch_knn_hamming for descriptors of at most 64 bytes.  qw/tw: word rows (nw words per row, zero padded).
+int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_words, const uint32_t *tw, size_t t_batch_words,
+                            int nq, int nt, int nw, int batch, int dshift, hipStream_t s, int *rps_out, int *nsplit_out,
+                            uint2 **part_out) {
+    int ks = 1;
+    while (ks * 2 < nw) ks *= 2;  // 64-bit K-steps: nw <= 2 -> 1, 4 -> 2, 8 -> 4, 16 -> 8
+    if (nw > 16) {
+        set_error("knn_hamming (mfma): descriptors above 64 bytes take the VALU kernels");
+        return MLPL_E_BAD_INPUT;
+    }
+    // query tiles per wave: fill the chip first, then amortise the train fragment loads over more queries
+    const int nqt = (nq + 31) / 32;
+    const int max_qt = ks <= 4 ? 4 : 2;
+    int qt = max_qt;
+    while (qt > 1 && (long long)((nqt + 4 * qt - 1) / (4 * qt)) * batch * 4 < (long long)ctx->num_cus) qt >>= 1;
+    const int qblocks = (nqt + 4 * qt - 1) / (4 * qt);
+    const int q_tiles_padded = qblocks * 4 * qt;
+    const int t_tiles = (nt + 31) / 32;
+
+    // train splits: ~opt blocks per CU in flight, whole tiles, bounded so that the re-based fraction stays exact
+    const long long target_blocks = (long long)std::max(1, ctx->opt_hamming_mfma_blocks_per_cu) * ctx->num_cus;
+    long long want = (target_blocks + (long long)qblocks * batch - 1) / ((long long)qblocks * batch);
+    int nsplit = (int)std::max<long long>(1, std::min<long long>(want, t_tiles));
+    int rps = ((nt + nsplit - 1) / nsplit + 31) / 32 * 32;
+    rps = std::min(rps, kMaxRowsPerSplit);
+    nsplit = (nt + rps - 1) / rps;
+    if (nsplit > 65535) {
+        set_error("knn_hamming: train set too large (nt=%d)", nt);
+        return MLPL_E_BAD_INPUT;
+    }
+
+    void *qf = nullptr, *tf = nullptr, *part = nullptr;
+    int rc;
+    const size_t q_u4 = (size_t)q_tiles_padded * ks * 64, t_u4 = (size_t)t_tiles * ks * 64;
+    if ((rc = ws_get(ctx, WS_FRAG_Q, (size_t)batch * q_u4 * 16, &qf))) return rc;
+    if ((rc = ws_get(ctx, WS_FRAG_T, (size_t)batch * t_u4 * 16, &tf))) return rc;
+    if ((rc = ws_get(ctx, WS_PARTIAL, (size_t)batch * nsplit * nq * sizeof(uint2), &part))) return rc;
+    hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)std::min<size_t>((q_u4 + 255) / 256, 8192), batch), dim3(256), 0, s, qw,
+                       q_batch_words, nq, nw, ks, q_tiles_padded, (uint4 *)qf);
+    hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)std::min<size_t>((t_u4 + 255) / 256, 8192), batch), dim3(256), 0, s, tw,
+                       t_batch_words, nt, nw, ks, t_tiles, (uint4 *)tf);
+    dim3 grid(qblocks, nsplit, batch);
+    prof_mark(ctx, MLPL_PROF_KNN_HAMMING, 0, s);
+    switch (ks) {
+        case 1: launch_mfma<1>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, (uint2 *)part); break;
+        case 2: launch_mfma<2>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, (uint2 *)part); break;
+        case 4: launch_mfma<4>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, (uint2 *)part); break;
+        default: launch_mfma<8>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, (uint2 *)part); break;
+    }
+    prof_mark(ctx, MLPL_PROF_KNN_HAMMING, 1, s);
+    *rps_out = rps;
+    *nsplit_out = nsplit;
+    *part_out = (uint2 *)part;
+    return MLPL_OK;
+}
+
+}  // namespace mlpl

@@ -42,6 +42,8 @@ enum WsSlot {
     WS_AUX7,
     WS_SCALARS,   // small host-readable outputs of the host-pointer entry points (match counts)
     WS_L2_FLAG,   // device gate flag of the L2 auto path
+    WS_FRAG_Q,    // fp4 MFMA fragments of the query / train descriptors (knn_hamming_mfma.hip)
+    WS_FRAG_T,
     WS_NUM_SLOTS
 };
 
@@ -63,6 +65,7 @@ struct mlpl_ctx {
     int opt_hamming_variant;        // 0 = LDS-tiled broadcast reads, 1 = scalar-load (SGPR operand) kernel
     int opt_hamming_qpl;            // queries per lane for variant 1 (1 or 2)
     int opt_hamming_blocks_per_cu;  // grid sizing target
+    int opt_hamming_mfma_blocks_per_cu;  // grid sizing target of the matrix-core kernel (4-wave blocks)
     int opt_ransac_chunk;           // hypotheses per device pass (0 = 32768)
     // cached table T[g] = cvRANSACUpdateNumIters1(conf, (n-g)/n, 5, inf) for the last (n, conf) (host libm values)
     int32_t *ransac_T_host;

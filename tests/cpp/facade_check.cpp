@@ -5,6 +5,7 @@
 //        int32 sr_rc ; sr_E[9] ; int32 sr_inliers
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "matchinglib_poselib/matchinglib_matchers.h"
@@ -73,6 +74,16 @@ int main(int argc, char **argv) {
     fwrite(&rc, 4, 1, o);
     fwrite(rc == 0 ? (const void *)sr.E_new.data : (const void *)zero, 8, 9, o);
     fwrite(&inl, 4, 1, o);
+
+    // estimateEssentialMat(..., "LMEDS") (pose_estim.cpp:874-877): same seed control, no refit
+    poselib::setRansacSeed(seed);
+    cv::Mat El, maskl;
+    int32_t okl = poselib::estimateEssentialMat(El, p1, p2, "LMEDS", th, true, maskl) ? 1 : 0;
+    fwrite(&okl, 4, 1, o);
+    fwrite(okl ? (const void *)El.data : (const void *)zero, 8, 9, o);
+    std::vector<uint8_t> ml((size_t)n, 0);
+    if (okl) std::memcpy(ml.data(), maskl.data, (size_t)n);
+    fwrite(ml.data(), 1, (size_t)n, o);
     fclose(o);
     return 0;
 }

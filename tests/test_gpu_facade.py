@@ -68,3 +68,11 @@ def test_cpp_facade_end_to_end(oracle, tmp_path):
     o2 = oracle.ransac_essential(q1, q2, 0.8 * synth.PIX_TO_CAM, confidence=0.999, max_iters=1000, lesqu=False, seed=seed)
     assert sr_inl == o2["n_inliers"]
     assert min(np.abs(sr_E - o2["E"]).max(), np.abs(sr_E + o2["E"]).max()) < 1e-8
+
+    okl = take(np.int32, 1)[0]
+    El = take(np.float64, 9).reshape(3, 3)
+    ml = take(np.uint8, 1200)
+    o3 = oracle.lmeds_essential(p1, p2, confidence=0.999, max_iters=2000, seed=seed)
+    assert okl == 1 and o3["ok"]
+    assert min(np.abs(El - o3["E"]).max(), np.abs(El + o3["E"]).max()) < 1e-8
+    assert (ml != o3["mask"]).sum() <= 2

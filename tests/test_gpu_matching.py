@@ -318,3 +318,61 @@ def test_l2_device_batched(ctx, oracle):
     for b in range(B):
         oi, od = oracle.knn_l2sq(pairs[b][0], pairs[b][1])
         assert np.array_equal(idx[b].cpu().numpy(), oi) and dist[b].cpu().numpy().tobytes() == od.tobytes(), b
+
+
+HAMMING_VARIANTS = {0: "LDS-tiled VALU", 1: "scalar-operand VALU", 2: "one wave per block VALU", 3: "fp4 matrix-core"}
+
+
+@pytest.mark.parametrize("variant", sorted(HAMMING_VARIANTS))
+def test_hamming_every_kernel_variant_bit_exact(ctx, oracle, variant):
+    """Every selectable Hamming kernel gives the oracle's (distance, index) pairs bit for bit: shapes around the tile sizes
+    (32-row MFMA tiles, 128-row LDS tiles), descriptor widths around the K-step (8 bytes), ties, ragged last tiles, k = 1."""
+    ctx.set_option("hamming_variant", variant)
+    try:
+        for nq, nt, nbytes, k in [(1, 2, 32, 2), (15, 15, 32, 2), (64, 1000, 32, 1), (300, 129, 32, 2), (1000, 5000, 32, 2),
+                                  (77, 333, 64, 2), (50, 200, 16, 2), (40, 90, 61, 2), (33, 70, 24, 2), (20, 40, 1, 2),
+                                  (10, 600, 128, 2), (31, 33, 8, 2), (129, 4097, 32, 2), (513, 31, 32, 2), (2048, 2048, 32, 2),
+                                  (100, 9000, 64, 2), (640, 96, 9, 2)]:
+            q, t = synth.orb_pair(nq, nt, nbytes=nbytes, seed=2000 + nq + nt + nbytes)
+            idx, dist = mpa.knn_hamming(q, t, k=k, ctx=ctx)
+            oi, od = oracle.knn_hamming(q, t, k=k)
+            assert np.array_equal(dist, od), (variant, nq, nt, nbytes, k)
+            assert np.array_equal(idx, oi), (variant, nq, nt, nbytes, k)
+        # ties everywhere: 5 distinct descriptors, the smaller train index must win in every merge level
+        rng = np.random.default_rng(9)
+        base = rng.integers(0, 256, (5, 32), dtype=np.uint8)
+        t = base[rng.integers(0, 5, 3000)]
+        q = base[rng.integers(0, 5, 500)]
+        idx, dist = mpa.knn_hamming(q, t, ctx=ctx)
+        oi, od = oracle.knn_hamming(q, t)
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+        # extremes of the distance range: all-equal and all-different bits
+        z = np.zeros((70, 32), np.uint8)
+        o = np.full((90, 32), 255, np.uint8)
+        for a, b in ((z, o), (z, z[:40]), (o, np.concatenate([z[:45], o[:3]]))):
+            idx, dist = mpa.knn_hamming(a, b, ctx=ctx)
+            oi, od = oracle.knn_hamming(a, b)
+            assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+        # the fused getMatches path on this variant
+        q, t = synth.orb_pair(700, 900, seed=31)
+        err, m = mpa.getMatches([None] * 700, [None] * 900, q, t, matcher_name="LINEAR", ctx=ctx)
+        rc, om = oracle.get_matches_linear(700, 900, q, t)
+        assert err == rc == 0 and m.tobytes() == om.tobytes()
+    finally:
+        ctx.set_option("hamming_variant", 0)
+
+
+@pytest.mark.parametrize("variant", [3])
+def test_c2_full_size_matrix_core_equals_valu(ctx, oracle, variant):
+    """BASELINE C2 (8192 x 8192 x 256 bit): the matrix-core kernel against the VALU kernel (itself oracle-checked on samples)."""
+    q, t = synth.orb_pair(8192, 8192, seed=20260102)
+    idx0, dist0 = mpa.knn_hamming(q, t, ctx=ctx)
+    ctx.set_option("hamming_variant", variant)
+    try:
+        idx3, dist3 = mpa.knn_hamming(q, t, ctx=ctx)
+    finally:
+        ctx.set_option("hamming_variant", 0)
+    assert np.array_equal(idx0, idx3) and np.array_equal(dist0, dist3)
+    rows = np.random.default_rng(1).choice(8192, 64, replace=False)
+    oi, od = oracle.knn_hamming(q[rows], t)
+    assert np.array_equal(idx3[rows], oi) and np.array_equal(dist3[rows], od)
