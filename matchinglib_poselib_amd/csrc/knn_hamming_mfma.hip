@@ -61,10 +61,18 @@ __device__ __forceinline__ uint32_t expand_byte(uint32_t x) {
 // Rows of `nw` 32-bit words (word rows as the VALU path uses them) -> fragment order.  Lane (r = l & 31, h = l >> 5) of
 // K-step s holds bits [64 s + 32 h, 64 s + 32 h + 32) of row 32 * tile + r: word 2 s + h.  Rows >= n and words >= nw read
 // as zero bits (the same in both operands, so they add nothing to a distance).  `tiles` covers the padded row count.
-__global__ void hamming_expand_kernel(const uint32_t *__restrict__ src, size_t src_batch_words, int n, int nw, int ks, int tiles,
-                                      uint4 *__restrict__ dst) {
+// One launch expands both operands: blockIdx.z = 0 queries, 1 train rows.
+struct ExpandArgs {
+    const uint32_t *src;
+    size_t src_batch_words;
+    int n, tiles;
+    uint4 *dst;
+};
+
+__global__ void hamming_expand_kernel(ExpandArgs qa, ExpandArgs ta, int nw, int ks) {
+    const ExpandArgs A = blockIdx.z ? ta : qa;
     const int b = blockIdx.y;
-    const long long total = (long long)tiles * ks * 64;
+    const long long total = (long long)A.tiles * ks * 64;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int l = (int)(i & 63);
         const long long ts = i >> 6;
@@ -72,8 +80,8 @@ __global__ void hamming_expand_kernel(const uint32_t *__restrict__ src, size_t s
         const int tile = (int)(ts / ks);
         const int row = tile * 32 + (l & 31);
         const int w = 2 * s + (l >> 5);
-        const uint32_t v = (row < n && w < nw) ? src[(size_t)b * src_batch_words + (size_t)row * nw + w] : 0u;
-        dst[(size_t)b * total + i] =
+        const uint32_t v = (row < A.n && w < nw) ? A.src[(size_t)b * A.src_batch_words + (size_t)row * nw + w] : 0u;
+        A.dst[(size_t)b * total + i] =
             make_uint4(expand_byte(v & 255u), expand_byte((v >> 8) & 255u), expand_byte((v >> 16) & 255u), expand_byte(v >> 24));
     }
 }
@@ -87,7 +95,7 @@ __device__ __forceinline__ v16f mfma_fp4(uint4 a, uint4 b, v16f c) {
 
 // KS K-steps of 64 bits, QT query tiles (32 queries each) per wave; 4 waves per block share a train range.
 template <int KS, int QT>
-__global__ __launch_bounds__(256, 2) void knn_hamming_mfma_kernel(const uint4 *__restrict__ qfrag, size_t q_batch_u4,
+__global__ __launch_bounds__(256, (KS >= 8 ? 2 : 3)) void knn_hamming_mfma_kernel(const uint4 *__restrict__ qfrag, size_t q_batch_u4,
                                                                const uint4 *__restrict__ tfrag, size_t t_batch_u4, int nq, int nt,
                                                                int rows_per_split, int nsplit, int dshift,
                                                                uint2 *__restrict__ part) {
@@ -121,12 +129,14 @@ __global__ __launch_bounds__(256, 2) void knn_hamming_mfma_kernel(const uint4 *_
 #pragma unroll
     for (int t = 0; t < QT; ++t) m1[t] = m2[t] = -INFINITY;
 
-    uint4 a[KS], an[KS];
+    // fragment stream of this split; the buffer carries one spare tile, so the prefetch past the last tile needs no clamp
+    const uint4 *tp = tf + (size_t)tile0 * KS * 64;
+    uint4 fa[KS], fb[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) a[s] = tf[(size_t)(tile0 * KS + s) * 64];
+    for (int s = 0; s < KS; ++s) fa[s] = tp[s * 64];
 
-    // one train tile against the wave's QT query tiles: KS MFMAs + 34 VALU ops per query tile
-    auto tile_body = [&](const v16f &c0) {
+    // one train tile against the wave's QT query tiles: KS MFMAs + 22 VALU ops per query tile
+    auto tile_body = [&](const uint4 (&a)[KS], const v16f &c0) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             v16f acc = mfma_fp4(a[0], bq[t][0], c0);
@@ -135,11 +145,15 @@ __global__ __launch_bounds__(256, 2) void knn_hamming_mfma_kernel(const uint4 *_
             // re-base the running pair to this tile's row origin (exact; -inf stays -inf)
             m1[t] += 32.0f * kEps;
             m2[t] += 32.0f * kEps;
+            // four candidates per step, 5 VALU ops: with T = {m1, a, b} the second largest of T + {m2} is max(med3(T), m2)
+            // because m2 <= m1; two such pairs share one max3 for m2 (values are distinct, or -inf)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float v = acc[reg];
-                m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], v);
-                m1[t] = __builtin_fmaxf(m1[t], v);
+            for (int reg = 0; reg < 16; reg += 4) {
+                const float s0 = __builtin_amdgcn_fmed3f(m1[t], acc[reg], acc[reg + 1]);
+                const float t0 = __builtin_fmaxf(__builtin_fmaxf(m1[t], acc[reg]), acc[reg + 1]);
+                const float s1 = __builtin_amdgcn_fmed3f(t0, acc[reg + 2], acc[reg + 3]);
+                m1[t] = __builtin_fmaxf(__builtin_fmaxf(t0, acc[reg + 2]), acc[reg + 3]);
+                m2[t] = __builtin_fmaxf(__builtin_fmaxf(m2[t], s0), s1);
             }
         }
     };
@@ -147,13 +161,22 @@ __global__ __launch_bounds__(256, 2) void knn_hamming_mfma_kernel(const uint4 *_
     // only the last tile of the train set can be ragged; it gets its own C (rows >= nt start at -inf and stay there)
     const bool ragged = row0 + ntiles * 32 > nt;
     const int nfull = ragged ? ntiles - 1 : ntiles;
-    for (int it = 0; it < nfull; ++it) {
-        const int nxt = min(it + 1, ntiles - 1);  // the last iteration re-reads its own tile: harmless, branch-free
+    int it = 0;
+    for (; it + 2 <= nfull; it += 2) {  // ping-pong between the two fragment sets: no register copies in the steady state
 #pragma unroll
-        for (int s = 0; s < KS; ++s) an[s] = tf[(size_t)((tile0 + nxt) * KS + s) * 64];
-        tile_body(cinit);
+        for (int s = 0; s < KS; ++s) fb[s] = tp[(KS + s) * 64];
+        tile_body(fa, cinit);
+        tp += 2 * KS * 64;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) a[s] = an[s];
+        for (int s = 0; s < KS; ++s) fa[s] = tp[s * 64];
+        tile_body(fb, cinit);
+    }
+    if (it < nfull) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) fb[s] = tp[(KS + s) * 64];
+        tile_body(fa, cinit);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) fa[s] = fb[s];
     }
     if (ragged) {
         const int tile_row0 = row0 + nfull * 32;
@@ -163,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void knn_hamming_mfma_kernel(const uint4 *_
             const int lr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
             cl[reg] = (tile_row0 + lr < nt) ? -(float)lr * kEps : -INFINITY;
         }
-        tile_body(cl);
+        tile_body(fa, cl);
     }
 
     // decode (frame = last tile): v = (64 KS - 2 d) + (32 (ntiles - 1) - local_row) * eps
@@ -247,12 +270,11 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     int rc;
     const size_t q_u4 = (size_t)q_tiles_padded * ks * 64, t_u4 = (size_t)t_tiles * ks * 64;
     if ((rc = ws_get(ctx, WS_FRAG_Q, (size_t)batch * q_u4 * 16, &qf))) return rc;
-    if ((rc = ws_get(ctx, WS_FRAG_T, (size_t)batch * t_u4 * 16, &tf))) return rc;
+    if ((rc = ws_get(ctx, WS_FRAG_T, ((size_t)batch * t_u4 + (size_t)ks * 64) * 16, &tf))) return rc;  // + one spare tile
     if ((rc = ws_get(ctx, WS_PARTIAL, (size_t)batch * nsplit * nq * sizeof(uint2), &part))) return rc;
-    hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)std::min<size_t>((q_u4 + 255) / 256, 8192), batch), dim3(256), 0, s, qw,
-                       q_batch_words, nq, nw, ks, q_tiles_padded, (uint4 *)qf);
-    hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)std::min<size_t>((t_u4 + 255) / 256, 8192), batch), dim3(256), 0, s, tw,
-                       t_batch_words, nt, nw, ks, t_tiles, (uint4 *)tf);
+    const ExpandArgs qa{qw, q_batch_words, nq, q_tiles_padded, (uint4 *)qf}, ta{tw, t_batch_words, nt, t_tiles, (uint4 *)tf};
+    hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)std::min<size_t>((std::max(q_u4, t_u4) + 255) / 256, 8192), batch, 2),
+                       dim3(256), 0, s, qa, ta, nw, ks);
     dim3 grid(qblocks, nsplit, batch);
     prof_mark(ctx, MLPL_PROF_KNN_HAMMING, 0, s);
     switch (ks) {

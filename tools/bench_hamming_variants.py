@@ -1,5 +1,5 @@
 """Times the selectable Hamming kernels on the C2 shape (8 pairs per launch and a single pair) on one GPU.
-Usage: python tools/bench_hamming_variants.py [variant ...]"""
+Usage: python tools/bench_hamming_variants.py [variant ...] [--batch=N] [--bpc=N]"""
 import json
 import os
 import sys
@@ -14,11 +14,15 @@ from matchinglib_poselib_amd import _lib, synth  # noqa: E402
 
 
 def main():
-    variants = [int(v) for v in sys.argv[1:]] or [0, 3]
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    opts = dict(a[2:].split("=") for a in sys.argv[1:] if a.startswith("--"))
+    variants = [int(v) for v in args] or [0, 3]
+    batches = [int(opts["batch"])] if "batch" in opts else [8, 1]
+    bpcs = [int(opts["bpc"])] if "bpc" in opts else None
     ctx = mpa.Context(0)
     dev = torch.device("cuda:0")
     out = {}
-    for batch in (8, 1):
+    for batch in batches:
         qs, ts = [], []
         for b in range(batch):
             q, t = synth.orb_pair(8192, 8192, seed=100 + b)
@@ -31,7 +35,7 @@ def main():
         st = torch.cuda.current_stream().cuda_stream
         ref = None
         for v in variants:
-            for bpc in ((2, 3, 4, 6) if v == 3 else (32,)):
+            for bpc in (bpcs or ((2, 3, 4, 6) if v == 3 else (32,))):
                 ctx.set_option("hamming_variant", v)
                 ctx.set_option("hamming_mfma_blocks_per_cu" if v == 3 else "hamming_blocks_per_cu", bpc)
 
