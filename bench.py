@@ -21,11 +21,21 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
 BYTES_PER_PAIR = 64              # streaming-equivalent algorithmic bytes: two 32-byte operands
-OPS_PER_PAIR = 19                # 8 v_xor + 8 v_bcnt(acc) + v_lshl_or + v_med3 + v_min per descriptor pair (ORB-256)
-# Issue cost of that instruction mix per wave and train row, from tools/valu_peak.hip on this pool (8 waves/SIMD, cycles per
-# wave-instruction per SIMD at 2.4 GHz): v_xor 3.24, v_bcnt 4.73, v_lshl_or/v_med3 4.8, v_min 3.24
+FP4_MFMA_PEAK_TFLOPS = 10000.0   # dense FP4 MFMA peak (MI355X_MICROARCH.md, Matrix cores table: ~10 PF dense)
+FLOP_PER_PAIR = 2 * 256          # one +-1 multiply-add per descriptor bit: the distance table is a K = 256 GEMM
+N_SIMD = 256 * 4
+# --- matrix-core kernel (default): per unit = one 32 x 32 distance tile = 1024 pairs the kernel issues 4 fp4 MFMAs and 22 VALU
+# ops (20 for the running top-2, 2 re-base adds).  tools/mfma_unit_probe.hip measures that instruction stream with operands in
+# registers and no memory traffic: 226 / 138 / 111 / 100 cycles per unit per SIMD at 1 / 2 / 3 / 4 resident waves, at the
+# 1.85 GHz the chip holds under this load.  The 4-wave figure is the vector-issue floor (22 x ~4.3 cycles + MFMA issue).
+MFMA_UNIT_PAIRS = 1024
+MFMA_UNIT_FLOOR_CYCLES = 100.0
+MFMA_CLOCK_HZ = 1.85e9
+# --- VALU kernels (--hamming-variant 0/1/2): 8 v_xor + 8 v_bcnt(acc) + v_lshl_or + v_med3 + v_min per descriptor pair.
+# Issue cost per wave and train row from tools/valu_peak.hip (8 waves/SIMD, cycles per wave-instruction per SIMD at 2.4 GHz).
+OPS_PER_PAIR = 19
 MIX_CYCLES_PER_WAVE_ROW = 8 * 3.24 + 8 * 4.73 + 4.8 + 4.8 + 3.24
-N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
+CLOCK_HZ = 2.4e9
 
 
 def main():
@@ -38,9 +48,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-queries", type=int, default=8192)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with HIP events")
+    ap.add_argument("--kernel-event-every", type=int, default=8,
+                    help="bracket every Nth launch of the dominant kernel inside the timed region (two event records cost ~10 us)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (RANSAC / L2) measurements")
+    ap.add_argument("--hamming-variant", type=int, default=3,
+                    help="3 = fp4 matrix-core kernel (library default), 0/1/2 = the integer VALU kernels")
     args = ap.parse_args()
 
     import numpy as np
@@ -68,6 +82,7 @@ def main():
 
     ctx = mpa.Context(local_rank)
     lib = ctx.lib
+    ctx.set_option("hamming_variant", args.hamming_variant)
     P, n = args.pairs_per_gpu, args.n
     # synthetic C2 inputs, one distinct pair per (rank, slot); resident in HBM before the timed region
     qs, ts = [], []
@@ -111,7 +126,7 @@ def main():
         step()
     barrier()
     _lib.check(lib.mlpl_profile_reset(ctx.handle), "profile_reset")
-    _lib.check(lib.mlpl_profile_enable(ctx.handle, 0 if args.no_kernel_events else 1), "profile_enable")
+    _lib.check(lib.mlpl_profile_enable(ctx.handle, 0 if args.no_kernel_events else max(1, args.kernel_event_every)), "profile_enable")
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -136,16 +151,63 @@ def main():
         assert g.shape == (world, P) and (g[rank] == np.array(counts)).all() and (g > 0).all(), "gathered records are wrong"
 
     if rank == 0:
-        alg_bytes = pairs_per_step_rank * BYTES_PER_PAIR           # per launch of the dominant kernel
         kern_ms = kern_ms if kern_ms > 0 else float('nan')
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        hbm_equiv = pairs_per_step_rank * BYTES_PER_PAIR / (kern_ms * 1e-3) / 1e9   # north_star's "HBM-roofline GB/s" reading
+        mfma_path = args.hamming_variant == 3
+        kernel_name = "knn_hamming_mfma_kernel<4, 4>" if mfma_path else "knn_hamming_partial_kernel<8>"
         traffic = None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("knn_hamming_partial_bytes_per_launch")
+                traffic = json.load(open(tf)).get("knn_hamming_mfma_bytes_per_launch" if mfma_path
+                                                  else "knn_hamming_partial_bytes_per_launch")
             except Exception:
                 traffic = None
+        if mfma_path:
+            flops = pairs_per_step_rank * FLOP_PER_PAIR          # algorithmic FLOP per launch of the dominant kernel
+            achieved = flops / (kern_ms * 1e-3) / 1e12
+            floor_ms = pairs_per_step_rank / MFMA_UNIT_PAIRS / N_SIMD * MFMA_UNIT_FLOOR_CYCLES / MFMA_CLOCK_HZ * 1e3
+            roofline = {
+                "kernel": kernel_name,
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": FP4_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP4_MFMA_PEAK_TFLOPS,
+                "traffic": traffic,
+                "kernel_ms_avg": kern_ms,
+                "launches_timed": launches.value,
+                "note": "the all-pairs Hamming table as a +-1 GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 x fp4, fp32 accumulate, "
+                        "exact): 2*256 FLOP per descriptor pair against the dense FP4 peak.  The kernel is bound by VECTOR ISSUE, not "
+                        "by the matrix pipe: per 32x32 tile it issues 4 MFMAs and 22 VALU ops (running top-2); issue_floor_ms is that "
+                        "stream's measured cost with operands in registers (tools/mfma_unit_probe.hip, 4 waves/SIMD)",
+                "flop_per_pair": FLOP_PER_PAIR,
+                "issue_floor_ms": floor_ms,
+                "issue_frac": floor_ms / kern_ms,
+                "hbm_equiv_GBps": hbm_equiv,
+                "hbm_equiv_frac": hbm_equiv / HBM_PEAK_GBS,
+            }
+            dtype = "fp4 (E2M1 +-1 per descriptor bit) MFMA, fp32 accumulate -- exact integer distances"
+        else:
+            roofline = {
+                "kernel": kernel_name,
+                "bound": "hbm",
+                "achieved": hbm_equiv,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": hbm_equiv / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel_ms_avg": kern_ms,
+                "launches_timed": launches.value,
+                "note": "streaming-equivalent bytes (64 B per descriptor pair, SURVEY 8(d)); operands are LDS/L2-"
+                        "resident so the kernel is integer-VALU bound: valu_frac = measured instruction-issue floor of the xor/bcnt/"
+                        "med3 mix (tools/valu_peak.hip) / kernel time",
+                "valu_ops_per_pair": OPS_PER_PAIR,
+                "valu_achieved_Tops": pairs_per_step_rank * OPS_PER_PAIR / (kern_ms * 1e-3) / 1e12,
+                "valu_issue_floor_ms": pairs_per_step_rank / 64 * MIX_CYCLES_PER_WAVE_ROW / N_SIMD / CLOCK_HZ * 1e3,
+                "valu_frac": (pairs_per_step_rank / 64 * MIX_CYCLES_PER_WAVE_ROW / N_SIMD / CLOCK_HZ * 1e3) / kern_ms,
+            }
+            dtype = "u32 (xor + popcount on packed 256-bit descriptors)"
         rec = {
             "metric": "descriptor-pairs/s (8k x 8k ORB BF-Hamming kNN=2 + ratio)",
             "value": value,
@@ -157,7 +219,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 (xor + popcount on packed 256-bit descriptors)",
+            "dtype": dtype,
             "data": "synthetic",
             "config": {
                 "workload": f"C2: {n}x{n} ORB-256 BF-Hamming kNN=2 + 0.75 ratio + DMatch compaction, "
@@ -165,25 +227,9 @@ def main():
                 "pairs_per_gpu": P,
                 "matches_first_pair": counts[0],
                 "parallelism": f"shard{world}",
+                "hamming_kernel": kernel_name,
             },
-            "roofline": {
-                "kernel": "knn_hamming_partial_kernel<8>",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel_ms_avg": kern_ms,
-                "launches_timed": launches.value,
-                "note": "streaming-equivalent bytes (64 B per descriptor pair, SURVEY 8(d)); operands are LDS/L2-"
-                        "resident so the kernel is integer-VALU bound: valu_frac = measured instruction-issue floor of the xor/bcnt/"
-                        "med3 mix (tools/valu_peak.hip) / kernel time",
-                "valu_ops_per_pair": OPS_PER_PAIR,
-                "valu_achieved_Tops": pairs_per_step_rank * OPS_PER_PAIR / (kern_ms * 1e-3) / 1e12,
-                "valu_issue_floor_ms": pairs_per_step_rank / 64 * MIX_CYCLES_PER_WAVE_ROW / N_SIMD / CLOCK_HZ * 1e3,
-                "valu_frac": (pairs_per_step_rank / 64 * MIX_CYCLES_PER_WAVE_ROW / N_SIMD / CLOCK_HZ * 1e3) / kern_ms,
-            },
+            "roofline": roofline,
         }
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))

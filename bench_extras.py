@@ -142,6 +142,24 @@ def run(ctx, dev, cpu_baseline=True):
     ms = e0.elapsed_time(e1) / 20
     out["hamming_c2_single_pair"] = {"value": B * 8192 * 8192 / (ms * 1e-3), "unit": "descriptor-pairs/s",
                                      "ms_per_call": ms, "pairs_per_call": B}
+    # ---- the headline step (8 pairs per launch) on the integer VALU kernel, for comparison with the matrix-core default ----
+    cur_variant = 3
+    qs, ts = zip(*[synth.orb_pair(8192, 8192, seed=20260310 + b) for b in range(8)])
+    bq8 = torch.from_numpy(np.stack(qs)).to(dev)
+    bt8 = torch.from_numpy(np.stack(ts)).to(dev)
+    for variant, name in ((0, "hamming_c2_8pairs_valu_kernel"), (3, "hamming_c2_8pairs_mfma_kernel")):
+        ctx.set_option("hamming_variant", variant)
+        res8 = match_hamming_device(bq8, bt8, ctx=ctx)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            res8 = match_hamming_device(bq8, bt8, ctx=ctx, out=res8)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        out[name] = {"value": 8 * 8192 * 8192 / (ms * 1e-3), "unit": "descriptor-pairs/s", "ms_per_call": ms, "pairs_per_call": 8,
+                     "matches_first_pair": int(res8["count"][0].item())}
+    ctx.set_option("hamming_variant", cur_variant)
     # ---- the drop-in host-pointer API on one C2 pair: PCIe-inclusive (H2D 512 KiB, D2H <= 128 KiB, one sync) ----
     hq, ht = synth.orb_pair(8192, 8192, seed=20260102)
     kp = [None] * 8192

@@ -59,16 +59,19 @@ void *mlpl_ctx_stream(mlpl_ctx *ctx);
 int mlpl_ctx_device(mlpl_ctx *ctx);
 int mlpl_ctx_synchronize(mlpl_ctx *ctx);
 
-/* Tuning knobs (performance only, never results): "hamming_variant" 0 = LDS-tiled broadcast reads, 1 = scalar-load
- * kernel; "hamming_qpl" queries per lane 1|2; "hamming_blocks_per_cu" grid sizing target; "ransac_chunk" hypotheses per
+/* Tuning knobs (performance only, never results): "hamming_variant" 3 = fp4 matrix-core kernel (default; descriptors above
+ * 64 bytes fall back to 0), 0 = LDS-tiled VALU kernel, 1 = scalar-operand VALU kernel, 2 = one-wave-per-block VALU kernel;
+ * "hamming_mfma_blocks_per_cu" (default 3) and "hamming_mfma_qt" (query tiles per wave, 0 = automatic) size the matrix-core
+ * grid; "hamming_qpl" queries per lane 1|2 and "hamming_blocks_per_cu" size the VALU grids; "ransac_chunk" hypotheses per
  * device pass (0 = 32768; the sequential best/niters rule is replayed across passes). */
 int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value);
 
 /* ---- in-library kernel timing (for roofline accounting) ------------------------------------------------------
  * When enabled, the launches of the dominant kernel of each path are bracketed with hipEvents on the stream
  * they run on.  mlpl_profile_read() synchronises those events and returns the summed duration and the
- * launch count since the last reset.  kernel_id: 0 = knn_hamming_partial, 1 = knn_l2 (exact or MFMA),
- * 2 = 5-point solver, 3 = Sampson scoring, 4 = recover_pose. */
+ * launch count since the last reset.  kernel_id: 0 = Hamming partial top-2 (matrix-core or VALU kernel), 1 = knn_l2 (exact or
+ * MFMA), 2 = 5-point solver, 3 = Sampson scoring, 4 = recover_pose.  mlpl_profile_enable(ctx, N): 0 = off, 1 = every launch,
+ * N > 1 = every Nth launch (sampling: the two event records cost ~10 us of stream time per bracketed launch). */
 #define MLPL_PROF_KNN_HAMMING 0
 #define MLPL_PROF_KNN_L2 1
 #define MLPL_PROF_SOLVE_5PT 2

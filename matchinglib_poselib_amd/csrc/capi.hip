@@ -65,6 +65,9 @@ void prof_mark(mlpl_ctx *ctx, int id, int phase, hipStream_t s) {
         for (int i = 0; i < 2 * kProfMaxLaunches; ++i) (void)hipEventCreate(&ctx->prof_ev[id][i]);
     }
     if (ctx->prof_n[id] >= kProfMaxLaunches) return;
+    // prof_on = N > 1: bracket every Nth launch only (two event records cost ~10 us of stream time per launch)
+    if (phase == 0) ctx->prof_take[id] = (ctx->prof_calls[id]++ % ctx->prof_on) == 0;
+    if (!ctx->prof_take[id]) return;
     (void)hipEventRecord(ctx->prof_ev[id][2 * ctx->prof_n[id] + phase], s);
     if (phase == 1) ctx->prof_n[id]++;
 }
@@ -108,10 +111,11 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     std::memset(ctx, 0, sizeof(*ctx));
     ctx->device = device_ordinal;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    ctx->opt_hamming_variant = 0;
+    ctx->opt_hamming_variant = 3;
     ctx->opt_hamming_qpl = 1;
     ctx->opt_hamming_blocks_per_cu = 32;
-    ctx->opt_hamming_mfma_blocks_per_cu = 2;
+    ctx->opt_hamming_mfma_blocks_per_cu = 3;
+    ctx->opt_hamming_mfma_qt = 0;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -150,6 +154,7 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx) {
 int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     if (!ctx || !name) return MLPL_E_BAD_INPUT;
     if (!std::strcmp(name, "hamming_variant") && value >= 0 && value <= 3) ctx->opt_hamming_variant = value;
+    else if (!std::strcmp(name, "hamming_mfma_qt") && (value == 0 || value == 1 || value == 2 || value == 4)) ctx->opt_hamming_mfma_qt = value;
     else if (!std::strcmp(name, "hamming_mfma_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_mfma_blocks_per_cu = value;
     else if (!std::strcmp(name, "hamming_qpl") && (value == 1 || value == 2)) ctx->opt_hamming_qpl = value;
     else if (!std::strcmp(name, "hamming_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_blocks_per_cu = value;
@@ -163,14 +168,14 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
 
 int mlpl_profile_enable(mlpl_ctx *ctx, int on) {
     if (!ctx) return MLPL_E_BAD_INPUT;
-    ctx->prof_on = on ? 1 : 0;
+    ctx->prof_on = on > 0 ? on : 0;  // N > 1: every Nth launch of a kernel is bracketed
     return MLPL_OK;
 }
 
 int mlpl_profile_reset(mlpl_ctx *ctx) {
     if (!ctx) return MLPL_E_BAD_INPUT;
     MLPL_HIP_TRY(hipDeviceSynchronize());
-    for (int k = 0; k < MLPL_PROF_NUM; ++k) ctx->prof_n[k] = 0;
+    for (int k = 0; k < MLPL_PROF_NUM; ++k) ctx->prof_n[k] = ctx->prof_calls[k] = 0;
     return MLPL_OK;
 }
 

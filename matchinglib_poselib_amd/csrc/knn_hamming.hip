@@ -379,8 +379,9 @@ int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_strid
         tbw = (size_t)nt * nw;
     }
 
-    const int variant = ctx->opt_hamming_variant;
-    if (variant == 3 && nw <= 16) {  // matrix-core kernel (knn_hamming_mfma.hip); wider descriptors take the VALU kernels
+    int variant = ctx->opt_hamming_variant;
+    if (variant == 3 && nw > 16) variant = 0;  // descriptors above 64 bytes: LDS-tiled VALU kernel
+    if (variant == 3) {  // matrix-core kernel (knn_hamming_mfma.hip); wider descriptors take the VALU kernels
         int rps = 0, nsplit = 0;
         uint2 *part = nullptr;
         int rc = launch_knn_hamming_mfma(ctx, qw, qbw, tw, tbw, nq, nt, nw, batch, dshift, s, &rps, &nsplit, &part);

@@ -24,6 +24,7 @@
 
 #include "mlpl_internal.h"
 
+
 namespace mlpl {
 
 namespace {
@@ -97,13 +98,21 @@ __device__ __forceinline__ v16f mfma_fp4(uint4 a, uint4 b, v16f c) {
 template <int KS, int QT>
 __global__ __launch_bounds__(256, (KS >= 8 ? 2 : 3)) void knn_hamming_mfma_kernel(const uint4 *__restrict__ qfrag, size_t q_batch_u4,
                                                                const uint4 *__restrict__ tfrag, size_t t_batch_u4, int nq, int nt,
-                                                               int rows_per_split, int nsplit, int dshift,
+                                                               int rows_per_split, int nsplit, int dshift, int qblocks, int n_items,
                                                                uint2 *__restrict__ part) {
     const int l = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
-    const int b = blockIdx.z;
-    const int split = blockIdx.y;
-    const int qt0 = (blockIdx.x * 4 + w) * QT;  // first query tile of this wave (the fragment buffer is padded to whole blocks)
+    // XCD-aware work assignment.  Workgroups go round-robin to the 8 XCDs (each with its own L2), so workgroup L runs on
+    // XCD L % 8.  The work items are ordered (batch item, split, query block) and XCD x takes the x-th contiguous eighth of
+    // that order: with 8 image pairs per launch every XCD streams ONE pair's train fragments (1 MiB at C2) through its L2
+    // instead of all eight; with one pair an XCD sees an eighth of the train splits.
+    const int per_xcd = (int)(gridDim.x >> 3);  // the grid is padded to a multiple of 8
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= n_items) return;  // block-uniform
+    const int qb = item % qblocks;
+    const int split = (item / qblocks) % nsplit;
+    const int b = item / (qblocks * nsplit);
+    const int qt0 = (qb * 4 + w) * QT;  // first query tile of this wave (the fragment buffer is padded to whole blocks)
     if (qt0 * 32 >= nq) return;                 // wave-uniform; the kernel has no barriers
     const uint4 *qf = qfrag + (size_t)b * q_batch_u4 + (size_t)qt0 * KS * 64 + l;
     const uint4 *tf = tfrag + (size_t)b * t_batch_u4 + l;
@@ -220,17 +229,17 @@ __global__ __launch_bounds__(256, (KS >= 8 ? 2 : 3)) void knn_hamming_mfma_kerne
 
 template <int KS>
 void launch_mfma(int qt, dim3 grid, hipStream_t s, const uint4 *qf, size_t qb, const uint4 *tf, size_t tb, int nq, int nt, int rps,
-                 int nsplit, int dshift, uint2 *part) {
+                 int nsplit, int dshift, int qblocks, int n_items, uint2 *part) {
     if constexpr (KS <= 4) {
         if (qt == 4) {
-            hipLaunchKernelGGL((knn_hamming_mfma_kernel<KS, 4>), grid, dim3(256), 0, s, qf, qb, tf, tb, nq, nt, rps, nsplit, dshift, part);
+            hipLaunchKernelGGL((knn_hamming_mfma_kernel<KS, 4>), grid, dim3(256), 0, s, qf, qb, tf, tb, nq, nt, rps, nsplit, dshift, qblocks, n_items, part);
             return;
         }
     }
     if (qt >= 2)
-        hipLaunchKernelGGL((knn_hamming_mfma_kernel<KS, 2>), grid, dim3(256), 0, s, qf, qb, tf, tb, nq, nt, rps, nsplit, dshift, part);
+        hipLaunchKernelGGL((knn_hamming_mfma_kernel<KS, 2>), grid, dim3(256), 0, s, qf, qb, tf, tb, nq, nt, rps, nsplit, dshift, qblocks, n_items, part);
     else
-        hipLaunchKernelGGL((knn_hamming_mfma_kernel<KS, 1>), grid, dim3(256), 0, s, qf, qb, tf, tb, nq, nt, rps, nsplit, dshift, part);
+        hipLaunchKernelGGL((knn_hamming_mfma_kernel<KS, 1>), grid, dim3(256), 0, s, qf, qb, tf, tb, nq, nt, rps, nsplit, dshift, qblocks, n_items, part);
 }
 
 }  // namespace
@@ -249,7 +258,8 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     const int nqt = (nq + 31) / 32;
     const int max_qt = ks <= 4 ? 4 : 2;
     int qt = max_qt;
-    while (qt > 1 && (long long)((nqt + 4 * qt - 1) / (4 * qt)) * batch * 4 < (long long)ctx->num_cus) qt >>= 1;
+    if (ctx->opt_hamming_mfma_qt > 0) qt = std::min(ctx->opt_hamming_mfma_qt, max_qt);
+    while (ctx->opt_hamming_mfma_qt <= 0 && qt > 1 && (long long)((nqt + 4 * qt - 1) / (4 * qt)) * batch * 4 < (long long)ctx->num_cus) qt >>= 1;
     const int qblocks = (nqt + 4 * qt - 1) / (4 * qt);
     const int q_tiles_padded = qblocks * 4 * qt;
     const int t_tiles = (nt + 31) / 32;
@@ -275,13 +285,15 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     const ExpandArgs qa{qw, q_batch_words, nq, q_tiles_padded, (uint4 *)qf}, ta{tw, t_batch_words, nt, t_tiles, (uint4 *)tf};
     hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)std::min<size_t>((std::max(q_u4, t_u4) + 255) / 256, 8192), batch, 2),
                        dim3(256), 0, s, qa, ta, nw, ks);
-    dim3 grid(qblocks, nsplit, batch);
+    // 1-D grid, remapped in the kernel (XCD-aware); padded so that every XCD gets the same number of workgroups
+    const long long items = (long long)qblocks * nsplit * batch;
+    dim3 grid((unsigned)((items + 7) / 8 * 8));
     prof_mark(ctx, MLPL_PROF_KNN_HAMMING, 0, s);
     switch (ks) {
-        case 1: launch_mfma<1>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, (uint2 *)part); break;
-        case 2: launch_mfma<2>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, (uint2 *)part); break;
-        case 4: launch_mfma<4>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, (uint2 *)part); break;
-        default: launch_mfma<8>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, (uint2 *)part); break;
+        case 1: launch_mfma<1>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part); break;
+        case 2: launch_mfma<2>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part); break;
+        case 4: launch_mfma<4>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part); break;
+        default: launch_mfma<8>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part); break;
     }
     prof_mark(ctx, MLPL_PROF_KNN_HAMMING, 1, s);
     *rps_out = rps;

@@ -62,10 +62,11 @@ struct mlpl_ctx {
     int l2_mode;
     int num_cus;
     // tuning knobs (mlpl_set_option)
-    int opt_hamming_variant;        // 0 = LDS-tiled broadcast reads, 1 = scalar-load (SGPR operand) kernel
+    int opt_hamming_variant;        // 3 = fp4 matrix-core kernel (default), 0 = LDS-tiled VALU, 1 = scalar-operand VALU, 2 = one wave per block
     int opt_hamming_qpl;            // queries per lane for variant 1 (1 or 2)
     int opt_hamming_blocks_per_cu;  // grid sizing target
     int opt_hamming_mfma_blocks_per_cu;  // grid sizing target of the matrix-core kernel (4-wave blocks)
+    int opt_hamming_mfma_qt;             // query tiles per wave (0 = automatic, else 1, 2 or 4)
     int opt_ransac_chunk;           // hypotheses per device pass (0 = 32768)
     // cached table T[g] = cvRANSACUpdateNumIters1(conf, (n-g)/n, 5, inf) for the last (n, conf) (host libm values)
     int32_t *ransac_T_host;
@@ -76,6 +77,8 @@ struct mlpl_ctx {
     int prof_on;
     hipEvent_t *prof_ev[MLPL_PROF_NUM];  // pairs: [2*i] start, [2*i+1] stop
     int prof_n[MLPL_PROF_NUM];
+    int prof_calls[MLPL_PROF_NUM];  // launches seen since the last reset (sampling: every prof_on-th is bracketed)
+    int prof_take[MLPL_PROF_NUM];
 };
 
 namespace mlpl {

@@ -320,14 +320,26 @@ def test_l2_device_batched(ctx, oracle):
         assert np.array_equal(idx[b].cpu().numpy(), oi) and dist[b].cpu().numpy().tobytes() == od.tobytes(), b
 
 
-HAMMING_VARIANTS = {0: "LDS-tiled VALU", 1: "scalar-operand VALU", 2: "one wave per block VALU", 3: "fp4 matrix-core"}
+# (hamming_variant, hamming_mfma_qt)
+HAMMING_VARIANTS = {
+    "valu_lds_tiled": (0, 0), "valu_scalar_operand": (1, 0), "valu_one_wave_blocks": (2, 0),
+    "mfma_fp4": (3, 0), "mfma_fp4_qt2": (3, 2), "mfma_fp4_qt1": (3, 1),
+}
+
+
+HAMMING_DEFAULT = (3, 0)   # the library default: matrix-core kernel, automatic query tiles per wave
+
+
+def _set_hamming(ctx, cfg):
+    ctx.set_option("hamming_variant", cfg[0])
+    ctx.set_option("hamming_mfma_qt", cfg[1])
 
 
 @pytest.mark.parametrize("variant", sorted(HAMMING_VARIANTS))
 def test_hamming_every_kernel_variant_bit_exact(ctx, oracle, variant):
     """Every selectable Hamming kernel gives the oracle's (distance, index) pairs bit for bit: shapes around the tile sizes
     (32-row MFMA tiles, 128-row LDS tiles), descriptor widths around the K-step (8 bytes), ties, ragged last tiles, k = 1."""
-    ctx.set_option("hamming_variant", variant)
+    _set_hamming(ctx, HAMMING_VARIANTS[variant])
     try:
         for nq, nt, nbytes, k in [(1, 2, 32, 2), (15, 15, 32, 2), (64, 1000, 32, 1), (300, 129, 32, 2), (1000, 5000, 32, 2),
                                   (77, 333, 64, 2), (50, 200, 16, 2), (40, 90, 61, 2), (33, 70, 24, 2), (20, 40, 1, 2),
@@ -359,19 +371,20 @@ def test_hamming_every_kernel_variant_bit_exact(ctx, oracle, variant):
         rc, om = oracle.get_matches_linear(700, 900, q, t)
         assert err == rc == 0 and m.tobytes() == om.tobytes()
     finally:
-        ctx.set_option("hamming_variant", 0)
+        _set_hamming(ctx, HAMMING_DEFAULT)
 
 
-@pytest.mark.parametrize("variant", [3])
+@pytest.mark.parametrize("variant", ["mfma_fp4", "mfma_fp4_qt2"])
 def test_c2_full_size_matrix_core_equals_valu(ctx, oracle, variant):
     """BASELINE C2 (8192 x 8192 x 256 bit): the matrix-core kernel against the VALU kernel (itself oracle-checked on samples)."""
     q, t = synth.orb_pair(8192, 8192, seed=20260102)
+    _set_hamming(ctx, HAMMING_VARIANTS["valu_lds_tiled"])
     idx0, dist0 = mpa.knn_hamming(q, t, ctx=ctx)
-    ctx.set_option("hamming_variant", variant)
+    _set_hamming(ctx, HAMMING_VARIANTS[variant])
     try:
         idx3, dist3 = mpa.knn_hamming(q, t, ctx=ctx)
     finally:
-        ctx.set_option("hamming_variant", 0)
+        _set_hamming(ctx, HAMMING_DEFAULT)
     assert np.array_equal(idx0, idx3) and np.array_equal(dist0, dist3)
     rows = np.random.default_rng(1).choice(8192, 64, replace=False)
     oi, od = oracle.knn_hamming(q[rows], t)

@@ -19,7 +19,10 @@ def main():
     variants = [int(v) for v in args] or [0, 3]
     batches = [int(opts["batch"])] if "batch" in opts else [8, 1]
     bpcs = [int(opts["bpc"])] if "bpc" in opts else None
+    ctx_opts = {k: int(v) for k, v in opts.items() if k not in ("batch", "bpc")}
     ctx = mpa.Context(0)
+    for k, v in ctx_opts.items():
+        ctx.set_option(k, v)
     dev = torch.device("cuda:0")
     out = {}
     for batch in batches:

@@ -1,0 +1,132 @@
+// What does one (4 x fp4 MFMA + 22 VALU top-2 update) unit cost per SIMD with W waves resident and NO memory traffic?
+// Build: hipcc -w -O3 --offload-arch=gfx950 -fno-honor-nans -o /tmp/u tools/mfma_unit_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ v16f mf(uint4 a, uint4 b, v16f c) {
+    const v8i av = {(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
+    const v8i bv = {(int)b.x, (int)b.y, (int)b.z, (int)b.w, 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
+__device__ __forceinline__ void update(float &m1, float &m2, const v16f &acc) {
+    m1 += 0.001953125f;
+    m2 += 0.001953125f;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg += 4) {
+        const float s0 = __builtin_amdgcn_fmed3f(m1, acc[reg], acc[reg + 1]);
+        const float t0 = __builtin_fmaxf(__builtin_fmaxf(m1, acc[reg]), acc[reg + 1]);
+        const float s1 = __builtin_amdgcn_fmed3f(t0, acc[reg + 2], acc[reg + 3]);
+        m1 = __builtin_fmaxf(__builtin_fmaxf(t0, acc[reg + 2]), acc[reg + 3]);
+        m2 = __builtin_fmaxf(__builtin_fmaxf(m2, s0), s1);
+    }
+}
+
+template <int PIPE>
+__global__ __launch_bounds__(1024) void unitk(const uint4 *src, float *out, int iters, long long *cyc) {
+    const int l = threadIdx.x & 63;
+    uint4 a[4], b[4][4];
+    for (int s = 0; s < 4; ++s) a[s] = src[l + 64 * s];
+    for (int t = 0; t < 4; ++t)
+        for (int s = 0; s < 4; ++s) b[t][s] = src[l + 64 * (4 + 4 * t + s)];
+    v16f cinit;
+    for (int i = 0; i < 16; ++i) cinit[i] = -(float)i * (1.0f / 16384.0f);
+    float m1[4], m2[4];
+    for (int t = 0; t < 4; ++t) m1[t] = m2[t] = -1e30f;
+    auto chain = [&](int t) {
+        v16f acc = mf(a[0], b[t][0], cinit);
+#pragma unroll
+        for (int s = 1; s < 4; ++s) acc = mf(a[s], b[t][s], acc);
+        return acc;
+    };
+    long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    if (PIPE == 0) {
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                v16f acc = chain(t);
+                update(m1[t], m2[t], acc);
+            }
+        }
+    } else {
+        v16f cur = chain(0);
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const v16f nxt = chain((t + 1) & 3);
+                update(m1[t], m2[t], cur);
+                if (PIPE == 1) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                }
+                cur = nxt;
+            }
+        }
+        m1[0] += cur[0];
+    }
+    long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        cyc[2 * w] = t1 - t0;
+        cyc[2 * w + 1] = r1 - r0;
+    }
+    float s = 0;
+    for (int t = 0; t < 4; ++t) s += m1[t] + m2[t];
+    out[(blockIdx.x * blockDim.x + threadIdx.x) & 16383] = s;
+}
+
+template <int PIPE>
+void run(const uint4 *src, float *out, int wpb, int blocks) {
+    long long *dc;
+    const int waves = blocks * wpb, iters = 4000;
+    hipMalloc(&dc, waves * 16);
+    hipLaunchKernelGGL((unitk<PIPE>), dim3(blocks), dim3(64 * wpb), 0, 0, src, out, iters, dc);
+    long long *h = new long long[waves * 2];
+    hipMemcpy(h, dc, waves * 16, hipMemcpyDeviceToHost);
+    double cs = 0, rs = 0;
+    for (int i = 0; i < waves; ++i) cs += h[2 * i], rs += h[2 * i + 1];
+    const double per_wave_unit = cs / waves / (iters * 4.0);
+    const double wps = (double)waves / 1024.0;
+    printf("pipe=%d waves/SIMD=%.0f: %.3f GHz, %.1f cycles per unit per wave -> %.1f cycles per unit per SIMD\n", PIPE, wps, cs / rs * 0.1,
+           per_wave_unit, per_wave_unit / wps);
+    hipFree(dc);
+    delete[] h;
+}
+
+int main() {
+    uint4 *src;
+    float *out;
+    hipMalloc(&src, 64 * 20 * 16);
+    hipMalloc(&out, 1 << 16);
+    uint32_t *h = new uint32_t[64 * 20 * 4];
+    uint32_t x = 12345;
+    for (int i = 0; i < 64 * 20 * 4; ++i) {
+        uint32_t w = 0;
+        for (int n = 0; n < 8; ++n) {
+            x = x * 1664525u + 1013904223u;
+            w |= ((x >> 16) & 1 ? 0x2u : 0xAu) << (4 * n);
+        }
+        h[i] = w;
+    }
+    hipMemcpy(src, h, 64 * 20 * 16, hipMemcpyHostToDevice);
+    for (int wpb : {4, 8, 12, 16}) {  // 256 blocks = one per CU -> wpb/4 waves per SIMD
+        run<0>(src, out, wpb, 256);
+        run<1>(src, out, wpb, 256);
+        run<2>(src, out, wpb, 256);
+    }
+    return 0;
+}
