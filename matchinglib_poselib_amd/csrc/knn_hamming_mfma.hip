@@ -60,9 +60,11 @@ __device__ __forceinline__ uint32_t expand_byte(uint32_t x) {
 }
 
 // Rows of `nw` 32-bit words (word rows as the VALU path uses them) -> fragment order.  Lane (r = l & 31, h = l >> 5) of
-// K-step s holds bits [64 s + 32 h, 64 s + 32 h + 32) of row 32 * tile + r: word 2 s + h.  Rows >= n and words >= nw read
-// as zero bits (the same in both operands, so they add nothing to a distance).  `tiles` covers the padded row count.
-// One launch expands both operands: blockIdx.z = 0 queries, 1 train rows.
+// K-step s holds word h * KS + s of row 32 * tile + r, i.e. each lane owns KS CONSECUTIVE words of its row (one 16-byte
+// load at KS = 4, and the wave reads one contiguous KiB); which 32 bits go to which K position is free as long as both
+// operands use the same rule, and they do -- this kernel expands both.  Rows >= n and words >= nw read as zero bits (the
+// same in both operands, so they add nothing to a distance).  `tiles` covers the padded row count.
+// One launch: blockIdx.z = 0 queries, 1 train rows; one thread per (tile, lane), KS x 16 bytes out.
 struct ExpandArgs {
     const uint32_t *src;
     size_t src_batch_words;
@@ -70,20 +72,41 @@ struct ExpandArgs {
     uint4 *dst;
 };
 
-__global__ void hamming_expand_kernel(ExpandArgs qa, ExpandArgs ta, int nw, int ks) {
+template <int KS>
+__global__ __launch_bounds__(256) void hamming_expand_kernel(ExpandArgs qa, ExpandArgs ta, int nw) {
     const ExpandArgs A = blockIdx.z ? ta : qa;
     const int b = blockIdx.y;
-    const long long total = (long long)A.tiles * ks * 64;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int l = (int)(i & 63);
-        const long long ts = i >> 6;
-        const int s = (int)(ts % ks);
-        const int tile = (int)(ts / ks);
-        const int row = tile * 32 + (l & 31);
-        const int w = 2 * s + (l >> 5);
-        const uint32_t v = (row < A.n && w < nw) ? A.src[(size_t)b * A.src_batch_words + (size_t)row * nw + w] : 0u;
-        A.dst[(size_t)b * total + i] =
-            make_uint4(expand_byte(v & 255u), expand_byte((v >> 8) & 255u), expand_byte((v >> 16) & 255u), expand_byte(v >> 24));
+    const int i = blockIdx.x * 256 + threadIdx.x;  // tile * 64 + lane
+    if (i >= A.tiles * 64) return;
+    const int l = i & 63, tile = i >> 6;
+    const int row = tile * 32 + (l & 31);
+    const int w0 = (l >> 5) * KS;
+    uint32_t v[KS];
+    const uint32_t *p = A.src + (size_t)b * A.src_batch_words + (size_t)row * nw + w0;
+    if (row < A.n && nw == 2 * KS) {  // whole words, KS * 4-byte aligned (rows are nw words): one vector load
+        if constexpr (KS == 4) {
+            const uint4 x = *reinterpret_cast<const uint4 *>(p);
+            v[0] = x.x, v[1] = x.y, v[2] = x.z, v[3] = x.w;
+        } else if constexpr (KS == 8) {
+            const uint4 x = reinterpret_cast<const uint4 *>(p)[0], y = reinterpret_cast<const uint4 *>(p)[1];
+            v[0] = x.x, v[1] = x.y, v[2] = x.z, v[3] = x.w, v[4] = y.x, v[5] = y.y, v[6] = y.z, v[7] = y.w;
+        } else if constexpr (KS == 2) {
+            const uint2 x = *reinterpret_cast<const uint2 *>(p);
+            v[0] = x.x, v[1] = x.y;
+        } else {
+            v[0] = p[0];
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) v[s] = (row < A.n && w0 + s < nw) ? p[s] : 0u;
+    }
+    uint4 *out = A.dst + ((size_t)b * A.tiles + tile) * KS * 64 + l;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 o = {expand_byte(v[s] & 255u), expand_byte((v[s] >> 8) & 255u), expand_byte((v[s] >> 16) & 255u),
+                         expand_byte(v[s] >> 24)};
+        __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(out + s * 64));
     }
 }
 
@@ -94,26 +117,26 @@ __device__ __forceinline__ v16f mfma_fp4(uint4 a, uint4 b, v16f c) {
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
 
-// KS K-steps of 64 bits, QT query tiles (32 queries each) per wave; 4 waves per block share a train range.
+// KS K-steps of 64 bits, QT query tiles (32 queries each) per wave.  A wave's work item is (batch item, train split, query
+// group of QT tiles); the 4 waves of a workgroup are independent (no LDS, no barriers) and take consecutive items, i.e.
+// neighbouring query groups of the same train split, so they stream the same train fragments through the CU's L1.
 template <int KS, int QT>
-__global__ __launch_bounds__(256, (KS >= 8 ? 2 : 3)) void knn_hamming_mfma_kernel(const uint4 *__restrict__ qfrag, size_t q_batch_u4,
-                                                               const uint4 *__restrict__ tfrag, size_t t_batch_u4, int nq, int nt,
-                                                               int rows_per_split, int nsplit, int dshift, int qblocks, int n_items,
-                                                               uint2 *__restrict__ part) {
+__global__ __launch_bounds__(256, (KS >= 8 ? 2 : 3)) void knn_hamming_mfma_kernel(
+    const uint4 *__restrict__ qfrag, size_t q_batch_u4, const uint4 *__restrict__ tfrag, size_t t_batch_u4, int nq, int nt,
+    int rows_per_split, int nsplit, int dshift, int qgroups, int n_items, uint2 *__restrict__ part) {
     const int l = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     // XCD-aware work assignment.  Workgroups go round-robin to the 8 XCDs (each with its own L2), so workgroup L runs on
-    // XCD L % 8.  The work items are ordered (batch item, split, query block) and XCD x takes the x-th contiguous eighth of
+    // XCD L % 8.  The work items are ordered (batch item, split, query group) and XCD x takes the x-th contiguous eighth of
     // that order: with 8 image pairs per launch every XCD streams ONE pair's train fragments (1 MiB at C2) through its L2
     // instead of all eight; with one pair an XCD sees an eighth of the train splits.
     const int per_xcd = (int)(gridDim.x >> 3);  // the grid is padded to a multiple of 8
-    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (item >= n_items) return;  // block-uniform
-    const int qb = item % qblocks;
-    const int split = (item / qblocks) % nsplit;
-    const int b = item / (qblocks * nsplit);
-    const int qt0 = (qb * 4 + w) * QT;  // first query tile of this wave (the fragment buffer is padded to whole blocks)
-    if (qt0 * 32 >= nq) return;                 // wave-uniform; the kernel has no barriers
+    const int item = ((int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3)) * 4 + w;
+    if (item >= n_items) return;  // wave-uniform; the kernel has no barriers
+    const int qg = item % qgroups;
+    const int split = (item / qgroups) % nsplit;
+    const int b = item / (qgroups * nsplit);
+    const int qt0 = qg * QT;  // first query tile of this wave (the fragment buffer is padded to whole groups)
     const uint4 *qf = qfrag + (size_t)b * q_batch_u4 + (size_t)qt0 * KS * 64 + l;
     const uint4 *tf = tfrag + (size_t)b * t_batch_u4 + l;
 
@@ -229,17 +252,21 @@ __global__ __launch_bounds__(256, (KS >= 8 ? 2 : 3)) void knn_hamming_mfma_kerne
 
 template <int KS>
 void launch_mfma(int qt, dim3 grid, hipStream_t s, const uint4 *qf, size_t qb, const uint4 *tf, size_t tb, int nq, int nt, int rps,
-                 int nsplit, int dshift, int qblocks, int n_items, uint2 *part) {
+                 int nsplit, int dshift, int qgroups, int n_items, uint2 *part) {
+#define MLPL_MFMA_LAUNCH(QT_)                                                                                                    \
+    hipLaunchKernelGGL((knn_hamming_mfma_kernel<KS, QT_>), grid, dim3(256), 0, s, qf, qb, tf, tb, nq, nt, rps, nsplit, dshift, qgroups, \
+                       n_items, part)
     if constexpr (KS <= 4) {
         if (qt == 4) {
-            hipLaunchKernelGGL((knn_hamming_mfma_kernel<KS, 4>), grid, dim3(256), 0, s, qf, qb, tf, tb, nq, nt, rps, nsplit, dshift, qblocks, n_items, part);
+            MLPL_MFMA_LAUNCH(4);
             return;
         }
     }
     if (qt >= 2)
-        hipLaunchKernelGGL((knn_hamming_mfma_kernel<KS, 2>), grid, dim3(256), 0, s, qf, qb, tf, tb, nq, nt, rps, nsplit, dshift, qblocks, n_items, part);
+        MLPL_MFMA_LAUNCH(2);
     else
-        hipLaunchKernelGGL((knn_hamming_mfma_kernel<KS, 1>), grid, dim3(256), 0, s, qf, qb, tf, tb, nq, nt, rps, nsplit, dshift, qblocks, n_items, part);
+        MLPL_MFMA_LAUNCH(1);
+#undef MLPL_MFMA_LAUNCH
 }
 
 }  // namespace
@@ -259,14 +286,14 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     const int max_qt = ks <= 4 ? 4 : 2;
     int qt = max_qt;
     if (ctx->opt_hamming_mfma_qt > 0) qt = std::min(ctx->opt_hamming_mfma_qt, max_qt);
-    while (ctx->opt_hamming_mfma_qt <= 0 && qt > 1 && (long long)((nqt + 4 * qt - 1) / (4 * qt)) * batch * 4 < (long long)ctx->num_cus) qt >>= 1;
-    const int qblocks = (nqt + 4 * qt - 1) / (4 * qt);
-    const int q_tiles_padded = qblocks * 4 * qt;
+    while (ctx->opt_hamming_mfma_qt <= 0 && qt > 1 && (long long)((nqt + qt - 1) / qt) * batch < (long long)ctx->num_cus) qt >>= 1;
+    const int qgroups = (nqt + qt - 1) / qt;  // wave-level work: one group of qt query tiles against one train split
+    const int q_tiles_padded = qgroups * qt;
     const int t_tiles = (nt + 31) / 32;
 
-    // train splits: ~opt blocks per CU in flight, whole tiles, bounded so that the re-based fraction stays exact
-    const long long target_blocks = (long long)std::max(1, ctx->opt_hamming_mfma_blocks_per_cu) * ctx->num_cus;
-    long long want = (target_blocks + (long long)qblocks * batch - 1) / ((long long)qblocks * batch);
+    // train splits: ~4 * opt waves per CU in flight, whole tiles, bounded so that the re-based fraction stays exact
+    const long long target_waves = 4LL * std::max(1, ctx->opt_hamming_mfma_blocks_per_cu) * ctx->num_cus;
+    long long want = (target_waves + (long long)qgroups * batch - 1) / ((long long)qgroups * batch);
     int nsplit = (int)std::max<long long>(1, std::min<long long>(want, t_tiles));
     int rps = ((nt + nsplit - 1) / nsplit + 31) / 32 * 32;
     rps = std::min(rps, kMaxRowsPerSplit);
@@ -275,6 +302,7 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
         set_error("knn_hamming: train set too large (nt=%d)", nt);
         return MLPL_E_BAD_INPUT;
     }
+    const long long items = (long long)qgroups * nsplit * batch;
 
     void *qf = nullptr, *tf = nullptr, *part = nullptr;
     int rc;
@@ -283,17 +311,22 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     if ((rc = ws_get(ctx, WS_FRAG_T, ((size_t)batch * t_u4 + (size_t)ks * 64) * 16, &tf))) return rc;  // + one spare tile
     if ((rc = ws_get(ctx, WS_PARTIAL, (size_t)batch * nsplit * nq * sizeof(uint2), &part))) return rc;
     const ExpandArgs qa{qw, q_batch_words, nq, q_tiles_padded, (uint4 *)qf}, ta{tw, t_batch_words, nt, t_tiles, (uint4 *)tf};
-    hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)std::min<size_t>((std::max(q_u4, t_u4) + 255) / 256, 8192), batch, 2),
-                       dim3(256), 0, s, qa, ta, nw, ks);
+    const dim3 egrid((unsigned)((std::max(q_tiles_padded, t_tiles) * 64 + 255) / 256), batch, 2);
+    switch (ks) {
+        case 1: hipLaunchKernelGGL(hamming_expand_kernel<1>, egrid, dim3(256), 0, s, qa, ta, nw); break;
+        case 2: hipLaunchKernelGGL(hamming_expand_kernel<2>, egrid, dim3(256), 0, s, qa, ta, nw); break;
+        case 4: hipLaunchKernelGGL(hamming_expand_kernel<4>, egrid, dim3(256), 0, s, qa, ta, nw); break;
+        default: hipLaunchKernelGGL(hamming_expand_kernel<8>, egrid, dim3(256), 0, s, qa, ta, nw); break;
+    }
     // 1-D grid, remapped in the kernel (XCD-aware); padded so that every XCD gets the same number of workgroups
-    const long long items = (long long)qblocks * nsplit * batch;
-    dim3 grid((unsigned)((items + 7) / 8 * 8));
+    const long long blocks = (items + 3) / 4;
+    dim3 grid((unsigned)((blocks + 7) / 8 * 8));
     prof_mark(ctx, MLPL_PROF_KNN_HAMMING, 0, s);
     switch (ks) {
-        case 1: launch_mfma<1>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part); break;
-        case 2: launch_mfma<2>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part); break;
-        case 4: launch_mfma<4>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part); break;
-        default: launch_mfma<8>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part); break;
+        case 1: launch_mfma<1>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qgroups, (int)items, (uint2 *)part); break;
+        case 2: launch_mfma<2>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qgroups, (int)items, (uint2 *)part); break;
+        case 4: launch_mfma<4>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qgroups, (int)items, (uint2 *)part); break;
+        default: launch_mfma<8>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qgroups, (int)items, (uint2 *)part); break;
     }
     prof_mark(ctx, MLPL_PROF_KNN_HAMMING, 1, s);
     *rps_out = rps;

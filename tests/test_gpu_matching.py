@@ -323,10 +323,8 @@ def test_l2_device_batched(ctx, oracle):
 # (hamming_variant, hamming_mfma_qt)
 HAMMING_VARIANTS = {
     "valu_lds_tiled": (0, 0), "valu_scalar_operand": (1, 0), "valu_one_wave_blocks": (2, 0),
-    "mfma_fp4": (3, 0), "mfma_fp4_qt2": (3, 2), "mfma_fp4_qt1": (3, 1),
+    "mfma_fp4": (3, 0), "mfma_fp4_qt4": (3, 4), "mfma_fp4_qt2": (3, 2), "mfma_fp4_qt1": (3, 1),
 }
-
-
 HAMMING_DEFAULT = (3, 0)   # the library default: matrix-core kernel, automatic query tiles per wave
 
 
