@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of one round on the GPU box (run through gpurun from the repo root):
+#   bash tools/collect_profiles.sh r01
+# Outputs under gpurun_out/<round>/; tools/summarise_profiles.py turns them into profiles/<round>_*.
+set -e -o pipefail
+R=${1:-r01}
+OUT=gpurun_out/$R
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+# 1. the plain default bench line (what the driver runs)
+timeout -k 10 500 python bench.py > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
+# 2. kernel trace + stats of the same command
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python bench.py > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
+# 3. counters, each in its own pass (no tracing alongside), short run without the CPU baseline
+ARGS="bench.py --steps 20 --warmup 2 --no-cpu-baseline"
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python $ARGS > "$OUT/pmc_fetch.log" 2>&1
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python $ARGS > "$OUT/pmc_write.log" 2>&1
+timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F16 SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/pmc_sq" -- python $ARGS > "$OUT/pmc_sq.log" 2>&1
+timeout -k 10 400 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_grbm" -- python $ARGS > "$OUT/pmc_grbm.log" 2>&1
+ls -R "$OUT" | head -40

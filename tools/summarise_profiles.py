@@ -1,0 +1,82 @@
+"""Turns gpurun_out/<round>/ (tools/collect_profiles.sh) into the committed summaries under profiles/.
+Usage: python tools/summarise_profiles.py r01"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+SRC = os.path.join(ROOT, "gpurun_out", R)
+DST = os.path.join(ROOT, "profiles")
+
+
+def short(name):
+    return name.replace("mlpl::(anonymous namespace)::", "").replace("void ", "")[:70]
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(SRC, pattern))
+    return f[0] if f else None
+
+
+# kernel stats of the default bench run
+ks = one("trace/*/*kernel_stats.csv")
+if ks:
+    shutil.copy(ks, os.path.join(DST, f"{R}_bench_default_kernel_stats.csv"))
+for name in ("bench_plain.json", "bench_under_rocprof.json"):
+    p = os.path.join(SRC, name)
+    if os.path.exists(p):
+        line = [x for x in open(p).read().splitlines() if x.startswith("{")]
+        if line:
+            json.dump(json.loads(line[-1]), open(os.path.join(DST, f"{R}_{name}"), "w"), indent=1)
+
+summary = {}
+for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm"):
+    f = one(f"{tag}/*/*counter_collection.csv")
+    if not f:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k, v in agg.items():
+        e = summary.setdefault(k, {})
+        for c, vals in v.items():
+            e[c] = {"mean": sum(vals) / len(vals), "dispatches": len(vals)}
+        e.setdefault("duration_ns_under_pmc", {})[tag] = sum(dur[k]) / len(dur[k])
+json.dump(summary, open(os.path.join(DST, f"{R}_pmc_summary.json"), "w"), indent=1)
+
+# roofline.traffic of bench.py: HBM-side bytes per launch of the dominant kernel (FETCH_SIZE doubled on gfx950 for 16-B/lane streams,
+# MI355X_MICROARCH.md HBM section)
+traffic = {"round": R, "pairs_per_launch": 8,
+           "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 20 --warmup 2 "
+                  "--no-cpu-baseline` (8 image pairs per launch); (2*FETCH_SIZE + WRITE_SIZE)*1024 B, FETCH_SIZE doubled per "
+                  "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B for 16-B/lane streams)"}
+for k, e in summary.items():
+    if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+        b = (2 * e["FETCH_SIZE"]["mean"] + e["WRITE_SIZE"]["mean"]) * 1024
+        if k.startswith("knn_hamming_mfma_kernel<4, 4>"):  # the headline launch (8 pairs); <4, 1> is the single-pair extras launch
+            traffic["knn_hamming_mfma_bytes_per_launch"] = b
+            traffic["mfma_fetch_KiB_raw"] = e["FETCH_SIZE"]["mean"]
+            traffic["mfma_write_KiB"] = e["WRITE_SIZE"]["mean"]
+        if k.startswith("knn_hamming_partial_kernel"):
+            traffic["knn_hamming_partial_bytes_per_launch"] = b
+        if k.startswith("hamming_expand_kernel"):
+            traffic["hamming_expand_bytes_per_launch"] = b
+old = os.path.join(DST, "pmc_traffic.json")
+if os.path.exists(old):
+    prev = json.load(open(old))
+    for k in ("knn_hamming_partial_bytes_per_launch",):
+        if k not in traffic and k in prev:
+            traffic[k] = prev[k]
+            traffic[k + "_note"] = "VALU kernel (hamming_variant 0), measured earlier in round 1 before the matrix-core kernel became the default"
+json.dump(traffic, open(old, "w"), indent=1)
+print(json.dumps(traffic, indent=1))
+for k, e in summary.items():
+    print(k, {c: round(v["mean"], 1) for c, v in e.items() if isinstance(v, dict) and "mean" in v})
