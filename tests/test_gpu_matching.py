@@ -387,3 +387,19 @@ def test_c2_full_size_matrix_core_equals_valu(ctx, oracle, variant):
     rows = np.random.default_rng(1).choice(8192, 64, replace=False)
     oi, od = oracle.knn_hamming(q[rows], t)
     assert np.array_equal(idx3[rows], oi) and np.array_equal(dist3[rows], od)
+
+
+@pytest.mark.parametrize("variant", ["mfma_fp4", "valu_lds_tiled"])
+def test_hamming_many_splits_large_train_set(ctx, oracle, variant):
+    """Train sets far beyond one split (the matrix-core kernel caps a split at 4096 rows, i.e. 18 splits here, the last one
+    ragged) and a query count that is not a multiple of anything; checked on a sample of queries against the oracle."""
+    q, t = synth.orb_pair(3001, 70001, seed=77)
+    _set_hamming(ctx, HAMMING_VARIANTS[variant])
+    try:
+        idx, dist = mpa.knn_hamming(q, t, ctx=ctx)
+    finally:
+        _set_hamming(ctx, HAMMING_DEFAULT)
+    rows = np.random.default_rng(5).choice(3001, 48, replace=False)
+    oi, od = oracle.knn_hamming(q[rows], t)
+    assert np.array_equal(idx[rows], oi) and np.array_equal(dist[rows], od)
+    assert idx.min() >= 0 and idx.max() < 70001 and (dist[:, 0] <= dist[:, 1]).all()
