@@ -190,4 +190,18 @@ def run(ctx, dev, cpu_baseline=True):
                                "note": "8192 keypoints per image, Hamming 2-NN + ratio, fused gather/ImgToCamCoordTrans, RANSAC "
                                        "(1000 iterations, 0.999, adaptive stop), getPoseTriangPts; sequential per pair, host API for "
                                        "the pose step"}
+    # the same 8 pairs with 4 pairs in flight (independent contexts, streams and host threads on this one GPU)
+    pw = batch.PairWorkers(dev.index or 0, workers=4)
+    try:
+        pw.process(dev_in, K, K, seeds=[100 + i for i in range(npairs)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 4
+        for _ in range(reps):
+            recs4 = pw.process(dev_in, K, K, seeds=[100 + i for i in range(npairs)])
+        dt = (time.perf_counter() - t0) / reps
+    finally:
+        pw.close()
+    out["c5_pair_pipeline_4_in_flight"] = {"value": npairs / dt, "unit": "image-pairs/s (one GPU)", "ms_per_pair": dt / npairs * 1e3,
+                                           "same_records_as_sequential": bool(np.concatenate(recs).tobytes() == recs4.tobytes())}
     return out

@@ -96,3 +96,53 @@ def process_pair_on_device(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, th_pix:
     rec["R"] = R.reshape(-1)
     rec["t"] = t.reshape(-1)
     return rec
+
+
+class PairWorkers:
+    """`workers` independent (library context, torch stream, host thread) triples on one GPU.  One image pair's pipeline
+    is latency-bound (a dozen small launches and two host hops), so a rank overlaps several pairs instead of queueing
+    them; every pair still runs exactly process_pair_on_device, so records do not depend on the worker count."""
+
+    def __init__(self, device_index: int = 0, workers: int = 4):
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+
+        self.device = torch.device("cuda", device_index)
+        self.ctxs = [Context(device_index) for _ in range(workers)]
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(workers)]
+        self.scratch = [{} for _ in range(workers)]
+        self.pool = ThreadPoolExecutor(max_workers=workers)
+        self.workers = workers
+
+    def _run(self, w, jobs, K0, K1, kw):
+        import torch
+
+        out = []
+        torch.cuda.set_device(self.device)
+        with torch.cuda.stream(self.streams[w]):
+            for pair_id, seed, (d_q, d_t, d_kp1, d_kp2) in jobs:
+                out.append(process_pair_on_device(self.ctxs[w], d_q, d_t, d_kp1, d_kp2, K0, K1, seed=seed, pair_id=pair_id,
+                                                  scratch=self.scratch[w], **kw))
+            self.streams[w].synchronize()
+        return out
+
+    def process(self, pairs, K0, K1, seeds=None, pair_ids=None, **kw) -> np.ndarray:
+        """pairs: list of (d_q, d_t, d_kp1, d_kp2) device tensors.  Returns the records in input order."""
+        import torch
+
+        n = len(pairs)
+        seeds = list(range(n)) if seeds is None else list(seeds)
+        pair_ids = list(range(n)) if pair_ids is None else list(pair_ids)
+        torch.cuda.current_stream(self.device).synchronize()  # inputs were produced on the caller's stream
+        jobs = [[(pair_ids[i], seeds[i], pairs[i]) for i in range(w, n, self.workers)] for w in range(self.workers)]
+        futs = [self.pool.submit(self._run, w, jobs[w], K0, K1, kw) for w in range(self.workers)]
+        recs = np.zeros(n, RECORD_DTYPE)
+        for w, f in enumerate(futs):
+            for k, r in enumerate(f.result()):
+                recs[w + k * self.workers] = r[0]
+        return recs
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+        for c in self.ctxs:
+            c.close()

@@ -49,3 +49,21 @@ def test_single_rank_gather_is_identity(ctx):
     local["n_matches"] = [5, 6, 7]
     rec = batch.gather_records(local, 3, 0, 1, device=torch.device("cuda", 0))
     assert rec.tobytes() == local.tobytes()
+
+
+def test_concurrent_pair_workers_equal_sequential(ctx):
+    """Several pairs in flight on one GPU (independent contexts / streams / threads) give the records of the sequential loop."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    sps = [synth.stereo_pair(2048, seed=900 + i) for i in range(6)]
+    pairs = [tuple(torch.from_numpy(sp[k]).to(dev) for k in ("desc1", "desc2", "kp1", "kp2")) for sp in sps]
+    K = sps[0]["K"]
+    seq = np.concatenate([batch.process_pair_on_device(ctx, *pairs[i], K, K, seed=40 + i, pair_id=i) for i in range(6)])
+    pw = batch.PairWorkers(0, workers=3)
+    try:
+        con = pw.process(pairs, K, K, seeds=[40 + i for i in range(6)])
+    finally:
+        pw.close()
+    assert con.tobytes() == seq.tobytes()
+    assert (seq["status"] == 0).all() and (seq["n_inliers"] > 100).all()
