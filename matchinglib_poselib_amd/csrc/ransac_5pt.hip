@@ -602,6 +602,61 @@ __global__ __launch_bounds__(256) void score_models_kernel(const double4 *__rest
     }
 }
 
+// Scoring for FEW models (an adaptive RANSAC pass of <= ~1000 hypotheses, the refit's <= 10 models): one 256-thread block per
+// model.  score_models_kernel gives a model 4 lanes that walk all n correspondences, which is the right shape for 10^5 models
+// but leaves the chip idle and takes n/4 serial error evaluations (~55 instructions each) when there are a few hundred.  Here
+// the errors of a model are evaluated by all 256 threads into LDS; only the additions stay serial, because the error sum is
+// DEFINED by its order (four interleaved double accumulators, element i -> accumulator i mod 4, combined as (s0+s2)+(s1+s3)):
+// lane 0 reads four consecutive errors per ds_read_b128 and keeps the four chains in flight.  Same counts, same sums, bit for bit.
+constexpr int kScoreBlockMaxN = 16384;  // floats of (dynamic) LDS per block: 4 n bytes, up to 64 KiB
+__global__ __launch_bounds__(256) void score_models_block_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
+                                                                 const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
+                                                                 int total_host, double thresh2, int32_t *__restrict__ good,
+                                                                 double *__restrict__ esum) {
+    extern __shared__ __attribute__((aligned(16))) float errs[];  // n floats
+    __shared__ int wave_cnt[4];
+    const int m = blockIdx.x;
+    if (m >= (total_ptr ? *total_ptr : total_host)) return;  // block-uniform
+    const int tid = threadIdx.x;
+    double e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = E_list[(size_t)m * 9 + k];
+    int cnt = 0;
+    for (int i = tid; i < n; i += 256) {
+        const double4 p = pts[i];
+        const float err = sampson_err_f32(e, p.x, p.y, p.z, p.w);
+        errs[i] = err;
+        cnt += ((double)err <= thresh2) ? 1 : 0;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+    if ((tid & 63) == 0) wave_cnt[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid < 4) {  // lane j = accumulator j: elements j, j + 4, ... in order; eight reads in flight per chain step
+        double sacc = 0;
+        int i = tid;
+        for (; i + 28 < n; i += 32) {
+            const float v0 = errs[i], v1 = errs[i + 4], v2 = errs[i + 8], v3 = errs[i + 12], v4 = errs[i + 16], v5 = errs[i + 20],
+                        v6 = errs[i + 24], v7 = errs[i + 28];
+            sacc = __dadd_rn(sacc, (double)v0);
+            sacc = __dadd_rn(sacc, (double)v1);
+            sacc = __dadd_rn(sacc, (double)v2);
+            sacc = __dadd_rn(sacc, (double)v3);
+            sacc = __dadd_rn(sacc, (double)v4);
+            sacc = __dadd_rn(sacc, (double)v5);
+            sacc = __dadd_rn(sacc, (double)v6);
+            sacc = __dadd_rn(sacc, (double)v7);
+        }
+        for (; i < n; i += 4) sacc = __dadd_rn(sacc, (double)errs[i]);
+        const double s0 = __shfl(sacc, 0), s1 = __shfl(sacc, 1), s2 = __shfl(sacc, 2), s3 = __shfl(sacc, 3);
+        if (tid == 0) {
+            const int o = ids ? ids[m] : m;
+            good[o] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            esum[o] = __dadd_rn(__dadd_rn(s0, s2), __dadd_rn(s1, s3));
+        }
+    }
+}
+
 __global__ void inlier_mask_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E, double thresh2,
                                    uint8_t *__restrict__ mask) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -827,40 +882,85 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
                 G[b][a] = gsum[t];
                 ++t;
             }
-        for (int a = 0; a < 9; ++a)
-            for (int b = 0; b < 9; ++b) Vv[a][b] = (a == b) ? 1.0 : 0.0;
-        // cyclic Jacobi eigenvalue iteration on the symmetric 9x9 (sequential: once per RANSAC call)
-        for (int sweep = 0; sweep < 60; ++sweep) {
-            double off = 0, diag = 0;
-            for (int a = 0; a < 9; ++a) {
-                diag += G[a][a] * G[a][a];
-                for (int b = a + 1; b < 9; ++b) off += G[a][b] * G[a][b];
-            }
-            if (off <= 1e-32 * diag) break;
-            for (int p = 0; p < 8; ++p)
-                for (int q = p + 1; q < 9; ++q) {
+    }
+    for (int e = lane; e < 81; e += 64) Vv[e / 9][e % 9] = (e / 9 == e % 9) ? 1.0 : 0.0;
+    __syncthreads();
+    // Jacobi eigenvalue iteration on the symmetric 9x9 in the parallel (round-robin) ordering: the 9 indices plus one idle
+    // slot form 5 disjoint pairs per round, 9 rounds visit all 36 pairs once (= one sweep).  Lanes 0..4 compute the rotations
+    // of a round, then all lanes apply J^T G J and V J element-wise (disjoint rotations commute).
+    __shared__ int partner[10];
+    __shared__ double cself[10], cpart[10];
+    __shared__ int ring[10];
+    __shared__ double Gn[9][9], Vn[9][9];
+    if (lane < 10) ring[lane] = lane;
+    __syncthreads();
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        // off-diagonal mass against the diagonal (wave reduction; every lane gets the totals)
+        double off = 0, diag = 0;
+        for (int e = lane; e < 81; e += 64) {
+            const double v = G[e / 9][e % 9];
+            if (e / 9 == e % 9)
+                diag += v * v;
+            else if (e / 9 < e % 9)
+                off += v * v;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            off += __shfl_xor(off, d);
+            diag += __shfl_xor(diag, d);
+        }
+        if (off <= 1e-32 * diag) break;  // wave-uniform
+        for (int round = 0; round < 9; ++round) {
+            if (lane < 5) {
+                const int p0 = ring[lane], q0 = ring[9 - lane];
+                const int p = min(p0, q0), q = max(p0, q0);
+                double c = 1.0, sn = 0.0;
+                if (q < 9) {
                     const double apq = G[p][q];
-                    if (apq == 0.0) continue;
-                    const double theta = (G[q][q] - G[p][p]) / (2.0 * apq);
-                    const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                    const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
-                    for (int k = 0; k < 9; ++k) {
-                        const double gkp = G[k][p], gkq = G[k][q];
-                        G[k][p] = c * gkp - s * gkq;
-                        G[k][q] = s * gkp + c * gkq;
-                    }
-                    for (int k = 0; k < 9; ++k) {
-                        const double gpk = G[p][k], gqk = G[q][k];
-                        G[p][k] = c * gpk - s * gqk;
-                        G[q][k] = s * gpk + c * gqk;
-                    }
-                    for (int k = 0; k < 9; ++k) {
-                        const double vkp = Vv[k][p], vkq = Vv[k][q];
-                        Vv[k][p] = c * vkp - s * vkq;
-                        Vv[k][q] = s * vkp + c * vkq;
+                    if (apq != 0.0) {
+                        const double theta = (G[q][q] - G[p][p]) / (2.0 * apq);
+                        const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        c = 1.0 / sqrt(tt * tt + 1.0);
+                        sn = tt * c;
                     }
                 }
+                // column p' = c col_p - s col_q ; column q' = s col_p + c col_q
+                partner[p] = q;
+                cself[p] = c;
+                cpart[p] = -sn;
+                partner[q] = p;
+                cself[q] = c;
+                cpart[q] = sn;
+            }
+            __syncthreads();
+            for (int e = lane; e < 81; e += 64) {
+                const int a = e / 9, b = e % 9;
+                const int pa = partner[a], pb = partner[b];
+                const double ca = cself[a], ka = cpart[a], cb = cself[b], kb = cpart[b];
+                // an index paired with the idle slot keeps c = 1, k = 0; its partner index (9) is never read with weight
+                const double gab = G[a][b];
+                const double gapb = (pb < 9) ? G[a][pb] : 0.0;
+                const double gpab = (pa < 9) ? G[pa][b] : 0.0;
+                const double gpapb = (pa < 9 && pb < 9) ? G[pa][pb] : 0.0;
+                Gn[a][b] = ca * cb * gab + ca * kb * gapb + ka * cb * gpab + ka * kb * gpapb;
+                const double vab = Vv[a][b];
+                const double vapb = (pb < 9) ? Vv[a][pb] : 0.0;
+                Vn[a][b] = cb * vab + kb * vapb;
+            }
+            __syncthreads();
+            for (int e = lane; e < 81; e += 64) {
+                G[e / 9][e % 9] = Gn[e / 9][e % 9];
+                Vv[e / 9][e % 9] = Vn[e / 9][e % 9];
+            }
+            if (lane == 0) {  // rotate the ring: slot 0 stays, the others move one place
+                const int last = ring[9];
+                for (int k = 9; k > 1; --k) ring[k] = ring[k - 1];
+                ring[1] = last;
+            }
+            __syncthreads();
         }
+    }
+    if (lane == 0) {
         // order eigenvalues descending; EE = eigenvectors of the 4 smallest, in descending order (five-point.cpp:388)
         int order[9];
         for (int a = 0; a < 9; ++a) order[a] = a;
@@ -1106,6 +1206,20 @@ int update_num_iters(double p, double ep, int model_points, int max_iters) {
 
 // Launchers used by the C ABI ------------------------------------------------------------------------------------
 
+// Sampson scoring of up to `max_models` models (dense list, live count on the device or the host): few models -> one block per
+// model, many -> 4 lanes per model (see the two kernels).  Identical results either way.
+constexpr int kScoreBlockMaxModels = 24576;
+static void launch_score(hipStream_t s, const double4 *pts, int n, const double *E_list, const int32_t *ids, const int32_t *total_ptr,
+                         int total_host, int max_models, double thresh2, int32_t *good, double *esum) {
+    if (max_models <= 0) return;
+    if (n <= kScoreBlockMaxN && max_models <= kScoreBlockMaxModels)
+        hipLaunchKernelGGL(score_models_block_kernel, dim3(max_models), dim3(256), (size_t)((n + 3) / 4 * 4) * sizeof(float), s, pts, n,
+                           E_list, ids, total_ptr, total_host, thresh2, good, esum);
+    else
+        hipLaunchKernelGGL(score_models_kernel, dim3((max_models + 63) / 64), dim3(256), 0, s, pts, n, E_list, ids, total_ptr,
+                           total_host, thresh2, good, esum);
+}
+
 static int pack_points(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double4 **d_pts, hipStream_t s) {
     void *buf = nullptr;
     int rc = ws_get(ctx, WS_AUX3, (size_t)n * sizeof(double4), &buf);
@@ -1239,9 +1353,8 @@ int mlpl_score_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, 
     double4 *pts;
     if ((rc = pack_points(ctx, (const double *)dp1, (const double *)dp2, n, &pts, s))) return rc;
     prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
-    hipLaunchKernelGGL(score_models_kernel, dim3((n_models + 63) / 64), dim3(256), 0, s, (const double4 *)pts, n,
-                       (const double *)dE, (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, thresh * thresh,
-                       (int32_t *)dgood, (double *)dsum);
+    launch_score(s, (const double4 *)pts, n, (const double *)dE, nullptr, nullptr, n_models, n_models, thresh * thresh, (int32_t *)dgood,
+                 (double *)dsum);
     prof_mark(ctx, MLPL_PROF_SCORE, 1, s);
     MLPL_HIP_TRY(hipGetLastError());
     MLPL_HIP_TRY(hipMemcpyAsync(count, dgood, (size_t)n_models * 4, hipMemcpyDeviceToHost, s));
@@ -1334,9 +1447,8 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
             off += m;
         }
         prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
-        hipLaunchKernelGGL(score_models_kernel, dim3((cnt * 10 + 63) / 64), dim3(256), 0, s, (const double4 *)pts, n,
-                           (const double *)B.dense_E, (const int32_t *)B.dense_id, (const int32_t *)B.total, 0, thresh2,
-                           B.good, B.esum);
+        launch_score(s, (const double4 *)pts, n, (const double *)B.dense_E, (const int32_t *)B.dense_id, (const int32_t *)B.total, 0,
+                     cnt * 10, thresh2, B.good, B.esum);
         prof_mark(ctx, MLPL_PROF_SCORE, 1, s);
         hipLaunchKernelGGL(hyp_best_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, (const int32_t *)B.n_models,
                            (const int32_t *)B.good, (const double *)B.esum, cnt, B.hgood, B.hsum, B.hslot);
@@ -1366,8 +1478,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, s, (const double *)d_gram, gblocks, B.recs);
         hipLaunchKernelGGL(roots_kernel, dim3(1), dim3(64), 0, s, (const PolyRec *)B.recs, 0, 1, d_Etab, d_nm, (double *)nullptr,
                            (int32_t *)nullptr, (int32_t *)nullptr);
-        hipLaunchKernelGGL(score_models_kernel, dim3(1), dim3(256), 0, s, (const double4 *)pts, n, (const double *)d_Etab,
-                           (const int32_t *)nullptr, (const int32_t *)d_nm, 0, thresh2, d_good, d_es);
+        launch_score(s, (const double4 *)pts, n, (const double *)d_Etab, nullptr, (const int32_t *)d_nm, 0, 10, thresh2, d_good, d_es);
         hipLaunchKernelGGL(refit_decide_kernel, dim3(1), dim3(64), 0, s, (const int32_t *)d_nm, (const int32_t *)d_good,
                            (const double *)d_es, (const double *)d_Etab, d_st);
         // re-evaluating the mask with the (possibly unchanged) model held is idempotent

@@ -1,19 +1,36 @@
-import sys, os, time
+"""Wall time per RANSAC call (device-resident points) at the C3 throughput settings and at the reference's own settings.
+Usage: python tools/ransac_timeline.py   (run under `rocprofv3 --kernel-trace --stats` for the kernel timeline)"""
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-import matchinglib_poselib_amd as mpa
-from matchinglib_poselib_amd import pose, synth
+import numpy as np  # noqa: E402,F401
+import torch  # noqa: E402
+
+import matchinglib_poselib_amd as mpa  # noqa: E402
+from matchinglib_poselib_amd import pose, synth  # noqa: E402
+
 ctx = mpa.Context(0)
 dev = torch.device("cuda", 0)
 p1, p2, R, t, mask, th = synth.pose_scene(5000, seed=20260103)
-d1 = torch.from_numpy(p1).to(dev); d2 = torch.from_numpy(p2).to(dev)
+d1 = torch.from_numpy(p1).to(dev)
+d2 = torch.from_numpy(p2).to(dev)
 dm = torch.empty(5000, dtype=torch.uint8, device=dev)
-for _ in range(3):
-    pose.ransac_essential_device(d1, d2, th, confidence=1.0, max_iters=20000, refit=False, seed=12345, ctx=ctx, mask_out=dm)
-torch.cuda.synchronize()
-ts = []
-for _ in range(10):
-    t0 = time.perf_counter()
-    r = pose.ransac_essential_device(d1, d2, th, confidence=1.0, max_iters=20000, refit=False, seed=12345, ctx=ctx, mask_out=dm)
-    ts.append(time.perf_counter() - t0)
-print("wall ms per call:", [round(x * 1e3, 3) for x in ts], r["iters"], r["n_inliers"])
+for name, conf, iters, refit in (("C3 throughput (20000, 1.0)", 1.0, 20000, False), ("reference settings (1000, 0.999)", 0.999, 1000, False),
+                                 ("reference settings + refit", 0.999, 1000, True)):
+    call = lambda: pose.ransac_essential_device(d1, d2, th, confidence=conf, max_iters=iters, refit=refit, seed=12345, ctx=ctx,  # noqa: E731
+                                                mask_out=dm)
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        r = call()
+        ts.append(time.perf_counter() - t0)
+    print(f"{name}: median {np.median(ts) * 1e3:.3f} ms, min {min(ts) * 1e3:.3f} ms; iterations {r['iters']}, inliers {r['n_inliers']}", flush=True)
+t0 = time.perf_counter()
+for _ in range(20):
+    r = pose.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, refit=True, seed=12345, ctx=ctx)
+print(f"host API, reference settings + refit: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per call")
