@@ -83,6 +83,22 @@ def run(ctx, dev, cpu_baseline=True):
         tc = time.perf_counter() - tc
         out["ransac_c3"]["cpu_baseline"] = {"value": ci / tc, "unit": "hypotheses/s", "cores": 1, "kind": "port",
                                             "sample": f"first {ci} of the 20000 iterations of the same run ({tc:.2f} s)"}
+    # ---- the reference's own RANSAC settings on the C3 scene: 1000 iterations, confidence 0.999, refit on (latency shape) ----
+    rc = lambda: pose.ransac_essential_device(d1, d2, th, confidence=0.999, max_iters=1000, refit=True, seed=12345, ctx=ctx,  # noqa: E731
+                                              mask_out=dm)
+    rr = rc()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        rc()
+    dtr = (time.perf_counter() - t0) / 20
+    out["ransac_reference_settings_refit"] = {"metric": "one estimateEssentialMat(RANSAC, refine=true)-shaped call, device-resident points",
+                                              "ms_per_call": dtr * 1e3, "iters_used": rr["iters"], "n_inliers": rr["n_inliers"]}
+    if cpu_baseline:
+        tc = time.perf_counter()
+        ora.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, lesqu=True, seed=12345)
+        out["ransac_reference_settings_refit"]["cpu_baseline"] = {"ms_per_call": (time.perf_counter() - tc) * 1e3, "cores": 1,
+                                                                  "kind": "port", "sample": "the same call"}
     # ---- LMedS on the C3 scene: the reference's LMEDS settings (134 samples at confidence 0.999) and the largest sample count a double confidence reaches (711) ----
     for conf, name in ((0.999, "lmeds_reference_settings"), (1.0 - 1e-16, "lmeds_711_samples")):
         lc = lambda: pose.lmeds_essential(p1, p2, confidence=conf, max_iters=2000, seed=12345, ctx=ctx)  # noqa: E731
