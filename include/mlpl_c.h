@@ -242,6 +242,12 @@ int mlpl_recover_pose(mlpl_ctx *ctx, const double E[9], const double *p1, const 
  * candidates [I|t], [I|-t] compete.  t_only = getTfromTransEssential(E) (P/source/pose_helper.cpp:422-433). */
 int mlpl_recover_pose_translation(mlpl_ctx *ctx, const double t_only[3], const double *p1, const double *p2, int n,
                                   double dist, double R[9], double t[3], double *Q, uint8_t *mask_inout);
+/* mlpl_recover_pose on device-resident correspondences: d_p1, d_p2 n x 2 doubles, d_Q n x 3 doubles or NULL, d_mask_inout n bytes
+ * (nonzero = use; rewritten with the chosen candidate's mask) or NULL -- all device pointers; E, R, t are host.  One host hop:
+ * the four candidate counts (five-point.cpp:299-336) decide whose outputs are kept.  Returns the number of valid 3-D points. */
+int mlpl_recover_pose_dev(mlpl_ctx *ctx, const double E[9], const double *d_p1, const double *d_p2, int n, double dist,
+                          double R[9], double t[3], double *d_Q, uint8_t *d_mask_inout, void *stream);
+
 
 #ifdef __cplusplus
 }

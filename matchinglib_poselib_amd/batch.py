@@ -92,7 +92,7 @@ def process_pair_on_device(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, th_pix:
         return rec
     rec["n_inliers"] = r["n_inliers"]
     rec["E"] = r["E"].reshape(-1)
-    n_good, R, t, Q, m = pose.getPoseTriangPts(r["E"], p1.cpu().numpy(), p2.cpu().numpy(), r["mask"].cpu().numpy(), dist, ctx=ctx)
+    n_good, R, t = pose.getPoseTriangPts_device(r["E"], p1, p2, r["mask"], dist, ctx=ctx)  # points and mask stay on the device
     rec["R"] = R.reshape(-1)
     rec["t"] = t.reshape(-1)
     return rec

@@ -185,7 +185,19 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const double *__restri
 using namespace mlpl;
 
 static int recover_pose_impl(mlpl_ctx *ctx, const double *E, const double *t_only, const double *p1, const double *p2, int n,
-                             double dist, double *R, double *t, double *Q, uint8_t *mask_inout);
+                             double dist, double *R, double *t, double *Q, uint8_t *mask_inout, bool dev = false,
+                             hipStream_t stream = nullptr);
+
+// Device-resident correspondences (d_p1, d_p2: n x 2 doubles; d_Q: n x 3 doubles or NULL; d_mask_inout: n bytes or NULL, all on
+// the device); E, R, t are host.  One host hop (the four candidate counts decide which candidate's outputs are kept).
+extern "C" int mlpl_recover_pose_dev(mlpl_ctx *ctx, const double E[9], const double *d_p1, const double *d_p2, int n, double dist,
+                                     double R[9], double t[3], double *d_Q, uint8_t *d_mask_inout, void *stream) {
+    if (!E || !ctx) {
+        set_error("mlpl_recover_pose_dev: ctx and E are mandatory");
+        return MLPL_E_BAD_INPUT;
+    }
+    return recover_pose_impl(ctx, E, nullptr, d_p1, d_p2, n, dist, R, t, d_Q, d_mask_inout, true, pick_stream(ctx, stream));
+}
 
 extern "C" int mlpl_recover_pose(mlpl_ctx *ctx, const double E[9], const double *p1, const double *p2, int n, double dist,
                                  double R[9], double t[3], double *Q, uint8_t *mask_inout) {
@@ -206,18 +218,20 @@ extern "C" int mlpl_recover_pose_translation(mlpl_ctx *ctx, const double t_only[
 }
 
 static int recover_pose_impl(mlpl_ctx *ctx, const double *E, const double *t_only, const double *p1, const double *p2, int n,
-                             double dist, double *R, double *t, double *Q, uint8_t *mask_inout) {
-    if (!ctx || !p1 || !p2 || !R || !t || !Q || n < 0) {
+                             double dist, double *R, double *t, double *Q, uint8_t *mask_inout, bool dev, hipStream_t stream) {
+    if (!ctx || !p1 || !p2 || !R || !t || (!Q && !dev) || n < 0) {
         set_error("mlpl_recover_pose: R, t and Q are mandatory outputs");  // pose_estim.cpp:925-926 returns -1
         return MLPL_E_BAD_INPUT;
     }
     MLPL_HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    void *dp1, *dp2, *dQ, *dmask, *dsmall;
+    hipStream_t s = dev ? stream : ctx->stream;
+    void *dp1 = const_cast<double *>(p1), *dp2 = const_cast<double *>(p2), *dQ, *dmask, *dsmall;
     int rc;
     const size_t nn = (size_t)std::max(n, 1);
-    if ((rc = ws_get(ctx, WS_AUX0, nn * 16, &dp1))) return rc;
-    if ((rc = ws_get(ctx, WS_AUX1, nn * 16, &dp2))) return rc;
+    if (!dev) {
+        if ((rc = ws_get(ctx, WS_AUX0, nn * 16, &dp1))) return rc;
+        if ((rc = ws_get(ctx, WS_AUX1, nn * 16, &dp2))) return rc;
+    }
     if ((rc = ws_get(ctx, WS_AUX5, nn * 4 * 3 * 8, &dQ))) return rc;
     if ((rc = ws_get(ctx, WS_AUX6, nn * 5, &dmask))) return rc;
     if ((rc = ws_get(ctx, WS_AUX2, 4096, &dsmall))) return rc;
@@ -242,11 +256,12 @@ static int recover_pose_impl(mlpl_ctx *ctx, const double *E, const double *t_onl
         MLPL_HIP_TRY(hipMemcpyAsync(dP, hPt, sizeof(hPt), hipMemcpyHostToDevice, s));
     }
     MLPL_HIP_TRY(hipMemsetAsync(dcnt, 0, 16, s));
-    if (n > 0) {
+    if (n > 0 && !dev) {
         MLPL_HIP_TRY(hipMemcpyAsync(dp1, p1, (size_t)n * 16, hipMemcpyHostToDevice, s));
         MLPL_HIP_TRY(hipMemcpyAsync(dp2, p2, (size_t)n * 16, hipMemcpyHostToDevice, s));
         if (mask_inout) MLPL_HIP_TRY(hipMemcpyAsync(dmask_in, mask_inout, (size_t)n, hipMemcpyHostToDevice, s));
     }
+    if (n > 0 && dev && mask_inout) dmask_in = mask_inout;  // read in place; the chosen candidate's mask is copied back below
     if (E) hipLaunchKernelGGL(decompose_kernel, dim3(1), dim3(64), 0, s, (const double *)dE, dP);
     if (n > 0) {
         prof_mark(ctx, MLPL_PROF_RECOVER_POSE, 0, s);
@@ -278,16 +293,25 @@ static int recover_pose_impl(mlpl_ctx *ctx, const double *E, const double *t_onl
         std::memcpy(R, hP + ((pick & 1) ? 57 : 48), 72);
         const double sg = (pick < 2) ? 1.0 : -1.0;
         for (int i = 0; i < 3; ++i) t[i] = sg * hP[66 + i];
-        if (n > 0) {
+        if (n > 0 && !dev) {
             MLPL_HIP_TRY(hipMemcpy(Q, (double *)dQ + (size_t)pick * n * 3, (size_t)n * 24, hipMemcpyDeviceToHost));
             if (mask_inout) MLPL_HIP_TRY(hipMemcpy(mask_inout, (uint8_t *)dmask + (size_t)pick * n, (size_t)n, hipMemcpyDeviceToHost));
+        } else if (n > 0) {
+            if (Q) MLPL_HIP_TRY(hipMemcpyAsync(Q, (double *)dQ + (size_t)pick * n * 3, (size_t)n * 24, hipMemcpyDeviceToDevice, s));
+            if (mask_inout)
+                MLPL_HIP_TRY(hipMemcpyAsync(mask_inout, (uint8_t *)dmask + (size_t)pick * n, (size_t)n, hipMemcpyDeviceToDevice, s));
         }
     } else {
         const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         std::memcpy(R, I, 72);
         t[0] = t[1] = t[2] = 0;
-        std::memset(Q, 0, (size_t)n * 24);
-        if (mask_inout) std::memset(mask_inout, 0, (size_t)n);
+        if (!dev) {
+            std::memset(Q, 0, (size_t)n * 24);
+            if (mask_inout) std::memset(mask_inout, 0, (size_t)n);
+        } else {
+            if (Q) MLPL_HIP_TRY(hipMemsetAsync(Q, 0, (size_t)n * 24, s));
+            if (mask_inout) MLPL_HIP_TRY(hipMemsetAsync(mask_inout, 0, (size_t)n, s));
+        }
     }
     return ret;
 }

@@ -177,6 +177,25 @@ def getPoseTriangPts(E, p1, p2, mask=None, dist: float = 50.0, translatE: bool =
     return rc, R, t, Q, m
 
 
+def getPoseTriangPts_device(E, p1, p2, mask=None, dist: float = 50.0, Q_out=None, ctx: Optional[Context] = None,
+                            stream: Optional[int] = None):
+    """getPoseTriangPts on device-resident torch tensors (float64 [n,2]; mask uint8 [n], rewritten in place; Q_out float64 [n,3]
+    or None) -> (n_good, R, t).  One host hop."""
+    import torch
+
+    assert p1.is_cuda and p2.is_cuda and p1.dtype == torch.float64 and p1.is_contiguous() and p2.is_contiguous()
+    ctx = ctx or default_context(p1.device.index or 0)
+    E = np.ascontiguousarray(E, np.float64).reshape(3, 3)
+    R, t = np.zeros((3, 3)), np.zeros((3, 1))
+    st = torch.cuda.current_stream(p1.device).cuda_stream if stream is None else stream
+    rc = ctx.lib.mlpl_recover_pose_dev(ctx.handle, E.ctypes.data, p1.data_ptr(), p2.data_ptr(), p1.shape[0], float(dist),
+                                       R.ctypes.data, t.ctypes.data, None if Q_out is None else Q_out.data_ptr(),
+                                       None if mask is None else mask.data_ptr(), st)
+    if rc < 0:
+        raise MlplError(rc, "mlpl_recover_pose_dev", _lib.last_error())
+    return rc, R, t
+
+
 def ImgToCamCoordTrans(points, K, ctx: Optional[Context] = None) -> np.ndarray:
     """poselib::ImgToCamCoordTrans (pose_helper.cpp:1100-1109): float32 n x 2 pixel points -> camera coordinates."""
     ctx = ctx or default_context()

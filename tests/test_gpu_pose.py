@@ -262,3 +262,24 @@ def test_lmeds_through_estimate_essential_mat(ctx, oracle):
         pose.lmeds_essential(p1[:5], p2[:5], ctx=ctx)
     with pytest.raises(NotImplementedError):
         pose.estimateEssentialMat(p1, p2, "ARRSAC", ctx=ctx)
+
+
+def test_recover_pose_device_variant_equals_host_api(ctx, oracle):
+    import torch
+
+    p1, p2, R, t, mask, th = synth.pose_scene(3000, seed=61)
+    E = essential_from(R, t.reshape(-1))
+    m0 = (np.random.default_rng(1).random(3000) < 0.8).astype(np.uint8)
+    ng, Rh, th_, Qh, mh = pose.getPoseTriangPts(E, p1, p2, m0, 50.0, ctx=ctx)
+    d1, d2 = torch.from_numpy(p1).cuda(), torch.from_numpy(p2).cuda()
+    dm = torch.from_numpy(m0.copy()).cuda()
+    dQ = torch.empty((3000, 3), dtype=torch.float64, device="cuda")
+    ngd, Rd, td = pose.getPoseTriangPts_device(E, d1, d2, dm, 50.0, Q_out=dQ, ctx=ctx)
+    torch.cuda.synchronize()
+    assert ngd == ng and np.array_equal(Rd, Rh) and np.array_equal(td, th_)
+    assert np.array_equal(dm.cpu().numpy(), mh) and np.array_equal(dQ.cpu().numpy(), Qh)
+    go, Ro, to, Qo, mo = oracle.recover_pose(E, p1, p2, 50.0, m0)
+    assert ngd == go and np.abs(Rd - Ro).max() < 1e-9
+    # no mask, no Q
+    ng2, R2, t2 = pose.getPoseTriangPts_device(E, d1, d2, ctx=ctx)
+    assert ng2 == oracle.recover_pose(E, p1, p2, 50.0, None)[0]
