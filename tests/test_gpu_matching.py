@@ -403,3 +403,26 @@ def test_hamming_many_splits_large_train_set(ctx, oracle, variant):
     oi, od = oracle.knn_hamming(q[rows], t)
     assert np.array_equal(idx[rows], oi) and np.array_equal(dist[rows], od)
     assert idx.min() >= 0 and idx.max() < 70001 and (dist[:, 0] <= dist[:, 1]).all()
+
+
+def test_hamming_property_random_shapes_and_ties(ctx, oracle):
+    """Property test (hypothesis): any small shape, any descriptor width 1..64 bytes, k in {1, 2}, descriptors drawn from a small
+    alphabet so that equal distances are the rule -- the default (matrix-core) path returns the oracle's pairs bit for bit."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(nq=st.integers(1, 200), nt=st.integers(2, 1500), nbytes=st.integers(1, 64), k=st.integers(1, 2),
+           alphabet=st.integers(1, 40), seed=st.integers(0, 2**31 - 1))
+    def check(nq, nt, nbytes, k, alphabet, seed):
+        rng = np.random.default_rng(seed)
+        base = rng.integers(0, 256, (alphabet, nbytes), dtype=np.uint8)
+        t = base[rng.integers(0, alphabet, nt)]
+        q = base[rng.integers(0, alphabet, nq)]
+        flip = rng.random(q.shape) < 0.02          # a few perturbed bytes: near-ties as well as exact ties
+        q = np.where(flip, rng.integers(0, 256, q.shape, dtype=np.uint8), q)
+        idx, dist = mpa.knn_hamming(q, t, k=k, ctx=ctx)
+        oi, od = oracle.knn_hamming(q, t, k=k)
+        assert np.array_equal(dist, od) and np.array_equal(idx, oi), (nq, nt, nbytes, k, alphabet, seed)
+
+    _set_hamming(ctx, HAMMING_DEFAULT)
+    check()
