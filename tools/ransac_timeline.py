@@ -30,7 +30,11 @@ for name, conf, iters, refit in (("C3 throughput (20000, 1.0)", 1.0, 20000, Fals
         r = call()
         ts.append(time.perf_counter() - t0)
     print(f"{name}: median {np.median(ts) * 1e3:.3f} ms, min {min(ts) * 1e3:.3f} ms; iterations {r['iters']}, inliers {r['n_inliers']}", flush=True)
-t0 = time.perf_counter()
-for _ in range(20):
-    r = pose.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, refit=True, seed=12345, ctx=ctx)
-print(f"host API, reference settings + refit: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per call")
+pose.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, refit=True, seed=12345, ctx=ctx)  # first call: workspace growth
+for refit in (False, True):
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        r = pose.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, refit=refit, seed=12345, ctx=ctx)
+        ts.append(time.perf_counter() - t0)
+    print(f"host API refit={refit}: median {np.median(ts) * 1e3:.3f} ms, min {min(ts) * 1e3:.3f}, max {max(ts) * 1e3:.3f}")
