@@ -227,6 +227,84 @@ void run_share(const uint4 *src, float *out, int wps) {
     delete[] h;
 }
 
+// Group staging: G tiles per barrier (two LDS groups of G tiles, glds prefetch of the next group while the current one is
+// consumed), 4-wave workgroups, A fragments single-buffered from LDS.
+template <int G>
+__global__ __launch_bounds__(256) void groupk(const uint4 *src, float *out, int iters, long long *cyc) {
+    __shared__ uint4 ring[2 * G * 256];
+    const int l = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint4 b[4][4];
+    for (int t = 0; t < 4; ++t)
+        for (int s = 0; s < 4; ++s) b[t][s] = src[l + 64 * (4 + 4 * t + s)];
+    v16f cinit;
+    for (int i = 0; i < 16; ++i) cinit[i] = -(float)i * (1.0f / 16384.0f);
+    float m1[4], m2[4];
+    for (int t = 0; t < 4; ++t) m1[t] = m2[t] = -1e30f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4 *)ring + (uint32_t)l * 16u;
+    auto stage_group = [&](int grp) {  // wave w moves K-step w of each of the G tiles: G glds per wave
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const uint4 *g = src + (((grp * G + j) & 3) * 256) + w * 64 + l;
+            uint4 *d = ring + ((grp & 1) * G + j) * 256 + w * 64;
+            __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)d, 16, 0, 0);
+        }
+    };
+    long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    stage_group(0);
+    for (int grp = 0; grp < iters / G; ++grp) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of this group have landed
+        __builtin_amdgcn_s_barrier();                     // everyone's have, and everyone is done with the other group
+        stage_group(grp + 1);
+        for (int j = 0; j < G; ++j) {
+            uint4 a[4];
+            const uint32_t addr = ring_lds + (uint32_t)(((grp & 1) * G + j) * 4096);
+            asm volatile(
+                "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3])
+                : "v"(addr)
+                : "memory");
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                v16f acc = mf(a[0], b[t][0], cinit);
+#pragma unroll
+                for (int s = 1; s < 4; ++s) acc = mf(a[s], b[t][s], acc);
+                update(m1[t], m2[t], acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        const int wi = blockIdx.x * 4 + (threadIdx.x >> 6);
+        cyc[2 * wi] = t1 - t0;
+        cyc[2 * wi + 1] = r1 - r0;
+    }
+    float sres = 0;
+    for (int t = 0; t < 4; ++t) sres += m1[t] + m2[t];
+    out[(blockIdx.x * blockDim.x + threadIdx.x) & 16383] = sres;
+}
+
+template <int G>
+void run_group(const uint4 *src, float *out, int wps) {
+    long long *dc;
+    const int blocks = 256 * wps, waves = blocks * 4, iters = 1024;
+    hipMalloc(&dc, waves * 16);
+    hipLaunchKernelGGL((groupk<G>), dim3(blocks), dim3(256), 0, 0, src, out, iters, dc);
+    long long *h = new long long[waves * 2];
+    hipMemcpy(h, dc, waves * 16, hipMemcpyDeviceToHost);
+    double cs = 0, rs = 0;
+    for (int i = 0; i < waves; ++i) cs += h[2 * i], rs += h[2 * i + 1];
+    const double per_wave_unit = cs / waves / (iters * 4.0);
+    printf("LDS group staging, %d tiles per barrier, %d blocks of 4 waves per CU: %.3f GHz, %.1f cycles per unit per wave -> %.1f per SIMD\n", G,
+           wps, cs / rs * 0.1, per_wave_unit, per_wave_unit / wps);
+    hipFree(dc);
+    delete[] h;
+}
+
 int main() {
     uint4 *src;
     float *out;
@@ -252,5 +330,10 @@ int main() {
         run_share<1>(src, out, wps);
         run_share<2>(src, out, wps);
     }
+    for (int wps : {3, 4}) {
+        run_group<2>(src, out, wps);
+        run_group<4>(src, out, wps);
+    }
+    run_group<8>(src, out, 2);
     return 0;
 }
