@@ -60,10 +60,7 @@ int pinned_get(mlpl_ctx *ctx, size_t bytes, void **out) {
 
 void prof_mark(mlpl_ctx *ctx, int id, int phase, hipStream_t s) {
     if (!ctx->prof_on) return;
-    if (!ctx->prof_ev[id]) {
-        ctx->prof_ev[id] = new hipEvent_t[2 * kProfMaxLaunches];
-        for (int i = 0; i < 2 * kProfMaxLaunches; ++i) (void)hipEventCreate(&ctx->prof_ev[id][i]);
-    }
+    if (!ctx->prof_ev[id]) return;  // pools are created by mlpl_profile_enable, outside any timed region
     if (ctx->prof_n[id] >= kProfMaxLaunches) return;
     // prof_on = N > 1: bracket every Nth launch only (two event records cost ~10 us of stream time per launch)
     if (phase == 0) ctx->prof_take[id] = (ctx->prof_calls[id]++ % ctx->prof_on) == 0;
@@ -169,6 +166,14 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
 int mlpl_profile_enable(mlpl_ctx *ctx, int on) {
     if (!ctx) return MLPL_E_BAD_INPUT;
     ctx->prof_on = on > 0 ? on : 0;  // N > 1: every Nth launch of a kernel is bracketed
+    if (ctx->prof_on) {
+        // event pools up front: creating them lazily put ~10^4 hipEventCreate calls into the caller's first timed launch
+        for (int id = 0; id < MLPL_PROF_NUM; ++id) {
+            if (ctx->prof_ev[id]) continue;
+            ctx->prof_ev[id] = new hipEvent_t[2 * kProfMaxLaunches];
+            for (int i = 0; i < 2 * kProfMaxLaunches; ++i) (void)hipEventCreate(&ctx->prof_ev[id][i]);
+        }
+    }
     return MLPL_OK;
 }
 

@@ -89,7 +89,7 @@ namespace mlpl {
 int ws_get(mlpl_ctx *ctx, WsSlot slot, size_t bytes, void **out);
 int pinned_get(mlpl_ctx *ctx, size_t bytes, void **out);
 
-constexpr int kProfMaxLaunches = 8192;
+constexpr int kProfMaxLaunches = 2048;
 // Records the start (phase 0) / stop (phase 1) event of one launch of kernel `id` on stream s when profiling is on.
 void prof_mark(mlpl_ctx *ctx, int id, int phase, hipStream_t s);
 
