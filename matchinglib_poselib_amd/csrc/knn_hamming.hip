@@ -25,8 +25,7 @@ namespace {
 
 constexpr int kQueriesPerBlock = 256;
 constexpr int kTileRows = 128;
-constexpr int kMergeLanes = 16;                    // lanes cooperating on one query in the merge kernel
-constexpr int kMergeGroup = 1024 / kMergeLanes;    // queries per merge block (= kCountGroup of ratio_write_kernel)
+constexpr int kMergeGroup = 64;                    // queries per merge block (= kCountGroup of ratio_write_kernel)
 static_assert(kMergeGroup == kCountGroup, "merge kernel and ratio_write_kernel disagree on the count granularity");
 
 // bits needed for a distance in [0, 32*nw]
@@ -238,19 +237,22 @@ __global__ __launch_bounds__(BT) void knn_hamming_partial_sgpr_kernel(
         if (qidx[j] < nq) part[((size_t)b * nsplit + split) * nq + qidx[j]] = make_uint2(k0[j], k1[j]);
 }
 
-// Merge of the per-split partial top-2 lists, kMergeLanes lanes per query (each lane folds every kMergeLanes-th
-// split, then xor-shuffles combine the lanes), on 64-bit (dist << 32 | global row) keys.  Also evaluates the ratio predicate and
-// leaves the number of passing queries of this 256-query group in group_counts (consumed by ratio_write_kernel), so
-// the fused getMatches path needs no separate counting pass.
-__global__ __launch_bounds__(1024) void knn_hamming_merge_kernel(const uint2 *__restrict__ part, int nq, int nsplit,
-                                                                 int rows_per_split, int dshift, int k, float ratio,
-                                                                 int32_t *__restrict__ idx, int32_t *__restrict__ dist,
-                                                                 int32_t *__restrict__ group_counts) {
-    __shared__ int wave_tot[16];
+// Merge of the per-split partial top-2 lists, LANES lanes per query (each lane folds every LANES-th split, then xor-shuffles
+// combine the lanes), on 64-bit (dist << 32 | global row) keys; kMergeGroup queries per block (block = kMergeGroup * LANES threads).
+// Also evaluates the ratio predicate and leaves the number of passing queries of this query group in group_counts (consumed by
+// ratio_write_kernel), so the fused getMatches path needs no separate counting pass.  LANES = 4 serves the usual handful of
+// splits (a quarter of the threads and shuffles of the 16-lane form), LANES = 16 many splits.
+template <int LANES>
+__global__ __launch_bounds__(kMergeGroup * LANES) void knn_hamming_merge_kernel(const uint2 *__restrict__ part, int nq, int nsplit,
+                                                                                 int rows_per_split, int dshift, int k, float ratio,
+                                                                                 int32_t *__restrict__ idx, int32_t *__restrict__ dist,
+                                                                                 int32_t *__restrict__ group_counts) {
+    constexpr int kWaves = kMergeGroup * LANES / 64;
+    __shared__ int wave_tot[kWaves];
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
-    const int sub = tid & (kMergeLanes - 1);
-    const int qi = blockIdx.x * kMergeGroup + tid / kMergeLanes;
+    const int sub = tid & (LANES - 1);
+    const int qi = blockIdx.x * kMergeGroup + tid / LANES;
     const uint32_t lmask = (1u << dshift) - 1u;
     unsigned long long b0 = ~0ull, b1 = ~0ull;
     auto upd = [&](unsigned long long g) {
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(1024) void knn_hamming_merge_kernel(const uint2 *__
         b0 = lt0 ? g : b0;
     };
     if (qi < nq) {
-        for (int s = sub; s < nsplit; s += kMergeLanes) {
+        for (int s = sub; s < nsplit; s += LANES) {
             const uint2 p = part[((size_t)b * nsplit + s) * nq + qi];
             const unsigned long long base = (unsigned long long)s * rows_per_split;
             if (p.x != 0xFFFFFFFFu) upd(((unsigned long long)(p.x >> dshift) << 32) | (base + (p.x & lmask)));
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(1024) void knn_hamming_merge_kernel(const uint2 *__
         }
     }
 #pragma unroll
-    for (int off = 1; off < kMergeLanes; off <<= 1) {
+    for (int off = 1; off < LANES; off <<= 1) {
         const unsigned long long o0 = __shfl_xor(b0, off), o1 = __shfl_xor(b1, off);
         upd(o0);
         upd(o1);
@@ -294,10 +296,21 @@ __global__ __launch_bounds__(1024) void knn_hamming_merge_kernel(const uint2 *__
         if (tid == 0) {
             int tot = 0;
 #pragma unroll
-            for (int w = 0; w < 16; ++w) tot += wave_tot[w];
+            for (int w = 0; w < kWaves; ++w) tot += wave_tot[w];
             group_counts[(size_t)b * gridDim.x + blockIdx.x] = tot;
         }
     }
+}
+
+static void launch_merge(hipStream_t s, const uint2 *part, int nq, int nsplit, int rps, int dshift, int k, float ratio, int batch,
+                         int32_t *d_idx, int32_t *d_dist, int32_t *d_group_counts) {
+    dim3 mgrid((nq + kMergeGroup - 1) / kMergeGroup, batch);
+    if (nsplit <= 8)
+        hipLaunchKernelGGL(knn_hamming_merge_kernel<4>, mgrid, dim3(kMergeGroup * 4), 0, s, part, nq, nsplit, rps, dshift, k, ratio, d_idx,
+                           d_dist, d_group_counts);
+    else
+        hipLaunchKernelGGL(knn_hamming_merge_kernel<16>, mgrid, dim3(kMergeGroup * 16), 0, s, part, nq, nsplit, rps, dshift, k, ratio,
+                           d_idx, d_dist, d_group_counts);
 }
 
 template <int NW>
@@ -386,9 +399,7 @@ int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_strid
         uint2 *part = nullptr;
         int rc = launch_knn_hamming_mfma(ctx, qw, qbw, tw, tbw, nq, nt, nw, batch, dshift, s, &rps, &nsplit, &part);
         if (rc) return rc;
-        dim3 mgrid((nq + kMergeGroup - 1) / kMergeGroup, batch);
-        hipLaunchKernelGGL(knn_hamming_merge_kernel, mgrid, dim3(1024), 0, s, (const uint2 *)part, nq, nsplit, rps, dshift, k,
-                           ratio, d_idx, d_dist, d_group_counts);
+        launch_merge(s, (const uint2 *)part, nq, nsplit, rps, dshift, k, ratio, batch, d_idx, d_dist, d_group_counts);
         MLPL_HIP_TRY(hipGetLastError());
         return MLPL_OK;
     }
@@ -429,9 +440,7 @@ int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_strid
         default: set_error("knn_hamming: unsupported descriptor width %d bytes", nbytes); return MLPL_E_BAD_INPUT;
     }
     prof_mark(ctx, MLPL_PROF_KNN_HAMMING, 1, s);
-    dim3 mgrid((nq + kMergeGroup - 1) / kMergeGroup, batch);
-    hipLaunchKernelGGL(knn_hamming_merge_kernel, mgrid, dim3(1024), 0, s, (const uint2 *)part, nq, nsplit, rps, dshift, k,
-                       ratio, d_idx, d_dist, d_group_counts);
+    launch_merge(s, (const uint2 *)part, nq, nsplit, rps, dshift, k, ratio, batch, d_idx, d_dist, d_group_counts);
     MLPL_HIP_TRY(hipGetLastError());
     return MLPL_OK;
 }
