@@ -132,19 +132,30 @@ __global__ __launch_bounds__(kQPB) void knn_l2_exact_kernel(const float *__restr
     if (qi < nq) part[((size_t)b * nsplit + split) * nq + qi] = make_ulonglong2(k0, k1);
 }
 
-__global__ void knn_l2_merge_kernel(const ulonglong2 *__restrict__ part, int nq, int nsplit, int k,
-                                    int32_t *__restrict__ idx, float *__restrict__ dist, const int *__restrict__ gate,
-                                    int gate_want) {
+// LANES lanes per query: each lane folds every LANES-th split, xor-shuffles combine the lanes (64-bit (dist bits, row) keys).
+template <int LANES>
+__global__ __launch_bounds__(256) void knn_l2_merge_kernel(const ulonglong2 *__restrict__ part, int nq, int nsplit, int k,
+                                                           int32_t *__restrict__ idx, float *__restrict__ dist,
+                                                           const int *__restrict__ gate, int gate_want) {
     if (gate && ((*gate != 0) ? 1 : 0) != gate_want) return;
     const int b = blockIdx.y;
-    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi >= nq) return;
+    const int sub = threadIdx.x & (LANES - 1);
+    const int qi = blockIdx.x * (256 / LANES) + threadIdx.x / LANES;
     u64 b0 = ~0ull, b1 = ~0ull;
-    for (int s = 0; s < nsplit; ++s) {
-        const ulonglong2 p = part[((size_t)b * nsplit + s) * nq + qi];
-        if (p.x != ~0ull) top2_update(b0, b1, p.x);
-        if (p.y != ~0ull) top2_update(b0, b1, p.y);
+    if (qi < nq) {
+        for (int s = sub; s < nsplit; s += LANES) {
+            const ulonglong2 p = part[((size_t)b * nsplit + s) * nq + qi];
+            if (p.x != ~0ull) top2_update(b0, b1, p.x);
+            if (p.y != ~0ull) top2_update(b0, b1, p.y);
+        }
     }
+#pragma unroll
+    for (int off = 1; off < LANES; off <<= 1) {
+        const u64 o0 = __shfl_xor(b0, off), o1 = __shfl_xor(b1, off);
+        top2_update(b0, b1, o0);
+        top2_update(b0, b1, o1);
+    }
+    if (sub != 0 || qi >= nq) return;
     const size_t o = ((size_t)b * nq + qi) * k;
     idx[o] = (int32_t)(b0 & 0xFFFFFFFFull);
     dist[o] = __uint_as_float((uint32_t)(b0 >> 32));
@@ -158,9 +169,15 @@ __global__ void knn_l2_merge_kernel(const ulonglong2 *__restrict__ part, int nq,
 
 void launch_knn_l2_merge(const void *part, int nq, int nsplit, int k, int batch, int32_t *d_idx, float *d_dist,
                          hipStream_t s, const int *gate, int gate_want) {
-    dim3 mgrid((nq + 255) / 256, batch);
-    hipLaunchKernelGGL(knn_l2_merge_kernel, mgrid, dim3(256), 0, s, (const ulonglong2 *)part, nq, nsplit, k, d_idx, d_dist, gate,
-                       gate_want);
+    if (nsplit <= 4) {
+        dim3 mgrid((nq + 255) / 256, batch);
+        hipLaunchKernelGGL(knn_l2_merge_kernel<1>, mgrid, dim3(256), 0, s, (const ulonglong2 *)part, nq, nsplit, k, d_idx, d_dist, gate,
+                           gate_want);
+    } else {
+        dim3 mgrid((nq + 15) / 16, batch);
+        hipLaunchKernelGGL(knn_l2_merge_kernel<16>, mgrid, dim3(256), 0, s, (const ulonglong2 *)part, nq, nsplit, k, d_idx, d_dist, gate,
+                           gate_want);
+    }
 }
 
 int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t, int nt,
