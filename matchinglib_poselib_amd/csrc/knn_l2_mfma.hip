@@ -38,11 +38,18 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 }
 
 // X: [n][dim] f32 (row stride `stride`) -> frag[(tile*KS + s)*64 + lane] = 8 halfs X[tile*32 + (lane&31)][16 s + 8 (lane>>5) + j];
-// flags[0] |= 1 when an element is not an integer in [0,255].
-__global__ void l2_prep_kernel(const float *__restrict__ X, size_t stride, size_t bstride, int n, int dim, int KS, int ntiles,
-                               uint4 *__restrict__ frag, int *__restrict__ flags) {
+// flags[0] |= 1 when an element is not an integer in [0,255].  One launch for both operands: blockIdx.z = 0 queries, 1 train rows.
+struct L2PrepArgs {
+    const float *X;
+    size_t stride, bstride;
+    int n, ntiles;
+    uint4 *frag;
+};
+
+__global__ void l2_prep_kernel(L2PrepArgs qa, L2PrepArgs ta, int dim, int KS, int *__restrict__ flags) {
+    const L2PrepArgs A = blockIdx.z ? ta : qa;
     const int b = blockIdx.y;
-    const long long total = (long long)ntiles * KS * 64;
+    const long long total = (long long)A.ntiles * KS * 64;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
     const int lane = (int)(g & 63);
@@ -55,12 +62,12 @@ __global__ void l2_prep_kernel(const float *__restrict__ X, size_t stride, size_
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float v = 0.f;
-        if (row < n && k0 + j < dim) v = X[(size_t)b * bstride + (size_t)row * stride + k0 + j];
+        if (row < A.n && k0 + j < dim) v = A.X[(size_t)b * A.bstride + (size_t)row * A.stride + k0 + j];
         bad = bad || !(v >= 0.f && v <= 255.f && v == floorf(v));
         h[j] = (_Float16)v;
     }
     if (bad) atomicOr(flags, 1);
-    frag[(size_t)b * total + g] = *reinterpret_cast<uint4 *>(&h);
+    A.frag[(size_t)b * total + g] = *reinterpret_cast<uint4 *>(&h);
 }
 
 // Squared norms of the rows of both sets in one launch: 8 lanes per row (coalesced 32-byte segments), xor-shuffle sum.
@@ -218,10 +225,9 @@ int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride,
     MLPL_HIP_TRY(hipMemsetAsync(dflag, 0, 4, s));
     {
         const long long tq = (long long)nq_tiles * ksel * 64, tt = (long long)nt_tiles * ksel * 64;
-        hipLaunchKernelGGL(l2_prep_kernel, dim3((unsigned)((tq + 255) / 256), batch), dim3(256), 0, s, d_q, q_stride, q_bstride, nq,
-                           dim, ksel, nq_tiles, (uint4 *)qf, dflag);
-        hipLaunchKernelGGL(l2_prep_kernel, dim3((unsigned)((tt + 255) / 256), batch), dim3(256), 0, s, d_t, t_stride, t_bstride, nt,
-                           dim, ksel, nt_tiles, (uint4 *)tf, dflag);
+        const L2PrepArgs qa{d_q, q_stride, q_bstride, nq, nq_tiles, (uint4 *)qf}, ta{d_t, t_stride, t_bstride, nt, nt_tiles, (uint4 *)tf};
+        hipLaunchKernelGGL(l2_prep_kernel, dim3((unsigned)((std::max(tq, tt) + 255) / 256), batch, 2), dim3(256), 0, s, qa, ta, dim,
+                           ksel, dflag);
         const long long rows8 = (long long)(nq_pad + nt_pad) * 8;
         hipLaunchKernelGGL(l2_norm_kernel, dim3((unsigned)((rows8 + 255) / 256), batch), dim3(256), 0, s, d_q, q_stride, q_bstride,
                            nq, nq_pad, d_t, t_stride, t_bstride, nt, nt_pad, dim, qn, tn);
