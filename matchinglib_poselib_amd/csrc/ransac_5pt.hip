@@ -134,7 +134,7 @@ struct PolyRec {
 static_assert(sizeof(PolyRec) == 88 * 8, "PolyRec layout");
 
 // Steps 2..4 of the solver (one wave): EE basis in LDS -> PolyRec in global memory.
-__device__ void solve_from_basis(SolveLds &L, int lane, PolyRec *__restrict__ rec) {
+__device__ __forceinline__ void solve_from_basis(SolveLds &L, int lane, PolyRec *__restrict__ rec) {
     // ---- 2. trilinear coefficient tensors (lane = ordered index triple (i,j,k)), symmetrised into A ----
     {
         const int i = lane >> 4, j = (lane >> 2) & 3, k = lane & 3;
