@@ -303,6 +303,10 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
         return MLPL_E_BAD_INPUT;
     }
     const long long items = (long long)qgroups * nsplit * batch;
+    if (items > (1LL << 30)) {
+        set_error("knn_hamming: problem too large for one launch (nq=%d nt=%d batch=%d)", nq, nt, batch);
+        return MLPL_E_BAD_INPUT;
+    }
 
     void *qf = nullptr, *tf = nullptr, *part = nullptr;
     int rc;
