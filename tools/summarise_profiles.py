@@ -19,8 +19,8 @@ def short(name):
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(SRC, pattern))
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(SRC, pattern)), key=os.path.getmtime)  # gpurun merges runs into one tree: newest wins
+    return f[-1] if f else None
 
 
 # kernel stats of the default bench run
