@@ -206,18 +206,22 @@ def run(ctx, dev, cpu_baseline=True):
                                "note": "8192 keypoints per image, Hamming 2-NN + ratio, fused gather/ImgToCamCoordTrans, RANSAC "
                                        "(1000 iterations, 0.999, adaptive stop), getPoseTriangPts; sequential per pair, host API for "
                                        "the pose step"}
-    # the same 8 pairs with 4 pairs in flight (independent contexts, streams and host threads on this one GPU)
-    pw = batch.PairWorkers(dev.index or 0, workers=4)
-    try:
-        pw.process(dev_in, K, K, seeds=[100 + i for i in range(npairs)])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        reps = 4
-        for _ in range(reps):
-            recs4 = pw.process(dev_in, K, K, seeds=[100 + i for i in range(npairs)])
-        dt = (time.perf_counter() - t0) / reps
-    finally:
-        pw.close()
-    out["c5_pair_pipeline_4_in_flight"] = {"value": npairs / dt, "unit": "image-pairs/s (one GPU)", "ms_per_pair": dt / npairs * 1e3,
-                                           "same_records_as_sequential": bool(np.concatenate(recs).tobytes() == recs4.tobytes())}
+    # the same pairs (x2) with several pairs in flight (independent contexts, streams and host threads on this one GPU)
+    many = dev_in + dev_in
+    seeds = [100 + (i % npairs) for i in range(len(many))]
+    for workers in (4, 8):
+        pw = batch.PairWorkers(dev.index or 0, workers=workers)
+        try:
+            pw.process(many, K, K, seeds=seeds)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                recsw = pw.process(many, K, K, seeds=seeds)
+            dt = (time.perf_counter() - t0) / reps
+        finally:
+            pw.close()
+        same = bool(np.concatenate(recs).tobytes() == recsw[:npairs].tobytes())
+        out[f"c5_pair_pipeline_{workers}_in_flight"] = {"value": len(many) / dt, "unit": "image-pairs/s (one GPU)",
+                                                        "ms_per_pair": dt / len(many) * 1e3, "same_records_as_sequential": same}
     return out
