@@ -190,7 +190,8 @@ def run(ctx, dev, cpu_baseline=True):
     # ---- C5 unit: whole per-pair pipeline (8k ORB match -> gather -> RANSAC 1000 it/0.999 -> cheirality), device-resident ----
     from matchinglib_poselib_amd import batch
     npairs = 8
-    sps = [synth.stereo_pair(8192, seed=20260200 + i) for i in range(npairs)]
+    # 30-45 % of the queries have no true neighbour, so the number of matches (RANSAC's n) differs from pair to pair, as on real images
+    sps = [synth.stereo_pair(8192, seed=20260200 + i, unmatched_frac=0.30 + 0.02 * i) for i in range(npairs)]
     dev_in = [(torch.from_numpy(sp["desc1"]).to(dev), torch.from_numpy(sp["desc2"]).to(dev), torch.from_numpy(sp["kp1"]).to(dev),
                torch.from_numpy(sp["kp2"]).to(dev)) for sp in sps]
     K = sps[0]["K"]

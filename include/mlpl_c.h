@@ -63,7 +63,9 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  * 64 bytes fall back to 0), 0 = LDS-tiled VALU kernel, 1 = scalar-operand VALU kernel, 2 = one-wave-per-block VALU kernel;
  * "hamming_mfma_blocks_per_cu" (default 3) and "hamming_mfma_qt" (query tiles per wave, 0 = automatic) size the matrix-core
  * grid; "hamming_qpl" queries per lane 1|2 and "hamming_blocks_per_cu" size the VALU grids; "ransac_chunk" hypotheses per
- * device pass (0 = 32768; the sequential best/niters rule is replayed across passes). */
+ * device pass (0 = 32768; the sequential best/niters rule is replayed across passes); "ransac_host_table" 1 = build the
+ * iteration-bound table T[g] on the host for every call (default 0: the device evaluates the few bounds it needs and the host
+ * verifies exactly those against its libm, falling back to the table when one differs). */
 int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value);
 
 /* ---- in-library kernel timing (for roofline accounting) ------------------------------------------------------

@@ -68,10 +68,13 @@ struct mlpl_ctx {
     int opt_hamming_mfma_blocks_per_cu;  // grid sizing target of the matrix-core kernel (4-wave blocks)
     int opt_hamming_mfma_qt;             // query tiles per wave (0 = automatic, else 1, 2 or 4)
     int opt_ransac_chunk;           // hypotheses per device pass (0 = 32768)
+    int opt_ransac_host_table;      // 1 = always build the niters table on the host (default: evaluate on the device, verify)
     // cached table T[g] = cvRANSACUpdateNumIters1(conf, (n-g)/n, 5, inf) for the last (n, conf) (host libm values)
     int32_t *ransac_T_host;
     int ransac_T_n;
     double ransac_T_conf;
+    int ransac_force_table;        // 1 = build the host niters table (fallback / tests)
+    long long ransac_table_fallbacks;  // calls redone on the host table because a device-evaluated bound differed
     long long last_ransac_models, last_ransac_iters;  // statistics of the last mlpl_ransac_essential* call
     // optional per-kernel hipEvent bracketing (mlpl_profile_*)
     int prof_on;

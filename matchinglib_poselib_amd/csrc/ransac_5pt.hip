@@ -997,7 +997,29 @@ struct ReplayState {
     int32_t refit_models; // models produced by the refit step (-1 = refit not run)
     int32_t refit_taken;  // slot of the refit model taken, -1 = none
     long long models_scored;  // essential matrices scored over all passes (statistics)
+    // iteration bounds the replay evaluated ON THE DEVICE (no host table): (inlier count g, T(g)) per record-breaking count,
+    // verified by the host against its libm after the call (ransac driver); t_count > kTUsedMax = list overflow
+    int32_t t_count;
+    int32_t t_pad;
+    int32_t t_g[48];
+    int32_t t_val[48];
 };
+constexpr int kTUsedMax = 48;
+
+// cvRANSACUpdateNumIters1 (modelest.cpp:86-109) with max_iters = "infinity", evaluated on the device.  The host recomputes
+// every value the replay used with glibc and falls back to a host-built table if one differs (device log/pow are not glibc's,
+// so a quotient within an ulp-scale distance of x.5 could round the other way; that has probability ~1e-8 per value).
+__device__ __forceinline__ int dev_num_iters(double p, int n, int g) {
+    p = fmin(fmax(p, 0.), 1.);
+    double ep = (double)(n - g) / n;
+    ep = fmin(fmax(ep, 0.), 1.);
+    double num = fmax(1. - p, DBL_MIN);
+    double denom = 1. - pow(1. - ep, 5.0);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return (denom >= 0 || -num >= (double)INT32_MAX * (-denom)) ? INT32_MAX : (int)round(num / denom);
+}
 
 // Per-hypothesis arg-max under (good desc, error sum asc, slot asc): the only model of a hypothesis that can ever be taken.
 __global__ void hyp_best_kernel(const int32_t *__restrict__ n_models, const int32_t *__restrict__ good,
@@ -1025,7 +1047,8 @@ __global__ void hyp_best_kernel(const int32_t *__restrict__ n_models, const int3
 __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict__ hgood, const double *__restrict__ hsum,
                                                       const int32_t *__restrict__ hslot, const double *__restrict__ E_tab, int cnt,
                                                       const int32_t *__restrict__ Ttab, int npts, long long base_index,
-                                                      const int32_t *__restrict__ dense_total, ReplayState *__restrict__ st) {
+                                                      const int32_t *__restrict__ dense_total, ReplayState *__restrict__ st,
+                                                      double confidence) {
     __shared__ int wave_max_s[16];
     __shared__ int stop_idx;
     __shared__ int s_best_good[1024];
@@ -1057,8 +1080,22 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
             tot = max(tot, c);
         }
         const int running = max(pre, v);
+        const int up = __shfl_up(v, 1);
+        const int prev_running = lane ? max(pre, up) : pre;  // running count before this iteration
         if (i < cnt) {
-            const int nit = (running >= 5) ? min(niters0, Ttab[min(running, npts)]) : niters0;
+            int nit = niters0;
+            if (running >= 5) {
+                const int g = min(running, npts);
+                const int T = Ttab ? Ttab[g] : dev_num_iters(confidence, npts, g);
+                nit = min(niters0, T);
+                if (!Ttab && running > prev_running) {  // a new best count: remember the bound used for it
+                    const int slot = atomicAdd(&st->t_count, 1);
+                    if (slot < kTUsedMax) {
+                        st->t_g[slot] = g;
+                        st->t_val[slot] = T;
+                    }
+                }
+            }
             if (iter0 + i + 1 >= nit) atomicMin(&stop_idx, i);
         }
         carry = tot;
@@ -1114,7 +1151,9 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
             for (int k = 0; k < 9; ++k) st->E[k] = E_tab[(size_t)idx * 9 + k];
         }
         st->maxGood = newMax;
-        const int nit = (newMax >= 5) ? min(niters0, Ttab[min(newMax, npts)]) : niters0;
+        // newMax is a count pass 1 (or an earlier chunk) has already evaluated and recorded
+        const int nit = (newMax >= 5) ? min(niters0, Ttab ? Ttab[min(newMax, npts)] : dev_num_iters(confidence, npts, min(newMax, npts)))
+                                      : niters0;
         st->niters = nit;
         st->iter = iter0 + processed;
         st->stop = (iter0 + processed >= nit) ? 1 : 0;
@@ -1388,7 +1427,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     // small device block: replay state | niters table | refit scratch
     const int gblocks = std::max(1, std::min(256, (n + 255) / 256));
     void *dsm;
-    const size_t off_T = 256, off_refit = off_T + ((size_t)(n + 1) * 4 + 255) / 256 * 256;
+    const size_t off_T = 1024, off_refit = off_T + ((size_t)(n + 1) * 4 + 255) / 256 * 256;
     if ((rc = ws_get(ctx, WS_AUX2, off_refit + (144 + (size_t)gblocks * 45) * 8, &dsm))) return rc;
     ReplayState *d_st = (ReplayState *)dsm;
     int32_t *d_T = (int32_t *)((char *)dsm + off_T);
@@ -1396,22 +1435,31 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
 
     // pinned staging: samples up, state down
     void *pin;
-    if ((rc = pinned_get(ctx, (size_t)chunk_cap * 20 + (size_t)(n + 1) * 4 + 1024, &pin))) return rc;
+    if ((rc = pinned_get(ctx, (size_t)chunk_cap * 20 + (size_t)(n + 1) * 4 + 2048, &pin))) return rc;
+    static_assert(sizeof(ReplayState) <= 1024, "staging layout");
     ReplayState *h_st = (ReplayState *)pin;
-    int32_t *h_T = (int32_t *)((char *)pin + 512);
+    int32_t *h_T = (int32_t *)((char *)pin + 1024);
     int32_t *h_samples = h_T + (n + 1);
     int32_t *d_samples_mapped = nullptr;  // device view of the pinned sample table
     MLPL_HIP_TRY(hipHostGetDevicePointer((void **)&d_samples_mapped, h_samples, 0));
 
-    // T[g] = cvRANSACUpdateNumIters1(confidence, (n-g)/n, 5, "infinity")  (modelest.cpp:86-109, host libm)
-    if (ctx->ransac_T_n != n || ctx->ransac_T_conf != confidence || !ctx->ransac_T_host) {
-        delete[] ctx->ransac_T_host;
-        ctx->ransac_T_host = new int32_t[(size_t)n + 1];
-        for (int g = 0; g <= n; ++g) ctx->ransac_T_host[g] = update_num_iters(confidence, (double)(n - g) / n, 5, INT32_MAX);
-        ctx->ransac_T_n = n;
-        ctx->ransac_T_conf = confidence;
+    // T[g] = cvRANSACUpdateNumIters1(confidence, (n-g)/n, 5, "infinity")  (modelest.cpp:86-109).  The replay evaluates it on the
+    // device for the handful of counts it meets and the host checks exactly those values against its libm after the call; the
+    // full host table (n + 1 log/pow pairs, 0.3 ms at n = 8192 -- more than the rest of an adaptive call, and rebuilt whenever
+    // n changes, i.e. for every image pair) is only built when that check fails.
+    const bool use_table = ctx->ransac_force_table != 0 || ctx->opt_ransac_host_table != 0;
+    if (use_table) {
+        if (ctx->ransac_T_n != n || ctx->ransac_T_conf != confidence || !ctx->ransac_T_host) {
+            delete[] ctx->ransac_T_host;
+            ctx->ransac_T_host = new int32_t[(size_t)n + 1];
+            for (int g = 0; g <= n; ++g) ctx->ransac_T_host[g] = update_num_iters(confidence, (double)(n - g) / n, 5, INT32_MAX);
+            ctx->ransac_T_n = n;
+            ctx->ransac_T_conf = confidence;
+        }
+        std::memcpy(h_T, ctx->ransac_T_host, (size_t)(n + 1) * 4);
+    } else {
+        d_T = nullptr;
     }
-    std::memcpy(h_T, ctx->ransac_T_host, (size_t)(n + 1) * 4);
     ReplayState init;
     std::memset(&init, 0, sizeof(init));
     init.niters = max_iters;
@@ -1421,7 +1469,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     init.refit_taken = -1;
     *h_st = init;
     MLPL_HIP_TRY(hipMemcpyAsync(d_st, h_st, sizeof(ReplayState), hipMemcpyHostToDevice, s));
-    MLPL_HIP_TRY(hipMemcpyAsync(d_T, h_T, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
+    if (use_table) MLPL_HIP_TRY(hipMemcpyAsync(d_T, h_T, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
 
     GlibcRand rng;
     rng.seed(seed);
@@ -1454,7 +1502,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
                            (const int32_t *)B.good, (const double *)B.esum, cnt, B.hgood, B.hsum, B.hslot);
         hipLaunchKernelGGL(replay_kernel, dim3(1), dim3(1024), 0, s, (const int32_t *)B.hgood, (const double *)B.hsum,
                            (const int32_t *)B.hslot, (const double *)B.E_tab, cnt, (const int32_t *)d_T, n, (long long)base * 10,
-                           (const int32_t *)B.total, d_st);
+                           (const int32_t *)B.total, d_st, confidence);
         MLPL_HIP_TRY(hipGetLastError());
         if (base + chunk_cap < max_iters) {  // more chunks may follow: the host needs niters / stop to size the next one
             MLPL_HIP_TRY(hipMemcpyAsync(h_st, d_st, sizeof(ReplayState), hipMemcpyDeviceToHost, s));
@@ -1489,6 +1537,20 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     MLPL_HIP_TRY(hipMemcpyAsync(h_st, d_st, sizeof(ReplayState), hipMemcpyDeviceToHost, s));
     MLPL_HIP_TRY(hipStreamSynchronize(s));  // the single host hop of the call (per 32768-iteration chunk)
     const ReplayState fin = *h_st;
+    if (!use_table) {
+        // every iteration bound the device used must be what the CPU path's libm gives; otherwise redo the call on a host table
+        bool ok = fin.t_count <= kTUsedMax;
+        for (int i = 0; ok && i < fin.t_count; ++i)
+            ok = fin.t_val[i] == update_num_iters(confidence, (double)(n - fin.t_g[i]) / n, 5, INT32_MAX);
+        if (!ok) {
+            ctx->ransac_force_table = 1;
+            const int rc2 = mlpl_ransac_essential_dev(ctx, d_p1, d_p2, n, thresh, confidence, max_iters, refit, seed, E, d_mask, n_inliers,
+                                                      iters_used, stream);
+            ctx->ransac_force_table = 0;
+            ctx->ransac_table_fallbacks++;
+            return rc2;
+        }
+    }
     ctx->last_ransac_models = fin.models_scored;
     ctx->last_ransac_iters = fin.iter;
     if (iters_used) *iters_used = fin.iter;

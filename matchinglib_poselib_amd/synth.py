@@ -81,7 +81,7 @@ def pose_scene(n: int = 5000, inlier_frac: float = 0.5, seed: int = 20260103, no
 
 
 def stereo_pair(n: int = 2000, seed: int = 20260200, inlier_frac: float = 0.5, f: float = 800.0, cx: float = 320.0,
-                cy: float = 240.0, nbytes: int = 32, flip_p: float = 0.04):
+                cy: float = 240.0, nbytes: int = 32, flip_p: float = 0.04, unmatched_frac: float = 0.0):
     """One synthetic image pair for the whole pipeline (C5 unit): keypoints in pixels (float32), binary descriptors whose
     nearest neighbours are the true correspondences (train side shuffled), and the ground-truth pose.
     Returns dict(desc1, desc2, kp1, kp2, K, R, t, train_of_query)."""
@@ -95,5 +95,8 @@ def stereo_pair(n: int = 2000, seed: int = 20260200, inlier_frac: float = 0.5, f
     d2 = rng.integers(0, 256, size=(n, nbytes), dtype=np.uint8)
     flips = np.packbits(rng.random((n, nbytes * 8)) < flip_p, axis=1, bitorder="little")
     d1 = d2[perm] ^ flips
+    if unmatched_frac > 0:  # queries without a true neighbour: they fail the ratio test, so the match count varies with the seed
+        lost = rng.random(n) < unmatched_frac
+        d1[lost] = rng.integers(0, 256, size=(int(lost.sum()), nbytes), dtype=np.uint8)
     K = np.array([f, f, cx, cy], np.float64)
     return dict(desc1=d1, desc2=d2, kp1=kp1, kp2=kp2, K=K, R=R, t=t, train_of_query=perm.astype(np.int32))

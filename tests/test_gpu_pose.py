@@ -283,3 +283,19 @@ def test_recover_pose_device_variant_equals_host_api(ctx, oracle):
     # no mask, no Q
     ng2, R2, t2 = pose.getPoseTriangPts_device(E, d1, d2, ctx=ctx)
     assert ng2 == oracle.recover_pose(E, p1, p2, 50.0, None)[0]
+
+
+@pytest.mark.parametrize("n", [5000, 4321, 777])
+def test_ransac_device_iteration_bounds_equal_host_table(ctx, oracle, n):
+    """The adaptive iteration bound is evaluated on the device and verified by the host; forcing the host table must give the
+    same iteration count, model and mask -- and both equal the oracle (varying n: the table would be rebuilt per call)."""
+    p1, p2, R, t, mask, th = synth.pose_scene(n, seed=500 + n)
+    ctx.set_option("ransac_host_table", 1)
+    try:
+        a = pose.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, refit=False, seed=n, ctx=ctx)
+    finally:
+        ctx.set_option("ransac_host_table", 0)
+    b = pose.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, refit=False, seed=n, ctx=ctx)
+    o = oracle.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, lesqu=False, seed=n)
+    assert a["iters"] == b["iters"] == o["iters"] and a["n_inliers"] == b["n_inliers"] == o["n_inliers"]
+    assert np.array_equal(a["E"], b["E"]) and np.array_equal(a["mask"], b["mask"]) and np.array_equal(b["mask"], o["mask"])

@@ -12,7 +12,7 @@ from matchinglib_poselib_amd import batch, synth  # noqa: E402
 
 ctx = mpa.Context(0)
 dev = torch.device("cuda:0")
-sps = [synth.stereo_pair(8192, seed=20260200 + i) for i in range(4)]
+sps = [synth.stereo_pair(8192, seed=20260200 + i, unmatched_frac=0.30 + 0.02 * i) for i in range(4)]
 ins = [tuple(torch.from_numpy(sp[k]).to(dev) for k in ("desc1", "desc2", "kp1", "kp2")) for sp in sps]
 K = sps[0]["K"]
 scratch = {}
