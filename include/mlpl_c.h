@@ -209,6 +209,21 @@ int mlpl_lmeds_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int 
 int mlpl_lmeds_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double confidence, int max_iters,
                              uint32_t seed, double E[9], uint8_t *d_mask, int *n_inliers, double *min_median, void *stream);
 
+/*
+ * One image pair through the whole hot path, device-resident (the per-pair body of the reference harness loop,
+ * tests/poselib-test/main.cpp:1440-2072, and of StereoRefine's first call): Hamming 2-NN + 0.75 ratio test -> gather of the matched
+ * keypoints with ImgToCamCoordTrans -> RANSAC essential matrix -> cheirality.  d_q/d_t: dense nq/nt x nbytes descriptors,
+ * d_kp1/d_kp2: (x, y) float pixel coordinates per keypoint, K = {fx, fy, cx, cy}, thresh in camera units.  Two host hops.
+ * status: 0 = pose found, -1 = fewer than 16 matches, -2 = RANSAC found no model.
+ */
+typedef struct {
+    int32_t n_matches, n_inliers, n_good, status, iters, pad;
+    double E[9], R[9], t[3];
+} mlpl_pair_result;
+int mlpl_pair_pose_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
+                       const float *d_kp2, const double K0[4], const double K1[4], double thresh, int max_iters, double confidence,
+                       int refit, uint32_t seed, double dist, mlpl_pair_result *out, void *stream);
+
 /* Building blocks, exposed for parity tests and for callers that schedule the phases themselves. */
 /* 5-point minimal solver, one wavefront per sample: samples = n_samples x 5 indices into p1/p2 (host).
  * E_out: n_samples x 10 x 9 doubles, n_models: n_samples ints (host). Replaces run5Point (five-point.cpp:366-471). */

@@ -58,43 +58,38 @@ def gather_records(local: np.ndarray, num_pairs: int, rank: int, world: int, dev
     return rec
 
 
+class _PairResult(C.Structure):
+    _fields_ = [("n_matches", C.c_int32), ("n_inliers", C.c_int32), ("n_good", C.c_int32), ("status", C.c_int32), ("iters", C.c_int32),
+                ("pad", C.c_int32), ("E", C.c_double * 9), ("R", C.c_double * 9), ("t", C.c_double * 3)]
+
+
 def process_pair_on_device(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, th_pix: float = 0.8, max_iters: int = 1000,
                            confidence: float = 0.999, refit: bool = False, seed: int = 0, dist: float = 50.0, pair_id: int = 0,
                            scratch: Optional[dict] = None) -> np.ndarray:
     """One image pair, device-resident inputs (torch CUDA tensors): Hamming 2-NN + ratio -> gather matched keypoints
-    (ImgToCamCoordTrans) -> RANSAC essential matrix -> cheirality.  Returns one RECORD_DTYPE record."""
+    (ImgToCamCoordTrans) -> RANSAC essential matrix -> cheirality, in one library call (mlpl_pair_pose_dev: two host hops,
+    nothing else leaves the device).  Returns one RECORD_DTYPE record.  `scratch` is accepted for compatibility and unused."""
     import torch
-    from .matching import match_hamming_device
-    from . import pose
 
+    assert d_q.is_cuda and d_q.dtype == torch.uint8 and d_q.is_contiguous() and d_t.is_contiguous()
+    assert d_kp1.dtype == torch.float32 and d_kp2.dtype == torch.float32 and d_kp1.is_contiguous() and d_kp2.is_contiguous()
     rec = np.zeros(1, RECORD_DTYPE)
     rec["pair_id"] = pair_id
-    out = match_hamming_device(d_q, d_t, ctx=ctx, out=None if scratch is None else scratch.get("match"))
-    if scratch is not None:
-        scratch["match"] = out
-    n = int(out["count"][0].item())  # the only host hop before RANSAC: the match count sizes the next launches
-    rec["n_matches"] = n
-    if n < 16:
-        rec["status"] = -1
-        return rec
-    dev = d_q.device
-    p1 = torch.empty((n, 2), dtype=torch.float64, device=dev)
-    p2 = torch.empty((n, 2), dtype=torch.float64, device=dev)
     k0 = (C.c_double * 4)(*K0)
     k1 = (C.c_double * 4)(*K1)
-    st = torch.cuda.current_stream(dev).cuda_stream
-    check(ctx.lib.mlpl_gather_match_points_dev(ctx.handle, out["matches"].data_ptr(), n, d_kp1.data_ptr(), d_kp2.data_ptr(),
-                                               k0, k1, p1.data_ptr(), p2.data_ptr(), st), "mlpl_gather_match_points_dev")
     th = th_pix * 4.0 / (np.sqrt(2.0) * (K0[0] + K0[1] + K1[0] + K1[1]))  # stereo_pose_refinement.h:280-286
-    r = pose.ransac_essential_device(p1, p2, th, confidence=confidence, max_iters=max_iters, refit=refit, seed=seed, ctx=ctx)
-    if not r["ok"]:
-        rec["status"] = -2
-        return rec
-    rec["n_inliers"] = r["n_inliers"]
-    rec["E"] = r["E"].reshape(-1)
-    n_good, R, t = pose.getPoseTriangPts_device(r["E"], p1, p2, r["mask"], dist, ctx=ctx)  # points and mask stay on the device
-    rec["R"] = R.reshape(-1)
-    rec["t"] = t.reshape(-1)
+    res = _PairResult()
+    st = torch.cuda.current_stream(d_q.device).cuda_stream
+    check(ctx.lib.mlpl_pair_pose_dev(ctx.handle, d_q.data_ptr(), d_q.shape[0], d_t.data_ptr(), d_t.shape[0], d_q.shape[1],
+                                     d_kp1.data_ptr(), d_kp2.data_ptr(), k0, k1, float(th), int(max_iters), float(confidence),
+                                     1 if refit else 0, int(seed) & 0xFFFFFFFF, float(dist), C.addressof(res), st), "mlpl_pair_pose_dev")
+    rec["n_matches"] = res.n_matches
+    rec["status"] = res.status
+    if res.status == 0:
+        rec["n_inliers"] = res.n_inliers
+        rec["E"] = np.frombuffer(res.E, np.float64)
+        rec["R"] = np.frombuffer(res.R, np.float64)
+        rec["t"] = np.frombuffer(res.t, np.float64)
     return rec
 
 

@@ -44,6 +44,7 @@ enum WsSlot {
     WS_L2_FLAG,   // device gate flag of the L2 auto path
     WS_FRAG_Q,    // fp4 MFMA fragments of the query / train descriptors (knn_hamming_mfma.hip)
     WS_FRAG_T,
+    WS_PIPE,      // per-pair pipeline block (mlpl_pair_pose_dev)
     WS_NUM_SLOTS
 };
 
