@@ -305,6 +305,89 @@ void run_group(const uint4 *src, float *out, int wps) {
     delete[] h;
 }
 
+// Barrier-free LDS sharing: each of the 4 waves of a workgroup stages ITS K-step piece of every tile (one ordinary
+// global_load_dwordx4, prefetched one tile ahead, then ds_write_b128) into a ring of NB slots; per-slot LDS counters say
+// "all four pieces of tile i have landed" (ready) and "all four waves have read tile i" (done).  Waves drift up to NB - 1 tiles
+// apart; nobody waits at a barrier.  Spins are bounded (a protocol error must not hang the GPU).
+template <int QT>
+__global__ __launch_bounds__(256, 4) void flagk(const uint4 *src, float *out, int iters, long long *cyc) {
+    constexpr int NB = 4;
+    __shared__ uint4 ring[NB * 256];
+    __shared__ unsigned ready[NB], done[NB];
+    const int l = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < NB) ready[threadIdx.x] = 0, done[threadIdx.x] = 0;
+    __syncthreads();
+    uint4 b[QT][4];
+    for (int t = 0; t < QT; ++t)
+        for (int s = 0; s < 4; ++s) b[t][s] = src[l + 64 * (4 + 4 * t + s)];
+    v16f cinit;
+    for (int i = 0; i < 16; ++i) cinit[i] = -(float)i * (1.0f / 16384.0f);
+    float m1[QT], m2[QT];
+    for (int t = 0; t < QT; ++t) m1[t] = m2[t] = -1e30f;
+    volatile unsigned *vready = ready, *vdone = done;
+    int bad = 0;
+    long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    uint4 staged = src[w * 64 + l];  // my piece of tile 0
+    for (int it = 0; it < iters; ++it) {
+        const int slot = it & (NB - 1);
+        const unsigned round = (unsigned)(it / NB);
+        // WAR: slot is free once all four waves have read the tile that lived there NB tiles ago
+        if (it >= NB) {
+            int spins = 0;
+            while (vdone[slot] < 4u * round && ++spins < (1 << 16)) {}
+            bad |= spins >= (1 << 16);
+        }
+        ring[slot * 256 + w * 64 + l] = staged;                       // ds_write_b128 of my piece
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (l == 0) atomicAdd(&ready[slot], 1u);
+        staged = src[(((it + 1) & 3) * 256) + w * 64 + l];            // prefetch my piece of the next tile
+        {
+            int spins = 0;
+            while (vready[slot] < 4u * (round + 1) && ++spins < (1 << 16)) {}
+            bad |= spins >= (1 << 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        uint4 a[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[s] = ring[slot * 256 + s * 64 + l];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            v16f acc = mf(a[0], b[t][0], cinit);
+#pragma unroll
+            for (int s = 1; s < 4; ++s) acc = mf(a[s], b[t][s], acc);
+            update(m1[t], m2[t], acc);
+        }
+        if (l == 0) atomicAdd(&done[slot], 1u);  // my reads of this slot were consumed by the MFMAs above
+    }
+    long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        const int wi = blockIdx.x * 4 + (threadIdx.x >> 6);
+        cyc[2 * wi] = t1 - t0;
+        cyc[2 * wi + 1] = r1 - r0;
+    }
+    float sres = (float)bad;
+    for (int t = 0; t < QT; ++t) sres += m1[t] + m2[t];
+    out[(blockIdx.x * blockDim.x + threadIdx.x) & 16383] = sres + staged.x;
+}
+
+template <int QT>
+void run_flag(const uint4 *src, float *out, int wps) {
+    long long *dc;
+    const int blocks = 256 * wps, waves = blocks * 4, iters = 1024;
+    hipMalloc(&dc, waves * 16);
+    hipLaunchKernelGGL((flagk<QT>), dim3(blocks), dim3(256), 0, 0, src, out, iters, dc);
+    long long *h = new long long[waves * 2];
+    hipMemcpy(h, dc, waves * 16, hipMemcpyDeviceToHost);
+    double cs = 0, rs = 0;
+    for (int i = 0; i < waves; ++i) cs += h[2 * i], rs += h[2 * i + 1];
+    const double per_wave_unit = cs / waves / (iters * (double)QT);
+    printf("LDS sharing with ready/done counters (no barrier), QT=%d, %d blocks of 4 waves per CU: %.3f GHz, %.1f cycles per unit per wave -> %.1f per SIMD\n",
+           QT, wps, cs / rs * 0.1, per_wave_unit, per_wave_unit / wps);
+    hipFree(dc);
+    delete[] h;
+}
+
 int main() {
     uint4 *src;
     float *out;
@@ -335,5 +418,9 @@ int main() {
         run_group<4>(src, out, wps);
     }
     run_group<8>(src, out, 2);
+    for (int wps : {3, 4}) {
+        run_flag<4>(src, out, wps);
+        run_flag<3>(src, out, wps);
+    }
     return 0;
 }
