@@ -63,7 +63,9 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  * 64 bytes fall back to 0), 0 = LDS-tiled VALU kernel, 1 = scalar-operand VALU kernel, 2 = one-wave-per-block VALU kernel;
  * "hamming_mfma_blocks_per_cu" (default 3) and "hamming_mfma_qt" (query tiles per wave, 0 = automatic) size the matrix-core
  * grid; "hamming_qpl" queries per lane 1|2 and "hamming_blocks_per_cu" size the VALU grids; "ransac_chunk" hypotheses per
- * device pass (0 = 32768; the sequential best/niters rule is replayed across passes); "ransac_host_table" 1 = build the
+ * device pass (0 = 32768; the sequential best/niters rule is replayed across passes); "ransac_lazy_sums" (default 1) = the RANSAC passes count inliers
+ * without the division and compute error sums only for the models that can still win, 0 = sums for every model;
+ * "ransac_host_table" 1 = build the
  * iteration-bound table T[g] on the host for every call (default 0: the device evaluates the few bounds it needs and the host
  * verifies exactly those against its libm, falling back to the table when one differs). */
 int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value);
@@ -233,6 +235,12 @@ int mlpl_solve_5pt(mlpl_ctx *ctx, const double *p1, const double *p2, int n, con
  * err_sum[i] = sum of the float-rounded errors (findInliers + cv::sum(err), modelest.cpp:69-83,407). */
 int mlpl_score_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const double *E, int n_models,
                       double thresh, int32_t *count, double *err_sum);
+
+/* Inlier counts only, by the division-free predicate the RANSAC passes use (exactly (double)(float)(N / D) <= thresh2, see
+ * sampson_inlier in ransac_5pt.hip); thresh2 is the SQUARED threshold as the reference holds it (modelest.cpp:79).
+ * shape: 0 = automatic, 1 = 4-lanes-per-model kernel, 2 = block-per-model kernel (for tests). */
+int mlpl_count_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const double *E, int n_models, double thresh2, int shape,
+                      int32_t *count);
 
 /* Median of the float Sampson errors per model, as runLMeDS takes it (modelest.cpp:540-544: errors sorted as int bit patterns;
  * even n: float sum of the two middle values * 0.5).  median: n_models doubles (host). */

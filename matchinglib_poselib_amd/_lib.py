@@ -80,6 +80,7 @@ _SIGNATURES = {
     "mlpl_img_to_cam": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "mlpl_remove_lens_dist": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.POINTER(c_int)]),
     "mlpl_get_inliers_strict": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_double, c_void_p, c_void_p]),
+    "mlpl_count_models": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_double, c_int, c_void_p]),
     "mlpl_median_models": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "mlpl_lmeds_essential": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_u32, c_void_p, c_void_p, c_void_p,
                                      c_void_p]),

@@ -542,8 +542,9 @@ __global__ void pack_points_kernel(const double *__restrict__ p1, const double *
     if (i < n) pts[i] = make_double4(p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
 }
 
-__device__ __forceinline__ float sampson_err_f32(const double *e, double x1, double y1, double x2, double y2) {
-    // computeReprojError3 (five-point.cpp:490-502): k-ordered 3-term sums, no contraction, double -> float
+// computeReprojError3 (five-point.cpp:490-502): numerator and denominator of the Sampson error in the reference's operation
+// order (k-ordered 3-term sums, no contraction); err = (float)(N / D).
+__device__ __forceinline__ void sampson_nd(const double *e, double x1, double y1, double x2, double y2, double &N, double &D) {
     const double Ex1_0 = __dadd_rn(__dadd_rn(__dmul_rn(e[0], x1), __dmul_rn(e[1], y1)), e[2]);
     const double Ex1_1 = __dadd_rn(__dadd_rn(__dmul_rn(e[3], x1), __dmul_rn(e[4], y1)), e[5]);
     const double Ex1_2 = __dadd_rn(__dadd_rn(__dmul_rn(e[6], x1), __dmul_rn(e[7], y1)), e[8]);
@@ -551,17 +552,42 @@ __device__ __forceinline__ float sampson_err_f32(const double *e, double x1, dou
     const double Etx2_0 = __dadd_rn(__dadd_rn(__dmul_rn(e[0], x2), __dmul_rn(e[3], y2)), e[6]);
     const double Etx2_1 = __dadd_rn(__dadd_rn(__dmul_rn(e[1], x2), __dmul_rn(e[4], y2)), e[7]);
     const double a = __dmul_rn(Ex1_0, Ex1_0), b = __dmul_rn(Ex1_1, Ex1_1), c = __dmul_rn(Etx2_0, Etx2_0), d = __dmul_rn(Etx2_1, Etx2_1);
-    const double den = __dadd_rn(__dadd_rn(__dadd_rn(a, b), c), d);
-    return (float)__ddiv_rn(__dmul_rn(x2tEx1, x2tEx1), den);
+    D = __dadd_rn(__dadd_rn(__dadd_rn(a, b), c), d);
+    N = __dmul_rn(x2tEx1, x2tEx1);
+}
+
+__device__ __forceinline__ float sampson_err_f32(const double *e, double x1, double y1, double x2, double y2) {
+    double N, D;
+    sampson_nd(e, x1, y1, x2, y2, N, D);
+    return (float)__ddiv_rn(N, D);
+}
+
+// findInliers' predicate  (double)(float)(N / D) <= thresh^2  (modelest.cpp:79-81) WITHOUT the division.
+// Let f* be the largest float <= thresh^2 and qmax the largest DOUBLE whose float rounding is <= f* (the midpoint above f*, or its
+// predecessor when ties-to-even would round the midpoint up): the predicate is  RN64(N / D) <= qmax,  i.e.  N / D < M  (or = M on an
+// even tie) with M = qmax + half an ulp.  With p = RN64(qmax * D):  M * D lies in (p - ulp(p)/2, p + 1.6 ulp(p)), so
+//     N < p             =>  inlier         (N <= pred(p) <= p - ulp(p)/2 < M * D)
+//     N > p (1 + 2^-50) =>  outlier        (N > p + 4 ulp(p) > M * D)
+// and only for N within four ulps of p -- probability ~2^-50 per correspondence -- the reference arithmetic itself decides.
+// qmax comes from the host (inlier_bound()).  D below 1e-200 (degenerate model or point) also takes the reference arithmetic.
+__device__ __forceinline__ bool sampson_inlier(double N, double D, double qmax, double thresh2) {
+    const double p = __dmul_rn(qmax, D);
+    const bool safe = D >= 1e-200;
+    if (safe && N < p) return true;
+    if (safe && N > __dmul_rn(p, 1.0 + 0x1p-50)) return false;
+    return (double)(float)__ddiv_rn(N, D) <= thresh2;
 }
 
 // 4 lanes per model (lane j takes the correspondences i = j mod 4, in order), 64 models per 256-thread block; the
 // correspondences go through LDS in tiles of 512.  The float errors are accumulated in double per lane and combined as
 // (s0 + s2) + (s1 + s3): four interleaved accumulators, the shape of an SSE2 cv::sum over CV_32F.
+// SUMS = false: inlier counts only (no division, no float rounding, no sum): the RANSAC passes, whose error sums are computed
+// afterwards for the few models that can still win (candidate_kernel / esum_models_kernel).
 constexpr int kScoreTile = 512;
+template <bool SUMS>
 __global__ __launch_bounds__(256) void score_models_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
                                                            const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
-                                                           int total_host, double thresh2, int32_t *__restrict__ good,
+                                                           int total_host, double thresh2, double qmax, int32_t *__restrict__ good,
                                                            double *__restrict__ esum) {
     __shared__ double4 tile[kScoreTile];
     const int total = total_ptr ? *total_ptr : total_host;
@@ -584,9 +610,15 @@ __global__ __launch_bounds__(256) void score_models_kernel(const double4 *__rest
 #pragma unroll 4
             for (int i = j; i < rows; i += 4) {
                 const double4 p = tile[i];
-                const float err = sampson_err_f32(e, p.x, p.y, p.z, p.w);
-                cnt += ((double)err <= thresh2) ? 1 : 0;
-                s = __dadd_rn(s, (double)err);
+                if constexpr (SUMS) {
+                    const float err = sampson_err_f32(e, p.x, p.y, p.z, p.w);
+                    cnt += ((double)err <= thresh2) ? 1 : 0;
+                    s = __dadd_rn(s, (double)err);
+                } else {
+                    double N, D;
+                    sampson_nd(e, p.x, p.y, p.z, p.w, N, D);
+                    cnt += sampson_inlier(N, D, qmax, thresh2) ? 1 : 0;
+                }
             }
         }
     }
@@ -598,7 +630,7 @@ __global__ __launch_bounds__(256) void score_models_kernel(const double4 *__rest
     if (live && j == 0) {
         const int o = ids ? ids[m] : m;
         good[o] = cnt;
-        esum[o] = __dadd_rn(__dadd_rn(s0, s2), __dadd_rn(s1, s3));
+        if constexpr (SUMS) esum[o] = __dadd_rn(__dadd_rn(s0, s2), __dadd_rn(s1, s3));
     }
 }
 
@@ -609,51 +641,117 @@ __global__ __launch_bounds__(256) void score_models_kernel(const double4 *__rest
 // DEFINED by its order (four interleaved double accumulators, element i -> accumulator i mod 4, combined as (s0+s2)+(s1+s3)):
 // lane 0 reads four consecutive errors per ds_read_b128 and keeps the four chains in flight.  Same counts, same sums, bit for bit.
 constexpr int kScoreBlockMaxN = 16384;  // floats of (dynamic) LDS per block: 4 n bytes, up to 64 KiB
+// COUNT: write inlier counts; SUMS: write error sums (needs the n-float LDS buffer).  `pick` != NULL: the models to process are
+// E_list[pick[c]] for c < total (candidate ids; outputs indexed by the id), else E_list[c] (outputs through `ids`).
+template <bool COUNT, bool SUMS>
 __global__ __launch_bounds__(256) void score_models_block_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
                                                                  const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
-                                                                 int total_host, double thresh2, int32_t *__restrict__ good,
-                                                                 double *__restrict__ esum) {
-    extern __shared__ __attribute__((aligned(16))) float errs[];  // n floats
+                                                                 int total_host, double thresh2, double qmax, int32_t *__restrict__ good,
+                                                                 double *__restrict__ esum, const int32_t *__restrict__ pick) {
+    extern __shared__ __attribute__((aligned(16))) float errs[];  // n floats when SUMS
     __shared__ int wave_cnt[4];
-    const int m = blockIdx.x;
-    if (m >= (total_ptr ? *total_ptr : total_host)) return;  // block-uniform
+    const int total = total_ptr ? *total_ptr : total_host;
     const int tid = threadIdx.x;
-    double e[9];
+    for (int c = blockIdx.x; c < total; c += gridDim.x) {  // block-uniform loop
+        const int m = pick ? pick[c] : c;
+        const int o = pick ? m : (ids ? ids[m] : m);
+        double e[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) e[k] = E_list[(size_t)m * 9 + k];
-    int cnt = 0;
-    for (int i = tid; i < n; i += 256) {
-        const double4 p = pts[i];
-        const float err = sampson_err_f32(e, p.x, p.y, p.z, p.w);
-        errs[i] = err;
-        cnt += ((double)err <= thresh2) ? 1 : 0;
+        for (int k = 0; k < 9; ++k) e[k] = E_list[(size_t)m * 9 + k];
+        int cnt = 0;
+        for (int i = tid; i < n; i += 256) {
+            const double4 p = pts[i];
+            if constexpr (SUMS) {
+                const float err = sampson_err_f32(e, p.x, p.y, p.z, p.w);
+                errs[i] = err;
+                if constexpr (COUNT) cnt += ((double)err <= thresh2) ? 1 : 0;
+            } else {
+                double N, D;
+                sampson_nd(e, p.x, p.y, p.z, p.w, N, D);
+                cnt += sampson_inlier(N, D, qmax, thresh2) ? 1 : 0;
+            }
+        }
+        if constexpr (COUNT) {
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+            if ((tid & 63) == 0) wave_cnt[tid >> 6] = cnt;
+        }
+        __syncthreads();
+        if constexpr (COUNT) {
+            if (tid == 0) good[o] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        }
+        if constexpr (SUMS) {
+            if (tid < 4) {  // lane j = accumulator j: elements j, j + 4, ... in order; eight reads in flight per chain step
+                double sacc = 0;
+                int i = tid;
+                for (; i + 28 < n; i += 32) {
+                    const float v0 = errs[i], v1 = errs[i + 4], v2 = errs[i + 8], v3 = errs[i + 12], v4 = errs[i + 16], v5 = errs[i + 20],
+                                v6 = errs[i + 24], v7 = errs[i + 28];
+                    sacc = __dadd_rn(sacc, (double)v0);
+                    sacc = __dadd_rn(sacc, (double)v1);
+                    sacc = __dadd_rn(sacc, (double)v2);
+                    sacc = __dadd_rn(sacc, (double)v3);
+                    sacc = __dadd_rn(sacc, (double)v4);
+                    sacc = __dadd_rn(sacc, (double)v5);
+                    sacc = __dadd_rn(sacc, (double)v6);
+                    sacc = __dadd_rn(sacc, (double)v7);
+                }
+                for (; i < n; i += 4) sacc = __dadd_rn(sacc, (double)errs[i]);
+                const double s0 = __shfl(sacc, 0), s1 = __shfl(sacc, 1), s2 = __shfl(sacc, 2), s3 = __shfl(sacc, 3);
+                if (tid == 0) esum[o] = __dadd_rn(__dadd_rn(s0, s2), __dadd_rn(s1, s3));
+            }
+        }
+        __syncthreads();  // errs / wave_cnt are reused by the next model of this block
     }
+}
+
+// Which models can still win (modelest.cpp:377-416)?  The replay takes a hypothesis only if its best count beats, or ties, the
+// best count of everything before it (a tie is decided by the error sums), so error sums are needed only for the models that
+// hold their hypothesis' top count where that count is >= 5 and >= the running maximum before the hypothesis (incl. the count
+// carried over from earlier passes).  One block: max-scan over the hypotheses in iteration order, candidates appended to a list.
+__global__ void hyp_max_kernel(const int32_t *__restrict__ n_models, const int32_t *__restrict__ good, int cnt,
+                               int32_t *__restrict__ hmax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const int nm = n_models[i];
+    int h = 0;
+    for (int m = 0; m < nm; ++m) h = max(h, good[(size_t)i * 10 + m]);
+    hmax[i] = h;
+}
+
+__global__ __launch_bounds__(1024) void candidate_kernel(const int32_t *__restrict__ n_models, const int32_t *__restrict__ good,
+                                                         const int32_t *__restrict__ hmax_in, int cnt, int carried_best,
+                                                         int32_t *__restrict__ cand, int32_t *__restrict__ cand_count) {
+    __shared__ int wave_max_s[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int carry = carried_best;
+    for (int base = 0; base < cnt; base += 1024) {
+        const int i = base + tid;
+        const int hmax = (i < cnt) ? hmax_in[i] : 0;
+        int v = hmax;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
-    if ((tid & 63) == 0) wave_cnt[tid >> 6] = cnt;
-    __syncthreads();
-    if (tid < 4) {  // lane j = accumulator j: elements j, j + 4, ... in order; eight reads in flight per chain step
-        double sacc = 0;
-        int i = tid;
-        for (; i + 28 < n; i += 32) {
-            const float v0 = errs[i], v1 = errs[i + 4], v2 = errs[i + 8], v3 = errs[i + 12], v4 = errs[i + 16], v5 = errs[i + 20],
-                        v6 = errs[i + 24], v7 = errs[i + 28];
-            sacc = __dadd_rn(sacc, (double)v0);
-            sacc = __dadd_rn(sacc, (double)v1);
-            sacc = __dadd_rn(sacc, (double)v2);
-            sacc = __dadd_rn(sacc, (double)v3);
-            sacc = __dadd_rn(sacc, (double)v4);
-            sacc = __dadd_rn(sacc, (double)v5);
-            sacc = __dadd_rn(sacc, (double)v6);
-            sacc = __dadd_rn(sacc, (double)v7);
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(v, off);
+            if (lane >= off) v = max(v, o);
         }
-        for (; i < n; i += 4) sacc = __dadd_rn(sacc, (double)errs[i]);
-        const double s0 = __shfl(sacc, 0), s1 = __shfl(sacc, 1), s2 = __shfl(sacc, 2), s3 = __shfl(sacc, 3);
-        if (tid == 0) {
-            const int o = ids ? ids[m] : m;
-            good[o] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-            esum[o] = __dadd_rn(__dadd_rn(s0, s2), __dadd_rn(s1, s3));
+        const int up = __shfl_up(v, 1);
+        if (lane == 63) wave_max_s[wave] = v;
+        __syncthreads();
+        int pre = carry, tot = carry;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = wave_max_s[w];
+            if (w < wave) pre = max(pre, c);
+            tot = max(tot, c);
         }
+        const int before = lane ? max(pre, up) : pre;  // best count of everything before hypothesis i
+        if (i < cnt && hmax >= 5 && hmax >= before) {
+            const int nm = n_models[i];
+            for (int m = 0; m < nm; ++m)
+                if (good[(size_t)i * 10 + m] == hmax) cand[atomicAdd(cand_count, 1)] = i * 10 + m;
+        }
+        carry = tot;
+        __syncthreads();
     }
 }
 
@@ -1049,7 +1147,7 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
                                                       const int32_t *__restrict__ Ttab, int npts, long long base_index,
                                                       const int32_t *__restrict__ dense_total, ReplayState *__restrict__ st,
                                                       double confidence) {
-    __shared__ int wave_max_s[16];
+    __shared__ int wave_max_s[16], wave_min_s[16];
     __shared__ int stop_idx;
     __shared__ int s_best_good[1024];
     __shared__ double s_best_sum[1024];
@@ -1061,7 +1159,7 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
 
     // pass 1: running best count (inclusive prefix max in iteration order), niters after each iteration, first iteration
     // after which the loop ends.  1024 iterations per step, coalesced.
-    int carry = maxGood0;
+    int carry = maxGood0, carry_T = INT32_MAX;
     for (int base = 0; base < cnt; base += 1024) {
         const int i = base + tid;
         int v = (i < cnt) ? hgood[i] : 0;
@@ -1082,22 +1180,41 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
         const int running = max(pre, v);
         const int up = __shfl_up(v, 1);
         const int prev_running = lane ? max(pre, up) : pre;  // running count before this iteration
-        if (i < cnt) {
-            int nit = niters0;
-            if (running >= 5) {
-                const int g = min(running, npts);
-                const int T = Ttab ? Ttab[g] : dev_num_iters(confidence, npts, g);
-                nit = min(niters0, T);
-                if (!Ttab && running > prev_running) {  // a new best count: remember the bound used for it
-                    const int slot = atomicAdd(&st->t_count, 1);
-                    if (slot < kTUsedMax) {
-                        st->t_g[slot] = g;
-                        st->t_val[slot] = T;
-                    }
+        // The bound after iteration i is min(niters0, T(running_i)).  T falls as the count rises and the running count never
+        // falls, so T(running_i) = min over the record-breaking iterations j <= i of T(running_j): evaluate T only where the
+        // running count changes (a few lanes per pass -- log/pow in fp64 for every lane doubled this kernel's time) and take
+        // an inclusive min-scan.  The count carried in from earlier passes is already inside niters0.
+        int Tv = INT32_MAX;
+        if (i < cnt && running >= 5 && running > prev_running) {
+            const int g = min(running, npts);
+            Tv = Ttab ? Ttab[g] : dev_num_iters(confidence, npts, g);
+            if (!Ttab) {  // remember the bound used for this count: the host re-evaluates it with its libm
+                const int slot = atomicAdd(&st->t_count, 1);
+                if (slot < kTUsedMax) {
+                    st->t_g[slot] = g;
+                    st->t_val[slot] = Tv;
                 }
             }
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {  // inclusive min-scan inside the wave
+            const int o = __shfl_up(Tv, off);
+            if (lane >= off) Tv = min(Tv, o);
+        }
+        if (lane == 63) wave_min_s[wave] = Tv;
+        __syncthreads();
+        int tpre = carry_T, ttot = carry_T;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = wave_min_s[w];
+            if (w < wave) tpre = min(tpre, c);
+            ttot = min(ttot, c);
+        }
+        if (i < cnt) {
+            const int nit = min(niters0, min(tpre, Tv));
             if (iter0 + i + 1 >= nit) atomicMin(&stop_idx, i);
         }
+        carry_T = ttot;
         carry = tot;
         __syncthreads();
         if (stop_idx < cnt) break;  // block-uniform after the barrier
@@ -1241,6 +1358,19 @@ int update_num_iters(double p, double ep, int model_points, int max_iters) {
     return denom >= 0 || -num >= (double)max_iters * (-denom) ? max_iters : (int)std::round(num / denom);
 }
 
+// qmax of sampson_inlier(): the largest double whose float rounding is <= thresh^2.
+double inlier_bound(double thresh2) {
+    float f = (float)thresh2;
+    if ((double)f > thresh2) f = std::nextafterf(f, 0.0f);  // f* = largest float <= thresh^2
+    if (!(f >= 0.0f) || !std::isfinite(f)) return -1.0;     // nothing (or everything) passes: the kernels' slow path handles it
+    const float fn = std::nextafterf(f, INFINITY);
+    if (!std::isfinite(fn)) return -1.0;
+    const double mid = 0.5 * ((double)f + (double)fn);      // exact: two adjacent floats
+    uint32_t bits;
+    std::memcpy(&bits, &f, 4);
+    return (bits & 1u) ? std::nextafter(mid, 0.0) : mid;     // ties-to-even sends the midpoint to f* only if f* is even
+}
+
 }  // namespace
 
 // Launchers used by the C ABI ------------------------------------------------------------------------------------
@@ -1249,14 +1379,26 @@ int update_num_iters(double p, double ep, int model_points, int max_iters) {
 // model, many -> 4 lanes per model (see the two kernels).  Identical results either way.
 constexpr int kScoreBlockMaxModels = 24576;
 static void launch_score(hipStream_t s, const double4 *pts, int n, const double *E_list, const int32_t *ids, const int32_t *total_ptr,
-                         int total_host, int max_models, double thresh2, int32_t *good, double *esum) {
+                         int total_host, int max_models, double thresh2, int32_t *good, double *esum, bool sums = true,
+                         double qmax = -1.0) {
     if (max_models <= 0) return;
-    if (n <= kScoreBlockMaxN && max_models <= kScoreBlockMaxModels)
-        hipLaunchKernelGGL(score_models_block_kernel, dim3(max_models), dim3(256), (size_t)((n + 3) / 4 * 4) * sizeof(float), s, pts, n,
-                           E_list, ids, total_ptr, total_host, thresh2, good, esum);
-    else
-        hipLaunchKernelGGL(score_models_kernel, dim3((max_models + 63) / 64), dim3(256), 0, s, pts, n, E_list, ids, total_ptr,
-                           total_host, thresh2, good, esum);
+    const size_t lds = (size_t)((n + 3) / 4 * 4) * sizeof(float);
+    const bool block = n <= kScoreBlockMaxN && max_models <= kScoreBlockMaxModels;
+    if (sums) {
+        if (block)
+            hipLaunchKernelGGL((score_models_block_kernel<true, true>), dim3(max_models), dim3(256), lds, s, pts, n, E_list, ids, total_ptr,
+                               total_host, thresh2, qmax, good, esum, (const int32_t *)nullptr);
+        else
+            hipLaunchKernelGGL(score_models_kernel<true>, dim3((max_models + 63) / 64), dim3(256), 0, s, pts, n, E_list, ids, total_ptr,
+                               total_host, thresh2, qmax, good, esum);
+    } else {
+        if (block)
+            hipLaunchKernelGGL((score_models_block_kernel<true, false>), dim3(max_models), dim3(256), 0, s, pts, n, E_list, ids, total_ptr,
+                               total_host, thresh2, qmax, good, esum, (const int32_t *)nullptr);
+        else
+            hipLaunchKernelGGL(score_models_kernel<false>, dim3((max_models + 63) / 64), dim3(256), 0, s, pts, n, E_list, ids, total_ptr,
+                               total_host, thresh2, qmax, good, esum);
+    }
 }
 
 static int pack_points(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double4 **d_pts, hipStream_t s) {
@@ -1281,6 +1423,8 @@ struct RansacBuffers {
     int32_t *hslot;     // [chunk]
     double *hsum;       // [chunk]
     PolyRec *recs;      // [chunk]  solver -> roots hand-over
+    int32_t *cand;      // [chunk*10] ids of the models whose error sum is needed (lazy sums)
+    int32_t *cand_count;  // [1]
 };
 
 static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
@@ -1295,7 +1439,7 @@ static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
     if ((rc = ws_get(ctx, WS_PARTIAL, (size_t)chunk * sizeof(PolyRec), &p))) return rc;
     B.recs = (PolyRec *)p;
     // one slot for the small integer/double tables: [n_models | dense_id | good | total] + esum
-    const size_t ints = (size_t)chunk * (1 + 10 + 10 + 2) + 16;
+    const size_t ints = (size_t)chunk * (1 + 10 + 10 + 2 + 10) + 32;
     if ((rc = ws_get(ctx, WS_AUX7, ints * 4 + (size_t)chunk * 11 * 8 + 64, &p))) return rc;
     B.esum = (double *)p;
     B.hsum = B.esum + (size_t)chunk * 10;
@@ -1305,6 +1449,8 @@ static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
     B.hgood = B.good + (size_t)chunk * 10;
     B.hslot = B.hgood + chunk;
     B.total = B.hslot + chunk;
+    B.cand_count = B.total + 8;
+    B.cand = B.total + 16;
     return MLPL_OK;
 }
 
@@ -1370,12 +1516,10 @@ int mlpl_solve_5pt(mlpl_ctx *ctx, const double *p1, const double *p2, int n, con
     return MLPL_OK;
 }
 
-int mlpl_score_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const double *E, int n_models, double thresh,
-                      int32_t *count, double *err_sum) {
-    if (!ctx || !p1 || !p2 || !E || !count || !err_sum || n < 1 || n_models < 0) {
-        set_error("mlpl_score_models: bad arguments");
-        return MLPL_E_BAD_INPUT;
-    }
+// err_sum == NULL: count-only (division-free) kernels with the squared threshold given as is; shape 1 / 2 forces the
+// 4-lanes-per-model / block-per-model kernel (tests), 0 = automatic.
+static int score_models_impl(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const double *E, int n_models, double thresh2,
+                             int32_t *count, double *err_sum, int shape) {
     if (n_models == 0) return MLPL_OK;
     MLPL_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -1392,14 +1536,42 @@ int mlpl_score_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, 
     double4 *pts;
     if ((rc = pack_points(ctx, (const double *)dp1, (const double *)dp2, n, &pts, s))) return rc;
     prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
-    launch_score(s, (const double4 *)pts, n, (const double *)dE, nullptr, nullptr, n_models, n_models, thresh * thresh, (int32_t *)dgood,
-                 (double *)dsum);
+    const double qmax = inlier_bound(thresh2);
+    if (shape == 1 && !err_sum)
+        hipLaunchKernelGGL(score_models_kernel<false>, dim3((n_models + 63) / 64), dim3(256), 0, s, (const double4 *)pts, n,
+                           (const double *)dE, (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, thresh2, qmax,
+                           (int32_t *)dgood, (double *)dsum);
+    else if (shape == 2 && !err_sum)
+        hipLaunchKernelGGL((score_models_block_kernel<true, false>), dim3(std::min(n_models, 4096)), dim3(256), 0, s, (const double4 *)pts,
+                           n, (const double *)dE, (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, thresh2, qmax,
+                           (int32_t *)dgood, (double *)dsum, (const int32_t *)nullptr);
+    else
+        launch_score(s, (const double4 *)pts, n, (const double *)dE, nullptr, nullptr, n_models, n_models, thresh2, (int32_t *)dgood,
+                     (double *)dsum, err_sum != nullptr, qmax);
     prof_mark(ctx, MLPL_PROF_SCORE, 1, s);
     MLPL_HIP_TRY(hipGetLastError());
     MLPL_HIP_TRY(hipMemcpyAsync(count, dgood, (size_t)n_models * 4, hipMemcpyDeviceToHost, s));
-    MLPL_HIP_TRY(hipMemcpyAsync(err_sum, dsum, (size_t)n_models * 8, hipMemcpyDeviceToHost, s));
+    if (err_sum) MLPL_HIP_TRY(hipMemcpyAsync(err_sum, dsum, (size_t)n_models * 8, hipMemcpyDeviceToHost, s));
     MLPL_HIP_TRY(hipStreamSynchronize(s));
     return MLPL_OK;
+}
+
+int mlpl_score_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const double *E, int n_models, double thresh,
+                      int32_t *count, double *err_sum) {
+    if (!ctx || !p1 || !p2 || !E || !count || !err_sum || n < 1 || n_models < 0) {
+        set_error("mlpl_score_models: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    return score_models_impl(ctx, p1, p2, n, E, n_models, thresh * thresh, count, err_sum, 0);
+}
+
+int mlpl_count_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const double *E, int n_models, double thresh2, int shape,
+                      int32_t *count) {
+    if (!ctx || !p1 || !p2 || !E || !count || n < 1 || n_models < 0 || shape < 0 || shape > 2) {
+        set_error("mlpl_count_models: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    return score_models_impl(ctx, p1, p2, n, E, n_models, thresh2, count, nullptr, shape);
 }
 
 int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thresh, double confidence,
@@ -1414,6 +1586,9 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     if (n_inliers) *n_inliers = 0;
     if (iters_used) *iters_used = 0;
     const double thresh2 = thresh * thresh;  // modelest.cpp:79
+    // inlier counts without the division, error sums only where a tie has to be broken (sampson_inlier / candidate_kernel)
+    const double qmax = inlier_bound(thresh2);
+    const bool lazy = ctx->opt_ransac_lazy_sums != 0 && qmax > 0 && n <= kScoreBlockMaxN;
 
     double4 *pts;
     int rc = pack_points(ctx, d_p1, d_p2, n, &pts, s);
@@ -1496,7 +1671,18 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         }
         prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
         launch_score(s, (const double4 *)pts, n, (const double *)B.dense_E, (const int32_t *)B.dense_id, (const int32_t *)B.total, 0,
-                     cnt * 10, thresh2, B.good, B.esum);
+                     cnt * 10, thresh2, B.good, B.esum, !lazy, qmax);
+        if (lazy) {
+            // error sums only for the models that can still win (ties on the inlier count are decided by them)
+            MLPL_HIP_TRY(hipMemsetAsync(B.cand_count, 0, 4, s));
+            hipLaunchKernelGGL(hyp_max_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, (const int32_t *)B.n_models, (const int32_t *)B.good,
+                               cnt, B.hgood);
+            hipLaunchKernelGGL(candidate_kernel, dim3(1), dim3(1024), 0, s, (const int32_t *)B.n_models, (const int32_t *)B.good,
+                               (const int32_t *)B.hgood, cnt, cur.maxGood, B.cand, B.cand_count);
+            hipLaunchKernelGGL((score_models_block_kernel<false, true>), dim3(256), dim3(256), (size_t)((n + 3) / 4 * 4) * sizeof(float), s,
+                               (const double4 *)pts, n, (const double *)B.E_tab, (const int32_t *)nullptr, (const int32_t *)B.cand_count, 0,
+                               thresh2, qmax, (int32_t *)nullptr, B.esum, (const int32_t *)B.cand);
+        }
         prof_mark(ctx, MLPL_PROF_SCORE, 1, s);
         hipLaunchKernelGGL(hyp_best_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, (const int32_t *)B.n_models,
                            (const int32_t *)B.good, (const double *)B.esum, cnt, B.hgood, B.hsum, B.hslot);

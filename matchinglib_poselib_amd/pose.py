@@ -50,6 +50,17 @@ def score_models(p1, p2, E, thresh: float, ctx: Optional[Context] = None) -> Tup
     return good, esum
 
 
+def count_models(p1, p2, E, thresh2: float, shape: int = 0, ctx: Optional[Context] = None) -> np.ndarray:
+    """Inlier counts by the division-free predicate of the RANSAC passes; thresh2 = squared threshold (modelest.cpp:79)."""
+    ctx = ctx or default_context()
+    p1, p2 = _pts(p1), _pts(p2)
+    E = np.ascontiguousarray(E, np.float64).reshape(-1, 9)
+    good = np.zeros(E.shape[0], np.int32)
+    check(ctx.lib.mlpl_count_models(ctx.handle, p1.ctypes.data, p2.ctypes.data, p1.shape[0], E.ctypes.data, E.shape[0], float(thresh2),
+                                    int(shape), good.ctypes.data), "mlpl_count_models")
+    return good
+
+
 def median_models(p1, p2, E, ctx: Optional[Context] = None) -> np.ndarray:
     """Median Sampson error per model as runLMeDS takes it (modelest.cpp:540-544)."""
     ctx = ctx or default_context()

@@ -299,3 +299,49 @@ def test_ransac_device_iteration_bounds_equal_host_table(ctx, oracle, n):
     o = oracle.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, lesqu=False, seed=n)
     assert a["iters"] == b["iters"] == o["iters"] and a["n_inliers"] == b["n_inliers"] == o["n_inliers"]
     assert np.array_equal(a["E"], b["E"]) and np.array_equal(a["mask"], b["mask"]) and np.array_equal(b["mask"], o["mask"])
+
+
+@pytest.mark.parametrize("shape", [1, 2])
+def test_division_free_inlier_count_is_the_reference_predicate(ctx, oracle, shape):
+    """sampson_inlier: (double)(float)(N / D) <= thresh^2 decided without the division.  Thresholds that sit exactly ON float
+    error values (the predicate's <= and the float/double rounding boundaries) and one ulp either side of them."""
+    p1, p2, R, t, mask, th = synth.pose_scene(3000, seed=71)
+    samples = oracle.sample_table(5, p1, p2, 12)
+    Es = np.concatenate([oracle.run5point(p1[s], p2[s]) for s in samples])[:24]
+    errs = oracle.sampson_err(p1, p2, Es[0]).astype(np.float64)          # float errors of model 0, widened
+    picks = np.sort(errs)[[10, 500, 1500, 2500, 2990]]
+    t2s = [th * th]
+    for v in picks:
+        t2s += [v, np.nextafter(v, 0.0), np.nextafter(v, 1.0), float(np.nextafter(np.float32(v), np.float32(0))),
+                0.5 * (v + float(np.nextafter(np.float32(v), np.float32(1))))]   # a float, its double neighbours, the float midpoint
+    for t2 in t2s:
+        got = pose.count_models(p1, p2, Es, t2, shape=shape, ctx=ctx)
+        for k, E in enumerate(Es):
+            want = int((oracle.sampson_err(p1, p2, E).astype(np.float64) <= t2).sum())
+            assert got[k] == want, (shape, t2, k, got[k], want)
+    # degenerate model: all-zero E gives N = D = 0 -> NaN error -> never an inlier
+    z = pose.count_models(p1, p2, np.zeros((1, 3, 3)), th * th, shape=shape, ctx=ctx)
+    assert z[0] == 0
+
+
+@pytest.mark.parametrize("n,chunk", [(5000, 0), (300, 0), (40, 0), (7, 0), (2000, 100)])
+def test_ransac_lazy_error_sums_equal_full_sums(ctx, oracle, n, chunk):
+    """Counting without the division and summing errors only for the models that can still win must not change anything: same
+    iteration count, model, mask as with sums for every model, for adaptive and exhaustive runs, tiny n (ties on the inlier
+    count everywhere) and multi-pass replays."""
+    p1, p2, R, t, mask, th = synth.pose_scene(n, seed=900 + n)
+    ctx.set_option("ransac_chunk", chunk)
+    try:
+        for conf, iters, seed in ((0.999, 1000, 3), (1.0, 700, 4), (0.99, 300, 5)):
+            ctx.set_option("ransac_lazy_sums", 0)
+            a = pose.ransac_essential(p1, p2, th, confidence=conf, max_iters=iters, refit=True, seed=seed, ctx=ctx)
+            ctx.set_option("ransac_lazy_sums", 1)
+            b = pose.ransac_essential(p1, p2, th, confidence=conf, max_iters=iters, refit=True, seed=seed, ctx=ctx)
+            assert a["ok"] == b["ok"] and a["iters"] == b["iters"] and a["n_inliers"] == b["n_inliers"], (n, conf)
+            assert np.array_equal(a["E"], b["E"]) and np.array_equal(a["mask"], b["mask"])
+            o = oracle.ransac_essential(p1, p2, th, confidence=conf, max_iters=iters, lesqu=False, seed=seed)
+            c = pose.ransac_essential(p1, p2, th, confidence=conf, max_iters=iters, refit=False, seed=seed, ctx=ctx)
+            assert c["iters"] == o["iters"] and c["n_inliers"] == o["n_inliers"] and np.array_equal(c["mask"], o["mask"])
+    finally:
+        ctx.set_option("ransac_lazy_sums", 1)
+        ctx.set_option("ransac_chunk", 0)
