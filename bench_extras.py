@@ -68,8 +68,8 @@ def run(ctx, dev, cpu_baseline=True):
         "score_roofline": {"bound": "fp64-valu", "achieved": 39.0 * n * models / (score_ms * 1e-3) / 1e12,
                            "peak": FP64_VALU_PEAK / 1e12, "unit": "TFLOP/s",
                            "frac": 39.0 * n * models / (score_ms * 1e-3) / FP64_VALU_PEAK,
-                           "note": "39 fp64 FLOP per (model, correspondence) (SURVEY 8(d)); the IEEE division alone issues ~15 "
-                                   "instructions, so ~55 instructions per point are issued"},
+                           "note": "39 fp64 FLOP per (model, correspondence) (SURVEY 8(d)) over the scoring pass of the call (count-only "
+                                   "kernel without the division + candidate selection + error sums of the candidates)"},
         "includes": "host sample table (glibc rand stream, pinned/mapped), solve + score + replay + mask kernels, one 200-byte "
                     "state readback",
     }
