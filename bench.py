@@ -4,7 +4,8 @@
 A step = one pass of getMatches("LINEAR") device path (knn2_hamming partial + merge + ratio/compaction) over one
 batch of `--pairs-per-gpu` (default 8) synthetic image pairs of BASELINE config C2 (8192 x 8192 ORB-256 each), one batched
 launch per kernel, inputs resident in HBM.  The single-pair (latency) figure is reported under extras.  One process per GPU; image pairs shard across ranks with no data-path collective (weak scaling); with N > 1
-each step ends with one RCCL all_gather of the fixed-size per-pair result records (match counts).
+the fixed-size per-pair result records (match counts) of every 8 steps (= a rank's 64-pair share of a C5 batch) are gathered by one
+asynchronous RCCL all_gather that overlaps the next block's kernels.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured live with HIP events inside the library,
 see mlpl_profile_*) and `cpu_baseline` (the oracle's single-thread LUT port timed on this host).
@@ -52,6 +53,7 @@ def main():
                     help="bracket every Nth launch of the dominant kernel inside the timed region (two event records cost ~10 us)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--gather-every", type=int, default=8, help="steps per record gather (N > 1): 8 steps x 8 pairs = a C5 shard of 64 pairs")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (RANSAC / L2) measurements")
     ap.add_argument("--hamming-variant", type=int, default=3,
                     help="3 = fp4 matrix-core kernel (library default), 0/1/2 = the integer VALU kernels")
@@ -93,27 +95,37 @@ def main():
     d_q = torch.from_numpy(np.stack(qs)).to(dev)
     d_t = torch.from_numpy(np.stack(ts)).to(dev)
     stream = None  # = torch's current stream, so torch/RCCL work is ordered after our kernels
-    # Two result buffers: the gather of step k (fixed-size per-pair records, here the match counts) runs asynchronously on
-    # RCCL's stream and overlaps the kernels of step k+1; a buffer is reused only after its gather has completed.
-    outs = [None, None]
-    gathered = [torch.empty((world * P,), dtype=torch.int32, device=dev) for _ in range(2)] if world > 1 else None
+    # Result records (here: the match counts) are gathered per SHARD BLOCK of G steps = G * P image pairs per rank (G = 8, P = 8:
+    # the 64 pairs a rank owns of BASELINE's C5 batch of 512 on 8 GPUs), not per step: the kernels of a step write their counts
+    # straight into their row of the block's record buffer, and one asynchronous RCCL all_gather per block runs on RCCL's stream
+    # while the next block computes (two record buffers; a buffer is reused only after its gather has completed).
+    G = max(1, args.gather_every)
+    first = match_hamming_device(d_q, d_t, ratio_test=True, ratio=0.75, ctx=ctx, stream=stream)   # allocates idx/dist/matches
+    records = [torch.zeros((G * P,), dtype=torch.int32, device=dev) for _ in range(2)]
+    outs = [[dict(first, count=records[b][g * P:(g + 1) * P]) for g in range(G)] for b in range(2)]
+    gathered = [torch.empty((world * G * P,), dtype=torch.int32, device=dev) for _ in range(2)] if world > 1 else None
     pending = [None, None]
     step_no = 0
     out = None
 
+    def flush(b):
+        if world > 1:
+            pending[b] = dist.all_gather_into_tensor(gathered[b], records[b], async_op=True)
+
     def step():
         nonlocal out, step_no
-        slot = step_no & 1
-        if pending[slot] is not None:
-            pending[slot].wait()
-            pending[slot] = None
-        outs[slot] = match_hamming_device(d_q, d_t, ratio_test=True, ratio=0.75, ctx=ctx, out=outs[slot], stream=stream)
-        out = outs[slot]
-        if world > 1:
-            pending[slot] = dist.all_gather_into_tensor(gathered[slot], out["count"], async_op=True)
+        b, g = (step_no // G) & 1, step_no % G
+        if g == 0 and pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
+        out = match_hamming_device(d_q, d_t, ratio_test=True, ratio=0.75, ctx=ctx, out=outs[b][g], stream=stream)
         step_no += 1
+        if step_no % G == 0:
+            flush(b)
 
     def barrier():
+        if step_no % G:  # a partial block at the end of a phase
+            flush((step_no // G) & 1)
         for i in (0, 1):
             if pending[i] is not None:
                 pending[i].wait()
@@ -147,9 +159,10 @@ def main():
     value = world * pairs_per_step_rank * args.steps / elapsed
     counts = out["count"].cpu().numpy().tolist()
     if world > 1:  # every rank must hold every rank's records after the last gather
-        g = gathered[(step_no - 1) & 1].cpu().numpy().reshape(world, P)
-        assert g.shape == (world, P) and (g[rank] == np.array(counts)).all() and (g > 0).all(), "gathered records are wrong"
-
+        lastb = ((step_no - 1) // G) & 1
+        g = gathered[lastb].cpu().numpy().reshape(world, G * P)
+        mine = records[lastb].cpu().numpy()
+        assert (g[rank] == mine).all() and (g[:, :P] > 0).all(), "gathered records are wrong"
     if rank == 0:
         kern_ms = kern_ms if kern_ms > 0 else float('nan')
         hbm_equiv = pairs_per_step_rank * BYTES_PER_PAIR / (kern_ms * 1e-3) / 1e9   # north_star's "HBM-roofline GB/s" reading
@@ -227,6 +240,7 @@ def main():
                 "pairs_per_gpu": P,
                 "matches_first_pair": counts[0],
                 "parallelism": f"shard{world}",
+                "records_gathered_every_steps": G,
                 "hamming_kernel": kernel_name,
             },
             "roofline": roofline,
