@@ -787,9 +787,13 @@ struct LmedsState {
 
 __device__ __forceinline__ uint32_t lmeds_key(float err) { return __float_as_uint(err) ^ 0x80000000u; }  // signed-int order
 
+// CACHE: the model's n error keys are computed once into (dynamic) LDS and the five passes read them from there; without it
+// (n above kScoreBlockMaxN) every pass recomputes the errors.
+template <bool CACHE>
 __global__ __launch_bounds__(256) void median_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ dense_E,
                                                      const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
                                                      int total_host, double *__restrict__ median_out) {
+    extern __shared__ uint32_t keys[];  // n keys when CACHE
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_bin, s_below;
     __shared__ uint32_t s_cnt_lt, s_max_lt;
@@ -801,13 +805,23 @@ __global__ __launch_bounds__(256) void median_kernel(const double4 *__restrict__
     for (int k = 0; k < 9; ++k) e[k] = dense_E[(size_t)m * 9 + k];
     uint32_t k = (uint32_t)(n / 2);  // upper middle (the median itself for odd n)
     uint32_t prefix = 0, care = 0;
+    auto key_of = [&](int i) -> uint32_t {
+        if constexpr (CACHE) return keys[i];
+        const double4 p = pts[i];
+        return lmeds_key(sampson_err_f32(e, p.x, p.y, p.z, p.w));
+    };
+    if constexpr (CACHE) {
+        for (int i = tid; i < n; i += 256) {
+            const double4 p = pts[i];
+            keys[i] = lmeds_key(sampson_err_f32(e, p.x, p.y, p.z, p.w));
+        }
+    }
     for (int pass = 3; pass >= 0; --pass) {
         hist[tid] = 0;
         __syncthreads();
         const int sh = pass * 8;
         for (int i = tid; i < n; i += 256) {
-            const double4 p = pts[i];
-            const uint32_t v = lmeds_key(sampson_err_f32(e, p.x, p.y, p.z, p.w));
+            const uint32_t v = key_of(i);
             if ((v & care) == prefix) atomicAdd(&hist[(v >> sh) & 255u], 1u);
         }
         __syncthreads();
@@ -860,8 +874,7 @@ __global__ __launch_bounds__(256) void median_kernel(const double4 *__restrict__
         __syncthreads();
         uint32_t c = 0, mx = 0;
         for (int i = tid; i < n; i += 256) {
-            const double4 p = pts[i];
-            const uint32_t v = lmeds_key(sampson_err_f32(e, p.x, p.y, p.z, p.w));
+            const uint32_t v = key_of(i);
             if (v < key_hi) {
                 ++c;
                 mx = max(mx, v);
@@ -1799,8 +1812,12 @@ int mlpl_median_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n,
     MLPL_HIP_TRY(hipMemcpyAsync(dE, E, (size_t)n_models * 72, hipMemcpyHostToDevice, s));
     double4 *pts;
     if ((rc = pack_points(ctx, (const double *)dp1, (const double *)dp2, n, &pts, s))) return rc;
-    hipLaunchKernelGGL(median_kernel, dim3(n_models), dim3(256), 0, s, (const double4 *)pts, n, (const double *)dE,
-                       (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, (double *)dmed);
+    if (n <= kScoreBlockMaxN)
+        hipLaunchKernelGGL(median_kernel<true>, dim3(n_models), dim3(256), (size_t)n * 4, s, (const double4 *)pts, n, (const double *)dE,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, (double *)dmed);
+    else
+        hipLaunchKernelGGL(median_kernel<false>, dim3(n_models), dim3(256), 0, s, (const double4 *)pts, n, (const double *)dE,
+                           (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, (double *)dmed);
     MLPL_HIP_TRY(hipGetLastError());
     MLPL_HIP_TRY(hipMemcpyAsync(median, dmed, (size_t)n_models * 8, hipMemcpyDeviceToHost, s));
     MLPL_HIP_TRY(hipStreamSynchronize(s));
@@ -1848,8 +1865,12 @@ int mlpl_lmeds_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_
                        niters, B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total);
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
     prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
-    hipLaunchKernelGGL(median_kernel, dim3(niters * 10), dim3(256), 0, s, (const double4 *)pts, n, (const double *)B.dense_E,
-                       (const int32_t *)B.dense_id, (const int32_t *)B.total, 0, B.esum);
+    if (n <= kScoreBlockMaxN)
+        hipLaunchKernelGGL(median_kernel<true>, dim3(niters * 10), dim3(256), (size_t)n * 4, s, (const double4 *)pts, n,
+                           (const double *)B.dense_E, (const int32_t *)B.dense_id, (const int32_t *)B.total, 0, B.esum);
+    else
+        hipLaunchKernelGGL(median_kernel<false>, dim3(niters * 10), dim3(256), 0, s, (const double4 *)pts, n, (const double *)B.dense_E,
+                           (const int32_t *)B.dense_id, (const int32_t *)B.total, 0, B.esum);
     prof_mark(ctx, MLPL_PROF_SCORE, 1, s);
     hipLaunchKernelGGL(lmeds_argmin_kernel, dim3(1), dim3(1024), 0, s, (const int32_t *)B.n_models, (const double *)B.esum,
                        (const double *)B.E_tab, niters, d_st);
