@@ -153,7 +153,7 @@ def estimateEssentialMat(p1, p2, method: str = "ARRSAC", threshold: float = PIX_
             r = ransac_essential(p1, p2, threshold, confidence=0.999, max_iters=1000, refit=refine, seed=s, ctx=ctx)
         return r["ok"], r["E"], r["mask"]
     if method == "ARRSAC":
-        raise NotImplementedError(f"{method} is outside the RANSAC hot path built here")
+        raise NotImplementedError(f"{method} is not built here (RANSAC and LMEDS are)")
     if method == "USAC":
         print("USAC must be executed by function estimateEssentialOrPoseUSAC as it needs additional paramters! Exiting.")
     else:
