@@ -1,0 +1,42 @@
+"""One-off soak: many random shapes, the matrix-core Hamming kernel against the integer VALU kernel (both exact by their own
+tests against the oracle).  Usage: python tools/stress_hamming.py [seconds]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import matchinglib_poselib_amd as mpa  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+ctx = mpa.Context(0)
+rng = np.random.default_rng(12345)
+t0 = time.time()
+cases = 0
+while time.time() - t0 < budget:
+    nq = int(rng.integers(1, 3000))
+    nt = int(rng.integers(2, 20000))
+    nbytes = int(rng.choice([1, 2, 3, 4, 7, 8, 9, 15, 16, 17, 24, 31, 32, 33, 40, 48, 61, 63, 64]))
+    k = int(rng.integers(1, 3))
+    alphabet = int(rng.choice([1, 2, 5, 50, 100000]))
+    if alphabet >= 100000:
+        q = rng.integers(0, 256, (nq, nbytes), dtype=np.uint8)
+        t = rng.integers(0, 256, (nt, nbytes), dtype=np.uint8)
+    else:
+        base = rng.integers(0, 256, (alphabet, nbytes), dtype=np.uint8)
+        t = base[rng.integers(0, alphabet, nt)]
+        q = base[rng.integers(0, alphabet, nq)]
+        if rng.random() < 0.5:
+            flip = rng.random(q.shape) < 0.03
+            q = np.where(flip, rng.integers(0, 256, q.shape, dtype=np.uint8), q)
+    ctx.set_option("hamming_variant", 0)
+    i0, d0 = mpa.knn_hamming(q, t, k=k, ctx=ctx)
+    ctx.set_option("hamming_variant", 3)
+    ctx.set_option("hamming_mfma_qt", int(rng.choice([0, 1, 2, 4])))
+    i3, d3 = mpa.knn_hamming(q, t, k=k, ctx=ctx)
+    if not (np.array_equal(i0, i3) and np.array_equal(d0, d3)):
+        print("MISMATCH", nq, nt, nbytes, k, alphabet, flush=True)
+        sys.exit(1)
+    cases += 1
+print(f"{cases} random cases in {time.time() - t0:.0f} s: matrix-core == VALU kernel on all of them")
