@@ -345,3 +345,27 @@ def test_ransac_lazy_error_sums_equal_full_sums(ctx, oracle, n, chunk):
     finally:
         ctx.set_option("ransac_lazy_sums", 1)
         ctx.set_option("ransac_chunk", 0)
+
+
+def test_ransac_random_small_scenes_vs_oracle(ctx, oracle):
+    """Many small random scenes (n = 6..400: inlier counts tie constantly, the adaptive bound moves on almost every record):
+    iteration count, inlier count and mask equal the oracle's for every one; E up to the solver tolerance."""
+    rng = np.random.default_rng(2026)
+    checked = 0
+    for case in range(160):
+        n = int(rng.integers(6, 400))
+        frac = float(rng.uniform(0.3, 0.95))
+        p1, p2, R, t, mask, th = synth.pose_scene(n, inlier_frac=frac, seed=int(rng.integers(1, 1 << 30)))
+        conf = float(rng.choice([0.9, 0.99, 0.999, 1.0]))
+        iters = int(rng.choice([50, 300, 1000]))
+        seed = int(rng.integers(0, 1 << 31))
+        g = pose.ransac_essential(p1, p2, th, confidence=conf, max_iters=iters, refit=False, seed=seed, ctx=ctx)
+        o = oracle.ransac_essential(p1, p2, th, confidence=conf, max_iters=iters, lesqu=False, seed=seed)
+        assert g["ok"] == o["ok"], (case, n, conf, iters, seed)
+        if not o["ok"]:
+            continue
+        assert g["iters"] == o["iters"] and g["n_inliers"] == o["n_inliers"], (case, n, conf, iters, seed, g["iters"], o["iters"])
+        assert np.array_equal(g["mask"], o["mask"]), (case, n, seed)
+        assert e_dist(g["E"], o["E"]) < 1e-6
+        checked += 1
+    assert checked > 120
