@@ -134,6 +134,15 @@ struct PolyRec {
 static_assert(sizeof(PolyRec) == 88 * 8, "PolyRec layout");
 
 // Steps 2..4 of the solver (one wave): EE basis in LDS -> PolyRec in global memory.
+// The solver kernels run ONE wave per workgroup.  A wave's LDS instructions execute in program order, so a write by one lane is
+// visible to a later read by another lane of the same wave without s_barrier; what is needed is only that the compiler keeps the
+// order (and it waits for a read's data before using it anyway).  The ~100 __syncthreads() of a solve (s_barrier plus a full
+// counter drain each) were most of its latency.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ void solve_from_basis(SolveLds &L, int lane, PolyRec *__restrict__ rec) {
     // ---- 2. trilinear coefficient tensors (lane = ordered index triple (i,j,k)), symmetrised into A ----
     {
@@ -178,10 +187,10 @@ __device__ __forceinline__ void solve_from_basis(SolveLds &L, int lane, PolyRec 
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (int r = 0; r < 5; ++r) L.F[r][lane] = T[half * 5 + r];
-            __syncthreads();
+            wave_sync();
             if (lane < 20) {
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
@@ -194,7 +203,7 @@ __device__ __forceinline__ void solve_from_basis(SolveLds &L, int lane, PolyRec 
             }
         }
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- 3. Gauss-Jordan with partial pivoting: A <- [I | inv(A1) A2] ----
     bool singular = false;
@@ -212,17 +221,17 @@ __device__ __forceinline__ void solve_from_basis(SolveLds &L, int lane, PolyRec 
             singular = true;
             break;
         }
-        __syncthreads();
+        wave_sync();
         if (piv != col && lane < 20) {
             const double t = L.A[col][lane];
             L.A[col][lane] = L.A[piv][lane];
             L.A[piv][lane] = t;
         }
-        __syncthreads();
+        wave_sync();
         const double inv = 1.0 / L.A[col][col];
-        __syncthreads();
+        wave_sync();
         if (lane < 20) L.A[col][lane] *= inv;
-        __syncthreads();
+        wave_sync();
         double nv[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -232,7 +241,7 @@ __device__ __forceinline__ void solve_from_basis(SolveLds &L, int lane, PolyRec 
                 nv[t] = (r == col) ? L.A[r][j] : (L.A[r][j] - L.A[r][col] * L.A[col][j]);
             }
         }
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int e = lane + 64 * t;
@@ -241,7 +250,7 @@ __device__ __forceinline__ void solve_from_basis(SolveLds &L, int lane, PolyRec 
                 L.A[r][j] = nv[t];
             }
         }
-        __syncthreads();
+        wave_sync();
     }
     if (singular) {  // wave-uniform
         if (lane == 0) rec->ok = 0.0;
@@ -263,7 +272,7 @@ __device__ __forceinline__ void solve_from_basis(SolveLds &L, int lane, PolyRec 
         else if (j >= 8 && j <= 11) v2 = r2[j - 2];
         L.b[i][j] = v1 - v2;
     }
-    __syncthreads();
+    wave_sync();
     if (lane < 11) {
         // entries of B as ascending polynomials: P[i][0] = b[i][3-k] (deg 3), P[i][1] = b[i][7-k] (deg 3), P[i][2] = b[i][12-k] (deg 4)
         auto coef = [&](int row, int colm, int k) -> double {
@@ -287,7 +296,7 @@ __device__ __forceinline__ void solve_from_basis(SolveLds &L, int lane, PolyRec 
         }
         L.c[lane] = ck;
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- hand over to roots_kernel ----
     if (lane < 11) rec->c[lane] = L.c[lane];
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(64) void roots_kernel(const PolyRec *__restrict__ r
         const int smp = sample0 + hh;
         R[hh][k] = (smp < n_samples) ? reinterpret_cast<const double *>(recs + (smp - sample_offset))[k] : 0.0;
     }
-    __syncthreads();
+    wave_sync();
     const bool lane_ok = (h < kHypPerWave) && (sample0 + h < n_samples) && (R[h < kHypPerWave ? h : 0][86] != 0.0);
     const int hs = h < kHypPerWave ? h : 0;
     const double *c = &R[hs][0];
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(64) void roots_kernel(const PolyRec *__restrict__ r
     for (int iter = 0; iter < 400; ++iter) {
         rr[lane] = pr;
         ri[lane] = pim;
-        __syncthreads();
+        wave_sync();
         double dr = 0, di = 0;
         if (active && !done) {
             // Ehrlich-Aberth step: w = (p/p') / (1 - (p/p') * sum_{j != r} 1/(z - z_j));  p, p' by one Horner pass
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(64) void roots_kernel(const PolyRec *__restrict__ r
             pim -= di;
         }
         relbuf[lane] = (active && !done) ? sqrt(dr * dr + di * di) / (1.0 + sqrt(pr * pr + pim * pim)) : 0.0;
-        __syncthreads();
+        wave_sync();
         if (!done) {
             double rel = 0;
             bool nan = false;
@@ -486,7 +495,7 @@ __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__
         double *r = L.Q[lane];
         r[0] = x1 * x2, r[1] = y1 * x2, r[2] = x2, r[3] = x1 * y2, r[4] = y1 * y2, r[5] = y2, r[6] = x1, r[7] = y1, r[8] = 1.0;
     }
-    __syncthreads();
+    wave_sync();
     // ---- 1b. Householder QR of M = Q^T (9x5): M[r][c] = L.Q[c][r] ----
     for (int k = 0; k < 5; ++k) {
         double nrm2 = 0;
@@ -495,10 +504,10 @@ __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__
         const double alpha = (x0 >= 0 ? -1.0 : 1.0) * sqrt(nrm2);
         // v = x - alpha e_k ; |v|^2 = 2 (nrm2 - alpha x0)
         const double vn2 = 2.0 * (nrm2 - alpha * x0);
-        __syncthreads();
+        wave_sync();
         if (lane < 9) L.V[k][lane] = (lane < k) ? 0.0 : ((lane == k) ? (x0 - alpha) : L.Q[k][lane]);
         if (lane == 0) L.vn2[k] = vn2;
-        __syncthreads();
+        wave_sync();
         // apply H_k to the remaining columns c > k
         double upd = 0;
         bool doit = false;
@@ -511,16 +520,16 @@ __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__
                 upd = L.Q[c][r] - 2.0 * L.V[k][r] * dot / vn2;
             }
         }
-        __syncthreads();
+        wave_sync();
         if (doit) L.Q[lane / 9][lane % 9] = upd;
-        __syncthreads();
+        wave_sync();
     }
     // ---- 1c. null space: n_j = H_0 H_1 ... H_4 e_{5+j} ----
     if (lane < 36) {
         const int j = lane / 9, r = lane - j * 9;
         L.EE[j][r] = (r == 5 + j) ? 1.0 : 0.0;
     }
-    __syncthreads();
+    wave_sync();
     for (int k = 4; k >= 0; --k) {
         double upd = 0;
         const int j = lane / 9, r = lane - j * 9;
@@ -530,9 +539,9 @@ __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__
             for (int rr = k; rr < 9; ++rr) dot += L.V[k][rr] * L.EE[j][rr];
             upd = (vn2 > 0) ? (L.EE[j][r] - 2.0 * L.V[k][r] * dot / vn2) : L.EE[j][r];
         }
-        __syncthreads();
+        wave_sync();
         if (lane < 36) L.EE[j][r] = upd;
-        __syncthreads();
+        wave_sync();
     }
 
     solve_from_basis(L, lane, recs + (sample - sample_offset));
@@ -988,7 +997,7 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
         for (int pblk = 0; pblk < nparts; ++pblk) sacc += gram_part[(size_t)pblk * 45 + lane];
         gsum[lane] = sacc;
     }
-    __syncthreads();
+    wave_sync();
     if (lane == 0) {
         int t = 0;
         for (int a = 0; a < 9; ++a)
@@ -999,7 +1008,7 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
             }
     }
     for (int e = lane; e < 81; e += 64) Vv[e / 9][e % 9] = (e / 9 == e % 9) ? 1.0 : 0.0;
-    __syncthreads();
+    wave_sync();
     // Jacobi eigenvalue iteration on the symmetric 9x9 in the parallel (round-robin) ordering: the 9 indices plus one idle
     // slot form 5 disjoint pairs per round, 9 rounds visit all 36 pairs once (= one sweep).  Lanes 0..4 compute the rotations
     // of a round, then all lanes apply J^T G J and V J element-wise (disjoint rotations commute).
@@ -1008,7 +1017,7 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
     __shared__ int ring[10];
     __shared__ double Gn[9][9], Vn[9][9];
     if (lane < 10) ring[lane] = lane;
-    __syncthreads();
+    wave_sync();
     for (int sweep = 0; sweep < 60; ++sweep) {
         // off-diagonal mass against the diagonal (wave reduction; every lane gets the totals)
         double off = 0, diag = 0;
@@ -1047,7 +1056,7 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
                 cself[q] = c;
                 cpart[q] = sn;
             }
-            __syncthreads();
+            wave_sync();
             for (int e = lane; e < 81; e += 64) {
                 const int a = e / 9, b = e % 9;
                 const int pa = partner[a], pb = partner[b];
@@ -1062,7 +1071,7 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
                 const double vapb = (pb < 9) ? Vv[a][pb] : 0.0;
                 Vn[a][b] = cb * vab + kb * vapb;
             }
-            __syncthreads();
+            wave_sync();
             for (int e = lane; e < 81; e += 64) {
                 G[e / 9][e % 9] = Gn[e / 9][e % 9];
                 Vv[e / 9][e % 9] = Vn[e / 9][e % 9];
@@ -1072,7 +1081,7 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
                 for (int k = 9; k > 1; --k) ring[k] = ring[k - 1];
                 ring[1] = last;
             }
-            __syncthreads();
+            wave_sync();
         }
     }
     if (lane == 0) {
@@ -1090,7 +1099,7 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
         for (int j = 0; j < 4; ++j)
             for (int r = 0; r < 9; ++r) L.EE[j][r] = Vv[r][order[5 + j]];
     }
-    __syncthreads();
+    wave_sync();
     solve_from_basis(L, lane, rec);
 }
 
