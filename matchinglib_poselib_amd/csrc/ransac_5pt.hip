@@ -737,10 +737,20 @@ __global__ __launch_bounds__(1024) void candidate_kernel(const int32_t *__restri
                                                          int32_t *__restrict__ cand, int32_t *__restrict__ cand_count) {
     __shared__ int wave_max_s[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) *cand_count = 0;  // single block: reset here instead of a memset launch
+    __syncthreads();
     int carry = carried_best;
     for (int base = 0; base < cnt; base += 1024) {
         const int i = base + tid;
-        const int hmax = (i < cnt) ? hmax_in[i] : 0;
+        int hmax = 0;
+        if (i < cnt) {
+            if (hmax_in) {
+                hmax = hmax_in[i];
+            } else {  // few hypotheses: no separate hyp_max pass
+                const int nm0 = n_models[i];
+                for (int m = 0; m < nm0; ++m) hmax = max(hmax, good[(size_t)i * 10 + m]);
+            }
+        }
         int v = hmax;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -1700,11 +1710,12 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
                      cnt * 10, thresh2, B.good, B.esum, !lazy, qmax);
         if (lazy) {
             // error sums only for the models that can still win (ties on the inlier count are decided by them)
-            MLPL_HIP_TRY(hipMemsetAsync(B.cand_count, 0, 4, s));
-            hipLaunchKernelGGL(hyp_max_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, (const int32_t *)B.n_models, (const int32_t *)B.good,
-                               cnt, B.hgood);
+            const bool sep = cnt > 2048;  // many hypotheses: per-hypothesis maxima in a grid-wide pass first
+            if (sep)
+                hipLaunchKernelGGL(hyp_max_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, (const int32_t *)B.n_models,
+                                   (const int32_t *)B.good, cnt, B.hgood);
             hipLaunchKernelGGL(candidate_kernel, dim3(1), dim3(1024), 0, s, (const int32_t *)B.n_models, (const int32_t *)B.good,
-                               (const int32_t *)B.hgood, cnt, cur.maxGood, B.cand, B.cand_count);
+                               sep ? (const int32_t *)B.hgood : (const int32_t *)nullptr, cnt, cur.maxGood, B.cand, B.cand_count);
             hipLaunchKernelGGL((score_models_block_kernel<false, true>), dim3(256), dim3(256), (size_t)((n + 3) / 4 * 4) * sizeof(float), s,
                                (const double4 *)pts, n, (const double *)B.E_tab, (const int32_t *)nullptr, (const int32_t *)B.cand_count, 0,
                                thresh2, qmax, (int32_t *)nullptr, B.esum, (const int32_t *)B.cand);
