@@ -114,6 +114,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_hamming_mfma_blocks_per_cu = 3;
     ctx->opt_hamming_mfma_qt = 0;
     ctx->opt_ransac_lazy_sums = 1;
+    ctx->opt_solver_polish = 1;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -157,6 +158,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "hamming_qpl") && (value == 1 || value == 2)) ctx->opt_hamming_qpl = value;
     else if (!std::strcmp(name, "hamming_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_blocks_per_cu = value;
     else if (!std::strcmp(name, "ransac_lazy_sums") && (value == 0 || value == 1)) ctx->opt_ransac_lazy_sums = value;
+    else if (!std::strcmp(name, "solver_polish") && (value == 0 || value == 1)) ctx->opt_solver_polish = value;
     else if (!std::strcmp(name, "ransac_host_table") && (value == 0 || value == 1)) ctx->opt_ransac_host_table = value;
     else if (!std::strcmp(name, "ransac_chunk") && value >= 0 && value <= (1 << 20)) ctx->opt_ransac_chunk = value;
     else {

@@ -70,6 +70,7 @@ struct mlpl_ctx {
     int opt_hamming_mfma_qt;             // query tiles per wave (0 = automatic, else 1, 2 or 4)
     int opt_ransac_chunk;           // hypotheses per device pass (0 = 32768)
     int opt_ransac_lazy_sums;       // 1 (default) = division-free inlier counts + error sums only for models that can still win
+    int opt_solver_polish;          // 1 (default) = Gauss-Newton polish of every 5-point solution on the cubic constraints
     int opt_ransac_host_table;      // 1 = always build the niters table on the host (default: evaluate on the device, verify)
     // cached table T[g] = cvRANSACUpdateNumIters1(conf, (n-g)/n, 5, inf) for the last (n, conf) (host libm values)
     int32_t *ransac_T_host;

@@ -305,6 +305,112 @@ __device__ __forceinline__ void solve_from_basis(SolveLds &L, int lane, PolyRec 
     if (lane == 0) rec->ok = 1.0;
 }
 
+// Gauss-Newton polish of one solution (x, y, z) on the ten cubic constraints themselves (det E = 0, E E^T E - 1/2 tr(E E^T) E = 0 for
+// E = x E0 + y E1 + z E2 + E3).  The elimination (10x10 Gauss-Jordan) and the degree-10 polynomial amplify rounding by the condition
+// of the eliminated block, which depends on the null-space basis: on ~0.5 % of random 5-point samples the root path alone leaves E
+// wrong by 1e-7..1e-5 (in the CPU path just as here, but on DIFFERENT samples, because its SVD basis differs from the Householder
+// basis).  Two or three Newton steps on the constraints, which are well conditioned in E, take every accepted root to the solution of
+// the polynomial system at rounding level (constraint residual <= 1e-13), so the models no longer depend on the basis.  A step is
+// kept only while the residual norm decreases; a converged solution moves by ~1e-15.
+__device__ __forceinline__ double constraint_eval(const double *EE, double x, double y, double z, double *step) {
+    double E[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) E[k] = EE[k] * x + EE[9 + k] * y + EE[18 + k] * z + EE[27 + k];
+    double G[9];  // E E^T
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) G[r * 3 + c] = E[r * 3] * E[c * 3] + E[r * 3 + 1] * E[c * 3 + 1] + E[r * 3 + 2] * E[c * 3 + 2];
+    const double tr = G[0] + G[4] + G[8];
+    double Cf[9];  // cofactors of E
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            Cf[i * 3 + j] = E[i1 * 3 + j1] * E[i2 * 3 + j2] - E[i1 * 3 + j2] * E[i2 * 3 + j1];
+        }
+    double F[10];
+    F[0] = E[0] * Cf[0] + E[1] * Cf[1] + E[2] * Cf[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            F[1 + r * 3 + c] = G[r * 3] * E[c] + G[r * 3 + 1] * E[3 + c] + G[r * 3 + 2] * E[6 + c] - 0.5 * tr * E[r * 3 + c];
+    double f2 = 0;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) f2 += F[k] * F[k];
+    // Jacobian columns (directional derivatives along the basis matrices) -> normal equations
+    double JtJ[6] = {0, 0, 0, 0, 0, 0}, JtF[3] = {0, 0, 0};
+    double Jc[3][10];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        const double *D = EE + 9 * v;
+        double dd = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dd += Cf[k] * D[k];
+        Jc[v][0] = dd;
+        double DEt[9], EtE_col;  // D E^T
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) DEt[r * 3 + c] = D[r * 3] * E[c * 3] + D[r * 3 + 1] * E[c * 3 + 1] + D[r * 3 + 2] * E[c * 3 + 2];
+        const double trd = DEt[0] + DEt[4] + DEt[8];  // tr(D E^T) = tr(E D^T)
+        (void)EtE_col;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                // (D E^T) E + (E D^T) E + (E E^T) D - tr(E D^T) E - 1/2 tr(E E^T) D ;  E D^T = (D E^T)^T
+                double a = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) a += (DEt[r * 3 + k] + DEt[k * 3 + r]) * E[k * 3 + c] + G[r * 3 + k] * D[k * 3 + c];
+                Jc[v][1 + r * 3 + c] = a - trd * E[r * 3 + c] - 0.5 * tr * D[r * 3 + c];
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        JtJ[0] += Jc[0][k] * Jc[0][k];
+        JtJ[1] += Jc[0][k] * Jc[1][k];
+        JtJ[2] += Jc[0][k] * Jc[2][k];
+        JtJ[3] += Jc[1][k] * Jc[1][k];
+        JtJ[4] += Jc[1][k] * Jc[2][k];
+        JtJ[5] += Jc[2][k] * Jc[2][k];
+        JtF[0] += Jc[0][k] * F[k];
+        JtF[1] += Jc[1][k] * F[k];
+        JtF[2] += Jc[2][k] * F[k];
+    }
+    // symmetric 3x3 solve by cofactors: [a b c; b d e; c e f]
+    const double a = JtJ[0], b = JtJ[1], c = JtJ[2], d = JtJ[3], e = JtJ[4], f = JtJ[5];
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double det = a * c00 + b * c01 + c * c02;
+    if (det != 0 && det == det) {
+        const double c11 = a * f - c * c, c12 = b * c - a * e, c22 = a * d - b * b;
+        const double id = -1.0 / det;
+        step[0] = (c00 * JtF[0] + c01 * JtF[1] + c02 * JtF[2]) * id;
+        step[1] = (c01 * JtF[0] + c11 * JtF[1] + c12 * JtF[2]) * id;
+        step[2] = (c02 * JtF[0] + c12 * JtF[1] + c22 * JtF[2]) * id;
+    } else {
+        step[0] = step[1] = step[2] = 0;
+    }
+    return f2;
+}
+
+__device__ __forceinline__ void polish_xyz(const double *EE, double &x, double &y, double &z) {
+    double px = x, py = y, pz = z, pf = 0;
+    for (int it = 0; it < 4; ++it) {
+        double st[3];
+        const double f2 = constraint_eval(EE, x, y, z, st);
+        if (!(f2 == f2) || (it > 0 && !(f2 < pf))) {  // no further decrease (or NaN): keep the previous point
+            x = px, y = py, z = pz;
+            return;
+        }
+        px = x, py = y, pz = z, pf = f2;
+        if (it == 3 || !(st[0] == st[0] && st[1] == st[1] && st[2] == st[2])) return;
+        x += st[0], y += st[1], z += st[2];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Steps 5..6: roots and models.  Durand-Kerner needs one lane per root, i.e. 10 lanes per hypothesis, so SIX hypotheses
 // share a wave here (lane = 10*h + r) instead of idling 54 lanes of the solver wave.  All complex roots are found
@@ -318,7 +424,7 @@ constexpr int kHypPerWave = 6;
 __global__ __launch_bounds__(64) void roots_kernel(const PolyRec *__restrict__ recs, int sample_offset, int n_samples,
                                                    double *__restrict__ E_tab, int32_t *__restrict__ n_models,
                                                    double *__restrict__ dense_E, int32_t *__restrict__ dense_id,
-                                                   int32_t *__restrict__ dense_total) {
+                                                   int32_t *__restrict__ dense_total, int polish) {
     __shared__ double R[kHypPerWave][88];
     __shared__ double rr[64], ri[64], relbuf[64];
     const int lane = threadIdx.x;
@@ -439,11 +545,12 @@ __global__ __launch_bounds__(64) void roots_kernel(const PolyRec *__restrict__ r
         double xy1[3];
         null_vector_3x3(bz, xy1);
         if (!(fabs(xy1[2]) < 1e-10)) {
-            const double x = xy1[0] / xy1[2], y = xy1[1] / xy1[2];
+            double x = xy1[0] / xy1[2], y = xy1[1] / xy1[2], zp = z1;
+            if (polish) polish_xyz(EE, x, y, zp);
             double nrm = 0;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                E[k] = EE[k] * x + EE[9 + k] * y + EE[18 + k] * z1 + EE[27 + k];
+                E[k] = EE[k] * x + EE[9 + k] * y + EE[18 + k] * zp + EE[27 + k];
                 nrm += E[k] * E[k];
             }
             nrm = sqrt(nrm);
@@ -1543,7 +1650,7 @@ int mlpl_solve_5pt(mlpl_ctx *ctx, const double *p1, const double *p2, int n, con
     hipLaunchKernelGGL(solve5pt_kernel, dim3(n_samples), dim3(64), 0, s, (const double *)dp1, (const double *)dp2, B.samples, 0,
                        n_samples, B.recs);
     hipLaunchKernelGGL(roots_kernel, dim3((n_samples + kHypPerWave - 1) / kHypPerWave), dim3(64), 0, s, (const PolyRec *)B.recs, 0,
-                       n_samples, B.E_tab, B.n_models, (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+                       n_samples, B.E_tab, B.n_models, (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, ctx->opt_solver_polish);
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
     MLPL_HIP_TRY(hipGetLastError());
     MLPL_HIP_TRY(hipMemcpyAsync(E_out, B.E_tab, (size_t)n_samples * 720, hipMemcpyDeviceToHost, s));
@@ -1701,7 +1808,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
             hipLaunchKernelGGL(solve5pt_kernel, dim3(m), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, off, off + m,
                                B.recs);
             hipLaunchKernelGGL(roots_kernel, dim3((m + kHypPerWave - 1) / kHypPerWave), dim3(64), 0, s, (const PolyRec *)B.recs,
-                               off, off + m, B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total);
+                               off, off + m, B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total, ctx->opt_solver_polish);
             prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
             off += m;
         }
@@ -1748,7 +1855,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         hipLaunchKernelGGL(gram_kernel, dim3(gblocks), dim3(256), 0, s, (const double4 *)pts, (const uint8_t *)d_mask, n, d_gram);
         hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, s, (const double *)d_gram, gblocks, B.recs);
         hipLaunchKernelGGL(roots_kernel, dim3(1), dim3(64), 0, s, (const PolyRec *)B.recs, 0, 1, d_Etab, d_nm, (double *)nullptr,
-                           (int32_t *)nullptr, (int32_t *)nullptr);
+                           (int32_t *)nullptr, (int32_t *)nullptr, ctx->opt_solver_polish);
         launch_score(s, (const double4 *)pts, n, (const double *)d_Etab, nullptr, (const int32_t *)d_nm, 0, 10, thresh2, d_good, d_es);
         hipLaunchKernelGGL(refit_decide_kernel, dim3(1), dim3(64), 0, s, (const int32_t *)d_nm, (const int32_t *)d_good,
                            (const double *)d_es, (const double *)d_Etab, d_st);
@@ -1882,7 +1989,7 @@ int mlpl_lmeds_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
     hipLaunchKernelGGL(solve5pt_kernel, dim3(niters), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, 0, niters, B.recs);
     hipLaunchKernelGGL(roots_kernel, dim3((niters + kHypPerWave - 1) / kHypPerWave), dim3(64), 0, s, (const PolyRec *)B.recs, 0,
-                       niters, B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total);
+                       niters, B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total, ctx->opt_solver_polish);
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
     prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
     if (n <= kScoreBlockMaxN)

@@ -88,6 +88,10 @@ int oracle_get_subset(oracle_glibc_rand *st, const double *p1, const double *p2,
 /* CvEMEstimator::run5Point (five-point.cpp:366-471).  q1,q2: n x 2 doubles (n>=5).
  * E_out: up to 10 row-major 3x3 matrices.  Returns the number of solutions. */
 int oracle_run5point(const double *q1, const double *q2, int n, double *E_out);
+/* The same plus diagnostics: c_out[11] = the degree-10 polynomial (ascending powers), roots_out[20] = solvePoly's roots as
+ * (re, im) in root order, xy1z_out[10] = third component of the SVD::solveZ vector per root (NaN = rejected as complex). */
+int oracle_run5point_dbg(const double *q1, const double *q2, int n, double *E_out, double *c_out, double *roots_out,
+                         double *xy1z_out);
 
 /* computeReprojError3 (five-point.cpp:476-503): Sampson error in fp64 stored as float. */
 void oracle_sampson_err(const double *p1, const double *p2, int n, const double *E, float *err);

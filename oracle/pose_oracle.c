@@ -347,7 +347,8 @@ static void poly_mul(const double *a, int da, const double *b, int db, double *o
         for (int j = 0; j <= db; ++j) out[i + j] += a[i] * b[j];
 }
 
-int oracle_run5point(const double *q1, const double *q2, int n, double *E_out) {
+static int run5point_impl(const double *q1, const double *q2, int n, double *E_out, double *c_out, double *roots_out,
+                          double *xy1z_out) {
     if (n < 5) return 0;
     /* Q rows: [x1x2, y1x2, x2, x1y2, y1y2, y2, x1, y1, 1]  (five-point.cpp:374-383) */
     double *Q = (double *)malloc(sizeof(double) * (size_t)n * 9);
@@ -421,6 +422,10 @@ int oracle_run5point(const double *q1, const double *q2, int n, double *E_out) {
 
     double roots[2 * 10];
     oracle_solve_poly(c, 10, roots, 0);
+    if (c_out) memcpy(c_out, c, sizeof(c));
+    if (roots_out) memcpy(roots_out, roots, sizeof(roots));
+    if (xy1z_out)
+        for (int i = 0; i < 10; ++i) xy1z_out[i] = NAN;
 
     int count = 0;
     for (int i = 0; i < 10; ++i) {
@@ -436,6 +441,7 @@ int oracle_run5point(const double *q1, const double *q2, int n, double *E_out) {
         double w3[3], V3[9];
         jacobi_svd_impl(bz, 3, 3, w3, V3, NULL);
         const double xy1[3] = {V3[0 * 3 + 2], V3[1 * 3 + 2], V3[2 * 3 + 2]}; /* SVD::solveZ */
+        if (xy1z_out) xy1z_out[i] = xy1[2];
         if (fabs(xy1[2]) < 1e-10) continue;                                  /* five-point.cpp:457 */
         const double x = xy1[0] / xy1[2], y = xy1[1] / xy1[2];
         double Ev[9], nrm = 0;
@@ -448,6 +454,17 @@ int oracle_run5point(const double *q1, const double *q2, int n, double *E_out) {
         count++;
     }
     return count;
+}
+
+int oracle_run5point(const double *q1, const double *q2, int n, double *E_out) {
+    return run5point_impl(q1, q2, n, E_out, NULL, NULL, NULL);
+}
+
+/* Diagnostics for the parity tests: the degree-10 polynomial (ascending), solvePoly's roots (re, im) in root order and the
+ * third component of the solveZ vector per root (NaN where the root was rejected as complex). */
+int oracle_run5point_dbg(const double *q1, const double *q2, int n, double *E_out, double *c_out, double *roots_out,
+                         double *xy1z_out) {
+    return run5point_impl(q1, q2, n, E_out, c_out, roots_out, xy1z_out);
 }
 
 /* ------------------------------------------------------------------------------------------------------------

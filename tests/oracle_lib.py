@@ -78,6 +78,17 @@ class Oracle:
         n = self.lib.oracle_run5point(q1.ctypes.data, q2.ctypes.data, q1.shape[0], E.ctypes.data)
         return E[:n].copy()
 
+    def run5point_dbg(self, q1, q2):
+        """run5point plus (polynomial c[0..10] ascending, complex roots in solvePoly order, solveZ z-components)."""
+        q1 = np.ascontiguousarray(q1, np.float64)
+        q2 = np.ascontiguousarray(q2, np.float64)
+        E = np.zeros((10, 3, 3))
+        c, roots, z = np.zeros(11), np.zeros((10, 2)), np.zeros(10)
+        self.lib.oracle_run5point_dbg.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+        n = self.lib.oracle_run5point_dbg(q1.ctypes.data, q2.ctypes.data, q1.shape[0], E.ctypes.data, c.ctypes.data,
+                                          roots.ctypes.data, z.ctypes.data)
+        return E[:n].copy(), c, roots[:, 0] + 1j * roots[:, 1], z
+
     def find_inliers(self, p1, p2, E, thresh):
         p1 = np.ascontiguousarray(p1, np.float64)
         p2 = np.ascontiguousarray(p2, np.float64)
