@@ -65,6 +65,8 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  * grid; "hamming_qpl" queries per lane 1|2 and "hamming_blocks_per_cu" size the VALU grids; "ransac_chunk" hypotheses per
  * device pass (0 = 32768; the sequential best/niters rule is replayed across passes); "ransac_lazy_sums" (default 1) = the RANSAC passes count inliers
  * without the division and compute error sums only for the models that can still win, 0 = sums for every model;
+ * "solver_polish" (default 1) = every 5-point solution is polished by Gauss-Newton on the ten cubic constraints (0 = the plain
+ * elimination + root path, which is off by up to 1e-5 on the ~0.5 % of samples whose eliminated block is ill conditioned);
  * "ransac_host_table" 1 = build the
  * iteration-bound table T[g] on the host for every call (default 0: the device evaluates the few bounds it needs and the host
  * verifies exactly those against its libm, falling back to the table when one differs). */

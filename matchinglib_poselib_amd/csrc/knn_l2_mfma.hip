@@ -2,11 +2,14 @@
 //
 // Replaces cvflann::Index<L2<float>>(LinearIndexParams).knnSearch (reference matchinglib/source/matchers.cpp:634-664)
 // for float descriptors whose elements are all integers in [0,255] (OpenCV SIFT layout).  For such data
-//     d2(q,t) = |q|^2 + |t|^2 - 2 q.t
-// is exact in this formulation: the operands are exact in fp16, every product <= 65025 and every partial dot product
-// <= dim*65025 < 2^24 is exact in the fp32 MFMA accumulator, the norms likewise -- and the reference's own fp32 running sum of
-// integer squares is exact for the same reason.  So distances, hence the lexicographic (d2, trainIdx) order, are bit-identical
-// to the CPU path.  Anything else (fractional / negative / large values, dim > 256) takes knn_l2_exact_kernel.
+//     d2(q,t) = |q|^2 + (|t|^2 - 2 q.t)
+// is exact in this formulation: the train operand is stored as -2 t (exact in fp16: |.| <= 510), the accumulator starts at |t|^2,
+// and every value it can pass through -- |t|^2 plus any subset of the products -2 q_k t_k -- is an integer in
+// [|t|^2 - 2 q.t, |t|^2] = [d2 - |q|^2, |t|^2], i.e. of magnitude < dim*65025 < 2^24 (dim <= 256), hence exact in fp32 whatever order
+// the matrix core adds in; the final d2 = acc + |q|^2 is an integer < 2^24, so that add is exact too (|q|^2 + |t|^2 itself can
+// exceed 2^24 for dim > 128 and is never formed).  The reference's own fp32 running sum of integer squares is exact for the same
+// reason.  So distances, hence the lexicographic (d2, trainIdx) order, are bit-identical to the CPU path.  Anything else
+// (fractional / negative / large values, dim > 256) takes knn_l2_exact_kernel.
 //
 // Mapping: v_mfma_f32_32x32x16_f16 with A = 32 train rows, B = 32 queries, so a lane's 16 accumulators are 16 train rows of
 // ONE query (column = lane & 31): the running top-2 stays per lane, on packed 32-bit keys  d2 << ib | row_in_split
@@ -37,8 +40,9 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     return r;
 }
 
-// X: [n][dim] f32 (row stride `stride`) -> frag[(tile*KS + s)*64 + lane] = 8 halfs X[tile*32 + (lane&31)][16 s + 8 (lane>>5) + j];
-// flags[0] |= 1 when an element is not an integer in [0,255].  One launch for both operands: blockIdx.z = 0 queries, 1 train rows.
+// X: [n][dim] f32 (row stride `stride`) -> frag[(tile*KS + s)*64 + lane] = 8 halfs X[tile*32 + (lane&31)][16 s + 8 (lane>>5) + j]
+// (train rows scaled by -2, see above); flags[0] |= 1 when an element is not an integer in [0,255].  One launch for both operands:
+// blockIdx.z = 0 queries, 1 train rows.
 struct L2PrepArgs {
     const float *X;
     size_t stride, bstride;
@@ -64,7 +68,7 @@ __global__ void l2_prep_kernel(L2PrepArgs qa, L2PrepArgs ta, int dim, int KS, in
         float v = 0.f;
         if (row < A.n && k0 + j < dim) v = A.X[(size_t)b * A.bstride + (size_t)row * A.stride + k0 + j];
         bad = bad || !(v >= 0.f && v <= 255.f && v == floorf(v));
-        h[j] = (_Float16)v;
+        h[j] = (_Float16)(blockIdx.z ? -2.0f * v : v);
     }
     if (bad) atomicOr(flags, 1);
     A.frag[(size_t)b * total + g] = *reinterpret_cast<uint4 *>(&h);
@@ -140,22 +144,21 @@ __global__ __launch_bounds__(256) void knn_l2_mfma_kernel(const uint4 *__restric
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
         if (t + 1 < t_end) stage(t + 1, buf ^ 1);  // the other buffer was released by the barrier ending iteration t-1
+        // accumulator reg r of this lane is train row (r&3) + 8 (r>>2) + 4 (lane>>5) of the tile, query lane&31; it starts at |t|^2
         float16v acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[r] = tileN[buf][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const uint4 av = tileA[buf][s * 64 + lane];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8 *>(&av), qf[s], acc, 0, 0, 0);
         }
-        // epilogue: accumulator reg r of this lane is train row (r&3) + 8 (r>>2) + 4 (lane>>5) of the tile, query lane&31
         const int lrow0 = (t - t_begin) * 32 + 4 * (lane >> 5);
         const bool partial = (t * 32 + 32 > nt);  // wave-uniform: only the last tile of the set
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2);
-            const float tn = tileN[buf][m + 4 * (lane >> 5)];
-            const float d = fmaf(-2.0f, acc[r], qn + tn);  // exact: all integers < 2^24
+            const float d = acc[r] + qn;  // = |t|^2 - 2 q.t + |q|^2, exact: see the header
             uint32_t key = ((uint32_t)d << ib) | (uint32_t)(lrow0 + m);
             if (partial && (t * 32 + m + 4 * (lane >> 5) >= nt)) key = 0xFFFFFFFFu;
             k1 = umed3(k0, k1, key);

@@ -1,28 +1,33 @@
-// ransac_5pt.hip -- RANSAC for the essential matrix on gfx950: one 5-point Nister solve per wavefront, thread-per-model
-// Sampson scoring, host replay of the reference's sequential best/niters logic.
+// ransac_5pt.hip -- RANSAC / LMedS for the essential matrix on gfx950: one 5-point Nister solve per wavefront, grid-wide Sampson
+// scoring, and a device-side replay of the reference's sequential best/niters rule.
 //
 // Replaces, under reference poselib/source/five-point-nister/ :
-//   modelest.cpp:343-474  CvModelEstimator3::runRANSAC        (driver; replayed exactly on the host from device tables)
-//   modelest.cpp:567-650  getSubset / checkSubset             (sample table from the glibc rand() stream, host)
-//   five-point.cpp:366-471 CvEMEstimator::run5Point           (solve5pt_kernel, one hypothesis per wave)
-//   five-point.cpp:476-503 computeReprojError3 + modelest.cpp:69-83 findInliers (score_models_kernel)
+//   modelest.cpp:343-474  CvModelEstimator3::runRANSAC        (hyp_best_kernel + replay_kernel: prefix-max scan in iteration order)
+//   modelest.cpp:483-564  CvModelEstimator3::runLMeDS         (median_kernel + lmeds_argmin_kernel)
+//   modelest.cpp:567-650  getSubset / checkSubset             (sample table from the glibc rand() stream, host, pinned + mapped)
+//   five-point.cpp:366-471 CvEMEstimator::run5Point           (solve5pt_kernel + roots_kernel)
+//   five-point.cpp:476-503 computeReprojError3 + modelest.cpp:69-83 findInliers (score_models_kernel / score_models_block_kernel)
 //
-// solve5pt_kernel (64 threads = one wave per sample; all cross-lane traffic goes through ~7 KiB of LDS):
+// solve5pt_kernel (64 threads = ONE wave per sample; cross-lane traffic through ~7 KiB of LDS, ordered by wave_sync(), no s_barrier):
 //   1. the 5x9 epipolar matrix; its 4-dim null space by Householder QR of the 9x5 transpose (orthonormal basis, like the
 //      reference's SVD basis; any orthonormal basis yields the same set of essential matrices);
 //   2. the ten cubic constraints det(E)=0, E E^T E - 1/2 tr(E E^T) E = 0 for E = x E0 + y E1 + z E2 + E3: lane (i,j,k) of the
 //      64 = 4^3 lanes evaluates the trilinear coefficient tensor, 20 lanes symmetrise it into the 10x20 matrix in the
 //      reference's monomial order (five-point.cpp:813-823);
 //   3. Gauss-Jordan with partial pivoting on the 10x20 system, 200 elements spread over the wave;
-//   4. B(z) (3x13) and the degree-10 determinant polynomial, one coefficient per lane;
-//   5. all complex roots by Durand-Kerner, one root per lane, start values (1+i)^k as cv::solvePoly, Jacobi-style sweeps
-//      until the corrections vanish to rounding; a root is real iff |imag| <= 1e-10 (five-point.cpp:438);
-//   6. per real root: null vector of Bz (3x3 one-sided Jacobi SVD in registers), reject |xy1[2]| < 1e-10 (:457),
-//      E = x E0 + y E1 + z E2 + E3, Frobenius-normalised; ballot-compacted into the output.
-// score_models_kernel: 4 lanes per model over interleaved correspondences staged through LDS, fp64 Sampson error rounded to
-//   float exactly as the reference stores it, `err <= thresh^2` count and the 4-accumulator double sum of the float
-//   errors -- bit-identical to the CPU path for the same E (no FMA contraction: this file is compiled with
-//   -ffp-contract=off like the reference's -msse4.2 build).
+//   4. B(z) (3x13) and the degree-10 determinant polynomial, one coefficient per lane -> PolyRec in global memory.
+// roots_kernel (SIX hypotheses per wave, one root per lane):
+//   5. all complex roots simultaneously by Ehrlich-Aberth from cv::solvePoly's start values (1+i)^k (solvePoly itself iterates
+//      Durand-Kerner; a converged simultaneous iteration delivers the same roots to rounding); a root is real iff
+//      |imag| <= 1e-10 (five-point.cpp:438);
+//   6. per real root: null vector of Bz (3x3 one-sided Jacobi SVD in registers), reject |xy1[2]| < 1e-10 (:457), a Gauss-Newton
+//      polish of (x, y, z) on the ten constraints (polish_xyz), E = x E0 + y E1 + z E2 + E3, Frobenius-normalised;
+//      ballot-compacted into the per-hypothesis table and the dense model list.
+// Scoring: fp64 Sampson error in the reference's operation order rounded to float exactly as the reference stores it,
+//   `err <= thresh^2` counts (division-free predicate, sampson_inlier) and the 4-accumulator double sum of the float errors --
+//   bit-identical to the CPU path for the same E (no FMA contraction: this file is compiled with -ffp-contract=off like the
+//   reference's -msse4.2 build).
+// The solver kernels must be launched with exactly 64 threads: wave_sync() orders LDS traffic inside ONE wave only.
 
 #include <algorithm>
 #include <cfloat>
@@ -138,6 +143,7 @@ static_assert(sizeof(PolyRec) == 88 * 8, "PolyRec layout");
 // visible to a later read by another lane of the same wave without s_barrier; what is needed is only that the compiler keeps the
 // order (and it waits for a read's data before using it anyway).  The ~100 __syncthreads() of a solve (s_barrier plus a full
 // counter drain each) were most of its latency.
+constexpr int kSolverThreads = 64;
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -427,6 +433,7 @@ __global__ __launch_bounds__(64) void roots_kernel(const PolyRec *__restrict__ r
                                                    int32_t *__restrict__ dense_total, int polish) {
     __shared__ double R[kHypPerWave][88];
     __shared__ double rr[64], ri[64], relbuf[64];
+    if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
     const int lane = threadIdx.x;
     const int h = lane / 10, r = lane - h * 10;
     const int sample0 = sample_offset + blockIdx.x * kHypPerWave;
@@ -591,6 +598,7 @@ __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__
                                                       const int32_t *__restrict__ samples, int sample_offset, int n_samples,
                                                       PolyRec *__restrict__ recs /* indexed from sample_offset */) {
     __shared__ SolveLds L;
+    if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
     const int lane = threadIdx.x;
     const int sample = sample_offset + blockIdx.x;
     if (sample >= n_samples) return;
@@ -689,10 +697,11 @@ __device__ __forceinline__ float sampson_err_f32(const double *e, double x1, dou
 //     N < p             =>  inlier         (N <= pred(p) <= p - ulp(p)/2 < M * D)
 //     N > p (1 + 2^-50) =>  outlier        (N > p + 4 ulp(p) > M * D)
 // and only for N within four ulps of p -- probability ~2^-50 per correspondence -- the reference arithmetic itself decides.
-// qmax comes from the host (inlier_bound()).  D below 1e-200 (degenerate model or point) also takes the reference arithmetic.
+// qmax comes from the host (inlier_bound()); qmax <= 0 means "no usable bound" (thresh^2 outside the float range, e.g. above FLT_MAX
+// where every finite error passes) and, like D below 1e-200 (degenerate model or point), takes the reference arithmetic.
 __device__ __forceinline__ bool sampson_inlier(double N, double D, double qmax, double thresh2) {
     const double p = __dmul_rn(qmax, D);
-    const bool safe = D >= 1e-200;
+    const bool safe = D >= 1e-200 && qmax > 0;
     if (safe && N < p) return true;
     if (safe && N > __dmul_rn(p, 1.0 + 0x1p-50)) return false;
     return (double)(float)__ddiv_rn(N, D) <= thresh2;
@@ -1108,6 +1117,7 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
                                                          PolyRec *__restrict__ rec) {
     __shared__ SolveLds L;
     __shared__ double G[9][9], Vv[9][9], gsum[45];
+    if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
     const int lane = threadIdx.x;
     if (lane < 45) {  // fixed summation order over the blocks: run-to-run deterministic
         double sacc = 0;

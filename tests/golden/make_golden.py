@@ -123,6 +123,108 @@ def nms_wrapper_case():
     print("bruteforce_nms: ok")
 
 
+# ---- G2: squared-L2 2-NN on integer-valued SIFT-like descriptors ---------------------------------------------------
+def l2_case():
+    """Exact d^2 (integers < 2^24) by numpy int64 brute force with lexicographic (d^2, idx) selection = the cvflann order;
+    cross-checked against the reference's vendored NMSLIB `l2` space (sqrt distances, tie-free indices)."""
+    out = {}
+    for tag, (nq, nt, dim) in {"sift128": (300, 411, 128), "d64": (130, 257, 64)}.items():
+        q, t = synth.sift_pair(nq, nt, dim=dim, seed=20260130 + dim)
+        if tag == "d64":  # adversarial ties: duplicated train rows and exact copies as queries
+            t[17] = t[3]; t[200] = t[3]; q[:10] = t[:10]
+        qi, ti = q.astype(np.int64), t.astype(np.int64)
+        idx = np.empty((nq, 2), np.int32)
+        d2 = np.empty((nq, 2), np.int64)
+        tie_free = np.zeros(nq, bool)
+        for i in range(nq):
+            d = ((ti - qi[i][None, :]) ** 2).sum(axis=1)
+            order = np.lexsort((np.arange(nt), d))[:2]
+            idx[i], d2[i] = order, d[order]
+            tie_free[i] = (d <= d[order[1]]).sum() == 2 and d[order[0]] < d[order[1]]
+        assert d2.max() < (1 << 24)
+        nidx, ndist = run_nmslib("l2", q, t)
+        assert np.array_equal(ndist, np.sqrt(d2.astype(np.float32))), "NMSLIB l2 distances disagree with the exact integers"
+        assert np.array_equal(nidx[tie_free], idx[tie_free])
+        keep = d2[:, 0].astype(np.float32) < np.float32(0.75) * d2[:, 1].astype(np.float32)
+        out.update({f"{tag}_q": q, f"{tag}_t": t, f"{tag}_idx": idx, f"{tag}_d2": d2.astype(np.float32), f"{tag}_nms_idx": nidx,
+                    f"{tag}_tie_free": tie_free, f"{tag}_match_q": np.nonzero(keep)[0].astype(np.int32)})
+        print("l2", tag, q.shape, t.shape, "tie-free", int(tie_free.sum()), "matches", int(keep.sum()))
+    np.savez_compressed(os.path.join(HERE, "l2_integer_sift.npz"), **out)
+
+
+# ---- G4: glibc srand/rand stream (from libc itself) + compact runRANSAC trace of the CPU restatement --------------------
+def ransac_case():
+    import ctypes
+    import zlib
+    libc = ctypes.CDLL("libc.so.6")
+    seeds = np.array([0, 1, 12345, 20260103, 4294967295], np.uint32)
+    head = np.empty((len(seeds), 2000), np.int32)
+    crc = np.empty(len(seeds), np.uint32)
+    for k, sd in enumerate(seeds):
+        libc.srand(ctypes.c_uint(int(sd)))
+        stream = np.array([libc.rand() for _ in range(100000)], np.int32)
+        head[k] = stream[:2000]
+        crc[k] = zlib.crc32(stream.tobytes())
+    ora = oracle_lib.load()
+    out = dict(rand_seeds=seeds, rand_head=head, rand_crc32_100000=crc)
+    # scene = C3's generator at the reference's own settings (1000 iterations, confidence 0.999) and a no-early-exit run
+    for tag, (n, conf, iters, seed) in {"ref": (5000, 0.999, 1000, 12345), "full": (800, 1.0, 400, 7)}.items():
+        p1, p2, R, t, mask, th = synth.pose_scene(n, seed=20260103)
+        o = ora.ransac_essential(p1, p2, th, confidence=conf, max_iters=iters, lesqu=False, seed=seed, trace=True)
+        k = o["iters"]
+        tr = o["trace"]
+        out.update({
+            f"{tag}_params": np.array([n, conf, iters, seed, th], np.float64),
+            f"{tag}_iters": np.int32(k), f"{tag}_n_inliers": np.int32(o["n_inliers"]), f"{tag}_E": o["E"], f"{tag}_mask": np.packbits(o["mask"]),
+            f"{tag}_idx": np.array([list(tr[i].idx) for i in range(k)], np.int32),
+            f"{tag}_nmodels": np.array([tr[i].nmodels for i in range(k)], np.int8),
+            f"{tag}_good": np.array([list(tr[i].good) for i in range(k)], np.int16),
+            f"{tag}_err_sum": np.array([list(tr[i].err_sum) for i in range(k)], np.float64),
+            f"{tag}_niters_after": np.array([tr[i].niters_after for i in range(k)], np.int32),
+            f"{tag}_best_taken": np.array([tr[i].best_taken for i in range(k)], np.int8)})
+        lo = ora.ransac_essential(p1, p2, th, confidence=conf, max_iters=iters, lesqu=True, seed=seed)
+        out.update({f"{tag}_refit_E": lo["E"], f"{tag}_refit_mask": np.packbits(lo["mask"]), f"{tag}_refit_n_inliers": np.int32(lo["n_inliers"])})
+        print("ransac", tag, "iters", k, "inliers", o["n_inliers"], "refit inliers", lo["n_inliers"])
+    np.savez_compressed(os.path.join(HERE, "ransac_trace.npz"), **out)
+
+
+# ---- G5: cheirality / pose recovery on scenes with a known (R, t) -----------------------------------------------------
+def cheirality_case():
+    """Noise-free correspondences of a known pose, with far points (z >= dist), points behind one camera (mirrored input) and an
+    input mask; expected = analytic truth (R, t, which points pass z > 0 in both views and z < dist) AND the CPU restatement's
+    outputs (count, mask, R, t, Q)."""
+    ora = oracle_lib.load()
+    rng = np.random.default_rng(20260140)
+    out = {}
+    for tag, (axis, deg, tt) in {"a": ((0.2, 0.9, 0.1), 5.0, (1.0, 0.05, -0.02)), "b": ((-0.5, 0.3, 0.8), 12.0, (-0.2, 0.1, 1.0))}.items():
+        R = synth._rot(axis, deg)
+        t = np.asarray(tt, float)
+        t /= np.linalg.norm(t)
+        n = 400
+        X = np.stack([rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), rng.uniform(4, 12, n)], axis=1)
+        X[:40, 2] = rng.uniform(60, 200, 40)                 # far points: fail z < dist (dist = 50)
+        X[40:60, 2] = rng.uniform(49.0, 51.0, 20)            # around the distance gate
+        p1 = X[:, :2] / X[:, 2:3]
+        X2 = X @ R.T + t
+        p2 = X2[:, :2] / X2[:, 2:3]
+        p1[60:80] = -p1[60:80]                               # inconsistent pairs: land behind a camera for the true pose
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        E = tx @ R
+        m_in = (rng.random(n) < 0.85).astype(np.uint8)
+        for variant, (Ein, mk) in {"plain": (E, None), "neg_scaled_masked": (-3.7 * E, m_in)}.items():
+            good, Ro, to, Qo, mo = ora.recover_pose(Ein, p1, p2, 50.0, mk)
+            truth_ok = (X[:, 2] < 50.0)
+            truth_ok[60:80] = False
+            key = f"{tag}_{variant}"
+            out.update({f"{key}_E": Ein, f"{key}_good": np.int32(good), f"{key}_R": Ro, f"{key}_t": to, f"{key}_Q": Qo,
+                        f"{key}_mask_out": (mo if mo is not None else np.zeros(0, np.uint8))})
+            assert np.abs(Ro - R).max() < 1e-9 and np.abs(to - t).max() < 1e-9, "restatement does not recover the known pose"
+        out.update({f"{tag}_p1": p1, f"{tag}_p2": p2, f"{tag}_R_true": R, f"{tag}_t_true": t, f"{tag}_X_true": X, f"{tag}_mask_in": m_in,
+                    f"{tag}_truth_ok": truth_ok})
+        print("cheirality", tag, "good", good)
+    np.savez_compressed(os.path.join(HERE, "cheirality.npz"), **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "nms"):
@@ -131,3 +233,9 @@ if __name__ == "__main__":
         main()
     if what in ("all", "pose"):
         fivept_case()
+    if what in ("all", "l2"):
+        l2_case()
+    if what in ("all", "ransac"):
+        ransac_case()
+    if what in ("all", "cheirality"):
+        cheirality_case()

@@ -205,6 +205,33 @@ def test_l2_mfma_integer_descriptors_bit_exact(ctx, oracle, nq, nt, dim):
     assert dist.tobytes() == od.tobytes()
 
 
+@pytest.mark.parametrize("dim", [256, 200, 144])
+def test_l2_mfma_high_magnitude_above_128_dims(ctx, oracle, dim):
+    """dim > 128 with large values: |q|^2 + |t|^2 exceeds 2^24 (not a float), d^2 itself does not.  The advisor's counterexample
+    (q = [201, 200, ...], t = [200, ...] -> d^2 = 1, not 0) plus near-duplicate high-valued rows whose d^2 are small integers."""
+    rng = np.random.default_rng(dim)
+    t = rng.integers(180, 256, size=(300, dim)).astype(np.float32)
+    t[0] = 200.0
+    q = t[rng.integers(0, 300, 150)].copy()
+    q[0] = 200.0
+    q[0, 0] = 201.0                               # d^2(q0, t0) = 1
+    for i in range(1, 150):                       # 1..3 elements off by one: d^2 in {1, 2, 3}, ties broken by train index
+        for c in rng.integers(0, dim, 1 + i % 3):
+            q[i, c] = q[i, c] - 1.0 if q[i, c] > 200 else q[i, c] + 1.0
+    oi, od = oracle.knn_l2sq(q, t)
+    assert od[0, 0] == 1.0 and oi[0, 0] == 0
+    for mode in (2, 0):
+        _set_l2(ctx, mode)
+        try:
+            idx, dist = mpa.knn_l2sq(q, t, ctx=ctx)
+        finally:
+            _set_l2(ctx, 0)
+        assert np.array_equal(idx, oi) and dist.tobytes() == od.tobytes(), mode
+    err, m = mpa.getMatches([None] * 150, [None] * 300, q, t, matcher_name="LINEAR", ctx=ctx)
+    rc, mo = oracle.get_matches_linear(150, 300, q, t)
+    assert err == rc and m.tobytes() == mo.tobytes()
+
+
 def test_l2_auto_path_selection(ctx, oracle):
     import matchinglib_poselib_amd as m
     rng = np.random.default_rng(12)

@@ -318,6 +318,11 @@ def test_division_free_inlier_count_is_the_reference_predicate(ctx, oracle, shap
     # degenerate model: all-zero E gives N = D = 0 -> NaN error -> never an inlier
     z = pose.count_models(p1, p2, np.zeros((1, 3, 3)), th * th, shape=shape, ctx=ctx)
     assert z[0] == 0
+    # thresholds outside the float range: above FLT_MAX every finite error passes, a negative one passes nothing
+    big = pose.count_models(p1, p2, Es, 1e39, shape=shape, ctx=ctx)
+    assert (big == 3000).all()
+    neg = pose.count_models(p1, p2, Es, -1.0, shape=shape, ctx=ctx)
+    assert (neg == 0).all()
 
 
 @pytest.mark.parametrize("n,chunk", [(5000, 0), (300, 0), (40, 0), (7, 0), (2000, 100)])
