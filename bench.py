@@ -9,6 +9,12 @@ asynchronous RCCL all_gather that overlaps the next block's kernels.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured live with HIP events inside the library,
 see mlpl_profile_*) and `cpu_baseline` (the oracle's single-thread LUT port timed on this host).
+
+`python bench.py --gpus N` works by itself: when N > 1 and no torch.distributed environment is present, this process starts the N
+rank processes (python -m torch.distributed.run on 127.0.0.1) BEFORE it touches the GPU and relays their output; under an external
+launcher (RANK / WORLD_SIZE set) it is a rank.  `--workload c5` times BASELINE config 5 instead: 512 stereo pairs, each through the
+whole per-pair pipeline (8k ORB match -> gather -> 5-pt RANSAC -> cheirality), dealt to the ranks by batch.pair_shard, records
+gathered by one RCCL all_gather per step.
 """
 import argparse
 import ctypes as C
@@ -39,6 +45,88 @@ MIX_CYCLES_PER_WAVE_ROW = 8 * 3.24 + 8 * 4.73 + 4.8 + 4.8 + 3.24
 CLOCK_HZ = 2.4e9
 
 
+def spawn_ranks(n):
+    """Parent of a self-launched multi-GPU run: start n rank processes and relay their output.  Nothing here may touch the GPU
+    (a process that has initialised HIP must not be replaced or forked into ranks), so torch is not even imported."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def run_c5(args, rank, local_rank, world, dev, ctx):
+    """BASELINE config 5: `--c5-pairs` (512) stereo pairs x (8192-keypoint ORB match + ratio -> gather/ImgToCamCoordTrans -> RANSAC
+    1000 it / 0.999 -> cheirality), pairs dealt to ranks in contiguous blocks, several pairs in flight per rank (independent
+    contexts/streams), one all_gather of the 184-byte records per step.  Total work is fixed: strong scaling."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from matchinglib_poselib_amd import batch, synth
+
+    total = args.c5_pairs
+    begin, end = batch.pair_shard(total, rank, world)
+    mine = end - begin
+    distinct = max(1, min(mine, args.c5_distinct))
+    sps = [synth.stereo_pair(args.n, seed=20260200 + begin + i, unmatched_frac=0.30 + 0.02 * (i % 8)) for i in range(distinct)]
+    dev_in = [tuple(torch.from_numpy(sp[k]).to(dev) for k in ("desc1", "desc2", "kp1", "kp2")) for sp in sps]
+    K = sps[0]["K"]
+    pairs = [dev_in[i % distinct] for i in range(mine)]
+    seeds = [100 + begin + i for i in range(mine)]
+    ids = list(range(begin, end))
+    pw = batch.PairWorkers(local_rank, workers=args.c5_workers)
+    allrec = None
+
+    def step():
+        nonlocal allrec
+        recs = pw.process(pairs, K, K, seeds=seeds, pair_ids=ids)
+        allrec = batch.gather_records(recs, total, rank, world, device=dev if args.backend == "nccl" or world == 1 else None)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    try:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        pw.close()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert len(allrec) == total and (allrec["status"] == 0).all(), "a pair failed"
+    if rank == 0:
+        rec = {
+            "metric": "image-pairs/s (C5: stereo pairs x (8k ORB BF-Hamming match + 5-pt RANSAC + cheirality))",
+            "value": total * args.steps / elapsed, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "fp4 MFMA (Hamming, exact) + f64 (solver, Sampson, cheirality)", "data": "synthetic",
+            "config": {"workload": f"C5: {total} stereo pairs x ({args.n} ORB-256 keypoints per image: Hamming 2-NN + 0.75 ratio -> "
+                                   "ImgToCamCoordTrans gather -> RANSAC 1000 it / 0.999 -> getPoseTriangPts), one step = the whole batch",
+                       "pairs_total": total, "pairs_this_rank": mine, "distinct_inputs_per_rank": distinct,
+                       "pairs_in_flight_per_gpu": args.c5_workers, "parallelism": f"shard{world}", "world_size": world,
+                       "backend": args.backend, "records_gathered": "one all_gather of 184-byte records per step",
+                       "mean_matches": float(allrec["n_matches"].mean()), "mean_inliers": float(allrec["n_inliers"].mean())},
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(rec), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,7 +145,15 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (RANSAC / L2) measurements")
     ap.add_argument("--hamming-variant", type=int, default=3,
                     help="3 = fp4 matrix-core kernel (library default), 0/1/2 = the integer VALU kernels")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5"],
+                    help="c2 (default, the headline metric): batched 8k x 8k Hamming matching; c5: 512 stereo pairs through the whole per-pair pipeline")
+    ap.add_argument("--c5-pairs", type=int, default=512)
+    ap.add_argument("--c5-distinct", type=int, default=8, help="distinct synthetic inputs generated per rank (cycled over its shard)")
+    ap.add_argument("--c5-workers", type=int, default=6, help="image pairs in flight per GPU")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))          # before any GPU call: this process only launches and relays
 
     import numpy as np
     import torch
@@ -66,7 +162,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus} (under an external launcher pass --gpus = its world size)"
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -85,6 +181,15 @@ def main():
     ctx = mpa.Context(local_rank)
     lib = ctx.lib
     ctx.set_option("hamming_variant", args.hamming_variant)
+    if args.workload == "c5":
+        if args.steps == 200 and args.warmup == 20:   # the defaults are sized for the C2 step; a C5 step is a whole batch
+            args.steps, args.warmup = 3, 1
+        run_c5(args, rank, local_rank, world, dev, ctx)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        ctx.close()
+        return
     P, n = args.pairs_per_gpu, args.n
     # synthetic C2 inputs, one distinct pair per (rank, slot); resident in HBM before the timed region
     qs, ts = [], []
@@ -158,6 +263,22 @@ def main():
     pairs_per_step_rank = P * n * n
     value = world * pairs_per_step_rank * args.steps / elapsed
     counts = out["count"].cpu().numpy().tolist()
+    # a wrong kernel must not produce a fast number silently: half of the queries of every synthetic pair are true matches that pass
+    # the ratio test, the rest (almost) never do
+    assert all(abs(c - n // 2) <= max(8, n // 100) for c in counts), f"match counts {counts} are not ~{n // 2}"
+    # the literal config 2 (ONE image pair per launch, latency shape) beside the batched headline
+    single_ms = None
+    if rank == 0:
+        o1 = match_hamming_device(d_q[:1], d_t[:1], ratio_test=True, ratio=0.75, ctx=ctx, stream=stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            o1 = match_hamming_device(d_q[:1], d_t[:1], ratio_test=True, ratio=0.75, ctx=ctx, out=o1, stream=stream)
+        e1.record()
+        torch.cuda.synchronize()
+        single_ms = e0.elapsed_time(e1) / 50
+        assert int(o1["count"][0].item()) == counts[0] or P == 0
     if world > 1:  # every rank must hold every rank's records after the last gather
         lastb = ((step_no - 1) // G) & 1
         g = gathered[lastb].cpu().numpy().reshape(world, G * P)
@@ -168,12 +289,14 @@ def main():
         hbm_equiv = pairs_per_step_rank * BYTES_PER_PAIR / (kern_ms * 1e-3) / 1e9   # north_star's "HBM-roofline GB/s" reading
         mfma_path = args.hamming_variant == 3
         kernel_name = "knn_hamming_mfma_kernel<4, 4>" if mfma_path else "knn_hamming_partial_kernel<8>"
-        traffic = None
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("knn_hamming_mfma_bytes_per_launch" if mfma_path
-                                                  else "knn_hamming_partial_bytes_per_launch")
+                tj = json.load(open(tf))
+                traffic = tj.get("knn_hamming_mfma_bytes_per_launch" if mfma_path else "knn_hamming_partial_bytes_per_launch")
+                traffic_src = f"from profiles/pmc_traffic.json (round {tj.get('round', '?')}, {tj.get('pairs_per_launch', '?')} pairs per " \
+                              "launch; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes) -- not measured in this run"
             except Exception:
                 traffic = None
         if mfma_path:
@@ -188,6 +311,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP4_MFMA_PEAK_TFLOPS,
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel_ms_avg": kern_ms,
                 "launches_timed": launches.value,
                 "note": "the all-pairs Hamming table as a +-1 GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 x fp4, fp32 accumulate, "
@@ -210,6 +334,7 @@ def main():
                 "unit": "GB/s",
                 "frac": hbm_equiv / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel_ms_avg": kern_ms,
                 "launches_timed": launches.value,
                 "note": "streaming-equivalent bytes (64 B per descriptor pair, SURVEY 8(d)); operands are LDS/L2-"
@@ -237,7 +362,13 @@ def main():
             "config": {
                 "workload": f"C2: {n}x{n} ORB-256 BF-Hamming kNN=2 + 0.75 ratio + DMatch compaction, "
                             f"{P} image pair(s) per GPU per step",
+                "value_is": f"the BATCHED rate: {P} independent C2 image pairs per launch per GPU (a rank's slice of a C5 batch); "
+                            "value_single_pair is the same path with ONE pair per launch (the literal config 2, latency shape)",
+                "value_single_pair": (n * n / (single_ms * 1e-3)) if single_ms else None,
+                "ms_single_pair": single_ms,
                 "pairs_per_gpu": P,
+                "world_size": world,
+                "backend": args.backend if world > 1 else None,
                 "matches_first_pair": counts[0],
                 "parallelism": f"shard{world}",
                 "records_gathered_every_steps": G,
@@ -251,8 +382,11 @@ def main():
             ora = oracle_lib.load()
             nqs = min(args.cpu_sample_queries, n)
             tc = time.perf_counter()
-            ora.knn_hamming(qs[0][:nqs], ts[0])
+            oi, od = ora.knn_hamming(qs[0][:nqs], ts[0])
             tc = time.perf_counter() - tc
+            gi, gd = out["idx"][0, :nqs].cpu().numpy(), out["dist"][0, :nqs].cpu().numpy()
+            assert np.array_equal(gi, oi) and np.array_equal(gd, od), "the timed step's (idx, dist) differ from the CPU path"
+            rec["config"]["verified"] = f"(idx, dist) of the last timed step, pair 0, queries 0..{nqs - 1}: bit-exact vs the CPU port"
             rec["cpu_baseline"] = {
                 "value": nqs * n / tc,
                 "unit": "descriptor-pairs/s",
