@@ -256,6 +256,11 @@ int mlpl_ransac_last_stats(mlpl_ctx *ctx, long long stats[2]);
  * the (atomic) bookkeeping on.  Not for production use. */
 int mlpl_debug_dk_stats(mlpl_ctx *ctx, int enable, int stats[3]);
 
+/* Diagnostics: with option "hamming_stamps" = 1 every wave of the matrix-core Hamming kernel records {shader-clock cycles, 100 MHz
+ * real-time ticks, 32x32 tiles processed, start tick}; this copies up to max_items records of 4 x u64 of the LAST launch to `out`
+ * and returns their number.  In-kernel clock = cycles / ticks * 100 MHz.  Not for production use. */
+int mlpl_debug_hamming_stamps(mlpl_ctx *ctx, unsigned long long *out, int max_items);
+
 /* ---- cheirality / pose recovery --------------------------------------------------------------------------
  * Replaces poselib::getPoseTriangPts (P/source/pose_estim.cpp:913-946) = recoverPose
  * (five-point.cpp:150-338) with t_only empty: decomposeEssentialMat (:340-352), four triangulations,

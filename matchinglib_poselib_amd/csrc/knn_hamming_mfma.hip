@@ -123,9 +123,16 @@ __device__ __forceinline__ v16f mfma_fp4(uint4 a, uint4 b, v16f c) {
 template <int KS, int QT>
 __global__ __launch_bounds__(256, (KS >= 8 ? 2 : 3)) void knn_hamming_mfma_kernel(
     const uint4 *__restrict__ qfrag, size_t q_batch_u4, const uint4 *__restrict__ tfrag, size_t t_batch_u4, int nq, int nt,
-    int rows_per_split, int nsplit, int dshift, int qgroups, int n_items, uint2 *__restrict__ part) {
+    int rows_per_split, int nsplit, int dshift, int qgroups, int n_items, uint2 *__restrict__ part,
+    unsigned long long *__restrict__ stamps) {
     const int l = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
+    // diagnostics only (stamps != nullptr, "hamming_stamps" option): shader-clock and 100 MHz real-time deltas per wave
+    unsigned long long st_c = 0, st_r = 0;
+    if (stamps) {
+        st_c = __builtin_amdgcn_s_memtime();
+        st_r = __builtin_amdgcn_s_memrealtime();
+    }
     // XCD-aware work assignment.  Workgroups go round-robin to the 8 XCDs (each with its own L2), so workgroup L runs on
     // XCD L % 8.  The work items are ordered (batch item, split, query group) and XCD x takes the x-th contiguous eighth of
     // that order: with 8 image pairs per launch every XCD streams ONE pair's train fragments (1 MiB at C2) through its L2
@@ -248,14 +255,205 @@ __global__ __launch_bounds__(256, (KS >= 8 ? 2 : 3)) void knn_hamming_mfma_kerne
         const int q = (qt0 + t) * 32 + (l & 31);
         if (h == 0 && q < nq) part[((size_t)b * nsplit + split) * nq + q] = make_uint2(k0, k1);
     }
+    if (stamps && l == 0) {
+        unsigned long long *o = stamps + (size_t)item * 4;
+        o[0] = __builtin_amdgcn_s_memtime() - st_c;
+        o[1] = __builtin_amdgcn_s_memrealtime() - st_r;
+        // HW_REG_HW_ID (4): wave/simd/cu/sh/se ids; HW_REG_XCC_ID (20): the XCD
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+        o[2] = (unsigned long long)ntiles * QT | ((unsigned long long)(hw & 0xFFFFFu) << 32) | ((unsigned long long)(xcc & 15u) << 56);
+        o[3] = st_r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// KS = 4 (descriptors of 17..32 bytes: ORB-256) with the train tiles SHARED by the 4 waves of a workgroup through an LDS ring.
+// Why (tools/hamming_unit_probe3.hip, in-kernel clock stamps): a 1 KiB global_load_dwordx4 occupies the CU's one vector-memory/L1 path
+// (64 B/clk) for 16 cycles; with every wave fetching its own 4 KiB per tile the four SIMDs of a CU need 64 of the ~130 cycles a unit
+// costs them, and the fragment double buffer (32 VGPRs) holds the kernel at 3 waves per SIMD, where a wave's ~44-cycle MFMA issue
+// interval is not hidden (178-193 cycles per unit per SIMD measured; MFMA and VALU do not overlap on a SIMD, they add: ~90 + ~40).
+// Here wave w copies K-step w of every tile straight into LDS (global_load_lds_dwordx4: no staging registers, a quarter of the L1
+// traffic), all four read the tile back with ds_read_b128 (LDS: 256 B/clk), and 120 VGPRs give 4 waves per SIMD.
+// Ring protocol (NB = 4 slots of 4 KiB, prefetch distance D = 2, one s_barrier per tile): in iteration `it` a wave issues the copy of
+// tile it + 2, waits for its own piece of tile `it` (vmcnt counts LDS-DMA in issue order), and the barrier makes all four pieces
+// visible.  Slot (it + 2) % 4 was last read in iteration it - 2, and a wave that has passed the barrier of iteration it - 1 knows that
+// every wave has finished iteration it - 2 (its MFMAs consumed those reads), so the copy cannot overtake a reader.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int QT, int PRIO>
+__global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
+    const uint4 *__restrict__ qfrag, size_t q_batch_u4, const uint4 *__restrict__ tfrag, size_t t_batch_u4, int nq, int nt,
+    int rows_per_split, int nsplit, int dshift, int qblocks, int n_items, uint2 *__restrict__ part,
+    unsigned long long *__restrict__ stamps) {
+    constexpr int KS = 4, NB = 4;
+    __shared__ __attribute__((aligned(16))) uint4 ring[NB][KS * 64];
+    const int l = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned long long st_c = 0, st_r = 0;
+    if (stamps) {
+        st_c = __builtin_amdgcn_s_memtime();
+        st_r = __builtin_amdgcn_s_memrealtime();
+    }
+    // XCD-aware, as above, at workgroup granularity: item = (batch item, train split, block of 4 query groups)
+    const int per_xcd = (int)(gridDim.x >> 3);
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= n_items) return;  // workgroup-uniform: no wave of this workgroup reaches a barrier
+    const int qb = item % qblocks;
+    const int split = (item / qblocks) % nsplit;
+    const int b = item / (qblocks * nsplit);
+    const int qt0 = (qb * 4 + w) * QT;  // the query fragment buffer is padded to whole workgroups (zero rows)
+    const uint4 *qf = qfrag + (size_t)b * q_batch_u4 + (size_t)qt0 * KS * 64 + l;
+
+    uint4 bq[QT][KS];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bq[t][s] = qf[(size_t)(t * KS + s) * 64];
+
+    const int h = l >> 5;
+    v16f cinit;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) cinit[reg] = -(float)((reg & 3) + 8 * (reg >> 2) + 4 * h) * kEps;
+
+    const int row0 = split * rows_per_split;
+    const int row1 = min(nt, row0 + rows_per_split);
+    const int tile0 = row0 >> 5;
+    const int ntiles = (row1 - row0 + 31) >> 5;
+
+    float m1[QT], m2[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) m1[t] = m2[t] = -INFINITY;
+
+    // my piece (K-step w) of the split's first tile; a tile is KS * 64 uint4 = 4 KiB, contiguous
+    const uint4 *tbase = tfrag + (size_t)b * t_batch_u4 + (size_t)tile0 * KS * 64 + (size_t)w * 64;  // wave-uniform
+    auto copy_tile = [&](int t_rel) {
+        __builtin_amdgcn_global_load_lds((const void *)(tbase + (size_t)t_rel * KS * 64 + l),
+                                         (__attribute__((address_space(3))) void *)&ring[t_rel & (NB - 1)][w * 64], 16, 0, 0);
+    };
+    // The tile is read back with hand-written ds_read_b128: for a compiler-visible LDS load the waitcnt pass would first drain EVERY
+    // outstanding LDS-DMA (vmcnt(0): it cannot know that the copies in flight target other ring slots), which serialises the prefetch.
+    // The reads return in order, so K-step s is complete once at most 3 - s of them are outstanding.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4 *)&ring[0][0] + (uint32_t)l * 16u;
+    auto tile_body = [&](int slot, const v16f &c0) {
+        u32x4 r[KS];
+        const uint32_t addr = ring_lds + (uint32_t)slot * (KS * 1024u);
+        asm volatile(
+            "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+            : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+            : "v"(addr)
+            : "memory");
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(r[0]));
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r[1]));
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(r[2]));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[3]));
+        uint4 a[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[s] = make_uint4(r[s].x, r[s].y, r[s].z, r[s].w);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            v16f acc = mfma_fp4(a[0], bq[t][0], c0);
+#pragma unroll
+            for (int s = 1; s < KS; ++s) acc = mfma_fp4(a[s], bq[t][s], acc);
+            m1[t] += 32.0f * kEps;
+            m2[t] += 32.0f * kEps;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg += 4) {
+                const float s0 = __builtin_amdgcn_fmed3f(m1[t], acc[reg], acc[reg + 1]);
+                const float t0 = __builtin_fmaxf(__builtin_fmaxf(m1[t], acc[reg]), acc[reg + 1]);
+                const float s1 = __builtin_amdgcn_fmed3f(t0, acc[reg + 2], acc[reg + 3]);
+                m1[t] = __builtin_fmaxf(__builtin_fmaxf(t0, acc[reg + 2]), acc[reg + 3]);
+                m2[t] = __builtin_fmaxf(__builtin_fmaxf(m2[t], s0), s1);
+            }
+        }
+    };
+
+    copy_tile(0);
+    if (ntiles > 1) copy_tile(1);
+    // only the last tile of the train set can be ragged; it runs after the loop with its own C (rows >= nt start at -inf and stay there)
+    const bool ragged = row0 + ntiles * 32 > nt;
+    const int nfull = ragged ? ntiles - 1 : ntiles;
+    // own piece of tile `it` landed <=> at most the copies of the tiles after it are still in flight (LDS-DMA retires in issue order)
+    auto arrive = [&](int it) {
+        if (it + 2 < ntiles) {
+            copy_tile(it + 2);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else if (it + 1 < ntiles) {
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    };
+    // Optional (PRIO, off by default): the hardware arbitrates oldest-first among equal priorities, so with identical work items the four
+    // resident waves of a SIMD finish one after the other (28 -> 50 us measured).  Rotating s_setprio on a clock slice (2048 shader
+    // cycles ~ 1 us) by (time + wave slot) makes them finish together (38 -> 50 us) -- but the launch is no shorter: the SIMD's
+    // throughput is the same either way.  Kept as a measured negative result and a diagnostic.
+    const int wslot = (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3u);  // HW_ID.wave_id: slot within the SIMD
+    auto rotate_prio = [&]() {
+        if (!PRIO) return;
+        const int p = (int)(((unsigned)(__builtin_amdgcn_s_memtime() >> 11) + (unsigned)wslot) & 3u);
+        if (p == 0) __builtin_amdgcn_s_setprio(0);
+        else if (p == 1) __builtin_amdgcn_s_setprio(1);
+        else if (p == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    };
+    for (int it = 0; it < nfull; ++it) {
+        rotate_prio();
+        arrive(it);
+        tile_body(it & (NB - 1), cinit);
+    }
+    if (ragged) {
+        arrive(nfull);
+        const int tile_row0 = row0 + nfull * 32;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int lr = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            cinit[reg] = (tile_row0 + lr < nt) ? -(float)lr * kEps : -INFINITY;
+        }
+        tile_body(nfull & (NB - 1), cinit);
+    }
+
+    const float frame = (float)(32 * (ntiles - 1));
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        uint32_t k[2];
+        const float mm[2] = {m1[t], m2[t]};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (mm[j] == -INFINITY) {
+                k[j] = 0xFFFFFFFFu;
+            } else {
+                const float ip = rintf(mm[j]);
+                const int d = (64 * KS - (int)ip) >> 1;
+                const int lrow = (int)(frame - (mm[j] - ip) * 16384.0f);
+                k[j] = ((uint32_t)d << dshift) | (uint32_t)lrow;
+            }
+        }
+        const uint32_t o0 = __shfl_xor(k[0], 32), o1 = __shfl_xor(k[1], 32);
+        uint32_t k0 = k[0], k1 = k[1];
+        k1 = umed3(k0, k1, o0);
+        k0 = min(k0, o0);
+        k1 = umed3(k0, k1, o1);
+        k0 = min(k0, o1);
+        const int q = (qt0 + t) * 32 + (l & 31);
+        if (h == 0 && q < nq) part[((size_t)b * nsplit + split) * nq + q] = make_uint2(k0, k1);
+    }
+    if (stamps && l == 0) {
+        unsigned long long *o = stamps + ((size_t)item * 4 + w) * 4;
+        o[0] = __builtin_amdgcn_s_memtime() - st_c;
+        o[1] = __builtin_amdgcn_s_memrealtime() - st_r;
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+        o[2] = (unsigned long long)ntiles * QT | ((unsigned long long)(hw & 0xFFFFFu) << 32) | ((unsigned long long)(xcc & 15u) << 56);
+        o[3] = st_r;
+    }
 }
 
 template <int KS>
 void launch_mfma(int qt, dim3 grid, hipStream_t s, const uint4 *qf, size_t qb, const uint4 *tf, size_t tb, int nq, int nt, int rps,
-                 int nsplit, int dshift, int qgroups, int n_items, uint2 *part) {
+                 int nsplit, int dshift, int qgroups, int n_items, uint2 *part, unsigned long long *stamps) {
 #define MLPL_MFMA_LAUNCH(QT_)                                                                                                    \
     hipLaunchKernelGGL((knn_hamming_mfma_kernel<KS, QT_>), grid, dim3(256), 0, s, qf, qb, tf, tb, nq, nt, rps, nsplit, dshift, qgroups, \
-                       n_items, part)
+                       n_items, part, stamps)
     if constexpr (KS <= 4) {
         if (qt == 4) {
             MLPL_MFMA_LAUNCH(4);
@@ -288,12 +486,16 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     if (ctx->opt_hamming_mfma_qt > 0) qt = std::min(ctx->opt_hamming_mfma_qt, max_qt);
     while (ctx->opt_hamming_mfma_qt <= 0 && qt > 1 && (long long)((nqt + qt - 1) / qt) * batch < (long long)ctx->num_cus) qt >>= 1;
     const int qgroups = (nqt + qt - 1) / qt;  // wave-level work: one group of qt query tiles against one train split
-    const int q_tiles_padded = qgroups * qt;
+    const bool lds_ring = ks == 4 && ctx->opt_hamming_mfma_lds != 0;  // workgroup-level work: 4 query groups share the train tiles
+    const int qblocks = (qgroups + 3) / 4;
+    const int q_tiles_padded = lds_ring ? qblocks * 4 * qt : qgroups * qt;
     const int t_tiles = (nt + 31) / 32;
 
     // train splits: ~4 * opt waves per CU in flight, whole tiles, bounded so that the re-based fraction stays exact
-    const long long target_waves = 4LL * std::max(1, ctx->opt_hamming_mfma_blocks_per_cu) * ctx->num_cus;
-    long long want = (target_waves + (long long)qgroups * batch - 1) / ((long long)qgroups * batch);
+    const int bpc = lds_ring ? std::max(4, ctx->opt_hamming_mfma_blocks_per_cu) : std::max(1, ctx->opt_hamming_mfma_blocks_per_cu);
+    const long long target_waves = 4LL * bpc * ctx->num_cus;
+    const long long wave_groups = lds_ring ? 4LL * qblocks : (long long)qgroups;
+    long long want = (target_waves + wave_groups * batch - 1) / (wave_groups * batch);
     int nsplit = (int)std::max<long long>(1, std::min<long long>(want, t_tiles));
     int rps = ((nt + nsplit - 1) / nsplit + 31) / 32 * 32;
     rps = std::min(rps, kMaxRowsPerSplit);
@@ -302,7 +504,7 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
         set_error("knn_hamming: train set too large (nt=%d)", nt);
         return MLPL_E_BAD_INPUT;
     }
-    const long long items = (long long)qgroups * nsplit * batch;
+    const long long items = (lds_ring ? (long long)qblocks : (long long)qgroups) * nsplit * batch;  // workgroups (ring) or waves
     if (items > (1LL << 30)) {
         set_error("knn_hamming: problem too large for one launch (nq=%d nt=%d batch=%d)", nq, nt, batch);
         return MLPL_E_BAD_INPUT;
@@ -312,7 +514,7 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     int rc;
     const size_t q_u4 = (size_t)q_tiles_padded * ks * 64, t_u4 = (size_t)t_tiles * ks * 64;
     if ((rc = ws_get(ctx, WS_FRAG_Q, (size_t)batch * q_u4 * 16, &qf))) return rc;
-    if ((rc = ws_get(ctx, WS_FRAG_T, ((size_t)batch * t_u4 + (size_t)ks * 64) * 16, &tf))) return rc;  // + one spare tile
+    if ((rc = ws_get(ctx, WS_FRAG_T, ((size_t)batch * t_u4 + (size_t)ks * 64) * 16, &tf))) return rc;  // + one spare tile (register prefetch)
     if ((rc = ws_get(ctx, WS_PARTIAL, (size_t)batch * nsplit * nq * sizeof(uint2), &part))) return rc;
     const ExpandArgs qa{qw, q_batch_words, nq, q_tiles_padded, (uint4 *)qf}, ta{tw, t_batch_words, nt, t_tiles, (uint4 *)tf};
     const dim3 egrid((unsigned)((std::max(q_tiles_padded, t_tiles) * 64 + 255) / 256), batch, 2);
@@ -323,14 +525,39 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
         default: hipLaunchKernelGGL(hamming_expand_kernel<8>, egrid, dim3(256), 0, s, qa, ta, nw); break;
     }
     // 1-D grid, remapped in the kernel (XCD-aware); padded so that every XCD gets the same number of workgroups
-    const long long blocks = (items + 3) / 4;
+    const long long blocks = lds_ring ? items : (items + 3) / 4;
     dim3 grid((unsigned)((blocks + 7) / 8 * 8));
+    unsigned long long *stamps = nullptr;
+    ctx->dbg_stamp_items = 0;
+    if (ctx->opt_hamming_stamps) {
+        void *sp = nullptr;
+        const long long waves = lds_ring ? items * 4 : items;
+        if ((rc = ws_get(ctx, WS_DEBUG, (size_t)waves * 32, &sp))) return rc;
+        MLPL_HIP_TRY(hipMemsetAsync(sp, 0, (size_t)waves * 32, s));
+        stamps = (unsigned long long *)sp;
+        ctx->dbg_stamp_items = (int)waves;
+    }
     prof_mark(ctx, MLPL_PROF_KNN_HAMMING, 0, s);
+    if (lds_ring) {
+#define MLPL_RING_LAUNCH(QT_)                                                                                                          \
+    do {                                                                                                                               \
+        if (ctx->opt_hamming_mfma_prio)                                                                                                \
+            hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<QT_, 1>), grid, dim3(256), 0, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, \
+                               t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps);                          \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<QT_, 0>), grid, dim3(256), 0, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, \
+                               t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps);                          \
+    } while (0)
+        if (qt == 4) MLPL_RING_LAUNCH(4);
+        else if (qt == 2) MLPL_RING_LAUNCH(2);
+        else MLPL_RING_LAUNCH(1);
+#undef MLPL_RING_LAUNCH
+    } else
     switch (ks) {
-        case 1: launch_mfma<1>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qgroups, (int)items, (uint2 *)part); break;
-        case 2: launch_mfma<2>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qgroups, (int)items, (uint2 *)part); break;
-        case 4: launch_mfma<4>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qgroups, (int)items, (uint2 *)part); break;
-        default: launch_mfma<8>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qgroups, (int)items, (uint2 *)part); break;
+        case 1: launch_mfma<1>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qgroups, (int)items, (uint2 *)part, stamps); break;
+        case 2: launch_mfma<2>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qgroups, (int)items, (uint2 *)part, stamps); break;
+        case 4: launch_mfma<4>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qgroups, (int)items, (uint2 *)part, stamps); break;
+        default: launch_mfma<8>(qt, grid, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit, dshift, qgroups, (int)items, (uint2 *)part, stamps); break;
     }
     prof_mark(ctx, MLPL_PROF_KNN_HAMMING, 1, s);
     *rps_out = rps;

@@ -45,6 +45,7 @@ enum WsSlot {
     WS_FRAG_Q,    // fp4 MFMA fragments of the query / train descriptors (knn_hamming_mfma.hip)
     WS_FRAG_T,
     WS_PIPE,      // per-pair pipeline block (mlpl_pair_pose_dev)
+    WS_DEBUG,     // diagnostics (per-wave clock stamps)
     WS_NUM_SLOTS
 };
 
@@ -68,6 +69,10 @@ struct mlpl_ctx {
     int opt_hamming_blocks_per_cu;  // grid sizing target
     int opt_hamming_mfma_blocks_per_cu;  // grid sizing target of the matrix-core kernel (4-wave blocks)
     int opt_hamming_mfma_qt;             // query tiles per wave (0 = automatic, else 1, 2 or 4)
+    int opt_hamming_mfma_lds;       // 1 (default) = 32-byte descriptors use the LDS-ring matrix-core kernel, 0 = the register-prefetch one
+    int opt_hamming_mfma_prio;      // 1 = the LDS-ring kernel rotates wave priorities on a clock slice (equal finish times per SIMD; measured: no faster). Default 0
+    int opt_hamming_stamps;         // diagnostics: the matrix-core kernel records per-wave clock stamps (mlpl_debug_hamming_stamps)
+    int dbg_stamp_items;
     int opt_ransac_chunk;           // hypotheses per device pass (0 = 32768)
     int opt_ransac_lazy_sums;       // 1 (default) = division-free inlier counts + error sums only for models that can still win
     int opt_solver_polish;          // 1 (default) = Gauss-Newton polish of every 5-point solution on the cubic constraints
