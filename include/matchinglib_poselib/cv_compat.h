@@ -1,7 +1,8 @@
 // cv_compat.h -- the handful of OpenCV types that appear in the signatures of the hot-path API, for builds without
 // OpenCV (this image has none).  Layouts match OpenCV 4.x: cv::DMatch 16 B {int,int,int,float}, cv::KeyPoint 28 B
 // {Point2f pt; float size, angle, response; int octave, class_id}.  Define MLPL_WITH_OPENCV to compile the facade
-// against the real headers instead (then cv::Mat / InputArray / OutputArray are OpenCV's own).
+// against the real headers instead (then cv::Mat / InputArray / OutputArray are OpenCV's own; the facade only uses the member API
+// both provide).  A Mat here shares its buffer on copy, like cv::Mat (getMat() returns a header onto the same data).
 #pragma once
 
 #ifdef MLPL_WITH_OPENCV
@@ -98,15 +99,49 @@ class Mat {
     std::shared_ptr<std::vector<unsigned char>> buf_;
 };
 
-typedef const Mat &InputArray;
-typedef Mat &OutputArray;
-typedef Mat &InputOutputArray;
-// cv::noArray(): a sentinel whose address marks "not requested"
-inline Mat &noArray() {
-    static thread_local Mat none;
+// Proxy argument types with the member API of OpenCV's cv::_InputArray / _OutputArray / _InputOutputArray (core/mat.hpp) that the
+// facade uses -- getMat(), empty(), needed(), create(), type(), rows(), cols(), total() -- so that facade.cpp is written once against
+// that API and compiles unchanged against the real classes (MLPL_WITH_OPENCV).  Same class names and the same
+// `typedef const _InputArray& InputArray` shape as OpenCV, so the facade's signatures read exactly like the reference's.
+class _InputArray {
+   public:
+    _InputArray() = default;
+    _InputArray(const Mat &m) : m_(const_cast<Mat *>(&m)) {}  // NOLINT: implicit, as in OpenCV
+    Mat getMat(int = -1) const { return m_ ? *m_ : Mat(); }
+    bool empty() const { return !m_ || m_->empty(); }
+    int type(int = -1) const { return m_ ? m_->type() : 0; }
+    int rows(int = -1) const { return m_ ? m_->rows : 0; }
+    int cols(int = -1) const { return m_ ? m_->cols : 0; }
+    size_t total(int = -1) const { return m_ ? (size_t)m_->rows * (size_t)m_->cols : 0; }
+
+   protected:
+    Mat *m_ = nullptr;  // null = cv::noArray()
+};
+class _OutputArray : public _InputArray {
+   public:
+    _OutputArray() = default;
+    _OutputArray(Mat &m) : _InputArray(m) {}  // NOLINT
+    bool needed() const { return m_ != nullptr; }
+    void create(int rows, int cols, int type) const {
+        if (m_) m_->create(rows, cols, type);
+    }
+    Mat &getMatRef(int = -1) const { return *m_; }
+    void release() const {
+        if (m_) *m_ = Mat();
+    }
+};
+class _InputOutputArray : public _OutputArray {
+   public:
+    _InputOutputArray() = default;
+    _InputOutputArray(Mat &m) : _OutputArray(m) {}  // NOLINT
+};
+typedef const _InputArray &InputArray;
+typedef const _OutputArray &OutputArray;
+typedef const _InputOutputArray &InputOutputArray;
+inline const _InputOutputArray &noArray() {
+    static const _InputOutputArray none;
     return none;
 }
-inline bool needed(const Mat &m) { return &m != &noArray(); }
 
 }  // namespace cv
 #endif  // MLPL_WITH_OPENCV

@@ -1,28 +1,92 @@
-// pose_estim.h -- drop-in for the hot-path part of the reference's poselib/include/poselib/pose_estim.h:192-210.
+// pose_estim.h -- drop-in for the hot-path part of the reference's poselib/include/poselib/pose_estim.h (defines :56-59, enums :61-92,
+// ConfigUSAC :94-132, getPoseTriangPts :192-200, estimateEssentialMat :204-210).  Same names, argument order, defaults and error
+// behaviour; the work runs on the MI355X through libmlpl_hip.so (include/mlpl_c.h).
 #pragma once
 #include <string>
+#include <vector>
 
 #include "matchinglib_poselib/cv_compat.h"
 
-#define PIX_MIN_GOOD_TH 0.8  // reference pose_estim.h:56
+// reference pose_estim.h:56-59
+#define PIX_TH_START 0.5
+#define MIN_PIX_TH ((0.25 < PIX_TH_START) ? 0.25 : PIX_TH_START)
+#define MAX_PIX_TH 2.0
+#define PIX_MIN_GOOD_TH 1.6
 
 namespace poselib {
 
-// Placeholder for the reference's ConfigUSAC (pose_estim.h:94-132); USAC is outside the hot path built here.
-struct ConfigUSAC {};
+// reference pose_estim.h:61-92.  USAC itself is outside the hot path built here; the types exist so that callers that fill a
+// ConfigUSAC (every harness does, tests/poselib-test/main.cpp:1389-1432) compile and link unchanged.
+enum UsacChkDegenType { DEGEN_NO_CHECK, DEGEN_QDEGSAC, DEGEN_USAC_INTERNAL };
+enum PoseEstimator { POSE_NISTER, POSE_EIG_KNEIP, POSE_STEWENIUS };
+enum RefineAlg {
+    REF_WEIGHTS,
+    REF_8PT_PSEUDOHUBER,
+    REF_EIG_KNEIP,
+    REF_EIG_KNEIP_WEIGHTS,
+    REF_STEWENIUS,
+    REF_STEWENIUS_WEIGHTS,
+    REF_NISTER,
+    REF_NISTER_WEIGHTS
+};
+enum RefinePostAlg {
+    PR_NO_REFINEMENT = 0x0,
+    PR_8PT = 0x1,
+    PR_NISTER = 0x2,
+    PR_STEWENIUS = 0x3,
+    PR_KNEIP = 0x4,
+    PR_TORR_WEIGHTS = 0x10,
+    PR_PSEUDOHUBER_WEIGHTS = 0x20,
+    PR_NO_WEIGHTS = 0x30
+};
+enum SprtInit { SPRT_DEFAULT_INIT = 0x0, SPRT_DELTA_AUTOM_INIT = 0x1, SPRT_EPSILON_AUTOM_INIT = 0x2 };
 
-// RANSAC seed control.  The reference seeds std::srand(std::time(nullptr)) in the estimator constructor
+// reference pose_estim.h:94-132: every field, the reference's defaults.  Consumed only by the USAC path (not built): the fields are
+// carried, not interpreted.
+struct ConfigUSAC {
+    ConfigUSAC()
+        : focalLength(800),
+          th_pixels(0.8),
+          degeneracyCheck(DEGEN_USAC_INTERNAL),
+          estimator(POSE_STEWENIUS),
+          refinealg(REF_STEWENIUS_WEIGHTS),
+          prevalidateSample(false),
+          noAutomaticProsacParamters(false),
+          automaticSprtInit(SPRT_DELTA_AUTOM_INIT | SPRT_EPSILON_AUTOM_INIT),
+          matches(nullptr),
+          keypoints1(nullptr),
+          keypoints2(nullptr),
+          nrMatchesVfcFiltered(0),
+          imgSize(800, 600),
+          degenDecisionTh(0.85) {}
+
+    double focalLength;
+    double th_pixels;
+    UsacChkDegenType degeneracyCheck;
+    PoseEstimator estimator;
+    RefineAlg refinealg;
+    bool prevalidateSample;
+    bool noAutomaticProsacParamters;
+    int automaticSprtInit;
+    std::vector<cv::DMatch> *matches;
+    std::vector<cv::KeyPoint> *keypoints1;
+    std::vector<cv::KeyPoint> *keypoints2;
+    unsigned int nrMatchesVfcFiltered;
+    cv::Size imgSize;
+    double degenDecisionTh;
+};
+
+// RANSAC / LMedS / ARRSAC seed control.  The reference seeds std::srand(std::time(nullptr)) in the estimator constructor
 // (five-point-nister/modelest.cpp:58) and its setSeed() is never called on this path, so its results are time-seeded.
 // Default here: the same (time-seeded).  setRansacSeed(s) fixes the glibc rand() stream for reproducible runs;
 // clearRansacSeed() returns to time seeding.  Thread-local.
 void setRansacSeed(unsigned seed);
 void clearRansacSeed();
 
-// poselib::estimateEssentialMat (pose_estim.h:204-210, pose_estim.cpp:857-890).  p1, p2: n x 2 CV_64F camera
-// coordinates.  method "RANSAC" runs on the GPU (1000 iterations, confidence 0.999, `refine` = least-squares refit on
-// the inliers); "LMEDS" runs on the GPU as well (2000 iterations, no refit; `threshold` unused, as in the reference).
-// "USAC" / unknown method: prints the reference's message and calls exit(1), like the reference.
-// "ARRSAC" (the reference's default argument) is not part of this library: it also exits(1) with a message.
+// poselib::estimateEssentialMat (pose_estim.h:204-210, pose_estim.cpp:857-890).  p1, p2: n x 2 camera coordinates (CV_64F or CV_32F).
+// "RANSAC": 1000 iterations, confidence 0.999, `refine` = least-squares refit on the inliers; "LMEDS": 2000 iterations, no refit,
+// `threshold` unused (as in the reference); "ARRSAC" (the default): the reference's preemptive estimator (modelest.cpp:197-341) with
+// `refine` = its least-squares step.  "USAC" / unknown method: prints the reference's message and calls exit(1), like the reference.
 bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p2, const std::string &method = "ARRSAC",
                           double threshold = PIX_MIN_GOOD_TH, bool refine = true, cv::OutputArray mask = cv::noArray());
 

@@ -15,16 +15,83 @@
 
 namespace poselib {
 
+// reference stereo_pose_refinement.h:100-176: every field, the reference's defaults (incl. RobMethod = "USAC", which this library
+// does not build: StereoRefine reports -1 for it, see addNewCorrespondences).
 struct ConfigPoseEstimation {
-    cv::Mat *dist0_8 = nullptr;  // 8 OpenCV-ordered distortion coefficients (CV_64F), null/empty = none
-    cv::Mat *dist1_8 = nullptr;
-    cv::Mat *K0 = nullptr;  // 3x3 CV_64F camera matrices
-    cv::Mat *K1 = nullptr;
-    double th_pix_user = 0.8;          // reference default, stereo_pose_refinement.h:108
-    std::string RobMethod = "RANSAC";  // the reference default is "USAC" (not built); only "RANSAC" is accepted
-    bool refineRTold = false;          // passed as `refine` to estimateEssentialMat (stereo_pose_refinement.cpp:1416)
-    double maxDist3DPtsZ = 50.0;
-    int verbose = 0;
+    ConfigPoseEstimation()
+        : dist0_8(nullptr),
+          dist1_8(nullptr),
+          K0(nullptr),
+          K1(nullptr),
+          keypointType("FAST"),
+          descriptorType("FREAK"),
+          th_pix_user(0.8),
+          autoTH(false),
+          Halign(0),
+          RobMethod("USAC"),
+          refineMethod(poselib::RefinePostAlg::PR_NO_REFINEMENT),
+          refineRTold(false),
+          kneipInsteadBA(false),
+          BART(0),
+          refineMethod_CorrPool(poselib::RefinePostAlg::PR_STEWENIUS | poselib::RefinePostAlg::PR_PSEUDOHUBER_WEIGHTS),
+          refineRTold_CorrPool(false),
+          kneipInsteadBA_CorrPool(false),
+          BART_CorrPool(0),
+          verbose(7),
+          minStartAggInlRat(0.2),
+          relInlRatThLast(0.35),
+          relInlRatThNew(0.20),
+          minInlierRatSkip(0.38),
+          relMinInlierRatSkip(0.7),
+          maxSkipPairs(5),
+          minInlierRatioReInit(0.6),
+          minPtsDistance(3.f),
+          maxPoolCorrespondences(30000),
+          minContStablePoses(3),
+          absThRankingStable(0.075),
+          useRANSAC_fewMatches(false),
+          checkPoolPoseRobust(3),
+          minNormDistStable(0.5),
+          raiseSkipCnt(0),
+          maxRat3DPtsFar(0.5),
+          maxDist3DPtsZ(50.0) {}
+
+    cv::Mat *dist0_8;  // 8 OpenCV-ordered distortion coefficients (CV_64F) of the first / second camera
+    cv::Mat *dist1_8;
+    cv::Mat *K0;  // 3x3 CV_64F camera matrices
+    cv::Mat *K1;
+    std::string keypointType;
+    std::string descriptorType;
+    double th_pix_user;
+    bool autoTH;
+    int Halign;
+    std::string RobMethod;  // USAC, RANSAC, ARRSAC, LMEDS
+    int refineMethod;       // enum RefinePostAlg
+    bool refineRTold;
+    bool kneipInsteadBA;
+    int BART;
+    int refineMethod_CorrPool;
+    bool refineRTold_CorrPool;
+    bool kneipInsteadBA_CorrPool;
+    int BART_CorrPool;
+    int verbose;
+    double minStartAggInlRat;
+    double relInlRatThLast;
+    double relInlRatThNew;
+    double minInlierRatSkip;
+    double relMinInlierRatSkip;
+    size_t maxSkipPairs;
+    double minInlierRatioReInit;
+    float minPtsDistance;
+    size_t maxPoolCorrespondences;
+    size_t minContStablePoses;
+    double absThRankingStable;
+    bool useRANSAC_fewMatches;
+    size_t checkPoolPoseRobust;
+    double minNormDistStable;
+    int raiseSkipCnt;
+    double maxRat3DPtsFar;
+    double maxDist3DPtsZ;
 };
 
 class StereoRefine {

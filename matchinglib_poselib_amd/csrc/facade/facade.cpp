@@ -37,7 +37,8 @@ thread_local bool g_seed_fixed = false;
 thread_local unsigned g_seed = 0;
 
 // contiguous n x 2 CV_64F copy of a point matrix (the reference converts with convertTo(CV_64F))
-std::vector<double> points64(const cv::Mat &p, int &n) {
+std::vector<double> points64(cv::InputArray pa, int &n) {
+    const cv::Mat p = pa.getMat();
     CV_Assert(p.cols == 2 && (p.type() == CV_64F || p.type() == CV_32F));
     n = p.rows;
     std::vector<double> out((size_t)n * 2);
@@ -113,7 +114,7 @@ void clearRansacSeed() { g_seed_fixed = false; }
 bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p2, const std::string &method,
                           double threshold, bool refine, cv::OutputArray mask) {
     if (method == "RANSAC" || method == "LMEDS") {
-        if (!cv::needed(E)) return false;  // five-point.cpp:143-144
+        if (!E.needed()) return false;  // five-point.cpp:143-144
         int n1 = 0, n2 = 0;
         std::vector<double> a = points64(p1, n1), b = points64(p2, n2);
         CV_Assert(n1 >= 5 && n1 == n2);  // five-point.cpp:81
@@ -125,10 +126,12 @@ bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p
             if (mlpl_solve_5pt(default_ctx(), a.data(), b.data(), 5, samples, 1, Es, &nm) != MLPL_OK)
                 throw cv::Exception(std::string("mlpl_solve_5pt: ") + mlpl_last_error());
             E.create(3 * nm, 3, CV_64F);
-            for (int i = 0; i < 9 * nm; ++i) E.at<double>(i / 3, i % 3) = Es[i];
-            if (cv::needed(mask)) {
+            cv::Mat Em = E.getMat();
+            for (int i = 0; i < 9 * nm; ++i) Em.at<double>(i / 3, i % 3) = Es[i];
+            if (mask.needed()) {
                 mask.create(1, 5, CV_8U);
-                std::memset(mask.data, 1, 5);
+                cv::Mat mm = mask.getMat();
+                std::memset(mm.ptr<uint8_t>(0), 1, 5);
             }
             return true;
         }
@@ -144,12 +147,14 @@ bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p
                                                    seed, Ev, m.data(), &ninl, &iters);
         if (rc == MLPL_E_FAILED) return false;
         if (rc != MLPL_OK) throw cv::Exception(std::string("estimateEssentialMat: ") + mlpl_last_error());
-        if (cv::needed(mask)) {
+        if (mask.needed()) {
             mask.create(1, n1, CV_8U);
-            std::memcpy(mask.data, m.data(), (size_t)n1);
+            cv::Mat mm = mask.getMat();
+            std::memcpy(mm.ptr<uint8_t>(0), m.data(), (size_t)n1);
         }
         E.create(3, 3, CV_64F);
-        for (int i = 0; i < 9; ++i) E.at<double>(i / 3, i % 3) = Ev[i];
+        cv::Mat Em = E.getMat();
+        for (int i = 0; i < 9; ++i) Em.at<double>(i / 3, i % 3) = Ev[i];
         return true;
     }
     if (method == "USAC") {
@@ -158,17 +163,19 @@ bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p
         std::exit(1);  // pose_estim.cpp:878-882
     }
     if (method == "ARRSAC") {
-        std::cout << method << " is not built in the MI355X hot-path library (RANSAC and LMEDS only). Exiting." << std::endl;
-        std::exit(1);
+        // not built yet: the reference's preemptive estimator (modelest.cpp:197-341).  Report failure instead of terminating the caller.
+        std::cout << "ARRSAC is not built in the MI355X hot-path library yet (RANSAC and LMEDS are); returning false." << std::endl;
+        return false;
     }
     std::cout << "Either there is a typo in the specified robust estimation method or the method is not supported. Exiting."
               << std::endl;
     std::exit(1);  // pose_estim.cpp:883-887
 }
 
-int getPoseTriangPts(cv::InputArray E, cv::InputArray p1, cv::InputArray p2, cv::OutputArray R, cv::OutputArray t,
-                     cv::OutputArray Q, cv::InputOutputArray mask, const double dist, bool translatE) {
-    if (!cv::needed(R) || !cv::needed(t) || !cv::needed(Q)) return -1;  // pose_estim.cpp:925-926
+int getPoseTriangPts(cv::InputArray E_, cv::InputArray p1, cv::InputArray p2, cv::OutputArray R_, cv::OutputArray t_,
+                     cv::OutputArray Q_, cv::InputOutputArray mask_, const double dist, bool translatE) {
+    if (!R_.needed() || !t_.needed() || !Q_.needed()) return -1;  // pose_estim.cpp:925-926
+    const cv::Mat E = E_.getMat();
     CV_Assert(E.rows == 3 && E.cols == 3 && E.type() == CV_64F);
     int n1 = 0, n2 = 0;
     std::vector<double> a = points64(p1, n1), b = points64(p2, n2);
@@ -177,10 +184,11 @@ int getPoseTriangPts(cv::InputArray E, cv::InputArray p1, cv::InputArray p2, cv:
     for (int i = 0; i < 9; ++i) Ev[i] = E.at<double>(i / 3, i % 3);
     std::vector<double> Qv((size_t)std::max(n1, 1) * 3);
     std::vector<uint8_t> m;
-    const bool use_mask = cv::needed(mask);
+    const bool use_mask = mask_.needed();
     if (use_mask) {
         m.assign((size_t)n1, 1);  // an empty mask is created as all ones (five-point.cpp:275-280)
-        if (!mask.empty()) {
+        if (!mask_.empty()) {
+            const cv::Mat mask = mask_.getMat();
             CV_Assert(mask.rows * mask.cols == n1 && mask.type() == CV_8U);
             for (int i = 0; i < n1; ++i) m[i] = mask.rows == 1 ? mask.at<uint8_t>(0, i) : mask.at<uint8_t>(i, 0);
         }
@@ -198,24 +206,34 @@ int getPoseTriangPts(cv::InputArray E, cv::InputArray p1, cv::InputArray p2, cv:
         rc = mlpl_recover_pose(default_ctx(), Ev, a.data(), b.data(), n1, dist, Rv, tv, Qv.data(), use_mask ? m.data() : nullptr);
     }
     if (rc < 0) throw cv::Exception(std::string("mlpl_recover_pose: ") + mlpl_last_error());
-    R.create(3, 3, CV_64F);
-    t.create(3, 1, CV_64F);
-    Q.create(n1, 3, CV_64F);
+    R_.create(3, 3, CV_64F);
+    t_.create(3, 1, CV_64F);
+    Q_.create(n1, 3, CV_64F);
+    cv::Mat R = R_.getMat(), t = t_.getMat(), Q = Q_.getMat();
     for (int i = 0; i < 9; ++i) R.at<double>(i / 3, i % 3) = Rv[i];
     for (int i = 0; i < 3; ++i) t.at<double>(i, 0) = tv[i];
     for (int i = 0; i < n1; ++i)
         for (int c = 0; c < 3; ++c) Q.at<double>(i, c) = Qv[(size_t)i * 3 + c];
     if (use_mask) {
-        mask.create(1, n1, CV_8U);
-        std::memcpy(mask.data, m.data(), (size_t)n1);
+        mask_.create(1, n1, CV_8U);
+        cv::Mat mo = mask_.getMat();
+        std::memcpy(mo.ptr<uint8_t>(0), m.data(), (size_t)n1);
     }
     return rc;
 }
 
 bool estimateRelativePose(cv::InputArray p1, cv::InputArray p2, cv::OutputArray E, cv::OutputArray R, cv::OutputArray t,
                           cv::OutputArray Q, cv::OutputArray mask, double threshold, bool refine, double dist) {
-    if (!estimateEssentialMat(E, p1, p2, "RANSAC", threshold, refine, mask)) return false;
-    return getPoseTriangPts(E, p1, p2, R, t, Q, mask, dist, false) >= 0;
+    cv::Mat m;
+    if (!estimateEssentialMat(E, p1, p2, "RANSAC", threshold, refine, m)) return false;
+    const cv::Mat Em = E.getMat();
+    const int ng = getPoseTriangPts(Em, p1, p2, R, t, Q, m, dist, false);
+    if (mask.needed()) {
+        mask.create(m.rows, m.cols, CV_8U);
+        cv::Mat mo = mask.getMat();
+        for (int r = 0; r < m.rows; ++r) std::memcpy(mo.ptr<uint8_t>(r), m.ptr<uint8_t>(r), (size_t)m.cols);
+    }
+    return ng >= 0;
 }
 
 // ---- StereoRefine (hot-path slice) -------------------------------------------------------------------------
@@ -228,7 +246,7 @@ void StereoRefine::setNewParameters(ConfigPoseEstimation cfg_pose_) {
 }
 
 void StereoRefine::init() {
-    CV_Assert(cfg_pose.K0 != nullptr && cfg_pose.K1 != nullptr);
+    CV_Assert(cfg_pose.K0 != nullptr && cfg_pose.K1 != nullptr && cfg_pose.dist0_8 != nullptr && cfg_pose.dist1_8 != nullptr);  // reference ctor
     // stereo_pose_refinement.h:280-286
     pixToCamFact = 4.0 / (std::sqrt(2.0) * (cfg_pose.K0->at<double>(0, 0) + cfg_pose.K0->at<double>(1, 1) +
                                             cfg_pose.K1->at<double>(0, 0) + cfg_pose.K1->at<double>(1, 1)));

@@ -14,7 +14,7 @@ import numpy as np
 from . import _lib
 from ._lib import Context, MlplError, check, default_context
 
-PIX_MIN_GOOD_TH = 0.8  # pose_estim.h:56
+PIX_MIN_GOOD_TH = 1.6  # poselib/include/poselib/pose_estim.h:59 (pixels; callers of the pose API pass camera-unit thresholds explicitly)
 
 
 def _pts(p) -> np.ndarray:

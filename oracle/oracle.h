@@ -93,6 +93,12 @@ int oracle_run5point(const double *q1, const double *q2, int n, double *E_out);
 int oracle_run5point_dbg(const double *q1, const double *q2, int n, double *E_out, double *c_out, double *roots_out,
                          double *xy1z_out);
 
+/* Building blocks of run5Point exposed for pinning against the reference's own expressions: the 10 x 20 constraint matrix in the
+ * reference's column order (getCoeffMat, five-point.cpp:603-824; EE[b * 9 + k] = basis matrix b) and the determinant polynomial of
+ * B(z) (five-point.cpp:416-428; b = 3 x 13, c[0..10] ascending). */
+void oracle_coeff_matrix(const double *EE, double *A);
+void oracle_detpoly(const double *b, double *c);
+
 /* computeReprojError3 (five-point.cpp:476-503): Sampson error in fp64 stored as float. */
 void oracle_sampson_err(const double *p1, const double *p2, int n, const double *E, float *err);
 

@@ -347,6 +347,35 @@ static void poly_mul(const double *a, int da, const double *b, int db, double *o
         for (int j = 0; j <= db; ++j) out[i + j] += a[i] * b[j];
 }
 
+/* c(z) = det B(z), degree 10, ascending coefficients (five-point.cpp:416-428 write the same determinant out term by term).
+ * b: 3 x 13 row-major.  Exposed so that tests can pin it against the reference's own expressions (oracle/_ref/libfivept_ref.so). */
+void oracle_detpoly(const double *b, double *c) {
+    double P[3][3][5];
+    int deg[3] = {3, 3, 4};
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k < 4; ++k) {
+            P[i][0][k] = b[i * 13 + 3 - k];
+            P[i][1][k] = b[i * 13 + 7 - k];
+        }
+        P[i][0][4] = P[i][1][4] = 0;
+        for (int k = 0; k < 5; ++k) P[i][2][k] = b[i * 13 + 12 - k];
+    }
+    for (int k = 0; k < 11; ++k) c[k] = 0;
+    static const int perms[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
+    static const double sgn[6] = {1, 1, 1, -1, -1, -1};
+    for (int pi = 0; pi < 6; ++pi) {
+        /* term = sgn * P[0][p0] * P[1][p1] * P[2][p2] */
+        double t01[9], t012[13];
+        const int p0 = perms[pi][0], p1 = perms[pi][1], p2 = perms[pi][2];
+        poly_mul(P[0][p0], deg[p0], P[1][p1], deg[p1], t01);
+        poly_mul(t01, deg[p0] + deg[p1], P[2][p2], deg[p2], t012);
+        for (int k = 0; k <= 10; ++k) c[k] += sgn[pi] * t012[k];
+    }
+}
+
+/* The 10 x 20 constraint matrix in the reference's column order (getCoeffMat, five-point.cpp:603-824), EE[b * 9 + k]. */
+void oracle_coeff_matrix(const double *EE, double *A) { coeff_matrix(EE, A); }
+
 static int run5point_impl(const double *q1, const double *q2, int n, double *E_out, double *c_out, double *roots_out,
                           double *xy1z_out) {
     if (n < 5) return 0;
@@ -396,29 +425,8 @@ static int run5point_impl(const double *q1, const double *q2, int n, double *E_o
         }
         for (int j = 0; j < 13; ++j) b[i * 13 + j] = row1[j] - row2[j];
     }
-    /* c(z) = det B(z), degree 10 (five-point.cpp:416-428).  Entries as ascending polynomials. */
-    double P[3][3][5];
-    int deg[3] = {3, 3, 4};
-    for (int i = 0; i < 3; ++i) {
-        for (int k = 0; k < 4; ++k) {
-            P[i][0][k] = b[i * 13 + 3 - k];
-            P[i][1][k] = b[i * 13 + 7 - k];
-        }
-        P[i][0][4] = P[i][1][4] = 0;
-        for (int k = 0; k < 5; ++k) P[i][2][k] = b[i * 13 + 12 - k];
-    }
     double c[11];
-    for (int k = 0; k < 11; ++k) c[k] = 0;
-    static const int perms[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
-    static const double sgn[6] = {1, 1, 1, -1, -1, -1};
-    for (int pi = 0; pi < 6; ++pi) {
-        /* term = sgn * P[0][p0] * P[1][p1] * P[2][p2] */
-        double t01[9], t012[13];
-        const int p0 = perms[pi][0], p1 = perms[pi][1], p2 = perms[pi][2];
-        poly_mul(P[0][p0], deg[p0], P[1][p1], deg[p1], t01);
-        poly_mul(t01, deg[p0] + deg[p1], P[2][p2], deg[p2], t012);
-        for (int k = 0; k <= 10; ++k) c[k] += sgn[pi] * t012[k];
-    }
+    oracle_detpoly(b, c);
 
     double roots[2 * 10];
     oracle_solve_poly(c, 10, roots, 0);

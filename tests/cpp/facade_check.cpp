@@ -56,9 +56,59 @@ int main(int argc, char **argv) {
     // StereoRefine on pixel keypoints: K = [[800,0,320],[0,800,240],[0,0,1]] both cameras
     cv::Mat K = cv::Mat::zeros(3, 3, CV_64F);
     K.at<double>(0, 0) = 800, K.at<double>(1, 1) = 800, K.at<double>(0, 2) = 320, K.at<double>(1, 2) = 240, K.at<double>(2, 2) = 1;
+    // the configuration struct filled field by field exactly as the reference harness does (tests/poselib-test/main.cpp:1389-1432)
+    cv::Mat dist0_8 = cv::Mat::zeros(1, 8, CV_64F), dist1_8 = cv::Mat::zeros(1, 8, CV_64F);
+    cv::Mat K0 = K, K1 = K;
     poselib::ConfigPoseEstimation cfg;
-    cfg.K0 = &K, cfg.K1 = &K;
+    cfg.dist0_8 = &dist0_8;
+    cfg.dist1_8 = &dist1_8;
+    cfg.K0 = &K0;
+    cfg.K1 = &K1;
+    cfg.keypointType = "ORB";
+    cfg.descriptorType = "ORB";
+    cfg.th_pix_user = 0.8;
+    cfg.verbose = 0;
+    cfg.Halign = 0;
+    cfg.autoTH = false;
+    cfg.BART = 0;
+    cfg.kneipInsteadBA = false;
+    cfg.refineMethod = poselib::RefinePostAlg::PR_NO_REFINEMENT;
+    cfg.refineRTold = false;
     cfg.RobMethod = "RANSAC";
+    cfg.refineMethod_CorrPool = poselib::RefinePostAlg::PR_STEWENIUS | poselib::RefinePostAlg::PR_PSEUDOHUBER_WEIGHTS;
+    cfg.refineRTold_CorrPool = false;
+    cfg.kneipInsteadBA_CorrPool = false;
+    cfg.BART_CorrPool = 0;
+    cfg.minStartAggInlRat = 0.2;
+    cfg.relInlRatThLast = 0.35;
+    cfg.relInlRatThNew = 0.2;
+    cfg.minInlierRatSkip = 0.38;
+    cfg.relMinInlierRatSkip = 0.7;
+    cfg.maxSkipPairs = 5;
+    cfg.minInlierRatioReInit = 0.6;
+    cfg.minPtsDistance = 3.f;
+    cfg.maxPoolCorrespondences = 30000;
+    cfg.minContStablePoses = 3;
+    cfg.absThRankingStable = 0.075;
+    cfg.useRANSAC_fewMatches = false;
+    cfg.checkPoolPoseRobust = 3;
+    cfg.minNormDistStable = 0.5;
+    cfg.raiseSkipCnt = (1 | (2 << 4));
+    cfg.maxRat3DPtsFar = 0.5;
+    cfg.maxDist3DPtsZ = 50.0;
+    // ConfigUSAC likewise (main.cpp:1441-1458 fills it per image pair); carried, USAC itself is not part of this library
+    poselib::ConfigUSAC cfg_usac;
+    cfg_usac.focalLength = 800.0;
+    cfg_usac.th_pixels = 0.8;
+    cfg_usac.degeneracyCheck = poselib::UsacChkDegenType::DEGEN_USAC_INTERNAL;
+    cfg_usac.estimator = poselib::PoseEstimator::POSE_STEWENIUS;
+    cfg_usac.refinealg = poselib::RefineAlg::REF_STEWENIUS_WEIGHTS;
+    cfg_usac.prevalidateSample = false;
+    cfg_usac.noAutomaticProsacParamters = false;
+    cfg_usac.automaticSprtInit = poselib::SprtInit::SPRT_DELTA_AUTOM_INIT | poselib::SprtInit::SPRT_EPSILON_AUTOM_INIT;
+    cfg_usac.imgSize = cv::Size(640, 480);
+    cfg_usac.degenDecisionTh = 0.85;
+    static_assert(PIX_MIN_GOOD_TH == 1.6, "reference pose_estim.h:59");
     poselib::StereoRefine sr(cfg);
     std::vector<cv::KeyPoint> a((size_t)n), b((size_t)n);
     std::vector<cv::DMatch> mm((size_t)n);
@@ -68,7 +118,9 @@ int main(int argc, char **argv) {
         mm[i].queryIdx = i, mm[i].trainIdx = i;
     }
     poselib::setRansacSeed(seed);
-    int32_t rc = sr.addNewCorrespondences(mm, a, b, poselib::ConfigUSAC());
+    cfg_usac.matches = &mm, cfg_usac.keypoints1 = &a, cfg_usac.keypoints2 = &b;
+    cfg_usac.nrMatchesVfcFiltered = (unsigned)mm.size();
+    int32_t rc = sr.addNewCorrespondences(mm, a, b, cfg_usac);
     int32_t inl = (int32_t)sr.nr_inliers_new;
     double zero[9] = {0};
     fwrite(&rc, 4, 1, o);

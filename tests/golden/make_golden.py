@@ -225,6 +225,33 @@ def cheirality_case():
     np.savez_compressed(os.path.join(HERE, "cheirality.npz"), **out)
 
 
+# ---- reference's own coefficient arithmetic (getCoeffMat + c[0..10]) compiled in place: oracle/_ref/libfivept_ref.so ----
+def coeff_case():
+    import ctypes as C
+    so = os.path.join(ROOT, "oracle", "_ref", "libfivept_ref.so")
+    assert os.path.exists(so), "build oracle/_ref first: make -C oracle ref"
+    ref = C.CDLL(so)
+    rng = np.random.default_rng(20260150)
+    n = 40
+    EE = np.empty((n, 4, 9))
+    A = np.empty((n, 10, 20))
+    b = rng.normal(size=(n, 3, 13))
+    c = np.empty((n, 11))
+    for i in range(n):
+        Q, _ = np.linalg.qr(rng.normal(size=(9, 9)))
+        EE[i] = Q[:, :4].T
+        e = np.ascontiguousarray(EE[i]).copy()
+        a = np.zeros(200)
+        ref.ref_getCoeffMat(C.c_void_p(e.ctypes.data), C.c_void_p(a.ctypes.data))
+        A[i] = a.reshape(10, 20)
+        bi = np.ascontiguousarray(b[i])
+        ci = np.zeros(11)
+        ref.ref_detpoly(C.c_void_p(bi.ctypes.data), C.c_void_p(ci.ctypes.data))
+        c[i] = ci
+    np.savez_compressed(os.path.join(HERE, "coeff_ref.npz"), EE=EE, A=A, b=b, c=c)
+    print("coeff_ref: ok")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "nms"):
@@ -239,3 +266,5 @@ if __name__ == "__main__":
         ransac_case()
     if what in ("all", "cheirality"):
         cheirality_case()
+    if what in ("all", "coeff"):
+        coeff_case()

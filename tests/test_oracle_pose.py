@@ -193,3 +193,19 @@ def test_lmeds_recovers_pose(oracle):
     p1b, p2b, *_ , maskb, thb = synth.pose_scene(1500, inlier_frac=0.3, seed=23)
     rb = oracle.lmeds_essential(p1b, p2b, seed=12345)
     assert rb["min_median"] > 100 * r["min_median"]
+
+
+def test_coefficient_arithmetic_equals_the_references_own_expressions(oracle):
+    """The oracle derives the 10 x 20 constraint matrix and the degree-10 determinant polynomial by polynomial arithmetic; the
+    golden values come from the reference's own generated expressions (getCoeffMat, five-point.cpp:603-824, and c[0..10],
+    :418-428), compiled where they lie into oracle/_ref/libfivept_ref.so.  Equal to rounding (1e-14 relative)."""
+    import ctypes as C
+    g = np.load(os.path.join(GOLD, "coeff_ref.npz"))
+    for EE, Aref, b, cref in zip(g["EE"], g["A"], g["b"], g["c"]):
+        A, c = np.zeros(200), np.zeros(11)
+        EE = np.ascontiguousarray(EE)
+        b = np.ascontiguousarray(b)
+        oracle.lib.oracle_coeff_matrix(C.c_void_p(EE.ctypes.data), C.c_void_p(A.ctypes.data))
+        oracle.lib.oracle_detpoly(C.c_void_p(b.ctypes.data), C.c_void_p(c.ctypes.data))
+        assert np.abs(A.reshape(10, 20) - Aref).max() <= 1e-14 * np.abs(Aref).max()
+        assert np.abs(c - cref).max() <= 1e-14 * np.abs(cref).max()
