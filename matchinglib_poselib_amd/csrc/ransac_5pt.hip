@@ -665,9 +665,15 @@ __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__
 // ---------------------------------------------------------------------------------------------------------------
 // Sampson scoring: one thread per model.
 // ---------------------------------------------------------------------------------------------------------------
+// Also pmag[i] = (|x1| + |y1| + 1) (|x2| + |y2| + 1), stored behind the points: the magnitude bound of x2^T E x1 / max|E| that the
+// fused-multiply-add fast path of the inlier predicate needs for its error band (sampson_inlier_fma).
 __global__ void pack_points_kernel(const double *__restrict__ p1, const double *__restrict__ p2, int n, double4 *__restrict__ pts) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) pts[i] = make_double4(p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+    if (i < n) {
+        const double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
+        pts[i] = make_double4(x1, y1, x2, y2);
+        reinterpret_cast<double *>(pts + n)[i] = (fabs(x1) + fabs(y1) + 1.0) * (fabs(x2) + fabs(y2) + 1.0);
+    }
 }
 
 // computeReprojError3 (five-point.cpp:490-502): numerator and denominator of the Sampson error in the reference's operation
@@ -707,6 +713,45 @@ __device__ __forceinline__ bool sampson_inlier(double N, double D, double qmax, 
     return (double)(float)__ddiv_rn(N, D) <= thresh2;
 }
 
+// The same predicate on fused multiply-adds: ~28 instructions instead of ~41, exact by construction.
+// N' = s'^2 and D' are evaluated with FMAs (any order).  Against the reference-order values: every product chain e_ij x2_i x1_j passes
+// at most 4 (here) + 6 (reference) roundings, so |s' - s_ref| <= 10.1 u T with T = sum |e_ij x2_i x1_j| <= max|e| * pmag; likewise
+// every component q of D (Ex1_0, Ex1_1, E^T x2_0, E^T x2_1) has |q' - q_ref| <= 5.1 u max|e| pmag.  With delta = 2^-49 max|e| pmag
+// (= 16 u ...: slack for the rounding of pmag itself):
+//     |N_ref - N'| <= delta (2 |s'| + delta) (1 + 2^-50) + 2^-51 N'
+//     |p_ref - p'| <= qmax (4 delta sqrt(D') + 4 delta^2) + 11 u p' <= 2 delta (qmax + p') (1 + 2^-40) + 11 u p'      (2 sqrt(D) <= 1 + D)
+// and sampson_inlier() decides `inlier` for N_ref < p_ref and `outlier` for N_ref > p_ref (1 + 2^-50).  Both follow from
+//     |N' - p'| > h := delta (2 |s'| + 2 (qmax + p') + delta) (1 + 2^-40) + 2^-47 (N' + p')
+// with the sign of N' - p'.  Otherwise (a correspondence within ~1e-12 of the threshold, a NaN, an unusable qmax) the reference arithmetic
+// itself runs.  d0 = 2^-49 * max|e| * (1 + 2^-40), per model.
+__device__ __forceinline__ bool sampson_inlier_fma(const double *e, double d0, double x1, double y1, double x2, double y2, double pmag,
+                                                   double qmax, double thresh2) {
+    const double A = __fma_rn(e[0], x1, __fma_rn(e[1], y1, e[2]));
+    const double B = __fma_rn(e[3], x1, __fma_rn(e[4], y1, e[5]));
+    const double C = __fma_rn(e[6], x1, __fma_rn(e[7], y1, e[8]));
+    const double sv = __fma_rn(x2, A, __fma_rn(y2, B, C));
+    const double A2 = __fma_rn(e[0], x2, __fma_rn(e[3], y2, e[6]));
+    const double B2 = __fma_rn(e[1], x2, __fma_rn(e[4], y2, e[7]));
+    const double D = __fma_rn(A, A, __fma_rn(B, B, __fma_rn(A2, A2, B2 * B2)));
+    const double N = sv * sv;
+    const double p = qmax * D;
+    const double dl = d0 * pmag;
+    const double w = __fma_rn(2.0, fabs(sv) + (qmax + p), dl);
+    const double h = __fma_rn(0x1p-47, N + p, w * dl);
+    const double diff = N - p;
+    if (fabs(diff) > h && qmax > 0) return diff < 0;  // false for NaNs: they take the reference path
+    double Nr, Dr;
+    sampson_nd(e, x1, y1, x2, y2, Nr, Dr);
+    return sampson_inlier(Nr, Dr, qmax, thresh2);
+}
+
+__device__ __forceinline__ double model_band(const double *e) {
+    double m = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m = fmax(m, fabs(e[k]));
+    return m * (0x1p-49 * (1.0 + 0x1p-40));  // NaN / inf entries give a NaN / inf band: every correspondence takes the reference path
+}
+
 // 4 lanes per model (lane j takes the correspondences i = j mod 4, in order), 64 models per 256-thread block; the
 // correspondences go through LDS in tiles of 512.  The float errors are accumulated in double per lane and combined as
 // (s0 + s2) + (s1 + s3): four interleaved accumulators, the shape of an SSE2 cv::sum over CV_32F.
@@ -719,6 +764,8 @@ __global__ __launch_bounds__(256) void score_models_kernel(const double4 *__rest
                                                            int total_host, double thresh2, double qmax, int32_t *__restrict__ good,
                                                            double *__restrict__ esum) {
     __shared__ double4 tile[kScoreTile];
+    __shared__ double tile_mag[SUMS ? 1 : kScoreTile];
+    const double *__restrict__ pmag = reinterpret_cast<const double *>(pts + n);
     const int total = total_ptr ? *total_ptr : total_host;
     if (blockIdx.x * 64 >= total) return;  // block-uniform
     const int tid = threadIdx.x;
@@ -728,12 +775,16 @@ __global__ __launch_bounds__(256) void score_models_kernel(const double4 *__rest
     double e[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) e[k] = live ? E_list[(size_t)m * 9 + k] : 0.0;
+    const double d0 = model_band(e);
     int cnt = 0;
     double s = 0.0;
     for (int base = 0; base < n; base += kScoreTile) {
         const int rows = min(kScoreTile, n - base);
         __syncthreads();
-        for (int i = tid; i < rows; i += 256) tile[i] = pts[base + i];
+        for (int i = tid; i < rows; i += 256) {
+            tile[i] = pts[base + i];
+            if constexpr (!SUMS) tile_mag[i] = pmag[base + i];
+        }
         __syncthreads();
         if (live) {
 #pragma unroll 4
@@ -744,9 +795,7 @@ __global__ __launch_bounds__(256) void score_models_kernel(const double4 *__rest
                     cnt += ((double)err <= thresh2) ? 1 : 0;
                     s = __dadd_rn(s, (double)err);
                 } else {
-                    double N, D;
-                    sampson_nd(e, p.x, p.y, p.z, p.w, N, D);
-                    cnt += sampson_inlier(N, D, qmax, thresh2) ? 1 : 0;
+                    cnt += sampson_inlier_fma(e, d0, p.x, p.y, p.z, p.w, tile_mag[i], qmax, thresh2) ? 1 : 0;
                 }
             }
         }
@@ -787,6 +836,8 @@ __global__ __launch_bounds__(256) void score_models_block_kernel(const double4 *
         double e[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) e[k] = E_list[(size_t)m * 9 + k];
+        const double d0 = model_band(e);
+        const double *__restrict__ pmag = reinterpret_cast<const double *>(pts + n);
         int cnt = 0;
         for (int i = tid; i < n; i += 256) {
             const double4 p = pts[i];
@@ -795,9 +846,7 @@ __global__ __launch_bounds__(256) void score_models_block_kernel(const double4 *
                 errs[i] = err;
                 if constexpr (COUNT) cnt += ((double)err <= thresh2) ? 1 : 0;
             } else {
-                double N, D;
-                sampson_nd(e, p.x, p.y, p.z, p.w, N, D);
-                cnt += sampson_inlier(N, D, qmax, thresh2) ? 1 : 0;
+                cnt += sampson_inlier_fma(e, d0, p.x, p.y, p.z, p.w, pmag[i], qmax, thresh2) ? 1 : 0;
             }
         }
         if constexpr (COUNT) {
@@ -1556,7 +1605,7 @@ static void launch_score(hipStream_t s, const double4 *pts, int n, const double 
 
 static int pack_points(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double4 **d_pts, hipStream_t s) {
     void *buf = nullptr;
-    int rc = ws_get(ctx, WS_AUX3, (size_t)n * sizeof(double4), &buf);
+    int rc = ws_get(ctx, WS_AUX3, (size_t)n * (sizeof(double4) + sizeof(double)), &buf);  // points, then pmag[n]
     if (rc) return rc;
     hipLaunchKernelGGL(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_p1, d_p2, n, (double4 *)buf);
     *d_pts = (double4 *)buf;
