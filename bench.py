@@ -32,12 +32,14 @@ FP4_MFMA_PEAK_TFLOPS = 10000.0   # dense FP4 MFMA peak (MI355X_MICROARCH.md, Mat
 FLOP_PER_PAIR = 2 * 256          # one +-1 multiply-add per descriptor bit: the distance table is a K = 256 GEMM
 N_SIMD = 256 * 4
 # --- matrix-core kernel (default): per unit = one 32 x 32 distance tile = 1024 pairs the kernel issues 4 fp4 MFMAs and 22 VALU
-# ops (20 for the running top-2, 2 re-base adds).  tools/mfma_unit_probe.hip measures that instruction stream with operands in
-# registers and no memory traffic: 226 / 138 / 111 / 100 cycles per unit per SIMD at 1 / 2 / 3 / 4 resident waves, at the
-# 1.85 GHz the chip holds under this load.  The 4-wave figure is the vector-issue floor (22 x ~4.3 cycles + MFMA issue).
+# ops (20 for the running top-2, 2 re-base adds).  tools/hamming_unit_probe3.hip (occupancy-controlled, AGGREGATE throughput = all
+# units / wall time, in-kernel shader clock): the 4 MFMAs alone cost 141 cycles per unit per SIMD at 4 waves (LDS-fed operands;
+# nominal 4 x 32 = 128), MFMA + top-2 update 175 (they do not overlap on a SIMD: the VALU work adds), at the ~1.9 GHz the chip
+# holds on random descriptors (2.3 GHz on zeros).  MFMA_UNIT_FLOOR_CYCLES is the measured MFMA-only figure.
 MFMA_UNIT_PAIRS = 1024
-MFMA_UNIT_FLOOR_CYCLES = 100.0
-MFMA_CLOCK_HZ = 1.85e9
+MFMA_UNIT_FLOOR_CYCLES = 141.0
+MFMA_UNIT_WITH_TOP2_CYCLES = 175.0
+MFMA_CLOCK_HZ = 1.9e9
 # --- VALU kernels (--hamming-variant 0/1/2): 8 v_xor + 8 v_bcnt(acc) + v_lshl_or + v_med3 + v_min per descriptor pair.
 # Issue cost per wave and train row from tools/valu_peak.hip (8 waves/SIMD, cycles per wave-instruction per SIMD at 2.4 GHz).
 OPS_PER_PAIR = 19
@@ -288,7 +290,7 @@ def main():
         kern_ms = kern_ms if kern_ms > 0 else float('nan')
         hbm_equiv = pairs_per_step_rank * BYTES_PER_PAIR / (kern_ms * 1e-3) / 1e9   # north_star's "HBM-roofline GB/s" reading
         mfma_path = args.hamming_variant == 3
-        kernel_name = "knn_hamming_mfma_kernel<4, 4>" if mfma_path else "knn_hamming_partial_kernel<8>"
+        kernel_name = "knn_hamming_mfma_lds_kernel<4, 0>" if mfma_path else "knn_hamming_partial_kernel<8>"
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
@@ -315,12 +317,16 @@ def main():
                 "kernel_ms_avg": kern_ms,
                 "launches_timed": launches.value,
                 "note": "the all-pairs Hamming table as a +-1 GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 x fp4, fp32 accumulate, "
-                        "exact): 2*256 FLOP per descriptor pair against the dense FP4 peak.  The kernel is bound by VECTOR ISSUE, not "
-                        "by the matrix pipe: per 32x32 tile it issues 4 MFMAs and 22 VALU ops (running top-2); issue_floor_ms is that "
-                        "stream's measured cost with operands in registers (tools/mfma_unit_probe.hip, 4 waves/SIMD)",
+                        "exact): 2*256 FLOP per descriptor pair against the dense FP4 peak at the nominal 2.4 GHz.  Per 32x32 tile "
+                        "the kernel issues 4 MFMAs and 22 VALU ops (running top-2), which do NOT overlap on a SIMD: "
+                        "mfma_only_floor_ms is the measured cost of the MFMAs alone (141 cycles per tile per SIMD at 4 waves, "
+                        "tools/hamming_unit_probe3.hip) at the ~1.9 GHz the chip holds on random descriptors, mfma_plus_top2_ms the "
+                        "measured cost of MFMAs + top-2 update with LDS-fed operands and no synchronisation (175 cycles)",
                 "flop_per_pair": FLOP_PER_PAIR,
-                "issue_floor_ms": floor_ms,
-                "issue_frac": floor_ms / kern_ms,
+                "mfma_only_floor_ms": floor_ms,
+                "mfma_plus_top2_ms": floor_ms * MFMA_UNIT_WITH_TOP2_CYCLES / MFMA_UNIT_FLOOR_CYCLES,
+                "frac_of_mfma_only_floor": floor_ms / kern_ms,
+                "frac_of_mfma_plus_top2": floor_ms * MFMA_UNIT_WITH_TOP2_CYCLES / MFMA_UNIT_FLOOR_CYCLES / kern_ms,
                 "hbm_equiv_GBps": hbm_equiv,
                 "hbm_equiv_frac": hbm_equiv / HBM_PEAK_GBS,
             }

@@ -114,6 +114,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_hamming_mfma_blocks_per_cu = 3;
     ctx->opt_hamming_mfma_qt = 0;
     ctx->opt_hamming_mfma_lds = 1;
+    ctx->opt_hamming_mfma_weighted = 1;
     ctx->opt_hamming_mfma_prio = 0;
     ctx->opt_ransac_lazy_sums = 1;
     ctx->opt_solver_polish = 1;
@@ -157,8 +158,9 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     if (!std::strcmp(name, "hamming_variant") && value >= 0 && value <= 3) ctx->opt_hamming_variant = value;
     else if (!std::strcmp(name, "hamming_mfma_qt") && (value == 0 || value == 1 || value == 2 || value == 4)) ctx->opt_hamming_mfma_qt = value;
     else if (!std::strcmp(name, "hamming_mfma_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_mfma_blocks_per_cu = value;
-    else if (!std::strcmp(name, "hamming_mfma_lds") && (value == 0 || value == 1)) ctx->opt_hamming_mfma_lds = value;
-    else if (!std::strcmp(name, "hamming_mfma_prio") && (value == 0 || value == 1)) ctx->opt_hamming_mfma_prio = value;
+    else if (!std::strcmp(name, "hamming_mfma_lds") && (value >= 0 && value <= 2)) ctx->opt_hamming_mfma_lds = value;
+    else if (!std::strcmp(name, "hamming_mfma_prio") && (value >= 0 && value <= 2)) ctx->opt_hamming_mfma_prio = value;
+    else if (!std::strcmp(name, "hamming_mfma_weighted") && (value == 0 || value == 1)) ctx->opt_hamming_mfma_weighted = value;
     else if (!std::strcmp(name, "hamming_stamps") && (value == 0 || value == 1)) ctx->opt_hamming_stamps = value;
     else if (!std::strcmp(name, "hamming_qpl") && (value == 1 || value == 2)) ctx->opt_hamming_qpl = value;
     else if (!std::strcmp(name, "hamming_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_blocks_per_cu = value;
@@ -177,6 +179,13 @@ int mlpl_debug_hamming_stamps(mlpl_ctx *ctx, unsigned long long *out, int max_it
     if (!ctx || !out) return MLPL_E_BAD_INPUT;
     MLPL_HIP_TRY(hipSetDevice(ctx->device));
     MLPL_HIP_TRY(hipDeviceSynchronize());
+    // max_items < 0: the per-tile trace that follows the records (48 u64 per wave), -max_items waves at most
+    if (max_items < 0) {
+        const int n = ctx->dbg_stamp_items < -max_items ? ctx->dbg_stamp_items : -max_items;
+        if (n > 0 && ctx->ws[WS_DEBUG])
+            MLPL_HIP_TRY(hipMemcpy(out, (char *)ctx->ws[WS_DEBUG] + (size_t)ctx->dbg_stamp_items * 32, (size_t)n * 48 * 8, hipMemcpyDeviceToHost));
+        return n;
+    }
     const int n = ctx->dbg_stamp_items < max_items ? ctx->dbg_stamp_items : max_items;
     if (n > 0 && ctx->ws[WS_DEBUG]) MLPL_HIP_TRY(hipMemcpy(out, ctx->ws[WS_DEBUG], (size_t)n * 32, hipMemcpyDeviceToHost));
     return n;

@@ -237,6 +237,13 @@ __global__ __launch_bounds__(BT) void knn_hamming_partial_sgpr_kernel(
         if (qidx[j] < nq) part[((size_t)b * nsplit + split) * nq + qidx[j]] = make_uint2(k0[j], k1[j]);
 }
 
+struct MergeTail {  // train rows [row0, row0 + n) to be folded in by the merge itself (n = 0: none)
+    const uint32_t *qw, *tw;
+    size_t q_batch_words, t_batch_words;
+    int nw, row0, n;
+    const int32_t *split_tile0;  // != NULL: split s of pair b starts at train row 32 * split_tile0[b * (nsplit + 1) + s]
+};
+
 // Merge of the per-split partial top-2 lists, LANES lanes per query (each lane folds every LANES-th split, then xor-shuffles
 // combine the lanes), on 64-bit (dist << 32 | global row) keys; kMergeGroup queries per block (block = kMergeGroup * LANES threads).
 // Also evaluates the ratio predicate and leaves the number of passing queries of this query group in group_counts (consumed by
@@ -244,9 +251,9 @@ __global__ __launch_bounds__(BT) void knn_hamming_partial_sgpr_kernel(
 // splits (a quarter of the threads and shuffles of the 16-lane form), LANES = 16 many splits.
 template <int LANES>
 __global__ __launch_bounds__(kMergeGroup * LANES) void knn_hamming_merge_kernel(const uint2 *__restrict__ part, int nq, int nsplit,
-                                                                                 int rows_per_split, int dshift, int k, float ratio,
+                                                                                 int rows_per_split, int sps, int dshift, int k, float ratio,
                                                                                  int32_t *__restrict__ idx, int32_t *__restrict__ dist,
-                                                                                 int32_t *__restrict__ group_counts) {
+                                                                                 int32_t *__restrict__ group_counts, MergeTail tail) {
     constexpr int kWaves = kMergeGroup * LANES / 64;
     __shared__ int wave_tot[kWaves];
     const int b = blockIdx.y;
@@ -263,9 +270,22 @@ __global__ __launch_bounds__(kMergeGroup * LANES) void knn_hamming_merge_kernel(
     if (qi < nq) {
         for (int s = sub; s < nsplit; s += LANES) {
             const uint2 p = part[((size_t)b * nsplit + s) * nq + qi];
-            const unsigned long long base = (unsigned long long)s * rows_per_split;
+            // sps partial slots share one row origin (dynamic splits: the members of a team; static splits: sps = 1)
+            const unsigned long long base = tail.split_tile0 ? 32ull * (unsigned long long)tail.split_tile0[(size_t)b * (nsplit + 1) + s]
+                                                             : (unsigned long long)(sps == 1 ? s : s / sps) * rows_per_split;
             if (p.x != 0xFFFFFFFFu) upd(((unsigned long long)(p.x >> dshift) << 32) | (base + (p.x & lmask)));
             if (p.y != 0xFFFFFFFFu) upd(((unsigned long long)(p.y >> dshift) << 32) | (base + (p.y & lmask)));
+        }
+    }
+    // train rows the partial kernels did not see (the dynamic-split matrix-core kernel works on whole 32-row tiles only): < 32 rows,
+    // exact xor/popcount here, the lanes of a query take them in turn
+    if (tail.n > 0 && qi < nq) {
+        const uint32_t *qrow = tail.qw + (size_t)b * tail.q_batch_words + (size_t)qi * tail.nw;
+        for (int r = sub; r < tail.n; r += LANES) {
+            const uint32_t *trow = tail.tw + (size_t)b * tail.t_batch_words + (size_t)(tail.row0 + r) * tail.nw;
+            uint32_t d = 0;
+            for (int w = 0; w < tail.nw; ++w) d += __popc(qrow[w] ^ trow[w]);
+            upd(((unsigned long long)d << 32) | (unsigned long long)(tail.row0 + r));
         }
     }
 #pragma unroll
@@ -303,14 +323,15 @@ __global__ __launch_bounds__(kMergeGroup * LANES) void knn_hamming_merge_kernel(
 }
 
 static void launch_merge(hipStream_t s, const uint2 *part, int nq, int nsplit, int rps, int dshift, int k, float ratio, int batch,
-                         int32_t *d_idx, int32_t *d_dist, int32_t *d_group_counts) {
+                         int32_t *d_idx, int32_t *d_dist, int32_t *d_group_counts, int sps = 1,
+                         MergeTail tail = MergeTail{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr}) {
     dim3 mgrid((nq + kMergeGroup - 1) / kMergeGroup, batch);
     if (nsplit <= 8)
-        hipLaunchKernelGGL(knn_hamming_merge_kernel<4>, mgrid, dim3(kMergeGroup * 4), 0, s, part, nq, nsplit, rps, dshift, k, ratio, d_idx,
-                           d_dist, d_group_counts);
+        hipLaunchKernelGGL(knn_hamming_merge_kernel<4>, mgrid, dim3(kMergeGroup * 4), 0, s, part, nq, nsplit, rps, sps, dshift, k, ratio, d_idx,
+                           d_dist, d_group_counts, tail);
     else
-        hipLaunchKernelGGL(knn_hamming_merge_kernel<16>, mgrid, dim3(kMergeGroup * 16), 0, s, part, nq, nsplit, rps, dshift, k, ratio,
-                           d_idx, d_dist, d_group_counts);
+        hipLaunchKernelGGL(knn_hamming_merge_kernel<16>, mgrid, dim3(kMergeGroup * 16), 0, s, part, nq, nsplit, rps, sps, dshift, k, ratio,
+                           d_idx, d_dist, d_group_counts, tail);
 }
 
 template <int NW>
@@ -339,7 +360,7 @@ void launch_partial(int variant, int qpl, dim3 grid, hipStream_t s, const uint32
 
 int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_words, const uint32_t *tw, size_t t_batch_words,
                             int nq, int nt, int nw, int batch, int dshift, hipStream_t s, int *rps_out, int *nsplit_out,
-                            uint2 **part_out);
+                            int *sps_out, int *tail_row0_out, const int32_t **split_tab_out, uint2 **part_out);
 
 int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_stride, size_t q_bstride,
                        const uint8_t *d_t, int nt, size_t t_stride, size_t t_bstride, int nbytes, int k, int batch,
@@ -395,11 +416,14 @@ int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_strid
     int variant = ctx->opt_hamming_variant;
     if (variant == 3 && nw > 16) variant = 0;  // descriptors above 64 bytes: LDS-tiled VALU kernel
     if (variant == 3) {  // matrix-core kernel (knn_hamming_mfma.hip); wider descriptors take the VALU kernels
-        int rps = 0, nsplit = 0;
+        int rps = 0, nsplit = 0, sps = 1, tail_row0 = nt;
+        const int32_t *split_tab = nullptr;
         uint2 *part = nullptr;
-        int rc = launch_knn_hamming_mfma(ctx, qw, qbw, tw, tbw, nq, nt, nw, batch, dshift, s, &rps, &nsplit, &part);
+        int rc = launch_knn_hamming_mfma(ctx, qw, qbw, tw, tbw, nq, nt, nw, batch, dshift, s, &rps, &nsplit, &sps, &tail_row0, &split_tab,
+                                         &part);
         if (rc) return rc;
-        launch_merge(s, (const uint2 *)part, nq, nsplit, rps, dshift, k, ratio, batch, d_idx, d_dist, d_group_counts);
+        const MergeTail tail{qw, tw, qbw, tbw, nw, tail_row0, nt - tail_row0, split_tab};
+        launch_merge(s, (const uint2 *)part, nq, nsplit, rps, dshift, k, ratio, batch, d_idx, d_dist, d_group_counts, sps, tail);
         MLPL_HIP_TRY(hipGetLastError());
         return MLPL_OK;
     }

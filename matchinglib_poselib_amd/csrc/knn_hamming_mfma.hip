@@ -22,6 +22,10 @@
 // Output: the same [batch][split][nq] uint2 table of packed (dist << dshift | local row) keys the VALU kernels write,
 // merged by knn_hamming_merge_kernel.
 
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 #include "mlpl_internal.h"
 
 
@@ -73,9 +77,12 @@ struct ExpandArgs {
 };
 
 template <int KS>
-__global__ __launch_bounds__(256) void hamming_expand_kernel(ExpandArgs qa, ExpandArgs ta, int nw) {
+__global__ __launch_bounds__(256) void hamming_expand_kernel(ExpandArgs qa, ExpandArgs ta, int nw, int *__restrict__ counters,
+                                                             int counters_per_batch) {
     const ExpandArgs A = blockIdx.z ? ta : qa;
     const int b = blockIdx.y;
+    if (counters && blockIdx.x == 0 && blockIdx.z == 0)  // chunk counters of the dynamic-split kernel that follows in the stream
+        for (int i = threadIdx.x; i < counters_per_batch; i += 256) counters[(size_t)b * counters_per_batch + i] = 0;
     const int i = blockIdx.x * 256 + threadIdx.x;  // tile * 64 + lane
     if (i >= A.tiles * 64) return;
     const int l = i & 63, tile = i >> 6;
@@ -283,7 +290,7 @@ template <int QT, int PRIO>
 __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
     const uint4 *__restrict__ qfrag, size_t q_batch_u4, const uint4 *__restrict__ tfrag, size_t t_batch_u4, int nq, int nt,
     int rows_per_split, int nsplit, int dshift, int qblocks, int n_items, uint2 *__restrict__ part,
-    unsigned long long *__restrict__ stamps) {
+    unsigned long long *__restrict__ stamps, const int32_t *__restrict__ split_tile0) {
     constexpr int KS = 4, NB = 4;
     __shared__ __attribute__((aligned(16))) uint4 ring[NB][KS * 64];
     const int l = threadIdx.x & 63;
@@ -314,8 +321,13 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) cinit[reg] = -(float)((reg & 3) + 8 * (reg >> 2) + 4 * h) * kEps;
 
-    const int row0 = split * rows_per_split;
-    const int row1 = min(nt, row0 + rows_per_split);
+    // split geometry: equal splits, or the age-aware table of the launcher (tiles [tab[s], tab[s + 1]) per image pair)
+    int row0 = split * rows_per_split;
+    int row1 = min(nt, row0 + rows_per_split);
+    if (split_tile0) {
+        row0 = 32 * split_tile0[(size_t)b * (nsplit + 1) + split];
+        row1 = min(nt, 32 * split_tile0[(size_t)b * (nsplit + 1) + split + 1]);
+    }
     const int tile0 = row0 >> 5;
     const int ntiles = (row1 - row0 + 31) >> 5;
 
@@ -325,6 +337,7 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
 
     // my piece (K-step w) of the split's first tile; a tile is KS * 64 uint4 = 4 KiB, contiguous
     const uint4 *tbase = tfrag + (size_t)b * t_batch_u4 + (size_t)tile0 * KS * 64 + (size_t)w * 64;  // wave-uniform
+    if (PRIO == 2) tbase = tfrag + (size_t)w * 64;  // diagnostics: every workgroup streams the SAME tiles (wrong results, L1/L2-hot source)
     auto copy_tile = [&](int t_rel) {
         __builtin_amdgcn_global_load_lds((const void *)(tbase + (size_t)t_rel * KS * 64 + l),
                                          (__attribute__((address_space(3))) void *)&ring[t_rel & (NB - 1)][w * 64], 16, 0, 0);
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
     // throughput is the same either way.  Kept as a measured negative result and a diagnostic.
     const int wslot = (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3u);  // HW_ID.wave_id: slot within the SIMD
     auto rotate_prio = [&]() {
-        if (!PRIO) return;
+        if (PRIO != 1) return;
         const int p = (int)(((unsigned)(__builtin_amdgcn_s_memtime() >> 11) + (unsigned)wslot) & 3u);
         if (p == 0) __builtin_amdgcn_s_setprio(0);
         else if (p == 1) __builtin_amdgcn_s_setprio(1);
@@ -400,6 +413,7 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
     for (int it = 0; it < nfull; ++it) {
         rotate_prio();
         arrive(it);
+        if (stamps && l == 0 && it < 48) stamps[(size_t)n_items * 16 + ((size_t)item * 4 + w) * 48 + it] = __builtin_amdgcn_s_memtime();
         tile_body(it & (NB - 1), cinit);
     }
     if (ragged) {
@@ -448,6 +462,206 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The LDS-ring kernel with DYNAMIC train splits.  With fixed, equal work items the hardware's oldest-first arbitration lets the four
+// workgroups of a CU finish one after the other (28 ... 50 us for identical items) and the CU runs the second half of the launch
+// under-occupied.  Here the workgroups that serve one (image pair, block of 4 query groups, row span) form a TEAM and draw chunks of
+// `chunk_tiles` (>= 2) train tiles from the team's counter: a fast workgroup simply takes more chunks, and all of them run dry
+// within a chunk of each other.  A workgroup still writes ONE partial top-2 per query (slot = its member index), so the partial
+// table and the merge are unchanged; the rows it has seen are not contiguous, so the running pair is re-based by the actual tile
+// distance and local rows are relative to the span (<= 8192 rows: (row offset) * 2^-14 < 1/2 keeps rint() exact, see the decode).
+// Ring: NB = 3 slots, prefetch distance 1 (the copy of the next tile runs under the current tile's ~2400 cycles).  The chunk after
+// the current one is requested (one returning atomic by lane 0 of wave 0, issued BEFORE this iteration's copy so that the iteration's
+// own vmcnt wait covers it) at the first tile of every chunk and published to the other waves through LDS behind the barrier.
+// The ragged last tile of the train set is the last tile of the last chunk, hence always the last tile of its workgroup.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int QT>
+__global__ __launch_bounds__(256, 4) void knn_hamming_mfma_dyn_kernel(
+    const uint4 *__restrict__ qfrag, size_t q_batch_u4, const uint4 *__restrict__ tfrag, size_t t_batch_u4, int nq, int nt,
+    int span_tiles, int nspan, int nmem, int chunk_tiles, int dshift, int qblocks, int n_items, uint2 *__restrict__ part,
+    int *__restrict__ counters, unsigned long long *__restrict__ stamps) {
+    constexpr int KS = 4, NB = 3;
+    __shared__ __attribute__((aligned(16))) uint4 ring[NB][KS * 64];
+    __shared__ int s_claim, s_first;
+    const int l = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned long long st_c = 0, st_r = 0;
+    if (stamps) {
+        st_c = __builtin_amdgcn_s_memtime();
+        st_r = __builtin_amdgcn_s_memrealtime();
+    }
+    const int per_xcd = (int)(gridDim.x >> 3);
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= n_items) return;  // workgroup-uniform
+    const int slots = nspan * nmem;
+    const int qb = item % qblocks;
+    const int slot_id = (item / qblocks) % slots;
+    const int b = item / (qblocks * slots);
+    const int span = slot_id / nmem;
+    int *ctr = counters + ((size_t)b * qblocks + qb) * nspan + span;
+    const int qt0 = (qb * 4 + w) * QT;
+    const uint4 *qf = qfrag + (size_t)b * q_batch_u4 + (size_t)qt0 * KS * 64 + l;
+
+    // first chunk (the latency of this one atomic hides under the query fragment loads)
+    if (threadIdx.x == 0) s_first = atomicAdd(ctr, 1);
+
+    uint4 bq[QT][KS];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bq[t][s] = qf[(size_t)(t * KS + s) * 64];
+
+    const int h = l >> 5;
+    v16f cinit;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) cinit[reg] = -(float)((reg & 3) + 8 * (reg >> 2) + 4 * h) * kEps;
+
+    const int total_tiles = nt >> 5;  // FULL tiles only: the < 32 rows behind them are folded in by the merge kernel
+    const int span_tile0 = span * span_tiles;
+    const int ntl = min(span_tiles, total_tiles - span_tile0);  // tiles of this span (>= 1)
+    const int nchunks = (ntl + chunk_tiles - 1) / chunk_tiles;
+
+    float m1[QT], m2[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) m1[t] = m2[t] = -INFINITY;
+
+    const uint4 *tbase = tfrag + (size_t)b * t_batch_u4 + (size_t)w * 64;  // wave-uniform; tile T at + T * KS * 64
+    const uint32_t l16 = (uint32_t)l * 16u;
+    auto copy_tile = [&](int tile, int slot) {  // scalar base + 32-bit lane offset
+        __builtin_amdgcn_global_load_lds((const void *)(reinterpret_cast<const char *>(tbase + (size_t)tile * KS * 64) + l16),
+                                         (__attribute__((address_space(3))) void *)&ring[slot][w * 64], 16, 0, 0);
+    };
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4 *)&ring[0][0];
+    auto tile_body = [&](int slot, float rebase) {
+        u32x4 r[KS];
+        const uint32_t addr = l16 + (ring_base + (uint32_t)slot * (KS * 1024u));
+        asm volatile(
+            "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+            : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+            : "v"(addr)
+            : "memory");
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(r[0]));
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r[1]));
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(r[2]));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[3]));
+        uint4 a[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[s] = make_uint4(r[s].x, r[s].y, r[s].z, r[s].w);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            v16f acc = mfma_fp4(a[0], bq[t][0], cinit);
+#pragma unroll
+            for (int s = 1; s < KS; ++s) acc = mfma_fp4(a[s], bq[t][s], acc);
+            m1[t] += rebase;  // to this tile's row origin (exact; -inf stays -inf)
+            m2[t] += rebase;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg += 4) {
+                const float s0 = __builtin_amdgcn_fmed3f(m1[t], acc[reg], acc[reg + 1]);
+                const float t0 = __builtin_fmaxf(__builtin_fmaxf(m1[t], acc[reg]), acc[reg + 1]);
+                const float s1 = __builtin_amdgcn_fmed3f(t0, acc[reg + 2], acc[reg + 3]);
+                m1[t] = __builtin_fmaxf(__builtin_fmaxf(t0, acc[reg + 2]), acc[reg + 3]);
+                m2[t] = __builtin_fmaxf(__builtin_fmaxf(m2[t], s0), s1);
+            }
+            // one accumulator tile alive at a time: without this tie the scheduler interleaves the next unit's MFMA chain on a second
+            // accumulator (which buys nothing: MFMA and VALU do not overlap on a SIMD) and pays for it by spilling query fragments.
+            // (An empty volatile asm that "rewrites" this unit's result and the next unit's first operand orders the two.)
+            asm volatile("" : "+v"(m1[t]), "+v"(m2[t]), "+v"(a[0].x));
+        }
+    };
+
+    __syncthreads();  // s_first
+    int c_cur = __builtin_amdgcn_readfirstlane(s_first);
+    int last_tile = span_tile0;  // frame of the decode (stays there when this workgroup got no chunk: everything is -inf)
+    if (c_cur < nchunks) {
+        int c_nxt = nchunks;  // unknown until requested
+        int pos = 0;
+        int len = min(chunk_tiles, ntl - c_cur * chunk_tiles);
+        int tile = span_tile0 + c_cur * chunk_tiles;
+        int prev_tile = tile;
+        int slot = 0;
+        bool first = true;
+        copy_tile(tile, 0);
+        for (;;) {
+            // request the chunk after this one at the chunk's first tile (not needed when this is the span's last chunk)
+            uint32_t req = 0;
+            const bool ask = first && (c_cur + 1 < nchunks);
+            if (ask && threadIdx.x == 0) {
+                const uint32_t zero = 0, one = 1;  // scalar base + zero vector offset: no live 64-bit address register
+                asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(req) : "v"(zero), "v"(one), "s"(ctr) : "memory");
+            }
+            // where is the next tile?  inside the chunk, or at the start of the chunk requested one chunk ago
+            int next_tile = -1;
+            if (pos + 1 < len) next_tile = tile + 1;
+            else if (!first && c_nxt < nchunks) next_tile = span_tile0 + c_nxt * chunk_tiles;
+            // (first && pos + 1 == len  <=>  a one-tile chunk, which is always the span's last chunk: no next tile)
+            const int nslot = slot == NB - 1 ? 0 : slot + 1;
+            if (next_tile >= 0) {
+                copy_tile(next_tile, nslot);
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // this tile's piece (and the atomic, which is older than the copy)
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (ask && threadIdx.x == 0) s_claim = (int)req;
+            __builtin_amdgcn_s_barrier();
+            tile_body(slot, (float)(32 * (tile - prev_tile)) * kEps);
+            last_tile = tile;
+            if (ask) c_nxt = __builtin_amdgcn_readfirstlane(s_claim);  // written before this iteration's barrier
+            prev_tile = tile;
+            if (pos + 1 < len) {
+                ++pos;
+                ++tile;
+                first = false;
+            } else if (next_tile >= 0) {
+                c_cur = c_nxt;
+                c_nxt = nchunks;
+                pos = 0;
+                len = min(chunk_tiles, ntl - c_cur * chunk_tiles);
+                tile = next_tile;
+                first = true;
+            } else {
+                break;
+            }
+            slot = nslot;
+        }
+    }
+
+    // decode (frame = the last tile processed): v = (64 KS - 2 d) + (32 (last_tile - span_tile0) - local_row) * eps, |fraction| < 1/2
+    const float frame = (float)(32 * (last_tile - span_tile0));
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        uint32_t k[2];
+        const float mm[2] = {m1[t], m2[t]};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (mm[j] == -INFINITY) {
+                k[j] = 0xFFFFFFFFu;
+            } else {
+                const float ip = rintf(mm[j]);
+                const int d = (64 * KS - (int)ip) >> 1;
+                const int lrow = (int)(frame - (mm[j] - ip) * 16384.0f);
+                k[j] = ((uint32_t)d << dshift) | (uint32_t)lrow;
+            }
+        }
+        const uint32_t o0 = __shfl_xor(k[0], 32), o1 = __shfl_xor(k[1], 32);
+        uint32_t k0 = k[0], k1 = k[1];
+        k1 = umed3(k0, k1, o0);
+        k0 = min(k0, o0);
+        k1 = umed3(k0, k1, o1);
+        k0 = min(k0, o1);
+        const int q = (qt0 + t) * 32 + (l & 31);
+        if (h == 0 && q < nq) part[((size_t)b * slots + slot_id) * nq + q] = make_uint2(k0, k1);
+    }
+    if (stamps && l == 0) {
+        unsigned long long *o = stamps + ((size_t)item * 4 + w) * 4;
+        o[0] = __builtin_amdgcn_s_memtime() - st_c;
+        o[1] = __builtin_amdgcn_s_memrealtime() - st_r;
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+        o[2] = 1ull | ((unsigned long long)(hw & 0xFFFFFu) << 32) | ((unsigned long long)(xcc & 15u) << 56);
+        o[3] = st_r;
+    }
+}
+
 template <int KS>
 void launch_mfma(int qt, dim3 grid, hipStream_t s, const uint4 *qf, size_t qb, const uint4 *tf, size_t tb, int nq, int nt, int rps,
                  int nsplit, int dshift, int qgroups, int n_items, uint2 *part, unsigned long long *stamps) {
@@ -472,7 +686,7 @@ void launch_mfma(int qt, dim3 grid, hipStream_t s, const uint4 *qf, size_t qb, c
 // Called by launch_knn_hamming for descriptors of at most 64 bytes.  qw/tw: word rows (nw words per row, zero padded).
 int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_words, const uint32_t *tw, size_t t_batch_words,
                             int nq, int nt, int nw, int batch, int dshift, hipStream_t s, int *rps_out, int *nsplit_out,
-                            uint2 **part_out) {
+                            int *sps_out, int *tail_row0_out, const int32_t **split_tab_out, uint2 **part_out) {
     int ks = 1;
     while (ks * 2 < nw) ks *= 2;  // 64-bit K-steps: nw <= 2 -> 1, 4 -> 2, 8 -> 4, 16 -> 8
     if (nw > 16) {
@@ -487,6 +701,7 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     while (ctx->opt_hamming_mfma_qt <= 0 && qt > 1 && (long long)((nqt + qt - 1) / qt) * batch < (long long)ctx->num_cus) qt >>= 1;
     const int qgroups = (nqt + qt - 1) / qt;  // wave-level work: one group of qt query tiles against one train split
     const bool lds_ring = ks == 4 && ctx->opt_hamming_mfma_lds != 0;  // workgroup-level work: 4 query groups share the train tiles
+    const bool dyn = lds_ring && ctx->opt_hamming_mfma_lds == 2 && nt >= 32;  // ... and the train splits are drawn dynamically
     const int qblocks = (qgroups + 3) / 4;
     const int q_tiles_padded = lds_ring ? qblocks * 4 * qt : qgroups * qt;
     const int t_tiles = (nt + 31) / 32;
@@ -504,6 +719,24 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
         set_error("knn_hamming: train set too large (nt=%d)", nt);
         return MLPL_E_BAD_INPUT;
     }
+    // dynamic splits: spans of <= 8192 rows, `nmem` workgroups per (pair, query block, span) drawing chunks of 2 tiles
+    int nspan = 1, span_tiles = t_tiles, nmem = 1, sps = 1;
+    const int chunk_tiles = 2;
+    if (dyn) {
+        const int t_full = nt >> 5;  // whole tiles; rows [32 t_full, nt) are folded in by the merge kernel
+        nspan = (t_full + 255) / 256;
+        span_tiles = (t_full + nspan - 1) / nspan;
+        const long long teams = (long long)qblocks * nspan * batch;
+        const long long want_mem = ((long long)bpc * ctx->num_cus + teams - 1) / teams;
+        nmem = (int)std::max<long long>(1, std::min<long long>(want_mem, (span_tiles + chunk_tiles - 1) / chunk_tiles));
+        nsplit = nspan * nmem;
+        rps = span_tiles * 32;
+        sps = nmem;
+        if (nsplit > 65535) {
+            set_error("knn_hamming: train set too large (nt=%d)", nt);
+            return MLPL_E_BAD_INPUT;
+        }
+    }
     const long long items = (lds_ring ? (long long)qblocks : (long long)qgroups) * nsplit * batch;  // workgroups (ring) or waves
     if (items > (1LL << 30)) {
         set_error("knn_hamming: problem too large for one launch (nq=%d nt=%d batch=%d)", nq, nt, batch);
@@ -516,37 +749,114 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     if ((rc = ws_get(ctx, WS_FRAG_Q, (size_t)batch * q_u4 * 16, &qf))) return rc;
     if ((rc = ws_get(ctx, WS_FRAG_T, ((size_t)batch * t_u4 + (size_t)ks * 64) * 16, &tf))) return rc;  // + one spare tile (register prefetch)
     if ((rc = ws_get(ctx, WS_PARTIAL, (size_t)batch * nsplit * nq * sizeof(uint2), &part))) return rc;
+    int *counters = nullptr;
+    const int counters_per_batch = dyn ? qblocks * nspan : 0;
+    if (dyn) {
+        void *cp = nullptr;
+        if ((rc = ws_get(ctx, WS_COUNTERS, (size_t)batch * counters_per_batch * sizeof(int), &cp))) return rc;
+        counters = (int *)cp;
+    }
     const ExpandArgs qa{qw, q_batch_words, nq, q_tiles_padded, (uint4 *)qf}, ta{tw, t_batch_words, nt, t_tiles, (uint4 *)tf};
     const dim3 egrid((unsigned)((std::max(q_tiles_padded, t_tiles) * 64 + 255) / 256), batch, 2);
     switch (ks) {
-        case 1: hipLaunchKernelGGL(hamming_expand_kernel<1>, egrid, dim3(256), 0, s, qa, ta, nw); break;
-        case 2: hipLaunchKernelGGL(hamming_expand_kernel<2>, egrid, dim3(256), 0, s, qa, ta, nw); break;
-        case 4: hipLaunchKernelGGL(hamming_expand_kernel<4>, egrid, dim3(256), 0, s, qa, ta, nw); break;
-        default: hipLaunchKernelGGL(hamming_expand_kernel<8>, egrid, dim3(256), 0, s, qa, ta, nw); break;
+        case 1: hipLaunchKernelGGL(hamming_expand_kernel<1>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch); break;
+        case 2: hipLaunchKernelGGL(hamming_expand_kernel<2>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch); break;
+        case 4: hipLaunchKernelGGL(hamming_expand_kernel<4>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch); break;
+        default: hipLaunchKernelGGL(hamming_expand_kernel<8>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch); break;
     }
     // 1-D grid, remapped in the kernel (XCD-aware); padded so that every XCD gets the same number of workgroups
     const long long blocks = lds_ring ? items : (items + 3) / 4;
     dim3 grid((unsigned)((blocks + 7) / 8 * 8));
+    // Age-aware split sizes (static LDS-ring kernel).  With exactly R = 4 workgroups per CU the dispatcher deals workgroups breadth
+    // first, so workgroup L is the (L / num_cus)-th oldest wave set on its CU, and the SIMD arbitrates oldest-first: measured per-tile
+    // costs with all four ranks active are 1700 / 2100 / 3200 / 5300 cycles (tools/hamming_trace.py), i.e. equal splits finish at
+    // 62k / 75k / 90k / 105k cycles and the CU runs the second half of the launch under-occupied.  Splits sized by the ranks' rates
+    // (weights 1/cost) let the four finish together.  Correctness never depends on this: the table only moves split boundaries, and
+    // it is used only when every query block of a (pair, split) has the same rank.
+    const int32_t *split_tab = nullptr;
+    if (lds_ring && !dyn && ctx->opt_hamming_mfma_weighted && blocks == 4LL * ctx->num_cus && nsplit >= 4 && nsplit <= 256 &&
+        batch * (nsplit + 1) <= 4096) {
+        const int per_xcd = (int)(grid.x >> 3);
+        std::vector<int> rank((size_t)batch * nsplit, -1);
+        bool ok = true;
+        for (long long bid = 0; bid < blocks && ok; ++bid) {
+            const long long item = (bid & 7) * per_xcd + (bid >> 3);
+            if (item >= items) continue;
+            const int sp = (int)((item / qblocks) % nsplit), bb = (int)(item / ((long long)qblocks * nsplit));
+            const int r = (int)(bid / ctx->num_cus);
+            int &slot = rank[(size_t)bb * nsplit + sp];
+            if (slot < 0) slot = r;
+            else if (slot != r) ok = false;
+        }
+        if (ok) {
+            static const double kRate[4] = {1.0 / 1700, 1.0 / 2100, 1.0 / 3200, 1.0 / 5300};
+            const long long key = ((long long)nt << 32) ^ ((long long)nsplit << 20) ^ ((long long)batch << 8) ^ qblocks;
+            void *tabp = nullptr;
+            if ((rc = ws_get(ctx, WS_SPLIT_TAB, 4096 * sizeof(int32_t), &tabp))) return rc;
+            if (ctx->split_tab_key != key || ctx->split_tab_ptr != tabp) {
+                void *pin = nullptr;
+                if ((rc = pinned_get(ctx, 4096 * sizeof(int32_t), &pin))) return rc;
+                int32_t *h = (int32_t *)pin;  // staging: free again after the synchronous upload below
+                for (int bb = 0; bb < batch; ++bb) {
+                    double wsum = 0;
+                    for (int sp = 0; sp < nsplit; ++sp) wsum += kRate[rank[(size_t)bb * nsplit + sp]];
+                    int acc_tiles = 0;
+                    double acc_w = 0;
+                    for (int sp = 0; sp < nsplit; ++sp) {
+                        h[bb * (nsplit + 1) + sp] = acc_tiles;
+                        acc_w += kRate[rank[(size_t)bb * nsplit + sp]];
+                        int upto = (int)std::llround(t_tiles * acc_w / wsum);
+                        upto = std::max(upto, acc_tiles + 1);                        // at least one tile per split
+                        upto = std::min(upto, t_tiles - (nsplit - 1 - sp));          // and one left for every later split
+                        upto = std::min(upto, acc_tiles + kMaxRowsPerSplit / 32);    // exact re-basing bound
+                        acc_tiles = upto;
+                    }
+                    h[bb * (nsplit + 1) + nsplit] = t_tiles;
+                    if (t_tiles - h[bb * (nsplit + 1) + nsplit - 1] > kMaxRowsPerSplit / 32) ok = false;
+                }
+                if (ok) {
+                    MLPL_HIP_TRY(hipStreamSynchronize(s));  // the previous table may still be read by kernels in flight
+                    MLPL_HIP_TRY(hipMemcpyAsync(tabp, h, (size_t)batch * (nsplit + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+                    MLPL_HIP_TRY(hipStreamSynchronize(s));  // the staging memory is shared with other entry points
+                    ctx->split_tab_key = key;
+                    ctx->split_tab_ptr = tabp;
+                }
+            }
+            if (ok) split_tab = (const int32_t *)tabp;
+        }
+    }
     unsigned long long *stamps = nullptr;
     ctx->dbg_stamp_items = 0;
     if (ctx->opt_hamming_stamps) {
         void *sp = nullptr;
         const long long waves = lds_ring ? items * 4 : items;
-        if ((rc = ws_get(ctx, WS_DEBUG, (size_t)waves * 32, &sp))) return rc;
-        MLPL_HIP_TRY(hipMemsetAsync(sp, 0, (size_t)waves * 32, s));
+        // per-wave records (4 x u64), then a per-tile clock trace of 48 u64 per wave (LDS-ring kernel, static splits)
+        if ((rc = ws_get(ctx, WS_DEBUG, (size_t)waves * (32 + 48 * 8), &sp))) return rc;
+        MLPL_HIP_TRY(hipMemsetAsync(sp, 0, (size_t)waves * (32 + 48 * 8), s));
         stamps = (unsigned long long *)sp;
         ctx->dbg_stamp_items = (int)waves;
     }
     prof_mark(ctx, MLPL_PROF_KNN_HAMMING, 0, s);
-    if (lds_ring) {
+    if (dyn) {
+#define MLPL_DYN_LAUNCH(QT_)                                                                                                          \
+    hipLaunchKernelGGL((knn_hamming_mfma_dyn_kernel<QT_>), grid, dim3(256), 0, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, t_u4, nq, nt, \
+                       span_tiles, nspan, nmem, chunk_tiles, dshift, qblocks, (int)items, (uint2 *)part, counters, stamps)
+        if (qt == 4) MLPL_DYN_LAUNCH(4);
+        else if (qt == 2) MLPL_DYN_LAUNCH(2);
+        else MLPL_DYN_LAUNCH(1);
+#undef MLPL_DYN_LAUNCH
+    } else if (lds_ring) {
 #define MLPL_RING_LAUNCH(QT_)                                                                                                          \
     do {                                                                                                                               \
-        if (ctx->opt_hamming_mfma_prio)                                                                                                \
+        if (ctx->opt_hamming_mfma_prio == 2)                                                                                           \
+            hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<QT_, 2>), grid, dim3(256), 0, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, \
+                               t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab);               \
+        else if (ctx->opt_hamming_mfma_prio)                                                                                           \
             hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<QT_, 1>), grid, dim3(256), 0, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, \
-                               t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps);                          \
+                               t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab);               \
         else                                                                                                                           \
             hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<QT_, 0>), grid, dim3(256), 0, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, \
-                               t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps);                          \
+                               t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab);               \
     } while (0)
         if (qt == 4) MLPL_RING_LAUNCH(4);
         else if (qt == 2) MLPL_RING_LAUNCH(2);
@@ -562,6 +872,9 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     prof_mark(ctx, MLPL_PROF_KNN_HAMMING, 1, s);
     *rps_out = rps;
     *nsplit_out = nsplit;
+    *sps_out = sps;
+    *split_tab_out = split_tab;
+    *tail_row0_out = dyn ? (nt >> 5) << 5 : nt;
     *part_out = (uint2 *)part;
     return MLPL_OK;
 }

@@ -46,6 +46,8 @@ enum WsSlot {
     WS_FRAG_T,
     WS_PIPE,      // per-pair pipeline block (mlpl_pair_pose_dev)
     WS_DEBUG,     // diagnostics (per-wave clock stamps)
+    WS_COUNTERS,  // chunk counters of the dynamic-split Hamming kernel
+    WS_SPLIT_TAB, // age-aware split table of the static LDS-ring Hamming kernel
     WS_NUM_SLOTS
 };
 
@@ -69,8 +71,11 @@ struct mlpl_ctx {
     int opt_hamming_blocks_per_cu;  // grid sizing target
     int opt_hamming_mfma_blocks_per_cu;  // grid sizing target of the matrix-core kernel (4-wave blocks)
     int opt_hamming_mfma_qt;             // query tiles per wave (0 = automatic, else 1, 2 or 4)
-    int opt_hamming_mfma_lds;       // 1 (default) = 32-byte descriptors use the LDS-ring matrix-core kernel, 0 = the register-prefetch one
+    int opt_hamming_mfma_lds;       // 32-byte descriptors: 2 (default) = LDS-ring kernel with dynamic train splits, 1 = LDS ring with static splits, 0 = register-prefetch kernel
     int opt_hamming_mfma_prio;      // 1 = the LDS-ring kernel rotates wave priorities on a clock slice (equal finish times per SIMD; measured: no faster). Default 0
+    int opt_hamming_mfma_weighted;  // 1 (default) = age-aware split sizes in the static LDS-ring kernel (4 workgroups per CU)
+    long long split_tab_key;        // shape key of the split table currently in WS_COUNTERS
+    void *split_tab_ptr;
     int opt_hamming_stamps;         // diagnostics: the matrix-core kernel records per-wave clock stamps (mlpl_debug_hamming_stamps)
     int dbg_stamp_items;
     int opt_ransac_chunk;           // hypotheses per device pass (0 = 32768)

@@ -9,13 +9,13 @@ import matchinglib_poselib_amd as mpa
 from matchinglib_poselib_amd import synth
 from matchinglib_poselib_amd.matching import match_hamming_device
 
-def run(ctx, P, n, bpc, qt, zero=False, secs=2.0, lds=1, prio=1):
+def run(ctx, P, n, bpc, qt, zero=False, secs=2.0, lds=1, prio=1, weighted=1):
     dev = torch.device("cuda", 0)
     qs, ts = zip(*[synth.orb_pair(n, n, seed=20260102 + p) for p in range(P)])
     dq = torch.from_numpy(np.stack(qs)).to(dev); dt = torch.from_numpy(np.stack(ts)).to(dev)
     if zero:
         dq.zero_(); dt.zero_()
-    ctx.set_option("hamming_mfma_blocks_per_cu", bpc); ctx.set_option("hamming_mfma_qt", qt); ctx.set_option("hamming_mfma_lds", lds); ctx.set_option("hamming_mfma_prio", prio)
+    ctx.set_option("hamming_mfma_blocks_per_cu", bpc); ctx.set_option("hamming_mfma_qt", qt); ctx.set_option("hamming_mfma_lds", lds); ctx.set_option("hamming_mfma_prio", prio); ctx.set_option("hamming_mfma_weighted", weighted)
     out = match_hamming_device(dq, dt, ctx=ctx)
     torch.cuda.synchronize()
     t0 = time.perf_counter(); k = 0
@@ -61,11 +61,11 @@ def run(ctx, P, n, bpc, qt, zero=False, secs=2.0, lds=1, prio=1):
     span = (s[:, 3].max() + s[:, 1].max() - s[:, 3].min()) / 100.0   # us, launch start -> last wave end (approx)
     units_total = P * (n // 32) ** 2
     waves = m
-    print(f"P={P} n={n} bpc={bpc} qt={qt} zero={zero} lds={lds} prio={prio}: step {step_us:.1f} us, waves {waves}, in-kernel clock {clk/1e9:.3f} GHz, "
+    print(f"P={P} n={n} bpc={bpc} qt={qt} zero={zero} lds={lds} prio={prio} weighted={weighted}: step {step_us:.1f} us, waves {waves}, in-kernel clock {clk/1e9:.3f} GHz, "
           f"wave-cycles/unit {cyc_unit:.0f}, kernel span ~{span:.1f} us, units/SIMD {units_total/1024:.0f}, "
           f"SIMD-cycles/unit (span) {span*1e-6*clk/(units_total/1024):.0f}")
 
 ctx = mpa.Context(0)
-for P, bpc, qt, lds, prio in [(8, 4, 0, 1, 0), (8, 4, 0, 1, 1), (8, 8, 0, 1, 1), (1, 4, 0, 1, 0), (1, 4, 0, 1, 1), (1, 4, 4, 1, 1)]:
-    run(ctx, P, 8192, bpc, qt, False, 1.0, lds, prio)
+for P, bpc, qt, lds, wt in [(8, 4, 0, 1, 0), (8, 4, 0, 1, 1), (1, 4, 0, 1, 0), (1, 4, 0, 1, 1), (4, 4, 0, 1, 0), (4, 4, 0, 1, 1)]:
+    run(ctx, P, 8192, bpc, qt, False, 1.0, lds, 0, wt)
 ctx.close()

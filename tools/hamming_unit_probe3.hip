@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <algorithm>
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
@@ -81,8 +82,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if ((threadIdx.x & 63) == 0) {
         const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        cyc[2 * w] = t1 - t0;
-        cyc[2 * w + 1] = r1 - r0;
+        cyc[4 * w] = t1 - t0;
+        cyc[4 * w + 1] = r1 - r0;
+        cyc[4 * w + 2] = r0;
+        cyc[4 * w + 3] = r1;
     }
     float s = 0.f;
     for (int t = 0; t < QT; ++t) s += m1[t] + m2[t];
@@ -93,17 +96,24 @@ template <int QT, int ILV, int WPE, int DB, int VALU>
 void run(const uint4 *src, float *out) {
     long long *dc;
     const int blocks = 256 * WPE, waves = blocks * 4, iters = 3000;
-    hipMalloc(&dc, waves * 16);
+    hipMalloc(&dc, waves * 32);
     int nb = 0;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, probe<QT, ILV, WPE, DB, VALU>, 256, 0);
     for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<QT, ILV, WPE, DB, VALU>), dim3(blocks), dim3(256), 0, 0, src, out, iters, dc);
-    std::vector<long long> h(waves * 2);
-    hipMemcpy(h.data(), dc, waves * 16, hipMemcpyDeviceToHost);
+    std::vector<long long> h(waves * 4);
+    hipMemcpy(h.data(), dc, waves * 32, hipMemcpyDeviceToHost);
     double cs = 0, rs = 0;
-    for (int i = 0; i < waves; ++i) cs += h[2 * i], rs += h[2 * i + 1];
+    long long rmin = h[2], rmax = h[3];
+    for (int i = 0; i < waves; ++i) {
+        cs += h[4 * i], rs += h[4 * i + 1];
+        rmin = std::min(rmin, h[4 * i + 2]);
+        rmax = std::max(rmax, h[4 * i + 3]);
+    }
+    const double span_cycles = (double)(rmax - rmin) * (cs / rs);  // realtime ticks (100 MHz) -> shader cycles
     const double per_wave_unit = cs / waves / (iters * (double)QT);
     printf("QT=%d ILV=%d DB=%d VALU=%d waves/SIMD=%d (occupancy API: %d blocks/CU): %.3f GHz, %6.1f cycles/unit/wave -> %6.1f cycles per unit per SIMD\n",
            QT, ILV, DB, VALU, WPE, nb, cs / rs * 0.1, per_wave_unit, per_wave_unit / WPE);
+    printf("      launch span: %.0f cycles -> %.1f cycles per unit per SIMD (AGGREGATE: all units / wall time)\n", span_cycles, span_cycles / (iters * (double)QT * WPE));
     hipFree(dc);
 }
 
@@ -168,8 +178,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if ((threadIdx.x & 63) == 0) {
         const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        cyc[2 * w] = t1 - t0;
-        cyc[2 * w + 1] = r1 - r0;
+        cyc[4 * w] = t1 - t0;
+        cyc[4 * w + 1] = r1 - r0;
+        cyc[4 * w + 2] = r0;
+        cyc[4 * w + 3] = r1;
     }
     float s = 0.f;
     for (int t = 0; t < QT; ++t)
@@ -180,17 +192,24 @@ template <int QT, int WPE, int VALU>
 void run16(const uint4 *src, float *out) {
     long long *dc;
     const int blocks = 256 * WPE, waves = blocks * 4, iters = 3000;
-    hipMalloc(&dc, waves * 16);
+    hipMalloc(&dc, waves * 32);
     int nb = 0;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, probe16<QT, WPE, VALU>, 256, 0);
     for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe16<QT, WPE, VALU>), dim3(blocks), dim3(256), 0, 0, src, out, iters, dc);
-    std::vector<long long> h(waves * 2);
-    hipMemcpy(h.data(), dc, waves * 16, hipMemcpyDeviceToHost);
+    std::vector<long long> h(waves * 4);
+    hipMemcpy(h.data(), dc, waves * 32, hipMemcpyDeviceToHost);
     double cs = 0, rs = 0;
-    for (int i = 0; i < waves; ++i) cs += h[2 * i], rs += h[2 * i + 1];
+    long long rmin = h[2], rmax = h[3];
+    for (int i = 0; i < waves; ++i) {
+        cs += h[4 * i], rs += h[4 * i + 1];
+        rmin = std::min(rmin, h[4 * i + 2]);
+        rmax = std::max(rmax, h[4 * i + 3]);
+    }
+    const double span_cycles = (double)(rmax - rmin) * (cs / rs);  // realtime ticks (100 MHz) -> shader cycles
     const double per_wave_unit = cs / waves / (iters * (double)QT);
     printf("16x16x128: QT=%d VALU=%d waves/SIMD=%d (occupancy API: %d blocks/CU): %.3f GHz, %6.1f cycles/unit/wave -> %6.1f cycles per unit per SIMD\n",
            QT, VALU, WPE, nb, cs / rs * 0.1, per_wave_unit, per_wave_unit / WPE);
+    printf("      launch span: %.0f cycles -> %.1f cycles per unit per SIMD (AGGREGATE)\n", span_cycles, span_cycles / (iters * (double)QT * WPE));
     hipFree(dc);
 }
 
@@ -265,8 +284,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if ((threadIdx.x & 63) == 0) {
         const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        cyc[2 * wv] = t1 - t0;
-        cyc[2 * wv + 1] = r1 - r0;
+        cyc[4 * wv] = t1 - t0;
+        cyc[4 * wv + 1] = r1 - r0;
+        cyc[4 * wv + 2] = r0;
+        cyc[4 * wv + 3] = r1;
     }
     float sres = 0.f;
     for (int t = 0; t < QT; ++t) sres += m1[t] + m2[t];
@@ -276,17 +297,126 @@ template <int QT, int WPE, int S, int SYNC>
 void run_ring(const uint4 *src, float *out) {
     long long *dc;
     const int blocks = 256 * WPE, waves = blocks * 4, iters = 3000;
-    hipMalloc(&dc, waves * 16);
+    hipMalloc(&dc, waves * 32);
     int nb = 0;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ringk<QT, WPE, S, SYNC>, 256, 0);
     for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((ringk<QT, WPE, S, SYNC>), dim3(blocks), dim3(256), 0, 0, src, out, iters, dc);
-    std::vector<long long> h(waves * 2);
-    hipMemcpy(h.data(), dc, waves * 16, hipMemcpyDeviceToHost);
+    std::vector<long long> h(waves * 4);
+    hipMemcpy(h.data(), dc, waves * 32, hipMemcpyDeviceToHost);
     double cs = 0, rs = 0;
-    for (int i = 0; i < waves; ++i) cs += h[2 * i], rs += h[2 * i + 1];
+    long long rmin = h[2], rmax = h[3];
+    for (int i = 0; i < waves; ++i) {
+        cs += h[4 * i], rs += h[4 * i + 1];
+        rmin = std::min(rmin, h[4 * i + 2]);
+        rmax = std::max(rmax, h[4 * i + 3]);
+    }
+    const double span_cycles = (double)(rmax - rmin) * (cs / rs);  // realtime ticks (100 MHz) -> shader cycles
     const double per_wave_unit = cs / waves / ((iters / S * S) * (double)QT);
     printf("ring: QT=%d S=%d SYNC=%d waves/SIMD=%d (occupancy API: %d blocks/CU): %.3f GHz, %6.1f cycles/unit/wave -> %6.1f cycles per unit per SIMD\n",
            QT, S, SYNC, WPE, nb, cs / rs * 0.1, per_wave_unit, per_wave_unit / WPE);
+    printf("      launch span: %.0f cycles -> %.1f cycles per unit per SIMD (AGGREGATE)\n", span_cycles, span_cycles / ((iters / S * S) * (double)QT * WPE));
+    hipFree(dc);
+}
+
+// 16-wave workgroups (1024 threads, ONE per CU): the four waves of every SIMD belong to the same workgroup and advance together
+// (one barrier per stage of S tiles), so there is no spread of finish times.  Wave w copies K-step (w & 3) of the tiles t with
+// (t & 3) == (w >> 2) of each group of four tiles; S must be a multiple of 4.
+template <int QT, int S>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void bigk(const uint4 *__restrict__ src, float *out,
+                                                                                        int iters, long long *cyc) {
+    constexpr int NBS = 3;
+    __shared__ __attribute__((aligned(16))) uint4 ring[NBS * S][256];
+    for (int i = threadIdx.x; i < NBS * S * 256; i += 1024) ring[i >> 8][i & 255] = src[i & 255];
+    __syncthreads();
+    const int l = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint4 b[QT][4];
+    for (int t = 0; t < QT; ++t)
+        for (int s = 0; s < 4; ++s) b[t][s] = src[l + 64 * (4 + 4 * t + s)];
+    v16f cinit;
+    for (int i = 0; i < 16; ++i) cinit[i] = -(float)i * (1.0f / 16384.0f);
+    float m1[QT], m2[QT];
+    for (int t = 0; t < QT; ++t) m1[t] = m2[t] = -1e30f;
+    const uint4 *tbase = src + (size_t)(w & 3) * 64;
+    auto copy_stage = [&](int st) {
+#pragma unroll
+        for (int k = (w >> 2); k < S; k += 4)
+            __builtin_amdgcn_global_load_lds((const void *)(tbase + (size_t)(((st * S + k) & 7) * 256) + l),
+                                             (__attribute__((address_space(3))) void *)&ring[(st % NBS) * S + k][(w & 3) * 64], 16, 0, 0);
+    };
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4 *)&ring[0][0] + (uint32_t)l * 16u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    copy_stage(0);
+    const long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    const int nst = iters / S;
+    for (int st = 0; st < nst; ++st) {
+        copy_stage(st + 1);
+        if (S == 4) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            u32x4 r[4];
+            const uint32_t addr = ring_lds + (uint32_t)((st % NBS) * S + k) * 4096u;
+            asm volatile(
+                "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+                : "v"(addr)
+                : "memory");
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(r[0]));
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r[1]));
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(r[2]));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[3]));
+            uint4 a[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a[s] = make_uint4(r[s].x, r[s].y, r[s].z, r[s].w);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                v16f acc = mf(a[0], b[t][0], cinit);
+#pragma unroll
+                for (int s = 1; s < 4; ++s) acc = mf(a[s], b[t][s], acc);
+                update(m1[t], m2[t], acc);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        cyc[4 * wv] = t1 - t0;
+        cyc[4 * wv + 1] = r1 - r0;
+        cyc[4 * wv + 2] = r0;
+        cyc[4 * wv + 3] = r1;
+    }
+    float sres = 0.f;
+    for (int t = 0; t < QT; ++t) sres += m1[t] + m2[t];
+    out[(blockIdx.x * blockDim.x + threadIdx.x) & 16383] = sres;
+}
+template <int QT, int S>
+void run_big(const uint4 *src, float *out) {
+    long long *dc;
+    const int blocks = 256, waves = blocks * 16, iters = 3000;
+    hipMalloc(&dc, waves * 32);
+    int nb = 0;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bigk<QT, S>, 1024, 0);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((bigk<QT, S>), dim3(blocks), dim3(1024), 0, 0, src, out, iters, dc);
+    std::vector<long long> h(waves * 4);
+    hipMemcpy(h.data(), dc, waves * 32, hipMemcpyDeviceToHost);
+    double cs = 0, rs = 0, mx = 0, mn = 1e30;
+    long long rmin = h[2], rmax = h[3];
+    for (int i = 0; i < waves; ++i) {
+        cs += h[4 * i], rs += h[4 * i + 1];
+        mx = std::max(mx, (double)h[4 * i]);
+        mn = std::min(mn, (double)h[4 * i]);
+        rmin = std::min(rmin, h[4 * i + 2]);
+        rmax = std::max(rmax, h[4 * i + 3]);
+    }
+    const double span_cycles = (double)(rmax - rmin) * (cs / rs);
+    const double per_wave_unit = cs / waves / ((iters / S * S) * (double)QT);
+    printf("16-wave blocks: QT=%d S=%d (occupancy API: %d blocks/CU): %.3f GHz, %6.1f cycles/unit/wave -> %6.1f cycles per unit per SIMD (min/max wave %.0f / %.0f kcycles)\n",
+           QT, S, nb, cs / rs * 0.1, per_wave_unit, per_wave_unit / 4, mn / 1e3, mx / 1e3);
+    printf("      launch span: %.0f cycles -> %.1f cycles per unit per SIMD (AGGREGATE)\n", span_cycles, span_cycles / ((iters / S * S) * (double)QT * 4));
     hipFree(dc);
 }
 
@@ -306,15 +436,14 @@ int main() {
         v = w;
     }
     hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-    run<4, 1, 4, 2, 1>(src, out);
+    run<4, 1, 3, 1, 1>(src, out);   // shipped r1 shape
+    run<4, 1, 4, 2, 1>(src, out);   // LDS-fed, 4 waves
+    run<4, 1, 4, 2, 0>(src, out);   // MFMA only
+    run<2, 1, 5, 2, 1>(src, out);
+    run<1, 1, 8, 2, 1>(src, out);
+    run<1, 1, 8, 2, 0>(src, out);
     run_ring<4, 4, 1, 1>(src, out);
-    run_ring<4, 4, 1, 0>(src, out);
-    run_ring<4, 4, 1, 2>(src, out);
-    run_ring<4, 4, 2, 1>(src, out);
-    run_ring<4, 4, 2, 0>(src, out);
-    run_ring<2, 4, 2, 1>(src, out);
-    run_ring<2, 5, 2, 1>(src, out);
-    run_ring<2, 5, 1, 1>(src, out);
+    run_big<4, 4>(src, out);
     hipDeviceSynchronize();
     return 0;
 }
