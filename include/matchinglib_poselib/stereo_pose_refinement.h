@@ -1,12 +1,25 @@
-// stereo_pose_refinement.h -- the hot-path slice of the reference's poselib::StereoRefine
-// (poselib/include/poselib/stereo_pose_refinement.h:100-313, poselib/source/stereo_pose_refinement.cpp:416-478,
-// 1272-1579).  What is kept: construction from ConfigPoseEstimation (K0, K1 mandatory), the pixel -> camera threshold
-// (th = th_pix_user * 4/(sqrt(2)(fx0+fy0+fx1+fy1))), addNewCorrespondences() = gather matched keypoints ->
-// ImgToCamCoordTrans + Remove_LensDist (pose_helper.cpp:1100-1109, 1169-1279; both on the GPU) -> robust estimation with the
-// non-USAC branch (estimateEssentialMat(RobMethod, th, refineRTold) + getPoseTriangPts(maxDist3DPtsZ)) on the GPU.
-// What is NOT built ("next"): the correspondence pool, pose history and
-// stability logic, refinement/BA; every call is a fresh robust estimation (the reference's first-call path).
+// stereo_pose_refinement.h -- drop-in for the reference's poselib::StereoRefine
+// (poselib/include/poselib/stereo_pose_refinement.h:100-334, poselib/source/stereo_pose_refinement.cpp).
+//
+// Built here: the whole multi-frame state machine of addNewCorrespondences() as the reference runs it for the estimators of the hot
+// path -- first-call robust initialisation; on later frames the strict getInliers() test against the last pose (GPU), the decision tree
+// on the inlier ratios (re-estimate / restore the last pose / re-initialise, :486-560), the correspondence pool with its minPtsDistance
+// filter and quality comparison (:2107-2316, :2450-2548), robust re-estimation on the pool (:1075-1128), pose history, the
+// near-to-mean pose rating and the stability flags (:2817-3298), maxSkipPairs handling (:3300-3317).
+// Every robust estimation and every error evaluation runs on the MI355X (estimateEssentialMat / getPoseTriangPts / mlpl_get_inliers_strict).
+//
+// Not built (outside the hot path): USAC, automatic thresholds (autoTH), homography alignment
+// (Halign), the linear refinement solvers (refineMethod / refineMethod_CorrPool: Nister/Stewenius/Kneip/8pt with weights), the old
+// robust refinement (refineRTold after the estimation) and bundle adjustment (BART).  Consequences, all reported once on std::cout:
+//   * RobMethod must be "RANSAC", "LMEDS" or "ARRSAC"; "USAC", autoTH and Halign make addNewCorrespondences() return -1;
+//   * refinement / BA options are ignored;
+//   * the pool is always re-estimated robustly (the reference's behaviour for checkPoolPoseRobust = 1) instead of refined linearly;
+//   * thinning an over-full pool (checkPoolSize) drops the lowest-weight correspondences; the reference first thins dense image regions
+//     by image morphology (cv::dilate / cv::erode on a density image), which is image-side work;
+//   * the radius search over the pool returns neighbours by ascending distance (the reference's nanoflann call leaves its dynamic
+//     kd-tree's traversal order).
 #pragma once
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -96,26 +109,38 @@ struct ConfigPoseEstimation {
 
 class StereoRefine {
    public:
-    cv::Mat E_new, Q, R_new, t_new;
-    cv::Mat E_mostLikely, R_mostLikely, t_mostLikely;  // == the newest pose (no history in this slice)
-    bool poseIsStable = false, mostLikelyPose_stable = false;
-    cv::Mat mask_E_new, mask_Q_new;
-    size_t nr_inliers_new = 0, nr_corrs_new = 0;
+    // reference stereo_pose_refinement.h:283-291
+    cv::Mat E_new;         // newest essential matrix
+    cv::Mat Q;             // 3-D points of the latest estimation
+    cv::Mat R_new;         // newest rotation
+    cv::Mat t_new;         // newest translation (unit norm)
+    cv::Mat E_mostLikely;  // pose of the history that is nearest to the centre of gravity of all stored poses
+    cv::Mat R_mostLikely;
+    cv::Mat t_mostLikely;
+    bool poseIsStable = false;
+    bool mostLikelyPose_stable = false;
 
     explicit StereoRefine(ConfigPoseEstimation cfg_pose_, bool verbose_ = false);
+    ~StereoRefine();
     void setNewParameters(ConfigPoseEstimation cfg_pose_);
-    // 0 ok, -1 too few correspondences / bad configuration, -2 robust estimation failed (reference codes:
-    // stereo_pose_refinement.cpp:411-414).
+    // 0 ok; -1 robust estimation failed / too few matches / unsupported configuration; -2 the pool had to be re-initialised;
+    // -3 too low an inlier ratio after the estimation on the pool (reference codes: stereo_pose_refinement.cpp:411-414).
     int addNewCorrespondences(std::vector<cv::DMatch> matches, std::vector<cv::KeyPoint> kp1, std::vector<cv::KeyPoint> kp2,
                               const poselib::ConfigUSAC &cfg);
-    size_t getCorrespondencePoolSize() { return 0; }
-    double inlierThreshold() const { return th; }
+    size_t getCorrespondencePoolSize();
+
+    // Read-only views of the private state the reference keeps (same names), for tests and diagnostics.
+    double inlierThreshold() const;
+    size_t nrInliersNew() const;
+    size_t nrCorrsNew() const;
+    size_t nrEstimations() const;
+    size_t skipCounter() const;
+    size_t poseHistorySize() const;
+    const cv::Mat &maskENew() const;
 
    private:
-    ConfigPoseEstimation cfg_pose;
-    double pixToCamFact = 0, th = 0;
-    bool verbose = false;
-    void init();
+    struct Impl;
+    std::unique_ptr<Impl> d;
 };
 
 }  // namespace poselib

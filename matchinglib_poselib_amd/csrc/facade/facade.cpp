@@ -1,5 +1,6 @@
 // facade.cpp -- C++ drop-in facade (reference signatures) over the C ABI of libmlpl_hip.so.  Host glue only: argument
 // checks, cv::Mat <-> pointer plumbing and the reference's error behaviour (return codes, cv::Exception, exit(1)).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -9,6 +10,7 @@
 #include "matchinglib_poselib/matchinglib_matchers.h"
 #include "matchinglib_poselib/pose_estim.h"
 #include "matchinglib_poselib/stereo_pose_refinement.h"
+#include "facade_internal.h"
 #include "mlpl_c.h"
 
 namespace {
@@ -29,6 +31,19 @@ mlpl_ctx *default_ctx() {
             // no CPU fallback: the drop-in fails loudly when the GPU path is unavailable
             throw cv::Exception(std::string("mlpl_ctx_create failed: ") + mlpl_last_error());
         }
+        // MLPL_OPTIONS="name=value,name=value": tuning knobs of mlpl_set_option for callers that only see the reference's API
+        if (const char *e = std::getenv("MLPL_OPTIONS")) {
+            std::string opts(e);
+            size_t pos = 0;
+            while (pos < opts.size()) {
+                const size_t end = std::min(opts.find(',', pos), opts.size());
+                const std::string kv = opts.substr(pos, end - pos);
+                const size_t eq = kv.find('=');
+                if (eq == std::string::npos || mlpl_set_option(h.ctx, kv.substr(0, eq).c_str(), std::atoi(kv.c_str() + eq + 1)) != MLPL_OK)
+                    throw cv::Exception("MLPL_OPTIONS: cannot apply '" + kv + "'");
+                pos = end + 1;
+            }
+        }
     }
     return h.ctx;
 }
@@ -48,6 +63,8 @@ std::vector<double> points64(cv::InputArray pa, int &n) {
 }
 
 }  // namespace
+
+mlpl_ctx *mlpl_facade_default_ctx() { return default_ctx(); }
 
 namespace matchinglib {
 
@@ -234,78 +251,6 @@ bool estimateRelativePose(cv::InputArray p1, cv::InputArray p2, cv::OutputArray 
         for (int r = 0; r < m.rows; ++r) std::memcpy(mo.ptr<uint8_t>(r), m.ptr<uint8_t>(r), (size_t)m.cols);
     }
     return ng >= 0;
-}
-
-// ---- StereoRefine (hot-path slice) -------------------------------------------------------------------------
-
-StereoRefine::StereoRefine(ConfigPoseEstimation cfg_pose_, bool verbose_) : cfg_pose(cfg_pose_), verbose(verbose_) { init(); }
-
-void StereoRefine::setNewParameters(ConfigPoseEstimation cfg_pose_) {
-    cfg_pose = cfg_pose_;
-    init();
-}
-
-void StereoRefine::init() {
-    CV_Assert(cfg_pose.K0 != nullptr && cfg_pose.K1 != nullptr && cfg_pose.dist0_8 != nullptr && cfg_pose.dist1_8 != nullptr);  // reference ctor
-    // stereo_pose_refinement.h:280-286
-    pixToCamFact = 4.0 / (std::sqrt(2.0) * (cfg_pose.K0->at<double>(0, 0) + cfg_pose.K0->at<double>(1, 1) +
-                                            cfg_pose.K1->at<double>(0, 0) + cfg_pose.K1->at<double>(1, 1)));
-    th = cfg_pose.th_pix_user * pixToCamFact;
-}
-
-int StereoRefine::addNewCorrespondences(std::vector<cv::DMatch> matches, std::vector<cv::KeyPoint> kp1,
-                                        std::vector<cv::KeyPoint> kp2, const poselib::ConfigUSAC &) {
-    if (cfg_pose.RobMethod != "RANSAC") {
-        std::cout << "StereoRefine (MI355X slice): only RobMethod == \"RANSAC\" is built." << std::endl;
-        return -1;
-    }
-    int n = (int)matches.size();
-    nr_corrs_new = (size_t)n;
-    if (n < 16) return -1;
-    // stereo_pose_refinement.cpp:428-455: gather the matched keypoints, ImgToCamCoordTrans on both sets, Remove_LensDist
-    // (drops correspondences whose undistortion fails; `false` when fewer than 16 remain), then CV_64F n x 2
-    std::vector<float> a((size_t)n * 2), b((size_t)n * 2);
-    for (int i = 0; i < n; ++i) {
-        const cv::Point2f pa = kp1[(size_t)matches[i].queryIdx].pt, pb = kp2[(size_t)matches[i].trainIdx].pt;
-        a[2 * i] = pa.x, a[2 * i + 1] = pa.y, b[2 * i] = pb.x, b[2 * i + 1] = pb.y;
-    }
-    const cv::Mat &K0 = *cfg_pose.K0, &K1 = *cfg_pose.K1;
-    const double k0[4] = {K0.at<double>(0, 0), K0.at<double>(1, 1), K0.at<double>(0, 2), K0.at<double>(1, 2)};
-    const double k1[4] = {K1.at<double>(0, 0), K1.at<double>(1, 1), K1.at<double>(0, 2), K1.at<double>(1, 2)};
-    mlpl_ctx *ctx = default_ctx();
-    if (mlpl_img_to_cam(ctx, a.data(), n, k0) != MLPL_OK || mlpl_img_to_cam(ctx, b.data(), n, k1) != MLPL_OK)
-        throw cv::Exception(std::string("mlpl_img_to_cam: ") + mlpl_last_error());
-    double d0[8] = {0}, d1[8] = {0};
-    auto read_dist = [](const cv::Mat *m, double *out) {
-        if (!m || m->empty()) return;
-        CV_Assert(m->rows * m->cols == 8 && m->type() == CV_64F);
-        for (int i = 0; i < 8; ++i) out[i] = m->rows == 1 ? m->at<double>(0, i) : m->at<double>(i, 0);
-    };
-    read_dist(cfg_pose.dist0_8, d0);
-    read_dist(cfg_pose.dist1_8, d1);
-    int n_left = n;
-    const int rcd = mlpl_remove_lens_dist(ctx, a.data(), b.data(), n, d0, d1, &n_left);
-    if (rcd == MLPL_E_FAILED) return -1;  // "Undistortion failed"
-    if (rcd != MLPL_OK) throw cv::Exception(std::string("mlpl_remove_lens_dist: ") + mlpl_last_error());
-    n = n_left;
-    cv::Mat p1(n, 2, CV_64F), p2(n, 2, CV_64F);
-    for (int i = 0; i < n; ++i) {
-        p1.at<double>(i, 0) = (double)a[2 * i], p1.at<double>(i, 1) = (double)a[2 * i + 1];
-        p2.at<double>(i, 0) = (double)b[2 * i], p2.at<double>(i, 1) = (double)b[2 * i + 1];
-    }
-    cv::Mat E, mask;
-    if (!estimateEssentialMat(E, p1, p2, cfg_pose.RobMethod, th, cfg_pose.refineRTold, mask)) return -2;
-    mask_E_new = mask.clone();
-    size_t ninl = 0;
-    for (int i = 0; i < n; ++i) ninl += mask.at<uint8_t>(0, i) != 0;
-    nr_inliers_new = ninl;
-    cv::Mat R, t, Q3;
-    cv::Mat mq = mask.clone();
-    if (getPoseTriangPts(E, p1, p2, R, t, Q3, mq, cfg_pose.maxDist3DPtsZ) < 0) return -2;  // stereo_pose_refinement.cpp:1557
-    mask_Q_new = mq;
-    E_new = E, R_new = R, t_new = t, Q = Q3;
-    E_mostLikely = E, R_mostLikely = R, t_mostLikely = t;
-    return 0;
 }
 
 }  // namespace poselib

@@ -121,7 +121,7 @@ int main(int argc, char **argv) {
     cfg_usac.matches = &mm, cfg_usac.keypoints1 = &a, cfg_usac.keypoints2 = &b;
     cfg_usac.nrMatchesVfcFiltered = (unsigned)mm.size();
     int32_t rc = sr.addNewCorrespondences(mm, a, b, cfg_usac);
-    int32_t inl = (int32_t)sr.nr_inliers_new;
+    int32_t inl = (int32_t)sr.nrInliersNew();
     double zero[9] = {0};
     fwrite(&rc, 4, 1, o);
     fwrite(rc == 0 ? (const void *)sr.E_new.data : (const void *)zero, 8, 9, o);
