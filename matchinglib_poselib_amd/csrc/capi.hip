@@ -162,6 +162,8 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "hamming_mfma_prio") && (value >= 0 && value <= 2)) ctx->opt_hamming_mfma_prio = value;
     else if (!std::strcmp(name, "hamming_mfma_weighted") && (value == 0 || value == 1)) ctx->opt_hamming_mfma_weighted = value;
     else if (!std::strcmp(name, "hamming_stamps") && (value == 0 || value == 1)) ctx->opt_hamming_stamps = value;
+    else if (!std::strcmp(name, "l2_mfma_waves") && (value == 0 || value == 4 || value == 8)) ctx->opt_l2_mfma_waves = value;
+    else if (!std::strcmp(name, "l2_mfma_blocks_per_cu") && value >= 0 && value <= 16) ctx->opt_l2_mfma_blocks_per_cu = value;
     else if (!std::strcmp(name, "hamming_qpl") && (value == 1 || value == 2)) ctx->opt_hamming_qpl = value;
     else if (!std::strcmp(name, "hamming_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_blocks_per_cu = value;
     else if (!std::strcmp(name, "ransac_lazy_sums") && (value == 0 || value == 1)) ctx->opt_ransac_lazy_sums = value;

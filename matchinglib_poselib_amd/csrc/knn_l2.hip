@@ -14,13 +14,15 @@
 // Keys are 64-bit (float_bits(d2) << 32 | trainIdx): non-negative floats order like unsigned ints, so the
 // running top-2 is a lexicographic (distance, trainIdx) min exactly like cvflann's KNNUniqueResultSet.
 
+#include <algorithm>
+
 #include "mlpl_internal.h"
 
 namespace mlpl {
 
 int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t, int nt,
-                       size_t t_stride, size_t t_bstride, int dim, int k, int batch, int32_t *d_idx, float *d_dist,
-                       hipStream_t s, int force, const int **gate_out);
+                       size_t t_stride, size_t t_bstride, int dim, int batch, hipStream_t s, int force, L2Gate *gate_out,
+                       const void **part_out, int *nsplit_out);
 
 namespace {
 
@@ -62,8 +64,8 @@ template <int DIM4, bool NMS>
 __global__ __launch_bounds__(kQPB) void knn_l2_exact_kernel(const float *__restrict__ q, size_t q_stride, size_t q_bstride,
                                                             const float *__restrict__ t, size_t t_stride, size_t t_bstride,
                                                             int nq, int nt, int dim, int rows_per_split, int nsplit, int tile_rows,
-                                                            ulonglong2 *__restrict__ part, const int *__restrict__ gate) {
-    if (gate && *gate == 0) return;  // auto mode: the MFMA pipeline already produced the (identical) result
+                                                            ulonglong2 *__restrict__ part, L2Gate gate) {
+    if (gate.flag && *gate.flag != gate.gen) return;  // auto mode: the MFMA kernel already produced the (identical) partials
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [tile_rows][dim_pad]
     const int dim_pad = (dim + 3) & ~3;
     const int tid = threadIdx.x;
@@ -133,11 +135,16 @@ __global__ __launch_bounds__(kQPB) void knn_l2_exact_kernel(const float *__restr
 }
 
 // LANES lanes per query: each lane folds every LANES-th split, xor-shuffles combine the lanes (64-bit (dist bits, row) keys).
+// Two partial tables may be offered: the exact kernel's (part, nsplit) and the MFMA kernel's (part_m, nsplit_m); the gate says which
+// one this call filled (one merge launch serves both outcomes of the auto path).
 template <int LANES>
-__global__ __launch_bounds__(256) void knn_l2_merge_kernel(const ulonglong2 *__restrict__ part, int nq, int nsplit, int k,
-                                                           int32_t *__restrict__ idx, float *__restrict__ dist,
-                                                           const int *__restrict__ gate, int gate_want) {
-    if (gate && ((*gate != 0) ? 1 : 0) != gate_want) return;
+__global__ __launch_bounds__(256) void knn_l2_merge_kernel(const ulonglong2 *__restrict__ part, int nsplit,
+                                                           const ulonglong2 *__restrict__ part_m, int nsplit_m, L2Gate gate, int nq,
+                                                           int k, int32_t *__restrict__ idx, float *__restrict__ dist) {
+    if (part_m && !(gate.flag && *gate.flag == gate.gen)) {
+        part = part_m;
+        nsplit = nsplit_m;
+    }
     const int b = blockIdx.y;
     const int sub = threadIdx.x & (LANES - 1);
     const int qi = blockIdx.x * (256 / LANES) + threadIdx.x / LANES;
@@ -165,20 +172,20 @@ __global__ __launch_bounds__(256) void knn_l2_merge_kernel(const ulonglong2 *__r
     }
 }
 
-}  // namespace
-
-void launch_knn_l2_merge(const void *part, int nq, int nsplit, int k, int batch, int32_t *d_idx, float *d_dist,
-                         hipStream_t s, const int *gate, int gate_want) {
-    if (nsplit <= 4) {
+void launch_knn_l2_merge(const void *part, int nsplit, const void *part_m, int nsplit_m, L2Gate gate, int nq, int k, int batch,
+                         int32_t *d_idx, float *d_dist, hipStream_t s) {
+    if (std::max(nsplit, nsplit_m) <= 4) {
         dim3 mgrid((nq + 255) / 256, batch);
-        hipLaunchKernelGGL(knn_l2_merge_kernel<1>, mgrid, dim3(256), 0, s, (const ulonglong2 *)part, nq, nsplit, k, d_idx, d_dist, gate,
-                           gate_want);
+        hipLaunchKernelGGL(knn_l2_merge_kernel<1>, mgrid, dim3(256), 0, s, (const ulonglong2 *)part, nsplit, (const ulonglong2 *)part_m,
+                           nsplit_m, gate, nq, k, d_idx, d_dist);
     } else {
         dim3 mgrid((nq + 15) / 16, batch);
-        hipLaunchKernelGGL(knn_l2_merge_kernel<16>, mgrid, dim3(256), 0, s, (const ulonglong2 *)part, nq, nsplit, k, d_idx, d_dist, gate,
-                           gate_want);
+        hipLaunchKernelGGL(knn_l2_merge_kernel<16>, mgrid, dim3(256), 0, s, (const ulonglong2 *)part, nsplit, (const ulonglong2 *)part_m,
+                           nsplit_m, gate, nq, k, d_idx, d_dist);
     }
 }
+
+}  // namespace
 
 int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t, int nt,
                   size_t t_stride, size_t t_bstride, int dim, int k, int batch, int32_t *d_idx, float *d_dist,
@@ -190,15 +197,25 @@ int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size
     }
     if (nq == 0) return MLPL_OK;
 
-    const int *gate = nullptr;
+    L2Gate gate{nullptr, 0};
+    const void *part_m = nullptr;
+    int nsplit_m = 0;
     if (ctx->l2_mode != 1 && !nms_order) {
-        // fp16 MFMA distance-GEMM when the data qualify (auto) or when forced.  In auto mode both pipelines are enqueued and a
-        // device flag written by the operand-preparation kernel decides which one does the work: no host round trip.
-        int rc = launch_knn_l2_mfma(ctx, d_q, nq, q_stride, q_bstride, d_t, nt, t_stride, t_bstride, dim, k, batch, d_idx,
-                                    d_dist, s, ctx->l2_mode == 2, &gate);
+        // fp16 MFMA distance-GEMM when the data qualify (auto) or when forced.  In auto mode both kernels are enqueued and a device
+        // flag written by the operand-preparation kernel decides which one does the work and which partial table the one merge reads:
+        // four launches, no host round trip.
+        int rc = launch_knn_l2_mfma(ctx, d_q, nq, q_stride, q_bstride, d_t, nt, t_stride, t_bstride, dim, batch, s, ctx->l2_mode == 2,
+                                    &gate, &part_m, &nsplit_m);
         if (rc < 0) return rc;
-        if (rc == 0 && ctx->l2_mode == 2) return MLPL_OK;
-        if (rc == 1) gate = nullptr;  // MFMA path not applicable at all: run the exact kernel unconditionally
+        if (rc == 0 && ctx->l2_mode == 2) {
+            launch_knn_l2_merge(nullptr, 0, part_m, nsplit_m, L2Gate{nullptr, 0}, nq, k, batch, d_idx, d_dist, s);
+            MLPL_HIP_TRY(hipGetLastError());
+            return MLPL_OK;
+        }
+        if (rc == 1) {  // MFMA path not applicable at all: run the exact kernel unconditionally
+            gate = L2Gate{nullptr, 0};
+            part_m = nullptr;
+        }
     }
 
     const int dim_pad = (dim + 3) & ~3;
@@ -234,7 +251,7 @@ int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size
     else if (g4 == 8) MLPL_L2_LAUNCH(8);
     else MLPL_L2_LAUNCH(0);
 #undef MLPL_L2_LAUNCH
-    launch_knn_l2_merge(part, nq, nsplit, k, batch, d_idx, d_dist, s, gate, 1);
+    launch_knn_l2_merge(part, nsplit, part_m, nsplit_m, gate, nq, k, batch, d_idx, d_dist, s);
     MLPL_HIP_TRY(hipGetLastError());
     return MLPL_OK;
 }

@@ -54,6 +54,13 @@ enum WsSlot {
 int launch_gather_match_points(const mlpl_dmatch *d_matches, int n, const float *d_kp1, const float *d_kp2, const double K0[4],
                                const double K1[4], double *d_p1, double *d_p2, hipStream_t s);
 
+// Device gate of the L2 auto path: *flag == gen <=> the descriptors of call `gen` are not integer-valued in [0,255] (knn_l2_mfma.hip).
+// flag == nullptr: no gate.
+struct L2Gate {
+    const int *flag;
+    int gen;
+};
+
 }  // namespace mlpl
 
 struct mlpl_ctx {
@@ -64,6 +71,10 @@ struct mlpl_ctx {
     void *pinned;  // small pinned host scratch for async result readback
     size_t pinned_bytes;
     int l2_mode;
+    int opt_l2_mfma_waves;          // waves per workgroup of the L2 matrix-core kernel: 4, 8 or 0 = automatic
+    int opt_l2_mfma_blocks_per_cu;  // its grid sizing target (0 = automatic)
+    int l2_gen;         // call counter of the L2 auto path (see L2Gate)
+    void *l2_flag_ptr;  // the flag buffer l2_gen counts for
     int num_cus;
     // tuning knobs (mlpl_set_option)
     int opt_hamming_variant;        // 3 = fp4 matrix-core kernel (default), 0 = LDS-tiled VALU, 1 = scalar-operand VALU, 2 = one wave per block
