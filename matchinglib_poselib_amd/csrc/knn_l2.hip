@@ -16,13 +16,13 @@
 
 #include <algorithm>
 
+#include "knn_l2_mfma_body.h"
 #include "mlpl_internal.h"
 
 namespace mlpl {
 
 int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t, int nt,
-                       size_t t_stride, size_t t_bstride, int dim, int batch, hipStream_t s, int force, L2Gate *gate_out,
-                       const void **part_out, int *nsplit_out);
+                       size_t t_stride, size_t t_bstride, int dim, int batch, hipStream_t s, int force, l2mfma::L2MfmaPlan *plan);
 
 namespace {
 
@@ -60,17 +60,27 @@ __device__ __forceinline__ void l2_group4_nms(float4 &t, float4 a, float4 b) {
 
 // NMS = false: cvflann::L2<float> order, squared distance (LINEAR).  NMS = true: NMSLIB "l2" space order and TRUE distance
 // sqrt(sum) (BRUTEFORCENMS, reference matchers.cpp:476-519); there the query is the first operand (x - y with x = query).
+struct L2ExactArgs {
+    const float *q;
+    size_t q_stride, q_bstride;
+    const float *t;
+    size_t t_stride, t_bstride;
+    int nq, nt, dim, rows_per_split, nsplit, tile_rows;
+    ulonglong2 *part;
+};
+
+// smem: [tile_rows][dim_pad] floats; (bx, by, bz) = (query block, split, batch item).  Every thread of the 256-thread workgroup calls.
 template <int DIM4, bool NMS>
-__global__ __launch_bounds__(kQPB) void knn_l2_exact_kernel(const float *__restrict__ q, size_t q_stride, size_t q_bstride,
-                                                            const float *__restrict__ t, size_t t_stride, size_t t_bstride,
-                                                            int nq, int nt, int dim, int rows_per_split, int nsplit, int tile_rows,
-                                                            ulonglong2 *__restrict__ part, L2Gate gate) {
-    if (gate.flag && *gate.flag != gate.gen) return;  // auto mode: the MFMA kernel already produced the (identical) partials
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [tile_rows][dim_pad]
+__device__ __forceinline__ void l2_exact_body(const L2ExactArgs &a, float *smem, int bx, int by, int bz) {
+    const float *__restrict__ q = a.q;
+    const float *__restrict__ t = a.t;
+    const size_t q_stride = a.q_stride, q_bstride = a.q_bstride, t_stride = a.t_stride, t_bstride = a.t_bstride;
+    const int nq = a.nq, nt = a.nt, dim = a.dim, rows_per_split = a.rows_per_split, nsplit = a.nsplit, tile_rows = a.tile_rows;
+    ulonglong2 *__restrict__ part = a.part;
     const int dim_pad = (dim + 3) & ~3;
     const int tid = threadIdx.x;
-    const int split = blockIdx.y, b = blockIdx.z;
-    const int qi = blockIdx.x * kQPB + tid;
+    const int split = by, b = bz;
+    const int qi = bx * kQPB + tid;
     q += (size_t)b * q_bstride;
     t += (size_t)b * t_bstride;
     const int ngroups = dim / 4;
@@ -132,6 +142,29 @@ __global__ __launch_bounds__(kQPB) void knn_l2_exact_kernel(const float *__restr
         }
     }
     if (qi < nq) part[((size_t)b * nsplit + split) * nq + qi] = make_ulonglong2(k0, k1);
+}
+
+template <int DIM4, bool NMS>
+__global__ __launch_bounds__(kQPB) void knn_l2_exact_kernel(L2ExactArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    l2_exact_body<DIM4, NMS>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The auto path in one launch: the operand-preparation kernel has decided (device flag) whether the descriptors are integer-valued
+// in [0,255]; if so the workgroups run the int8 matrix-core tile loop (knn_l2_mfma_body.h), otherwise the exact fp32 kernel body --
+// bit-identical results either way, different partial tables (the merge reads the same flag).  1-D grid = the larger of the two
+// grids; the surplus workgroups of the path taken exit at once.
+template <int DIM4, int KS>
+__global__ __launch_bounds__(kQPB) void knn_l2_auto_kernel(l2mfma::L2MfmaArgs m, unsigned grid_m, L2ExactArgs e, int qtiles_e,
+                                                           unsigned grid_e, L2Gate gate) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (*gate.flag != gate.gen) {
+        if (blockIdx.x < grid_m) l2mfma::l2_mfma_body<KS, 4>(m, reinterpret_cast<l2mfma::v4i *>(smem), blockIdx.x);
+        return;
+    }
+    if (blockIdx.x >= grid_e) return;
+    const int bx = blockIdx.x % qtiles_e, rest = blockIdx.x / qtiles_e;
+    l2_exact_body<DIM4, false>(e, smem, bx, rest % e.nsplit, rest / e.nsplit);
 }
 
 // LANES lanes per query: each lane folds every LANES-th split, xor-shuffles combine the lanes (64-bit (dist bits, row) keys).
@@ -200,22 +233,26 @@ int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size
     L2Gate gate{nullptr, 0};
     const void *part_m = nullptr;
     int nsplit_m = 0;
+    l2mfma::L2MfmaPlan plan{};
+    bool fused = false;
     if (ctx->l2_mode != 1 && !nms_order) {
-        // fp16 MFMA distance-GEMM when the data qualify (auto) or when forced.  In auto mode both kernels are enqueued and a device
-        // flag written by the operand-preparation kernel decides which one does the work and which partial table the one merge reads:
-        // four launches, no host round trip.
-        int rc = launch_knn_l2_mfma(ctx, d_q, nq, q_stride, q_bstride, d_t, nt, t_stride, t_bstride, dim, batch, s, ctx->l2_mode == 2,
-                                    &gate, &part_m, &nsplit_m);
+        // int8 matrix-core distance-GEMM when the data qualify (auto) or when forced.  In auto mode ONE kernel holds both paths and a
+        // device flag written by the operand-preparation kernel decides which one its workgroups run and which partial table the one
+        // merge reads: three launches, no host round trip.
+        int rc = launch_knn_l2_mfma(ctx, d_q, nq, q_stride, q_bstride, d_t, nt, t_stride, t_bstride, dim, batch, s, ctx->l2_mode == 2, &plan);
         if (rc < 0) return rc;
-        if (rc == 0 && ctx->l2_mode == 2) {
-            launch_knn_l2_merge(nullptr, 0, part_m, nsplit_m, L2Gate{nullptr, 0}, nq, k, batch, d_idx, d_dist, s);
-            MLPL_HIP_TRY(hipGetLastError());
-            return MLPL_OK;
+        if (rc == 0) {
+            part_m = plan.args.part;
+            nsplit_m = plan.args.nsplit;
+            if (ctx->l2_mode == 2) {
+                launch_knn_l2_merge(nullptr, 0, part_m, nsplit_m, L2Gate{nullptr, 0}, nq, k, batch, d_idx, d_dist, s);
+                MLPL_HIP_TRY(hipGetLastError());
+                return MLPL_OK;
+            }
+            gate = plan.gate;
+            fused = true;
         }
-        if (rc == 1) {  // MFMA path not applicable at all: run the exact kernel unconditionally
-            gate = L2Gate{nullptr, 0};
-            part_m = nullptr;
-        }
+        // rc == 1: the matrix-core path is not applicable at all: the exact kernel runs unconditionally
     }
 
     const int dim_pad = (dim + 3) & ~3;
@@ -237,20 +274,42 @@ int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size
     if (rc) return rc;
 
     const size_t shmem = (size_t)kTileRows * dim_pad * sizeof(float);
-    dim3 grid(qtiles, nsplit, batch);
-#define MLPL_L2_LAUNCH(D4)                                                                                                  \
-    if (nms_order)                                                                                                          \
-        hipLaunchKernelGGL((knn_l2_exact_kernel<D4, true>), grid, dim3(kQPB), shmem, s, d_q, q_stride, q_bstride, d_t,     \
-                           t_stride, t_bstride, nq, nt, dim, rps, nsplit, kTileRows, (ulonglong2 *)part, gate);            \
-    else                                                                                                                    \
-        hipLaunchKernelGGL((knn_l2_exact_kernel<D4, false>), grid, dim3(kQPB), shmem, s, d_q, q_stride, q_bstride, d_t, t_stride, \
-                       t_bstride, nq, nt, dim, rps, nsplit, kTileRows, (ulonglong2 *)part, gate)
+    const L2ExactArgs ea{d_q, q_stride, q_bstride, d_t, t_stride, t_bstride, nq, nt, dim, rps, nsplit, kTileRows, (ulonglong2 *)part};
     const int g4 = dim / 4;
-    if (g4 == 32) MLPL_L2_LAUNCH(32);
-    else if (g4 == 16) MLPL_L2_LAUNCH(16);
-    else if (g4 == 8) MLPL_L2_LAUNCH(8);
-    else MLPL_L2_LAUNCH(0);
+    if (fused) {
+        const long long grid_e = (long long)qtiles * nsplit * batch;
+        if (grid_e > 0x7FFFFFFFLL) {
+            set_error("knn_l2: problem too large (%lld workgroups)", grid_e);
+            return MLPL_E_BAD_INPUT;
+        }
+        const unsigned grid = std::max<unsigned>(plan.grid, (unsigned)grid_e);
+        const size_t lds = std::max<size_t>(shmem, 18432);  // l2_mfma_lds_bytes<KS>() <= 18432 for every KS
+        prof_mark(ctx, MLPL_PROF_KNN_L2, 0, s);
+#define MLPL_L2_AUTO(D4, KS)                                                                                                         \
+    hipLaunchKernelGGL((knn_l2_auto_kernel<D4, KS>), dim3(grid), dim3(kQPB), lds, s, plan.args, plan.grid, ea, qtiles, (unsigned)grid_e, \
+                       gate)
+        if (g4 == 32 && plan.ksel == 4) MLPL_L2_AUTO(32, 4);
+        else if (g4 == 16 && plan.ksel == 2) MLPL_L2_AUTO(16, 2);
+        else if (g4 == 8 && plan.ksel == 1) MLPL_L2_AUTO(8, 1);
+        else if (plan.ksel == 1) MLPL_L2_AUTO(0, 1);
+        else if (plan.ksel == 2) MLPL_L2_AUTO(0, 2);
+        else if (plan.ksel == 4) MLPL_L2_AUTO(0, 4);
+        else MLPL_L2_AUTO(0, 8);
+#undef MLPL_L2_AUTO
+        prof_mark(ctx, MLPL_PROF_KNN_L2, 1, s);
+    } else {
+        dim3 grid(qtiles, nsplit, batch);
+#define MLPL_L2_LAUNCH(D4)                                                                              \
+    if (nms_order)                                                                                      \
+        hipLaunchKernelGGL((knn_l2_exact_kernel<D4, true>), grid, dim3(kQPB), shmem, s, ea);            \
+    else                                                                                                \
+        hipLaunchKernelGGL((knn_l2_exact_kernel<D4, false>), grid, dim3(kQPB), shmem, s, ea)
+        if (g4 == 32) MLPL_L2_LAUNCH(32);
+        else if (g4 == 16) MLPL_L2_LAUNCH(16);
+        else if (g4 == 8) MLPL_L2_LAUNCH(8);
+        else MLPL_L2_LAUNCH(0);
 #undef MLPL_L2_LAUNCH
+    }
     launch_knn_l2_merge(part, nsplit, part_m, nsplit_m, gate, nq, k, batch, d_idx, d_dist, s);
     MLPL_HIP_TRY(hipGetLastError());
     return MLPL_OK;

@@ -22,28 +22,14 @@
 
 #include <algorithm>
 
+#include "knn_l2_mfma_body.h"
 #include "mlpl_internal.h"
 
 namespace mlpl {
 
 namespace {
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-typedef unsigned long long u64;
-
-constexpr int kMaxKS = 8;  // dim <= 256
-
-__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+using namespace l2mfma;
 
 // Operand preparation, one launch for both sets (blockIdx.z = 0 queries, 1 train rows), one block per 32-row tile:
 //   frag[(tile*KS + s)*64 + lane] = 16 int8: enc(X[tile*32 + (lane&31)][32 s + 16 (lane>>5) + j]), enc = x - 128 (queries) / 127 - x
@@ -60,6 +46,8 @@ struct L2PrepArgs {
     int *cst;
 };
 
+// VEC: rows are 16-byte aligned and dim is a multiple of 16 -> four 16-byte loads per half-step instead of sixteen scalar ones.
+template <bool VEC>
 __global__ __launch_bounds__(256) void l2_prep_kernel(L2PrepArgs qa, L2PrepArgs ta, int dim, int KS, int *__restrict__ flag, int gen) {
     const L2PrepArgs A = blockIdx.z ? ta : qa;
     const int tile = blockIdx.x;
@@ -75,11 +63,22 @@ __global__ __launch_bounds__(256) void l2_prep_kernel(L2PrepArgs qa, L2PrepArgs 
     for (int u = c; u < 2 * KS; u += 8) {
         const int k0 = 16 * u;
         uint32_t w[4] = {0, 0, 0, 0};
+        float xv[16];
+        if constexpr (VEC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < A.n && k0 < dim) f = *reinterpret_cast<const float4 *>(x + k0 + 4 * j);
+                xv[4 * j] = f.x, xv[4 * j + 1] = f.y, xv[4 * j + 2] = f.z, xv[4 * j + 3] = f.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) xv[j] = (row < A.n && k0 + j < dim) ? x[k0 + j] : 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            float v = 0.f;
             const bool in = row < A.n && k0 + j < dim;
-            if (in) v = x[k0 + j];
+            const float v = xv[j];
             bad = bad || !(v >= 0.f && v <= 255.f && v == floorf(v));
             const int iv = (int)v;
             s1 += iv;
@@ -100,150 +99,23 @@ __global__ __launch_bounds__(256) void l2_prep_kernel(L2PrepArgs qa, L2PrepArgs 
     }
 }
 
-// One workgroup = W waves = W query tiles (32 queries each) against the train tiles of one split, consumed in groups of G = 16/KS tiles
-// (16 KiB of LDS; 8 tiles for KS = 1).  A whole group is requested from memory at once and the next group's loads are in flight (16 VGPRs per thread)
-// while this one is multiplied.  Work items are numbered so that each XCD (block id mod 8) owns a contiguous range of
-// (batch, split, query block): neighbouring splits share an L2, so each XCD pulls every query fragment but only an eighth of the
-// train fragments across the fabric.
+// Stand-alone form of the tile loop (forced mode, any W); the auto path runs the same body inside knn_l2_auto_kernel (knn_l2.hip).
 template <int KS, int W>
-__global__ __launch_bounds__(64 * W, 2) void knn_l2_mfma_kernel(const uint4 *__restrict__ qfrag, const int *__restrict__ qcst,
-                                                             const uint4 *__restrict__ tfrag, const int *__restrict__ tcst, int nq,
-                                                             int nt, int nq_tiles, int nt_tiles, int tiles_per_split, int nsplit,
-                                                             int qblocks, int batch, int ib, ulonglong2 *__restrict__ part, L2Gate gate,
-                                                             unsigned long long *__restrict__ stamps) {
-    unsigned long long st0 = 0, st1 = 0;
-    if (stamps) st0 = __builtin_readcyclecounter(), st1 = __builtin_amdgcn_s_memrealtime();
-    constexpr int G = KS == 1 ? 8 : 16 / KS;  // tiles per group (at most 256 rows: one thread per row in commit)
-    constexpr int NT = 64 * W;               // threads
-    constexpr int kPre = G * KS * 64 / NT;   // uint4 per thread and group
-    // (native vector types throughout the staging path: an array of HIP_vector_type structs is not split into registers and ends up
-    // in scratch, with a wait per load)
-    __shared__ __attribute__((aligned(16))) v4i lds[G * KS * 64 + 2 * G * 8];  // fragments | accumulator starts | row words
-    v4i *tileA = lds;
-    int *tileC = reinterpret_cast<int *>(lds + G * KS * 64);
-    uint32_t *tileR = reinterpret_cast<uint32_t *>(lds + G * KS * 64 + G * 8);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware work numbering
-    const long long total = (long long)batch * nsplit * qblocks, per_xcd = (total + 7) / 8;
-    const long long j = blockIdx.x >> 3, w = (long long)(blockIdx.x & 7) * per_xcd + j;
-    if (j >= per_xcd || w >= total) return;
-    const int qb = (int)(w % qblocks), split = (int)((w / qblocks) % nsplit), b = (int)(w / ((long long)qblocks * nsplit));
-    const int qtile = qb * W + wave;
-    const bool wave_active = qtile < nq_tiles;
-    qfrag += (size_t)b * nq_tiles * KS * 64;
-    tfrag += (size_t)b * nt_tiles * KS * 64;
-    qcst += (size_t)b * nq_tiles * 32;
-    tcst += (size_t)b * nt_tiles * 32;
-
-    const int t_begin = split * tiles_per_split;
-    const int t_end = min(nt_tiles, t_begin + tiles_per_split);
-    v4i pre[kPre];
-    int pre_c = 0;
-    // a whole group is always moved (no per-load predicates: they would serialise the loads); what lies past t_end is the next
-    // split's tiles or the padding the launcher allocates behind the last tile, and is never multiplied
-    auto fetch = [&](int t0) {
-        const v4i *src = reinterpret_cast<const v4i *>(tfrag) + (size_t)t0 * KS * 64;
-#pragma unroll
-        for (int i = 0; i < kPre; ++i) pre[i] = src[tid + NT * i];
-        pre_c = tcst[t0 * 32 + (tid & (G * 32 - 1))];
-    };
-    auto commit = [&](int t0) {
-#pragma unroll
-        for (int i = 0; i < kPre; ++i) tileA[tid + NT * i] = pre[i];
-        if (G * 32 >= NT || tid < G * 32) {
-            tileC[tid] = pre_c >> 1;
-            // rows past the end of the train set get an all-ones row word: their keys come out as 0xFFFFFFFF = "none"
-            tileR[tid] = (t0 * 32 + tid < nt) ? (((uint32_t)pre_c & 1u) << ib) | (uint32_t)tid : 0xFFFFFFFFu;
-        }
-    };
-    // every load of the prologue is issued before the first wait (the gate test below), so the block pays one round trip, not three
-    if (t_begin < t_end) fetch(t_begin);
-    v4i qf[KS];
-    const int qtile_ld = wave_active ? qtile : 0;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) qf[s] = reinterpret_cast<const v4i *>(qfrag)[((size_t)qtile_ld * KS + s) * 64 + lane];
-    const int qd = qcst[qtile_ld * 32 + (lane & 31)];
-    if (*gate.flag == gate.gen) return;  // some element is not an integer in [0,255]: the exact kernel (gated the other way) runs instead
-
-    u64 g0 = ~0ull, g1 = ~0ull;  // (float bits of d2) << 32 | train row
-    auto upd = [&](u64 g) {
-        const bool lt0 = g < g0, lt1 = g < g1;
-        g1 = lt0 ? g0 : (lt1 ? g : g1);
-        g0 = lt0 ? g : g0;
-    };
-    const uint32_t lmask = (1u << ib) - 1u;
-    for (int t0 = t_begin; t0 < t_end; t0 += G) {
-        if (t0 != t_begin) __syncthreads();  // every wave is done with the previous group
-        commit(t0);
-        if (t0 + G < t_end) fetch(t0 + G);
-        __syncthreads();
-        const int g_end = min(t0 + G, t_end);
-        uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
-        for (int t = t0; t < g_end; ++t) {
-            const v4i *A = tileA + (t - t0) * KS * 64;
-            // accumulator reg r of this lane is train row (r&3) + 8 (r>>2) + 4 (lane>>5) of the tile, query lane&31; it starts at Tcb >> 1
-            v16i acc;
-            uint32_t rw[16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const v4i c4 = *reinterpret_cast<const v4i *>(&tileC[(t - t0) * 32 + 8 * g + 4 * (lane >> 5)]);
-                const v4i r4 = *reinterpret_cast<const v4i *>(&tileR[(t - t0) * 32 + 8 * g + 4 * (lane >> 5)]);
-                acc[4 * g] = c4[0], acc[4 * g + 1] = c4[1], acc[4 * g + 2] = c4[2], acc[4 * g + 3] = c4[3];
-                rw[4 * g] = (uint32_t)r4[0], rw[4 * g + 1] = (uint32_t)r4[1], rw[4 * g + 2] = (uint32_t)r4[2], rw[4 * g + 3] = (uint32_t)r4[3];
-            }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[s * 64 + lane], qf[s], acc, 0, 0, 0);
-            }
-            uint32_t key[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) key[r] = ((uint32_t)acc[r] << (ib + 1)) | rw[r];
-            // four candidates per step, 5 ops: with T = {k0, a, b} the second smallest of T + {k1} is min(med3(T), k1) because k1 >= k0
-#pragma unroll
-            for (int r = 0; r < 16; r += 4) {
-                const uint32_t s0 = umed3(k0, key[r], key[r + 1]);
-                const uint32_t u0 = umin3(k0, key[r], key[r + 1]);
-                const uint32_t s1 = umed3(u0, key[r + 2], key[r + 3]);
-                k0 = umin3(u0, key[r + 2], key[r + 3]);
-                k1 = umin3(k1, s0, s1);
-            }
-        }
-        // fold the group's pair into the 64-bit keys: d2 = e + Qd is exact in float (< 2^24)
-        auto to_global = [&](uint32_t key) -> u64 {
-            if (key == 0xFFFFFFFFu) return ~0ull;
-            const float d = (float)((int)(key >> ib) + qd);
-            return ((u64)__float_as_uint(d) << 32) | (u64)((uint32_t)t0 * 32u + (key & lmask));
-        };
-        upd(to_global(k0));
-        upd(to_global(k1));
-    }
-    // combine the two lanes that share a query column
-    const u64 o0 = __shfl_xor(g0, 32), o1 = __shfl_xor(g1, 32);
-    upd(o0);
-    upd(o1);
-    const int qi = qtile * 32 + (lane & 31);
-    if (wave_active && lane < 32 && qi < nq) part[((size_t)b * nsplit + split) * nq + qi] = make_ulonglong2(g0, g1);
-    if (stamps && tid == 0) {  // diagnostics: {cycles, start tick (100 MHz), end tick, hardware id} per workgroup
-        unsigned hw = 0, xcc = 0;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long *o = stamps + 4 * (size_t)w;
-        o[0] = __builtin_readcyclecounter() - st0;
-        o[1] = st1;
-        o[2] = __builtin_amdgcn_s_memrealtime();
-        o[3] = (unsigned long long)hw | ((unsigned long long)(xcc & 0xF) << 32);
-    }
+__global__ __launch_bounds__(64 * W, 2) void knn_l2_mfma_kernel(L2MfmaArgs a, L2Gate gate) {
+    __shared__ __attribute__((aligned(16))) v4i lds[l2_mfma_lds_bytes<KS>() / 16];
+    if (*gate.flag == gate.gen) return;  // some element is not an integer in [0,255]
+    l2_mfma_body<KS, W>(a, lds, blockIdx.x);
 }
 
 }  // namespace
 
-// Returns 1 when the matrix-core path cannot apply at all (caller runs the exact kernel ungated), 0 when the operand preparation and
-// the MFMA kernel were enqueued: *part_out / *nsplit_out describe its partial table and *gate_out the device flag (flag == gen: the
-// data did not qualify, the MFMA kernel exited early and the caller's exact kernel, gated the other way, produces the partials).  The
-// caller launches the one merge.  < 0 on error.  Nothing here synchronises in auto mode, so the *_dev entry points stay asynchronous.
+// Prepares the matrix-core path: enqueues the operand preparation and fills *plan (kernel arguments, K-step class, gate, grid).
+// Returns 1 when the path cannot apply at all (caller runs the exact kernel ungated), 0 on success, < 0 on error.  In forced mode the
+// stand-alone tile-loop kernel is enqueued here as well (after a host check of the gate); in auto mode the caller launches
+// knn_l2_auto_kernel, which runs this plan or the exact kernel's depending on the device flag, and then the one merge.  Nothing here
+// synchronises in auto mode, so the *_dev entry points stay asynchronous.
 int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t, int nt,
-                       size_t t_stride, size_t t_bstride, int dim, int batch, hipStream_t s, int force, L2Gate *gate_out,
-                       const void **part_out, int *nsplit_out) {
+                       size_t t_stride, size_t t_bstride, int dim, int batch, hipStream_t s, int force, L2MfmaPlan *plan) {
     const int KS = (dim + 31) / 32;
     int ksel = 0;
     for (int c : {1, 2, 4, 8})
@@ -283,8 +155,11 @@ int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride,
     const L2Gate gate{dflag, ++ctx->l2_gen};
     {
         const L2PrepArgs qa{d_q, q_stride, q_bstride, nq, nq_tiles, (uint4 *)qf, qc}, ta{d_t, t_stride, t_bstride, nt, nt_tiles, (uint4 *)tf, tc};
-        hipLaunchKernelGGL(l2_prep_kernel, dim3((unsigned)std::max(nq_tiles, nt_tiles), batch, 2), dim3(256), 0, s, qa, ta, dim, ksel,
-                           dflag, gate.gen);
+        const bool vec = dim % 16 == 0 && ((uintptr_t)d_q | (uintptr_t)d_t) % 16 == 0 &&
+                         (q_stride | q_bstride | t_stride | t_bstride) % 4 == 0;
+        const dim3 pgrid((unsigned)std::max(nq_tiles, nt_tiles), batch, 2);
+        if (vec) hipLaunchKernelGGL(l2_prep_kernel<true>, pgrid, dim3(256), 0, s, qa, ta, dim, ksel, dflag, gate.gen);
+        else hipLaunchKernelGGL(l2_prep_kernel<false>, pgrid, dim3(256), 0, s, qa, ta, dim, ksel, dflag, gate.gen);
     }
     if (force) {  // forcing is a test/diagnostic mode: report non-qualifying data as an error (one host hop)
         int hflag = 0;
@@ -295,15 +170,17 @@ int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride,
             return MLPL_E_BAD_INPUT;
         }
     }
-    *gate_out = gate;
+    plan->gate = gate;
 
     // Waves (= query tiles) per workgroup and train tiles per split (a whole number of groups).  What bounds this kernel on the
     // sizes of an image pair is the traffic from L2 into the CUs (a workgroup loads W query tiles and tps train tiles for W * tps
     // tile products), so the workgroup is made as square as the grid allows: 8 waves when that still gives every CU a workgroup.
     int waves = ctx->opt_l2_mfma_waves;
-    if (waves != 4 && waves != 8) waves = ((long long)((nq_tiles + 7) / 8) * ((nt_tiles + 7) / 8) * batch >= ctx->num_cus) ? 8 : 4;
+    if (!force) waves = 4;  // the fused auto-path kernel is a 256-thread kernel
+    else if (waves != 4 && waves != 8) waves = ((long long)((nq_tiles + 7) / 8) * ((nt_tiles + 7) / 8) * batch >= ctx->num_cus) ? 8 : 4;
     const int qblocks = (nq_tiles + waves - 1) / waves;
-    const int per_cu = ctx->opt_l2_mfma_blocks_per_cu > 0 ? ctx->opt_l2_mfma_blocks_per_cu : (waves == 8 ? 1 : 4);
+    // (the fused auto-path kernel carries the exact kernel's registers: two 256-thread workgroups per CU for 128-dim descriptors)
+    const int per_cu = ctx->opt_l2_mfma_blocks_per_cu > 0 ? ctx->opt_l2_mfma_blocks_per_cu : (waves == 8 ? 1 : (force ? 4 : 2));
     long long want_splits = ((long long)per_cu * ctx->num_cus + (long long)qblocks * batch - 1) / ((long long)qblocks * batch);
     int tps = (int)std::max<long long>(1, (nt_tiles + want_splits - 1) / std::max<long long>(1, want_splits));
     tps = (tps + group - 1) / group * group;
@@ -322,11 +199,13 @@ int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride,
         stamps = (unsigned long long *)sp;
         ctx->dbg_stamp_items = (int)total;
     }
+    plan->args = L2MfmaArgs{(const uint4 *)qf, (const int *)qc, (const uint4 *)tf, (const int *)tc, nq, nt, nq_tiles, nt_tiles, tps, nsplit,
+                            qblocks, batch, ib, (ulonglong2 *)part, stamps};
+    plan->ksel = ksel;
+    plan->grid = grid;
+    if (!force) return MLPL_OK;
     prof_mark(ctx, MLPL_PROF_KNN_L2, 0, s);
-#define MLPL_MFMA_LAUNCH_W(K, WV)                                                                                                    \
-    hipLaunchKernelGGL((knn_l2_mfma_kernel<K, WV>), dim3(grid), dim3(64 * WV), 0, s, (const uint4 *)qf, (const int *)qc,                  \
-                       (const uint4 *)tf, (const int *)tc, nq, nt, nq_tiles, nt_tiles, tps, nsplit, qblocks, batch, ib, (ulonglong2 *)part, \
-                       gate, stamps)
+#define MLPL_MFMA_LAUNCH_W(K, WV) hipLaunchKernelGGL((knn_l2_mfma_kernel<K, WV>), dim3(grid), dim3(64 * WV), 0, s, plan->args, gate)
 #define MLPL_MFMA_LAUNCH(K)          \
     if (waves == 8)                  \
         MLPL_MFMA_LAUNCH_W(K, 8);    \
@@ -342,8 +221,6 @@ int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride,
 #undef MLPL_MFMA_LAUNCH
     prof_mark(ctx, MLPL_PROF_KNN_L2, 1, s);
     MLPL_HIP_TRY(hipGetLastError());
-    *part_out = part;
-    *nsplit_out = nsplit;
     return MLPL_OK;
 }
 
