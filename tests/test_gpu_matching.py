@@ -185,7 +185,7 @@ def _set_l2(ctx, mode):
 @pytest.mark.parametrize("nq,nt,dim", [(4096, 4096, 128), (300, 1000, 128), (33, 65, 64), (100, 257, 32), (64, 64, 100),
                                        (50, 700, 256), (31, 40, 16)])
 def test_l2_mfma_integer_descriptors_bit_exact(ctx, oracle, nq, nt, dim):
-    """fp16 MFMA distance-GEMM path on integer-valued 0..255 descriptors (OpenCV SIFT layout): bit-exact vs cvflann order."""
+    """int8 matrix-core distance-GEMM path on integer-valued 0..255 descriptors (OpenCV SIFT layout): bit-exact vs cvflann order."""
     q, t = synth.sift_pair(nq, nt, dim=dim, seed=900 + nq + dim)
     if nt > 10:
         t[7] = t[3]            # duplicated train rows -> exact distance ties -> smaller index must win
@@ -203,6 +203,32 @@ def test_l2_mfma_integer_descriptors_bit_exact(ctx, oracle, nq, nt, dim):
         idx, dist = idx[sub], dist[sub]
     assert np.array_equal(idx, oi)
     assert dist.tobytes() == od.tobytes()
+
+
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("nq,nt,dim", [(16384, 8192, 128), (5000, 9000, 64), (777, 40000, 128), (3000, 3000, 255), (2500, 2500, 129), (900, 900, 7)])
+def test_l2_matrix_core_many_groups_per_split_and_extreme_values(ctx, oracle, nq, nt, dim, waves):
+    """Sizes at which a workgroup walks several groups of train tiles (the 64-bit fold between groups), both workgroup shapes of the
+    forced mode and the fused auto-path kernel; rows of all 0 / all 255 (largest d^2, largest key), K-padding (dim % 32 != 0)."""
+    q, t = synth.sift_pair(nq, nt, dim=dim, seed=4000 + nq + dim)
+    t[0] = 0.0
+    t[1] = 255.0
+    q[0] = 255.0            # nearest: t[1] at d^2 = 0; farthest possible: t[0] at 255^2 dim
+    q[1] = 0.0
+    t[nt - 1] = t[nt // 2]  # a tie across splits: the smaller index must win
+    q[2] = t[nt // 2]
+    sub = np.unique(np.concatenate([np.arange(0, 8), np.arange(0, nq, max(1, nq // 97)), [nq - 1]]))
+    oi, od = oracle.knn_l2sq(q[sub], t)
+    assert od[2, 0] == 0.0 and oi[2, 0] == nt // 2 and oi[2, 1] == nt - 1
+    ctx.set_option("l2_mfma_waves", waves)
+    try:
+        for mode in (2, 0):
+            _set_l2(ctx, mode)
+            idx, dist = mpa.knn_l2sq(q, t, ctx=ctx)
+            assert np.array_equal(idx[sub], oi) and dist[sub].tobytes() == od.tobytes(), (mode, waves)
+    finally:
+        _set_l2(ctx, 0)
+        ctx.set_option("l2_mfma_waves", 0)
 
 
 @pytest.mark.parametrize("dim", [256, 200, 144])

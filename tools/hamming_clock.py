@@ -66,6 +66,9 @@ def run(ctx, P, n, bpc, qt, zero=False, secs=2.0, lds=1, prio=1, weighted=1):
           f"SIMD-cycles/unit (span) {span*1e-6*clk/(units_total/1024):.0f}")
 
 ctx = mpa.Context(0)
-for P, bpc, qt, lds, wt in [(8, 4, 0, 1, 0), (8, 4, 0, 1, 1), (1, 4, 0, 1, 0), (1, 4, 0, 1, 1), (4, 4, 0, 1, 0), (4, 4, 0, 1, 1)]:
+CASES = [(8, 4, 0, 1, 0), (8, 4, 0, 1, 1), (1, 4, 0, 1, 0), (1, 4, 0, 1, 1), (4, 4, 0, 1, 0), (4, 4, 0, 1, 1)]
+if len(sys.argv) > 1 and sys.argv[1] == 'ab':  # same-box A/B of the 8-pair step: register-prefetch kernel (r1) vs LDS ring, twice
+    CASES = [(8, 3, 0, 0, 0), (8, 4, 0, 1, 0), (8, 4, 0, 1, 1), (8, 3, 0, 0, 0), (8, 4, 0, 1, 1)]
+for P, bpc, qt, lds, wt in CASES:
     run(ctx, P, 8192, bpc, qt, False, 1.0, lds, 0, wt)
 ctx.close()
