@@ -897,49 +897,86 @@ __global__ void hyp_max_kernel(const int32_t *__restrict__ n_models, const int32
     hmax[i] = h;
 }
 
+// Scans over the hypotheses of a pass in iteration order, one 1024-thread block.  Wave w owns the contiguous range
+// [w*R*64, (w+1)*R*64), R = ceil(cnt / 1024), and walks it in rows of 64 (lane = position in the row): loads are coalesced and
+// independent of the scan state, row scans are wave shuffles, and the 16 waves meet only once per phase to exchange one value each
+// (the chunk-per-step form of round 1 paid a global-load latency and up to three block barriers per 1024 hypotheses).
+constexpr int kScanBatch = 8;  // rows whose loads are in flight together
+
+template <bool kMax>
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off);
+        if (lane >= off) v = kMax ? max(v, o) : min(v, o);
+    }
+    return v;
+}
+template <bool kMax>
+__device__ __forceinline__ int wave_reduce(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(v, off);
+        v = kMax ? max(v, o) : min(v, o);
+    }
+    return v;
+}
+// Every wave contributes `v` (wave-uniform); returns the combination of `carry` and the contributions of the waves before this one.
+template <bool kMax>
+__device__ __forceinline__ int waves_exclusive_scan_16(int v, int carry, int *wave_s) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();  // wave_s may still be read from an earlier exchange
+    if (lane == 0) wave_s[wave] = v;
+    __syncthreads();
+    int pre = carry;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int c = wave_s[w];
+        if (w < wave) pre = kMax ? max(pre, c) : min(pre, c);
+    }
+    return pre;
+}
+
 __global__ __launch_bounds__(1024) void candidate_kernel(const int32_t *__restrict__ n_models, const int32_t *__restrict__ good,
                                                          const int32_t *__restrict__ hmax_in, int cnt, int carried_best,
                                                          int32_t *__restrict__ cand, int32_t *__restrict__ cand_count) {
-    __shared__ int wave_max_s[16];
+    __shared__ int wave_s[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) *cand_count = 0;  // single block: reset here instead of a memset launch
-    __syncthreads();
-    int carry = carried_best;
-    for (int base = 0; base < cnt; base += 1024) {
-        const int i = base + tid;
-        int hmax = 0;
-        if (i < cnt) {
-            if (hmax_in) {
-                hmax = hmax_in[i];
-            } else {  // few hypotheses: no separate hyp_max pass
-                const int nm0 = n_models[i];
-                for (int m = 0; m < nm0; ++m) hmax = max(hmax, good[(size_t)i * 10 + m]);
+    if (tid == 0) *cand_count = 0;  // single block: reset here instead of a memset launch (ordered by the barriers of the exchange)
+    const int R = (cnt + 1023) / 1024;
+    const int w0 = wave * R * 64;
+    auto hyp_max = [&](int i) {
+        if (i >= cnt) return 0;
+        if (hmax_in) return hmax_in[i];
+        int h = 0;  // few hypotheses: no separate hyp_max pass
+        const int nm0 = n_models[i];
+        for (int m = 0; m < nm0; ++m) h = max(h, good[(size_t)i * 10 + m]);
+        return h;
+    };
+    int local = 0;
+#pragma unroll 4
+    for (int r = 0; r < R; ++r) local = max(local, hyp_max(w0 + r * 64 + lane));
+    int carry = waves_exclusive_scan_16<true>(wave_reduce<true>(local), carried_best, wave_s);  // best count before this wave's range
+
+    for (int r0 = 0; r0 < R; r0 += kScanBatch) {
+        int hv[kScanBatch];  // the loads of a batch of rows are issued together: one memory latency per batch, not per row
+#pragma unroll
+        for (int j = 0; j < kScanBatch; ++j) hv[j] = (r0 + j < R) ? hyp_max(w0 + (r0 + j) * 64 + lane) : 0;
+#pragma unroll
+        for (int j = 0; j < kScanBatch; ++j) {
+            if (r0 + j >= R) break;  // wave-uniform
+            const int i = w0 + (r0 + j) * 64 + lane;
+            const int hmax = hv[j];
+            const int inc = wave_inclusive_scan<true>(hmax, lane);
+            const int up = __shfl_up(inc, 1);
+            const int before = lane ? max(carry, up) : carry;  // best count of everything before hypothesis i
+            if (i < cnt && hmax >= 5 && hmax >= before) {
+                const int nm = n_models[i];
+                for (int m = 0; m < nm; ++m)
+                    if (good[(size_t)i * 10 + m] == hmax) cand[atomicAdd(cand_count, 1)] = i * 10 + m;
             }
+            carry = max(carry, __shfl(inc, 63));
         }
-        int v = hmax;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_up(v, off);
-            if (lane >= off) v = max(v, o);
-        }
-        const int up = __shfl_up(v, 1);
-        if (lane == 63) wave_max_s[wave] = v;
-        __syncthreads();
-        int pre = carry, tot = carry;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int c = wave_max_s[w];
-            if (w < wave) pre = max(pre, c);
-            tot = max(tot, c);
-        }
-        const int before = lane ? max(pre, up) : pre;  // best count of everything before hypothesis i
-        if (i < cnt && hmax >= 5 && hmax >= before) {
-            const int nm = n_models[i];
-            for (int m = 0; m < nm; ++m)
-                if (good[(size_t)i * 10 + m] == hmax) cand[atomicAdd(cand_count, 1)] = i * 10 + m;
-        }
-        carry = tot;
-        __syncthreads();
     }
 }
 
@@ -1349,77 +1386,91 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
                                                       const int32_t *__restrict__ Ttab, int npts, long long base_index,
                                                       const int32_t *__restrict__ dense_total, ReplayState *__restrict__ st,
                                                       double confidence) {
-    __shared__ int wave_max_s[16], wave_min_s[16];
+    __shared__ int wave_s[16];
     __shared__ int stop_idx;
     __shared__ int s_best_good[1024];
     __shared__ double s_best_sum[1024];
     __shared__ int s_best_idx[1024];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int maxGood0 = st->maxGood, niters0 = st->niters, iter0 = st->iter;
     if (tid == 0) stop_idx = cnt;  // "no stop inside this chunk"
-    __syncthreads();
 
-    // pass 1: running best count (inclusive prefix max in iteration order), niters after each iteration, first iteration
-    // after which the loop ends.  1024 iterations per step, coalesced.
-    int carry = maxGood0, carry_T = INT32_MAX;
-    for (int base = 0; base < cnt; base += 1024) {
-        const int i = base + tid;
-        int v = (i < cnt) ? hgood[i] : 0;
+    // pass 1: running best count (prefix max in iteration order), niters after each iteration, first iteration after which the loop
+    // ends.  Wave-owned contiguous ranges, see above.
+    const int lane = tid & 63, wave = tid >> 6;
+    const int R = (cnt + 1023) / 1024;
+    const int w0 = wave * R * 64;
+    int local = 0;
+#pragma unroll 4
+    for (int r = 0; r < R; ++r) {
+        const int i = w0 + r * 64 + lane;
+        local = max(local, i < cnt ? hgood[i] : 0);
+    }
+    const int wpre = waves_exclusive_scan_16<true>(wave_reduce<true>(local), maxGood0, wave_s);  // running count before this wave's range
+    // The bound after iteration i is min(niters0, T(running_i)).  T falls as the count rises and the running count never falls, so
+    // T(running_i) = min over the record-breaking iterations j <= i of T(running_j): evaluate T only where the running count changes
+    // (a handful of iterations per pass -- log/pow in fp64 for every lane doubled this kernel's time).  The count carried in from
+    // earlier passes is already inside niters0.
+    auto bound_at = [&](int running) {
+        const int g = min(running, npts);
+        return Ttab ? Ttab[g] : dev_num_iters(confidence, npts, g);
+    };
+    int local_T = INT32_MAX;
+    {
+        int carry = wpre;
+        for (int r0 = 0; r0 < R; r0 += kScanBatch) {
+        int hv[kScanBatch];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {  // inclusive max-scan inside the wave
-            const int o = __shfl_up(v, off);
-            if (lane >= off) v = max(v, o);
+        for (int j = 0; j < kScanBatch; ++j) {
+            const int i = w0 + (r0 + j) * 64 + lane;
+            hv[j] = (r0 + j < R && i < cnt) ? hgood[i] : 0;
         }
-        if (lane == 63) wave_max_s[wave] = v;
-        __syncthreads();
-        int pre = carry, tot = carry;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int c = wave_max_s[w];
-            if (w < wave) pre = max(pre, c);
-            tot = max(tot, c);
-        }
-        const int running = max(pre, v);
-        const int up = __shfl_up(v, 1);
-        const int prev_running = lane ? max(pre, up) : pre;  // running count before this iteration
-        // The bound after iteration i is min(niters0, T(running_i)).  T falls as the count rises and the running count never
-        // falls, so T(running_i) = min over the record-breaking iterations j <= i of T(running_j): evaluate T only where the
-        // running count changes (a few lanes per pass -- log/pow in fp64 for every lane doubled this kernel's time) and take
-        // an inclusive min-scan.  The count carried in from earlier passes is already inside niters0.
-        int Tv = INT32_MAX;
-        if (i < cnt && running >= 5 && running > prev_running) {
-            const int g = min(running, npts);
-            Tv = Ttab ? Ttab[g] : dev_num_iters(confidence, npts, g);
-            if (!Ttab) {  // remember the bound used for this count: the host re-evaluates it with its libm
-                const int slot = atomicAdd(&st->t_count, 1);
-                if (slot < kTUsedMax) {
-                    st->t_g[slot] = g;
-                    st->t_val[slot] = Tv;
+        for (int j = 0; j < kScanBatch; ++j) {
+            if (r0 + j >= R) break;  // wave-uniform
+            const int i = w0 + (r0 + j) * 64 + lane;
+            const int inc = wave_inclusive_scan<true>(hv[j], lane);
+            const int running = max(carry, inc);
+            const int up = __shfl_up(inc, 1);
+            const int prev_running = lane ? max(carry, up) : carry;  // running count before this iteration
+            if (i < cnt && running >= 5 && running > prev_running) {
+                const int Tv = bound_at(running);
+                if (!Ttab) {  // remember the bound used for this count: the host re-evaluates it with its libm
+                    const int slot = atomicAdd(&st->t_count, 1);
+                    if (slot < kTUsedMax) {
+                        st->t_g[slot] = min(running, npts);
+                        st->t_val[slot] = Tv;
+                    }
                 }
+                local_T = min(local_T, Tv);
             }
+            carry = max(carry, __shfl(inc, 63));
         }
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {  // inclusive min-scan inside the wave
-            const int o = __shfl_up(Tv, off);
-            if (lane >= off) Tv = min(Tv, o);
         }
-        if (lane == 63) wave_min_s[wave] = Tv;
-        __syncthreads();
-        int tpre = carry_T, ttot = carry_T;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int c = wave_min_s[w];
-            if (w < wave) tpre = min(tpre, c);
-            ttot = min(ttot, c);
+    }
+    const int wave_T = wave_reduce<false>(local_T);
+    const int tpre = waves_exclusive_scan_16<false>(wave_T, INT32_MAX, wave_s);  // min bound over the events before this wave's range
+    // Can the loop end inside this wave's range at all?  The bound only falls, so the smallest bound of the range is the one after its
+    // last event: no stop unless the last iteration of the range reaches it (wave-uniform; all but one wave skip the second sweep).
+    if (w0 < cnt && iter0 + min(cnt, w0 + R * 64) >= min(niters0, min(tpre, wave_T))) {
+        int carry = wpre, carry_T = tpre;
+        for (int r = 0; r < R; ++r) {
+            const int i = w0 + r * 64 + lane;
+            const int inc = wave_inclusive_scan<true>(i < cnt ? hgood[i] : 0, lane);
+            const int running = max(carry, inc);
+            const int up = __shfl_up(inc, 1);
+            const int prev_running = lane ? max(carry, up) : carry;
+            int Tv = INT32_MAX;
+            if (i < cnt && running >= 5 && running > prev_running) Tv = bound_at(running);
+            Tv = wave_inclusive_scan<false>(Tv, lane);
+            const bool stop_here = i < cnt && iter0 + i + 1 >= min(niters0, min(carry_T, Tv));
+            if (__ballot(stop_here)) {  // wave-uniform: the first stopping lane of the first such row
+                if (stop_here) atomicMin(&stop_idx, i);
+                break;
+            }
+            carry = max(carry, __shfl(inc, 63));
+            carry_T = min(carry_T, __shfl(Tv, 63));
         }
-        if (i < cnt) {
-            const int nit = min(niters0, min(tpre, Tv));
-            if (iter0 + i + 1 >= nit) atomicMin(&stop_idx, i);
-        }
-        carry_T = ttot;
-        carry = tot;
-        __syncthreads();
-        if (stop_idx < cnt) break;  // block-uniform after the barrier
     }
     __syncthreads();
     const int processed = min(cnt, stop_idx + 1);
@@ -1427,14 +1478,24 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
     // pass 2: arg-max over the processed iterations (good desc, sum asc, earlier first), only counts >= 5 qualify
     int bg = 0, bi = -1;
     double bs = 0;
-    for (int i = tid; i < processed; i += 1024) {
-        const int g = hgood[i];
-        if (g < 5) continue;
-        const double e = hsum[i];
-        if (bi < 0 || g > bg || (g == bg && e < bs)) {  // i increases per thread: strict comparisons keep the earlier one
-            bg = g;
-            bs = e;
-            bi = i;
+    for (int i0 = tid; i0 < processed; i0 += 1024 * kScanBatch) {
+        int gv[kScanBatch];
+        double ev[kScanBatch];
+#pragma unroll
+        for (int j = 0; j < kScanBatch; ++j) {  // unconditional loads, all in flight together
+            const int i = i0 + 1024 * j;
+            gv[j] = i < processed ? hgood[i] : 0;
+            ev[j] = i < processed ? hsum[i] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < kScanBatch; ++j) {
+            const int i = i0 + 1024 * j, g = gv[j];
+            const double e = ev[j];
+            if (i < processed && g >= 5 && (bi < 0 || g > bg || (g == bg && e < bs))) {  // i increases per thread: strict comparisons keep the earlier one
+                bg = g;
+                bs = e;
+                bi = i;
+            }
         }
     }
     s_best_good[tid] = bg;
