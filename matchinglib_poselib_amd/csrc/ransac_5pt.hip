@@ -665,14 +665,15 @@ __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__
 // ---------------------------------------------------------------------------------------------------------------
 // Sampson scoring: one thread per model.
 // ---------------------------------------------------------------------------------------------------------------
-// Also pmag[i] = (|x1| + |y1| + 1) (|x2| + |y2| + 1), stored behind the points: the magnitude bound of x2^T E x1 / max|E| that the
-// fused-multiply-add fast path of the inlier predicate needs for its error band (sampson_inlier_fma).
+// Also kp[i] (a polynomial in |x1|+|y1|+1 and |x2|+|y2|+1), stored behind the points: the per-point factor of the error band of the
+// fused-multiply-add fast path of the inlier predicate (sampson_inlier_fma).
 __global__ void pack_points_kernel(const double *__restrict__ p1, const double *__restrict__ p2, int n, double4 *__restrict__ pts) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
         pts[i] = make_double4(x1, y1, x2, y2);
-        reinterpret_cast<double *>(pts + n)[i] = (fabs(x1) + fabs(y1) + 1.0) * (fabs(x2) + fabs(y2) + 1.0);
+        const double P1 = fabs(x1) + fabs(y1) + 1.0, P2 = fabs(x2) + fabs(y2) + 1.0, pmag = P1 * P2;
+        reinterpret_cast<double *>(pts + n)[i] = 1.001 * pmag * (pmag + 1.0 + (P1 * P1 + P2 * P2));  // kp of sampson_inlier_fma
     }
 }
 
@@ -724,7 +725,13 @@ __device__ __forceinline__ bool sampson_inlier(double N, double D, double qmax, 
 //     |N' - p'| > h := delta (2 |s'| + 2 (qmax + p') + delta) (1 + 2^-40) + 2^-47 (N' + p')
 // with the sign of N' - p'.  Otherwise (a correspondence within ~1e-12 of the threshold, a NaN, an unusable qmax) the reference arithmetic
 // itself runs.  d0 = 2^-49 * max|e| * (1 + 2^-40), per model.
-__device__ __forceinline__ bool sampson_inlier_fma(const double *e, double d0, double x1, double y1, double x2, double y2, double pmag,
+// The band is then loosened into ONE product of a per-model and a per-point constant (4 instructions fewer per evaluation): with
+// P1 = |x1|+|y1|+1, P2 = |x2|+|y2|+1, pmag = P1 P2, psq = P1^2 + P2^2 and m = max|e| one has |s'| <= m pmag and D' <= 2 m^2 psq (all up to
+// a factor 1 + 1e-15), hence  2|s'| + 2(qmax + p') + delta <= (2m + d0) pmag + 2 qmax + 4 qmax m^2 psq <= cmax (pmag + 1 + psq)  with
+// cmax = max(2m + d0, 2 qmax, 4 qmax m^2), and  delta = d0 pmag.  So
+//     h <= km * kp + 2^-46 max(N', p'),     km = 1.001 d0 cmax (model_band),   kp = 1.001 pmag (pmag + 1 + psq) (pack_points_kernel)
+// (the factors 1.001 cover every rounding in forming km, kp and the bounds above).
+__device__ __forceinline__ bool sampson_inlier_fma(const double *e, double km, double x1, double y1, double x2, double y2, double kp,
                                                    double qmax, double thresh2) {
     const double A = __fma_rn(e[0], x1, __fma_rn(e[1], y1, e[2]));
     const double B = __fma_rn(e[3], x1, __fma_rn(e[4], y1, e[5]));
@@ -735,9 +742,7 @@ __device__ __forceinline__ bool sampson_inlier_fma(const double *e, double d0, d
     const double D = __fma_rn(A, A, __fma_rn(B, B, __fma_rn(A2, A2, B2 * B2)));
     const double N = sv * sv;
     const double p = qmax * D;
-    const double dl = d0 * pmag;
-    const double w = __fma_rn(2.0, fabs(sv) + (qmax + p), dl);
-    const double h = __fma_rn(0x1p-47, N + p, w * dl);
+    const double h = __fma_rn(0x1p-46, fmax(N, p), km * kp);
     const double diff = N - p;
     if (fabs(diff) > h && qmax > 0) return diff < 0;  // false for NaNs: they take the reference path
     double Nr, Dr;
@@ -745,11 +750,14 @@ __device__ __forceinline__ bool sampson_inlier_fma(const double *e, double d0, d
     return sampson_inlier(Nr, Dr, qmax, thresh2);
 }
 
-__device__ __forceinline__ double model_band(const double *e) {
+__device__ __forceinline__ double model_band(const double *e, double qmax) {
     double m = 0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) m = fmax(m, fabs(e[k]));
-    return m * (0x1p-49 * (1.0 + 0x1p-40));  // NaN / inf entries give a NaN / inf band: every correspondence takes the reference path
+    const double d0 = m * (0x1p-49 * (1.0 + 0x1p-40));
+    const double cmax = fmax(fmax(2.0 * m + d0, 2.0 * qmax), 4.0 * qmax * m * m);
+    // NaN entries must give a NaN band (every correspondence then takes the reference path): fmax drops NaNs, the product below keeps them
+    return 1.001 * d0 * cmax + 0.0 * (e[0] + e[1] + e[2] + e[3] + e[4] + e[5] + e[6] + e[7] + e[8]);
 }
 
 // 4 lanes per model (lane j takes the correspondences i = j mod 4, in order), 64 models per 256-thread block; the
@@ -775,7 +783,7 @@ __global__ __launch_bounds__(256) void score_models_kernel(const double4 *__rest
     double e[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) e[k] = live ? E_list[(size_t)m * 9 + k] : 0.0;
-    const double d0 = model_band(e);
+    const double d0 = model_band(e, qmax);
     int cnt = 0;
     double s = 0.0;
     for (int base = 0; base < n; base += kScoreTile) {
@@ -836,7 +844,7 @@ __global__ __launch_bounds__(256) void score_models_block_kernel(const double4 *
         double e[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) e[k] = E_list[(size_t)m * 9 + k];
-        const double d0 = model_band(e);
+        const double d0 = model_band(e, qmax);
         const double *__restrict__ pmag = reinterpret_cast<const double *>(pts + n);
         int cnt = 0;
         for (int i = tid; i < n; i += 256) {
