@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, (KS >= 8 ? 2 : 3)) void knn_hamming_mfma_kerne
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int QT, int PRIO>
 __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
-    const uint4 *__restrict__ qfrag, size_t q_batch_u4, const uint4 *__restrict__ tfrag, size_t t_batch_u4, int nq, int nt,
+    const uint32_t *__restrict__ qw, size_t q_batch_words, const uint4 *__restrict__ tfrag, size_t t_batch_u4, int nq, int nt,
     int rows_per_split, int nsplit, int dshift, int qblocks, int n_items, uint2 *__restrict__ part,
     unsigned long long *__restrict__ stamps, const int32_t *__restrict__ split_tile0) {
     constexpr int KS = 4, NB = 4;
@@ -307,16 +307,25 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
     const int qb = item % qblocks;
     const int split = (item / qblocks) % nsplit;
     const int b = item / (qblocks * nsplit);
-    const int qt0 = (qb * 4 + w) * QT;  // the query fragment buffer is padded to whole workgroups (zero rows)
-    const uint4 *qf = qfrag + (size_t)b * q_batch_u4 + (size_t)qt0 * KS * 64 + l;
+    const int qt0 = (qb * 4 + w) * QT;
+    const int h = l >> 5;
 
+    // The query operand is expanded to fp4 HERE, once per wave, from the raw 32-byte descriptors (lane (r, h) owns words 4h..4h+3 of its
+    // row: one 16-byte load per tile; the same word -> K-position rule as hamming_expand_kernel, which now runs for the train set only --
+    // that one has to exist in fragment order in memory because it is streamed into LDS by DMA).  Rows >= nq read as zero bits.
     uint4 bq[QT][KS];
 #pragma unroll
-    for (int t = 0; t < QT; ++t)
+    for (int t = 0; t < QT; ++t) {
+        const int row = (qt0 + t) * 32 + (l & 31);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row < nq) v = *reinterpret_cast<const uint4 *>(qw + (size_t)b * q_batch_words + (size_t)row * (2 * KS) + (size_t)h * KS);
+        const uint32_t vs[KS] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int s = 0; s < KS; ++s) bq[t][s] = qf[(size_t)(t * KS + s) * 64];
+        for (int s = 0; s < KS; ++s)
+            bq[t][s] = make_uint4(expand_byte(vs[s] & 255u), expand_byte((vs[s] >> 8) & 255u), expand_byte((vs[s] >> 16) & 255u),
+                                  expand_byte(vs[s] >> 24));
+    }
 
-    const int h = l >> 5;
     v16f cinit;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) cinit[reg] = -(float)((reg & 3) + 8 * (reg >> 2) + 4 * h) * kEps;
@@ -756,8 +765,11 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
         if ((rc = ws_get(ctx, WS_COUNTERS, (size_t)batch * counters_per_batch * sizeof(int), &cp))) return rc;
         counters = (int *)cp;
     }
-    const ExpandArgs qa{qw, q_batch_words, nq, q_tiles_padded, (uint4 *)qf}, ta{tw, t_batch_words, nt, t_tiles, (uint4 *)tf};
-    const dim3 egrid((unsigned)((std::max(q_tiles_padded, t_tiles) * 64 + 255) / 256), batch, 2);
+    // the static LDS-ring kernel expands its query operand itself (in registers): only the train set goes through the expansion kernel
+    const bool expand_q = !(lds_ring && !dyn);
+    const ExpandArgs ta{tw, t_batch_words, nt, t_tiles, (uint4 *)tf};
+    const ExpandArgs qa = expand_q ? ExpandArgs{qw, q_batch_words, nq, q_tiles_padded, (uint4 *)qf} : ta;  // blockIdx.z == 0
+    const dim3 egrid((unsigned)(((expand_q ? std::max(q_tiles_padded, t_tiles) : t_tiles) * 64 + 255) / 256), batch, expand_q ? 2 : 1);
     switch (ks) {
         case 1: hipLaunchKernelGGL(hamming_expand_kernel<1>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch); break;
         case 2: hipLaunchKernelGGL(hamming_expand_kernel<2>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch); break;
@@ -849,13 +861,13 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
 #define MLPL_RING_LAUNCH(QT_)                                                                                                          \
     do {                                                                                                                               \
         if (ctx->opt_hamming_mfma_prio == 2)                                                                                           \
-            hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<QT_, 2>), grid, dim3(256), 0, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, \
+            hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<QT_, 2>), grid, dim3(256), 0, s, qw, q_batch_words, (const uint4 *)tf, \
                                t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab);               \
         else if (ctx->opt_hamming_mfma_prio)                                                                                           \
-            hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<QT_, 1>), grid, dim3(256), 0, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, \
+            hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<QT_, 1>), grid, dim3(256), 0, s, qw, q_batch_words, (const uint4 *)tf, \
                                t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab);               \
         else                                                                                                                           \
-            hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<QT_, 0>), grid, dim3(256), 0, s, (const uint4 *)qf, q_u4, (const uint4 *)tf, \
+            hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<QT_, 0>), grid, dim3(256), 0, s, qw, q_batch_words, (const uint4 *)tf, \
                                t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab);               \
     } while (0)
         if (qt == 4) MLPL_RING_LAUNCH(4);
