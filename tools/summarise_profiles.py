@@ -61,7 +61,9 @@ traffic = {"round": R, "pairs_per_launch": 8,
 for k, e in summary.items():
     if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
         b = (2 * e["FETCH_SIZE"]["mean"] + e["WRITE_SIZE"]["mean"]) * 1024
-        if k.startswith("knn_hamming_mfma_kernel<4, 4>"):  # the headline launch (8 pairs); <4, 1> is the single-pair extras launch
+        # the headline launch (8 pairs per launch): round 1 knn_hamming_mfma_kernel<4, 4>, since round 2 the LDS-ring kernel <4, 0>
+        # (<1, 0> / <4, 1> are the single-pair extras launches)
+        if k.startswith("knn_hamming_mfma_kernel<4, 4>") or k.startswith("knn_hamming_mfma_lds_kernel<4, 0>"):
             traffic["knn_hamming_mfma_bytes_per_launch"] = b
             traffic["mfma_fetch_KiB_raw"] = e["FETCH_SIZE"]["mean"]
             traffic["mfma_write_KiB"] = e["WRITE_SIZE"]["mean"]
