@@ -47,10 +47,14 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 
 // monomial order of the reference's coefficient matrix: exponents of (x, y, z); the 4th variable w = 1 takes the rest.
-__constant__ int8_t kMonoVars[20][3] = {
-    // as variable indices of the three factors (0=x,1=y,2=z,3=w), sorted
-    {0, 0, 0}, {1, 1, 1}, {0, 0, 1}, {0, 1, 1}, {0, 0, 2}, {0, 0, 3}, {1, 1, 2}, {1, 1, 3}, {0, 1, 2}, {0, 1, 3},
-    {0, 2, 2}, {0, 2, 3}, {0, 3, 3}, {1, 2, 2}, {1, 2, 3}, {1, 3, 3}, {2, 2, 2}, {2, 2, 3}, {2, 3, 3}, {3, 3, 3}};
+// kMonoVars[20][3] (variable indices of the three factors, 0=x 1=y 2=z 3=w, sorted):
+//   {0, 0, 0}, {1, 1, 1}, {0, 0, 1}, {0, 1, 1}, {0, 0, 2}, {0, 0, 3}, {1, 1, 2}, {1, 1, 3}, {0, 1, 2}, {0, 1, 3},
+//   {0, 2, 2}, {0, 2, 3}, {0, 3, 3}, {1, 2, 2}, {1, 2, 3}, {1, 3, 3}, {2, 2, 2}, {2, 2, 3}, {2, 3, 3}, {3, 3, 3}};
+
+// the distinct orderings (a*16 + b*4 + c) of each monomial above, in the order (abc, acb, bac, bca, cab, cba) with repeats dropped
+__constant__ int8_t kMonoNumPerms[20] = {1, 1, 3, 3, 3, 3, 3, 3, 6, 6, 3, 6, 3, 3, 6, 3, 1, 3, 3, 1};
+__constant__ int8_t kMonoPerms[20][6] = {
+    {0, 0, 0, 0, 0, 0}, {21, 0, 0, 0, 0, 0}, {1, 4, 16, 0, 0, 0}, {5, 17, 20, 0, 0, 0}, {2, 8, 32, 0, 0, 0}, {3, 12, 48, 0, 0, 0}, {22, 25, 37, 0, 0, 0}, {23, 29, 53, 0, 0, 0}, {6, 9, 18, 24, 33, 36}, {7, 13, 19, 28, 49, 52}, {10, 34, 40, 0, 0, 0}, {11, 14, 35, 44, 50, 56}, {15, 51, 60, 0, 0, 0}, {26, 38, 41, 0, 0, 0}, {27, 30, 39, 45, 54, 57}, {31, 55, 61, 0, 0, 0}, {42, 0, 0, 0, 0, 0}, {43, 46, 58, 0, 0, 0}, {47, 59, 62, 0, 0, 0}, {63, 0, 0, 0, 0, 0}};
 
 struct SolveLds {
     double Q[5][9];     // epipolar rows; overwritten by the QR (as its transpose M[r][c] = Q[c][r])
@@ -171,25 +175,13 @@ __device__ __forceinline__ void solve_from_basis(SolveLds &L, int lane, PolyRec 
             for (int c = 0; c < 3; ++c)
                 T[1 + r * 3 + c] = P[r][0] * Ek[c] + P[r][1] * Ek[3 + c] + P[r][2] * Ek[6 + c] - htr * Ek[r * 3 + c];
 
-        // the distinct orderings of this lane's monomial (lanes 0..19)
+        // the distinct orderings of this lane's monomial (lanes 0..19): index triples a*16 + b*4 + c, from a table
         int perm[6];
         int np = 0;
         if (lane < 20) {
-            const int a = kMonoVars[lane][0], b = kMonoVars[lane][1], c = kMonoVars[lane][2];
-            const int cand[6] = {a * 16 + b * 4 + c, a * 16 + c * 4 + b, b * 16 + a * 4 + c,
-                                 b * 16 + c * 4 + a, c * 16 + a * 4 + b, c * 16 + b * 4 + a};
+            np = kMonoNumPerms[lane];
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                bool dup = false;
-#pragma unroll
-                for (int u = 0; u < 6; ++u) dup = dup || (u < np && perm[u] == cand[t]);
-                if (!dup) {
-#pragma unroll
-                    for (int u = 0; u < 6; ++u)
-                        if (u == np) perm[u] = cand[t];
-                    ++np;
-                }
-            }
+            for (int u = 0; u < 6; ++u) perm[u] = kMonoPerms[lane][u];
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -279,28 +271,46 @@ __device__ __forceinline__ void solve_from_basis(SolveLds &L, int lane, PolyRec 
         L.b[i][j] = v1 - v2;
     }
     wave_sync();
-    if (lane < 11) {
-        // entries of B as ascending polynomials: P[i][0] = b[i][3-k] (deg 3), P[i][1] = b[i][7-k] (deg 3), P[i][2] = b[i][12-k] (deg 4)
+    // det B(z) = sum over the 6 permutations of sgn * P[0][p0] * P[1][p1] * P[2][p2], with the entries of B as ascending polynomials
+    // P[i][0] = b[i][3-k] (degree 3), P[i][1] = b[i][7-k] (degree 3), P[i][2] = b[i][12-k] (degree 4).  Two convolution stages spread over
+    // the wave: lane (pi, m) forms coefficient m of P[0][p0] * P[1][p1] (48 lanes, <= 5 products each), then lane k adds up
+    // sgn * (that product) * P[2][p2] for its coefficient k (11 lanes, <= 30 products each).  (The triple loop per output coefficient
+    // this replaces ran ~25 index combinations x 6 permutations on 11 lanes -- the longest phase of the kernel.)
+    {
         auto coef = [&](int row, int colm, int k) -> double {
+            if (k < 0) return 0.0;
             if (colm == 0) return (k <= 3) ? L.b[row][3 - k] : 0.0;
             if (colm == 1) return (k <= 3) ? L.b[row][7 - k] : 0.0;
             return (k <= 4) ? L.b[row][12 - k] : 0.0;
         };
-        const int perms[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};
-        const double sgn[6] = {1, 1, 1, -1, -1, -1};
-        double ck = 0;
-        for (int pi = 0; pi < 6; ++pi) {
-            const int p0 = perms[pi][0], p1 = perms[pi][1], p2 = perms[pi][2];
-            double s = 0;
-            for (int i0 = 0; i0 <= 4; ++i0)
-                for (int i1 = 0; i1 <= 4 && i0 + i1 <= lane; ++i1) {
-                    const int i2 = lane - i0 - i1;
-                    if (i2 > 4) continue;
-                    s += coef(0, p0, i0) * coef(1, p1, i1) * coef(2, p2, i2);
-                }
-            ck += sgn[pi] * s;
+        // permutation pi = (p0, p1, p2): even ones first
+        const int pi = lane >> 3, m = lane & 7;  // m = 0..7: degree of P0*P1 is at most 3 + 4
+        const int p0 = (pi < 3) ? pi : pi - 3;
+        const int p1 = (pi < 3) ? (pi + 1) % 3 : (pi - 3 + 2) % 3;
+        if (lane < 48) {
+            double q = 0;
+#pragma unroll
+            for (int i0 = 0; i0 <= 4; ++i0) q += coef(0, p0, i0) * coef(1, p1, m - i0);
+            L.F[0][lane] = q;  // F is free again after phase 2
         }
-        L.c[lane] = ck;
+        wave_sync();
+        if (lane < 11) {
+            double ck = 0;
+#pragma unroll
+            for (int pj = 0; pj < 6; ++pj) {
+                const int q0 = (pj < 3) ? pj : pj - 3;
+                const int q1 = (pj < 3) ? (pj + 1) % 3 : (pj - 3 + 2) % 3;
+                const int q2 = 3 - q0 - q1;
+                double sacc = 0;
+#pragma unroll
+                for (int i2 = 0; i2 <= 4; ++i2) {
+                    const int mm = lane - i2;
+                    if (mm >= 0 && mm <= 7) sacc += L.F[0][pj * 8 + mm] * coef(2, q2, i2);
+                }
+                ck += (pj < 3) ? sacc : -sacc;
+            }
+            L.c[lane] = ck;
+        }
     }
     wave_sync();
 
