@@ -59,7 +59,7 @@ __constant__ int8_t kMonoPerms[20][6] = {
 struct SolveLds {
     double Q[5][9];     // epipolar rows; overwritten by the QR (as its transpose M[r][c] = Q[c][r])
     double V[5][9];     // Householder vectors
-    double vn2[5];      // their squared norms
+    double vn2[5];      // 2 / (their squared norms): the reflection factor (0 = no reflection)
     double EE[4][9];    // null-space basis
     double F[5][64];    // trilinear tensors, five constraint rows at a time
     double A[10][20];   // constraint matrix
@@ -629,9 +629,10 @@ __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__
         const double alpha = (x0 >= 0 ? -1.0 : 1.0) * sqrt(nrm2);
         // v = x - alpha e_k ; |v|^2 = 2 (nrm2 - alpha x0)
         const double vn2 = 2.0 * (nrm2 - alpha * x0);
+        const double hfac = vn2 > 0 ? 2.0 / vn2 : 0.0;
         wave_sync();
         if (lane < 9) L.V[k][lane] = (lane < k) ? 0.0 : ((lane == k) ? (x0 - alpha) : L.Q[k][lane]);
-        if (lane == 0) L.vn2[k] = vn2;
+        if (lane == 0) L.vn2[k] = vn2 > 0 ? 2.0 / vn2 : 0.0;  // stored as the factor 2 / |v|^2 (0: no reflection)
         wave_sync();
         // apply H_k to the remaining columns c > k
         double upd = 0;
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__
             if (doit) {
                 double dot = 0;
                 for (int rr = k; rr < 9; ++rr) dot += L.V[k][rr] * L.Q[c][rr];
-                upd = L.Q[c][r] - 2.0 * L.V[k][r] * dot / vn2;
+                upd = L.Q[c][r] - L.V[k][r] * dot * hfac;
             }
         }
         wave_sync();
@@ -658,11 +659,11 @@ __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__
     for (int k = 4; k >= 0; --k) {
         double upd = 0;
         const int j = lane / 9, r = lane - j * 9;
-        const double vn2 = L.vn2[k];
+        const double hfac = L.vn2[k];
         if (lane < 36) {
             double dot = 0;
             for (int rr = k; rr < 9; ++rr) dot += L.V[k][rr] * L.EE[j][rr];
-            upd = (vn2 > 0) ? (L.EE[j][r] - 2.0 * L.V[k][r] * dot / vn2) : L.EE[j][r];
+            upd = L.EE[j][r] - L.V[k][r] * dot * hfac;
         }
         wave_sync();
         if (lane < 36) L.EE[j][r] = upd;
