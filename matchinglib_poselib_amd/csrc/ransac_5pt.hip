@@ -496,7 +496,7 @@ __global__ __launch_bounds__(64) void roots_kernel(const PolyRec *__restrict__ r
                                                    double *__restrict__ dense_E, int32_t *__restrict__ dense_id,
                                                    int32_t *__restrict__ dense_total, int polish) {
     __shared__ double R[kHypPerWave][88];
-    __shared__ double rr[64], ri[64], relbuf[64];
+    __shared__ double rr[64], ri[64];
     if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
     const int lane = threadIdx.x;
     const int h = lane / 10, r = lane - h * 10;
@@ -576,20 +576,20 @@ __global__ __launch_bounds__(64) void roots_kernel(const PolyRec *__restrict__ r
             pr -= dr;
             pim -= di;
         }
-        relbuf[lane] = (active && !done) ? sqrt(dr * dr + di * di) / (1.0 + sqrt(pr * pr + pim * pim)) : 0.0;
-        wave_sync();
+        // convergence per hypothesis from two ballots (no LDS round trip, no sqrt / divide): a correction counts as large while
+        // |d|^2 > 2e-18 (1 + |z|^2), i.e. |d| / (1 + |z|) above 1e-9 .. 1.4e-9 (never stricter than the 1e-9 of the sqrt form it replaces:
+        // corrections at a double root stall around 1e-9 and a stricter test keeps such a wave sweeping for nothing)
+        const double d2 = dr * dr + di * di, z2 = pr * pr + pim * pim;
+        const bool moving = active && !done && d2 > 2e-18 * (1.0 + z2);
+        const bool isnan = active && !done && !(d2 == d2 && z2 == z2);
+        const unsigned long long hbits = ((1ull << 10) - 1ull) << (hs * 10);
+        const bool any_moving = (__ballot(moving) & hbits) != 0, any_nan = (__ballot(isnan) & hbits) != 0;
+        wave_sync();  // rr / ri are rewritten at the top of the next sweep
         if (!done) {
-            double rel = 0;
-            bool nan = false;
-            for (int j = 0; j < 10; ++j) {
-                const double v = relbuf[hs * 10 + j];
-                nan = nan || (v != v);
-                rel = fmax(rel, v);
-            }
             dk_sweeps = iter + 1;
             // cubic convergence: once every correction is below 1e-9 (relative) one more sweep reaches rounding level
-            if (nan) done = true;
-            else if (!(rel > 1e-9)) done = (++settle >= 2);
+            if (any_nan) done = true;
+            else if (!any_moving) done = (++settle >= 2);
             else settle = 0;
         }
         if (!__any(!done)) break;
