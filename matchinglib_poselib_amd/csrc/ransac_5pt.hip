@@ -494,7 +494,7 @@ constexpr int kHypPerWave = 6;
 __global__ __launch_bounds__(64) void roots_kernel(const PolyRec *__restrict__ recs, int sample_offset, int n_samples,
                                                    double *__restrict__ E_tab, int32_t *__restrict__ n_models,
                                                    double *__restrict__ dense_E, int32_t *__restrict__ dense_id,
-                                                   int32_t *__restrict__ dense_total, int polish) {
+                                                   int32_t *__restrict__ dense_total, int polish, int32_t *__restrict__ good_zero) {
     __shared__ double R[kHypPerWave][88];
     __shared__ double rr[64], ri[64];
     if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
@@ -508,6 +508,8 @@ __global__ __launch_bounds__(64) void roots_kernel(const PolyRec *__restrict__ r
         R[hh][k] = (smp < n_samples) ? reinterpret_cast<const double *>(recs + (smp - sample_offset))[k] : 0.0;
     }
     wave_sync();
+    // the count table of the scoring pass is accumulated with atomics (correspondences split over four workgroups): start it at zero
+    if (good_zero && h < kHypPerWave && sample0 + h < n_samples) good_zero[(size_t)(sample0 + h) * 10 + r] = 0;
     const bool lane_ok = (h < kHypPerWave) && (sample0 + h < n_samples) && (R[h < kHypPerWave ? h : 0][86] != 0.0);
     const int hs = h < kHypPerWave ? h : 0;
     const double *c = &R[hs][0];
@@ -857,7 +859,9 @@ __global__ __launch_bounds__(kScoreThreads) void score_models_kernel(const doubl
     const double d0 = model_band(e, qmax);
     int cnt = 0;
     double s = 0.0;
-    for (int base = 0; base < n; base += kScoreTile) {
+    // gridDim.y > 1 (count-only form): the tiles are dealt round-robin to gridDim.y workgroups per model group, which add their
+    // counts into a zeroed table -- units a fifth the size even out the load over the CUs without re-reading any correspondence
+    for (int base = blockIdx.y * kScoreTile; base < n; base += kScoreTile * gridDim.y) {
         const int rows = min(kScoreTile, n - base);
         __syncthreads();
         for (int i = tid; i < rows; i += kScoreThreads) {
@@ -886,7 +890,8 @@ __global__ __launch_bounds__(kScoreThreads) void score_models_kernel(const doubl
     cnt += __shfl_xor(cnt, 2);
     if (live && j == 0) {
         const int o = ids ? ids[m] : m;
-        good[o] = cnt;
+        if (gridDim.y > 1) atomicAdd(&good[o], cnt);
+        else good[o] = cnt;
         if constexpr (SUMS) esum[o] = __dadd_rn(__dadd_rn(s0, s2), __dadd_rn(s1, s3));
     }
 }
@@ -1723,7 +1728,7 @@ double inlier_bound(double thresh2) {
 constexpr int kScoreBlockMaxModels = 24576;
 static void launch_score(hipStream_t s, const double4 *pts, int n, const double *E_list, const int32_t *ids, const int32_t *total_ptr,
                          int total_host, int max_models, double thresh2, int32_t *good, double *esum, bool sums = true,
-                         double qmax = -1.0) {
+                         double qmax = -1.0, int point_splits = 1) {
     if (max_models <= 0) return;
     const size_t lds = (size_t)((n + 3) / 4 * 4) * sizeof(float);
     const bool block = n <= kScoreBlockMaxN && max_models <= kScoreBlockMaxModels;
@@ -1739,9 +1744,18 @@ static void launch_score(hipStream_t s, const double4 *pts, int n, const double 
             hipLaunchKernelGGL((score_models_block_kernel<true, false>), dim3(max_models), dim3(256), 0, s, pts, n, E_list, ids, total_ptr,
                                total_host, thresh2, qmax, good, esum, (const int32_t *)nullptr);
         else
-            hipLaunchKernelGGL(score_models_kernel<false>, dim3((max_models + kScoreModels - 1) / kScoreModels), dim3(kScoreThreads), 0, s, pts, n, E_list, ids, total_ptr,
-                               total_host, thresh2, qmax, good, esum);
+            hipLaunchKernelGGL(score_models_kernel<false>, dim3((max_models + kScoreModels - 1) / kScoreModels, point_splits), dim3(kScoreThreads), 0, s, pts,
+                               n, E_list, ids, total_ptr, total_host, thresh2, qmax, good, esum);
     }
+}
+
+// Workgroups per model group of the count-only scoring pass (see score_models_kernel): two tiles each, at most eight; 1 = the table
+// is written, not accumulated (few models: the one-workgroup-per-model kernel runs instead, or sums are wanted).
+static int score_point_splits(int n, int max_models, bool sums) {
+    const bool block = n <= kScoreBlockMaxN && max_models <= kScoreBlockMaxModels;
+    if (sums || block) return 1;
+    const int ntiles = (n + kScoreTile - 1) / kScoreTile;
+    return std::max(1, std::min(8, ntiles / 2));
 }
 
 static int pack_points(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double4 **d_pts, hipStream_t s) {
@@ -1850,7 +1864,7 @@ int mlpl_solve_5pt(mlpl_ctx *ctx, const double *p1, const double *p2, int n, con
     hipLaunchKernelGGL(solve5pt_kernel, dim3(n_samples), dim3(64), 0, s, (const double *)dp1, (const double *)dp2, B.samples, 0,
                        n_samples, B.recs);
     hipLaunchKernelGGL(roots_kernel, dim3((n_samples + kHypPerWave - 1) / kHypPerWave), dim3(64), 0, s, (const PolyRec *)B.recs, 0,
-                       n_samples, B.E_tab, B.n_models, (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, ctx->opt_solver_polish);
+                       n_samples, B.E_tab, B.n_models, (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, ctx->opt_solver_polish, (int32_t *)nullptr);
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
     MLPL_HIP_TRY(hipGetLastError());
     MLPL_HIP_TRY(hipMemcpyAsync(E_out, B.E_tab, (size_t)n_samples * 720, hipMemcpyDeviceToHost, s));
@@ -2001,6 +2015,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         // (20 bytes per wave over PCIe, no staging copy in the stream).  Two slices: the device solves the first while the
         // host draws the rest.
         const int first = std::min(cnt, 4096);
+        const int point_splits = score_point_splits(n, cnt * 10, !lazy);
         for (int off = 0; off < cnt;) {
             const int m = (off == 0) ? first : cnt - off;
             for (int i = off; i < off + m; ++i) draw_sample(rng, n, &h_samples[(size_t)i * 5]);
@@ -2008,13 +2023,14 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
             hipLaunchKernelGGL(solve5pt_kernel, dim3(m), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, off, off + m,
                                B.recs);
             hipLaunchKernelGGL(roots_kernel, dim3((m + kHypPerWave - 1) / kHypPerWave), dim3(64), 0, s, (const PolyRec *)B.recs,
-                               off, off + m, B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total, ctx->opt_solver_polish);
+                               off, off + m, B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total, ctx->opt_solver_polish,
+                               point_splits > 1 ? B.good : (int32_t *)nullptr);
             prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
             off += m;
         }
         prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
         launch_score(s, (const double4 *)pts, n, (const double *)B.dense_E, (const int32_t *)B.dense_id, (const int32_t *)B.total, 0,
-                     cnt * 10, thresh2, B.good, B.esum, !lazy, qmax);
+                     cnt * 10, thresh2, B.good, B.esum, !lazy, qmax, point_splits);
         if (lazy) {
             // error sums only for the models that can still win (ties on the inlier count are decided by them)
             const bool sep = cnt > 2048;  // many hypotheses: per-hypothesis maxima in a grid-wide pass first
@@ -2055,7 +2071,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         hipLaunchKernelGGL(gram_kernel, dim3(gblocks), dim3(256), 0, s, (const double4 *)pts, (const uint8_t *)d_mask, n, d_gram);
         hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, s, (const double *)d_gram, gblocks, B.recs);
         hipLaunchKernelGGL(roots_kernel, dim3(1), dim3(64), 0, s, (const PolyRec *)B.recs, 0, 1, d_Etab, d_nm, (double *)nullptr,
-                           (int32_t *)nullptr, (int32_t *)nullptr, ctx->opt_solver_polish);
+                           (int32_t *)nullptr, (int32_t *)nullptr, ctx->opt_solver_polish, (int32_t *)nullptr);
         launch_score(s, (const double4 *)pts, n, (const double *)d_Etab, nullptr, (const int32_t *)d_nm, 0, 10, thresh2, d_good, d_es);
         hipLaunchKernelGGL(refit_decide_kernel, dim3(1), dim3(64), 0, s, (const int32_t *)d_nm, (const int32_t *)d_good,
                            (const double *)d_es, (const double *)d_Etab, d_st);
@@ -2189,7 +2205,7 @@ int mlpl_lmeds_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
     hipLaunchKernelGGL(solve5pt_kernel, dim3(niters), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, 0, niters, B.recs);
     hipLaunchKernelGGL(roots_kernel, dim3((niters + kHypPerWave - 1) / kHypPerWave), dim3(64), 0, s, (const PolyRec *)B.recs, 0,
-                       niters, B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total, ctx->opt_solver_polish);
+                       niters, B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total, ctx->opt_solver_polish, (int32_t *)nullptr);
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
     prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
     if (n <= kScoreBlockMaxN)
