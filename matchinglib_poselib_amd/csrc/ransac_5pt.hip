@@ -730,12 +730,47 @@ __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__
     solve_from_basis(L, lane, recs + (sample - sample_offset));
 }
 
+// State of the device-side replay of runRANSAC (see replay_kernel); defined here because pack_points_kernel also initialises it.
+struct ReplayState {
+    int32_t maxGood;      // best inlier count so far (0 = none)
+    int32_t niters;       // current iteration bound
+    int32_t iter;         // iterations executed so far
+    int32_t stop;         // 1 once iter >= niters
+    double errminsum;     // error sum of the model held
+    long long best;       // global index iteration*10 + slot of the model held, -1 = none
+    double E[9];          // the model held
+    int32_t refit_models; // models produced by the refit step (-1 = refit not run)
+    int32_t refit_taken;  // slot of the refit model taken, -1 = none
+    long long models_scored;  // essential matrices scored over all passes (statistics)
+    // iteration bounds the replay evaluated ON THE DEVICE (no host table): (inlier count g, T(g)) per record-breaking count,
+    // verified by the host against its libm after the call (ransac driver); t_count > kTUsedMax = list overflow
+    int32_t t_count;
+    int32_t t_pad;
+    int32_t t_g[48];
+    int32_t t_val[48];
+};
+constexpr int kTUsedMax = 48;
+
+
 // ---------------------------------------------------------------------------------------------------------------
 // Sampson scoring: one thread per model.
 // ---------------------------------------------------------------------------------------------------------------
 // Also kp[i] (a polynomial in |x1|+|y1|+1 and |x2|+|y2|+1), stored behind the points: the per-point factor of the error band of the
 // fused-multiply-add fast path of the inlier predicate (sampson_inlier_fma).
-__global__ void pack_points_kernel(const double *__restrict__ p1, const double *__restrict__ p2, int n, double4 *__restrict__ pts) {
+__global__ void pack_points_kernel(const double *__restrict__ p1, const double *__restrict__ p2, int n, double4 *__restrict__ pts,
+                                   ReplayState *__restrict__ st, int niters, int32_t *__restrict__ zero_ints, int n_zero) {
+    if (st && blockIdx.x == 0 && threadIdx.x < 64) {  // start state of the replay + zeroed counters: saves two stream operations per call
+        if (threadIdx.x < n_zero) zero_ints[threadIdx.x] = 0;
+        if (threadIdx.x == 0) {
+            st->maxGood = 0, st->niters = niters, st->iter = 0, st->stop = 0;
+            st->errminsum = DBL_MAX;
+            st->best = -1;
+            for (int k = 0; k < 9; ++k) st->E[k] = 0.0;
+            st->refit_models = -1, st->refit_taken = -1;
+            st->models_scored = 0;
+            st->t_count = 0, st->t_pad = 0;
+        }
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
@@ -1408,25 +1443,6 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
 // T[g] = cvRANSACUpdateNumIters1(confidence, (n-g)/n, 5, +inf) is tabulated on the HOST (glibc log/pow, so the values are
 // the CPU path's).  So the loop's stopping point and winner are a prefix-max scan, a find-first and an arg-max reduction.
 // ---------------------------------------------------------------------------------------------------------------
-struct ReplayState {
-    int32_t maxGood;      // best inlier count so far (0 = none)
-    int32_t niters;       // current iteration bound
-    int32_t iter;         // iterations executed so far
-    int32_t stop;         // 1 once iter >= niters
-    double errminsum;     // error sum of the model held
-    long long best;       // global index iteration*10 + slot of the model held, -1 = none
-    double E[9];          // the model held
-    int32_t refit_models; // models produced by the refit step (-1 = refit not run)
-    int32_t refit_taken;  // slot of the refit model taken, -1 = none
-    long long models_scored;  // essential matrices scored over all passes (statistics)
-    // iteration bounds the replay evaluated ON THE DEVICE (no host table): (inlier count g, T(g)) per record-breaking count,
-    // verified by the host against its libm after the call (ransac driver); t_count > kTUsedMax = list overflow
-    int32_t t_count;
-    int32_t t_pad;
-    int32_t t_g[48];
-    int32_t t_val[48];
-};
-constexpr int kTUsedMax = 48;
 
 // cvRANSACUpdateNumIters1 (modelest.cpp:86-109) with max_iters = "infinity", evaluated on the device.  The host recomputes
 // every value the replay used with glibc and falls back to a host-built table if one differs (device log/pow are not glibc's,
@@ -1758,11 +1774,13 @@ static int score_point_splits(int n, int max_models, bool sums) {
     return std::max(1, std::min(8, ntiles / 2));
 }
 
-static int pack_points(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double4 **d_pts, hipStream_t s) {
+static int pack_points(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double4 **d_pts, hipStream_t s,
+                       ReplayState *d_st = nullptr, int niters = 0, int32_t *zero_ints = nullptr, int n_zero = 0) {
     void *buf = nullptr;
-    int rc = ws_get(ctx, WS_AUX3, (size_t)n * (sizeof(double4) + sizeof(double)), &buf);  // points, then pmag[n]
+    int rc = ws_get(ctx, WS_AUX3, (size_t)n * (sizeof(double4) + sizeof(double)), &buf);  // points, then kp[n]
     if (rc) return rc;
-    hipLaunchKernelGGL(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_p1, d_p2, n, (double4 *)buf);
+    hipLaunchKernelGGL(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_p1, d_p2, n, (double4 *)buf, d_st, niters, zero_ints,
+                       n_zero);
     *d_pts = (double4 *)buf;
     return MLPL_OK;
 }
@@ -1948,8 +1966,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     const bool lazy = ctx->opt_ransac_lazy_sums != 0 && qmax > 0 && n <= kScoreBlockMaxN;
 
     double4 *pts;
-    int rc = pack_points(ctx, d_p1, d_p2, n, &pts, s);
-    if (rc) return rc;
+    int rc;
 
     const int kChunk = ctx->opt_ransac_chunk > 0 ? ctx->opt_ransac_chunk : 32768;
     const int chunk_cap = std::min(max_iters, kChunk);
@@ -1999,8 +2016,8 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     init.best = -1;
     init.refit_models = -1;
     init.refit_taken = -1;
-    *h_st = init;
-    MLPL_HIP_TRY(hipMemcpyAsync(d_st, h_st, sizeof(ReplayState), hipMemcpyHostToDevice, s));
+    // the packing kernel also writes the start state of the replay and zeroes the dense-list counter of the first pass
+    if ((rc = pack_points(ctx, d_p1, d_p2, n, &pts, s, d_st, max_iters, B.total, 1))) return rc;
     if (use_table) MLPL_HIP_TRY(hipMemcpyAsync(d_T, h_T, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
 
     GlibcRand rng;
@@ -2009,15 +2026,18 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     for (int base = 0; base < max_iters; base += chunk_cap) {
         const int cnt = std::min(chunk_cap, std::min(max_iters, cur.niters) - base);
         if (cnt <= 0) break;
-        if (base > 0) MLPL_HIP_TRY(hipStreamSynchronize(s));  // the pinned sample buffer is being reused
-        MLPL_HIP_TRY(hipMemsetAsync(B.total, 0, 4, s));
+        if (base > 0) {
+            MLPL_HIP_TRY(hipStreamSynchronize(s));  // the pinned sample buffer is being reused
+            MLPL_HIP_TRY(hipMemsetAsync(B.total, 0, 4, s));  // (the first pass's counter was zeroed by pack_points_kernel)
+        }
         // The glibc-stream sample table is drawn on the host into pinned, device-mapped memory that the solver reads in place
-        // (20 bytes per wave over PCIe, no staging copy in the stream).  Two slices: the device solves the first while the
-        // host draws the rest.
-        const int first = std::min(cnt, 4096);
+        // (20 bytes per wave over PCIe, no staging copy in the stream).  The host draws ~9 ns per sample, the device solves 13-25 ns
+        // per sample: a large pass runs in three slices (1024, up to 8192, the rest) so that the device starts after ~10 us of drawing
+        // and always finds the next slice ready; up to 4096 hypotheses are one slice (two small solver launches would cost more than
+        // the wait).
         const int point_splits = score_point_splits(n, cnt * 10, !lazy);
         for (int off = 0; off < cnt;) {
-            const int m = (off == 0) ? first : cnt - off;
+            const int m = cnt <= 4096 ? cnt : (off == 0 ? 1024 : (off == 1024 ? std::min(cnt - off, 7168) : cnt - off));
             for (int i = off; i < off + m; ++i) draw_sample(rng, n, &h_samples[(size_t)i * 5]);
             prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
             hipLaunchKernelGGL(solve5pt_kernel, dim3(m), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, off, off + m,
