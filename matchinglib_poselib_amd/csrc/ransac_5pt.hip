@@ -874,8 +874,9 @@ __device__ __forceinline__ double model_band(const double *e, double qmax) {
 constexpr int kScoreThreads = 512;
 constexpr int kScoreModels = kScoreThreads / 4;
 constexpr int kScoreTile = 512;
-template <bool SUMS>
-__global__ __launch_bounds__(kScoreThreads) void score_models_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
+constexpr int kScoreThreadsSmall = 128;  // count-only passes of a few thousand models: 32 models per workgroup, one tile each
+template <bool SUMS, int kThreads = kScoreThreads>
+__global__ __launch_bounds__(kThreads) void score_models_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
                                                            const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
                                                            int total_host, double thresh2, double qmax, int32_t *__restrict__ good,
                                                            double *__restrict__ esum) {
@@ -883,10 +884,10 @@ __global__ __launch_bounds__(kScoreThreads) void score_models_kernel(const doubl
     __shared__ double tile_mag[SUMS ? 1 : kScoreTile];
     const double *__restrict__ pmag = reinterpret_cast<const double *>(pts + n);
     const int total = total_ptr ? *total_ptr : total_host;
-    if (blockIdx.x * kScoreModels >= total) return;  // block-uniform
+    if (blockIdx.x * (kThreads / 4) >= total) return;  // block-uniform
     const int tid = threadIdx.x;
     const int j = tid & 3;
-    const int m = blockIdx.x * kScoreModels + (tid >> 2);
+    const int m = blockIdx.x * (kThreads / 4) + (tid >> 2);
     const bool live = m < total;
     double e[9];
 #pragma unroll
@@ -899,7 +900,7 @@ __global__ __launch_bounds__(kScoreThreads) void score_models_kernel(const doubl
     for (int base = blockIdx.y * kScoreTile; base < n; base += kScoreTile * gridDim.y) {
         const int rows = min(kScoreTile, n - base);
         __syncthreads();
-        for (int i = tid; i < rows; i += kScoreThreads) {
+        for (int i = tid; i < rows; i += kThreads) {
             tile[i] = pts[base + i];
             if constexpr (!SUMS) tile_mag[i] = pmag[base + i];
         }
@@ -1755,22 +1756,25 @@ static void launch_score(hipStream_t s, const double4 *pts, int n, const double 
         else
             hipLaunchKernelGGL(score_models_kernel<true>, dim3((max_models + kScoreModels - 1) / kScoreModels), dim3(kScoreThreads), 0, s, pts, n, E_list, ids, total_ptr,
                                total_host, thresh2, qmax, good, esum);
+    } else if (point_splits == 0) {  // one workgroup per model, no accumulation: callers that do not zero the table
+        hipLaunchKernelGGL((score_models_block_kernel<true, false>), dim3(max_models), dim3(256), 0, s, pts, n, E_list, ids, total_ptr,
+                           total_host, thresh2, qmax, good, esum, (const int32_t *)nullptr);
+    } else if (max_models <= kScoreBlockMaxModels) {
+        hipLaunchKernelGGL((score_models_kernel<false, kScoreThreadsSmall>), dim3((max_models + kScoreThreadsSmall / 4 - 1) / (kScoreThreadsSmall / 4), point_splits),
+                           dim3(kScoreThreadsSmall), 0, s, pts, n, E_list, ids, total_ptr, total_host, thresh2, qmax, good, esum);
     } else {
-        if (block)
-            hipLaunchKernelGGL((score_models_block_kernel<true, false>), dim3(max_models), dim3(256), 0, s, pts, n, E_list, ids, total_ptr,
-                               total_host, thresh2, qmax, good, esum, (const int32_t *)nullptr);
-        else
-            hipLaunchKernelGGL(score_models_kernel<false>, dim3((max_models + kScoreModels - 1) / kScoreModels, point_splits), dim3(kScoreThreads), 0, s, pts,
-                               n, E_list, ids, total_ptr, total_host, thresh2, qmax, good, esum);
+        hipLaunchKernelGGL((score_models_kernel<false, kScoreThreads>), dim3((max_models + kScoreModels - 1) / kScoreModels, point_splits), dim3(kScoreThreads), 0,
+                           s, pts, n, E_list, ids, total_ptr, total_host, thresh2, qmax, good, esum);
     }
 }
 
-// Workgroups per model group of the count-only scoring pass (see score_models_kernel): two tiles each, at most eight; 1 = the table
-// is written, not accumulated (few models: the one-workgroup-per-model kernel runs instead, or sums are wanted).
+// Workgroups per model group of the count-only scoring pass (see score_models_kernel); with more than one the counts are ACCUMULATED
+// into a table the caller has zeroed (roots_kernel does that for the RANSAC pass).  launch_score(point_splits = 0) is the form for
+// callers with an unzeroed table: one workgroup per model.
 static int score_point_splits(int n, int max_models, bool sums) {
-    const bool block = n <= kScoreBlockMaxN && max_models <= kScoreBlockMaxModels;
-    if (sums || block) return 1;
+    if (sums) return 1;
     const int ntiles = (n + kScoreTile - 1) / kScoreTile;
+    if (max_models <= kScoreBlockMaxModels) return std::max(1, std::min(16, ntiles));  // small passes: one tile per workgroup
     return std::max(1, std::min(8, ntiles / 2));
 }
 
