@@ -491,10 +491,12 @@ __device__ __forceinline__ void polish_xyz(const double *EE, double &x, double &
 // registers), reject |xy1[2]| < 1e-10 (:457), E = x E0 + y E1 + z E2 + E3, Frobenius-normalised.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kHypPerWave = 6;
-__global__ __launch_bounds__(64) void roots_kernel(const PolyRec *__restrict__ recs, int sample_offset, int n_samples,
+template <bool kPolish>  // compile-time: the polished instance does not carry the Jacobi SVD's registers
+__global__ __launch_bounds__(64) void roots_kernel_t(const PolyRec *__restrict__ recs, int sample_offset, int n_samples,
                                                    double *__restrict__ E_tab, int32_t *__restrict__ n_models,
                                                    double *__restrict__ dense_E, int32_t *__restrict__ dense_id,
-                                                   int32_t *__restrict__ dense_total, int polish, int32_t *__restrict__ good_zero) {
+                                                   int32_t *__restrict__ dense_total, int32_t *__restrict__ good_zero) {
+    constexpr bool polish = kPolish;
     __shared__ double R[kHypPerWave][88];
     __shared__ double rr[64], ri[64];
     if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
@@ -616,11 +618,11 @@ __global__ __launch_bounds__(64) void roots_kernel(const PolyRec *__restrict__ r
             bz[j * 3 + 2] = br[8] * z4 + br[9] * z3 + br[10] * z2 + br[11] * z1 + br[12];
         }
         double xy1[3];
-        if (polish) null_vector_3x3_cross(bz, xy1);  // the polish step below puts (x, y, z) on the constraints whatever the last digits here
-        else null_vector_3x3(bz, xy1);               // plain root path: the SVD null vector, as the CPU path
+        if constexpr (polish) null_vector_3x3_cross(bz, xy1);  // the polish step below puts (x, y, z) on the constraints whatever the last digits here
+        else null_vector_3x3(bz, xy1);                         // plain root path: the SVD null vector, as the CPU path
         if (!(fabs(xy1[2]) < 1e-10)) {
             double x = xy1[0] / xy1[2], y = xy1[1] / xy1[2], zp = z1;
-            if (polish) polish_xyz(EE, x, y, zp);
+            if constexpr (polish) polish_xyz(EE, x, y, zp);
             double nrm = 0;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
@@ -660,6 +662,13 @@ __global__ __launch_bounds__(64) void roots_kernel(const PolyRec *__restrict__ r
     }
     if (h < kHypPerWave && r == 0 && sample < n_samples) n_models[sample] = cnt_h;
 }
+
+// launch helper: picks the instance by the context's solver_polish option
+#define MLPL_LAUNCH_ROOTS(polish_flag, grid, stream, ...)                                                        \
+    do {                                                                                                         \
+        if (polish_flag) hipLaunchKernelGGL(roots_kernel_t<true>, grid, dim3(64), 0, stream, __VA_ARGS__);       \
+        else hipLaunchKernelGGL(roots_kernel_t<false>, grid, dim3(64), 0, stream, __VA_ARGS__);                  \
+    } while (0)
 
 __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
                                                       const int32_t *__restrict__ samples, int sample_offset, int n_samples,
@@ -1885,8 +1894,8 @@ int mlpl_solve_5pt(mlpl_ctx *ctx, const double *p1, const double *p2, int n, con
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
     hipLaunchKernelGGL(solve5pt_kernel, dim3(n_samples), dim3(64), 0, s, (const double *)dp1, (const double *)dp2, B.samples, 0,
                        n_samples, B.recs);
-    hipLaunchKernelGGL(roots_kernel, dim3((n_samples + kHypPerWave - 1) / kHypPerWave), dim3(64), 0, s, (const PolyRec *)B.recs, 0,
-                       n_samples, B.E_tab, B.n_models, (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, ctx->opt_solver_polish, (int32_t *)nullptr);
+    MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((n_samples + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)B.recs, 0, n_samples,
+                      B.E_tab, B.n_models, (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
     MLPL_HIP_TRY(hipGetLastError());
     MLPL_HIP_TRY(hipMemcpyAsync(E_out, B.E_tab, (size_t)n_samples * 720, hipMemcpyDeviceToHost, s));
@@ -2046,9 +2055,8 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
             prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
             hipLaunchKernelGGL(solve5pt_kernel, dim3(m), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, off, off + m,
                                B.recs);
-            hipLaunchKernelGGL(roots_kernel, dim3((m + kHypPerWave - 1) / kHypPerWave), dim3(64), 0, s, (const PolyRec *)B.recs,
-                               off, off + m, B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total, ctx->opt_solver_polish,
-                               point_splits > 1 ? B.good : (int32_t *)nullptr);
+            MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((m + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)B.recs, off, off + m,
+                              B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total, point_splits > 1 ? B.good : (int32_t *)nullptr);
             prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
             off += m;
         }
@@ -2094,8 +2102,8 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         double *d_gram = d_rf + 144;                 // [gblocks][45]
         hipLaunchKernelGGL(gram_kernel, dim3(gblocks), dim3(256), 0, s, (const double4 *)pts, (const uint8_t *)d_mask, n, d_gram);
         hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, s, (const double *)d_gram, gblocks, B.recs);
-        hipLaunchKernelGGL(roots_kernel, dim3(1), dim3(64), 0, s, (const PolyRec *)B.recs, 0, 1, d_Etab, d_nm, (double *)nullptr,
-                           (int32_t *)nullptr, (int32_t *)nullptr, ctx->opt_solver_polish, (int32_t *)nullptr);
+        MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3(1), s, (const PolyRec *)B.recs, 0, 1, d_Etab, d_nm, (double *)nullptr,
+                          (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
         launch_score(s, (const double4 *)pts, n, (const double *)d_Etab, nullptr, (const int32_t *)d_nm, 0, 10, thresh2, d_good, d_es);
         hipLaunchKernelGGL(refit_decide_kernel, dim3(1), dim3(64), 0, s, (const int32_t *)d_nm, (const int32_t *)d_good,
                            (const double *)d_es, (const double *)d_Etab, d_st);
@@ -2228,8 +2236,8 @@ int mlpl_lmeds_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_
     MLPL_HIP_TRY(hipMemsetAsync(B.total, 0, 4, s));
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
     hipLaunchKernelGGL(solve5pt_kernel, dim3(niters), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, 0, niters, B.recs);
-    hipLaunchKernelGGL(roots_kernel, dim3((niters + kHypPerWave - 1) / kHypPerWave), dim3(64), 0, s, (const PolyRec *)B.recs, 0,
-                       niters, B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total, ctx->opt_solver_polish, (int32_t *)nullptr);
+    MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((niters + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)B.recs, 0, niters, B.E_tab,
+                      B.n_models, B.dense_E, B.dense_id, B.total, (int32_t *)nullptr);
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
     prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
     if (n <= kScoreBlockMaxN)
