@@ -15,18 +15,20 @@
 //      64 = 4^3 lanes evaluates the trilinear coefficient tensor, 20 lanes symmetrise it into the 10x20 matrix in the
 //      reference's monomial order (five-point.cpp:813-823);
 //   3. Gauss-Jordan with partial pivoting on the 10x20 system, 200 elements spread over the wave;
-//   4. B(z) (3x13) and the degree-10 determinant polynomial, one coefficient per lane -> PolyRec in global memory.
-// roots_kernel (SIX hypotheses per wave, one root per lane):
+//   4. B(z) (3x13) and the degree-10 determinant polynomial as two convolution stages over the wave -> PolyRec in global memory.
+// roots_kernel_t<polish> (SIX hypotheses per wave, one root per lane):
 //   5. all complex roots simultaneously by Ehrlich-Aberth from cv::solvePoly's start values (1+i)^k (solvePoly itself iterates
 //      Durand-Kerner; a converged simultaneous iteration delivers the same roots to rounding); a root is real iff
 //      |imag| <= 1e-10 (five-point.cpp:438);
-//   6. per real root: null vector of Bz (3x3 one-sided Jacobi SVD in registers), reject |xy1[2]| < 1e-10 (:457), a Gauss-Newton
-//      polish of (x, y, z) on the ten constraints (polish_xyz), E = x E0 + y E1 + z E2 + E3, Frobenius-normalised;
-//      ballot-compacted into the per-hypothesis table and the dense model list.
+//   6. per real root: null vector of Bz, reject |xy1[2]| < 1e-10 (:457), E = x E0 + y E1 + z E2 + E3, Frobenius-normalised,
+//      ballot-compacted into the per-hypothesis table and the dense model list.  polish = true (default): cross-product null
+//      vector + Gauss-Newton polish of (x, y, z) on the ten constraints (polish_xyz: every model satisfies them to rounding);
+//      polish = false: the 3x3 one-sided Jacobi SVD null vector, the plain root path of the CPU code.
 // Scoring: fp64 Sampson error in the reference's operation order rounded to float exactly as the reference stores it,
-//   `err <= thresh^2` counts (division-free predicate, sampson_inlier) and the 4-accumulator double sum of the float errors --
-//   bit-identical to the CPU path for the same E (no FMA contraction: this file is compiled with -ffp-contract=off like the
-//   reference's -msse4.2 build).
+//   `err <= thresh^2` counts and the 4-accumulator double sum of the float errors -- bit-identical to the CPU path for the same E (no
+//   FMA contraction: this file is compiled with -ffp-contract=off like the reference's -msse4.2 build).  The RANSAC passes count
+//   without dividing and on explicit FMAs inside a rigorous error band (sampson_inlier_fma; same counts), split the correspondences
+//   of a model group over several workgroups (atomic counts), and compute error sums only for the models that can still win.
 // The solver kernels must be launched with exactly 64 threads: wave_sync() orders LDS traffic inside ONE wave only.
 
 #include <algorithm>
