@@ -117,11 +117,19 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_hamming_mfma_weighted = 1;
     ctx->opt_hamming_mfma_prio = 0;
     ctx->opt_ransac_lazy_sums = 1;
+    ctx->opt_ransac_overlap = 1;
     ctx->opt_solver_polish = 1;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
         delete ctx;
+        return MLPL_E_HIP;
+    }
+    e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
+    for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipEventCreateWithFlags(&ctx->aux_ev[i], hipEventDisableTiming);
+    if (e != hipSuccess) {
+        set_error("helper stream / events: %s", hipGetErrorString(e));
+        mlpl_ctx_destroy(ctx);
         return MLPL_E_HIP;
     }
     *out = ctx;
@@ -142,6 +150,9 @@ void mlpl_ctx_destroy(mlpl_ctx *ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete[] ctx->ransac_T_host;
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    for (int i = 0; i < 8; ++i)
+        if (ctx->aux_ev[i]) (void)hipEventDestroy(ctx->aux_ev[i]);
     delete ctx;
 }
 
@@ -167,6 +178,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "hamming_qpl") && (value == 1 || value == 2)) ctx->opt_hamming_qpl = value;
     else if (!std::strcmp(name, "hamming_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_blocks_per_cu = value;
     else if (!std::strcmp(name, "ransac_lazy_sums") && (value == 0 || value == 1)) ctx->opt_ransac_lazy_sums = value;
+    else if (!std::strcmp(name, "ransac_overlap") && (value == 0 || value == 1)) ctx->opt_ransac_overlap = value;
     else if (!std::strcmp(name, "solver_polish") && (value == 0 || value == 1)) ctx->opt_solver_polish = value;
     else if (!std::strcmp(name, "ransac_host_table") && (value == 0 || value == 1)) ctx->opt_ransac_host_table = value;
     else if (!std::strcmp(name, "ransac_chunk") && value >= 0 && value <= (1 << 20)) ctx->opt_ransac_chunk = value;

@@ -66,6 +66,8 @@ struct L2Gate {
 struct mlpl_ctx {
     int device;
     hipStream_t stream;
+    hipStream_t aux_stream;        // helper stream of the RANSAC driver: the root kernel of slice i runs beside the elimination kernel of slice i+1
+    hipEvent_t aux_ev[8];          // fork/join events for it (timing disabled)
     void *ws[mlpl::WS_NUM_SLOTS];
     size_t ws_bytes[mlpl::WS_NUM_SLOTS];
     void *pinned;  // small pinned host scratch for async result readback
@@ -90,6 +92,7 @@ struct mlpl_ctx {
     int opt_hamming_stamps;         // diagnostics: the matrix-core kernel records per-wave clock stamps (mlpl_debug_hamming_stamps)
     int dbg_stamp_items;
     int opt_ransac_chunk;           // hypotheses per device pass (0 = 32768)
+    int opt_ransac_overlap;         // 1 (default) = large passes run their root kernels on the helper stream
     int opt_ransac_lazy_sums;       // 1 (default) = division-free inlier counts + error sums only for models that can still win
     int opt_solver_polish;          // 1 (default) = Gauss-Newton polish of every 5-point solution on the cubic constraints
     int opt_ransac_host_table;      // 1 = always build the niters table on the host (default: evaluate on the device, verify)

@@ -1682,37 +1682,67 @@ __global__ void refit_decide_kernel(const int32_t *__restrict__ n_models, const 
 // ---------------------------------------------------------------------------------------------------------------
 
 // glibc srand()/rand() (TYPE_3 additive feedback), so that a seed reproduces the reference's sample stream
+// glibc srand()/rand() (TYPE_3 additive feedback generator: r[k+3] += r[k] over a ring of 31 words, output r >> 1, the first 310
+// outputs discarded), produced 31 values at a time: one unrolled pass over the ring has no index wrap-around and three independent
+// dependency chains.  After seeding the generator is block-aligned (310 = 10 * 31), so block k holds outputs 31 k .. 31 k + 30.
 struct GlibcRand {
-    int32_t r[34];
-    int f, b;
+    uint32_t r[31];
+    int32_t out[31];
+    int pos;
+    void refill() {
+#pragma unroll
+        for (int k = 0; k < 28; ++k) {
+            r[k + 3] += r[k];
+            out[k] = (int32_t)(r[k + 3] >> 1);
+        }
+        for (int k = 28; k < 31; ++k) {
+            r[k - 28] += r[k];
+            out[k] = (int32_t)(r[k - 28] >> 1);
+        }
+        pos = 0;
+    }
     void seed(unsigned s) {
         if (s == 0) s = 1;
-        r[0] = (int32_t)s;
+        int32_t t[31];
+        t[0] = (int32_t)s;
         for (int i = 1; i < 31; ++i) {
-            const long hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+            const long hi = t[i - 1] / 127773, lo = t[i - 1] % 127773;
             long w = 16807 * lo - 2836 * hi;
             if (w < 0) w += 2147483647;
-            r[i] = (int32_t)w;
+            t[i] = (int32_t)w;
         }
-        f = 3;
-        b = 0;
-        for (int i = 0; i < 310; ++i) (void)next();
+        for (int i = 0; i < 31; ++i) r[i] = (uint32_t)t[i];
+        for (int i = 0; i < 10; ++i) refill();
+        pos = 31;
     }
     int next() {
-        uint32_t *u = reinterpret_cast<uint32_t *>(r);
-        u[f] += u[b];
-        const uint32_t res = u[f] >> 1;
-        if (++f >= 31) f = 0;
-        if (++b >= 31) b = 0;
-        return (int)res;
+        if (pos == 31) refill();
+        return out[pos++];
     }
 };
 
 // getSubset (modelest.cpp:567-610): 5 distinct indices, duplicates redrawn.  checkSubset (:613-650) returns
 // `i >= i1` with i0 == i1, i.e. true for every input, so no geometric rejection ever happens in the reference.
-void draw_sample(GlibcRand &g, int n, int32_t *idx) {
-    for (int i = 0; i < 5;) {
-        const int v = g.next() % n;
+// v % n for 0 <= v < 2^31 without a division (Lemire's fastmod, exact for 32-bit operands): M = floor((2^64 - 1) / n) + 1.
+struct FastMod {
+    uint64_t M;
+    uint32_t n;
+    explicit FastMod(int n_) : M(UINT64_C(0xFFFFFFFFFFFFFFFF) / (uint32_t)n_ + 1), n((uint32_t)n_) {}
+    int operator()(int v) const { return (int)(((unsigned __int128)(M * (uint32_t)v) * n) >> 64); }
+};
+
+void draw_sample(GlibcRand &g, const FastMod &mod, int32_t *idx) {
+    if (g.pos + 5 <= 31) {  // the common case in one go: five independent reductions, no duplicate among them
+        const int32_t *o = g.out + g.pos;
+        const int v0 = mod(o[0]), v1 = mod(o[1]), v2 = mod(o[2]), v3 = mod(o[3]), v4 = mod(o[4]);
+        if (v0 != v1 && v0 != v2 && v0 != v3 && v0 != v4 && v1 != v2 && v1 != v3 && v1 != v4 && v2 != v3 && v2 != v4 && v3 != v4) {
+            idx[0] = v0, idx[1] = v1, idx[2] = v2, idx[3] = v3, idx[4] = v4;
+            g.pos += 5;
+            return;
+        }
+    }
+    for (int i = 0; i < 5;) {  // the reference's loop: one draw per pick, duplicates redrawn
+        const int v = mod(g.next());
         bool dup = false;
         for (int j = 0; j < i; ++j) dup = dup || (idx[j] == v);
         if (dup) continue;
@@ -2037,6 +2067,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
 
     GlibcRand rng;
     rng.seed(seed);
+    const FastMod fmod_n(n);
     ReplayState cur = init;
     for (int base = 0; base < max_iters; base += chunk_cap) {
         const int cnt = std::min(chunk_cap, std::min(max_iters, cur.niters) - base);
@@ -2051,16 +2082,32 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         // and always finds the next slice ready; up to 4096 hypotheses are one slice (two small solver launches would cost more than
         // the wait).
         const int point_splits = score_point_splits(n, cnt * 10, !lazy);
-        for (int off = 0; off < cnt;) {
+        // Large passes: the root kernel of a slice goes to the helper stream, so it runs beside the elimination kernel of the next
+        // slice (both are latency-bound at these sizes and leave most issue slots idle; unlike the counting kernel, which saturates
+        // the vector units and gains nothing from company -- DESIGN section 5).
+        const bool overlap = cnt > 4096 && ctx->opt_ransac_overlap != 0;
+        hipStream_t sr = overlap ? ctx->aux_stream : s;
+        int slice_no = 0;
+        for (int off = 0; off < cnt; ++slice_no) {
             const int m = cnt <= 4096 ? cnt : (off == 0 ? 1024 : (off == 1024 ? std::min(cnt - off, 7168) : cnt - off));
-            for (int i = off; i < off + m; ++i) draw_sample(rng, n, &h_samples[(size_t)i * 5]);
+            for (int i = off; i < off + m; ++i) draw_sample(rng, fmod_n, &h_samples[(size_t)i * 5]);
             prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
+            // (the hand-over records are indexed from the slice's first sample: each slice gets its own part of the buffer, the root
+            // kernel of slice i and the elimination kernel of slice i+1 run side by side)
             hipLaunchKernelGGL(solve5pt_kernel, dim3(m), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, off, off + m,
-                               B.recs);
-            MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((m + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)B.recs, off, off + m,
-                              B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total, point_splits > 1 ? B.good : (int32_t *)nullptr);
+                               B.recs + off);
+            if (overlap) {  // everything the root kernel reads is complete once this event fires (the first one also covers the setup)
+                MLPL_HIP_TRY(hipEventRecord(ctx->aux_ev[slice_no], s));
+                MLPL_HIP_TRY(hipStreamWaitEvent(sr, ctx->aux_ev[slice_no], 0));
+            }
+            MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((m + kHypPerWave - 1) / kHypPerWave), sr, (const PolyRec *)(B.recs + off), off,
+                              off + m, B.E_tab, B.n_models, B.dense_E, B.dense_id, B.total, point_splits > 1 ? B.good : (int32_t *)nullptr);
             prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
             off += m;
+        }
+        if (overlap) {  // join: the counting pass needs every root kernel
+            MLPL_HIP_TRY(hipEventRecord(ctx->aux_ev[7], sr));
+            MLPL_HIP_TRY(hipStreamWaitEvent(s, ctx->aux_ev[7], 0));
         }
         prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
         launch_score(s, (const double4 *)pts, n, (const double *)B.dense_E, (const int32_t *)B.dense_id, (const int32_t *)B.total, 0,
@@ -2234,7 +2281,8 @@ int mlpl_lmeds_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_
 
     GlibcRand rng;
     rng.seed(seed);
-    for (int i = 0; i < niters; ++i) draw_sample(rng, n, &h_samples[(size_t)i * 5]);
+    const FastMod fmod_n(n);
+    for (int i = 0; i < niters; ++i) draw_sample(rng, fmod_n, &h_samples[(size_t)i * 5]);
     MLPL_HIP_TRY(hipMemsetAsync(B.total, 0, 4, s));
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
     hipLaunchKernelGGL(solve5pt_kernel, dim3(niters), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, 0, niters, B.recs);
