@@ -125,7 +125,8 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
         delete ctx;
         return MLPL_E_HIP;
     }
-    e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
+    e = hipStreamCreateWithFlags(&ctx->aux_stream[0], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream[1], hipStreamNonBlocking);
     for (int i = 0; e == hipSuccess && i < 8; ++i) e = hipEventCreateWithFlags(&ctx->aux_ev[i], hipEventDisableTiming);
     if (e != hipSuccess) {
         set_error("helper stream / events: %s", hipGetErrorString(e));
@@ -150,7 +151,8 @@ void mlpl_ctx_destroy(mlpl_ctx *ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete[] ctx->ransac_T_host;
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->aux_stream[i]) (void)hipStreamDestroy(ctx->aux_stream[i]);
     for (int i = 0; i < 8; ++i)
         if (ctx->aux_ev[i]) (void)hipEventDestroy(ctx->aux_ev[i]);
     delete ctx;

@@ -66,8 +66,8 @@ struct L2Gate {
 struct mlpl_ctx {
     int device;
     hipStream_t stream;
-    hipStream_t aux_stream;        // helper stream of the RANSAC driver: the root kernel of slice i runs beside the elimination kernel of slice i+1
-    hipEvent_t aux_ev[8];          // fork/join events for it (timing disabled)
+    hipStream_t aux_stream[2];     // helper streams of the RANSAC driver: the root kernels of the slices run beside the elimination kernels and each other
+    hipEvent_t aux_ev[8];          // fork/join events for them (timing disabled)
     void *ws[mlpl::WS_NUM_SLOTS];
     size_t ws_bytes[mlpl::WS_NUM_SLOTS];
     void *pinned;  // small pinned host scratch for async result readback

@@ -2086,7 +2086,6 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         // slice (both are latency-bound at these sizes and leave most issue slots idle; unlike the counting kernel, which saturates
         // the vector units and gains nothing from company -- DESIGN section 5).
         const bool overlap = cnt > 4096 && ctx->opt_ransac_overlap != 0;
-        hipStream_t sr = overlap ? ctx->aux_stream : s;
         int slice_no = 0;
         for (int off = 0; off < cnt; ++slice_no) {
             const int m = cnt <= 4096 ? cnt : (off == 0 ? 1024 : (off == 1024 ? std::min(cnt - off, 7168) : cnt - off));
@@ -2096,6 +2095,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
             // kernel of slice i and the elimination kernel of slice i+1 run side by side)
             hipLaunchKernelGGL(solve5pt_kernel, dim3(m), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, off, off + m,
                                B.recs + off);
+            hipStream_t sr = overlap ? ctx->aux_stream[slice_no & 1] : s;  // two helper streams: consecutive root kernels overlap too
             if (overlap) {  // everything the root kernel reads is complete once this event fires (the first one also covers the setup)
                 MLPL_HIP_TRY(hipEventRecord(ctx->aux_ev[slice_no], s));
                 MLPL_HIP_TRY(hipStreamWaitEvent(sr, ctx->aux_ev[slice_no], 0));
@@ -2106,8 +2106,10 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
             off += m;
         }
         if (overlap) {  // join: the counting pass needs every root kernel
-            MLPL_HIP_TRY(hipEventRecord(ctx->aux_ev[7], sr));
-            MLPL_HIP_TRY(hipStreamWaitEvent(s, ctx->aux_ev[7], 0));
+            for (int h = 0; h < 2; ++h) {
+                MLPL_HIP_TRY(hipEventRecord(ctx->aux_ev[6 + h], ctx->aux_stream[h]));
+                MLPL_HIP_TRY(hipStreamWaitEvent(s, ctx->aux_ev[6 + h], 0));
+            }
         }
         prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
         launch_score(s, (const double4 *)pts, n, (const double *)B.dense_E, (const int32_t *)B.dense_id, (const int32_t *)B.total, 0,
