@@ -92,6 +92,7 @@ struct mlpl_ctx {
     int opt_hamming_stamps;         // diagnostics: the matrix-core kernel records per-wave clock stamps (mlpl_debug_hamming_stamps)
     int dbg_stamp_items;
     int opt_ransac_chunk;           // hypotheses per device pass (0 = 32768)
+    int opt_ransac_event_cap;       // tests: capacity of the record-event list of candidate / replay kernels (0 = 1024); forces their serial fallback
     int opt_ransac_overlap;         // 1 (default) = large passes run their root kernels on the helper stream
     int opt_ransac_lazy_sums;       // 1 (default) = division-free inlier counts + error sums only for models that can still win
     int opt_solver_polish;          // 1 (default) = Gauss-Newton polish of every 5-point solution on the cubic constraints

@@ -1034,6 +1034,7 @@ __global__ void hyp_max_kernel(const int32_t *__restrict__ n_models, const int32
 // independent of the scan state, row scans are wave shuffles, and the 16 waves meet only once per phase to exchange one value each
 // (the chunk-per-step form of round 1 paid a global-load latency and up to three block barriers per 1024 hypotheses).
 constexpr int kScanBatch = 8;  // rows whose loads are in flight together
+constexpr int kMaxScanEvents = 1024;  // record / tie events of one pass that are expanded in parallel after the scan (one thread each)
 
 template <bool kMax>
 __device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
@@ -1071,10 +1072,14 @@ __device__ __forceinline__ int waves_exclusive_scan_16(int v, int carry, int *wa
 
 __global__ __launch_bounds__(1024) void candidate_kernel(const int32_t *__restrict__ n_models, const int32_t *__restrict__ good,
                                                          const int32_t *__restrict__ hmax_in, int cnt, int carried_best,
-                                                         int32_t *__restrict__ cand, int32_t *__restrict__ cand_count) {
+                                                         int32_t *__restrict__ cand, int32_t *__restrict__ cand_count, int ev_cap) {
     __shared__ int wave_s[16];
+    __shared__ int ev_pos[kMaxScanEvents], ev_val[kMaxScanEvents], ev_n;  // ev_cap <= kMaxScanEvents entries are used (tests shrink it)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) *cand_count = 0;  // single block: reset here instead of a memset launch (ordered by the barriers of the exchange)
+    if (tid == 0) {
+        *cand_count = 0;  // single block: reset here instead of a memset launch (ordered by the barriers below)
+        ev_n = 0;
+    }
     const int R = (cnt + 1023) / 1024;
     const int w0 = wave * R * 64;
     auto hyp_max = [&](int i) {
@@ -1103,12 +1108,27 @@ __global__ __launch_bounds__(1024) void candidate_kernel(const int32_t *__restri
             const int up = __shfl_up(inc, 1);
             const int before = lane ? max(carry, up) : carry;  // best count of everything before hypothesis i
             if (i < cnt && hmax >= 5 && hmax >= before) {
-                const int nm = n_models[i];
-                for (int m = 0; m < nm; ++m)
-                    if (good[(size_t)i * 10 + m] == hmax) cand[atomicAdd(cand_count, 1)] = i * 10 + m;
+                // a hypothesis that holds or ties the running best: a handful per pass.  They are only noted here and expanded below by
+                // one thread each -- inline, their dependent loads ran one after the other inside the wave that met most of them
+                const int e = atomicAdd(&ev_n, 1);
+                if (e < ev_cap) {
+                    ev_pos[e] = i;
+                    ev_val[e] = hmax;
+                } else {  // list full (never seen: it takes that many successive ties/records): expand in place
+                    const int nm = n_models[i];
+                    for (int m = 0; m < nm; ++m)
+                        if (good[(size_t)i * 10 + m] == hmax) cand[atomicAdd(cand_count, 1)] = i * 10 + m;
+                }
             }
             carry = max(carry, __shfl(inc, 63));
         }
+    }
+    __syncthreads();
+    if (tid < min(ev_n, ev_cap)) {
+        const int i = ev_pos[tid], hmax = ev_val[tid];
+        const int nm = n_models[i];
+        for (int m = 0; m < nm; ++m)
+            if (good[(size_t)i * 10 + m] == hmax) cand[atomicAdd(cand_count, 1)] = i * 10 + m;
     }
 }
 
@@ -1498,15 +1518,19 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
                                                       const int32_t *__restrict__ hslot, const double *__restrict__ E_tab, int cnt,
                                                       const int32_t *__restrict__ Ttab, int npts, long long base_index,
                                                       const int32_t *__restrict__ dense_total, ReplayState *__restrict__ st,
-                                                      double confidence) {
+                                                      double confidence, int ev_cap) {
     __shared__ int wave_s[16];
     __shared__ int stop_idx;
+    __shared__ int ev_pos[kMaxScanEvents], ev_val[kMaxScanEvents], ev_n;
     __shared__ int s_best_good[1024];
     __shared__ double s_best_sum[1024];
     __shared__ int s_best_idx[1024];
     const int tid = threadIdx.x;
     const int maxGood0 = st->maxGood, niters0 = st->niters, iter0 = st->iter;
-    if (tid == 0) stop_idx = cnt;  // "no stop inside this chunk"
+    if (tid == 0) {
+        stop_idx = cnt;  // "no stop inside this chunk"
+        ev_n = 0;
+    }
 
     // pass 1: running best count (prefix max in iteration order), niters after each iteration, first iteration after which the loop
     // ends.  Wave-owned contiguous ranges, see above.
@@ -1528,60 +1552,101 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
         const int g = min(running, npts);
         return Ttab ? Ttab[g] : dev_num_iters(confidence, npts, g);
     };
-    int local_T = INT32_MAX;
+    // Sweep 1 only NOTES the record-breaking iterations (position, count); their bounds are then evaluated by one thread each (the fp64
+    // pow + log of a bound is a few microseconds -- inline, the records of the first wave's range ran one after the other).
     {
         int carry = wpre;
         for (int r0 = 0; r0 < R; r0 += kScanBatch) {
-        int hv[kScanBatch];
+            int hv[kScanBatch];
 #pragma unroll
-        for (int j = 0; j < kScanBatch; ++j) {
-            const int i = w0 + (r0 + j) * 64 + lane;
-            hv[j] = (r0 + j < R && i < cnt) ? hgood[i] : 0;
-        }
+            for (int j = 0; j < kScanBatch; ++j) {
+                const int i = w0 + (r0 + j) * 64 + lane;
+                hv[j] = (r0 + j < R && i < cnt) ? hgood[i] : 0;
+            }
 #pragma unroll
-        for (int j = 0; j < kScanBatch; ++j) {
-            if (r0 + j >= R) break;  // wave-uniform
-            const int i = w0 + (r0 + j) * 64 + lane;
-            const int inc = wave_inclusive_scan<true>(hv[j], lane);
-            const int running = max(carry, inc);
-            const int up = __shfl_up(inc, 1);
-            const int prev_running = lane ? max(carry, up) : carry;  // running count before this iteration
-            if (i < cnt && running >= 5 && running > prev_running) {
-                const int Tv = bound_at(running);
-                if (!Ttab) {  // remember the bound used for this count: the host re-evaluates it with its libm
-                    const int slot = atomicAdd(&st->t_count, 1);
-                    if (slot < kTUsedMax) {
-                        st->t_g[slot] = min(running, npts);
-                        st->t_val[slot] = Tv;
+            for (int j = 0; j < kScanBatch; ++j) {
+                if (r0 + j >= R) break;  // wave-uniform
+                const int i = w0 + (r0 + j) * 64 + lane;
+                const int inc = wave_inclusive_scan<true>(hv[j], lane);
+                const int running = max(carry, inc);
+                const int up = __shfl_up(inc, 1);
+                const int prev_running = lane ? max(carry, up) : carry;  // running count before this iteration
+                if (i < cnt && running >= 5 && running > prev_running) {
+                    const int e = atomicAdd(&ev_n, 1);
+                    if (e < ev_cap) {
+                        ev_pos[e] = i;
+                        ev_val[e] = running;
                     }
                 }
-                local_T = min(local_T, Tv);
+                carry = max(carry, __shfl(inc, 63));
             }
-            carry = max(carry, __shfl(inc, 63));
-        }
         }
     }
+    __syncthreads();
+    const bool ev_overflow = ev_n > ev_cap;  // more records than the list holds (adversarial input): serial fallback below
+    const int nev = ev_overflow ? 0 : ev_n;
+    if (ev_overflow && tid == 0) {
+        int running = maxGood0, Tmin = INT32_MAX;
+        for (int i = 0; i < cnt; ++i) {
+            const int h = hgood[i];
+            if (h > running) {
+                running = h;
+                if (running >= 5) {
+                    const int Tv = bound_at(running);
+                    if (!Ttab) {
+                        const int slot = atomicAdd(&st->t_count, 1);
+                        if (slot < kTUsedMax) {
+                            st->t_g[slot] = min(running, npts);
+                            st->t_val[slot] = Tv;
+                        }
+                    }
+                    Tmin = min(Tmin, Tv);
+                }
+            }
+            if (iter0 + i + 1 >= min(niters0, Tmin)) {
+                stop_idx = i;
+                break;
+            }
+        }
+    }
+    if (tid < nev) {
+        const int running = ev_val[tid];
+        const int Tv = bound_at(running);
+        if (!Ttab) {  // remember the bound used for this count: the host re-evaluates it with its libm
+            const int slot = atomicAdd(&st->t_count, 1);
+            if (slot < kTUsedMax) {
+                st->t_g[slot] = min(running, npts);
+                st->t_val[slot] = Tv;
+            }
+        }
+        ev_val[tid] = Tv;  // the list now holds (position, bound)
+    }
+    __syncthreads();
+    // bounds of the events inside / before this wave's range
+    int local_T = INT32_MAX, before_T = INT32_MAX;
+    const int w1 = w0 + R * 64;
+    for (int e = lane; e < nev; e += 64) {
+        const int p = ev_pos[e], Tv = ev_val[e];
+        if (p < w0) before_T = min(before_T, Tv);
+        else if (p < w1) local_T = min(local_T, Tv);
+    }
     const int wave_T = wave_reduce<false>(local_T);
-    const int tpre = waves_exclusive_scan_16<false>(wave_T, INT32_MAX, wave_s);  // min bound over the events before this wave's range
+    const int tpre = wave_reduce<false>(before_T);  // min bound over the events before this wave's range
     // Can the loop end inside this wave's range at all?  The bound only falls, so the smallest bound of the range is the one after its
     // last event: no stop unless the last iteration of the range reaches it (wave-uniform; all but one wave skip the second sweep).
-    if (w0 < cnt && iter0 + min(cnt, w0 + R * 64) >= min(niters0, min(tpre, wave_T))) {
-        int carry = wpre, carry_T = tpre;
+    if (!ev_overflow && w0 < cnt && iter0 + min(cnt, w1) >= min(niters0, min(tpre, wave_T))) {
+        int carry_T = tpre;
         for (int r = 0; r < R; ++r) {
             const int i = w0 + r * 64 + lane;
-            const int inc = wave_inclusive_scan<true>(i < cnt ? hgood[i] : 0, lane);
-            const int running = max(carry, inc);
-            const int up = __shfl_up(inc, 1);
-            const int prev_running = lane ? max(carry, up) : carry;
-            int Tv = INT32_MAX;
-            if (i < cnt && running >= 5 && running > prev_running) Tv = bound_at(running);
+            int Tv = INT32_MAX;  // the bound of an event AT this iteration, from the list
+            for (int e = 0; e < nev; ++e)
+                if (ev_pos[e] == i) Tv = ev_val[e];
             Tv = wave_inclusive_scan<false>(Tv, lane);
             const bool stop_here = i < cnt && iter0 + i + 1 >= min(niters0, min(carry_T, Tv));
             if (__ballot(stop_here)) {  // wave-uniform: the first stopping lane of the first such row
                 if (stop_here) atomicMin(&stop_idx, i);
                 break;
             }
-            carry = max(carry, __shfl(inc, 63));
             carry_T = min(carry_T, __shfl(Tv, 63));
         }
     }
@@ -2082,6 +2147,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         // and always finds the next slice ready; up to 4096 hypotheses are one slice (two small solver launches would cost more than
         // the wait).
         const int point_splits = score_point_splits(n, cnt * 10, !lazy);
+        const int ev_cap = ctx->opt_ransac_event_cap > 0 ? std::min(ctx->opt_ransac_event_cap, kMaxScanEvents) : kMaxScanEvents;
         // Large passes: the root kernel of a slice goes to the helper stream, so it runs beside the elimination kernel of the next
         // slice (both are latency-bound at these sizes and leave most issue slots idle; unlike the counting kernel, which saturates
         // the vector units and gains nothing from company -- DESIGN section 5).
@@ -2121,7 +2187,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
                 hipLaunchKernelGGL(hyp_max_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, (const int32_t *)B.n_models,
                                    (const int32_t *)B.good, cnt, B.hgood);
             hipLaunchKernelGGL(candidate_kernel, dim3(1), dim3(1024), 0, s, (const int32_t *)B.n_models, (const int32_t *)B.good,
-                               sep ? (const int32_t *)B.hgood : (const int32_t *)nullptr, cnt, cur.maxGood, B.cand, B.cand_count);
+                               sep ? (const int32_t *)B.hgood : (const int32_t *)nullptr, cnt, cur.maxGood, B.cand, B.cand_count, ev_cap);
             hipLaunchKernelGGL((score_models_block_kernel<false, true>), dim3(256), dim3(256), (size_t)((n + 3) / 4 * 4) * sizeof(float), s,
                                (const double4 *)pts, n, (const double *)B.E_tab, (const int32_t *)nullptr, (const int32_t *)B.cand_count, 0,
                                thresh2, qmax, (int32_t *)nullptr, B.esum, (const int32_t *)B.cand);
@@ -2131,7 +2197,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
                            (const int32_t *)B.good, (const double *)B.esum, cnt, B.hgood, B.hsum, B.hslot);
         hipLaunchKernelGGL(replay_kernel, dim3(1), dim3(1024), 0, s, (const int32_t *)B.hgood, (const double *)B.hsum,
                            (const int32_t *)B.hslot, (const double *)B.E_tab, cnt, (const int32_t *)d_T, n, (long long)base * 10,
-                           (const int32_t *)B.total, d_st, confidence);
+                           (const int32_t *)B.total, d_st, confidence, ev_cap);
         MLPL_HIP_TRY(hipGetLastError());
         if (base + chunk_cap < max_iters) {  // more chunks may follow: the host needs niters / stop to size the next one
             MLPL_HIP_TRY(hipMemcpyAsync(h_st, d_st, sizeof(ReplayState), hipMemcpyDeviceToHost, s));

@@ -74,6 +74,24 @@ def test_ransac_more_iterations_than_one_default_pass(ctx, oracle, n, iters):
     assert_same_run(g, o, p1, p2, oracle, e_tol=1e-7)
 
 
+@pytest.mark.parametrize("cap", [1, 3])
+@pytest.mark.parametrize("conf,iters,host_table", [(0.999, 1000, 0), (1.0, 6000, 0), (0.999, 3000, 1)])
+def test_ransac_record_list_overflow_takes_the_serial_path(ctx, oracle, cap, conf, iters, host_table):
+    """The candidate / replay kernels note the record-breaking hypotheses of a pass in a 1024-entry list and expand them in parallel; with
+    more records than entries they fall back to expanding in place (candidates) and to a serial replay.  A list of 1 or 3 entries forces
+    those paths on ordinary data: the run must not change."""
+    p1, p2, R, t, mask, th = synth.pose_scene(2500, inlier_frac=0.45, seed=77)
+    want = oracle.ransac_essential(p1, p2, th, confidence=conf, max_iters=iters, lesqu=False, seed=9)
+    ctx.set_option("ransac_event_cap", cap)
+    ctx.set_option("ransac_host_table", host_table)
+    try:
+        g = pose.ransac_essential(p1, p2, th, confidence=conf, max_iters=iters, refit=False, seed=9, ctx=ctx)
+    finally:
+        ctx.set_option("ransac_event_cap", 0)
+        ctx.set_option("ransac_host_table", 0)
+    assert_same_run(g, want, p1, p2, oracle)
+
+
 def test_ransac_tiny_inlier_fraction_uses_every_iteration(ctx, oracle):
     """20 % inliers at the reference's settings: the adaptive bound stays above max_iters for a long time."""
     p1, p2, R, t, mask, th = synth.pose_scene(3000, inlier_frac=0.2, seed=99)
