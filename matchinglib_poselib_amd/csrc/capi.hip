@@ -184,7 +184,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "ransac_event_cap") && value >= 0 && value <= 1024) ctx->opt_ransac_event_cap = value;
     else if (!std::strcmp(name, "solver_polish") && (value == 0 || value == 1)) ctx->opt_solver_polish = value;
     else if (!std::strcmp(name, "ransac_host_table") && (value == 0 || value == 1)) ctx->opt_ransac_host_table = value;
-    else if (!std::strcmp(name, "ransac_chunk") && value >= 0 && value <= (1 << 20)) ctx->opt_ransac_chunk = value;
+    else if (!std::strcmp(name, "ransac_chunk") && value >= 0 && value <= 32768) ctx->opt_ransac_chunk = value;
     else {
         set_error("mlpl_set_option: unknown option or bad value: %s=%d", name, value);
         return MLPL_E_BAD_INPUT;

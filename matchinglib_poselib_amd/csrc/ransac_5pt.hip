@@ -1033,7 +1033,9 @@ __global__ void hyp_max_kernel(const int32_t *__restrict__ n_models, const int32
 // [w*R*64, (w+1)*R*64), R = ceil(cnt / 1024), and walks it in rows of 64 (lane = position in the row): loads are coalesced and
 // independent of the scan state, row scans are wave shuffles, and the 16 waves meet only once per phase to exchange one value each
 // (the chunk-per-step form of round 1 paid a global-load latency and up to three block barriers per 1024 hypotheses).
-constexpr int kScanBatch = 8;  // rows whose loads are in flight together
+constexpr int kScanRows = 32;  // rows of 64 per wave: a pass holds at most 16 * 32 * 64 = 32768 hypotheses (the driver's pass size cap).
+                               // A thread keeps its whole column in registers: every load of a scan is issued before the first use -- the
+                               // tables were written by kernels on other XCDs, a dependent batch of loads costs ~2 us each time
 constexpr int kMaxScanEvents = 1024;  // record / tie events of one pass that are expanded in parallel after the scan (one thread each)
 
 template <bool kMax>
@@ -1090,37 +1092,35 @@ __global__ __launch_bounds__(1024) void candidate_kernel(const int32_t *__restri
         for (int m = 0; m < nm0; ++m) h = max(h, good[(size_t)i * 10 + m]);
         return h;
     };
+    int hv[kScanRows];
+#pragma unroll
+    for (int r = 0; r < kScanRows; ++r) hv[r] = (r < R) ? hyp_max(w0 + r * 64 + lane) : 0;
     int local = 0;
-#pragma unroll 4
-    for (int r = 0; r < R; ++r) local = max(local, hyp_max(w0 + r * 64 + lane));
+#pragma unroll
+    for (int r = 0; r < kScanRows; ++r) local = max(local, hv[r]);
     int carry = waves_exclusive_scan_16<true>(wave_reduce<true>(local), carried_best, wave_s);  // best count before this wave's range
-
-    for (int r0 = 0; r0 < R; r0 += kScanBatch) {
-        int hv[kScanBatch];  // the loads of a batch of rows are issued together: one memory latency per batch, not per row
 #pragma unroll
-        for (int j = 0; j < kScanBatch; ++j) hv[j] = (r0 + j < R) ? hyp_max(w0 + (r0 + j) * 64 + lane) : 0;
-#pragma unroll
-        for (int j = 0; j < kScanBatch; ++j) {
-            if (r0 + j >= R) break;  // wave-uniform
-            const int i = w0 + (r0 + j) * 64 + lane;
-            const int hmax = hv[j];
-            const int inc = wave_inclusive_scan<true>(hmax, lane);
-            const int up = __shfl_up(inc, 1);
-            const int before = lane ? max(carry, up) : carry;  // best count of everything before hypothesis i
-            if (i < cnt && hmax >= 5 && hmax >= before) {
-                // a hypothesis that holds or ties the running best: a handful per pass.  They are only noted here and expanded below by
-                // one thread each -- inline, their dependent loads ran one after the other inside the wave that met most of them
-                const int e = atomicAdd(&ev_n, 1);
-                if (e < ev_cap) {
-                    ev_pos[e] = i;
-                    ev_val[e] = hmax;
-                } else {  // list full (never seen: it takes that many successive ties/records): expand in place
-                    const int nm = n_models[i];
-                    for (int m = 0; m < nm; ++m)
-                        if (good[(size_t)i * 10 + m] == hmax) cand[atomicAdd(cand_count, 1)] = i * 10 + m;
-                }
+    for (int r = 0; r < kScanRows; ++r) {
+        if (r < R) {  // wave-uniform (no break: the loop has to unroll fully for hv[] to stay in registers)
+        const int i = w0 + r * 64 + lane;
+        const int hmax = hv[r];
+        const int inc = wave_inclusive_scan<true>(hmax, lane);
+        const int up = __shfl_up(inc, 1);
+        const int before = lane ? max(carry, up) : carry;  // best count of everything before hypothesis i
+        if (i < cnt && hmax >= 5 && hmax >= before) {
+            // a hypothesis that holds or ties the running best: a handful per pass.  They are only noted here and expanded below by
+            // one thread each -- inline, their dependent loads ran one after the other inside the wave that met most of them
+            const int e = atomicAdd(&ev_n, 1);
+            if (e < ev_cap) {
+                ev_pos[e] = i;
+                ev_val[e] = hmax;
+            } else {  // list full (never seen: it takes that many successive ties/records): expand in place
+                const int nm = n_models[i];
+                for (int m = 0; m < nm; ++m)
+                    if (good[(size_t)i * 10 + m] == hmax) cand[atomicAdd(cand_count, 1)] = i * 10 + m;
             }
-            carry = max(carry, __shfl(inc, 63));
+        }
+        carry = max(carry, __shfl(inc, 63));
         }
     }
     __syncthreads();
@@ -1479,16 +1479,17 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
 // cvRANSACUpdateNumIters1 (modelest.cpp:86-109) with max_iters = "infinity", evaluated on the device.  The host recomputes
 // every value the replay used with glibc and falls back to a host-built table if one differs (device log/pow are not glibc's,
 // so a quotient within an ulp-scale distance of x.5 could round the other way; that has probability ~1e-8 per value).
-__device__ __forceinline__ int dev_num_iters(double p, int n, int g) {
-    p = fmin(fmax(p, 0.), 1.);
+// `log_num` = log(max(1 - p, DBL_MIN)) comes from the host (glibc's value, constant for the call); (1 - ep)^5 is four multiplications
+// here, not pow(): the device's pow() walks lookup tables in memory and a record-breaking count waited microseconds for it.  The
+// host's re-evaluation with the reference formula (update_num_iters) decides whether a device value is accepted.
+__device__ __forceinline__ int dev_num_iters(double log_num, int n, int g) {
     double ep = (double)(n - g) / n;
     ep = fmin(fmax(ep, 0.), 1.);
-    double num = fmax(1. - p, DBL_MIN);
-    double denom = 1. - pow(1. - ep, 5.0);
+    const double x = 1. - ep, x2 = x * x;
+    double denom = 1. - x2 * x2 * x;
     if (denom < DBL_MIN) return 0;
-    num = log(num);
     denom = log(denom);
-    return (denom >= 0 || -num >= (double)INT32_MAX * (-denom)) ? INT32_MAX : (int)round(num / denom);
+    return (denom >= 0 || -log_num >= (double)INT32_MAX * (-denom)) ? INT32_MAX : (int)round(log_num / denom);
 }
 
 // Per-hypothesis arg-max under (good desc, error sum asc, slot asc): the only model of a hypothesis that can ever be taken.
@@ -1518,7 +1519,7 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
                                                       const int32_t *__restrict__ hslot, const double *__restrict__ E_tab, int cnt,
                                                       const int32_t *__restrict__ Ttab, int npts, long long base_index,
                                                       const int32_t *__restrict__ dense_total, ReplayState *__restrict__ st,
-                                                      double confidence, int ev_cap) {
+                                                      double log_num, int ev_cap) {
     __shared__ int wave_s[16];
     __shared__ int stop_idx;
     __shared__ int ev_pos[kMaxScanEvents], ev_val[kMaxScanEvents], ev_n;
@@ -1537,12 +1538,15 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
     const int lane = tid & 63, wave = tid >> 6;
     const int R = (cnt + 1023) / 1024;
     const int w0 = wave * R * 64;
-    int local = 0;
-#pragma unroll 4
-    for (int r = 0; r < R; ++r) {
+    int hv[kScanRows];  // this thread's column of the pass: hypothesis w0 + r * 64 + lane in row r
+#pragma unroll
+    for (int r = 0; r < kScanRows; ++r) {
         const int i = w0 + r * 64 + lane;
-        local = max(local, i < cnt ? hgood[i] : 0);
+        hv[r] = (r < R && i < cnt) ? hgood[i] : 0;
     }
+    int local = 0;
+#pragma unroll
+    for (int r = 0; r < kScanRows; ++r) local = max(local, hv[r]);
     const int wpre = waves_exclusive_scan_16<true>(wave_reduce<true>(local), maxGood0, wave_s);  // running count before this wave's range
     // The bound after iteration i is min(niters0, T(running_i)).  T falls as the count rises and the running count never falls, so
     // T(running_i) = min over the record-breaking iterations j <= i of T(running_j): evaluate T only where the running count changes
@@ -1550,35 +1554,28 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
     // earlier passes is already inside niters0.
     auto bound_at = [&](int running) {
         const int g = min(running, npts);
-        return Ttab ? Ttab[g] : dev_num_iters(confidence, npts, g);
+        return Ttab ? Ttab[g] : dev_num_iters(log_num, npts, g);
     };
     // Sweep 1 only NOTES the record-breaking iterations (position, count); their bounds are then evaluated by one thread each (the fp64
     // pow + log of a bound is a few microseconds -- inline, the records of the first wave's range ran one after the other).
     {
         int carry = wpre;
-        for (int r0 = 0; r0 < R; r0 += kScanBatch) {
-            int hv[kScanBatch];
 #pragma unroll
-            for (int j = 0; j < kScanBatch; ++j) {
-                const int i = w0 + (r0 + j) * 64 + lane;
-                hv[j] = (r0 + j < R && i < cnt) ? hgood[i] : 0;
-            }
-#pragma unroll
-            for (int j = 0; j < kScanBatch; ++j) {
-                if (r0 + j >= R) break;  // wave-uniform
-                const int i = w0 + (r0 + j) * 64 + lane;
-                const int inc = wave_inclusive_scan<true>(hv[j], lane);
-                const int running = max(carry, inc);
-                const int up = __shfl_up(inc, 1);
-                const int prev_running = lane ? max(carry, up) : carry;  // running count before this iteration
-                if (i < cnt && running >= 5 && running > prev_running) {
-                    const int e = atomicAdd(&ev_n, 1);
-                    if (e < ev_cap) {
-                        ev_pos[e] = i;
-                        ev_val[e] = running;
-                    }
+        for (int r = 0; r < kScanRows; ++r) {
+            if (r < R) {  // wave-uniform
+            const int i = w0 + r * 64 + lane;
+            const int inc = wave_inclusive_scan<true>(hv[r], lane);
+            const int running = max(carry, inc);
+            const int up = __shfl_up(inc, 1);
+            const int prev_running = lane ? max(carry, up) : carry;  // running count before this iteration
+            if (i < cnt && running >= 5 && running > prev_running) {
+                const int e = atomicAdd(&ev_n, 1);
+                if (e < ev_cap) {
+                    ev_pos[e] = i;
+                    ev_val[e] = running;
                 }
-                carry = max(carry, __shfl(inc, 63));
+            }
+            carry = max(carry, __shfl(inc, 63));
             }
         }
     }
@@ -1656,20 +1653,19 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
     // pass 2: arg-max over the processed iterations (good desc, sum asc, earlier first), only counts >= 5 qualify
     int bg = 0, bi = -1;
     double bs = 0;
-    for (int i0 = tid; i0 < processed; i0 += 1024 * kScanBatch) {
-        int gv[kScanBatch];
-        double ev[kScanBatch];
 #pragma unroll
-        for (int j = 0; j < kScanBatch; ++j) {  // unconditional loads, all in flight together
-            const int i = i0 + 1024 * j;
-            gv[j] = i < processed ? hgood[i] : 0;
-            ev[j] = i < processed ? hsum[i] : 0.0;
+    for (int half = 0; half < 2; ++half) {  // two batches of 16 rows: the register budget of a 1024-thread block is 128
+        double ev[kScanRows / 2];
+#pragma unroll
+        for (int q = 0; q < kScanRows / 2; ++q) {  // the error sums of this thread's column, the loads of a batch in flight together
+            const int r = half * (kScanRows / 2) + q, i = w0 + r * 64 + lane;
+            ev[q] = (r < R && i < processed && hv[r] >= 5) ? hsum[i] : 0.0;
         }
 #pragma unroll
-        for (int j = 0; j < kScanBatch; ++j) {
-            const int i = i0 + 1024 * j, g = gv[j];
-            const double e = ev[j];
-            if (i < processed && g >= 5 && (bi < 0 || g > bg || (g == bg && e < bs))) {  // i increases per thread: strict comparisons keep the earlier one
+        for (int q = 0; q < kScanRows / 2; ++q) {
+            const int r = half * (kScanRows / 2) + q, i = w0 + r * 64 + lane, g = hv[r];
+            const double e = ev[q];
+            if (r < R && i < processed && g >= 5 && (bi < 0 || g > bg || (g == bg && e < bs))) {  // i increases with r: strict comparisons keep the earlier one
                 bg = g;
                 bs = e;
                 bi = i;
@@ -1710,7 +1706,7 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
         }
         st->maxGood = newMax;
         // newMax is a count pass 1 (or an earlier chunk) has already evaluated and recorded
-        const int nit = (newMax >= 5) ? min(niters0, Ttab ? Ttab[min(newMax, npts)] : dev_num_iters(confidence, npts, min(newMax, npts)))
+        const int nit = (newMax >= 5) ? min(niters0, Ttab ? Ttab[min(newMax, npts)] : dev_num_iters(log_num, npts, min(newMax, npts)))
                                       : niters0;
         st->niters = nit;
         st->iter = iter0 + processed;
@@ -2133,6 +2129,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     GlibcRand rng;
     rng.seed(seed);
     const FastMod fmod_n(n);
+    const double log_num = std::log(std::max(1. - std::min(std::max(confidence, 0.), 1.), DBL_MIN));  // update_num_iters' numerator
     ReplayState cur = init;
     for (int base = 0; base < max_iters; base += chunk_cap) {
         const int cnt = std::min(chunk_cap, std::min(max_iters, cur.niters) - base);
@@ -2197,7 +2194,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
                            (const int32_t *)B.good, (const double *)B.esum, cnt, B.hgood, B.hsum, B.hslot);
         hipLaunchKernelGGL(replay_kernel, dim3(1), dim3(1024), 0, s, (const int32_t *)B.hgood, (const double *)B.hsum,
                            (const int32_t *)B.hslot, (const double *)B.E_tab, cnt, (const int32_t *)d_T, n, (long long)base * 10,
-                           (const int32_t *)B.total, d_st, confidence, ev_cap);
+                           (const int32_t *)B.total, d_st, log_num, ev_cap);
         MLPL_HIP_TRY(hipGetLastError());
         if (base + chunk_cap < max_iters) {  // more chunks may follow: the host needs niters / stop to size the next one
             MLPL_HIP_TRY(hipMemcpyAsync(h_st, d_st, sizeof(ReplayState), hipMemcpyDeviceToHost, s));
