@@ -885,14 +885,15 @@ __device__ __forceinline__ double model_band(const double *e, double qmax) {
 constexpr int kScoreThreads = 512;
 constexpr int kScoreModels = kScoreThreads / 4;
 constexpr int kScoreTile = 512;
-constexpr int kScoreThreadsSmall = 128;  // count-only passes of a few thousand models: 32 models per workgroup, one tile each
-template <bool SUMS, int kThreads = kScoreThreads>
+constexpr int kScoreThreadsSmall = 128;  // count-only passes of a few thousand models: 32 models per workgroup, one 256-point tile each
+constexpr int kScoreTileSmall = 256;
+template <bool SUMS, int kThreads = kScoreThreads, int kTile = kScoreTile>
 __global__ __launch_bounds__(kThreads) void score_models_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
                                                            const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
                                                            int total_host, double thresh2, double qmax, int32_t *__restrict__ good,
                                                            double *__restrict__ esum) {
-    __shared__ double4 tile[kScoreTile];
-    __shared__ double tile_mag[SUMS ? 1 : kScoreTile];
+    __shared__ double4 tile[kTile];
+    __shared__ double tile_mag[SUMS ? 1 : kTile];
     const double *__restrict__ pmag = reinterpret_cast<const double *>(pts + n);
     const int total = total_ptr ? *total_ptr : total_host;
     if (blockIdx.x * (kThreads / 4) >= total) return;  // block-uniform
@@ -908,8 +909,8 @@ __global__ __launch_bounds__(kThreads) void score_models_kernel(const double4 *_
     double s = 0.0;
     // gridDim.y > 1 (count-only form): the tiles are dealt round-robin to gridDim.y workgroups per model group, which add their
     // counts into a zeroed table -- units a fifth the size even out the load over the CUs without re-reading any correspondence
-    for (int base = blockIdx.y * kScoreTile; base < n; base += kScoreTile * gridDim.y) {
-        const int rows = min(kScoreTile, n - base);
+    for (int base = blockIdx.y * kTile; base < n; base += kTile * gridDim.y) {
+        const int rows = min(kTile, n - base);
         __syncthreads();
         for (int i = tid; i < rows; i += kThreads) {
             tile[i] = pts[base + i];
@@ -1862,7 +1863,7 @@ static void launch_score(hipStream_t s, const double4 *pts, int n, const double 
         hipLaunchKernelGGL((score_models_block_kernel<true, false>), dim3(max_models), dim3(256), 0, s, pts, n, E_list, ids, total_ptr,
                            total_host, thresh2, qmax, good, esum, (const int32_t *)nullptr);
     } else if (max_models <= kScoreBlockMaxModels) {
-        hipLaunchKernelGGL((score_models_kernel<false, kScoreThreadsSmall>), dim3((max_models + kScoreThreadsSmall / 4 - 1) / (kScoreThreadsSmall / 4), point_splits),
+        hipLaunchKernelGGL((score_models_kernel<false, kScoreThreadsSmall, kScoreTileSmall>), dim3((max_models + kScoreThreadsSmall / 4 - 1) / (kScoreThreadsSmall / 4), point_splits),
                            dim3(kScoreThreadsSmall), 0, s, pts, n, E_list, ids, total_ptr, total_host, thresh2, qmax, good, esum);
     } else {
         hipLaunchKernelGGL((score_models_kernel<false, kScoreThreads>), dim3((max_models + kScoreModels - 1) / kScoreModels, point_splits), dim3(kScoreThreads), 0,
@@ -1876,7 +1877,8 @@ static void launch_score(hipStream_t s, const double4 *pts, int n, const double 
 static int score_point_splits(int n, int max_models, bool sums) {
     if (sums) return 1;
     const int ntiles = (n + kScoreTile - 1) / kScoreTile;
-    if (max_models <= kScoreBlockMaxModels) return std::max(1, std::min(16, ntiles));  // small passes: one tile per workgroup
+    if (max_models <= kScoreBlockMaxModels)  // small passes: one 256-point tile per workgroup (occupancy is what hides the LDS latency)
+        return std::max(1, std::min(32, (n + kScoreTileSmall - 1) / kScoreTileSmall));
     return std::max(1, std::min(8, ntiles / 2));
 }
 
