@@ -118,6 +118,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_hamming_mfma_prio = 0;
     ctx->opt_ransac_lazy_sums = 1;
     ctx->opt_ransac_overlap = 1;
+    ctx->opt_ransac_f32_filter = 1;
     ctx->opt_solver_polish = 1;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -181,6 +182,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "hamming_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_blocks_per_cu = value;
     else if (!std::strcmp(name, "ransac_lazy_sums") && (value == 0 || value == 1)) ctx->opt_ransac_lazy_sums = value;
     else if (!std::strcmp(name, "ransac_overlap") && (value == 0 || value == 1)) ctx->opt_ransac_overlap = value;
+    else if (!std::strcmp(name, "ransac_f32_filter") && (value == 0 || value == 1)) ctx->opt_ransac_f32_filter = value;
     else if (!std::strcmp(name, "ransac_event_cap") && value >= 0 && value <= 1024) ctx->opt_ransac_event_cap = value;
     else if (!std::strcmp(name, "solver_polish") && (value == 0 || value == 1)) ctx->opt_solver_polish = value;
     else if (!std::strcmp(name, "ransac_host_table") && (value == 0 || value == 1)) ctx->opt_ransac_host_table = value;

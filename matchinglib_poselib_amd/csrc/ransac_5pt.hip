@@ -787,7 +787,15 @@ __global__ void pack_points_kernel(const double *__restrict__ p1, const double *
         const double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
         pts[i] = make_double4(x1, y1, x2, y2);
         const double P1 = fabs(x1) + fabs(y1) + 1.0, P2 = fabs(x2) + fabs(y2) + 1.0, pmag = P1 * P2;
-        reinterpret_cast<double *>(pts + n)[i] = 1.001 * pmag * (pmag + 1.0 + (P1 * P1 + P2 * P2));  // kp of sampson_inlier_fma
+        const double kp = 1.001 * pmag * (pmag + 1.0 + (P1 * P1 + P2 * P2));
+        reinterpret_cast<double *>(pts + n)[i] = kp;  // kp of sampson_inlier_fma
+        // single-precision copy for the fp32 pre-filter of the counting kernels (count_models_f32_kernel): the coordinates rounded to
+        // float and the per-point factor KPs of its error band, rounded up; +inf switches the filter off for a point that is out of range
+        float *f = reinterpret_cast<float *>(reinterpret_cast<double *>(pts + n) + n) + (size_t)i * 5;
+        const double Pm = fmax(P1, P2);
+        const double kps = 1.01 * (pmag * pmag + Pm * Pm + kp);
+        f[0] = (float)x1, f[1] = (float)y1, f[2] = (float)x2, f[3] = (float)y2;
+        f[4] = (pmag <= 0x1p40 && kps < 0x1p120) ? (float)kps * (1.0f + 0x1p-22f) : INFINITY;
     }
 }
 
@@ -941,6 +949,122 @@ __global__ __launch_bounds__(kThreads) void score_models_kernel(const double4 *_
         if (gridDim.y > 1) atomicAdd(&good[o], cnt);
         else good[o] = cnt;
         if constexpr (SUMS) esum[o] = __dadd_rn(__dadd_rn(s0, s2), __dadd_rn(s1, s3));
+    }
+}
+
+
+// ---- count-only scoring with an fp32 pre-filter -------------------------------------------------------------------------------------
+// The inlier predicate N <= qmax D is first evaluated in single precision on packed operations (v_pk_fma_f32: two correspondences per
+// instruction) and accepted only outside a rigorous error band; the (few) evaluations inside the band -- and any point or model whose
+// scale is out of range -- re-run the fp64 predicate (sampson_inlier_fma, itself exact by construction).  Same counts as every other
+// scoring kernel.
+//
+// Error analysis (u = 2^-24; s, N, D, p the exact values on the double inputs; *32 the fp32 results from float-rounded inputs by FMAs):
+//   |s32 - s| <= 8u T,  T = sum |e_ij x2_i x1_j| <= emax pmag   (three input roundings + four FMA roundings per term)   =: ds
+//   |N32 - N| <= ds (2 |s32| + ds) + 1.01u N32 <= (2^-6 + 3u) N32 + 65 ds^2                       (2ab <= 2^-6 a^2 + 2^6 b^2)
+//   every component q of D: |q32 - q| <= 5u emax Pmax =: dq;   |D32 - D| <= 4 dq sqrt(D32) + 4 dq^2 + 4.1u D32
+//                                                                <= 15u D32 + 10.1u emax^2 Pmax^2      (2 sqrt(z) <= c + z/c, c = emax Pmax)
+//   |p32 - p| <= 18u p32 + 10.2u qmax emax^2 Pmax^2                                               (p32 = fl(fl(qmax) D32))
+// and the fp64 predicate is certain, with the sign of N - p, once |N - p| exceeds its own band km kp + 2^-46 max(N, p).  Hence
+//   |N32 - p32| > H := KMs KPs + 2^-6 * 1.02 (N32 + p32),
+//   KMs = 1.01 max(65 (8.01u emax)^2, 10.2u qmax emax^2, km)   per model,     KPs = 1.01 (pmag^2 + Pmax^2 + kp)   per point
+// decides with the sign of N32 - p32.  Ranges: emax in [2^-40, 2^20], qmax in [2^-60, 1], pmag <= 2^40 keep every intermediate inside the
+// normal float range or make its underflow error negligible against KMs KPs (>= 2^-116); outside them KMs / KPs is +inf, an overflow
+// makes N32 + p32 infinite: H = +inf or NaN and the comparison fails -> fp64 path.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int kThreads, int kTile>
+__global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
+                                                                    const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
+                                                                    int total_host, double thresh2, double qmax, int32_t *__restrict__ good) {
+    // pair layout: the two consecutive correspondences of a lane class (j = i & 3) sit side by side, so a lane reads its pair's
+    // (x1a,x1b, y1a,y1b, x2a,x2b, y2a,y2b) with two ds_read_b128 and (KPs_a, KPs_b) with one ds_read_b64
+    __shared__ __attribute__((aligned(16))) float tile_xy[(kTile / 2) * 8];
+    __shared__ __attribute__((aligned(8))) float tile_k[(kTile / 2) * 2];
+    const double *__restrict__ kp64 = reinterpret_cast<const double *>(pts + n);
+    const float *__restrict__ rec = reinterpret_cast<const float *>(kp64 + n);
+    const int total = total_ptr ? *total_ptr : total_host;
+    if (blockIdx.x * (kThreads / 4) >= total) return;  // block-uniform
+    const int tid = threadIdx.x;
+    const int j = tid & 3;
+    const int m = blockIdx.x * (kThreads / 4) + (tid >> 2);
+    const bool live = m < total;
+    double e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = live ? E_list[(size_t)m * 9 + k] : 0.0;
+    const double km = model_band(e, qmax);
+    double emax = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) emax = fmax(emax, fabs(e[k]));
+    const double u = 0x1p-24;
+    const double kms64 = 1.01 * fmax(fmax(65.0 * (8.01 * u * emax) * (8.01 * u * emax), 10.2 * u * qmax * emax * emax), km);
+    const bool in_range = emax >= 0x1p-40 && emax <= 0x1p20 && qmax >= 0x1p-60 && qmax <= 1.0 && km == km;
+    const float kms = in_range ? (float)kms64 * (1.0f + 0x1p-22f) : INFINITY;
+    f32x2 E[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) E[k] = f32x2{(float)e[k], (float)e[k]};
+    const f32x2 Q = {(float)qmax, (float)qmax}, KM = {kms, kms}, C6 = {0x1p-6f * 1.02f, 0x1p-6f * 1.02f};
+    int cnt = 0;
+    for (int base = blockIdx.y * kTile; base < n; base += kTile * gridDim.y) {
+        const int rows = min(kTile, n - base);
+        __syncthreads();
+        for (int i = tid; i < rows; i += kThreads) {
+            const float *r = rec + (size_t)(base + i) * 5;
+            const int k = i >> 2, slot = ((k >> 1) * 4 + (i & 3)), half = k & 1;
+            float *xy = tile_xy + slot * 8 + half;
+            xy[0] = r[0], xy[2] = r[1], xy[4] = r[2], xy[6] = r[3];
+            tile_k[slot * 2 + half] = r[4];
+        }
+        __syncthreads();
+        if (live) {
+            const int nk = (rows - j + 3) >> 2;  // correspondences of this lane's class in the tile: i = 4k + j, k < nk
+            const int npairs = nk >> 1;
+#pragma unroll 2
+            for (int q = 0; q < npairs; ++q) {
+                const int slot = q * 4 + j;
+                const float4 v0 = *reinterpret_cast<const float4 *>(tile_xy + slot * 8);
+                const float4 v1 = *reinterpret_cast<const float4 *>(tile_xy + slot * 8 + 4);
+                const float2 kk = *reinterpret_cast<const float2 *>(tile_k + slot * 2);
+                const f32x2 X1 = {v0.x, v0.y}, Y1 = {v0.z, v0.w}, X2 = {v1.x, v1.y}, Y2 = {v1.z, v1.w}, KP = {kk.x, kk.y};
+                const f32x2 A = __builtin_elementwise_fma(E[0], X1, __builtin_elementwise_fma(E[1], Y1, E[2]));
+                const f32x2 B = __builtin_elementwise_fma(E[3], X1, __builtin_elementwise_fma(E[4], Y1, E[5]));
+                const f32x2 C = __builtin_elementwise_fma(E[6], X1, __builtin_elementwise_fma(E[7], Y1, E[8]));
+                const f32x2 S = __builtin_elementwise_fma(X2, A, __builtin_elementwise_fma(Y2, B, C));
+                const f32x2 A2 = __builtin_elementwise_fma(E[0], X2, __builtin_elementwise_fma(E[3], Y2, E[6]));
+                const f32x2 B2 = __builtin_elementwise_fma(E[1], X2, __builtin_elementwise_fma(E[4], Y2, E[7]));
+                const f32x2 D = __builtin_elementwise_fma(A, A, __builtin_elementwise_fma(B, B, __builtin_elementwise_fma(A2, A2, B2 * B2)));
+                const f32x2 N = S * S;
+                const f32x2 P = Q * D;
+                const f32x2 H = __builtin_elementwise_fma(C6, N + P, KM * KP);
+                const f32x2 diff = N - P;
+                const bool c0 = fabsf(diff.x) > H.x, c1 = fabsf(diff.y) > H.y;  // false for NaN / inf bands
+                cnt += (c0 && diff.x < 0.f) ? 1 : 0;
+                cnt += (c1 && diff.y < 0.f) ? 1 : 0;
+                if (__builtin_expect(!(c0 && c1), 0)) {  // inside the band (or out of range): the fp64 predicate decides
+                    const int i0 = base + 4 * (2 * q) + j, i1 = i0 + 4;
+                    if (!c0) {
+                        const double4 p = pts[i0];
+                        cnt += sampson_inlier_fma(e, km, p.x, p.y, p.z, p.w, kp64[i0], qmax, thresh2) ? 1 : 0;
+                    }
+                    if (!c1) {
+                        const double4 p = pts[i1];
+                        cnt += sampson_inlier_fma(e, km, p.x, p.y, p.z, p.w, kp64[i1], qmax, thresh2) ? 1 : 0;
+                    }
+                }
+            }
+            if (nk & 1) {  // the unpaired last correspondence of the class: fp64
+                const int i0 = base + 4 * (nk - 1) + j;
+                const double4 p = pts[i0];
+                cnt += sampson_inlier_fma(e, km, p.x, p.y, p.z, p.w, kp64[i0], qmax, thresh2) ? 1 : 0;
+            }
+        }
+    }
+    cnt += __shfl_xor(cnt, 1);
+    cnt += __shfl_xor(cnt, 2);
+    if (live && j == 0) {
+        const int o = ids ? ids[m] : m;
+        if (gridDim.y > 1) atomicAdd(&good[o], cnt);
+        else good[o] = cnt;
     }
 }
 
@@ -1848,7 +1972,7 @@ double inlier_bound(double thresh2) {
 constexpr int kScoreBlockMaxModels = 24576;
 static void launch_score(hipStream_t s, const double4 *pts, int n, const double *E_list, const int32_t *ids, const int32_t *total_ptr,
                          int total_host, int max_models, double thresh2, int32_t *good, double *esum, bool sums = true,
-                         double qmax = -1.0, int point_splits = 1) {
+                         double qmax = -1.0, int point_splits = 1, bool f32_filter = false) {
     if (max_models <= 0) return;
     const size_t lds = (size_t)((n + 3) / 4 * 4) * sizeof(float);
     const bool block = n <= kScoreBlockMaxN && max_models <= kScoreBlockMaxModels;
@@ -1863,11 +1987,21 @@ static void launch_score(hipStream_t s, const double4 *pts, int n, const double 
         hipLaunchKernelGGL((score_models_block_kernel<true, false>), dim3(max_models), dim3(256), 0, s, pts, n, E_list, ids, total_ptr,
                            total_host, thresh2, qmax, good, esum, (const int32_t *)nullptr);
     } else if (max_models <= kScoreBlockMaxModels) {
-        hipLaunchKernelGGL((score_models_kernel<false, kScoreThreadsSmall, kScoreTileSmall>), dim3((max_models + kScoreThreadsSmall / 4 - 1) / (kScoreThreadsSmall / 4), point_splits),
-                           dim3(kScoreThreadsSmall), 0, s, pts, n, E_list, ids, total_ptr, total_host, thresh2, qmax, good, esum);
+        const dim3 grid((max_models + kScoreThreadsSmall / 4 - 1) / (kScoreThreadsSmall / 4), point_splits);
+        if (f32_filter)
+            hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreadsSmall, kScoreTileSmall>), grid, dim3(kScoreThreadsSmall), 0, s, pts, n, E_list, ids,
+                               total_ptr, total_host, thresh2, qmax, good);
+        else
+            hipLaunchKernelGGL((score_models_kernel<false, kScoreThreadsSmall, kScoreTileSmall>), grid, dim3(kScoreThreadsSmall), 0, s, pts, n, E_list,
+                               ids, total_ptr, total_host, thresh2, qmax, good, esum);
     } else {
-        hipLaunchKernelGGL((score_models_kernel<false, kScoreThreads>), dim3((max_models + kScoreModels - 1) / kScoreModels, point_splits), dim3(kScoreThreads), 0,
-                           s, pts, n, E_list, ids, total_ptr, total_host, thresh2, qmax, good, esum);
+        const dim3 grid((max_models + kScoreModels - 1) / kScoreModels, point_splits);
+        if (f32_filter)
+            hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile>), grid, dim3(kScoreThreads), 0, s, pts, n, E_list, ids, total_ptr,
+                               total_host, thresh2, qmax, good);
+        else
+            hipLaunchKernelGGL((score_models_kernel<false, kScoreThreads>), grid, dim3(kScoreThreads), 0, s, pts, n, E_list, ids, total_ptr,
+                               total_host, thresh2, qmax, good, esum);
     }
 }
 
@@ -1885,7 +2019,7 @@ static int score_point_splits(int n, int max_models, bool sums) {
 static int pack_points(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double4 **d_pts, hipStream_t s,
                        ReplayState *d_st = nullptr, int niters = 0, int32_t *zero_ints = nullptr, int n_zero = 0) {
     void *buf = nullptr;
-    int rc = ws_get(ctx, WS_AUX3, (size_t)n * (sizeof(double4) + sizeof(double)), &buf);  // points, then kp[n]
+    int rc = ws_get(ctx, WS_AUX3, (size_t)n * (sizeof(double4) + sizeof(double) + 5 * sizeof(float)), &buf);  // points, kp[n], float records
     if (rc) return rc;
     hipLaunchKernelGGL(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_p1, d_p2, n, (double4 *)buf, d_st, niters, zero_ints,
                        n_zero);
@@ -2020,7 +2154,11 @@ static int score_models_impl(mlpl_ctx *ctx, const double *p1, const double *p2, 
     if ((rc = pack_points(ctx, (const double *)dp1, (const double *)dp2, n, &pts, s))) return rc;
     prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
     const double qmax = inlier_bound(thresh2);
-    if (shape == 1 && !err_sum)
+    if (shape == 1 && !err_sum && ctx->opt_ransac_f32_filter)
+        hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile>), dim3((n_models + kScoreModels - 1) / kScoreModels), dim3(kScoreThreads), 0, s,
+                           (const double4 *)pts, n, (const double *)dE, (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, thresh2, qmax,
+                           (int32_t *)dgood);
+    else if (shape == 1 && !err_sum)
         hipLaunchKernelGGL(score_models_kernel<false>, dim3((n_models + kScoreModels - 1) / kScoreModels), dim3(kScoreThreads), 0, s, (const double4 *)pts, n,
                            (const double *)dE, (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, thresh2, qmax,
                            (int32_t *)dgood, (double *)dsum);
@@ -2178,7 +2316,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         }
         prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
         launch_score(s, (const double4 *)pts, n, (const double *)B.dense_E, (const int32_t *)B.dense_id, (const int32_t *)B.total, 0,
-                     cnt * 10, thresh2, B.good, B.esum, !lazy, qmax, point_splits);
+                     cnt * 10, thresh2, B.good, B.esum, !lazy, qmax, point_splits, ctx->opt_ransac_f32_filter != 0);
         if (lazy) {
             // error sums only for the models that can still win (ties on the inlier count are decided by them)
             const bool sep = cnt > 2048;  // many hypotheses: per-hypothesis maxima in a grid-wide pass first
