@@ -325,6 +325,51 @@ def test_division_free_inlier_count_is_the_reference_predicate(ctx, oracle, shap
     assert (neg == 0).all()
 
 
+@pytest.mark.parametrize("scale,escale", [(1.0, 1.0), (800.0, 1.0), (1e-3, 1.0), (1.0, 1e-9), (3e5, 1e6), (1e13, 1.0), (1.0, 1e-45), (1e-30, 1e30)])
+def test_fp32_prefilter_counts_at_every_scale(ctx, oracle, scale, escale):
+    """The packed-fp32 pre-filter of the count-only kernels must never change a count: camera units, pixel units (x ~ 10^3), tiny and
+    huge coordinates, unnormalised models, and scales at which it has to switch itself off (float overflow / underflow of the inputs).
+    Compared with the same kernel with the filter off (pure fp64 predicate) and with the dividing reference arithmetic on the CPU."""
+    p1, p2, R, t, mask, th = synth.pose_scene(2600, seed=123)
+    samples = oracle.sample_table(7, p1, p2, 10)
+    Es = np.concatenate([oracle.run5point(p1[s], p2[s]) for s in samples])[:20] * escale
+    # scaling both images by c multiplies the Sampson error by c^2 when E stays fixed only for the bilinear part; simply rescale the
+    # data and re-derive the expected counts from the CPU arithmetic on the rescaled inputs
+    q1, q2 = p1 * scale, p2 * scale
+    ref_err = np.stack([oracle.sampson_err(q1, q2, E).astype(np.float64) for E in Es])
+    finite = np.isfinite(ref_err)
+    for frac in (0.1, 0.5, 0.9):
+        t2 = float(np.quantile(ref_err[finite], frac)) if finite.any() else 1.0
+        if not (t2 > 0 and np.isfinite(t2)):
+            continue
+        want = (ref_err <= t2).sum(axis=1)
+        got = {}
+        for f in (1, 0):
+            ctx.set_option("ransac_f32_filter", f)
+            try:
+                got[f] = pose.count_models(q1, q2, Es, t2, shape=1, ctx=ctx)
+            finally:
+                ctx.set_option("ransac_f32_filter", 1)
+        assert np.array_equal(got[1], got[0]), (scale, escale, frac, np.nonzero(got[1] != got[0])[0][:5])
+        assert np.array_equal(got[1], want), (scale, escale, frac, got[1][:5], want[:5])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_ransac_with_and_without_the_fp32_prefilter(ctx, oracle, seed):
+    p1, p2, R, t, mask, th = synth.pose_scene(4000, inlier_frac=0.35, seed=900 + seed)
+    runs = []
+    for f in (1, 0):
+        ctx.set_option("ransac_f32_filter", f)
+        try:
+            runs.append(pose.ransac_essential(p1, p2, th, confidence=0.999, max_iters=6000, refit=False, seed=seed, ctx=ctx))
+        finally:
+            ctx.set_option("ransac_f32_filter", 1)
+    a, b = runs
+    assert a["iters"] == b["iters"] and a["n_inliers"] == b["n_inliers"] and np.array_equal(a["E"], b["E"]) and np.array_equal(a["mask"], b["mask"])
+    o = oracle.ransac_essential(p1, p2, th, confidence=0.999, max_iters=6000, lesqu=False, seed=seed)
+    assert a["iters"] == o["iters"] and a["n_inliers"] == o["n_inliers"] and np.array_equal(a["mask"], o["mask"])
+
+
 @pytest.mark.parametrize("n,chunk", [(5000, 0), (300, 0), (40, 0), (7, 0), (2000, 100)])
 def test_ransac_lazy_error_sums_equal_full_sums(ctx, oracle, n, chunk):
     """Counting without the division and summing errors only for the models that can still win must not change anything: same
