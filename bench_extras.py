@@ -65,11 +65,16 @@ def run(ctx, dev, cpu_baseline=True):
         "solve_kernels_ms_per_call": solve_ms,
         "score_kernel_ms_per_call": score_ms,
         "models_scored": models,
-        "score_roofline": {"bound": "fp64-valu", "achieved": 39.0 * n * models / (score_ms * 1e-3) / 1e12,
-                           "peak": FP64_VALU_PEAK / 1e12, "unit": "TFLOP/s",
+        "score_roofline": {"bound": "valu (packed fp32 pre-filter + fp64 predicate inside its error band)",
+                           "achieved": 39.0 * n * models / (score_ms * 1e-3) / 1e12,
+                           "peak": FP64_VALU_PEAK / 1e12, "unit": "TFLOP/s (fp64-equivalent)",
                            "frac": 39.0 * n * models / (score_ms * 1e-3) / FP64_VALU_PEAK,
                            "note": "39 fp64 FLOP per (model, correspondence) (SURVEY 8(d)) over the scoring pass of the call (count-only "
-                                   "kernel without the division + candidate selection + error sums of the candidates)"},
+                                   "kernel + candidate selection + error sums of the candidates), priced against the fp64 vector peak. "
+                                   "Since round 2 the counting kernel decides most evaluations in packed single precision (two per "
+                                   "instruction) inside a rigorous error band and runs the fp64 predicate only inside the band -- same "
+                                   "counts -- so the fp64-equivalent rate can exceed what an all-fp64 kernel could reach; the fp64-only "
+                                   "kernel (option ransac_f32_filter=0) sits at 0.52 of that peak"},
         "includes": "host sample table (glibc rand stream, pinned/mapped), solve + score + replay + mask kernels, one 200-byte "
                     "state readback",
     }

@@ -59,17 +59,25 @@ void *mlpl_ctx_stream(mlpl_ctx *ctx);
 int mlpl_ctx_device(mlpl_ctx *ctx);
 int mlpl_ctx_synchronize(mlpl_ctx *ctx);
 
-/* Tuning knobs (performance only, never results): "hamming_variant" 3 = fp4 matrix-core kernel (default; descriptors above
- * 64 bytes fall back to 0), 0 = LDS-tiled VALU kernel, 1 = scalar-operand VALU kernel, 2 = one-wave-per-block VALU kernel;
- * "hamming_mfma_blocks_per_cu" (default 3) and "hamming_mfma_qt" (query tiles per wave, 0 = automatic) size the matrix-core
- * grid; "hamming_qpl" queries per lane 1|2 and "hamming_blocks_per_cu" size the VALU grids; "ransac_chunk" hypotheses per
- * device pass (0 = 32768; the sequential best/niters rule is replayed across passes); "ransac_lazy_sums" (default 1) = the RANSAC passes count inliers
- * without the division and compute error sums only for the models that can still win, 0 = sums for every model;
- * "solver_polish" (default 1) = every 5-point solution is polished by Gauss-Newton on the ten cubic constraints (0 = the plain
- * elimination + root path, which is off by up to 1e-5 on the ~0.5 % of samples whose eliminated block is ill conditioned);
- * "ransac_host_table" 1 = build the
- * iteration-bound table T[g] on the host for every call (default 0: the device evaluates the few bounds it needs and the host
- * verifies exactly those against its libm, falling back to the table when one differs). */
+/* Tuning knobs (performance only, never results -- except "solver_polish", see below):
+ *   Hamming: "hamming_variant" 3 = fp4 matrix-core kernels (default; descriptors above 64 bytes fall back to 0), 0 = LDS-tiled VALU
+ *     kernel, 1 = scalar-operand VALU kernel, 2 = one-wave-per-block VALU kernel; "hamming_mfma_lds" 1 (default) = LDS-ring kernel for
+ *     32-byte descriptors, 0 = register-prefetch kernel, 2 = dynamic train splits; "hamming_mfma_weighted" (default 1) = age-aware split
+ *     sizes; "hamming_mfma_prio" 0|1|2 (diagnostics); "hamming_mfma_blocks_per_cu" and "hamming_mfma_qt" (query tiles per wave,
+ *     0 = automatic) size the matrix-core grid; "hamming_qpl" queries per lane 1|2 and "hamming_blocks_per_cu" size the VALU grids;
+ *     "hamming_stamps" 1 = per-wave / per-workgroup clock stamps (mlpl_debug_hamming_stamps).
+ *   L2: "l2_mfma_waves" 0|4|8 and "l2_mfma_blocks_per_cu" shape the int8 matrix-core kernel of the forced mode (see mlpl_set_l2_path).
+ *   RANSAC: "ransac_chunk" hypotheses per device pass (0 = 32768 = the maximum; the sequential best/niters rule is replayed across
+ *     passes); "ransac_lazy_sums" (default 1) = the passes count inliers without the division and compute error sums only for the
+ *     models that can still win, 0 = sums for every model; "ransac_f32_filter" (default 1) = the counting kernels decide in packed single
+ *     precision outside a rigorous error band and in fp64 inside it (same counts), 0 = fp64 only; "ransac_overlap" (default 1) = the
+ *     root kernels of a large pass run on helper streams beside the elimination kernels; "ransac_host_table" 1 = build the
+ *     iteration-bound table T[g] on the host for every call (default 0: the device evaluates the few bounds it needs and the host
+ *     verifies exactly those against its libm, falling back to the table when one differs); "ransac_event_cap" (tests) = capacity of
+ *     the record-event list of the replay kernels.
+ *   "solver_polish" (default 1) = every 5-point solution is polished by Gauss-Newton on the ten cubic constraints; 0 = the plain
+ *     elimination + root path, which -- like the CPU code -- is off by up to 1e-5 on the ~0.5 % of samples whose eliminated block is ill
+ *     conditioned.  This is the one option that changes results (towards the exact solution). */
 int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value);
 
 /* ---- in-library kernel timing (for roofline accounting) ------------------------------------------------------
