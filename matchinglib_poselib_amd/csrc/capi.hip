@@ -151,6 +151,7 @@ void mlpl_ctx_destroy(mlpl_ctx *ctx) {
     }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete[] ctx->ransac_T_host;
+    mlpl::free_rand_cache(ctx->rand_cache);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (int i = 0; i < 2; ++i)
         if (ctx->aux_stream[i]) (void)hipStreamDestroy(ctx->aux_stream[i]);
@@ -182,6 +183,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "hamming_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_blocks_per_cu = value;
     else if (!std::strcmp(name, "ransac_lazy_sums") && (value == 0 || value == 1)) ctx->opt_ransac_lazy_sums = value;
     else if (!std::strcmp(name, "ransac_overlap") && (value == 0 || value == 1)) ctx->opt_ransac_overlap = value;
+    else if (!std::strcmp(name, "rand_cache_max") && value >= 0) ctx->opt_rand_cache_max = value;
     else if (!std::strcmp(name, "ransac_f32_filter") && (value == 0 || value == 1)) ctx->opt_ransac_f32_filter = value;
     else if (!std::strcmp(name, "ransac_event_cap") && value >= 0 && value <= 1024) ctx->opt_ransac_event_cap = value;
     else if (!std::strcmp(name, "solver_polish") && (value == 0 || value == 1)) ctx->opt_solver_polish = value;

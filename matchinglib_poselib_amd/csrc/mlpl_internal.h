@@ -99,6 +99,8 @@ struct mlpl_ctx {
     int opt_solver_polish;          // 1 (default) = Gauss-Newton polish of every 5-point solution on the cubic constraints
     int opt_ransac_host_table;      // 1 = always build the niters table on the host (default: evaluate on the device, verify)
     // cached table T[g] = cvRANSACUpdateNumIters1(conf, (n-g)/n, 5, inf) for the last (n, conf) (host libm values)
+    int opt_rand_cache_max;         // tests: values of the rand() stream kept per context (0 = 4 Mi); beyond it a call generates privately
+    void *rand_cache;               // raw rand() stream of the last RANSAC / LMedS seed (ransac_5pt.hip: RandCache)
     int32_t *ransac_T_host;
     int ransac_T_n;
     double ransac_T_conf;
@@ -147,5 +149,6 @@ int launch_ratio_compact(mlpl_ctx *ctx, const int32_t *d_idx, const void *d_dist
 
 int launch_gather_match_points(const mlpl_dmatch *d_matches, int n, const float *d_kp1, const float *d_kp2, const double K0[4],
                                const double K1[4], double *d_p1, double *d_p2, hipStream_t s);
+void free_rand_cache(void *p);
 
 }  // namespace mlpl

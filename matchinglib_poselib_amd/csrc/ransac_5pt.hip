@@ -1917,9 +1917,58 @@ struct FastMod {
     int operator()(int v) const { return (int)(((unsigned __int128)(M * (uint32_t)v) * n) >> 64); }
 };
 
-void draw_sample(GlibcRand &g, const FastMod &mod, int32_t *idx) {
-    if (g.pos + 5 <= 31) {  // the common case in one go: five independent reductions, no duplicate among them
-        const int32_t *o = g.out + g.pos;
+// The raw rand() stream of a seed does not depend on the data, and the reference seeds with time(NULL): every call within the same
+// second -- and every call of a run with a fixed seed -- walks the same stream.  The context therefore keeps the stream of the last
+// seed (up to kRandCacheMax values, extended on demand); a call then only reduces it modulo ITS n and parses the samples.
+constexpr size_t kRandCacheMax = size_t(1) << 22;  // 16 MiB
+struct RandCache {
+    unsigned seed = 0;
+    bool valid = false;
+    GlibcRand gen;             // positioned behind the last cached value
+    std::vector<int32_t> raw;  // outputs 0 .. raw.size() - 1 of srand(seed)
+};
+
+struct RandCursor {
+    RandCache *c;
+    size_t pos = 0;
+    bool live = false;  // beyond the cached prefix: a private generator continues
+    GlibcRand tail;
+    size_t cap;
+    RandCursor(RandCache *cache, unsigned seed, size_t cap_) : c(cache), cap(cap_ ? cap_ : kRandCacheMax) {
+        if (!c->valid || c->seed != seed || c->raw.size() > cap) {
+            c->seed = seed;
+            c->valid = true;
+            c->gen.seed(seed);
+            c->raw.clear();
+        }
+    }
+    // pointer to `count` (<= 31) consecutive cached values at the cursor, or nullptr when they are not all inside the cache
+    const int32_t *peek(size_t count) {
+        if (live) return nullptr;
+        while (c->raw.size() < pos + count) {
+            if (c->raw.size() + 31 > cap) return nullptr;
+            c->gen.refill();
+            c->raw.insert(c->raw.end(), c->gen.out, c->gen.out + 31);
+            c->gen.pos = 31;
+        }
+        return c->raw.data() + pos;
+    }
+    int next() {
+        if (!live) {
+            if (const int32_t *p = peek(1)) {
+                ++pos;
+                return *p;
+            }
+            // the cache is full and the cursor is at its end: continue with a private copy of the generator
+            tail = c->gen;
+            live = true;
+        }
+        return tail.next();
+    }
+};
+
+void draw_sample(RandCursor &g, const FastMod &mod, int32_t *idx) {
+    if (const int32_t *o = g.peek(5)) {  // the common case in one go: five independent reductions, no duplicate among them
         const int v0 = mod(o[0]), v1 = mod(o[1]), v2 = mod(o[2]), v3 = mod(o[3]), v4 = mod(o[4]);
         if (v0 != v1 && v0 != v2 && v0 != v3 && v0 != v4 && v1 != v2 && v1 != v3 && v1 != v4 && v2 != v3 && v2 != v4 && v3 != v4) {
             idx[0] = v0, idx[1] = v1, idx[2] = v2, idx[3] = v3, idx[4] = v4;
@@ -2070,6 +2119,8 @@ static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
     B.cand = B.total + 16;
     return MLPL_OK;
 }
+
+void free_rand_cache(void *p) { delete static_cast<RandCache *>(p); }
 
 }  // namespace mlpl
 
@@ -2266,8 +2317,8 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     if ((rc = pack_points(ctx, d_p1, d_p2, n, &pts, s, d_st, max_iters, B.total, 1))) return rc;
     if (use_table) MLPL_HIP_TRY(hipMemcpyAsync(d_T, h_T, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
 
-    GlibcRand rng;
-    rng.seed(seed);
+    if (!ctx->rand_cache) ctx->rand_cache = new RandCache();
+    RandCursor rng(static_cast<RandCache *>(ctx->rand_cache), seed, (size_t)ctx->opt_rand_cache_max);
     const FastMod fmod_n(n);
     const double log_num = std::log(std::max(1. - std::min(std::max(confidence, 0.), 1.), DBL_MIN));  // update_num_iters' numerator
     ReplayState cur = init;
@@ -2484,8 +2535,8 @@ int mlpl_lmeds_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_
     int32_t *d_samples_mapped = nullptr;
     MLPL_HIP_TRY(hipHostGetDevicePointer((void **)&d_samples_mapped, h_samples, 0));
 
-    GlibcRand rng;
-    rng.seed(seed);
+    if (!ctx->rand_cache) ctx->rand_cache = new RandCache();
+    RandCursor rng(static_cast<RandCache *>(ctx->rand_cache), seed, (size_t)ctx->opt_rand_cache_max);
     const FastMod fmod_n(n);
     for (int i = 0; i < niters; ++i) draw_sample(rng, fmod_n, &h_samples[(size_t)i * 5]);
     MLPL_HIP_TRY(hipMemsetAsync(B.total, 0, 4, s));

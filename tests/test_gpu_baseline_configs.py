@@ -92,6 +92,24 @@ def test_ransac_record_list_overflow_takes_the_serial_path(ctx, oracle, cap, con
     assert_same_run(g, want, p1, p2, oracle)
 
 
+@pytest.mark.parametrize("cache_max", [0, 40, 1000])
+def test_rand_stream_cache_across_calls_seeds_and_its_cap(ctx, oracle, cache_max):
+    """The context keeps the raw rand() stream of the last seed.  Calls with the same seed and different n, a changed seed, LMedS in
+    between, and a cache far too small for a call (a private generator continues behind it) must all see the stream srand(seed) gives."""
+    ctx.set_option("rand_cache_max", cache_max)
+    try:
+        for n, seed, iters in [(900, 5, 800), (1300, 5, 1500), (700, 6, 600), (900, 5, 800), (2000, 5, 5000)]:
+            p1, p2, R, t, mask, th = synth.pose_scene(n, inlier_frac=0.5, seed=n)
+            g = pose.ransac_essential(p1, p2, th, confidence=0.999, max_iters=iters, refit=False, seed=seed, ctx=ctx)
+            o = oracle.ransac_essential(p1, p2, th, confidence=0.999, max_iters=iters, lesqu=False, seed=seed)
+            assert_same_run(g, o, p1, p2, oracle)
+            gl = pose.lmeds_essential(p1, p2, seed=seed + 1, ctx=ctx)
+            ol = oracle.lmeds_essential(p1, p2, seed=seed + 1)
+            assert gl["ok"] == ol["ok"] and gl["n_inliers"] == ol["n_inliers"]
+    finally:
+        ctx.set_option("rand_cache_max", 0)
+
+
 def test_ransac_tiny_inlier_fraction_uses_every_iteration(ctx, oracle):
     """20 % inliers at the reference's settings: the adaptive bound stays above max_iters for a long time."""
     p1, p2, R, t, mask, th = synth.pose_scene(3000, inlier_frac=0.2, seed=99)
