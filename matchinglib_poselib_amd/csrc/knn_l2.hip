@@ -98,14 +98,55 @@ __device__ __forceinline__ void l2_exact_body(const L2ExactArgs &a, float *smem,
     u64 k0 = ~0ull, k1 = ~0ull;
     const int r_begin = split * rows_per_split;
     const int r_end = min(nt, r_begin + rows_per_split);
+    // cvflann order with the query in registers: TWO train rows per instruction on packed fp32 ops (v_pk_add_f32 / v_pk_mul_f32; no
+    // FMA, the per-row operation order is exactly l2_group4's), the tile stored pair-interleaved: element c of rows 2p, 2p+1 side by side
+    constexpr bool kPacked = DIM4 > 0 && !NMS;
     for (int base = r_begin; base < r_end; base += tile_rows) {
         const int rows = min(tile_rows, r_end - base);
         __syncthreads();
         for (int i = tid; i < rows * dim_pad; i += kQPB) {
             const int r = i / dim_pad, c = i - r * dim_pad;
-            smem[i] = (c < dim) ? t[(size_t)(base + r) * t_stride + c] : 0.f;
+            const float v = (c < dim) ? t[(size_t)(base + r) * t_stride + c] : 0.f;
+            if constexpr (kPacked) smem[((size_t)(r >> 1) * dim_pad + c) * 2 + (r & 1)] = v;
+            else smem[i] = v;
         }
         __syncthreads();
+        if constexpr (kPacked) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            for (int rp = 0; 2 * rp < rows; ++rp) {
+                const float4 *tp = reinterpret_cast<const float4 *>(smem + (size_t)rp * dim_pad * 2);
+                f32x2 res = {0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < DIM4; ++g) {
+                    // the query already holds 4 * DIM4 registers: keep at most eight 16-byte LDS loads in flight (without the fence
+                    // the scheduler hoists all 2 * DIM4 of them and the kernel drops to one wave per SIMD)
+                    if ((g & 3) == 0) asm volatile("" ::: "memory");
+                    const float4 v0 = tp[2 * g], v1 = tp[2 * g + 1];
+                    // t - q with the query element broadcast to both halves by op_sel straight from the register pair it lives in
+                    // (written as (t, t') - (q, q) the compiler materialises every (q, q) pair outside the row loop: 256 more registers)
+                    const f32x2 qxy = {qa[g].x, qa[g].y}, qzw = {qa[g].z, qa[g].w};
+                    f32x2 d0, d1, d2, d3;
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d0) : "v"(f32x2{v0.x, v0.y}), "v"(qxy));
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d1) : "v"(f32x2{v0.z, v0.w}), "v"(qxy));
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d2) : "v"(f32x2{v1.x, v1.y}), "v"(qzw));
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d3) : "v"(f32x2{v1.z, v1.w}), "v"(qzw));
+                    f32x2 sg = d0 * d0 + d1 * d1;  // (this file is compiled with -ffp-contract=off: separate multiplies and adds)
+                    sg = sg + d2 * d2;
+                    sg = sg + d3 * d3;
+                    res = res + sg;
+                }
+                float ra = res.x, rb = res.y;
+                const float *tt = smem + ((size_t)rp * dim_pad + ngroups * 4) * 2;  // scalar tail: result += diff*diff, one element at a time
+                for (int j = 0; j < tail; ++j) {
+                    const float da = __fsub_rn(tt[2 * j], qtail[j]), db = __fsub_rn(tt[2 * j + 1], qtail[j]);
+                    ra = __fadd_rn(ra, __fmul_rn(da, da));
+                    rb = __fadd_rn(rb, __fmul_rn(db, db));
+                }
+                const int r = 2 * rp;
+                top2_update(k0, k1, ((u64)__float_as_uint(ra) << 32) | (u64)(uint32_t)(base + r));
+                if (r + 1 < rows) top2_update(k0, k1, ((u64)__float_as_uint(rb) << 32) | (u64)(uint32_t)(base + r + 1));
+            }
+        } else
         for (int r = 0; r < rows; ++r) {
             const float4 *trow = reinterpret_cast<const float4 *>(smem + (size_t)r * dim_pad);
             float res = 0.f;
