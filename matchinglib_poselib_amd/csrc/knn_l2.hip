@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kQPB) void knn_l2_exact_kernel(L2ExactArgs a) {
 // bit-identical results either way, different partial tables (the merge reads the same flag).  1-D grid = the larger of the two
 // grids; the surplus workgroups of the path taken exit at once.
 template <int DIM4, int KS>
-__global__ __launch_bounds__(kQPB) void knn_l2_auto_kernel(l2mfma::L2MfmaArgs m, unsigned grid_m, L2ExactArgs e, int qtiles_e,
+__global__ __launch_bounds__(kQPB, 3) void knn_l2_auto_kernel(l2mfma::L2MfmaArgs m, unsigned grid_m, L2ExactArgs e, int qtiles_e,
                                                            unsigned grid_e, L2Gate gate) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (*gate.flag != gate.gen) {

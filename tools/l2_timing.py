@@ -14,7 +14,7 @@ for n in (4096, 2048, 8192):
     idx = torch.empty((n, 2), dtype=torch.int32, device=dev)
     dist = torch.empty((n, 2), dtype=torch.float32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    for waves, bpc in ((4, 4), (4, 2), (8, 1), (8, 2), (0, 0)):
+    for waves, bpc in ((0, 2), (0, 3), (0, 4), (0, 0), (0, 2), (0, 3)):
         mode = 0
         ctx.lib.mlpl_set_option(ctx.handle, b"l2_mfma_waves", waves)
         ctx.lib.mlpl_set_option(ctx.handle, b"l2_mfma_blocks_per_cu", bpc)
