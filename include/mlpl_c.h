@@ -222,6 +222,35 @@ int mlpl_lmeds_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_
                              uint32_t seed, double E[9], uint8_t *d_mask, int *n_inliers, double *min_median, void *stream);
 
 /*
+ * CvModelEstimator3::runARRSAC (modelest.cpp:197-341) as findEssentialMat drives it for method ARRSAC, the DEFAULT method of
+ * poselib::estimateEssentialMat (pose_estim.h:204-210, pose_estim.cpp:866-869; five-point.cpp:120-124): theia::Arrsac(5, thresh^2, 500
+ * hypotheses, blocks of 100, inner RANSAC on 14 / at least 8 points) (include/arrsac/arrsac.h:236-547) over the 5-point solver with
+ * CvEMEstimator::ValidModel (five-point.cpp:534-601), PROSAC and uniform sampling from two cv::RNG streams, Wald's sequential test per
+ * hypothesis, then the preemptive breadth-first stage; the mask is findInliers of the winner; `refine` != 0 runs
+ * robustEssentialRefine (pose_estim.cpp:337-792) on its inliers (>= 50 needed) and returns the refined matrix with the unrefined
+ * model's mask, as the reference does (modelest.cpp:280-318).  Solver, validity test, all error evaluations and the refinement run on
+ * the device in speculative batches; the sequential decisions are taken on the host.
+ * rng_state: in/out, the states of the reference's two function-local `static cv::RNG rng;` (prosac_sampler.h:115, random_sampler.h:65),
+ * which live as long as the PROCESS there: both are 0xffffffff before the first ARRSAC call of a program and carry over from call to
+ * call -- the caller keeps them (the C++ facade keeps one pair per process).  Returns 0, MLPL_E_FAILED when no hypothesis passed or the
+ * winner has < 15 inliers (< 50 when n > 200) (modelest.cpp:275-278; the mask and *n_inliers are still written then), -1 on bad input
+ * (n must exceed 5; with exactly 5 correspondences findEssentialMat never reaches runARRSAC, use mlpl_solve_5pt).
+ */
+int mlpl_arrsac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n, double thresh, int refine, uint64_t rng_state[2],
+                          double E[9], uint8_t *mask, int *n_inliers);
+int mlpl_arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thresh, int refine,
+                              uint64_t rng_state[2], double E[9], uint8_t *d_mask, int *n_inliers, void *stream);
+/* Statistics of the last mlpl_arrsac_essential[_dev] call: {k of the initial hypothesis set, hypotheses after it, PROSAC samples,
+ * inner-RANSAC samples, inner-RANSAC restarts, samples of the preemptive stage, correspondence index where that stage ended,
+ * hypotheses left there, device batches, samples solved on the device, samples the control flow consumed, refinement status
+ * (-1 not run, 0 converged, 1 stopped on an invalid matrix, 2 rejected)}. */
+int mlpl_arrsac_last_stats(mlpl_ctx *ctx, long long stats[12]);
+/* Diagnostics: the following mlpl_arrsac_essential* calls record the turns of their first stage into buf (20 ints per turn: k, inner-RANSAC
+ * turn?, sample size, its first five indices, valid models, per model 1000 * accepted + inliers seen by the sequential test); returns the
+ * number of ints written since the previous call of this function.  buf = NULL switches the recording off. */
+int mlpl_debug_arrsac_trace(mlpl_ctx *ctx, int32_t *buf, int cap);
+
+/*
  * One image pair through the whole hot path, device-resident (the per-pair body of the reference harness loop,
  * tests/poselib-test/main.cpp:1440-2072, and of StereoRefine's first call): Hamming 2-NN + 0.75 ratio test -> gather of the matched
  * keypoints with ImgToCamCoordTrans -> RANSAC essential matrix -> cheirality.  d_q/d_t: dense nq/nt x nbytes descriptors,

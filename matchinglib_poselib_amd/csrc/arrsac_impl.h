@@ -1,0 +1,963 @@
+// arrsac_impl.h -- ARRSAC (estimateEssentialMat's default method) on the MI355X.  Included by ransac_5pt.hip inside namespace mlpl: it
+// reuses that file's solver tail (solve_from_basis, roots_kernel_t), its Jacobi 9x9 and the reference-arithmetic Sampson error.
+//
+// Reference: CvModelEstimator3::runARRSAC (poselib/source/five-point-nister/modelest.cpp:197-341) around theia::Arrsac
+// (poselib/include/arrsac/arrsac.h:236-547) with EssentialMatEstimatorTheia (modelest.cpp:111-195), the PROSAC and uniform samplers
+// (include/arrsac/prosac_sampler.h:85-157, random_sampler.h:57-78), the sequential probability ratio test
+// (include/arrsac/sequential_probability_ratio.h:88-126, source/arrsac/sequential_probability_ratio.cc:38-62), CvEMEstimator::ValidModel
+// (five-point.cpp:534-601) and, for `refine`, robustEssentialRefine (poselib/source/pose_estim.cpp:337-792).
+//
+// How a sequential estimator runs on a GPU.  The reference forms ONE hypothesis at a time; which sample comes next depends on the outcome
+// of the previous test only through rare events (an accepted hypothesis with a new best support switches the sampler to an inner RANSAC on
+// its inliers for 20 turns and shrinks the hypothesis budget).  Between events the sample sequence is a pure function of the two cv::RNG
+// streams.  So the host runs the reference's control flow literally, and whenever it needs the models of a sample it has not seen, it first
+// plays the samplers FORWARD from copies of their state under the assumption "no event", and sends the next up to 64..512 samples to the
+// device as one batch:
+//   arrsac_sample_kernel   one wave per sample: 5 points -> Householder null space; 6..7 points -> 4 smallest eigenvectors of the Gram
+//                          matrix (the reference runs its 5-point kernel on them, cv::SVD of a 6x9 / 7x9 system); 8..14 points ->
+//                          cv::findFundamentalMat(FM_8POINT) restated (float32 inputs, normalisation, 9x9 eigenvector, rank 2)
+//   roots_kernel_t         the degree-10 polynomial's roots -> up to 10 essential matrices per sample (as RANSAC)
+//   arrsac_check_kernel    one wave per model: ValidModel (Eigen's two-sided Jacobi SVD restated, V's column signs included) and the
+//                          inlier bit of the model for the first 1024 correspondences (float Sampson error < thresh^2, the only
+//                          correspondences ARRSAC ever tests: 100 in the first stage, < 900 in the preemptive stage)
+// Results land in a cache keyed by the sample (kind, ordered indices).  The SPRT walks, the sigma / epsilon / threshold updates, the
+// hypothesis bookkeeping and the preemptive stage's std::sort run on the host over those bit rows -- they are the control plane, a few
+// thousand scalar operations.  A wrong guess costs a discarded batch, never a wrong result: the cache is keyed by content and the random
+// streams the host advances are the real ones.  Final mask: inlier_mask_count_kernel; refinement: arrsac_refine_kernel (one workgroup,
+// iteratively re-weighted 9x9 eigenproblem, no host hop inside).
+
+namespace {
+
+constexpr int kArrSmpStride = 16;     // int32 per sample: [0] size m, [1..14] indices, [15] kind (0 = 5-point solver, 1 = 8-point fit)
+constexpr int kArrMaxSample = 14;
+constexpr int kArrFlagPoints = 1024;  // correspondences a hypothesis can ever be tested on
+constexpr int kArrFlagWords = kArrFlagPoints / 64;
+constexpr int kArrBatchCap = 512;
+
+// ---- Eigen::JacobiSVD<Matrix3d>(M, ComputeFullU | ComputeFullV) restated: two-sided Jacobi in Eigen's pair order, left rotation =
+// symmetrising rotation * right^T, signs of the singular values absorbed by U, descending sort by column swaps.  V's columns carry
+// Eigen's signs (ValidModel's epipole is V.col(2)). ----
+struct JRot {
+    double c, s;
+};
+template <int P, int Q>
+__device__ __forceinline__ void jrot_rows(double *M, JRot j) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double x = M[P * 3 + i], y = M[Q * 3 + i];
+        M[P * 3 + i] = j.c * x + j.s * y;
+        M[Q * 3 + i] = -j.s * x + j.c * y;
+    }
+}
+template <int P, int Q>
+__device__ __forceinline__ void jrot_cols(double *M, JRot j) {  // applyOnTheRight(p, q, j): the columns turn with j^T
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double x = M[i * 3 + P], y = M[i * 3 + Q];
+        M[i * 3 + P] = j.c * x - j.s * y;
+        M[i * 3 + Q] = j.s * x + j.c * y;
+    }
+}
+template <int P, int Q>
+__device__ __forceinline__ bool jsvd_pair(double *W, double *U, double *V, double &max_diag) {
+    const double threshold = fmax(DBL_MIN, 2.0 * DBL_EPSILON * max_diag);
+    if (!(fabs(W[P * 3 + Q]) > threshold || fabs(W[Q * 3 + P]) > threshold)) return false;
+    double m00 = W[P * 3 + P], m01 = W[P * 3 + Q], m10 = W[Q * 3 + P], m11 = W[Q * 3 + Q];
+    JRot rot1;
+    const double t = m00 + m11, d = m10 - m01;
+    if (fabs(d) < DBL_MIN) {
+        rot1 = {1.0, 0.0};
+    } else {
+        const double u = t / d, tmp = sqrt(1.0 + u * u);
+        rot1 = {u / tmp, 1.0 / tmp};
+    }
+    {
+        const double a0 = rot1.c * m00 + rot1.s * m10, a1 = rot1.c * m01 + rot1.s * m11;
+        const double b1 = -rot1.s * m01 + rot1.c * m11;
+        m00 = a0, m01 = a1, m11 = b1;
+    }
+    JRot jr = {1.0, 0.0};
+    const double deno = 2.0 * fabs(m01);
+    if (!(deno < DBL_MIN)) {
+        const double tau = (m00 - m11) / deno;
+        const double w = sqrt(tau * tau + 1.0);
+        const double tt = tau > 0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+        const double sign_t = tt > 0 ? 1.0 : -1.0;
+        const double nn = 1.0 / sqrt(tt * tt + 1.0);
+        jr = {nn, -sign_t * (m01 / fabs(m01)) * fabs(tt) * nn};
+    }
+    const JRot jl = {rot1.c * jr.c + rot1.s * jr.s, -rot1.c * jr.s + rot1.s * jr.c};  // rot1 * jr^T
+    jrot_rows<P, Q>(W, jl);
+    jrot_cols<P, Q>(U, JRot{jl.c, -jl.s});
+    jrot_cols<P, Q>(W, jr);
+    jrot_cols<P, Q>(V, jr);
+    max_diag = fmax(max_diag, fmax(fabs(W[P * 3 + P]), fabs(W[Q * 3 + Q])));
+    return true;
+}
+template <int A, int B>
+__device__ __forceinline__ void jswap_cols(double *sv, double *U, double *V) {
+    double t = sv[A];
+    sv[A] = sv[B], sv[B] = t;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        t = U[r * 3 + A], U[r * 3 + A] = U[r * 3 + B], U[r * 3 + B] = t;
+        t = V[r * 3 + A], V[r * 3 + A] = V[r * 3 + B], V[r * 3 + B] = t;
+    }
+}
+__device__ void svd3_eigen(const double *Min, double *sv, double *U, double *V) {
+    double W[9];
+    double scale = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) scale = fmax(scale, fabs(Min[i]));
+    if (scale == 0) scale = 1;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        W[i] = Min[i] / scale;
+        U[i] = V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
+    double max_diag = fmax(fabs(W[0]), fmax(fabs(W[4]), fabs(W[8])));
+    for (int guard = 0; guard < 100; ++guard) {
+        bool any = jsvd_pair<1, 0>(W, U, V, max_diag);
+        any |= jsvd_pair<2, 0>(W, U, V, max_diag);
+        any |= jsvd_pair<2, 1>(W, U, V, max_diag);
+        if (!any) break;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double a = W[i * 4];
+        sv[i] = fabs(a) * scale;
+        if (a < 0) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) U[r * 3 + i] = -U[r * 3 + i];
+        }
+    }
+    // descending order, first maximum wins (Eigen: swap with the largest of the tail, stop at a zero)
+    if (sv[1] > sv[0] && sv[1] >= sv[2]) jswap_cols<0, 1>(sv, U, V);
+    else if (sv[2] > sv[0] && sv[2] > sv[1]) jswap_cols<0, 2>(sv, U, V);
+    if (sv[0] != 0 && sv[2] > sv[1]) jswap_cols<1, 2>(sv, U, V);
+}
+
+__device__ __forceinline__ bool arr_is_zero(double d) { return d < 1e-3 && d > -1e-3; }  // five-point.hpp:76-81
+
+// CvEMEstimator::ValidModel (five-point.cpp:534-601): q = the m sample correspondences as (x1, y1, x2, y2).  V(-M) == V(M) for the
+// decomposition above (the sign goes into U), so the second pass with -E re-uses e2.
+__device__ bool valid_model_dev(const double (*q)[4], int m, const double *E) {
+    double Et[9], sv[3], U[9], V[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Et[r * 3 + c] = E[c * 3 + r];
+    svd3_eigen(Et, sv, U, V);
+    if (sv[0] / sv[1] > 1.2) return false;
+    if (!arr_is_zero(0.01 * sv[2] / sv[1])) return false;
+    const double e2[3] = {V[2], V[5], V[8]};
+    double sgn = 1.0;
+    bool emult = false;
+    int fail = 0;
+    for (int i = 0; i < m; ++i) {
+        const double x1 = q[i][0], y1 = q[i][1], x2 = q[i][2], y2 = q[i][3];
+        const double l1[3] = {e2[1] - e2[2] * y2, e2[2] * x2 - e2[0], e2[0] * y2 - e2[1] * x2};
+        bool neg = false;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double l2 = sgn * E[j * 3] * x1 + sgn * E[j * 3 + 1] * y1 + sgn * E[j * 3 + 2];
+            if (neg || arr_is_zero(0.1 * l1[j]) || arr_is_zero(0.1 * l2)) continue;
+            if (l1[j] * l2 < 0) neg = true;
+        }
+        if (neg) {
+            if (!emult) {  // the reference restarts the whole loop with -E
+                emult = true;
+                sgn = -1.0;
+                fail = 0;
+                i = -1;
+                continue;
+            }
+            fail++;
+        }
+    }
+    return !((float)fail / (float)m >= 0.4f);
+}
+
+__device__ __forceinline__ double arr_row_elem(const double *p, int a) {  // epipolar row [x1x2, y1x2, x2, x1y2, y1y2, y2, x1, y1, 1]
+    const double x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+    switch (a) {
+        case 0: return x1 * x2;
+        case 1: return y1 * x2;
+        case 2: return x2;
+        case 3: return x1 * y2;
+        case 4: return y1 * y2;
+        case 5: return y2;
+        case 6: return x1;
+        case 7: return y1;
+        default: return 1.0;
+    }
+}
+
+__device__ __forceinline__ void order_desc9(const Jacobi9Lds &J, int *order) {
+    for (int a = 0; a < 9; ++a) order[a] = a;
+    for (int a = 0; a < 8; ++a) {
+        int best = a;
+        for (int b = a + 1; b < 9; ++b)
+            if (J.G[order[b]][order[b]] > J.G[order[best]][order[best]]) best = b;
+        const int t2 = order[a];
+        order[a] = order[best];
+        order[best] = t2;
+    }
+}
+
+__global__ __launch_bounds__(64) void arrsac_sample_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
+                                                           const int32_t *__restrict__ smp, int n_samples, PolyRec *__restrict__ recs,
+                                                           double *__restrict__ direct_E, int32_t *__restrict__ direct_ok) {
+    __shared__ SolveLds L;
+    __shared__ Jacobi9Lds J;
+    __shared__ double xn[kArrMaxSample][4];
+    __shared__ double nrm[6];
+    __shared__ int s_ok;
+    if (blockDim.x != kSolverThreads) __builtin_trap();
+    const int lane = threadIdx.x, b = blockIdx.x;
+    if (b >= n_samples) return;
+    const int32_t *sm = smp + (size_t)b * kArrSmpStride;
+    const int m = sm[0], kind = sm[15];
+    if (lane == 0) direct_ok[b] = 0;
+    if (kind == 0 && m == 5) {
+        if (lane < 5) {
+            const int idx = sm[1 + lane];
+            const double x1 = p1[2 * idx], y1 = p1[2 * idx + 1], x2 = p2[2 * idx], y2 = p2[2 * idx + 1];
+            double *r = L.Q[lane];
+            r[0] = x1 * x2, r[1] = y1 * x2, r[2] = x2, r[3] = x1 * y2, r[4] = y1 * y2, r[5] = y2, r[6] = x1, r[7] = y1, r[8] = 1.0;
+        }
+        wave_sync();
+        householder_basis(L, lane);
+        solve_from_basis(L, lane, recs + b);
+        return;
+    }
+    if (lane < m) {
+        const int idx = sm[1 + lane];
+        double x1 = p1[2 * idx], y1 = p1[2 * idx + 1], x2 = p2[2 * idx], y2 = p2[2 * idx + 1];
+        if (kind == 1) x1 = (double)(float)x1, y1 = (double)(float)y1, x2 = (double)(float)x2, y2 = (double)(float)y2;  // convertTo(CV_32F)
+        xn[lane][0] = x1, xn[lane][1] = y1, xn[lane][2] = x2, xn[lane][3] = y2;
+    }
+    wave_sync();
+    if (kind == 1) {
+        if (lane == 0) {  // run8Point's normalisation (OpenCV calib3d fundam.cpp)
+            double c1x = 0, c1y = 0, c2x = 0, c2y = 0, s1 = 0, s2 = 0;
+            for (int i = 0; i < m; ++i) c1x += xn[i][0], c1y += xn[i][1], c2x += xn[i][2], c2y += xn[i][3];
+            const double t = 1. / m;
+            c1x *= t, c1y *= t, c2x *= t, c2y *= t;
+            for (int i = 0; i < m; ++i) {
+                const double dx1 = xn[i][0] - c1x, dy1 = xn[i][1] - c1y, dx2 = xn[i][2] - c2x, dy2 = xn[i][3] - c2y;
+                s1 += sqrt(dx1 * dx1 + dy1 * dy1);
+                s2 += sqrt(dx2 * dx2 + dy2 * dy2);
+            }
+            s1 *= t, s2 *= t;
+            s_ok = !(s1 < (double)FLT_EPSILON || s2 < (double)FLT_EPSILON);
+            s1 = sqrt(2.) / s1, s2 = sqrt(2.) / s2;
+            nrm[0] = c1x, nrm[1] = c1y, nrm[2] = s1, nrm[3] = c2x, nrm[4] = c2y, nrm[5] = s2;
+        }
+        wave_sync();
+        for (int k = lane; k < 88; k += 64) reinterpret_cast<double *>(recs + b)[k] = 0.0;  // no polynomial: the root kernel skips it
+        if (!s_ok) return;
+        if (lane < m) {
+            xn[lane][0] = (xn[lane][0] - nrm[0]) * nrm[2], xn[lane][1] = (xn[lane][1] - nrm[1]) * nrm[2];
+            xn[lane][2] = (xn[lane][2] - nrm[3]) * nrm[5], xn[lane][3] = (xn[lane][3] - nrm[4]) * nrm[5];
+        }
+        wave_sync();
+    }
+    for (int e = lane; e < 81; e += 64) {
+        const int a = e / 9, c = e - a * 9;
+        double acc = 0;
+        for (int i = 0; i < m; ++i) acc += arr_row_elem(xn[i], a) * arr_row_elem(xn[i], c);
+        J.G[a][c] = acc;
+        J.Vv[a][c] = (a == c) ? 1.0 : 0.0;
+    }
+    wave_sync();
+    jacobi9_wave(J, lane);
+    if (kind == 0) {
+        if (lane == 0) {
+            int order[9];
+            order_desc9(J, order);
+            for (int j = 0; j < 4; ++j)
+                for (int r = 0; r < 9; ++r) L.EE[j][r] = J.Vv[r][order[5 + j]];
+        }
+        wave_sync();
+        solve_from_basis(L, lane, recs + b);
+        return;
+    }
+    if (lane == 0) {
+        int order[9];
+        order_desc9(J, order);
+        if (!(fabs(J.G[order[7]][order[7]]) < DBL_EPSILON)) {
+            double F0[9], sv[3], U[9], V[9];
+            for (int k = 0; k < 9; ++k) F0[k] = J.Vv[k][order[8]];
+            svd3_eigen(F0, sv, U, V);
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) F0[r * 3 + c] = U[r * 3] * sv[0] * V[c * 3] + U[r * 3 + 1] * sv[1] * V[c * 3 + 1];
+            // F = T2^T F0 T1 with T = [s 0 -s cx; 0 s -s cy; 0 0 1]
+            const double s1 = nrm[2], a1 = -nrm[2] * nrm[0], b1 = -nrm[2] * nrm[1];
+            const double s2 = nrm[5], a2 = -nrm[5] * nrm[3], b2 = -nrm[5] * nrm[4];
+            double G2[9];  // T2^T F0
+            for (int c = 0; c < 3; ++c) {
+                G2[c] = s2 * F0[c];
+                G2[3 + c] = s2 * F0[3 + c];
+                G2[6 + c] = a2 * F0[c] + b2 * F0[3 + c] + F0[6 + c];
+            }
+            double F[9];
+            for (int r = 0; r < 3; ++r) {
+                F[r * 3] = G2[r * 3] * s1;
+                F[r * 3 + 1] = G2[r * 3 + 1] * s1;
+                F[r * 3 + 2] = G2[r * 3] * a1 + G2[r * 3 + 1] * b1 + G2[r * 3 + 2];
+            }
+            if (fabs(F[8]) > (double)FLT_EPSILON) {
+                const double inv = 1. / F[8];
+                for (int k = 0; k < 9; ++k) F[k] *= inv;
+            }
+            for (int k = 0; k < 9; ++k) direct_E[(size_t)b * 9 + k] = F[k];
+            direct_ok[b] = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void arrsac_check_kernel(const double4 *__restrict__ pts, int flag_points, const double *__restrict__ p1,
+                                                          const double *__restrict__ p2, const int32_t *__restrict__ smp, int n_samples,
+                                                          double *__restrict__ E_tab, const int32_t *__restrict__ n_models,
+                                                          const double *__restrict__ direct_E, const int32_t *__restrict__ direct_ok,
+                                                          double thresh2, int32_t *__restrict__ out_nm, int32_t *__restrict__ out_valid,
+                                                          unsigned long long *__restrict__ out_flags) {
+    __shared__ double q[kArrMaxSample][4];
+    __shared__ int s_valid;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x / 10, slot = blockIdx.x - b * 10;
+    if (b >= n_samples) return;
+    const int32_t *sm = smp + (size_t)b * kArrSmpStride;
+    const int m = sm[0], kind = sm[15];
+    const int nm = kind ? direct_ok[b] : n_models[b];
+    if (slot == 0 && lane == 0) out_nm[b] = nm;
+    if (slot >= nm) {
+        if (lane == 0) out_valid[b * 10 + slot] = 0;
+        return;
+    }
+    double e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = kind ? direct_E[(size_t)b * 9 + k] : E_tab[((size_t)b * 10 + slot) * 9 + k];
+    if (!kind) {
+        // sign convention of a 5-point solution: its element of largest magnitude is positive.  (The reference's sign comes from the
+        // last null vector cv::SVD happens to return -- rounding noise decides it -- and ValidModel is not sign-symmetric.)
+        int at = 0;
+#pragma unroll
+        for (int k = 1; k < 9; ++k)
+            if (fabs(e[k]) > fabs(e[at])) at = k;
+        double pick = e[0];
+#pragma unroll
+        for (int k = 1; k < 9; ++k) pick = (at == k) ? e[k] : pick;
+        if (pick < 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) e[k] = -e[k];
+        }
+    }
+    if (lane < 9) {
+        double v = e[0];
+#pragma unroll
+        for (int k = 1; k < 9; ++k) v = (lane == k) ? e[k] : v;
+        E_tab[((size_t)b * 10 + slot) * 9 + lane] = v;
+    }
+    if (lane < m) {
+        const int idx = sm[1 + lane];
+        q[lane][0] = p1[2 * idx], q[lane][1] = p1[2 * idx + 1], q[lane][2] = p2[2 * idx], q[lane][3] = p2[2 * idx + 1];
+    }
+    wave_sync();
+    if (lane == 0) {
+        s_valid = valid_model_dev(q, m, e) ? 1 : 0;
+        out_valid[b * 10 + slot] = s_valid;
+    }
+    wave_sync();
+    if (!s_valid) return;
+    for (int w = 0; w < kArrFlagWords; ++w) {
+        const int i = w * 64 + lane;
+        bool in = false;
+        if (i < flag_points) {
+            const double4 p = pts[i];
+            in = (double)sampson_err_f32(e, p.x, p.y, p.z, p.w) < thresh2;  // Estimator::Error(...) < error_thresh, strict
+        }
+        const unsigned long long bal = __ballot(in);
+        if (lane == 0) out_flags[((size_t)b * 10 + slot) * kArrFlagWords + w] = bal;
+    }
+}
+
+// robustEssentialRefine(inliers, E_init, th, iters = 0, makeClosestE = true) (pose_estim.cpp:337-792; model 0, no normalisation): up to
+// 50 rounds of { pseudo-Huber weights on the Sampson distance under the current matrix (pose_helper.cpp:115-143, BA_driver.cpp:2639-2648),
+// weighted 9x9 normal matrix, eigenvector of its smallest eigenvalue, closest essential matrix (getClosestE, pose_helper.cpp:152-177) },
+// stopped by the reference's tests on the residual.  One workgroup; the normal matrix is summed unnormalised and divided by the weight
+// norm afterwards (the reference scales every row first).  info = {rounds, status: 0 converged/exhausted, 1 stopped on an invalid matrix,
+// 2 rejected (too few points or a rank-deficient system: E_init is returned)}.
+__global__ __launch_bounds__(1024) void arrsac_refine_kernel(const double4 *__restrict__ pts, const uint8_t *__restrict__ mask, int n,
+                                                             const double *__restrict__ E_init, double th, double *__restrict__ E_out,
+                                                             int32_t *__restrict__ info) {
+    __shared__ double red[16][46];
+    __shared__ Jacobi9Lds J;
+    __shared__ double F3[9];
+    __shared__ double s_err_old;
+    __shared__ int s_stop, s_cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_cnt = 0, s_stop = 0, s_err_old = 1e12;
+    if (tid < 9) F3[tid] = E_init[tid];
+    __syncthreads();
+    {
+        int c = 0;
+        for (int i = tid; i < n; i += 1024) c += mask[i] ? 1 : 0;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+        if (lane == 0 && c) atomicAdd(&s_cnt, c);
+    }
+    __syncthreads();
+    const int npoints = s_cnt;
+    if (npoints < 50) {
+        if (tid < 9) E_out[tid] = E_init[tid];
+        if (tid == 0) info[0] = 0, info[1] = 2;
+        return;
+    }
+    const double min_diff = th / 10, min_err = th * th / 100 * npoints;
+    int j = 0;
+    for (; j < 50; ++j) {
+        double e[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) e[k] = F3[k];
+        double acc[46];
+#pragma unroll
+        for (int k = 0; k < 46; ++k) acc[k] = 0;
+        for (int i = tid; i < n; i += 1024) {
+            if (!mask[i]) continue;
+            const double4 p = pts[i];
+            const double x0 = p.x, y0 = p.y, x1 = p.z, y1 = p.w;
+            // SampsonL1: num = x2^T E x1, denom1 = 1 / (sqrt(|E x1|_xy^2 + |E^T x2|_xy^2) + 1e-8)
+            const double g0 = x1 * e[0] + y1 * e[3] + e[6], g1 = x1 * e[1] + y1 * e[4] + e[7], g2 = x1 * e[2] + y1 * e[5] + e[8];
+            const double num = g0 * x0 + g1 * y0 + g2;
+            const double h0 = e[0] * x0 + e[1] * y0 + e[2], h1 = e[3] * x0 + e[4] * y0 + e[5];
+            const double denom1 = 1 / (sqrt(h0 * h0 + h1 * h1 + g0 * g0 + g1 * g1) + 1e-8);
+            const double d_abs = fabs(num * denom1) + 1e-12;
+            const double qq = d_abs / th;
+            const double w = sqrt(2 * th * th * (sqrt(1 + qq * qq) - 1)) / d_abs;  // costPseudoHuber
+            const double f = denom1 * w, f2 = f * f;
+            const double r[9] = {x1 * x0, x1 * y0, x1, y1 * x0, y1 * y0, y1, x0, y0, 1.0};
+            int t = 0;
+#pragma unroll
+            for (int a = 0; a < 9; ++a)
+#pragma unroll
+                for (int c = a; c < 9; ++c) acc[t++] += f2 * r[a] * r[c];
+            acc[45] += f2;
+        }
+#pragma unroll
+        for (int k = 0; k < 46; ++k) {
+            double v = acc[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0) red[wave][k] = v;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            if (lane < 46) {
+                double sacc = 0;
+                for (int wv = 0; wv < 16; ++wv) sacc += red[wv][lane];
+                red[0][lane] = sacc;
+            }
+            wave_sync();
+            const double wn2 = red[0][45];
+            if (lane == 0) {
+                int t = 0;
+                for (int a = 0; a < 9; ++a)
+                    for (int c = a; c < 9; ++c) {
+                        const double v = red[0][t++] / wn2;
+                        J.G[a][c] = v;
+                        J.G[c][a] = v;
+                    }
+            }
+            for (int ee = lane; ee < 81; ee += 64) J.Vv[ee / 9][ee % 9] = (ee / 9 == ee % 9) ? 1.0 : 0.0;
+            wave_sync();
+            jacobi9_wave(J, lane);
+            if (lane == 0) {
+                int order[9];
+                order_desc9(J, order);
+                if (fabs(J.G[order[7]][order[7]]) < DBL_EPSILON) {
+                    s_stop = 3;  // "Refinement failed!": the initial matrix is returned
+                } else {
+                    double F2[9], sv[3], U[9], V[9];
+                    for (int k = 0; k < 9; ++k) F2[k] = J.Vv[k][order[8]];
+                    svd3_eigen(F2, sv, U, V);
+                    if (!arr_is_zero(sv[2]) || sv[0] / sv[1] > 1.5 || sv[0] / sv[1] < 0.66 || !(sv[1] > 0)) {
+                        s_stop = 2;  // "taking last valid E"
+                    } else {
+                        for (int r = 0; r < 3; ++r)
+                            for (int c = 0; c < 3; ++c) F3[r * 3 + c] = U[r * 3] * sv[0] * V[c * 3] + U[r * 3 + 1] * sv[1] * V[c * 3 + 1];
+                        const double err = J.G[order[8]][order[8]];  // |A1 lastCol|^2 = the eigenvalue
+                        const double diff = fabs(s_err_old - err);
+                        if (j > 1 && (diff < min_diff || err < min_err)) s_stop = 1;
+                        s_err_old = err;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (s_stop) break;
+    }
+    if (tid < 9) E_out[tid] = (s_stop == 3) ? E_init[tid] : F3[tid];
+    if (tid == 0) info[0] = j, info[1] = (s_stop == 3) ? 2 : (s_stop == 2 ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------------------
+struct CvRng {  // cv::RNG (OpenCV core): multiply-with-carry
+    uint64_t state;
+    unsigned next() {
+        state = (uint64_t)(unsigned)state * 4164903690U + (unsigned)(state >> 32);
+        return (unsigned)state;
+    }
+    int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+
+struct ArrModelHost {
+    double E[9];
+    uint64_t bits[kArrFlagWords];
+};
+using ArrKey = std::vector<int32_t>;  // {kind, i0, i1, ...}
+
+struct ArrsacRun {
+    mlpl_ctx *ctx;
+    hipStream_t s;
+    const double *d_p1, *d_p2;
+    const double4 *pts;
+    int n, flag_points;
+    double thresh2;
+    // device / pinned buffers of a batch
+    int32_t *d_smp = nullptr;
+    PolyRec *d_recs = nullptr;
+    double *d_direct = nullptr;
+    int32_t *d_direct_ok = nullptr, *d_nm5 = nullptr;
+    char *d_out = nullptr, *h_out = nullptr;
+    int32_t *h_smp = nullptr;
+    // results
+    std::vector<ArrModelHost> pool;
+    std::map<ArrKey, std::vector<int>> cache;  // sample -> ids of its VALID models in the solver's order
+    long long stats[12] = {0};                 // [8] batches, [9] samples sent, [10] samples used
+
+    // Arrsac(5, thr^2, 500, 100, 14, 8) (modelest.cpp:270) and its members (arrsac.h:102-118)
+    static constexpr int kMinSample = 5, kMaxHyps = 500, kBlock = 100, kNonMin = 14, kNonMinMin = 8, kMaxInner = 20;
+    double sigma = 0.05, epsilon = 0.1;
+    static constexpr double kConf = 0.95, kTimeRatio = 250.0;
+    int verified_accum = 0, num_rejected = 0;
+    double rejected_accum = 0.0;
+    CvRng prosac_rng, random_rng;
+
+    static size_t out_bytes(int B) { return (size_t)B * 4 + (size_t)B * 40 + (size_t)B * 720 + (size_t)B * 10 * kArrFlagWords * 8 + 64; }
+
+    int alloc() {
+        void *p;
+        int rc;
+        if ((rc = ws_get(ctx, WS_AUX4, (size_t)kArrBatchCap * kArrSmpStride * 4, &p))) return rc;
+        d_smp = (int32_t *)p;
+        if ((rc = ws_get(ctx, WS_PARTIAL, (size_t)kArrBatchCap * sizeof(PolyRec), &p))) return rc;
+        d_recs = (PolyRec *)p;
+        if ((rc = ws_get(ctx, WS_AUX6, (size_t)kArrBatchCap * (72 + 8), &p))) return rc;
+        d_direct = (double *)p;
+        d_direct_ok = (int32_t *)(d_direct + (size_t)kArrBatchCap * 9);
+        d_nm5 = d_direct_ok + kArrBatchCap;
+        if ((rc = ws_get(ctx, WS_AUX5, out_bytes(kArrBatchCap), &p))) return rc;
+        d_out = (char *)p;
+        if ((rc = pinned_get(ctx, out_bytes(kArrBatchCap) + (size_t)kArrBatchCap * kArrSmpStride * 4, &p))) return rc;
+        h_out = (char *)p;
+        h_smp = (int32_t *)(h_out + out_bytes(kArrBatchCap));
+        return MLPL_OK;
+    }
+
+    // one device batch: every key not yet cached gets its entry
+    int run_batch(const std::vector<ArrKey> &keys) {
+        const int B = (int)keys.size();
+        if (B == 0) return MLPL_OK;
+        for (int b = 0; b < B; ++b) {
+            int32_t *sm = h_smp + (size_t)b * kArrSmpStride;
+            const int m = (int)keys[b].size() - 1;
+            sm[0] = m;
+            for (int i = 0; i < kArrMaxSample; ++i) sm[1 + i] = i < m ? keys[b][1 + i] : 0;
+            sm[15] = keys[b][0];
+        }
+        // layout of the result block: out_nm[B] | out_valid[B*10] | E_tab[B*90] | flags[B*10*16]
+        const size_t off_valid = (size_t)B * 4, off_E = ((size_t)B * 44 + 7) & ~(size_t)7, off_flags = off_E + (size_t)B * 720;
+        const size_t total = off_flags + (size_t)B * 10 * kArrFlagWords * 8;
+        int32_t *o_nm = (int32_t *)d_out, *o_valid = (int32_t *)(d_out + off_valid);
+        double *o_E = (double *)(d_out + off_E);
+        unsigned long long *o_flags = (unsigned long long *)(d_out + off_flags);
+        MLPL_HIP_TRY(hipMemcpyAsync(d_smp, h_smp, (size_t)B * kArrSmpStride * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(arrsac_sample_kernel, dim3(B), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_smp, B, d_recs, d_direct, d_direct_ok);
+        MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((B + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)d_recs, 0, B, o_E, d_nm5,
+                          (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+        hipLaunchKernelGGL(arrsac_check_kernel, dim3(B * 10), dim3(64), 0, s, pts, flag_points, d_p1, d_p2, (const int32_t *)d_smp, B, o_E,
+                           (const int32_t *)d_nm5, (const double *)d_direct, (const int32_t *)d_direct_ok, thresh2, o_nm, o_valid, o_flags);
+        MLPL_HIP_TRY(hipGetLastError());
+        MLPL_HIP_TRY(hipMemcpyAsync(h_out, d_out, total, hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipStreamSynchronize(s));
+        const int32_t *h_nm = (const int32_t *)h_out, *h_valid = (const int32_t *)(h_out + off_valid);
+        const double *h_E = (const double *)(h_out + off_E);
+        const uint64_t *h_flags = (const uint64_t *)(h_out + off_flags);
+        for (int b = 0; b < B; ++b) {
+            std::vector<int> ids;
+            // order of a sample's solutions: ascending E(0,0) under the sign convention of arrsac_check_kernel.  (The reference's order is
+            // cv::solvePoly's root order for a polynomial written in cv::SVD's null-space basis, which rounding noise decides.)
+            int order[10];
+            const int nm = std::min(h_nm[b], 10);
+            for (int i = 0; i < nm; ++i) order[i] = i;
+            std::stable_sort(order, order + nm, [&](int x, int y) { return h_E[((size_t)b * 10 + x) * 9] < h_E[((size_t)b * 10 + y) * 9]; });
+            for (int oi = 0; oi < nm; ++oi) {
+                const int slot = order[oi];
+                if (!h_valid[b * 10 + slot]) continue;
+                ArrModelHost mh;
+                std::memcpy(mh.E, h_E + ((size_t)b * 10 + slot) * 9, 72);
+                std::memcpy(mh.bits, h_flags + ((size_t)b * 10 + slot) * kArrFlagWords, sizeof(mh.bits));
+                ids.push_back((int)pool.size());
+                pool.push_back(mh);
+            }
+            cache.emplace(keys[b], std::move(ids));
+        }
+        stats[8]++;
+        stats[9] += B;
+        return MLPL_OK;
+    }
+
+    bool bit(int id, int i) const { return (pool[id].bits[i >> 6] >> (i & 63)) & 1; }
+
+    // ProsacSampler::Sample for sample number k over the first `count` correspondences (prosac_sampler.h:85-157)
+    static void prosac_sample(CvRng &rng, int count, int k, ArrKey &key) {
+        double t_n = 200000;
+        int nn = kMinSample;
+        for (int i = 0; i < kMinSample; i++) t_n *= static_cast<double>(nn - i) / (double)((size_t)count - i);
+        double t_n_prime = 1.0;
+        for (int t = 1; t <= k; t++) {
+            if (t > t_n_prime && nn < count) {
+                const double t_n_plus1 = (t_n * ((double)nn + 1.0)) / ((double)nn + 1.0 - (double)kMinSample);
+                t_n_prime += std::ceil(t_n_plus1 - t_n);
+                t_n = t_n_plus1;
+                nn++;
+            }
+        }
+        key.assign(1, 0);
+        const bool all_random = t_n_prime < k;
+        const int picks = all_random ? kMinSample : kMinSample - 1, range = all_random ? nn : nn - 1;
+        for (int i = 0; i < picks; i++) {
+            int r;
+            do r = rng.uniform(0, range);
+            while (std::find(key.begin() + 1, key.end(), r) != key.end());
+            key.push_back(r);
+        }
+        if (!all_random) key.push_back(nn - 1);
+    }
+    // RandomSampler::Sample (random_sampler.h:57-78): `size` distinct positions of the universe
+    static void random_sample(CvRng &rng, const std::vector<int> &universe, int size, int kind, ArrKey &key) {
+        key.assign(1, kind);
+        std::vector<int> used;
+        for (int i = 0; i < size; i++) {
+            int r;
+            do r = rng.uniform(0, (int)universe.size());
+            while (std::find(used.begin(), used.end(), r) != used.end());
+            used.push_back(r);
+            key.push_back(universe[r]);
+        }
+    }
+    static int to_int_x86(double v) { return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : INT_MIN; }  // cvttsd2si
+    static int hyps_needed(double eps, double power) {
+        return std::min(kMaxHyps, to_int_x86(std::ceil(std::log(1.0 - kConf) / std::log(1.0 - std::pow(eps, power)))));
+    }
+    static double sprt_threshold(double sg, double ep, int nmv) {  // sequential_probability_ratio.cc:38-62
+        const double c = (1.0 - sg) * std::log((1.0 - sg) / (1.0 - ep)) + sg * std::log(sg / ep);
+        const double a_0 = kTimeRatio * c / static_cast<double>(nmv) + 1.0;
+        double th = a_0;
+        for (int i = 0; i < 1000; i++) {
+            const double nt = a_0 + std::log(th);
+            const double step = std::fabs(nt - th);
+            th = nt;
+            if (step < 1e-4) break;
+        }
+        return th;
+    }
+    // SequentialProbabilityRatioTest over the first `count` correspondences, on the model's bit row
+    bool sprt(int id, int count, double dt, double *ratio, int *num_inl) const {
+        *num_inl = 0;
+        double lr = 1.0;
+        const double up = sigma / epsilon, down = (1.0 - sigma) / (1.0 - epsilon);
+        for (int i = 0; i < count; ++i) {
+            if (bit(id, i)) {
+                lr *= up;
+                *num_inl += 1;
+            } else {
+                lr *= down;
+            }
+            if (lr > dt) {
+                *ratio = static_cast<double>(*num_inl) / static_cast<double>(i + 1);
+                return false;
+            }
+        }
+        *ratio = static_cast<double>(*num_inl) / static_cast<double>(count);
+        return true;
+    }
+    void rejected(double ratio) {
+        rejected_accum += ratio;
+        num_rejected++;
+        const double st = rejected_accum / static_cast<double>(num_rejected);
+        if (st > 0) sigma = st;
+    }
+
+    struct Scored {
+        int id;
+        double score;
+    };
+    // diagnostics (mlpl_debug_arrsac_trace): 20 ints per turn of the first stage
+    void trace_turn(int k, int inner_turn, const ArrKey &key, int nvalid, const int *res) {
+        if (!ctx->arrsac_trace || ctx->arrsac_trace_len + 20 > ctx->arrsac_trace_cap) return;
+        int32_t *r = ctx->arrsac_trace + ctx->arrsac_trace_len;
+        r[0] = k, r[1] = inner_turn, r[2] = (int)key.size() - 1;
+        for (int i = 0; i < 5; ++i) r[3 + i] = key[1 + i];
+        r[8] = nvalid;
+        for (int i = 0; i < 10; ++i) r[9 + i] = i < nvalid ? res[i] : -1;
+        r[19] = 0;
+        ctx->arrsac_trace_len += 20;
+    }
+
+    // Arrsac::GenerateInitialHypothesisSet (arrsac.h:236-372)
+    int initial_set(int count, std::vector<Scored> &accepted, int *rc_out) {
+        int k = 1, k2 = 0, m_prime = kMaxHyps, inner_its = 0, max_num_inliers = 0, random_size = kNonMin;
+        bool inner = false;
+        std::vector<int> data;
+        ArrKey key;
+        while (k <= m_prime) {
+            // the sample of this turn, from the real streams
+            if (!inner) {
+                prosac_sample(prosac_rng, count, k, key);
+                stats[2]++;
+            } else {
+                const int kind = (random_size == kMinSample || random_size < kNonMinMin) ? 0 : 1;
+                random_sample(random_rng, data, random_size, kind, key);
+                stats[3]++;
+            }
+            auto it = cache.find(key);
+            if (it == cache.end()) {
+                // play the samplers forward under "no event" and solve what is coming in one batch
+                std::vector<ArrKey> batch(1, key);
+                CvRng pr = prosac_rng, rr = random_rng;
+                int kk = k + 1, its = inner_its;
+                bool in = inner;
+                if (in && ++its == kMaxInner) its = 0, in = false;
+                const int want = 64;
+                ArrKey nk;
+                while (kk <= m_prime && (int)batch.size() < want) {
+                    if (!in) {
+                        prosac_sample(pr, count, kk, nk);
+                    } else {
+                        const int kind = (random_size == kMinSample || random_size < kNonMinMin) ? 0 : 1;
+                        random_sample(rr, data, random_size, kind, nk);
+                        if (++its == kMaxInner) its = 0, in = false;
+                    }
+                    kk++;
+                    if (cache.find(nk) == cache.end() && std::find(batch.begin(), batch.end(), nk) == batch.end()) batch.push_back(nk);
+                }
+                if ((*rc_out = run_batch(batch))) return 0;
+                it = cache.find(key);
+            }
+            stats[10]++;
+            const std::vector<int> &hyps = it->second;
+            const int inner_turn = inner ? 1 : 0;
+            if (inner) {
+                inner_its++;
+                if (inner_its == kMaxInner) inner_its = 0, inner = false;
+            }
+            if (hyps.empty()) {
+                trace_turn(k, inner_turn, key, 0, nullptr);
+                k2++, k++;
+                continue;
+            }
+            verified_accum += (int)hyps.size();
+            const double dt = sprt_threshold(sigma, epsilon, verified_accum / (k - k2));
+            int res[10];
+            for (size_t j = 0; j < hyps.size(); j++) {
+                int num_inl;
+                double ratio;
+                const bool ok = sprt(hyps[j], count, dt, &ratio, &num_inl);
+                if (j < 10) res[j] = (ok ? 1000 : 0) + num_inl;
+                if (!ok) {
+                    rejected(ratio);
+                } else if (num_inl > max_num_inliers) {
+                    max_num_inliers = num_inl;
+                    accepted.push_back(Scored{hyps[j], (double)num_inl});
+                    if (num_inl > kMinSample) {
+                        inner = true;
+                        inner_its = 0;
+                        random_size = std::max(std::min(kNonMin, (int)std::floor((float)max_num_inliers / 2.0f)), kMinSample);
+                        data.clear();
+                        for (int i = 0; i < count; i++)
+                            if (bit(hyps[j], i)) data.push_back(i);
+                        epsilon = ratio == 1.0 ? 0.9999 : ratio;
+                        m_prime = hyps_needed(epsilon, (double)kMinSample);
+                        stats[4]++;
+                    }
+                } else {
+                    accepted.push_back(Scored{hyps[j], (double)num_inl});
+                }
+            }
+            trace_turn(k, inner_turn, key, (int)std::min<size_t>(hyps.size(), 10), res);
+            k++;
+        }
+        if (accepted.empty()) return 0;
+        return k - k2 - 1;
+    }
+
+    // Arrsac::Estimate (arrsac.h:375-547); returns the pool id of the best model or -1
+    int estimate(int *rc_out) {
+        const int sub_block = (int)std::floor((float)kBlock / 5.0);
+        const int kill_thresh = (int)std::floor(7.0 * (float)sub_block / 12.0);
+        std::vector<Scored> hyps;
+        int k = initial_set(std::min(n, kBlock), hyps, rc_out);
+        stats[0] = k, stats[1] = (long long)hyps.size();
+        if (*rc_out || k == 0) return -1;
+        if (n <= kBlock) {
+            double hi = 0.0;
+            int at = 0;
+            for (size_t i = 0; i < hyps.size(); i++)
+                if (hyps[i].score > hi) hi = hyps[i].score, at = (int)i;
+            return hyps[at].id;
+        }
+        auto cmp = [](Scored a, Scored b) { return a.score > b.score; };  // CompareScoredData (arrsac.h:82-84); std::sort as the reference
+        std::vector<int> all(n);
+        for (int i = 0; i < n; ++i) all[i] = i;
+        int nh = (int)hyps.size();
+        int i = kBlock;
+        for (; i < n; i++) {
+            if (i >= flag_points) {  // cannot happen: the hypothesis count halves every block (n1 below), one is left before 900
+                set_error("mlpl_arrsac_essential: preemptive stage ran past the %d tested correspondences", flag_points);
+                *rc_out = MLPL_E_FAILED;
+                return -1;
+            }
+            if ((i + 1) % kBlock == 0) {
+                std::sort(hyps.begin(), hyps.end(), cmp);
+                double max_inliers = hyps[0].score;
+                epsilon = max_inliers / static_cast<double>(i + 1);
+                if (epsilon == 1.0) epsilon = 0.9999;
+                int temp_max = hyps_needed(epsilon, (double)(i + 1));
+                if (temp_max > k) {
+                    int k2 = 0;
+                    ArrKey key;
+                    for (int j = 0; j < (long long)temp_max - k; j++) {
+                        random_sample(random_rng, all, kMinSample, 0, key);
+                        stats[5]++;
+                        auto it = cache.find(key);
+                        if (it == cache.end()) {  // the uniform sampler's future does not depend on any outcome
+                            std::vector<ArrKey> batch(1, key);
+                            CvRng rr = random_rng;
+                            ArrKey nk;
+                            for (int jj = j + 1, kk = k + 1; jj < (long long)temp_max - kk && (int)batch.size() < kArrBatchCap; ++jj, ++kk) {
+                                random_sample(rr, all, kMinSample, 0, nk);
+                                if (cache.find(nk) == cache.end()) batch.push_back(nk);
+                            }
+                            if ((*rc_out = run_batch(batch))) return -1;
+                            it = cache.find(key);
+                        }
+                        stats[10]++;
+                        const std::vector<int> &est = it->second;
+                        if (est.empty()) {
+                            k2++;
+                            continue;
+                        }
+                        verified_accum += (int)est.size();
+                        const double dt = sprt_threshold(sigma, epsilon, verified_accum / (k + j + 1 - k2));
+                        for (size_t m = 0; m < est.size(); m++) {
+                            int num_inl;
+                            double ratio;
+                            const bool ok = sprt(est[m], i + 1, dt, &ratio, &num_inl);
+                            if (!ok) {
+                                rejected(ratio);
+                            } else if (num_inl > (int)max_inliers) {
+                                hyps.push_back(Scored{est[m], (double)num_inl});
+                                max_inliers = static_cast<double>(num_inl);
+                                epsilon = ratio == 1.0 ? 0.9999 : ratio;
+                                temp_max = hyps_needed(epsilon, (double)(i + 1));
+                                if (temp_max <= (k + j + 1)) break;
+                            } else {
+                                hyps.push_back(Scored{est[m], (double)num_inl});
+                            }
+                        }
+                        k++;
+                    }
+                    nh = (int)hyps.size();
+                } else {
+                    const int n1 = std::max(1, (int)std::floor((float)k * std::pow(2.0, -1.0 * std::floor((float)(i + 1) / (float)kBlock))));
+                    if (n1 < static_cast<int>(hyps.size())) {
+                        hyps.resize(n1);
+                        nh = n1;
+                    }
+                }
+            } else if ((i + 1) % sub_block == 0) {
+                std::sort(hyps.begin(), hyps.end(), cmp);
+                int j = nh - 1;
+                for (; j > 0; j--)
+                    if (hyps[j - 1].score - hyps[j].score > kill_thresh) break;
+                nh = nh - j;
+                hyps.resize(nh);
+            }
+            if (nh == 1) break;
+            for (size_t j = 0; j < hyps.size(); j++)
+                if (bit(hyps[j].id, i)) hyps[j].score += 1.0;
+        }
+        stats[6] = i, stats[7] = nh;
+        return hyps[0].id;
+    }
+};
+
+}  // namespace
+
+int arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thresh, int refine, uint64_t *rng_state,
+                         double *E, uint8_t *d_mask, int *n_inliers, hipStream_t s) {
+    ArrsacRun R;
+    R.ctx = ctx, R.s = s, R.d_p1 = d_p1, R.d_p2 = d_p2, R.n = n;
+    R.flag_points = std::min(n, kArrFlagPoints);
+    R.thresh2 = thresh * thresh;
+    R.prosac_rng.state = rng_state[0], R.random_rng.state = rng_state[1];
+    int rc;
+    double4 *pts = nullptr;
+    if ((rc = pack_points(ctx, d_p1, d_p2, n, &pts, s))) return rc;
+    R.pts = pts;
+    if ((rc = R.alloc())) return rc;
+    void *p;
+    if ((rc = ws_get(ctx, WS_AUX7, 256, &p))) return rc;
+    double *d_E = (double *)p;           // [0..8] best model, [9..17] refined
+    int32_t *d_info = (int32_t *)(d_E + 18);  // [0] inlier count, [1..2] refinement info
+    rc = MLPL_OK;
+    const int best = R.estimate(&rc);
+    rng_state[0] = R.prosac_rng.state, rng_state[1] = R.random_rng.state;
+    std::memcpy(ctx->last_arrsac_stats, R.stats, sizeof(ctx->last_arrsac_stats));
+    if (rc) return rc;
+    if (n_inliers) *n_inliers = 0;
+    if (best < 0) {
+        set_error("mlpl_arrsac_essential: no hypothesis passed the sequential test");
+        return MLPL_E_FAILED;
+    }
+    // findInliers with the best model (modelest.cpp:274), then the reference's plausibility test (:275-278)
+    MLPL_HIP_TRY(hipMemcpyAsync(d_E, R.pool[best].E, 72, hipMemcpyHostToDevice, s));
+    MLPL_HIP_TRY(hipMemsetAsync(d_info, 0, 16, s));
+    hipLaunchKernelGGL(inlier_mask_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double4 *)pts, n, (const double *)d_E,
+                       R.thresh2, d_mask, d_info);
+    if (refine)  // the kernel itself returns the initial matrix below 50 inliers, as the reference does (modelest.cpp:304-309)
+        hipLaunchKernelGGL(arrsac_refine_kernel, dim3(1), dim3(1024), 0, s, (const double4 *)pts, (const uint8_t *)d_mask, n,
+                           (const double *)d_E, thresh / 50.0, d_E + 9, d_info + 1);
+    MLPL_HIP_TRY(hipGetLastError());
+    void *hp;
+    if ((rc = pinned_get(ctx, 256, &hp))) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(hp, d_E, 256, hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipStreamSynchronize(s));
+    const double *hE = (const double *)hp;
+    const int32_t *hinfo = (const int32_t *)(hE + 18);
+    const int good = hinfo[0];
+    if (n_inliers) *n_inliers = good;
+    ctx->last_arrsac_stats[11] = refine ? hinfo[1] : -1;
+    if ((good < 50 && n > 200) || good < 15) {
+        set_error("mlpl_arrsac_essential: the best hypothesis has too few inliers (%d)", good);
+        return MLPL_E_FAILED;
+    }
+    // with `refine` the reference always takes the refined matrix (its acceptance test compares the unrefined model's inlier count
+    // with itself, modelest.cpp:312-318) and keeps the unrefined model's mask
+    std::memcpy(E, (refine && good >= 50) ? hE + 9 : hE, 72);
+    return MLPL_OK;
+}

@@ -107,6 +107,9 @@ struct mlpl_ctx {
     int ransac_force_table;        // 1 = build the host niters table (fallback / tests)
     long long ransac_table_fallbacks;  // calls redone on the host table because a device-evaluated bound differed
     long long last_ransac_models, last_ransac_iters;  // statistics of the last mlpl_ransac_essential* call
+    int32_t *arrsac_trace;                             // diagnostics: host buffer for the turn records of ARRSAC's first stage
+    int arrsac_trace_cap, arrsac_trace_len;
+    long long last_arrsac_stats[12];                   // ... of the last mlpl_arrsac_essential* call (mlpl_arrsac_last_stats)
     // optional per-kernel hipEvent bracketing (mlpl_profile_*)
     int prof_on;
     hipEvent_t *prof_ev[MLPL_PROF_NUM];  // pairs: [2*i] start, [2*i+1] stop

@@ -36,6 +36,7 @@
 #include <climits>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "mlpl_internal.h"
@@ -672,23 +673,8 @@ __global__ __launch_bounds__(64) void roots_kernel_t(const PolyRec *__restrict__
         else hipLaunchKernelGGL(roots_kernel_t<false>, grid, dim3(64), 0, stream, __VA_ARGS__);                  \
     } while (0)
 
-__global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
-                                                      const int32_t *__restrict__ samples, int sample_offset, int n_samples,
-                                                      PolyRec *__restrict__ recs /* indexed from sample_offset */) {
-    __shared__ SolveLds L;
-    if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
-    const int lane = threadIdx.x;
-    const int sample = sample_offset + blockIdx.x;
-    if (sample >= n_samples) return;
-
-    // ---- 1a. epipolar rows Q[i] = [x1x2, y1x2, x2, x1y2, y1y2, y2, x1, y1, 1]  (five-point.cpp:375-383) ----
-    if (lane < 5) {
-        const int idx = samples[sample * 5 + lane];
-        const double x1 = p1[2 * idx], y1 = p1[2 * idx + 1], x2 = p2[2 * idx], y2 = p2[2 * idx + 1];
-        double *r = L.Q[lane];
-        r[0] = x1 * x2, r[1] = y1 * x2, r[2] = x2, r[3] = x1 * y2, r[4] = y1 * y2, r[5] = y2, r[6] = x1, r[7] = y1, r[8] = 1.0;
-    }
-    wave_sync();
+// Null-space basis of the five epipolar rows in L.Q (one wave): Householder QR of Q^T, then n_j = H_0 ... H_4 e_{5+j}.
+__device__ __forceinline__ void householder_basis(SolveLds &L, int lane) {
     // ---- 1b. Householder QR of M = Q^T (9x5): M[r][c] = L.Q[c][r] ----
     for (int k = 0; k < 5; ++k) {
         double nrm2 = 0;
@@ -738,6 +724,26 @@ __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__
         wave_sync();
     }
 
+}
+
+__global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
+                                                      const int32_t *__restrict__ samples, int sample_offset, int n_samples,
+                                                      PolyRec *__restrict__ recs /* indexed from sample_offset */) {
+    __shared__ SolveLds L;
+    if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
+    const int lane = threadIdx.x;
+    const int sample = sample_offset + blockIdx.x;
+    if (sample >= n_samples) return;
+
+    // ---- 1a. epipolar rows Q[i] = [x1x2, y1x2, x2, x1y2, y1y2, y2, x1, y1, 1]  (five-point.cpp:375-383) ----
+    if (lane < 5) {
+        const int idx = samples[sample * 5 + lane];
+        const double x1 = p1[2 * idx], y1 = p1[2 * idx + 1], x2 = p2[2 * idx], y2 = p2[2 * idx + 1];
+        double *r = L.Q[lane];
+        r[0] = x1 * x2, r[1] = y1 * x2, r[2] = x2, r[3] = x1 * y2, r[4] = y1 * y2, r[5] = y2, r[6] = x1, r[7] = y1, r[8] = 1.0;
+    }
+    wave_sync();
+    householder_basis(L, lane);
     solve_from_basis(L, lane, recs + (sample - sample_offset));
 }
 
@@ -1476,43 +1482,25 @@ __global__ __launch_bounds__(256) void gram_kernel(const double4 *__restrict__ p
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restrict__ gram_part, int nparts,
-                                                         PolyRec *__restrict__ rec) {
-    __shared__ SolveLds L;
-    __shared__ double G[9][9], Vv[9][9], gsum[45];
-    if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
-    const int lane = threadIdx.x;
-    if (lane < 45) {  // fixed summation order over the blocks: run-to-run deterministic
-        double sacc = 0;
-        for (int pblk = 0; pblk < nparts; ++pblk) sacc += gram_part[(size_t)pblk * 45 + lane];
-        gsum[lane] = sacc;
-    }
-    wave_sync();
-    if (lane == 0) {
-        int t = 0;
-        for (int a = 0; a < 9; ++a)
-            for (int b = a; b < 9; ++b) {
-                G[a][b] = gsum[t];
-                G[b][a] = gsum[t];
-                ++t;
-            }
-    }
-    for (int e = lane; e < 81; e += 64) Vv[e / 9][e % 9] = (e / 9 == e % 9) ? 1.0 : 0.0;
-    wave_sync();
+struct Jacobi9Lds {
+    double G[9][9], Vv[9][9], Gn[9][9], Vn[9][9];
+    int partner[10], ring[10];
+    double cself[10], cpart[10];
+};
+
+// Eigen-decomposition of the symmetric 9x9 J.G by one wave: on return J.G is diagonal (the eigenvalues, unordered) and the columns
+// of J.Vv are the eigenvectors.  J.Vv must hold the identity on entry.
+__device__ __forceinline__ void jacobi9_wave(Jacobi9Lds &J, int lane) {
     // Jacobi eigenvalue iteration on the symmetric 9x9 in the parallel (round-robin) ordering: the 9 indices plus one idle
     // slot form 5 disjoint pairs per round, 9 rounds visit all 36 pairs once (= one sweep).  Lanes 0..4 compute the rotations
     // of a round, then all lanes apply J^T G J and V J element-wise (disjoint rotations commute).
-    __shared__ int partner[10];
-    __shared__ double cself[10], cpart[10];
-    __shared__ int ring[10];
-    __shared__ double Gn[9][9], Vn[9][9];
-    if (lane < 10) ring[lane] = lane;
+    if (lane < 10) J.ring[lane] = lane;
     wave_sync();
     for (int sweep = 0; sweep < 60; ++sweep) {
         // off-diagonal mass against the diagonal (wave reduction; every lane gets the totals)
         double off = 0, diag = 0;
         for (int e = lane; e < 81; e += 64) {
-            const double v = G[e / 9][e % 9];
+            const double v = J.G[e / 9][e % 9];
             if (e / 9 == e % 9)
                 diag += v * v;
             else if (e / 9 < e % 9)
@@ -1526,54 +1514,81 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
         if (off <= 1e-32 * diag) break;  // wave-uniform
         for (int round = 0; round < 9; ++round) {
             if (lane < 5) {
-                const int p0 = ring[lane], q0 = ring[9 - lane];
+                const int p0 = J.ring[lane], q0 = J.ring[9 - lane];
                 const int p = min(p0, q0), q = max(p0, q0);
                 double c = 1.0, sn = 0.0;
                 if (q < 9) {
-                    const double apq = G[p][q];
+                    const double apq = J.G[p][q];
                     if (apq != 0.0) {
-                        const double theta = (G[q][q] - G[p][p]) / (2.0 * apq);
+                        const double theta = (J.G[q][q] - J.G[p][p]) / (2.0 * apq);
                         const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                         c = 1.0 / sqrt(tt * tt + 1.0);
                         sn = tt * c;
                     }
                 }
                 // column p' = c col_p - s col_q ; column q' = s col_p + c col_q
-                partner[p] = q;
-                cself[p] = c;
-                cpart[p] = -sn;
-                partner[q] = p;
-                cself[q] = c;
-                cpart[q] = sn;
+                J.partner[p] = q;
+                J.cself[p] = c;
+                J.cpart[p] = -sn;
+                J.partner[q] = p;
+                J.cself[q] = c;
+                J.cpart[q] = sn;
             }
             wave_sync();
             for (int e = lane; e < 81; e += 64) {
                 const int a = e / 9, b = e % 9;
-                const int pa = partner[a], pb = partner[b];
-                const double ca = cself[a], ka = cpart[a], cb = cself[b], kb = cpart[b];
+                const int pa = J.partner[a], pb = J.partner[b];
+                const double ca = J.cself[a], ka = J.cpart[a], cb = J.cself[b], kb = J.cpart[b];
                 // an index paired with the idle slot keeps c = 1, k = 0; its partner index (9) is never read with weight
-                const double gab = G[a][b];
-                const double gapb = (pb < 9) ? G[a][pb] : 0.0;
-                const double gpab = (pa < 9) ? G[pa][b] : 0.0;
-                const double gpapb = (pa < 9 && pb < 9) ? G[pa][pb] : 0.0;
-                Gn[a][b] = ca * cb * gab + ca * kb * gapb + ka * cb * gpab + ka * kb * gpapb;
-                const double vab = Vv[a][b];
-                const double vapb = (pb < 9) ? Vv[a][pb] : 0.0;
-                Vn[a][b] = cb * vab + kb * vapb;
+                const double gab = J.G[a][b];
+                const double gapb = (pb < 9) ? J.G[a][pb] : 0.0;
+                const double gpab = (pa < 9) ? J.G[pa][b] : 0.0;
+                const double gpapb = (pa < 9 && pb < 9) ? J.G[pa][pb] : 0.0;
+                J.Gn[a][b] = ca * cb * gab + ca * kb * gapb + ka * cb * gpab + ka * kb * gpapb;
+                const double vab = J.Vv[a][b];
+                const double vapb = (pb < 9) ? J.Vv[a][pb] : 0.0;
+                J.Vn[a][b] = cb * vab + kb * vapb;
             }
             wave_sync();
             for (int e = lane; e < 81; e += 64) {
-                G[e / 9][e % 9] = Gn[e / 9][e % 9];
-                Vv[e / 9][e % 9] = Vn[e / 9][e % 9];
+                J.G[e / 9][e % 9] = J.Gn[e / 9][e % 9];
+                J.Vv[e / 9][e % 9] = J.Vn[e / 9][e % 9];
             }
             if (lane == 0) {  // rotate the ring: slot 0 stays, the others move one place
-                const int last = ring[9];
-                for (int k = 9; k > 1; --k) ring[k] = ring[k - 1];
-                ring[1] = last;
+                const int last = J.ring[9];
+                for (int k = 9; k > 1; --k) J.ring[k] = J.ring[k - 1];
+                J.ring[1] = last;
             }
             wave_sync();
         }
     }
+}
+
+__global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restrict__ gram_part, int nparts,
+                                                         PolyRec *__restrict__ rec) {
+    __shared__ SolveLds L;
+    __shared__ Jacobi9Lds J;
+    __shared__ double gsum[45];
+    if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
+    const int lane = threadIdx.x;
+    if (lane < 45) {  // fixed summation order over the blocks: run-to-run deterministic
+        double sacc = 0;
+        for (int pblk = 0; pblk < nparts; ++pblk) sacc += gram_part[(size_t)pblk * 45 + lane];
+        gsum[lane] = sacc;
+    }
+    wave_sync();
+    if (lane == 0) {
+        int t = 0;
+        for (int a = 0; a < 9; ++a)
+            for (int b = a; b < 9; ++b) {
+                J.G[a][b] = gsum[t];
+                J.G[b][a] = gsum[t];
+                ++t;
+            }
+    }
+    for (int e = lane; e < 81; e += 64) J.Vv[e / 9][e % 9] = (e / 9 == e % 9) ? 1.0 : 0.0;
+    wave_sync();
+    jacobi9_wave(J, lane);
     if (lane == 0) {
         // order eigenvalues descending; EE = eigenvectors of the 4 smallest, in descending order (five-point.cpp:388)
         int order[9];
@@ -1581,13 +1596,13 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
         for (int a = 0; a < 8; ++a) {
             int best = a;
             for (int b = a + 1; b < 9; ++b)
-                if (G[order[b]][order[b]] > G[order[best]][order[best]]) best = b;
+                if (J.G[order[b]][order[b]] > J.G[order[best]][order[best]]) best = b;
             const int t2 = order[a];
             order[a] = order[best];
             order[best] = t2;
         }
         for (int j = 0; j < 4; ++j)
-            for (int r = 0; r < 9; ++r) L.EE[j][r] = Vv[r][order[5 + j]];
+            for (int r = 0; r < 9; ++r) L.EE[j][r] = J.Vv[r][order[5 + j]];
     }
     wave_sync();
     solve_from_basis(L, lane, rec);
@@ -2120,6 +2135,8 @@ static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
     return MLPL_OK;
 }
 
+#include "arrsac_impl.h"
+
 void free_rand_cache(void *p) { delete static_cast<RandCache *>(p); }
 
 }  // namespace mlpl
@@ -2608,6 +2625,51 @@ int mlpl_lmeds_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int 
     if (rc && rc != MLPL_E_FAILED) return rc;
     MLPL_HIP_TRY(hipMemcpy(mask, dmask, (size_t)n, hipMemcpyDeviceToHost));
     return rc;
+}
+
+int mlpl_arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thresh, int refine,
+                              uint64_t rng_state[2], double E[9], uint8_t *d_mask, int *n_inliers, void *stream) {
+    if (!ctx || !d_p1 || !d_p2 || !E || !d_mask || !rng_state || n < 6 || !(thresh > 0)) {
+        set_error("mlpl_arrsac_essential_dev: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    return arrsac_essential_dev(ctx, d_p1, d_p2, n, thresh, refine, rng_state, E, d_mask, n_inliers, pick_stream(ctx, stream));
+}
+
+int mlpl_arrsac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n, double thresh, int refine, uint64_t rng_state[2],
+                          double E[9], uint8_t *mask, int *n_inliers) {
+    if (!ctx || !p1 || !p2 || !E || !mask || !rng_state || n < 6 || !(thresh > 0)) {
+        set_error("mlpl_arrsac_essential: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    void *dp1, *dp2, *dmask;
+    int rc;
+    if ((rc = ws_get(ctx, WS_AUX0, (size_t)n * 16, &dp1))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX1, (size_t)n * 16, &dp2))) return rc;
+    if ((rc = ws_get(ctx, WS_MATCH, (size_t)n, &dmask))) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(dp1, p1, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    MLPL_HIP_TRY(hipMemcpyAsync(dp2, p2, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    rc = arrsac_essential_dev(ctx, (const double *)dp1, (const double *)dp2, n, thresh, refine, rng_state, E, (uint8_t *)dmask, n_inliers,
+                              ctx->stream);
+    // the mask is meaningful whenever a hypothesis was found, also when its inlier count fails the final test
+    if (rc && !(rc == MLPL_E_FAILED && n_inliers && *n_inliers > 0)) return rc;
+    MLPL_HIP_TRY(hipMemcpy(mask, dmask, (size_t)n, hipMemcpyDeviceToHost));
+    return rc;
+}
+
+int mlpl_debug_arrsac_trace(mlpl_ctx *ctx, int32_t *buf, int cap) {
+    if (!ctx) return MLPL_E_BAD_INPUT;
+    const int len = ctx->arrsac_trace_len;
+    ctx->arrsac_trace = buf, ctx->arrsac_trace_cap = buf ? cap : 0, ctx->arrsac_trace_len = 0;
+    return len;
+}
+
+int mlpl_arrsac_last_stats(mlpl_ctx *ctx, long long stats[12]) {
+    if (!ctx || !stats) return MLPL_E_BAD_INPUT;
+    std::memcpy(stats, ctx->last_arrsac_stats, sizeof(ctx->last_arrsac_stats));
+    return MLPL_OK;
 }
 
 }  // extern "C"

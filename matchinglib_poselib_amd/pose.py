@@ -108,6 +108,32 @@ def lmeds_essential(p1, p2, confidence: float = 0.999, max_iters: int = 2000, se
     return dict(ok=(rc == 0), E=E, mask=mask, n_inliers=ninl.value, min_median=med.value)
 
 
+# The reference's ARRSAC samplers draw from two function-local `static cv::RNG rng;` (prosac_sampler.h:115, random_sampler.h:65) that
+# live as long as the process: this pair is their mirror for callers that do not keep their own.
+ARRSAC_RNG_FRESH = (0xFFFFFFFF, 0xFFFFFFFF)
+_arrsac_rng_state = np.array(ARRSAC_RNG_FRESH, np.uint64)
+
+
+def arrsac_essential(p1, p2, thresh: float, refine: bool = True, rng_state=None, ctx: Optional[Context] = None) -> dict:
+    """CvModelEstimator3::runARRSAC (modelest.cpp:197-341) as findEssentialMat(ARRSAC) drives it.  rng_state: uint64[2] array
+    (updated in place) = the two cv::RNG states; None = the process-wide pair, as the reference's statics."""
+    ctx = ctx or default_context()
+    p1, p2 = _pts(p1), _pts(p2)
+    n = p1.shape[0]
+    st = _arrsac_rng_state if rng_state is None else rng_state
+    assert st.dtype == np.uint64 and st.shape == (2,) and st.flags.c_contiguous
+    E = np.zeros((3, 3))
+    mask = np.zeros(n, np.uint8)
+    ninl = C.c_int(0)
+    rc = ctx.lib.mlpl_arrsac_essential(ctx.handle, p1.ctypes.data, p2.ctypes.data, n, float(thresh), 1 if refine else 0, st.ctypes.data,
+                                       E.ctypes.data, mask.ctypes.data, C.addressof(ninl))
+    if rc not in (0, _lib.MLPL_E_FAILED):
+        raise MlplError(rc, "mlpl_arrsac_essential", _lib.last_error())
+    stats = np.zeros(12, np.int64)
+    ctx.lib.mlpl_arrsac_last_stats(ctx.handle, stats.ctypes.data)
+    return dict(ok=(rc == 0), E=E, mask=mask, n_inliers=ninl.value, stats=stats)
+
+
 def ransac_essential_device(p1, p2, thresh: float, confidence: float = 0.999, max_iters: int = 1000, refit: bool = True,
                             seed: int = 0, ctx: Optional[Context] = None, mask_out=None, stream: Optional[int] = None) -> dict:
     """Same as ransac_essential on device-resident torch tensors (float64 [n,2]); the mask stays on the device."""
@@ -133,11 +159,11 @@ def estimateEssentialMat(p1, p2, method: str = "ARRSAC", threshold: float = PIX_
                          seed: Optional[int] = None, ctx: Optional[Context] = None):
     """poselib::estimateEssentialMat (pose_estim.h:204-210, pose_estim.cpp:857-890) -> (ok, E, mask).
 
-    "RANSAC" (the hot path) and "LMEDS" are built in this library.  Like the reference, "USAC" and unknown method
-    names are fatal (the reference prints and calls exit(1), pose_estim.cpp:878-887): SystemExit(1) is raised.
-    "ARRSAC" (the reference's default) is outside the hot path: NotImplementedError.
-    `seed` = None mirrors the reference's std::srand(std::time(nullptr)) (modelest.cpp:58)."""
-    if method in ("RANSAC", "LMEDS"):
+    "RANSAC" (the hot path), "LMEDS" and "ARRSAC" (the reference's default) are built in this library.  Like the reference, "USAC"
+    and unknown method names are fatal (the reference prints and calls exit(1), pose_estim.cpp:878-887): SystemExit(1) is raised.
+    `seed` = None mirrors the reference's std::srand(std::time(nullptr)) (modelest.cpp:58); ARRSAC takes no seed (its cv::RNG
+    streams are process-wide, see arrsac_essential)."""
+    if method in ("RANSAC", "LMEDS", "ARRSAC"):
         import time
 
         a, b = _pts(p1), _pts(p2)
@@ -146,14 +172,15 @@ def estimateEssentialMat(p1, p2, method: str = "ARRSAC", threshold: float = PIX_
             # mask all true
             Es, nm = solve_5pt(a, b, np.arange(5, dtype=np.int32)[None, :], ctx=ctx)
             return True, Es[0, : nm[0]].reshape(-1, 3).copy(), np.ones(5, np.uint8)
+        if method == "ARRSAC":
+            r = arrsac_essential(p1, p2, threshold, refine=refine, ctx=ctx)
+            return r["ok"], r["E"], r["mask"]
         s = int(time.time()) if seed is None else seed
         if method == "LMEDS":  # no least-squares refit on this branch (pose_estim.cpp:874-877)
             r = lmeds_essential(p1, p2, confidence=0.999, max_iters=2000, seed=s, ctx=ctx)
         else:
             r = ransac_essential(p1, p2, threshold, confidence=0.999, max_iters=1000, refit=refine, seed=s, ctx=ctx)
         return r["ok"], r["E"], r["mask"]
-    if method == "ARRSAC":
-        raise NotImplementedError(f"{method} is not built here (RANSAC and LMEDS are)")
     if method == "USAC":
         print("USAC must be executed by function estimateEssentialOrPoseUSAC as it needs additional paramters! Exiting.")
     else:

@@ -158,6 +158,24 @@ int oracle_remove_lens_dist(float *points1, float *points2, int n, const double 
 int oracle_get_inliers_strict(const double *p1, const double *p2, int n, const double *E, double th2, double *err,
                               unsigned char *mask);
 
+/* ---- ARRSAC (arrsac_oracle.cpp; SURVEY 8(f) rank 4, first half): P/source/five-point-nister/modelest.cpp:111-341,
+ *      P/include/arrsac/{arrsac,prosac_sampler,random_sampler,sequential_probability_ratio}.h, P/source/pose_estim.cpp:337-792 ---- */
+/* cv::RNG: `count` values of next(), *state updated. */
+void oracle_cv_rng_stream(uint64_t *state, int count, uint32_t *out);
+/* Eigen::JacobiSVD<Matrix3d>(M, ComputeFullU | ComputeFullV): M = U diag(sv) V^T, row-major, Eigen's column signs. */
+void oracle_eigen_svd3(const double *M, double *sv, double *U, double *V);
+/* CvEMEstimator::ValidModel (five-point.cpp:534-601) on the m sample correspondences q1, q2 (m x 2). */
+int oracle_valid_model(const double *q1, const double *q2, int m, const double *E);
+/* cv::findFundamentalMat(q1, q2, FM_8POINT), m >= 8 (float32 input rounding as OpenCV); returns 0 when degenerate. */
+int oracle_cv_fm_8point(const double *q1, const double *q2, int m, double *F);
+double oracle_sprt_threshold(double sigma, double epsilon, double time_ratio, int num_models_verified);
+int oracle_robust_essential_refine(const double *p1, const double *p2, int n, const double *E_init, double th, double *E_refined,
+                                   double *err2);
+int oracle_arrsac_essential(const double *p1, const double *p2, int n, double thresh, int refine, uint64_t *rng_state, double *E,
+                            uint8_t *mask, int *n_inliers, int64_t *stats);
+void oracle_std_sort_desc(const double *score, int n, int32_t *perm);
+int oracle_arrsac_trace(int32_t *buf, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -202,6 +202,61 @@ class Oracle:
         self.lib.oracle_solve_poly(c.ctypes.data, deg, r.ctypes.data, 0)
         return r[:, 0] + 1j * r[:, 1]
 
+    # ---- ARRSAC (arrsac_oracle.cpp) ----
+    def arrsac_essential(self, p1, p2, thresh, refine=True, rng_state=None):
+        """runARRSAC as findEssentialMat drives it; rng_state = uint64[2] (updated in place), None = a fresh process."""
+        p1 = np.ascontiguousarray(p1, np.float64)
+        p2 = np.ascontiguousarray(p2, np.float64)
+        n = p1.shape[0]
+        st = np.array([0xFFFFFFFF, 0xFFFFFFFF], np.uint64) if rng_state is None else rng_state
+        E, mask, ninl, stats = np.zeros((3, 3)), np.zeros(n, np.uint8), C.c_int(0), np.zeros(8, np.int64)
+        f = self.lib.oracle_arrsac_essential
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        ok = f(p1.ctypes.data, p2.ctypes.data, n, float(thresh), 1 if refine else 0, st.ctypes.data, E.ctypes.data, mask.ctypes.data,
+               C.addressof(ninl), stats.ctypes.data)
+        return dict(ok=bool(ok), E=E, mask=mask, n_inliers=ninl.value, stats=stats, rng_state=st)
+
+    def eigen_svd3(self, M):
+        M = np.ascontiguousarray(M, np.float64)
+        sv, U, V = np.zeros(3), np.zeros((3, 3)), np.zeros((3, 3))
+        self.lib.oracle_eigen_svd3.argtypes = [C.c_void_p] * 4
+        self.lib.oracle_eigen_svd3(M.ctypes.data, sv.ctypes.data, U.ctypes.data, V.ctypes.data)
+        return sv, U, V
+
+    def valid_model(self, q1, q2, E):
+        q1, q2, E = (np.ascontiguousarray(a, np.float64) for a in (q1, q2, E))
+        self.lib.oracle_valid_model.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        return bool(self.lib.oracle_valid_model(q1.ctypes.data, q2.ctypes.data, len(q1), E.ctypes.data))
+
+    def cv_fm_8point(self, q1, q2):
+        q1, q2 = (np.ascontiguousarray(a, np.float64) for a in (q1, q2))
+        F = np.zeros((3, 3))
+        self.lib.oracle_cv_fm_8point.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        ok = self.lib.oracle_cv_fm_8point(q1.ctypes.data, q2.ctypes.data, len(q1), F.ctypes.data)
+        return bool(ok), F
+
+    def cv_rng_stream(self, state, count):
+        st = np.array([state], np.uint64)
+        out = np.zeros(count, np.uint32)
+        self.lib.oracle_cv_rng_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self.lib.oracle_cv_rng_stream(st.ctypes.data, count, out.ctypes.data)
+        return out, int(st[0])
+
+    def robust_essential_refine(self, p1, p2, E_init, th):
+        p1, p2, E_init = (np.ascontiguousarray(a, np.float64) for a in (p1, p2, E_init))
+        E, err = np.zeros((3, 3)), np.zeros(2)
+        f = self.lib.oracle_robust_essential_refine
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+        it = f(p1.ctypes.data, p2.ctypes.data, len(p1), E_init.ctypes.data, float(th), E.ctypes.data, err.ctypes.data)
+        return it, E, err
+
+    def std_sort_desc(self, score):
+        score = np.ascontiguousarray(score, np.float64)
+        perm = np.zeros(len(score), np.int32)
+        self.lib.oracle_std_sort_desc.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self.lib.oracle_std_sort_desc(score.ctypes.data, len(score), perm.ctypes.data)
+        return perm
+
     # ---- matching ----
     def knn_hamming(self, q, t, k=2):
         q = np.ascontiguousarray(q, np.uint8)
@@ -280,7 +335,7 @@ _cached = None
 def load() -> Oracle:
     global _cached
     if _cached is None:
-        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith(("_oracle.c", ".h"))]
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith(("_oracle.c", "_oracle.cpp", ".h"))]
         if not os.path.exists(LIB) or any(os.path.getmtime(f) > os.path.getmtime(LIB) for f in srcs):
             subprocess.run(["make", "-C", ORACLE_DIR], check=True, stdout=subprocess.DEVNULL)
         _cached = Oracle(C.CDLL(LIB))
