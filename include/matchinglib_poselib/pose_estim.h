@@ -2,6 +2,7 @@
 // ConfigUSAC :94-132, getPoseTriangPts :192-200, estimateEssentialMat :204-210).  Same names, argument order, defaults and error
 // behaviour; the work runs on the MI355X through libmlpl_hip.so (include/mlpl_c.h).
 #pragma once
+#include <cstdint>
 #include <string>
 #include <vector>
 
@@ -83,10 +84,18 @@ struct ConfigUSAC {
 void setRansacSeed(unsigned seed);
 void clearRansacSeed();
 
+// ARRSAC draws from two cv::RNG streams that are function-local statics in the reference (include/arrsac/prosac_sampler.h:115,
+// random_sampler.h:65): process-wide, default-seeded (0xffffffff), never reset -- the n-th ARRSAC call of a program continues where the
+// (n-1)-th stopped.  The library keeps the same process-wide pair; these two functions let a test or a caller that wants reproducible
+// runs read and set it.
+void setArrsacRngState(uint64_t prosac_state, uint64_t uniform_state);
+void getArrsacRngState(uint64_t *prosac_state, uint64_t *uniform_state);
+
 // poselib::estimateEssentialMat (pose_estim.h:204-210, pose_estim.cpp:857-890).  p1, p2: n x 2 camera coordinates (CV_64F or CV_32F).
 // "RANSAC": 1000 iterations, confidence 0.999, `refine` = least-squares refit on the inliers; "LMEDS": 2000 iterations, no refit,
 // `threshold` unused (as in the reference); "ARRSAC" (the default): the reference's preemptive estimator (modelest.cpp:197-341) with
-// `refine` = its least-squares step.  "USAC" / unknown method: prints the reference's message and calls exit(1), like the reference.
+// `refine` = robustEssentialRefine on the winner's inliers (pose_estim.cpp:866-869).  "USAC" / unknown method: prints the reference's
+// message and calls exit(1), like the reference.
 bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p2, const std::string &method = "ARRSAC",
                           double threshold = PIX_MIN_GOOD_TH, bool refine = true, cv::OutputArray mask = cv::noArray());
 

@@ -951,7 +951,7 @@ int arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, 
     const int32_t *hinfo = (const int32_t *)(hE + 18);
     const int good = hinfo[0];
     if (n_inliers) *n_inliers = good;
-    ctx->last_arrsac_stats[11] = refine ? hinfo[1] : -1;
+    ctx->last_arrsac_stats[11] = refine ? hinfo[2] : -1;
     if ((good < 50 && n > 200) || good < 15) {
         set_error("mlpl_arrsac_essential: the best hypothesis has too few inliers (%d)", good);
         return MLPL_E_FAILED;

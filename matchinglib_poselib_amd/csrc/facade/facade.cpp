@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <ctime>
 #include <iostream>
+#include <mutex>
+#include <string>
 
 #include "matchinglib_poselib/matchinglib_matchers.h"
 #include "matchinglib_poselib/pose_estim.h"
@@ -128,9 +130,23 @@ void setRansacSeed(unsigned seed) {
 }
 void clearRansacSeed() { g_seed_fixed = false; }
 
+namespace {
+std::mutex g_arrsac_mutex;
+uint64_t g_arrsac_rng[2] = {0xffffffffull, 0xffffffffull};  // cv::RNG's default state
+}  // namespace
+
+void setArrsacRngState(uint64_t prosac_state, uint64_t uniform_state) {
+    std::lock_guard<std::mutex> lock(g_arrsac_mutex);
+    g_arrsac_rng[0] = prosac_state, g_arrsac_rng[1] = uniform_state;
+}
+void getArrsacRngState(uint64_t *prosac_state, uint64_t *uniform_state) {
+    std::lock_guard<std::mutex> lock(g_arrsac_mutex);
+    *prosac_state = g_arrsac_rng[0], *uniform_state = g_arrsac_rng[1];
+}
+
 bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p2, const std::string &method,
                           double threshold, bool refine, cv::OutputArray mask) {
-    if (method == "RANSAC" || method == "LMEDS") {
+    if (method == "RANSAC" || method == "LMEDS" || method == "ARRSAC") {
         if (!E.needed()) return false;  // five-point.cpp:143-144
         int n1 = 0, n2 = 0;
         std::vector<double> a = points64(p1, n1), b = points64(p2, n2);
@@ -158,10 +174,18 @@ bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p
         const unsigned seed = g_seed_fixed ? g_seed : (unsigned)std::time(nullptr);  // modelest.cpp:58
         // RANSAC: 1000 iterations + optional refit (pose_estim.cpp:870-873); LMEDS: 2000 iterations, no refit (:874-877,
         // five-point.cpp:125-129)
-        const int rc = method == "LMEDS"
-                           ? mlpl_lmeds_essential(default_ctx(), a.data(), b.data(), n1, 0.999, 2000, seed, Ev, m.data(), &ninl, nullptr)
-                           : mlpl_ransac_essential(default_ctx(), a.data(), b.data(), n1, threshold, 0.999, 1000, refine ? 1 : 0,
-                                                   seed, Ev, m.data(), &ninl, &iters);
+        int rc;
+        if (method == "ARRSAC") {
+            // pose_estim.cpp:866-869: ARRSAC with the pseudo-Huber refinement as its `lesqu` step.  The two cv::RNG streams are
+            // process-wide in the reference (function-local statics of the samplers); so is this pair.
+            std::lock_guard<std::mutex> lock(g_arrsac_mutex);
+            rc = mlpl_arrsac_essential(default_ctx(), a.data(), b.data(), n1, threshold, refine ? 1 : 0, g_arrsac_rng, Ev, m.data(), &ninl);
+        } else {
+            rc = method == "LMEDS"
+                     ? mlpl_lmeds_essential(default_ctx(), a.data(), b.data(), n1, 0.999, 2000, seed, Ev, m.data(), &ninl, nullptr)
+                     : mlpl_ransac_essential(default_ctx(), a.data(), b.data(), n1, threshold, 0.999, 1000, refine ? 1 : 0, seed, Ev,
+                                             m.data(), &ninl, &iters);
+        }
         if (rc == MLPL_E_FAILED) return false;
         if (rc != MLPL_OK) throw cv::Exception(std::string("estimateEssentialMat: ") + mlpl_last_error());
         if (mask.needed()) {
@@ -178,11 +202,6 @@ bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p
         std::cout << "USAC must be executed by function estimateEssentialOrPoseUSAC as it needs additional paramters! Exiting."
                   << std::endl;
         std::exit(1);  // pose_estim.cpp:878-882
-    }
-    if (method == "ARRSAC") {
-        // not built yet: the reference's preemptive estimator (modelest.cpp:197-341).  Report failure instead of terminating the caller.
-        std::cout << "ARRSAC is not built in the MI355X hot-path library yet (RANSAC and LMEDS are); returning false." << std::endl;
-        return false;
     }
     std::cout << "Either there is a typo in the specified robust estimation method or the method is not supported. Exiting."
               << std::endl;

@@ -136,6 +136,17 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> ml((size_t)n, 0);
     if (okl) std::memcpy(ml.data(), maskl.data, (size_t)n);
     fwrite(ml.data(), 1, (size_t)n, o);
+
+    // estimateEssentialMat with its DEFAULT method (ARRSAC, pose_estim.h:207), twice: the second call continues the samplers' streams
+    for (int call = 0; call < 2; ++call) {
+        cv::Mat Ea, maska;
+        int32_t oka = poselib::estimateEssentialMat(Ea, p1, p2) ? 1 : 0;
+        fwrite(&oka, 4, 1, o);
+        fwrite(oka ? (const void *)Ea.data : (const void *)zero, 8, 9, o);
+        uint64_t st[2];
+        poselib::getArrsacRngState(&st[0], &st[1]);
+        fwrite(st, 8, 2, o);
+    }
     fclose(o);
     return 0;
 }

@@ -7,6 +7,7 @@ the reference's vendored NMSLIB seq_search (oracle/_ref/nmslib_knn, built from /
 for the distances and the tie-free indices, and a numpy brute force with lexicographic (dist, idx) selection for
 the cvflann tie order.  Fixtures are data only (inputs + expected outputs).
 """
+import ctypes as C
 import os
 import subprocess
 import sys
@@ -252,8 +253,61 @@ def coeff_case():
     print("coeff_ref: ok")
 
 
+def eigen_svd_case():
+    """Eigen::JacobiSVD<Matrix3d> of the Eigen 3.2.0 the reference vendors (oracle/_ref/eigen_svd3): singular values, U, V with
+    Eigen's column signs, for random matrices, near-essential matrices (the ValidModel regime) and their negatives."""
+    import struct
+    import tempfile
+    tool = os.path.join(ROOT, "oracle", "_ref", "eigen_svd3")
+    rng = np.random.default_rng(20260301)
+    Ms = rng.standard_normal((600, 3, 3))
+    for i in range(300):
+        u, _, vt = np.linalg.svd(Ms[i])
+        Ms[i] = u @ np.diag([1.0, 1.0 + 0.15 * rng.random(), 0.02 * rng.random()]) @ vt
+    Ms = np.concatenate([Ms, -Ms[:100]])
+    with tempfile.TemporaryDirectory() as d:
+        fi, fo = os.path.join(d, "i.bin"), os.path.join(d, "o.bin")
+        open(fi, "wb").write(struct.pack("i", len(Ms)) + Ms.tobytes())
+        subprocess.run([tool, fi, fo], check=True)
+        out = np.fromfile(fo).reshape(-1, 21)
+    np.savez_compressed(os.path.join(HERE, "eigen_svd3.npz"), M=Ms, sv=out[:, :3], U=out[:, 3:12].reshape(-1, 3, 3),
+                        V=out[:, 12:].reshape(-1, 3, 3))
+    print("eigen_svd3: ok", len(Ms))
+
+
+def arrsac_case():
+    """ARRSAC fixture (oracle-generated, like the RANSAC trace): scenes, the cv::RNG stream head, and per scene the oracle's
+    result + statistics + the first 60 turns of its first stage."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from matchinglib_poselib_amd import synth
+    ora = oracle_lib.load()
+    out = {}
+    stream, st = ora.cv_rng_stream(0xFFFFFFFF, 64)
+    out["rng_head"], out["rng_state_after"] = stream, np.array([st], np.uint64)
+    ora.lib.oracle_arrsac_trace.argtypes = [C.c_void_p, C.c_int]
+    cases = [(1500, 0.5, 20260401), (400, 0.7, 20260402), (90, 0.6, 20260403), (1200, 0.92, 20260404)]
+    out["cases"] = np.array(cases, np.float64)
+    for ci, (n, frac, seed) in enumerate(cases):
+        p1, p2, R, t, truth, th = synth.pose_scene(n, frac, seed=seed)
+        buf = np.zeros(20 * 4000, np.int32)
+        ora.lib.oracle_arrsac_trace(buf.ctypes.data, len(buf))
+        o = ora.arrsac_essential(p1, p2, th, refine=True)
+        ln = ora.lib.oracle_arrsac_trace(None, 0)
+        out[f"c{ci}_p1"], out[f"c{ci}_p2"], out[f"c{ci}_th"] = p1, p2, np.array([th])
+        out[f"c{ci}_ok"], out[f"c{ci}_E"], out[f"c{ci}_mask"] = np.array([o["ok"]]), o["E"], np.packbits(o["mask"])
+        out[f"c{ci}_stats"], out[f"c{ci}_rng"] = o["stats"], o["rng_state"]
+        out[f"c{ci}_turns"] = buf[:ln].reshape(-1, 20)[:60].copy()
+    np.savez_compressed(os.path.join(HERE, "arrsac_trace.npz"), **out)
+    print("arrsac_trace: ok")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("all", "eigen"):
+        eigen_svd_case()
+    if what in ("all", "arrsac"):
+        arrsac_case()
     if what in ("all", "nms"):
         nms_wrapper_case()
     if what in ("all", "matching"):

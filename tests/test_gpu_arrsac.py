@@ -39,3 +39,78 @@ def test_arrsac_equals_the_sequential_oracle(ctx, oracle, n, frac, seed, polish)
                 assert e_dist(g["E"], o["E"]) < (2e-5 if polish else 1e-7), e_dist(g["E"], o["E"])
     finally:
         ctx.set_option("solver_polish", 1)
+
+
+def test_arrsac_fixture_on_the_device(ctx):
+    """The committed oracle fixture (tests/golden/arrsac_trace.npz): result, statistics, stream positions and the first 60 turns."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "arrsac_trace.npz"))
+    ctx.set_option("solver_polish", 0)
+    try:
+        for ci in range(len(g["cases"])):
+            buf = np.zeros(20 * 4000, np.int32)
+            ctx.lib.mlpl_debug_arrsac_trace(ctx.handle, buf.ctypes.data, len(buf))
+            st = np.array(pose.ARRSAC_RNG_FRESH, np.uint64)
+            r = pose.arrsac_essential(g[f"c{ci}_p1"], g[f"c{ci}_p2"], float(g[f"c{ci}_th"][0]), refine=True, rng_state=st, ctx=ctx)
+            ln = ctx.lib.mlpl_debug_arrsac_trace(ctx.handle, None, 0)
+            assert r["ok"] == bool(g[f"c{ci}_ok"][0]) and np.array_equal(r["stats"][:8], g[f"c{ci}_stats"])
+            assert np.array_equal(st, g[f"c{ci}_rng"]) and np.array_equal(np.packbits(r["mask"]), g[f"c{ci}_mask"])
+            assert e_dist(r["E"], g[f"c{ci}_E"]) < 1e-7
+            assert np.array_equal(buf[:ln].reshape(-1, 20)[:60], g[f"c{ci}_turns"])
+    finally:
+        ctx.set_option("solver_polish", 1)
+
+
+def test_arrsac_streams_carry_over_and_default_method(ctx, oracle):
+    """Second call of a process = the reference's second call (static cv::RNGs); estimateEssentialMat's default method is ARRSAC."""
+    p1, p2, R, t, truth, th = synth.pose_scene(1500, 0.5, seed=6)
+    ctx.set_option("solver_polish", 0)
+    try:
+        st_g, st_o = np.array(pose.ARRSAC_RNG_FRESH, np.uint64), np.array(pose.ARRSAC_RNG_FRESH, np.uint64)
+        for call in range(3):
+            g = pose.arrsac_essential(p1, p2, th, refine=False, rng_state=st_g, ctx=ctx)
+            o = oracle.arrsac_essential(p1, p2, th, refine=False, rng_state=st_o)
+            assert g["ok"] == o["ok"] and np.array_equal(st_g, st_o) and g["stats"][:8].tolist() == o["stats"].tolist(), call
+            assert np.array_equal(g["mask"], o["mask"])
+        pose._arrsac_rng_state[:] = pose.ARRSAC_RNG_FRESH
+        ok, E, mask = pose.estimateEssentialMat(p1, p2, threshold=th, refine=True, ctx=ctx)
+        o = oracle.arrsac_essential(p1, p2, th, refine=True)
+        assert ok and o["ok"] and np.array_equal(mask, o["mask"]) and e_dist(E, o["E"]) < 1e-7
+        assert np.array_equal(pose._arrsac_rng_state, o["rng_state"])
+    finally:
+        ctx.set_option("solver_polish", 1)
+
+
+def test_arrsac_generation_in_the_preemptive_stage(ctx, oracle):
+    """Scenes whose first block is almost all inliers make the preemptive stage generate more hypotheses (uniform sampler over ALL
+    correspondences, sequential test over the first i+1): large device batches, scores that double-count, the n == 1 exit."""
+    hit = 0
+    ctx.set_option("solver_polish", 0)
+    try:
+        for seed in range(40, 60):
+            p1, p2, R, t, truth, th = synth.pose_scene(1200, 0.97, seed=seed)
+            o = oracle.arrsac_essential(p1, p2, th, refine=False)
+            if o["stats"][5] == 0:
+                continue
+            hit += 1
+            st = np.array(pose.ARRSAC_RNG_FRESH, np.uint64)
+            g = pose.arrsac_essential(p1, p2, th, refine=False, rng_state=st, ctx=ctx)
+            assert g["ok"] == o["ok"] and g["stats"][:8].tolist() == o["stats"].tolist() and np.array_equal(st, o["rng_state"])
+            assert np.array_equal(g["mask"], o["mask"])
+            if hit == 4:
+                break
+        assert hit >= 1, "no scene reached the generation branch"
+    finally:
+        ctx.set_option("solver_polish", 1)
+
+
+def test_arrsac_bad_arguments_and_failure(ctx):
+    p1, p2, R, t, truth, th = synth.pose_scene(300, 0.5, seed=8)
+    from matchinglib_poselib_amd._lib import MlplError
+    with pytest.raises(MlplError):
+        pose.arrsac_essential(p1[:5], p2[:5], th, ctx=ctx)                # runARRSAC is never reached with 5 correspondences
+    with pytest.raises(MlplError):
+        pose.arrsac_essential(p1, p2, 0.0, ctx=ctx)
+    rng = np.random.default_rng(0)                                         # pure noise: a winner with too few inliers -> not ok
+    r = pose.arrsac_essential(rng.uniform(-0.4, 0.4, (400, 2)), rng.uniform(-0.4, 0.4, (400, 2)), th, rng_state=np.array(pose.ARRSAC_RNG_FRESH, np.uint64), ctx=ctx)
+    assert not r["ok"]

@@ -76,3 +76,16 @@ def test_cpp_facade_end_to_end(oracle, tmp_path):
     assert okl == 1 and o3["ok"]
     assert min(np.abs(El - o3["E"]).max(), np.abs(El + o3["E"]).max()) < 1e-8
     assert (ml != o3["mask"]).sum() <= 2
+
+    # the default method, ARRSAC with refinement, called twice in one process: the second call starts from the stream positions the
+    # first one left (function-local static cv::RNGs in the reference)
+    st = np.array([0xFFFFFFFF, 0xFFFFFFFF], np.uint64)
+    for call in range(2):
+        oka = take(np.int32, 1)[0]
+        Ea = take(np.float64, 9).reshape(3, 3)
+        sta = take(np.uint64, 2)
+        o4 = oracle.arrsac_essential(p1, p2, 1.6, refine=True, rng_state=st)
+        assert oka == int(o4["ok"]) and sta.tolist() == st.tolist(), (call, oka, o4["ok"], sta, st)
+        if oka:
+            a, b = Ea / np.linalg.norm(Ea), o4["E"] / np.linalg.norm(o4["E"])
+            assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 2e-5

@@ -1,0 +1,130 @@
+"""CPU tests of the ARRSAC oracle (oracle/arrsac_oracle.cpp): its building blocks against independent statements and against the
+fixtures under tests/golden/ (Eigen's JacobiSVD from the reference's vendored Eigen; the oracle's own trace)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from matchinglib_poselib_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_cv_rng_is_the_multiply_with_carry_generator(oracle):
+    out, st = oracle.cv_rng_stream(0xFFFFFFFF, 50)
+    state = 0xFFFFFFFF
+    for v in out:
+        state = ((state & 0xFFFFFFFF) * 4164903690 + (state >> 32)) & 0xFFFFFFFFFFFFFFFF
+        assert int(v) == state & 0xFFFFFFFF
+    assert st == state
+    g = np.load(os.path.join(GOLD, "arrsac_trace.npz"))
+    assert np.array_equal(oracle.cv_rng_stream(0xFFFFFFFF, 64)[0], g["rng_head"])
+
+
+def test_eigen_jacobi_svd_equals_the_vendored_eigen(oracle):
+    """Singular values, U and V including the SIGNS of the columns (ValidModel's epipole is V.col(2))."""
+    g = np.load(os.path.join(GOLD, "eigen_svd3.npz"))
+    for M, sv, U, V in zip(g["M"], g["sv"], g["U"], g["V"]):
+        s2, U2, V2 = oracle.eigen_svd3(M)
+        assert np.abs(s2 - sv).max() < 1e-12 and np.abs(V2 - V).max() < 1e-9 and np.abs(U2 - U).max() < 1e-9
+        assert np.abs(U2 @ np.diag(s2) @ V2.T - M).max() < 1e-13
+    # V(-M) == V(M): the sign goes into U (what lets ValidModel's second pass re-use the epipole)
+    for M in g["M"][:50]:
+        assert np.array_equal(oracle.eigen_svd3(M)[2], oracle.eigen_svd3(-M)[2])
+
+
+def test_eigen_jacobi_svd_live_against_the_reference_build(oracle, tmp_path):
+    tool = oracle_lib.ref_tool("eigen_svd3")
+    if tool is None:
+        pytest.skip("oracle/_ref/eigen_svd3 is built only where /root/reference exists")
+    import struct
+    import subprocess
+    Ms = np.random.default_rng(5).standard_normal((300, 3, 3))
+    (tmp_path / "i.bin").write_bytes(struct.pack("i", len(Ms)) + Ms.tobytes())
+    subprocess.run([tool, str(tmp_path / "i.bin"), str(tmp_path / "o.bin")], check=True)
+    ref = np.fromfile(tmp_path / "o.bin").reshape(-1, 21)
+    for M, r in zip(Ms, ref):
+        sv, U, V = oracle.eigen_svd3(M)
+        assert np.abs(sv - r[:3]).max() < 1e-12 and np.abs(V - r[12:].reshape(3, 3)).max() < 1e-9
+
+
+def test_std_sort_is_a_descending_permutation_and_deterministic(oracle):
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 16, 17, 100, 733):
+        score = rng.integers(0, 12, n).astype(np.float64)       # integer scores: ties everywhere, as in the preemptive stage
+        perm = oracle.std_sort_desc(score)
+        assert sorted(perm.tolist()) == list(range(n)) and np.all(np.diff(score[perm]) <= 0)
+        assert np.array_equal(perm, oracle.std_sort_desc(score))
+
+
+def _skew(t):
+    return np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+
+
+def test_valid_model_and_eight_point_fit(oracle):
+    p1, p2, R, t, truth, th = synth.pose_scene(400, 1.0, seed=9, noise_px=0.0)
+    E = _skew(t) @ R
+    assert oracle.valid_model(p1[:5], p2[:5], E) and oracle.valid_model(p1[:5], p2[:5], -E)
+    assert not oracle.valid_model(p1[:5], p2[:5], E + 0.3 * np.diag([1.0, 0, 0]))         # singular values 1.3 : 1
+    bad = E.copy(); bad[2, 2] += 0.5                                                       # third singular value far from zero
+    assert not oracle.valid_model(p1[:5], p2[:5], bad)
+    for m in (8, 11, 14):
+        ok, F = oracle.cv_fm_8point(p1[:m], p2[:m])
+        assert ok and abs(F[2, 2] - 1.0) < 1e-12
+        x1, x2 = np.c_[p1[:m], np.ones(m)], np.c_[p2[:m], np.ones(m)]
+        assert np.abs(np.einsum("ij,jk,ik->i", x2, F, x1)).max() < 1e-4                    # float32 inputs
+        a, b = F / np.linalg.norm(F), E / np.linalg.norm(E)
+        assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 1e-3
+    assert not oracle.cv_fm_8point(np.zeros((8, 2)), np.zeros((8, 2)))[0]
+
+
+def test_robust_refinement_pulls_a_perturbed_matrix_back(oracle):
+    p1, p2, R, t, truth, th = synth.pose_scene(600, 1.0, seed=10)
+    E = _skew(t) @ R
+    E0 = E / np.linalg.norm(E) + 0.004 * np.random.default_rng(1).standard_normal((3, 3))
+    it, E1, err = oracle.robust_essential_refine(p1, p2, E0, th / 50.0)
+    d = lambda a: min(np.abs(a / np.linalg.norm(a) - E / np.linalg.norm(E)).max(), np.abs(a / np.linalg.norm(a) + E / np.linalg.norm(E)).max())  # noqa: E731
+    assert it >= 2 and d(E1) < 0.7 * d(E0)           # the reference stops as soon as the residual changes by < th / 10
+    s = np.linalg.svd(E1, compute_uv=False)
+    assert s[2] < 1e-12 * s[0]                                                              # getClosestE: rank 2
+    it2, E2, _ = oracle.robust_essential_refine(p1[:40], p2[:40], E0, th / 50.0)            # < 50 points: returned as is
+    assert it2 == 0 and np.array_equal(E2, E0)
+
+
+@pytest.mark.parametrize("n,frac,seed", [(3000, 0.5, 1), (3000, 0.3, 2), (600, 0.8, 3), (90, 0.7, 4)])
+def test_arrsac_recovers_the_pose(oracle, n, frac, seed):
+    p1, p2, R, t, truth, th = synth.pose_scene(n, frac, seed=seed)
+    o = oracle.arrsac_essential(p1, p2, th, refine=True)
+    assert o["ok"]
+    E = _skew(t) @ R
+    a, b = o["E"] / np.linalg.norm(o["E"]), E / np.linalg.norm(E)
+    assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 0.05
+    assert o["mask"].sum() == o["n_inliers"] and (o["mask"].astype(bool) & truth).sum() > 0.8 * truth.sum()
+
+
+def test_arrsac_streams_carry_over_between_calls(oracle):
+    p1, p2, R, t, truth, th = synth.pose_scene(1500, 0.5, seed=6)
+    st = np.array([0xFFFFFFFF, 0xFFFFFFFF], np.uint64)
+    a = oracle.arrsac_essential(p1, p2, th, refine=False, rng_state=st)
+    first = st.copy()
+    b = oracle.arrsac_essential(p1, p2, th, refine=False, rng_state=st)
+    fresh = oracle.arrsac_essential(p1, p2, th, refine=False)
+    assert not np.array_equal(first, [0xFFFFFFFF, 0xFFFFFFFF]) and not np.array_equal(st, first)
+    assert np.array_equal(fresh["E"], a["E"]) and np.array_equal(fresh["rng_state"], first)
+    assert a["stats"].tolist() != b["stats"].tolist()      # the second call of a process is a different run
+
+
+def test_arrsac_fixture(oracle):
+    g = np.load(os.path.join(GOLD, "arrsac_trace.npz"))
+    import ctypes as C
+    oracle.lib.oracle_arrsac_trace.argtypes = [C.c_void_p, C.c_int]
+    for ci in range(len(g["cases"])):
+        buf = np.zeros(20 * 4000, np.int32)
+        oracle.lib.oracle_arrsac_trace(buf.ctypes.data, len(buf))
+        o = oracle.arrsac_essential(g[f"c{ci}_p1"], g[f"c{ci}_p2"], float(g[f"c{ci}_th"][0]), refine=True)
+        ln = oracle.lib.oracle_arrsac_trace(None, 0)
+        assert o["ok"] == bool(g[f"c{ci}_ok"][0]) and np.array_equal(o["stats"], g[f"c{ci}_stats"])
+        assert np.array_equal(o["rng_state"], g[f"c{ci}_rng"]) and np.array_equal(np.packbits(o["mask"]), g[f"c{ci}_mask"])
+        assert np.abs(o["E"] - g[f"c{ci}_E"]).max() < 1e-12
+        assert np.array_equal(buf[:ln].reshape(-1, 20)[:60], g[f"c{ci}_turns"])
