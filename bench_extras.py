@@ -121,6 +121,23 @@ def run(ctx, dev, cpu_baseline=True):
         ora.lmeds_essential(p1, p2, seed=12345)
         out["lmeds_reference_settings"]["cpu_baseline"] = {"ms_per_call": (time.perf_counter() - tc) * 1e3, "cores": 1,
                                                            "kind": "port", "sample": "the same call"}
+    # ---- ARRSAC (estimateEssentialMat's default method) on the C3 scene, fresh cv::RNG streams every call ----
+    ac = lambda: pose.arrsac_essential(p1, p2, th, refine=True, rng_state=np.array(pose.ARRSAC_RNG_FRESH, np.uint64), ctx=ctx)  # noqa: E731
+    ar = ac()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ac()
+    dt = (time.perf_counter() - t0) / 10
+    out["arrsac_default_method"] = {"metric": "one estimateEssentialMat(ARRSAC, refine=true)-shaped call, host points in / E + mask out (5000 correspondences)",
+                                    "ms_per_call": dt * 1e3, "n_inliers": ar["n_inliers"], "device_batches": int(ar["stats"][8]),
+                                    "samples_solved": int(ar["stats"][9]), "samples_consumed": int(ar["stats"][10]),
+                                    "includes": "H2D of the points, speculative sample batches (solver + validity + inlier bit rows, one host hop "
+                                                "each), the sequential tests and the preemptive stage on the host, mask + refinement kernels, D2H"}
+    if cpu_baseline:
+        tc = time.perf_counter()
+        ora.arrsac_essential(p1, p2, th, refine=True)
+        out["arrsac_default_method"]["cpu_baseline"] = {"ms_per_call": (time.perf_counter() - tc) * 1e3, "cores": 1, "kind": "port",
+                                                        "sample": "the same call"}
     # ---- C4: L2 ----
     q, tt = synth.sift_pair(4096, 4096, seed=20260104)
     dq = torch.from_numpy(q).to(dev)

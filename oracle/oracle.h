@@ -12,6 +12,9 @@
  *     against numpy brute force; the reference ships no golden vectors of its own for this path.
  *   - 5-point solver: pinned against the reference's vendored OpenGV fivept_nister built into
  *     oracle/_ref/ (E-sets up to sign).
+ *   - ARRSAC (arrsac_oracle.cpp): Eigen::JacobiSVD<Matrix3d> pinned against the Eigen 3.2.0 the reference vendors (oracle/_ref/eigen_svd3,
+ *     tests/golden/eigen_svd3.npz); cv::RNG, cv::findFundamentalMat(FM_8POINT), Eigen::EigenSolver restated, unpinned; the sign and the
+ *     order of the 5-point solutions are fixed by convention (artefacts of cv::SVD's null-space basis, see that file's header).
  *   - The arithmetic of cvflann::LinearIndex / cv::SVD / cv::solvePoly / cv::triangulatePoints lives in
  *     OpenCV 4.2.0 (pinned in ci/make_opencv.sh:6), which is NOT vendored under /root/reference and is
  *     not installed here; those steps restate the published algorithms and are "parity unpinned" at

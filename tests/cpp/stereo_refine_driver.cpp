@@ -1,7 +1,7 @@
 // stereo_refine_driver.cpp -- runs poselib::StereoRefine over a sequence of stereo frames the way the reference harness does
 // (tests/poselib-test/main.cpp:1460-1530: one addNewCorrespondences() per image pair) and dumps the state after every frame;
 // tests/test_gpu_stereo_refine.py compares the dump with the CPU restatement of the state machine (tests/stereo_refine_oracle.py).
-//   in : int32 nframes, robMethod(0 RANSAC, 1 LMEDS) ; uint32 seed ; f64 K0[4], K1[4] (fx fy cx cy) ; f64 dist0[8], dist1[8] ; f64 cfg[18] ;
+//   in : int32 nframes, robMethod(0 RANSAC, 1 LMEDS, 2 ARRSAC) ; uint32 seed ; f64 K0[4], K1[4] (fx fy cx cy) ; f64 dist0[8], dist1[8] ; f64 cfg[18] ;
 //        per frame: int32 n ; f32 kp1[n][3] (x, y, response) ; f32 kp2[n][3] ; f32 descrDist[n]      (match i joins kp1[i] and kp2[i])
 //   out: per frame: int32 rc, nr_inliers_new, nr_corrs_new, pool, nrEstimation, skipCount, poseIsStable, mostLikelyPose_stable, history ;
 //        f64 E_new[9], R_new[9], t_new[3], E_mostLikely[9]  (zeros while empty)
@@ -34,7 +34,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 8; ++i) dist0.at<double>(0, i) = d0[i], dist1.at<double>(0, i) = d1[i];
     poselib::ConfigPoseEstimation cfg;
     cfg.K0 = &K0, cfg.K1 = &K1, cfg.dist0_8 = &dist0, cfg.dist1_8 = &dist1;
-    cfg.RobMethod = hdr[1] == 1 ? "LMEDS" : "RANSAC";
+    cfg.RobMethod = hdr[1] == 1 ? "LMEDS" : hdr[1] == 2 ? "ARRSAC" : "RANSAC";
     cfg.checkPoolPoseRobust = 1;
     cfg.refineMethod_CorrPool = poselib::RefinePostAlg::PR_STEWENIUS | poselib::RefinePostAlg::PR_PSEUDOHUBER_WEIGHTS;
     cfg.th_pix_user = c[0];

@@ -155,6 +155,11 @@ class StereoRefineOracle:
             method = "RANSAC"
         if method == "RANSAC":
             r = self.o.ransac_essential(a, b, self.th, confidence=0.999, max_iters=1000, lesqu=self.cfg.refineRTold, seed=self.seed)
+        elif method == "ARRSAC":
+            # the samplers' cv::RNG streams are process-wide in the reference: every estimation continues where the last one stopped
+            if not hasattr(self, "arrsac_rng"):
+                self.arrsac_rng = np.array([0xFFFFFFFF, 0xFFFFFFFF], np.uint64)
+            r = self.o.arrsac_essential(a, b, self.th, refine=self.cfg.refineRTold, rng_state=self.arrsac_rng)
         else:
             r = self.o.lmeds_essential(a, b, confidence=0.999, max_iters=2000, seed=self.seed)
         if not r["ok"]:

@@ -61,6 +61,8 @@ SEQUENCES = {
     "small_pool": dict(seed=6, cfg=dict(maxPoolCorrespondences=1300, raiseSkipCnt=(1 | (1 << 4)), absThRankingStable=0.05, minNormDistStable=0.6),
                        frames=[(650, "A", 0.2)] * 12, want=["pool+shrink"]),
     "lmeds": dict(seed=9, cfg=dict(RobMethod="LMEDS"), frames=[(500, "A", 0.2)] * 5, want=["pool"]),
+    "arrsac": dict(seed=13, cfg=dict(RobMethod="ARRSAC"), frames=[(500, "A", 0.2)] * 4 + [(500, "B", 0.3)] * 3, want=["pool"]),
+    "arrsac_refined": dict(seed=14, cfg=dict(RobMethod="ARRSAC", refineRTold=True), frames=[(450, "A", 0.25)] * 5, want=["pool"]),
     "lens_distortion_refit": dict(seed=10, cfg=dict(refineRTold=True, th_pix_user=1.0), frames=[(600, "A", 0.2)] * 6, want=["pool"],
                                   dist=(np.array([-0.12, 0.03, 0, 0, 0, 0, 0, 0.0]), np.array([-0.10, 0.02, 0, 0, 0, 0, 0, 0.0]))),
     "weak_start_few_matches": dict(seed=11, cfg=dict(useRANSAC_fewMatches=True, RobMethod="LMEDS", minStartAggInlRat=0.5),
@@ -97,7 +99,7 @@ def run_gpu(name, tmp_path, seed=777, options=None):
     d0, d1 = (np.zeros(8), np.zeros(8)) if dist is None else dist
     fin, fout = tmp_path / f"{name}.in", tmp_path / f"{name}.out"
     with open(fin, "wb") as f:
-        np.array([len(frames), 1 if method == "LMEDS" else 0], np.int32).tofile(f)
+        np.array([len(frames), {"RANSAC": 0, "LMEDS": 1, "ARRSAC": 2}[method]], np.int32).tofile(f)
         np.array([seed], np.uint32).tofile(f)
         K.tofile(f)
         K.tofile(f)
@@ -168,20 +170,28 @@ def test_stereo_refine_sequence_matches_the_cpu_state_machine(oracle, tmp_path, 
     drift, cpu_off = 0, False
     for i, (g, w) in enumerate(zip(got, want)):
         st = dict(zip(["rc", "inl", "corrs", "pool", "est", "skip", "stable", "ml", "hist"], g["st"].tolist()))
-        if w["E"] is not None and constraint_residual(w["E"]) > 1e-9:
+        arrsac = name.startswith("arrsac")   # its winner may be an 8-point fit or a refined matrix: no exact essential matrix to expect
+        if w["E"] is not None and constraint_residual(w["E"]) > 1e-9 and not arrsac:
             cpu_off = True
         for k in ("rc", "est", "skip", "stable", "ml", "hist"):
             assert st[k] == w[k], (name, i, k, st, {k: w[k] for k in st})
+        # ARRSAC draws its hypotheses from the pool's FIRST 100 correspondences, which do not change from frame to frame: successive frames
+        # often re-find the same 5-point model, the pool's error history then holds two roundings of the same number, and
+        # compareCorrespondences' "last error > previous error" (:2491-2495) is decided by the last bit (tools/sr_compare.py <seq> hybrid)
         for k in ("inl", "corrs", "pool"):
-            assert abs(st[k] - w[k]) <= (5 if cpu_off else 0), (name, i, k, st, {k: w[k] for k in st})
+            assert abs(st[k] - w[k]) <= (5 if (cpu_off or arrsac) else 0), (name, i, k, st, {k: w[k] for k in st})
             drift = max(drift, abs(st[k] - w[k]))
         tol = 1e-6 if not cpu_off else 1e-2
+        if arrsac and polish:
+            tol = 2e-5                         # polished 5-point hypotheses against the CPU path's unpolished ones
         if w["E"] is not None:
-            assert same_up_to_sign(g["E"].reshape(3, 3), w["E"], tol), (name, i)
+            unit = lambda a: a / np.linalg.norm(a)  # noqa: E731
+            assert same_up_to_sign(unit(g["E"].reshape(3, 3)), unit(w["E"]), tol), (name, i)
             assert np.abs(g["R"].reshape(3, 3) - w["R"]).max() < tol and np.abs(g["t"] - w["t"]).max() < tol, (name, i)
-            assert polish == 0 or constraint_residual(g["E"].reshape(3, 3)) < 1e-12
+            assert polish == 0 or arrsac or constraint_residual(g["E"].reshape(3, 3)) < 1e-12
         if w["Eml"] is not None:
-            assert same_up_to_sign(g["Eml"].reshape(3, 3), w["Eml"], tol), (name, i)
+            unit = lambda a: a / np.linalg.norm(a)  # noqa: E731
+            assert same_up_to_sign(unit(g["Eml"].reshape(3, 3)), unit(w["Eml"]), tol), (name, i)
     print(f"{name}: largest count difference {drift}, cpu model off the constraints: {cpu_off}")
     if name in ("steady", "stable", "bad_pairs_restore_and_skip", "uncertain_pairs", "small_pool", "drift_loses_the_pair"):
         assert drift == 0
