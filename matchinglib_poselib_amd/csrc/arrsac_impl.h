@@ -11,7 +11,7 @@
 // of the previous test only through rare events (an accepted hypothesis with a new best support switches the sampler to an inner RANSAC on
 // its inliers for 20 turns and shrinks the hypothesis budget).  Between events the sample sequence is a pure function of the two cv::RNG
 // streams.  So the host runs the reference's control flow literally, and whenever it needs the models of a sample it has not seen, it first
-// plays the samplers FORWARD from copies of their state under the assumption "no event", and sends the next up to 64..512 samples to the
+// plays the samplers FORWARD from copies of their state under the assumption "no event", and sends the next up to 128..512 samples to the
 // device as one batch:
 //   arrsac_sample_kernel   one wave per sample: 5 points -> Householder null space; 6..7 points -> 4 smallest eigenvectors of the Gram
 //                          matrix (the reference runs its 5-point kernel on them, cv::SVD of a 6x9 / 7x9 system); 8..14 points ->
@@ -32,6 +32,8 @@ constexpr int kArrSmpStride = 16;     // int32 per sample: [0] size m, [1..14] i
 constexpr int kArrMaxSample = 14;
 constexpr int kArrFlagPoints = 1024;  // correspondences a hypothesis can ever be tested on
 constexpr int kArrFlagWords = kArrFlagPoints / 64;
+constexpr int kArrHeadWords = 2;      // the first stage tests a hypothesis on the first 100 correspondences only
+constexpr int kArrPoolSamples = 8192; // samples whose models the device keeps per call (speculation included)
 constexpr int kArrBatchCap = 512;
 
 // ---- Eigen::JacobiSVD<Matrix3d>(M, ComputeFullU | ComputeFullV) restated: two-sided Jacobi in Eigen's pair order, left rotation =
@@ -322,7 +324,8 @@ __global__ __launch_bounds__(64) void arrsac_check_kernel(const double4 *__restr
                                                           double *__restrict__ E_tab, const int32_t *__restrict__ n_models,
                                                           const double *__restrict__ direct_E, const int32_t *__restrict__ direct_ok,
                                                           double thresh2, int32_t *__restrict__ out_nm, int32_t *__restrict__ out_valid,
-                                                          unsigned long long *__restrict__ out_flags) {
+                                                          double *__restrict__ out_e00, unsigned long long *__restrict__ out_head,
+                                                          unsigned long long *__restrict__ flag_rows) {
     __shared__ double q[kArrMaxSample][4];
     __shared__ int s_valid;
     const int lane = threadIdx.x;
@@ -379,8 +382,24 @@ __global__ __launch_bounds__(64) void arrsac_check_kernel(const double4 *__restr
             in = (double)sampson_err_f32(e, p.x, p.y, p.z, p.w) < thresh2;  // Estimator::Error(...) < error_thresh, strict
         }
         const unsigned long long bal = __ballot(in);
-        if (lane == 0) out_flags[((size_t)b * 10 + slot) * kArrFlagWords + w] = bal;
+        if (lane == 0) {
+            flag_rows[((size_t)b * 10 + slot) * kArrFlagWords + w] = bal;  // the whole row stays on the device (arrsac_gather_kernel)
+            if (w < kArrHeadWords) out_head[((size_t)b * 10 + slot) * kArrHeadWords + w] = bal;
+        }
     }
+    if (lane == 0) out_e00[b * 10 + slot] = e[0];
+}
+
+// Rows of the device-side model pool the host asks for (accepted hypotheses; models of the preemptive stage's generation branch):
+// out[i] = { E[9], bits[16] } of pool row rows[i].
+__global__ void arrsac_gather_kernel(const int32_t *__restrict__ rows, int n_rows, const double *__restrict__ E_pool,
+                                     const unsigned long long *__restrict__ F_pool, double *__restrict__ out) {
+    const int i = blockIdx.x, t = threadIdx.x;
+    if (i >= n_rows || t >= 9 + kArrFlagWords) return;
+    const size_t row = (size_t)rows[i];
+    double *o = out + (size_t)i * (9 + kArrFlagWords);
+    if (t < 9) o[t] = E_pool[row * 9 + t];
+    else reinterpret_cast<unsigned long long *>(o)[t] = F_pool[row * kArrFlagWords + (t - 9)];
 }
 
 // robustEssentialRefine(inliers, E_init, th, iters = 0, makeClosestE = true) (pose_estim.cpp:337-792; model 0, no normalisation): up to
@@ -514,6 +533,11 @@ struct CvRng {  // cv::RNG (OpenCV core): multiply-with-carry
 };
 
 struct ArrModelHost {
+    int row;                       // row of the device-side pool (E, all flag words)
+    int full;                      // index into ArrsacRun::full_rows once the whole row was fetched, else -1
+    uint64_t head[kArrHeadWords];  // inlier bits of the first 128 correspondences
+};
+struct ArrFullRow {
     double E[9];
     uint64_t bits[kArrFlagWords];
 };
@@ -535,6 +559,10 @@ struct ArrsacRun {
     int32_t *h_smp = nullptr;
     // results
     std::vector<ArrModelHost> pool;
+    std::vector<ArrFullRow> full_rows;
+    double *d_Epool = nullptr;
+    unsigned long long *d_Fpool = nullptr;
+    int pool_samples = 0;  // samples whose rows are in use
     std::map<ArrKey, std::vector<int>> cache;  // sample -> ids of its VALID models in the solver's order
     long long stats[12] = {0};                 // [8] batches, [9] samples sent, [10] samples used
 
@@ -546,7 +574,10 @@ struct ArrsacRun {
     double rejected_accum = 0.0;
     CvRng prosac_rng, random_rng;
 
-    static size_t out_bytes(int B) { return (size_t)B * 4 + (size_t)B * 40 + (size_t)B * 720 + (size_t)B * 10 * kArrFlagWords * 8 + 64; }
+    static size_t out_bytes(int B) {
+        const size_t batch = (size_t)B * 4 + (size_t)B * 40 + (size_t)B * 80 + (size_t)B * 10 * kArrHeadWords * 8 + 64;
+        return std::max(batch, (size_t)B * 10 * sizeof(ArrFullRow) + (size_t)B * 40);  // the same blocks carry gathered rows
+    }
 
     int alloc() {
         void *p;
@@ -564,6 +595,10 @@ struct ArrsacRun {
         if ((rc = pinned_get(ctx, out_bytes(kArrBatchCap) + (size_t)kArrBatchCap * kArrSmpStride * 4, &p))) return rc;
         h_out = (char *)p;
         h_smp = (int32_t *)(h_out + out_bytes(kArrBatchCap));
+        if ((rc = ws_get(ctx, WS_ARR_E, (size_t)kArrPoolSamples * 720, &p))) return rc;
+        d_Epool = (double *)p;
+        if ((rc = ws_get(ctx, WS_ARR_F, (size_t)kArrPoolSamples * 10 * kArrFlagWords * 8, &p))) return rc;
+        d_Fpool = (unsigned long long *)p;
         return MLPL_OK;
     }
 
@@ -578,64 +613,114 @@ struct ArrsacRun {
             for (int i = 0; i < kArrMaxSample; ++i) sm[1 + i] = i < m ? keys[b][1 + i] : 0;
             sm[15] = keys[b][0];
         }
-        // layout of the result block: out_nm[B] | out_valid[B*10] | E_tab[B*90] | flags[B*10*16]
-        const size_t off_valid = (size_t)B * 4, off_E = ((size_t)B * 44 + 7) & ~(size_t)7, off_flags = off_E + (size_t)B * 720;
-        const size_t total = off_flags + (size_t)B * 10 * kArrFlagWords * 8;
+        if (pool_samples + B > kArrPoolSamples) {
+            set_error("mlpl_arrsac_essential: more than %d samples solved in one call", kArrPoolSamples);
+            return MLPL_E_FAILED;
+        }
+        // layout of the result block: out_nm[B] | out_valid[B*10] | E00[B*10] | head[B*10*2]; models and whole flag rows go to the pool
+        const size_t off_valid = (size_t)B * 4, off_e00 = ((size_t)B * 44 + 7) & ~(size_t)7, off_head = off_e00 + (size_t)B * 80;
+        const size_t total = off_head + (size_t)B * 10 * kArrHeadWords * 8;
         int32_t *o_nm = (int32_t *)d_out, *o_valid = (int32_t *)(d_out + off_valid);
-        double *o_E = (double *)(d_out + off_E);
-        unsigned long long *o_flags = (unsigned long long *)(d_out + off_flags);
+        double *o_e00 = (double *)(d_out + off_e00);
+        unsigned long long *o_head = (unsigned long long *)(d_out + off_head);
+        double *o_E = d_Epool + (size_t)pool_samples * 90;
+        unsigned long long *o_rows = d_Fpool + (size_t)pool_samples * 10 * kArrFlagWords;
         MLPL_HIP_TRY(hipMemcpyAsync(d_smp, h_smp, (size_t)B * kArrSmpStride * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(arrsac_sample_kernel, dim3(B), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_smp, B, d_recs, d_direct, d_direct_ok);
         MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((B + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)d_recs, 0, B, o_E, d_nm5,
                           (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
         hipLaunchKernelGGL(arrsac_check_kernel, dim3(B * 10), dim3(64), 0, s, pts, flag_points, d_p1, d_p2, (const int32_t *)d_smp, B, o_E,
-                           (const int32_t *)d_nm5, (const double *)d_direct, (const int32_t *)d_direct_ok, thresh2, o_nm, o_valid, o_flags);
+                           (const int32_t *)d_nm5, (const double *)d_direct, (const int32_t *)d_direct_ok, thresh2, o_nm, o_valid, o_e00, o_head,
+                           o_rows);
         MLPL_HIP_TRY(hipGetLastError());
         MLPL_HIP_TRY(hipMemcpyAsync(h_out, d_out, total, hipMemcpyDeviceToHost, s));
         MLPL_HIP_TRY(hipStreamSynchronize(s));
         const int32_t *h_nm = (const int32_t *)h_out, *h_valid = (const int32_t *)(h_out + off_valid);
-        const double *h_E = (const double *)(h_out + off_E);
-        const uint64_t *h_flags = (const uint64_t *)(h_out + off_flags);
+        const double *h_e00 = (const double *)(h_out + off_e00);
+        const uint64_t *h_head = (const uint64_t *)(h_out + off_head);
         for (int b = 0; b < B; ++b) {
             std::vector<int> ids;
             // order of a sample's solutions: ascending E(0,0) under the sign convention of arrsac_check_kernel.  (The reference's order is
             // cv::solvePoly's root order for a polynomial written in cv::SVD's null-space basis, which rounding noise decides.)
-            int order[10];
+            int order[10], nv = 0;
             const int nm = std::min(h_nm[b], 10);
-            for (int i = 0; i < nm; ++i) order[i] = i;
-            std::stable_sort(order, order + nm, [&](int x, int y) { return h_E[((size_t)b * 10 + x) * 9] < h_E[((size_t)b * 10 + y) * 9]; });
-            for (int oi = 0; oi < nm; ++oi) {
+            for (int i = 0; i < nm; ++i)
+                if (h_valid[b * 10 + i]) order[nv++] = i;  // an invalid model's E(0,0) is not written; the order among valid ones is what counts
+            std::stable_sort(order, order + nv, [&](int x, int y) { return h_e00[b * 10 + x] < h_e00[b * 10 + y]; });
+            for (int oi = 0; oi < nv; ++oi) {
                 const int slot = order[oi];
-                if (!h_valid[b * 10 + slot]) continue;
                 ArrModelHost mh;
-                std::memcpy(mh.E, h_E + ((size_t)b * 10 + slot) * 9, 72);
-                std::memcpy(mh.bits, h_flags + ((size_t)b * 10 + slot) * kArrFlagWords, sizeof(mh.bits));
+                mh.row = (pool_samples + b) * 10 + slot;
+                mh.full = -1;
+                std::memcpy(mh.head, h_head + ((size_t)b * 10 + slot) * kArrHeadWords, sizeof(mh.head));
                 ids.push_back((int)pool.size());
                 pool.push_back(mh);
             }
             cache.emplace(keys[b], std::move(ids));
         }
+        pool_samples += B;
         stats[8]++;
         stats[9] += B;
         return MLPL_OK;
     }
 
-    bool bit(int id, int i) const { return (pool[id].bits[i >> 6] >> (i & 63)) & 1; }
+    // Fetches the whole pool rows (model + all flag words) of the given models, once each: one gather kernel, one host hop.
+    int ensure_full(const std::vector<int> &ids) {
+        std::vector<int> need;
+        for (int id : ids)
+            if (pool[id].full < 0 && std::find(need.begin(), need.end(), id) == need.end()) need.push_back(id);
+        for (size_t at = 0; at < need.size(); at += (size_t)kArrBatchCap * 10) {
+            const int cnt = (int)std::min(need.size() - at, (size_t)kArrBatchCap * 10);
+            int32_t *h_rows = (int32_t *)h_out;
+            for (int i = 0; i < cnt; ++i) h_rows[i] = pool[need[at + i]].row;
+            int32_t *d_rows = (int32_t *)d_out;
+            double *d_g = (double *)(d_out + (((size_t)cnt * 4 + 7) & ~(size_t)7));
+            MLPL_HIP_TRY(hipMemcpyAsync(d_rows, h_rows, (size_t)cnt * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(arrsac_gather_kernel, dim3(cnt), dim3(32), 0, s, (const int32_t *)d_rows, cnt, (const double *)d_Epool,
+                               (const unsigned long long *)d_Fpool, d_g);
+            MLPL_HIP_TRY(hipGetLastError());
+            MLPL_HIP_TRY(hipMemcpyAsync(h_out, d_g, (size_t)cnt * sizeof(ArrFullRow), hipMemcpyDeviceToHost, s));
+            MLPL_HIP_TRY(hipStreamSynchronize(s));
+            const ArrFullRow *g = (const ArrFullRow *)h_out;
+            for (int i = 0; i < cnt; ++i) {
+                pool[need[at + i]].full = (int)full_rows.size();
+                full_rows.push_back(g[i]);
+            }
+        }
+        return MLPL_OK;
+    }
 
-    // ProsacSampler::Sample for sample number k over the first `count` correspondences (prosac_sampler.h:85-157)
-    static void prosac_sample(CvRng &rng, int count, int k, ArrKey &key) {
+    bool bit(int id, int i) const {
+        const ArrModelHost &m = pool[id];
+        if (i < kArrHeadWords * 64) return (m.head[i >> 6] >> (i & 63)) & 1;
+        return (full_rows[m.full].bits[i >> 6] >> (i & 63)) & 1;  // callers fetch the row first (ensure_full)
+    }
+
+    // ProsacSampler::Sample for sample number k over the first `count` correspondences (prosac_sampler.h:85-157).  The growth function
+    // (subset size n and T'_n after k turns, Eq. 3-5 of the PROSAC paper as the reference evaluates them) does not depend on the stream:
+    // one pass tabulates it for every k the call can reach.
+    std::vector<int> prosac_nn;
+    std::vector<double> prosac_tnp;
+    void prosac_table(int count) {
+        prosac_nn.assign(kMaxHyps + 2, kMinSample);
+        prosac_tnp.assign(kMaxHyps + 2, 1.0);
         double t_n = 200000;
         int nn = kMinSample;
         for (int i = 0; i < kMinSample; i++) t_n *= static_cast<double>(nn - i) / (double)((size_t)count - i);
         double t_n_prime = 1.0;
-        for (int t = 1; t <= k; t++) {
+        for (int t = 1; t <= kMaxHyps + 1; t++) {
             if (t > t_n_prime && nn < count) {
                 const double t_n_plus1 = (t_n * ((double)nn + 1.0)) / ((double)nn + 1.0 - (double)kMinSample);
                 t_n_prime += std::ceil(t_n_plus1 - t_n);
                 t_n = t_n_plus1;
                 nn++;
             }
+            prosac_nn[t] = nn, prosac_tnp[t] = t_n_prime;
         }
+    }
+    void prosac_sample(CvRng &rng, int k, ArrKey &key) const {
+        const int nn = prosac_nn[k];
+        const double t_n_prime = prosac_tnp[k];
         key.assign(1, 0);
         const bool all_random = t_n_prime < k;
         const int picks = all_random ? kMinSample : kMinSample - 1, range = all_random ? nn : nn - 1;
@@ -724,10 +809,11 @@ struct ArrsacRun {
         bool inner = false;
         std::vector<int> data;
         ArrKey key;
+        prosac_table(count);
         while (k <= m_prime) {
             // the sample of this turn, from the real streams
             if (!inner) {
-                prosac_sample(prosac_rng, count, k, key);
+                prosac_sample(prosac_rng, k, key);
                 stats[2]++;
             } else {
                 const int kind = (random_size == kMinSample || random_size < kNonMinMin) ? 0 : 1;
@@ -742,11 +828,11 @@ struct ArrsacRun {
                 int kk = k + 1, its = inner_its;
                 bool in = inner;
                 if (in && ++its == kMaxInner) its = 0, in = false;
-                const int want = 64;
+                const int want = 128;
                 ArrKey nk;
                 while (kk <= m_prime && (int)batch.size() < want) {
                     if (!in) {
-                        prosac_sample(pr, count, kk, nk);
+                        prosac_sample(pr, kk, nk);
                     } else {
                         const int kind = (random_size == kMinSample || random_size < kNonMinMin) ? 0 : 1;
                         random_sample(rr, data, random_size, kind, nk);
@@ -824,6 +910,11 @@ struct ArrsacRun {
         std::vector<int> all(n);
         for (int i = 0; i < n; ++i) all[i] = i;
         int nh = (int)hyps.size();
+        {  // the preemptive stage walks the accepted hypotheses' bits beyond the first block: fetch their rows (one host hop)
+            std::vector<int> ids;
+            for (const Scored &h : hyps) ids.push_back(h.id);
+            if ((*rc_out = ensure_full(ids))) return -1;
+        }
         int i = kBlock;
         for (; i < n; i++) {
             if (i >= flag_points) {  // cannot happen: the hypothesis count halves every block (n1 below), one is left before 900
@@ -853,6 +944,11 @@ struct ArrsacRun {
                                 if (cache.find(nk) == cache.end()) batch.push_back(nk);
                             }
                             if ((*rc_out = run_batch(batch))) return -1;
+                            // these are tested on i + 1 > 128 correspondences: their whole rows are needed
+                            std::vector<int> ids;
+                            for (const ArrKey &bk : batch)
+                                for (int id : cache.find(bk)->second) ids.push_back(id);
+                            if ((*rc_out = ensure_full(ids))) return -1;
                             it = cache.find(key);
                         }
                         stats[10]++;
@@ -935,7 +1031,8 @@ int arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, 
         return MLPL_E_FAILED;
     }
     // findInliers with the best model (modelest.cpp:274), then the reference's plausibility test (:275-278)
-    MLPL_HIP_TRY(hipMemcpyAsync(d_E, R.pool[best].E, 72, hipMemcpyHostToDevice, s));
+    // the winner's matrix is in the device pool already
+    MLPL_HIP_TRY(hipMemcpyAsync(d_E, R.d_Epool + (size_t)R.pool[best].row * 9, 72, hipMemcpyDeviceToDevice, s));
     MLPL_HIP_TRY(hipMemsetAsync(d_info, 0, 16, s));
     hipLaunchKernelGGL(inlier_mask_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double4 *)pts, n, (const double *)d_E,
                        R.thresh2, d_mask, d_info);

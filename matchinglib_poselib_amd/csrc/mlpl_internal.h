@@ -48,6 +48,8 @@ enum WsSlot {
     WS_DEBUG,     // diagnostics (per-wave clock stamps)
     WS_COUNTERS,  // chunk counters of the dynamic-split Hamming kernel
     WS_SPLIT_TAB, // age-aware split table of the static LDS-ring Hamming kernel
+    WS_ARR_E,     // ARRSAC: models of every sample solved in a call
+    WS_ARR_F,     // ARRSAC: their inlier bit rows
     WS_NUM_SLOTS
 };
 

@@ -1494,13 +1494,14 @@ __device__ __forceinline__ void jacobi9_wave(Jacobi9Lds &J, int lane) {
     // Jacobi eigenvalue iteration on the symmetric 9x9 in the parallel (round-robin) ordering: the 9 indices plus one idle
     // slot form 5 disjoint pairs per round, 9 rounds visit all 36 pairs once (= one sweep).  Lanes 0..4 compute the rotations
     // of a round, then all lanes apply J^T G J and V J element-wise (disjoint rotations commute).
-    if (lane < 10) J.ring[lane] = lane;
-    wave_sync();
+    // The matrices ping-pong between (G, Vv) and (Gn, Vn): a round reads one pair and writes the other.  Slot k of the ring holds, in
+    // round r, index 1 + (k - 1 - r) mod 9 (slot 0 keeps index 0; index 9 is the idle slot).
+    double(*Gc)[9] = J.G, (*Vc)[9] = J.Vv, (*Gx)[9] = J.Gn, (*Vx)[9] = J.Vn;
     for (int sweep = 0; sweep < 60; ++sweep) {
         // off-diagonal mass against the diagonal (wave reduction; every lane gets the totals)
         double off = 0, diag = 0;
         for (int e = lane; e < 81; e += 64) {
-            const double v = J.G[e / 9][e % 9];
+            const double v = Gc[e / 9][e % 9];
             if (e / 9 == e % 9)
                 diag += v * v;
             else if (e / 9 < e % 9)
@@ -1514,13 +1515,13 @@ __device__ __forceinline__ void jacobi9_wave(Jacobi9Lds &J, int lane) {
         if (off <= 1e-32 * diag) break;  // wave-uniform
         for (int round = 0; round < 9; ++round) {
             if (lane < 5) {
-                const int p0 = J.ring[lane], q0 = J.ring[9 - lane];
+                const int p0 = lane == 0 ? 0 : 1 + (lane - 1 - round + 9) % 9, q0 = 1 + (9 - lane - 1 - round + 9) % 9;
                 const int p = min(p0, q0), q = max(p0, q0);
                 double c = 1.0, sn = 0.0;
                 if (q < 9) {
-                    const double apq = J.G[p][q];
+                    const double apq = Gc[p][q];
                     if (apq != 0.0) {
-                        const double theta = (J.G[q][q] - J.G[p][p]) / (2.0 * apq);
+                        const double theta = (Gc[q][q] - Gc[p][p]) / (2.0 * apq);
                         const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                         c = 1.0 / sqrt(tt * tt + 1.0);
                         sn = tt * c;
@@ -1540,27 +1541,28 @@ __device__ __forceinline__ void jacobi9_wave(Jacobi9Lds &J, int lane) {
                 const int pa = J.partner[a], pb = J.partner[b];
                 const double ca = J.cself[a], ka = J.cpart[a], cb = J.cself[b], kb = J.cpart[b];
                 // an index paired with the idle slot keeps c = 1, k = 0; its partner index (9) is never read with weight
-                const double gab = J.G[a][b];
-                const double gapb = (pb < 9) ? J.G[a][pb] : 0.0;
-                const double gpab = (pa < 9) ? J.G[pa][b] : 0.0;
-                const double gpapb = (pa < 9 && pb < 9) ? J.G[pa][pb] : 0.0;
-                J.Gn[a][b] = ca * cb * gab + ca * kb * gapb + ka * cb * gpab + ka * kb * gpapb;
-                const double vab = J.Vv[a][b];
-                const double vapb = (pb < 9) ? J.Vv[a][pb] : 0.0;
-                J.Vn[a][b] = cb * vab + kb * vapb;
+                const double gab = Gc[a][b];
+                const double gapb = (pb < 9) ? Gc[a][pb] : 0.0;
+                const double gpab = (pa < 9) ? Gc[pa][b] : 0.0;
+                const double gpapb = (pa < 9 && pb < 9) ? Gc[pa][pb] : 0.0;
+                Gx[a][b] = ca * cb * gab + ca * kb * gapb + ka * cb * gpab + ka * kb * gpapb;
+                const double vab = Vc[a][b];
+                const double vapb = (pb < 9) ? Vc[a][pb] : 0.0;
+                Vx[a][b] = cb * vab + kb * vapb;
             }
             wave_sync();
-            for (int e = lane; e < 81; e += 64) {
-                J.G[e / 9][e % 9] = J.Gn[e / 9][e % 9];
-                J.Vv[e / 9][e % 9] = J.Vn[e / 9][e % 9];
-            }
-            if (lane == 0) {  // rotate the ring: slot 0 stays, the others move one place
-                const int last = J.ring[9];
-                for (int k = 9; k > 1; --k) J.ring[k] = J.ring[k - 1];
-                J.ring[1] = last;
-            }
-            wave_sync();
+            double(*tg)[9] = Gc;
+            Gc = Gx, Gx = tg;
+            double(*tv)[9] = Vc;
+            Vc = Vx, Vx = tv;
         }
+    }
+    if (Gc != J.G) {  // an odd number of rounds: the result sits in the second pair
+        for (int e = lane; e < 81; e += 64) {
+            J.G[e / 9][e % 9] = J.Gn[e / 9][e % 9];
+            J.Vv[e / 9][e % 9] = J.Vn[e / 9][e % 9];
+        }
+        wave_sync();
     }
 }
 
