@@ -328,6 +328,7 @@ __global__ __launch_bounds__(64) void arrsac_check_kernel(const double4 *__restr
                                                           unsigned long long *__restrict__ flag_rows) {
     __shared__ double q[kArrMaxSample][4];
     __shared__ int s_valid;
+    if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
     const int lane = threadIdx.x;
     const int b = blockIdx.x / 10, slot = blockIdx.x - b * 10;
     if (b >= n_samples) return;
