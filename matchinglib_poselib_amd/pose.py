@@ -155,6 +155,27 @@ def ransac_essential_device(p1, p2, thresh: float, confidence: float = 0.999, ma
     return dict(ok=(rc == 0), E=E, mask=mask_out, n_inliers=ninl.value, iters=iters.value)
 
 
+def arrsac_essential_device(p1, p2, thresh: float, refine: bool = True, rng_state=None, ctx: Optional[Context] = None, mask_out=None,
+                            stream: Optional[int] = None) -> dict:
+    """Same as arrsac_essential on device-resident torch tensors (float64 [n,2]); the mask stays on the device."""
+    import torch
+
+    assert p1.is_cuda and p2.is_cuda and p1.dtype == torch.float64 and p1.is_contiguous() and p2.is_contiguous()
+    ctx = ctx or default_context(p1.device.index or 0)
+    n = p1.shape[0]
+    if mask_out is None:
+        mask_out = torch.empty(n, dtype=torch.uint8, device=p1.device)
+    st = _arrsac_rng_state if rng_state is None else rng_state
+    E = np.zeros((3, 3))
+    ninl = C.c_int(0)
+    sm = torch.cuda.current_stream(p1.device).cuda_stream if stream is None else stream
+    rc = ctx.lib.mlpl_arrsac_essential_dev(ctx.handle, p1.data_ptr(), p2.data_ptr(), n, float(thresh), 1 if refine else 0, st.ctypes.data,
+                                           E.ctypes.data, mask_out.data_ptr(), C.addressof(ninl), sm)
+    if rc not in (0, _lib.MLPL_E_FAILED):
+        raise MlplError(rc, "mlpl_arrsac_essential_dev", _lib.last_error())
+    return dict(ok=(rc == 0), E=E, mask=mask_out, n_inliers=ninl.value)
+
+
 def estimateEssentialMat(p1, p2, method: str = "ARRSAC", threshold: float = PIX_MIN_GOOD_TH, refine: bool = True,
                          seed: Optional[int] = None, ctx: Optional[Context] = None):
     """poselib::estimateEssentialMat (pose_estim.h:204-210, pose_estim.cpp:857-890) -> (ok, E, mask).

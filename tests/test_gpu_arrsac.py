@@ -144,3 +144,17 @@ def test_arrsac_forty_scenes_on_one_stream_pair(ctx, oracle, polish):
         assert exact >= 36, exact
     finally:
         ctx.set_option("solver_polish", 1)
+
+
+def test_arrsac_device_variant_equals_host_api(ctx):
+    import torch
+    p1, p2, R, t, truth, th = synth.pose_scene(2500, 0.45, seed=77)
+    a = pose.arrsac_essential(p1, p2, th, refine=True, rng_state=np.array(pose.ARRSAC_RNG_FRESH, np.uint64), ctx=ctx)
+    st = np.array(pose.ARRSAC_RNG_FRESH, np.uint64)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        d1, d2 = torch.from_numpy(p1).cuda(), torch.from_numpy(p2).cuda()
+        b = pose.arrsac_essential_device(d1, d2, th, refine=True, rng_state=st, ctx=ctx)
+    stream.synchronize()
+    assert a["ok"] and b["ok"] and a["n_inliers"] == b["n_inliers"] and np.array_equal(a["E"], b["E"])
+    assert np.array_equal(b["mask"].cpu().numpy(), a["mask"])
