@@ -128,3 +128,29 @@ def test_arrsac_fixture(oracle):
         assert np.array_equal(o["rng_state"], g[f"c{ci}_rng"]) and np.array_equal(np.packbits(o["mask"]), g[f"c{ci}_mask"])
         assert np.abs(o["E"] - g[f"c{ci}_E"]).max() < 1e-12
         assert np.array_equal(buf[:ln].reshape(-1, 20)[:60], g[f"c{ci}_turns"])
+
+
+def test_sign_and_order_of_five_point_solutions_are_rounding_noise(oracle):
+    """Why ARRSAC needs a convention (oracle/arrsac_oracle.cpp: canonical_sign, ascending E(0,0)): with the null space taken from a Jacobi
+    SVD of the 5 x 9 system, as the reference does through cv::SVD, a ONE-ULP perturbation of the inputs flips the sign of a third of
+    the solutions and reorders most samples' solution lists -- while the solutions themselves move by ~1e-10."""
+    p1, p2, R, t, truth, th = synth.pose_scene(2000, 0.5, seed=3)
+    rng = np.random.default_rng(0)
+    flips = reorders = models = 0
+    for _ in range(120):
+        idx = rng.choice(2000, 5, replace=False)
+        a, b = p1[idx], p2[idx]
+        E0 = [np.asarray(e).reshape(3, 3) for e in oracle.run5point(a, b)]
+        a2 = a * (1 + rng.choice([-1, 1], a.shape) * 2.2e-16)
+        b2 = b * (1 + rng.choice([-1, 1], b.shape) * 2.2e-16)
+        E1 = [np.asarray(e).reshape(3, 3) for e in oracle.run5point(a2, b2)]
+        if len(E0) != len(E1):
+            continue
+        for i, e in enumerate(E0):
+            d = [min(np.abs(e - x).max(), np.abs(e + x).max()) for x in E1]
+            j = int(np.argmin(d))
+            if d[j] < 1e-6:
+                models += 1
+                flips += np.abs(e + E1[j]).max() < 1e-6
+                reorders += j != i
+    assert models > 300 and flips > 0.15 * models and reorders > 0.3 * models, (models, flips, reorders)
