@@ -158,3 +158,23 @@ def test_arrsac_device_variant_equals_host_api(ctx):
     stream.synchronize()
     assert a["ok"] and b["ok"] and a["n_inliers"] == b["n_inliers"] and np.array_equal(a["E"], b["E"])
     assert np.array_equal(b["mask"].cpu().numpy(), a["mask"])
+
+
+@pytest.mark.parametrize("n", [6, 7, 8, 10, 14, 20, 37])
+def test_arrsac_tiny_inputs(ctx, oracle, n):
+    """Fewer correspondences than one block: the first stage alone decides (arrsac.h:388-401); the result fails the final
+    plausibility test below 15 inliers (modelest.cpp:275-278) -- both sides must say so alike."""
+    p1, p2, R, t, truth, th = synth.pose_scene(n, 0.9, seed=500 + n)
+    ctx.set_option("solver_polish", 0)
+    try:
+        st = np.array(pose.ARRSAC_RNG_FRESH, np.uint64)
+        g = pose.arrsac_essential(p1, p2, th, refine=True, rng_state=st, ctx=ctx)
+        o = oracle.arrsac_essential(p1, p2, th, refine=True)
+        assert g["ok"] == o["ok"] and g["n_inliers"] == o["n_inliers"] and np.array_equal(st, o["rng_state"])
+        assert g["stats"][:8].tolist() == o["stats"].tolist()
+        if g["n_inliers"]:
+            assert np.array_equal(g["mask"], o["mask"])
+        if g["ok"]:
+            assert e_dist(g["E"], o["E"]) < 1e-7
+    finally:
+        ctx.set_option("solver_polish", 1)
