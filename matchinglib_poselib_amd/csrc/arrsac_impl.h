@@ -542,7 +542,39 @@ struct ArrFullRow {
     double E[9];
     uint64_t bits[kArrFlagWords];
 };
-using ArrKey = std::vector<int32_t>;  // {kind, i0, i1, ...}
+// A sample as the device sees it: [0] size m, [1..14] ordered indices (0 beyond m), [15] kind -- also the cache key (no heap traffic).
+struct ArrKey {
+    int32_t v[kArrSmpStride];
+    int size() const { return v[0]; }
+    int kind() const { return v[15]; }
+    void reset(int kind) {
+        std::memset(v, 0, sizeof(v));
+        v[15] = kind;
+    }
+    void push(int idx) { v[1 + v[0]++] = idx; }
+    bool has(int idx) const {
+        for (int i = 0; i < v[0]; ++i)
+            if (v[1 + i] == idx) return true;
+        return false;
+    }
+    bool operator==(const ArrKey &o) const { return std::memcmp(v, o.v, sizeof(v)) == 0; }
+};
+struct ArrKeyHash {
+    size_t operator()(const ArrKey &k) const {
+        uint64_t h = 1469598103934665603ull;
+        for (int i = 0; i < kArrSmpStride; ++i) h = (h ^ (uint32_t)k.v[i]) * 1099511628211ull;
+        return (size_t)h;
+    }
+};
+struct ArrIds {  // ids of a sample's VALID models in the order of the convention
+    int n;
+    int id[10];
+    size_t size() const { return (size_t)n; }
+    bool empty() const { return n == 0; }
+    int operator[](size_t i) const { return id[i]; }
+    const int *begin() const { return id; }
+    const int *end() const { return id + n; }
+};
 
 struct ArrsacRun {
     mlpl_ctx *ctx;
@@ -564,7 +596,7 @@ struct ArrsacRun {
     double *d_Epool = nullptr;
     unsigned long long *d_Fpool = nullptr;
     int pool_samples = 0;  // samples whose rows are in use
-    std::map<ArrKey, std::vector<int>> cache;  // sample -> ids of its VALID models in the solver's order
+    std::unordered_map<ArrKey, ArrIds, ArrKeyHash> cache;  // sample -> its valid models
     long long stats[12] = {0};                 // [8] batches, [9] samples sent, [10] samples used
 
     // Arrsac(5, thr^2, 500, 100, 14, 8) (modelest.cpp:270) and its members (arrsac.h:102-118)
@@ -607,13 +639,7 @@ struct ArrsacRun {
     int run_batch(const std::vector<ArrKey> &keys) {
         const int B = (int)keys.size();
         if (B == 0) return MLPL_OK;
-        for (int b = 0; b < B; ++b) {
-            int32_t *sm = h_smp + (size_t)b * kArrSmpStride;
-            const int m = (int)keys[b].size() - 1;
-            sm[0] = m;
-            for (int i = 0; i < kArrMaxSample; ++i) sm[1 + i] = i < m ? keys[b][1 + i] : 0;
-            sm[15] = keys[b][0];
-        }
+        for (int b = 0; b < B; ++b) std::memcpy(h_smp + (size_t)b * kArrSmpStride, keys[b].v, sizeof(keys[b].v));
         if (pool_samples + B > kArrPoolSamples) {
             set_error("mlpl_arrsac_essential: more than %d samples solved in one call", kArrPoolSamples);
             return MLPL_E_FAILED;
@@ -640,7 +666,8 @@ struct ArrsacRun {
         const double *h_e00 = (const double *)(h_out + off_e00);
         const uint64_t *h_head = (const uint64_t *)(h_out + off_head);
         for (int b = 0; b < B; ++b) {
-            std::vector<int> ids;
+            ArrIds ids;
+            ids.n = 0;
             // order of a sample's solutions: ascending E(0,0) under the sign convention of arrsac_check_kernel.  (The reference's order is
             // cv::solvePoly's root order for a polynomial written in cv::SVD's null-space basis, which rounding noise decides.)
             int order[10], nv = 0;
@@ -654,10 +681,10 @@ struct ArrsacRun {
                 mh.row = (pool_samples + b) * 10 + slot;
                 mh.full = -1;
                 std::memcpy(mh.head, h_head + ((size_t)b * 10 + slot) * kArrHeadWords, sizeof(mh.head));
-                ids.push_back((int)pool.size());
+                ids.id[ids.n++] = (int)pool.size();
                 pool.push_back(mh);
             }
-            cache.emplace(keys[b], std::move(ids));
+            cache.emplace(keys[b], ids);
         }
         pool_samples += B;
         stats[8]++;
@@ -722,27 +749,27 @@ struct ArrsacRun {
     void prosac_sample(CvRng &rng, int k, ArrKey &key) const {
         const int nn = prosac_nn[k];
         const double t_n_prime = prosac_tnp[k];
-        key.assign(1, 0);
+        key.reset(0);
         const bool all_random = t_n_prime < k;
         const int picks = all_random ? kMinSample : kMinSample - 1, range = all_random ? nn : nn - 1;
         for (int i = 0; i < picks; i++) {
             int r;
             do r = rng.uniform(0, range);
-            while (std::find(key.begin() + 1, key.end(), r) != key.end());
-            key.push_back(r);
+            while (key.has(r));
+            key.push(r);
         }
-        if (!all_random) key.push_back(nn - 1);
+        if (!all_random) key.push(nn - 1);
     }
     // RandomSampler::Sample (random_sampler.h:57-78): `size` distinct positions of the universe
     static void random_sample(CvRng &rng, const std::vector<int> &universe, int size, int kind, ArrKey &key) {
-        key.assign(1, kind);
-        std::vector<int> used;
+        key.reset(kind);
+        int used[kArrMaxSample];
         for (int i = 0; i < size; i++) {
             int r;
             do r = rng.uniform(0, (int)universe.size());
-            while (std::find(used.begin(), used.end(), r) != used.end());
-            used.push_back(r);
-            key.push_back(universe[r]);
+            while (std::find(used, used + i, r) != used + i);
+            used[i] = r;
+            key.push(universe[r]);
         }
     }
     static int to_int_x86(double v) { return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : INT_MIN; }  // cvttsd2si
@@ -796,8 +823,8 @@ struct ArrsacRun {
     void trace_turn(int k, int inner_turn, const ArrKey &key, int nvalid, const int *res) {
         if (!ctx->arrsac_trace || ctx->arrsac_trace_len + 20 > ctx->arrsac_trace_cap) return;
         int32_t *r = ctx->arrsac_trace + ctx->arrsac_trace_len;
-        r[0] = k, r[1] = inner_turn, r[2] = (int)key.size() - 1;
-        for (int i = 0; i < 5; ++i) r[3 + i] = key[1 + i];
+        r[0] = k, r[1] = inner_turn, r[2] = key.size();
+        for (int i = 0; i < 5; ++i) r[3 + i] = key.v[1 + i];
         r[8] = nvalid;
         for (int i = 0; i < 10; ++i) r[9 + i] = i < nvalid ? res[i] : -1;
         r[19] = 0;
@@ -825,6 +852,8 @@ struct ArrsacRun {
             if (it == cache.end()) {
                 // play the samplers forward under "no event" and solve what is coming in one batch
                 std::vector<ArrKey> batch(1, key);
+                std::unordered_set<ArrKey, ArrKeyHash> in_batch;
+                in_batch.insert(key);
                 CvRng pr = prosac_rng, rr = random_rng;
                 int kk = k + 1, its = inner_its;
                 bool in = inner;
@@ -840,13 +869,13 @@ struct ArrsacRun {
                         if (++its == kMaxInner) its = 0, in = false;
                     }
                     kk++;
-                    if (cache.find(nk) == cache.end() && std::find(batch.begin(), batch.end(), nk) == batch.end()) batch.push_back(nk);
+                    if (cache.find(nk) == cache.end() && in_batch.insert(nk).second) batch.push_back(nk);
                 }
                 if ((*rc_out = run_batch(batch))) return 0;
                 it = cache.find(key);
             }
             stats[10]++;
-            const std::vector<int> &hyps = it->second;
+            const ArrIds &hyps = it->second;
             const int inner_turn = inner ? 1 : 0;
             if (inner) {
                 inner_its++;
@@ -938,11 +967,13 @@ struct ArrsacRun {
                         auto it = cache.find(key);
                         if (it == cache.end()) {  // the uniform sampler's future does not depend on any outcome
                             std::vector<ArrKey> batch(1, key);
+                            std::unordered_set<ArrKey, ArrKeyHash> in_batch;
+                            in_batch.insert(key);
                             CvRng rr = random_rng;
                             ArrKey nk;
                             for (int jj = j + 1, kk = k + 1; jj < (long long)temp_max - kk && (int)batch.size() < kArrBatchCap; ++jj, ++kk) {
                                 random_sample(rr, all, kMinSample, 0, nk);
-                                if (cache.find(nk) == cache.end()) batch.push_back(nk);
+                                if (cache.find(nk) == cache.end() && in_batch.insert(nk).second) batch.push_back(nk);
                             }
                             if ((*rc_out = run_batch(batch))) return -1;
                             // these are tested on i + 1 > 128 correspondences: their whole rows are needed
@@ -953,7 +984,7 @@ struct ArrsacRun {
                             it = cache.find(key);
                         }
                         stats[10]++;
-                        const std::vector<int> &est = it->second;
+                        const ArrIds &est = it->second;
                         if (est.empty()) {
                             k2++;
                             continue;

@@ -36,7 +36,8 @@
 #include <climits>
 #include <cmath>
 #include <cstring>
-#include <map>
+#include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "mlpl_internal.h"
@@ -1482,8 +1483,10 @@ __global__ __launch_bounds__(256) void gram_kernel(const double4 *__restrict__ p
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+constexpr double kJacobiTol = 1e-32;  // on the squared off-diagonal mass relative to the squared diagonal (1e-28 is no faster: measured)
+
 struct Jacobi9Lds {
-    double G[9][9], Vv[9][9], Gn[9][9], Vn[9][9];
+    double G[9][9], Gn[9][9], Vv[9][9], Vn[9][9];  // (G, Gn) and (Vv, Vn) adjacent: the iteration indexes them as [2][9][9]
     int partner[10], ring[10];
     double cself[10], cpart[10];
 };
@@ -1496,24 +1499,37 @@ __device__ __forceinline__ void jacobi9_wave(Jacobi9Lds &J, int lane) {
     // of a round, then all lanes apply J^T G J and V J element-wise (disjoint rotations commute).
     // The matrices ping-pong between (G, Vv) and (Gn, Vn): a round reads one pair and writes the other.  Slot k of the ring holds, in
     // round r, index 1 + (k - 1 - r) mod 9 (slot 0 keeps index 0; index 9 is the idle slot).
-    double(*Gc)[9] = J.G, (*Vc)[9] = J.Vv, (*Gx)[9] = J.Gn, (*Vx)[9] = J.Vn;
+    double(*GG)[9][9] = reinterpret_cast<double(*)[9][9]>(&J.G[0][0]);    // GG[0] = G, GG[1] = Gn
+    double(*VV)[9][9] = reinterpret_cast<double(*)[9][9]>(&J.Vv[0][0]);   // VV[0] = Vv, VV[1] = Vn
+    int cur = 0;
+    // the (at most two) matrix elements this lane owns
+    const int e0 = lane, e1 = lane + 64;
+    const int a0 = e0 / 9, b0 = e0 - a0 * 9, a1 = e1 / 9, b1 = e1 - a1 * 9;
+    const bool has1 = e1 < 81;
     for (int sweep = 0; sweep < 60; ++sweep) {
         // off-diagonal mass against the diagonal (wave reduction; every lane gets the totals)
         double off = 0, diag = 0;
-        for (int e = lane; e < 81; e += 64) {
-            const double v = Gc[e / 9][e % 9];
-            if (e / 9 == e % 9)
-                diag += v * v;
-            else if (e / 9 < e % 9)
-                off += v * v;
+        {
+            const double v0 = GG[cur][a0][b0];
+            if (a0 == b0) diag += v0 * v0;
+            else if (a0 < b0) off += v0 * v0;
+            if (has1) {
+                const double v1 = GG[cur][a1][b1];
+                if (a1 == b1) diag += v1 * v1;
+                else if (a1 < b1) off += v1 * v1;
+            }
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
             off += __shfl_xor(off, d);
             diag += __shfl_xor(diag, d);
         }
-        if (off <= 1e-32 * diag) break;  // wave-uniform
+        if (off <= kJacobiTol * diag) break;  // wave-uniform
         for (int round = 0; round < 9; ++round) {
+            const double(*Gc)[9] = GG[cur];
+            const double(*Vc)[9] = VV[cur];
+            double(*Gx)[9] = GG[cur ^ 1];
+            double(*Vx)[9] = VV[cur ^ 1];
             if (lane < 5) {
                 const int p0 = lane == 0 ? 0 : 1 + (lane - 1 - round + 9) % 9, q0 = 1 + (9 - lane - 1 - round + 9) % 9;
                 const int p = min(p0, q0), q = max(p0, q0);
@@ -1536,8 +1552,10 @@ __device__ __forceinline__ void jacobi9_wave(Jacobi9Lds &J, int lane) {
                 J.cpart[q] = sn;
             }
             wave_sync();
-            for (int e = lane; e < 81; e += 64) {
-                const int a = e / 9, b = e % 9;
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                if (which == 1 && !has1) break;
+                const int a = which ? a1 : a0, b = which ? b1 : b0;
                 const int pa = J.partner[a], pb = J.partner[b];
                 const double ca = J.cself[a], ka = J.cpart[a], cb = J.cself[b], kb = J.cpart[b];
                 // an index paired with the idle slot keeps c = 1, k = 0; its partner index (9) is never read with weight
@@ -1551,16 +1569,15 @@ __device__ __forceinline__ void jacobi9_wave(Jacobi9Lds &J, int lane) {
                 Vx[a][b] = cb * vab + kb * vapb;
             }
             wave_sync();
-            double(*tg)[9] = Gc;
-            Gc = Gx, Gx = tg;
-            double(*tv)[9] = Vc;
-            Vc = Vx, Vx = tv;
+            cur ^= 1;
         }
     }
-    if (Gc != J.G) {  // an odd number of rounds: the result sits in the second pair
-        for (int e = lane; e < 81; e += 64) {
-            J.G[e / 9][e % 9] = J.Gn[e / 9][e % 9];
-            J.Vv[e / 9][e % 9] = J.Vn[e / 9][e % 9];
+    if (cur) {  // an odd number of rounds: the result sits in the second pair
+        J.G[a0][b0] = J.Gn[a0][b0];
+        J.Vv[a0][b0] = J.Vn[a0][b0];
+        if (has1) {
+            J.G[a1][b1] = J.Gn[a1][b1];
+            J.Vv[a1][b1] = J.Vn[a1][b1];
         }
         wave_sync();
     }
