@@ -858,7 +858,10 @@ struct ArrsacRun {
                 int kk = k + 1, its = inner_its;
                 bool in = inner;
                 if (in && ++its == kMaxInner) its = 0, in = false;
-                const int want = 128;
+                // speculation depth: 128 samples while the device pool is at most half full, 16 afterwards.  An event (at most one per value of
+                // the best support, < 100) costs one batch, so the pool of 8192 samples cannot overflow in this stage: 4096 / 128 = 32 deep
+                // batches, then 256 shallow ones.
+                const int want = pool_samples <= kArrPoolSamples / 2 ? 128 : 16;
                 ArrKey nk;
                 while (kk <= m_prime && (int)batch.size() < want) {
                     if (!in) {
