@@ -99,6 +99,16 @@ void getArrsacRngState(uint64_t *prosac_state, uint64_t *uniform_state);
 bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p2, const std::string &method = "ARRSAC",
                           double threshold = PIX_MIN_GOOD_TH, bool refine = true, cv::OutputArray mask = cv::noArray());
 
+// poselib::robustEssentialRefine (pose_estim.h:225-228, pose_estim.cpp:337-792): pseudo-Huber re-weighted linear refinement of an
+// essential matrix on the device.  Built for what the library's own callers use: model 0 (essential matrix), iters = 0 (run to the
+// reference's stopping tests), makeClosestE = true, no normalisation, no oriented-epipolar test; other argument values throw
+// cv::Exception.  `mask` (1 x n or n x 1 CV_8U) selects the correspondences and is left as it is; `errors` receives the final Sampson
+// errors (n x 1 CV_64F) when requested.
+void robustEssentialRefine(cv::InputArray points1, cv::InputArray points2, cv::InputArray E_init, cv::Mat &E_refined, double th = 0.005,
+                           unsigned int iters = 0, bool makeClosestE = true, double *sumSqrErr_init = nullptr, double *sumSqrErr = nullptr,
+                           cv::OutputArray errors = cv::noArray(), cv::InputOutputArray mask = cv::noArray(), int model = 0,
+                           bool tryOrientedEpipolar = false, bool normalizeCorrs = false);
+
 // poselib::getPoseTriangPts (pose_estim.h:192-200, pose_estim.cpp:913-946).  Returns the number of valid 3-D points,
 // or -1 when R, t or Q is cv::noArray().  translatE = true: E is a translational essential matrix, R = I.
 int getPoseTriangPts(cv::InputArray E, cv::InputArray p1, cv::InputArray p2, cv::OutputArray R, cv::OutputArray t,

@@ -9,8 +9,9 @@
 // Every robust estimation and every error evaluation runs on the MI355X (estimateEssentialMat / getPoseTriangPts / mlpl_get_inliers_strict).
 //
 // Not built (outside the hot path): USAC, automatic thresholds (autoTH), homography alignment
-// (Halign), the linear refinement solvers (refineMethod / refineMethod_CorrPool: Nister/Stewenius/Kneip/8pt with weights), the old
-// robust refinement (refineRTold after the estimation) and bundle adjustment (BART).  Consequences, all reported once on std::cout:
+// (Halign), the linear refinement solvers (refineMethod / refineMethod_CorrPool: Nister/Stewenius/Kneip/8pt with weights) and bundle
+// adjustment (BART).  refineRTold IS built: the estimator's own refinement step plus poselib::robustEssentialRefine on the inliers
+// (:1460-1474), on the device.  Consequences of what is not built, all reported once on std::cout:
 //   * RobMethod must be "RANSAC", "LMEDS" or "ARRSAC"; "USAC", autoTH and Halign make addNewCorrespondences() return -1;
 //   * refinement / BA options are ignored;
 //   * the pool is always re-estimated robustly (the reference's behaviour for checkPoolPoseRobust = 1) instead of refined linearly;

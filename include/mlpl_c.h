@@ -240,6 +240,18 @@ int mlpl_arrsac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int
                           double E[9], uint8_t *mask, int *n_inliers);
 int mlpl_arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thresh, int refine,
                               uint64_t rng_state[2], double E[9], uint8_t *d_mask, int *n_inliers, void *stream);
+/*
+ * poselib::robustEssentialRefine(points1, points2, E_init, E_refined, th, 0, true, ..., mask, 0) (pose_estim.h:225-228,
+ * pose_estim.cpp:337-792) for the essential-matrix model without normalisation: iteratively re-weighted (pseudo-Huber on the Sampson
+ * distance, threshold th) 9 x 9 eigenproblem over the correspondences with mask != 0 (mask == NULL: all), the closest essential matrix
+ * after every round, the reference's stopping tests; one workgroup on the device.  Fewer than 50 correspondences or a rank-deficient
+ * system return E_init.  info (may be NULL) = {rounds, status: 0 converged or exhausted, 1 stopped on an invalid matrix (last valid one
+ * returned), 2 rejected (E_init returned)}.  StereoRefine's refineRTold step (stereo_pose_refinement.cpp:1460-1474) and ARRSAC's
+ * `refine` are this.
+ */
+int mlpl_robust_essential_refine(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const uint8_t *mask, const double E_init[9],
+                                 double th, double E_refined[9], int info[2]);
+
 /* Statistics of the last mlpl_arrsac_essential[_dev] call: {k of the initial hypothesis set, hypotheses after it, PROSAC samples,
  * inner-RANSAC samples, inner-RANSAC restarts, samples of the preemptive stage, correspondence index where that stage ended,
  * hypotheses left there, device batches, samples solved on the device, samples the control flow consumed, refinement status

@@ -208,6 +208,35 @@ bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p
     std::exit(1);  // pose_estim.cpp:883-887
 }
 
+void robustEssentialRefine(cv::InputArray points1, cv::InputArray points2, cv::InputArray E_init, cv::Mat &E_refined, double th,
+                           unsigned int iters, bool makeClosestE, double *sumSqrErr_init, double *sumSqrErr, cv::OutputArray errors,
+                           cv::InputOutputArray mask, int model, bool tryOrientedEpipolar, bool normalizeCorrs) {
+    if (iters != 0 || !makeClosestE || model != 0 || tryOrientedEpipolar || normalizeCorrs || sumSqrErr_init || sumSqrErr || errors.needed())
+        throw cv::Exception("robustEssentialRefine (MI355X hot-path library): built for model 0, iters 0, makeClosestE, without normalisation, "
+                            "oriented-epipolar test and error outputs");
+    int n1 = 0, n2 = 0;
+    std::vector<double> a = points64(points1, n1), b = points64(points2, n2);
+    CV_Assert(n1 == n2 && n1 > 0);
+    const cv::Mat E0 = E_init.getMat();
+    CV_Assert(E0.rows == 3 && E0.cols == 3 && E0.type() == CV_64F);
+    double Ei[9], Eo[9];
+    for (int i = 0; i < 9; ++i) Ei[i] = E0.at<double>(i / 3, i % 3);
+    std::vector<uint8_t> m;
+    if (mask.needed() && !mask.empty()) {
+        const cv::Mat mm = mask.getMat();
+        CV_Assert(mm.rows * mm.cols == n1 && mm.type() == CV_8U);
+        m.resize((size_t)n1);
+        for (int i = 0; i < n1; ++i) m[i] = mm.rows == 1 ? mm.at<uint8_t>(0, i) : mm.at<uint8_t>(i, 0);
+    }
+    int info[2] = {0, 0};
+    if (mlpl_robust_essential_refine(default_ctx(), a.data(), b.data(), n1, m.empty() ? nullptr : m.data(), Ei, th, Eo, info) != MLPL_OK)
+        throw cv::Exception(std::string("robustEssentialRefine: ") + mlpl_last_error());
+    if (info[1] == 2 && info[0] == 0) std::cout << "There are too less points for a refinement left!" << std::endl;  // pose_estim.cpp:411-416
+    cv::Mat out(3, 3, CV_64F);
+    for (int i = 0; i < 9; ++i) out.at<double>(i / 3, i % 3) = Eo[i];
+    E_refined = out;
+}
+
 int getPoseTriangPts(cv::InputArray E_, cv::InputArray p1, cv::InputArray p2, cv::OutputArray R_, cv::OutputArray t_,
                      cv::OutputArray Q_, cv::InputOutputArray mask_, const double dist, bool translatE) {
     if (!R_.needed() || !t_.needed() || !Q_.needed()) return -1;  // pose_estim.cpp:925-926

@@ -341,6 +341,8 @@ int StereoRefine::Impl::robustPoseEstimation() {
     mask_E_new.assign(mask.ptr<uint8_t>(0), mask.ptr<uint8_t>(0) + n);
     nr_inliers_new = 0;
     for (uint8_t v : mask_E_new) nr_inliers_new += v != 0;
+    if (cfg_pose.refineRTold)  // :1460-1474: the "old" robust refinement on the inliers, threshold th / 10; the mask stays
+        robustEssentialRefine(P1, P2, E, E, th / 10.0, 0, true, nullptr, nullptr, cv::noArray(), mask, 0);
     cv::Mat R, t, Q3;
     if (getPoseTriangPts(E, P1, P2, R, t, Q3, mask, cfg_pose.maxDist3DPtsZ) <= 0) {  // :1557
         std::cout << "Unable to triangulate 3D points" << std::endl;

@@ -2678,6 +2678,40 @@ int mlpl_arrsac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int
     return rc;
 }
 
+int mlpl_robust_essential_refine(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const uint8_t *mask, const double E_init[9],
+                                 double th, double E_refined[9], int info[2]) {
+    if (!ctx || !p1 || !p2 || !E_init || !E_refined || n < 1 || !(th > 0)) {
+        set_error("mlpl_robust_essential_refine: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    void *dp1, *dp2, *dmask, *dE;
+    int rc;
+    if ((rc = ws_get(ctx, WS_AUX0, (size_t)n * 16, &dp1))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX1, (size_t)n * 16, &dp2))) return rc;
+    if ((rc = ws_get(ctx, WS_MATCH, (size_t)n, &dmask))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX7, 256, &dE))) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(dp1, p1, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(dp2, p2, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    if (mask) MLPL_HIP_TRY(hipMemcpyAsync(dmask, mask, (size_t)n, hipMemcpyHostToDevice, s));
+    else MLPL_HIP_TRY(hipMemsetAsync(dmask, 1, (size_t)n, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(dE, E_init, 72, hipMemcpyHostToDevice, s));
+    double4 *pts = nullptr;
+    if ((rc = pack_points(ctx, (const double *)dp1, (const double *)dp2, n, &pts, s))) return rc;
+    double *d_E = (double *)dE;
+    int32_t *d_info = (int32_t *)(d_E + 18);
+    hipLaunchKernelGGL(arrsac_refine_kernel, dim3(1), dim3(1024), 0, s, (const double4 *)pts, (const uint8_t *)dmask, n, (const double *)d_E, th,
+                       d_E + 9, d_info);
+    MLPL_HIP_TRY(hipGetLastError());
+    double h[20];
+    MLPL_HIP_TRY(hipMemcpyAsync(h, d_E + 9, 88, hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(E_refined, h, 72);
+    if (info) std::memcpy(info, h + 9, 8);
+    return MLPL_OK;
+}
+
 int mlpl_debug_arrsac_trace(mlpl_ctx *ctx, int32_t *buf, int cap) {
     if (!ctx) return MLPL_E_BAD_INPUT;
     const int len = ctx->arrsac_trace_len;

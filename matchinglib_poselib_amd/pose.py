@@ -134,6 +134,19 @@ def arrsac_essential(p1, p2, thresh: float, refine: bool = True, rng_state=None,
     return dict(ok=(rc == 0), E=E, mask=mask, n_inliers=ninl.value, stats=stats)
 
 
+def robust_essential_refine(p1, p2, E_init, th: float, mask=None, ctx: Optional[Context] = None):
+    """poselib::robustEssentialRefine for the essential-matrix model (pose_estim.cpp:337-792) -> (E_refined, rounds, status)."""
+    ctx = ctx or default_context()
+    p1, p2 = _pts(p1), _pts(p2)
+    E0 = np.ascontiguousarray(E_init, np.float64).reshape(3, 3)
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(-1)
+    E = np.zeros((3, 3))
+    info = np.zeros(2, np.int32)
+    check(ctx.lib.mlpl_robust_essential_refine(ctx.handle, p1.ctypes.data, p2.ctypes.data, p1.shape[0], None if m is None else m.ctypes.data,
+                                               E0.ctypes.data, float(th), E.ctypes.data, info.ctypes.data), "mlpl_robust_essential_refine")
+    return E, int(info[0]), int(info[1])
+
+
 def ransac_essential_device(p1, p2, thresh: float, confidence: float = 0.999, max_iters: int = 1000, refit: bool = True,
                             seed: int = 0, ctx: Optional[Context] = None, mask_out=None, stream: Optional[int] = None) -> dict:
     """Same as ransac_essential on device-resident torch tensors (float64 [n,2]); the mask stays on the device."""

@@ -166,6 +166,10 @@ class StereoRefineOracle:
             return False
         self.mask_E = r["mask"].copy()
         self.nr_inliers = int(np.count_nonzero(self.mask_E))
+        if self.cfg.refineRTold:  # :1460-1474: robustEssentialRefine on the inliers, th / 10
+            sel = self.mask_E.astype(bool)
+            _, Er, _ = self.o.robust_essential_refine(a[sel], b[sel], r["E"], self.th / 10.0)
+            r = dict(r, E=Er)
         good, R, t, Q, m = self.o.recover_pose(r["E"], a, b, self.cfg.maxDist3DPtsZ, r["mask"])
         if good <= 0:
             return False

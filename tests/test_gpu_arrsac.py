@@ -178,3 +178,19 @@ def test_arrsac_tiny_inputs(ctx, oracle, n):
             assert e_dist(g["E"], o["E"]) < 1e-7
     finally:
         ctx.set_option("solver_polish", 1)
+
+
+def test_robust_essential_refine_on_the_device(ctx, oracle):
+    """poselib::robustEssentialRefine (pose_estim.cpp:337-792): rounds, result and the < 50 points rule against the CPU restatement."""
+    p1, p2, R, t, truth, th = synth.pose_scene(3000, 0.6, seed=71)
+    o = oracle.ransac_essential(p1, p2, th, confidence=0.999, max_iters=300, lesqu=False, seed=5)
+    mask = o["mask"]
+    sel = mask.astype(bool)
+    for scale in (50.0, 10.0, 2.0):
+        it_o, E_o, err = oracle.robust_essential_refine(p1[sel], p2[sel], o["E"], th / scale)
+        E_g, it_g, status = pose.robust_essential_refine(p1, p2, o["E"], th / scale, mask=mask, ctx=ctx)
+        assert status == 0 and it_g == it_o and e_dist(E_g, E_o) < 1e-9, (scale, it_g, it_o, e_dist(E_g, E_o))
+        s = np.linalg.svd(E_g, compute_uv=False)
+        assert s[2] < 1e-12 * s[0]
+    E_g, it_g, status = pose.robust_essential_refine(p1[:40], p2[:40], o["E"], th / 10, ctx=ctx)      # too few points: returned as is
+    assert status == 2 and np.array_equal(E_g, o["E"])

@@ -188,7 +188,9 @@ def test_stereo_refine_sequence_matches_the_cpu_state_machine(oracle, tmp_path, 
             unit = lambda a: a / np.linalg.norm(a)  # noqa: E731
             assert same_up_to_sign(unit(g["E"].reshape(3, 3)), unit(w["E"]), tol), (name, i)
             assert np.abs(g["R"].reshape(3, 3) - w["R"]).max() < tol and np.abs(g["t"] - w["t"]).max() < tol, (name, i)
-            assert polish == 0 or arrsac or constraint_residual(g["E"].reshape(3, 3)) < 1e-12
+            # (a matrix that went through robustEssentialRefine has rank 2 but two unequal singular values: getClosestE keeps both)
+            refined = SEQUENCES[name]["cfg"].get("refineRTold", False)
+            assert polish == 0 or arrsac or refined or constraint_residual(g["E"].reshape(3, 3)) < 1e-12
         if w["Eml"] is not None:
             unit = lambda a: a / np.linalg.norm(a)  # noqa: E731
             assert same_up_to_sign(unit(g["Eml"].reshape(3, 3)), unit(w["Eml"]), tol), (name, i)
