@@ -14,7 +14,9 @@
 // (:1460-1474), on the device.  Consequences of what is not built, all reported once on std::cout:
 //   * RobMethod must be "RANSAC", "LMEDS" or "ARRSAC"; "USAC", autoTH and Halign make addNewCorrespondences() return -1;
 //   * refinement / BA options are ignored;
-//   * the pool is always re-estimated robustly (the reference's behaviour for checkPoolPoseRobust = 1) instead of refined linearly;
+//   * between robust estimations the pool pose is REFINED (checkPoolPoseRobust != 1, the reference's schedule :680-716) only with
+//     refineRTold_CorrPool, the refinement that is built (refinePoseFromPool :1767-2084 with robustEssentialRefine on the device);
+//     with the linear solvers selected the pool is re-estimated robustly on every frame (the reference's checkPoolPoseRobust = 1);
 //   * thinning an over-full pool (checkPoolSize) drops the lowest-weight correspondences; the reference first thins dense image regions
 //     by image morphology (cv::dilate / cv::erode on a density image), which is image-side work;
 //   * the radius search over the pool returns neighbours by ascending distance (the reference's nanoflann call leaves its dynamic

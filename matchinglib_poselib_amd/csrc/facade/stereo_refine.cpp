@@ -209,6 +209,8 @@ struct StereoRefine::Impl {
     bool reinitializeSystem(double &inlier_ratio, std::vector<cv::DMatch> &matches, std::vector<cv::KeyPoint> &kp1,
                             std::vector<cv::KeyPoint> &kp2);
     int robustEstimationOnPool();
+    int refinePoseFromPool();
+    size_t failed_refinements = 0;  // function-local static in the reference (:678): process-wide there, per object here
     int addCorrespondencesToPool(const std::vector<cv::DMatch> &matches, const std::vector<cv::KeyPoint> &kp1,
                                  const std::vector<cv::KeyPoint> &kp2);
     int filterNewCorrespondences(std::vector<cv::DMatch> &matches, const std::vector<cv::KeyPoint> &kp1,
@@ -264,10 +266,12 @@ void StereoRefine::Impl::checkInputParamters() {  // :187-400 (values only; the 
     if (c.minContStablePoses <= 2) c.minContStablePoses = 3;
     if (c.absThRankingStable < 0.01) c.absThRankingStable = 0.01;
     else if (c.absThRankingStable > 0.9) c.absThRankingStable = 0.6;
-    // not built: the linear refinement of the pool -> the pool is always re-estimated robustly (reference: checkPoolPoseRobust = 1)
-    if (c.checkPoolPoseRobust != 1) {
-        notice("linear refinement of the correspondence pool is not built; the pool is re-estimated robustly on every frame "
-               "(the reference's checkPoolPoseRobust = 1)");
+    // The pool is REFINED between robust estimations (checkPoolPoseRobust != 1) only through refineRTold_CorrPool, the refinement that is
+    // built (robustEssentialRefine on the device); with the linear solvers (refineMethod_CorrPool) selected instead, the pool is
+    // re-estimated robustly on every frame (the reference's checkPoolPoseRobust = 1).
+    if (c.checkPoolPoseRobust != 1 && !c.refineRTold_CorrPool) {
+        notice("the linear refinement solvers of the correspondence pool are not built; the pool is re-estimated robustly on every frame "
+               "(the reference's checkPoolPoseRobust = 1); set refineRTold_CorrPool for the refinement that is built");
         c.checkPoolPoseRobust = 1;
     }
     if ((c.refineMethod & 0xF) != PR_NO_REFINEMENT || c.refineRTold || c.kneipInsteadBA || c.BART || c.BART_CorrPool)
@@ -405,6 +409,47 @@ int StereoRefine::Impl::robustEstimationOnPool() {  // :1075-1128: the robust es
     std::swap(p1Cam, p1new);
     std::swap(p2Cam, p2new);
     return rc ? -1 : 0;
+}
+
+// refinePoseFromPool (:1767-2084) for refineRTold_CorrPool: robustEssentialRefine of the current E on ALL pool correspondences (th / 10),
+// R, t and the 3-D points from the refined matrix, E rebuilt from them (getEfromRT, pose_helper.cpp:785-788).  No correspondence is
+// marked as an outlier on this path.
+int StereoRefine::Impl::refinePoseFromPool() {
+    const int n = (int)(p1Cam.size() / 2);
+    nr_inliers_new = (size_t)n;
+    have_Q = false;
+    Qv.clear();
+    cv::Mat P1(n, 2, CV_64F, p1Cam.data()), P2(n, 2, CV_64F, p2Cam.data());
+    cv::Mat E(3, 3, CV_64F), mask(1, n, CV_8U);
+    for (int i = 0; i < 9; ++i) E.at<double>(i / 3, i % 3) = E_[i];
+    std::memset(mask.ptr<uint8_t>(0), 1, (size_t)n);
+    robustEssentialRefine(P1, P2, E, E, th / 10.0, 0, true, nullptr, nullptr, cv::noArray(), mask, 0);
+    mask_E_new.assign((size_t)n, 1);
+    cv::Mat R, t, Q3;
+    if (getPoseTriangPts(E, P1, P2, R, t, Q3, mask, cfg_pose.maxDist3DPtsZ) <= 0) {
+        std::cout << "No 3D points left after triangulation!" << std::endl;
+        return -1;
+    }
+    double nrm = 0;
+    for (int i = 0; i < 3; ++i) nrm += t.at<double>(i, 0) * t.at<double>(i, 0);
+    nrm = std::sqrt(nrm);
+    double tn[3];
+    for (int i = 0; i < 3; ++i) tn[i] = t.at<double>(i, 0) / nrm;
+    const double S[9] = {0, -tn[2], tn[1], tn[2], 0, -tn[0], -tn[1], tn[0], 0};
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double v = 0;
+            for (int k = 0; k < 3; ++k) v += S[r * 3 + k] * R.at<double>(k, c);
+            E_[r * 3 + c] = v;
+        }
+    copy9(R, R_);
+    for (int i = 0; i < 3; ++i) t_[i] = tn[i];
+    mask_Q_new.assign(mask.ptr<uint8_t>(0), mask.ptr<uint8_t>(0) + n);
+    Qv.resize((size_t)n * 3);
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) Qv[(size_t)i * 3 + c] = Q3.at<double>(i, c);
+    have_Q = true;
+    return 0;
 }
 
 // ---- the pool (:1143-1266, :2107-2548) ------------------------------------------------------------------------------------------------
@@ -1089,8 +1134,10 @@ int StereoRefine::Impl::addNewCorrespondences(std::vector<cv::DMatch> &matches, 
 
         double E_old[9], R_old[9], t_old[3];
         std::memcpy(E_old, E_, 72), std::memcpy(R_old, R_, 72), std::memcpy(t_old, t_, 24);
-        const double minRelRemainingCorrsRef = 0.7;  // robust estimation on the pool (:619-716): always, see checkInputParamters
-        {
+        double minRelRemainingCorrsRef = 0.75;
+        // robust estimation on the pool or refinement of the last pose on it (:680-820)
+        if (cfg_pose.checkPoolPoseRobust == 1 || nr_since_robust > checkPoolPoseRobust_tmp ||
+            (!maxPoolSizeReached && checkPoolPoseRobust_tmp * initNumberInliers < correspondencePool.size())) {
             const std::vector<uint8_t> mE = mask_E_new;
             const size_t nr_old = nr_inliers_new;
             mask_Q_new.clear();
@@ -1106,7 +1153,44 @@ int StereoRefine::Impl::addNewCorrespondences(std::vector<cv::DMatch> &matches, 
                 if (!reinitializeSystem(inlier_ratio_new1, matches, kp1, kp2)) return -2;
                 return -3;
             }
+            if (cfg_pose.checkPoolPoseRobust > 1) {
+                if (maxPoolSizeReached)
+                    checkPoolPoseRobust_tmp = cfg_pose.checkPoolPoseRobust > 10 ? cfg_pose.checkPoolPoseRobust : 10;
+                else if (checkPoolPoseRobust_tmp > 50)
+                    checkPoolPoseRobust_tmp = cfg_pose.maxPoolCorrespondences / initNumberInliers + 2;
+                else
+                    checkPoolPoseRobust_tmp =
+                        (size_t)std::round((double)cfg_pose.checkPoolPoseRobust + std::exp(0.8 + (double)checkPoolPoseRobust_tmp / 6.0));
+            }
             nr_since_robust = 0;
+            minRelRemainingCorrsRef = 0.7;
+        } else {
+            if (maxPoolSizeReached) nr_since_robust++;
+            else nr_since_robust = 0;
+            if (refinePoseFromPool()) {
+                std::cout << "Taking old pose!" << std::endl;
+                std::memcpy(E_, E_old, 72), std::memcpy(R_, R_old, 72), std::memcpy(t_, t_old, 24);
+                skipCount++;
+                if (failed_refinements > 0) {
+                    failed_refinements = 0;
+                    std::cout << "Reinitializing system!" << std::endl;
+                    clearHistoryAndPool();
+                } else {
+                    std::vector<size_t> newIdx(newAddedPoolCorrs);
+                    for (size_t i = 0; i < newAddedPoolCorrs; i++) newIdx[i] = corrIdx - 1 - i;
+                    if (poolCorrespondenceDelete(newIdx)) {
+                        clearHistoryAndPool();
+                        failed_refinements = 0;
+                        const int err = robustInitialization(inlier_ratio_new1, matches, kp1, kp2);
+                        if (err == -1) return -1;
+                        if (err == -3) return 0;
+                        return -2;
+                    }
+                    failed_refinements++;
+                }
+                return -3;
+            }
+            failed_refinements = 0;
         }
         if ((double)nr_inliers_new < minRelRemainingCorrsRef * (double)correspondencePool.size()) {
             std::cout << "Too less inliers (<75%) after refinement! Reinitializing system and taking old pose!" << std::endl;

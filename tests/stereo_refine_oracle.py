@@ -35,6 +35,8 @@ class Cfg:
         self.raiseSkipCnt = 0
         self.maxRat3DPtsFar = 0.5
         self.maxDist3DPtsZ = 50.0
+        self.checkPoolPoseRobust = 1       # the struct's default is 3; 1 = always re-estimate robustly (the tests' historical setting)
+        self.refineRTold_CorrPool = False
         for k, v in kw.items():
             assert hasattr(self, k), k
             setattr(self, k, v)
@@ -43,8 +45,12 @@ class Cfg:
         return np.array([self.th_pix_user, self.minStartAggInlRat, self.relInlRatThLast, self.relInlRatThNew, self.minInlierRatSkip,
                          self.relMinInlierRatSkip, self.maxSkipPairs, self.minInlierRatioReInit, self.minPtsDistance,
                          self.maxPoolCorrespondences, self.minContStablePoses, self.absThRankingStable, float(self.useRANSAC_fewMatches),
-                         self.minNormDistStable, self.raiseSkipCnt, self.maxRat3DPtsFar, self.maxDist3DPtsZ, float(self.refineRTold)],
-                        np.float64)
+                         self.minNormDistStable, self.raiseSkipCnt, self.maxRat3DPtsFar, self.maxDist3DPtsZ, float(self.refineRTold),
+                         float(self.checkPoolPoseRobust), float(self.refineRTold_CorrPool)], np.float64)
+
+
+def round_half_away(x):  # std::round
+    return math.floor(x + 0.5) if x >= 0 else math.ceil(x - 0.5)
 
 
 def near_zero(d):
@@ -128,6 +134,12 @@ class StereoRefineOracle:
         elif c.absThRankingStable > 0.9:
             c.absThRankingStable = 0.6
         self.max_skip_new = c.maxSkipPairs
+        if c.checkPoolPoseRobust != 1 and not c.refineRTold_CorrPool:  # the linear pool solvers are not built (same rule as the library)
+            c.checkPoolPoseRobust = 1
+        self.check_tmp = c.checkPoolPoseRobust
+        self.init_inliers = 0
+        self.nr_since_robust = 0
+        self.failed_refinements = 0
 
     def clear(self):  # clearHistoryAndPool :1038-1064
         self.pool = []
@@ -486,6 +498,25 @@ class StereoRefineOracle:
         a, b = self.pool_coords()
         return self.robust(a, b)
 
+    def refine_from_pool(self):
+        """refinePoseFromPool (:1767-2084) for refineRTold_CorrPool: robustEssentialRefine of the current E on all pool correspondences,
+        R, t, Q from the refined matrix, E rebuilt from R and t (getEfromRT, pose_helper.cpp:785-788)."""
+        a, b = self.pool_coords()
+        n = len(a)
+        self.nr_inliers = n
+        self.Q = self.mask_Q = None
+        _, E, _ = self.o.robust_essential_refine(a, b, self.E, self.th / 10.0)
+        self.mask_E = np.ones(n, np.uint8)
+        good, R, t, Q, m = self.o.recover_pose(E, a, b, self.cfg.maxDist3DPtsZ, np.ones(n, np.uint8))
+        if good <= 0:
+            return False
+        t = t / np.sqrt(np.sum(t * t))
+        tv = np.asarray(t).reshape(-1)
+        S = np.array([[0, -tv[2], tv[1]], [tv[2], 0, -tv[0]], [-tv[1], tv[0], 0]])
+        self.E, self.R, self.t = S @ R, R, t
+        self.Q, self.mask_Q = Q, m
+        return True
+
     def add(self, kp1, kp2, dd):
         """kp1 / kp2: n x 3 float32 (x, y, response); dd: n float32 descriptor distances.  Returns the reference's return code."""
         c = self.cfg
@@ -500,8 +531,10 @@ class StereoRefineOracle:
         self.branch = ""
         if self.nr_est == 0:
             self.branch = "init"
+            self.check_tmp = c.checkPoolPoseRobust  # robustInitialization :973-978
             if not self.robust(fr["a"], fr["b"]):
                 return -1
+            self.init_inliers = self.nr_inliers
             ratio = self.nr_inliers / self.nr_corrs
             if ratio < c.minStartAggInlRat:
                 return 0  # err -3 of robustInitialization -> 0
@@ -553,17 +586,47 @@ class StereoRefineOracle:
             if n_new + len(self.pool) > c.maxPoolCorrespondences:
                 self.shrink_pool(c.maxPoolCorrespondences - n_new)
                 self.branch += "+shrink"
+            n_before = len(self.pool)
             self.add_to_pool(fr)
             old = (self.E, self.R, self.t)
             saved = (self.mask_E, self.nr_inliers)
-            self.mask_Q = self.Q = None
-            if not self.robust_on_pool():
-                self.E, self.R, self.t = old
-                self.mask_E, self.nr_inliers = saved
-                self.Q = None
-                self.reinit(ratio1, fr)
-                return -3
-            if self.nr_inliers < 0.7 * len(self.pool):
+            min_rel = 0.75
+            # robust estimation on the pool or refinement of the last pose on it (:680-820)
+            if c.checkPoolPoseRobust == 1 or self.nr_since_robust > self.check_tmp or \
+                    (not self.max_pool_reached and self.check_tmp * self.init_inliers < len(self.pool)):
+                self.mask_Q = self.Q = None
+                if not self.robust_on_pool():
+                    self.E, self.R, self.t = old
+                    self.mask_E, self.nr_inliers = saved
+                    self.Q = None
+                    self.reinit(ratio1, fr)
+                    return -3
+                if c.checkPoolPoseRobust > 1:
+                    if self.max_pool_reached:
+                        self.check_tmp = c.checkPoolPoseRobust if c.checkPoolPoseRobust > 10 else 10
+                    elif self.check_tmp > 50:
+                        self.check_tmp = int(c.maxPoolCorrespondences) // self.init_inliers + 2
+                    else:
+                        self.check_tmp = int(round_half_away(c.checkPoolPoseRobust + math.exp(0.8 + self.check_tmp / 6.0)))
+                self.nr_since_robust = 0
+                min_rel = 0.7
+                if c.checkPoolPoseRobust != 1:
+                    self.branch += "+robust"
+            else:
+                self.nr_since_robust = self.nr_since_robust + 1 if self.max_pool_reached else 0
+                self.branch += "+refined"
+                if not self.refine_from_pool():
+                    self.E, self.R, self.t = old
+                    self.skip += 1
+                    if self.failed_refinements > 0:
+                        self.failed_refinements = 0
+                        self.clear()
+                    else:
+                        self.delete_from_pool(list(range(n_before, len(self.pool))))
+                        self.failed_refinements += 1
+                    return -3
+                self.failed_refinements = 0
+            if self.nr_inliers < min_rel * len(self.pool):
                 self.E, self.R, self.t = old
                 self.clear()
                 self.branch += "+pool_lost"

@@ -63,6 +63,10 @@ SEQUENCES = {
     "lmeds": dict(seed=9, cfg=dict(RobMethod="LMEDS"), frames=[(500, "A", 0.2)] * 5, want=["pool"]),
     "arrsac": dict(seed=13, cfg=dict(RobMethod="ARRSAC"), frames=[(500, "A", 0.2)] * 4 + [(500, "B", 0.3)] * 3, want=["pool"]),
     "arrsac_refined": dict(seed=14, cfg=dict(RobMethod="ARRSAC", refineRTold=True), frames=[(450, "A", 0.25)] * 5, want=["pool"]),
+    "pool_refined": dict(seed=15, cfg=dict(checkPoolPoseRobust=3, refineRTold_CorrPool=True), frames=[(400, "A", 0.2)] * 12,
+                         want=["pool+refined", "pool+robust"]),
+    "pool_refined_small_pool": dict(seed=16, cfg=dict(checkPoolPoseRobust=2, refineRTold_CorrPool=True, maxPoolCorrespondences=1500),
+                                    frames=[(500, "A", 0.25)] * 14, want=["pool+refined"]),
     "lens_distortion_refit": dict(seed=10, cfg=dict(refineRTold=True, th_pix_user=1.0), frames=[(600, "A", 0.2)] * 6, want=["pool"],
                                   dist=(np.array([-0.12, 0.03, 0, 0, 0, 0, 0, 0.0]), np.array([-0.10, 0.02, 0, 0, 0, 0, 0, 0.0]))),
     "weak_start_few_matches": dict(seed=11, cfg=dict(useRANSAC_fewMatches=True, RobMethod="LMEDS", minStartAggInlRat=0.5),
