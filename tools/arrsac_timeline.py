@@ -1,5 +1,6 @@
-"""Kernel timeline of ARRSAC calls on the C3 scene.  Run under
-`rocprofv3 --kernel-trace --output-format csv -d <dir> -- python tools/arrsac_timeline.py`, then summarise with `... summarise <dir>`."""
+"""Kernel timeline of ARRSAC calls on the C3 scene (or `n inlier_fraction seed`).  Run under
+`rocprofv3 --kernel-trace --output-format csv -d <dir> -- python tools/arrsac_timeline.py [n frac seed]`, then summarise with
+`python tools/arrsac_timeline.py summarise <dir>`."""
 import glob, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +19,8 @@ if len(sys.argv) > 2 and sys.argv[1] == "summarise":
 import matchinglib_poselib_amd as mpa
 from matchinglib_poselib_amd import pose, synth
 ctx = mpa.Context(0)
-p1, p2, R, t, truth, th = synth.pose_scene(5000, 0.5, seed=20260103)
+_n, _f, _s = (int(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (5000, 0.5, 20260103)
+p1, p2, R, t, truth, th = synth.pose_scene(_n, _f, seed=_s)
 for _ in range(5):
     g = pose.arrsac_essential(p1, p2, th, refine=True, rng_state=np.array(pose.ARRSAC_RNG_FRESH, np.uint64), ctx=ctx)
 t0 = time.perf_counter()
