@@ -122,6 +122,7 @@ def run(ctx, dev, cpu_baseline=True):
         out["lmeds_reference_settings"]["cpu_baseline"] = {"ms_per_call": (time.perf_counter() - tc) * 1e3, "cores": 1,
                                                            "kind": "port", "sample": "the same call"}
     # ---- ARRSAC (estimateEssentialMat's default method) on the C3 scene, fresh cv::RNG streams every call ----
+    arr_scene = (p1, p2, th)
     ac = lambda: pose.arrsac_essential(p1, p2, th, refine=True, rng_state=np.array(pose.ARRSAC_RNG_FRESH, np.uint64), ctx=ctx)  # noqa: E731
     ar = ac()
     t0 = time.perf_counter()
@@ -133,23 +134,6 @@ def run(ctx, dev, cpu_baseline=True):
                                     "samples_solved": int(ar["stats"][9]), "samples_consumed": int(ar["stats"][10]),
                                     "includes": "H2D of the points, speculative sample batches (solver + validity + inlier bit rows, one host hop "
                                                 "each), the sequential tests and the preemptive stage on the host, mask + refinement kernels, D2H"}
-    # the call is a chain of dependent host hops: several calls in flight (one library context + host thread each) overlap them
-    from concurrent.futures import ThreadPoolExecutor
-    import matchinglib_poselib_amd as mpa
-    nw, per = 4, 8
-    wctx = [mpa.Context(dev.index or 0) for _ in range(nw)]
-    def many(w):
-        for _ in range(per):
-            pose.arrsac_essential(p1, p2, th, refine=True, rng_state=np.array(pose.ARRSAC_RNG_FRESH, np.uint64), ctx=wctx[w])
-    with ThreadPoolExecutor(max_workers=nw) as ex:
-        list(ex.map(many, range(nw)))   # warm-up: workspaces
-        t0 = time.perf_counter()
-        list(ex.map(many, range(nw)))
-        dt4 = (time.perf_counter() - t0) / (nw * per)
-    for c in wctx:
-        c.close()
-    out["arrsac_default_method_4_in_flight"] = {"metric": "the same call from 4 host threads with one library context each", "ms_per_call": dt4 * 1e3,
-                                                "value": 1.0 / dt4, "unit": "calls/s"}
     if cpu_baseline:
         tc = time.perf_counter()
         ora.arrsac_essential(p1, p2, th, refine=True)
@@ -264,4 +248,22 @@ def run(ctx, dev, cpu_baseline=True):
         same = bool(np.concatenate(recs).tobytes() == recsw[:npairs].tobytes())
         out[f"c5_pair_pipeline_{workers}_in_flight"] = {"value": len(many) / dt, "unit": "image-pairs/s (one GPU)",
                                                         "ms_per_pair": dt / len(many) * 1e3, "same_records_as_sequential": same}
+    p1, p2, th = arr_scene
+    # the call is a chain of dependent host hops: several calls in flight (one library context + host thread each) overlap them
+    from concurrent.futures import ThreadPoolExecutor
+    import matchinglib_poselib_amd as mpa
+    nw, per = 4, 8
+    wctx = [mpa.Context(dev.index or 0) for _ in range(nw)]
+    def many(w):
+        for _ in range(per):
+            pose.arrsac_essential(p1, p2, th, refine=True, rng_state=np.array(pose.ARRSAC_RNG_FRESH, np.uint64), ctx=wctx[w])
+    with ThreadPoolExecutor(max_workers=nw) as ex:
+        list(ex.map(many, range(nw)))   # warm-up: workspaces
+        t0 = time.perf_counter()
+        list(ex.map(many, range(nw)))
+        dt4 = (time.perf_counter() - t0) / (nw * per)
+    for c in wctx:
+        c.close()
+    out["arrsac_default_method_4_in_flight"] = {"metric": "the same call from 4 host threads with one library context each", "ms_per_call": dt4 * 1e3,
+                                                "value": 1.0 / dt4, "unit": "calls/s"}
     return out
