@@ -696,7 +696,10 @@ struct ArrsacRun {
     int ensure_full(const std::vector<int> &ids) {
         std::vector<int> need;
         for (int id : ids)
-            if (pool[id].full < 0 && std::find(need.begin(), need.end(), id) == need.end()) need.push_back(id);
+            if (pool[id].full == -1) {
+                pool[id].full = -2;  // queued
+                need.push_back(id);
+            }
         for (size_t at = 0; at < need.size(); at += (size_t)kArrBatchCap * 10) {
             const int cnt = (int)std::min(need.size() - at, (size_t)kArrBatchCap * 10);
             int32_t *h_rows = (int32_t *)h_out;
