@@ -252,13 +252,21 @@ int mlpl_arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
 int mlpl_robust_essential_refine(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const uint8_t *mask, const double E_init[9],
                                  double th, double E_refined[9], int info[2]);
 
+/* ARRSAC's model estimators on ONE sample (EssentialMatEstimatorTheia::EstimateModel / EstimateModelNonminimal, modelest.cpp:111-178), a
+ * building block exposed for parity tests: idx = m indices into p1/p2; kind 0 = the 5-point solver on 5..7 correspondences (the reference
+ * runs run5Point on them: cv::SVD of an m x 9 system, its four last right singular vectors), kind 1 = cv::findFundamentalMat(FM_8POINT)
+ * on 8..14.  E_out: 10 x 9 doubles, the first *n_models are models (solver order, library sign convention); valid[i] = ValidModel
+ * (five-point.cpp:534-601) on the sample's correspondences.  thresh only sizes internal buffers' inlier rows. */
+int mlpl_arrsac_sample_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const int32_t *idx, int m, int kind, double thresh,
+                              double *E_out, int32_t *n_models, uint8_t *valid);
+
 /* Statistics of the last mlpl_arrsac_essential[_dev] call: {k of the initial hypothesis set, hypotheses after it, PROSAC samples,
  * inner-RANSAC samples, inner-RANSAC restarts, samples of the preemptive stage, correspondence index where that stage ended,
  * hypotheses left there, device batches, samples solved on the device, samples the control flow consumed, refinement status
  * (-1 not run, 0 converged, 1 stopped on an invalid matrix, 2 rejected)}. */
 int mlpl_arrsac_last_stats(mlpl_ctx *ctx, long long stats[12]);
 /* Diagnostics: the following mlpl_arrsac_essential* calls record the turns of their first stage into buf (20 ints per turn: k, inner-RANSAC
- * turn?, sample size, its first five indices, valid models, per model 1000 * accepted + inliers seen by the sequential test); returns the
+ * turn?, sample size, its first five indices, valid models, per model 1000 * accepted + inliers seen by the sequential test, sixth + 100 * seventh index); returns the
  * number of ints written since the previous call of this function.  buf = NULL switches the recording off. */
 int mlpl_debug_arrsac_trace(mlpl_ctx *ctx, int32_t *buf, int cap);
 

@@ -830,7 +830,7 @@ struct ArrsacRun {
         for (int i = 0; i < 5; ++i) r[3 + i] = key.v[1 + i];
         r[8] = nvalid;
         for (int i = 0; i < 10; ++i) r[9 + i] = i < nvalid ? res[i] : -1;
-        r[19] = 0;
+        r[19] = (key.size() > 5 ? key.v[6] : 0) + 100 * (key.size() > 6 ? key.v[7] : 0);  // indices of the first stage are < 100
         ctx->arrsac_trace_len += 20;
     }
 
@@ -1041,6 +1041,30 @@ struct ArrsacRun {
 };
 
 }  // namespace
+
+// The estimators of one ARRSAC sample, for tests: all models the device forms for it (before the validity filter) with their flags.
+int arrsac_sample_models(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, const int32_t *idx, int m, int kind, double thresh,
+                         double *E_out, int32_t *n_models, uint8_t *valid, hipStream_t s) {
+    ArrsacRun R;
+    R.ctx = ctx, R.s = s, R.d_p1 = d_p1, R.d_p2 = d_p2, R.n = n;
+    R.flag_points = std::min(n, kArrFlagPoints);
+    R.thresh2 = thresh * thresh;
+    int rc;
+    double4 *pts = nullptr;
+    if ((rc = pack_points(ctx, d_p1, d_p2, n, &pts, s))) return rc;
+    R.pts = pts;
+    if ((rc = R.alloc())) return rc;
+    ArrKey key;
+    key.reset(kind);
+    for (int i = 0; i < m; ++i) key.push(idx[i]);
+    if ((rc = R.run_batch(std::vector<ArrKey>(1, key)))) return rc;
+    const int32_t *h_nm = (const int32_t *)R.h_out, *h_valid = (const int32_t *)(R.h_out + 4);  // B = 1: out_nm | out_valid
+    const int nm = std::min(h_nm[0], 10);
+    *n_models = nm;
+    for (int i = 0; i < 10; ++i) valid[i] = i < nm && h_valid[i] ? 1 : 0;
+    MLPL_HIP_TRY(hipMemcpy(E_out, R.d_Epool, 720, hipMemcpyDeviceToHost));
+    return MLPL_OK;
+}
 
 int arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thresh, int refine, uint64_t *rng_state,
                          double *E, uint8_t *d_mask, int *n_inliers, hipStream_t s) {

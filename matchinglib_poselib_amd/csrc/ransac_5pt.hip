@@ -2678,6 +2678,28 @@ int mlpl_arrsac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int
     return rc;
 }
 
+int mlpl_arrsac_sample_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const int32_t *idx, int m, int kind, double thresh,
+                              double *E_out, int32_t *n_models, uint8_t *valid) {
+    if (!ctx || !p1 || !p2 || !idx || !E_out || !n_models || !valid || n < 5 || m < 5 || m > kArrMaxSample || (kind != 0 && kind != 1) ||
+        (kind == 0 && m > 7) || (kind == 1 && m < 8) || !(thresh > 0)) {
+        set_error("mlpl_arrsac_sample_models: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    for (int i = 0; i < m; ++i)
+        if (idx[i] < 0 || idx[i] >= n) {
+            set_error("mlpl_arrsac_sample_models: sample index out of range");
+            return MLPL_E_BAD_INPUT;
+        }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    void *dp1, *dp2;
+    int rc;
+    if ((rc = ws_get(ctx, WS_AUX0, (size_t)n * 16, &dp1))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX1, (size_t)n * 16, &dp2))) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(dp1, p1, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    MLPL_HIP_TRY(hipMemcpyAsync(dp2, p2, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    return arrsac_sample_models(ctx, (const double *)dp1, (const double *)dp2, n, idx, m, kind, thresh, E_out, n_models, valid, ctx->stream);
+}
+
 int mlpl_robust_essential_refine(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const uint8_t *mask, const double E_init[9],
                                  double th, double E_refined[9], int info[2]) {
     if (!ctx || !p1 || !p2 || !E_init || !E_refined || n < 1 || !(th > 0)) {

@@ -134,6 +134,19 @@ def arrsac_essential(p1, p2, thresh: float, refine: bool = True, rng_state=None,
     return dict(ok=(rc == 0), E=E, mask=mask, n_inliers=ninl.value, stats=stats)
 
 
+def arrsac_sample_models(p1, p2, idx, kind: int, thresh: float = 1e-3, ctx: Optional[Context] = None):
+    """ARRSAC's estimators on one sample (modelest.cpp:111-178) -> (models [k,3,3] before the validity filter, valid flags [k])."""
+    ctx = ctx or default_context()
+    p1, p2 = _pts(p1), _pts(p2)
+    idx = np.ascontiguousarray(idx, np.int32)
+    E = np.zeros((10, 3, 3))
+    nm = C.c_int(0)
+    valid = np.zeros(10, np.uint8)
+    check(ctx.lib.mlpl_arrsac_sample_models(ctx.handle, p1.ctypes.data, p2.ctypes.data, p1.shape[0], idx.ctypes.data, len(idx), int(kind),
+                                            float(thresh), E.ctypes.data, C.addressof(nm), valid.ctypes.data), "mlpl_arrsac_sample_models")
+    return E[: nm.value].copy(), valid[: nm.value].astype(bool)
+
+
 def robust_essential_refine(p1, p2, E_init, th: float, mask=None, ctx: Optional[Context] = None):
     """poselib::robustEssentialRefine for the essential-matrix model (pose_estim.cpp:337-792) -> (E_refined, rounds, status)."""
     ctx = ctx or default_context()

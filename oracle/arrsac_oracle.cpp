@@ -302,7 +302,7 @@ void trace_turn(int k, int inner, const std::vector<int> &subset, int nvalid, co
     for (int i = 0; i < 5; ++i) r[3 + i] = subset[i];
     r[8] = nvalid;
     for (int i = 0; i < 10; ++i) r[9 + i] = i < nvalid ? res[i] : -1;
-    r[19] = 0;
+    r[19] = (subset.size() > 5 ? subset[5] : 0) + 100 * (subset.size() > 6 ? subset[6] : 0);  // indices of the first stage are < 100
     g_trace_len += 20;
 }
 
@@ -775,7 +775,8 @@ int oracle_arrsac_essential(const double *p1, const double *p2, int n, double th
 }
 
 /* Test hook: record the turns of the first stage of the following oracle_arrsac_essential calls into buf (20 ints per turn:
- * k, inner, sample size, first five indices, valid models, per model 1000 * accepted + inliers seen); returns the ints written so far. */
+ * k, inner, sample size, first five indices, valid models, per model 1000 * accepted + inliers seen, sixth + 100 * seventh index);
+ * returns the ints written so far. */
 int oracle_arrsac_trace(int32_t *buf, int cap) {
     const int len = g_trace_len;
     g_trace = buf, g_trace_cap = cap, g_trace_len = 0;

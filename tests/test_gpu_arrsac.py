@@ -194,3 +194,50 @@ def test_robust_essential_refine_on_the_device(ctx, oracle):
         assert s[2] < 1e-12 * s[0]
     E_g, it_g, status = pose.robust_essential_refine(p1[:40], p2[:40], o["E"], th / 10, ctx=ctx)      # too few points: returned as is
     assert status == 2 and np.array_equal(E_g, o["E"])
+
+
+def _cubic_residual(E):
+    E = E / np.linalg.norm(E)
+    return max(np.abs(2 * E @ E.T @ E - np.trace(E @ E.T) * E).max(), abs(np.linalg.det(E)))
+
+
+def test_arrsac_estimators_on_single_samples(ctx, oracle):
+    """The estimators ARRSAC's inner RANSAC uses, sample by sample: the 5-point solver on 6 and 7 correspondences (cv::SVD's four last
+    right singular vectors of an m x 9 system there, the Gram matrix's four smallest eigenvectors here) and the 8-point fit on 8..14.
+    Every oracle solution that IS an essential matrix (cubic constraints to 1e-9) must be reproduced; where the CPU elimination is ill
+    conditioned its solutions are off the constraints by up to 1e-2 (tools/arrsac_sample_check.py 600 0.7 1436 0 1.0 9,2,28,3,65,94)
+    while the device's stay on them -- those are counted, not compared."""
+    p1, p2, R, t, truth, th = synth.pose_scene(400, 0.8, seed=91, noise_px=1.0)
+    rng = np.random.default_rng(7)
+    ctx.set_option("solver_polish", 0)
+    try:
+        compared = off = 0
+        for trial in range(60):
+            m = 6 + (trial & 1)
+            idx = rng.choice(100, m, replace=False).astype(np.int32)
+            Eg, vg = pose.arrsac_sample_models(p1, p2, idx, 0, ctx=ctx)
+            Eo = [np.asarray(e).reshape(3, 3) for e in oracle.run5point(p1[idx], p2[idx])]
+            A = np.array([[a[0] * b[0], a[1] * b[0], b[0], a[0] * b[1], a[1] * b[1], b[1], a[0], a[1], 1.0] for a, b in zip(p1[idx], p2[idx])])
+            N = np.linalg.svd(A)[2][-4:].T
+            for e in Eg:   # every device model lies in the reference's subspace and on the constraints
+                v = e.reshape(9) / np.linalg.norm(e)
+                assert np.linalg.norm(v - N @ (N.T @ v)) < 1e-9 and _cubic_residual(e) < 1e-6
+            for e in Eo:
+                if _cubic_residual(e) > 1e-9:
+                    off += 1
+                    continue
+                compared += 1
+                j = int(np.argmin([e_dist(e, x) for x in Eg]))
+                assert e_dist(e, Eg[j]) < 1e-6, (trial, e_dist(e, Eg[j]))
+                s = 1.0 if np.abs(e / np.linalg.norm(e) - Eg[j] / np.linalg.norm(Eg[j])).max() < 1e-6 else -1.0
+                assert vg[j] == oracle.valid_model(p1[idx], p2[idx], s * e), trial      # same verdict for the same signed matrix
+        assert compared > 100, (compared, off)
+        for m in range(8, 15):
+            for trial in range(6):
+                idx = rng.choice(100, m, replace=False).astype(np.int32)
+                Eg, vg = pose.arrsac_sample_models(p1, p2, idx, 1, ctx=ctx)
+                ok, F = oracle.cv_fm_8point(p1[idx], p2[idx])
+                assert ok and len(Eg) == 1 and np.abs(Eg[0] - F).max() < 1e-8 * np.abs(F).max(), (m, trial)
+                assert vg[0] == oracle.valid_model(p1[idx], p2[idx], F)
+    finally:
+        ctx.set_option("solver_polish", 1)

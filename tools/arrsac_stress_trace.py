@@ -31,6 +31,18 @@ for i in range(min(len(tg), len(to))):
     if not np.array_equal(tg[i], to[i]):
         print("first difference at turn", i); print(" gpu", tg[i].tolist()); print(" cpu", to[i].tolist())
         m = to[i, 2]
+        if m in (6, 7):
+            idx = list(to[i, 3:8]) + [int(to[i, 19]) % 100] + ([int(to[i, 19]) // 100] if m == 7 else [])
+            idx = np.array(idx)
+            Eo = ora.run5point(p1[idx], p2[idx])
+            A = np.array([[a[0] * b[0], a[1] * b[0], b[0], a[0] * b[1], a[1] * b[1], b[1], a[0], a[1], 1.0] for a, b in zip(p1[idx], p2[idx])])
+            print(" sample", idx.tolist(), "singular values of the", A.shape, "system:", np.linalg.svd(A, compute_uv=False))
+            w, V = np.linalg.eigh(A.T @ A)
+            print(" eigenvalues of the Gram matrix:", w)
+            for e in Eo:
+                e = np.asarray(e).reshape(3, 3)
+                err = ora.sampson_err(p1[:100], p2[:100], e) if hasattr(ora, "sampson_err") else None
+                print("   oracle model inliers on the first 100:", None if err is None else int((err < th * th).sum()), "valid", ora.valid_model(p1[idx], p2[idx], e), ora.valid_model(p1[idx], p2[idx], -e))
         if m == 5:
             idx = to[i, 3:8]
             Eo = ora.run5point(p1[idx], p2[idx])
