@@ -1537,9 +1537,19 @@ __device__ __forceinline__ void jacobi9_wave(Jacobi9Lds &J, int lane) {
                 if (q < 9) {
                     const double apq = Gc[p][q];
                     if (apq != 0.0) {
-                        const double theta = (Gc[q][q] - Gc[p][p]) / (2.0 * apq);
-                        const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                        c = 1.0 / sqrt(tt * tt + 1.0);
+                        // The rotation is orthogonal to rounding for ANY tangent tt as long as c = (1 + tt^2)^-1/2 is accurate and s = tt c;
+                        // an inexact tt only leaves a'_pq at ~1e-8 a_pq instead of 0, which the next sweep removes.  So the tangent comes
+                        // from the hardware approximations (v_rcp_f64 / v_sqrt_f64, ~2^-27) and only c gets a Newton step: two IEEE
+                        // divisions and two IEEE square roots (~500 dependent cycles per round) become ~150.
+                        const double theta = (Gc[q][q] - Gc[p][p]) * __builtin_amdgcn_rcp(2.0 * apq);
+                        const double at = fabs(theta);
+                        double tt = __builtin_amdgcn_rcp(at + __builtin_amdgcn_sqrt(at * at + 1.0));
+                        tt = theta >= 0 ? tt : -tt;
+                        if (!(at < 1e150)) tt = 0.5 / theta;  // theta^2 overflows: t = 1 / (2 theta) to rounding
+                        const double x = tt * tt + 1.0;
+                        const double y0 = __builtin_amdgcn_rsq(x);
+                        c = y0 * (1.5 - 0.5 * x * y0 * y0);
+                        c = c * (1.5 - 0.5 * x * c * c);
                         sn = tt * c;
                     }
                 }
