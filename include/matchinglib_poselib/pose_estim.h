@@ -109,6 +109,32 @@ void robustEssentialRefine(cv::InputArray points1, cv::InputArray points2, cv::I
                            cv::OutputArray errors = cv::noArray(), cv::InputOutputArray mask = cv::noArray(), int model = 0,
                            bool tryOrientedEpipolar = false, bool normalizeCorrs = false);
 
+// poselib::AutoThEpi (pose_estim.h:137-190, pose_estim.cpp:81-300): ARRSAC with an inlier threshold estimated from the error statistics
+// of its own result -- estimate, derive a threshold (mean + 3 sigma of the Sampson distances, or median + 3 MAD-sigma when the two
+// disagree, clamped to [0.25, 2] pixels), re-estimate until the threshold settles.  Thresholds in camera units unless stated.
+class AutoThEpi {
+   public:
+    explicit AutoThEpi(double pixToCamFact_, bool thStable = false)
+        : corr_filt_cam_th(PIX_TH_START * pixToCamFact_),
+          corr_filt_pix_th(PIX_TH_START),
+          corr_filt_min_pix_th(MIN_PIX_TH),
+          th_stable(thStable),
+          pixToCamFact(pixToCamFact_) {}
+    double getThCam() { return corr_filt_cam_th; }
+    double getThPix() { return corr_filt_pix_th; }
+    void setThStable(bool isStable) { th_stable = isStable; }
+    // 0 ok; -1 no essential matrix at any threshold tried; -2 E not requested.  *th is read and updated.
+    int estimateEVarTH(cv::InputArray p1, cv::InputArray p2, cv::OutputArray E, cv::OutputArray mask, double *th, int *nrgoodPts);
+    // useImgCoordSystem = true needs camera matrices the class does not hold (the reference asserts there): camera units only.
+    double estimateThresh(cv::InputArray p1, cv::InputArray p2, cv::InputArray E, bool useImgCoordSystem = false, bool storeGlobally = false);
+    double setCorrTH(double thresh, bool useImgCoordSystem = false, bool storeGlobally = true);
+
+   private:
+    double corr_filt_cam_th, corr_filt_pix_th, corr_filt_min_pix_th;
+    bool th_stable;
+    double pixToCamFact;
+};
+
 // poselib::getPoseTriangPts (pose_estim.h:192-200, pose_estim.cpp:913-946).  Returns the number of valid 3-D points,
 // or -1 when R, t or Q is cv::noArray().  translatE = true: E is a translational essential matrix, R = I.
 int getPoseTriangPts(cv::InputArray E, cv::InputArray p1, cv::InputArray p2, cv::OutputArray R, cv::OutputArray t,

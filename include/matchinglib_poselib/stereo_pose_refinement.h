@@ -8,11 +8,12 @@
 // near-to-mean pose rating and the stability flags (:2817-3298), maxSkipPairs handling (:3300-3317).
 // Every robust estimation and every error evaluation runs on the MI355X (estimateEssentialMat / getPoseTriangPts / mlpl_get_inliers_strict).
 //
-// Not built (outside the hot path): USAC, automatic thresholds (autoTH), homography alignment
+// Not built (outside the hot path): USAC, homography alignment
 // (Halign), the linear refinement solvers (refineMethod / refineMethod_CorrPool: Nister/Stewenius/Kneip/8pt with weights) and bundle
 // adjustment (BART).  refineRTold IS built: the estimator's own refinement step plus poselib::robustEssentialRefine on the inliers
 // (:1460-1474), on the device.  Consequences of what is not built, all reported once on std::cout:
-//   * RobMethod must be "RANSAC", "LMEDS" or "ARRSAC"; "USAC", autoTH and Halign make addNewCorrespondences() return -1;
+//   * RobMethod must be "RANSAC", "LMEDS" or "ARRSAC"; "USAC" and Halign make addNewCorrespondences() return -1; autoTH (ARRSAC with
+//     poselib::AutoThEpi's threshold estimation, :1330-1342) is built;
 //   * refinement / BA options are ignored;
 //   * between robust estimations the pool pose is REFINED (checkPoolPoseRobust != 1, the reference's schedule :680-716) only with
 //     refineRTold_CorrPool, the refinement that is built (refinePoseFromPool :1767-2084 with robustEssentialRefine on the device);

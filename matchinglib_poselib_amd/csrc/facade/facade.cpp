@@ -237,6 +237,143 @@ void robustEssentialRefine(cv::InputArray points1, cv::InputArray points2, cv::I
     E_refined = out;
 }
 
+// ---- AutoThEpi (pose_estim.cpp:81-300) ------------------------------------------------------------------------------------------------
+namespace {
+struct FullStats {
+    double medErr = 0, arithErr = 0, arithStd = 0, medStd = 0;
+};
+// getStatsfromVec (pose_helper.cpp:358-413) with its quartile rejection and the rounding of a tiny variance
+FullStats fullStatsFromVec(const std::vector<double> &vals, bool rejQuartiles, bool roundStd = true) {
+    FullStats st;
+    if (vals.empty()) return st;
+    int n = (int)vals.size();
+    const int qrt_si = (int)std::floor(0.25 * (double)n);
+    std::vector<double> v(vals);
+    std::sort(v.begin(), v.end());
+    st.medErr = (n % 2) ? v[(n - 1) / 2] : (v[n / 2] + v[n / 2 - 1]) / 2.0;
+    double sum = 0, sum2 = 0;
+    std::vector<double> mad;
+    for (int i = rejQuartiles ? qrt_si : 0; i < (rejQuartiles ? (n - qrt_si) : n); i++) {
+        sum += v[i];
+        sum2 += v[i] * v[i];
+        mad.push_back(std::abs(v[i] - st.medErr));
+    }
+    if (rejQuartiles) n -= 2 * qrt_si;
+    st.arithErr = sum / (double)n;
+    std::sort(mad.begin(), mad.end());
+    st.medStd = (n % 2) ? 1.4826 * mad[(n - 1) / 2] : 1.4826 * (mad[n / 2] + mad[n / 2 - 1]) / 2.0;
+    const double hlp = sum2 - (double)n * st.arithErr * st.arithErr;
+    st.arithStd = (roundStd && std::abs(hlp) < 1e-6) ? 0.0 : std::sqrt(hlp / ((double)n - 1.0));
+    return st;
+}
+}  // namespace
+
+double AutoThEpi::setCorrTH(double thresh, bool useImgCoordSystem, bool storeGlobally) {  // :279-300
+    double pix = useImgCoordSystem ? thresh : thresh / pixToCamFact;
+    if (pix < corr_filt_min_pix_th) pix = corr_filt_min_pix_th;
+    else if (pix > MAX_PIX_TH) pix = MAX_PIX_TH;
+    const double cam = pix * pixToCamFact;
+    if (storeGlobally) corr_filt_pix_th = pix, corr_filt_cam_th = cam;
+    return useImgCoordSystem ? pix : cam;
+}
+
+double AutoThEpi::estimateThresh(cv::InputArray p1, cv::InputArray p2, cv::InputArray E_, bool useImgCoordSystem, bool storeGlobally) {  // :196-262
+    if (useImgCoordSystem) throw cv::Exception("AutoThEpi::estimateThresh: image coordinates need camera matrices the class does not hold");
+    int n1 = 0, n2 = 0;
+    std::vector<double> a = points64(p1, n1), b = points64(p2, n2);
+    CV_Assert(n1 == n2 && n1 > 0);
+    const cv::Mat E = E_.getMat();
+    double Ev[9];
+    for (int i = 0; i < 9; ++i) Ev[i] = E.at<double>(i / 3, i % 3);
+    std::vector<double> error((size_t)n1);
+    std::vector<uint8_t> m((size_t)n1);
+    if (mlpl_get_inliers_strict(default_ctx(), a.data(), b.data(), n1, Ev, 1.0, error.data(), m.data()) < 0)  // computeReprojError2 on the device
+        throw cv::Exception(std::string("AutoThEpi::estimateThresh: ") + mlpl_last_error());
+    for (double &e : error) e = std::sqrt(e);
+    double th = corr_filt_cam_th;
+    double maxInlDist = 4.0 * th;
+    maxInlDist = maxInlDist > 5.0 * pixToCamFact ? (5.0 * pixToCamFact) : maxInlDist;
+    const double r1 = *std::max_element(error.begin(), error.end()) - *std::min_element(error.begin(), error.end());
+    const FullStats qp = fullStatsFromVec(error, r1 > maxInlDist);
+    double th_tmp;
+    if ((qp.arithErr / qp.medErr > 2.0) || (qp.arithErr / qp.medErr < 0.5)) th_tmp = qp.medErr + 3.0 * qp.medStd;
+    else th_tmp = qp.arithErr + 3.0 * qp.arithStd;
+    if ((th_tmp < 5.0 * th) || (th_tmp < 4.0 * PIX_MIN_GOOD_TH)) {  // (sic) the second test compares camera units with pixels: always true
+        th = setCorrTH(th_tmp, false, storeGlobally);
+    } else if (th < (MAX_PIX_TH / 2) * pixToCamFact) {
+        th = setCorrTH(th * 2.0, false, storeGlobally);
+    } else {
+        th = setCorrTH(corr_filt_min_pix_th, true, storeGlobally) * pixToCamFact;
+    }
+    return th;
+}
+
+int AutoThEpi::estimateEVarTH(cv::InputArray p1, cv::InputArray p2, cv::OutputArray E, cv::OutputArray mask, double *th, int *nrgoodPts) {  // :81-178
+    bool th_sem[3] = {true, true, false};
+    int th_fail_cnt = 2;
+    double th_failed = *th, th_old;
+    cv::Mat mask_, E_;
+    int n1 = 0;
+    {
+        int n2 = 0;
+        points64(p1, n1);
+        (void)n2;
+    }
+    auto count = [](const cv::Mat &m) {
+        int c = 0;
+        for (int i = 0; i < m.rows * m.cols; ++i) c += (m.rows == 1 ? m.at<uint8_t>(0, i) : m.at<uint8_t>(i, 0)) != 0;
+        return c;
+    };
+    // findEssentialMat(E, p1, p2, ARRSAC, 0.99, th, mask, true, robustEssentialRefine)
+    auto find = [&](double t) {
+        cv::Mat e, m;
+        if (!estimateEssentialMat(e, p1, p2, "ARRSAC", t, true, m)) return false;
+        E_ = e, mask_ = m;
+        return true;
+    };
+    do {
+        mask_ = cv::Mat();
+        th_old = *th;
+        if (!find(*th)) {
+            if ((*th < PIX_MIN_GOOD_TH * pixToCamFact) && !th_stable && !th_sem[2]) {
+                th_failed = *th;
+                *th = PIX_MIN_GOOD_TH * pixToCamFact;
+                th_old = *th;
+                if (!find(*th)) return -1;
+                th_sem[2] = true;
+            } else if (th_sem[2]) {
+                th_fail_cnt *= 2;
+            } else {
+                return -1;
+            }
+        } else {
+            if (th_sem[2] && (th_fail_cnt > 2)) corr_filt_min_pix_th = *th / pixToCamFact;
+            th_sem[2] = false;
+        }
+        if ((th_fail_cnt <= 2) || !th_sem[2]) *nrgoodPts = mask_.empty() ? 0 : count(mask_);
+        if (!th_stable) {
+            if ((th_fail_cnt <= 2) || !th_sem[2]) *th = estimateThresh(p1, p2, E_);
+            else *th = th_failed * (double)th_fail_cnt;
+            if (th_sem[2] && (th_failed >= *th)) *th = th_failed * (double)th_fail_cnt;
+            if (!th_sem[2]) {
+                if (th_old / *th > 1.0 + 1e-6) th_sem[0] = false;
+                else if (th_old / *th < 1.0 - 1e-6) th_sem[1] = false;
+            }
+        }
+    } while (((th_old / *th < 0.9) || (*th / th_old < 0.9)) &&
+             ((((float)*nrgoodPts / (float)n1 < 0.67) && (th_sem[0] || th_sem[1])) || th_sem[2]));
+    if (!E.needed()) return -2;
+    E.create(3, 3, CV_64F);
+    cv::Mat Eo = E.getMat();
+    for (int i = 0; i < 9; ++i) Eo.at<double>(i / 3, i % 3) = E_.at<double>(i / 3, i % 3);
+    if (mask.needed()) {
+        mask.create(1, n1, CV_8U);
+        cv::Mat mo = mask.getMat();
+        for (int i = 0; i < n1; ++i) mo.at<uint8_t>(0, i) = mask_.rows == 1 ? mask_.at<uint8_t>(0, i) : mask_.at<uint8_t>(i, 0);
+    }
+    return 0;
+}
+
 int getPoseTriangPts(cv::InputArray E_, cv::InputArray p1, cv::InputArray p2, cv::OutputArray R_, cv::OutputArray t_,
                      cv::OutputArray Q_, cv::InputOutputArray mask_, const double dist, bool translatE) {
     if (!R_.needed() || !t_.needed() || !Q_.needed()) return -1;  // pose_estim.cpp:925-926

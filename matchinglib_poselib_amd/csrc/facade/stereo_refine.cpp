@@ -330,15 +330,27 @@ int StereoRefine::Impl::robustPoseEstimation() {
     have_Q = false;
     Qv.clear();
     std::string method = cfg_pose.RobMethod;
-    if (cfg_pose.autoTH || cfg_pose.Halign || method == "USAC") {
-        std::cout << "StereoRefine (MI355X hot-path library): autoTH, Halign and RobMethod USAC are not built." << std::endl;
+    if (cfg_pose.Halign || (method == "USAC" && !cfg_pose.autoTH)) {
+        std::cout << "StereoRefine (MI355X hot-path library): Halign and RobMethod USAC are not built." << std::endl;
         return -1;
     }
     const int n = (int)(p1new.size() / 2);
-    if (cfg_pose.useRANSAC_fewMatches && n < 100 && method != "RANSAC") method = "RANSAC";  // :1295-1323
+    bool autoTH = cfg_pose.autoTH;
+    // :1295-1323: below 100 matches RANSAC replaces the configured estimator (and the automatic threshold) for this one estimation
+    if (cfg_pose.useRANSAC_fewMatches && n < 100 && (method != "RANSAC" || autoTH)) method = "RANSAC", autoTH = false;
     cv::Mat P1(n, 2, CV_64F, p1new.data()), P2(n, 2, CV_64F, p2new.data());
     cv::Mat E, mask;
-    if (!estimateEssentialMat(E, P1, P2, method, th, cfg_pose.refineRTold, mask)) {
+    if (autoTH) {
+        // :1330-1342: ARRSAC with the threshold estimated from its own error statistics; `th` keeps the estimate for the frames to come
+        // (th2, the squared threshold of the strict inlier test, is NOT updated -- as in the reference, :159-160)
+        int inlierPoints = 0;
+        AutoThEpi Eautoth(pixToCamFact);
+        if (Eautoth.estimateEVarTH(P1, P2, E, mask, &th, &inlierPoints) != 0) {
+            std::cout << "Estimation of essential matrix using automatic threshold estimation and ARRSAC failed!" << std::endl;
+            return -1;
+        }
+        std::cout << "Estimated threshold: " << th / pixToCamFact << " pixels" << std::endl;
+    } else if (!estimateEssentialMat(E, P1, P2, method, th, cfg_pose.refineRTold, mask)) {
         std::cout << "Estimation of essential matrix using " << method << " failed!" << std::endl;
         return -1;
     }

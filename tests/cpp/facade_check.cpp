@@ -147,6 +147,19 @@ int main(int argc, char **argv) {
         poselib::getArrsacRngState(&st[0], &st[1]);
         fwrite(st, 8, 2, o);
     }
+    // AutoThEpi (pose_estim.cpp:81-300): ARRSAC with the threshold estimated from its own error statistics, starting at the file's threshold
+    {
+        const double pixToCam = th / 0.8;   // the scene generator's threshold is 0.8 pixels in camera units
+        poselib::AutoThEpi ath(pixToCam);
+        double tha = th;
+        int32_t ng = 0;
+        cv::Mat Eat, mat;
+        int32_t rca = ath.estimateEVarTH(p1, p2, Eat, mat, &tha, &ng);
+        fwrite(&rca, 4, 1, o);
+        fwrite(&tha, 8, 1, o);
+        fwrite(&ng, 4, 1, o);
+        fwrite(rca == 0 ? (const void *)Eat.data : (const void *)zero, 8, 9, o);
+    }
     fclose(o);
     return 0;
 }

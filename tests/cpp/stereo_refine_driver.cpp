@@ -1,7 +1,7 @@
 // stereo_refine_driver.cpp -- runs poselib::StereoRefine over a sequence of stereo frames the way the reference harness does
 // (tests/poselib-test/main.cpp:1460-1530: one addNewCorrespondences() per image pair) and dumps the state after every frame;
 // tests/test_gpu_stereo_refine.py compares the dump with the CPU restatement of the state machine (tests/stereo_refine_oracle.py).
-//   in : int32 nframes, robMethod(0 RANSAC, 1 LMEDS, 2 ARRSAC) ; uint32 seed ; f64 K0[4], K1[4] (fx fy cx cy) ; f64 dist0[8], dist1[8] ; f64 cfg[20] ;
+//   in : int32 nframes, robMethod(0 RANSAC, 1 LMEDS, 2 ARRSAC) ; uint32 seed ; f64 K0[4], K1[4] (fx fy cx cy) ; f64 dist0[8], dist1[8] ; f64 cfg[21] ;
 //        per frame: int32 n ; f32 kp1[n][3] (x, y, response) ; f32 kp2[n][3] ; f32 descrDist[n]      (match i joins kp1[i] and kp2[i])
 //   out: per frame: int32 rc, nr_inliers_new, nr_corrs_new, pool, nrEstimation, skipCount, poseIsStable, mostLikelyPose_stable, history ;
 //        f64 E_new[9], R_new[9], t_new[3], E_mostLikely[9]  (zeros while empty)
@@ -24,9 +24,9 @@ int main(int argc, char **argv) {
     if (!f) return 2;
     int32_t hdr[2];
     uint32_t seed;
-    double k0[4], k1[4], d0[8], d1[8], c[20];
+    double k0[4], k1[4], d0[8], d1[8], c[21];
     if (fread(hdr, 4, 2, f) != 2 || fread(&seed, 4, 1, f) != 1 || fread(k0, 8, 4, f) != 4 || fread(k1, 8, 4, f) != 4 ||
-        fread(d0, 8, 8, f) != 8 || fread(d1, 8, 8, f) != 8 || fread(c, 8, 20, f) != 20)
+        fread(d0, 8, 8, f) != 8 || fread(d1, 8, 8, f) != 8 || fread(c, 8, 21, f) != 21)
         return 2;
     cv::Mat K0 = cv::Mat::zeros(3, 3, CV_64F), K1 = cv::Mat::zeros(3, 3, CV_64F), dist0(1, 8, CV_64F), dist1(1, 8, CV_64F);
     K0.at<double>(0, 0) = k0[0], K0.at<double>(1, 1) = k0[1], K0.at<double>(0, 2) = k0[2], K0.at<double>(1, 2) = k0[3], K0.at<double>(2, 2) = 1;
@@ -56,6 +56,7 @@ int main(int argc, char **argv) {
     cfg.refineRTold = c[17] != 0;
     cfg.checkPoolPoseRobust = (size_t)c[18];
     cfg.refineRTold_CorrPool = c[19] != 0;
+    cfg.autoTH = c[20] != 0;
     poselib::ConfigUSAC cfg_usac;
     poselib::setRansacSeed(seed);
     poselib::StereoRefine sr(cfg);

@@ -35,6 +35,7 @@ class Cfg:
         self.raiseSkipCnt = 0
         self.maxRat3DPtsFar = 0.5
         self.maxDist3DPtsZ = 50.0
+        self.autoTH = False
         self.checkPoolPoseRobust = 1       # the struct's default is 3; 1 = always re-estimate robustly (the tests' historical setting)
         self.refineRTold_CorrPool = False
         for k, v in kw.items():
@@ -46,7 +47,107 @@ class Cfg:
                          self.relMinInlierRatSkip, self.maxSkipPairs, self.minInlierRatioReInit, self.minPtsDistance,
                          self.maxPoolCorrespondences, self.minContStablePoses, self.absThRankingStable, float(self.useRANSAC_fewMatches),
                          self.minNormDistStable, self.raiseSkipCnt, self.maxRat3DPtsFar, self.maxDist3DPtsZ, float(self.refineRTold),
-                         float(self.checkPoolPoseRobust), float(self.refineRTold_CorrPool)], np.float64)
+                         float(self.checkPoolPoseRobust), float(self.refineRTold_CorrPool), float(self.autoTH)], np.float64)
+
+
+def full_stats(vals, rej_quartiles, round_std=True):
+    """getStatsfromVec (pose_helper.cpp:358-413) -> (medErr, arithErr, arithStd, medStd)."""
+    v = np.sort(np.asarray(vals, np.float64))
+    n = len(v)
+    if n == 0:
+        return 0.0, 0.0, 0.0, 0.0
+    q = int(math.floor(0.25 * n))
+    med = v[(n - 1) // 2] if n % 2 else (v[n // 2] + v[n // 2 - 1]) / 2.0
+    lo, hi = (q, n - q) if rej_quartiles else (0, n)
+    s = s2 = 0.0
+    mad = []
+    for i in range(lo, hi):
+        s += v[i]
+        s2 += v[i] * v[i]
+        mad.append(abs(v[i] - med))
+    if rej_quartiles:
+        n -= 2 * q
+    arith = s / n
+    mad.sort()
+    med_std = 1.4826 * mad[(n - 1) // 2] if n % 2 else 1.4826 * (mad[n // 2] + mad[n // 2 - 1]) / 2.0
+    hlp = s2 - n * arith * arith
+    std = 0.0 if (round_std and abs(hlp) < 1e-6) else math.sqrt(hlp / (n - 1.0))
+    return med, arith, std, med_std
+
+
+class AutoThEpiOracle:
+    """poselib::AutoThEpi (pose_estim.cpp:81-300) over the CPU oracle: `find(th)` -> dict(ok, E, mask) is ARRSAC with refinement."""
+    PIX_TH_START, MIN_PIX_TH, MAX_PIX_TH, PIX_MIN_GOOD_TH = 0.5, 0.25, 2.0, 1.6
+
+    def __init__(self, o, f, find):
+        self.o, self.f, self.find = o, f, find
+        self.cam_th, self.pix_th, self.min_pix_th, self.stable = self.PIX_TH_START * f, self.PIX_TH_START, self.MIN_PIX_TH, False
+
+    def set_corr_th(self, thresh, img=False, store=True):
+        pix = thresh if img else thresh / self.f
+        pix = self.min_pix_th if pix < self.min_pix_th else (self.MAX_PIX_TH if pix > self.MAX_PIX_TH else pix)
+        cam = pix * self.f
+        if store:
+            self.pix_th, self.cam_th = pix, cam
+        return pix if img else cam
+
+    def estimate_thresh(self, a, b, E):
+        err = np.sqrt(self.o.get_inliers_strict(a, b, E, 1.0)[2])
+        th = self.cam_th
+        max_inl = min(4.0 * th, 5.0 * self.f)
+        med, arith, std, med_std = full_stats(err, (err.max() - err.min()) > max_inl)
+        th_tmp = med + 3.0 * med_std if (arith / med > 2.0 or arith / med < 0.5) else arith + 3.0 * std
+        if th_tmp < 5.0 * th or th_tmp < 4.0 * self.PIX_MIN_GOOD_TH:
+            return self.set_corr_th(th_tmp, False, False)
+        if th < (self.MAX_PIX_TH / 2) * self.f:
+            return self.set_corr_th(th * 2.0, False, False)
+        return self.set_corr_th(self.min_pix_th, True, False) * self.f
+
+    def estimate_e_var_th(self, a, b, th):
+        """-> (rc, E, mask, th, nr_good)"""
+        sem = [True, True, False]
+        fail_cnt, th_failed = 2, th
+        E = mask = None
+        nr_good = 0
+        while True:
+            mask = None
+            th_old = th
+            r = self.find(th)
+            if not r["ok"]:
+                if th < self.PIX_MIN_GOOD_TH * self.f and not self.stable and not sem[2]:
+                    th_failed = th
+                    th = self.PIX_MIN_GOOD_TH * self.f
+                    th_old = th
+                    r = self.find(th)
+                    if not r["ok"]:
+                        return -1, None, None, th, nr_good
+                    E, mask = r["E"], r["mask"]
+                    sem[2] = True
+                elif sem[2]:
+                    fail_cnt *= 2
+                else:
+                    return -1, None, None, th, nr_good
+            else:
+                E, mask = r["E"], r["mask"]
+                if sem[2] and fail_cnt > 2:
+                    self.min_pix_th = th / self.f
+                sem[2] = False
+            if fail_cnt <= 2 or not sem[2]:
+                nr_good = 0 if mask is None else int(np.count_nonzero(mask))
+            if not self.stable:
+                th = self.estimate_thresh(a, b, E) if (fail_cnt <= 2 or not sem[2]) else th_failed * fail_cnt
+                if sem[2] and th_failed >= th:
+                    th = th_failed * fail_cnt
+                if not sem[2]:
+                    if th_old / th > 1.0 + 1e-6:
+                        sem[0] = False
+                    elif th_old / th < 1.0 - 1e-6:
+                        sem[1] = False
+            again = (th_old / th < 0.9 or th / th_old < 0.9) and \
+                ((np.float32(nr_good) / np.float32(len(a)) < np.float32(0.67) and (sem[0] or sem[1])) or sem[2])
+            if not again:
+                break
+        return 0, E, mask, th, nr_good
 
 
 def round_half_away(x):  # std::round
@@ -163,9 +264,16 @@ class StereoRefineOracle:
         self.Q = self.mask_Q = None
         method = self.cfg.RobMethod
         n = len(a)
+        auto_th = self.cfg.autoTH
         if self.cfg.useRANSAC_fewMatches and n < 100:
-            method = "RANSAC"
-        if method == "RANSAC":
+            method, auto_th = "RANSAC", False
+        if auto_th:  # :1330-1342; th is updated for the frames to come, th2 is not (:159-160)
+            if not hasattr(self, "arrsac_rng"):
+                self.arrsac_rng = np.array([0xFFFFFFFF, 0xFFFFFFFF], np.uint64)
+            auto = AutoThEpiOracle(self.o, self.pix2cam, lambda t: self.o.arrsac_essential(a, b, t, refine=True, rng_state=self.arrsac_rng))
+            rc, E, mask, self.th, _ = auto.estimate_e_var_th(a, b, self.th)
+            r = dict(ok=(rc == 0), E=E, mask=mask)
+        elif method == "RANSAC":
             r = self.o.ransac_essential(a, b, self.th, confidence=0.999, max_iters=1000, lesqu=self.cfg.refineRTold, seed=self.seed)
         elif method == "ARRSAC":
             # the samplers' cv::RNG streams are process-wide in the reference: every estimation continues where the last one stopped

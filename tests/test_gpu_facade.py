@@ -89,3 +89,15 @@ def test_cpp_facade_end_to_end(oracle, tmp_path):
         if oka:
             a, b = Ea / np.linalg.norm(Ea), o4["E"] / np.linalg.norm(o4["E"])
             assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 2e-5
+
+    # AutoThEpi::estimateEVarTH: the same loop over the CPU oracle, continuing the samplers' streams
+    from stereo_refine_oracle import AutoThEpiOracle
+    rca = take(np.int32, 1)[0]
+    tha = take(np.float64, 1)[0]
+    nga = take(np.int32, 1)[0]
+    Eat = take(np.float64, 9).reshape(3, 3)
+    auto = AutoThEpiOracle(oracle, th / 0.8, lambda t: oracle.arrsac_essential(p1, p2, t, refine=True, rng_state=st))
+    rc_o, E_o, mask_o, th_o, ng_o = auto.estimate_e_var_th(p1, p2, th)
+    assert rca == rc_o == 0 and nga == ng_o and abs(tha - th_o) < 1e-9 * th_o, (rca, rc_o, nga, ng_o, tha, th_o)
+    a, b = Eat / np.linalg.norm(Eat), E_o / np.linalg.norm(E_o)
+    assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 2e-5

@@ -67,6 +67,9 @@ SEQUENCES = {
                          want=["pool+refined", "pool+robust"]),
     "pool_refined_small_pool": dict(seed=16, cfg=dict(checkPoolPoseRobust=2, refineRTold_CorrPool=True, maxPoolCorrespondences=1500),
                                     frames=[(500, "A", 0.25)] * 14, want=["pool+refined"]),
+    "auto_threshold": dict(seed=17, cfg=dict(autoTH=True, RobMethod="ARRSAC", th_pix_user=0.5), frames=[(500, "A", 0.25)] * 5, want=["pool"]),
+    "auto_threshold_few_matches": dict(seed=18, cfg=dict(autoTH=True, RobMethod="ARRSAC", useRANSAC_fewMatches=True, minStartAggInlRat=0.5),
+                                       frames=[(90, "A", 0.7)] + [(90, "A", 0.2)] * 2 + [(400, "A", 0.2)] * 3, want=["init"]),
     "lens_distortion_refit": dict(seed=10, cfg=dict(refineRTold=True, th_pix_user=1.0), frames=[(600, "A", 0.2)] * 6, want=["pool"],
                                   dist=(np.array([-0.12, 0.03, 0, 0, 0, 0, 0, 0.0]), np.array([-0.10, 0.02, 0, 0, 0, 0, 0, 0.0]))),
     "weak_start_few_matches": dict(seed=11, cfg=dict(useRANSAC_fewMatches=True, RobMethod="LMEDS", minStartAggInlRat=0.5),
@@ -174,7 +177,7 @@ def test_stereo_refine_sequence_matches_the_cpu_state_machine(oracle, tmp_path, 
     drift, cpu_off = 0, False
     for i, (g, w) in enumerate(zip(got, want)):
         st = dict(zip(["rc", "inl", "corrs", "pool", "est", "skip", "stable", "ml", "hist"], g["st"].tolist()))
-        arrsac = name.startswith("arrsac")   # its winner may be an 8-point fit or a refined matrix: no exact essential matrix to expect
+        arrsac = name.startswith("arrsac") or name.startswith("auto_threshold")   # its winner may be an 8-point fit or a refined matrix: no exact essential matrix to expect
         if w["E"] is not None and constraint_residual(w["E"]) > 1e-9 and not arrsac:
             cpu_off = True
         for k in ("rc", "est", "skip", "stable", "ml", "hist"):
