@@ -588,7 +588,7 @@ struct ArrsacRun {
     PolyRec *d_recs = nullptr;
     double *d_direct = nullptr;
     int32_t *d_direct_ok = nullptr, *d_nm5 = nullptr;
-    char *d_out = nullptr, *h_out = nullptr;
+    char *d_out = nullptr, *h_out = nullptr, *h_out_dev = nullptr;
     int32_t *h_smp = nullptr;
     // results
     std::vector<ArrModelHost> pool;
@@ -615,8 +615,6 @@ struct ArrsacRun {
     int alloc() {
         void *p;
         int rc;
-        if ((rc = ws_get(ctx, WS_AUX4, (size_t)kArrBatchCap * kArrSmpStride * 4, &p))) return rc;
-        d_smp = (int32_t *)p;
         if ((rc = ws_get(ctx, WS_PARTIAL, (size_t)kArrBatchCap * sizeof(PolyRec), &p))) return rc;
         d_recs = (PolyRec *)p;
         if ((rc = ws_get(ctx, WS_AUX6, (size_t)kArrBatchCap * (72 + 8), &p))) return rc;
@@ -628,6 +626,12 @@ struct ArrsacRun {
         if ((rc = pinned_get(ctx, out_bytes(kArrBatchCap) + (size_t)kArrBatchCap * kArrSmpStride * 4, &p))) return rc;
         h_out = (char *)p;
         h_smp = (int32_t *)(h_out + out_bytes(kArrBatchCap));
+        // the sample table is read by the kernels straight from the pinned (mapped) host block: 64 bytes per wave, no copy command
+        void *dev_alias = nullptr;
+        MLPL_HIP_TRY(hipHostGetDevicePointer(&dev_alias, h_smp, 0));
+        d_smp = (int32_t *)dev_alias;
+        MLPL_HIP_TRY(hipHostGetDevicePointer(&dev_alias, h_out, 0));
+        h_out_dev = (char *)dev_alias;
         if ((rc = ws_get(ctx, WS_ARR_E, (size_t)kArrPoolSamples * 720, &p))) return rc;
         d_Epool = (double *)p;
         if ((rc = ws_get(ctx, WS_ARR_F, (size_t)kArrPoolSamples * 10 * kArrFlagWords * 8, &p))) return rc;
@@ -647,12 +651,13 @@ struct ArrsacRun {
         // layout of the result block: out_nm[B] | out_valid[B*10] | E00[B*10] | head[B*10*2]; models and whole flag rows go to the pool
         const size_t off_valid = (size_t)B * 4, off_e00 = ((size_t)B * 44 + 7) & ~(size_t)7, off_head = off_e00 + (size_t)B * 80;
         const size_t total = off_head + (size_t)B * 10 * kArrHeadWords * 8;
-        int32_t *o_nm = (int32_t *)d_out, *o_valid = (int32_t *)(d_out + off_valid);
-        double *o_e00 = (double *)(d_out + off_e00);
-        unsigned long long *o_head = (unsigned long long *)(d_out + off_head);
+        // the small per-model results are written by the check kernel straight into the pinned (mapped) host block: no copy command
+        char *o_base = h_out_dev;
+        int32_t *o_nm = (int32_t *)o_base, *o_valid = (int32_t *)(o_base + off_valid);
+        double *o_e00 = (double *)(o_base + off_e00);
+        unsigned long long *o_head = (unsigned long long *)(o_base + off_head);
         double *o_E = d_Epool + (size_t)pool_samples * 90;
         unsigned long long *o_rows = d_Fpool + (size_t)pool_samples * 10 * kArrFlagWords;
-        MLPL_HIP_TRY(hipMemcpyAsync(d_smp, h_smp, (size_t)B * kArrSmpStride * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(arrsac_sample_kernel, dim3(B), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_smp, B, d_recs, d_direct, d_direct_ok);
         MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((B + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)d_recs, 0, B, o_E, d_nm5,
                           (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
@@ -660,8 +665,8 @@ struct ArrsacRun {
                            (const int32_t *)d_nm5, (const double *)d_direct, (const int32_t *)d_direct_ok, thresh2, o_nm, o_valid, o_e00, o_head,
                            o_rows);
         MLPL_HIP_TRY(hipGetLastError());
-        MLPL_HIP_TRY(hipMemcpyAsync(h_out, d_out, total, hipMemcpyDeviceToHost, s));
-        MLPL_HIP_TRY(hipStreamSynchronize(s));
+        (void)total;
+        MLPL_HIP_TRY(hipStreamSynchronize(s));  // kernel completion makes its system-scope writes visible
         const int32_t *h_nm = (const int32_t *)h_out, *h_valid = (const int32_t *)(h_out + off_valid);
         const double *h_e00 = (const double *)(h_out + off_e00);
         const uint64_t *h_head = (const uint64_t *)(h_out + off_head);
