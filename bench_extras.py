@@ -238,16 +238,18 @@ def run(ctx, dev, cpu_baseline=True):
         try:
             pw.process(many, K, K, seeds=seeds)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
+            times = []
+            for _ in range(5):   # median of five passes: with this many host threads one pass in ten stalls for milliseconds on the runtime's locks
+                t0 = time.perf_counter()
                 recsw = pw.process(many, K, K, seeds=seeds)
-            dt = (time.perf_counter() - t0) / reps
+                times.append(time.perf_counter() - t0)
+            dt = sorted(times)[len(times) // 2]
         finally:
             pw.close()
         same = bool(np.concatenate(recs).tobytes() == recsw[:npairs].tobytes())
         out[f"c5_pair_pipeline_{workers}_in_flight"] = {"value": len(many) / dt, "unit": "image-pairs/s (one GPU)",
-                                                        "ms_per_pair": dt / len(many) * 1e3, "same_records_as_sequential": same}
+                                                        "ms_per_pair": dt / len(many) * 1e3, "same_records_as_sequential": same,
+                                                        "ms_per_pair_each_pass": [round(t / len(many) * 1e3, 4) for t in times]}
     p1, p2, th = arr_scene
     # the call is a chain of dependent host hops: several calls in flight (one library context + host thread each) overlap them
     from concurrent.futures import ThreadPoolExecutor
