@@ -542,37 +542,47 @@ __global__ __launch_bounds__(64) void roots_kernel_t(const PolyRec *__restrict__
         if (active && !done) {
             // Ehrlich-Aberth step: w = (p/p') / (1 - (p/p') * sum_{j != r} 1/(z - z_j));  p, p' by one Horner pass
             double fr = c[n], fi = 0, gr = 0, gi = 0;  // f = p(z), g = p'(z)
-            for (int j = n - 1; j >= 0; --j) {
-                const double t0 = gr * pr - gi * pim + fr;
-                gi = gr * pim + gi * pr + fi;
+            for (int j = n - 1; j >= 0; --j) {  // g = g z + f, f = f z + c_j on fused multiply-adds (this file is built without contraction)
+                const double t0 = __fma_rn(gr, pr, __fma_rn(-gi, pim, fr));
+                gi = __fma_rn(gr, pim, __fma_rn(gi, pr, fi));
                 gr = t0;
-                const double t1 = fr * pr - fi * pim + c[j];
-                fi = fr * pim + fi * pr;
+                const double t1 = __fma_rn(fr, pr, __fma_rn(-fi, pim, c[j]));
+                fi = __fma_rn(fr, pim, fi * pr);
                 fr = t1;
             }
+            // The other roots of this hypothesis: all twenty LDS reads go out together, and the ten terms of the repulsion sum are
+            // independent chains (as a loop over j < n with `continue` the terms ran one after the other, each behind its own LDS
+            // round trip: two thirds of a sweep).  Terms beyond the degree, the root itself and coincident roots contribute zero.
+            double zr[10], zi[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) zr[j] = rr[h * 10 + j], zi[j] = ri[h * 10 + j];
             double sr = 0, si = 0;
-            for (int j = 0; j < n; ++j) {
-                if (j == r) continue;
-                const double xr = pr - rr[h * 10 + j], xi = pim - ri[h * 10 + j];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const double xr = pr - zr[j], xi = pim - zi[j];
                 const double m2 = xr * xr + xi * xi;
-                if (m2 > 0) {
-                    // Aberth's repulsion sum only steers the iteration (the fixed point is p(z) = 0 whatever S is), so the nine
-                    // reciprocals per sweep use v_rcp_f64 + two Newton steps (5 instructions) instead of the ~15 of an IEEE divide
-                    double inv = __builtin_amdgcn_rcp(m2);
-                    inv = __fma_rn(inv, __fma_rn(-m2, inv, 1.0), inv);
-                    inv = __fma_rn(inv, __fma_rn(-m2, inv, 1.0), inv);
-                    sr += xr * inv;
-                    si -= xi * inv;
-                }
+                const bool use = j < n && j != r && m2 > 0;
+                // Aberth's repulsion sum only steers the iteration (the fixed point is p(z) = 0 whatever S is: the correction is
+                // q / (1 - q S) with q = p / p'), so the nine reciprocals per sweep are the bare v_rcp_f64 (~2^-26): one instruction
+                // instead of the ~15 of an IEEE divide
+                const double inv = __builtin_amdgcn_rcp(use ? m2 : 1.0);
+                sr += use ? xr * inv : 0.0;
+                si -= use ? xi * inv : 0.0;
             }
             const double g2 = gr * gr + gi * gi;
             if (g2 > 0) {
-                const double ig = 1.0 / g2;
+                // reciprocals by v_rcp_f64 + two Newton steps (to ~1 ulp): the correction vanishes with p(z) whatever their last bit is,
+                // and an IEEE divide is a ~200-cycle dependent chain twice per sweep
+                double ig = __builtin_amdgcn_rcp(g2);
+                ig = __fma_rn(ig, __fma_rn(-g2, ig, 1.0), ig);
+                ig = __fma_rn(ig, __fma_rn(-g2, ig, 1.0), ig);
                 const double qr = (fr * gr + fi * gi) * ig, qi = (fi * gr - fr * gi) * ig;  // q = p/p'
                 const double ur = 1.0 - (qr * sr - qi * si), ui = -(qr * si + qi * sr);     // 1 - q*S
                 const double u2 = ur * ur + ui * ui;
                 if (u2 > 0) {
-                    const double iu = 1.0 / u2;
+                    double iu = __builtin_amdgcn_rcp(u2);
+                    iu = __fma_rn(iu, __fma_rn(-u2, iu, 1.0), iu);
+                    iu = __fma_rn(iu, __fma_rn(-u2, iu, 1.0), iu);
                     dr = (qr * ur + qi * ui) * iu;
                     di = (qi * ur - qr * ui) * iu;
                 } else {

@@ -19,6 +19,8 @@ if len(sys.argv) > 2 and sys.argv[1] == "summarise":
 import matchinglib_poselib_amd as mpa
 from matchinglib_poselib_amd import pose, synth
 ctx = mpa.Context(0)
+if os.environ.get("POLISH") is not None:
+    ctx.set_option("solver_polish", int(os.environ["POLISH"]))
 _n, _f, _s = (int(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (5000, 0.5, 20260103)
 p1, p2, R, t, truth, th = synth.pose_scene(_n, _f, seed=_s)
 for _ in range(5):
