@@ -533,6 +533,9 @@ __global__ __launch_bounds__(64) void roots_kernel_t(const PolyRec *__restrict__
     }
     const bool active = lane_ok && r < n;
     bool done = !lane_ok;  // identical for the 10 lanes of a hypothesis
+    double cc[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) cc[k] = c[k];
     int settle = 0, dk_sweeps = 0;
     for (int iter = 0; iter < 400; ++iter) {
         rr[lane] = pr;
@@ -541,14 +544,30 @@ __global__ __launch_bounds__(64) void roots_kernel_t(const PolyRec *__restrict__
         double dr = 0, di = 0;
         if (active && !done) {
             // Ehrlich-Aberth step: w = (p/p') / (1 - (p/p') * sum_{j != r} 1/(z - z_j));  p, p' by one Horner pass
-            double fr = c[n], fi = 0, gr = 0, gi = 0;  // f = p(z), g = p'(z)
-            for (int j = n - 1; j >= 0; --j) {  // g = g z + f, f = f z + c_j on fused multiply-adds (this file is built without contraction)
-                const double t0 = __fma_rn(gr, pr, __fma_rn(-gi, pim, fr));
-                gi = __fma_rn(gr, pim, __fma_rn(gi, pr, fi));
-                gr = t0;
-                const double t1 = __fma_rn(fr, pr, __fma_rn(-fi, pim, c[j]));
-                fi = __fma_rn(fr, pim, fi * pr);
-                fr = t1;
+            // g = g z + f, f = f z + c_j on fused multiply-adds (this file is built without contraction); the coefficients sit in
+            // registers (cc, loaded once before the sweeps): read from LDS inside this loop every step waited for its own round trip
+            double fr, fi = 0, gr = 0, gi = 0;  // f = p(z), g = p'(z)
+            if (n == 10) {
+                fr = cc[10];
+#pragma unroll
+                for (int j = 9; j >= 0; --j) {
+                    const double t0 = __fma_rn(gr, pr, __fma_rn(-gi, pim, fr));
+                    gi = __fma_rn(gr, pim, __fma_rn(gi, pr, fi));
+                    gr = t0;
+                    const double t1 = __fma_rn(fr, pr, __fma_rn(-fi, pim, cc[j]));
+                    fi = __fma_rn(fr, pim, fi * pr);
+                    fr = t1;
+                }
+            } else {  // vanishing leading coefficients were trimmed (cv::solvePoly does the same): rare
+                fr = c[n];
+                for (int j = n - 1; j >= 0; --j) {
+                    const double t0 = __fma_rn(gr, pr, __fma_rn(-gi, pim, fr));
+                    gi = __fma_rn(gr, pim, __fma_rn(gi, pr, fi));
+                    gr = t0;
+                    const double t1 = __fma_rn(fr, pr, __fma_rn(-fi, pim, c[j]));
+                    fi = __fma_rn(fr, pim, fi * pr);
+                    fr = t1;
+                }
             }
             // The other roots of this hypothesis: all twenty LDS reads go out together, and the ten terms of the repulsion sum are
             // independent chains (as a loop over j < n with `continue` the terms ran one after the other, each behind its own LDS
