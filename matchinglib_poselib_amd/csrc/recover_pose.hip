@@ -41,11 +41,22 @@ __device__ __forceinline__ void jacobi_right_vectors(double (&G)[N][N], double (
                     beta += G[i][q] * G[i][q];
                     gamma += G[i][p] * G[i][q];
                 }
-                if (fabs(gamma) <= eps * sqrt(alpha * beta) || gamma == 0.0) continue;
+                if (gamma * gamma <= (eps * eps) * (alpha * beta) || gamma == 0.0) continue;  // |gamma| <= eps sqrt(alpha beta)
                 rotated = true;
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                // A plane rotation stays orthogonal to rounding for ANY tangent t as long as c = (1 + t^2)^-1/2 is accurate and s = c t;
+                // an inexact t only leaves the pair at ~1e-8 of its former inner product, which the next sweep removes, and the
+                // iteration still ends on the test above.  So the tangent comes from v_rcp_f64 / v_sqrt_f64 (~2^-26) and only c is
+                // Newton-refined: three IEEE divisions and three IEEE square roots (~150 instructions per pair) become ~25.
+                const double zeta = (beta - alpha) * __builtin_amdgcn_rcp(2.0 * gamma);
+                const double az = fabs(zeta);
+                double t = __builtin_amdgcn_rcp(az + __builtin_amdgcn_sqrt(az * az + 1.0));
+                t = zeta >= 0 ? t : -t;
+                if (!(az < 1e150)) t = 0.5 / zeta;  // zeta^2 overflows: t = 1 / (2 zeta) to rounding
+                const double x1 = t * t + 1.0;
+                double c = __builtin_amdgcn_rsq(x1);
+                c = c * (1.5 - 0.5 * x1 * c * c);
+                c = c * (1.5 - 0.5 * x1 * c * c);
+                const double s = c * t;
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
                     const double gp = G[i][p], gq = G[i][q];
