@@ -234,38 +234,39 @@ __device__ __forceinline__ void solve_from_basis(SolveLds &L, int lane, PolyRec 
 
     // ---- 3. Gauss-Jordan with partial pivoting: A <- [I | inv(A1) A2] ----
     bool singular = false;
+    // Per column ONE read phase and ONE write phase.  The pivot column is read as a batch (ten loads in flight) and searched in
+    // registers (first maximum, as a loop from `col` would find it); the row swap, the scaling of the pivot row and the elimination are
+    // folded into the single pass that rewrites all 200 elements anyway: new A[r] comes from old A[src(r)] with src swapping col and
+    // piv, and the scaled pivot-row element sc = A[piv][j] / pivot is formed in registers exactly as the stored one used to be.  Same
+    // operations, same roundings; the separate swap / scale phases cost two more LDS round trips and four more orderings per column.
     for (int col = 0; col < 10; ++col) {
+        double cv[10];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) cv[r] = L.A[r][col];
         int piv = col;
-        double pmax = fabs(L.A[col][col]);
-        for (int r = col + 1; r < 10; ++r) {
-            const double v = fabs(L.A[r][col]);
-            if (v > pmax) {
-                pmax = v;
-                piv = r;
-            }
+        double pmax = -1.0, pvt = 0.0;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const double v = fabs(cv[r]);
+            const bool take = (r == col) || (r > col && v > pmax);
+            pmax = take ? v : pmax;
+            pvt = take ? cv[r] : pvt;
+            piv = take ? r : piv;
         }
         if (pmax < DBL_EPSILON * 1e-3) {
             singular = true;
             break;
         }
-        wave_sync();
-        if (piv != col && lane < 20) {
-            const double t = L.A[col][lane];
-            L.A[col][lane] = L.A[piv][lane];
-            L.A[piv][lane] = t;
-        }
-        wave_sync();
-        const double inv = 1.0 / L.A[col][col];
-        wave_sync();
-        if (lane < 20) L.A[col][lane] *= inv;
-        wave_sync();
+        const double inv = 1.0 / pvt;
         double nv[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int e = lane + 64 * t;
             if (e < 200) {
                 const int r = e / 20, j = e - r * 20;
-                nv[t] = (r == col) ? L.A[r][j] : (L.A[r][j] - L.A[r][col] * L.A[col][j]);
+                const int src = (r == col) ? piv : ((r == piv) ? col : r);
+                const double sc = L.A[piv][j] * inv;
+                nv[t] = (r == col) ? sc : (L.A[src][j] - L.A[src][col] * sc);
             }
         }
         wave_sync();
