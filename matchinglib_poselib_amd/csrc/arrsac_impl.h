@@ -409,10 +409,13 @@ __global__ void arrsac_gather_kernel(const int32_t *__restrict__ rows, int n_row
 // stopped by the reference's tests on the residual.  One workgroup; the normal matrix is summed unnormalised and divided by the weight
 // norm afterwards (the reference scales every row first).  info = {rounds, status: 0 converged/exhausted, 1 stopped on an invalid matrix,
 // 2 rejected (too few points or a rank-deficient system: E_init is returned)}.
-__global__ __launch_bounds__(1024) void arrsac_refine_kernel(const double4 *__restrict__ pts, const uint8_t *__restrict__ mask, int n,
+// 512 threads: the 46 running sums of a thread need ~130 registers; at 1024 threads per workgroup (four waves per SIMD, 128 registers
+// each) the compiler spilled 213 of them and every round spent 60 us in scratch traffic.
+constexpr int kArrRefineThreads = 512;
+__global__ __launch_bounds__(kArrRefineThreads) void arrsac_refine_kernel(const double4 *__restrict__ pts, const uint8_t *__restrict__ mask, int n,
                                                              const double *__restrict__ E_init, double th, double *__restrict__ E_out,
                                                              int32_t *__restrict__ info) {
-    __shared__ double red[16][46];
+    __shared__ double red[kArrRefineThreads / 64][46];
     __shared__ Jacobi9Lds J;
     __shared__ double F3[9];
     __shared__ double s_err_old;
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(1024) void arrsac_refine_kernel(const double4 *__re
     __syncthreads();
     {
         int c = 0;
-        for (int i = tid; i < n; i += 1024) c += mask[i] ? 1 : 0;
+        for (int i = tid; i < n; i += kArrRefineThreads) c += mask[i] ? 1 : 0;
         for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
         if (lane == 0 && c) atomicAdd(&s_cnt, c);
     }
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(1024) void arrsac_refine_kernel(const double4 *__re
         double acc[46];
 #pragma unroll
         for (int k = 0; k < 46; ++k) acc[k] = 0;
-        for (int i = tid; i < n; i += 1024) {
+        for (int i = tid; i < n; i += kArrRefineThreads) {
             if (!mask[i]) continue;
             const double4 p = pts[i];
             const double x0 = p.x, y0 = p.y, x1 = p.z, y1 = p.w;
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(1024) void arrsac_refine_kernel(const double4 *__re
         if (wave == 0) {
             if (lane < 46) {
                 double sacc = 0;
-                for (int wv = 0; wv < 16; ++wv) sacc += red[wv][lane];
+                for (int wv = 0; wv < kArrRefineThreads / 64; ++wv) sacc += red[wv][lane];
                 red[0][lane] = sacc;
             }
             wave_sync();
@@ -1104,7 +1107,7 @@ int arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, 
     hipLaunchKernelGGL(inlier_mask_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double4 *)pts, n, (const double *)d_E,
                        R.thresh2, d_mask, d_info);
     if (refine)  // the kernel itself returns the initial matrix below 50 inliers, as the reference does (modelest.cpp:304-309)
-        hipLaunchKernelGGL(arrsac_refine_kernel, dim3(1), dim3(1024), 0, s, (const double4 *)pts, (const uint8_t *)d_mask, n,
+        hipLaunchKernelGGL(arrsac_refine_kernel, dim3(1), dim3(kArrRefineThreads), 0, s, (const double4 *)pts, (const uint8_t *)d_mask, n,
                            (const double *)d_E, thresh / 50.0, d_E + 9, d_info + 1);
     MLPL_HIP_TRY(hipGetLastError());
     void *hp;

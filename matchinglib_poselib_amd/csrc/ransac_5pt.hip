@@ -2763,7 +2763,7 @@ int mlpl_robust_essential_refine(mlpl_ctx *ctx, const double *p1, const double *
     if ((rc = pack_points(ctx, (const double *)dp1, (const double *)dp2, n, &pts, s))) return rc;
     double *d_E = (double *)dE;
     int32_t *d_info = (int32_t *)(d_E + 18);
-    hipLaunchKernelGGL(arrsac_refine_kernel, dim3(1), dim3(1024), 0, s, (const double4 *)pts, (const uint8_t *)dmask, n, (const double *)d_E, th,
+    hipLaunchKernelGGL(arrsac_refine_kernel, dim3(1), dim3(kArrRefineThreads), 0, s, (const double4 *)pts, (const uint8_t *)dmask, n, (const double *)d_E, th,
                        d_E + 9, d_info);
     MLPL_HIP_TRY(hipGetLastError());
     double h[20];
