@@ -195,18 +195,6 @@ __device__ __forceinline__ double arr_row_elem(const double *p, int a) {  // epi
     }
 }
 
-__device__ __forceinline__ void order_desc9(const Jacobi9Lds &J, int *order) {
-    for (int a = 0; a < 9; ++a) order[a] = a;
-    for (int a = 0; a < 8; ++a) {
-        int best = a;
-        for (int b = a + 1; b < 9; ++b)
-            if (J.G[order[b]][order[b]] > J.G[order[best]][order[best]]) best = b;
-        const int t2 = order[a];
-        order[a] = order[best];
-        order[best] = t2;
-    }
-}
-
 __global__ __launch_bounds__(64) void arrsac_sample_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
                                                            const int32_t *__restrict__ smp, int n_samples, PolyRec *__restrict__ recs,
                                                            double *__restrict__ direct_E, int32_t *__restrict__ direct_ok) {

@@ -1623,6 +1623,25 @@ __device__ __forceinline__ void jacobi9_wave(Jacobi9Lds &J, int lane) {
     }
 }
 
+// Indices of the nine eigenvalues in descending order, the first of equal values first (what a selection sort from the top gives).  The
+// diagonal is read once (nine loads in flight) and every index gets its position by counting in registers; as a selection sort over LDS
+// the 36 comparisons were 72 dependent round trips (~4 us on one lane).
+__device__ __forceinline__ void order_desc9(const Jacobi9Lds &J, int *order) {
+    double d[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+        d[a] = J.G[a][a];
+        order[a] = a;  // (NaNs leave positions unassigned: keep every entry a valid index)
+    }
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+        int pos = 0;
+#pragma unroll
+        for (int b = 0; b < 9; ++b) pos += ((d[b] > d[a]) || (d[b] == d[a] && b < a)) ? 1 : 0;
+        order[pos] = a;
+    }
+}
+
 __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restrict__ gram_part, int nparts,
                                                          PolyRec *__restrict__ rec) {
     __shared__ SolveLds L;
@@ -1651,15 +1670,7 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
     if (lane == 0) {
         // order eigenvalues descending; EE = eigenvectors of the 4 smallest, in descending order (five-point.cpp:388)
         int order[9];
-        for (int a = 0; a < 9; ++a) order[a] = a;
-        for (int a = 0; a < 8; ++a) {
-            int best = a;
-            for (int b = a + 1; b < 9; ++b)
-                if (J.G[order[b]][order[b]] > J.G[order[best]][order[best]]) best = b;
-            const int t2 = order[a];
-            order[a] = order[best];
-            order[best] = t2;
-        }
+        order_desc9(J, order);
         for (int j = 0; j < 4; ++j)
             for (int r = 0; r < 9; ++r) L.EE[j][r] = J.Vv[r][order[5 + j]];
     }
