@@ -70,8 +70,16 @@ __device__ __forceinline__ bool jsvd_pair(double *W, double *U, double *V, doubl
     if (fabs(d) < DBL_MIN) {
         rot1 = {1.0, 0.0};
     } else {
-        const double u = t / d, tmp = sqrt(1.0 + u * u);
-        rot1 = {u / tmp, 1.0 / tmp};
+        // (c, s) = (u, 1) / sqrt(1 + u^2): orthogonal to rounding for any u as long as the inverse root is accurate -- u = t / d from
+        // v_rcp_f64 (~2^-26), the inverse root from v_rsq_f64 with two Newton steps; an inexact u leaves the 2x2 block slightly
+        // unsymmetric, which the next sweep removes (the iteration ends on its own threshold test)
+        double u = t * __builtin_amdgcn_rcp(d);
+        if (!(fabs(u) < 1e150)) u = t / d;
+        const double x = 1.0 + u * u;
+        double it = __builtin_amdgcn_rsq(x);
+        it = it * (1.5 - 0.5 * x * it * it);
+        it = it * (1.5 - 0.5 * x * it * it);
+        rot1 = {u * it, it};
     }
     {
         const double a0 = rot1.c * m00 + rot1.s * m10, a1 = rot1.c * m01 + rot1.s * m11;
@@ -81,11 +89,15 @@ __device__ __forceinline__ bool jsvd_pair(double *W, double *U, double *V, doubl
     JRot jr = {1.0, 0.0};
     const double deno = 2.0 * fabs(m01);
     if (!(deno < DBL_MIN)) {
-        const double tau = (m00 - m11) / deno;
-        const double w = sqrt(tau * tau + 1.0);
-        const double tt = tau > 0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+        double tau = (m00 - m11) * __builtin_amdgcn_rcp(deno);
+        if (!(fabs(tau) < 1e150)) tau = (m00 - m11) / deno;
+        const double w = __builtin_amdgcn_sqrt(tau * tau + 1.0);
+        const double tt = tau > 0 ? __builtin_amdgcn_rcp(tau + w) : __builtin_amdgcn_rcp(tau - w);
         const double sign_t = tt > 0 ? 1.0 : -1.0;
-        const double nn = 1.0 / sqrt(tt * tt + 1.0);
+        const double x2 = tt * tt + 1.0;
+        double nn = __builtin_amdgcn_rsq(x2);
+        nn = nn * (1.5 - 0.5 * x2 * nn * nn);
+        nn = nn * (1.5 - 0.5 * x2 * nn * nn);
         jr = {nn, -sign_t * (m01 / fabs(m01)) * fabs(tt) * nn};
     }
     const JRot jl = {rot1.c * jr.c + rot1.s * jr.s, -rot1.c * jr.s + rot1.s * jr.c};  // rot1 * jr^T
@@ -363,13 +375,16 @@ __global__ __launch_bounds__(64) void arrsac_check_kernel(const double4 *__restr
     }
     wave_sync();
     if (!s_valid) return;
+    // the sixteen correspondences of this lane: all loads go out together (one after the other, each of the sixteen rounds waited
+    // for its own: 4.4 us of a 13 us wave)
+    double4 pp[kArrFlagWords];
+#pragma unroll
+    for (int w = 0; w < kArrFlagWords; ++w) pp[w] = pts[min(w * 64 + lane, flag_points - 1)];
+#pragma unroll
     for (int w = 0; w < kArrFlagWords; ++w) {
         const int i = w * 64 + lane;
-        bool in = false;
-        if (i < flag_points) {
-            const double4 p = pts[i];
-            in = (double)sampson_err_f32(e, p.x, p.y, p.z, p.w) < thresh2;  // Estimator::Error(...) < error_thresh, strict
-        }
+        const double4 p = pp[w];
+        const bool in = i < flag_points && (double)sampson_err_f32(e, p.x, p.y, p.z, p.w) < thresh2;  // Estimator::Error(...) < error_thresh, strict
         const unsigned long long bal = __ballot(in);
         if (lane == 0) {
             flag_rows[((size_t)b * 10 + slot) * kArrFlagWords + w] = bal;  // the whole row stays on the device (arrsac_gather_kernel)
