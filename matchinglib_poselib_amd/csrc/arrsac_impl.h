@@ -153,43 +153,40 @@ __device__ void svd3_eigen(const double *Min, double *sv, double *U, double *V) 
 
 __device__ __forceinline__ bool arr_is_zero(double d) { return d < 1e-3 && d > -1e-3; }  // five-point.hpp:76-81
 
-// CvEMEstimator::ValidModel (five-point.cpp:534-601): q = the m sample correspondences as (x1, y1, x2, y2).  V(-M) == V(M) for the
-// decomposition above (the sign goes into U), so the second pass with -E re-uses e2.
-__device__ bool valid_model_dev(const double (*q)[4], int m, const double *E) {
-    double Et[9], sv[3], U[9], V[9];
+// CvEMEstimator::ValidModel (five-point.cpp:534-601) by one wave.  The reference walks the m sample correspondences with E; at the first
+// one that violates the oriented epipolar constraint it starts over with -E and counts the violations; V(-M) == V(M) for the
+// decomposition above (the sign goes into U), so the epipole e2 is the same in both passes and the products only change sign.  Hence:
+//   P_i = correspondence i violates under E,  Q_i = under -E;   valid = (no P_i) or (#Q_i / m < 0.4).
+// Lane 0 decomposes E^T (singular-value tests, epipole); lane i < m evaluates P_i and Q_i; two ballots finish.  `sh` = 4 doubles of LDS.
+__device__ __forceinline__ bool valid_model_wave(double x1, double y1, double x2, double y2, int m, const double *E, double *sh, int lane) {
+    if (lane == 0) {
+        double Et[9], sv[3], U[9], V[9];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) Et[r * 3 + c] = E[c * 3 + r];
-    svd3_eigen(Et, sv, U, V);
-    if (sv[0] / sv[1] > 1.2) return false;
-    if (!arr_is_zero(0.01 * sv[2] / sv[1])) return false;
-    const double e2[3] = {V[2], V[5], V[8]};
-    double sgn = 1.0;
-    bool emult = false;
-    int fail = 0;
-    for (int i = 0; i < m; ++i) {
-        const double x1 = q[i][0], y1 = q[i][1], x2 = q[i][2], y2 = q[i][3];
+            for (int c = 0; c < 3; ++c) Et[r * 3 + c] = E[c * 3 + r];
+        svd3_eigen(Et, sv, U, V);
+        const bool ok = !(sv[0] / sv[1] > 1.2) && arr_is_zero(0.01 * sv[2] / sv[1]);
+        sh[0] = V[2], sh[1] = V[5], sh[2] = V[8], sh[3] = ok ? 1.0 : 0.0;
+    }
+    wave_sync();
+    const double e2[3] = {sh[0], sh[1], sh[2]};
+    const bool sv_ok = sh[3] != 0.0;
+    bool P = false, Q = false;
+    if (lane < m) {
         const double l1[3] = {e2[1] - e2[2] * y2, e2[2] * x2 - e2[0], e2[0] * y2 - e2[1] * x2};
-        bool neg = false;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const double l2 = sgn * E[j * 3] * x1 + sgn * E[j * 3 + 1] * y1 + sgn * E[j * 3 + 2];
-            if (neg || arr_is_zero(0.1 * l1[j]) || arr_is_zero(0.1 * l2)) continue;
-            if (l1[j] * l2 < 0) neg = true;
-        }
-        if (neg) {
-            if (!emult) {  // the reference restarts the whole loop with -E
-                emult = true;
-                sgn = -1.0;
-                fail = 0;
-                i = -1;
-                continue;
-            }
-            fail++;
+            const double l2 = E[j * 3] * x1 + E[j * 3 + 1] * y1 + E[j * 3 + 2];
+            const bool skip = arr_is_zero(0.1 * l1[j]) || arr_is_zero(0.1 * l2);
+            const double pr = l1[j] * l2;
+            P = P || (!skip && pr < 0);
+            Q = Q || (!skip && pr > 0);  // l1 * (-l2) < 0
         }
     }
-    return !((float)fail / (float)m >= 0.4f);
+    const bool anyP = __ballot(P) != 0;
+    const int fail = __popcll(__ballot(Q));
+    return sv_ok && (!anyP || !((float)fail / (float)m >= 0.4f));
 }
 
 __device__ __forceinline__ double arr_row_elem(const double *p, int a) {  // epipolar row [x1x2, y1x2, x2, x1y2, y1y2, y2, x1, y1, 1]
@@ -326,8 +323,7 @@ __global__ __launch_bounds__(64) void arrsac_check_kernel(const double4 *__restr
                                                           double thresh2, int32_t *__restrict__ out_nm, int32_t *__restrict__ out_valid,
                                                           double *__restrict__ out_e00, unsigned long long *__restrict__ out_head,
                                                           unsigned long long *__restrict__ flag_rows) {
-    __shared__ double q[kArrMaxSample][4];
-    __shared__ int s_valid;
+    __shared__ double q[1][4];  // the epipole and the singular-value verdict, lane 0 -> wave
     if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
     const int lane = threadIdx.x;
     const int b = blockIdx.x / 10, slot = blockIdx.x - b * 10;
@@ -364,17 +360,14 @@ __global__ __launch_bounds__(64) void arrsac_check_kernel(const double4 *__restr
         for (int k = 1; k < 9; ++k) v = (lane == k) ? e[k] : v;
         E_tab[((size_t)b * 10 + slot) * 9 + lane] = v;
     }
+    double sx1 = 0, sy1 = 0, sx2 = 0, sy2 = 0;  // this lane's sample correspondence
     if (lane < m) {
         const int idx = sm[1 + lane];
-        q[lane][0] = p1[2 * idx], q[lane][1] = p1[2 * idx + 1], q[lane][2] = p2[2 * idx], q[lane][3] = p2[2 * idx + 1];
+        sx1 = p1[2 * idx], sy1 = p1[2 * idx + 1], sx2 = p2[2 * idx], sy2 = p2[2 * idx + 1];
     }
-    wave_sync();
-    if (lane == 0) {
-        s_valid = valid_model_dev(q, m, e) ? 1 : 0;
-        out_valid[b * 10 + slot] = s_valid;
-    }
-    wave_sync();
-    if (!s_valid) return;
+    const bool valid = valid_model_wave(sx1, sy1, sx2, sy2, m, e, &q[0][0], lane);  // wave-uniform
+    if (lane == 0) out_valid[b * 10 + slot] = valid ? 1 : 0;
+    if (!valid) return;
     // the sixteen correspondences of this lane: all loads go out together (one after the other, each of the sixteen rounds waited
     // for its own: 4.4 us of a 13 us wave)
     double4 pp[kArrFlagWords];
