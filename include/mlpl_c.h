@@ -271,6 +271,54 @@ int mlpl_arrsac_last_stats(mlpl_ctx *ctx, long long stats[12]);
 int mlpl_debug_arrsac_trace(mlpl_ctx *ctx, int32_t *buf, int cap);
 
 /*
+ * USAC essential-matrix estimation with the Nister minimal solver -- poselib::estimateEssentialOrPoseUSAC (pose_estim.h:212-223,
+ * pose_estim.cpp:1737-2244) -> estimateEssentialMatUsac (source/usac/usac_estimations.cpp:283-735) -> USAC<EssentialMatEstimator>::solve
+ * (include/usac/estimators/USAC.h:335-620, EssentialMatEstimator.h): PROSAC or uniform sampling, sample pre-validation, the oriented
+ * epipolar constraint on every model, Wald's sequential test over a shuffled evaluation order with re-estimated delta / epsilon,
+ * local optimisation (5 inner repetitions of a 14-point fit + 4 re-weighted refits, REF_WEIGHTS) on every new best model, and the
+ * SPRT-aware stopping criterion.  The harness default estimator (tests/poselib-test/main.cpp:734).  Minimal solves, validity tests and
+ * every error evaluation run on the device in speculative batches, the refits as one launch per local optimisation; the sequential
+ * decisions are taken on the host.  No degeneracy tests (UsacChkDegenType::DEGEN_NO_CHECK).
+ * The reference seeds srand(time(nullptr)) and shuffles its evaluation order on the process-wide stream; `seed` is that seed.
+ * estimator: PoseEstimator value, 0 = POSE_NISTER, 2 = POSE_STEWENIUS (both are exact 5-point solvers with the same real solution set;
+ * the device solver serves both, solutions ordered by the library's convention); refine: RefineAlg value, 0 = REF_WEIGHTS (8-point
+ * fit with Torr weights).  Other values: MLPL_E_UNSUPPORTED.
+ * results[12] = {1, hypotheses, models, samples rejected by pre-validation, models rejected by the oriented constraint, inliers of the
+ * best model, correspondences verified, local optimisations, SPRT delta and epsilon the reference reports back (newest history entry,
+ * usac_estimations.cpp:459-468 halves epsilon itself), delta and epsilon at the end}.  mask: n bytes, 1 = inlier of the returned model.
+ * Returns 0; MLPL_E_FAILED when solve() refuses (fewer than 5 correspondences, or fewer than 20 with PROSAC).
+ */
+typedef struct {
+    double th;             /* inlier threshold in camera coordinates (not squared) */
+    double conf;           /* 0.99 */
+    int32_t max_hyp;       /* 50000 */
+    int32_t estimator;     /* poselib::PoseEstimator */
+    int32_t refine;        /* poselib::RefineAlg */
+    uint32_t seed;
+    double prosac_beta;    /* 0.09, or the SPRT delta when the automatic PROSAC parameter is on */
+    double sprt_delta;     /* 0.05 */
+    double sprt_epsilon;   /* 0.15 */
+    double sprt_mS;        /* 8.5 for Nister on the first call of a process, then models / hypotheses so far */
+    double sprt_tM;        /* 2314 (Nister), 2736 (Stewenius) */
+    const uint32_t *sorted_idx; /* HOST pointer: NULL = uniform sampling; else n indices, best match first = PROSAC */
+} mlpl_usac_params;
+void mlpl_usac_default_params(mlpl_usac_params *p, double th);
+int mlpl_usac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const mlpl_usac_params *params, double E[9],
+                        uint8_t *mask, double results[12]);
+int mlpl_usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, const mlpl_usac_params *params, double E[9],
+                            uint8_t *d_mask, double results[12], void *stream);
+/* Statistics of the last mlpl_usac_essential[_dev] call: {device batches, samples solved on the device, samples the control flow
+ * consumed, local-optimisation launches, of which chain resumes, 0, 0, 0}. */
+int mlpl_usac_last_stats(mlpl_ctx *ctx, long long stats[8]);
+/* Diagnostics: the following mlpl_usac_essential* calls record their decisions into buf, 16 doubles per record: [0] type -- 1 sample
+ * {hypothesis, 5 indices, solutions (-1 = rejected by pre-validation)}, 2 evaluation {hypothesis, model, start position in the evaluation
+ * order, inliers seen, correspondences tested, accepted, delta, epsilon, decision threshold, squared inlier threshold, local
+ * optimisations so far}, 3 refined model {hypothesis, points, weighted, 1, model[9]}, 4 model stored {hypothesis, model, inliers},
+ * 5 minimal model {hypothesis, index, model[9]}, 6 model rejected by the oriented constraint {hypothesis, index}.  Returns the number of
+ * records produced since the previous call of this function (may exceed cap: only cap are written).  buf = NULL switches it off. */
+int mlpl_debug_usac_trace(mlpl_ctx *ctx, double *buf, int cap_records);
+
+/*
  * One image pair through the whole hot path, device-resident (the per-pair body of the reference harness loop,
  * tests/poselib-test/main.cpp:1440-2072, and of StereoRefine's first call): Hamming 2-NN + 0.75 ratio test -> gather of the matched
  * keypoints with ImgToCamCoordTrans -> RANSAC essential matrix -> cheirality.  d_q/d_t: dense nq/nt x nbytes descriptors,

@@ -93,6 +93,11 @@ _SIGNATURES = {
     "mlpl_arrsac_sample_models": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "mlpl_robust_essential_refine": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p]),
     "mlpl_debug_arrsac_trace": (c_int, [c_void_p, c_void_p, c_int]),
+    "mlpl_usac_default_params": (None, [c_void_p, c_double]),
+    "mlpl_usac_essential": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mlpl_usac_essential_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mlpl_usac_last_stats": (c_int, [c_void_p, c_void_p]),
+    "mlpl_debug_usac_trace": (c_int, [c_void_p, c_void_p, c_int]),
     "mlpl_ransac_essential": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int, c_int, c_u32,
                                       c_void_p, c_void_p, C.POINTER(c_int), C.POINTER(c_int)]),
     "mlpl_ransac_essential_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int, c_int,

@@ -112,6 +112,10 @@ struct mlpl_ctx {
     int32_t *arrsac_trace;                             // diagnostics: host buffer for the turn records of ARRSAC's first stage
     int arrsac_trace_cap, arrsac_trace_len;
     long long last_arrsac_stats[12];                   // ... of the last mlpl_arrsac_essential* call (mlpl_arrsac_last_stats)
+    double *usac_trace;                                // diagnostics: host buffer for the decision records of USAC (16 doubles each)
+    int usac_trace_cap, usac_trace_len;
+    long long last_usac_stats[8];
+    int opt_usac_lo_stepwise;                          // tests: every step of a local-optimisation chain goes through the resume path
     // optional per-kernel hipEvent bracketing (mlpl_profile_*)
     int prof_on;
     hipEvent_t *prof_ev[MLPL_PROF_NUM];  // pairs: [2*i] start, [2*i+1] stop

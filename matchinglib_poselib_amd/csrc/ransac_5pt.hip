@@ -2207,6 +2207,7 @@ static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
 }
 
 #include "arrsac_impl.h"
+#include "usac_impl.h"
 
 void free_rand_cache(void *p) { delete static_cast<RandCache *>(p); }
 
@@ -2784,6 +2785,80 @@ int mlpl_robust_essential_refine(mlpl_ctx *ctx, const double *p1, const double *
     std::memcpy(E_refined, h, 72);
     if (info) std::memcpy(info, h + 9, 8);
     return MLPL_OK;
+}
+
+void mlpl_usac_default_params(mlpl_usac_params *p, double th) {
+    if (!p) return;
+    p->th = th, p->conf = 0.99, p->max_hyp = 50000, p->estimator = 0, p->refine = 0, p->seed = 1u;
+    p->prosac_beta = 0.09, p->sprt_delta = 0.05, p->sprt_epsilon = 0.15, p->sprt_mS = 8.5, p->sprt_tM = 2314.0, p->sorted_idx = nullptr;
+}
+
+static int usac_check_params(const mlpl_usac_params *P, int n, const char *who) {
+    if (!P || n < 0 || !(P->th > 0) || !(P->conf >= 0 && P->conf <= 1) || P->max_hyp < 1 || !(P->sprt_delta > 0 && P->sprt_delta < 1) ||
+        !(P->sprt_epsilon > 0 && P->sprt_epsilon < 1) || !(P->sprt_mS > 0) || !(P->sprt_tM > 0)) {
+        set_error("%s: bad arguments", who);
+        return MLPL_E_BAD_INPUT;
+    }
+    if ((P->estimator != 0 && P->estimator != 2) || P->refine != 0) {
+        set_error("%s: estimator %d / refinement %d not built (POSE_NISTER, POSE_STEWENIUS with REF_WEIGHTS are)", who, P->estimator, P->refine);
+        return MLPL_E_UNSUPPORTED;
+    }
+    if (P->sorted_idx)
+        for (int i = 0; i < n; ++i)
+            if (P->sorted_idx[i] >= (uint32_t)n) {
+                set_error("%s: sorted index out of range", who);
+                return MLPL_E_BAD_INPUT;
+            }
+    return MLPL_OK;
+}
+
+int mlpl_usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, const mlpl_usac_params *params, double E[9],
+                            uint8_t *d_mask, double results[12], void *stream) {
+    if (!ctx || !d_p1 || !d_p2 || !E) {
+        set_error("mlpl_usac_essential_dev: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    int rc;
+    if ((rc = usac_check_params(params, n, "mlpl_usac_essential_dev"))) return rc;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    return usac_essential_dev(ctx, d_p1, d_p2, n, params, E, d_mask, results, pick_stream(ctx, stream));
+}
+
+int mlpl_usac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const mlpl_usac_params *params, double E[9],
+                        uint8_t *mask, double results[12]) {
+    if (!ctx || !p1 || !p2 || !E) {
+        set_error("mlpl_usac_essential: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    int rc;
+    if ((rc = usac_check_params(params, n, "mlpl_usac_essential"))) return rc;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    void *dp1, *dp2, *dmask;
+    const size_t pb = (size_t)std::max(n, 1) * 16;
+    if ((rc = ws_get(ctx, WS_AUX0, pb, &dp1)) || (rc = ws_get(ctx, WS_AUX1, pb, &dp2)) || (rc = ws_get(ctx, WS_AUX2, (size_t)std::max(n, 1), &dmask)))
+        return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(dp1, p1, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    MLPL_HIP_TRY(hipMemcpyAsync(dp2, p2, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    rc = usac_essential_dev(ctx, (const double *)dp1, (const double *)dp2, n, params, E, (uint8_t *)dmask, results, ctx->stream);
+    if (rc) return rc;
+    if (mask) {
+        MLPL_HIP_TRY(hipMemcpyAsync(mask, dmask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        MLPL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return MLPL_OK;
+}
+
+int mlpl_usac_last_stats(mlpl_ctx *ctx, long long stats[8]) {
+    if (!ctx || !stats) return MLPL_E_BAD_INPUT;
+    std::memcpy(stats, ctx->last_usac_stats, sizeof(ctx->last_usac_stats));
+    return MLPL_OK;
+}
+
+int mlpl_debug_usac_trace(mlpl_ctx *ctx, double *buf, int cap_records) {
+    if (!ctx) return MLPL_E_BAD_INPUT;
+    const int len = ctx->usac_trace_len;
+    ctx->usac_trace = buf, ctx->usac_trace_cap = buf ? cap_records : 0, ctx->usac_trace_len = 0;
+    return len;
 }
 
 int mlpl_debug_arrsac_trace(mlpl_ctx *ctx, int32_t *buf, int cap) {

@@ -1,0 +1,1072 @@
+// usac_impl.h -- USAC (PROSAC + SPRT + LO-RANSAC) essential-matrix estimation with the Nister minimal solver on the MI355X.
+// Included by ransac_5pt.hip inside namespace mlpl, after arrsac_impl.h: it reuses solve5pt_kernel / roots_kernel_t, the glibc stream
+// and the 9 x 9 Jacobi eigen-solver of that file.
+//
+// Replaces, under reference poselib/ :
+//   source/usac/usac_estimations.cpp:283-470   estimateEssentialMatUsac (POSE_NISTER; configuration: 0.99, 50000 hypotheses, SPRT, LO 5 x 14)
+//   include/usac/estimators/USAC.h             solve :335-620 and everything it calls (samplers, SPRT design / history / stopping, LO)
+//   include/usac/estimators/EssentialMatEstimator.h   generateMinimalSampleModels :384-520, validateSample :1043, validateModel :1085,
+//                                              evaluateModel :1110-1178, generateRefinedModel REFINE_WEIGHTS :540-599, findWeights :2366-2390
+//
+// USAC is a sequential program: every model is verified by Wald's sequential test, whose start position in a shuffled evaluation order,
+// likelihood ratios and decision threshold depend on all earlier verifications.  Its DATA dependence is thin, though: the sample sequence
+// is a function of the rand() stream until a model becomes the new best (an "event": local optimisation consumes the stream, PROSAC's
+// stopping length changes).  So the host runs the reference's control flow literally and, when it meets a sample it has not seen, plays
+// the sampler forward under "no event" and sends the next <= 128 samples to the device as ONE batch:
+//   solve5pt_kernel -> roots_kernel_t -> usac_check_kernel (one wave per model: the order key, the oriented-constraint test of
+//   validateModel, and the model's inlier BIT for every correspondence in evaluation-pool order, written straight into pinned host
+//   memory).  The sequential tests then walk those bit rows on the host (evaluateModel's loop without its arithmetic: the error of a
+//   correspondence does not depend on when it is asked for).  An event discards what was speculated, never changes a result.
+// Local optimisation (5 inner repetitions x [14-point fit, evaluation, refit on the 2 x threshold inliers, 4 re-weighted refits with a
+// shrinking threshold, final evaluation]) runs as ONE launch of usac_lo_kernel, a workgroup per repetition, under the assumption that
+// no sequential test inside it rejects (the refined models of a good hypothesis pass); the host verifies that on the bit rows and, where
+// a test does reject, resumes that repetition from the reference's state (usac_lo_kernel with a start model).
+// Arithmetic that decides inlier bits is the reference's, operation for operation (this file is compiled without FMA contraction).
+// Two stated deviations, both where the reference's own numerical routines are inaccurate (tests/test_oracle_usac.py):
+// the 5-point models are the exact solutions (OpenGV's Sturm bracketing returns unconverged roots on a share of samples) in the order
+// convention of oracle/ref_drivers/usac_ref.cpp, and the 9 x 9 / 3 x 3 decompositions of the refits are Jacobi iterations (ccmath's
+// svdu1v / svduv stop early on ~0.2 % of inputs).
+
+namespace {
+
+constexpr int kUsacBatch = 128;
+constexpr int kUsacLoReps = 5, kUsacLoSample = 14, kUsacLoSteps = 4, kUsacLoEvals = 2 + kUsacLoSteps;
+constexpr int kUsacLoThreads = 512;
+
+struct UsacGeom {
+    double T1[9], T2[9], T2t[9], T1i[9], T2ti[9];
+};
+
+__device__ __forceinline__ void usac_mul3(double *c, const double *a, const double *b) {  // MathTools::mmul: k ascending from 0.
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double s = 0.;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s += a[3 * i + k] * b[3 * k + j];
+            c[3 * i + j] = s;
+        }
+}
+// FTools::normalizePoints' MathTools::vmul on a homogeneous point (x, y, 1)
+__device__ __forceinline__ void usac_normalise(const double *T, double x, double y, double *o) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double s = 0.;
+        s += T[3 * k] * x;
+        s += T[3 * k + 1] * y;
+        s += T[3 * k + 2] * 1.0;
+        o[k] = s;
+    }
+}
+// evaluateModel's Sampson error (EssentialMatEstimator.h:1133-1139), the reference's operation order
+__device__ __forceinline__ double usac_sampson(const double *m, double x1, double y1, double x2, double y2) {
+    const double rxc = m[0] * x2 + m[3] * y2 + m[6];
+    const double ryc = m[1] * x2 + m[4] * y2 + m[7];
+    const double rwc = m[2] * x2 + m[5] * y2 + m[8];
+    const double r = (x1 * rxc + y1 * ryc + rwc);
+    const double rx = m[0] * x1 + m[1] * y1 + m[2];
+    const double ry = m[3] * x1 + m[4] * y1 + m[5];
+    return r * r / (rxc * rxc + ryc * ryc + rx * rx + ry * ry);
+}
+
+__global__ void usac_pool_pack_kernel(const double *__restrict__ p1, const double *__restrict__ p2, const int32_t *__restrict__ pool, int n,
+                                      double4 *__restrict__ pts_pool) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int i = pool[j];
+    pts_pool[j] = make_double4(p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+}
+
+// One wave per (sample, solution slot).  out_* live in pinned, device-mapped host memory.
+__global__ __launch_bounds__(64) void usac_check_kernel(const double4 *__restrict__ pts_pool, int n, int words, const double *__restrict__ p1,
+                                                        const double *__restrict__ p2, const int32_t *__restrict__ samples, int B,
+                                                        const double *__restrict__ E_tab, const int32_t *__restrict__ n_models, UsacGeom g,
+                                                        double thr, int32_t *__restrict__ out_nm, double *__restrict__ out_key,
+                                                        int32_t *__restrict__ out_valid, unsigned long long *__restrict__ out_rows) {
+    const int b = blockIdx.x / 10, slot = blockIdx.x - b * 10;
+    const int lane = threadIdx.x;
+    if (b >= B) return;
+    const int nm = min(n_models[b], 10);
+    if (slot == 0 && lane == 0) out_nm[b] = nm;
+    if (slot >= nm) return;
+    double E[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) E[k] = E_tab[((size_t)b * 10 + slot) * 9 + k];
+    if (lane == 0) {
+        // order convention: ascending E(0,0) of the unit-Frobenius matrix whose largest-magnitude element is positive
+        double big = 0, n2 = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (fabs(E[k]) > fabs(big)) big = E[k];
+            n2 += E[k] * E[k];
+        }
+        out_key[b * 10 + slot] = (big < 0 ? -E[0] : E[0]) / sqrt(n2);
+        // validateModel: oriented epipolar constraint on the five sample points, in normalised coordinates
+        double t[9], F[9], e[3];
+        usac_mul3(t, g.T2ti, E);
+        usac_mul3(F, t, g.T1i);
+        e[0] = F[1] * F[8] - F[2] * F[7], e[1] = F[2] * F[6] - F[0] * F[8], e[2] = F[0] * F[7] - F[1] * F[6];  // row 0 x row 2
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if ((e[i] > 1.9984e-15) || (e[i] < -1.9984e-15)) any = true;
+        if (!any) e[0] = F[4] * F[8] - F[5] * F[7], e[1] = F[5] * F[6] - F[3] * F[8], e[2] = F[3] * F[7] - F[4] * F[6];  // row 1 x row 2
+        double sig1 = 0;
+        int ok = 1;
+        for (int i = 0; i < 5; ++i) {
+            const int idx = samples[b * 5 + i];
+            double a[3], c[3];
+            usac_normalise(g.T1, p1[2 * idx], p1[2 * idx + 1], a);
+            usac_normalise(g.T2, p2[2 * idx], p2[2 * idx + 1], c);
+            const double s = (F[0] * c[0] + F[3] * c[1] + F[6] * c[2]) * (e[1] * a[2] - e[2] * a[1]);
+            if (i == 0)
+                sig1 = s;
+            else if (sig1 * s < 0) {
+                ok = 0;
+                break;
+            }
+        }
+        out_valid[b * 10 + slot] = ok;
+    }
+    unsigned long long *row = out_rows + ((size_t)b * 10 + slot) * words;
+    for (int w = 0; w < words; ++w) {
+        const int j = w * 64 + lane;
+        bool in = false;
+        if (j < n) {
+            const double4 p = pts_pool[j];
+            in = usac_sampson(E, p.x, p.y, p.z, p.w) < thr;
+        }
+        const unsigned long long bal = __ballot(in);
+        if (lane == 0) row[w] = bal;
+    }
+}
+
+// ---- local optimisation ---------------------------------------------------------------------------------------------------------------
+struct UsacLoOut {          // per repetition, pinned host memory; followed by kUsacLoEvals bit rows of `words` words
+    int32_t evals;          // evaluations performed (the chain stops when a 2 x threshold inlier set has < 5 members)
+    int32_t cnt2;           // members of the 2 x threshold set after the first evaluation (the first refit's point count)
+    int32_t count[kUsacLoEvals];      // inliers at the threshold per evaluation
+    int32_t fit_pts[kUsacLoEvals];    // points the model of evaluation e was fitted to (0 = the start model of a resumed chain)
+    double F[kUsacLoEvals][9];        // the evaluated models, normalised coordinates (models_[0])
+    double E[kUsacLoEvals][9];        // ... and denormalised (models_denorm_[0])
+};
+struct UsacLoIn {           // per repetition
+    int32_t start_step;     // -1 = from the 14-point sample; j >= 0 = resume at re-weighting step j with the model below
+    int32_t sample[kUsacLoSample];
+    double F[9], E[9];
+};
+
+struct UsacLoLds {
+    Jacobi9Lds J;
+    double red[8][45];
+    double F[9], E[9];
+    int scan[kUsacLoThreads / 64 + 1];
+    int total, K;
+};
+
+// Fit of REFINE_WEIGHTS from the 45 accumulated products in L.red[0] (wave 0): smallest eigenvector of the covariance matrix, rank-2
+// projection (FTools::singulF), denormalisation.
+__device__ __forceinline__ void usac_fit_from_cov(UsacLoLds &L, const UsacGeom &g, int tid) {
+    if (tid < 64) {
+        if (tid == 0) {
+            int t = 0;
+            for (int a = 0; a < 9; ++a)
+                for (int b = a; b < 9; ++b) {
+                    L.J.G[a][b] = L.red[0][t];
+                    L.J.G[b][a] = L.red[0][t];
+                    ++t;
+                }
+        }
+        for (int e = tid; e < 81; e += 64) L.J.Vv[e / 9][e % 9] = (e / 9 == e % 9) ? 1.0 : 0.0;
+        wave_sync();
+        jacobi9_wave(L.J, tid);
+        if (tid == 0) {
+            int m = 0;
+            for (int a = 1; a < 9; ++a)
+                if (L.J.G[a][a] < L.J.G[m][m]) m = a;
+            double F[9], v[3], Fv[3];
+            for (int k = 0; k < 9; ++k) F[k] = L.J.Vv[k][m];
+            null_vector_3x3(F, v);
+            for (int r = 0; r < 3; ++r) Fv[r] = F[3 * r] * v[0] + F[3 * r + 1] * v[1] + F[3 * r + 2] * v[2];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) F[3 * r + c] -= Fv[r] * v[c];
+            double t[9], E[9];
+            usac_mul3(t, g.T2t, F);
+            usac_mul3(E, t, g.T1);
+            for (int k = 0; k < 9; ++k) L.F[k] = F[k], L.E[k] = E[k];
+        }
+    }
+}
+
+// block-wide sum of 45 per-thread accumulators into L.red[0]
+__device__ __forceinline__ void usac_reduce45(UsacLoLds &L, const double *acc, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 45; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) L.red[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid < 45) {
+        double s = 0;
+        for (int w = 0; w < kUsacLoThreads / 64; ++w) s += L.red[w][tid];
+        L.red[0][tid] = s;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void usac_cov_add(double *acc, const double *a, const double *c, double w) {
+    // row of the data matrix (FTools::computeDataMatrix): entry 3 j + k = x2n[j] * x1n[k]; weighted element by element as the reference
+    double q[9];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) q[3 * j + k] = (c[j] * a[k]) * w;
+    int t = 0;
+#pragma unroll
+    for (int x = 0; x < 9; ++x)
+#pragma unroll
+        for (int y = x; y < 9; ++y) acc[t++] += q[x] * q[y];
+}
+
+__global__ __launch_bounds__(kUsacLoThreads) void usac_lo_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
+                                                                 const int32_t *__restrict__ pool, int n, int words, UsacGeom g, double thr,
+                                                                 double lo_mult, const UsacLoIn *__restrict__ in, char *__restrict__ out_base,
+                                                                 size_t out_stride, double *__restrict__ err_scratch) {
+    __shared__ UsacLoLds L;
+    const int tid = threadIdx.x, rep = blockIdx.x;
+    const UsacLoIn &I = in[rep];
+    UsacLoOut *O = reinterpret_cast<UsacLoOut *>(out_base + (size_t)rep * out_stride);
+    unsigned long long *rows = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(O) + sizeof(UsacLoOut));
+    double *err = err_scratch + (size_t)rep * n;
+    const int chunk = (n + kUsacLoThreads - 1) / kUsacLoThreads;
+    const int i0 = min(tid * chunk, n), i1 = min(i0 + chunk, n);
+    const double step = (lo_mult * thr - thr) / kUsacLoSteps;
+    int eval = 0;
+    int fit_pts = 0;
+
+    if (I.start_step < 0) {  // model of the 14-point sample, unit weights
+        double acc[45];
+#pragma unroll
+        for (int k = 0; k < 45; ++k) acc[k] = 0;
+        if (tid < kUsacLoSample) {
+            const int i = I.sample[tid];
+            double a[3], c[3];
+            usac_normalise(g.T1, p1[2 * i], p1[2 * i + 1], a);
+            usac_normalise(g.T2, p2[2 * i], p2[2 * i + 1], c);
+            usac_cov_add(acc, a, c, 1.0);
+        }
+        usac_reduce45(L, acc, tid);
+        usac_fit_from_cov(L, g, tid);
+        fit_pts = kUsacLoSample;
+    } else {
+        if (tid < 9) L.F[tid] = I.F[tid], L.E[tid] = I.E[tid];
+    }
+    __syncthreads();
+
+    // phase -1: the evaluation after the sample model + refit on the 2 x threshold set; phases 0..3: re-weighted refits; then the last evaluation
+    for (int phase = (I.start_step < 0 ? -1 : I.start_step); phase <= kUsacLoSteps; ++phase) {
+        double E[9], F[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) E[k] = L.E[k], F[k] = L.F[k];
+        // ---- evaluation: errors in point order, inlier count, bit row in pool order ----
+        int cnt = 0;
+        for (int i = i0; i < i1; ++i) {
+            const double e = usac_sampson(E, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+            err[i] = e;
+            cnt += e < thr ? 1 : 0;
+        }
+        {
+            int v = cnt;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if ((tid & 63) == 0) L.scan[tid >> 6] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int s = 0;
+            for (int w = 0; w < kUsacLoThreads / 64; ++w) s += L.scan[w];
+            L.K = s;
+            O->count[eval] = s;
+            O->fit_pts[eval] = fit_pts;
+            for (int k = 0; k < 9; ++k) O->F[eval][k] = F[k], O->E[eval][k] = E[k];
+        }
+        {
+            unsigned long long *row = rows + (size_t)eval * words;
+            const int lane = tid & 63;
+            for (int w = tid >> 6; w < words; w += kUsacLoThreads / 64) {
+                const int j = w * 64 + lane;
+                const bool inl = j < n && err[pool[j]] < thr;
+                const unsigned long long bal = __ballot(inl);
+                if (lane == 0) row[w] = bal;
+            }
+        }
+        __syncthreads();
+        ++eval;
+        if (phase == kUsacLoSteps) break;
+        // ---- the point set of the next fit: the first K members (ascending index) of {err < limit} ----
+        const double limit = phase < 0 ? lo_mult * thr : (lo_mult * thr) - (phase + 1) * step;
+        const int K = phase < 0 ? n : L.K;  // findInliers' own count for the first refit, evaluateModel's count afterwards
+        int mine = 0;
+        for (int i = i0; i < i1; ++i) mine += err[i] < limit ? 1 : 0;
+        int incl = mine;  // inclusive scan over the wave, then over the waves
+        {
+            const int lane = tid & 63;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off);
+                if (lane >= off) incl += o;
+            }
+            if (lane == 63) L.scan[tid >> 6] = incl;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int s = 0;
+            for (int w = 0; w < kUsacLoThreads / 64; ++w) {
+                const int v = L.scan[w];
+                L.scan[w] = s;
+                s += v;
+            }
+            L.total = s;
+        }
+        __syncthreads();
+        int rank = L.scan[tid >> 6] + incl - mine;
+        const int used = min(L.total, K);
+        if (phase < 0 && tid == 0) O->cnt2 = L.total;
+        if (used < 5) {  // generateRefinedModel refuses (or, after the first evaluation, the repetition ends: temp_inliers < min sample)
+            if (phase < 0) break;
+            __syncthreads();
+            continue;  // the model stays
+        }
+        double acc[45];
+#pragma unroll
+        for (int k = 0; k < 45; ++k) acc[k] = 0;
+        for (int i = i0; i < i1; ++i) {
+            if (!(err[i] < limit)) continue;
+            if (rank++ >= K) break;
+            double a[3], c[3];
+            usac_normalise(g.T1, p1[2 * i], p1[2 * i + 1], a);
+            usac_normalise(g.T2, p2[2 * i], p2[2 * i + 1], c);
+            double w = 1.0;
+            if (phase >= 0) {  // findWeights, REFINE_WEIGHTS: Torr's weight from the normalised model
+                const double rxc = F[0] * c[0] + F[3] * c[1] + F[6];
+                const double ryc = F[1] * c[0] + F[4] * c[1] + F[7];
+                const double rx = F[0] * a[0] + F[1] * a[1] + F[2];
+                const double ry = F[3] * a[0] + F[4] * a[1] + F[5];
+                w = 1 / sqrt(rxc * rxc + ryc * ryc + rx * rx + ry * ry);
+            }
+            usac_cov_add(acc, a, c, w);
+        }
+        usac_reduce45(L, acc, tid);
+        usac_fit_from_cov(L, g, tid);
+        fit_pts = used;
+        __syncthreads();
+    }
+    if (tid == 0) O->evals = eval;
+}
+
+struct UsacWald {
+    double epsilon, delta, A;
+    unsigned k;
+};
+struct UsacKey {
+    uint32_t v[5];
+    bool operator==(const UsacKey &o) const { return std::memcmp(v, o.v, sizeof(v)) == 0; }
+};
+struct UsacKeyHash {
+    size_t operator()(const UsacKey &k) const {
+        uint64_t h = 1469598103934665603ull;
+        for (int i = 0; i < 5; ++i) h = (h ^ k.v[i]) * 1099511628211ull;
+        return (size_t)h;
+    }
+};
+struct UsacModel {  // one minimal model as the host holds it
+    double E[9];
+    int valid;
+    std::vector<uint64_t> bits;  // pool order
+};
+struct UsacSampleModels {
+    int n = 0;
+    UsacModel m[10];
+};
+
+unsigned usac_to_uint(double v) {  // (unsigned int) of a double as x86-64 compilers convert: cvttsd2si to 64 bits, low half
+    const long long w = (v > -9.2233720368547758e18 && v < 9.2233720368547758e18) ? (long long)v : (long long)0x8000000000000000ull;
+    return (unsigned)(unsigned long long)w;
+}
+
+struct UsacRun {
+    mlpl_ctx *ctx;
+    hipStream_t s;
+    const double *d_p1, *d_p2;
+    std::vector<double> hp1, hp2;  // host copies (sample validation, normalisation)
+    unsigned n = 0, max_hyp = 50000;
+    double conf = 0.99, thr = 0;
+    bool prosac = false;
+    unsigned prosac_max_samples = 1000, prosac_min_stop = 20;
+    double prosac_beta = 0.09, prosac_non_rand_conf = 0.99;
+    std::vector<unsigned> sorted_idx;
+    double sprt_tM = 2314.0, sprt_mS = 8.5, sprt_delta = 0.05, sprt_epsilon = 0.15, sprt_A = 0;
+    double lo_mult = 2.0;
+    int lo_stepwise = 0;
+    UsacGeom g;
+    GlibcRand rng;
+    int words = 0;
+    // device / pinned buffers
+    double4 *d_pts_pool = nullptr;
+    int32_t *d_pool = nullptr;
+    int32_t *h_smp = nullptr, *d_smp = nullptr;  // pinned + its device alias
+    char *h_out = nullptr, *h_out_dev = nullptr;
+    PolyRec *d_recs = nullptr;
+    double *d_Etab = nullptr;
+    int32_t *d_nm = nullptr;
+    double *d_err = nullptr;
+    UsacLoIn *h_lo_in = nullptr, *d_lo_in = nullptr;
+    int batch_cap = kUsacBatch;
+    // state
+    std::vector<unsigned> min_sample, pool;
+    unsigned pool_index = 0;
+    std::vector<UsacWald> history;
+    unsigned last_wald_update = 0;
+    unsigned subset_size = 5, largest_size = 5, stop_len = 0;
+    std::vector<unsigned> growth, non_random, maximality;
+    std::unordered_map<UsacKey, UsacSampleModels, UsacKeyHash> cache;
+    double cache_thr = 0;
+    // results
+    unsigned hyp_count = 0, model_count = 0, rejected_samples = 0, rejected_models = 0, best = 0, points_verified = 0, num_lo = 0;
+    std::vector<uint8_t> flags;
+    std::vector<uint64_t> best_bits;  // pool order: the errors of the best model as far as anything reads them
+    double final_model[9] = {0};
+    long long stats[8] = {0};  // [0] batches, [1] samples solved, [2] samples consumed, [3] LO launches, [4] LO resumes
+
+    void emit(double type, const double *v, int nv) {
+        if (!ctx->usac_trace) return;
+        if (ctx->usac_trace_len < ctx->usac_trace_cap) {
+            double *r = ctx->usac_trace + (size_t)ctx->usac_trace_len * 16;
+            std::memset(r, 0, 128);
+            r[0] = type;
+            for (int i = 0; i < nv && i < 15; ++i) r[1 + i] = v[i];
+        }
+        ctx->usac_trace_len++;
+    }
+
+    static void mul3(double *c, const double *a, const double *b) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double sacc = 0.;
+                for (int k = 0; k < 3; ++k) sacc += a[3 * i + k] * b[3 * k + j];
+                c[3 * i + j] = sacc;
+            }
+    }
+    static void inv_similarity(const double *T, double *Ti) {
+        std::memset(Ti, 0, 72);
+        const double sc = T[0];
+        Ti[0] = 1.0 / sc, Ti[4] = 1.0 / sc, Ti[8] = 1.0;
+        if (T[2] != 0 || T[5] != 0) Ti[2] = -T[2] / sc, Ti[5] = -T[5] / sc;
+        if (T[6] != 0 || T[7] != 0) Ti[6] = -T[6] / sc, Ti[7] = -T[7] / sc;
+    }
+
+    // FTools::normalizePoints (FundmatrixFunctions.cpp:7-62): means and mean distances in the reference's (sequential) summation order
+    void normalisation() {
+        double *T1 = g.T1, *T2 = g.T2;
+        std::memset(T1, 0, 72), std::memset(T2, 0, 72);
+        double m1[2] = {0, 0}, m2[2] = {0, 0};
+        for (unsigned i = 0; i < n; ++i) m1[0] += hp1[2 * i], m1[1] += hp1[2 * i + 1], m2[0] += hp2[2 * i], m2[1] += hp2[2 * i + 1];
+        m1[0] /= (double)n, m2[0] /= (double)n, m1[1] /= (double)n, m2[1] /= (double)n;
+        double d1 = 0, d2 = 0;
+        for (unsigned i = 0; i < n; ++i) {
+            d1 += sqrt((hp1[2 * i] - m1[0]) * (hp1[2 * i] - m1[0]) + (hp1[2 * i + 1] - m1[1]) * (hp1[2 * i + 1] - m1[1]));
+            d2 += sqrt((hp2[2 * i] - m2[0]) * (hp2[2 * i] - m2[0]) + (hp2[2 * i + 1] - m2[1]) * (hp2[2 * i + 1] - m2[1]));
+        }
+        d1 /= (double)n, d2 /= (double)n;
+        const double s1 = sqrt(2.0) / d1, s2 = sqrt(2.0) / d2;
+        T1[0] = s1, T1[2] = -s1 * m1[0], T1[4] = s1, T1[5] = -s1 * m1[1], T1[8] = 1.0;
+        T2[0] = s2, T2[2] = -s2 * m2[0], T2[4] = s2, T2[5] = -s2 * m2[1], T2[8] = 1.0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) g.T2t[3 * i + j] = T2[3 * j + i];
+        inv_similarity(T1, g.T1i), inv_similarity(g.T2t, g.T2ti);
+    }
+    void norm1(unsigned idx, double *o) const {  // normalised first-image point (vmul's order)
+        for (int k = 0; k < 3; ++k) {
+            double sacc = 0.;
+            sacc += g.T1[3 * k] * hp1[2 * idx];
+            sacc += g.T1[3 * k + 1] * hp1[2 * idx + 1];
+            sacc += g.T1[3 * k + 2] * 1.0;
+            o[k] = sacc;
+        }
+    }
+
+    int setup() {
+        normalisation();
+        min_sample.assign(5, 0);
+        if (prosac) init_prosac();
+        last_wald_update = 0, history.clear();
+        design_sprt();
+        pool_index = 0;
+        pool.resize(n);
+        for (unsigned i = 0; i < n; ++i) pool[i] = i;
+        for (unsigned i = 1; i < n; ++i) {  // std::random_shuffle (libstdc++): swap(i, rand() % (i + 1))
+            const unsigned j = (unsigned)rng.next() % (i + 1);
+            if (i != j) std::swap(pool[i], pool[j]);
+        }
+        flags.assign(n, 0);
+        words = (int)((n + 63) / 64);
+        best_bits.assign(words, 0);
+        // buffers
+        batch_cap = std::max(8, std::min(kUsacBatch, (int)((size_t)(6u << 20) / ((size_t)10 * words * 8))));
+        void *p;
+        int rc;
+        if ((rc = ws_get(ctx, WS_AUX3, (size_t)n * sizeof(double4) + (size_t)n * 4 + 64, &p))) return rc;
+        d_pts_pool = (double4 *)p;
+        d_pool = (int32_t *)(d_pts_pool + n);
+        if ((rc = ws_get(ctx, WS_PARTIAL, (size_t)batch_cap * sizeof(PolyRec), &p))) return rc;
+        d_recs = (PolyRec *)p;
+        if ((rc = ws_get(ctx, WS_AUX5, (size_t)batch_cap * 90 * 8 + (size_t)batch_cap * 4 + 64, &p))) return rc;
+        d_Etab = (double *)p;
+        d_nm = (int32_t *)(d_Etab + (size_t)batch_cap * 90);
+        if ((rc = ws_get(ctx, WS_AUX6, (size_t)kUsacLoReps * n * 8 + 64, &p))) return rc;
+        d_err = (double *)p;
+        const size_t out_bytes = std::max(batch_out_bytes(batch_cap), (size_t)kUsacLoReps * lo_out_stride());
+        const size_t smp_bytes = (size_t)batch_cap * 5 * 4, lo_in_bytes = (size_t)kUsacLoReps * sizeof(UsacLoIn);
+        if ((rc = pinned_get(ctx, out_bytes + smp_bytes + lo_in_bytes + 256, &p))) return rc;
+        h_out = (char *)p;
+        h_smp = (int32_t *)(h_out + ((out_bytes + 63) & ~(size_t)63));
+        h_lo_in = (UsacLoIn *)((char *)h_smp + ((smp_bytes + 63) & ~(size_t)63));
+        void *alias = nullptr;
+        MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, h_out, 0));
+        h_out_dev = (char *)alias;
+        MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, h_smp, 0));
+        d_smp = (int32_t *)alias;
+        MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, h_lo_in, 0));
+        d_lo_in = (UsacLoIn *)alias;
+        // the evaluation pool on the device: the permutation itself and the points gathered in its order
+        MLPL_HIP_TRY(hipMemcpyAsync(d_pool, pool.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(usac_pool_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_p1, d_p2, (const int32_t *)d_pool, (int)n, d_pts_pool);
+        MLPL_HIP_TRY(hipGetLastError());
+        MLPL_HIP_TRY(hipStreamSynchronize(s));  // `pool` may be rewritten only after the copy (pageable source)
+        return MLPL_OK;
+    }
+    size_t batch_out_bytes(int B) const { return (size_t)B * 4 + 64 + (size_t)B * 10 * (8 + 4) + 64 + (size_t)B * 10 * words * 8; }
+    size_t lo_out_stride() const { return (sizeof(UsacLoOut) + (size_t)kUsacLoEvals * words * 8 + 63) & ~(size_t)63; }
+
+    void uniform_sample(GlibcRand &r, unsigned data_size, unsigned sample_size, std::vector<unsigned> &sample) const {
+        unsigned count = 0;
+        do {
+            const unsigned index = (unsigned)r.next() % data_size;
+            if (std::find(sample.begin(), sample.begin() + count, index) == sample.begin() + count) sample[count++] = index;
+        } while (count < sample_size);
+    }
+
+    void init_prosac() {
+        growth.assign(n, 0);
+        double T_n = prosac_max_samples;
+        unsigned T_n_p = 1;
+        for (unsigned i = 0; i < 5; ++i) T_n *= (double)(5 - i) / (n - i);
+        for (unsigned i = 0; i < n; ++i) {
+            if (i + 1 <= 5) {
+                growth[i] = T_n_p;
+                continue;
+            }
+            const double temp = (double)(i + 1) * T_n / (i + 1 - 5);
+            growth[i] = T_n_p + (unsigned)ceil(temp - T_n);
+            T_n = temp;
+            T_n_p = growth[i];
+        }
+        non_random.assign(n, 0);
+        double pn_i = 1.0;
+        for (unsigned nn = 6; nn <= n; ++nn) {
+            if (nn - 1 > 1000) {
+                non_random[nn - 1] = non_random[nn - 2];
+                continue;
+            }
+            std::vector<double> v(n, 0);
+            v[5] = prosac_beta * std::pow((double)1 - prosac_beta, (double)nn - 5 - 1) * (nn - 5);
+            pn_i = v[5];
+            for (unsigned i = 7; i <= nn; ++i) {
+                if (i == nn) {
+                    v[nn - 1] = std::pow((double)prosac_beta, (double)nn - 5);
+                    break;
+                }
+                v[i - 1] = pn_i * (prosac_beta / (1 - prosac_beta)) * ((double)(nn - i) / (i - 5 + 1));
+                pn_i = v[i - 1];
+            }
+            double accp = 0.0;
+            unsigned i_min = 0;
+            for (unsigned i = nn; i >= 6; --i) {
+                accp += v[i - 1];
+                if (accp < 1 - prosac_non_rand_conf)
+                    i_min = i;
+                else
+                    break;
+            }
+            non_random[nn - 1] = i_min;
+        }
+        maximality.assign(n, max_hyp);
+        largest_size = 5, subset_size = 5, stop_len = n;
+    }
+    // generatePROSACMinSample on explicit state, so that the speculation can run it on copies
+    void prosac_sample(GlibcRand &r, unsigned &subset, unsigned &largest, unsigned stop, unsigned hyp, std::vector<unsigned> &sample) const {
+        if (hyp > prosac_max_samples) {
+            uniform_sample(r, n, 5, sample);
+            return;
+        }
+        if (subset > stop) uniform_sample(r, stop, 5, sample);  // no return in the reference: overwritten below, the stream is consumed
+        if (hyp > growth[subset - 1]) {
+            ++subset;
+            if (subset > n) subset = n;
+            if (largest < subset) largest = subset;
+        }
+        uniform_sample(r, subset - 1, 4, sample);
+        sample[4] = subset - 1;
+        for (auto &i : sample) i = sorted_idx[i];
+    }
+
+    unsigned standard_stopping(unsigned num_inliers, unsigned tot, unsigned sample_size) const {
+        double n_inl = 1.0, n_pts = 1.0;
+        for (unsigned i = 0; i < sample_size; ++i) {
+            n_inl *= num_inliers - i;  // unsigned arithmetic, as the reference
+            n_pts *= tot - i;
+        }
+        const double p = n_inl / n_pts;
+        if (p < std::numeric_limits<double>::epsilon()) return max_hyp;
+        if (1 - p < std::numeric_limits<double>::epsilon()) return 1;
+        return usac_to_uint(ceil(log(1 - conf) / log(1 - p)));
+    }
+    unsigned prosac_stopping(unsigned hyp) {
+        unsigned max_samples = maximality[stop_len - 1];
+        unsigned inl = 0;
+        for (unsigned i = 0; i < prosac_min_stop; ++i) inl += flags[sorted_idx[i]];
+        for (unsigned i = prosac_min_stop; i < n; ++i) {
+            inl += flags[sorted_idx[i]];
+            if (non_random[i] < inl) {
+                non_random[i] = inl;
+                if ((i == n - 1) || (flags[sorted_idx[i]] && !flags[sorted_idx[i + 1]])) {
+                    unsigned ns = standard_stopping(inl, i + 1, 5);
+                    if (i + 1 < largest_size) ns += hyp - growth[i];
+                    if (ns < maximality[i]) {
+                        maximality[i] = ns;
+                        if ((ns < max_samples) || ((ns == max_samples) && (i + 1 >= stop_len))) {
+                            stop_len = i + 1;
+                            max_samples = ns;
+                        }
+                    }
+                }
+            }
+        }
+        return max_samples;
+    }
+    void design_sprt() {
+        const double C = (1 - sprt_delta) * log((1 - sprt_delta) / (1 - sprt_epsilon)) + sprt_delta * (log(sprt_delta / sprt_epsilon));
+        const double K = (sprt_tM * C) / sprt_mS + 1;
+        double An_1 = K, An = 0;
+        for (unsigned i = 0; i < 10; ++i) {
+            An = K + log(An_1);
+            if (An - An_1 < 1.5e-8) break;
+            An_1 = An;
+        }
+        sprt_A = An;
+    }
+    void add_history(unsigned num_hyp) {
+        history.push_back(UsacWald{sprt_epsilon, sprt_delta, sprt_A, num_hyp - last_wald_update});
+        last_wald_update = num_hyp;
+    }
+    static double exp_sprt(double new_eps, double epsilon, double delta) {
+        const double al = log(delta / epsilon), be = log((1.0 - delta) / (1.0 - epsilon));
+        const double x0 = log(1.0 / (1.0 - new_eps)) / be;
+        const double v0 = new_eps * exp(x0 * al);
+        const double x1 = log((1.0 - 2.0 * v0) / (1.0 - new_eps)) / be;
+        const double v1 = new_eps * exp(x1 * al) + (1.0 - new_eps) * exp(x1 * be);
+        return x0 - (x0 - x1) / (1.0 + v0 - v1) * v0;
+    }
+    unsigned sprt_stopping(unsigned num_inliers, unsigned tot) const {
+        double n_inl = 1.0, n_pts = 1.0, k = 0.0, log_eta = 0.0;
+        const double new_eps = (double)num_inliers / tot;
+        for (unsigned i = 0; i < 5; ++i) {
+            n_inl *= (double)(num_inliers - i);
+            n_pts *= (double)(tot - i);
+        }
+        const double p = n_inl / n_pts;
+        if (p < std::numeric_limits<double>::epsilon()) return max_hyp;
+        if (1.0 - p < std::numeric_limits<double>::epsilon()) return 1;
+        for (size_t t = history.size(); t-- > 0;) {
+            const UsacWald &w = history[t];
+            k += w.k;
+            const double h = exp_sprt(new_eps, w.epsilon, w.delta);
+            const double reject = 1.0 / (exp(h * log(w.A)));
+            log_eta += (double)w.k * log(1.0 - p * (1.0 - reject));
+        }
+        const double ns = k + (log(1.0 - conf) - log_eta) / log(1.0 - p * (1.0 - (1.0 / sprt_A)));
+        return usac_to_uint(ceil(ns));
+    }
+
+    bool validate_sample(const std::vector<unsigned> &smp) const {
+        int i, j, k;
+        for (i = 0; i < 5; i++) {
+            for (j = 0; j < i; j++) {
+                double a[3], b[3];
+                norm1(smp[i], a), norm1(smp[j], b);
+                const double pix = a[0] / a[2], piy = a[1] / a[2], pjx = b[0] / b[2], pjy = b[1] / b[2];
+                const double dx1 = pjx - pix, dy1 = pjy - piy;
+                for (k = 0; k < j; k++) {
+                    double c[3];
+                    norm1(smp[k], c);
+                    const double dx2 = c[0] / c[2] - pix, dy2 = c[1] / c[2] - piy;
+                    if (fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) break;
+                }
+                if (k < j) break;
+            }
+            if (j < i) break;
+        }
+        return i >= 4;
+    }
+
+    // ---- device batches ----
+    int run_batch(const std::vector<UsacKey> &keys) {
+        const int B = (int)keys.size();
+        if (B == 0) return MLPL_OK;
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < 5; ++i) h_smp[b * 5 + i] = (int32_t)keys[b].v[i];
+        const size_t off_key = ((size_t)B * 4 + 63) & ~(size_t)63, off_valid = off_key + (size_t)B * 80;
+        const size_t off_rows = (off_valid + (size_t)B * 40 + 63) & ~(size_t)63;
+        int32_t *o_nm = (int32_t *)h_out_dev, *o_valid = (int32_t *)(h_out_dev + off_valid);
+        double *o_key = (double *)(h_out_dev + off_key);
+        unsigned long long *o_rows = (unsigned long long *)(h_out_dev + off_rows);
+        hipLaunchKernelGGL(solve5pt_kernel, dim3(B), dim3(kSolverThreads), 0, s, d_p1, d_p2, (const int32_t *)d_smp, 0, B, d_recs);
+        MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((B + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)d_recs, 0, B, d_Etab, d_nm,
+                          (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+        hipLaunchKernelGGL(usac_check_kernel, dim3(B * 10), dim3(64), 0, s, (const double4 *)d_pts_pool, (int)n, words, d_p1, d_p2,
+                           (const int32_t *)d_smp, B, (const double *)d_Etab, (const int32_t *)d_nm, g, thr, o_nm, o_key, o_valid, o_rows);
+        MLPL_HIP_TRY(hipGetLastError());
+        MLPL_HIP_TRY(hipMemcpyAsync(h_Etab_host(B), d_Etab, (size_t)B * 720, hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipStreamSynchronize(s));
+        const int32_t *h_nm = (const int32_t *)h_out, *h_valid = (const int32_t *)(h_out + off_valid);
+        const double *h_key = (const double *)(h_out + off_key);
+        const uint64_t *h_rows = (const uint64_t *)(h_out + off_rows);
+        const double *hE = h_Etab_host(B);
+        for (int b = 0; b < B; ++b) {
+            UsacSampleModels sm;
+            const int nm = std::min(h_nm[b], 10);
+            int order[10];
+            for (int i = 0; i < nm; ++i) order[i] = i;
+            std::stable_sort(order, order + nm, [&](int x, int y) { return h_key[b * 10 + x] < h_key[b * 10 + y]; });
+            sm.n = nm;
+            for (int oi = 0; oi < nm; ++oi) {
+                const int slot = order[oi];
+                UsacModel &m = sm.m[oi];
+                std::memcpy(m.E, hE + ((size_t)b * 10 + slot) * 9, 72);
+                m.valid = h_valid[b * 10 + slot];
+                m.bits.assign(h_rows + ((size_t)b * 10 + slot) * words, h_rows + ((size_t)b * 10 + slot + 1) * words);
+            }
+            cache.emplace(keys[b], std::move(sm));
+        }
+        stats[0]++, stats[1] += B;
+        return MLPL_OK;
+    }
+    std::vector<double> etab_host;
+    double *h_Etab_host(int B) {
+        if (etab_host.size() < (size_t)B * 90) etab_host.resize((size_t)kUsacBatch * 90);
+        return etab_host.data();
+    }
+
+    // evaluateModel's sequential test on a bit row (pool order)
+    bool sprt_walk(const uint64_t *bits, unsigned *num_inl, unsigned *tested) {
+        bool good = true;
+        double lj, lj1 = 1.0;
+        *num_inl = 0, *tested = 0;
+        const double up = sprt_delta / sprt_epsilon, down = (1 - sprt_delta) / (1 - sprt_epsilon);
+        for (unsigned i = 0; i < n; ++i) {
+            if (pool_index > n - 1) pool_index = 0;
+            const unsigned j = pool_index;
+            ++pool_index;
+            const bool in = (bits[j >> 6] >> (j & 63)) & 1;
+            if (in) {
+                ++(*num_inl);
+                lj = lj1 * up;
+            } else
+                lj = lj1 * down;
+            if (lj <= DBL_EPSILON) lj = DBL_EPSILON * 10;
+            if (lj > sprt_A) {
+                good = false;
+                *tested = i + 1;
+                break;
+            }
+            lj1 = lj;
+        }
+        if (good) *tested = n;
+        return good;
+    }
+    void emit_eval(unsigned mi, unsigned start, unsigned inl, unsigned tested, bool good) {
+        double v[11] = {(double)hyp_count, (double)mi, (double)start, (double)inl, (double)tested, good ? 1.0 : 0.0,
+                        sprt_delta, sprt_epsilon, sprt_A, thr, (double)num_lo};
+        emit(2, v, 11);
+    }
+
+    void store_solution(unsigned mi, unsigned num_inl, const uint64_t *bits, const double *E) {
+        best = num_inl;
+        for (unsigned j = 0; j < n; ++j) flags[pool[j]] = (uint8_t)((bits[j >> 6] >> (j & 63)) & 1);
+        best_bits.assign(bits, bits + words);
+        std::memcpy(final_model, E, 72);
+        double v[3] = {(double)hyp_count, (double)mi, (double)num_inl};
+        emit(4, v, 3);
+    }
+
+    // ---- local optimisation ----
+    int launch_lo(int reps_from, int reps_to) {  // h_lo_in[reps_from .. reps_to) are filled
+        hipLaunchKernelGGL(usac_lo_kernel, dim3(reps_to - reps_from), dim3(kUsacLoThreads), 0, s, d_p1, d_p2, (const int32_t *)d_pool, (int)n,
+                           words, g, thr, lo_mult, (const UsacLoIn *)(d_lo_in + reps_from), h_out_dev + (size_t)reps_from * lo_out_stride(),
+                           lo_out_stride(), d_err + (size_t)reps_from * n);
+        MLPL_HIP_TRY(hipGetLastError());
+        MLPL_HIP_TRY(hipStreamSynchronize(s));
+        stats[3]++;
+        return MLPL_OK;
+    }
+    void emit_refined(unsigned pts, bool weighted, const double *E) {
+        double v[13];
+        v[0] = hyp_count, v[1] = pts, v[2] = weighted ? 1 : 0, v[3] = 1;
+        std::memcpy(v + 4, E, 72);
+        emit(3, v, 13);
+    }
+
+    // locallyOptimizeSolution (USAC.h:947-1073) over the device chains
+    int local_optimization(unsigned best_inliers, unsigned *out) {
+        *out = 0;
+        if (best_inliers < 2 * kUsacLoSample) return MLPL_OK;
+        std::vector<unsigned> orig(n), sample(kUsacLoSample);
+        unsigned c = 0;
+        for (unsigned i = 0; i < n; ++i)
+            if (flags[i]) orig[c++] = i;  // findInliers(err_ptr_[1], threshold): the flags are that predicate
+        unsigned lo_inliers = best_inliers;
+        ++num_lo;
+        // all samples are known up front: nothing inside a repetition consumes the stream
+        for (int r = 0; r < kUsacLoReps; ++r) {
+            uniform_sample(rng, best_inliers, kUsacLoSample, sample);
+            h_lo_in[r].start_step = -1;
+            for (int j = 0; j < kUsacLoSample; ++j) h_lo_in[r].sample[j] = (int32_t)orig[sample[j]];
+        }
+        int rc;
+        if ((rc = launch_lo(0, kUsacLoReps))) return rc;
+        const size_t stride = lo_out_stride();
+        for (int r = 0; r < kUsacLoReps; ++r) {
+            // the chain of this repetition: evaluation record e of O holds the model evaluated there, its inlier count and its bit row
+            const UsacLoOut *O = (const UsacLoOut *)(h_out + (size_t)r * stride);
+            const uint64_t *rows = (const uint64_t *)((const char *)O + sizeof(UsacLoOut));
+            int e = 0;
+            unsigned tmp = 0, tested;
+            auto evaluate = [&]() {
+                const unsigned start = pool_index;
+                const bool good = sprt_walk(rows + (size_t)e * words, &tmp, &tested);
+                emit_eval(0, start, tmp, tested, good);
+                return good;
+            };
+            // restart the chain at re-weighting step `step` (kUsacLoSteps = only the last evaluation) from the model of record e
+            auto resume = [&](int step) {
+                UsacLoIn &I = h_lo_in[r];
+                I.start_step = step;
+                std::memcpy(I.F, O->F[e], 72), std::memcpy(I.E, O->E[e], 72);
+                e = 0;
+                stats[4]++;
+                return launch_lo(r, r + 1);
+            };
+            emit_refined(kUsacLoSample, false, O->E[0]);
+            if (!evaluate()) continue;
+            if ((unsigned)O->cnt2 < 5) continue;  // findInliers at 2 x threshold < minimal sample
+            e = 1;
+            emit_refined((unsigned)O->cnt2, false, O->E[1]);
+            for (int j = 0; j < kUsacLoSteps; ++j) {
+                if (lo_stepwise && (rc = resume(j))) return rc;  // tests: every step through the resume path (same model, same results)
+                if (!evaluate()) {  // rejected: the model stays and is evaluated again by the next step
+                    if ((rc = resume(j + 1))) return rc;
+                    continue;
+                }
+                ++e;  // the refitted model (or the same one again when fewer than 5 points were left)
+                if (tmp >= 5) emit_refined((unsigned)O->fit_pts[e], true, O->E[e]);
+            }
+            if (!evaluate()) continue;
+            if (tmp > lo_inliers) {
+                lo_inliers = tmp;
+                store_solution(0, lo_inliers, rows + (size_t)e * words, O->E[e]);
+            }
+        }
+        *out = lo_inliers;
+        return MLPL_OK;
+    }
+
+    int solve(bool *ok) {
+        unsigned adaptive = max_hyp;
+        bool update_sprt_stopping = true;
+        *ok = false;
+        if (n < 5 || (prosac && n < prosac_min_stop)) return MLPL_OK;
+        const unsigned max2 = max_hyp / 2, max3 = 2 * max_hyp / 3;
+        int rc;
+        while (hyp_count < adaptive && hyp_count < max_hyp) {
+            ++hyp_count;
+            if ((hyp_count == max2) && (best == 0))
+                thr *= 1.33;
+            else if ((hyp_count == max3) && (best == 0))
+                thr *= 1.13;
+            if (thr != cache_thr) cache.clear(), cache_thr = thr;  // bit rows are per threshold
+            if (prosac)
+                prosac_sample(rng, subset_size, largest_size, stop_len, hyp_count, min_sample);
+            else
+                uniform_sample(rng, n, 5, min_sample);
+            if (!validate_sample(min_sample)) {
+                double v[7] = {(double)hyp_count, (double)min_sample[0], (double)min_sample[1], (double)min_sample[2], (double)min_sample[3],
+                               (double)min_sample[4], -1.0};
+                emit(1, v, 7);
+                ++rejected_samples;
+                continue;
+            }
+            UsacKey key;
+            for (int i = 0; i < 5; ++i) key.v[i] = min_sample[i];
+            auto it = cache.find(key);
+            if (it == cache.end()) {
+                // play the sampler forward under "no event" and solve what is coming in one batch
+                std::vector<UsacKey> batch(1, key);
+                std::unordered_set<UsacKey, UsacKeyHash> in_batch;
+                in_batch.insert(key);
+                GlibcRand r2 = rng;
+                unsigned sub = subset_size, lar = largest_size;
+                std::vector<unsigned> smp(5);
+                unsigned hyp = hyp_count;
+                const unsigned horizon = std::min(std::min(adaptive, max_hyp), best == 0 ? (hyp_count < max2 ? max2 - 1 : (hyp_count < max3 ? max3 - 1 : max_hyp)) : max_hyp);
+                while (hyp < horizon && (int)batch.size() < batch_cap) {
+                    ++hyp;
+                    if (prosac)
+                        prosac_sample(r2, sub, lar, stop_len, hyp, smp);
+                    else
+                        uniform_sample(r2, n, 5, smp);
+                    if (!validate_sample(smp)) continue;
+                    UsacKey k2;
+                    for (int i = 0; i < 5; ++i) k2.v[i] = smp[i];
+                    if (cache.find(k2) == cache.end() && in_batch.insert(k2).second) batch.push_back(k2);
+                }
+                if ((rc = run_batch(batch))) return rc;
+                it = cache.find(key);
+            }
+            stats[2]++;
+            const UsacSampleModels &sm = it->second;
+            const unsigned ns = (unsigned)sm.n;
+            {
+                double v[8] = {(double)hyp_count, (double)min_sample[0], (double)min_sample[1], (double)min_sample[2], (double)min_sample[3],
+                               (double)min_sample[4], (double)ns, 0};
+                emit(1, v, 7);
+                for (unsigned i = 0; i < ns; ++i) {
+                    double w[11];
+                    w[0] = hyp_count, w[1] = i;
+                    std::memcpy(w + 2, sm.m[i].E, 72);
+                    emit(5, w, 11);
+                }
+            }
+            model_count += ns;
+            bool update_best = false;
+            for (unsigned i = 0; i < ns; ++i) {
+                const UsacModel &m = sm.m[i];
+                if (!m.valid) {
+                    double v[2] = {(double)hyp_count, (double)i};
+                    emit(6, v, 2);
+                    ++rejected_models;
+                    continue;
+                }
+                unsigned inl, tested;
+                const unsigned start = pool_index;
+                const bool good = sprt_walk(m.bits.data(), &inl, &tested);
+                emit_eval(i, start, inl, tested, good);
+                if (!good) {
+                    points_verified += tested;
+                    const double delta_new = (double)inl / tested;
+                    if (delta_new > 0 && fabs(sprt_delta - delta_new) / sprt_delta > 0.1) {
+                        add_history(hyp_count);
+                        sprt_delta = delta_new;
+                        design_sprt();
+                    }
+                } else {
+                    points_verified += n;
+                    if (inl > best) {
+                        update_best = true;
+                        best = inl;
+                        add_history(hyp_count);
+                        sprt_epsilon = (double)best / n;
+                        design_sprt();
+                        update_sprt_stopping = true;
+                        store_solution(i, best, m.bits.data(), m.E);
+                    }
+                }
+            }
+            if (update_best) {
+                unsigned lo = 0;
+                // the cache entry `sm` may be invalidated by nothing below (no insertion during LO)
+                if ((rc = local_optimization(best, &lo))) return rc;
+                if (lo > best) best = lo;
+                if (prosac && hyp_count <= prosac_max_samples)
+                    adaptive = prosac_stopping(hyp_count);
+                else
+                    adaptive = standard_stopping(best, n, 5);
+            }
+            if (!prosac) {
+                if (hyp_count >= adaptive && update_sprt_stopping) {
+                    adaptive = sprt_stopping(best, n);
+                    update_sprt_stopping = false;
+                }
+            }
+        }
+        *ok = true;
+        return MLPL_OK;
+    }
+};
+
+}  // namespace
+
+int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, const mlpl_usac_params *P, double *E, uint8_t *d_mask,
+                       double *results, hipStream_t s) {
+    UsacRun R;
+    R.ctx = ctx, R.s = s, R.d_p1 = d_p1, R.d_p2 = d_p2, R.n = (unsigned)n;
+    R.max_hyp = (unsigned)P->max_hyp, R.conf = P->conf, R.thr = P->th * P->th;
+    R.prosac = P->sorted_idx != nullptr;
+    if (R.prosac) R.sorted_idx.assign(P->sorted_idx, P->sorted_idx + n);
+    R.prosac_beta = P->prosac_beta, R.sprt_delta = P->sprt_delta, R.sprt_epsilon = P->sprt_epsilon;
+    R.sprt_mS = P->sprt_mS, R.sprt_tM = P->sprt_tM;
+    R.lo_stepwise = ctx->opt_usac_lo_stepwise;
+    R.hp1.resize((size_t)2 * n), R.hp2.resize((size_t)2 * n);
+    MLPL_HIP_TRY(hipMemcpyAsync(R.hp1.data(), d_p1, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(R.hp2.data(), d_p2, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipStreamSynchronize(s));
+    R.rng.seed(P->seed);
+    int rc;
+    bool ok = false;
+    if (n >= 5) {
+        if ((rc = R.setup())) return rc;
+        if ((rc = R.solve(&ok))) return rc;
+    }
+    std::memcpy(ctx->last_usac_stats, R.stats, sizeof(R.stats));
+    if (results) {
+        const double fin[12] = {ok ? 1.0 : 0.0,
+                                (double)R.hyp_count,
+                                (double)R.model_count,
+                                (double)R.rejected_samples,
+                                (double)R.rejected_models,
+                                (double)R.best,
+                                (double)R.points_verified,
+                                (double)R.num_lo,
+                                R.history.empty() ? 0.0 : R.history.back().delta,
+                                R.history.empty() ? 0.0 : R.history.back().epsilon,
+                                R.sprt_delta,
+                                R.sprt_epsilon};
+        std::memcpy(results, fin, sizeof(fin));
+    }
+    if (!ok) {
+        set_error("mlpl_usac_essential: too few correspondences (%d)", n);
+        return MLPL_E_FAILED;
+    }
+    std::memcpy(E, R.final_model, 72);
+    if (d_mask) {
+        void *hp;
+        if ((rc = pinned_get(ctx, (size_t)n, &hp))) return rc;  // the batch blocks are no longer needed
+        std::memcpy(hp, R.flags.data(), (size_t)n);
+        MLPL_HIP_TRY(hipMemcpyAsync(d_mask, hp, (size_t)n, hipMemcpyHostToDevice, s));
+        MLPL_HIP_TRY(hipStreamSynchronize(s));
+    }
+    return MLPL_OK;
+}

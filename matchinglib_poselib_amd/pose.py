@@ -134,6 +134,44 @@ def arrsac_essential(p1, p2, thresh: float, refine: bool = True, rng_state=None,
     return dict(ok=(rc == 0), E=E, mask=mask, n_inliers=ninl.value, stats=stats)
 
 
+class UsacParams(C.Structure):
+    """mlpl_usac_params (include/mlpl_c.h): the configuration estimateEssentialMatUsac builds (usac_estimations.cpp:283-470)."""
+    _fields_ = [("th", C.c_double), ("conf", C.c_double), ("max_hyp", C.c_int32), ("estimator", C.c_int32), ("refine", C.c_int32),
+                ("seed", C.c_uint32), ("prosac_beta", C.c_double), ("sprt_delta", C.c_double), ("sprt_epsilon", C.c_double),
+                ("sprt_mS", C.c_double), ("sprt_tM", C.c_double), ("sorted_idx", C.c_void_p)]
+
+
+def usac_essential(p1, p2, th: float, seed: int, sorted_idx=None, max_hyp: int = 50000, conf: float = 0.99, prosac_beta: float = 0.09,
+                   sprt_delta: float = 0.05, sprt_epsilon: float = 0.15, sprt_ms: float = 8.5, sprt_tm: float = 2314.0, estimator: int = 0,
+                   refine: int = 0, event_cap: int = 0, ctx: Optional[Context] = None) -> dict:
+    """estimateEssentialMatUsac with the Nister solver and REF_WEIGHTS (usac_estimations.cpp:283-735) on the device; `seed` is the
+    reference's srand(time) seed.  sorted_idx (best match first) switches PROSAC on.  event_cap > 0 also returns the decision trace."""
+    ctx = ctx or default_context()
+    p1, p2 = _pts(p1), _pts(p2)
+    n = p1.shape[0]
+    P = UsacParams()
+    ctx.lib.mlpl_usac_default_params(C.addressof(P), float(th))
+    P.conf, P.max_hyp, P.estimator, P.refine, P.seed = float(conf), int(max_hyp), int(estimator), int(refine), int(seed) & 0xFFFFFFFF
+    P.prosac_beta, P.sprt_delta, P.sprt_epsilon, P.sprt_mS, P.sprt_tM = float(prosac_beta), float(sprt_delta), float(sprt_epsilon), \
+        float(sprt_ms), float(sprt_tm)
+    si = None
+    if sorted_idx is not None:
+        si = np.ascontiguousarray(sorted_idx, np.uint32)
+        P.sorted_idx = si.ctypes.data
+    E, mask, res = np.zeros(9), np.zeros(n, np.uint8), np.zeros(12)
+    ev = np.zeros((max(event_cap, 1), 16))
+    if event_cap:
+        ctx.lib.mlpl_debug_usac_trace(ctx.handle, ev.ctypes.data, int(event_cap))
+    rc = ctx.lib.mlpl_usac_essential(ctx.handle, p1.ctypes.data, p2.ctypes.data, n, C.addressof(P), E.ctypes.data, mask.ctypes.data,
+                                     res.ctypes.data)
+    nev = ctx.lib.mlpl_debug_usac_trace(ctx.handle, None, 0) if event_cap else 0
+    if rc not in (0, _lib.MLPL_E_FAILED):
+        raise MlplError(rc, "mlpl_usac_essential", _lib.last_error())
+    stats = np.zeros(8, np.int64)
+    ctx.lib.mlpl_usac_last_stats(ctx.handle, stats.ctypes.data)
+    return dict(ok=(rc == 0), E=E, flags=mask, final=res, events=ev[:min(nev, event_cap)], n_events=nev, stats=stats)
+
+
 def arrsac_sample_models(p1, p2, idx, kind: int, thresh: float = 1e-3, ctx: Optional[Context] = None):
     """ARRSAC's estimators on one sample (modelest.cpp:111-178) -> (models [k,3,3] before the validity filter, valid flags [k])."""
     ctx = ctx or default_context()

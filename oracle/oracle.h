@@ -179,6 +179,18 @@ int oracle_arrsac_essential(const double *p1, const double *p2, int n, double th
 void oracle_std_sort_desc(const double *score, int n, int32_t *perm);
 int oracle_arrsac_trace(int32_t *buf, int cap);
 
+/* ---- USAC with the Nister minimal solver (usac_oracle.cpp; SURVEY 8(f) rank 4, second half): P/include/usac/estimators/USAC.h,
+ *      EssentialMatEstimator.h, P/source/usac/usac_estimations.cpp:283-470 (estimateEssentialMatUsac without degeneracy tests).
+ * th = inlier threshold (not squared); seed = the srand() seed (reference: time(nullptr)); refine 0 = REF_WEIGHTS, 6 = REF_NISTER;
+ * sorted_idx NULL = uniform sampling, else PROSAC over these indices (best match first).  results[12] = ok, hypotheses, models,
+ * rejected samples, rejected models, best inlier count, points verified, local optimisations, SPRT delta / epsilon of the newest
+ * history entry (what the reference returns), delta / epsilon at the end.  events: optional trace, 16 doubles per record
+ * (type 1 sample, 2 evaluation, 3 refined model, 4 stored model, 5 minimal model, 6 model rejected by the oriented constraint);
+ * *n_events = records produced (may exceed event_cap: only event_cap are written).  Returns 1 if solve() ran. */
+int oracle_usac_essential(const double *p1, const double *p2, int n, double th, unsigned seed, int refine, const uint32_t *sorted_idx,
+                          int max_hyp, double conf, double prosac_beta, double sprt_delta, double sprt_epsilon, double sprt_mS,
+                          double sprt_tM, double *E, uint8_t *inlier_flags, double *results, double *events, int event_cap, int *n_events);
+
 #ifdef __cplusplus
 }
 #endif

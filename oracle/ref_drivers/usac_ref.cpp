@@ -1,0 +1,460 @@
+// usac_ref.cpp -- drives the REFERENCE's own USAC control flow (poselib/include/usac/estimators/USAC.h, a header-only template with
+// no OpenCV dependency: PROSAC sampling, SPRT verification, LO-RANSAC, stopping criteria) compiled WHERE IT LIES under /root/reference,
+// together with the reference's usac/utils {MathFunctions,FundmatrixFunctions,PoseFunctions}.cpp and its vendored OpenGV fivept_nister
+// (the minimal solver of PoseEstimator::POSE_NISTER, EssentialMatEstimator.h:395).
+//
+// TEST INFRASTRUCTURE: built only where /root/reference exists (oracle/Makefile target `ref`), output oracle/_ref/usac_ref.  It pins
+// oracle/usac_oracle.cpp and the device path turn by turn (tests/golden/usac_trace.npz, generator tests/golden/make_golden.py).
+//
+// What is the reference's and what is ours.  The reference's problem class, EssentialMatEstimator (EssentialMatEstimator.h, 2447 lines),
+// cannot be compiled here: it includes OpenCV (cv::Mat members, poselib/pose_estim.h).  The class below is OUR restatement of the members
+// the POSE_NISTER path without degeneracy tests executes -- initProblem :189-352, generateMinimalSampleModels :384-398 + :505-520,
+// generateRefinedModel REFINE_WEIGHTS :540-599 / REFINE_NISTER :757-850, validateSample :1043-1078, validateModel :1085-1104,
+// evaluateModel :1110-1178, findWeights :2366-2390, storeModel :2436-2445 -- calling the reference's own FTools / MathTools / PoseTools /
+// OpenGV functions wherever the original does.  Everything USAC<> does with them (solve(), the samplers, designSPRTTest, the SPRT
+// history, updateSPRTStopping, locallyOptimizeSolution, storeSolution, std::random_shuffle of the evaluation pool on the process-wide
+// rand() stream) is the reference's code, unmodified.  This file contains no reference source text.
+//
+// ONE convention on top of OpenGV (shared with oracle/usac_oracle.cpp and the device path): the solutions of a minimal sample are
+// ordered by ascending E(0,0) after scaling each to unit Frobenius norm with its largest-magnitude element positive.  OpenGV's own order
+// is the breadth-first order of its Sturm bracketing in a null-space basis that Eigen's column-pivoted QR picks among five columns of
+// EQUAL norm (unit bearing vectors): the pivot, hence the basis and the root order, is decided by the last bits of a vectorised sum whose
+// association depends on the Eigen version and the alignment of the column -- rounding noise no restatement can reproduce.  The SET of
+// solutions does not depend on it.  `--native-order` keeps OpenGV's order (diagnostics).
+//
+// usage: usac_ref in.bin out.bin [--native-order] [--solver-oracle]
+//   in.bin : int32 n, seed, refine (0 = REF_WEIGHTS, 6 = REF_NISTER), prosac (0/1), max_hyp, reserved[3];
+//            double th, prosac_beta, sprt_delta, sprt_epsilon, sprt_mS, sprt_tM, conf, reserved;
+//            n * 4 doubles (x1,y1,x2,y2); if prosac: n uint32 sorted indices
+//   out.bin: int32 n_events; n_events * 16 doubles (event records, see emit()); then the final record (see main)
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <fstream>
+#include <string>
+#include <memory>
+#include <vector>
+
+#include "usac/config/ConfigParamsEssentialMat.h"
+#include "usac/utils/MathFunctions.h"
+#include "usac/utils/FundmatrixFunctions.h"
+#include "usac/utils/HomographyFunctions.h"
+#include "usac/utils/PoseFunctions.h"
+#include "usac/estimators/USAC.h"
+
+#include <opengv/relative_pose/methods.hpp>
+#include <opengv/relative_pose/CentralRelativeAdapter.hpp>
+
+static bool g_native_order = false;
+// --solver-oracle: the minimal and the REFINE_NISTER models come from oracle_run5point (oracle/pose_oracle.c, linked in) instead of
+// OpenGV, so that the trace of the reference's CONTROL FLOW can be compared decision by decision with oracle/usac_oracle.cpp, which uses
+// the same solver.  (OpenGV's fivept_nister returns unconverged roots on a noticeable share of samples -- its Sturm brackets are
+// bound / (10 roots) wide and get five Newton steps -- so with it the traces part at the first such sample; see tests/test_oracle_usac.py.)
+static bool g_solver_oracle = false;
+extern "C" int oracle_run5point(const double *q1, const double *q2, int n, double *E_out);
+static std::vector<double> g_events;  // 16 doubles per event
+
+class RefEssential : public USAC<RefEssential> {
+   public:
+    std::vector<double> final_model_params_;
+    int in_lo = 0;
+
+    void emit(double type, const double *v, int nv) {
+        double rec[16] = {0};
+        rec[0] = type;
+        for (int i = 0; i < nv && i < 15; ++i) rec[1 + i] = v[i];
+        g_events.insert(g_events.end(), rec, rec + 16);
+    }
+
+    bool initProblem(const ConfigParamsEssential &cfg, double *pointData) {
+        const unsigned n = cfg.common.numDataPoints;
+        input_points_denorm_ = pointData;
+        input_points_.assign((size_t)6 * n, 0.0);
+        FTools::normalizePoints(input_points_denorm_, input_points_.data(), n, m_T1_, m_T2_);
+        MathTools::mattr(m_T2_trans_, m_T2_, 3, 3);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                m_T1_e(i, j) = m_T1_[3 * i + j];
+                m_T2_e(i, j) = m_T2_[3 * i + j];
+                m_T2_trans_e(i, j) = m_T2_trans_[3 * i + j];
+            }
+        m_T1_e_inv = m_T1_e.inverse();
+        m_T2_e_inv = m_T2_e.inverse();
+        m_T2_trans_e_inv = m_T2_trans_e.inverse();
+        final_model_params_.assign(9, 0.0);
+        models_.assign(usac_max_solns_per_sample_, std::vector<double>(9, 0.0));
+        models_denorm_.assign(usac_max_solns_per_sample_, std::vector<double>(9, 0.0));
+        opengv::bearingVectors_t &b1 = bearing1_, &b2 = bearing2_;  // the adapter keeps references to them
+        for (unsigned i = 0; i < n; i++) {
+            const double *p = input_points_denorm_ + 6 * i;
+            opengv::point_t v1, v2;
+            v1 << p[0], p[1], p[2];
+            v2 << p[3], p[4], p[5];
+            b1.push_back(v1 / v1.norm());
+            b2.push_back(v2 / v2.norm());
+        }
+        adapter_denorm.reset(new opengv::relative_pose::CentralRelativeAdapter(b2, b1));
+        essentials = opengv::essentials_t(usac_max_solns_per_sample_);
+        essentials_denorm = opengv::essentials_t(usac_max_solns_per_sample_);
+        data_matrix_.assign((size_t)9 * n, 0.0);
+        FTools::computeDataMatrix(data_matrix_.data(), n, input_points_.data());
+        refineMethod = cfg.fund.refineMethod;
+        return true;
+    }
+
+    static double order_key(const opengv::essential_t &E) {
+        double big = 0, nrm = E.norm();
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                if (std::fabs(E(r, c)) > std::fabs(big)) big = E(r, c);
+        return (big < 0 ? -E(0, 0) : E(0, 0)) / nrm;
+    }
+    opengv::essentials_t five_point(const std::vector<int> &indices) {
+        if (!g_solver_oracle) return opengv::relative_pose::fivept_nister(*adapter_denorm, indices);
+        std::vector<double> q1(2 * indices.size()), q2(2 * indices.size());
+        for (size_t i = 0; i < indices.size(); ++i) {
+            const double *p = input_points_denorm_ + 6 * indices[i];
+            q1[2 * i] = p[0], q1[2 * i + 1] = p[1], q2[2 * i] = p[3], q2[2 * i + 1] = p[4];
+        }
+        double Es[90];
+        const int ns = oracle_run5point(q1.data(), q2.data(), (int)indices.size(), Es);
+        opengv::essentials_t out;
+        for (int k = 0; k < ns; ++k) {
+            opengv::essential_t E;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) E(r, c) = Es[9 * k + 3 * r + c];
+            out.push_back(E);
+        }
+        return out;
+    }
+
+    unsigned int generateMinimalSampleModels() override {
+        std::vector<int> indices;
+        for (unsigned i = 0; i < usac_min_sample_size_; ++i) indices.push_back((int)min_sample_[i]);
+        essentials_denorm.clear();
+        essentials_denorm = five_point(indices);
+        unsigned nsols = (unsigned)essentials_denorm.size();
+        {
+            double v[8] = {(double)usac_results_.hyp_count_, (double)min_sample_[0], (double)min_sample_[1], (double)min_sample_[2],
+                           (double)min_sample_[3], (double)min_sample_[4], (double)nsols, 0};
+            emit(1, v, 7);
+        }
+        if (nsols > usac_max_solns_per_sample_) return 0;
+        if (!g_native_order) {  // the order convention (see the header)
+            std::vector<std::pair<double, int>> key(nsols);
+            for (unsigned i = 0; i < nsols; ++i) key[i] = std::make_pair(order_key(essentials_denorm[i]), (int)i);
+            std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a.first < b.first; });
+            opengv::essentials_t sorted;
+            for (unsigned i = 0; i < nsols; ++i) sorted.push_back(essentials_denorm[key[i].second]);
+            essentials_denorm = sorted;
+        }
+        essentials.clear();
+        for (unsigned i = 0; i < nsols; ++i) {
+            essentials.push_back(m_T2_trans_e_inv * essentials_denorm.at(i) * m_T1_e_inv);
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) {
+                    models_[i][r * 3 + c] = essentials[i](r, c);
+                    models_denorm_[i][r * 3 + c] = essentials_denorm[i](r, c);
+                }
+            double v[15];
+            v[0] = usac_results_.hyp_count_, v[1] = i;
+            for (int k = 0; k < 9; ++k) v[2 + k] = models_denorm_[i][k];
+            emit(5, v, 11);
+        }
+        return nsols;
+    }
+
+    bool generateRefinedModel(std::vector<unsigned int> &sample, const unsigned int numPoints, bool weighted = false,
+                              double *weights = nullptr) override {
+        if (numPoints < usac_min_sample_size_) return false;
+        bool ok = true;
+        if (refineMethod == USACConfig::REFINE_WEIGHTS) {
+            std::vector<double> A((size_t)numPoints * 9);
+            double *dst = A.data();
+            for (unsigned i = 0; i < numPoints; ++i) {
+                const double *src = data_matrix_.data() + sample[i];
+                for (unsigned j = 0; j < 9; ++j) {
+                    *dst++ = weighted ? (*src) * weights[i] : *src;
+                    src += usac_num_data_points_;
+                }
+            }
+            double Cv[81], V[81], D[9];
+            FTools::formCovMat(Cv, A.data(), numPoints, 9);
+            MathTools::svdu1v(D, Cv, 9, V, 9);
+            unsigned j = 0;
+            for (unsigned i = 1; i < 9; ++i)
+                if (D[i] < D[j]) j = i;
+            for (unsigned i = 0; i < 9; ++i) models_[0][i] = V[9 * i + j];
+            FTools::singulF(models_[0].data());
+            double T2_F[9];
+            MathTools::mmul(T2_F, m_T2_trans_, models_[0].data(), 3);
+            MathTools::mmul(models_denorm_[0].data(), T2_F, m_T1_, 3);
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) {
+                    essentials[0](r, c) = models_[0][r * 3 + c];
+                    essentials_denorm[0](r, c) = models_denorm_[0][r * 3 + c];
+                }
+        } else if (refineMethod == USACConfig::REFINE_NISTER) {
+            std::vector<int> indices;
+            for (unsigned i = 0; i < numPoints; ++i) indices.push_back((int)sample[i]);
+            opengv::essentials_t Es = five_point(indices);
+            if (!g_native_order && Es.size() > 1) {  // the order convention decides ties of the error sums only
+                std::stable_sort(Es.begin(), Es.end(), [](const opengv::essential_t &a, const opengv::essential_t &b) { return order_key(a) < order_key(b); });
+            }
+            const size_t nsols = Es.size();
+            opengv::essential_t E1;
+            if (nsols > 1) {
+                std::vector<double> errSums(nsols, 0);
+                std::vector<std::vector<double>> pm(nsols, std::vector<double>(9));
+                for (size_t j = 0; j < nsols; j++)
+                    for (int r = 0; r < 3; r++)
+                        for (int c = 0; c < 3; c++) pm[j][r * 3 + c] = Es[j](r, c);
+                for (unsigned i = 0; i < usac_num_data_points_; ++i) {
+                    if (usac_results_.inlier_flags_[i]) {
+                        for (size_t j = 0; j < nsols; j++) errSums[j] += PoseTools::getSampsonError(pm[j], input_points_denorm_, i);
+                        if ((i > 3) && (i % 4 == 0)) {
+                            std::vector<double> t = errSums;
+                            std::partial_sort(t.begin(), t.begin() + 2, t.end());
+                            if (t[0] < 0.66 * t[1]) break;
+                        }
+                    }
+                }
+                E1 = Es[std::distance(errSums.begin(), std::min_element(errSums.begin(), errSums.end()))];
+            } else if (nsols == 1)
+                E1 = Es[0];
+            else
+                ok = false;
+            if (ok) {
+                essentials_denorm[0] = E1;
+                essentials[0] = m_T2_trans_e_inv * E1 * m_T1_e_inv;
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 3; c++) {
+                        models_[0][r * 3 + c] = essentials[0](r, c);
+                        models_denorm_[0][r * 3 + c] = essentials_denorm[0](r, c);
+                    }
+            }
+        } else {
+            return false;
+        }
+        double v[15];
+        v[0] = usac_results_.hyp_count_, v[1] = numPoints, v[2] = weighted ? 1 : 0, v[3] = ok ? 1 : 0;
+        for (int k = 0; k < 9; ++k) v[4 + k] = ok ? models_denorm_[0][k] : 0.0;
+        emit(3, v, 13);
+        return ok;
+    }
+
+    bool validateSample() override {
+        int j, k, i;
+        const double *ip = input_points_.data();
+        for (i = 0; i < (int)usac_min_sample_size_; i++) {
+            for (j = 0; j < i; j++) {
+                const double pix = ip[min_sample_[i] * 6] / ip[min_sample_[i] * 6 + 2], piy = ip[min_sample_[i] * 6 + 1] / ip[min_sample_[i] * 6 + 2];
+                const double pjx = ip[min_sample_[j] * 6] / ip[min_sample_[j] * 6 + 2], pjy = ip[min_sample_[j] * 6 + 1] / ip[min_sample_[j] * 6 + 2];
+                const double dx1 = pjx - pix, dy1 = pjy - piy;
+                for (k = 0; k < j; k++) {
+                    const double pkx = ip[min_sample_[k] * 6] / ip[min_sample_[k] * 6 + 2], pky = ip[min_sample_[k] * 6 + 1] / ip[min_sample_[k] * 6 + 2];
+                    const double dx2 = pkx - pix, dy2 = pky - piy;
+                    if (fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) break;
+                }
+                if (k < j) break;
+            }
+            if (j < i) break;
+        }
+        const bool ok = i >= (int)usac_min_sample_size_ - 1;
+        if (!ok) {
+            double v[7] = {(double)usac_results_.hyp_count_, (double)min_sample_[0], (double)min_sample_[1], (double)min_sample_[2],
+                           (double)min_sample_[3], (double)min_sample_[4], -1.0};
+            emit(1, v, 7);
+        }
+        return ok;
+    }
+
+    bool validateModel(unsigned int modelIndex) override {
+        double e[3], sig1, sig2;
+        bool ok = true;
+        FTools::computeEpipole(e, models_[modelIndex].data());
+        sig1 = FTools::getOriSign(models_[modelIndex].data(), e, input_points_.data() + 6 * min_sample_[0]);
+        for (unsigned i = 1; i < min_sample_.size(); ++i) {
+            sig2 = FTools::getOriSign(models_[modelIndex].data(), e, input_points_.data() + 6 * min_sample_[i]);
+            if (sig1 * sig2 < 0) {
+                ok = false;
+                break;
+            }
+        }
+        if (!ok) {
+            double v[3] = {(double)usac_results_.hyp_count_, (double)modelIndex, 0};
+            emit(6, v, 2);
+        }
+        return ok;
+    }
+
+    bool evaluateModel(unsigned int modelIndex, unsigned int *numInliers, unsigned int *numPointsTested) override {
+        const double *model = models_denorm_[modelIndex].data();
+        auto current_err_array = err_ptr_[0];
+        bool good_flag = true;
+        double lambdaj, lambdaj_1 = 1.0;
+        *numInliers = 0;
+        *numPointsTested = 0;
+        const unsigned start_index = eval_pool_index_;
+        unsigned i = 0;
+        for (; i < usac_num_data_points_; ++i) {
+            if (eval_pool_index_ > usac_num_data_points_ - 1) eval_pool_index_ = 0;
+            const unsigned pt_index = evaluation_pool_[eval_pool_index_];
+            ++eval_pool_index_;
+            const double temp_err = PoseTools::getSampsonError(models_denorm_[modelIndex], input_points_denorm_, pt_index);
+            *(current_err_array + pt_index) = temp_err;
+            if (temp_err < usac_inlier_threshold_) ++(*numInliers);
+            if (usac_verif_method_ == USACConfig::VERIF_SPRT) {
+                if (temp_err < usac_inlier_threshold_)
+                    lambdaj = lambdaj_1 * (sprt_delta_ / sprt_epsilon_);
+                else
+                    lambdaj = lambdaj_1 * ((1 - sprt_delta_) / (1 - sprt_epsilon_));
+                if (lambdaj <= DBL_EPSILON) lambdaj = DBL_EPSILON * 10;
+                if (lambdaj > decision_threshold_sprt_) {
+                    good_flag = false;
+                    *numPointsTested = i + 1;
+                    break;
+                } else
+                    lambdaj_1 = lambdaj;
+            }
+        }
+        if (good_flag) *numPointsTested = usac_num_data_points_;
+        (void)model;
+        double v[12] = {(double)usac_results_.hyp_count_, (double)modelIndex, (double)start_index, (double)*numInliers,
+                        (double)*numPointsTested, good_flag ? 1.0 : 0.0, sprt_delta_, sprt_epsilon_, decision_threshold_sprt_,
+                        usac_inlier_threshold_, (double)usac_results_.num_local_optimizations_, 0};
+        emit(2, v, 11);
+        return good_flag;
+    }
+
+    void testSolutionDegeneracy(bool *degenerateModel, bool *upgradeModel) override { *degenerateModel = false, *upgradeModel = false; }
+    unsigned int upgradeDegenerateModel() override { return 0; }
+
+    void findWeights(unsigned int modelIndex, const std::vector<unsigned int> &inliers, unsigned int numInliers, double *weights) override {
+        if (refineMethod != USACConfig::REFINE_WEIGHTS) return;
+        const double *model = models_[modelIndex].data();
+        for (unsigned i = 0; i < numInliers; ++i) {
+            const double *pt = input_points_.data() + 6 * inliers[i];
+            const double rxc = model[0] * pt[3] + model[3] * pt[4] + model[6];
+            const double ryc = model[1] * pt[3] + model[4] * pt[4] + model[7];
+            const double rx = model[0] * pt[0] + model[1] * pt[1] + model[2];
+            const double ry = model[3] * pt[0] + model[4] * pt[1] + model[5];
+            weights[i] = 1 / sqrt(rxc * rxc + ryc * ryc + rx * rx + ry * ry);
+        }
+    }
+
+    void storeModel(unsigned int modelIndex, unsigned int numInliers) override {
+        for (unsigned i = 0; i < 9; ++i) final_model_params_[i] = models_denorm_[modelIndex][i];
+        double v[3] = {(double)usac_results_.hyp_count_, (double)modelIndex, (double)numInliers};
+        emit(4, v, 3);
+    }
+
+    double sprtDelta() const { return sprt_delta_; }
+    double sprtEpsilon() const { return sprt_epsilon_; }
+    const std::vector<unsigned int> &pool() const { return evaluation_pool_; }
+
+   private:
+    double *input_points_denorm_ = nullptr;
+    std::vector<double> input_points_, data_matrix_;
+    double m_T1_[9], m_T2_[9], m_T2_trans_[9];
+    Eigen::Matrix3d m_T1_e, m_T2_e, m_T2_trans_e, m_T1_e_inv, m_T2_e_inv, m_T2_trans_e_inv;
+    opengv::essentials_t essentials, essentials_denorm;
+    std::vector<std::vector<double>> models_, models_denorm_;
+    opengv::bearingVectors_t bearing1_, bearing2_;
+    std::shared_ptr<opengv::relative_pose::CentralRelativeAdapter> adapter_denorm;
+    USACConfig::RefineAlgorithm refineMethod;
+};
+
+int main(int argc, char **argv) {
+    if (argc < 3) return 1;
+    for (int a = 3; a < argc; ++a)
+        if (!std::strcmp(argv[a], "--native-order")) g_native_order = true;
+        else if (!std::strcmp(argv[a], "--solver-oracle")) g_solver_oracle = true;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    int32_t ih[8];
+    double dh[8];
+    if (fread(ih, 4, 8, f) != 8 || fread(dh, 8, 8, f) != 8) return 2;
+    const int n = ih[0];
+    std::vector<double> pts((size_t)n * 4);
+    if (fread(pts.data(), 8, pts.size(), f) != pts.size()) return 2;
+    std::vector<unsigned int> sorted;
+    if (ih[3]) {
+        sorted.resize(n);
+        if (fread(sorted.data(), 4, n, f) != (size_t)n) return 2;
+    }
+    fclose(f);
+
+    // estimateEssentialMatUsac (poselib/source/usac/usac_estimations.cpp:283-470) with the seed exposed (the reference: time(nullptr))
+    srand((unsigned)ih[1]);
+    std::vector<double> pointData((size_t)6 * n);
+    for (int i = 0; i < n; ++i) {
+        pointData[6 * i] = pts[4 * i], pointData[6 * i + 1] = pts[4 * i + 1], pointData[6 * i + 2] = 1.0;
+        pointData[6 * i + 3] = pts[4 * i + 2], pointData[6 * i + 4] = pts[4 * i + 3], pointData[6 * i + 5] = 1.0;
+    }
+    USACConfig::Common c_com;
+    USACConfig::Losac c_lo;
+    USACConfig::Prosac c_pro;
+    USACConfig::Sprt c_sprt;
+    USACConfig::EssMat c_ess;
+    c_com.confThreshold = dh[6];
+    c_com.minSampleSize = 5;
+    c_com.inlierThreshold = dh[0];
+    c_com.maxHypotheses = ih[4];
+    c_com.maxSolutionsPerSample = 10;
+    c_com.numDataPoints = n;
+    c_com.prevalidateSample = true;
+    c_com.prevalidateModel = true;
+    c_com.testDegeneracy = false;
+    c_com.testDegeneracyLOSAC = false;
+    c_com.randomSamplingMethod = sorted.empty() ? USACConfig::SAMP_UNIFORM : USACConfig::SAMP_PROSAC;
+    c_com.verifMethod = USACConfig::VERIF_SPRT;
+    c_com.localOptMethod = USACConfig::LO_LOSAC;
+    c_lo.innerRansacRepetitions = 5;
+    c_lo.innerSampleSize = 14;
+    c_lo.thresholdMultiplier = 2.0;
+    c_lo.numStepsIterative = 4;
+    if (!sorted.empty()) {
+        c_pro.beta = dh[1];
+        c_pro.maxSamples = 1000;
+        c_pro.minStopLen = 20;
+        c_pro.nonRandConf = 0.99;
+        c_pro.sortedPointIndices = sorted.data();
+    }
+    c_sprt.delta = dh[2];
+    c_sprt.epsilon = dh[3];
+    c_sprt.mS = dh[4];
+    c_sprt.tM = dh[5];
+    c_ess.refineMethod = ih[2] == 6 ? USACConfig::REFINE_NISTER : USACConfig::REFINE_WEIGHTS;
+    c_ess.used_estimator = USACConfig::ESTIM_NISTER;
+    ConfigParamsEssential cfg(c_com, c_pro, c_sprt, c_lo, c_ess, false);
+    std::unique_ptr<RefEssential> est(new RefEssential);
+    est->initParamsUSAC(cfg);
+    est->initDataUSAC(cfg);
+    est->initProblem(cfg, pointData.data());
+    const bool ok = est->solve();
+
+    FILE *out = fopen(argv[2], "wb");
+    const int32_t ne = (int32_t)(g_events.size() / 16);
+    fwrite(&ne, 4, 1, out);
+    fwrite(g_events.data(), 8, g_events.size(), out);
+    // final: [ok, hyp_count, model_count, rejected_samples, rejected_models, best_inliers, points_verified, num_lo, sprt_delta_res,
+    //         sprt_epsilon_res, delta_at_end, epsilon_at_end], E[9], n flags (as doubles), n pool entries
+    const UsacResults &r = est->usac_results_;
+    double fin[12] = {ok ? 1.0 : 0.0, (double)r.hyp_count_, (double)r.model_count_, (double)r.rejected_sample_count_,
+                      (double)r.rejected_model_count_, (double)r.best_inlier_count_, (double)r.total_points_verified_,
+                      (double)r.num_local_optimizations_, r.sprt_delta_, r.sprt_epsilon_, est->sprtDelta(), est->sprtEpsilon()};
+    fwrite(fin, 8, 12, out);
+    fwrite(est->final_model_params_.data(), 8, 9, out);
+    std::vector<double> flags(n, 0.0), pool(n, 0.0);
+    for (int i = 0; i < n && i < (int)r.inlier_flags_.size(); ++i) flags[i] = r.inlier_flags_[i];
+    for (int i = 0; i < n && i < (int)est->pool().size(); ++i) pool[i] = est->pool()[i];
+    fwrite(flags.data(), 8, n, out);
+    fwrite(pool.data(), 8, n, out);
+    fclose(out);
+    return 0;
+}

@@ -302,8 +302,63 @@ def arrsac_case():
     print("arrsac_trace: ok")
 
 
+USAC_CASES = [(5000, 0.5, 20260103), (300, 0.5, 13), (1200, 0.9, 15), (150, 0.6, 16), (64, 0.8, 18), (4000, 0.4, 19), (2000, 0.7, 12),
+              (600, 0.35, 21)]
+
+
+USAC_EVENTS_KEPT = 700
+
+
+def usac_scene(n, frac, seed):
+    """Scene + PROSAC order (a noisy quality score: inliers tend to come first) of one USAC fixture case."""
+    from matchinglib_poselib_amd import synth
+    p1, p2, R, t, truth, th = synth.pose_scene(n, frac, seed=seed)
+    score = np.random.default_rng(seed).random(n) + 0.6 * (~truth)
+    return p1, p2, th, truth, np.argsort(score, kind="stable").astype(np.uint32)
+
+
+def usac_case():
+    """USAC fixture: decision traces of the REFERENCE's USAC.h (include/usac/estimators/USAC.h) + usac/utils compiled in place
+    (oracle/_ref/usac_ref).  Two solver modes per case: `--solver-oracle` (the minimal models come from the oracle's 5-point solver, so
+    the trace pins the control-flow restatement decision by decision) and OpenGV (the reference's own solver: final results only, its
+    unconverged roots make the traces part).  Cases where ccmath's svdu1v / svduv (the reference's 9 x 9 / 3 x 3 decompositions) stop
+    early are recorded with agree = 0: there the reference's refined model is inaccurate and the oracle's Jacobi iteration is not."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import oracle_lib
+    import usac_compare
+    import usac_ref_tool as u
+    ora = oracle_lib.load()
+    out = {"cases": np.array(USAC_CASES, np.float64)}
+    k = 0
+    for (n, frac, seed) in USAC_CASES:
+        p1, p2, th, truth, order = usac_scene(n, frac, seed)
+        for prosac in (0, 1):
+            for usac_seed in (12345, 7):
+                si = order if prosac else None
+                r = u.run(p1, p2, th, usac_seed, sorted_idx=si, solver_oracle=True)
+                g = u.run(p1, p2, th, usac_seed, sorted_idx=si)
+                o = ora.usac_essential(p1, p2, th, usac_seed, sorted_idx=si, event_cap=200000)
+                first, d = usac_compare.compare(r["events"], o["events"])
+                agree = int(first is None and np.array_equal(r["flags"], o["flags"]))
+                out[f"k{k}_meta"] = np.array([n, frac, seed, prosac, usac_seed, agree], np.float64)
+                out[f"k{k}_events"] = r["events"][:USAC_EVENTS_KEPT]   # the head of the trace + its length; the final record pins the rest
+                out[f"k{k}_n_events"] = np.array([len(r["events"])])
+                out[f"k{k}_final"], out[f"k{k}_E"], out[f"k{k}_flags"] = r["final"], r["E"], np.packbits(r["flags"])
+                out[f"k{k}_pool_head"] = r["pool"][:64]
+                out[f"k{k}_opengv_final"], out[f"k{k}_opengv_flags"] = g["final"], np.packbits(g["flags"])
+                print(f"usac case {k}: n {n} prosac {prosac} seed {usac_seed}: events {len(r['events'])} agree {agree} "
+                      f"inliers ref/opengv {int(r['final'][5])}/{int(g['final'][5])} hyps {int(r['final'][1])}/{int(g['final'][1])}")
+                k += 1
+    out["n_cases"] = np.array([k])
+    np.savez_compressed(os.path.join(HERE, "usac_trace.npz"), **out)
+    print("usac_trace: ok", os.path.getsize(os.path.join(HERE, "usac_trace.npz")), "bytes")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("all", "usac"):
+        usac_case()
     if what in ("all", "eigen"):
         eigen_svd_case()
     if what in ("all", "arrsac"):
