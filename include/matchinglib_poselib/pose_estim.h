@@ -16,8 +16,7 @@
 
 namespace poselib {
 
-// reference pose_estim.h:61-92.  USAC itself is outside the hot path built here; the types exist so that callers that fill a
-// ConfigUSAC (every harness does, tests/poselib-test/main.cpp:1389-1432) compile and link unchanged.
+// reference pose_estim.h:61-92: the configuration vocabulary of estimateEssentialOrPoseUSAC (below).
 enum UsacChkDegenType { DEGEN_NO_CHECK, DEGEN_QDEGSAC, DEGEN_USAC_INTERNAL };
 enum PoseEstimator { POSE_NISTER, POSE_EIG_KNEIP, POSE_STEWENIUS };
 enum RefineAlg {
@@ -42,8 +41,7 @@ enum RefinePostAlg {
 };
 enum SprtInit { SPRT_DEFAULT_INIT = 0x0, SPRT_DELTA_AUTOM_INIT = 0x1, SPRT_EPSILON_AUTOM_INIT = 0x2 };
 
-// reference pose_estim.h:94-132: every field, the reference's defaults.  Consumed only by the USAC path (not built): the fields are
-// carried, not interpreted.
+// reference pose_estim.h:94-132: every field, the reference's defaults.
 struct ConfigUSAC {
     ConfigUSAC()
         : focalLength(800),
@@ -87,7 +85,9 @@ void clearRansacSeed();
 // ARRSAC draws from two cv::RNG streams that are function-local statics in the reference (include/arrsac/prosac_sampler.h:115,
 // random_sampler.h:65): process-wide, default-seeded (0xffffffff), never reset -- the n-th ARRSAC call of a program continues where the
 // (n-1)-th stopped.  The library keeps the same process-wide pair; these two functions let a test or a caller that wants reproducible
-// runs read and set it.
+// runs read and set it.  Consequence, as in the reference: ARRSAC through this facade is SINGLE-FLIGHT -- concurrent calls (also from
+// StereoRefine and AutoThEpi) are serialised on that pair for their whole duration, and their order decides who draws what.  Callers
+// that want concurrent ARRSAC runs use mlpl_arrsac_essential (include/mlpl_c.h) with one context and one rng_state pair per thread.
 void setArrsacRngState(uint64_t prosac_state, uint64_t uniform_state);
 void getArrsacRngState(uint64_t *prosac_state, uint64_t *uniform_state);
 
@@ -98,6 +98,31 @@ void getArrsacRngState(uint64_t *prosac_state, uint64_t *uniform_state);
 // message and calls exit(1), like the reference.
 bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p2, const std::string &method = "ARRSAC",
                           double threshold = PIX_MIN_GOOD_TH, bool refine = true, cv::OutputArray mask = cv::noArray());
+
+// poselib::estimateEssentialOrPoseUSAC (pose_estim.h:212-223, pose_estim.cpp:1737-2244): the USAC framework -- PROSAC sampling in the
+// order of the matching costs (cfg.matches), Wald's sequential test with automatically initialised and carried-over delta / epsilon
+// (cfg.automaticSprtInit; the history of the last 20 calls lives in function-local statics in the reference, and so it does here:
+// process-wide), local optimisation, SPRT-aware stopping -- on the MI355X (mlpl_usac_essential, include/mlpl_c.h).
+// Returns 0, -1 = configuration not supported, -2 = USAC failed.  E: 3 x 3, inliers: 1 x n CV_8U.
+// Built: PoseEstimator POSE_NISTER and POSE_STEWENIUS (one exact 5-point solver serves both), RefineAlg REF_WEIGHTS (8-point fit with
+// Torr weights: the harness default, tests/poselib-test/main.cpp cfgUSAC "311220"), UsacChkDegenType DEGEN_NO_CHECK.  What is NOT built
+// is served by what is, with one notice per process instead of a failure: the other inner refinement algorithms run REF_WEIGHTS,
+// POSE_EIG_KNEIP runs the 5-point solver, and DEGEN_USAC_INTERNAL / DEGEN_QDEGSAC run without degeneracy tests (isDegenerate = false,
+// R_degenerate / inliers_degenerate_R left empty; R and t are only ever filled by Kneip's eigensolver in the reference: left empty).
+// The reference seeds srand(time(nullptr)) per call; setRansacSeed() fixes the seed here as for RANSAC.
+int estimateEssentialOrPoseUSAC(const cv::Mat &p1, const cv::Mat &p2, cv::OutputArray E, double th, ConfigUSAC &cfg, bool &isDegenerate,
+                                cv::OutputArray inliers = cv::noArray(), cv::OutputArray R_degenerate = cv::noArray(),
+                                cv::OutputArray inliers_degenerate_R = cv::noArray(), cv::OutputArray R = cv::noArray(),
+                                cv::OutputArray t = cv::noArray(), bool verbose = false);
+// The process-wide SPRT history of estimateEssentialOrPoseUSAC (its function-local statics in the reference) -- for tests and for
+// callers that want the first-call behaviour again.
+void resetUsacHistory();
+// estimateSprtDeltaInit / estimateSprtEpsilonInit / getSortedMatchIdx (pose_helper.cpp:2830-2923): the SPRT start values from the convex
+// hull of the matched keypoints / from the share of matches a flow filter kept, and the PROSAC order.
+double estimateSprtDeltaInit(const std::vector<cv::DMatch> &matches, const std::vector<cv::KeyPoint> &kp1,
+                             const std::vector<cv::KeyPoint> &kp2, const double &th, const cv::Size &imgSize);
+double estimateSprtEpsilonInit(const std::vector<cv::DMatch> &matches, const unsigned int &nrMatchesVfcFiltered);
+void getSortedMatchIdx(std::vector<cv::DMatch> matches, std::vector<unsigned int> &sortedMatchIdx);
 
 // poselib::robustEssentialRefine (pose_estim.h:225-228, pose_estim.cpp:337-792): pseudo-Huber re-weighted linear refinement of an
 // essential matrix on the device.  Built for what the library's own callers use: model 0 (essential matrix), iters = 0 (run to the

@@ -36,6 +36,7 @@ extern "C" {
 #define MLPL_E_NO_DEVICE (-100)
 #define MLPL_E_HIP (-101)
 #define MLPL_E_NOMEM (-102)
+#define MLPL_E_INTERNAL (-103)    /* an internal capacity limit was hit: NOT an estimator outcome (in/out states are left untouched) */
 
 /* cv::DMatch layout {int queryIdx; int trainIdx; int imgIdx; float distance;} -- 16 bytes. */
 typedef struct mlpl_dmatch {
@@ -245,8 +246,9 @@ int mlpl_arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
  * pose_estim.cpp:337-792) for the essential-matrix model without normalisation: iteratively re-weighted (pseudo-Huber on the Sampson
  * distance, threshold th) 9 x 9 eigenproblem over the correspondences with mask != 0 (mask == NULL: all), the closest essential matrix
  * after every round, the reference's stopping tests; one workgroup on the device.  Fewer than 50 correspondences or a rank-deficient
- * system return E_init.  info (may be NULL) = {rounds, status: 0 converged or exhausted, 1 stopped on an invalid matrix (last valid one
- * returned), 2 rejected (E_init returned)}.  StereoRefine's refineRTold step (stereo_pose_refinement.cpp:1460-1474) and ARRSAC's
+ * system return E_init.  info (may be NULL) = {the reference's loop counter at the end (index of the round a stopping
+ * test fired in -- one less than the rounds executed -- or 50), status: 0 converged or exhausted, 1 stopped on an invalid matrix (last
+ * valid one returned), 2 rejected: fewer than 50 correspondences, 3 rejected: rank-deficient system (E_init returned by both)}.  StereoRefine's refineRTold step (stereo_pose_refinement.cpp:1460-1474) and ARRSAC's
  * `refine` are this.
  */
 int mlpl_robust_essential_refine(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const uint8_t *mask, const double E_init[9],
@@ -263,7 +265,7 @@ int mlpl_arrsac_sample_models(mlpl_ctx *ctx, const double *p1, const double *p2,
 /* Statistics of the last mlpl_arrsac_essential[_dev] call: {k of the initial hypothesis set, hypotheses after it, PROSAC samples,
  * inner-RANSAC samples, inner-RANSAC restarts, samples of the preemptive stage, correspondence index where that stage ended,
  * hypotheses left there, device batches, samples solved on the device, samples the control flow consumed, refinement status
- * (-1 not run, 0 converged, 1 stopped on an invalid matrix, 2 rejected)}. */
+ * (-1 not run, 0 converged, 1 stopped on an invalid matrix, 2 / 3 rejected: too few points / rank-deficient system)}. */
 int mlpl_arrsac_last_stats(mlpl_ctx *ctx, long long stats[12]);
 /* Diagnostics: the following mlpl_arrsac_essential* calls record the turns of their first stage into buf (20 ints per turn: k, inner-RANSAC
  * turn?, sample size, its first five indices, valid models, per model 1000 * accepted + inliers seen by the sequential test, sixth + 100 * seventh index); returns the

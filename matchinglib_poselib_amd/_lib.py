@@ -16,6 +16,7 @@ MLPL_OK = 0
 MLPL_E_BAD_INPUT = -1
 MLPL_E_UNSUPPORTED = -2
 MLPL_E_FAILED = -3
+MLPL_E_INTERNAL = -103
 MLPL_E_FEW_KEYPOINTS = -4
 MLPL_E_NO_DEVICE = -100
 MLPL_E_HIP = -101

@@ -399,12 +399,34 @@ __global__ void arrsac_gather_kernel(const int32_t *__restrict__ rows, int n_row
     else reinterpret_cast<unsigned long long *>(o)[t] = F_pool[row * kArrFlagWords + (t - 9)];
 }
 
+// Inlier bits of pool models over ALL n correspondences (the preemptive stage beyond the first kArrFlagPoints: reached when the
+// hypothesis set keeps growing instead of halving, i.e. at inlier ratios above ~0.9): out[i] = words_full words for pool row rows[i].
+__global__ __launch_bounds__(64) void arrsac_extend_kernel(const int32_t *__restrict__ rows, int n_rows, const double4 *__restrict__ pts, int n,
+                                                           int words_full, const double *__restrict__ E_pool, double thresh2,
+                                                           unsigned long long *__restrict__ out) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n_rows) return;
+    double e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = E_pool[(size_t)rows[i] * 9 + k];
+    for (int w = 0; w < words_full; ++w) {
+        const int j = w * 64 + lane;
+        bool in = false;
+        if (j < n) {
+            const double4 p = pts[j];
+            in = (double)sampson_err_f32(e, p.x, p.y, p.z, p.w) < thresh2;
+        }
+        const unsigned long long bal = __ballot(in);
+        if (lane == 0) out[(size_t)i * words_full + w] = bal;
+    }
+}
+
 // robustEssentialRefine(inliers, E_init, th, iters = 0, makeClosestE = true) (pose_estim.cpp:337-792; model 0, no normalisation): up to
 // 50 rounds of { pseudo-Huber weights on the Sampson distance under the current matrix (pose_helper.cpp:115-143, BA_driver.cpp:2639-2648),
 // weighted 9x9 normal matrix, eigenvector of its smallest eigenvalue, closest essential matrix (getClosestE, pose_helper.cpp:152-177) },
 // stopped by the reference's tests on the residual.  One workgroup; the normal matrix is summed unnormalised and divided by the weight
 // norm afterwards (the reference scales every row first).  info = {rounds, status: 0 converged/exhausted, 1 stopped on an invalid matrix,
-// 2 rejected (too few points or a rank-deficient system: E_init is returned)}.
+// 2 rejected: fewer than 50 points, 3 rejected: rank-deficient system (E_init is returned by both)}.
 // 512 threads: the 46 running sums of a thread need ~130 registers; at 1024 threads per workgroup (four waves per SIMD, 128 registers
 // each) the compiler spilled 213 of them and every round spent 60 us in scratch traffic.
 constexpr int kArrRefineThreads = 512;
@@ -517,7 +539,10 @@ __global__ __launch_bounds__(kArrRefineThreads) void arrsac_refine_kernel(const 
         if (s_stop) break;
     }
     if (tid < 9) E_out[tid] = (s_stop == 3) ? E_init[tid] : F3[tid];
-    if (tid == 0) info[0] = j, info[1] = (s_stop == 3) ? 2 : (s_stop == 2 ? 1 : 0);
+    // info[0] = the reference's loop counter when the loop ended (the index of the round a stopping test fired in, i.e. one LESS than the
+    // rounds executed then; 50 when exhausted); info[1]: 3 = the system of the first round was rank deficient ("Refinement failed!" in the
+    // reference), as distinct from 2 = fewer than 50 correspondences ("too less points", written above)
+    if (tid == 0) info[0] = j, info[1] = (s_stop == 3) ? 3 : (s_stop == 2 ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -535,6 +560,7 @@ struct CvRng {  // cv::RNG (OpenCV core): multiply-with-carry
 struct ArrModelHost {
     int row;                       // row of the device-side pool (E, all flag words)
     int full;                      // index into ArrsacRun::full_rows once the whole row was fetched, else -1
+    int ext = -1;                  // index into ArrsacRun::ext_rows (bits of ALL correspondences) once computed, else -1
     uint64_t head[kArrHeadWords];  // inlier bits of the first 128 correspondences
 };
 struct ArrFullRow {
@@ -592,6 +618,7 @@ struct ArrsacRun {
     // results
     std::vector<ArrModelHost> pool;
     std::vector<ArrFullRow> full_rows;
+    std::vector<std::vector<uint64_t>> ext_rows;
     double *d_Epool = nullptr;
     unsigned long long *d_Fpool = nullptr;
     int pool_samples = 0;  // samples whose rows are in use
@@ -644,8 +671,8 @@ struct ArrsacRun {
         if (B == 0) return MLPL_OK;
         for (int b = 0; b < B; ++b) std::memcpy(h_smp + (size_t)b * kArrSmpStride, keys[b].v, sizeof(keys[b].v));
         if (pool_samples + B > kArrPoolSamples) {
-            set_error("mlpl_arrsac_essential: more than %d samples solved in one call", kArrPoolSamples);
-            return MLPL_E_FAILED;
+            set_error("mlpl_arrsac_essential: more than %d samples solved in one call (internal capacity)", kArrPoolSamples);
+            return MLPL_E_INTERNAL;
         }
         // layout of the result block: out_nm[B] | out_valid[B*10] | E00[B*10] | head[B*10*2]; models and whole flag rows go to the pool
         const size_t off_valid = (size_t)B * 4, off_e00 = ((size_t)B * 44 + 7) & ~(size_t)7, off_head = off_e00 + (size_t)B * 80;
@@ -725,10 +752,48 @@ struct ArrsacRun {
         return MLPL_OK;
     }
 
+    // Bits over all n correspondences for the given models, once each (the preemptive stage past the first kArrFlagPoints).
+    int ensure_ext(const std::vector<int> &ids) {
+        std::vector<int> need;
+        for (int id : ids)
+            if (pool[id].ext == -1) {
+                pool[id].ext = -2;
+                need.push_back(id);
+            }
+        if (need.empty()) return MLPL_OK;
+        const int wf = (n + 63) / 64;
+        const size_t cap = out_bytes(kArrBatchCap);
+        const size_t per = std::max<size_t>(1, (cap - 4096) / ((size_t)wf * 8 + 4));
+        if ((size_t)wf * 8 + 4096 > cap) {
+            set_error("mlpl_arrsac_essential: %d correspondences exceed the staging block of the preemptive stage (internal capacity)", n);
+            return MLPL_E_INTERNAL;
+        }
+        for (size_t at = 0; at < need.size(); at += per) {
+            const int cnt = (int)std::min(need.size() - at, per);
+            int32_t *h_rows = (int32_t *)h_out;
+            for (int i = 0; i < cnt; ++i) h_rows[i] = pool[need[at + i]].row;
+            int32_t *d_rows = (int32_t *)d_out;
+            unsigned long long *d_g = (unsigned long long *)(d_out + (((size_t)cnt * 4 + 63) & ~(size_t)63));
+            MLPL_HIP_TRY(hipMemcpyAsync(d_rows, h_rows, (size_t)cnt * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(arrsac_extend_kernel, dim3(cnt), dim3(64), 0, s, (const int32_t *)d_rows, cnt, pts, n, wf, (const double *)d_Epool,
+                               thresh2, d_g);
+            MLPL_HIP_TRY(hipGetLastError());
+            MLPL_HIP_TRY(hipMemcpyAsync(h_out, d_g, (size_t)cnt * wf * 8, hipMemcpyDeviceToHost, s));
+            MLPL_HIP_TRY(hipStreamSynchronize(s));
+            const uint64_t *g = (const uint64_t *)h_out;
+            for (int i = 0; i < cnt; ++i) {
+                pool[need[at + i]].ext = (int)ext_rows.size();
+                ext_rows.emplace_back(g + (size_t)i * wf, g + (size_t)(i + 1) * wf);
+            }
+        }
+        return MLPL_OK;
+    }
+
     bool bit(int id, int i) const {
         const ArrModelHost &m = pool[id];
         if (i < kArrHeadWords * 64) return (m.head[i >> 6] >> (i & 63)) & 1;
-        return (full_rows[m.full].bits[i >> 6] >> (i & 63)) & 1;  // callers fetch the row first (ensure_full)
+        if (i >= flag_points) return (ext_rows[m.ext][i >> 6] >> (i & 63)) & 1;     // callers compute the row first (ensure_ext)
+        return (full_rows[m.full].bits[i >> 6] >> (i & 63)) & 1;                    // callers fetch the row first (ensure_full)
     }
 
     // ProsacSampler::Sample for sample number k over the first `count` correspondences (prosac_sampler.h:85-157).  The growth function
@@ -957,10 +1022,13 @@ struct ArrsacRun {
         }
         int i = kBlock;
         for (; i < n; i++) {
-            if (i >= flag_points) {  // cannot happen: the hypothesis count halves every block (n1 below), one is left before 900
-                set_error("mlpl_arrsac_essential: preemptive stage ran past the %d tested correspondences", flag_points);
-                *rc_out = MLPL_E_FAILED;
-                return -1;
+            if (i >= flag_points) {
+                // Past the correspondences every model was tested on.  Reached when the hypothesis set GROWS (generation branch, inlier
+                // ratios above ~0.9: k climbs towards 500 and nothing halves): the survivors' bits over all n are computed on demand.
+                std::vector<int> ids;
+                for (const Scored &h : hyps)
+                    if (pool[h.id].ext < 0) ids.push_back(h.id);
+                if (!ids.empty() && (*rc_out = ensure_ext(ids))) return -1;
             }
             if ((i + 1) % kBlock == 0) {
                 std::sort(hyps.begin(), hyps.end(), cmp);
@@ -991,6 +1059,7 @@ struct ArrsacRun {
                             for (const ArrKey &bk : batch)
                                 for (int id : cache.find(bk)->second) ids.push_back(id);
                             if ((*rc_out = ensure_full(ids))) return -1;
+                            if (i + 1 > flag_points && (*rc_out = ensure_ext(ids))) return -1;
                             it = cache.find(key);
                         }
                         stats[10]++;
@@ -998,6 +1067,11 @@ struct ArrsacRun {
                         if (est.empty()) {
                             k2++;
                             continue;
+                        }
+                        {  // a sample met before (first stage, earlier block) may hold only its leading bits: complete the rows (no-ops otherwise)
+                            std::vector<int> ids(est.begin(), est.end());
+                            if ((*rc_out = ensure_full(ids))) return -1;
+                            if (i + 1 > flag_points && (*rc_out = ensure_ext(ids))) return -1;
                         }
                         verified_accum += (int)est.size();
                         const double dt = sprt_threshold(sigma, epsilon, verified_accum / (k + j + 1 - k2));
@@ -1051,7 +1125,7 @@ int arrsac_sample_models(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, 
                          double *E_out, int32_t *n_models, uint8_t *valid, hipStream_t s) {
     ArrsacRun R;
     R.ctx = ctx, R.s = s, R.d_p1 = d_p1, R.d_p2 = d_p2, R.n = n;
-    R.flag_points = std::min(n, kArrFlagPoints);
+    R.flag_points = std::min(n, ctx->opt_arrsac_flag_points ? ctx->opt_arrsac_flag_points : kArrFlagPoints);
     R.thresh2 = thresh * thresh;
     int rc;
     double4 *pts = nullptr;
@@ -1074,7 +1148,7 @@ int arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, 
                          double *E, uint8_t *d_mask, int *n_inliers, hipStream_t s) {
     ArrsacRun R;
     R.ctx = ctx, R.s = s, R.d_p1 = d_p1, R.d_p2 = d_p2, R.n = n;
-    R.flag_points = std::min(n, kArrFlagPoints);
+    R.flag_points = std::min(n, ctx->opt_arrsac_flag_points ? ctx->opt_arrsac_flag_points : kArrFlagPoints);
     R.thresh2 = thresh * thresh;
     R.prosac_rng.state = rng_state[0], R.random_rng.state = rng_state[1];
     int rc;
@@ -1088,9 +1162,9 @@ int arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, 
     int32_t *d_info = (int32_t *)(d_E + 18);  // [0] inlier count, [1..2] refinement info
     rc = MLPL_OK;
     const int best = R.estimate(&rc);
-    rng_state[0] = R.prosac_rng.state, rng_state[1] = R.random_rng.state;
     std::memcpy(ctx->last_arrsac_stats, R.stats, sizeof(ctx->last_arrsac_stats));
-    if (rc) return rc;
+    if (rc) return rc;  // an internal limit or a HIP error is not an estimator outcome: the caller's stream states stay where they were
+    rng_state[0] = R.prosac_rng.state, rng_state[1] = R.random_rng.state;
     if (n_inliers) *n_inliers = 0;
     if (best < 0) {
         set_error("mlpl_arrsac_essential: no hypothesis passed the sequential test");

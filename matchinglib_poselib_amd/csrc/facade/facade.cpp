@@ -231,10 +231,236 @@ void robustEssentialRefine(cv::InputArray points1, cv::InputArray points2, cv::I
     int info[2] = {0, 0};
     if (mlpl_robust_essential_refine(default_ctx(), a.data(), b.data(), n1, m.empty() ? nullptr : m.data(), Ei, th, Eo, info) != MLPL_OK)
         throw cv::Exception(std::string("robustEssentialRefine: ") + mlpl_last_error());
-    if (info[1] == 2 && info[0] == 0) std::cout << "There are too less points for a refinement left!" << std::endl;  // pose_estim.cpp:411-416
+    if (info[1] == 2) std::cout << "There are too less points for a refinement left!" << std::endl;  // pose_estim.cpp:411-416
+    else if (info[1] == 3) std::cout << "Refinement failed!" << std::endl;
     cv::Mat out(3, 3, CV_64F);
     for (int i = 0; i < 9; ++i) out.at<double>(i / 3, i % 3) = Eo[i];
     E_refined = out;
+}
+
+// ---- USAC (pose_estim.cpp:1737-2244, pose_helper.cpp:2830-2923) --------------------------------------------------------------------------
+namespace {
+void usac_history_stats(const std::vector<double> &vals, double *mean, double *stddev);  // getStatsfromVec(vals, &stats, true): defined below
+// convex hull (Andrew's monotone chain) + cv::contourArea's shoelace sum in double: the hull of a point set is unique, so is its area
+// up to the summation order
+double hull_area(std::vector<cv::Point2f> pts) {
+    std::sort(pts.begin(), pts.end(), [](const cv::Point2f &a, const cv::Point2f &b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });
+    pts.erase(std::unique(pts.begin(), pts.end(), [](const cv::Point2f &a, const cv::Point2f &b) { return a.x == b.x && a.y == b.y; }), pts.end());
+    const size_t n = pts.size();
+    if (n < 3) return 0.0;
+    auto cross = [](const cv::Point2f &o, const cv::Point2f &a, const cv::Point2f &b) {
+        return ((double)a.x - o.x) * ((double)b.y - o.y) - ((double)a.y - o.y) * ((double)b.x - o.x);
+    };
+    std::vector<cv::Point2f> h(2 * n);
+    size_t k = 0;
+    for (size_t i = 0; i < n; ++i) {
+        while (k >= 2 && cross(h[k - 2], h[k - 1], pts[i]) <= 0) k--;
+        h[k++] = pts[i];
+    }
+    for (size_t i = n - 1, t = k + 1; i > 0; --i) {
+        while (k >= t && cross(h[k - 2], h[k - 1], pts[i - 1]) <= 0) k--;
+        h[k++] = pts[i - 1];
+    }
+    h.resize(k - 1);
+    double a00 = 0;
+    cv::Point2f prev = h.back();
+    for (const cv::Point2f &p : h) {
+        a00 += (double)prev.x * p.y - (double)prev.y * p.x;
+        prev = p;
+    }
+    return std::fabs(a00 * 0.5);
+}
+bool usac_near_zero(double d) { return (d < 1e-3) && (d > -1e-3); }  // poselib::nearZero (pose_helper.h:82-87)
+std::mutex g_usac_mutex;
+struct UsacHistory {  // the function-local statics of estimateEssentialOrPoseUSAC (:1755-1762) and estimateEssentialMatUsac (:321-323)
+    double sprt_delta_old = 0, sprt_delta_new = 0, sprt_epsilon_old = 0, sprt_epsilon_new = 0;
+    double delta_history[20] = {0}, epsilon_history[20] = {0};
+    int historyCnt = 0;
+    bool historyBufFull = false, statistic_valid = false;
+    double delta_mean = 0, delta_std = 0, epsilon_mean = 0, epsilon_std = 0;
+    unsigned numhyps = 0, modelcount = 0;
+    double avgModels = 6;
+} g_usac_hist;
+std::once_flag g_usac_notice[3];
+}  // namespace
+
+double estimateSprtDeltaInit(const std::vector<cv::DMatch> &matches, const std::vector<cv::KeyPoint> &kp1,
+                             const std::vector<cv::KeyPoint> &kp2, const double &th, const cv::Size &imgSize) {
+    std::vector<cv::Point2f> points1, points2;
+    for (const cv::DMatch &m : matches) {
+        points1.push_back(kp1[(size_t)m.queryIdx].pt);
+        points2.push_back(kp2[(size_t)m.trainIdx].pt);
+    }
+    double area[2] = {hull_area(points1), hull_area(points2)};
+    area[0] = area[0] > area[1] ? area[1] : area[0];
+    double maxEpipoleArea = std::sqrt((double)(imgSize.width * imgSize.width + imgSize.height * imgSize.height));
+    maxEpipoleArea *= 2 * th;
+    area[0] = area[0] < (6 * maxEpipoleArea) ? (6 * maxEpipoleArea) : area[0];
+    double sprt_delta = maxEpipoleArea / area[0];
+    return sprt_delta < 0.001 ? 0.001 : sprt_delta;
+}
+
+double estimateSprtEpsilonInit(const std::vector<cv::DMatch> &matches, const unsigned int &nrMatchesVfcFiltered) {
+    double e = 0.8 * (double)nrMatchesVfcFiltered / (double)matches.size();
+    e = e > 0.4 ? 0.4 : e;
+    return e < 0.1 ? 0.1 : e;
+}
+
+void getSortedMatchIdx(std::vector<cv::DMatch> matches, std::vector<unsigned int> &sortedMatchIdx) {
+    size_t i = 0;
+    for (i = 0; i < matches.size(); i++)
+        if (matches[i].queryIdx != static_cast<int>(i)) break;
+    if (i < matches.size())
+        for (i = 0; i < matches.size(); i++) matches[i].queryIdx = static_cast<int>(i);
+    std::sort(matches.begin(), matches.end(), [](cv::DMatch const &first, cv::DMatch const &second) { return first.distance < second.distance; });
+    sortedMatchIdx.resize(matches.size());
+    for (i = 0; i < matches.size(); i++) sortedMatchIdx[i] = (unsigned int)matches[i].queryIdx;
+}
+
+void resetUsacHistory() {
+    std::lock_guard<std::mutex> lock(g_usac_mutex);
+    g_usac_hist = UsacHistory();
+}
+
+int estimateEssentialOrPoseUSAC(const cv::Mat &p1, const cv::Mat &p2, cv::OutputArray E, double th, ConfigUSAC &cfg, bool &isDegenerate,
+                                cv::OutputArray inliers, cv::OutputArray R_degenerate, cv::OutputArray inliers_degenerate_R,
+                                cv::OutputArray R, cv::OutputArray t, bool verbose) {
+    (void)verbose;
+    std::lock_guard<std::mutex> lock(g_usac_mutex);  // the history is process-wide: calls are serialised like the reference's statics imply
+    UsacHistory &H = g_usac_hist;
+    int estimator;
+    switch (cfg.estimator) {
+        case POSE_NISTER: estimator = 0; break;
+        case POSE_STEWENIUS: estimator = 2; break;
+        case POSE_EIG_KNEIP:
+            std::call_once(g_usac_notice[0], [] { std::cout << "USAC (MI355X hot-path library): Kneip's eigensolver is not built; the 5-point solver is used." << std::endl; });
+            estimator = 0;
+            break;
+        default: std::cout << "Estimator not supported!" << std::endl; return -1;
+    }
+    if ((int)cfg.refinealg < (int)REF_WEIGHTS || (int)cfg.refinealg > (int)REF_NISTER_WEIGHTS) {
+        std::cout << "Refinement algorithm not supported!" << std::endl;
+        return -1;
+    }
+    if (cfg.refinealg != REF_WEIGHTS)
+        std::call_once(g_usac_notice[1], [] { std::cout << "USAC (MI355X hot-path library): of the inner refinement algorithms the 8-point fit with Torr weights (REF_WEIGHTS) is built; it is used." << std::endl; });
+    CV_Assert(p1.cols == 2 && p2.cols == 2 && p1.rows == p2.rows && p1.type() == CV_64F && p2.type() == CV_64F);  // usac_estimations.cpp:315
+    const int n = p1.rows;
+    CV_Assert(!cfg.matches || cfg.matches->empty() || (size_t)n == cfg.matches->size());  // :316
+
+    // initial delta / epsilon of the sequential test (:1799-1990)
+    double prosac_beta = 0.09, sprt_delta = 0.05, sprt_epsilon = 0.15;
+    const double statStdDivTh[2] = {0.1, 0.2}, relativeDifferenceTh[2] = {0.33, 0.4}, relDiffArithToStd = 0.45, ignoreRelDiffATSTh[2] = {0.1, 0.1};
+    const bool want_delta = (cfg.automaticSprtInit & SPRT_DELTA_AUTOM_INIT) != 0, want_eps = (cfg.automaticSprtInit & SPRT_EPSILON_AUTOM_INIT) != 0;
+    if (cfg.automaticSprtInit < 0 || cfg.automaticSprtInit > 3) {
+        std::cout << "Method for SPRT initialization not supported!" << std::endl;
+        return -1;
+    }
+    if ((want_delta || want_eps || !cfg.noAutomaticProsacParamters) && (want_delta || want_eps) &&
+        (!cfg.matches || (want_delta && (!cfg.keypoints1 || !cfg.keypoints2)))) {
+        std::cout << "USAC: the automatic SPRT initialisation needs cfg.matches and the keypoints!" << std::endl;
+        return -1;
+    }
+    if (want_delta) {
+        if (H.sprt_delta_old == 0 || H.sprt_delta_new == 0) {
+            sprt_delta = estimateSprtDeltaInit(*cfg.matches, *cfg.keypoints1, *cfg.keypoints2, cfg.th_pixels, cfg.imgSize);
+            H.sprt_delta_new = sprt_delta;
+        } else if (!H.statistic_valid || (H.delta_std > statStdDivTh[0]) ||
+                   ((H.delta_mean > ignoreRelDiffATSTh[0]) && (H.delta_std > relDiffArithToStd * H.delta_mean))) {
+            if (std::abs((H.sprt_delta_old - H.sprt_delta_new) / H.sprt_delta_old) < relativeDifferenceTh[0])
+                sprt_delta = H.sprt_delta_new;
+            else
+                sprt_delta = estimateSprtDeltaInit(*cfg.matches, *cfg.keypoints1, *cfg.keypoints2, cfg.th_pixels, cfg.imgSize);
+        } else
+            sprt_delta = H.delta_mean;
+    }
+    if (want_eps) {
+        if (H.sprt_epsilon_old == 0 || H.sprt_epsilon_new == 0) {
+            sprt_epsilon = estimateSprtEpsilonInit(*cfg.matches, cfg.nrMatchesVfcFiltered);
+            H.sprt_epsilon_new = sprt_epsilon;
+        } else if (!H.statistic_valid || (H.epsilon_std > statStdDivTh[1]) ||
+                   ((H.epsilon_mean > ignoreRelDiffATSTh[1]) && (H.epsilon_std > relDiffArithToStd * H.epsilon_mean))) {
+            if (std::abs((H.sprt_epsilon_old - H.sprt_epsilon_new) / H.sprt_epsilon_old) < relativeDifferenceTh[1])
+                sprt_epsilon = H.sprt_epsilon_new;
+            else
+                sprt_epsilon = estimateSprtEpsilonInit(*cfg.matches, cfg.nrMatchesVfcFiltered);
+        } else
+            sprt_epsilon = H.epsilon_mean;
+    }
+    if (!cfg.noAutomaticProsacParamters) prosac_beta = sprt_delta;
+    std::vector<unsigned int> sortedMatchIdx;
+    if (cfg.matches) getSortedMatchIdx(*cfg.matches, sortedMatchIdx);
+    if (cfg.degeneracyCheck != DEGEN_NO_CHECK && cfg.degeneracyCheck != DEGEN_QDEGSAC && cfg.degeneracyCheck != DEGEN_USAC_INTERNAL) {
+        std::cout << "Mothod for checking degeneracy not available!" << std::endl;
+        return -1;
+    }
+    if (cfg.degeneracyCheck != DEGEN_NO_CHECK)
+        std::call_once(g_usac_notice[2], [] { std::cout << "USAC (MI355X hot-path library): the degeneracy tests are not built; the estimation runs without them." << std::endl; });
+
+    // estimateEssentialMatUsac (usac_estimations.cpp:283-470)
+    mlpl_usac_params P;
+    mlpl_usac_default_params(&P, th);
+    P.estimator = estimator, P.refine = 0;
+    P.seed = g_seed_fixed ? g_seed : (unsigned)std::time(nullptr);
+    P.prosac_beta = prosac_beta, P.sprt_delta = sprt_delta, P.sprt_epsilon = sprt_epsilon;
+    if (H.numhyps == 0 || H.modelcount == 0)
+        P.sprt_mS = estimator == 0 ? 8.5 : H.avgModels;
+    else {
+        H.avgModels = (double)H.modelcount / (double)H.numhyps;
+        P.sprt_mS = H.avgModels;
+    }
+    P.sprt_tM = cfg.estimator == POSE_STEWENIUS ? 2736.0 : 2314.0;
+    P.sorted_idx = sortedMatchIdx.empty() ? nullptr : sortedMatchIdx.data();
+    std::vector<double> a((size_t)n * 2), b((size_t)n * 2);
+    for (int i = 0; i < n; ++i) {
+        a[2 * i] = p1.at<double>(i, 0), a[2 * i + 1] = p1.at<double>(i, 1);
+        b[2 * i] = p2.at<double>(i, 0), b[2 * i + 1] = p2.at<double>(i, 1);
+    }
+    double Ev[9], res[12];
+    std::vector<uint8_t> m((size_t)std::max(n, 1));
+    const int rc = mlpl_usac_essential(default_ctx(), a.data(), b.data(), n, &P, Ev, m.data(), res);
+    if (rc == MLPL_E_FAILED) {
+        std::cout << "USAC failed!" << std::endl;
+        return -2;
+    }
+    if (rc != MLPL_OK) throw cv::Exception(std::string("estimateEssentialOrPoseUSAC: ") + mlpl_last_error());
+    H.numhyps += (unsigned)res[1];
+    H.modelcount += (unsigned)res[2];
+    const double sprt_epsilon_res = (res[1] > 2000 && res[9] > 0.2) ? res[9] / 2.0 : res[9];  // :460-467
+    const double sprt_delta_res = res[8];
+    if (E.needed()) {
+        E.create(3, 3, CV_64F);
+        cv::Mat Em = E.getMat();
+        for (int i = 0; i < 9; ++i) Em.at<double>(i / 3, i % 3) = Ev[i];
+    }
+    if (inliers.needed()) {
+        inliers.create(1, n, CV_8U);
+        cv::Mat mm = inliers.getMat();
+        std::memcpy(mm.ptr<uint8_t>(0), m.data(), (size_t)n);
+    }
+    isDegenerate = false;
+    if (R.needed()) R.release();  // :2036-2042: only Kneip's eigensolver delivers R, t
+    if (t.needed()) t.release();
+    (void)R_degenerate, (void)inliers_degenerate_R;
+
+    // the carried-over statistics (:2201-2224)
+    H.sprt_delta_old = H.sprt_delta_new;
+    H.sprt_delta_new = sprt_delta_res;
+    H.sprt_epsilon_old = H.sprt_epsilon_new;
+    H.sprt_epsilon_new = sprt_epsilon_res;
+    if (!usac_near_zero(sprt_delta_res) && !usac_near_zero(sprt_epsilon_res)) {
+        H.delta_history[H.historyCnt] = sprt_delta_res;
+        H.epsilon_history[H.historyCnt] = sprt_epsilon_res;
+        H.historyCnt = (H.historyCnt + 1) % 20;
+        if (H.historyCnt == 0) H.historyBufFull = true;
+        const int cnt = H.historyBufFull ? 20 : (H.historyCnt > 5 ? H.historyCnt : 0);
+        if (cnt) {
+            usac_history_stats(std::vector<double>(H.delta_history, H.delta_history + cnt), &H.delta_mean, &H.delta_std);
+            usac_history_stats(std::vector<double>(H.epsilon_history, H.epsilon_history + cnt), &H.epsilon_mean, &H.epsilon_std);
+            if (!H.historyBufFull) H.statistic_valid = true;
+        }
+    }
+    return 0;
 }
 
 // ---- AutoThEpi (pose_estim.cpp:81-300) ------------------------------------------------------------------------------------------------
@@ -265,6 +491,10 @@ FullStats fullStatsFromVec(const std::vector<double> &vals, bool rejQuartiles, b
     const double hlp = sum2 - (double)n * st.arithErr * st.arithErr;
     st.arithStd = (roundStd && std::abs(hlp) < 1e-6) ? 0.0 : std::sqrt(hlp / ((double)n - 1.0));
     return st;
+}
+void usac_history_stats(const std::vector<double> &vals, double *mean, double *stddev) {
+    const FullStats st = fullStatsFromVec(vals, true);
+    *mean = st.arithErr, *stddev = st.arithStd;
 }
 }  // namespace
 

@@ -330,8 +330,8 @@ int StereoRefine::Impl::robustPoseEstimation() {
     have_Q = false;
     Qv.clear();
     std::string method = cfg_pose.RobMethod;
-    if (cfg_pose.Halign || (method == "USAC" && !cfg_pose.autoTH)) {
-        std::cout << "StereoRefine (MI355X hot-path library): Halign and RobMethod USAC are not built." << std::endl;
+    if (cfg_pose.Halign) {
+        std::cout << "StereoRefine (MI355X hot-path library): Halign is not built." << std::endl;
         return -1;
     }
     const int n = (int)(p1new.size() / 2);
@@ -350,6 +350,17 @@ int StereoRefine::Impl::robustPoseEstimation() {
             return -1;
         }
         std::cout << "Estimated threshold: " << th / pixToCamFact << " pixels" << std::endl;
+    } else if (method == "USAC") {
+        // :1355-1413: the harness default.  cfg_usac.matches / keypoints describe the correspondences the estimation runs on (the new
+        // pair, or the pool: robustEstimationOnPool)
+        bool isDegenerate = false;
+        cv::Mat R_degenerate, inliers_degenerate_R;
+        if (estimateEssentialOrPoseUSAC(P1, P2, E, th, cfg_usac, isDegenerate, mask, R_degenerate, inliers_degenerate_R, cv::noArray(),
+                                        cv::noArray(), verbose) != 0) {
+            std::cout << "Estimation of essential matrix using USAC failed!" << std::endl;
+            return -1;
+        }
+        if (isDegenerate) return -2;  // (:1400-1411; the degeneracy tests are not built: never taken)
     } else if (!estimateEssentialMat(E, P1, P2, method, th, cfg_pose.refineRTold, mask)) {
         std::cout << "Estimation of essential matrix using " << method << " failed!" << std::endl;
         return -1;
@@ -415,11 +426,28 @@ bool StereoRefine::Impl::reinitializeSystem(double &inlier_ratio, std::vector<cv
 }
 
 int StereoRefine::Impl::robustEstimationOnPool() {  // :1075-1128: the robust estimator runs on the pool coordinates
+    // USAC's PROSAC order and SPRT start values come from matches / keypoints: rebuilt from the pool (:1080-1102), restored afterwards
+    const ConfigUSAC saved = cfg_usac;
+    const size_t ps = correspondencePool.size();
+    std::vector<cv::DMatch> pool_matches(ps);
+    std::vector<cv::KeyPoint> kp1_tmp(ps), kp2_tmp(ps);
+    if (cfg_pose.RobMethod == "USAC") {
+        size_t i = 0;
+        for (const CoordinateProps &c : correspondencePool) {
+            pool_matches[i].queryIdx = pool_matches[i].trainIdx = (int)i, pool_matches[i].imgIdx = -1, pool_matches[i].distance = c.descrDist;
+            kp1_tmp[i].pt = c.pt1, kp1_tmp[i].size = 10.f, kp1_tmp[i].angle = -1.f, kp1_tmp[i].response = c.keyPResponses[0];
+            kp2_tmp[i].pt = c.pt2, kp2_tmp[i].size = 10.f, kp2_tmp[i].angle = -1.f, kp2_tmp[i].response = c.keyPResponses[1];
+            ++i;
+        }
+        cfg_usac.matches = &pool_matches, cfg_usac.keypoints1 = &kp1_tmp, cfg_usac.keypoints2 = &kp2_tmp;
+        cfg_usac.nrMatchesVfcFiltered = ps > UINT_MAX ? UINT_MAX : (unsigned int)ps;
+    }
     std::swap(p1Cam, p1new);
     std::swap(p2Cam, p2new);
     const int rc = robustPoseEstimation();
     std::swap(p1Cam, p1new);
     std::swap(p2Cam, p2new);
+    cfg_usac = saved;
     return rc ? -1 : 0;
 }
 
@@ -1010,6 +1038,9 @@ int StereoRefine::Impl::checkPoseStability() {  // :3131-3298
 int StereoRefine::Impl::addNewCorrespondences(std::vector<cv::DMatch> &matches, std::vector<cv::KeyPoint> &kp1,
                                               std::vector<cv::KeyPoint> &kp2, const ConfigUSAC &cfg) {
     cfg_usac = cfg;
+    // the caller's pointers describe the matches of this call (tests/poselib-test/main.cpp:1944-1957); the by-value copies this function
+    // works on are the same data and stay alive for the whole call, where the reference re-points cfg_usac.matches at them (:625-649)
+    if (cfg.matches) cfg_usac.matches = &matches, cfg_usac.keypoints1 = &kp1, cfg_usac.keypoints2 = &kp2;
     nr_corrs_new = matches.size();
     const int n0 = (int)nr_corrs_new;
     std::vector<float> a((size_t)n0 * 2), b((size_t)n0 * 2);

@@ -115,6 +115,7 @@ struct mlpl_ctx {
     double *usac_trace;                                // diagnostics: host buffer for the decision records of USAC (16 doubles each)
     int usac_trace_cap, usac_trace_len;
     long long last_usac_stats[8];
+    int opt_arrsac_flag_points;                        // tests: correspondences every ARRSAC model is tested on up front (0 = 1024)
     int opt_usac_lo_stepwise;                          // tests: every step of a local-optimisation chain goes through the resume path
     // optional per-kernel hipEvent bracketing (mlpl_profile_*)
     int prof_on;

@@ -160,6 +160,44 @@ int main(int argc, char **argv) {
         fwrite(&ng, 4, 1, o);
         fwrite(rca == 0 ? (const void *)Eat.data : (const void *)zero, 8, 9, o);
     }
+    // estimateEssentialOrPoseUSAC (pose_estim.h:212-223), twice: the second call starts its sequential test from what the first one handed
+    // back (function-local statics in the reference); then StereoRefine with the harness' default RobMethod
+    {
+        for (int i = 0; i < n; ++i) mm[i].distance = (float)((i * 7919) % n) + 0.5f;   // distinct matching costs: a definite PROSAC order
+        poselib::resetUsacHistory();
+        poselib::ConfigUSAC cu;
+        cu.focalLength = 800.0, cu.th_pixels = 0.8;
+        cu.degeneracyCheck = poselib::UsacChkDegenType::DEGEN_NO_CHECK;
+        cu.estimator = poselib::PoseEstimator::POSE_NISTER;
+        cu.refinealg = poselib::RefineAlg::REF_WEIGHTS;
+        cu.automaticSprtInit = poselib::SprtInit::SPRT_DELTA_AUTOM_INIT | poselib::SprtInit::SPRT_EPSILON_AUTOM_INIT;
+        cu.imgSize = cv::Size(640, 480);
+        cu.matches = &mm, cu.keypoints1 = &a, cu.keypoints2 = &b;
+        cu.nrMatchesVfcFiltered = (unsigned)(n / 2);
+        for (int call = 0; call < 2; ++call) {
+            poselib::setRansacSeed(seed + 1 + call);
+            cv::Mat Eu, inl;
+            bool degenerate = true;
+            int32_t rcu = poselib::estimateEssentialOrPoseUSAC(p1, p2, Eu, th, cu, degenerate, inl);
+            int32_t deg = degenerate ? 1 : 0;
+            fwrite(&rcu, 4, 1, o);
+            fwrite(&deg, 4, 1, o);
+            fwrite(rcu == 0 ? (const void *)Eu.data : (const void *)zero, 8, 9, o);
+            std::vector<uint8_t> mu((size_t)n, 0);
+            if (rcu == 0) std::memcpy(mu.data(), inl.data, (size_t)n);
+            fwrite(mu.data(), 1, (size_t)n, o);
+        }
+        poselib::resetUsacHistory();
+        poselib::ConfigPoseEstimation cfg2 = cfg;
+        cfg2.RobMethod = "USAC";
+        poselib::StereoRefine sr2(cfg2);
+        poselib::setRansacSeed(seed + 3);
+        int32_t rc2 = sr2.addNewCorrespondences(mm, a, b, cu);
+        int32_t inl2 = (int32_t)sr2.nrInliersNew();
+        fwrite(&rc2, 4, 1, o);
+        fwrite(rc2 == 0 ? (const void *)sr2.E_new.data : (const void *)zero, 8, 9, o);
+        fwrite(&inl2, 4, 1, o);
+    }
     fclose(o);
     return 0;
 }

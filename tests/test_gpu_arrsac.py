@@ -241,3 +241,28 @@ def test_arrsac_estimators_on_single_samples(ctx, oracle):
                 assert vg[0] == oracle.valid_model(p1[idx], p2[idx], F)
     finally:
         ctx.set_option("solver_polish", 1)
+
+
+def test_arrsac_preemptive_stage_past_the_up_front_rows(ctx, oracle):
+    """Inlier ratios above ~0.9: the preemptive stage takes its GENERATION branch (k grows, nothing halves) and can walk past the 1024
+    correspondences every hypothesis is tested on up front (the reference keeps going there); the survivors' remaining bits are then
+    computed on demand (arrsac_extend_kernel).  Scenes that get past 1024 are rare (none in 1500 tried: the longest stage ended at 819),
+    so the test lowers the up-front row length to 256 and 128 (option arrsac_flag_points) on scenes whose stage ends at 419..819:
+    statistics (stats[6] = where the stage ended), stream positions, inlier counts and masks equal to the oracle's, refinement on and off."""
+    past = 0
+    try:
+        for frac, noise, seed in ((0.9808375976373475, 0.3, 1218), (0.9937940121440533, 0.3, 1743), (0.9953357108295809, 0.01, 3073),
+                                  (0.9948514566031564, 0.05, 3193), (0.9881629620106517, 1.5, 1010), (0.9942391333394867, 0.02, 3152)):
+            p1, p2, R, t, truth, th = synth.pose_scene(2500, frac, seed=seed, noise_px=noise)
+            for refine in (False, True):
+                o = oracle.arrsac_essential(p1, p2, th, refine=refine)
+                for fp in (256, 128, 0):
+                    ctx.set_option("arrsac_flag_points", fp)
+                    st_g = np.array(pose.ARRSAC_RNG_FRESH, np.uint64)
+                    g = pose.arrsac_essential(p1, p2, th, refine=refine, rng_state=st_g, ctx=ctx)
+                    assert g["ok"] == o["ok"] and g["stats"][:8].tolist() == o["stats"].tolist(), (frac, noise, fp, g["stats"], o["stats"])
+                    assert st_g.tolist() == o["rng_state"].tolist() and g["n_inliers"] == o["n_inliers"] and np.array_equal(g["mask"], o["mask"])
+                past += int(o["stats"][6] >= 256)
+    finally:
+        ctx.set_option("arrsac_flag_points", 0)
+    assert past >= 8, past      # the scenes do run past the shortened rows

@@ -101,3 +101,47 @@ def test_cpp_facade_end_to_end(oracle, tmp_path):
     assert rca == rc_o == 0 and nga == ng_o and abs(tha - th_o) < 1e-9 * th_o, (rca, rc_o, nga, ng_o, tha, th_o)
     a, b = Eat / np.linalg.norm(Eat), E_o / np.linalg.norm(E_o)
     assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 2e-5
+
+    # estimateEssentialOrPoseUSAC: PROSAC in the order of the matching costs, delta from the convex hulls of the keypoints, epsilon from
+    # the share of matches a flow filter kept; the second call starts from the delta / epsilon the first one handed back
+    from scipy.spatial import ConvexHull
+    n = len(p1)
+    dist = (np.arange(n) * 7919 % n).astype(np.float32) + 0.5
+    order = np.argsort(dist, kind="stable").astype(np.uint32)
+    kpa = (p1 * 800 + np.array([320, 240])).astype(np.float32)
+    kpb = (p2 * 800 + np.array([320, 240])).astype(np.float32)
+    area = min(ConvexHull(kpa.astype(np.float64)).volume, ConvexHull(kpb.astype(np.float64)).volume)
+    max_epi = np.sqrt(640.0 ** 2 + 480.0 ** 2) * 2 * 0.8
+    delta0 = max(max_epi / max(area, 6 * max_epi), 0.001)
+    eps0 = min(max(0.8 * (n // 2) / n, 0.1), 0.4)
+    d_old, d_new, e_old, e_new, numhyps, models = 0.0, delta0, 0.0, eps0, 0, 0
+    for call in range(2):
+        rcu, deg = take(np.int32, 2)
+        Eu = take(np.float64, 9)
+        mu = take(np.uint8, n)
+        if call == 0:
+            delta, eps, ms = delta0, eps0, 8.5
+        else:   # pose_estim.cpp:1812-1875: no valid statistic yet -> the last result if it moved by less than 33 % / 40 %, else a new estimate
+            delta = d_new if abs((d_old - d_new) / d_old) < 0.33 else delta0
+            eps = e_new if abs((e_old - e_new) / e_old) < 0.4 else eps0
+            ms = models / numhyps
+        o5 = oracle.usac_essential(p1, p2, th, seed + 1 + call, sorted_idx=order, prosac_beta=delta, sprt_delta=delta, sprt_epsilon=eps,
+                                   sprt_ms=ms)
+        assert rcu == 0 and deg == 0 and o5["ok"]
+        assert np.array_equal(mu, o5["flags"]), (call, int((mu != o5["flags"]).sum()))
+        a5, b5 = Eu / np.linalg.norm(Eu), o5["E"] / np.linalg.norm(o5["E"])
+        assert min(np.abs(a5 - b5).max(), np.abs(a5 + b5).max()) < 1e-8
+        numhyps, models = numhyps + int(o5["final"][1]), models + int(o5["final"][2])
+        e_res = o5["final"][9] / 2 if (o5["final"][1] > 2000 and o5["final"][9] > 0.2) else o5["final"][9]
+        d_old, d_new, e_old, e_new = d_new, o5["final"][8], e_new, e_res
+    # StereoRefine with RobMethod = "USAC" (the harness default): first call = robust initialisation on float-rounded camera coordinates
+    rc2 = take(np.int32, 1)[0]
+    E2 = take(np.float64, 9)
+    inl2 = take(np.int32, 1)[0]
+    area2 = min(ConvexHull(kpa.astype(np.float64)).volume, ConvexHull(kpb.astype(np.float64)).volume)
+    o6 = oracle.usac_essential(q1, q2, 0.8 * synth.PIX_TO_CAM, seed + 3, sorted_idx=order, prosac_beta=delta0, sprt_delta=delta0,
+                               sprt_epsilon=eps0, sprt_ms=8.5)   # resetUsacHistory() also forgets the models-per-sample average
+    assert rc2 == 0 and area2 == area
+    assert inl2 == int(o6["flags"].sum())
+    a6, b6 = E2 / np.linalg.norm(E2), o6["E"] / np.linalg.norm(o6["E"])
+    assert min(np.abs(a6 - b6).max(), np.abs(a6 + b6).max()) < 1e-8
