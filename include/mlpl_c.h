@@ -335,6 +335,21 @@ int mlpl_pair_pose_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, const uint8_t 
                        const float *d_kp2, const double K0[4], const double K1[4], double thresh, int max_iters, double confidence,
                        int refit, uint32_t seed, double dist, mlpl_pair_result *out, void *stream);
 
+/*
+ * A BATCH of image pairs through the same pipeline with the pair as a grid dimension of every launch (the reference harness loop over
+ * image pairs, tests/poselib-test/main.cpp:1440-2072; BASELINE config 5): d_q / d_t / d_kp1 / d_kp2 hold n_pairs contiguous items
+ * ([n_pairs][nq][nbytes], [n_pairs][nt][nbytes], [n_pairs][nq][2], [n_pairs][nt][2]), seeds[n_pairs] and out[n_pairs] are HOST arrays.
+ * Every pair's record equals what mlpl_pair_pose_dev returns for it with the same seed.  Host hops per internal batch of 128 pairs
+ * (option "pair_batch"): the match counts, one per RANSAC pass (the first 324 iterations of every pair, then the rest for the pairs
+ * the adaptive bound has not stopped), the results.  refit != 0 runs the pairs one by one through mlpl_pair_pose_dev.
+ */
+int mlpl_pair_pose_batch_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
+                             const float *d_kp2, const double K0[4], const double K1[4], double thresh, int max_iters, double confidence,
+                             int refit, const uint32_t *seeds, double dist, mlpl_pair_result *out, void *stream);
+/* Statistics of the last mlpl_pair_pose_batch_dev call: {RANSAC passes, pair slots summed over the passes, pairs redone by the
+ * single-pair pipeline because a device-evaluated iteration bound differed from the host's libm, host microseconds spent drawing the sample tables}. */
+int mlpl_pair_batch_last_stats(mlpl_ctx *ctx, long long stats[4]);
+
 /* Building blocks, exposed for parity tests and for callers that schedule the phases themselves. */
 /* 5-point minimal solver, one wavefront per sample: samples = n_samples x 5 indices into p1/p2 (host).
  * E_out: n_samples x 10 x 9 doubles, n_models: n_samples ints (host). Replaces run5Point (five-point.cpp:366-471). */

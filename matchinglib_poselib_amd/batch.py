@@ -93,6 +93,40 @@ def process_pair_on_device(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, th_pix:
     return rec
 
 
+def process_pairs_batched(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, seeds, th_pix: float = 0.8, max_iters: int = 1000,
+                          confidence: float = 0.999, refit: bool = False, dist: float = 50.0, pair_ids=None) -> np.ndarray:
+    """A batch of image pairs in ONE library call (mlpl_pair_pose_batch_dev): device tensors d_q [B, nq, nbytes] uint8, d_t [B, nt, nbytes],
+    d_kp1 [B, nq, 2] float32, d_kp2 [B, nt, 2]; seeds: B RANSAC seeds.  The pair is a grid dimension of every launch -- no host threads, a
+    handful of host hops per 64 pairs -- and every record equals process_pair_on_device's for that pair.  Returns B RECORD_DTYPE records."""
+    import torch
+
+    B = d_q.shape[0]
+    assert d_q.is_cuda and d_q.dtype == torch.uint8 and d_q.dim() == 3 and d_t.dim() == 3 and d_t.shape[0] == B
+    assert d_kp1.dtype == torch.float32 and d_kp2.dtype == torch.float32 and d_kp1.shape == (B, d_q.shape[1], 2) and d_kp2.shape == (B, d_t.shape[1], 2)
+    assert d_q.is_contiguous() and d_t.is_contiguous() and d_kp1.is_contiguous() and d_kp2.is_contiguous()
+    k0 = (C.c_double * 4)(*K0)
+    k1 = (C.c_double * 4)(*K1)
+    th = th_pix * 4.0 / (np.sqrt(2.0) * (K0[0] + K0[1] + K1[0] + K1[1]))  # stereo_pose_refinement.h:280-286
+    sd = np.ascontiguousarray(np.asarray(seeds, np.int64) & 0xFFFFFFFF, np.uint32)
+    assert len(sd) == B
+    res = (_PairResult * B)()
+    st = torch.cuda.current_stream(d_q.device).cuda_stream
+    check(ctx.lib.mlpl_pair_pose_batch_dev(ctx.handle, B, d_q.data_ptr(), d_q.shape[1], d_t.data_ptr(), d_t.shape[1], d_q.shape[2], d_kp1.data_ptr(),
+                                           d_kp2.data_ptr(), k0, k1, float(th), int(max_iters), float(confidence), 1 if refit else 0, sd.ctypes.data,
+                                           float(dist), C.addressof(res), st), "mlpl_pair_pose_batch_dev")
+    rec = np.zeros(B, RECORD_DTYPE)
+    rec["pair_id"] = np.arange(B) if pair_ids is None else np.asarray(pair_ids)
+    for i in range(B):
+        r = res[i]
+        rec["n_matches"][i], rec["status"][i] = r.n_matches, r.status
+        if r.status == 0:
+            rec["n_inliers"][i] = r.n_inliers
+            rec["E"][i] = np.frombuffer(r.E, np.float64)
+            rec["R"][i] = np.frombuffer(r.R, np.float64)
+            rec["t"][i] = np.frombuffer(r.t, np.float64)
+    return rec
+
+
 class PairWorkers:
     """`workers` independent (library context, torch stream, host thread) triples on one GPU.  One image pair's pipeline
     is latency-bound (a dozen small launches and two host hops), so a rank overlaps several pairs instead of queueing

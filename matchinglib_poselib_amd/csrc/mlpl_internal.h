@@ -115,6 +115,8 @@ struct mlpl_ctx {
     double *usac_trace;                                // diagnostics: host buffer for the decision records of USAC (16 doubles each)
     int usac_trace_cap, usac_trace_len;
     long long last_usac_stats[8];
+    long long last_batch_stats[4];                     // mlpl_pair_pose_batch_dev: {RANSAC passes, pair slots over all passes, pairs redone on a host table, 0}
+    int opt_pair_batch;                                // pairs per internal batch of mlpl_pair_pose_batch_dev (0 = 128)
     int opt_arrsac_flag_points;                        // tests: correspondences every ARRSAC model is tested on up front (0 = 1024)
     int opt_usac_lo_stepwise;                          // tests: every step of a local-optimisation chain goes through the resume path
     // optional per-kernel hipEvent bracketing (mlpl_profile_*)
@@ -160,5 +162,18 @@ int launch_ratio_compact(mlpl_ctx *ctx, const int32_t *d_idx, const void *d_dist
 int launch_gather_match_points(const mlpl_dmatch *d_matches, int n, const float *d_kp1, const float *d_kp2, const double K0[4],
                                const double K1[4], double *d_p1, double *d_p2, hipStream_t s);
 void free_rand_cache(void *p);
+
+// cheirality for a batch of pairs (recover_pose.hip): decomposition, four triangulations, the reference's candidate choice and the mask
+// of the chosen candidate, all on the device; d_out[pair] = {valid 3-D points, candidate (-1 none), R, t}
+struct PairPoseDev {
+    int32_t n_good, pick;
+    double R[9], t[3];
+};
+int launch_recover_pose_batch(const char *d_E_base, size_t E_stride, const double *d_p1, const double *d_p2, const int32_t *d_counts,
+                              const int32_t *d_active, int B, int pair_stride, double dist, uint8_t *d_mask, double *d_P,
+                              uint8_t *d_cand_masks, int32_t *d_cand_counts, PairPoseDev *d_out, hipStream_t s);
+int launch_gather_match_points_batch(const mlpl_dmatch *d_matches, const int32_t *d_counts, int B, int pair_stride, const float *d_kp1,
+                                     size_t kp1_stride, const float *d_kp2, size_t kp2_stride, const double K0[4], const double K1[4],
+                                     double *d_p1, double *d_p2, hipStream_t s);
 
 }  // namespace mlpl

@@ -1,0 +1,242 @@
+// pair_batch_impl.h -- a BATCH of image pairs through the whole hot path with the pair as a grid dimension (BASELINE config 5).
+// Included by ransac_5pt.hip inside namespace mlpl.
+//
+// mlpl_pair_pose_dev runs one pair as ~14 launches and two host hops; its RANSAC half is latency-bound (1000 hypotheses do not fill a
+// quarter of the chip), so a rank had to keep several pairs in flight from host threads.  Here B pairs share every launch:
+//   matching          mlpl_match_hamming_dev(batch = B)                                          (one launch chain, as before)
+//   hop 1             the B match counts (they size the sample tables: getSubset draws rand() % count, modelest.cpp:585)
+//   gather + pack     blockIdx.y = pair
+//   RANSAC passes     the first 324 iterations of EVERY pair as one pass, then the remaining iterations of the pairs the adaptive bound
+//                     has not stopped (the reference's 0.999 / 1000 setting stops a 50 % inlier pair after ~220): solver and root kernels
+//                     over all (pair, hypothesis) samples at once (global point indices: the solver does not know about pairs), a dense
+//                     model list per pair, the counting kernel with blockIdx.z = pair, candidate / replay kernels with one workgroup per
+//                     pair.  One host hop per pass (the B replay states: which pairs go on).
+//   cheirality        decomposition, four triangulations and the reference's candidate choice per pair on the device
+//   last hop          the B results
+// Per pair the kernels are the single-pair kernels with per-slot arguments (PairSlot), so every pair's record is what
+// mlpl_pair_pose_dev returns for it (tests/test_gpu_batch.py: byte-identical E, R, t, counts).
+
+namespace {
+
+constexpr int kBatchFirstPass = 324;   // multiple of kHypPerWave; above the stopping point of pairs with >= ~45 % inliers at 0.999
+constexpr int kBatchPassMax = 1026;    // hypotheses per pair and pass (multiple of kHypPerWave)
+constexpr int kBatchPairsPerCall = 128;  // pairs per internal batch (workspace ~2.6 MB per pair)
+
+}  // namespace
+
+int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
+                        const float *d_kp2, const double K0[4], const double K1[4], double thresh, int max_iters, double confidence,
+                        const uint32_t *seeds, double dist, mlpl_pair_result *out, hipStream_t s) {
+    const int NQ = nq;
+    const size_t n = (size_t)NQ;
+    int rc;
+    // ---- workspace ----
+    const size_t pack_stride4 = (n * (sizeof(double4) + sizeof(double) + 5 * sizeof(float)) + sizeof(double4) - 1) / sizeof(double4);  // per pair, in double4 units
+    const int Hs = kBatchPassMax;  // slot stride of the hypothesis tables
+    const size_t off_idx = 0, off_dist = off_idx + (size_t)B * n * 8, off_match = off_dist + (size_t)B * n * 8,
+                 off_p1 = off_match + (size_t)B * n * 16, off_p2 = off_p1 + (size_t)B * n * 16, off_mask = off_p2 + (size_t)B * n * 16,
+                 off_cmask = (off_mask + (size_t)B * n + 255) / 256 * 256, off_small = (off_cmask + (size_t)B * 4 * n + 255) / 256 * 256;
+    // small block: counts[B] | active[B] | cand_counts[B][4] | states[B] | P[B][69] | pose[B] | slots[B] | dense_total[B] | cand_count[B]
+    const size_t sm_counts = 0, sm_active = sm_counts + (size_t)B * 4, sm_cc = sm_active + (size_t)B * 4, sm_st = (sm_cc + (size_t)B * 16 + 255) / 256 * 256,
+                 sm_P = sm_st + (size_t)B * sizeof(ReplayState), sm_pose = sm_P + (size_t)B * 69 * 8, sm_slots = sm_pose + (size_t)B * sizeof(PairPoseDev),
+                 sm_dt = sm_slots + (size_t)B * sizeof(PairSlot), sm_cnd = sm_dt + (size_t)B * 4, sm_end = sm_cnd + (size_t)B * 4;
+    void *blk = nullptr;
+    if ((rc = ws_get(ctx, WS_PIPE, off_small + sm_end + 256, &blk))) return rc;
+    char *b0 = (char *)blk, *sm = b0 + off_small;
+    mlpl_dmatch *d_m = (mlpl_dmatch *)(b0 + off_match);
+    double *d_p1 = (double *)(b0 + off_p1), *d_p2 = (double *)(b0 + off_p2);
+    uint8_t *d_mask = (uint8_t *)(b0 + off_mask), *d_cmask = (uint8_t *)(b0 + off_cmask);
+    int32_t *d_counts = (int32_t *)(sm + sm_counts), *d_active = (int32_t *)(sm + sm_active), *d_cc = (int32_t *)(sm + sm_cc);
+    ReplayState *d_st = (ReplayState *)(sm + sm_st);
+    double *d_P = (double *)(sm + sm_P);
+    PairPoseDev *d_pose = (PairPoseDev *)(sm + sm_pose);
+    PairSlot *d_slots = (PairSlot *)(sm + sm_slots);
+    int32_t *d_dense_total = (int32_t *)(sm + sm_dt), *d_cand_count = (int32_t *)(sm + sm_cnd);
+    void *p;
+    if ((rc = ws_get(ctx, WS_AUX3, (size_t)B * pack_stride4 * sizeof(double4), &p))) return rc;
+    double4 *d_pack = (double4 *)p;
+    const size_t hyps = (size_t)B * Hs;
+    if ((rc = ws_get(ctx, WS_AUX5, hyps * 90 * 8, &p))) return rc;
+    double *d_Etab = (double *)p;
+    if ((rc = ws_get(ctx, WS_AUX6, hyps * 90 * 8, &p))) return rc;
+    double *d_denseE = (double *)p;
+    if ((rc = ws_get(ctx, WS_PARTIAL, hyps * sizeof(PolyRec), &p))) return rc;
+    PolyRec *d_recs = (PolyRec *)p;
+    // tables: esum[hyps*10] hsum[hyps] | n_models[hyps] dense_id[hyps*10] good[hyps*10] hgood[hyps] hslot[hyps] hmax[hyps] cand[hyps*10]
+    if ((rc = ws_get(ctx, WS_AUX7, hyps * 11 * 8 + hyps * (1 + 10 + 10 + 1 + 1 + 1 + 10) * 4 + 256, &p))) return rc;
+    double *d_esum = (double *)p, *d_hsum = d_esum + hyps * 10;
+    int32_t *d_nm = (int32_t *)(d_hsum + hyps), *d_dense_id = d_nm + hyps, *d_good = d_dense_id + hyps * 10, *d_hgood = d_good + hyps * 10,
+            *d_hslot = d_hgood + hyps, *d_hmax = d_hslot + hyps, *d_cand = d_hmax + hyps;
+    // pinned: counts | states | pose | slots | samples
+    const size_t pin_counts = 0, pin_st = (pin_counts + (size_t)B * 4 + 255) / 256 * 256, pin_pose = pin_st + (size_t)B * sizeof(ReplayState),
+                 pin_slots = pin_pose + (size_t)B * sizeof(PairPoseDev), pin_act = pin_slots + (size_t)B * sizeof(PairSlot),
+                 pin_smp = (pin_act + (size_t)B * 4 + 255) / 256 * 256, pin_end = pin_smp + hyps * 20;
+    void *pin;
+    if ((rc = pinned_get(ctx, pin_end + 256, &pin))) return rc;
+    char *hp = (char *)pin;
+    int32_t *h_counts = (int32_t *)(hp + pin_counts), *h_active = (int32_t *)(hp + pin_act), *h_smp = (int32_t *)(hp + pin_smp);
+    ReplayState *h_st = (ReplayState *)(hp + pin_st);
+    PairPoseDev *h_pose = (PairPoseDev *)(hp + pin_pose);
+    PairSlot *h_slots = (PairSlot *)(hp + pin_slots);
+    int32_t *d_smp_mapped = nullptr;
+    MLPL_HIP_TRY(hipHostGetDevicePointer((void **)&d_smp_mapped, h_smp, 0));
+
+    // ---- matching, all pairs ----
+    rc = mlpl_match_hamming_dev(ctx, d_q, nq, (size_t)nbytes, (size_t)nq * nbytes, d_t, nt, (size_t)nbytes, (size_t)nt * nbytes, nbytes, 1, 0.75f, B,
+                                (int32_t *)(b0 + off_idx), (int32_t *)(b0 + off_dist), d_m, d_counts, s);
+    if (rc) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(h_counts, d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    // the raw glibc streams do not depend on the counts: generate them while the device matches
+    std::vector<RandCache> caches((size_t)B);
+    std::vector<RandCursor> cur;
+    cur.reserve((size_t)B);
+    for (int b = 0; b < B; ++b) {
+        cur.emplace_back(&caches[b], seeds[b], (size_t)0);
+        (void)cur[b].peek(31);
+        const size_t want = (size_t)std::min(max_iters, kBatchFirstPass) * 5 + 64;
+        while (caches[b].raw.size() < want) {
+            caches[b].gen.refill();
+            caches[b].raw.insert(caches[b].raw.end(), caches[b].gen.out, caches[b].gen.out + 31);
+            caches[b].gen.pos = 31;
+        }
+    }
+    MLPL_HIP_TRY(hipStreamSynchronize(s));  // hop 1: the match counts
+    std::vector<int> alive;
+    for (int b = 0; b < B; ++b) {
+        std::memset(&out[b], 0, sizeof(out[b]));
+        out[b].n_matches = h_counts[b];
+        h_active[b] = h_counts[b] >= 16 ? 1 : 0;  // below the reference's working minimum (Remove_LensDist / StereoRefine refuse fewer than 16)
+        if (h_active[b]) alive.push_back(b);
+        else out[b].status = -1;
+    }
+    if (alive.empty()) return MLPL_OK;
+    MLPL_HIP_TRY(hipMemcpyAsync(d_active, h_active, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    if ((rc = launch_gather_match_points_batch(d_m, d_counts, B, NQ, d_kp1, (size_t)nq * 2, d_kp2, (size_t)nt * 2, K0, K1, d_p1, d_p2, s))) return rc;
+    hipLaunchKernelGGL(pack_points_kernel, dim3((NQ + 255) / 256, B), dim3(256), 0, s, (const double *)d_p1, (const double *)d_p2, 0, d_pack, d_st, max_iters,
+                       (int32_t *)nullptr, 0, (const int32_t *)d_counts, NQ, pack_stride4);
+
+    const double thresh2 = thresh * thresh, qmax = inlier_bound(thresh2);
+    const double log_num = std::log(std::max(1. - std::min(std::max(confidence, 0.), 1.), DBL_MIN));
+    const int ev_cap = ctx->opt_ransac_event_cap > 0 ? std::min(ctx->opt_ransac_event_cap, kMaxScanEvents) : kMaxScanEvents;
+    std::vector<ReplayState> state((size_t)B);
+    for (int b : alive) {
+        std::memset(&state[b], 0, sizeof(ReplayState));
+        state[b].niters = max_iters;
+    }
+    int max_n = 0;
+    for (int b : alive) max_n = std::max(max_n, h_counts[b]);
+    int base = 0;
+    bool first_pass = true;
+    long long passes = 0, slots_total = 0, draw_us = 0;
+    while (!alive.empty() && base < max_iters) {
+        const int A = (int)alive.size();
+        const int H = std::min(first_pass ? kBatchFirstPass : kBatchPassMax, max_iters - base);
+        const int Hp = (H + kHypPerWave - 1) / kHypPerWave * kHypPerWave;  // slot stride of this pass: hypotheses beyond a slot's count are padding (no models)
+        if (!first_pass) MLPL_HIP_TRY(hipStreamSynchronize(s));           // the pinned sample / slot tables are rewritten
+        const auto t_draw0 = std::chrono::steady_clock::now();
+        for (int a = 0; a < A; ++a) {
+            const int b = alive[a];
+            const int cnt = std::min(H, std::min(max_iters, state[b].niters) - base);
+            PairSlot &S = h_slots[a];
+            S.pts = d_pack + (size_t)b * pack_stride4, S.n = h_counts[b], S.pair = b, S.cnt = cnt, S.iter_base = base;
+            const FastMod fm(h_counts[b]);
+            int32_t *row = h_smp + (size_t)a * Hp * 5;
+            for (int i = 0; i < cnt; ++i) {
+                draw_sample(cur[b], fm, row + (size_t)i * 5);
+                for (int k = 0; k < 5; ++k) row[(size_t)i * 5 + k] += b * NQ;  // global point index: the solver does not know about pairs
+            }
+            // (rows cnt .. Hp - 1 are padding: the solver writes "no models" for them without reading the row)
+        }
+        draw_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_draw0).count();
+        MLPL_HIP_TRY(hipMemcpyAsync(d_slots, h_slots, (size_t)A * sizeof(PairSlot), hipMemcpyHostToDevice, s));
+        MLPL_HIP_TRY(hipMemsetAsync(d_dense_total, 0, (size_t)A * 4, s));
+        const int total_hyps = A * Hp;
+        hipLaunchKernelGGL(solve5pt_kernel, dim3(total_hyps), dim3(64), 0, s, (const double *)d_p1, (const double *)d_p2, (const int32_t *)d_smp_mapped, 0,
+                           total_hyps, d_recs, (const PairSlot *)d_slots, Hp);
+        MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3(total_hyps / kHypPerWave), s, (const PolyRec *)d_recs, 0, total_hyps, d_Etab, d_nm, d_denseE,
+                          d_dense_id, d_dense_total, d_good, Hp);
+        // inlier counts: blockIdx.z = slot, the slot's dense model list against the slot's pair
+        {
+            const int point_splits = std::max(1, std::min(8, ((max_n + kScoreTile - 1) / kScoreTile) / 2));
+            const dim3 grid((Hp * 10 + kScoreModels - 1) / kScoreModels, point_splits, A);
+            hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile>), grid, dim3(kScoreThreads), 0, s, (const double4 *)nullptr, 0,
+                               (const double *)d_denseE, (const int32_t *)d_dense_id, (const int32_t *)d_dense_total, 0, thresh2, qmax, d_good,
+                               (const PairSlot *)d_slots, Hp);
+        }
+        hipLaunchKernelGGL(hyp_max_kernel, dim3((total_hyps + 255) / 256), dim3(256), 0, s, (const int32_t *)d_nm, (const int32_t *)d_good, total_hyps,
+                           d_hmax);
+        hipLaunchKernelGGL(candidate_kernel, dim3(A), dim3(1024), 0, s, (const int32_t *)d_nm, (const int32_t *)d_good, (const int32_t *)d_hmax, 0, 0,
+                           d_cand, d_cand_count, ev_cap, (const PairSlot *)d_slots, Hp, (const ReplayState *)d_st);
+        hipLaunchKernelGGL((score_models_block_kernel<false, true>), dim3(8, A), dim3(1024), (size_t)((max_n + 3) / 4 * 4) * sizeof(float), s,
+                           (const double4 *)nullptr, 0, (const double *)d_Etab, (const int32_t *)nullptr, (const int32_t *)d_cand_count, 0, thresh2, qmax,
+                           (int32_t *)nullptr, d_esum, (const int32_t *)d_cand, (const PairSlot *)d_slots, Hp);
+        hipLaunchKernelGGL(hyp_best_kernel, dim3((total_hyps + 255) / 256), dim3(256), 0, s, (const int32_t *)d_nm, (const int32_t *)d_good,
+                           (const double *)d_esum, total_hyps, d_hgood, d_hsum, d_hslot);
+        hipLaunchKernelGGL(replay_kernel, dim3(A), dim3(1024), 0, s, (const int32_t *)d_hgood, (const double *)d_hsum, (const int32_t *)d_hslot,
+                           (const double *)d_Etab, 0, (const int32_t *)nullptr, 0, 0ll, (const int32_t *)d_dense_total, d_st, log_num, ev_cap,
+                           (const PairSlot *)d_slots, Hp);
+        MLPL_HIP_TRY(hipGetLastError());
+        MLPL_HIP_TRY(hipMemcpyAsync(h_st, d_st, (size_t)B * sizeof(ReplayState), hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipStreamSynchronize(s));  // one hop per pass: which pairs go on
+        passes++, slots_total += A;
+        base += H;
+        std::vector<int> next;
+        for (int b : alive) {
+            state[b] = h_st[b];
+            if (!state[b].stop && base < std::min(max_iters, state[b].niters)) next.push_back(b);
+        }
+        alive.swap(next);
+        first_pass = false;
+    }
+    // every device-evaluated iteration bound must be what the CPU path's libm gives (see mlpl_ransac_essential_dev); a pair whose bound
+    // differs (probability ~1e-8 per value) is redone by the single-pair driver on a host table
+    std::vector<int> redo;
+    for (int b = 0; b < B; ++b) {
+        if (!h_active[b]) continue;
+        const ReplayState &fin = state[b];
+        bool ok = fin.t_count <= kTUsedMax;
+        for (int i = 0; ok && i < fin.t_count; ++i)
+            ok = fin.t_val[i] == update_num_iters(confidence, (double)(h_counts[b] - fin.t_g[i]) / h_counts[b], 5, INT32_MAX);
+        if (!ok) redo.push_back(b);
+    }
+    // masks of the models held, cheirality, results
+    {
+        std::vector<int> act;
+        for (int b = 0; b < B; ++b)
+            if (h_active[b] && state[b].maxGood > 0) act.push_back(b);
+        for (int b = 0; b < B; ++b)
+            if (h_active[b] && state[b].maxGood <= 0) h_active[b] = 0, out[b].status = -2, out[b].iters = state[b].iter;
+        if (!act.empty()) {
+            MLPL_HIP_TRY(hipStreamSynchronize(s));
+            for (size_t a = 0; a < act.size(); ++a) {
+                const int b = act[a];
+                PairSlot &S = h_slots[a];
+                S.pts = d_pack + (size_t)b * pack_stride4, S.n = h_counts[b], S.pair = b, S.cnt = 0, S.iter_base = 0;
+            }
+            MLPL_HIP_TRY(hipMemcpyAsync(d_slots, h_slots, act.size() * sizeof(PairSlot), hipMemcpyHostToDevice, s));
+            MLPL_HIP_TRY(hipMemcpyAsync(d_active, h_active, (size_t)B * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(inlier_mask_kernel, dim3((max_n + 255) / 256, (unsigned)act.size()), dim3(256), 0, s, (const double4 *)nullptr, 0,
+                               (const double *)nullptr, thresh2, d_mask, (const PairSlot *)d_slots, (const ReplayState *)d_st, NQ);
+            if ((rc = launch_recover_pose_batch((const char *)d_st + offsetof(ReplayState, E), sizeof(ReplayState), d_p1, d_p2, d_counts, d_active, B, NQ,
+                                                dist, d_mask, d_P, d_cmask, d_cc, d_pose, s)))
+                return rc;
+            MLPL_HIP_TRY(hipMemcpyAsync(h_pose, d_pose, (size_t)B * sizeof(PairPoseDev), hipMemcpyDeviceToHost, s));
+            MLPL_HIP_TRY(hipStreamSynchronize(s));  // last hop
+            for (int b : act) {
+                mlpl_pair_result &o = out[b];
+                o.status = 0, o.iters = state[b].iter, o.n_inliers = state[b].maxGood, o.n_good = h_pose[b].n_good;
+                std::memcpy(o.E, state[b].E, 72), std::memcpy(o.R, h_pose[b].R, 72), std::memcpy(o.t, h_pose[b].t, 24);
+            }
+        }
+    }
+    ctx->last_batch_stats[0] = passes, ctx->last_batch_stats[1] = slots_total, ctx->last_batch_stats[2] = (long long)redo.size(), ctx->last_batch_stats[3] = draw_us;
+    // the rare pairs whose iteration bound has to come from the host table: the single-pair pipeline on their inputs
+    for (int b : redo) {
+        ctx->ransac_force_table = 1;
+        rc = mlpl_pair_pose_dev(ctx, d_q + (size_t)b * nq * nbytes, nq, d_t + (size_t)b * nt * nbytes, nt, nbytes, d_kp1 + (size_t)b * nq * 2,
+                                d_kp2 + (size_t)b * nt * 2, K0, K1, thresh, max_iters, confidence, 0, seeds[b], dist, &out[b], s);
+        ctx->ransac_force_table = 0;
+        if (rc) return rc;
+    }
+    return MLPL_OK;
+}

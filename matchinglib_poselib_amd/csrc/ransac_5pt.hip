@@ -33,6 +33,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstring>
@@ -160,6 +161,17 @@ __device__ __forceinline__ void null_vector_3x3(const double *a, double *nv) {
 // essential matrices.  Returns (per lane) whether this lane holds a valid model in Eout[9].
 // ---------------------------------------------------------------------------------------------------------------
 __device__ int g_dk_iters_dbg[4] = {0, 0, 0, 0};  // [sum, count, max, enabled] -- diagnostics only (tools/)
+
+// Batched passes (pair_batch_impl.h: many image pairs per launch): one record per ACTIVE slot of a pass.  The hypothesis tables of slot a
+// start at a * slot_stride; kernels that take `const PairSlot *ps` pick their per-pair arguments from ps[slot] (ps == nullptr: the
+// single-pair form, arguments as passed).
+struct PairSlot {
+    const double4 *pts;  // packed correspondences of the pair (pack_points_kernel layout for ITS n)
+    int32_t n;           // correspondences
+    int32_t pair;        // index of the pair in the batch (replay state, mask)
+    int32_t cnt;         // hypotheses of this pass
+    int32_t iter_base;   // iterations of earlier passes
+};
 
 // What the per-hypothesis wave hands to the root-finding kernel: the degree-10 polynomial, B(z) and the null-space basis.
 struct PolyRec {
@@ -500,7 +512,7 @@ template <bool kPolish>  // compile-time: the polished instance does not carry t
 __global__ __launch_bounds__(64) void roots_kernel_t(const PolyRec *__restrict__ recs, int sample_offset, int n_samples,
                                                    double *__restrict__ E_tab, int32_t *__restrict__ n_models,
                                                    double *__restrict__ dense_E, int32_t *__restrict__ dense_id,
-                                                   int32_t *__restrict__ dense_total, int32_t *__restrict__ good_zero) {
+                                                   int32_t *__restrict__ dense_total, int32_t *__restrict__ good_zero, int slot_stride = 0) {
     constexpr bool polish = kPolish;
     __shared__ double R[kHypPerWave][88];
     __shared__ double rr[64], ri[64];
@@ -508,6 +520,12 @@ __global__ __launch_bounds__(64) void roots_kernel_t(const PolyRec *__restrict__
     const int lane = threadIdx.x;
     const int h = lane / 10, r = lane - h * 10;
     const int sample0 = sample_offset + blockIdx.x * kHypPerWave;
+    if (slot_stride) {  // batched pass: a dense model list per slot (slot_stride is a multiple of kHypPerWave: a wave never straddles slots)
+        const int a = sample0 / slot_stride;
+        dense_total += a;
+        dense_E += (size_t)a * slot_stride * 90;
+        dense_id += (size_t)a * slot_stride * 10;
+    }
     // cooperative load of the six records
     for (int i = lane; i < kHypPerWave * 88; i += 64) {
         const int hh = i / 88, k = i - hh * 88;
@@ -759,12 +777,20 @@ __device__ __forceinline__ void householder_basis(SolveLds &L, int lane) {
 
 __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
                                                       const int32_t *__restrict__ samples, int sample_offset, int n_samples,
-                                                      PolyRec *__restrict__ recs /* indexed from sample_offset */) {
+                                                      PolyRec *__restrict__ recs /* indexed from sample_offset */,
+                                                      const PairSlot *__restrict__ ps = nullptr, int slot_stride = 0) {
     __shared__ SolveLds L;
     if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
     const int lane = threadIdx.x;
     const int sample = sample_offset + blockIdx.x;
     if (sample >= n_samples) return;
+    if (ps) {  // batched pass: hypotheses beyond the slot's count are padding -- no models
+        const int a = sample / slot_stride;
+        if (sample - a * slot_stride >= ps[a].cnt) {
+            if (lane == 0) recs[sample - sample_offset].ok = 0.0;
+            return;
+        }
+    }
 
     // ---- 1a. epipolar rows Q[i] = [x1x2, y1x2, x2, x1y2, y1y2, y2, x1, y1, 1]  (five-point.cpp:375-383) ----
     if (lane < 5) {
@@ -805,8 +831,19 @@ constexpr int kTUsedMax = 48;
 // ---------------------------------------------------------------------------------------------------------------
 // Also kp[i] (a polynomial in |x1|+|y1|+1 and |x2|+|y2|+1), stored behind the points: the per-point factor of the error band of the
 // fused-multiply-add fast path of the inlier predicate (sampson_inlier_fma).
+// batch form (counts != nullptr): blockIdx.y = pair; its coordinates start at pair * pair_stride, its packed block at
+// pts + pair * pack_stride (in double4 units), its count is counts[pair], its replay state st[pair]
 __global__ void pack_points_kernel(const double *__restrict__ p1, const double *__restrict__ p2, int n, double4 *__restrict__ pts,
-                                   ReplayState *__restrict__ st, int niters, int32_t *__restrict__ zero_ints, int n_zero) {
+                                   ReplayState *__restrict__ st, int niters, int32_t *__restrict__ zero_ints, int n_zero,
+                                   const int32_t *__restrict__ counts = nullptr, int pair_stride = 0, size_t pack_stride = 0) {
+    if (counts) {
+        const int b = blockIdx.y;
+        n = counts[b];
+        p1 += (size_t)b * pair_stride * 2, p2 += (size_t)b * pair_stride * 2;
+        pts += (size_t)b * pack_stride;
+        st += b;
+        zero_ints = nullptr, n_zero = 0;
+    }
     if (st && blockIdx.x == 0 && threadIdx.x < 64) {  // start state of the replay + zeroed counters: saves two stream operations per call
         if (threadIdx.x < n_zero) zero_ints[threadIdx.x] = 0;
         if (threadIdx.x == 0) {
@@ -1013,7 +1050,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int kThreads, int kTile>
 __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
                                                                     const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
-                                                                    int total_host, double thresh2, double qmax, int32_t *__restrict__ good) {
+                                                                    int total_host, double thresh2, double qmax, int32_t *__restrict__ good,
+                                                                    const PairSlot *__restrict__ ps = nullptr, int slot_stride = 0) {
+    if (ps) {  // batched pass: blockIdx.z = slot
+        const int a = blockIdx.z;
+        pts = ps[a].pts, n = ps[a].n;
+        E_list += (size_t)a * slot_stride * 90, ids += (size_t)a * slot_stride * 10, total_ptr += a;
+    }
     // pair layout: the two consecutive correspondences of a lane class (j = i & 3) sit side by side, so a lane reads its pair's
     // (x1a,x1b, y1a,y1b, x2a,x2b, y2a,y2b) with two ds_read_b128 and (KPs_a, KPs_b) with one ds_read_b64
     __shared__ __attribute__((aligned(16))) float tile_xy[(kTile / 2) * 8];
@@ -1119,7 +1162,14 @@ template <bool COUNT, bool SUMS>
 __global__ __launch_bounds__((SUMS && !COUNT) ? 1024 : 256) void score_models_block_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
                                                                  const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
                                                                  int total_host, double thresh2, double qmax, int32_t *__restrict__ good,
-                                                                 double *__restrict__ esum, const int32_t *__restrict__ pick) {
+                                                                 double *__restrict__ esum, const int32_t *__restrict__ pick,
+                                                                 const PairSlot *__restrict__ ps = nullptr, int slot_stride = 0) {
+    if (ps) {  // batched pass: blockIdx.y = slot; `pick` ids and the outputs are local to the slot
+        const int a = blockIdx.y;
+        pts = ps[a].pts, n = ps[a].n;
+        E_list += (size_t)a * slot_stride * 90, total_ptr += a, esum += (size_t)a * slot_stride * 10, pick += (size_t)a * slot_stride * 10;
+        if (good) good += (size_t)a * slot_stride * 10;
+    }
     extern __shared__ __attribute__((aligned(16))) float errs[];  // n floats when SUMS
     __shared__ int wave_cnt[4];  // (the counting instances run 256 threads; the sums-only one 1024: its errors are a latency-bound
                                  // gather of n points, and four times the loads in flight shorten it from 5.8 to ~2.5 us at n = 4000)
@@ -1237,7 +1287,15 @@ __device__ __forceinline__ int waves_exclusive_scan_16(int v, int carry, int *wa
 
 __global__ __launch_bounds__(1024) void candidate_kernel(const int32_t *__restrict__ n_models, const int32_t *__restrict__ good,
                                                          const int32_t *__restrict__ hmax_in, int cnt, int carried_best,
-                                                         int32_t *__restrict__ cand, int32_t *__restrict__ cand_count, int ev_cap) {
+                                                         int32_t *__restrict__ cand, int32_t *__restrict__ cand_count, int ev_cap,
+                                                         const PairSlot *__restrict__ ps = nullptr, int slot_stride = 0,
+                                                         const ReplayState *__restrict__ st_all = nullptr) {
+    if (ps) {  // batched pass: blockIdx.x = slot; the candidate ids are local to the slot
+        const int a = blockIdx.x;
+        n_models += (size_t)a * slot_stride, good += (size_t)a * slot_stride * 10, hmax_in += (size_t)a * slot_stride;
+        cand += (size_t)a * slot_stride * 10, cand_count += a;
+        cnt = ps[a].cnt, carried_best = st_all[ps[a].pair].maxGood;
+    }
     __shared__ int wave_s[16];
     __shared__ int ev_pos[kMaxScanEvents], ev_val[kMaxScanEvents], ev_n;  // ev_cap <= kMaxScanEvents entries are used (tests shrink it)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1296,7 +1354,12 @@ __global__ __launch_bounds__(1024) void candidate_kernel(const int32_t *__restri
 }
 
 __global__ void inlier_mask_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E, double thresh2,
-                                   uint8_t *__restrict__ mask) {
+                                   uint8_t *__restrict__ mask, const PairSlot *__restrict__ ps = nullptr,
+                                   const ReplayState *__restrict__ st_all = nullptr, int mask_stride = 0) {
+    if (ps) {  // batch: blockIdx.y = slot
+        const PairSlot P = ps[blockIdx.y];
+        pts = P.pts, n = P.n, E = st_all[P.pair].E, mask += (size_t)P.pair * mask_stride;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double e[9];
@@ -1730,7 +1793,14 @@ __global__ __launch_bounds__(1024) void replay_kernel(const int32_t *__restrict_
                                                       const int32_t *__restrict__ hslot, const double *__restrict__ E_tab, int cnt,
                                                       const int32_t *__restrict__ Ttab, int npts, long long base_index,
                                                       const int32_t *__restrict__ dense_total, ReplayState *__restrict__ st,
-                                                      double log_num, int ev_cap) {
+                                                      double log_num, int ev_cap, const PairSlot *__restrict__ ps = nullptr,
+                                                      int slot_stride = 0) {
+    if (ps) {  // batched pass: blockIdx.x = slot
+        const int a = blockIdx.x;
+        hgood += (size_t)a * slot_stride, hsum += (size_t)a * slot_stride, hslot += (size_t)a * slot_stride;
+        E_tab += (size_t)a * slot_stride * 90, dense_total += a;
+        cnt = ps[a].cnt, npts = ps[a].n, base_index = (long long)ps[a].iter_base * 10, st += ps[a].pair;
+    }
     __shared__ int wave_s[16];
     __shared__ int stop_idx;
     __shared__ int ev_pos[kMaxScanEvents], ev_val[kMaxScanEvents], ev_n;
@@ -2208,6 +2278,7 @@ static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
 
 #include "arrsac_impl.h"
 #include "usac_impl.h"
+#include "pair_batch_impl.h"
 
 void free_rand_cache(void *p) { delete static_cast<RandCache *>(p); }
 
@@ -2784,6 +2855,44 @@ int mlpl_robust_essential_refine(mlpl_ctx *ctx, const double *p1, const double *
     MLPL_HIP_TRY(hipStreamSynchronize(s));
     std::memcpy(E_refined, h, 72);
     if (info) std::memcpy(info, h + 9, 8);
+    return MLPL_OK;
+}
+
+int mlpl_pair_pose_batch_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
+                             const float *d_kp2, const double K0[4], const double K1[4], double thresh, int max_iters, double confidence,
+                             int refit, const uint32_t *seeds, double dist, mlpl_pair_result *out, void *stream) {
+    if (!ctx || !d_q || !d_t || !d_kp1 || !d_kp2 || !K0 || !K1 || !out || !seeds || n_pairs < 1 || nq < 1 || nt < 2 || nbytes < 1 || max_iters < 1 ||
+        !(thresh > 0)) {
+        set_error("mlpl_pair_pose_batch_dev: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = pick_stream(ctx, stream);
+    const int per = ctx->opt_pair_batch > 0 ? ctx->opt_pair_batch : kBatchPairsPerCall;
+    std::memset(ctx->last_batch_stats, 0, sizeof(ctx->last_batch_stats));
+    long long acc[4] = {0, 0, 0, 0};
+    for (int at = 0; at < n_pairs; at += per) {
+        const int B = std::min(per, n_pairs - at);
+        int rc;
+        if (refit) {  // the refit step is not batched: the single-pair pipeline, pair by pair
+            for (int b = at; b < at + B; ++b)
+                if ((rc = mlpl_pair_pose_dev(ctx, d_q + (size_t)b * nq * nbytes, nq, d_t + (size_t)b * nt * nbytes, nt, nbytes, d_kp1 + (size_t)b * nq * 2,
+                                             d_kp2 + (size_t)b * nt * 2, K0, K1, thresh, max_iters, confidence, refit, seeds[b], dist, &out[b], stream)))
+                    return rc;
+            continue;
+        }
+        rc = pair_pose_batch_dev(ctx, B, d_q + (size_t)at * nq * nbytes, nq, d_t + (size_t)at * nt * nbytes, nt, nbytes, d_kp1 + (size_t)at * nq * 2,
+                                 d_kp2 + (size_t)at * nt * 2, K0, K1, thresh, max_iters, confidence, seeds + at, dist, out + at, s);
+        if (rc) return rc;
+        for (int k = 0; k < 4; ++k) acc[k] += ctx->last_batch_stats[k];
+    }
+    std::memcpy(ctx->last_batch_stats, acc, sizeof(acc));
+    return MLPL_OK;
+}
+
+int mlpl_pair_batch_last_stats(mlpl_ctx *ctx, long long stats[4]) {
+    if (!ctx || !stats) return MLPL_E_BAD_INPUT;
+    std::memcpy(stats, ctx->last_batch_stats, sizeof(ctx->last_batch_stats));
     return MLPL_OK;
 }
 

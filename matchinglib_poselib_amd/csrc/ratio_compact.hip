@@ -121,6 +121,34 @@ int launch_gather_match_points(const mlpl_dmatch *d_matches, int n, const float 
     return MLPL_OK;
 }
 
+// batch of pairs: blockIdx.y = pair; matches / coordinates of pair b at b * pair_stride, its keypoints at b * kp*_stride floats
+__global__ void gather_match_points_batch_kernel(const mlpl_dmatch *__restrict__ matches, const int32_t *__restrict__ counts, int pair_stride,
+                                                 const float *__restrict__ kp1, size_t kp1_stride, const float *__restrict__ kp2,
+                                                 size_t kp2_stride, double fx0, double fy0, double cx0, double cy0, double fx1, double fy1,
+                                                 double cx1, double cy1, double *__restrict__ p1, double *__restrict__ p2) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= counts[b]) return;
+    const mlpl_dmatch m = matches[(size_t)b * pair_stride + i];
+    const float *k1 = kp1 + (size_t)b * kp1_stride, *k2 = kp2 + (size_t)b * kp2_stride;
+    const float ax = k1[2 * m.queryIdx], ay = k1[2 * m.queryIdx + 1];
+    const float bx = k2[2 * m.trainIdx], by = k2[2 * m.trainIdx + 1];
+    const size_t o = ((size_t)b * pair_stride + i) * 2;
+    p1[o] = (double)(float)(((double)ax - cx0) / fx0);
+    p1[o + 1] = (double)(float)(((double)ay - cy0) / fy0);
+    p2[o] = (double)(float)(((double)bx - cx1) / fx1);
+    p2[o + 1] = (double)(float)(((double)by - cy1) / fy1);
+}
+
+int launch_gather_match_points_batch(const mlpl_dmatch *d_matches, const int32_t *d_counts, int B, int pair_stride, const float *d_kp1,
+                                     size_t kp1_stride, const float *d_kp2, size_t kp2_stride, const double K0[4], const double K1[4],
+                                     double *d_p1, double *d_p2, hipStream_t s) {
+    hipLaunchKernelGGL(gather_match_points_batch_kernel, dim3((pair_stride + 255) / 256, B), dim3(256), 0, s, d_matches, d_counts, pair_stride,
+                       d_kp1, kp1_stride, d_kp2, kp2_stride, K0[0], K0[1], K0[2], K0[3], K1[0], K1[1], K1[2], K1[3], d_p1, d_p2);
+    MLPL_HIP_TRY(hipGetLastError());
+    return MLPL_OK;
+}
+
 int launch_ratio_compact(mlpl_ctx *ctx, const int32_t *d_idx, const void *d_dist, int dist_is_float, int nq, int k,
                          int batch, float ratio, mlpl_dmatch *d_out, int32_t *d_n_out, hipStream_t s,
                          int32_t *d_group_counts_ready, int nms_emit) {

@@ -190,7 +190,178 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const double *__restri
     if (threadIdx.x == 0) atomicAdd(&counts[c], wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
 }
 
+// ---- batch of pairs (pair_batch_impl.h) -----------------------------------------------------------------------------------------------------
+// decompose: block = pair, E read from a strided table; triangulate: blockIdx.z = pair, its coordinates at pair * pair_stride, its count
+// counts[pair] (pairs flagged inactive: count forced to 0); select: the reference's if-chain (five-point.cpp:299-336) on the device, the
+// chosen candidate's mask copied over the pair's mask.
+__global__ void decompose_batch_kernel(const char *__restrict__ E_base, size_t E_stride, const int32_t *__restrict__ active,
+                                       double *__restrict__ P_all /*[B][69]*/) {
+    if (threadIdx.x != 0 || !active[blockIdx.x]) return;
+    const double *E = reinterpret_cast<const double *>(E_base + (size_t)blockIdx.x * E_stride);
+    double *out = P_all + (size_t)blockIdx.x * 69;
+    double G[3][3], V[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) G[i][j] = E[i * 3 + j];
+    jacobi_right_vectors<3>(G, V);
+    double w[3];
+    for (int j = 0; j < 3; ++j) w[j] = sqrt(G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j]);
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; ++a) {
+        int best = a;
+        for (int b = a + 1; b < 3; ++b)
+            if (w[ord[b]] > w[ord[best]]) best = b;
+        const int t = ord[a];
+        ord[a] = ord[best];
+        ord[best] = t;
+    }
+    double U[9], Vt[9], ws[3];
+    for (int j = 0; j < 3; ++j) {
+        ws[j] = w[ord[j]];
+        for (int i = 0; i < 3; ++i) {
+            U[i * 3 + j] = (ws[j] > 0) ? G[i][ord[j]] / ws[j] : 0.0;
+            Vt[j * 3 + i] = V[i][ord[j]];
+        }
+    }
+    if (!(ws[2] > 1e-12 * ws[0])) {
+        U[0 * 3 + 2] = U[1 * 3 + 0] * U[2 * 3 + 1] - U[2 * 3 + 0] * U[1 * 3 + 1];
+        U[1 * 3 + 2] = U[2 * 3 + 0] * U[0 * 3 + 1] - U[0 * 3 + 0] * U[2 * 3 + 1];
+        U[2 * 3 + 2] = U[0 * 3 + 0] * U[1 * 3 + 1] - U[1 * 3 + 0] * U[0 * 3 + 1];
+    }
+    if (det3(U) < 0)
+        for (int i = 0; i < 9; ++i) U[i] = -U[i];
+    if (det3(Vt) < 0)
+        for (int i = 0; i < 9; ++i) Vt[i] = -Vt[i];
+    const double W[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
+    const double Wt[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};
+    double T[9], R1[9], R2[9];
+    mat3_mul(U, W, T);
+    mat3_mul(T, Vt, R1);
+    mat3_mul(U, Wt, T);
+    mat3_mul(T, Vt, R2);
+    const double tv[3] = {U[2], U[5], U[8]};
+    for (int c = 0; c < 4; ++c) {
+        const double *R = (c & 1) ? R2 : R1;
+        const double sg = (c < 2) ? 1.0 : -1.0;
+        for (int r = 0; r < 3; ++r) {
+            for (int k = 0; k < 3; ++k) out[c * 12 + r * 4 + k] = R[r * 3 + k];
+            out[c * 12 + r * 4 + 3] = sg * tv[r];
+        }
+    }
+    for (int i = 0; i < 9; ++i) {
+        out[48 + i] = R1[i];
+        out[57 + i] = R2[i];
+    }
+    for (int i = 0; i < 3; ++i) out[66 + i] = tv[i];
+}
+
+__global__ __launch_bounds__(256) void triangulate_batch_kernel(const double *__restrict__ P_all, const double *__restrict__ p1,
+                                                                const double *__restrict__ p2, const int32_t *__restrict__ counts,
+                                                                const int32_t *__restrict__ active, int pair_stride, double dist,
+                                                                const uint8_t *__restrict__ mask_in /*[B][pair_stride]*/,
+                                                                uint8_t *__restrict__ mask_out /*[B][4][pair_stride]*/,
+                                                                int32_t *__restrict__ cand_counts /*[B][4]*/) {
+    __shared__ int wave_cnt[4];
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int n = active[b] ? counts[b] : 0;
+    if ((int)(blockIdx.x * blockDim.x) >= n) return;  // block-uniform
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool good = false;
+    // a correspondence outside the incoming mask cannot pass whatever its 3-D point is (the batch form returns no points): skip its SVD
+    if (i < n && mask_in && !mask_in[(size_t)b * pair_stride + i]) {
+        mask_out[((size_t)b * 4 + c) * pair_stride + i] = 0;
+    } else if (i < n) {
+        const double *Pc = P_all + (size_t)b * 69 + c * 12;
+        const size_t at = ((size_t)b * pair_stride + i) * 2;
+        const double x1 = p1[at], y1 = p1[at + 1], x2 = p2[at], y2 = p2[at + 1];
+        double G[4][4], V[4][4];
+        const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            G[0][k] = x1 * P0[8 + k] - P0[k];
+            G[1][k] = y1 * P0[8 + k] - P0[4 + k];
+            G[2][k] = x2 * Pc[8 + k] - Pc[k];
+            G[3][k] = y2 * Pc[8 + k] - Pc[4 + k];
+        }
+        jacobi_right_vectors<4>(G, V);
+        double w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j] + G[3][j] * G[3][j];
+        int m = 0;
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+            if (w[j] < w[m]) m = j;
+        double X[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X[k] = (m == 0) ? V[k][0] : (m == 1 ? V[k][1] : (m == 2 ? V[k][2] : V[k][3]));
+        bool mk = (X[2] * X[3] > 0);
+        const double qz = Pc[8] * X[0] + Pc[9] * X[1] + Pc[10] * X[2] + Pc[11] * X[3];
+        mk = mk && (qz * X[3] > 0);
+        const double qzz = X[2] / X[3];
+        mk = mk && (qzz < dist);
+        uint8_t mv = mk ? 255 : 0;
+        if (mask_in) mv &= mask_in[(size_t)b * pair_stride + i];
+        mask_out[((size_t)b * 4 + c) * pair_stride + i] = mv;
+        good = (mv != 0);
+    }
+    const unsigned long long bal = __ballot(good);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&cand_counts[b * 4 + c], wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
+}
+
+__global__ __launch_bounds__(256) void select_pose_batch_kernel(const double *__restrict__ P_all, const int32_t *__restrict__ cand_counts,
+                                                                const int32_t *__restrict__ counts, const int32_t *__restrict__ active,
+                                                                int pair_stride, const uint8_t *__restrict__ cand_masks,
+                                                                uint8_t *__restrict__ mask /*[B][pair_stride]*/,
+                                                                PairPoseDev *__restrict__ out) {
+    const int b = blockIdx.x;
+    if (!active[b]) return;
+    const int good1 = cand_counts[b * 4], good2 = cand_counts[b * 4 + 1], good3 = cand_counts[b * 4 + 2], good4 = cand_counts[b * 4 + 3];
+    int pick, ret;
+    if (good1 >= good2 && good1 >= good3 && good1 >= good4) {
+        pick = 0, ret = good1;
+    } else if (good2 && good2 >= good1 && good2 >= good3 && good2 >= good4) {
+        pick = 1, ret = good2;
+    } else if (good3 >= good1 && good3 >= good2 && good3 >= good4) {
+        pick = 2, ret = good3;
+    } else {
+        ret = good4;
+        pick = good4 ? 3 : -1;
+    }
+    const int n = counts[b];
+    if (threadIdx.x == 0) {
+        PairPoseDev &o = out[b];
+        o.n_good = ret, o.pick = pick;
+        const double *hP = P_all + (size_t)b * 69;
+        if (pick >= 0) {
+            for (int k = 0; k < 9; ++k) o.R[k] = hP[((pick & 1) ? 57 : 48) + k];
+            const double sg = (pick < 2) ? 1.0 : -1.0;
+            for (int k = 0; k < 3; ++k) o.t[k] = sg * hP[66 + k];
+        } else {
+            for (int k = 0; k < 9; ++k) o.R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+            o.t[0] = o.t[1] = o.t[2] = 0;
+        }
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        mask[(size_t)b * pair_stride + i] = pick >= 0 ? cand_masks[((size_t)b * 4 + pick) * pair_stride + i] : 0;
+}
+
 }  // namespace
+
+int launch_recover_pose_batch(const char *d_E_base, size_t E_stride, const double *d_p1, const double *d_p2, const int32_t *d_counts,
+                              const int32_t *d_active, int B, int pair_stride, double dist, uint8_t *d_mask, double *d_P /*[B][69]*/,
+                              uint8_t *d_cand_masks /*[B][4][pair_stride]*/, int32_t *d_cand_counts /*[B][4]*/, PairPoseDev *d_out,
+                              hipStream_t s) {
+    MLPL_HIP_TRY(hipMemsetAsync(d_cand_counts, 0, (size_t)B * 16, s));
+    hipLaunchKernelGGL(decompose_batch_kernel, dim3(B), dim3(64), 0, s, d_E_base, E_stride, d_active, d_P);
+    hipLaunchKernelGGL(triangulate_batch_kernel, dim3((pair_stride + 255) / 256, 4, B), dim3(256), 0, s, (const double *)d_P, d_p1, d_p2, d_counts,
+                       d_active, pair_stride, dist, (const uint8_t *)d_mask, d_cand_masks, d_cand_counts);
+    hipLaunchKernelGGL(select_pose_batch_kernel, dim3(B), dim3(256), 0, s, (const double *)d_P, (const int32_t *)d_cand_counts, d_counts, d_active,
+                       pair_stride, (const uint8_t *)d_cand_masks, d_mask, d_out);
+    MLPL_HIP_TRY(hipGetLastError());
+    return MLPL_OK;
+}
+
 }  // namespace mlpl
 
 using namespace mlpl;

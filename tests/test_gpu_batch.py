@@ -67,3 +67,52 @@ def test_concurrent_pair_workers_equal_sequential(ctx):
         pw.close()
     assert con.tobytes() == seq.tobytes()
     assert (seq["status"] == 0).all() and (seq["n_inliers"] > 100).all()
+
+
+def _stack(sps, dev):
+    return tuple(torch.from_numpy(np.stack([sp[k] for sp in sps])).to(dev) for k in ("desc1", "desc2", "kp1", "kp2"))
+
+
+def test_batched_pairs_equal_the_single_pair_pipeline(ctx):
+    """mlpl_pair_pose_batch_dev: 70 pairs (an internal batch of 64 + 6) of varied inlier ratio and match count -- pairs that stop in the
+    first pass of 324 iterations and pairs that need the second -- give byte-identical records to mlpl_pair_pose_dev pair by pair."""
+    dev = torch.device("cuda:0")
+    fracs = [0.5, 0.3, 0.7, 0.2, 0.45, 0.9, 0.25]
+    sps = [synth.stereo_pair(1536, seed=700 + i, inlier_frac=fracs[i % 7], unmatched_frac=0.1 * (i % 4)) for i in range(70)]
+    seeds = [9000 + 13 * i for i in range(70)]
+    K = sps[0]["K"]
+    one = np.concatenate([batch.process_pair_on_device(ctx, *(torch.from_numpy(sp[k]).to(dev) for k in ("desc1", "desc2", "kp1", "kp2")), K, K,
+                                                       seed=seeds[i], pair_id=i) for i, sp in enumerate(sps)])
+    dq, dt, k1, k2 = _stack(sps, dev)
+    bat = batch.process_pairs_batched(ctx, dq, dt, k1, k2, K, K, seeds)
+    stats = np.zeros(4, np.int64)
+    ctx.lib.mlpl_pair_batch_last_stats(ctx.handle, stats.ctypes.data)
+    for i in range(70):
+        assert bat[i].tobytes() == one[i].tobytes(), (i, bat[i], one[i])
+    assert (one["status"] == 0).all()
+    assert stats[0] >= 3 and 70 < stats[1] < 140, stats      # a second pass ran, and only for part of the pairs
+    # smaller internal batches give the same records
+    ctx.set_option("pair_batch", 16)
+    try:
+        assert batch.process_pairs_batched(ctx, dq, dt, k1, k2, K, K, seeds).tobytes() == bat.tobytes()
+    finally:
+        ctx.set_option("pair_batch", 0)
+
+
+def test_batched_pairs_edge_cases(ctx, oracle):
+    """A pair with too few matches (status -1), a pair of pure outliers (status -2 or a model with few inliers, as the single-pair
+    pipeline), long runs (max_iters 3000: three passes), and the refit variant (served pair by pair)."""
+    dev = torch.device("cuda:0")
+    sps = [synth.stereo_pair(1024, seed=800 + i, inlier_frac=0.5) for i in range(5)]
+    rng = np.random.default_rng(3)
+    sps[1]["desc1"] = rng.integers(0, 256, sps[1]["desc1"].shape, dtype=np.uint8)            # nothing passes the ratio test
+    sps[3]["kp2"] = rng.uniform(0, 640, sps[3]["kp2"].shape).astype(np.float32)              # matches without geometry
+    K = sps[0]["K"]
+    seeds = [5, 6, 7, 8, 9]
+    dq, dt, k1, k2 = _stack(sps, dev)
+    for kw in (dict(), dict(max_iters=3000, confidence=0.9999999), dict(refit=True)):
+        one = np.concatenate([batch.process_pair_on_device(ctx, *(torch.from_numpy(sp[k]).to(dev) for k in ("desc1", "desc2", "kp1", "kp2")), K, K,
+                                                           seed=seeds[i], pair_id=i, **kw) for i, sp in enumerate(sps)])
+        bat = batch.process_pairs_batched(ctx, dq, dt, k1, k2, K, K, seeds, **kw)
+        assert bat.tobytes() == one.tobytes(), (kw, bat, one)
+        assert one["status"][1] == -1 and one["status"][0] == 0
