@@ -13,8 +13,11 @@ see mlpl_profile_*) and `cpu_baseline` (the oracle's single-thread LUT port time
 `python bench.py --gpus N` works by itself: when N > 1 and no torch.distributed environment is present, this process starts the N
 rank processes (python -m torch.distributed.run on 127.0.0.1) BEFORE it touches the GPU and relays their output; under an external
 launcher (RANK / WORLD_SIZE set) it is a rank.  `--workload c5` times BASELINE config 5 instead: 512 stereo pairs, each through the
-whole per-pair pipeline (8k ORB match -> gather -> 5-pt RANSAC -> cheirality), dealt to the ranks by batch.pair_shard, records
-gathered by one RCCL all_gather per step.
+whole per-pair pipeline (8k ORB match -> gather -> 5-pt RANSAC -> cheirality), dealt to the ranks by batch.pair_shard, a rank's share
+as batches with the pair as a grid dimension (mlpl_pair_pose_batch_dev), records gathered by one RCCL all_gather per step and the
+padded match lists sent to rank 0 by grouped send / recv; the line carries `roofline` (dominant kernel of the pipeline) and
+`cpu_baseline` (the oracle pipeline on a sample of the pairs).  The default (C2) line carries the same C5 measurement under
+extras.c5_batch_sharded at every N.
 """
 import argparse
 import ctypes as C
@@ -64,68 +67,153 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
-def run_c5(args, rank, local_rank, world, dev, ctx):
+FP32_VALU_PEAK_TFLOPS = 157.3    # MI355X vector fp32 (MI355X_MICROARCH.md): the counting kernel decides in packed fp32
+FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector fp64
+FLOP_PER_HYPOTHESIS = 15e3       # fp64 FLOP of one 5-point solve (null space, 10 x 20 elimination, degree-10 roots, <= 10 models)
+FLOP_PER_SAMPSON = 39            # fp64 FLOP per (model, correspondence) evaluation
+
+
+def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_baseline):
     """BASELINE config 5: `--c5-pairs` (512) stereo pairs x (8192-keypoint ORB match + ratio -> gather/ImgToCamCoordTrans -> RANSAC
-    1000 it / 0.999 -> cheirality), pairs dealt to ranks in contiguous blocks, several pairs in flight per rank (independent
-    contexts/streams), one all_gather of the 184-byte records per step.  Total work is fixed: strong scaling."""
+    1000 it / 0.999 -> cheirality), pairs dealt to ranks in contiguous blocks; a rank's share goes through mlpl_pair_pose_batch_dev (the
+    pair is a grid dimension of every launch, no host threads); per step one all_gather of the 184-byte records and the padded match
+    lists to rank 0 by grouped send / recv.  Total work is fixed: strong scaling.  Returns the fields of the JSON line (rank 0: complete)."""
     import numpy as np
     import torch
     import torch.distributed as dist
-    from matchinglib_poselib_amd import batch, synth
+    from matchinglib_poselib_amd import _lib, batch, synth
 
     total = args.c5_pairs
     begin, end = batch.pair_shard(total, rank, world)
     mine = end - begin
+    cap = batch.shard_capacity(total, world)
     distinct = max(1, min(mine, args.c5_distinct))
     sps = [synth.stereo_pair(args.n, seed=20260200 + begin + i, unmatched_frac=0.30 + 0.02 * (i % 8)) for i in range(distinct)]
-    dev_in = [tuple(torch.from_numpy(sp[k]).to(dev) for k in ("desc1", "desc2", "kp1", "kp2")) for sp in sps]
     K = sps[0]["K"]
-    pairs = [dev_in[i % distinct] for i in range(mine)]
+    stacked = {k: torch.from_numpy(np.stack([sps[i % distinct][k] for i in range(mine)])).to(dev) for k in ("desc1", "desc2", "kp1", "kp2")}
     seeds = [100 + begin + i for i in range(mine)]
     ids = list(range(begin, end))
-    pw = batch.PairWorkers(local_rank, workers=args.c5_workers)
-    allrec = None
+    d_matches = torch.zeros((cap, args.n, 4), dtype=torch.int32, device=dev)
+    state = {}
+    use_rccl = args.backend == "nccl" or world == 1
 
     def step():
-        nonlocal allrec
-        recs = pw.process(pairs, K, K, seeds=seeds, pair_ids=ids)
-        allrec = batch.gather_records(recs, total, rank, world, device=dev if args.backend == "nccl" or world == 1 else None)
+        recs = batch.process_pairs_batched(ctx, stacked["desc1"], stacked["desc2"], stacked["kp1"], stacked["kp2"], K, K, seeds, pair_ids=ids,
+                                           matches_out=d_matches[:mine])
+        state["rec"] = batch.gather_records(recs, total, rank, world, device=dev if use_rccl else None)
+        state["matches"] = batch.gather_match_lists(d_matches if use_rccl else d_matches.cpu(), total, rank, world, root=0)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    try:
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-    finally:
-        pw.close()
+    for _ in range(warmup):
+        step()
+    barrier()
+    lib = ctx.lib
+    _lib.check(lib.mlpl_profile_reset(ctx.handle), "profile_reset")
+    _lib.check(lib.mlpl_profile_enable(ctx.handle, 0 if args.no_kernel_events else 1), "profile_enable")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.check(lib.mlpl_profile_enable(ctx.handle, 0), "profile_enable")
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if use_rccl else None)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    allrec = state["rec"]
     assert len(allrec) == total and (allrec["status"] == 0).all(), "a pair failed"
+    if rank != 0:
+        return None
+    # the gathered match lists are the lists the poses were computed from
+    m = state["matches"]
+    assert m.shape[0] == total
+    first = m[0, : int(allrec["n_matches"][0])].cpu().numpy()
+    assert (np.diff(first[:, 0]) > 0).all() and (first[:, 2] == -1).all(), "gathered match list of pair 0 is not a DMatch list"
+    stats = np.zeros(8, np.int64)
+    lib.mlpl_pair_batch_last_stats(ctx.handle, stats.ctypes.data)
+    prof = {}
+    for name, kid in (("knn_hamming_mfma_lds_kernel<4, 0>", 0), ("solve5pt_kernel + roots_kernel_t<true>", 2),
+                      ("count_models_f32_kernel<512, 512>", 3), ("decompose / triangulate / select (batch)", 4)):
+        ms, cnt = C.c_double(0), C.c_int(0)
+        lib.mlpl_profile_read(ctx.handle, kid, C.byref(ms), C.byref(cnt))
+        prof[name] = (ms.value, cnt.value)
+    per_step = {k: v[0] / max(steps, 1) for k, v in prof.items()}
+    dom = max(per_step, key=per_step.get)
+    evals = float(stats[5])  # Sampson evaluations of this rank's last step
+    score_ms = per_step["count_models_f32_kernel<512, 512>"]
+    ham_ms = per_step["knn_hamming_mfma_lds_kernel<4, 0>"]
+    out = {
+        "metric": "image-pairs/s (C5: stereo pairs x (8k ORB BF-Hamming match + 5-pt RANSAC + cheirality))",
+        "value": total * steps / elapsed, "unit": "image-pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "fp4 MFMA (Hamming, exact) + f64 / packed f32 inside a rigorous band (solver, Sampson, cheirality)", "data": "synthetic",
+        "config": {"workload": f"C5: {total} stereo pairs x ({args.n} ORB-256 keypoints per image: Hamming 2-NN + 0.75 ratio -> "
+                               "ImgToCamCoordTrans gather -> RANSAC 1000 it / 0.999 -> getPoseTriangPts), one step = the whole batch",
+                   "pairs_total": total, "pairs_this_rank": mine, "distinct_inputs_per_rank": distinct,
+                   "entry": "mlpl_pair_pose_batch_dev (pair = grid dimension; internal batches of 128 pairs)", "parallelism": f"shard{world}",
+                   "world_size": world, "backend": args.backend if world > 1 else None,
+                   "gathered_per_step": "184-byte records by all_gather + the padded match lists to rank 0 by grouped send / recv",
+                   "mean_matches": float(allrec["n_matches"].mean()), "mean_inliers": float(allrec["n_inliers"].mean()),
+                   "ransac_passes_rank0": int(stats[0]), "pair_slots_rank0": int(stats[1]), "iterations_rank0": int(stats[6]),
+                   "host_sample_drawing_ms_per_step_rank0": float(stats[3]) / 1e3},
+        "kernel_ms_per_step_rank0": per_step,
+        "roofline": {
+            "kernel": dom, "bound": "valu-fp32" if dom.startswith("count") else ("mfma" if dom.startswith("knn") else "valu-fp64 (issue / latency bound)"),
+            "kernel_ms_per_step": per_step[dom], "launches_timed": prof[dom][1],
+            "achieved": (evals * FLOP_PER_SAMPSON / (score_ms * 1e-3) / 1e12) if dom.startswith("count") else
+                        ((mine * args.n * args.n * FLOP_PER_PAIR / (ham_ms * 1e-3) / 1e12) if dom.startswith("knn") else
+                         (float(stats[6]) * FLOP_PER_HYPOTHESIS / (per_step[dom] * 1e-3) / 1e12)),
+            "peak": FP32_VALU_PEAK_TFLOPS if dom.startswith("count") else (FP4_MFMA_PEAK_TFLOPS if dom.startswith("knn") else FP64_VALU_PEAK_TFLOPS),
+            "unit": "TFLOP/s",
+            "traffic": None,
+            "note": "dominant kernel of the pipeline by HIP events inside the library (every launch bracketed).  count_models: 39 FLOP per "
+                    "(model, correspondence) evaluation x the evaluations of the step, decided in packed fp32 (two per instruction) inside "
+                    "a rigorous error band, priced against the fp32 vector peak; Hamming: 2 x 256 FLOP per descriptor pair against the "
+                    "dense FP4 peak; solver kernels: ~15 kFLOP (fp64) per 5-point hypothesis x the iterations of the step against the fp64 vector peak -- "
+                    "one hypothesis per wavefront, issue / latency bound, far from that roofline by construction (SURVEY 8(d))",
+            "sampson_evaluations_per_step": evals, "score_kernel_TFLOPs_equiv": evals * FLOP_PER_SAMPSON / (score_ms * 1e-3) / 1e12 if score_ms > 0 else None,
+            "hamming_kernel_frac_of_fp4_peak": mine * args.n * args.n * FLOP_PER_PAIR / (ham_ms * 1e-3) / 1e12 / FP4_MFMA_PEAK_TFLOPS if ham_ms > 0 else None,
+        },
+        "cpu_baseline": None,
+    }
+    r = out["roofline"]
+    r["frac"] = (r["achieved"] / r["peak"]) if r["achieved"] and r["peak"] else None
+    if cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        ora = oracle_lib.load()
+        ncpu = 6
+        tc = time.perf_counter()
+        for i in range(ncpu):
+            sp = sps[i % distinct]
+            n = len(sp["desc1"])
+            rc, mm = ora.get_matches_linear(n, n, sp["desc1"], sp["desc2"])
+            a, b = sp["kp1"][mm["queryIdx"]], sp["kp2"][mm["trainIdx"]]
+            cam = lambda p: np.stack([((p[:, 0].astype(np.float64) - K[2]) / K[0]).astype(np.float32),  # noqa: E731
+                                      ((p[:, 1].astype(np.float64) - K[3]) / K[1]).astype(np.float32)], axis=1).astype(np.float64)
+            p1, p2 = cam(a), cam(b)
+            th = 0.8 * 4.0 / (np.sqrt(2.0) * (2 * K[0] + 2 * K[1]))
+            o = ora.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, lesqu=False, seed=seeds[i])
+            good, R, t, Q, mk = ora.recover_pose(o["E"], p1, p2, 50.0, o["mask"])
+            if i < mine:   # the timed records are the CPU path's records
+                assert len(mm) == allrec["n_matches"][i] and o["n_inliers"] == allrec["n_inliers"][i], "pair record differs from the CPU path"
+                assert np.abs(allrec["R"][i].reshape(3, 3) - R).max() < 1e-6 and np.abs(allrec["t"][i] - t).max() < 1e-6
+        tc = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": ncpu / tc, "unit": "image-pairs/s", "cores": 1, "kind": "port",
+                               "sample": f"the first {ncpu} pairs of the batch through the oracle pipeline (LINEAR matching, RANSAC 1000 / 0.999, "
+                                         f"recoverPose), {tc:.1f} s; their records equal the timed step's (counts exact, R, t to 1e-6)",
+                               "host_cores_available": os.cpu_count()}
+    return out
+
+
+def run_c5(args, rank, local_rank, world, dev, ctx):
+    rec = measure_c5(args, rank, local_rank, world, dev, ctx, args.steps, args.warmup, not args.no_cpu_baseline)
     if rank == 0:
-        rec = {
-            "metric": "image-pairs/s (C5: stereo pairs x (8k ORB BF-Hamming match + 5-pt RANSAC + cheirality))",
-            "value": total * args.steps / elapsed, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "fp4 MFMA (Hamming, exact) + f64 (solver, Sampson, cheirality)", "data": "synthetic",
-            "config": {"workload": f"C5: {total} stereo pairs x ({args.n} ORB-256 keypoints per image: Hamming 2-NN + 0.75 ratio -> "
-                                   "ImgToCamCoordTrans gather -> RANSAC 1000 it / 0.999 -> getPoseTriangPts), one step = the whole batch",
-                       "pairs_total": total, "pairs_this_rank": mine, "distinct_inputs_per_rank": distinct,
-                       "pairs_in_flight_per_gpu": args.c5_workers, "parallelism": f"shard{world}", "world_size": world,
-                       "backend": args.backend, "records_gathered": "one all_gather of 184-byte records per step",
-                       "mean_matches": float(allrec["n_matches"].mean()), "mean_inliers": float(allrec["n_inliers"].mean())},
-            "roofline": None, "cpu_baseline": None,
-        }
         print(json.dumps(rec), flush=True)
 
 
@@ -151,7 +239,7 @@ def main():
                     help="c2 (default, the headline metric): batched 8k x 8k Hamming matching; c5: 512 stereo pairs through the whole per-pair pipeline")
     ap.add_argument("--c5-pairs", type=int, default=512)
     ap.add_argument("--c5-distinct", type=int, default=8, help="distinct synthetic inputs generated per rank (cycled over its shard)")
-    ap.add_argument("--c5-workers", type=int, default=6, help="image pairs in flight per GPU")
+    ap.add_argument("--c5-steps", type=int, default=3, help="timed C5 batches of the extras block of the default (C2) line")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -409,12 +497,20 @@ def main():
             tb = time.perf_counter() - tb
             rec["cpu_best"] = {"value": n * n / tb, "unit": "descriptor-pairs/s", "cores": used, "kind": "port",
                                "sample": f"one full C2 pair, popcnt64 + OpenMP ({tb:.3f} s)"}
-        if not args.no_extras:
+        if not args.no_extras and world == 1:
             try:
                 import bench_extras
                 rec["extras"] = bench_extras.run(ctx, dev, cpu_baseline=not args.no_cpu_baseline)
             except ImportError:
                 pass
+    # north_star's config 5 (the whole per-pair pipeline, sharded over the ranks, records + match lists gathered) beside the headline at
+    # EVERY N, so that a scaling run measures the RANSAC / cheirality half too -- not part of `value`, its own barrier-bracketed region
+    c5 = None
+    if not args.no_extras:
+        c5 = measure_c5(args, rank, local_rank, world, dev, ctx, args.c5_steps, 1, cpu_baseline=False)
+    if rank == 0:
+        if c5 is not None:
+            rec.setdefault("extras", {})["c5_batch_sharded"] = c5
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()

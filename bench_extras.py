@@ -10,6 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 FP64_VALU_PEAK = 78.6e12  # MI355X vector fp64 (spec)
+FP32_VALU_PEAK = 157.3e12  # MI355X vector fp32 (spec): what the counting kernel's packed fp32 pre-filter runs on
 
 
 def _prof(ctx, kid):
@@ -65,16 +66,15 @@ def run(ctx, dev, cpu_baseline=True):
         "solve_kernels_ms_per_call": solve_ms,
         "score_kernel_ms_per_call": score_ms,
         "models_scored": models,
-        "score_roofline": {"bound": "valu (packed fp32 pre-filter + fp64 predicate inside its error band)",
+        "score_roofline": {"bound": "valu-fp32 (packed fp32 pre-filter; the fp64 predicate only inside its error band, ~1-3 % of the wave steps)",
                            "achieved": 39.0 * n * models / (score_ms * 1e-3) / 1e12,
-                           "peak": FP64_VALU_PEAK / 1e12, "unit": "TFLOP/s (fp64-equivalent)",
-                           "frac": 39.0 * n * models / (score_ms * 1e-3) / FP64_VALU_PEAK,
-                           "note": "39 fp64 FLOP per (model, correspondence) (SURVEY 8(d)) over the scoring pass of the call (count-only "
-                                   "kernel + candidate selection + error sums of the candidates), priced against the fp64 vector peak. "
-                                   "Since round 2 the counting kernel decides most evaluations in packed single precision (two per "
-                                   "instruction) inside a rigorous error band and runs the fp64 predicate only inside the band -- same "
-                                   "counts -- so the fp64-equivalent rate can exceed what an all-fp64 kernel could reach; the fp64-only "
-                                   "kernel (option ransac_f32_filter=0) sits at 0.52 of that peak"},
+                           "peak": FP32_VALU_PEAK / 1e12, "unit": "TFLOP/s",
+                           "frac": 39.0 * n * models / (score_ms * 1e-3) / FP32_VALU_PEAK,
+                           "note": "39 FLOP per (model, correspondence) evaluation (SURVEY 8(d)) over the scoring pass of the call (count-only "
+                                   "kernel + candidate selection + error sums of the candidates), priced against the fp32 VECTOR peak: the "
+                                   "counting kernel decides ~97 % of the evaluations in packed single precision (two per instruction) inside "
+                                   "a rigorous error band.  The all-fp64 kernel (option ransac_f32_filter=0) reaches 0.52 of the fp64 vector "
+                                   "peak (78.6 TFLOP/s) on the same work"},
         "includes": "host sample table (glibc rand stream, pinned/mapped), solve + score + replay + mask kernels, one 200-byte "
                     "state readback",
     }
@@ -139,6 +139,23 @@ def run(ctx, dev, cpu_baseline=True):
         ora.arrsac_essential(p1, p2, th, refine=True)
         out["arrsac_default_method"]["cpu_baseline"] = {"ms_per_call": (time.perf_counter() - tc) * 1e3, "cores": 1, "kind": "port",
                                                         "sample": "the same call"}
+    # ---- USAC (the harness default estimator) on the C3 scene: uniform sampling and PROSAC over a noisy quality order ----
+    order = np.argsort(np.random.default_rng(20260103).random(n) + 0.6 * (~mask), kind="stable").astype(np.uint32)
+    for nm, si in (("usac_uniform", None), ("usac_prosac", order)):
+        uc = lambda: pose.usac_essential(p1, p2, th, 12345, sorted_idx=si, ctx=ctx)  # noqa: E731
+        ur = uc()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            uc()
+        dt = (time.perf_counter() - t0) / 10
+        out[nm] = {"metric": "one estimateEssentialOrPoseUSAC-shaped call (POSE_NISTER, REF_WEIGHTS), host points in / E + mask out (5000 correspondences)",
+                   "ms_per_call": dt * 1e3, "hypotheses": int(ur["final"][1]), "n_inliers": int(ur["final"][5]), "local_optimisations": int(ur["final"][7]),
+                   "device_batches": int(ur["stats"][0]), "samples_solved": int(ur["stats"][1]), "lo_launches": int(ur["stats"][3])}
+        if cpu_baseline:
+            tc = time.perf_counter()
+            ou = ora.usac_essential(p1, p2, th, 12345, sorted_idx=si)
+            out[nm]["cpu_baseline"] = {"ms_per_call": (time.perf_counter() - tc) * 1e3, "cores": 1, "kind": "port", "sample": "the same call",
+                                       "same_result": bool(np.array_equal(ou["flags"], ur["flags"]))}
     # ---- C4: L2 ----
     q, tt = synth.sift_pair(4096, 4096, seed=20260104)
     dq = torch.from_numpy(q).to(dev)
@@ -230,26 +247,51 @@ def run(ctx, dev, cpu_baseline=True):
                                "note": "8192 keypoints per image, Hamming 2-NN + ratio, fused gather/ImgToCamCoordTrans, RANSAC "
                                        "(1000 iterations, 0.999, adaptive stop), getPoseTriangPts; sequential per pair, host API for "
                                        "the pose step"}
-    # the same pairs (x2) with several pairs in flight (independent contexts, streams and host threads on this one GPU)
+    # the same pairs through the BATCHED entry (the pair is a grid dimension of every launch; no host threads): 128 pairs per call
+    nb = 128
+    stk = [torch.stack([dev_in[i % npairs][k] for i in range(nb)]) for k in range(4)]
+    bseeds = [100 + (i % npairs) for i in range(nb)]
+    recb = batch.process_pairs_batched(ctx, *stk, K, K, bseeds)
+    torch.cuda.synchronize()
+    tb = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        recb = batch.process_pairs_batched(ctx, *stk, K, K, bseeds)
+        torch.cuda.synchronize()
+        tb.append(time.perf_counter() - t0)
+    bst = np.zeros(8, np.int64)
+    ctx.lib.mlpl_pair_batch_last_stats(ctx.handle, bst.ctypes.data)
+    same = all(recb[i]["E"].tobytes() == recs[i % npairs][0]["E"].tobytes() and recb[i]["n_inliers"] == recs[i % npairs][0]["n_inliers"] for i in range(nb))
+    out["c5_pair_pipeline_batched"] = {"value": nb / min(tb), "unit": "image-pairs/s (one GPU)", "ms_per_pair": min(tb) / nb * 1e3,
+                                       "ms_per_pair_each_pass": [round(t / nb * 1e3, 4) for t in tb], "ms_per_pair_max_of_passes": max(tb) / nb * 1e3,
+                                       "same_records_as_sequential": bool(same), "ransac_passes": int(bst[0]), "pair_slots": int(bst[1]),
+                                       "host_sample_drawing_ms": float(bst[3]) / 1e3,
+                                       "note": "mlpl_pair_pose_batch_dev: one call, 128 pairs; host hops: match counts, one per RANSAC pass, results"}
+    # the round-2 shape for comparison (8 pairs in flight: independent contexts, streams and host threads) with EVERY pass and every
+    # call timed: round 2's record held one pass in five that took 30 x longer (3.4 ms per pair) -- the per-call records below say which
+    # worker's which call stalled, should it happen again
     many = dev_in + dev_in
     seeds = [100 + (i % npairs) for i in range(len(many))]
-    for workers in (4, 8):
-        pw = batch.PairWorkers(dev.index or 0, workers=workers)
-        try:
-            pw.process(many, K, K, seeds=seeds)
-            torch.cuda.synchronize()
-            times = []
-            for _ in range(5):   # median of five passes: with this many host threads one pass in ten stalls for milliseconds on the runtime's locks
-                t0 = time.perf_counter()
-                recsw = pw.process(many, K, K, seeds=seeds)
-                times.append(time.perf_counter() - t0)
-            dt = sorted(times)[len(times) // 2]
-        finally:
-            pw.close()
-        same = bool(np.concatenate(recs).tobytes() == recsw[:npairs].tobytes())
-        out[f"c5_pair_pipeline_{workers}_in_flight"] = {"value": len(many) / dt, "unit": "image-pairs/s (one GPU)",
-                                                        "ms_per_pair": dt / len(many) * 1e3, "same_records_as_sequential": same,
-                                                        "ms_per_pair_each_pass": [round(t / len(many) * 1e3, 4) for t in times]}
+    pw = batch.PairWorkers(dev.index or 0, workers=8)
+    try:
+        pw.process(many, K, K, seeds=seeds)
+        torch.cuda.synchronize()
+        times, calls = [], []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            recsw = pw.process(many, K, K, seeds=seeds)
+            times.append(time.perf_counter() - t0)
+            calls.append([[round(c * 1e3, 3) for c in w] for w in pw.last_call_ms])
+    finally:
+        pw.close()
+    worst = int(np.argmax(times))
+    out["c5_pair_pipeline_8_in_flight"] = {"value": len(many) / sorted(times)[len(times) // 2], "unit": "image-pairs/s (one GPU)",
+                                           "ms_per_pair": sorted(times)[len(times) // 2] / len(many) * 1e3,
+                                           "ms_per_pair_max_of_passes": max(times) / len(many) * 1e3,
+                                           "same_records_as_sequential": bool(np.concatenate(recs).tobytes() == recsw[:npairs].tobytes()),
+                                           "ms_per_pair_each_pass": [round(t / len(many) * 1e3, 4) for t in times],
+                                           "slowest_pass": worst, "slowest_pass_call_ms_per_worker": calls[worst],
+                                           "note": "superseded by c5_pair_pipeline_batched; kept to watch the stall seen in rounds 1-2"}
     p1, p2, th = arr_scene
     # the call is a chain of dependent host hops: several calls in flight (one library context + host thread each) overlap them
     from concurrent.futures import ThreadPoolExecutor

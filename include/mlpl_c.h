@@ -345,10 +345,13 @@ int mlpl_pair_pose_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, const uint8_t 
  */
 int mlpl_pair_pose_batch_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
                              const float *d_kp2, const double K0[4], const double K1[4], double thresh, int max_iters, double confidence,
-                             int refit, const uint32_t *seeds, double dist, mlpl_pair_result *out, void *stream);
-/* Statistics of the last mlpl_pair_pose_batch_dev call: {RANSAC passes, pair slots summed over the passes, pairs redone by the
- * single-pair pipeline because a device-evaluated iteration bound differed from the host's libm, host microseconds spent drawing the sample tables}. */
-int mlpl_pair_batch_last_stats(mlpl_ctx *ctx, long long stats[4]);
+                             int refit, const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out, void *stream);
+/* d_matches_out: NULL, or a device block [n_pairs][nq] that receives every pair's match list (out[i].n_matches valid entries each,
+ * ascending queryIdx) -- what a caller gathers beside the pose records (needs refit = 0).
+ * Statistics of the last mlpl_pair_pose_batch_dev call: {RANSAC passes, pair slots summed over the passes, pairs redone by the
+ * single-pair pipeline because a device-evaluated iteration bound differed from the host's libm, host microseconds spent drawing the
+ * sample tables, essential matrices scored, Sampson evaluations (matrices x correspondences), RANSAC iterations executed, 0}. */
+int mlpl_pair_batch_last_stats(mlpl_ctx *ctx, long long stats[8]);
 
 /* Building blocks, exposed for parity tests and for callers that schedule the phases themselves. */
 /* 5-point minimal solver, one wavefront per sample: samples = n_samples x 5 indices into p1/p2 (host).

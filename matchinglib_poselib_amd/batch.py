@@ -58,6 +58,32 @@ def gather_records(local: np.ndarray, num_pairs: int, rank: int, world: int, dev
     return rec
 
 
+def gather_match_lists(local, num_pairs: int, rank: int, world: int, root: int = 0, group=None):
+    """The padded match lists of every rank's pairs on `root` (RCCL has no gather -- grouped send / recv to the root; over
+    xGMI every peer -> root transfer rides its own link).  local: torch tensor [shard, nq, 4] int32 (cv::DMatch rows; the number of valid
+    rows per pair travels with the records).  Returns [num_pairs, nq, 4] in pair order on the root, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return local[:num_pairs]
+    nq = local.shape[1]
+    sizes = [pair_shard(num_pairs, r, world) for r in range(world)]
+    if rank == root:
+        out = torch.empty((num_pairs, nq, 4), dtype=local.dtype, device=local.device)
+        b, e = sizes[root]
+        out[b:e] = local[: e - b]
+        ops = [dist.P2POp(dist.irecv, out[sizes[r][0]:sizes[r][1]], r, group=group) for r in range(world) if r != root and sizes[r][1] > sizes[r][0]]
+    else:
+        out = None
+        b, e = sizes[rank]
+        ops = [dist.P2POp(dist.isend, local[: e - b].contiguous(), root, group=group)] if e > b else []
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return out
+
+
 class _PairResult(C.Structure):
     _fields_ = [("n_matches", C.c_int32), ("n_inliers", C.c_int32), ("n_good", C.c_int32), ("status", C.c_int32), ("iters", C.c_int32),
                 ("pad", C.c_int32), ("E", C.c_double * 9), ("R", C.c_double * 9), ("t", C.c_double * 3)]
@@ -94,10 +120,11 @@ def process_pair_on_device(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, th_pix:
 
 
 def process_pairs_batched(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, seeds, th_pix: float = 0.8, max_iters: int = 1000,
-                          confidence: float = 0.999, refit: bool = False, dist: float = 50.0, pair_ids=None) -> np.ndarray:
+                          confidence: float = 0.999, refit: bool = False, dist: float = 50.0, pair_ids=None, matches_out=None) -> np.ndarray:
     """A batch of image pairs in ONE library call (mlpl_pair_pose_batch_dev): device tensors d_q [B, nq, nbytes] uint8, d_t [B, nt, nbytes],
     d_kp1 [B, nq, 2] float32, d_kp2 [B, nt, 2]; seeds: B RANSAC seeds.  The pair is a grid dimension of every launch -- no host threads, a
-    handful of host hops per 64 pairs -- and every record equals process_pair_on_device's for that pair.  Returns B RECORD_DTYPE records."""
+    handful of host hops per 128 pairs -- and every record equals process_pair_on_device's for that pair.  matches_out: optional int32
+    CUDA tensor [B, nq, 4] that receives the match lists (cv::DMatch rows, n_matches valid per pair).  Returns B RECORD_DTYPE records."""
     import torch
 
     B = d_q.shape[0]
@@ -111,9 +138,12 @@ def process_pairs_batched(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, seeds, t
     assert len(sd) == B
     res = (_PairResult * B)()
     st = torch.cuda.current_stream(d_q.device).cuda_stream
+    if matches_out is not None:
+        assert matches_out.is_cuda and matches_out.dtype == torch.int32 and matches_out.shape == (B, d_q.shape[1], 4) and matches_out.is_contiguous()
     check(ctx.lib.mlpl_pair_pose_batch_dev(ctx.handle, B, d_q.data_ptr(), d_q.shape[1], d_t.data_ptr(), d_t.shape[1], d_q.shape[2], d_kp1.data_ptr(),
                                            d_kp2.data_ptr(), k0, k1, float(th), int(max_iters), float(confidence), 1 if refit else 0, sd.ctypes.data,
-                                           float(dist), C.addressof(res), st), "mlpl_pair_pose_batch_dev")
+                                           float(dist), C.addressof(res), matches_out.data_ptr() if matches_out is not None else None, st),
+          "mlpl_pair_pose_batch_dev")
     rec = np.zeros(B, RECORD_DTYPE)
     rec["pair_id"] = np.arange(B) if pair_ids is None else np.asarray(pair_ids)
     for i in range(B):
@@ -142,17 +172,23 @@ class PairWorkers:
         self.scratch = [{} for _ in range(workers)]
         self.pool = ThreadPoolExecutor(max_workers=workers)
         self.workers = workers
+        self.last_call_ms = [[] for _ in range(workers)]
 
     def _run(self, w, jobs, K0, K1, kw):
         import torch
 
-        out = []
+        import time
+
+        out, ms = [], []
         torch.cuda.set_device(self.device)
         with torch.cuda.stream(self.streams[w]):
             for pair_id, seed, (d_q, d_t, d_kp1, d_kp2) in jobs:
+                t0 = time.perf_counter()
                 out.append(process_pair_on_device(self.ctxs[w], d_q, d_t, d_kp1, d_kp2, K0, K1, seed=seed, pair_id=pair_id,
                                                   scratch=self.scratch[w], **kw))
+                ms.append(time.perf_counter() - t0)
             self.streams[w].synchronize()
+        self.last_call_ms[w] = ms   # wall time of every library call of this worker in the last process(): tells which call stalled
         return out
 
     def process(self, pairs, K0, K1, seeds=None, pair_ids=None, **kw) -> np.ndarray:

@@ -115,7 +115,7 @@ struct mlpl_ctx {
     double *usac_trace;                                // diagnostics: host buffer for the decision records of USAC (16 doubles each)
     int usac_trace_cap, usac_trace_len;
     long long last_usac_stats[8];
-    long long last_batch_stats[4];                     // mlpl_pair_pose_batch_dev: {RANSAC passes, pair slots over all passes, pairs redone on a host table, 0}
+    long long last_batch_stats[8];                     // mlpl_pair_pose_batch_dev: {RANSAC passes, pair slots over all passes, pairs redone on a host table, 0}
     int opt_pair_batch;                                // pairs per internal batch of mlpl_pair_pose_batch_dev (0 = 128)
     int opt_arrsac_flag_points;                        // tests: correspondences every ARRSAC model is tested on up front (0 = 1024)
     int opt_usac_lo_stepwise;                          // tests: every step of a local-optimisation chain goes through the resume path

@@ -26,7 +26,7 @@ constexpr int kBatchPairsPerCall = 128;  // pairs per internal batch (workspace 
 
 int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
                         const float *d_kp2, const double K0[4], const double K1[4], double thresh, int max_iters, double confidence,
-                        const uint32_t *seeds, double dist, mlpl_pair_result *out, hipStream_t s) {
+                        const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out, hipStream_t s) {
     const int NQ = nq;
     const size_t n = (size_t)NQ;
     int rc;
@@ -43,7 +43,7 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
     void *blk = nullptr;
     if ((rc = ws_get(ctx, WS_PIPE, off_small + sm_end + 256, &blk))) return rc;
     char *b0 = (char *)blk, *sm = b0 + off_small;
-    mlpl_dmatch *d_m = (mlpl_dmatch *)(b0 + off_match);
+    mlpl_dmatch *d_m = d_matches_out ? d_matches_out : (mlpl_dmatch *)(b0 + off_match);  // the caller's [B][nq] block, or the workspace
     double *d_p1 = (double *)(b0 + off_p1), *d_p2 = (double *)(b0 + off_p2);
     uint8_t *d_mask = (uint8_t *)(b0 + off_mask), *d_cmask = (uint8_t *)(b0 + off_cmask);
     int32_t *d_counts = (int32_t *)(sm + sm_counts), *d_active = (int32_t *)(sm + sm_active), *d_cc = (int32_t *)(sm + sm_cc);
@@ -151,11 +151,14 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
         MLPL_HIP_TRY(hipMemcpyAsync(d_slots, h_slots, (size_t)A * sizeof(PairSlot), hipMemcpyHostToDevice, s));
         MLPL_HIP_TRY(hipMemsetAsync(d_dense_total, 0, (size_t)A * 4, s));
         const int total_hyps = A * Hp;
+        prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
         hipLaunchKernelGGL(solve5pt_kernel, dim3(total_hyps), dim3(64), 0, s, (const double *)d_p1, (const double *)d_p2, (const int32_t *)d_smp_mapped, 0,
                            total_hyps, d_recs, (const PairSlot *)d_slots, Hp);
         MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3(total_hyps / kHypPerWave), s, (const PolyRec *)d_recs, 0, total_hyps, d_Etab, d_nm, d_denseE,
                           d_dense_id, d_dense_total, d_good, Hp);
+        prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
         // inlier counts: blockIdx.z = slot, the slot's dense model list against the slot's pair
+        prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
         {
             const int point_splits = std::max(1, std::min(8, ((max_n + kScoreTile - 1) / kScoreTile) / 2));
             const dim3 grid((Hp * 10 + kScoreModels - 1) / kScoreModels, point_splits, A);
@@ -163,6 +166,7 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
                                (const double *)d_denseE, (const int32_t *)d_dense_id, (const int32_t *)d_dense_total, 0, thresh2, qmax, d_good,
                                (const PairSlot *)d_slots, Hp);
         }
+        prof_mark(ctx, MLPL_PROF_SCORE, 1, s);
         hipLaunchKernelGGL(hyp_max_kernel, dim3((total_hyps + 255) / 256), dim3(256), 0, s, (const int32_t *)d_nm, (const int32_t *)d_good, total_hyps,
                            d_hmax);
         hipLaunchKernelGGL(candidate_kernel, dim3(A), dim3(1024), 0, s, (const int32_t *)d_nm, (const int32_t *)d_good, (const int32_t *)d_hmax, 0, 0,
@@ -217,9 +221,11 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
             MLPL_HIP_TRY(hipMemcpyAsync(d_active, h_active, (size_t)B * 4, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(inlier_mask_kernel, dim3((max_n + 255) / 256, (unsigned)act.size()), dim3(256), 0, s, (const double4 *)nullptr, 0,
                                (const double *)nullptr, thresh2, d_mask, (const PairSlot *)d_slots, (const ReplayState *)d_st, NQ);
+            prof_mark(ctx, MLPL_PROF_RECOVER_POSE, 0, s);
             if ((rc = launch_recover_pose_batch((const char *)d_st + offsetof(ReplayState, E), sizeof(ReplayState), d_p1, d_p2, d_counts, d_active, B, NQ,
                                                 dist, d_mask, d_P, d_cmask, d_cc, d_pose, s)))
                 return rc;
+            prof_mark(ctx, MLPL_PROF_RECOVER_POSE, 1, s);
             MLPL_HIP_TRY(hipMemcpyAsync(h_pose, d_pose, (size_t)B * sizeof(PairPoseDev), hipMemcpyDeviceToHost, s));
             MLPL_HIP_TRY(hipStreamSynchronize(s));  // last hop
             for (int b : act) {
@@ -230,11 +236,19 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
         }
     }
     ctx->last_batch_stats[0] = passes, ctx->last_batch_stats[1] = slots_total, ctx->last_batch_stats[2] = (long long)redo.size(), ctx->last_batch_stats[3] = draw_us;
+    ctx->last_batch_stats[4] = ctx->last_batch_stats[5] = ctx->last_batch_stats[6] = 0;
+    for (int b = 0; b < B; ++b)
+        if (h_counts[b] >= 16) {
+            ctx->last_batch_stats[4] += state[b].models_scored;
+            ctx->last_batch_stats[5] += state[b].models_scored * (long long)h_counts[b];
+            ctx->last_batch_stats[6] += state[b].iter;
+        }
     // the rare pairs whose iteration bound has to come from the host table: the single-pair pipeline on their inputs
     for (int b : redo) {
         ctx->ransac_force_table = 1;
         rc = mlpl_pair_pose_dev(ctx, d_q + (size_t)b * nq * nbytes, nq, d_t + (size_t)b * nt * nbytes, nt, nbytes, d_kp1 + (size_t)b * nq * 2,
                                 d_kp2 + (size_t)b * nt * 2, K0, K1, thresh, max_iters, confidence, 0, seeds[b], dist, &out[b], s);
+        // (the caller's match block already holds this pair's matches: the same kernels produced them)
         ctx->ransac_force_table = 0;
         if (rc) return rc;
     }

@@ -73,3 +73,39 @@ def test_gather_records_world2(num_pairs):
     for rank, blob, tmax in got:
         assert blob == expect.tobytes()       # every rank holds all records, in pair order
         assert tmax == float(world)
+
+
+def _match_worker(rank, world, port, num_pairs, nq, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, e = batch.pair_shard(num_pairs, rank, world)
+    cap = batch.shard_capacity(num_pairs, world)
+    local = torch.zeros((cap, nq, 4), dtype=torch.int32)          # padded to the shard capacity, as the bench allocates it
+    for i, pid in enumerate(range(b, e)):
+        local[i] = torch.from_numpy(np.random.default_rng(500 + pid).integers(0, 1 << 20, (nq, 4)).astype(np.int32))
+    out = batch.gather_match_lists(local, num_pairs, rank, world, root=0)
+    q.put((rank, None if out is None else out.numpy().tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_pairs", [5, 8])
+def test_gather_match_lists_world2(num_pairs):
+    """The padded match lists travel to the root by grouped send / recv (RCCL has no gather): root holds them in pair order."""
+    world, nq = 2, 37
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_match_worker, args=(r, world, port, num_pairs, nq, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = np.stack([np.random.default_rng(500 + pid).integers(0, 1 << 20, (nq, 4)).astype(np.int32) for pid in range(num_pairs)])
+    assert got[0] == expect.tobytes() and got[1] is None

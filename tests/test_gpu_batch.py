@@ -74,7 +74,7 @@ def _stack(sps, dev):
 
 
 def test_batched_pairs_equal_the_single_pair_pipeline(ctx):
-    """mlpl_pair_pose_batch_dev: 70 pairs (an internal batch of 64 + 6) of varied inlier ratio and match count -- pairs that stop in the
+    """mlpl_pair_pose_batch_dev: 70 pairs of varied inlier ratio and match count -- pairs that stop in the
     first pass of 324 iterations and pairs that need the second -- give byte-identical records to mlpl_pair_pose_dev pair by pair."""
     dev = torch.device("cuda:0")
     fracs = [0.5, 0.3, 0.7, 0.2, 0.45, 0.9, 0.25]
@@ -85,13 +85,14 @@ def test_batched_pairs_equal_the_single_pair_pipeline(ctx):
                                                        seed=seeds[i], pair_id=i) for i, sp in enumerate(sps)])
     dq, dt, k1, k2 = _stack(sps, dev)
     bat = batch.process_pairs_batched(ctx, dq, dt, k1, k2, K, K, seeds)
-    stats = np.zeros(4, np.int64)
+    stats = np.zeros(8, np.int64)
     ctx.lib.mlpl_pair_batch_last_stats(ctx.handle, stats.ctypes.data)
     for i in range(70):
         assert bat[i].tobytes() == one[i].tobytes(), (i, bat[i], one[i])
     assert (one["status"] == 0).all()
-    assert stats[0] >= 3 and 70 < stats[1] < 140, stats      # a second pass ran, and only for part of the pairs
-    # smaller internal batches give the same records
+    assert stats[0] == 2 and 70 < stats[1] < 140, stats      # a second pass ran, and only for part of the pairs
+    assert stats[6] >= 70 * 20 and stats[4] > stats[6] and stats[5] > 100 * stats[4], stats   # iterations, matrices scored, evaluations
+    # smaller internal batches (16 + 16 + 16 + 16 + 6) give the same records
     ctx.set_option("pair_batch", 16)
     try:
         assert batch.process_pairs_batched(ctx, dq, dt, k1, k2, K, K, seeds).tobytes() == bat.tobytes()
