@@ -780,8 +780,70 @@ int StereoRefine::Impl::poolCorrespondenceDelete(std::vector<size_t> delete_list
     return 0;
 }
 
-// checkPoolSize (:2550-2800).  The reference thins dense image regions first (duplicates per pixel, then image morphology on a density
-// image); here the n_del lowest-weight correspondences go (the reference's own last-resort ordering, :2745-2772).
+// checkPoolSize (:2550-2816): too many correspondences in the pool -> thin it where the image is densely covered.  First the
+// correspondences that share a LEFT pixel (rounded position) with another one go, the best weight of a pixel staying; then a density
+// image of the occupied pixels is dilated with an elliptic element of minPtsDistance and eroded with the next larger one (what survives
+// are pixels inside densely covered regions), the survivors are deleted -- all of them while fewer than the quota, with a growing element,
+// otherwise the lowest weights among them.  cv::getStructuringElement / dilate / erode / findNonZero (OpenCV imgproc, not in the
+// reference's tree) are restated from their published definitions: ellipse rows of half-width round(c * sqrt(1 - dy^2 / r^2)), anchor at
+// the element's centre (size / 2), constant border 0 (the reference passes cv::Scalar(0) for BOTH operations, so the erosion also eats
+// the image border), row-major scan order of findNonZero.
+namespace {
+struct Elem {
+    int w = 0, h = 0;
+    std::vector<uint8_t> k;
+};
+Elem ellipseElement(int size) {  // cv::getStructuringElement(MORPH_ELLIPSE, Size(size, size))
+    Elem e;
+    e.w = e.h = size;
+    e.k.assign((size_t)size * size, 0);
+    const int r = size / 2, c = size / 2;
+    const double inv_r2 = r ? 1. / ((double)r * r) : 0;
+    for (int i = 0; i < size; i++) {
+        int j1 = 0, j2 = 0;
+        const int dy = i - r;
+        if (std::abs(dy) <= r) {
+            const int dx = (int)std::nearbyint(c * std::sqrt((r * r - dy * dy) * inv_r2));  // saturate_cast<int>(double) = cvRound
+            j1 = std::max(c - dx, 0);
+            j2 = std::min(c + dx + 1, size);
+        }
+        for (int j = j1; j < j2; j++) e.k[(size_t)i * size + j] = 1;
+    }
+    return e;
+}
+// dst(y, x) = max (dilate) / min (erode) of src(y + i - ay, x + j - ax) over the element's non-zero cells, 0 outside the image
+void morph(const std::vector<uint8_t> &src, std::vector<uint8_t> &dst, int W, int H, const Elem &e, bool dilate) {
+    const int ax = e.w / 2, ay = e.h / 2;
+    std::vector<std::pair<int, int>> offs;
+    for (int i = 0; i < e.h; ++i)
+        for (int j = 0; j < e.w; ++j)
+            if (e.k[(size_t)i * e.w + j]) offs.emplace_back(i - ay, j - ax);
+    dst.assign((size_t)W * H, dilate ? 0 : 255);
+    if (dilate) {  // scatter from the (few) set pixels
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x)
+                if (src[(size_t)y * W + x])
+                    for (const auto &o : offs) {
+                        const int yy = y - o.first, xx = x - o.second;
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) dst[(size_t)yy * W + xx] = 255;
+                    }
+    } else {
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                uint8_t v = 255;
+                for (const auto &o : offs) {
+                    const int yy = y + o.first, xx = x + o.second;
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= W || !src[(size_t)yy * W + xx]) {
+                        v = 0;
+                        break;
+                    }
+                }
+                dst[(size_t)y * W + x] = v;
+            }
+    }
+}
+}  // namespace
+
 int StereoRefine::Impl::checkPoolSize(long long maxPoolSize) {
     size_t n_del = 0;
     const size_t pool_Size = correspondencePool.size();
@@ -793,15 +855,113 @@ int StereoRefine::Impl::checkPoolSize(long long maxPoolSize) {
         if (pool_Size > 20) n_del = pool_Size / 2;
         else return 0;
     }
-    std::vector<std::pair<double, size_t>> w;
-    w.reserve(pool_Size);
-    for (auto &c : correspondencePool)
-        w.emplace_back(computeCorrespondenceWeight(c.SampsonErrors.back(), c.descrDist, c.keyPResponses[0], c.keyPResponses[1], c.Q_tooFar,
-                                                   c.Q[2]),
-                       c.poolIdx);
-    std::stable_sort(w.begin(), w.end(), [](const std::pair<double, size_t> &x, const std::pair<double, size_t> &y) { return x.first < y.first; });
     std::vector<size_t> delIdx(n_del);
-    for (size_t i = 0; i < n_del; ++i) delIdx[i] = w[i].second;
+    size_t delIdxIdx = 0;
+    const int W = cfg_usac.imgSize.width, H = cfg_usac.imgSize.height;
+    auto weightOf = [&](size_t poolIdx) {
+        const CoordinateProps &c = *correspondencePoolIdx[poolIdx];
+        return computeCorrespondenceWeight(c.SampsonErrors.back(), c.descrDist, c.keyPResponses[0], c.keyPResponses[1], c.Q_tooFar, c.Q[2]);
+    };
+    // pool indices per (rounded) left pixel, in pool order; pixels holding more than one in the order they got their second
+    std::unordered_map<long long, std::vector<size_t>> idxPos;
+    std::vector<std::pair<int, int>> posMultCorrs;  // (x, y)
+    auto keyOf = [&](int x, int y) { return (long long)y * (long long)W + x; };
+    for (auto &c : correspondencePool) {
+        const int y = (int)std::round(c.pt1.y), x = (int)std::round(c.pt1.x);
+        if (x < 0 || y < 0 || x >= W || y >= H)
+            throw cv::Exception("StereoRefine::checkPoolSize: a pool correspondence lies outside cfg_usac.imgSize (the reference indexes an image-sized table with it)");
+        std::vector<size_t> &v = idxPos[keyOf(x, y)];
+        v.push_back(c.poolIdx);
+        if (v.size() == 2) posMultCorrs.emplace_back(x, y);
+    }
+    if (!posMultCorrs.empty()) {
+        std::vector<std::pair<size_t, size_t>> idx1;
+        std::vector<size_t> nr_entries(posMultCorrs.size());
+        for (size_t i = 0; i < posMultCorrs.size(); i++) {
+            nr_entries[i] = idxPos[keyOf(posMultCorrs[i].first, posMultCorrs[i].second)].size();
+            for (size_t j = 0; j < nr_entries[i]; j++) idx1.emplace_back(i, j);
+        }
+        const size_t n_multi = idx1.size() - posMultCorrs.size();
+        if (n_multi <= n_del) {
+            for (auto &pm : posMultCorrs) {
+                std::vector<size_t> &cell = idxPos[keyOf(pm.first, pm.second)];
+                std::vector<std::pair<double, size_t>> w;
+                for (size_t j = 0; j < cell.size(); j++) w.emplace_back(weightOf(cell[j]), j);
+                std::sort(w.begin(), w.end(), [](const std::pair<double, size_t> &f, const std::pair<double, size_t> &g) { return f.first > g.first; });
+                for (size_t j = 1; j < w.size(); j++) delIdx[delIdxIdx++] = cell[w[j].second];
+                const size_t keep = cell[w[0].second];
+                cell.clear();
+                cell.push_back(keep);
+            }
+            n_del -= n_multi;
+        } else {
+            // (the reference sizes this vector with idx1.size() value-initialised entries and then APPENDS the real ones: the first
+            // idx1.size() entries are (0.0, 0) and sort to the front -- they point at entry 0 of idx1 again and again, whose pixel loses
+            // one correspondence per visit while it has more than one.  Kept as it is: it decides which correspondences go.)
+            std::vector<std::pair<double, size_t>> w(idx1.size());
+            for (size_t i = 0; i < idx1.size(); i++) {
+                const auto &pm = posMultCorrs[idx1[i].first];
+                w.emplace_back(weightOf(idxPos[keyOf(pm.first, pm.second)][idx1[i].second]), i);
+            }
+            std::sort(w.begin(), w.end(), [](const std::pair<double, size_t> &f, const std::pair<double, size_t> &g) { return f.first < g.first; });
+            for (size_t i = 0, count = 0; i < w.size(); i++) {
+                const auto &ent = idx1[w[i].second];
+                if (nr_entries[ent.first] > 1) {
+                    const auto &pm = posMultCorrs[ent.first];
+                    delIdx[delIdxIdx++] = idxPos[keyOf(pm.first, pm.second)][ent.second];
+                    nr_entries[ent.first]--;
+                    count++;
+                }
+                if (count >= n_del) break;
+            }
+            n_del = 0;
+        }
+    }
+    if (n_del) {
+        std::vector<uint8_t> density((size_t)W * H, 0), init, tmp;
+        for (auto &c : correspondencePool) density[(size_t)((int)std::round(c.pt1.y)) * W + (int)std::round(c.pt1.x)] = 255;
+        init = density;
+        const double mpd = (double)cfg_pose.minPtsDistance;
+        const double frac = mpd - std::ceil(mpd);
+        int erosion_size = (frac < 1e-3 && frac > -1e-3) ? (int)std::ceil(mpd) + 1 : (int)std::ceil(mpd);  // nearZero (pose_helper.h:82)
+        int nr_erosions = 0;
+        do {
+            morph(density, tmp, W, H, ellipseElement(erosion_size), true);
+            morph(tmp, density, W, H, ellipseElement(erosion_size + 1), false);
+            for (size_t i = 0; i < density.size(); ++i) density[i] &= init[i];
+            std::vector<std::pair<int, int>> locations;  // (x, y), row-major scan (cv::findNonZero)
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x)
+                    if (density[(size_t)y * W + x]) locations.emplace_back(x, y);
+            size_t n_loc = locations.size();
+            if (n_loc <= n_del && nr_erosions < 100) {
+                for (auto &l : locations) delIdx[delIdxIdx++] = idxPos[keyOf(l.first, l.second)][0];
+                n_del -= n_loc;
+                if (n_del) {
+                    for (size_t i = 0; i < density.size(); ++i) density[i] = (uint8_t)(~density[i]) & init[i];
+                    init = density;
+                    erosion_size++;
+                    nr_erosions++;
+                }
+            } else {
+                if (nr_erosions >= 100) {
+                    locations.clear();
+                    for (int y = 0; y < H; ++y)
+                        for (int x = 0; x < W; ++x)
+                            if (init[(size_t)y * W + x]) locations.emplace_back(x, y);
+                    n_loc = locations.size();
+                }
+                std::vector<std::pair<double, size_t>> w(n_loc);
+                for (size_t i = 0; i < n_loc; ++i) w[i] = std::make_pair(weightOf(idxPos[keyOf(locations[i].first, locations[i].second)][0]), i);
+                std::sort(w.begin(), w.end(), [](const std::pair<double, size_t> &f, const std::pair<double, size_t> &g) { return f.first < g.first; });
+                for (size_t i = 0; i < n_del; i++) {
+                    const auto &l = locations[w[i].second];
+                    delIdx[delIdxIdx++] = idxPos[keyOf(l.first, l.second)][0];
+                }
+                n_del = 0;
+            }
+        } while (n_del);
+    }
     if (poolCorrespondenceDelete(delIdx)) return -1;
     maxPoolSizeReached = true;
     return 0;

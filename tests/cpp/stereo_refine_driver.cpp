@@ -58,6 +58,7 @@ int main(int argc, char **argv) {
     cfg.refineRTold_CorrPool = c[19] != 0;
     cfg.autoTH = c[20] != 0;
     poselib::ConfigUSAC cfg_usac;
+    cfg_usac.imgSize = cv::Size(1408, 1056);  // every keypoint of the test scenes lies inside (StereoRefine::checkPoolSize indexes an image-sized table)
     poselib::setRansacSeed(seed);
     poselib::StereoRefine sr(cfg);
     FILE *o = fopen(argv[2], "wb");

@@ -182,6 +182,8 @@ class StereoRefineOracle:
         self.pix2cam = 4.0 / (math.sqrt(2.0) * (K0[0] + K0[1] + K1[0] + K1[1]))  # :151-153
         self.th = cfg.th_pix_user * self.pix2cam
         self.th2 = self.th * self.th
+        self.shrink_log = []
+        self.img_size = (800, 600)   # ConfigUSAC's default imgSize (pose_estim.h:112): checkPoolSize indexes an image-sized table with it
         self.check_parameters()
         self.descr_max = F32(0)
         self.resp_max = F32(0)
@@ -424,7 +426,13 @@ class StereoRefineOracle:
         if not self.pool:
             self.q_all = self.q_far = 0
 
-    def shrink_pool(self, max_size):  # checkPoolSize :2550-2800 in the library's documented form (lowest weights go)
+    def shrink_pool(self, max_size):  # checkPoolSize :2550-2816
+        """Too many correspondences: thin the pool where the left image is densely covered.  (1) correspondences that share a rounded left
+        pixel with another one: all but the best weight of a pixel go -- or, when there are more of them than the quota, the reference's loop
+        over a weight list that starts with len(idx1) value-initialised (0.0, 0) entries; (2) density image of the occupied pixels, dilated with
+        the elliptic element of minPtsDistance and eroded with the next larger one, AND-ed with the occupied pixels: what is left lies inside
+        dense regions and goes -- everything while fewer than the quota (then the element grows), else the lowest weights among them.
+        An independent restatement (numpy shifts; OpenCV's element / anchor / border conventions from their published definitions)."""
         n = len(self.pool)
         if max_size < 0 and n > 20:
             n_del = n // 2
@@ -437,9 +445,96 @@ class StereoRefineOracle:
                 n_del = n // 2
             else:
                 return
-        w = [self.weight(c["errs"][-1], c["dd"], c["r1"], c["r2"], c["far"], c["Q"][2]) for c in self.pool]
-        order = sorted(range(n), key=lambda i: w[i])  # stable
-        self.delete_from_pool(order[:n_del])
+        W, H = self.img_size
+        wgt = lambda i: self.weight(self.pool[i]["errs"][-1], self.pool[i]["dd"], self.pool[i]["r1"], self.pool[i]["r2"], self.pool[i]["far"],  # noqa: E731
+                                    self.pool[i]["Q"][2])
+        pix = [(int(round_half_away(float(c["pt1"][0]))), int(round_half_away(float(c["pt1"][1])))) for c in self.pool]   # (x, y)
+        cells, multi = {}, []
+        for i, xy in enumerate(pix):
+            assert 0 <= xy[0] < W and 0 <= xy[1] < H
+            cells.setdefault(xy, []).append(i)
+            if len(cells[xy]) == 2:
+                multi.append(xy)
+        dele = []
+        rounds_done, by_weight = 0, False
+        if multi:
+            idx1 = [(m, j) for m, xy in enumerate(multi) for j in range(len(cells[xy]))]
+            nr = [len(cells[xy]) for xy in multi]
+            n_multi = len(idx1) - len(multi)
+            if n_multi <= n_del:
+                for xy in multi:
+                    order = sorted(range(len(cells[xy])), key=lambda j: -wgt(cells[xy][j]))
+                    dele += [cells[xy][j] for j in order[1:]]
+                    cells[xy] = [cells[xy][order[0]]]
+                n_del -= n_multi
+            else:
+                lst = [(0.0, 0)] * len(idx1) + [(wgt(cells[multi[m]][j]), k) for k, (m, j) in enumerate(idx1)]
+                lst.sort(key=lambda t: t[0])
+                count = 0
+                for _, k in lst:
+                    m, j = idx1[k]
+                    if nr[m] > 1:
+                        dele.append(cells[multi[m]][j])
+                        nr[m] -= 1
+                        count += 1
+                    if count >= n_del:
+                        break
+                n_del = 0
+        if n_del:
+            dens = np.zeros((H, W), bool)
+            for x, y in pix:
+                dens[y, x] = True
+            init = dens.copy()
+
+            def ellipse(size):
+                k = np.zeros((size, size), bool)
+                r = c = size // 2
+                for i in range(size):
+                    dy = i - r
+                    if abs(dy) <= r:
+                        dx = int(np.rint(c * np.sqrt((r * r - dy * dy) / (r * r)))) if r else 0
+                        k[i, max(c - dx, 0):min(c + dx + 1, size)] = True
+                return k
+
+            def shifted(img, dy, dx):   # out[y, x] = img[y + dy, x + dx], False outside
+                out = np.zeros_like(img)
+                ys, xs = slice(max(0, -dy), H - max(0, dy)), slice(max(0, -dx), W - max(0, dx))
+                yd, xd = slice(max(0, dy), H - max(0, -dy)), slice(max(0, dx), W - max(0, -dx))
+                out[ys, xs] = img[yd, xd]
+                return out
+
+            def morph(img, k, dilate):
+                a = k.shape[0] // 2
+                acc = np.zeros_like(img) if dilate else np.ones_like(img)
+                for i, j in zip(*np.nonzero(k)):
+                    sh = shifted(img, i - a, j - a)
+                    acc = (acc | sh) if dilate else (acc & sh)
+                return acc
+
+            mpd = float(self.cfg.minPtsDistance)
+            size = int(np.ceil(mpd)) + 1 if near_zero(mpd - np.ceil(mpd)) else int(np.ceil(mpd))
+            rounds = 0
+            while n_del:
+                dens = morph(morph(dens, ellipse(size), True), ellipse(size + 1), False) & init
+                loc = [(x, y) for y, x in zip(*np.nonzero(dens))]      # row-major, as cv::findNonZero
+                rounds_done += 1
+                if len(loc) <= n_del and rounds < 100:
+                    dele += [cells[xy][0] for xy in loc]
+                    n_del -= len(loc)
+                    if n_del:
+                        dens = ~dens & init
+                        init = dens.copy()
+                        size += 1
+                        rounds += 1
+                else:
+                    if rounds >= 100:
+                        loc = [(x, y) for y, x in zip(*np.nonzero(init))]
+                    by_weight = True
+                    order = sorted(range(len(loc)), key=lambda i: wgt(cells[loc[i]][0]))
+                    dele += [cells[loc[i]][0] for i in order[:n_del]]
+                    n_del = 0
+        self.shrink_log.append(dict(deleted=len(dele), shared_pixels=len(multi), density_rounds=rounds_done, by_weight=by_weight))
+        self.delete_from_pool(dele)
         self.max_pool_reached = True
 
     # ---- rating / stability ---------------------------------------------------------------------------------------------------------------

@@ -11,7 +11,8 @@ from stereo_refine_oracle import Cfg, StereoRefineOracle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "stereo_refine_driver")
-K = np.array([800.0, 800.0, 320.0, 240.0])
+K = np.array([800.0, 800.0, 640.0, 480.0])   # principal point such that every keypoint of the scenes lies inside IMG_SIZE
+IMG_SIZE = (1408, 1056)                      # cfg_usac.imgSize: StereoRefine::checkPoolSize indexes an image-sized table with the pool's left keypoints
 
 
 def rot(rx, ry, rz):
@@ -37,7 +38,7 @@ def frame(rng, n, pose, outlier_frac, noise_px=0.15, dist=None):
     p1 = x1 * K[:2] + K[2:] + rng.normal(0, noise_px, (n, 2))
     p2 = x2 * K[:2] + K[2:] + rng.normal(0, noise_px, (n, 2))
     bad = rng.random(n) < outlier_frac
-    p2[bad] = np.stack([rng.uniform(0, 640, bad.sum()), rng.uniform(0, 480, bad.sum())], 1)
+    p2[bad] = np.stack([rng.uniform(320, 960, bad.sum()), rng.uniform(240, 720, bad.sum())], 1)
     dd = np.where(bad, rng.uniform(50, 100, n), rng.uniform(15, 70, n))
     kp1 = np.concatenate([p1, rng.uniform(0.001, 0.1, (n, 1))], 1).astype(np.float32)
     kp2 = np.concatenate([p2, rng.uniform(0.001, 0.1, (n, 1))], 1).astype(np.float32)
@@ -91,7 +92,9 @@ def run_oracle(oracle, name, seed=777):
     cfg, method, dist, frames = sequence(name)
     d0, d1 = (np.zeros(8), np.zeros(8)) if dist is None else dist
     sr = StereoRefineOracle(oracle, cfg, K, K, d0, d1, seed)
+    sr.img_size = IMG_SIZE
     out = []
+    run_oracle.last = sr
     for kp1, kp2, dd in frames:
         rc = sr.add(kp1, kp2, dd)
         out.append(dict(rc=rc, inl=sr.nr_inliers, corrs=sr.nr_corrs, pool=len(sr.pool), est=sr.nr_est, skip=sr.skip,
@@ -151,6 +154,9 @@ def test_oracle_state_machine_runs_the_expected_branches(oracle, name):
         assert -3 in [o["rc"] for o in out] and any(o["pool"] == 0 for o in out)
     elif name == "small_pool":
         assert max(o["pool"] for o in out) <= 1300 and out[-1]["stable"] == 1  # stable through the error-range overlap fallback
+        log = run_oracle.last.shrink_log      # checkPoolSize ran its density-image thinning: dilate / erode rounds and the weight-ordered rest
+        assert len(log) >= 5 and all(e["density_rounds"] >= 1 for e in log) and any(e["by_weight"] for e in log), log
+        assert any(e["density_rounds"] >= 2 for e in log) or any(e["shared_pixels"] for e in log), log
     elif name == "weak_start_few_matches":
         assert out[0]["est"] == 0 and out[0]["pool"] == 0 and out[1]["est"] == 1
 
