@@ -2,10 +2,11 @@
 """bench.py -- descriptor-pairs/s of the brute-force Hamming 2-NN + ratio hot path on MI355X.
 
 A step = one pass of getMatches("LINEAR") device path (knn2_hamming partial + merge + ratio/compaction) over one
-batch of `--pairs-per-gpu` (default 8) synthetic image pairs of BASELINE config C2 (8192 x 8192 ORB-256 each), one batched
-launch per kernel, inputs resident in HBM.  The single-pair (latency) figure is reported under extras.  One process per GPU; image pairs shard across ranks with no data-path collective (weak scaling); with N > 1
-the fixed-size per-pair result records (match counts) of every 8 steps (= a rank's 64-pair share of a C5 batch) are gathered by one
-asynchronous RCCL all_gather that overlaps the next block's kernels.
+batch of `--pairs-per-gpu` (default 64 = a rank's share of BASELINE's 512-pair batch on 8 GPUs; rounds 1-2 used 8, still reported as
+value_8_pairs_per_launch) synthetic image pairs of BASELINE config C2 (8192 x 8192 ORB-256 each), one batched
+launch per kernel, inputs resident in HBM.  The single-pair (latency) figure is reported beside it.  One process per GPU; image pairs shard across ranks with no data-path collective (weak scaling); with N > 1
+the fixed-size per-pair result records (match counts) of every step (= a rank's 64-pair share of a C5 batch) are gathered by one
+asynchronous RCCL all_gather that overlaps the next step's kernels.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured live with HIP events inside the library,
 see mlpl_profile_*) and `cpu_baseline` (the oracle's single-thread LUT port timed on this host).
@@ -222,7 +223,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--pairs-per-gpu", type=int, default=8, help="image pairs per rank per step (one batched launch)")
+    ap.add_argument("--pairs-per-gpu", type=int, default=64, help="image pairs per rank per step (one batched launch per kernel)")
     ap.add_argument("--n", type=int, default=8192, help="descriptors per image")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-queries", type=int, default=8192)
@@ -231,7 +232,7 @@ def main():
                     help="bracket every Nth launch of the dominant kernel inside the timed region (two event records cost ~10 us)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--gather-every", type=int, default=8, help="steps per record gather (N > 1): 8 steps x 8 pairs = a C5 shard of 64 pairs")
+    ap.add_argument("--gather-every", type=int, default=1, help="steps per record gather (N > 1): one step of 64 pairs = a C5 shard")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (RANSAC / L2) measurements")
     ap.add_argument("--hamming-variant", type=int, default=3,
                     help="3 = fp4 matrix-core kernel (library default), 0/1/2 = the integer VALU kernels")
@@ -357,7 +358,7 @@ def main():
     # the ratio test, the rest (almost) never do
     assert all(abs(c - n // 2) <= max(8, n // 100) for c in counts), f"match counts {counts} are not ~{n // 2}"
     # the literal config 2 (ONE image pair per launch, latency shape) beside the batched headline
-    single_ms = None
+    single_ms = eight_ms = None
     if rank == 0:
         o1 = match_hamming_device(d_q[:1], d_t[:1], ratio_test=True, ratio=0.75, ctx=ctx, stream=stream)
         torch.cuda.synchronize()
@@ -369,6 +370,16 @@ def main():
         torch.cuda.synchronize()
         single_ms = e0.elapsed_time(e1) / 50
         assert int(o1["count"][0].item()) == counts[0] or P == 0
+        eight_ms = None
+        if P >= 8:   # the launch shape of rounds 1-2 (8 pairs per launch), for continuity
+            o8 = match_hamming_device(d_q[:8], d_t[:8], ratio_test=True, ratio=0.75, ctx=ctx, stream=stream)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(50):
+                o8 = match_hamming_device(d_q[:8], d_t[:8], ratio_test=True, ratio=0.75, ctx=ctx, out=o8, stream=stream)
+            e1.record()
+            torch.cuda.synchronize()
+            eight_ms = e0.elapsed_time(e1) / 50
     if world > 1:  # every rank must hold every rank's records after the last gather
         lastb = ((step_no - 1) // G) & 1
         g = gathered[lastb].cpu().numpy().reshape(world, G * P)
@@ -379,12 +390,15 @@ def main():
         hbm_equiv = pairs_per_step_rank * BYTES_PER_PAIR / (kern_ms * 1e-3) / 1e9   # north_star's "HBM-roofline GB/s" reading
         mfma_path = args.hamming_variant == 3
         kernel_name = "knn_hamming_mfma_lds_kernel<4, 0>" if mfma_path else "knn_hamming_partial_kernel<8>"
+        # traffic was measured with 8 pairs per launch: scale the per-launch figure to this run's launch size (it is per-pair work)
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
                 traffic = tj.get("knn_hamming_mfma_bytes_per_launch" if mfma_path else "knn_hamming_partial_bytes_per_launch")
+                if traffic and tj.get("pairs_per_launch"):
+                    traffic = traffic * P / float(tj["pairs_per_launch"])
                 traffic_src = f"from profiles/pmc_traffic.json (round {tj.get('round', '?')}, {tj.get('pairs_per_launch', '?')} pairs per " \
                               "launch; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes) -- not measured in this run"
             except Exception:
@@ -456,10 +470,13 @@ def main():
             "config": {
                 "workload": f"C2: {n}x{n} ORB-256 BF-Hamming kNN=2 + 0.75 ratio + DMatch compaction, "
                             f"{P} image pair(s) per GPU per step",
-                "value_is": f"the BATCHED rate: {P} independent C2 image pairs per launch per GPU (a rank's slice of a C5 batch); "
-                            "value_single_pair is the same path with ONE pair per launch (the literal config 2, latency shape)",
+                "value_is": f"the BATCHED rate: {P} independent C2 image pairs per launch per GPU (a rank's share of BASELINE's 512-pair batch "
+                            "on 8 GPUs); value_8_pairs_per_launch is the launch shape rounds 1-2 reported, value_single_pair the same path "
+                            "with ONE pair per launch (the literal config 2, latency shape)",
                 "value_single_pair": (n * n / (single_ms * 1e-3)) if single_ms else None,
                 "ms_single_pair": single_ms,
+                "value_8_pairs_per_launch": (8 * n * n / (eight_ms * 1e-3)) if eight_ms else None,
+                "ms_8_pairs_per_launch": eight_ms,
                 "pairs_per_gpu": P,
                 "world_size": world,
                 "backend": args.backend if world > 1 else None,
