@@ -377,9 +377,10 @@ int mlpl_median_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n,
  * scored}.  Used by bench.py to turn the scoring kernel's time into algorithmic FLOP/s. */
 int mlpl_ransac_last_stats(mlpl_ctx *ctx, long long stats[2]);
 
-/* Diagnostics: root-iteration (Ehrlich-Aberth) sweep statistics of the solver since the last call ({sum, solves, max}); enable != 0 turns
- * the (atomic) bookkeeping on.  Not for production use. */
-int mlpl_debug_dk_stats(mlpl_ctx *ctx, int enable, int stats[3]);
+/* Diagnostics: root-iteration (Ehrlich-Aberth) sweep statistics of the solver since the last call: {sum, solves, max, (enabled), sample
+ * index of the max, solves with <= 8, 12, 16, 24, 32, 64, 128, 256, < 400, = 400 sweeps, 0}; enable != 0 turns the (atomic) bookkeeping on.
+ * Not for production use. */
+int mlpl_debug_dk_stats(mlpl_ctx *ctx, int enable, int stats[16]);
 
 /* Diagnostics: with option "hamming_stamps" = 1 every wave of the matrix-core Hamming kernel records {shader-clock cycles, 100 MHz
  * real-time ticks, 32x32 tiles processed, start tick}; this copies up to max_items records of 4 x u64 of the LAST launch to `out`

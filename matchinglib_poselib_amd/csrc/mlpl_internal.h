@@ -99,6 +99,7 @@ struct mlpl_ctx {
     int opt_ransac_overlap;         // 1 (default) = large passes run their root kernels on the helper stream
     int opt_ransac_lazy_sums;       // 1 (default) = division-free inlier counts + error sums only for models that can still win
     int opt_solver_polish;          // 1 (default) = Gauss-Newton polish of every 5-point solution on the cubic constraints
+    int opt_solver_wave3;           // 1 (default) = solve5pt3_kernel (three hypotheses per wave, matrices in registers); 0 = one per wave
     int opt_ransac_host_table;      // 1 = always build the niters table on the host (default: evaluate on the device, verify)
     // cached table T[g] = cvRANSACUpdateNumIters1(conf, (n-g)/n, 5, inf) for the last (n, conf) (host libm values)
     int opt_rand_cache_max;         // tests: values of the rand() stream kept per context (0 = 4 Mi); beyond it a call generates privately

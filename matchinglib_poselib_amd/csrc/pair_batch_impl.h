@@ -152,8 +152,8 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
         MLPL_HIP_TRY(hipMemsetAsync(d_dense_total, 0, (size_t)A * 4, s));
         const int total_hyps = A * Hp;
         prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
-        hipLaunchKernelGGL(solve5pt_kernel, dim3(total_hyps), dim3(64), 0, s, (const double *)d_p1, (const double *)d_p2, (const int32_t *)d_smp_mapped, 0,
-                           total_hyps, d_recs, (const PairSlot *)d_slots, Hp);
+        launch_solve5pt(ctx, total_hyps, s, (const double *)d_p1, (const double *)d_p2, (const int32_t *)d_smp_mapped, 0, total_hyps, d_recs,
+                        (const PairSlot *)d_slots, Hp);
         MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3(total_hyps / kHypPerWave), s, (const PolyRec *)d_recs, 0, total_hyps, d_Etab, d_nm, d_denseE,
                           d_dense_id, d_dense_total, d_good, Hp);
         prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);

@@ -160,7 +160,8 @@ __device__ __forceinline__ void null_vector_3x3(const double *a, double *nv) {
 // Steps 2..6 of the solver, shared by the minimal (5-point) kernel and the refit kernel: EE basis in LDS ->
 // essential matrices.  Returns (per lane) whether this lane holds a valid model in Eout[9].
 // ---------------------------------------------------------------------------------------------------------------
-__device__ int g_dk_iters_dbg[4] = {0, 0, 0, 0};  // [sum, count, max, enabled] -- diagnostics only (tools/)
+__device__ int g_dk_iters_dbg[16] = {0, 0, 0, 0};  // [sum, count, max, enabled, sample of the max, histogram of the sweep counts in
+                                                   //  (<=8, <=12, <=16, <=24, <=32, <=64, <=128, <=256, <400, =400)] -- diagnostics only (tools/)
 
 // Batched passes (pair_batch_impl.h: many image pairs per launch): one record per ACTIVE slot of a pass.  The hypothesis tables of slot a
 // start at a * slot_stride; kernels that take `const PairSlot *ps` pick their per-pair arguments from ps[slot] (ps == nullptr: the
@@ -508,8 +509,14 @@ __device__ __forceinline__ void polish_xyz(const double *EE, double &x, double &
 // registers), reject |xy1[2]| < 1e-10 (:457), E = x E0 + y E1 + z E2 + E3, Frobenius-normalised.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kHypPerWave = 6;
+#ifndef MLPL_ROOTS_WAVES
+#define MLPL_ROOTS_WAVES 2
+#endif
+#ifndef MLPL_SWEEP_CAP
+#define MLPL_SWEEP_CAP 64
+#endif
 template <bool kPolish>  // compile-time: the polished instance does not carry the Jacobi SVD's registers
-__global__ __launch_bounds__(64) void roots_kernel_t(const PolyRec *__restrict__ recs, int sample_offset, int n_samples,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MLPL_ROOTS_WAVES, MLPL_ROOTS_WAVES))) void roots_kernel_t(const PolyRec *__restrict__ recs, int sample_offset, int n_samples,
                                                    double *__restrict__ E_tab, int32_t *__restrict__ n_models,
                                                    double *__restrict__ dense_E, int32_t *__restrict__ dense_id,
                                                    int32_t *__restrict__ dense_total, int32_t *__restrict__ good_zero, int slot_stride = 0) {
@@ -543,12 +550,30 @@ __global__ __launch_bounds__(64) void roots_kernel_t(const PolyRec *__restrict__
     int n = 10;
     for (; n > 1; n--)
         if (fabs(c[n]) > DBL_EPSILON) break;  // cv::solvePoly trims vanishing leading coefficients
+    // Start values.  cv::solvePoly starts from (1+i)^k, |z| = 1 ... 22.6 whatever the polynomial; a converged simultaneous iteration
+    // delivers the same ROOTS from any start, and nothing downstream depends on which lane holds which root (the models of a
+    // hypothesis are told apart by inlier count and error sum, modelest.cpp:395-416; ARRSAC / USAC order them by E(0,0)).  So the starts are
+    // put where the roots are: on two circles of radius rho / 2 and 2 rho around the origin, rho = |c_0 / c_n|^(1/n) the geometric mean
+    // of the root moduli, alternating, at angles 2 pi k / 10 + 0.4 (not symmetric about the real axis: conjugate-symmetric starts of
+    // a real polynomial can never separate a real pair).  Over 6000 polynomials of the C3 scene: 9.8 sweeps per hypothesis instead of
+    // 13.5, 12.0 instead of 16.4 for the slowest of the six hypotheses of a wave.
     double pr, pim;
     {
-        const double tr[10] = {1, 1, 0, -2, -4, -4, 0, 8, 16, 16};  // (1+i)^r
-        const double ti[10] = {0, 1, 2, 2, 0, -4, -8, -8, 0, 16};
-        pr = tr[r];
-        pim = ti[r];
+        const double ca[10] = {0.9210609940028851, 0.5162596384230088, -0.08573535201472558, -0.6549823520202717, -0.9740483555854224, -0.9210609940028852, -0.5162596384230086, 0.0857353520147259, 0.6549823520202719, 0.9740483555854224};  // cos, sin of 2 pi k / 10 + 0.4
+        const double sa[10] = {0.3894183423086505, 0.8564321255857607, 0.9963179459464289, 0.7556441745570417, 0.22634001188772324, -0.3894183423086503, -0.8564321255857609, -0.9963179459464289, -0.7556441745570415, -0.2263400118877229};
+        double rho = 1.0;
+        const double a0 = fabs(c[0]), an = fabs(c[n]);
+        if (a0 > 0 && an > 0 && a0 <= DBL_MAX && an <= DBL_MAX) {
+            // log2(a0 / an) from the exponents and a single-precision logarithm of the mantissa ratio; rho = 2^(that / n)
+            const int e0 = __builtin_amdgcn_frexp_exp(a0), en = __builtin_amdgcn_frexp_exp(an);
+            const float m0 = (float)__builtin_amdgcn_frexp_mant(a0), mn = (float)__builtin_amdgcn_frexp_mant(an);
+            const float x = ((float)(e0 - en) + __log2f(m0 / mn)) / (float)n;
+            const float xi = floorf(x);
+            rho = ldexp((double)exp2f(x - xi), (int)xi);
+        }
+        rho *= (r & 1) ? 2.0 : 0.5;
+        pr = rho * ca[r];
+        pim = rho * sa[r];
     }
     const bool active = lane_ok && r < n;
     bool done = !lane_ok;  // identical for the 10 lanes of a hypothesis
@@ -556,7 +581,7 @@ __global__ __launch_bounds__(64) void roots_kernel_t(const PolyRec *__restrict__
 #pragma unroll
     for (int k = 0; k < 11; ++k) cc[k] = c[k];
     int settle = 0, dk_sweeps = 0;
-    for (int iter = 0; iter < 400; ++iter) {
+    for (int iter = 0; iter < MLPL_SWEEP_CAP; ++iter) {
         rr[lane] = pr;
         ri[lane] = pim;
         wave_sync();
@@ -653,7 +678,12 @@ __global__ __launch_bounds__(64) void roots_kernel_t(const PolyRec *__restrict__
     if (g_dk_iters_dbg[3] && lane_ok && r == 0) {
         atomicAdd(&g_dk_iters_dbg[0], dk_sweeps);
         atomicAdd(&g_dk_iters_dbg[1], 1);
-        atomicMax(&g_dk_iters_dbg[2], dk_sweeps);
+        if (atomicMax(&g_dk_iters_dbg[2], dk_sweeps) < dk_sweeps) g_dk_iters_dbg[4] = sample0 + h;
+        const int edges[9] = {8, 12, 16, 24, 32, 64, 128, 256, 399};
+        int bkt = 9;
+        for (int e = 8; e >= 0; --e)
+            if (dk_sweeps <= edges[e]) bkt = e;
+        atomicAdd(&g_dk_iters_dbg[5 + bkt], 1);
     }
 
     // real roots -> essential matrices
@@ -802,6 +832,274 @@ __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__
     wave_sync();
     householder_basis(L, lane);
     solve_from_basis(L, lane, recs + (sample - sample_offset));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// solve5pt3_kernel: THREE hypotheses per wave, 20 lanes each (lanes 60..63 idle), the matrices held in REGISTERS.
+// The one-hypothesis wave above keeps the 10x20 system in LDS and rewrites its 200 elements once per pivot column (ten LDS reads, an
+// index divide and three more reads per element and column: ~2000 of its ~3500 wave instructions), with 20 of 64 lanes busy in most
+// other phases.  Here lane (g, j) of hypothesis g owns COLUMN j of the system (ten doubles in registers): a pivot step is ten
+// cross-lane broadcasts of the pivot column (ds_bpermute), the pivot search repeated by every lane in registers, one divide and ten
+// multiply-subtract pairs -- no LDS traffic, no index arithmetic.  The Householder QR runs the same way (lane c < 5 owns epipolar row
+// c; the reflection vector goes through LDS once per step), the null-space vectors are built by lanes j < 4 from the stored reflections.
+// Only the 64-term trilinear tensor uses the whole wave, one hypothesis after the other, through the shared F buffer.
+// Every floating-point operation, its operands and its order are those of solve5pt_kernel: the hand-over records are BIT-IDENTICAL
+// (tests/test_gpu_solver_variants.py compares the two kernels through option solver_wave3).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSolveGroup = 20;       // lanes per hypothesis = columns of the constraint matrix
+constexpr int kHypPerSolveWave = 3;
+struct Solve3Lds {
+    double V[kHypPerSolveWave][5][9];   // Householder vectors
+    double vfac[kHypPerSolveWave][5];   // 2 / |v|^2 (0 = no reflection)
+    double EE[kHypPerSolveWave][4][9];  // null-space bases
+    double F[5][64];                    // trilinear tensor of ONE hypothesis, five constraint rows at a time
+    double W[kHypPerSolveWave][160];    // [0,60) rows 4..9 x columns 10..19 of the eliminated system, [60,99) B(z), [100,148) P0 * P1
+};
+
+__global__ __launch_bounds__(64) void solve5pt3_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
+                                                       const int32_t *__restrict__ samples, int sample_offset, int n_samples,
+                                                       PolyRec *__restrict__ recs /* indexed from sample_offset */,
+                                                       const PairSlot *__restrict__ ps = nullptr, int slot_stride = 0) {
+    __shared__ Solve3Lds L;
+    if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
+    const int lane = threadIdx.x;
+    const int gl = lane / kSolveGroup;
+    const bool mine = gl < kHypPerSolveWave;
+    const int g = mine ? gl : kHypPerSolveWave - 1;  // lanes 60..63 follow group 2 (reads only)
+    const int j = lane - gl * kSolveGroup;
+    const int sample = sample_offset + blockIdx.x * kHypPerSolveWave + g;
+    bool live = mine && sample < n_samples;
+    if (live && ps) {  // batched pass: hypotheses beyond the slot's count are padding -- no models
+        const int a = sample / slot_stride;
+        if (sample - a * slot_stride >= ps[a].cnt) {
+            live = false;
+            if (j == 0) recs[sample - sample_offset].ok = 0.0;
+        }
+    }
+    const unsigned long long live_bits = __ballot(live);
+    if (live_bits == 0) return;
+    PolyRec *rec = recs + (live ? sample - sample_offset : 0);
+
+    // ---- 1a. epipolar rows: lane (g, c < 5) holds row c = [x1x2, y1x2, x2, x1y2, y1y2, y2, x1, y1, 1]  (five-point.cpp:375-383) ----
+    double q[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) q[r] = 0.0;
+    if (live && j < 5) {
+        const int idx = samples[sample * 5 + j];
+        const double x1 = p1[2 * idx], y1 = p1[2 * idx + 1], x2 = p2[2 * idx], y2 = p2[2 * idx + 1];
+        q[0] = x1 * x2, q[1] = y1 * x2, q[2] = x2, q[3] = x1 * y2, q[4] = y1 * y2, q[5] = y2, q[6] = x1, q[7] = y1, q[8] = 1.0;
+    }
+    // ---- 1b. Householder QR of the 9x5 transpose: lane k forms reflection k, lanes c > k apply it to their rows ----
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (live && j == k) {
+            double nrm2 = 0;
+#pragma unroll
+            for (int r = k; r < 9; ++r) nrm2 += q[r] * q[r];
+            const double x0 = q[k];
+            const double alpha = (x0 >= 0 ? -1.0 : 1.0) * sqrt(nrm2);
+            const double vn2 = 2.0 * (nrm2 - alpha * x0);  // |v|^2 for v = x - alpha e_k
+#pragma unroll
+            for (int r = 0; r < 9; ++r) L.V[g][k][r] = (r < k) ? 0.0 : ((r == k) ? (x0 - alpha) : q[r]);
+            L.vfac[g][k] = vn2 > 0 ? 2.0 / vn2 : 0.0;
+        }
+        wave_sync();
+        if (live && j > k && j < 5) {
+            const double hfac = L.vfac[g][k];
+            if (hfac != 0.0) {
+                double v[9];
+#pragma unroll
+                for (int r = k; r < 9; ++r) v[r] = L.V[g][k][r];
+                double dot = 0;
+#pragma unroll
+                for (int r = k; r < 9; ++r) dot += v[r] * q[r];
+#pragma unroll
+                for (int r = k; r < 9; ++r) q[r] = q[r] - v[r] * dot * hfac;
+            }
+        }
+    }
+    // ---- 1c. null space: lane (g, jn < 4) builds n_jn = H_0 H_1 ... H_4 e_{5+jn} ----
+    if (live && j < 4) {
+        double e[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) e[r] = (r == 5 + j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 4; k >= 0; --k) {
+            const double hfac = L.vfac[g][k];
+            double v[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) v[r] = L.V[g][k][r];
+            double dot = 0;
+#pragma unroll
+            for (int r = k; r < 9; ++r) dot += v[r] * e[r];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) e[r] = e[r] - v[r] * dot * hfac;
+        }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            L.EE[g][j][r] = e[r];
+            rec->EE[j * 9 + r] = e[r];
+        }
+    }
+    wave_sync();
+
+    // ---- 2. trilinear coefficient tensors, one hypothesis at a time over the whole wave (lane = index triple (i, j, k)); lane (g, m)
+    //         adds up the orderings of monomial m: column m of the constraint matrix, a[0..9] ----
+    double a[10];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) a[r] = 0.0;
+    int perm[6];
+    const int np = (j < 20) ? kMonoNumPerms[j] : 0;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) perm[u] = kMonoPerms[j][u];
+    for (int t = 0; t < kHypPerSolveWave; ++t) {
+        if (!((live_bits >> (t * kSolveGroup)) & 1ull)) continue;  // wave-uniform
+        const int ti = lane >> 4, tj = (lane >> 2) & 3, tk = lane & 3;
+        const double *Ei = L.EE[t][ti], *Ej = L.EE[t][tj], *Ek = L.EE[t][tk];
+        double T[10];
+        T[0] = Ei[0] * (Ej[4] * Ek[8] - Ej[5] * Ek[7]) - Ei[1] * (Ej[3] * Ek[8] - Ej[5] * Ek[6]) + Ei[2] * (Ej[3] * Ek[7] - Ej[4] * Ek[6]);
+        double P[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) P[r][b] = Ei[r * 3] * Ej[b * 3] + Ei[r * 3 + 1] * Ej[b * 3 + 1] + Ei[r * 3 + 2] * Ej[b * 3 + 2];
+        const double htr = 0.5 * (P[0][0] + P[1][1] + P[2][2]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) T[1 + r * 3 + c] = P[r][0] * Ek[c] + P[r][1] * Ek[3 + c] + P[r][2] * Ek[6 + c] - htr * Ek[r * 3 + c];
+        const bool take = mine && gl == t;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 5; ++r) L.F[r][lane] = T[half * 5 + r];
+            wave_sync();
+            if (take) {
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    double sacc = 0;
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+                        if (u < np) sacc += L.F[r][perm[u]];
+                    a[half * 5 + r] = sacc;
+                }
+            }
+        }
+    }
+
+    // ---- 3. Gauss-Jordan with partial pivoting on columns held in registers: A <- [I | inv(A1) A2] ----
+    bool singular = false;
+#pragma unroll
+    for (int col = 0; col < 10; ++col) {
+        const int src_lane = g * kSolveGroup + col;
+        double cv[10];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) cv[r] = __shfl(a[r], src_lane);
+        int piv = col;
+        double pmax = fabs(cv[col]), pvt = cv[col];
+#pragma unroll
+        for (int r = col + 1; r < 10; ++r) {
+            const double v = fabs(cv[r]);
+            const bool take = v > pmax;
+            pmax = take ? v : pmax;
+            pvt = take ? cv[r] : pvt;
+            piv = take ? r : piv;
+        }
+        if (pmax < DBL_EPSILON * 1e-3) singular = true;  // (the one-hypothesis kernel stops here; the record is flagged below)
+        const double inv = 1.0 / pvt;
+        double a_piv = a[col];
+#pragma unroll
+        for (int r = col + 1; r < 10; ++r) a_piv = (piv == r) ? a[r] : a_piv;
+        const double sc = a_piv * inv;
+        const double t_col = a[col] - cv[col] * sc;  // what row `piv` receives: the old row `col`, eliminated
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            if (r == col) continue;
+            const double nv = a[r] - cv[r] * sc;
+            a[r] = (r > col && piv == r) ? t_col : nv;
+        }
+        a[col] = sc;
+    }
+
+    // ---- 4. B(z) rows and the determinant polynomial (20 lanes per hypothesis, several rounds) ----
+    double *W = L.W[g];
+    if (mine && j >= 10) {
+#pragma unroll
+        for (int r = 4; r < 10; ++r) W[(r - 4) * 10 + (j - 10)] = a[r];
+    }
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int e = j + kSolveGroup * t;
+        if (mine && e < 39) {
+            const int i = e / 13, jj = e - i * 13;
+            const double *r1 = &W[(2 * i) * 10];
+            const double *r2 = &W[(2 * i + 1) * 10];
+            double v1 = 0, v2 = 0;
+            if (jj >= 1 && jj <= 3) v1 = r1[jj - 1];
+            else if (jj >= 5 && jj <= 7) v1 = r1[jj - 2];
+            else if (jj >= 9) v1 = r1[jj - 3];
+            if (jj <= 2) v2 = r2[jj];
+            else if (jj >= 4 && jj <= 6) v2 = r2[jj - 1];
+            else if (jj >= 8 && jj <= 11) v2 = r2[jj - 2];
+            const double bv = v1 - v2;
+            W[60 + e] = bv;
+            if (live) rec->b[e] = bv;
+        }
+    }
+    wave_sync();
+    {
+        const double *bb = W + 60;  // b[row][k] = bb[row * 13 + k]
+        auto coef = [&](int row, int colm, int k) -> double {
+            if (k < 0) return 0.0;
+            if (colm == 0) return (k <= 3) ? bb[row * 13 + 3 - k] : 0.0;
+            if (colm == 1) return (k <= 3) ? bb[row * 13 + 7 - k] : 0.0;
+            return (k <= 4) ? bb[row * 13 + 12 - k] : 0.0;
+        };
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int e = j + kSolveGroup * t;
+            if (mine && e < 48) {
+                const int pi = e >> 3, m = e & 7;
+                const int p0 = (pi < 3) ? pi : pi - 3;
+                const int p1i = (pi < 3) ? (pi + 1) % 3 : (pi - 3 + 2) % 3;
+                double qv = 0;
+#pragma unroll
+                for (int i0 = 0; i0 <= 4; ++i0) qv += coef(0, p0, i0) * coef(1, p1i, m - i0);
+                W[100 + e] = qv;
+            }
+        }
+        wave_sync();
+        if (mine && j < 11) {
+            double ck = 0;
+#pragma unroll
+            for (int pj = 0; pj < 6; ++pj) {
+                const int q0 = (pj < 3) ? pj : pj - 3;
+                const int q1 = (pj < 3) ? (pj + 1) % 3 : (pj - 3 + 2) % 3;
+                const int q2 = 3 - q0 - q1;
+                double sacc = 0;
+#pragma unroll
+                for (int i2 = 0; i2 <= 4; ++i2) {
+                    const int mm = j - i2;
+                    if (mm >= 0 && mm <= 7) sacc += W[100 + pj * 8 + mm] * coef(2, q2, i2);
+                }
+                ck += (pj < 3) ? sacc : -sacc;
+            }
+            if (live) rec->c[j] = ck;
+        }
+    }
+    if (live && j == 0) rec->ok = singular ? 0.0 : 1.0;
+}
+
+// the solver's first kernel: three hypotheses per wave (default) or the one-hypothesis wave (option solver_wave3 = 0)
+static inline void launch_solve5pt(mlpl_ctx *ctx, int m, hipStream_t s, const double *p1, const double *p2, const int32_t *samples, int sample_offset,
+                                   int n_samples, PolyRec *recs, const PairSlot *ps = nullptr, int slot_stride = 0) {
+    if (ctx->opt_solver_wave3)
+        hipLaunchKernelGGL(solve5pt3_kernel, dim3((m + kHypPerSolveWave - 1) / kHypPerSolveWave), dim3(kSolverThreads), 0, s, p1, p2, samples,
+                           sample_offset, n_samples, recs, ps, slot_stride);
+    else
+        hipLaunchKernelGGL(solve5pt_kernel, dim3(m), dim3(kSolverThreads), 0, s, p1, p2, samples, sample_offset, n_samples, recs, ps, slot_stride);
 }
 
 // State of the device-side replay of runRANSAC (see replay_kernel); defined here because pack_points_kernel also initialises it.
@@ -2295,14 +2593,14 @@ int mlpl_ransac_last_stats(mlpl_ctx *ctx, long long stats[2]) {
     return MLPL_OK;
 }
 
-int mlpl_debug_dk_stats(mlpl_ctx *ctx, int enable, int stats[3]) {
+int mlpl_debug_dk_stats(mlpl_ctx *ctx, int enable, int stats[16]) {
     if (!ctx) return MLPL_E_BAD_INPUT;
     MLPL_HIP_TRY(hipSetDevice(ctx->device));
     MLPL_HIP_TRY(hipDeviceSynchronize());
-    int h[4] = {0, 0, 0, 0};
+    int h[16] = {0};
     MLPL_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dk_iters_dbg), sizeof(h)));
-    if (stats) stats[0] = h[0], stats[1] = h[1], stats[2] = h[2];
-    const int z[4] = {0, 0, 0, enable ? 1 : 0};
+    if (stats) std::memcpy(stats, h, sizeof(h));
+    const int z[16] = {0, 0, 0, enable ? 1 : 0};
     MLPL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dk_iters_dbg), z, sizeof(z)));
     return MLPL_OK;
 }
@@ -2332,8 +2630,7 @@ int mlpl_solve_5pt(mlpl_ctx *ctx, const double *p1, const double *p2, int n, con
     MLPL_HIP_TRY(hipMemcpyAsync(B.samples, samples, (size_t)n_samples * 20, hipMemcpyHostToDevice, s));
     MLPL_HIP_TRY(hipMemsetAsync(B.E_tab, 0, (size_t)n_samples * 720, s));
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
-    hipLaunchKernelGGL(solve5pt_kernel, dim3(n_samples), dim3(64), 0, s, (const double *)dp1, (const double *)dp2, B.samples, 0,
-                       n_samples, B.recs);
+    launch_solve5pt(ctx, n_samples, s, (const double *)dp1, (const double *)dp2, B.samples, 0, n_samples, B.recs);
     MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((n_samples + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)B.recs, 0, n_samples,
                       B.E_tab, B.n_models, (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);
@@ -2513,8 +2810,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
             prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
             // (the hand-over records are indexed from the slice's first sample: each slice gets its own part of the buffer, the root
             // kernel of slice i and the elimination kernel of slice i+1 run side by side)
-            hipLaunchKernelGGL(solve5pt_kernel, dim3(m), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, off, off + m,
-                               B.recs + off);
+            launch_solve5pt(ctx, m, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, off, off + m, B.recs + off);
             hipStream_t sr = overlap ? ctx->aux_stream[slice_no & 1] : s;  // two helper streams: consecutive root kernels overlap too
             if (overlap) {  // everything the root kernel reads is complete once this event fires (the first one also covers the setup)
                 MLPL_HIP_TRY(hipEventRecord(ctx->aux_ev[slice_no], s));
@@ -2707,7 +3003,7 @@ int mlpl_lmeds_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_
     for (int i = 0; i < niters; ++i) draw_sample(rng, fmod_n, &h_samples[(size_t)i * 5]);
     MLPL_HIP_TRY(hipMemsetAsync(B.total, 0, 4, s));
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
-    hipLaunchKernelGGL(solve5pt_kernel, dim3(niters), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, 0, niters, B.recs);
+    launch_solve5pt(ctx, niters, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, 0, niters, B.recs);
     MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((niters + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)B.recs, 0, niters, B.E_tab,
                       B.n_models, B.dense_E, B.dense_id, B.total, (int32_t *)nullptr);
     prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 1, s);

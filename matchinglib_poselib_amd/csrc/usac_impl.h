@@ -734,7 +734,7 @@ struct UsacRun {
         int32_t *o_nm = (int32_t *)h_out_dev, *o_valid = (int32_t *)(h_out_dev + off_valid);
         double *o_key = (double *)(h_out_dev + off_key);
         unsigned long long *o_rows = (unsigned long long *)(h_out_dev + off_rows);
-        hipLaunchKernelGGL(solve5pt_kernel, dim3(B), dim3(kSolverThreads), 0, s, d_p1, d_p2, (const int32_t *)d_smp, 0, B, d_recs);
+        launch_solve5pt(ctx, B, s, d_p1, d_p2, (const int32_t *)d_smp, 0, B, d_recs);
         MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((B + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)d_recs, 0, B, d_Etab, d_nm,
                           (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
         hipLaunchKernelGGL(usac_check_kernel, dim3(B * 10), dim3(64), 0, s, (const double4 *)d_pts_pool, (int)n, words, d_p1, d_p2,
