@@ -43,6 +43,8 @@ for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm"):
     dur = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
+        if k.startswith(("knn_hamming_mfma_lds_kernel<4, 0>", "solve5pt", "roots_kernel_t<true>")):  # launched at several batch sizes (headline, 8-pair continuity, C5 extras): keep apart
+            k += " @grid " + r.get("Grid_Size", r.get("Grid_Size_X", "?"))
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for k, v in agg.items():
@@ -54,16 +56,21 @@ json.dump(summary, open(os.path.join(DST, f"{R}_pmc_summary.json"), "w"), indent
 
 # roofline.traffic of bench.py: HBM-side bytes per launch of the dominant kernel (FETCH_SIZE doubled on gfx950 for 16-B/lane streams,
 # MI355X_MICROARCH.md HBM section)
-traffic = {"round": R, "pairs_per_launch": 8,
+PAIRS = 64
+bp = os.path.join(DST, f"{R}_bench_plain.json")
+if os.path.exists(bp):
+    PAIRS = int(json.load(open(bp)).get("config", {}).get("pairs_per_gpu", PAIRS))
+HEADLINE_GRID = str(8192 * PAIRS)  # 128 workgroups of 64 threads per image pair
+traffic = {"round": R, "pairs_per_launch": PAIRS,
            "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 20 --warmup 2 "
-                  "--no-cpu-baseline` (8 image pairs per launch); (2*FETCH_SIZE + WRITE_SIZE)*1024 B, FETCH_SIZE doubled per "
+                  f"--no-cpu-baseline` (dispatches of {PAIRS} image pairs per launch, grid {HEADLINE_GRID}); (2*FETCH_SIZE + WRITE_SIZE)*1024 B, FETCH_SIZE doubled per "
                   "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B for 16-B/lane streams)"}
 for k, e in summary.items():
     if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
         b = (2 * e["FETCH_SIZE"]["mean"] + e["WRITE_SIZE"]["mean"]) * 1024
         # the headline launch (8 pairs per launch): round 1 knn_hamming_mfma_kernel<4, 4>, since round 2 the LDS-ring kernel <4, 0>
         # (<1, 0> / <4, 1> are the single-pair extras launches)
-        if k.startswith("knn_hamming_mfma_kernel<4, 4>") or k.startswith("knn_hamming_mfma_lds_kernel<4, 0>"):
+        if k.startswith("knn_hamming_mfma_lds_kernel<4, 0>") and k.endswith("@grid " + HEADLINE_GRID):
             traffic["knn_hamming_mfma_bytes_per_launch"] = b
             traffic["mfma_fetch_KiB_raw"] = e["FETCH_SIZE"]["mean"]
             traffic["mfma_write_KiB"] = e["WRITE_SIZE"]["mean"]
