@@ -181,6 +181,36 @@ def run(ctx, dev, cpu_baseline=True):
         out[name] = {"value": 4096 * 4096 / (ms * 1e-3), "unit": "descriptor-pairs/s", "ms_per_call": ms,
                      "gflops_equiv": 2 * 4096 * 4096 * 128 / (ms * 1e-3) / 1e9}
     ctx.lib.mlpl_set_l2_path(ctx.handle, 0)
+    # C4's shape with NON-integer descriptors (RootSIFT-like: L1-normalised, square-rooted): exact kernel vs the fp16 matrix-core
+    # candidate passes + exact re-rank (auto mode once the context has seen such data; same idx / distance bits)
+    rng = np.random.default_rng(4)
+    tr = rng.gamma(0.6, 1.0, size=(4096, 128))
+    qr = np.abs(tr + 0.5 * tr.mean() * rng.gamma(0.6, 1.0, size=tr.shape))
+    tr, qr = np.sqrt(tr / tr.sum(1, keepdims=True)).astype(np.float32), np.sqrt(qr / qr.sum(1, keepdims=True)).astype(np.float32)
+    dqr, dtr = torch.from_numpy(qr).to(dev), torch.from_numpy(tr).to(dev)
+    ref = None
+    for mode, name in ((1, "l2_c4_rootsift_exact_fp32"), (0, "l2_c4_rootsift_auto")):
+        ctx.lib.mlpl_set_l2_path(ctx.handle, mode)
+
+        def call():
+            _lib.check(ctx.lib.mlpl_knn2_l2sq_f32_dev(ctx.handle, dqr.data_ptr(), 4096, 128, 0, dtr.data_ptr(), 4096, 128, 0,
+                                                      128, 2, 1, idx.data_ptr(), dist.data_ptr(), st), "knn_l2_dev")
+        for _ in range(3):   # (auto: the first call leaves the hint, the later ones take the matrix-core path)
+            call()
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        got = (idx.cpu().numpy().copy(), dist.cpu().numpy().copy())
+        if ref is None:
+            ref = got
+        out[name] = {"value": 4096 * 4096 / (ms * 1e-3), "unit": "descriptor-pairs/s", "ms_per_call": ms,
+                     "same_bits_as_exact": bool(np.array_equal(got[0], ref[0]) and got[1].tobytes() == ref[1].tobytes())}
+    ctx.lib.mlpl_set_l2_path(ctx.handle, 0)
     # ---- C2 as ONE image pair per launch (latency shape; the headline step batches 8 pairs per launch) ----
     from matchinglib_poselib_amd.matching import match_hamming_device
     B = 1

@@ -67,7 +67,8 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  *     sizes; "hamming_mfma_prio" 0|1|2 (diagnostics); "hamming_mfma_blocks_per_cu" and "hamming_mfma_qt" (query tiles per wave,
  *     0 = automatic) size the matrix-core grid; "hamming_qpl" queries per lane 1|2 and "hamming_blocks_per_cu" size the VALU grids;
  *     "hamming_stamps" 1 = per-wave / per-workgroup clock stamps (mlpl_debug_hamming_stamps).
- *   L2: "l2_mfma_waves" 0|4|8 and "l2_mfma_blocks_per_cu" shape the int8 matrix-core kernel of the forced mode (see mlpl_set_l2_path).
+ *   L2: "l2_mfma_waves" 0|4|8 and "l2_mfma_blocks_per_cu" shape the int8 matrix-core kernel of the forced mode (see mlpl_set_l2_path);
+ *     "l2_float_mfma" 0|1|2 decides when the fp16 candidate path serves non-integer float descriptors (mlpl_set_l2_path, mode 0).
  *   RANSAC: "ransac_chunk" hypotheses per device pass (0 = 32768 = the maximum; the sequential best/niters rule is replayed across
  *     passes); "ransac_lazy_sums" (default 1) = the passes count inliers without the division and compute error sums only for the
  *     models that can still win, 0 = sums for every model; "ransac_f32_filter" (default 1) = the counting kernels decide in packed single
@@ -120,9 +121,15 @@ int mlpl_knn2_hamming_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_st
 int mlpl_knn2_l2sq_f32_dev(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_batch_stride,
                            const float *d_t, int nt, size_t t_stride, size_t t_batch_stride, int dim, int k,
                            int batch, int32_t *d_idx, float *d_dist, void *stream);
-/* L2 fast path selector for the *_dev/host float entries: 0 = auto (fp16 MFMA distance-GEMM when every
- * element is an integer in [0,255], else the exact fp32 VALU kernel), 1 = force exact fp32 VALU,
- * 2 = force MFMA (MLPL_E_BAD_INPUT if the data are not integer-valued 0..255). */
+/* L2 path selector for the *_dev/host float entries (results are identical on every path):
+ *   0 = auto: int8 matrix-core distance-GEMM when every element is an integer in [0,255] (OpenCV SIFT layout); otherwise fp16
+ *       matrix-core candidate passes + exact fp32 re-rank (dim <= 128; option "l2_float_mfma": 1 (default) = once the previous call of
+ *       this context saw non-integer data -- the first such call runs the exact kernel --, 2 = enqueued on every call, 0 = never), or the
+ *       exact fp32 VALU kernel in cvflann's summation order;
+ *   1 = force the exact fp32 VALU kernel;
+ *   2 = force the int8 matrix-core path (MLPL_E_BAD_INPUT if the data are not integer-valued 0..255);
+ *   3 = force the fp16 candidate path + exact re-rank (MLPL_E_BAD_INPUT if dim > 128 or a row is outside its range: non-finite,
+ *       |x| > 1e15, or largest element below 1e-12). */
 int mlpl_set_l2_path(mlpl_ctx *ctx, int mode);
 
 /* ---- ratio test + DMatch emission ----------------------------------------------------------------------
@@ -381,6 +388,12 @@ int mlpl_ransac_last_stats(mlpl_ctx *ctx, long long stats[2]);
  * index of the max, solves with <= 8, 12, 16, 24, 32, 64, 128, 256, < 400, = 400 sweeps, 0}; enable != 0 turns the (atomic) bookkeeping on.
  * Not for production use. */
 int mlpl_debug_dk_stats(mlpl_ctx *ctx, int enable, int stats[16]);
+
+/* Diagnostics: the four flag words of the float L2 paths after the calls enqueued so far have finished (synchronises the device):
+ * {generation of the last call whose data were not integer-valued (int8 preparation), generation of the last fp16-path call with a row
+ * outside that path's range, number of queries the fp16 path re-ranked against every train row since the flag block was created,
+ * generation of the last fp16-path call whose data were not integer-valued}. */
+int mlpl_debug_l2_flags(mlpl_ctx *ctx, int flags[4]);
 
 /* Diagnostics: with option "hamming_stamps" = 1 every wave of the matrix-core Hamming kernel records {shader-clock cycles, 100 MHz
  * real-time ticks, 32x32 tiles processed, start tick}; this copies up to max_items records of 4 x u64 of the LAST launch to `out`

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "mlpl_knn2_l2sq_f32_dev": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_size_t, c_void_p, c_int, c_size_t,
                                        c_size_t, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mlpl_set_l2_path": (c_int, [c_void_p, c_int]),
+    "mlpl_debug_l2_flags": (c_int, [c_void_p, c_void_p]),
     "mlpl_ratio_compact_i32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
                                        C.POINTER(c_int)]),
     "mlpl_ratio_compact_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,

@@ -121,6 +121,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_ransac_f32_filter = 1;
     ctx->opt_solver_polish = 1;
     ctx->opt_solver_wave3 = 1;
+    ctx->opt_l2_float_mfma = 1;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -151,6 +152,7 @@ void mlpl_ctx_destroy(mlpl_ctx *ctx) {
         delete[] ctx->prof_ev[k];
     }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->l2_hint_host) (void)hipHostFree(ctx->l2_hint_host);
     delete[] ctx->ransac_T_host;
     mlpl::free_rand_cache(ctx->rand_cache);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -189,6 +191,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "ransac_event_cap") && value >= 0 && value <= 1024) ctx->opt_ransac_event_cap = value;
     else if (!std::strcmp(name, "solver_polish") && (value == 0 || value == 1)) ctx->opt_solver_polish = value;
     else if (!std::strcmp(name, "solver_wave3") && (value == 0 || value == 1)) ctx->opt_solver_wave3 = value;
+    else if (!std::strcmp(name, "l2_float_mfma") && value >= 0 && value <= 2) ctx->opt_l2_float_mfma = value;
     else if (!std::strcmp(name, "arrsac_flag_points") && (value == 0 || (value >= 128 && value <= 1024 && value % 64 == 0))) ctx->opt_arrsac_flag_points = value;
     else if (!std::strcmp(name, "pair_batch") && value >= 0 && value <= 256) ctx->opt_pair_batch = value;
     else if (!std::strcmp(name, "usac_lo_stepwise") && (value == 0 || value == 1)) ctx->opt_usac_lo_stepwise = value;
@@ -253,8 +256,17 @@ int mlpl_profile_read(mlpl_ctx *ctx, int kernel_id, double *total_ms, int *launc
     return MLPL_OK;
 }
 
+int mlpl_debug_l2_flags(mlpl_ctx *ctx, int flags[4]) {
+    if (!ctx || !flags) return MLPL_E_BAD_INPUT;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    MLPL_HIP_TRY(hipDeviceSynchronize());
+    flags[0] = flags[1] = flags[2] = flags[3] = 0;
+    if (ctx->l2_flag_ptr) MLPL_HIP_TRY(hipMemcpy(flags, ctx->l2_flag_ptr, 16, hipMemcpyDeviceToHost));
+    return MLPL_OK;
+}
+
 int mlpl_set_l2_path(mlpl_ctx *ctx, int mode) {
-    if (!ctx || mode < 0 || mode > 2) return MLPL_E_BAD_INPUT;
+    if (!ctx || mode < 0 || mode > 3) return MLPL_E_BAD_INPUT;
     ctx->l2_mode = mode;
     return MLPL_OK;
 }

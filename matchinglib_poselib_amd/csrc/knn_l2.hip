@@ -15,7 +15,9 @@
 // running top-2 is a lexicographic (distance, trainIdx) min exactly like cvflann's KNNUniqueResultSet.
 
 #include <algorithm>
+#include <cstring>
 
+#include "knn_l2_common.h"
 #include "knn_l2_mfma_body.h"
 #include "mlpl_internal.h"
 
@@ -24,6 +26,9 @@ namespace mlpl {
 int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t, int nt,
                        size_t t_stride, size_t t_bstride, int dim, int batch, hipStream_t s, int force, l2mfma::L2MfmaPlan *plan);
 
+int launch_knn_l2_f16(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t, int nt, size_t t_stride,
+                      size_t t_bstride, int dim, int k, int batch, int gen, int *d_flags, int *d_hint, int32_t *d_idx, float *d_dist, hipStream_t s);
+
 namespace {
 
 constexpr int kQPB = 256;   // queries per block, one per lane
@@ -31,21 +36,7 @@ constexpr int kMaxTileRows = 32;
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ void top2_update(u64 &k0, u64 &k1, u64 key) {
-    const bool lt0 = key < k0;
-    const bool lt1 = key < k1;
-    k1 = lt0 ? k0 : (lt1 ? key : k1);
-    k0 = lt0 ? key : k0;
-}
-
-// cvflann::L2<float>::operator() restated for one 4-group.
-__device__ __forceinline__ float l2_group4(float result, float4 a, float4 b) {
-    const float d0 = __fsub_rn(a.x, b.x), d1 = __fsub_rn(a.y, b.y), d2 = __fsub_rn(a.z, b.z), d3 = __fsub_rn(a.w, b.w);
-    float s = __fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1));
-    s = __fadd_rn(s, __fmul_rn(d2, d2));
-    s = __fadd_rn(s, __fmul_rn(d3, d3));
-    return __fadd_rn(result, s);
-}
+__device__ __forceinline__ void top2_update(u64 &k0, u64 &k1, u64 key) { l2_top2_update(k0, k1, key); }  // (knn_l2_common.h, with l2_group4)
 
 // DIM4 = number of float4 groups held in registers per query (dim = 4*DIM4 + tail, tail < 4 handled via LDS/global).
 // Generic variant (DIM4 == 0) keeps the query in LDS as well.
@@ -197,9 +188,12 @@ __global__ __launch_bounds__(kQPB) void knn_l2_exact_kernel(L2ExactArgs a) {
 // grids; the surplus workgroups of the path taken exit at once.
 template <int DIM4, int KS>
 __global__ __launch_bounds__(kQPB, 3) void knn_l2_auto_kernel(l2mfma::L2MfmaArgs m, unsigned grid_m, L2ExactArgs e, int qtiles_e,
-                                                           unsigned grid_e, L2Gate gate) {
+                                                           unsigned grid_e, L2Gate gate, int *__restrict__ hint) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (*gate.flag != gate.gen) {
+    const bool nonint = *gate.flag == gate.gen;
+    // host-visible word for the NEXT call of this context (never waited for): which kind of data the last finished call saw
+    if (hint && blockIdx.x == 0 && threadIdx.x == 0) *hint = 2 * gate.gen + (nonint ? 1 : 0);
+    if (!nonint) {
         if (blockIdx.x < grid_m) l2mfma::l2_mfma_body<KS, 4>(m, reinterpret_cast<l2mfma::v4i *>(smem), blockIdx.x);
         return;
     }
@@ -276,6 +270,49 @@ int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size
     int nsplit_m = 0;
     l2mfma::L2MfmaPlan plan{};
     bool fused = false;
+    // The fp16 candidate path + exact re-rank (knn_l2_f16.hip) is exact for ANY float data; the int8 path is faster on integer-valued data.
+    // Auto mode picks by a hint, without a host hop: the last kernel of either path leaves "2 * generation + (data were not integer-valued)"
+    // in a pinned word; the next call reads whatever is there (a stale or missing hint costs speed, never results): odd -> fp16 path, even ->
+    // int8 / exact path as before.  Option l2_float_mfma: 0 = never, 2 = the fp16 path for every float call.
+    const bool f16_ok = !nms_order && knn_l2_f16_applicable(dim, nt, k);
+    if (ctx->l2_mode == 3 && !f16_ok) {
+        set_error("knn_l2 (fp16 path): not applicable (dim %d > 128 or the NMSLIB order)", dim);
+        return MLPL_E_BAD_INPUT;
+    }
+    if (ctx->l2_mode == 0 && ctx->opt_l2_float_mfma == 1 && !ctx->l2_hint_host) {  // the hint word lives with the context
+        void *h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess) {
+            std::memset(h, 0, 64);
+            ctx->l2_hint_host = (int *)h;
+            if (hipHostGetDevicePointer((void **)&ctx->l2_hint_dev, h, 0) != hipSuccess) ctx->l2_hint_dev = nullptr;
+        }
+    }
+    const bool hinted = ctx->l2_mode == 0 && ctx->opt_l2_float_mfma == 1 && ctx->l2_hint_host && (*(volatile int *)ctx->l2_hint_host & 1);
+    if (ctx->l2_mode == 3 || (ctx->l2_mode == 0 && f16_ok && (ctx->opt_l2_float_mfma == 2 || hinted))) {
+        void *flag;
+        int rc = ws_get(ctx, WS_L2_FLAG, 4096, &flag);
+        if (rc) return rc;
+        int *dflag = (int *)flag;
+        if (ctx->l2_flag_ptr != flag || ctx->l2_gen == 0x3FFFFFFF) {  // a fresh (or wrapped) flag block starts below every generation
+            MLPL_HIP_TRY(hipMemsetAsync(dflag, 0, 16, s));
+            ctx->l2_flag_ptr = flag;
+            ctx->l2_gen = 0;
+        }
+        const int gen = ++ctx->l2_gen;
+        if ((rc = launch_knn_l2_f16(ctx, d_q, nq, q_stride, q_bstride, d_t, nt, t_stride, t_bstride, dim, k, batch, gen, dflag,
+                                    ctx->l2_mode == 0 ? ctx->l2_hint_dev : nullptr, d_idx, d_dist, s)))
+            return rc;
+        if (ctx->l2_mode == 3) {  // forcing is a test / diagnostic mode: report out-of-range data as an error (one host hop; the result is still exact)
+            int hbad = 0;
+            MLPL_HIP_TRY(hipMemcpyAsync(&hbad, dflag + 1, 4, hipMemcpyDeviceToHost, s));
+            MLPL_HIP_TRY(hipStreamSynchronize(s));
+            if (hbad == gen) {
+                set_error("knn_l2 (fp16 path): a descriptor row is outside the path's range (non-finite, |x| > 1e15 or largest element < 1e-12)");
+                return MLPL_E_BAD_INPUT;
+            }
+        }
+        return MLPL_OK;
+    }
     if (ctx->l2_mode != 1 && !nms_order) {
         // int8 matrix-core distance-GEMM when the data qualify (auto) or when forced.  In auto mode ONE kernel holds both paths and a
         // device flag written by the operand-preparation kernel decides which one its workgroups run and which partial table the one
@@ -328,7 +365,7 @@ int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size
         prof_mark(ctx, MLPL_PROF_KNN_L2, 0, s);
 #define MLPL_L2_AUTO(D4, KS)                                                                                                         \
     hipLaunchKernelGGL((knn_l2_auto_kernel<D4, KS>), dim3(grid), dim3(kQPB), lds, s, plan.args, plan.grid, ea, qtiles, (unsigned)grid_e, \
-                       gate)
+                       gate, ctx->l2_mode == 0 ? ctx->l2_hint_dev : (int *)nullptr)
         if (g4 == 32 && plan.ksel == 4) MLPL_L2_AUTO(32, 4);
         else if (g4 == 16 && plan.ksel == 2) MLPL_L2_AUTO(16, 2);
         else if (g4 == 8 && plan.ksel == 1) MLPL_L2_AUTO(8, 1);

@@ -88,10 +88,11 @@ __global__ __launch_bounds__(256) void l2_prep_kernel(L2PrepArgs qa, L2PrepArgs 
         }
         frag[(u >> 1) * 64 + (u & 1) * 32 + r] = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    if (bad) atomicMax(flag, gen);
     part[0][c][r] = s1;
     part[1][c][r] = s2;
-    __syncthreads();
+    // (one atomic per block at most, and none once the word is set: with non-integer data every thread would queue on the same address)
+    const int any_bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0 && any_bad && *(volatile int *)flag != gen) atomicMax(flag, gen);
     if (c == 0) {
 #pragma unroll
         for (int i = 1; i < 8; ++i) s1 += part[0][i][r], s2 += part[1][i][r];
@@ -147,8 +148,8 @@ int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride,
     if ((rc = ws_get(ctx, WS_L2_FLAG, 4096, &flag))) return rc;
     int *qc = (int *)cst, *tc = qc + (size_t)batch * nq_tiles * 32;
     int *dflag = (int *)flag;
-    if (ctx->l2_flag_ptr != flag || ctx->l2_gen == 0x7FFFFFFF) {  // a fresh (or wrapped) flag starts below every generation
-        MLPL_HIP_TRY(hipMemsetAsync(dflag, 0, 4, s));
+    if (ctx->l2_flag_ptr != flag || ctx->l2_gen == 0x3FFFFFFF) {  // a fresh (or wrapped) flag starts below every generation
+        MLPL_HIP_TRY(hipMemsetAsync(dflag, 0, 16, s));  // {not integer-valued, outside the fp16 path's range, re-rank overflows, -}
         ctx->l2_flag_ptr = flag;
         ctx->l2_gen = 0;
     }

@@ -50,6 +50,11 @@ enum WsSlot {
     WS_SPLIT_TAB, // age-aware split table of the static LDS-ring Hamming kernel
     WS_ARR_E,     // ARRSAC: models of every sample solved in a call
     WS_ARR_F,     // ARRSAC: their inlier bit rows
+    WS_F16_Q,     // fp16 L2 path (knn_l2_f16.hip): hi / lo fragments of the queries, of the train rows, row constants, partial U pairs, candidates
+    WS_F16_T,
+    WS_F16_CST,
+    WS_F16_PART,
+    WS_F16_CAND,
     WS_NUM_SLOTS
 };
 
@@ -62,6 +67,8 @@ struct L2Gate {
     const int *flag;
     int gen;
 };
+
+bool knn_l2_f16_applicable(int dim, int nt, int k);
 
 }  // namespace mlpl
 
@@ -78,6 +85,10 @@ struct mlpl_ctx {
     int opt_l2_mfma_waves;          // waves per workgroup of the L2 matrix-core kernel: 4, 8 or 0 = automatic
     int opt_l2_mfma_blocks_per_cu;  // its grid sizing target (0 = automatic)
     int l2_gen;         // call counter of the L2 auto path (see L2Gate)
+    int opt_l2_float_mfma;  // non-integer float descriptors: 0 = exact fp32 kernel, 1 (default) = fp16 matrix-core candidates + exact re-rank once the
+                            // previous call's data were seen to be non-integer (hint, no host hop), 2 = always enqueue that path
+    int *l2_hint_host;      // pinned + device-mapped: 2 * generation + (not integer-valued) of the last auto call that has finished on the device
+    int *l2_hint_dev;
     void *l2_flag_ptr;  // the flag buffer l2_gen counts for
     int num_cus;
     // tuning knobs (mlpl_set_option)
