@@ -130,6 +130,31 @@ def test_many_near_ties_overflow_the_candidate_list(ctx):
         ctx.set_option("l2_float_mfma", 1)
 
 
+def test_distances_below_the_resolution_of_the_fp16_products(ctx):
+    """Train rows on a fine ladder of distances around a large common offset: neighbouring rungs differ by a tenth of the error window, so
+    the approximate distances order the first dozens of rows at random and every query has ~20 candidates.  The true top-2 must still be
+    among them (the window is a bound, not an estimate) -- and with < 64 candidates nobody falls back to the exhaustive re-rank."""
+    rng = np.random.default_rng(21)
+    dim = 128
+    base = (30.0 + rng.normal(size=dim)).astype(np.float64)
+    norm2 = float(base @ base)
+    step = 0.1 * 1.0e-3 * 2 * norm2
+    u = rng.normal(size=(600, dim))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    t = (base + np.sqrt(step * np.arange(1, 601))[:, None] * u).astype(np.float32)
+    t = t[rng.permutation(600)]
+    q = (base + 0.3 * rng.normal(size=(400, dim))).astype(np.float32)
+    ex = run(ctx, q, t, 1)
+    before = full_scans(ctx)
+    assert same(ex, run(ctx, q, t, 3))
+    assert full_scans(ctx) == before
+    # the same ladder with signs mixed (cancellation inside the dot products) and at a very different scale
+    sgn = np.where(rng.random(dim) < 0.5, -1.0, 1.0).astype(np.float32)
+    for scale in (1.0, 3e-4, 2e5):
+        q2, t2 = (q * sgn * scale).astype(np.float32), (t * sgn * scale).astype(np.float32)
+        assert same(run(ctx, q2, t2, 1), run(ctx, q2, t2, 3)), scale
+
+
 def test_integer_valued_data_through_the_fp16_path(ctx):
     q, t = synth.sift_pair(700, 1300, seed=12)
     assert same(run(ctx, q, t, 1), run(ctx, q, t, 3))
