@@ -194,6 +194,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "l2_float_mfma") && value >= 0 && value <= 2) ctx->opt_l2_float_mfma = value;
     else if (!std::strcmp(name, "arrsac_flag_points") && (value == 0 || (value >= 128 && value <= 1024 && value % 64 == 0))) ctx->opt_arrsac_flag_points = value;
     else if (!std::strcmp(name, "pair_batch") && value >= 0 && value <= 256) ctx->opt_pair_batch = value;
+    else if (!std::strcmp(name, "pair_batch_raw_cap") && (value == 0 || (value >= 64 && value <= (1 << 22)))) ctx->opt_pair_batch_raw_cap = value;
     else if (!std::strcmp(name, "usac_lo_stepwise") && (value == 0 || value == 1)) ctx->opt_usac_lo_stepwise = value;
     else if (!std::strcmp(name, "ransac_host_table") && (value == 0 || value == 1)) ctx->opt_ransac_host_table = value;
     else if (!std::strcmp(name, "ransac_chunk") && value >= 0 && value <= 32768) ctx->opt_ransac_chunk = value;

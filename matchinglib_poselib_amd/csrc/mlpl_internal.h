@@ -55,6 +55,7 @@ enum WsSlot {
     WS_F16_CST,
     WS_F16_PART,
     WS_F16_CAND,
+    WS_BATCH_SMP, // mlpl_pair_pose_batch_dev: sample tables of a pass (drawn on the device), stream positions
     WS_NUM_SLOTS
 };
 
@@ -129,6 +130,7 @@ struct mlpl_ctx {
     long long last_usac_stats[8];
     long long last_batch_stats[8];                     // mlpl_pair_pose_batch_dev: {RANSAC passes, pair slots over all passes, pairs redone on a host table, 0}
     int opt_pair_batch;                                // pairs per internal batch of mlpl_pair_pose_batch_dev (0 = 128)
+    int opt_pair_batch_raw_cap;                        // tests: rand() values kept per pair for the device-side sampling (0 = 6.25 per iteration + 1024)
     int opt_arrsac_flag_points;                        // tests: correspondences every ARRSAC model is tested on up front (0 = 1024)
     int opt_usac_lo_stepwise;                          // tests: every step of a local-optimisation chain goes through the resume path
     // optional per-kernel hipEvent bracketing (mlpl_profile_*)

@@ -22,6 +22,89 @@ constexpr int kBatchFirstPass = 324;   // multiple of kHypPerWave; above the sto
 constexpr int kBatchPassMax = 1026;    // hypotheses per pair and pass (multiple of kHypPerWave)
 constexpr int kBatchPairsPerCall = 128;  // pairs per internal batch (workspace ~2.6 MB per pair)
 
+// getSubset (modelest.cpp:567-610) on the device: one wave per slot turns the pair's raw rand() stream into the slot's samples --
+// five draws `rand() % n` per sample, a draw that repeats an index of the sample is redrawn.  The stream position of sample i + 1
+// depends on the redraws of sample i, so the wave speculates: lane l parses sample i0 + l at position pos0 + 5 l as if no earlier sample
+// had redrawn anything; the lanes before the first one that meets a repeat are right and store their samples, that lane replays the
+// reference's draw-by-draw loop for its own sample, and the wave restarts behind it.  A repeat costs one more round (~0.65 per 324 samples
+// at n = 5000).  The host drew these tables in the two gaps of every internal batch (340 us per 128 pairs, a tenth of the C5 step).
+// `raw`: [pairs][raw_cap] values of srand(seed) / rand(), written by the host while the device matches (pinned, device-mapped);
+// pos[pair]: stream position, carried from pass to pass; ovf[pair] = 1 when the pair's stream would have to be longer than raw_cap
+// (small n: many redraws) -- the host then redoes that pair through the single-pair entry.
+__global__ __launch_bounds__(64) void draw_samples_kernel(const PairSlot *__restrict__ slots, const int32_t *__restrict__ raw, int raw_cap, int Hp, int NQ,
+                                                          int32_t *__restrict__ smp, int32_t *__restrict__ pos, int32_t *__restrict__ ovf) {
+    const PairSlot S = slots[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int32_t *r = raw + (size_t)S.pair * raw_cap;
+    int32_t *out = smp + (size_t)blockIdx.x * Hp * 5;
+    const uint32_t n = (uint32_t)S.n;
+    const int add = S.pair * NQ;  // global point index: the solver does not know about pairs
+    int pos0 = pos[S.pair], i0 = 0;
+    bool overflow = ovf[S.pair] != 0;
+    while (i0 < S.cnt && !overflow) {
+        const int i = i0 + lane, p = pos0 + 5 * lane;
+        const bool valid = i < S.cnt, inb = p + 5 <= raw_cap;
+        int v[5] = {0, 0, 0, 0, 0};
+        bool dup = false;
+        if (valid && inb) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] = (int)((uint32_t)r[p + k] % n);
+            dup = v[0] == v[1] || v[0] == v[2] || v[0] == v[3] || v[0] == v[4] || v[1] == v[2] || v[1] == v[3] || v[1] == v[4] || v[2] == v[3] ||
+                  v[2] == v[4] || v[3] == v[4];
+        }
+        const unsigned long long need = __ballot(valid && (dup || !inb));
+        const int nvalid = min(64, S.cnt - i0);
+        const int first = need ? __ffsll((long long)need) - 1 : nvalid;
+        if (valid && lane < first) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) out[(size_t)i * 5 + k] = v[k] + add;
+        }
+        if (first >= nvalid) {
+            i0 += nvalid, pos0 += 5 * nvalid;
+            continue;
+        }
+        int consumed = 0, bad = 0;
+        if (lane == first) {  // the reference's loop: one draw per pick, repeats redrawn
+            int idx[5] = {0, 0, 0, 0, 0};
+            int c = 0, q = p;
+            while (c < 5) {
+                if (q >= raw_cap) {
+                    bad = 1;
+                    break;
+                }
+                const int w = (int)((uint32_t)r[q++] % n);
+                bool rep = false;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) rep = rep || (k < c && idx[k] == w);
+                if (rep) continue;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) idx[k] = (k == c) ? w : idx[k];
+                ++c;
+            }
+            if (!bad) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) out[(size_t)i * 5 + k] = idx[k] + add;
+            }
+            consumed = q - p;
+        }
+        consumed = __shfl(consumed, first), bad = __shfl(bad, first);
+        if (bad) {
+            overflow = true;
+            break;
+        }
+        i0 += first + 1, pos0 += 5 * first + consumed;
+    }
+    if (overflow) {  // the pair is redone by the host; until then its remaining rows must hold valid point indices (the solver reads them)
+        for (int i = i0 + lane; i < S.cnt; i += 64)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) out[(size_t)i * 5 + k] = k + add;
+    }
+    if (lane == 0) {
+        pos[S.pair] = pos0;
+        if (overflow) ovf[S.pair] = 1;
+    }
+}
+
 }  // namespace
 
 int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
@@ -67,38 +150,47 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
     double *d_esum = (double *)p, *d_hsum = d_esum + hyps * 10;
     int32_t *d_nm = (int32_t *)(d_hsum + hyps), *d_dense_id = d_nm + hyps, *d_good = d_dense_id + hyps * 10, *d_hgood = d_good + hyps * 10,
             *d_hslot = d_hgood + hyps, *d_hmax = d_hslot + hyps, *d_cand = d_hmax + hyps;
-    // pinned: counts | states | pose | slots | samples
+    // device: the sample tables of a pass | stream positions and overflow flags of the pairs
+    if ((rc = ws_get(ctx, WS_BATCH_SMP, hyps * 20 + (size_t)B * 8 + 256, &p))) return rc;
+    int32_t *d_smp = (int32_t *)p, *d_rng_pos = d_smp + hyps * 5 + 32, *d_rng_ovf = d_rng_pos + B;
+    // raw rand() values kept per pair: every iteration's five draws, a quarter more for redraws (a pair that needs more -- tiny n -- is redone)
+    const int raw_cap = ((ctx->opt_pair_batch_raw_cap > 0 ? ctx->opt_pair_batch_raw_cap
+                                                          : (int)std::min<long long>((long long)max_iters * 5 + (long long)max_iters * 5 / 4 + 1024, 1 << 22)) + 30) / 31 * 31;
+    // pinned: counts | states | pose | slots | overflow flags | raw streams
     const size_t pin_counts = 0, pin_st = (pin_counts + (size_t)B * 4 + 255) / 256 * 256, pin_pose = pin_st + (size_t)B * sizeof(ReplayState),
                  pin_slots = pin_pose + (size_t)B * sizeof(PairPoseDev), pin_act = pin_slots + (size_t)B * sizeof(PairSlot),
-                 pin_smp = (pin_act + (size_t)B * 4 + 255) / 256 * 256, pin_end = pin_smp + hyps * 20;
+                 pin_ovf = pin_act + (size_t)B * 4, pin_smp = (pin_ovf + (size_t)B * 4 + 255) / 256 * 256, pin_end = pin_smp + (size_t)B * raw_cap * 4;
     void *pin;
     if ((rc = pinned_get(ctx, pin_end + 256, &pin))) return rc;
     char *hp = (char *)pin;
-    int32_t *h_counts = (int32_t *)(hp + pin_counts), *h_active = (int32_t *)(hp + pin_act), *h_smp = (int32_t *)(hp + pin_smp);
+    int32_t *h_counts = (int32_t *)(hp + pin_counts), *h_active = (int32_t *)(hp + pin_act), *h_raw = (int32_t *)(hp + pin_smp), *h_ovf = (int32_t *)(hp + pin_ovf);
     ReplayState *h_st = (ReplayState *)(hp + pin_st);
     PairPoseDev *h_pose = (PairPoseDev *)(hp + pin_pose);
     PairSlot *h_slots = (PairSlot *)(hp + pin_slots);
-    int32_t *d_smp_mapped = nullptr;
-    MLPL_HIP_TRY(hipHostGetDevicePointer((void **)&d_smp_mapped, h_smp, 0));
+    int32_t *d_raw_mapped = nullptr;
+    MLPL_HIP_TRY(hipHostGetDevicePointer((void **)&d_raw_mapped, h_raw, 0));
 
     // ---- matching, all pairs ----
     rc = mlpl_match_hamming_dev(ctx, d_q, nq, (size_t)nbytes, (size_t)nq * nbytes, d_t, nt, (size_t)nbytes, (size_t)nt * nbytes, nbytes, 1, 0.75f, B,
                                 (int32_t *)(b0 + off_idx), (int32_t *)(b0 + off_dist), d_m, d_counts, s);
     if (rc) return rc;
     MLPL_HIP_TRY(hipMemcpyAsync(h_counts, d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, s));
-    // the raw glibc streams do not depend on the counts: generate them while the device matches
-    std::vector<RandCache> caches((size_t)B);
-    std::vector<RandCursor> cur;
-    cur.reserve((size_t)B);
-    for (int b = 0; b < B; ++b) {
-        cur.emplace_back(&caches[b], seeds[b], (size_t)0);
-        (void)cur[b].peek(31);
-        const size_t want = (size_t)std::min(max_iters, kBatchFirstPass) * 5 + 64;
-        while (caches[b].raw.size() < want) {
-            caches[b].gen.refill();
-            caches[b].raw.insert(caches[b].raw.end(), caches[b].gen.out, caches[b].gen.out + 31);
-            caches[b].gen.pos = 31;
+    MLPL_HIP_TRY(hipMemsetAsync(d_rng_pos, 0, (size_t)B * 8, s));  // positions and overflow flags
+    // the raw glibc streams do not depend on the counts: the host generates them while the device matches, straight into the pinned block
+    // the sampling kernel reads (the samples themselves -- rand() % count, repeats redrawn -- are drawn on the device, per pass)
+    long long draw_us = 0;
+    {
+        const auto t_draw0 = std::chrono::steady_clock::now();
+        GlibcRand g;
+        for (int b = 0; b < B; ++b) {
+            g.seed(seeds[b]);
+            int32_t *row = h_raw + (size_t)b * raw_cap;
+            for (int o = 0; o < raw_cap; o += 31) {
+                g.refill();
+                std::memcpy(row + o, g.out, 31 * sizeof(int32_t));
+            }
         }
+        draw_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_draw0).count();
     }
     MLPL_HIP_TRY(hipStreamSynchronize(s));  // hop 1: the match counts
     std::vector<int> alive;
@@ -127,32 +219,26 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
     for (int b : alive) max_n = std::max(max_n, h_counts[b]);
     int base = 0;
     bool first_pass = true;
-    long long passes = 0, slots_total = 0, draw_us = 0;
+    long long passes = 0, slots_total = 0;
     while (!alive.empty() && base < max_iters) {
         const int A = (int)alive.size();
         const int H = std::min(first_pass ? kBatchFirstPass : kBatchPassMax, max_iters - base);
         const int Hp = (H + kHypPerWave - 1) / kHypPerWave * kHypPerWave;  // slot stride of this pass: hypotheses beyond a slot's count are padding (no models)
         if (!first_pass) MLPL_HIP_TRY(hipStreamSynchronize(s));           // the pinned sample / slot tables are rewritten
-        const auto t_draw0 = std::chrono::steady_clock::now();
         for (int a = 0; a < A; ++a) {
             const int b = alive[a];
             const int cnt = std::min(H, std::min(max_iters, state[b].niters) - base);
             PairSlot &S = h_slots[a];
             S.pts = d_pack + (size_t)b * pack_stride4, S.n = h_counts[b], S.pair = b, S.cnt = cnt, S.iter_base = base;
-            const FastMod fm(h_counts[b]);
-            int32_t *row = h_smp + (size_t)a * Hp * 5;
-            for (int i = 0; i < cnt; ++i) {
-                draw_sample(cur[b], fm, row + (size_t)i * 5);
-                for (int k = 0; k < 5; ++k) row[(size_t)i * 5 + k] += b * NQ;  // global point index: the solver does not know about pairs
-            }
-            // (rows cnt .. Hp - 1 are padding: the solver writes "no models" for them without reading the row)
+            // (rows cnt .. Hp - 1 of a slot's sample table are padding: the solver writes "no models" for them without reading the row)
         }
-        draw_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_draw0).count();
         MLPL_HIP_TRY(hipMemcpyAsync(d_slots, h_slots, (size_t)A * sizeof(PairSlot), hipMemcpyHostToDevice, s));
         MLPL_HIP_TRY(hipMemsetAsync(d_dense_total, 0, (size_t)A * 4, s));
         const int total_hyps = A * Hp;
+        hipLaunchKernelGGL(draw_samples_kernel, dim3(A), dim3(64), 0, s, (const PairSlot *)d_slots, (const int32_t *)d_raw_mapped, raw_cap, Hp, NQ, d_smp,
+                           d_rng_pos, d_rng_ovf);
         prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
-        launch_solve5pt(ctx, total_hyps, s, (const double *)d_p1, (const double *)d_p2, (const int32_t *)d_smp_mapped, 0, total_hyps, d_recs,
+        launch_solve5pt(ctx, total_hyps, s, (const double *)d_p1, (const double *)d_p2, (const int32_t *)d_smp, 0, total_hyps, d_recs,
                         (const PairSlot *)d_slots, Hp);
         MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3(total_hyps / kHypPerWave), s, (const PolyRec *)d_recs, 0, total_hyps, d_Etab, d_nm, d_denseE,
                           d_dense_id, d_dense_total, d_good, Hp);
@@ -181,12 +267,14 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
                            (const PairSlot *)d_slots, Hp);
         MLPL_HIP_TRY(hipGetLastError());
         MLPL_HIP_TRY(hipMemcpyAsync(h_st, d_st, (size_t)B * sizeof(ReplayState), hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipMemcpyAsync(h_ovf, d_rng_ovf, (size_t)B * 4, hipMemcpyDeviceToHost, s));
         MLPL_HIP_TRY(hipStreamSynchronize(s));  // one hop per pass: which pairs go on
         passes++, slots_total += A;
         base += H;
         std::vector<int> next;
         for (int b : alive) {
             state[b] = h_st[b];
+            if (h_ovf[b]) continue;  // its stream ran out: redone below, sample tables from the host
             if (!state[b].stop && base < std::min(max_iters, state[b].niters)) next.push_back(b);
         }
         alive.swap(next);
@@ -198,7 +286,7 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
     for (int b = 0; b < B; ++b) {
         if (!h_active[b]) continue;
         const ReplayState &fin = state[b];
-        bool ok = fin.t_count <= kTUsedMax;
+        bool ok = fin.t_count <= kTUsedMax && !h_ovf[b];
         for (int i = 0; ok && i < fin.t_count; ++i)
             ok = fin.t_val[i] == update_num_iters(confidence, (double)(h_counts[b] - fin.t_g[i]) / h_counts[b], 5, INT32_MAX);
         if (!ok) redo.push_back(b);

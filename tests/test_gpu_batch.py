@@ -117,3 +117,40 @@ def test_batched_pairs_edge_cases(ctx, oracle):
         bat = batch.process_pairs_batched(ctx, dq, dt, k1, k2, K, K, seeds, **kw)
         assert bat.tobytes() == one.tobytes(), (kw, bat, one)
         assert one["status"][1] == -1 and one["status"][0] == 0
+
+
+def test_batched_pairs_few_matches_and_short_raw_streams(ctx):
+    """The samples of a batch are drawn on the device from the pairs' raw rand() streams (one wave per pair, speculating "no repeated
+    index" 64 samples at a time).  Pairs with 16-60 matches repeat an index in up to half of their samples: the draw-by-draw path of the
+    kernel; a raw stream cut short (test option) runs out in the first or in the second pass: those pairs are redone by the single-pair
+    entry.  Records byte-identical to mlpl_pair_pose_dev every time."""
+    dev = torch.device("cuda:0")
+    sizes = [40, 48, 64, 96, 128, 256, 40, 56, 1024, 72, 1536, 88]
+    sps = [synth.stereo_pair(sizes[i], seed=900 + i, inlier_frac=0.3 if i in (8, 10) else 0.55 + 0.03 * (i % 5), unmatched_frac=0.05 * (i % 3))
+           for i in range(12)]   # (pairs 8 and 10 need every one of the 1000 iterations: three passes)
+    nmax = max(sizes)
+    for sp in sps:   # common shape: pad the descriptor / keypoint blocks with rows that match nothing well
+        k = nmax - len(sp["desc1"])
+        if k:
+            rng = np.random.default_rng(len(sp["desc1"]))
+            for d in ("desc1", "desc2"):
+                sp[d] = np.concatenate([sp[d], rng.integers(0, 256, (k, sp[d].shape[1]), dtype=np.uint8)])
+            for kp in ("kp1", "kp2"):
+                sp[kp] = np.concatenate([sp[kp], rng.uniform(0, 600, (k, 2)).astype(np.float32)])
+    seeds = [4000 + 7 * i for i in range(12)]
+    K = sps[0]["K"]
+    one = np.concatenate([batch.process_pair_on_device(ctx, *(torch.from_numpy(sp[k]).to(dev) for k in ("desc1", "desc2", "kp1", "kp2")), K, K,
+                                                       seed=seeds[i], pair_id=i) for i, sp in enumerate(sps)])
+    assert 16 <= one["n_matches"].min() < 64 and (one["status"] == 0).sum() >= 10, one["n_matches"]
+    dq, dt, k1, k2 = _stack(sps, dev)
+    stats = np.zeros(8, np.int64)
+    for cap, redone in ((0, False), (1500, True), (2200, True), (400, True)):
+        ctx.set_option("pair_batch_raw_cap", cap)
+        try:
+            bat = batch.process_pairs_batched(ctx, dq, dt, k1, k2, K, K, seeds)
+        finally:
+            ctx.set_option("pair_batch_raw_cap", 0)
+        ctx.lib.mlpl_pair_batch_last_stats(ctx.handle, stats.ctypes.data)
+        for i in range(12):
+            assert bat[i].tobytes() == one[i].tobytes(), (cap, i, bat[i], one[i])
+        assert (stats[2] > 0) == redone, (cap, stats)
