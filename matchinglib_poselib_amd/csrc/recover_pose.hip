@@ -261,15 +261,32 @@ __global__ __launch_bounds__(256) void triangulate_batch_kernel(const double *__
                                                                 uint8_t *__restrict__ mask_out /*[B][4][pair_stride]*/,
                                                                 int32_t *__restrict__ cand_counts /*[B][4]*/) {
     __shared__ int wave_cnt[4];
+    __shared__ int todo[256];
     const int b = blockIdx.z, c = blockIdx.y;
     const int n = active[b] ? counts[b] : 0;
     if ((int)(blockIdx.x * blockDim.x) >= n) return;  // block-uniform
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    // A correspondence outside the incoming mask cannot pass whatever its 3-D point is (the batch form returns no points): no SVD for it.
+    // About half of the correspondences are such (the RANSAC outliers), scattered over the lanes: the block first compacts the ones to
+    // triangulate into a list, so that its first waves run the SVD with every lane busy and the others leave at once (as lane i = point
+    // i the kernel ran 467 us per 128 pairs with half of every wave idle through the Jacobi sweeps).
+    const bool want = i0 < n && (!mask_in || mask_in[(size_t)b * pair_stride + i0]);
+    if (i0 < n && !want) mask_out[((size_t)b * 4 + c) * pair_stride + i0] = 0;
+    const unsigned long long wb = __ballot(want);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wv] = __popcll(wb);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        before += (k < wv) ? wave_cnt[k] : 0;
+        total += wave_cnt[k];
+    }
+    if (want) todo[before + __popcll(wb & ((1ull << lane) - 1ull))] = i0;
+    __syncthreads();
     bool good = false;
-    // a correspondence outside the incoming mask cannot pass whatever its 3-D point is (the batch form returns no points): skip its SVD
-    if (i < n && mask_in && !mask_in[(size_t)b * pair_stride + i]) {
-        mask_out[((size_t)b * 4 + c) * pair_stride + i] = 0;
-    } else if (i < n) {
+    if ((int)threadIdx.x < total) {
+        const int i = todo[threadIdx.x];
         const double *Pc = P_all + (size_t)b * 69 + c * 12;
         const size_t at = ((size_t)b * pair_stride + i) * 2;
         const double x1 = p1[at], y1 = p1[at + 1], x2 = p2[at], y2 = p2[at + 1];
@@ -303,6 +320,7 @@ __global__ __launch_bounds__(256) void triangulate_batch_kernel(const double *__
         mask_out[((size_t)b * 4 + c) * pair_stride + i] = mv;
         good = (mv != 0);
     }
+    __syncthreads();  // wave_cnt is reused below
     const unsigned long long bal = __ballot(good);
     if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(bal);
     __syncthreads();
