@@ -138,7 +138,7 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
     stats = np.zeros(8, np.int64)
     lib.mlpl_pair_batch_last_stats(ctx.handle, stats.ctypes.data)
     prof = {}
-    for name, kid in (("knn_hamming_mfma_lds_kernel<4, 0>", 0), ("solve5pt_kernel + roots_kernel_t<true>", 2),
+    for name, kid in (("knn_hamming_mfma_lds_kernel<4, 0>", 0), ("solve5pt3_kernel + roots_kernel_t<true>", 2),
                       ("count_models_f32_kernel<512, 512>", 3), ("decompose / triangulate / select (batch)", 4)):
         ms, cnt = C.c_double(0), C.c_int(0)
         lib.mlpl_profile_read(ctx.handle, kid, C.byref(ms), C.byref(cnt))
@@ -161,7 +161,7 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
                    "gathered_per_step": "184-byte records by all_gather + the padded match lists to rank 0 by grouped send / recv",
                    "mean_matches": float(allrec["n_matches"].mean()), "mean_inliers": float(allrec["n_inliers"].mean()),
                    "ransac_passes_rank0": int(stats[0]), "pair_slots_rank0": int(stats[1]), "iterations_rank0": int(stats[6]),
-                   "host_sample_drawing_ms_per_step_rank0": float(stats[3]) / 1e3},
+                   "host_rand_stream_ms_per_step_rank0": float(stats[3]) / 1e3},
         "kernel_ms_per_step_rank0": per_step,
         "roofline": {
             "kernel": dom, "bound": "valu-fp32" if dom.startswith("count") else ("mfma" if dom.startswith("knn") else "valu-fp64 (issue / latency bound)"),

@@ -295,7 +295,7 @@ def run(ctx, dev, cpu_baseline=True):
     out["c5_pair_pipeline_batched"] = {"value": nb / min(tb), "unit": "image-pairs/s (one GPU)", "ms_per_pair": min(tb) / nb * 1e3,
                                        "ms_per_pair_each_pass": [round(t / nb * 1e3, 4) for t in tb], "ms_per_pair_max_of_passes": max(tb) / nb * 1e3,
                                        "same_records_as_sequential": bool(same), "ransac_passes": int(bst[0]), "pair_slots": int(bst[1]),
-                                       "host_sample_drawing_ms": float(bst[3]) / 1e3,
+                                       "host_rand_stream_ms": float(bst[3]) / 1e3,
                                        "note": "mlpl_pair_pose_batch_dev: one call, 128 pairs; host hops: match counts, one per RANSAC pass, results"}
     # the round-2 shape for comparison (8 pairs in flight: independent contexts, streams and host threads) with EVERY pass and every
     # call timed: round 2's record held one pass in five that took 30 x longer (3.4 ms per pair) -- the per-call records below say which

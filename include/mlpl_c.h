@@ -356,8 +356,8 @@ int mlpl_pair_pose_batch_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int
 /* d_matches_out: NULL, or a device block [n_pairs][nq] that receives every pair's match list (out[i].n_matches valid entries each,
  * ascending queryIdx) -- what a caller gathers beside the pose records (needs refit = 0).
  * Statistics of the last mlpl_pair_pose_batch_dev call: {RANSAC passes, pair slots summed over the passes, pairs redone by the
- * single-pair pipeline because a device-evaluated iteration bound differed from the host's libm, host microseconds spent drawing the
- * sample tables, essential matrices scored, Sampson evaluations (matrices x correspondences), RANSAC iterations executed, 0}. */
+ * single-pair pipeline (a device-evaluated iteration bound differed from the host's libm, or the pair's raw rand() stream ran out on the
+ * device), host microseconds spent generating the raw rand() streams (the samples themselves are drawn on the device), essential matrices scored, Sampson evaluations (matrices x correspondences), RANSAC iterations executed, 0}. */
 int mlpl_pair_batch_last_stats(mlpl_ctx *ctx, long long stats[8]);
 
 /* Building blocks, exposed for parity tests and for callers that schedule the phases themselves. */
