@@ -176,7 +176,7 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
                     "(model, correspondence) evaluation x the evaluations of the step, decided in packed fp32 (two per instruction) inside "
                     "a rigorous error band, priced against the fp32 vector peak; Hamming: 2 x 256 FLOP per descriptor pair against the "
                     "dense FP4 peak; solver kernels: ~15 kFLOP (fp64) per 5-point hypothesis x the iterations of the step against the fp64 vector peak -- "
-                    "one hypothesis per wavefront, issue / latency bound, far from that roofline by construction (SURVEY 8(d))",
+                    "three hypotheses per wavefront (elimination) and six (roots), issue / latency bound, far from that roofline by construction (SURVEY 8(d))",
             "sampson_evaluations_per_step": evals, "score_kernel_TFLOPs_equiv": evals * FLOP_PER_SAMPSON / (score_ms * 1e-3) / 1e12 if score_ms > 0 else None,
             "hamming_kernel_frac_of_fp4_peak": mine * args.n * args.n * FLOP_PER_PAIR / (ham_ms * 1e-3) / 1e12 / FP4_MFMA_PEAK_TFLOPS if ham_ms > 0 else None,
         },
