@@ -392,6 +392,7 @@ def main():
         kernel_name = "knn_hamming_mfma_lds_kernel<4, 0>" if mfma_path else "knn_hamming_partial_kernel<8>"
         # traffic was measured with 8 pairs per launch: scale the per-launch figure to this run's launch size (it is per-pair work)
         traffic, traffic_src = None, None
+        prof = {}   # counter-derived figures of the same launch shape from the committed profile (not measured in this run)
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
@@ -401,6 +402,8 @@ def main():
                     traffic = traffic * P / float(tj["pairs_per_launch"])
                 traffic_src = f"from profiles/pmc_traffic.json (round {tj.get('round', '?')}, {tj.get('pairs_per_launch', '?')} pairs per " \
                               "launch; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes) -- not measured in this run"
+                if mfma_path and tj.get("pairs_per_launch") == P:
+                    prof = {k: tj[k] for k in ("mfma_busy_frac", "mfma_busy_how", "shader_clock_GHz_under_pmc", "kernel_us_rocprof_trace") if k in tj}
             except Exception:
                 traffic = None
         if mfma_path:
@@ -416,6 +419,7 @@ def main():
                 "frac": achieved / FP4_MFMA_PEAK_TFLOPS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "from_profiles": prof or None,
                 "kernel_ms_avg": kern_ms,
                 "launches_timed": launches.value,
                 "note": "the all-pairs Hamming table as a +-1 GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 x fp4, fp32 accumulate, "

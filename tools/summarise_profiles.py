@@ -78,6 +78,22 @@ for k, e in summary.items():
             traffic["knn_hamming_partial_bytes_per_launch"] = b
         if k.startswith("hamming_expand_kernel"):
             traffic["hamming_expand_bytes_per_launch"] = b
+# matrix-core busy fraction of the headline launch: SQ_VALU_MFMA_BUSY_CYCLES over the SIMD-cycles of the launch (GRBM_GUI_ACTIVE sums the
+# eight XCDs' clocks; 1024 SIMDs), and the kernel's duration under `--kernel-trace` for the same grid
+for k, e in summary.items():
+    if k.startswith("knn_hamming_mfma_lds_kernel<4, 0>") and k.endswith("@grid " + HEADLINE_GRID):
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in e and "GRBM_GUI_ACTIVE" in e:
+            cyc = e["GRBM_GUI_ACTIVE"]["mean"] / 8.0
+            traffic["mfma_busy_frac"] = e["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (1024.0 * cyc)
+            traffic["mfma_busy_how"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), separate --pmc passes"
+            traffic["shader_clock_GHz_under_pmc"] = cyc / e["duration_ns_under_pmc"]["pmc_grbm"]
+kt = one("trace/*/*kernel_trace.csv")
+if kt:
+    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt))
+         if r["Kernel_Name"].find("knn_hamming_mfma_lds_kernel<4, 0>") >= 0 and r.get("Grid_Size_X", r.get("Grid_Size", "")) == HEADLINE_GRID]
+    if d:
+        traffic["kernel_us_rocprof_trace"] = sum(d) / len(d) / 1e3
+        traffic["kernel_launches_rocprof_trace"] = len(d)
 old = os.path.join(DST, "pmc_traffic.json")
 if os.path.exists(old):
     prev = json.load(open(old))
