@@ -69,7 +69,7 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  *     "hamming_stamps" 1 = per-wave / per-workgroup clock stamps (mlpl_debug_hamming_stamps).
  *   L2: "l2_mfma_waves" 0|4|8 and "l2_mfma_blocks_per_cu" shape the int8 matrix-core kernel of the forced mode (see mlpl_set_l2_path);
  *     "l2_float_mfma" 0|1|2 decides when the fp16 candidate path serves non-integer float descriptors (mlpl_set_l2_path, mode 0).
- *   RANSAC: "ransac_chunk" hypotheses per device pass (0 = 32768 = the maximum; the sequential best/niters rule is replayed across
+ *   RANSAC: "ransac_device_draw" (default 1) = large passes draw their samples on the device (mlpl_debug_ransac_draw); "ransac_chunk" hypotheses per device pass (0 = 32768 = the maximum; the sequential best/niters rule is replayed across
  *     passes); "ransac_lazy_sums" (default 1) = the passes count inliers without the division and compute error sums only for the
  *     models that can still win, 0 = sums for every model; "ransac_f32_filter" (default 1) = the counting kernels decide in packed single
  *     precision outside a rigorous error band and in fp64 inside it (same counts), 0 = fp64 only; "ransac_overlap" (default 1) = the
@@ -383,6 +383,10 @@ int mlpl_median_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n,
 /* Statistics of the last mlpl_ransac_essential[_dev] call on this context: {iterations executed, essential matrices
  * scored}.  Used by bench.py to turn the scoring kernel's time into algorithmic FLOP/s. */
 int mlpl_ransac_last_stats(mlpl_ctx *ctx, long long stats[2]);
+/* Diagnostics of the device-side sampling of large RANSAC passes (option "ransac_device_draw", default 1: passes of >= 4096 hypotheses on
+ * >= 64 correspondences draw their samples on the device from the cached raw rand() stream): {calls redone with the host drawing the table
+ * because a window / list / the stream ran out, 1 if the last call's samples were drawn on the device}. */
+int mlpl_debug_ransac_draw(mlpl_ctx *ctx, long long out[2]);
 
 /* Diagnostics: root-iteration (Ehrlich-Aberth) sweep statistics of the solver since the last call: {sum, solves, max, (enabled), sample
  * index of the max, solves with <= 8, 12, 16, 24, 32, 64, 128, 256, < 400, = 400 sweeps, 0}; enable != 0 turns the (atomic) bookkeeping on.

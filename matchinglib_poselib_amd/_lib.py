@@ -108,6 +108,7 @@ _SIGNATURES = {
     "mlpl_score_models": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_double, c_void_p,
                                   c_void_p]),
     "mlpl_ransac_last_stats": (c_int, [c_void_p, c_void_p]),
+    "mlpl_debug_ransac_draw": (c_int, [c_void_p, c_void_p]),
     "mlpl_debug_dk_stats": (c_int, [c_void_p, c_int, c_void_p]),
     "mlpl_debug_hamming_stamps": (c_int, [c_void_p, c_void_p, c_int]),
     "mlpl_pair_pose_dev": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double,

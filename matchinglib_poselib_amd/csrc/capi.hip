@@ -121,6 +121,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_ransac_f32_filter = 1;
     ctx->opt_solver_polish = 1;
     ctx->opt_solver_wave3 = 1;
+    ctx->opt_ransac_device_draw = 1;
     ctx->opt_l2_float_mfma = 1;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -191,6 +192,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "ransac_event_cap") && value >= 0 && value <= 1024) ctx->opt_ransac_event_cap = value;
     else if (!std::strcmp(name, "solver_polish") && (value == 0 || value == 1)) ctx->opt_solver_polish = value;
     else if (!std::strcmp(name, "solver_wave3") && (value == 0 || value == 1)) ctx->opt_solver_wave3 = value;
+    else if (!std::strcmp(name, "ransac_device_draw") && (value == 0 || value == 1)) ctx->opt_ransac_device_draw = value;
     else if (!std::strcmp(name, "l2_float_mfma") && value >= 0 && value <= 2) ctx->opt_l2_float_mfma = value;
     else if (!std::strcmp(name, "arrsac_flag_points") && (value == 0 || (value >= 128 && value <= 1024 && value % 64 == 0))) ctx->opt_arrsac_flag_points = value;
     else if (!std::strcmp(name, "pair_batch") && value >= 0 && value <= 256) ctx->opt_pair_batch = value;

@@ -56,6 +56,7 @@ enum WsSlot {
     WS_F16_PART,
     WS_F16_CAND,
     WS_BATCH_SMP, // mlpl_pair_pose_batch_dev: sample tables of a pass (drawn on the device), stream positions
+    WS_RAND_RAW,  // raw rand() stream of the last RANSAC seed on the device + the control block of the device-side sampling
     WS_NUM_SLOTS
 };
 
@@ -120,6 +121,13 @@ struct mlpl_ctx {
     int ransac_T_n;
     double ransac_T_conf;
     int ransac_force_table;        // 1 = build the host niters table (fallback / tests)
+    int ransac_force_host_draw;    // 1 = draw the sample table on the host (fallback of the device-side sampling)
+    int opt_ransac_device_draw;    // 1 (default) = passes of >= 4096 hypotheses draw their samples on the device from the cached raw stream
+    void *rand_dev_ptr;            // the WS_RAND_RAW block the fields below describe
+    unsigned rand_dev_seed;
+    size_t rand_dev_len;           // values of srand(rand_dev_seed) / rand() present on the device
+    long long ransac_draw_fallbacks;
+    int last_ransac_dev_draw;      // the last mlpl_ransac_essential* call drew its samples on the device
     long long ransac_table_fallbacks;  // calls redone on the host table because a device-evaluated bound differed
     long long last_ransac_models, last_ransac_iters;  // statistics of the last mlpl_ransac_essential* call
     int32_t *arrsac_trace;                             // diagnostics: host buffer for the turn records of ARRSAC's first stage

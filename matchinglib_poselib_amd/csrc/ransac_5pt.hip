@@ -2439,6 +2439,216 @@ void draw_sample(RandCursor &g, const FastMod &mod, int32_t *idx) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// getSubset (modelest.cpp:567-610) for ONE pair and a large pass, on the device.  The stream position of sample i + 1 depends on the
+// redraws of sample i, but redraws are rare (a sample repeats an index with probability ~10 / n) and between two of them the sample
+// starts are an arithmetic progression of step 5.  Three launches:
+//   draw_scan_kernel   every stream position p of the pass's window in parallel: the five values at p reduced modulo n; where two of
+//                      them coincide, p is an EVENT CANDIDATE -- a sample starting there redraws -- and the thread replays the reference's
+//                      draw-by-draw loop from p (draws consumed, the five indices) into a candidate list;
+//   draw_chain_kernel  one wave walks from event to event: the next event after position p is the smallest candidate q >= p with
+//                      q = p (mod 5); the samples before it form a segment (first sample, first position), the event sample takes the
+//                      candidate's indices, the walk continues behind the draws it consumed.  ~40 steps for 20 000 samples at n = 5000;
+//   draw_fill_kernel   every sample in parallel: its segment by binary search, its five values at first position + 5 (i - first sample),
+//                      written unless they repeat (then it is an event sample, already written).
+// The raw stream of the seed is cached on the device (uploaded when the seed changes).  Anything that does not fit -- window or lists too
+// small (tiny n: every second sample redraws), stream longer than the cache -- sets an overflow flag and the call is redone with the host
+// drawing the table.  The host (9 ns per sample, overlapped slice by slice with the solver) had become the solver phase's critical path
+// once the elimination kernel took three hypotheses per wave: 275 us for 20 000 hypotheses of which the kernels need 140.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kDrawCandCap = 4096;
+constexpr int kDrawSegCap = 1024;
+struct DrawCand {
+    int32_t p, c;       // window-relative position, draws consumed by the sample starting there (-1: the stream ran out)
+    int32_t idx[5];
+    int32_t pad;
+};
+struct DrawCtl {
+    int32_t pos;        // stream position at the start of the next pass
+    int32_t pos_prev;   // ... of the pass being filled
+    int32_t overflow;
+    int32_t ncand, nseg;
+    int32_t pad[3];
+    int32_t seg_first[kDrawSegCap], seg_pos[kDrawSegCap];
+};
+
+__global__ __launch_bounds__(256) void draw_scan_kernel(const int32_t *__restrict__ raw, int raw_len, int n, int window, DrawCtl *__restrict__ ctl,
+                                                        DrawCand *__restrict__ cand) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= window) return;
+    const int p = ctl->pos + w;
+    if (p + 5 > raw_len) return;  // (a sample that would have to start here makes the chain kernel report the overflow)
+    const uint32_t un = (uint32_t)n;
+    int v[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = (int)((uint32_t)raw[p + k] % un);
+    const bool dup = v[0] == v[1] || v[0] == v[2] || v[0] == v[3] || v[0] == v[4] || v[1] == v[2] || v[1] == v[3] || v[1] == v[4] || v[2] == v[3] ||
+                     v[2] == v[4] || v[3] == v[4];
+    if (!dup) return;
+    int idx[5] = {0, 0, 0, 0, 0};
+    int c = 0, q = p;
+    bool out = false;
+    while (c < 5) {  // the reference's loop: one draw per pick, repeats redrawn
+        if (q >= raw_len) {
+            out = true;
+            break;
+        }
+        const int x = (int)((uint32_t)raw[q++] % un);
+        bool rep = false;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) rep = rep || (k < c && idx[k] == x);
+        if (rep) continue;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) idx[k] = (k == c) ? x : idx[k];
+        ++c;
+    }
+    const int slot = atomicAdd(&ctl->ncand, 1);
+    if (slot < kDrawCandCap) {
+        DrawCand d;
+        d.p = w, d.c = out ? -1 : q - p, d.pad = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) d.idx[k] = idx[k];
+        cand[slot] = d;
+    }
+}
+
+// Minimum over the wave on data-parallel-primitive moves (row shifts inside the rows of 16 lanes, then the two row broadcasts of gfx9):
+// six dependent VALU instructions, against six dependent LDS-crossbar round trips of a __shfl_xor butterfly (~700 cycles, which made a
+// chain step 640 ns).  Lanes without a source keep INT_MAX.
+__device__ __forceinline__ int wave_min_i32(int x) {
+    x = min(x, __builtin_amdgcn_update_dpp(INT_MAX, x, 0x111, 0xf, 0xf, false));  // row_shr:1
+    x = min(x, __builtin_amdgcn_update_dpp(INT_MAX, x, 0x112, 0xf, 0xf, false));  // row_shr:2
+    x = min(x, __builtin_amdgcn_update_dpp(INT_MAX, x, 0x114, 0xf, 0xf, false));  // row_shr:4
+    x = min(x, __builtin_amdgcn_update_dpp(INT_MAX, x, 0x118, 0xf, 0xf, false));  // row_shr:8: lane 15 of a row holds the row's minimum
+    x = min(x, __builtin_amdgcn_update_dpp(INT_MAX, x, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
+    x = min(x, __builtin_amdgcn_update_dpp(INT_MAX, x, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+__global__ __launch_bounds__(64) void draw_chain_kernel(int raw_len, int cnt, int window, DrawCtl *__restrict__ ctl, const DrawCand *__restrict__ cand,
+                                                        int32_t *__restrict__ out) {
+    __shared__ int cp[kDrawCandCap], cc[kDrawCandCap];
+    __shared__ int ev_i[kDrawSegCap], ev_k[kDrawSegCap];  // event samples met on the way: (sample, candidate), written after the walk
+    __shared__ int sg_first[kDrawSegCap], sg_pos[kDrawSegCap];  // the segments, copied out after the walk (a global store per step stalled it)
+    const int lane = threadIdx.x;
+    // (this kernel is a chain of memory round trips around a short walk: every load that can be issued early is)
+    const int nc = ctl->ncand, ovf_in = ctl->overflow, pos_in = ctl->pos;
+    int2 first4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) first4[u] = *reinterpret_cast<const int2 *>(&cand[min(lane + 64 * u, kDrawCandCap - 1)]);  // (p, c) of a candidate
+    bool overflow = ovf_in != 0 || nc > kDrawCandCap;
+    const int ncl = min(nc, kDrawCandCap);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < ncl) cp[lane + 64 * u] = first4[u].x, cc[lane + 64 * u] = first4[u].y;
+    for (int k = lane + 256; k < ncl; k += 64) cp[k] = cand[k].p, cc[k] = cand[k].c;
+    __syncthreads();
+    int p = 0, i = 0, nseg = 0, p_end = 0, nev = 0;
+    // up to 256 candidates (the usual case: ~10 / n of the window's positions) stay in registers, four per lane: a step of the walk is then
+    // a handful of compares and the wave minimum, no LDS round trip
+    const bool in_regs = ncl <= 256;
+    int rp[4], rcn[4], rcl[4];  // position, draws consumed, position mod 5 (a progression's events share its residue)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = lane + 64 * u;
+        rp[u] = (in_regs && k < ncl) ? cp[k] : INT_MAX;
+        rcn[u] = (in_regs && k < ncl) ? cc[k] : -1;
+        rcl[u] = (in_regs && k < ncl) ? cp[k] % 5 : -1;
+    }
+    int cev = -1;  // draws consumed by the event sample found in this step
+    while (!overflow) {
+        // the next event: the smallest candidate position q >= p on this progression
+        int best = INT_MAX, bk = -1, bc = -1;
+        if (in_regs) {
+            const int pcl = p % 5;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = rp[u];
+                const bool take = rcl[u] == pcl && q >= p && q < best;
+                best = take ? q : best, bk = take ? lane + 64 * u : bk, bc = take ? rcn[u] : bc;
+            }
+        } else {
+            for (int k = lane; k < ncl; k += 64) {
+                const int q = cp[k];
+                if (q >= p && (q - p) % 5 == 0 && q < best) best = q, bk = k, bc = cc[k];
+            }
+        }
+        {
+            const int gbest = wave_min_i32(best);
+            const unsigned long long who = __ballot(best == gbest && gbest != INT_MAX);
+            const int leader = who ? __ffsll((long long)who) - 1 : 0;
+            bk = who ? __builtin_amdgcn_readlane(bk, leader) : -1;
+            cev = who ? __builtin_amdgcn_readlane(bc, leader) : -1;
+            best = gbest;
+        }
+        const long long ie = (best == INT_MAX) ? (long long)cnt : (long long)i + (best - p) / 5;
+        if (nseg >= kDrawSegCap) {
+            overflow = true;
+            break;
+        }
+        if (lane == 0) sg_first[nseg] = i, sg_pos[nseg] = p;
+        ++nseg;
+        if (ie >= cnt) {  // the rest of the pass lies on this progression
+            p_end = p + 5 * (cnt - i);
+            break;
+        }
+        const int c = cev;
+        if (c < 0) {
+            overflow = true;
+            break;
+        }
+        if (lane == 0) ev_i[nseg - 1] = (int)ie, ev_k[nseg - 1] = bk;  // (one event per segment closed)
+        ++nev;
+        p = best + c, i = (int)ie + 1, p_end = p;
+        if (i >= cnt) break;
+    }
+    if (!overflow && (p_end > window || pos_in + p_end > raw_len)) overflow = true;
+    __syncthreads();
+    for (int k = lane; k < nseg; k += 64) ctl->seg_first[k] = sg_first[k], ctl->seg_pos[k] = sg_pos[k];
+    // the event samples, all lanes (inside the walk each one cost the wave a memory round trip: 32 us for ~45 events)
+    for (int e = lane; e < nev && !overflow; e += 64) {
+        const DrawCand d = cand[ev_k[e]];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) out[(size_t)ev_i[e] * 5 + k] = d.idx[k];
+    }
+    if (lane == 0) {
+        ctl->nseg = nseg;
+        ctl->pos_prev = pos_in;
+        ctl->pos = pos_in + p_end;
+        ctl->ncand = 0;  // for the next pass
+        if (overflow) ctl->overflow = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void draw_fill_kernel(const int32_t *__restrict__ raw, int raw_len, int n, int cnt, const DrawCtl *__restrict__ ctl,
+                                                        int32_t *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    int v[5] = {0, 1, 2, 3, 4};  // what an overflowed pass leaves: valid indices (the call is redone)
+    bool write = true;
+    if (!ctl->overflow) {
+        int lo = 0, hi = ctl->nseg - 1;  // the last segment whose first sample is <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (ctl->seg_first[mid] <= i) lo = mid;
+            else hi = mid - 1;
+        }
+        const long long p = (long long)ctl->pos_prev + ctl->seg_pos[lo] + 5ll * (i - ctl->seg_first[lo]);
+        if (p + 5 <= raw_len) {
+            const uint32_t un = (uint32_t)n;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] = (int)((uint32_t)raw[p + k] % un);
+            write = !(v[0] == v[1] || v[0] == v[2] || v[0] == v[3] || v[0] == v[4] || v[1] == v[2] || v[1] == v[3] || v[1] == v[4] || v[2] == v[3] ||
+                      v[2] == v[4] || v[3] == v[4]);  // (a repeat: an event sample, written by the chain kernel)
+        }
+    }
+    if (write) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) out[(size_t)i * 5 + k] = v[k];
+    }
+}
+
 // cvRANSACUpdateNumIters1 (modelest.cpp:86-109)
 int update_num_iters(double p, double ep, int model_points, int max_iters) {
     p = std::max(p, 0.);
@@ -2593,6 +2803,13 @@ int mlpl_ransac_last_stats(mlpl_ctx *ctx, long long stats[2]) {
     return MLPL_OK;
 }
 
+int mlpl_debug_ransac_draw(mlpl_ctx *ctx, long long out[2]) {
+    if (!ctx || !out) return MLPL_E_BAD_INPUT;
+    out[0] = ctx->ransac_draw_fallbacks;
+    out[1] = ctx->last_ransac_dev_draw;
+    return MLPL_OK;
+}
+
 int mlpl_debug_dk_stats(mlpl_ctx *ctx, int enable, int stats[16]) {
     if (!ctx) return MLPL_E_BAD_INPUT;
     MLPL_HIP_TRY(hipSetDevice(ctx->device));
@@ -2739,8 +2956,9 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     // pinned staging: samples up, state down
     void *pin;
     if ((rc = pinned_get(ctx, (size_t)chunk_cap * 20 + (size_t)(n + 1) * 4 + 2048, &pin))) return rc;
-    static_assert(sizeof(ReplayState) <= 1024, "staging layout");
+    static_assert(sizeof(ReplayState) <= 1008, "staging layout");
     ReplayState *h_st = (ReplayState *)pin;
+    int32_t *h_ovf = (int32_t *)((char *)pin + 1008);  // overflow flag of the device-side sampling, read back with the final state
     int32_t *h_T = (int32_t *)((char *)pin + 1024);
     int32_t *h_samples = h_T + (n + 1);
     int32_t *d_samples_mapped = nullptr;  // device view of the pinned sample table
@@ -2778,6 +2996,42 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     RandCursor rng(static_cast<RandCache *>(ctx->rand_cache), seed, (size_t)ctx->opt_rand_cache_max);
     const FastMod fmod_n(n);
     const double log_num = std::log(std::max(1. - std::min(std::max(confidence, 0.), 1.), DBL_MIN));  // update_num_iters' numerator
+    // Device-side sampling for large passes (see draw_scan_kernel): the raw stream of the seed on the device, a control block behind it.
+    // (eligible: enough hypotheses to be worth three launches, and few enough samples that redraw -- ~ 56 / n of the window's positions --
+    // for the candidate list)
+    bool dev_draw = ctx->opt_ransac_device_draw != 0 && !ctx->ransac_force_host_draw && n >= 64 && chunk_cap >= 4096 &&
+                    (double)chunk_cap * 60.0 / n < 0.75 * kDrawCandCap;
+    const int32_t *d_raw = nullptr;
+    DrawCtl *d_ctl = nullptr;
+    DrawCand *d_cand = nullptr;
+    int raw_len = 0;
+    const double redraw = std::min(5.0, 40.0 / n);  // window margin per sample: ~3x the expected redraws (10 / n repeats x ~1.1 draws)
+    if (dev_draw) {
+        const size_t need = (size_t)((double)max_iters * (5.0 + redraw)) + 4096;
+        RandCache *rc_ = static_cast<RandCache *>(ctx->rand_cache);
+        if (need > kRandCacheMax || need > (size_t)(ctx->opt_rand_cache_max > 0 ? ctx->opt_rand_cache_max : kRandCacheMax)) dev_draw = false;
+        else {
+            while (rc_->raw.size() < need) {
+                rc_->gen.refill();
+                rc_->raw.insert(rc_->raw.end(), rc_->gen.out, rc_->gen.out + 31);
+                rc_->gen.pos = 31;
+            }
+            void *blk = nullptr;
+            const size_t raw_bytes = (kRandCacheMax * 4 + 255) / 256 * 256;
+            if ((rc = ws_get(ctx, WS_RAND_RAW, raw_bytes + sizeof(DrawCtl) + (size_t)kDrawCandCap * sizeof(DrawCand) + 256, &blk))) return rc;
+            if (ctx->rand_dev_ptr != blk || ctx->rand_dev_seed != seed) ctx->rand_dev_ptr = blk, ctx->rand_dev_seed = seed, ctx->rand_dev_len = 0;
+            if (ctx->rand_dev_len < need) {  // (pageable source: the copy stages through the runtime; only when the seed changes or the run is longer)
+                MLPL_HIP_TRY(hipMemcpyAsync((int32_t *)blk + ctx->rand_dev_len, rc_->raw.data() + ctx->rand_dev_len, (need - ctx->rand_dev_len) * 4,
+                                            hipMemcpyHostToDevice, s));
+                ctx->rand_dev_len = need;
+            }
+            d_raw = (const int32_t *)blk;
+            raw_len = (int)ctx->rand_dev_len;
+            d_ctl = (DrawCtl *)((char *)blk + raw_bytes);
+            d_cand = (DrawCand *)(d_ctl + 1);
+            MLPL_HIP_TRY(hipMemsetAsync(d_ctl, 0, 32, s));  // position 0, no overflow, empty lists
+        }
+    }
     ReplayState cur = init;
     for (int base = 0; base < max_iters; base += chunk_cap) {
         const int cnt = std::min(chunk_cap, std::min(max_iters, cur.niters) - base);
@@ -2796,21 +3050,32 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         // Large passes: the root kernel of a slice goes to the helper stream, so it runs beside the elimination kernel of the next
         // slice (both are latency-bound at these sizes and leave most issue slots idle; unlike the counting kernel, which saturates
         // the vector units and gains nothing from company -- DESIGN section 5).
-        const bool overlap = cnt > 4096 && ctx->opt_ransac_overlap != 0;
+        // (samples drawn on the device: nothing paces the solver, one elimination and one root launch -- 52 + 56 us for 20 000 hypotheses --
+        //  beat the four overlapped slice pairs, whose small launches are latency-bound: 177 us)
+        const bool overlap = cnt > 4096 && ctx->opt_ransac_overlap != 0 && !dev_draw;
+        const int32_t *d_samples = d_samples_mapped;
+        if (dev_draw) {
+            const int window = (int)std::min<long long>((long long)((double)cnt * (5.0 + redraw)) + 256, INT32_MAX / 2);
+            hipLaunchKernelGGL(draw_scan_kernel, dim3((window + 255) / 256), dim3(256), 0, s, d_raw, raw_len, n, window, d_ctl, d_cand);
+            hipLaunchKernelGGL(draw_chain_kernel, dim3(1), dim3(64), 0, s, raw_len, cnt, window, d_ctl, (const DrawCand *)d_cand, B.samples);
+            hipLaunchKernelGGL(draw_fill_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, d_raw, raw_len, n, cnt, (const DrawCtl *)d_ctl, B.samples);
+            d_samples = B.samples;
+        }
         int slice_no = 0;
         for (int off = 0; off < cnt; ++slice_no) {
             // slices of a large pass: 1024 first (the device starts at once), a small last one (its root kernel is the exposed tail
             // of the solver chain: ~50 us for 2048 hypotheses, ~90 us for 12000), the rest in two halves
             int m = cnt;
-            if (cnt > 4096) {
+            if (cnt > 4096 && !dev_draw) {
                 const int last = std::min(2048, cnt / 8), mid = cnt - 1024 - last;
                 m = slice_no == 0 ? 1024 : slice_no == 1 ? mid / 2 : slice_no == 2 ? mid - mid / 2 : last;
             }
-            for (int i = off; i < off + m; ++i) draw_sample(rng, fmod_n, &h_samples[(size_t)i * 5]);
+            if (!dev_draw)
+                for (int i = off; i < off + m; ++i) draw_sample(rng, fmod_n, &h_samples[(size_t)i * 5]);
             prof_mark(ctx, MLPL_PROF_SOLVE_5PT, 0, s);
             // (the hand-over records are indexed from the slice's first sample: each slice gets its own part of the buffer, the root
             // kernel of slice i and the elimination kernel of slice i+1 run side by side)
-            launch_solve5pt(ctx, m, s, d_p1, d_p2, (const int32_t *)d_samples_mapped, off, off + m, B.recs + off);
+            launch_solve5pt(ctx, m, s, d_p1, d_p2, d_samples, off, off + m, B.recs + off);
             hipStream_t sr = overlap ? ctx->aux_stream[slice_no & 1] : s;  // two helper streams: consecutive root kernels overlap too
             if (overlap) {  // everything the root kernel reads is complete once this event fires (the first one also covers the setup)
                 MLPL_HIP_TRY(hipEventRecord(ctx->aux_ev[slice_no], s));
@@ -2880,8 +3145,20 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     }
     MLPL_HIP_TRY(hipGetLastError());
     MLPL_HIP_TRY(hipMemcpyAsync(h_st, d_st, sizeof(ReplayState), hipMemcpyDeviceToHost, s));
+    *h_ovf = 0;
+    if (dev_draw) MLPL_HIP_TRY(hipMemcpyAsync(h_ovf, &d_ctl->overflow, 4, hipMemcpyDeviceToHost, s));
     MLPL_HIP_TRY(hipStreamSynchronize(s));  // the single host hop of the call (per 32768-iteration chunk)
     const ReplayState fin = *h_st;
+    if (dev_draw) {  // the device-side sampling ran out of window / list / stream somewhere: redo with the host drawing the table
+        if (*h_ovf) {
+            ctx->ransac_force_host_draw = 1;
+            const int rc2 = mlpl_ransac_essential_dev(ctx, d_p1, d_p2, n, thresh, confidence, max_iters, refit, seed, E, d_mask, n_inliers,
+                                                      iters_used, stream);
+            ctx->ransac_force_host_draw = 0;
+            ctx->ransac_draw_fallbacks++;
+            return rc2;
+        }
+    }
     if (!use_table) {
         // every iteration bound the device used must be what the CPU path's libm gives; otherwise redo the call on a host table
         bool ok = fin.t_count <= kTUsedMax;
@@ -2898,6 +3175,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
     }
     ctx->last_ransac_models = fin.models_scored;
     ctx->last_ransac_iters = fin.iter;
+    ctx->last_ransac_dev_draw = dev_draw ? 1 : 0;
     if (iters_used) *iters_used = fin.iter;
     if (fin.maxGood <= 0) {
         set_error("mlpl_ransac_essential: no model found");

@@ -75,3 +75,57 @@ def test_ransac_runs_bit_identical(ctx, refit):
         assert a["iters"] == b["iters"] and a["n_inliers"] == b["n_inliers"]
         assert np.array_equal(a["mask"], b["mask"])
         assert np.array_equal(np.asarray(a["E"]).view(np.uint64), np.asarray(b["E"]).view(np.uint64))
+
+
+def _draw_stats(ctx):
+    o = np.zeros(2, np.int64)
+    ctx.lib.mlpl_debug_ransac_draw(ctx.handle, o.ctypes.data)
+    return int(o[0]), int(o[1])
+
+
+@pytest.mark.parametrize("n,frac,iters", [(5000, 0.5, 20000), (700, 0.4, 9000), (64, 0.6, 5000), (150, 0.5, 40000), (2000, 0.3, 70000)])
+def test_device_drawn_samples_equal_the_host_drawn(ctx, n, frac, iters):
+    """Large passes draw their sample tables on the device (scan for samples that redraw, chain from event to event, fill in parallel):
+    the runs must equal the host-drawn ones bit for bit -- 70 000 iterations walk three passes with the stream position carried on the
+    device; with 64 or 150 correspondences too many samples redraw for the candidate list and the host draws."""
+    from matchinglib_poselib_amd import pose, synth
+
+    p1, p2, R, t, mask, th = synth.pose_scene(n, inlier_frac=frac, seed=3 * n + 1)
+    out = []
+    for dd in (0, 1):
+        ctx.set_option("ransac_device_draw", dd)
+        try:
+            f0, _ = _draw_stats(ctx)
+            r = pose.ransac_essential(p1, p2, th, confidence=1.0, max_iters=iters, refit=False, seed=77 + n, ctx=ctx)
+            f1, used = _draw_stats(ctx)
+        finally:
+            ctx.set_option("ransac_device_draw", 1)
+        eligible = min(iters, 32768) * 60.0 / n < 3072      # few enough redrawing samples for the candidate list (else the host draws)
+        assert used == (dd if eligible else 0) and f1 == f0, (dd, used, f0, f1)     # the device path ran (and did not fall back) exactly when asked
+        out.append(r)
+    a, b = out
+    assert a["iters"] == b["iters"] and a["n_inliers"] == b["n_inliers"]
+    assert np.array_equal(a["mask"], b["mask"]) and np.array_equal(np.asarray(a["E"]).view(np.uint64), np.asarray(b["E"]).view(np.uint64))
+
+
+def test_device_drawing_falls_back_when_samples_redraw_too_often(ctx):
+    """n = 70 with the stream cache capped below what 6000 iterations need: not eligible -> host path; and a seed change re-uploads."""
+    from matchinglib_poselib_amd import pose, synth
+
+    p1, p2, R, t, mask, th = synth.pose_scene(3000, inlier_frac=0.5, seed=5)
+    ref = {}
+    for seed in (1, 2, 1):
+        ctx.set_option("ransac_device_draw", 0)
+        h = pose.ransac_essential(p1, p2, th, confidence=1.0, max_iters=6000, refit=False, seed=seed, ctx=ctx)
+        ctx.set_option("ransac_device_draw", 1)
+        d = pose.ransac_essential(p1, p2, th, confidence=1.0, max_iters=6000, refit=False, seed=seed, ctx=ctx)
+        assert _draw_stats(ctx)[1] == 1
+        assert h["n_inliers"] == d["n_inliers"] and np.array_equal(h["mask"], d["mask"])
+        ref.setdefault(seed, d["n_inliers"])
+        assert ref[seed] == d["n_inliers"]
+    ctx.set_option("rand_cache_max", 20000)   # fewer values than 6000 samples need: the call is not eligible
+    try:
+        d = pose.ransac_essential(p1, p2, th, confidence=1.0, max_iters=6000, refit=False, seed=1, ctx=ctx)
+        assert _draw_stats(ctx)[1] == 0 and d["n_inliers"] == ref[1]
+    finally:
+        ctx.set_option("rand_cache_max", 0)
