@@ -353,6 +353,15 @@ int mlpl_pair_pose_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, const uint8_t 
 int mlpl_pair_pose_batch_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
                              const float *d_kp2, const double K0[4], const double K1[4], double thresh, int max_iters, double confidence,
                              int refit, const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out, void *stream);
+/* The same batch behind the matching -- the batched form of mlpl_ransac_essential_dev (refit = 0) followed, with recover_pose != 0, by
+ * mlpl_recover_pose_dev on the RANSAC inliers: problem b's correspondences are d_p1 / d_p2 + b * stride * 2 (camera coordinates, n x 2
+ * doubles, device), counts[b] <= stride of them (host array), seeds[b] its srand() seed.  Records as above with n_matches = counts[b];
+ * status -1 for fewer than 6 correspondences, -2 when RANSAC finds no model; R, t, n_good stay zero without recover_pose.  d_masks: NULL or
+ * a device block [n_problems][stride] that receives the inlier masks (after cheirality when recover_pose is set, as mlpl_recover_pose_dev
+ * leaves them).  Every record equals what the single-problem entries return for that problem (tests/test_gpu_batch.py). */
+int mlpl_ransac_essential_batch_dev(mlpl_ctx *ctx, int n_problems, const double *d_p1, const double *d_p2, int stride, const int32_t *counts, double thresh,
+                                    int max_iters, double confidence, const uint32_t *seeds, int recover_pose, double dist, mlpl_pair_result *out,
+                                    uint8_t *d_masks, void *stream);
 /* d_matches_out: NULL, or a device block [n_pairs][nq] that receives every pair's match list (out[i].n_matches valid entries each,
  * ascending queryIdx) -- what a caller gathers beside the pose records (needs refit = 0).
  * Statistics of the last mlpl_pair_pose_batch_dev call: {RANSAC passes, pair slots summed over the passes, pairs redone by the

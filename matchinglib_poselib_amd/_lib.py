@@ -116,6 +116,8 @@ _SIGNATURES = {
     "mlpl_pair_pose_batch_dev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
                                          c_int, c_double, c_int, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
     "mlpl_pair_batch_last_stats": (c_int, [c_void_p, c_void_p]),
+    "mlpl_ransac_essential_batch_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_double, c_int, c_double, c_void_p, c_int, c_double,
+                                        c_void_p, c_void_p, c_void_p]),
     "mlpl_recover_pose_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
     "mlpl_recover_pose_translation": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p,

@@ -157,6 +157,30 @@ def process_pairs_batched(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, seeds, t
     return rec
 
 
+def ransac_pose_batched(ctx: Context, d_p1, d_p2, counts, seeds, thresh: float, max_iters: int = 1000, confidence: float = 0.999,
+                        recover_pose: bool = True, dist: float = 50.0, masks_out=None) -> list:
+    """A batch of correspondence sets in ONE library call (mlpl_ransac_essential_batch_dev): d_p1, d_p2 float64 CUDA tensors [B, stride, 2]
+    (camera coordinates), counts[b] <= stride valid rows per problem, seeds[b] its RANSAC seed; masks_out: optional uint8 CUDA tensor
+    [B, stride].  Returns one dict per problem (status, n, n_inliers, n_good, iters, E, R, t): what ransac_essential_device(refit=False)
+    followed by getPoseTriangPts_device returns for it."""
+    import torch
+
+    B, stride = d_p1.shape[0], d_p1.shape[1]
+    assert d_p1.is_cuda and d_p1.dtype == torch.float64 and d_p1.shape == d_p2.shape == (B, stride, 2) and d_p1.is_contiguous() and d_p2.is_contiguous()
+    cn = np.ascontiguousarray(counts, np.int32)
+    sd = np.ascontiguousarray(np.asarray(seeds, np.int64) & 0xFFFFFFFF, np.uint32)
+    assert len(cn) == B and len(sd) == B
+    if masks_out is not None:
+        assert masks_out.is_cuda and masks_out.dtype == torch.uint8 and masks_out.shape == (B, stride) and masks_out.is_contiguous()
+    res = (_PairResult * B)()
+    st = torch.cuda.current_stream(d_p1.device).cuda_stream
+    check(ctx.lib.mlpl_ransac_essential_batch_dev(ctx.handle, B, d_p1.data_ptr(), d_p2.data_ptr(), stride, cn.ctypes.data, float(thresh), int(max_iters),
+                                                  float(confidence), sd.ctypes.data, 1 if recover_pose else 0, float(dist), C.addressof(res),
+                                                  masks_out.data_ptr() if masks_out is not None else None, st), "mlpl_ransac_essential_batch_dev")
+    return [dict(status=r.status, n=r.n_matches, n_inliers=r.n_inliers, n_good=r.n_good, iters=r.iters, E=np.frombuffer(r.E, np.float64).reshape(3, 3).copy(),
+                 R=np.frombuffer(r.R, np.float64).reshape(3, 3).copy(), t=np.frombuffer(r.t, np.float64).copy()) for r in res]
+
+
 class PairWorkers:
     """`workers` independent (library context, torch stream, host thread) triples on one GPU.  One image pair's pipeline
     is latency-bound (a dozen small launches and two host hops), so a rank overlaps several pairs instead of queueing

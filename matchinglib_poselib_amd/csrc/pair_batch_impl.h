@@ -107,9 +107,16 @@ __global__ __launch_bounds__(64) void draw_samples_kernel(const PairSlot *__rest
 
 }  // namespace
 
+// Correspondence mode (d_q == nullptr): the batch starts behind the matching -- problem b's correspondences are ext_p1 / ext_p2 + b * nq * 2
+// (camera coordinates, device), ext_counts[b] of them (host); want_pose = 0 stops after the inlier masks; d_masks_ext: the caller's [B][nq]
+// mask block or nullptr.  This is mlpl_ransac_essential_batch_dev.
 int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
                         const float *d_kp2, const double K0[4], const double K1[4], double thresh, int max_iters, double confidence,
-                        const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out, hipStream_t s) {
+                        const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out, hipStream_t s,
+                        const double *ext_p1 = nullptr, const double *ext_p2 = nullptr, const int32_t *ext_counts = nullptr, int want_pose = 1,
+                        uint8_t *d_masks_ext = nullptr) {
+    const bool points_mode = d_q == nullptr;
+    const int min_count = points_mode ? 6 : 16;  // mlpl_ransac_essential's limit / the reference's working minimum for a matched pair
     const int NQ = nq;
     const size_t n = (size_t)NQ;
     int rc;
@@ -127,8 +134,9 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
     if ((rc = ws_get(ctx, WS_PIPE, off_small + sm_end + 256, &blk))) return rc;
     char *b0 = (char *)blk, *sm = b0 + off_small;
     mlpl_dmatch *d_m = d_matches_out ? d_matches_out : (mlpl_dmatch *)(b0 + off_match);  // the caller's [B][nq] block, or the workspace
-    double *d_p1 = (double *)(b0 + off_p1), *d_p2 = (double *)(b0 + off_p2);
-    uint8_t *d_mask = (uint8_t *)(b0 + off_mask), *d_cmask = (uint8_t *)(b0 + off_cmask);
+    double *d_p1 = points_mode ? const_cast<double *>(ext_p1) : (double *)(b0 + off_p1);
+    double *d_p2 = points_mode ? const_cast<double *>(ext_p2) : (double *)(b0 + off_p2);
+    uint8_t *d_mask = d_masks_ext ? d_masks_ext : (uint8_t *)(b0 + off_mask), *d_cmask = (uint8_t *)(b0 + off_cmask);
     int32_t *d_counts = (int32_t *)(sm + sm_counts), *d_active = (int32_t *)(sm + sm_active), *d_cc = (int32_t *)(sm + sm_cc);
     ReplayState *d_st = (ReplayState *)(sm + sm_st);
     double *d_P = (double *)(sm + sm_P);
@@ -170,11 +178,16 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
     int32_t *d_raw_mapped = nullptr;
     MLPL_HIP_TRY(hipHostGetDevicePointer((void **)&d_raw_mapped, h_raw, 0));
 
-    // ---- matching, all pairs ----
-    rc = mlpl_match_hamming_dev(ctx, d_q, nq, (size_t)nbytes, (size_t)nq * nbytes, d_t, nt, (size_t)nbytes, (size_t)nt * nbytes, nbytes, 1, 0.75f, B,
-                                (int32_t *)(b0 + off_idx), (int32_t *)(b0 + off_dist), d_m, d_counts, s);
-    if (rc) return rc;
-    MLPL_HIP_TRY(hipMemcpyAsync(h_counts, d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    if (points_mode) {
+        for (int b = 0; b < B; ++b) h_counts[b] = std::max(0, std::min(ext_counts[b], NQ));
+        MLPL_HIP_TRY(hipMemcpyAsync(d_counts, h_counts, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    } else {
+        // ---- matching, all pairs ----
+        rc = mlpl_match_hamming_dev(ctx, d_q, nq, (size_t)nbytes, (size_t)nq * nbytes, d_t, nt, (size_t)nbytes, (size_t)nt * nbytes, nbytes, 1, 0.75f, B,
+                                    (int32_t *)(b0 + off_idx), (int32_t *)(b0 + off_dist), d_m, d_counts, s);
+        if (rc) return rc;
+        MLPL_HIP_TRY(hipMemcpyAsync(h_counts, d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    }
     MLPL_HIP_TRY(hipMemsetAsync(d_rng_pos, 0, (size_t)B * 8, s));  // positions and overflow flags
     // the raw glibc streams do not depend on the counts: the host generates them while the device matches, straight into the pinned block
     // the sampling kernel reads (the samples themselves -- rand() % count, repeats redrawn -- are drawn on the device, per pass)
@@ -192,18 +205,19 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
         }
         draw_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_draw0).count();
     }
-    MLPL_HIP_TRY(hipStreamSynchronize(s));  // hop 1: the match counts
+    if (!points_mode) MLPL_HIP_TRY(hipStreamSynchronize(s));  // hop 1: the match counts
     std::vector<int> alive;
     for (int b = 0; b < B; ++b) {
         std::memset(&out[b], 0, sizeof(out[b]));
         out[b].n_matches = h_counts[b];
-        h_active[b] = h_counts[b] >= 16 ? 1 : 0;  // below the reference's working minimum (Remove_LensDist / StereoRefine refuse fewer than 16)
+        h_active[b] = h_counts[b] >= min_count ? 1 : 0;  // (pairs: below 16 matches Remove_LensDist / StereoRefine refuse to work)
         if (h_active[b]) alive.push_back(b);
         else out[b].status = -1;
     }
     if (alive.empty()) return MLPL_OK;
     MLPL_HIP_TRY(hipMemcpyAsync(d_active, h_active, (size_t)B * 4, hipMemcpyHostToDevice, s));
-    if ((rc = launch_gather_match_points_batch(d_m, d_counts, B, NQ, d_kp1, (size_t)nq * 2, d_kp2, (size_t)nt * 2, K0, K1, d_p1, d_p2, s))) return rc;
+    if (!points_mode && (rc = launch_gather_match_points_batch(d_m, d_counts, B, NQ, d_kp1, (size_t)nq * 2, d_kp2, (size_t)nt * 2, K0, K1, d_p1, d_p2, s)))
+        return rc;
     hipLaunchKernelGGL(pack_points_kernel, dim3((NQ + 255) / 256, B), dim3(256), 0, s, (const double *)d_p1, (const double *)d_p2, 0, d_pack, d_st, max_iters,
                        (int32_t *)nullptr, 0, (const int32_t *)d_counts, NQ, pack_stride4);
 
@@ -309,30 +323,57 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
             MLPL_HIP_TRY(hipMemcpyAsync(d_active, h_active, (size_t)B * 4, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(inlier_mask_kernel, dim3((max_n + 255) / 256, (unsigned)act.size()), dim3(256), 0, s, (const double4 *)nullptr, 0,
                                (const double *)nullptr, thresh2, d_mask, (const PairSlot *)d_slots, (const ReplayState *)d_st, NQ);
-            prof_mark(ctx, MLPL_PROF_RECOVER_POSE, 0, s);
-            if ((rc = launch_recover_pose_batch((const char *)d_st + offsetof(ReplayState, E), sizeof(ReplayState), d_p1, d_p2, d_counts, d_active, B, NQ,
-                                                dist, d_mask, d_P, d_cmask, d_cc, d_pose, s)))
-                return rc;
-            prof_mark(ctx, MLPL_PROF_RECOVER_POSE, 1, s);
-            MLPL_HIP_TRY(hipMemcpyAsync(h_pose, d_pose, (size_t)B * sizeof(PairPoseDev), hipMemcpyDeviceToHost, s));
+            if (want_pose) {
+                prof_mark(ctx, MLPL_PROF_RECOVER_POSE, 0, s);
+                if ((rc = launch_recover_pose_batch((const char *)d_st + offsetof(ReplayState, E), sizeof(ReplayState), d_p1, d_p2, d_counts, d_active, B, NQ,
+                                                    dist, d_mask, d_P, d_cmask, d_cc, d_pose, s)))
+                    return rc;
+                prof_mark(ctx, MLPL_PROF_RECOVER_POSE, 1, s);
+                MLPL_HIP_TRY(hipMemcpyAsync(h_pose, d_pose, (size_t)B * sizeof(PairPoseDev), hipMemcpyDeviceToHost, s));
+            }
             MLPL_HIP_TRY(hipStreamSynchronize(s));  // last hop
             for (int b : act) {
                 mlpl_pair_result &o = out[b];
-                o.status = 0, o.iters = state[b].iter, o.n_inliers = state[b].maxGood, o.n_good = h_pose[b].n_good;
-                std::memcpy(o.E, state[b].E, 72), std::memcpy(o.R, h_pose[b].R, 72), std::memcpy(o.t, h_pose[b].t, 24);
+                o.status = 0, o.iters = state[b].iter, o.n_inliers = state[b].maxGood, o.n_good = want_pose ? h_pose[b].n_good : 0;
+                std::memcpy(o.E, state[b].E, 72);
+                if (want_pose) std::memcpy(o.R, h_pose[b].R, 72), std::memcpy(o.t, h_pose[b].t, 24);
             }
         }
     }
     ctx->last_batch_stats[0] = passes, ctx->last_batch_stats[1] = slots_total, ctx->last_batch_stats[2] = (long long)redo.size(), ctx->last_batch_stats[3] = draw_us;
     ctx->last_batch_stats[4] = ctx->last_batch_stats[5] = ctx->last_batch_stats[6] = 0;
     for (int b = 0; b < B; ++b)
-        if (h_counts[b] >= 16) {
+        if (h_counts[b] >= min_count) {
             ctx->last_batch_stats[4] += state[b].models_scored;
             ctx->last_batch_stats[5] += state[b].models_scored * (long long)h_counts[b];
             ctx->last_batch_stats[6] += state[b].iter;
         }
     // the rare pairs whose iteration bound has to come from the host table: the single-pair pipeline on their inputs
     for (int b : redo) {
+        if (points_mode) {  // the single-problem entries on this problem's correspondences
+            mlpl_pair_result &o = out[b];
+            const int nb = h_counts[b];
+            std::memset(&o, 0, sizeof(o));
+            o.n_matches = nb;
+            int ninl = 0, iters = 0;
+            ctx->ransac_force_table = 1;
+            rc = mlpl_ransac_essential_dev(ctx, d_p1 + (size_t)b * NQ * 2, d_p2 + (size_t)b * NQ * 2, nb, thresh, confidence, max_iters, 0, seeds[b], o.E,
+                                           d_mask + (size_t)b * NQ, &ninl, &iters, s);
+            ctx->ransac_force_table = 0;
+            o.iters = iters;
+            if (rc == MLPL_E_FAILED) {
+                o.status = -2;
+                continue;
+            }
+            if (rc) return rc;
+            o.n_inliers = ninl;
+            if (want_pose) {
+                rc = mlpl_recover_pose_dev(ctx, o.E, d_p1 + (size_t)b * NQ * 2, d_p2 + (size_t)b * NQ * 2, nb, dist, o.R, o.t, nullptr, d_mask + (size_t)b * NQ, s);
+                if (rc < 0) return rc;
+                o.n_good = rc;
+            }
+            continue;
+        }
         ctx->ransac_force_table = 1;
         rc = mlpl_pair_pose_dev(ctx, d_q + (size_t)b * nq * nbytes, nq, d_t + (size_t)b * nt * nbytes, nt, nbytes, d_kp1 + (size_t)b * nq * 2,
                                 d_kp2 + (size_t)b * nt * 2, K0, K1, thresh, max_iters, confidence, 0, seeds[b], dist, &out[b], s);

@@ -3472,6 +3472,36 @@ int mlpl_pair_pose_batch_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int
     return MLPL_OK;
 }
 
+int mlpl_ransac_essential_batch_dev(mlpl_ctx *ctx, int n_problems, const double *d_p1, const double *d_p2, int stride, const int32_t *counts, double thresh,
+                                    int max_iters, double confidence, const uint32_t *seeds, int recover_pose, double dist, mlpl_pair_result *out,
+                                    uint8_t *d_masks, void *stream) {
+    if (!ctx || !d_p1 || !d_p2 || !counts || !seeds || !out || n_problems < 1 || stride < 1 || max_iters < 1 || !(thresh > 0)) {
+        set_error("mlpl_ransac_essential_batch_dev: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    for (int b = 0; b < n_problems; ++b)
+        if (counts[b] < 0 || counts[b] > stride) {
+            set_error("mlpl_ransac_essential_batch_dev: counts[%d] = %d outside [0, stride = %d]", b, counts[b], stride);
+            return MLPL_E_BAD_INPUT;
+        }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = pick_stream(ctx, stream);
+    const int per = ctx->opt_pair_batch > 0 ? ctx->opt_pair_batch : kBatchPairsPerCall;
+    std::memset(ctx->last_batch_stats, 0, sizeof(ctx->last_batch_stats));
+    long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double K1_[4] = {1, 1, 0, 0};
+    for (int at = 0; at < n_problems; at += per) {
+        const int B = std::min(per, n_problems - at);
+        const int rc = pair_pose_batch_dev(ctx, B, nullptr, stride, nullptr, stride, 0, nullptr, nullptr, K1_, K1_, thresh, max_iters, confidence, seeds + at, dist,
+                                           out + at, nullptr, s, d_p1 + (size_t)at * stride * 2, d_p2 + (size_t)at * stride * 2, counts + at, recover_pose ? 1 : 0,
+                                           d_masks ? d_masks + (size_t)at * stride : nullptr);
+        if (rc) return rc;
+        for (int i = 0; i < 8; ++i) acc[i] += ctx->last_batch_stats[i];
+    }
+    std::memcpy(ctx->last_batch_stats, acc, sizeof(acc));
+    return MLPL_OK;
+}
+
 int mlpl_pair_batch_last_stats(mlpl_ctx *ctx, long long stats[8]) {
     if (!ctx || !stats) return MLPL_E_BAD_INPUT;
     std::memcpy(stats, ctx->last_batch_stats, sizeof(ctx->last_batch_stats));

@@ -154,3 +154,49 @@ def test_batched_pairs_few_matches_and_short_raw_streams(ctx):
         for i in range(12):
             assert bat[i].tobytes() == one[i].tobytes(), (cap, i, bat[i], one[i])
         assert (stats[2] > 0) == redone, (cap, stats)
+
+
+@pytest.mark.parametrize("recover", [True, False])
+def test_batched_correspondence_sets_equal_the_single_problem_entries(ctx, recover):
+    """mlpl_ransac_essential_batch_dev: 40 correspondence sets of 5...3000 points, 20-90 % inliers, each with its own seed, against
+    mlpl_ransac_essential_dev (refit = 0) + mlpl_recover_pose_dev problem by problem: iteration counts, inlier counts, E, R, t and the masks
+    bit for bit; fewer than 6 correspondences -> status -1; pure noise -> whatever the single entry says."""
+    from matchinglib_poselib_amd import pose
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    sizes = [5, 6, 9, 16, 40, 100, 333, 1000, 3000, 64] * 4
+    stride = max(sizes)
+    p1 = np.zeros((40, stride, 2))
+    p2 = np.zeros((40, stride, 2))
+    ths = None
+    for i, n in enumerate(sizes):
+        a, b, R, t, mask, th = synth.pose_scene(max(n, 8), inlier_frac=float(rng.choice([0.2, 0.5, 0.7, 0.9])), seed=1200 + i)
+        if i == 17:
+            b = rng.uniform(-0.4, 0.4, b.shape)       # no geometry at all
+        p1[i, :n], p2[i, :n] = a[:n], b[:n]
+        ths = th
+    seeds = [700 + 3 * i for i in range(40)]
+    d1, d2 = torch.from_numpy(p1).to(dev), torch.from_numpy(p2).to(dev)
+    masks = torch.zeros((40, stride), dtype=torch.uint8, device=dev)
+    got = batch.ransac_pose_batched(ctx, d1, d2, sizes, seeds, ths, recover_pose=recover, masks_out=masks)
+    mh = masks.cpu().numpy()
+    for i, n in enumerate(sizes):
+        g = got[i]
+        if n < 6:
+            assert g["status"] == -1 and g["n"] == n
+            continue
+        a, b = d1[i, :n].contiguous(), d2[i, :n].contiguous()
+        r = pose.ransac_essential_device(a, b, ths, confidence=0.999, max_iters=1000, refit=False, seed=seeds[i], ctx=ctx)
+        if not r["ok"]:
+            assert g["status"] == -2, i
+            continue
+        assert g["status"] == 0 and g["iters"] == r["iters"] and g["n_inliers"] == r["n_inliers"], (i, g, r)
+        assert np.array_equal(g["E"].view(np.uint64), np.asarray(r["E"]).view(np.uint64)), i
+        m = r["mask"]
+        if recover:
+            ng, R, t = pose.getPoseTriangPts_device(r["E"], a, b, mask=m, ctx=ctx)
+            assert g["n_good"] == ng and np.array_equal(g["R"].view(np.uint64), R.view(np.uint64)) and np.array_equal(g["t"].view(np.uint64), t.ravel().view(np.uint64)), i
+        else:
+            assert g["n_good"] == 0 and not g["R"].any()
+        assert np.array_equal(mh[i, :n], m.cpu().numpy()), i
