@@ -222,3 +222,30 @@ def test_get_matches_rootsift_c4_shape(ctx, oracle):
     ms = m[np.isin(m["queryIdx"], sub)]
     assert len(ms) == len(mo)
     assert np.array_equal(ms["trainIdx"], mo["trainIdx"]) and ms["distance"].tobytes() == mo["distance"].tobytes()
+
+
+def test_property_random_shapes_and_value_distributions(ctx):
+    """hypothesis: any shape up to 300 x 400 x 128 and a handful of value distributions (normal, heavy-tailed, sparse, quantised to a few
+    levels so that exact ties abound, rows copied between the sets): the fp16 candidate path returns the exact kernel's bits."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=80, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(nq=st.integers(1, 300), nt=st.integers(2, 400), dim=st.integers(1, 128), kind=st.integers(0, 4), seed=st.integers(0, 2 ** 31 - 1),
+           k=st.integers(1, 2))
+    def check(nq, nt, dim, kind, seed, k):
+        rng = np.random.default_rng(seed)
+        if kind == 0:
+            q, t = rng.normal(size=(nq, dim)), rng.normal(size=(nt, dim))
+        elif kind == 1:
+            q, t = rng.standard_cauchy(size=(nq, dim)) * 1e-2, rng.standard_cauchy(size=(nt, dim)) * 1e-2
+        elif kind == 2:
+            q, t = rng.normal(size=(nq, dim)) * (rng.random((nq, dim)) < 0.1), rng.normal(size=(nt, dim)) * (rng.random((nt, dim)) < 0.1)
+        elif kind == 3:
+            q, t = rng.integers(-2, 3, (nq, dim)) * 0.25, rng.integers(-2, 3, (nt, dim)) * 0.25
+        else:
+            t = rng.normal(size=(nt, dim))
+            q = t[rng.integers(0, nt, nq)] + 1e-3 * rng.normal(size=(nq, dim)) * (rng.random((nq, 1)) < 0.5)
+        q, t = q.astype(np.float32), t.astype(np.float32)
+        assert same(run(ctx, q, t, 1, k=k), run(ctx, q, t, 3, k=k))
+
+    check()
