@@ -513,7 +513,7 @@ constexpr int kHypPerWave = 6;
 #define MLPL_ROOTS_WAVES 2
 #endif
 #ifndef MLPL_SWEEP_CAP
-#define MLPL_SWEEP_CAP 64
+#define MLPL_SWEEP_CAP 32
 #endif
 template <bool kPolish>  // compile-time: the polished instance does not carry the Jacobi SVD's registers
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MLPL_ROOTS_WAVES, MLPL_ROOTS_WAVES))) void roots_kernel_t(const PolyRec *__restrict__ recs, int sample_offset, int n_samples,
