@@ -510,7 +510,7 @@ __device__ __forceinline__ void polish_xyz(const double *EE, double &x, double &
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kHypPerWave = 6;
 #ifndef MLPL_ROOTS_WAVES
-#define MLPL_ROOTS_WAVES 2
+#define MLPL_ROOTS_WAVES 3
 #endif
 #ifndef MLPL_SWEEP_CAP
 #define MLPL_SWEEP_CAP 32
