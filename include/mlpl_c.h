@@ -287,7 +287,11 @@ int mlpl_debug_arrsac_trace(mlpl_ctx *ctx, int32_t *buf, int cap);
  * local optimisation (5 inner repetitions of a 14-point fit + 4 re-weighted refits, REF_WEIGHTS) on every new best model, and the
  * SPRT-aware stopping criterion.  The harness default estimator (tests/poselib-test/main.cpp:734).  Minimal solves, validity tests and
  * every error evaluation run on the device in speculative batches, the refits as one launch per local optimisation; the sequential
- * decisions are taken on the host.  No degeneracy tests (UsacChkDegenType::DEGEN_NO_CHECK).
+ * decisions are taken on the host.  params->check_degeneracy switches the degeneracy handling of
+ * UsacChkDegenType::DEGEN_USAC_INTERNAL on: EssentialMatEstimator::testSolutionDegeneracyRot / NoMot and upgradeDegenerateModel
+ * (EssentialMatEstimator.h:1334-1362, 1511-1663, 1838-1911, 2098-2361); results through mlpl_usac_last_degeneracy.  Not built: the
+ * homography test the reference adds with the 8-point refinements (:1368-1505; its upgrade branch :1958-2015 writes past a vector and
+ * reads a translation nothing has set), DEGEN_QDEGSAC.
  * The reference seeds srand(time(nullptr)) and shuffles its evaluation order on the process-wide stream; `seed` is that seed.
  * estimator: PoseEstimator value, 0 = POSE_NISTER, 2 = POSE_STEWENIUS (both are exact 5-point solvers with the same real solution set;
  * the device solver serves both, solutions ordered by the library's convention); refine: RefineAlg value, 0 = REF_WEIGHTS (8-point
@@ -310,6 +314,12 @@ typedef struct {
     double sprt_mS;        /* 8.5 for Nister on the first call of a process, then models / hypotheses so far */
     double sprt_tM;        /* 2314 (Nister), 2736 (Stewenius) */
     const uint32_t *sorted_idx; /* HOST pointer: NULL = uniform sampling; else n indices, best match first = PROSAC */
+    int32_t check_degeneracy; /* 0 = DEGEN_NO_CHECK; 1 = the rotation-only / no-motion tests after every new best model and the
+                                 upgrade R -> R + t, no motion -> t (DEGEN_USAC_INTERNAL); 3 = also after every local optimisation
+                                 (what estimateEssentialMatUsac switches on with the 8-point refinements, usac_estimations.cpp:368-371) */
+    int32_t reserved;
+    double th_pixels;      /* ConfigUSAC::th_pixels (0.8): with focal_length the angular threshold of the degeneracy tests */
+    double focal_length;   /* ConfigUSAC::focalLength (800) */
 } mlpl_usac_params;
 void mlpl_usac_default_params(mlpl_usac_params *p, double th);
 int mlpl_usac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const mlpl_usac_params *params, double E[9],
@@ -317,13 +327,24 @@ int mlpl_usac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n
 int mlpl_usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, const mlpl_usac_params *params, double E[9],
                             uint8_t *d_mask, double results[12], void *stream);
 /* Statistics of the last mlpl_usac_essential[_dev] call: {device batches, samples solved on the device, samples the control flow
- * consumed, local-optimisation launches, of which chain resumes, 0, 0, 0}. */
+ * consumed, local-optimisation launches, of which chain resumes, launches of the degeneracy tests, 0, 0}. */
 int mlpl_usac_last_stats(mlpl_ctx *ctx, long long stats[8]);
+/* What the degeneracy tests of the last mlpl_usac_essential[_dev] call found -- the quantities estimateEssentialMatUsac hands to
+ * estimateEssentialOrPoseUSAC (usac_estimations.cpp:564-636, 689-726; pose_estim.cpp:2044-2133 takes the decision "degenerate" from
+ * them): info[16] = {1 if the tests ran, inliers of the best rotation-only model (degen_inlier_count_rot), inliers of "no motion"
+ * (degen_inlier_count_noMot), degeneracy type of the last test (EssentialMatEstimator.h:168-175 bit set), R_degenerate[9] row-major,
+ * 0...}; flags_rot / flags_nomot (n bytes each, may be NULL): the inlier masks of the two degenerate models.  Returns 0, or
+ * MLPL_E_BAD_INPUT when n differs from the last call's correspondence count (masks requested) or no call has been made. */
+int mlpl_usac_last_degeneracy(mlpl_ctx *ctx, double info[16], uint8_t *flags_rot, uint8_t *flags_nomot, int n);
 /* Diagnostics: the following mlpl_usac_essential* calls record their decisions into buf, 16 doubles per record: [0] type -- 1 sample
  * {hypothesis, 5 indices, solutions (-1 = rejected by pre-validation)}, 2 evaluation {hypothesis, model, start position in the evaluation
  * order, inliers seen, correspondences tested, accepted, delta, epsilon, decision threshold, squared inlier threshold, local
  * optimisations so far}, 3 refined model {hypothesis, points, weighted, 1, model[9]}, 4 model stored {hypothesis, model, inliers},
- * 5 minimal model {hypothesis, index, model[9]}, 6 model rejected by the oriented constraint {hypothesis, index}.  Returns the number of
+ * 5 minimal model {hypothesis, index, model[9]}, 6 model rejected by the oriented constraint {hypothesis, index}, 7 degeneracy test
+ * {hypothesis, degenerate, upgrade, type, inliers of the rotation, of "no motion", of the best model}, 8 rotation evaluated on all
+ * correspondences {hypothesis, pair of the sample, inliers of the two-point rotation, of its refit, stored}, 9 upgrade {hypothesis,
+ * 1 = no motion -> t / 2 = R -> R + t, candidates tried, best inlier count}, 10 upgrade candidate {hypothesis, branch, number, t[3] or
+ * E[9]}; evaluations of translation candidates are type 2 with model -1 and the angular threshold.  Returns the number of
  * records produced since the previous call of this function (may exceed cap: only cap are written).  buf = NULL switches it off. */
 int mlpl_debug_usac_trace(mlpl_ctx *ctx, double *buf, int cap_records);
 

@@ -99,6 +99,7 @@ _SIGNATURES = {
     "mlpl_usac_essential": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mlpl_usac_essential_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mlpl_usac_last_stats": (c_int, [c_void_p, c_void_p]),
+    "mlpl_usac_last_degeneracy": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "mlpl_debug_usac_trace": (c_int, [c_void_p, c_void_p, c_int]),
     "mlpl_ransac_essential": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_int, c_int, c_u32,
                                       c_void_p, c_void_p, C.POINTER(c_int), C.POINTER(c_int)]),

@@ -136,6 +136,9 @@ struct mlpl_ctx {
     double *usac_trace;                                // diagnostics: host buffer for the decision records of USAC (16 doubles each)
     int usac_trace_cap, usac_trace_len;
     long long last_usac_stats[8];
+    double last_usac_degen[16];                        // {tests on, inliers of the rotation, of "no motion", degeneracy type, R[9]}
+    uint8_t *last_usac_flags;                          // malloc'ed, 2 * last_usac_flags_n bytes: inlier masks of the rotation / of "no motion"
+    int last_usac_flags_n;
     long long last_batch_stats[8];                     // mlpl_pair_pose_batch_dev: {RANSAC passes, pair slots over all passes, pairs redone on a host table, 0}
     int opt_pair_batch;                                // pairs per internal batch of mlpl_pair_pose_batch_dev (0 = 128)
     int opt_pair_batch_raw_cap;                        // tests: rand() values kept per pair for the device-side sampling (0 = 6.25 per iteration + 1024)

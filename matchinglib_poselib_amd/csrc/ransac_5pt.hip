@@ -42,6 +42,7 @@
 #include <vector>
 
 #include "mlpl_internal.h"
+#include "usac_degen_math.h"
 
 namespace mlpl {
 
@@ -3526,12 +3527,17 @@ void mlpl_usac_default_params(mlpl_usac_params *p, double th) {
     if (!p) return;
     p->th = th, p->conf = 0.99, p->max_hyp = 50000, p->estimator = 0, p->refine = 0, p->seed = 1u;
     p->prosac_beta = 0.09, p->sprt_delta = 0.05, p->sprt_epsilon = 0.15, p->sprt_mS = 8.5, p->sprt_tM = 2314.0, p->sorted_idx = nullptr;
+    p->check_degeneracy = 0, p->reserved = 0, p->th_pixels = 0.8, p->focal_length = 800.0;
 }
 
 static int usac_check_params(const mlpl_usac_params *P, int n, const char *who) {
     if (!P || n < 0 || !(P->th > 0) || !(P->conf >= 0 && P->conf <= 1) || P->max_hyp < 1 || !(P->sprt_delta > 0 && P->sprt_delta < 1) ||
         !(P->sprt_epsilon > 0 && P->sprt_epsilon < 1) || !(P->sprt_mS > 0) || !(P->sprt_tM > 0)) {
         set_error("%s: bad arguments", who);
+        return MLPL_E_BAD_INPUT;
+    }
+    if ((P->check_degeneracy & ~3) || (P->check_degeneracy == 2) || (P->check_degeneracy && !(P->th_pixels > 0 && P->focal_length > 0))) {
+        set_error("%s: bad degeneracy-test parameters", who);
         return MLPL_E_BAD_INPUT;
     }
     if ((P->estimator != 0 && P->estimator != 2) || P->refine != 0) {
@@ -3557,6 +3563,23 @@ int mlpl_usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p
     if ((rc = usac_check_params(params, n, "mlpl_usac_essential_dev"))) return rc;
     MLPL_HIP_TRY(hipSetDevice(ctx->device));
     return usac_essential_dev(ctx, d_p1, d_p2, n, params, E, d_mask, results, pick_stream(ctx, stream));
+}
+
+int mlpl_usac_last_degeneracy(mlpl_ctx *ctx, double info[16], uint8_t *flags_rot, uint8_t *flags_nomot, int n) {
+    if (!ctx || !info) {
+        set_error("mlpl_usac_last_degeneracy: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    std::memcpy(info, ctx->last_usac_degen, sizeof(ctx->last_usac_degen));
+    if (flags_rot || flags_nomot) {
+        if (ctx->last_usac_degen[0] == 0.0 || !ctx->last_usac_flags || n != ctx->last_usac_flags_n) {
+            set_error("mlpl_usac_last_degeneracy: the last call ran no degeneracy tests on %d correspondences", n);
+            return MLPL_E_BAD_INPUT;
+        }
+        if (flags_rot) std::memcpy(flags_rot, ctx->last_usac_flags, (size_t)n);
+        if (flags_nomot) std::memcpy(flags_nomot, ctx->last_usac_flags + n, (size_t)n);
+    }
+    return MLPL_OK;
 }
 
 int mlpl_usac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const mlpl_usac_params *params, double E[9],

@@ -142,6 +142,73 @@ __global__ __launch_bounds__(64) void usac_check_kernel(const double4 *__restric
     }
 }
 
+
+// ---- degeneracy tests: per-correspondence errors of a rotation / of "no motion" / of a translation / of an upgrade candidate ---------
+// EssentialMatEstimator.h: PoseTools::getRotError / getNoMotError (usac/utils/PoseFunctions.cpp:43-141), evaluateModelTrans :1264-1327
+// (opengv::triangulation::triangulate2 under (I, t)), evaluateModel :1110-1178.  The adapter's view "1" is the SECOND image
+// (CentralRelativeAdapter(bearings2, bearings1), EssentialMatEstimator.h:289-291).
+struct UsacDgModel {
+    int32_t kind;  // 0 rotation (m = R, row-major), 1 no motion, 2 translation (m[0..2] = t), 3 essential matrix
+    int32_t pad;
+    double m[9];
+};
+__device__ __forceinline__ void dg_bearing(double x, double y, double *f) {
+    const double nrm = sqrt(x * x + (y * y + 1.0));
+    f[0] = x / nrm, f[1] = y / nrm, f[2] = 1.0 / nrm;
+}
+__device__ __forceinline__ double dg_dot(const double *a, const double *b) { return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); }
+// One workgroup per model: bit rows in evaluation-pool order, rows[(model * 2 + 0) * words ..] = error < thr_pose (kinds 0..2) or
+// Sampson error < thr_inl (kind 3); rows[(model * 2 + 1) * words ..] = error < thr_inl (kind 2 only: what storeSolution reads).
+__global__ __launch_bounds__(256) void usac_degen_rows_kernel(const double4 *__restrict__ pts_pool, int n, int words,
+                                                              const UsacDgModel *__restrict__ models, double thr_pose, double thr_inl,
+                                                              unsigned long long *__restrict__ rows) {
+    const UsacDgModel M = models[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long *row_a = rows + ((size_t)blockIdx.x * 2) * words, *row_b = row_a + words;
+    for (int w = wave; w < words; w += 4) {
+        const int j = w * 64 + lane;
+        bool in_a = false, in_b = false;
+        if (j < n) {
+            const double4 p = pts_pool[j];
+            if (M.kind == 3) {
+                in_a = usac_sampson(M.m, p.x, p.y, p.z, p.w) < thr_inl;
+            } else {
+                double f1[3], f2[3], err;
+                dg_bearing(p.z, p.w, f1);
+                dg_bearing(p.x, p.y, f2);
+                if (M.kind == 0) {
+                    double u[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) u[r] = (M.m[3 * r] * f2[0] + M.m[3 * r + 1] * f2[1]) + M.m[3 * r + 2] * f2[2];
+                    err = 1.0 - dg_dot(f1, u);
+                } else if (M.kind == 1) {
+                    err = 1.0 - dg_dot(f1, f2);
+                } else {
+                    const double *t = M.m;
+                    const double b0 = dg_dot(t, f1), b1 = dg_dot(t, f2);
+                    const double a00 = dg_dot(f1, f1), a10 = dg_dot(f1, f2), a01 = -a10, a11 = -dg_dot(f2, f2);
+                    const double invdet = 1.0 / (a00 * a11 - a10 * a01);
+                    const double i00 = a11 * invdet, i10 = -a10 * invdet, i01 = -a01 * invdet, i11 = a00 * invdet;
+                    const double l0 = i00 * b0 + i01 * b1, l1 = i10 * b0 + i11 * b1;
+                    double pt[3], q[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) pt[k] = ((l0 * f1[k]) + (t[k] + l1 * f2[k])) / 2;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) q[k] = pt[k] + (-t[k]);
+                    const double n1 = sqrt(pt[0] * pt[0] + (pt[1] * pt[1] + pt[2] * pt[2])), n2 = sqrt(q[0] * q[0] + (q[1] * q[1] + q[2] * q[2]));
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) pt[k] = pt[k] / n1, q[k] = q[k] / n2;
+                    err = (1.0 - dg_dot(f1, pt)) + (1.0 - dg_dot(f2, q));
+                    in_b = err < thr_inl;
+                }
+                in_a = err < thr_pose;
+            }
+        }
+        const unsigned long long ba = __ballot(in_a), bb = __ballot(in_b);
+        if (lane == 0) row_a[w] = ba, row_b[w] = bb;
+    }
+}
+
 // ---- local optimisation ---------------------------------------------------------------------------------------------------------------
 struct UsacLoOut {          // per repetition, pinned host memory; followed by kUsacLoEvals bit rows of `words` words
     int32_t evals;          // evaluations performed (the chain stops when a 2 x threshold inlier set has < 5 members)
@@ -531,11 +598,21 @@ struct UsacRun {
         d_err = (double *)p;
         const size_t out_bytes = std::max(batch_out_bytes(batch_cap), (size_t)kUsacLoReps * lo_out_stride());
         const size_t smp_bytes = (size_t)batch_cap * 5 * 4, lo_in_bytes = (size_t)kUsacLoReps * sizeof(UsacLoIn);
-        if ((rc = pinned_get(ctx, out_bytes + smp_bytes + lo_in_bytes + 256, &p))) return rc;
+        dg_cap = dg_on ? (int)std::max<size_t>(10, std::min<size_t>(128, out_bytes / ((size_t)2 * words * 8))) : 0;
+        const size_t dg_bytes = (size_t)dg_cap * sizeof(UsacDgModel);
+        if ((rc = pinned_get(ctx, out_bytes + smp_bytes + lo_in_bytes + dg_bytes + 320, &p))) return rc;
         h_out = (char *)p;
         h_smp = (int32_t *)(h_out + ((out_bytes + 63) & ~(size_t)63));
         h_lo_in = (UsacLoIn *)((char *)h_smp + ((smp_bytes + 63) & ~(size_t)63));
         void *alias = nullptr;
+        if (dg_on) {
+            h_dg = (UsacDgModel *)((char *)h_lo_in + ((lo_in_bytes + 63) & ~(size_t)63));
+            MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, h_dg, 0));
+            d_dg = (UsacDgModel *)alias;
+            pool_pos.resize(n);
+            for (unsigned j = 0; j < n; ++j) pool_pos[pool[j]] = j;
+            dg_in_rot.assign(n, 0), dg_out_rot.assign(n, 0), dg_in_nomot.assign(n, 0), dg_out_nomot.assign(n, 0);
+        }
         MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, h_out, 0));
         h_out_dev = (char *)alias;
         MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, h_smp, 0));
@@ -894,6 +971,350 @@ struct UsacRun {
         return MLPL_OK;
     }
 
+
+    // ---- degeneracy tests and model upgrade (ConfigUSAC::degeneracyCheck = DEGEN_USAC_INTERNAL) ---------------------------------------
+    // EssentialMatEstimator.h: testSolutionDegeneracy :1334-1362, testSolutionDegeneracyRot :1511-1663, testSolutionDegeneracyNoMot
+    // :1838-1911, upgradeDegenerateModel :1917-2365 (its two pose branches), as estimateEssentialMatUsac configures them
+    // (usac_estimations.cpp:443-456: 8000 upgrade samples, enableUpgradeDegenPose).  The homography test of the 8-point refinements is
+    // not part of it.  Errors of all correspondences come from usac_degen_rows_kernel as bit rows in pool order; what the
+    // reference reads from its two error arrays afterwards (errors below a threshold, entries never written = DBL_MAX) is kept per
+    // array as three bits per correspondence.
+    enum { DG_NOT_FOUND = 0x1, DG_H = 0x2, DG_ROT_TRANS = 0x4, DG_NO_MOT = 0x8, DG_UPGRADE = 0x10 };
+    bool dg_on = false, dg_losac = false;
+    double dg_thr = 0;  // poseDegenTheshold
+    unsigned dg_type = DG_NOT_FOUND, dg_cnt_rot = 0, dg_cnt_nomot = 0, dg_cnt_trans = 0;
+    unsigned dg_max_rot = 8000, dg_max_nomot = 8000;
+    std::vector<uint8_t> dg_in_rot, dg_out_rot, dg_in_nomot, dg_out_nomot;
+    double dg_R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    std::vector<int> dg_sample_rot, dg_sample_nomot;
+    std::vector<unsigned> pool_pos;
+    UsacDgModel *h_dg = nullptr, *d_dg = nullptr;
+    int dg_cap = 0;
+    struct DgErrs {  // one of the reference's two error arrays, as far as anything reads it
+        std::vector<uint8_t> touched, below_count, below_inl;
+    };
+
+    static bool near_zero(double d) { return (d < 1e-3) && (d > -1e-3); }  // poselib::nearZero
+    void view1(unsigned i, double *f) const { dgm::bearing(hp2[2 * i], hp2[2 * i + 1], f); }  // adapter view 1 = second image
+    void view2(unsigned i, double *f) const { dgm::bearing(hp1[2 * i], hp1[2 * i + 1], f); }
+    static bool row_bit(const uint64_t *row, unsigned j) { return (row[j >> 6] >> (j & 63)) & 1; }
+    unsigned row_count(const uint64_t *row) const {
+        unsigned c = 0;
+        for (int w = 0; w < words; ++w) c += (unsigned)__builtin_popcountll(row[w]);
+        return c;
+    }
+    // rows of h_dg[0 .. B): returns the pinned block, 2 rows of `words` words per model
+    int dg_rows(int B, const uint64_t **rows) {
+        hipLaunchKernelGGL(usac_degen_rows_kernel, dim3(B), dim3(256), 0, s, (const double4 *)d_pts_pool, (int)n, words,
+                           (const UsacDgModel *)d_dg, dg_thr, thr, (unsigned long long *)h_out_dev);
+        MLPL_HIP_TRY(hipGetLastError());
+        MLPL_HIP_TRY(hipStreamSynchronize(s));
+        *rows = (const uint64_t *)h_out;
+        stats[5]++;
+        return MLPL_OK;
+    }
+    void rotation_only(const std::vector<int> &idx, double *R) const {  // opengv rotationOnly: Arun on the centred bearing vectors
+        double c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0}, H[9] = {0};
+        for (int i : idx) {
+            double a[3], b[3];
+            view1((unsigned)i, a), view2((unsigned)i, b);
+            for (int k = 0; k < 3; ++k) c1[k] += a[k], c2[k] += b[k];
+        }
+        const double m = (double)idx.size();
+        for (int k = 0; k < 3; ++k) c1[k] = c1[k] / m, c2[k] = c2[k] / m;
+        for (int i : idx) {
+            double a[3], b[3];
+            view1((unsigned)i, a), view2((unsigned)i, b);
+            dgm::cross_cov_add(H, a, b, c1, c2);
+        }
+        dgm::arun(H, R);
+    }
+
+    int test_rotation(bool *degenerate) {
+        static const unsigned pair_of[20] = {0, 1, 0, 2, 0, 3, 0, 4, 1, 2, 1, 3, 1, 4, 2, 3, 2, 4, 3, 4};
+        static const unsigned rest_of[30] = {2, 3, 4, 1, 3, 4, 1, 2, 4, 1, 2, 3, 0, 3, 4, 0, 2, 4, 0, 2, 3, 0, 1, 4, 0, 1, 3, 0, 1, 2};
+        int rc;
+        for (unsigned i = 0; i < 10; ++i) {  // the ten two-point rotations of the sample, evaluated on all correspondences at once
+            double a0[3], b0[3], a1[3], b1[3];
+            const unsigned s0 = min_sample[pair_of[2 * i]], s1 = min_sample[pair_of[2 * i + 1]];
+            view1(s0, a0), view2(s0, b0), view1(s1, a1), view2(s1, b1);
+            h_dg[i].kind = 0;
+            dgm::twopt_rotation(a0, b0, a1, b1, h_dg[i].m);
+        }
+        const uint64_t *rows;
+        if ((rc = dg_rows(10, &rows))) return rc;
+        std::vector<uint64_t> first((size_t)10 * words);
+        for (unsigned i = 0; i < 10; ++i) std::memcpy(&first[(size_t)i * words], rows + (size_t)2 * i * words, (size_t)words * 8);
+        std::vector<int> sample(5, 0), inl;
+        for (unsigned i = 0; i < 10; ++i) {
+            const uint64_t *row = &first[(size_t)i * words];
+            for (unsigned j = 0; j < 2; ++j) sample[j] = (int)min_sample[pair_of[2 * i + j]];
+            unsigned count1 = 2, num = 0;
+            for (unsigned j = 0; j < 3; ++j) {
+                const unsigned idx = min_sample[rest_of[3 * i + j]];
+                if (row_bit(row, pool_pos[idx])) sample[count1++] = (int)idx, ++num;
+            }
+            if (num == 0) continue;
+            num = row_count(row);
+            const unsigned first_count = num;
+            if (num < 2) continue;
+            inl.clear();
+            for (unsigned j = 0; j < n; ++j)
+                if (row_bit(row, j)) {
+                    inl.push_back((int)pool[j]);
+                    if (count1 < 5) sample[count1++] = (int)pool[j];
+                }
+            h_dg[0].kind = 0;
+            rotation_only(inl, h_dg[0].m);
+            if ((rc = dg_rows(1, &rows))) return rc;
+            num = row_count(rows);
+            double v[5] = {(double)hyp_count, (double)i, (double)first_count, (double)num, 0};
+            if (num < best / 5) {
+                emit(8, v, 5);
+                continue;
+            }
+            *degenerate = true;
+            if (dg_type != (dg_type & (DG_UPGRADE | DG_ROT_TRANS))) dg_type = DG_ROT_TRANS;
+            if (num > dg_cnt_rot) {
+                dg_type |= DG_UPGRADE;
+                inl.clear();
+                for (unsigned j = 0; j < n; ++j)
+                    if (row_bit(rows, j)) inl.push_back((int)pool[j]);
+                rotation_only(inl, dg_R);
+                dg_cnt_rot = num;
+                for (unsigned j = 0; j < n; ++j) {
+                    const bool in = row_bit(rows, j);
+                    dg_in_rot[pool[j]] = in ? 1 : 0, dg_out_rot[pool[j]] = in ? 0 : 1;
+                }
+                dg_sample_rot = sample;
+                v[4] = 1;
+            }
+            emit(8, v, 5);
+        }
+        return MLPL_OK;
+    }
+
+    int test_no_motion(bool *degenerate) {
+        if (dg_cnt_nomot > 0) return MLPL_OK;
+        int rc;
+        const uint64_t *rows;
+        h_dg[0].kind = 1;
+        if ((rc = dg_rows(1, &rows))) return rc;
+        dg_sample_nomot.clear();
+        unsigned num = 0;
+        for (unsigned j = 0; j < 5; ++j)
+            if (row_bit(rows, pool_pos[min_sample[j]])) dg_sample_nomot.push_back((int)min_sample[j]), ++num;
+        if (num == 0) return MLPL_OK;
+        num = row_count(rows);
+        if (num < best / 5) return MLPL_OK;
+        *degenerate = true;
+        const bool dominant = (double)num > 0.7 * (double)dg_cnt_rot;
+        if (dominant)
+            if (dg_type != (dg_type & (DG_UPGRADE | DG_NO_MOT))) dg_type = DG_NO_MOT;
+        if (num > dg_cnt_nomot) {
+            if (dominant) dg_type |= DG_UPGRADE;
+            dg_cnt_nomot = num;
+            for (unsigned j = 0; j < n; ++j) {
+                const bool in = row_bit(rows, j);
+                dg_in_nomot[pool[j]] = in ? 1 : 0, dg_out_nomot[pool[j]] = in ? 0 : 1;
+                if (in && dg_sample_nomot.size() < 5) dg_sample_nomot.push_back((int)pool[j]);
+            }
+        }
+        return MLPL_OK;
+    }
+
+    int test_degeneracy(bool *degenerate, bool *upgrade) {
+        *degenerate = false, *upgrade = false;
+        dg_type = DG_H;  // :1346, taken whenever the homography test is off
+        int rc;
+        if ((rc = test_rotation(degenerate))) return rc;
+        if (dg_type & DG_UPGRADE) *upgrade = true;
+        if (dg_type == (unsigned)(DG_ROT_TRANS | DG_UPGRADE))
+            if ((rc = test_no_motion(degenerate))) return rc;
+        double v[7] = {(double)hyp_count, *degenerate ? 1.0 : 0.0, *upgrade ? 1.0 : 0.0, (double)dg_type, (double)dg_cnt_rot, (double)dg_cnt_nomot, (double)best};
+        emit(7, v, 7);
+        return MLPL_OK;
+    }
+
+    // storeSolution inside the upgrade loops: the inlier flags are whatever the current error array holds below the inlier threshold
+    void store_from_errs(const DgErrs &A, unsigned num_inl, const double *E) {
+        best = num_inl;
+        for (unsigned i = 0; i < n; ++i) flags[i] = A.touched[i] ? A.below_inl[i] : 0;
+        for (int w = 0; w < words; ++w) best_bits[w] = 0;
+        for (unsigned j = 0; j < n; ++j)
+            if (flags[pool[j]]) best_bits[j >> 6] |= 1ull << (j & 63);
+        std::memcpy(final_model, E, 72);
+        double v[3] = {(double)hyp_count, 0.0, (double)num_inl};
+        emit(4, v, 3);
+    }
+    unsigned standard_stopping_on(const DgErrs &A, const std::vector<unsigned> &idx, unsigned num_outliers) const {
+        unsigned c = 0, untouched = 0;
+        for (unsigned j : idx) {
+            if (A.touched[j] && A.below_count[j])
+                ++c;
+            else if (!A.touched[j])
+                ++untouched;
+        }
+        return standard_stopping(c, num_outliers - untouched, 1);
+    }
+
+    int upgrade_model(unsigned *result) {
+        unsigned best_up = best, best_up_rot = dg_cnt_rot, best_up_trans = dg_cnt_trans;
+        *result = 0;
+        if (n < 2) return MLPL_OK;
+        if (!(dg_type & DG_UPGRADE)) {
+            double v[4] = {(double)hyp_count, 0.0, 0.0, (double)best_up};
+            emit(9, v, 4);
+            *result = best_up;
+            return MLPL_OK;
+        }
+        const bool nomot = (dg_type & DG_NO_MOT) != 0;
+        const unsigned num_outliers = n - (nomot ? dg_cnt_nomot : dg_cnt_rot);
+        if (num_outliers < (nomot ? 1u : 3u)) return MLPL_OK;
+        std::vector<unsigned> outlier_indices(num_outliers, 0);
+        {
+            unsigned c = 0;
+            const std::vector<uint8_t> &of = nomot ? dg_out_nomot : dg_out_rot;
+            for (unsigned i = 0; i < n; ++i)
+                if (of[i]) outlier_indices[c++] = i;
+        }
+        // the two error arrays: errs[cur] plays err_ptr_[0] (filled with DBL_MAX), errs[1 - cur] holds the errors of the best model
+        DgErrs errs[2];
+        for (auto &e : errs) e.touched.assign(n, 0), e.below_count.assign(n, 0), e.below_inl.assign(n, 0);
+        int cur = 0;
+        const int counted = 0;  // current_err_array: the array that is err_ptr_[0] on entry, whatever the swaps do afterwards
+        for (unsigned i = 0; i < n; ++i) errs[1].touched[i] = 1, errs[1].below_inl[i] = flags[i];
+        unsigned &limit = nomot ? dg_max_nomot : dg_max_rot;
+        const unsigned size_nomot = (unsigned)dg_sample_nomot.size();
+        const unsigned k_draw = nomot ? 1u : 3u;
+        std::vector<unsigned> smp(k_draw);
+        struct Cand {
+            GlibcRand after;  // the stream after this candidate's draws
+            int index[5];
+            bool skip;        // translation too short: the loop continues without an evaluation
+            double E[9], t[3];
+            int model;        // its row block in the launch, -1 = none
+        };
+        std::vector<Cand> cands;
+        unsigned tried = 0;
+        int rc;
+        for (unsigned i = 0; i < limit;) {
+            // candidates do not depend on what is accepted: draw and solve a batch ahead, evaluate it in one launch
+            const unsigned want = std::min<unsigned>((unsigned)dg_cap, limit - i);
+            cands.clear();
+            GlibcRand r2 = rng;
+            int B = 0;
+            for (unsigned c = 0; c < want; ++c) {
+                Cand cd;
+                uniform_sample(r2, num_outliers, k_draw, smp);
+                cd.skip = false, cd.model = -1;
+                if (nomot) {
+                    cd.index[0] = (int)outlier_indices[smp[0]];
+                    cd.index[1] = dg_sample_nomot[(unsigned)r2.next() % size_nomot];
+                    double a0[3], b0[3], a1[3], b1[3];
+                    view1((unsigned)cd.index[0], a0), view2((unsigned)cd.index[0], b0), view1((unsigned)cd.index[1], a1), view2((unsigned)cd.index[1], b1);
+                    dgm::twopt_translation(a0, b0, a1, b1, cd.t);
+                    const double len = std::sqrt(cd.t[0] * cd.t[0] + (cd.t[1] * cd.t[1] + cd.t[2] * cd.t[2]));
+                    cd.skip = near_zero(len * 100);
+                    if (!cd.skip) {
+                        const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+                        dgm::e_from_rt(I3, cd.t, cd.E);
+                        h_dg[B].kind = 2;
+                        std::memset(h_dg[B].m, 0, 72);
+                        std::memcpy(h_dg[B].m, cd.t, 24);
+                        cd.model = B++;
+                    }
+                } else {
+                    for (int j = 0; j < 3; ++j) cd.index[j] = (int)outlier_indices[smp[j]];
+                    cd.index[3] = dg_sample_rot[0], cd.index[4] = dg_sample_rot[1];
+                    double f1[5][3], f2[5][3], R[9], t[3];
+                    for (int j = 0; j < 5; ++j) view1((unsigned)cd.index[j], f1[j]), view2((unsigned)cd.index[j], f2[j]);
+                    dgm::eigensolver(f1, f2, 5, dg_R, R, t);
+                    const double len = std::sqrt(t[0] * t[0] + (t[1] * t[1] + t[2] * t[2]));
+                    cd.skip = near_zero(len * 100);
+                    std::memset(cd.E, 0, 72);
+                    if (!cd.skip) {
+                        for (int k = 0; k < 3; ++k) cd.t[k] = t[k] / len;
+                        dgm::e_from_rt(R, cd.t, cd.E);
+                        h_dg[B].kind = 3;
+                        std::memcpy(h_dg[B].m, cd.E, 72);
+                        cd.model = B++;
+                    }
+                }
+                cd.after = r2;
+                cands.push_back(cd);
+            }
+            const uint64_t *rows = nullptr;
+            if (B > 0 && (rc = dg_rows(B, &rows))) return rc;
+            unsigned used = 0;
+            for (; used < cands.size() && i < limit; ++used, ++i) {
+                const Cand &cd = cands[used];
+                ++tried;
+                {
+                    double v[12] = {(double)hyp_count, nomot ? 1.0 : 2.0, (double)i};
+                    if (nomot)
+                        v[3] = cd.t[0], v[4] = cd.t[1], v[5] = cd.t[2];
+                    else
+                        std::memcpy(v + 3, cd.E, 72);
+                    emit(10, v, 12);
+                }
+                if (cd.skip) continue;
+                const uint64_t *row_a = rows + (size_t)2 * cd.model * words, *row_b = nomot ? row_a + words : row_a;
+                unsigned num = 0, tested = 0;
+                const unsigned start = pool_index;
+                const bool good = sprt_walk(row_a, &num, &tested);
+                {
+                    double v[11] = {(double)hyp_count, nomot ? -1.0 : 0.0, (double)start, (double)num, (double)tested, good ? 1.0 : 0.0,
+                                    sprt_delta, sprt_epsilon, sprt_A, nomot ? dg_thr : thr, (double)num_lo};
+                    emit(2, v, 11);
+                }
+                DgErrs &W = errs[cur];  // evaluateModel / evaluateModelTrans write err_ptr_[0] for the correspondences they reach
+                for (unsigned q = 0, j = start; q < tested; ++q, ++j) {
+                    if (j > n - 1) j = 0;
+                    const unsigned pt = pool[j];
+                    W.touched[pt] = 1, W.below_count[pt] = row_bit(row_a, j), W.below_inl[pt] = row_bit(row_b, j);
+                }
+                if (num > (nomot ? best_up_trans : best_up_rot)) {
+                    if (!nomot)
+                        for (int j = 2, c = 0; j < 5; ++j) dg_sample_rot[j] = cd.index[c++];
+                    if (num > best_up || (near_zero(final_model[0] * 100) && near_zero(final_model[4] * 100) && near_zero(final_model[8] * 100))) {
+                        store_from_errs(errs[cur], num, cd.E);
+                        cur = 1 - cur;
+                        best_up = num;
+                        if (nomot) {
+                            if (size_nomot > 3) {
+                                unsigned k = 0;
+                                for (size_t j = 0; j < 3; j++) {
+                                    if (dg_sample_nomot[k] == cd.index[1]) {
+                                        j--;
+                                        k++;
+                                        continue;
+                                    }
+                                    min_sample[j] = (unsigned)dg_sample_nomot[k];
+                                    k++;
+                                }
+                                min_sample[3] = (unsigned)cd.index[1], min_sample[4] = (unsigned)cd.index[0];
+                            }
+                            dg_cnt_trans = num;
+                        } else {
+                            for (size_t j = 0; j < 5; j++) min_sample[j] = (unsigned)dg_sample_rot[j];
+                        }
+                    }
+                    (nomot ? best_up_trans : best_up_rot) = num;
+                    const unsigned ns = standard_stopping_on(errs[counted], outlier_indices, num_outliers);
+                    if (ns < limit) limit = ns;
+                }
+            }
+            // the stream stands where the reference's loop left it
+            if (used > 0) rng = cands[used - 1].after;
+            if (used < cands.size()) break;
+        }
+        double v[4] = {(double)hyp_count, nomot ? 1.0 : 2.0, (double)tried, (double)best_up};
+        emit(9, v, 4);
+        *result = best_up;
+        return MLPL_OK;
+    }
+
     int solve(bool *ok) {
         unsigned adaptive = max_hyp;
         bool update_sprt_stopping = true;
@@ -995,10 +1416,28 @@ struct UsacRun {
                     }
                 }
             }
+            if (update_best && dg_on) {  // USAC.h:509-528
+                bool degenerate = false, upgrade = false;
+                if ((rc = test_degeneracy(&degenerate, &upgrade))) return rc;
+                if (degenerate && upgrade) {
+                    unsigned up = 0;
+                    if ((rc = upgrade_model(&up))) return rc;
+                    if (up > best) best = up;
+                }
+            }
             if (update_best) {
                 unsigned lo = 0;
                 // the cache entry `sm` may be invalidated by nothing below (no insertion during LO)
                 if ((rc = local_optimization(best, &lo))) return rc;
+                if (dg_losac) {  // USAC.h:540-556 (testDegeneracyLOSAC: the 8-point refinements)
+                    bool degenerate = false, upgrade = false;
+                    if ((rc = test_degeneracy(&degenerate, &upgrade))) return rc;
+                    if (degenerate && upgrade) {
+                        unsigned up = 0;
+                        if ((rc = upgrade_model(&up))) return rc;
+                        if (up > lo) lo = up;
+                    }
+                }
                 if (lo > best) best = lo;
                 if (prosac && hyp_count <= prosac_max_samples)
                     adaptive = prosac_stopping(hyp_count);
@@ -1029,6 +1468,9 @@ int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, in
     R.prosac_beta = P->prosac_beta, R.sprt_delta = P->sprt_delta, R.sprt_epsilon = P->sprt_epsilon;
     R.sprt_mS = P->sprt_mS, R.sprt_tM = P->sprt_tM;
     R.lo_stepwise = ctx->opt_usac_lo_stepwise;
+    R.dg_on = P->check_degeneracy != 0;
+    R.dg_losac = R.dg_on && (P->check_degeneracy & 2) != 0;
+    if (R.dg_on) R.dg_thr = 1.0 - std::cos(std::atan(P->th_pixels / P->focal_length));  // EssentialMatEstimator.h:349
     R.hp1.resize((size_t)2 * n), R.hp2.resize((size_t)2 * n);
     MLPL_HIP_TRY(hipMemcpyAsync(R.hp1.data(), d_p1, (size_t)n * 16, hipMemcpyDeviceToHost, s));
     MLPL_HIP_TRY(hipMemcpyAsync(R.hp2.data(), d_p2, (size_t)n * 16, hipMemcpyDeviceToHost, s));
@@ -1041,6 +1483,21 @@ int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, in
         if ((rc = R.solve(&ok))) return rc;
     }
     std::memcpy(ctx->last_usac_stats, R.stats, sizeof(R.stats));
+    {  // what estimateEssentialMatUsac reports of the degeneracy tests (usac_estimations.cpp:564-636, 689-726)
+        double *d = ctx->last_usac_degen;
+        std::memset(d, 0, sizeof(ctx->last_usac_degen));
+        d[0] = R.dg_on ? 1.0 : 0.0, d[1] = R.dg_cnt_rot, d[2] = R.dg_cnt_nomot, d[3] = R.dg_type;
+        std::memcpy(d + 4, R.dg_R, 72);
+        std::free(ctx->last_usac_flags);
+        ctx->last_usac_flags = nullptr, ctx->last_usac_flags_n = 0;
+        if (R.dg_on && n > 0 && R.dg_in_rot.size() == (size_t)n) {
+            ctx->last_usac_flags = (uint8_t *)std::malloc((size_t)2 * n);
+            if (!ctx->last_usac_flags) return MLPL_E_NOMEM;
+            std::memcpy(ctx->last_usac_flags, R.dg_in_rot.data(), (size_t)n);
+            std::memcpy(ctx->last_usac_flags + n, R.dg_in_nomot.data(), (size_t)n);
+            ctx->last_usac_flags_n = n;
+        }
+    }
     if (results) {
         const double fin[12] = {ok ? 1.0 : 0.0,
                                 (double)R.hyp_count,

@@ -138,14 +138,19 @@ class UsacParams(C.Structure):
     """mlpl_usac_params (include/mlpl_c.h): the configuration estimateEssentialMatUsac builds (usac_estimations.cpp:283-470)."""
     _fields_ = [("th", C.c_double), ("conf", C.c_double), ("max_hyp", C.c_int32), ("estimator", C.c_int32), ("refine", C.c_int32),
                 ("seed", C.c_uint32), ("prosac_beta", C.c_double), ("sprt_delta", C.c_double), ("sprt_epsilon", C.c_double),
-                ("sprt_mS", C.c_double), ("sprt_tM", C.c_double), ("sorted_idx", C.c_void_p)]
+                ("sprt_mS", C.c_double), ("sprt_tM", C.c_double), ("sorted_idx", C.c_void_p), ("check_degeneracy", C.c_int32),
+                ("reserved", C.c_int32), ("th_pixels", C.c_double), ("focal_length", C.c_double)]
 
 
 def usac_essential(p1, p2, th: float, seed: int, sorted_idx=None, max_hyp: int = 50000, conf: float = 0.99, prosac_beta: float = 0.09,
                    sprt_delta: float = 0.05, sprt_epsilon: float = 0.15, sprt_ms: float = 8.5, sprt_tm: float = 2314.0, estimator: int = 0,
-                   refine: int = 0, event_cap: int = 0, ctx: Optional[Context] = None) -> dict:
+                   refine: int = 0, event_cap: int = 0, check_degeneracy: int = 0, th_pixels: float = 0.8, focal_length: float = 800.0,
+                   ctx: Optional[Context] = None) -> dict:
     """estimateEssentialMatUsac with the Nister solver and REF_WEIGHTS (usac_estimations.cpp:283-735) on the device; `seed` is the
-    reference's srand(time) seed.  sorted_idx (best match first) switches PROSAC on.  event_cap > 0 also returns the decision trace."""
+    reference's srand(time) seed.  sorted_idx (best match first) switches PROSAC on.  event_cap > 0 also returns the decision trace.
+    check_degeneracy: 0 none, 1 the rotation-only / no-motion tests + model upgrade after every new best model (DEGEN_USAC_INTERNAL),
+    3 also after every local optimisation; the result then carries `degen` = [1, inliers of the rotation, of "no motion", type],
+    `R_degen`, `flags_rot`, `flags_nomot`."""
     ctx = ctx or default_context()
     p1, p2 = _pts(p1), _pts(p2)
     n = p1.shape[0]
@@ -154,6 +159,7 @@ def usac_essential(p1, p2, th: float, seed: int, sorted_idx=None, max_hyp: int =
     P.conf, P.max_hyp, P.estimator, P.refine, P.seed = float(conf), int(max_hyp), int(estimator), int(refine), int(seed) & 0xFFFFFFFF
     P.prosac_beta, P.sprt_delta, P.sprt_epsilon, P.sprt_mS, P.sprt_tM = float(prosac_beta), float(sprt_delta), float(sprt_epsilon), \
         float(sprt_ms), float(sprt_tm)
+    P.check_degeneracy, P.th_pixels, P.focal_length = int(check_degeneracy), float(th_pixels), float(focal_length)
     si = None
     if sorted_idx is not None:
         si = np.ascontiguousarray(sorted_idx, np.uint32)
@@ -169,7 +175,12 @@ def usac_essential(p1, p2, th: float, seed: int, sorted_idx=None, max_hyp: int =
         raise MlplError(rc, "mlpl_usac_essential", _lib.last_error())
     stats = np.zeros(8, np.int64)
     ctx.lib.mlpl_usac_last_stats(ctx.handle, stats.ctypes.data)
-    return dict(ok=(rc == 0), E=E, flags=mask, final=res, events=ev[:min(nev, event_cap)], n_events=nev, stats=stats)
+    out = dict(ok=(rc == 0), E=E, flags=mask, final=res, events=ev[:min(nev, event_cap)], n_events=nev, stats=stats)
+    if check_degeneracy and rc == 0:
+        info, fr, fn = np.zeros(16), np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        check(ctx.lib.mlpl_usac_last_degeneracy(ctx.handle, info.ctypes.data, fr.ctypes.data, fn.ctypes.data, n), "mlpl_usac_last_degeneracy")
+        out.update(degen=info[:4].copy(), R_degen=info[4:13].copy(), flags_rot=fr, flags_nomot=fn)
+    return out
 
 
 def arrsac_sample_models(p1, p2, idx, kind: int, thresh: float = 1e-3, ctx: Optional[Context] = None):

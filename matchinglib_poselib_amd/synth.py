@@ -50,20 +50,23 @@ def _rot(axis, deg):
 PIX_TO_CAM = 4.0 / (np.sqrt(2.0) * 3200.0)  # f = 800 on both cameras (stereo_pose_refinement.h:280-286)
 
 
-def pose_scene(n: int = 5000, inlier_frac: float = 0.5, seed: int = 20260103, noise_px: float = 0.3):
+def pose_scene(n: int = 5000, inlier_frac: float = 0.5, seed: int = 20260103, noise_px: float = 0.3, rot_deg: float = 5.0,
+               t_len: float = 1.0):
     """C3 scene: camera-normalised correspondences with known (R, t).
 
     3-D points uniform in x,y in [-2,2], z in [4,12]; R = rot((0.2,0.9,0.1), 5 deg), t = (1,0.05,-0.02)/|.|;
     Gaussian noise sigma = noise_px * PIX_TO_CAM on both views; outliers = uniform points in the same image box
-    paired at random; order shuffled.  Returns p1, p2 (n x 2 float64), R, t, inlier_mask, thresh (0.8 px)."""
+    paired at random; order shuffled.  Returns p1, p2 (n x 2 float64), R, t, inlier_mask, thresh (0.8 px).
+    `rot_deg` / `t_len` (baseline length; the scene is 4..12 deep) make the degenerate motions USAC tests for: t_len = 0 is a pure
+    rotation, rot_deg = 0 and t_len = 0 no motion at all."""
     rng = np.random.default_rng(seed)
-    R = _rot((0.2, 0.9, 0.1), 5.0)
+    R = _rot((0.2, 0.9, 0.1), rot_deg)
     t = np.array([1.0, 0.05, -0.02])
     t = t / np.linalg.norm(t)
     n_in = int(round(n * inlier_frac))
     X = np.stack([rng.uniform(-2, 2, n_in), rng.uniform(-2, 2, n_in), rng.uniform(4, 12, n_in)], axis=1)
     x1 = X[:, :2] / X[:, 2:3]
-    X2 = X @ R.T + t
+    X2 = X @ R.T + t_len * t
     x2 = X2[:, :2] / X2[:, 2:3]
     sigma = noise_px * PIX_TO_CAM
     x1 = x1 + rng.normal(0, sigma, x1.shape)

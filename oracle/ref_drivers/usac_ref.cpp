@@ -11,7 +11,12 @@
 // the POSE_NISTER path without degeneracy tests executes -- initProblem :189-352, generateMinimalSampleModels :384-398 + :505-520,
 // generateRefinedModel REFINE_WEIGHTS :540-599 / REFINE_NISTER :757-850, validateSample :1043-1078, validateModel :1085-1104,
 // evaluateModel :1110-1178, findWeights :2366-2390, storeModel :2436-2445 -- calling the reference's own FTools / MathTools / PoseTools /
-// OpenGV functions wherever the original does.  Everything USAC<> does with them (solve(), the samplers, designSPRTTest, the SPRT
+// OpenGV functions wherever the original does.  With `check_degeneracy` (in.bin ih[5]) the class also restates testSolutionDegeneracy
+// :1334-1362, testSolutionDegeneracyRot :1511-1663, testSolutionDegeneracyNoMot :1838-1911, upgradeDegenerateModel's pose branches
+// :2098-2361 and evaluateModelTrans :1264-1327 -- the configuration estimateEssentialMatUsac builds for a refinement other than the
+// 8-point ones (enableHDegen = false, enableUpgradeDegenPose = true, 8000 upgrade samples, usac_estimations.cpp:443-456) -- on the
+// reference's own opengv::relative_pose::{twopt_rotationOnly, rotationOnly, twopt, eigensolver}, opengv::triangulation::triangulate2 and
+// PoseTools::{getRotError, getNoMotError}.  Everything USAC<> does with them (solve(), the samplers, designSPRTTest, the SPRT
 // history, updateSPRTStopping, locallyOptimizeSolution, storeSolution, std::random_shuffle of the evaluation pool on the process-wide
 // rand() stream) is the reference's code, unmodified.  This file contains no reference source text.
 //
@@ -22,11 +27,15 @@
 // association depends on the Eigen version and the alignment of the column -- rounding noise no restatement can reproduce.  The SET of
 // solutions does not depend on it.  `--native-order` keeps OpenGV's order (diagnostics).
 //
-// usage: usac_ref in.bin out.bin [--native-order] [--solver-oracle]
-//   in.bin : int32 n, seed, refine (0 = REF_WEIGHTS, 6 = REF_NISTER), prosac (0/1), max_hyp, reserved[3];
-//            double th, prosac_beta, sprt_delta, sprt_epsilon, sprt_mS, sprt_tM, conf, reserved;
+// usage: usac_ref in.bin out.bin [--native-order] [--solver-oracle] [--eigvec-smallest]
+//   in.bin : int32 n, seed, refine (0 = REF_WEIGHTS, 6 = REF_NISTER), prosac (0/1), max_hyp, check_degeneracy (0, 1, 3 = also after local optimisations), reserved[2];
+//            double th, prosac_beta, sprt_delta, sprt_epsilon, sprt_mS, sprt_tM, conf, th_pixels / focal length;
 //            n * 4 doubles (x1,y1,x2,y2); if prosac: n uint32 sorted indices
 //   out.bin: int32 n_events; n_events * 16 doubles (event records, see emit()); then the final record (see main)
+//   event types: 1 sample, 2 evaluation, 3 refined model, 4 stored model, 5 minimal model, 6 model rejected by validateModel,
+//                7 degeneracy test [hyp, degenerate, upgrade, type, count_rot, count_noMot, best], 8 rotation found on all points
+//                [hyp, pair, inliers of the 2-point rotation, inliers of the refit, kept], 9 upgrade [hyp, branch 1 = no motion -> t /
+//                2 = R -> R + t, candidates tried, result], 10 upgrade candidate [hyp, branch, iteration, model (E, or t and 6 zeros)]
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -47,6 +56,7 @@
 #include "usac/estimators/USAC.h"
 
 #include <opengv/relative_pose/methods.hpp>
+#include <opengv/triangulation/methods.hpp>
 #include <opengv/relative_pose/CentralRelativeAdapter.hpp>
 
 static bool g_native_order = false;
@@ -55,6 +65,12 @@ static bool g_native_order = false;
 // the same solver.  (OpenGV's fivept_nister returns unconverged roots on a noticeable share of samples -- its Sturm brackets are
 // bound / (10 roots) wide and get five Newton steps -- so with it the traces part at the first such sample; see tests/test_oracle_usac.py.)
 static bool g_solver_oracle = false;
+// --eigvec-smallest: OpenGV's eigensolver takes its translation from column 0 of Eigen::EigenSolver's eigenvectors
+// (modules/main.cpp:646-659) -- meant to be the eigenvector of the smallest eigenvalue, but EigenSolver orders nothing: on symmetric
+// matrices of this kind the smallest eigenvalue sits at position 0 in about a third of the cases (probe: 6178 / 7806 / 6016 of 20000).
+// With this flag the R -> R + t upgrade takes the eigenvector of the smallest eigenvalue from the same eigensolver output, which is
+// what oracle/ and the device path do (stated deviation); without it the reference's own choice.
+static bool g_eigvec_smallest = false;
 extern "C" int oracle_run5point(const double *q1, const double *q2, int n, double *E_out);
 static std::vector<double> g_events;  // 16 doubles per event
 
@@ -331,8 +347,345 @@ class RefEssential : public USAC<RefEssential> {
         return good_flag;
     }
 
-    void testSolutionDegeneracy(bool *degenerateModel, bool *upgradeModel) override { *degenerateModel = false, *upgradeModel = false; }
-    unsigned int upgradeDegenerateModel() override { return 0; }
+    // ---- degeneracy tests and model upgrade (check_degeneracy; enableHDegen = false, enableUpgradeDegenPose = true) ------------------
+    enum { DG_NOT_FOUND = 0x1, DG_H = 0x2, DG_ROT_TRANS = 0x4, DG_NO_MOT = 0x8, DG_UPGRADE = 0x10 };
+    static bool near_zero(double d) { return (d < 1e-3) && (d > -1e-3); }  // poselib::nearZero (pose_helper.h:82-87)
+
+    void testSolutionDegeneracy(bool *degenerateModel, bool *upgradeModel) override {
+        *degenerateModel = false, *upgradeModel = false;
+        degeneracyType = DG_H;  // :1346, taken whenever the homography test is off
+        test_rotation(degenerateModel);
+        if (degeneracyType & DG_UPGRADE) *upgradeModel = true;
+        if (degeneracyType == (unsigned)(DG_ROT_TRANS | DG_UPGRADE)) test_no_motion(degenerateModel);
+        double v[7] = {(double)usac_results_.hyp_count_, *degenerateModel ? 1.0 : 0.0, *upgradeModel ? 1.0 : 0.0, (double)degeneracyType,
+                       (double)usac_results_.degen_inlier_count_rot, (double)usac_results_.degen_inlier_count_noMot,
+                       (double)usac_results_.best_inlier_count_};
+        emit(7, v, 7);
+    }
+
+    void test_rotation(bool *degenerateModel) {
+        static const unsigned pair_of[20] = {0, 1, 0, 2, 0, 3, 0, 4, 1, 2, 1, 3, 1, 4, 2, 3, 2, 4, 3, 4};
+        static const unsigned rest_of[30] = {2, 3, 4, 1, 3, 4, 1, 2, 4, 1, 2, 3, 0, 3, 4, 0, 2, 4, 0, 2, 3, 0, 1, 4, 0, 1, 3, 0, 1, 2};
+        const unsigned n = usac_num_data_points_;
+        opengv::rotation_t R_;
+        std::vector<int> sample(5);
+        std::vector<unsigned int> test(3);
+        std::vector<double> errs;
+        for (unsigned i = 0; i < 10; ++i) {
+            for (unsigned j = 0; j < 2; ++j) sample[j] = (int)min_sample_[pair_of[2 * i + j]];
+            R_ = opengv::relative_pose::twopt_rotationOnly(*adapter_denorm, sample);
+            for (unsigned j = 0; j < 3; ++j) test[j] = min_sample_[rest_of[3 * i + j]];
+            unsigned num_inliers = PoseTools::getRotError(test, 3, errs, adapter_denorm, R_, poseDegenTheshold);
+            unsigned count1 = 2;
+            for (unsigned j = 0; j < 3; ++j)
+                if (errs[j] < poseDegenTheshold) sample[count1++] = test[j];
+            if (num_inliers == 0) continue;
+            num_inliers = PoseTools::getRotError(evaluation_pool_, n, errs, adapter_denorm, R_, poseDegenTheshold);
+            const unsigned first_count = num_inliers;
+            if (num_inliers < 2) continue;
+            unsigned count = 0;
+            std::vector<int> inlier_sample(num_inliers);
+            for (unsigned j = 0; j < n; ++j)
+                if (errs[j] < poseDegenTheshold) {
+                    inlier_sample[count++] = (int)evaluation_pool_[j];
+                    if (count1 < 5) sample[count1++] = (int)evaluation_pool_[j];
+                }
+            R_ = opengv::relative_pose::rotationOnly(*adapter_denorm, inlier_sample);
+            num_inliers = PoseTools::getRotError(evaluation_pool_, n, errs, adapter_denorm, R_, poseDegenTheshold);
+            double v[5] = {(double)usac_results_.hyp_count_, (double)i, (double)first_count, (double)num_inliers, 0};
+            if (num_inliers < usac_results_.best_inlier_count_ / 5) {
+                emit(8, v, 5);
+                continue;
+            }
+            *degenerateModel = true;
+            if (degeneracyType != (degeneracyType & (DG_UPGRADE | DG_ROT_TRANS))) degeneracyType = DG_ROT_TRANS;
+            if (num_inliers > usac_results_.degen_inlier_count_rot) {
+                degeneracyType |= DG_UPGRADE;
+                count = 0;
+                inlier_sample.resize(num_inliers);
+                for (unsigned j = 0; j < n; ++j)
+                    if (errs[j] < poseDegenTheshold) inlier_sample[count++] = evaluation_pool_[j];
+                R_ = opengv::relative_pose::rotationOnly(*adapter_denorm, inlier_sample);
+                usac_results_.degen_inlier_count_rot = num_inliers;
+                for (unsigned r = 0; r < 3; ++r)
+                    for (unsigned c = 0; c < 3; ++c) degen_final_model_params_rot[r * 3 + c] = R_(r, c);
+                R_eigen_degen = R_;
+                for (unsigned j = 0; j < n; ++j) {
+                    const bool in = errs[j] < poseDegenTheshold;
+                    usac_results_.degen_inlier_flags_rot[evaluation_pool_[j]] = in ? 1 : 0;
+                    degen_outlier_flags_rot[evaluation_pool_[j]] = in ? 0 : 1;
+                }
+                degen_sample_rot = sample;
+                v[4] = 1;
+            }
+            emit(8, v, 5);
+        }
+    }
+
+    void test_no_motion(bool *degenerateModel) {
+        if (usac_results_.degen_inlier_count_noMot > 0) return;
+        const unsigned n = usac_num_data_points_;
+        std::vector<unsigned int> test(5);
+        std::vector<double> errs;
+        for (unsigned j = 0; j < 5; ++j) test[j] = min_sample_[j];
+        unsigned num_inliers = PoseTools::getNoMotError(test, 5, errs, adapter_denorm, poseDegenTheshold);
+        degen_sample_noMot.clear();
+        for (unsigned j = 0; j < 5; ++j)
+            if (errs[j] < poseDegenTheshold) degen_sample_noMot.push_back((int)test[j]);
+        if (num_inliers == 0) return;
+        num_inliers = PoseTools::getNoMotError(evaluation_pool_, n, errs, adapter_denorm, poseDegenTheshold);
+        if (num_inliers < usac_results_.best_inlier_count_ / 5) return;
+        *degenerateModel = true;
+        const bool dominant = (double)num_inliers > 0.7 * (double)usac_results_.degen_inlier_count_rot;
+        if (dominant)
+            if (degeneracyType != (degeneracyType & (DG_UPGRADE | DG_NO_MOT))) degeneracyType = DG_NO_MOT;
+        if (num_inliers > usac_results_.degen_inlier_count_noMot) {
+            if (dominant) degeneracyType |= DG_UPGRADE;
+            usac_results_.degen_inlier_count_noMot = num_inliers;
+            for (unsigned j = 0; j < n; ++j) {
+                if (errs[j] < poseDegenTheshold) {
+                    usac_results_.degen_inlier_flags_noMot[evaluation_pool_[j]] = 1;
+                    degen_outlier_flags_noMot[evaluation_pool_[j]] = 0;
+                    if (degen_sample_noMot.size() < 5) degen_sample_noMot.push_back((int)evaluation_pool_[j]);
+                } else {
+                    degen_outlier_flags_noMot[evaluation_pool_[j]] = 1;
+                    usac_results_.degen_inlier_flags_noMot[evaluation_pool_[j]] = 0;
+                }
+            }
+        }
+    }
+
+    // evaluateModelTrans (:1264-1327): reprojection error of the midpoint triangulation under (I, t), sequential test as evaluateModel
+    bool evaluate_translation(const opengv::translation_t &model, unsigned int *numInliers, unsigned int *numPointsTested) {
+        auto current_err_array = err_ptr_[0];
+        bool good_flag = true;
+        double lambdaj, lambdaj_1 = 1.0;
+        *numInliers = 0, *numPointsTested = 0;
+        const unsigned start_index = eval_pool_index_;
+        opengv::rotation_t rotation = opengv::rotation_t::Identity();
+        adapter_denorm->sett12(model);
+        adapter_denorm->setR12(rotation);
+        opengv::transformation_t inverseSolution;
+        inverseSolution.block<3, 3>(0, 0) = rotation.transpose();
+        inverseSolution.col(3) = -inverseSolution.block<3, 3>(0, 0) * model;
+        Eigen::Matrix<double, 4, 1> p_hom;
+        p_hom[3] = 1.0;
+        for (unsigned i = 0; i < usac_num_data_points_; ++i) {
+            if (eval_pool_index_ > usac_num_data_points_ - 1) eval_pool_index_ = 0;
+            const unsigned pt_index = evaluation_pool_[eval_pool_index_];
+            ++eval_pool_index_;
+            p_hom.block<3, 1>(0, 0) = opengv::triangulation::triangulate2(*adapter_denorm, pt_index);
+            opengv::bearingVector_t reprojection1 = p_hom.block<3, 1>(0, 0);
+            opengv::bearingVector_t reprojection2 = inverseSolution * p_hom;
+            reprojection1 = reprojection1 / reprojection1.norm();
+            reprojection2 = reprojection2 / reprojection2.norm();
+            opengv::bearingVector_t f1 = adapter_denorm->getBearingVector1(pt_index);
+            opengv::bearingVector_t f2 = adapter_denorm->getBearingVector2(pt_index);
+            const double reprojError1 = 1.0 - (f1.transpose() * reprojection1);
+            const double reprojError2 = 1.0 - (f2.transpose() * reprojection2);
+            const double temp_err = reprojError1 + reprojError2;
+            *(current_err_array + pt_index) = temp_err;
+            if (temp_err < poseDegenTheshold) ++(*numInliers);
+            if (usac_verif_method_ == USACConfig::VERIF_SPRT) {
+                if (temp_err < poseDegenTheshold)
+                    lambdaj = lambdaj_1 * (sprt_delta_ / sprt_epsilon_);
+                else
+                    lambdaj = lambdaj_1 * ((1 - sprt_delta_) / (1 - sprt_epsilon_));
+                if (lambdaj <= DBL_EPSILON) lambdaj = DBL_EPSILON * 10;
+                if (lambdaj > decision_threshold_sprt_) {
+                    good_flag = false;
+                    *numPointsTested = i + 1;
+                    break;
+                } else
+                    lambdaj_1 = lambdaj;
+            }
+        }
+        if (good_flag) *numPointsTested = usac_num_data_points_;
+        double v[12] = {(double)usac_results_.hyp_count_, -1.0, (double)start_index, (double)*numInliers, (double)*numPointsTested,
+                        good_flag ? 1.0 : 0.0, sprt_delta_, sprt_epsilon_, decision_threshold_sprt_, poseDegenTheshold,
+                        (double)usac_results_.num_local_optimizations_, 0};
+        emit(2, v, 11);
+        return good_flag;
+    }
+
+    // E = [t / |t|]_x R the way poselib::getEfromRT forms it (pose_helper.cpp:785-805: the vector times the reciprocal of its norm)
+    static void e_from_rt(const opengv::rotation_t &R, const opengv::translation_t &t, double *E) {
+        double nrm = 0;
+        for (int i = 0; i < 3; ++i) nrm += t[i] * t[i];
+        nrm = std::sqrt(nrm);
+        const double s = 1.0 / nrm;
+        const double a = t[0] * s, b = t[1] * s, c = t[2] * s;
+        const double S[9] = {0, -c, b, c, 0, -a, -b, a, 0};
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 3; ++k) {
+                double acc = 0;
+                for (int m = 0; m < 3; ++m) acc += S[3 * r + m] * R(m, k);
+                E[3 * r + k] = acc;
+            }
+    }
+
+    template <class It>
+    unsigned count_on(It err, const std::vector<unsigned int> &idx, double limit, unsigned *untouched) const {
+        unsigned c = 0, u = 0;
+        for (auto j : idx) {
+            if (err[j] < limit)
+                ++c;
+            else if (std::round(err[j] - DBL_MAX) == 0)
+                ++u;
+        }
+        *untouched = u;
+        return c;
+    }
+
+    unsigned int upgradeDegenerateModel() override {
+        const unsigned n = usac_num_data_points_;
+        unsigned best_upgrade_inliers = usac_results_.best_inlier_count_;
+        unsigned best_upgrade_inliers_rot = usac_results_.degen_inlier_count_rot;
+        unsigned best_upgrade_inliers_trans = usac_results_.degen_inlier_count_trans;
+        unsigned num_outliers = n - usac_results_.degen_inlier_count_;
+        if (num_outliers < 2) return 0;
+        unsigned tried = 0, branch = 0;
+        if (degeneracyType & DG_UPGRADE) {
+            if (degeneracyType & DG_NO_MOT) {  // no motion -> translation only
+                branch = 1;
+                num_outliers = n - usac_results_.degen_inlier_count_noMot;
+                if (num_outliers < 1) return 0;
+                std::vector<unsigned int> outlier_indices(num_outliers);
+                unsigned count = 0;
+                for (unsigned i = 0; i < n; ++i)
+                    if (degen_outlier_flags_noMot[i]) outlier_indices[count++] = i;
+                std::vector<unsigned int> outlier_sample(1);
+                std::fill(err_ptr_[0], err_ptr_[0] + n, DBL_MAX);
+                auto current_err_array = err_ptr_[0];
+                opengv::translation_t t_;
+                const unsigned size_noMot = (unsigned)degen_sample_noMot.size();
+                for (unsigned i = 0; i < degen_max_upgrade_samples_noMot_trans; ++i) {
+                    ++tried;
+                    generateUniformRandomSample(num_outliers, 1, &outlier_sample);
+                    std::vector<int> index(2);
+                    index[0] = (int)outlier_indices[outlier_sample[0]];
+                    const unsigned pick = std::rand() % size_noMot;
+                    index[1] = degen_sample_noMot[pick];
+                    t_ = opengv::relative_pose::twopt(*adapter_denorm, false, index);
+                    {
+                        double v[12] = {(double)usac_results_.hyp_count_, 1.0, (double)i, t_[0], t_[1], t_[2], 0, 0, 0, 0, 0, 0};
+                        emit(10, v, 12);
+                    }
+                    if (near_zero(t_.norm() * 100)) continue;
+                    unsigned num_inliers, num_pts_tested;
+                    evaluate_translation(t_, &num_inliers, &num_pts_tested);
+                    if (num_inliers > best_upgrade_inliers_trans) {
+                        if (num_inliers > best_upgrade_inliers ||
+                            (near_zero(final_model_params_[0] * 100) && near_zero(final_model_params_[4] * 100) && near_zero(final_model_params_[8] * 100))) {
+                            e_from_rt(opengv::rotation_t::Identity(), t_, models_denorm_[0].data());
+                            storeSolution(0, num_inliers);
+                            best_upgrade_inliers = num_inliers;
+                            if (size_noMot > 3) {
+                                unsigned k = 0;
+                                for (size_t j = 0; j < 3; j++) {
+                                    if (degen_sample_noMot[k] == index[1]) {
+                                        j--;
+                                        k++;
+                                        continue;
+                                    }
+                                    min_sample_[j] = degen_sample_noMot[k];
+                                    k++;
+                                }
+                                min_sample_[3] = index[1];
+                                min_sample_[4] = index[0];
+                            }
+                            usac_results_.degen_inlier_count_trans = num_inliers;
+                        }
+                        best_upgrade_inliers_trans = num_inliers;
+                        unsigned untouched = 0;
+                        count = count_on(current_err_array, outlier_indices, poseDegenTheshold, &untouched);
+                        const unsigned num_samples = updateStandardStopping(count, num_outliers - untouched, 1);
+                        if (num_samples < degen_max_upgrade_samples_noMot_trans) degen_max_upgrade_samples_noMot_trans = num_samples;
+                    }
+                }
+            } else {  // rotation -> rotation + translation
+                branch = 2;
+                num_outliers = n - usac_results_.degen_inlier_count_rot;
+                if (num_outliers < 3) return 0;
+                std::vector<unsigned int> outlier_indices(num_outliers);
+                unsigned count = 0;
+                for (unsigned i = 0; i < n; ++i)
+                    if (degen_outlier_flags_rot[i]) outlier_indices[count++] = i;
+                std::vector<unsigned int> outlier_sample(3);
+                std::fill(err_ptr_[0], err_ptr_[0] + n, DBL_MAX);
+                auto current_err_array = err_ptr_[0];
+                opengv::rotation_t R_;
+                opengv::translation_t t_;
+                for (unsigned i = 0; i < degen_max_upgrade_samples_rot; ++i) {
+                    ++tried;
+                    generateUniformRandomSample(num_outliers, 3, &outlier_sample);
+                    std::vector<int> index(5);
+                    for (unsigned j = 0; j < 3; j++) index[j] = (int)outlier_indices[outlier_sample[j]];
+                    index[3] = degen_sample_rot[0];
+                    index[4] = degen_sample_rot[1];
+                    opengv::eigensolverOutput_t eig_out;
+                    adapter_denorm->setR12(R_eigen_degen);
+                    eig_out.rotation = R_eigen_degen;
+                    R_ = opengv::relative_pose::eigensolver(*adapter_denorm, index, eig_out);
+                    t_ = eig_out.translation;
+                    if (g_eigvec_smallest) {  // see the flag: the eigenvector of the SMALLEST eigenvalue, sign by eigensolver's own rule
+                        int k = 0;
+                        for (int q = 1; q < 3; ++q)
+                            if (eig_out.eigenvalues[q] < eig_out.eigenvalues[k]) k = q;
+                        const double a = eig_out.eigenvalues[(k + 1) % 3], b = eig_out.eigenvalues[(k + 2) % 3];
+                        t_ = std::sqrt(a * a + b * b) * eig_out.eigenvectors.col(k);
+                        opengv::bearingVector_t f1 = adapter_denorm->getBearingVector1(index[0]);
+                        opengv::bearingVector_t f2 = R_ * adapter_denorm->getBearingVector2(index[0]);
+                        if ((f1 - f2).dot(t_) < 0.0) t_ = -t_;
+                    }
+                    if (near_zero(t_.norm() * 100)) {
+                        double v[12] = {(double)usac_results_.hyp_count_, 2.0, (double)i, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        emit(10, v, 12);
+                        continue;
+                    }
+                    t_ /= t_.norm();
+                    e_from_rt(R_, t_, models_denorm_[0].data());
+                    {
+                        double v[12] = {(double)usac_results_.hyp_count_, 2.0, (double)i};
+                        for (int k = 0; k < 9; ++k) v[3 + k] = models_denorm_[0][k];
+                        emit(10, v, 12);
+                    }
+                    unsigned num_inliers, num_pts_tested;
+                    evaluateModel(0, &num_inliers, &num_pts_tested);
+                    if (num_inliers > best_upgrade_inliers_rot) {
+                        count = 0;
+                        for (unsigned j = 2; j < 5; j++) degen_sample_rot[j] = index[count++];
+                        if (num_inliers > best_upgrade_inliers ||
+                            (near_zero(final_model_params_[0] * 100) && near_zero(final_model_params_[4] * 100) && near_zero(final_model_params_[8] * 100))) {
+                            storeSolution(0, num_inliers);
+                            best_upgrade_inliers = num_inliers;
+                            for (size_t j = 0; j < 5; j++) min_sample_[j] = (unsigned int)degen_sample_rot[j];
+                        }
+                        best_upgrade_inliers_rot = num_inliers;
+                        unsigned untouched = 0;
+                        count = count_on(current_err_array, outlier_indices, usac_inlier_threshold_, &untouched);
+                        const unsigned num_samples = updateStandardStopping(count, num_outliers - untouched, 1);
+                        if (num_samples < degen_max_upgrade_samples_rot) degen_max_upgrade_samples_rot = num_samples;
+                    }
+                }
+            }
+        }
+        double v[4] = {(double)usac_results_.hyp_count_, (double)branch, (double)tried, (double)best_upgrade_inliers};
+        emit(9, v, 4);
+        return best_upgrade_inliers;
+    }
+
+    void initDegeneracy(double rot_ratio) {
+        const unsigned n = usac_num_data_points_;
+        degeneracyType = DG_NOT_FOUND;
+        degen_max_upgrade_samples_rot = degen_max_upgrade_samples_noMot_trans = 8000;  // usac_estimations.cpp:446
+        degen_final_model_params_rot.assign(9, 0.0);
+        degen_outlier_flags_rot.assign(n, 0), degen_outlier_flags_noMot.assign(n, 0);
+        poseDegenTheshold = 1.0 - std::cos(std::atan(rot_ratio));  // EssentialMatEstimator.h:349
+        R_eigen_degen = opengv::rotation_t::Identity();
+    }
+    unsigned degeneracyType = DG_NOT_FOUND;
+    std::vector<double> degen_final_model_params_rot;
 
     void findWeights(unsigned int modelIndex, const std::vector<unsigned int> &inliers, unsigned int numInliers, double *weights) override {
         if (refineMethod != USACConfig::REFINE_WEIGHTS) return;
@@ -367,6 +720,11 @@ class RefEssential : public USAC<RefEssential> {
     opengv::bearingVectors_t bearing1_, bearing2_;
     std::shared_ptr<opengv::relative_pose::CentralRelativeAdapter> adapter_denorm;
     USACConfig::RefineAlgorithm refineMethod;
+    double poseDegenTheshold = 0;
+    unsigned degen_max_upgrade_samples_rot = 0, degen_max_upgrade_samples_noMot_trans = 0;
+    std::vector<unsigned int> degen_outlier_flags_rot, degen_outlier_flags_noMot;
+    std::vector<int> degen_sample_rot, degen_sample_noMot;
+    opengv::rotation_t R_eigen_degen;
 };
 
 int main(int argc, char **argv) {
@@ -374,6 +732,7 @@ int main(int argc, char **argv) {
     for (int a = 3; a < argc; ++a)
         if (!std::strcmp(argv[a], "--native-order")) g_native_order = true;
         else if (!std::strcmp(argv[a], "--solver-oracle")) g_solver_oracle = true;
+        else if (!std::strcmp(argv[a], "--eigvec-smallest")) g_eigvec_smallest = true;
     FILE *f = fopen(argv[1], "rb");
     if (!f) return 2;
     int32_t ih[8];
@@ -409,8 +768,8 @@ int main(int argc, char **argv) {
     c_com.numDataPoints = n;
     c_com.prevalidateSample = true;
     c_com.prevalidateModel = true;
-    c_com.testDegeneracy = false;
-    c_com.testDegeneracyLOSAC = false;
+    c_com.testDegeneracy = ih[5] != 0;
+    c_com.testDegeneracyLOSAC = (ih[5] & 2) != 0;  // the reference: with the 8-point refinements (usac_estimations.cpp:368-375)
     c_com.randomSamplingMethod = sorted.empty() ? USACConfig::SAMP_UNIFORM : USACConfig::SAMP_PROSAC;
     c_com.verifMethod = USACConfig::VERIF_SPRT;
     c_com.localOptMethod = USACConfig::LO_LOSAC;
@@ -436,6 +795,7 @@ int main(int argc, char **argv) {
     est->initParamsUSAC(cfg);
     est->initDataUSAC(cfg);
     est->initProblem(cfg, pointData.data());
+    if (ih[5]) est->initDegeneracy(dh[7]);
     const bool ok = est->solve();
 
     FILE *out = fopen(argv[2], "wb");
@@ -455,6 +815,15 @@ int main(int argc, char **argv) {
     for (int i = 0; i < n && i < (int)est->pool().size(); ++i) pool[i] = est->pool()[i];
     fwrite(flags.data(), 8, n, out);
     fwrite(pool.data(), 8, n, out);
+    if (ih[5]) {  // degeneracy results: [count_rot, count_noMot, type, 0], R_degenerate[9], n rotation flags, n no-motion flags
+        double dg[4] = {(double)r.degen_inlier_count_rot, (double)r.degen_inlier_count_noMot, (double)est->degeneracyType, 0};
+        fwrite(dg, 8, 4, out);
+        fwrite(est->degen_final_model_params_rot.data(), 8, 9, out);
+        std::vector<double> fr(n, 0.0), fn(n, 0.0);
+        for (int i = 0; i < n; ++i) fr[i] = r.degen_inlier_flags_rot[i], fn[i] = r.degen_inlier_flags_noMot[i];
+        fwrite(fr.data(), 8, n, out);
+        fwrite(fn.data(), 8, n, out);
+    }
     fclose(out);
     return 0;
 }

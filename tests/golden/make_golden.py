@@ -355,10 +355,69 @@ def usac_case():
     print("usac_trace: ok", os.path.getsize(os.path.join(HERE, "usac_trace.npz")), "bytes")
 
 
+def degen_math_case():
+    """Fixture for the host numerics of USAC's degeneracy handling: the reference's vendored OpenGV (twopt_rotationOnly, rotationOnly,
+    twopt, eigensolver) and PoseTools error functions compiled in place (oracle/_ref/opengv_degen) on three scenes -- pure rotation,
+    short baseline, general motion.  The eigensolver rows are kept for what they are: its Levenberg-Marquardt differentiates the
+    gradient by forward differences with a step of 1.5e-8 |x|, so its path follows the rounding noise of the build; the tests use them
+    with that in mind (tests/test_usac_degen_math.py)."""
+    import struct
+    import subprocess
+    import tempfile
+    from matchinglib_poselib_amd import synth
+
+    tool = os.path.join(ROOT, "oracle", "_ref", "opengv_degen")
+    out = {}
+    K, m = 48, 24
+    for s, (name, kw) in enumerate((("rotation", dict(t_len=0.0)), ("shortbase", dict(t_len=0.05)), ("general", {}))):
+        n = 300
+        p1, p2, R, t, truth, th = synth.pose_scene(n, 0.8, seed=50 + s, **kw)
+        rng = np.random.default_rng(70 + s)
+        inl = np.flatnonzero(truth)
+        pairs = np.stack([rng.choice(inl, 2, replace=False) for _ in range(K)]).astype(np.int32)
+        lists = np.stack([rng.choice(inl, m, replace=False) for _ in range(K)]).astype(np.int32)
+        fives = np.stack([rng.choice(inl, 5, replace=False) for _ in range(K)]).astype(np.int32)
+        # start rotations: identity for the first half, the true inverse rotation (view 2 -> view 1 of the adapter) perturbed for the rest
+        Rs = np.tile(np.eye(3).reshape(1, 9), (K, 1))
+        for k in range(K // 2, K):
+            w = rng.normal(0, 0.01, 3)
+            Wx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+            Rs[k] = ((np.eye(3) + Wx) @ R).reshape(9)
+        pts = np.concatenate([p1, p2], 1).astype(np.float64)
+        with tempfile.TemporaryDirectory() as d:
+            fi, fo = os.path.join(d, "i"), os.path.join(d, "o")
+            with open(fi, "wb") as f:
+                f.write(struct.pack("3i", n, K, m))
+                for a in (pts, pairs, lists, fives, Rs):
+                    f.write(np.ascontiguousarray(a).tobytes())
+            subprocess.run([tool, fi, fo], check=True)
+            raw = np.frombuffer(open(fo, "rb").read(), np.float64)
+        o = 0
+
+        def take(c):
+            nonlocal o
+            v = raw[o:o + c].copy()
+            o += c
+            return v
+
+        g = dict(pts=pts, pairs=pairs, lists=lists, fives=fives, Rs=Rs, R2=take(K * 9).reshape(K, 9), Rn=take(K * 9).reshape(K, 9),
+                 t2=take(K * 3).reshape(K, 3))
+        e = take(K * 24).reshape(K, 24)
+        g.update(eigR=e[:, :9], eigD=e[:, 9:12], eigV=e[:, 12:21], eigT=e[:, 21:24], err_rot=take(n), err_nomot=take(n), err_trans=take(n))
+        assert o == len(raw)
+        for k2, v in g.items():
+            out[f"{name}_{k2}"] = v
+        print(f"degen math {name}: twopt_rot det {np.linalg.det(g['R2'][0].reshape(3, 3)):.6f}, rot errors < 5e-7: {(g['err_rot'] < 5e-7).sum()}")
+    np.savez_compressed(os.path.join(HERE, "usac_degen_math.npz"), **out)
+    print("usac_degen_math: ok", os.path.getsize(os.path.join(HERE, "usac_degen_math.npz")), "bytes")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "usac"):
         usac_case()
+    if what in ("all", "degen"):
+        degen_math_case()
     if what in ("all", "eigen"):
         eigen_svd_case()
     if what in ("all", "arrsac"):

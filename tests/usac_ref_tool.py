@@ -18,19 +18,22 @@ def available() -> bool:
 
 
 def run(p1, p2, th, seed, refine=0, sorted_idx=None, max_hyp=50000, prosac_beta=0.09, sprt_delta=0.05, sprt_epsilon=0.15,
-        sprt_ms=8.5, sprt_tm=2314.0, conf=0.99, native_order=False, solver_oracle=False):
-    """Returns dict(events=(k,16) float64, final=(12,), E=(9,), flags=(n,) uint8, pool=(n,) int32)."""
+        sprt_ms=8.5, sprt_tm=2314.0, conf=0.99, native_order=False, solver_oracle=False, check_degeneracy=False, th_pixels=0.8,
+        focal=800.0, eigvec_smallest=False):
+    """Returns dict(events=(k,16) float64, final=(12,), E=(9,), flags=(n,) uint8, pool=(n,) int32); with check_degeneracy also
+    degen=(4,) [inliers of the rotation, of "no motion", degeneracy type, 0], R_degen=(9,), flags_rot, flags_nomot=(n,) uint8."""
     n = len(p1)
     pts = np.concatenate([np.asarray(p1, np.float64), np.asarray(p2, np.float64)], axis=1)
     with tempfile.TemporaryDirectory() as d:
         fi, fo = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
         with open(fi, "wb") as f:
-            f.write(struct.pack("8i", n, int(seed), int(refine), 0 if sorted_idx is None else 1, int(max_hyp), 0, 0, 0))
-            f.write(struct.pack("8d", th, prosac_beta, sprt_delta, sprt_epsilon, sprt_ms, sprt_tm, conf, 0.0))
+            f.write(struct.pack("8i", n, int(seed), int(refine), 0 if sorted_idx is None else 1, int(max_hyp), int(check_degeneracy), 0, 0))
+            f.write(struct.pack("8d", th, prosac_beta, sprt_delta, sprt_epsilon, sprt_ms, sprt_tm, conf, float(th_pixels) / float(focal)))
             f.write(np.ascontiguousarray(pts).tobytes())
             if sorted_idx is not None:
                 f.write(np.ascontiguousarray(sorted_idx, np.uint32).tobytes())
-        subprocess.run([TOOL, fi, fo] + (["--native-order"] if native_order else []) + (["--solver-oracle"] if solver_oracle else []),
+        subprocess.run([TOOL, fi, fo] + (["--native-order"] if native_order else []) + (["--solver-oracle"] if solver_oracle else [])
+                       + (["--eigvec-smallest"] if eigvec_smallest else []),
                        check=True)
         raw = open(fo, "rb").read()
     ne = struct.unpack("i", raw[:4])[0]
@@ -44,4 +47,11 @@ def run(p1, p2, th, seed, refine=0, sorted_idx=None, max_hyp=50000, prosac_beta=
     flags = np.frombuffer(raw, np.float64, n, off).astype(np.uint8)
     off += 8 * n
     pool = np.frombuffer(raw, np.float64, n, off).astype(np.int32)
-    return dict(events=ev, final=fin, E=E, flags=flags, pool=pool)
+    out = dict(events=ev, final=fin, E=E, flags=flags, pool=pool)
+    if check_degeneracy:
+        off += 8 * n
+        out["degen"] = np.frombuffer(raw, np.float64, 4, off).copy()
+        out["R_degen"] = np.frombuffer(raw, np.float64, 9, off + 32).copy()
+        out["flags_rot"] = np.frombuffer(raw, np.float64, n, off + 104).astype(np.uint8)
+        out["flags_nomot"] = np.frombuffer(raw, np.float64, n, off + 104 + 8 * n).astype(np.uint8)
+    return out

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-DEC = {1: [1, 2, 3, 4, 5, 6, 7], 2: [1, 2, 3, 4, 5, 6], 3: [1, 2, 3, 4], 4: [1, 2, 3], 5: [1, 2], 6: [1, 2]}
+DEC = {1: [1, 2, 3, 4, 5, 6, 7], 2: [1, 2, 3, 4, 5, 6], 3: [1, 2, 3, 4], 4: [1, 2, 3], 5: [1, 2], 6: [1, 2],
+       7: [1, 2, 3, 4, 5, 6, 7], 8: [1, 2, 3, 4, 5], 9: [1, 2, 3, 4], 10: [1, 2, 3]}
 
 
 def compare(a, b):
@@ -27,6 +28,15 @@ def compare(a, b):
     d = {}
     sa, sb = a[a[:, 0] == 2], b[b[:, 0] == 2]
     d["sprt"] = float(np.abs(sa[:, 7:11] - sb[:, 7:11]).max()) if len(sa) else 0.0
+    ca, cb = a[a[:, 0] == 10], b[b[:, 0] == 10]
+    for br, width, name in ((1, 3, "t10"), (2, 9, "E10")):  # upgrade candidates: translations (unit) / essential matrices
+        va, vb = ca[ca[:, 2] == br][:, 4:4 + width], cb[cb[:, 2] == br][:, 4:4 + width]
+        keep = (np.linalg.norm(va, axis=1) > 0) & np.isfinite(va).all(1) & np.isfinite(vb).all(1)
+        va, vb = va[keep], vb[keep]
+        if len(va):
+            dd = np.abs(va - vb).max(1)
+            d[name] = float(dd.max())
+            d[name + "_q98"] = float(np.quantile(dd, 0.98))
     for ty, lo in ((3, 5), (5, 3)):
         ea, eb = a[a[:, 0] == ty][:, lo:lo + 9], b[b[:, 0] == ty][:, lo:lo + 9]
         keep = np.linalg.norm(ea, axis=1) > 0
