@@ -281,7 +281,7 @@ struct UsacHistory {  // the function-local statics of estimateEssentialOrPoseUS
     unsigned numhyps = 0, modelcount = 0;
     double avgModels = 6;
 } g_usac_hist;
-std::once_flag g_usac_notice[3];
+std::once_flag g_usac_notice[4];
 }  // namespace
 
 double estimateSprtDeltaInit(const std::vector<cv::DMatch> &matches, const std::vector<cv::KeyPoint> &kp1,
@@ -394,8 +394,11 @@ int estimateEssentialOrPoseUSAC(const cv::Mat &p1, const cv::Mat &p2, cv::Output
         std::cout << "Mothod for checking degeneracy not available!" << std::endl;
         return -1;
     }
-    if (cfg.degeneracyCheck != DEGEN_NO_CHECK)
-        std::call_once(g_usac_notice[2], [] { std::cout << "USAC (MI355X hot-path library): the degeneracy tests are not built; the estimation runs without them." << std::endl; });
+    if (cfg.degeneracyCheck == DEGEN_QDEGSAC)
+        std::call_once(g_usac_notice[2], [] { std::cout << "USAC (MI355X hot-path library): QDEGSAC is not built; the estimation runs without a degeneracy check." << std::endl; });
+    const bool eight_point = cfg.refinealg == REF_WEIGHTS || cfg.refinealg == REF_8PT_PSEUDOHUBER;
+    if (cfg.degeneracyCheck == DEGEN_USAC_INTERNAL && eight_point)
+        std::call_once(g_usac_notice[3], [] { std::cout << "USAC (MI355X hot-path library): the rotation-only / no-motion tests and the model upgrade are built; the homography test the reference adds for the 8-point refinements is not." << std::endl; });
 
     // estimateEssentialMatUsac (usac_estimations.cpp:283-470)
     mlpl_usac_params P;
@@ -411,6 +414,10 @@ int estimateEssentialOrPoseUSAC(const cv::Mat &p1, const cv::Mat &p2, cv::Output
     }
     P.sprt_tM = cfg.estimator == POSE_STEWENIUS ? 2736.0 : 2314.0;
     P.sorted_idx = sortedMatchIdx.empty() ? nullptr : sortedMatchIdx.data();
+    if (cfg.degeneracyCheck == DEGEN_USAC_INTERNAL) {  // usac_estimations.cpp:367-375, 443-456
+        P.check_degeneracy = eight_point ? 3 : 1;
+        P.th_pixels = cfg.th_pixels, P.focal_length = cfg.focalLength;
+    }
     std::vector<double> a((size_t)n * 2), b((size_t)n * 2);
     for (int i = 0; i < n; ++i) {
         a[2 * i] = p1.at<double>(i, 0), a[2 * i + 1] = p1.at<double>(i, 1);
@@ -441,7 +448,38 @@ int estimateEssentialOrPoseUSAC(const cv::Mat &p1, const cv::Mat &p2, cv::Output
     isDegenerate = false;
     if (R.needed()) R.release();  // :2036-2042: only Kneip's eigensolver delivers R, t
     if (t.needed()) t.release();
-    (void)R_degenerate, (void)inliers_degenerate_R;
+    if (P.check_degeneracy) {  // the decision of DEGEN_USAC_INTERNAL (:2101-2133) on what estimateEssentialMatUsac reports (:564-636)
+        double info[16];
+        std::vector<uint8_t> fr((size_t)std::max(n, 1)), fn((size_t)std::max(n, 1));
+        if (mlpl_usac_last_degeneracy(default_ctx(), info, fr.data(), fn.data(), n) != MLPL_OK)
+            throw cv::Exception(std::string("estimateEssentialOrPoseUSAC: ") + mlpl_last_error());
+        const double nrInliers = res[5], fraction_inliers = nrInliers / (double)n;
+        const double fraction_R = info[1] > 2 ? (nrInliers > 0 ? info[1] / nrInliers : 0.0) : 0.0;
+        const double fraction_noMot = info[2] > 1 ? (nrInliers > 0 ? info[2] / nrInliers : 0.0) : 0.0;
+        auto put_mask = [&](const std::vector<uint8_t> &f) {
+            if (!inliers_degenerate_R.needed()) return;
+            inliers_degenerate_R.create(1, n, CV_8U);
+            cv::Mat mm = inliers_degenerate_R.getMat();
+            std::memcpy(mm.ptr<uint8_t>(0), f.data(), (size_t)n);
+        };
+        if (cfg.degenDecisionTh * fraction_inliers < fraction_R) {
+            isDegenerate = true;
+            if (R_degenerate.needed() && info[1] > 2) {
+                R_degenerate.create(3, 3, CV_64F);
+                cv::Mat Rm = R_degenerate.getMat();
+                for (int i = 0; i < 9; ++i) Rm.at<double>(i / 3, i % 3) = info[4 + i];
+            }
+            put_mask(fr);
+        } else if (cfg.degenDecisionTh * fraction_inliers < fraction_noMot) {
+            isDegenerate = true;
+            if (R_degenerate.needed()) {
+                R_degenerate.create(3, 3, CV_64F);
+                cv::Mat Rm = R_degenerate.getMat();
+                for (int i = 0; i < 9; ++i) Rm.at<double>(i / 3, i % 3) = (i % 4 == 0) ? 1.0 : 0.0;
+            }
+            put_mask(fn);
+        }
+    }
 
     // the carried-over statistics (:2201-2224)
     H.sprt_delta_old = H.sprt_delta_new;

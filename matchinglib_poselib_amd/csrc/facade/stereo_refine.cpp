@@ -360,7 +360,7 @@ int StereoRefine::Impl::robustPoseEstimation() {
             std::cout << "Estimation of essential matrix using USAC failed!" << std::endl;
             return -1;
         }
-        if (isDegenerate) return -2;  // (:1400-1411; the degeneracy tests are not built: never taken)
+        if (isDegenerate) return -2;  // :1400-1411: "Camera configuration is degenerate and, thus, rotation only. Skipping further calculations!"
     } else if (!estimateEssentialMat(E, P1, P2, method, th, cfg_pose.refineRTold, mask)) {
         std::cout << "Estimation of essential matrix using " << method << " failed!" << std::endl;
         return -1;
