@@ -15,6 +15,11 @@
  *   - ARRSAC (arrsac_oracle.cpp): Eigen::JacobiSVD<Matrix3d> pinned against the Eigen 3.2.0 the reference vendors (oracle/_ref/eigen_svd3,
  *     tests/golden/eigen_svd3.npz); cv::RNG, cv::findFundamentalMat(FM_8POINT), Eigen::EigenSolver restated, unpinned; the sign and the
  *     order of the 5-point solutions are fixed by convention (artefacts of cv::SVD's null-space basis, see that file's header).
+ *   - USAC (usac_oracle.cpp): control flow pinned by the reference's own USAC.h compiled in place (oracle/_ref/usac_ref).  USAC's
+ *     degeneracy handling (testSolutionDegeneracyRot / NoMot, upgradeDegenerateModel) is NOT restated in usac_oracle.cpp: its CPU checker
+ *     is the reference-built driver itself (oracle/ref_drivers/usac_ref.cpp restates those estimator members over the reference's own
+ *     OpenGV and PoseTools functions) with the fixtures it generates (tests/golden/usac_degen_trace.npz), and
+ *     oracle/ref_drivers/opengv_degen.cpp for the 3 x 3 numerics (tests/golden/usac_degen_math.npz).
  *   - The arithmetic of cvflann::LinearIndex / cv::SVD / cv::solvePoly / cv::triangulatePoints lives in
  *     OpenCV 4.2.0 (pinned in ci/make_opencv.sh:6), which is NOT vendored under /root/reference and is
  *     not installed here; those steps restate the published algorithms and are "parity unpinned" at
