@@ -15,11 +15,10 @@
  *   - ARRSAC (arrsac_oracle.cpp): Eigen::JacobiSVD<Matrix3d> pinned against the Eigen 3.2.0 the reference vendors (oracle/_ref/eigen_svd3,
  *     tests/golden/eigen_svd3.npz); cv::RNG, cv::findFundamentalMat(FM_8POINT), Eigen::EigenSolver restated, unpinned; the sign and the
  *     order of the 5-point solutions are fixed by convention (artefacts of cv::SVD's null-space basis, see that file's header).
- *   - USAC (usac_oracle.cpp): control flow pinned by the reference's own USAC.h compiled in place (oracle/_ref/usac_ref).  USAC's
- *     degeneracy handling (testSolutionDegeneracyRot / NoMot, upgradeDegenerateModel) is NOT restated in usac_oracle.cpp: its CPU checker
- *     is the reference-built driver itself (oracle/ref_drivers/usac_ref.cpp restates those estimator members over the reference's own
- *     OpenGV and PoseTools functions) with the fixtures it generates (tests/golden/usac_degen_trace.npz), and
- *     oracle/ref_drivers/opengv_degen.cpp for the 3 x 3 numerics (tests/golden/usac_degen_math.npz).
+ *   - USAC (usac_oracle.cpp): control flow pinned by the reference's own USAC.h compiled in place (oracle/_ref/usac_ref), incl. the
+ *     degeneracy handling (testSolutionDegeneracyRot / NoMot, upgradeDegenerateModel: oracle_usac_essential_degen), whose driver runs
+ *     the restated estimator members over the reference's own OpenGV and PoseTools functions (tests/golden/usac_degen_trace.npz);
+ *     oracle/ref_drivers/opengv_degen.cpp pins the 3 x 3 numerics one function at a time (tests/golden/usac_degen_math.npz).
  *   - The arithmetic of cvflann::LinearIndex / cv::SVD / cv::solvePoly / cv::triangulatePoints lives in
  *     OpenCV 4.2.0 (pinned in ci/make_opencv.sh:6), which is NOT vendored under /root/reference and is
  *     not installed here; those steps restate the published algorithms and are "parity unpinned" at
@@ -195,6 +194,16 @@ int oracle_arrsac_trace(int32_t *buf, int cap);
 int oracle_usac_essential(const double *p1, const double *p2, int n, double th, unsigned seed, int refine, const uint32_t *sorted_idx,
                           int max_hyp, double conf, double prosac_beta, double sprt_delta, double sprt_epsilon, double sprt_mS,
                           double sprt_tM, double *E, uint8_t *inlier_flags, double *results, double *events, int event_cap, int *n_events);
+
+/* The same with the degeneracy handling of ConfigUSAC's DEGEN_USAC_INTERNAL (EssentialMatEstimator.h:1334-1362, 1511-1663, 1838-1911,
+ * 2098-2361; no homography test): check_degeneracy 1 = after every new best model, 3 = also after every local optimisation; additional
+ * event types 7 degeneracy test, 8 rotation on all correspondences, 9 upgrade, 10 upgrade candidate (oracle/ref_drivers/usac_ref.cpp);
+ * degen[16] = {1, inliers of the rotation-only model, of "no motion", degeneracy type, R_degenerate[9]}. */
+int oracle_usac_essential_degen(const double *p1, const double *p2, int n, double th, unsigned seed, int refine, const uint32_t *sorted_idx,
+                                int max_hyp, double conf, double prosac_beta, double sprt_delta, double sprt_epsilon, double sprt_mS,
+                                double sprt_tM, int check_degeneracy, double th_pixels, double focal_length, double *E,
+                                uint8_t *inlier_flags, double *results, double *events, int event_cap, int *n_events, double *degen,
+                                uint8_t *flags_rot, uint8_t *flags_nomot);
 
 #ifdef __cplusplus
 }

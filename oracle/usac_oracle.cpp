@@ -13,6 +13,18 @@
 //                                                PROSAC 1000 samples, stop length 20, 0.99) and srand(seed) before the pool shuffle
 //   source/usac/utils/FundmatrixFunctions.cpp    normalizePoints :7-62, computeDataMatrix :64-88, formCovMat :312-332, singulF :334-361,
 //                                                computeEpipole :363-373, getOriSign :375-381
+//   include/usac/estimators/EssentialMatEstimator.h   with check_degeneracy: testSolutionDegeneracy :1334-1362, testSolutionDegeneracyRot
+//                                                :1511-1663, testSolutionDegeneracyNoMot :1838-1911, evaluateModelTrans :1264-1327,
+//                                                upgradeDegenerateModel :1917-2365 (its two pose branches), as configured by
+//                                                usac_estimations.cpp:367-375, 443-456 without the homography test
+//   source/usac/utils/PoseFunctions.cpp          getRotError :43-70, getNoMotError :118-141
+//   thirdparty/opengv/src/                       relative_pose/methods.cpp twopt :57-86, twopt_rotationOnly :98-122, rotationOnly :128-160,
+//                                                eigensolver :496-551; math/arun.cpp :33-56; triangulation/methods.cpp triangulate2 :94-117
+// The degeneracy part is pinned by oracle/_ref/usac_ref with check_degeneracy (tests/golden/usac_degen_trace.npz).  Its eigensolver is
+// restated as what it computes, not how: a damped Newton iteration on the smallest eigenvalue of M(R) (Jacobi eigenvalues, central
+// differences) from the same start rotation.  OpenGV's own Levenberg-Marquardt follows the rounding noise of its forward-difference
+// Jacobian (tests/test_usac_degen_math.py), so no restatement can follow it step by step; translation = eigenvector of the smallest
+// eigenvalue (usac_ref --eigvec-smallest explains the deviation from OpenGV's column 0).
 //
 // Pinned by oracle/_ref/usac_ref: the reference's USAC.h + usac/utils + vendored OpenGV compiled in place, turn by turn
 // (tests/golden/usac_trace.npz).  What is restated from published algorithms rather than compiled from the reference: the smallest
@@ -569,6 +581,420 @@ struct Usac {
         return lo_inliers;
     }
 
+
+    // ---- degeneracy tests and model upgrade --------------------------------------------------------------------------------------
+    enum { DG_NOT_FOUND = 0x1, DG_H = 0x2, DG_ROT_TRANS = 0x4, DG_NO_MOT = 0x8, DG_UPGRADE = 0x10 };
+    int check_degeneracy = 0;  // 0 off, 1 after every new best model, 3 also after every local optimisation
+    double dg_thr = 0;         // poseDegenTheshold = 1 - cos atan(th_pixels / focal length)
+    unsigned dg_type = DG_NOT_FOUND, cnt_rot = 0, cnt_nomot = 0, cnt_trans = 0, max_up_rot = 8000, max_up_nomot = 8000;
+    std::vector<unsigned> in_rot, out_rot, in_nomot, out_nomot;
+    std::vector<int> sample_rot, sample_nomot;
+    double R_degen[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    std::vector<double> v1, v2;  // bearing vectors: adapter view 1 = second image, view 2 = first image (:289-291)
+
+    static bool near_zero(double d) { return (d < 1e-3) && (d > -1e-3); }
+    static double dot3(const double *a, const double *b) { return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); }
+    static void cross3(const double *a, const double *b, double *o) {
+        o[0] = a[1] * b[2] - a[2] * b[1], o[1] = a[2] * b[0] - a[0] * b[2], o[2] = a[0] * b[1] - a[1] * b[0];
+    }
+    void init_degeneracy() {
+        v1.resize((size_t)3 * n), v2.resize((size_t)3 * n);
+        for (unsigned i = 0; i < n; ++i) {
+            const double a[3] = {p2[2 * i], p2[2 * i + 1], 1.0}, b[3] = {p1[2 * i], p1[2 * i + 1], 1.0};
+            const double na = sqrt(a[0] * a[0] + (a[1] * a[1] + a[2] * a[2])), nb = sqrt(b[0] * b[0] + (b[1] * b[1] + b[2] * b[2]));
+            for (int k = 0; k < 3; ++k) v1[3 * i + k] = a[k] / na, v2[3 * i + k] = b[k] / nb;
+        }
+        in_rot.assign(n, 0), out_rot.assign(n, 0), in_nomot.assign(n, 0), out_nomot.assign(n, 0);
+    }
+    double rot_error(const double *R, unsigned i) const {
+        const double *f2 = &v2[3 * i];
+        double u[3];
+        for (int r = 0; r < 3; ++r) u[r] = (R[3 * r] * f2[0] + R[3 * r + 1] * f2[1]) + R[3 * r + 2] * f2[2];
+        return 1.0 - dot3(&v1[3 * i], u);
+    }
+    double nomot_error(unsigned i) const { return 1.0 - dot3(&v1[3 * i], &v2[3 * i]); }
+    double trans_error(const double *t, unsigned i) const {  // evaluateModelTrans: midpoint triangulation under (I, t), both reprojections
+        const double *f1 = &v1[3 * i], *f2 = &v2[3 * i];
+        const double b0 = dot3(t, f1), b1 = dot3(t, f2);
+        const double a00 = dot3(f1, f1), a10 = dot3(f1, f2), a01 = -a10, a11 = -dot3(f2, f2);
+        const double invdet = 1.0 / (a00 * a11 - a10 * a01);
+        const double l0 = (a11 * invdet) * b0 + (-a01 * invdet) * b1, l1 = (-a10 * invdet) * b0 + (a00 * invdet) * b1;
+        double pt[3], q[3];
+        for (int k = 0; k < 3; ++k) pt[k] = ((l0 * f1[k]) + (t[k] + l1 * f2[k])) / 2, q[k] = pt[k] + (-t[k]);
+        const double n1 = sqrt(pt[0] * pt[0] + (pt[1] * pt[1] + pt[2] * pt[2])), n2 = sqrt(q[0] * q[0] + (q[1] * q[1] + q[2] * q[2]));
+        for (int k = 0; k < 3; ++k) pt[k] = pt[k] / n1, q[k] = q[k] / n2;
+        return (1.0 - dot3(f1, pt)) + (1.0 - dot3(f2, q));
+    }
+    static void arun(const double *H, double *R) {  // math/arun.cpp: V U^T, third column of V negated when the determinant is -1
+        double sv[3], U[9], V[9];
+        oracle_eigen_svd3(H, sv, U, V);
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) R[3 * r + c] = V[3 * r] * U[3 * c] + V[3 * r + 1] * U[3 * c + 1] + V[3 * r + 2] * U[3 * c + 2];
+            const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+            if (det >= 0) break;
+            for (int r = 0; r < 3; ++r) V[3 * r + 2] = -V[3 * r + 2];
+        }
+    }
+    void cross_cov(const std::vector<int> &idx, const double *c1, const double *c2, double *H) const {
+        std::memset(H, 0, 72);
+        for (int i : idx)
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) H[3 * r + c] += (v2[3 * i + r] - c2[r]) * (v1[3 * i + c] - c1[c]);
+    }
+    void twopt_rotation(int i0, int i1, double *R) const {
+        double c1[3], c2[3], H[9];
+        for (int k = 0; k < 3; ++k) c1[k] = (v1[3 * i0 + k] + v1[3 * i1 + k]) / 3.0, c2[k] = (v2[3 * i0 + k] + v2[3 * i1 + k]) / 3.0;
+        cross_cov({i0, i1}, c1, c2, H);
+        arun(H, R);
+    }
+    void rotation_only(const std::vector<int> &idx, double *R) const {
+        double c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0}, H[9];
+        for (int i : idx)
+            for (int k = 0; k < 3; ++k) c1[k] += v1[3 * i + k], c2[k] += v2[3 * i + k];
+        for (int k = 0; k < 3; ++k) c1[k] = c1[k] / (double)idx.size(), c2[k] = c2[k] / (double)idx.size();
+        cross_cov(idx, c1, c2, H);
+        arun(H, R);
+    }
+    void twopt_translation(int i0, int i1, double *t) const {
+        double n1[3], n2[3];
+        cross3(&v1[3 * i0], &v2[3 * i0], n1), cross3(&v1[3 * i1], &v2[3 * i1], n2);
+        cross3(n1, n2, t);
+        const double nrm = sqrt(t[0] * t[0] + (t[1] * t[1] + t[2] * t[2]));
+        double flow[3];
+        for (int k = 0; k < 3; ++k) t[k] = t[k] / nrm, flow[k] = v1[3 * i0 + k] - v2[3 * i0 + k];
+        if (dot3(flow, t) < 0)
+            for (int k = 0; k < 3; ++k) t[k] = -t[k];
+    }
+    // the eigensolver's objective from its definition: M(c) = sum (f1 x R f2)(f1 x R f2)^T, R = (1 + |c|^2) x the Cayley rotation
+    static void cayley_unscaled(const double *c, double *R) {
+        R[0] = 1 + c[0] * c[0] - c[1] * c[1] - c[2] * c[2], R[1] = 2 * (c[0] * c[1] - c[2]), R[2] = 2 * (c[0] * c[2] + c[1]);
+        R[3] = 2 * (c[0] * c[1] + c[2]), R[4] = 1 - c[0] * c[0] + c[1] * c[1] - c[2] * c[2], R[5] = 2 * (c[1] * c[2] - c[0]);
+        R[6] = 2 * (c[0] * c[2] - c[1]), R[7] = 2 * (c[1] * c[2] + c[0]), R[8] = 1 - c[0] * c[0] - c[1] * c[1] + c[2] * c[2];
+    }
+    void compose_M(const int *idx, const double *c, double *M) const {
+        double R[9];
+        cayley_unscaled(c, R);
+        std::memset(M, 0, 72);
+        for (int k = 0; k < 5; ++k) {
+            const double *f1 = &v1[3 * idx[k]], *f2 = &v2[3 * idx[k]];
+            double u[3], nv[3];
+            for (int r = 0; r < 3; ++r) u[r] = R[3 * r] * f2[0] + R[3 * r + 1] * f2[1] + R[3 * r + 2] * f2[2];
+            cross3(f1, u, nv);
+            for (int r = 0; r < 3; ++r)
+                for (int q = 0; q < 3; ++q) M[3 * r + q] += nv[r] * nv[q];
+        }
+    }
+    static void sym_eig3(const double *M, double *w, double *V) {  // ascending eigenvalues, V columns (via the singular pairs of a PSD matrix)
+        double s[3], Vv[9];
+        oracle_jacobi_svd(M, 3, 3, s, Vv);
+        for (int k = 0; k < 3; ++k) {
+            w[k] = s[2 - k];
+            for (int r = 0; r < 3; ++r) V[3 * r + k] = Vv[3 * r + (2 - k)];
+        }
+    }
+    double lambda_min(const int *idx, const double *c) const {
+        double M[9], w[3], V[9];
+        compose_M(idx, c, M);
+        sym_eig3(M, w, V);
+        return w[0];
+    }
+    void eigensolver(const int *idx, const double *R0, double *R, double *t) const {
+        // start: Cayley parameters of R0, C = (R0 - I)(R0 + I)^-1
+        double A[9], B[9], Bi[9], c[3];
+        for (int k = 0; k < 9; ++k) A[k] = R0[k] - (k % 4 == 0), B[k] = R0[k] + (k % 4 == 0);
+        const double det = B[0] * (B[4] * B[8] - B[5] * B[7]) - B[1] * (B[3] * B[8] - B[5] * B[6]) + B[2] * (B[3] * B[7] - B[4] * B[6]);
+        Bi[0] = (B[4] * B[8] - B[5] * B[7]) / det, Bi[1] = (B[2] * B[7] - B[1] * B[8]) / det, Bi[2] = (B[1] * B[5] - B[2] * B[4]) / det;
+        Bi[3] = (B[5] * B[6] - B[3] * B[8]) / det, Bi[4] = (B[0] * B[8] - B[2] * B[6]) / det, Bi[5] = (B[2] * B[3] - B[0] * B[5]) / det;
+        Bi[6] = (B[3] * B[7] - B[4] * B[6]) / det, Bi[7] = (B[1] * B[6] - B[0] * B[7]) / det, Bi[8] = (B[0] * B[4] - B[1] * B[3]) / det;
+        auto Cm = [&](int r, int k) { return A[3 * r] * Bi[k] + A[3 * r + 1] * Bi[3 + k] + A[3 * r + 2] * Bi[6 + k]; };
+        c[0] = -Cm(1, 2), c[1] = Cm(0, 2), c[2] = -Cm(0, 1);
+        // damped Newton on lambda_min with central differences (gradient h = 1e-6, Hessian from gradient differences)
+        auto grad = [&](const double *x, double *g) {
+            for (int k = 0; k < 3; ++k) {
+                double a[3] = {x[0], x[1], x[2]}, b[3] = {x[0], x[1], x[2]};
+                a[k] += 1e-6, b[k] -= 1e-6;
+                g[k] = (lambda_min(idx, a) - lambda_min(idx, b)) / 2e-6;
+            }
+        };
+        double f = lambda_min(idx, c), mu = 1e-9;
+        for (int it = 0; it < 40; ++it) {
+            double g[3], Hs[9];
+            grad(c, g);
+            for (int k = 0; k < 3; ++k) {
+                double a[3] = {c[0], c[1], c[2]}, b[3] = {c[0], c[1], c[2]}, ga[3], gb[3];
+                a[k] += 1e-4, b[k] -= 1e-4;
+                grad(a, ga), grad(b, gb);
+                for (int r = 0; r < 3; ++r) Hs[3 * r + k] = (ga[r] - gb[r]) / 2e-4;
+            }
+            bool moved = false;
+            for (int tries = 0; tries < 12 && !moved; ++tries) {
+                double Hd[9], step[3];
+                for (int k = 0; k < 9; ++k) Hd[k] = 0.5 * (Hs[k] + Hs[3 * (k % 3) + k / 3]) + (k % 4 == 0 ? mu : 0.0);
+                const double d = Hd[0] * (Hd[4] * Hd[8] - Hd[5] * Hd[7]) - Hd[1] * (Hd[3] * Hd[8] - Hd[5] * Hd[6]) + Hd[2] * (Hd[3] * Hd[7] - Hd[4] * Hd[6]);
+                if (d != 0 && std::isfinite(d)) {
+                    step[0] = ((Hd[4] * Hd[8] - Hd[5] * Hd[7]) * g[0] + (Hd[2] * Hd[7] - Hd[1] * Hd[8]) * g[1] + (Hd[1] * Hd[5] - Hd[2] * Hd[4]) * g[2]) / d;
+                    step[1] = ((Hd[5] * Hd[6] - Hd[3] * Hd[8]) * g[0] + (Hd[0] * Hd[8] - Hd[2] * Hd[6]) * g[1] + (Hd[2] * Hd[3] - Hd[0] * Hd[5]) * g[2]) / d;
+                    step[2] = ((Hd[3] * Hd[7] - Hd[4] * Hd[6]) * g[0] + (Hd[1] * Hd[6] - Hd[0] * Hd[7]) * g[1] + (Hd[0] * Hd[4] - Hd[1] * Hd[3]) * g[2]) / d;
+                    const double x[3] = {c[0] - step[0], c[1] - step[1], c[2] - step[2]};
+                    const double fx = lambda_min(idx, x);
+                    if (fx <= f && std::isfinite(fx)) {
+                        moved = fabs(step[0]) + fabs(step[1]) + fabs(step[2]) > 1e-13;
+                        f = fx, c[0] = x[0], c[1] = x[1], c[2] = x[2];
+                        mu = std::max(mu / 10, 1e-12);
+                        if (!moved) break;
+                        continue;
+                    }
+                }
+                mu *= 10;
+            }
+            if (!moved) break;
+        }
+        double Rr[9], M[9], w[3], V[9];
+        cayley_unscaled(c, Rr);
+        const double scale = 1 + c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+        for (int k = 0; k < 9; ++k) R[k] = Rr[k] / scale;
+        compose_M(idx, c, M);
+        sym_eig3(M, w, V);
+        const double mag = sqrt(w[1] * w[1] + w[2] * w[2]);
+        for (int k = 0; k < 3; ++k) t[k] = mag * V[3 * k];
+        const double *f1 = &v1[3 * idx[0]], *f2 = &v2[3 * idx[0]];
+        double flow[3];
+        for (int r = 0; r < 3; ++r) flow[r] = f1[r] - (R[3 * r] * f2[0] + R[3 * r + 1] * f2[1] + R[3 * r + 2] * f2[2]);
+        if (flow[0] * t[0] + flow[1] * t[1] + flow[2] * t[2] < 0)
+            for (int k = 0; k < 3; ++k) t[k] = -t[k];
+    }
+    static void e_from_rt(const double *R, const double *t, double *E) {  // poselib::getEfromRT
+        const double s = 1.0 / sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+        const double a = t[0] * s, b = t[1] * s, c = t[2] * s;
+        const double Sk[9] = {0, -c, b, c, 0, -a, -b, a, 0};
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 3; ++k) {
+                double acc = 0;
+                for (int m = 0; m < 3; ++m) acc += Sk[3 * r + m] * R[3 * m + k];
+                E[3 * r + k] = acc;
+            }
+    }
+
+    void test_rotation(bool *degenerate) {
+        static const unsigned pair_of[20] = {0, 1, 0, 2, 0, 3, 0, 4, 1, 2, 1, 3, 1, 4, 2, 3, 2, 4, 3, 4};
+        static const unsigned rest_of[30] = {2, 3, 4, 1, 3, 4, 1, 2, 4, 1, 2, 3, 0, 3, 4, 0, 2, 4, 0, 2, 3, 0, 1, 4, 0, 1, 3, 0, 1, 2};
+        std::vector<int> sample(5, 0), inl;
+        std::vector<double> e(n);
+        double R[9];
+        for (unsigned i = 0; i < 10; ++i) {
+            for (unsigned j = 0; j < 2; ++j) sample[j] = (int)min_sample[pair_of[2 * i + j]];
+            twopt_rotation(sample[0], sample[1], R);
+            unsigned count1 = 2, num = 0;
+            for (unsigned j = 0; j < 3; ++j) {
+                const unsigned idx = min_sample[rest_of[3 * i + j]];
+                if (rot_error(R, idx) < dg_thr) sample[count1++] = (int)idx, ++num;
+            }
+            if (num == 0) continue;
+            num = 0;
+            for (unsigned j = 0; j < n; ++j) {
+                e[j] = rot_error(R, pool[j]);
+                if (e[j] < dg_thr) ++num;
+            }
+            const unsigned first_count = num;
+            if (num < 2) continue;
+            inl.clear();
+            for (unsigned j = 0; j < n; ++j)
+                if (e[j] < dg_thr) {
+                    inl.push_back((int)pool[j]);
+                    if (count1 < 5) sample[count1++] = (int)pool[j];
+                }
+            rotation_only(inl, R);
+            num = 0;
+            for (unsigned j = 0; j < n; ++j) {
+                e[j] = rot_error(R, pool[j]);
+                if (e[j] < dg_thr) ++num;
+            }
+            double v[5] = {(double)hyp_count, (double)i, (double)first_count, (double)num, 0};
+            if (num < best / 5) {
+                emit(8, v, 5);
+                continue;
+            }
+            *degenerate = true;
+            if (dg_type != (dg_type & (DG_UPGRADE | DG_ROT_TRANS))) dg_type = DG_ROT_TRANS;
+            if (num > cnt_rot) {
+                dg_type |= DG_UPGRADE;
+                inl.clear();
+                for (unsigned j = 0; j < n; ++j)
+                    if (e[j] < dg_thr) inl.push_back((int)pool[j]);
+                rotation_only(inl, R_degen);
+                cnt_rot = num;
+                for (unsigned j = 0; j < n; ++j) in_rot[pool[j]] = e[j] < dg_thr ? 1 : 0, out_rot[pool[j]] = e[j] < dg_thr ? 0 : 1;
+                sample_rot = sample;
+                v[4] = 1;
+            }
+            emit(8, v, 5);
+        }
+    }
+    void test_no_motion(bool *degenerate) {
+        if (cnt_nomot > 0) return;
+        sample_nomot.clear();
+        unsigned num = 0;
+        for (unsigned j = 0; j < 5; ++j)
+            if (nomot_error(min_sample[j]) < dg_thr) sample_nomot.push_back((int)min_sample[j]), ++num;
+        if (num == 0) return;
+        std::vector<double> e(n);
+        num = 0;
+        for (unsigned j = 0; j < n; ++j) {
+            e[j] = nomot_error(pool[j]);
+            if (e[j] < dg_thr) ++num;
+        }
+        if (num < best / 5) return;
+        *degenerate = true;
+        const bool dominant = (double)num > 0.7 * (double)cnt_rot;
+        if (dominant)
+            if (dg_type != (dg_type & (DG_UPGRADE | DG_NO_MOT))) dg_type = DG_NO_MOT;
+        if (num > cnt_nomot) {
+            if (dominant) dg_type |= DG_UPGRADE;
+            cnt_nomot = num;
+            for (unsigned j = 0; j < n; ++j) {
+                const bool in = e[j] < dg_thr;
+                in_nomot[pool[j]] = in ? 1 : 0, out_nomot[pool[j]] = in ? 0 : 1;
+                if (in && sample_nomot.size() < 5) sample_nomot.push_back((int)pool[j]);
+            }
+        }
+    }
+    void test_degeneracy(bool *degenerate, bool *upgrade) {
+        *degenerate = false, *upgrade = false;
+        dg_type = DG_H;
+        test_rotation(degenerate);
+        if (dg_type & DG_UPGRADE) *upgrade = true;
+        if (dg_type == (unsigned)(DG_ROT_TRANS | DG_UPGRADE)) test_no_motion(degenerate);
+        double v[7] = {(double)hyp_count, *degenerate ? 1.0 : 0.0, *upgrade ? 1.0 : 0.0, (double)dg_type, (double)cnt_rot, (double)cnt_nomot, (double)best};
+        emit(7, v, 7);
+    }
+    bool evaluate_translation(const double *t, unsigned *num_inl, unsigned *tested) {
+        double *err = errs[cur].data();
+        bool good = true;
+        double lj, lj1 = 1.0;
+        *num_inl = 0, *tested = 0;
+        const unsigned start = pool_index;
+        for (unsigned i = 0; i < n; ++i) {
+            if (pool_index > n - 1) pool_index = 0;
+            const unsigned pt = pool[pool_index];
+            ++pool_index;
+            const double e = trans_error(t, pt);
+            err[pt] = e;
+            if (e < dg_thr) ++(*num_inl);
+            lj = e < dg_thr ? lj1 * (sprt_delta / sprt_epsilon) : lj1 * ((1 - sprt_delta) / (1 - sprt_epsilon));
+            if (lj <= DBL_EPSILON) lj = DBL_EPSILON * 10;
+            if (lj > sprt_A) {
+                good = false;
+                *tested = i + 1;
+                break;
+            }
+            lj1 = lj;
+        }
+        if (good) *tested = n;
+        double v[11] = {(double)hyp_count, -1.0, (double)start, (double)*num_inl, (double)*tested, good ? 1.0 : 0.0,
+                        sprt_delta, sprt_epsilon, sprt_A, dg_thr, (double)num_lo};
+        emit(2, v, 11);
+        return good;
+    }
+    unsigned stopping_on(const std::vector<double> &err, const std::vector<unsigned> &idx, double limit, unsigned num_outliers) const {
+        unsigned c = 0, untouched = 0;
+        for (unsigned j : idx) {
+            if (err[j] < limit)
+                ++c;
+            else if (std::round(err[j] - DBL_MAX) == 0)
+                ++untouched;
+        }
+        return standard_stopping(c, num_outliers - untouched, 1);
+    }
+    unsigned upgrade_model() {
+        unsigned best_up = best, best_up_rot = cnt_rot, best_up_trans = cnt_trans;
+        if (n < 2) return 0;
+        unsigned tried = 0, branch = 0;
+        if (dg_type & DG_UPGRADE) {
+            const bool nomot = (dg_type & DG_NO_MOT) != 0;
+            branch = nomot ? 1 : 2;
+            const unsigned num_outliers = n - (nomot ? cnt_nomot : cnt_rot);
+            if (num_outliers < (nomot ? 1u : 3u)) return 0;
+            std::vector<unsigned> outlier_indices(num_outliers, 0), smp(nomot ? 1 : 3);
+            unsigned c = 0;
+            for (unsigned i = 0; i < n; ++i)
+                if ((nomot ? out_nomot : out_rot)[i]) outlier_indices[c++] = i;
+            std::fill(errs[cur].begin(), errs[cur].end(), DBL_MAX);
+            const int counted = cur;  // current_err_array: a pointer, it does not follow the swaps of storeSolution
+            unsigned &limit = nomot ? max_up_nomot : max_up_rot;
+            const unsigned size_nomot = (unsigned)sample_nomot.size();
+            for (unsigned i = 0; i < limit; ++i) {
+                ++tried;
+                uniform_sample(num_outliers, nomot ? 1 : 3, smp);
+                int index[5];
+                double E[9], t[3], R[9];
+                unsigned num = 0, tested = 0;
+                if (nomot) {
+                    index[0] = (int)outlier_indices[smp[0]];
+                    index[1] = sample_nomot[(unsigned)oracle_rand(&rng) % size_nomot];
+                    twopt_translation(index[0], index[1], t);
+                    double v[12] = {(double)hyp_count, 1.0, (double)i, t[0], t[1], t[2]};
+                    emit(10, v, 12);
+                    if (near_zero(sqrt(t[0] * t[0] + (t[1] * t[1] + t[2] * t[2])) * 100)) continue;
+                    evaluate_translation(t, &num, &tested);
+                } else {
+                    for (int j = 0; j < 3; ++j) index[j] = (int)outlier_indices[smp[j]];
+                    index[3] = sample_rot[0], index[4] = sample_rot[1];
+                    eigensolver(index, R_degen, R, t);
+                    const double len = sqrt(t[0] * t[0] + (t[1] * t[1] + t[2] * t[2]));
+                    double v[12] = {(double)hyp_count, 2.0, (double)i};
+                    if (near_zero(len * 100)) {
+                        emit(10, v, 12);
+                        continue;
+                    }
+                    for (int k = 0; k < 3; ++k) t[k] = t[k] / len;
+                    e_from_rt(R, t, E);
+                    std::memcpy(v + 3, E, 72);
+                    emit(10, v, 12);
+                    set_model(0, E);
+                    evaluate(0, &num, &tested);
+                }
+                if (num > (nomot ? best_up_trans : best_up_rot)) {
+                    if (!nomot)
+                        for (int j = 2, q = 0; j < 5; ++j) sample_rot[j] = index[q++];
+                    if (num > best_up || (near_zero(final_model[0] * 100) && near_zero(final_model[4] * 100) && near_zero(final_model[8] * 100))) {
+                        if (nomot) {
+                            const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+                            e_from_rt(I3, t, E);
+                            set_model(0, E);
+                        }
+                        store_solution(0, num);
+                        best_up = num;
+                        if (nomot) {
+                            if (size_nomot > 3) {
+                                unsigned k = 0;
+                                for (size_t j = 0; j < 3; j++) {
+                                    if (sample_nomot[k] == index[1]) {
+                                        j--;
+                                        k++;
+                                        continue;
+                                    }
+                                    min_sample[j] = (unsigned)sample_nomot[k];
+                                    k++;
+                                }
+                                min_sample[3] = (unsigned)index[1], min_sample[4] = (unsigned)index[0];
+                            }
+                            cnt_trans = num;
+                        } else {
+                            for (size_t j = 0; j < 5; j++) min_sample[j] = (unsigned)sample_rot[j];
+                        }
+                    }
+                    (nomot ? best_up_trans : best_up_rot) = num;
+                    const unsigned ns = stopping_on(errs[counted], outlier_indices, nomot ? dg_thr : thr, num_outliers);
+                    if (ns < limit) limit = ns;
+                }
+            }
+        }
+        double v[4] = {(double)hyp_count, (double)branch, (double)tried, (double)best_up};
+        emit(9, v, 4);
+        return best_up;
+    }
+
     bool solve() {
         unsigned adaptive = max_hyp;
         bool update_sprt_stopping = true;
@@ -622,8 +1048,24 @@ struct Usac {
                     }
                 }
             }
+            if (update_best && check_degeneracy) {  // USAC.h:509-528
+                bool degenerate = false, upgrade = false;
+                test_degeneracy(&degenerate, &upgrade);
+                if (degenerate && upgrade) {
+                    const unsigned up = upgrade_model();
+                    if (up > best) best = up;
+                }
+            }
             if (update_best) {
-                const unsigned lo = local_optimization(best);
+                unsigned lo = local_optimization(best);
+                if (check_degeneracy & 2) {  // USAC.h:540-556
+                    bool degenerate = false, upgrade = false;
+                    test_degeneracy(&degenerate, &upgrade);
+                    if (degenerate && upgrade) {
+                        const unsigned up = upgrade_model();
+                        if (up > lo) lo = up;
+                    }
+                }
                 if (lo > best) best = lo;
                 if (num_prev_best_lo < best) num_prev_best_lo = best;
                 if (prosac && hyp_count <= prosac_max_samples)
@@ -677,5 +1119,48 @@ extern "C" int oracle_usac_essential(const double *p1, const double *p2, int n, 
     if (E) std::memcpy(E, u.final_model, 72);
     if (inlier_flags)
         for (int i = 0; i < n; ++i) inlier_flags[i] = (uint8_t)u.flags[i];
+    return ok ? 1 : 0;
+}
+
+// With the degeneracy handling of DEGEN_USAC_INTERNAL: check_degeneracy 1 (after every new best model) or 3 (also after every local
+// optimisation); degen[16] = {1, inliers of the rotation, of "no motion", type, R_degenerate[9]}; flags_rot / flags_nomot: n bytes each.
+extern "C" int oracle_usac_essential_degen(const double *p1, const double *p2, int n, double th, unsigned seed, int refine,
+                                           const uint32_t *sorted_idx, int max_hyp, double conf, double prosac_beta, double sprt_delta,
+                                           double sprt_epsilon, double sprt_mS, double sprt_tM, int check_degeneracy, double th_pixels,
+                                           double focal_length, double *E, uint8_t *inlier_flags, double *results, double *events,
+                                           int event_cap, int *n_events, double *degen, uint8_t *flags_rot, uint8_t *flags_nomot) {
+    Usac u;
+    u.n = (unsigned)n, u.max_hyp = (unsigned)max_hyp, u.conf = conf, u.thr = th * th, u.refine = refine;
+    u.p1 = p1, u.p2 = p2;
+    u.prosac = sorted_idx != nullptr;
+    if (u.prosac) u.sorted_idx.assign(sorted_idx, sorted_idx + n);
+    u.prosac_beta = prosac_beta, u.sprt_delta = sprt_delta, u.sprt_epsilon = sprt_epsilon, u.sprt_mS = sprt_mS, u.sprt_tM = sprt_tM;
+    u.events = events, u.event_cap = event_cap;
+    u.check_degeneracy = check_degeneracy;
+    u.dg_thr = 1.0 - cos(atan(th_pixels / focal_length));
+    oracle_srand(&u.rng, seed);
+    u.init();
+    if (check_degeneracy) u.init_degeneracy();
+    const bool ok = u.solve();
+    if (n_events) *n_events = u.n_events;
+    if (results) {
+        const double fin[12] = {ok ? 1.0 : 0.0, (double)u.hyp_count, (double)u.model_count, (double)u.rejected_samples, (double)u.rejected_models,
+                                (double)u.best, (double)u.points_verified, (double)u.num_lo, u.history.empty() ? 0.0 : u.history.back().delta,
+                                u.history.empty() ? 0.0 : u.history.back().epsilon, u.sprt_delta, u.sprt_epsilon};
+        std::memcpy(results, fin, sizeof(fin));
+    }
+    if (E) std::memcpy(E, u.final_model, 72);
+    if (inlier_flags)
+        for (int i = 0; i < n; ++i) inlier_flags[i] = (uint8_t)u.flags[i];
+    if (degen) {
+        std::memset(degen, 0, 128);
+        degen[0] = check_degeneracy ? 1.0 : 0.0, degen[1] = u.cnt_rot, degen[2] = u.cnt_nomot, degen[3] = u.dg_type;
+        std::memcpy(degen + 4, u.R_degen, 72);
+    }
+    if (check_degeneracy && ok)
+        for (int i = 0; i < n; ++i) {
+            if (flags_rot) flags_rot[i] = (uint8_t)u.in_rot[i];
+            if (flags_nomot) flags_nomot[i] = (uint8_t)u.in_nomot[i];
+        }
     return ok ? 1 : 0;
 }

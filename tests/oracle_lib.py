@@ -234,6 +234,28 @@ class Oracle:
                flags.ctypes.data, res.ctypes.data, ev.ctypes.data if event_cap else None, int(event_cap), C.addressof(nev))
         return dict(ok=bool(ok), E=E, flags=flags, final=res, events=ev[:min(nev.value, event_cap)], n_events=nev.value)
 
+    def usac_essential_degen(self, p1, p2, th, seed, check_degeneracy=1, th_pixels=0.8, focal_length=800.0, refine=0, sorted_idx=None,
+                             max_hyp=50000, conf=0.99, prosac_beta=0.09, sprt_delta=0.05, sprt_epsilon=0.15, sprt_ms=8.5, sprt_tm=2314.0,
+                             event_cap=0):
+        """usac_essential with the degeneracy handling of DEGEN_USAC_INTERNAL; adds degen = [1, inliers of the rotation, of "no motion",
+        type], R_degen, flags_rot, flags_nomot (same keys as pose.usac_essential and tests/usac_ref_tool.run)."""
+        p1 = np.ascontiguousarray(p1, np.float64)
+        p2 = np.ascontiguousarray(p2, np.float64)
+        n = p1.shape[0]
+        E, flags, res, nev = np.zeros(9), np.zeros(n, np.uint8), np.zeros(12), C.c_int(0)
+        info, fr, fn = np.zeros(16), np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        ev = np.zeros((max(event_cap, 1), 16))
+        si = None if sorted_idx is None else np.ascontiguousarray(sorted_idx, np.uint32)
+        f = self.lib.oracle_usac_essential_degen
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_uint, C.c_int, C.c_void_p, C.c_int] + [C.c_double] * 6 + \
+                     [C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p] + [C.c_void_p] * 3
+        ok = f(p1.ctypes.data, p2.ctypes.data, n, float(th), int(seed), int(refine), None if si is None else si.ctypes.data, int(max_hyp),
+               float(conf), float(prosac_beta), float(sprt_delta), float(sprt_epsilon), float(sprt_ms), float(sprt_tm), int(check_degeneracy),
+               float(th_pixels), float(focal_length), E.ctypes.data, flags.ctypes.data, res.ctypes.data,
+               ev.ctypes.data if event_cap else None, int(event_cap), C.addressof(nev), info.ctypes.data, fr.ctypes.data, fn.ctypes.data)
+        return dict(ok=bool(ok), E=E, flags=flags, final=res, events=ev[:min(nev.value, event_cap)], n_events=nev.value,
+                    degen=info[:4].copy(), R_degen=info[4:13].copy(), flags_rot=fr, flags_nomot=fn)
+
     def eigen_svd3(self, M):
         M = np.ascontiguousarray(M, np.float64)
         sv, U, V = np.zeros(3), np.zeros((3, 3)), np.zeros((3, 3))

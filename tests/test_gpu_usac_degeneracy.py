@@ -16,9 +16,8 @@ import sys
 import numpy as np
 import pytest
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
-import usac_compare  # noqa: E402
-import usac_degen_cases  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import usac_degen_checks as checks  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -27,123 +26,28 @@ pytestmark = pytest.mark.gpu
 def runs(ctx):
     from matchinglib_poselib_amd import pose
 
-    g = np.load(usac_degen_cases.FIXTURE)
-    out = []
-    for key, name, p1, p2, th, order, truth, usac_seed, prosac, chk in usac_degen_cases.cases():
-        d = pose.usac_essential(p1, p2, th, usac_seed, sorted_idx=order if prosac else None, event_cap=200000, check_degeneracy=chk, ctx=ctx)
-        out.append((key, name, g, d, len(p1)))
-    return out
-
-
-def first_of(ev, ty, cond=None):
-    for i, e in enumerate(ev):
-        if int(e[0]) == ty and (cond is None or cond(e)):
-            return i
-    return None
+    return checks.collect(lambda p1, p2, th, seed, si, chk: pose.usac_essential(p1, p2, th, seed, sorted_idx=si, event_cap=200000,
+                                                                               check_degeneracy=chk, ctx=ctx))
 
 
 def test_general_motion_nothing_found_and_identical(runs):
-    seen = 0
-    for key, name, g, d, n in runs:
-        if name != "general":
-            continue
-        ev = g[key + "_events"]
-        first, diffs = usac_compare.compare(ev, d["events"][:len(ev)])
-        assert first is None and int(g[key + "_meta"][4]) == d["n_events"], (key, first)
-        assert np.array_equal(g[key + "_final"][:8], d["final"][:8]) and np.array_equal(g[key + "_flags"], d["flags"])
-        assert d["degen"][1] == 0 and d["degen"][2] == 0 and not d["flags_rot"].any() and not d["flags_nomot"].any()
-        assert (ev[:, 0] == 7).sum() >= 1 and (ev[:, 0] == 9).sum() == 0        # tested, never upgraded
-        seen += 1
-    assert seen == 6
+    checks.check_general_motion_nothing_found_and_identical(runs)
 
 
 def test_first_degeneracy_test_is_identical(runs):
-    """Ten two-point rotations, their inlier counts over all correspondences, the refits (type 8) and the verdict (type 7)."""
-    parted_before = 0
-    for key, name, g, d, n in runs:
-        ev, dv = g[key + "_events"], d["events"]
-        i7 = first_of(ev, 7)
-        assert i7 is not None
-        first, _ = usac_compare.compare(ev[:i7 + 1], dv[:i7 + 1])
-        if first is not None:
-            # (c) of the module text: a minimal sample without parallax, whose 5-point solutions are ill-conditioned -- the inlier
-            # count of such a model differs between any two solvers
-            assert name != "general" and int(ev[first][0]) in (2, 5) and first < 80, (key, name, first, ev[first][:9], dv[first][:9])
-            parted_before += 1
-            continue
-        if name != "general":
-            assert ev[i7][2] == 1 and ev[i7][3] == 1 and ev[i7][5] > 0.1 * n, (key, ev[i7][:8])   # degenerate, upgrade asked for
-    assert parted_before <= 3
+    checks.check_first_degeneracy_test_is_identical(runs)
 
 
 def test_no_motion_upgrade_is_identical_candidate_by_candidate(runs):
-    seen = 0
-    for key, name, g, d, n in runs:
-        ev, dv = g[key + "_events"], d["events"]
-        i9 = first_of(ev, 9)
-        if i9 is None or ev[i9][2] != 1:
-            continue
-        first, _ = usac_compare.compare(ev[:i9 + 1], dv[:i9 + 1])
-        assert first is None, (key, name, first)
-        a, b = ev[:i9 + 1], dv[:i9 + 1]
-        ta, tb = a[(a[:, 0] == 10)][:, 4:7], b[(b[:, 0] == 10)][:, 4:7]
-        assert len(ta) > 20 and np.array_equal(ta, tb)                           # the two-point translations, to the bit
-        seen += 1
-    assert seen >= 4
+    checks.check_no_motion_upgrade_is_identical_candidate_by_candidate(runs)
 
 
 def test_rotation_upgrade_follows_until_the_eigensolver_noise_decides(runs):
-    """R -> R + t: candidates are the same correspondences (same stream), the models agree where the eigensolver converges, and the
-    run stays identical at least up to the upgrade's first candidate."""
-    seen, agree = 0, []
-    for key, name, g, d, n in runs:
-        ev, dv = g[key + "_events"], d["events"]
-        i10 = first_of(ev, 10, lambda e: e[2] == 2)
-        if i10 is None:
-            continue
-        first, _ = usac_compare.compare(ev[:i10 + 1], dv[:i10 + 1])
-        if first is not None:                        # parted earlier, at (b) an 8-point refit or (c) a sample without parallax
-            assert name != "general" and int(ev[first][0]) in (2, 3, 5), (key, name, first, ev[first][:9])
-            continue
-        m = min(len(ev), len(dv))
-        first, _ = usac_compare.compare(ev[:m], dv[:m])
-        stop = m if first is None else first
-        a, b = ev[:stop], dv[:stop]
-        ea, eb = a[(a[:, 0] == 10) & (a[:, 2] == 2)][:, 4:13], b[(b[:, 0] == 10) & (b[:, 2] == 2)][:, 4:13]
-        if len(ea):
-            agree.append(np.median(np.abs(ea - eb).max(1)))
-        seen += 1
-    assert seen >= 8 and np.median(agree) < 1e-3, (seen, agree)
-
-
-def degenerate_decision(n, n_inliers, degen, th=0.85):
-    """estimateEssentialOrPoseUSAC's decision (pose_estim.cpp:2101-2133): fraction of rotation / no-motion inliers among the inliers
-    of E against degenDecisionTh times the inlier ratio."""
-    frac_inl = n_inliers / n
-    f_rot = degen[0] / n_inliers if degen[0] > 2 and n_inliers > 0 else 0.0
-    f_nomot = degen[1] / n_inliers if degen[1] > 1 and n_inliers > 0 else 0.0
-    return (th * frac_inl < f_rot) or (th * frac_inl < f_nomot)
+    checks.check_rotation_upgrade_follows_until_the_eigensolver_noise_decides(runs)
 
 
 def test_degenerate_models_and_decision_at_the_end(runs):
-    for key, name, g, d, n in runs:
-        ref_deg, dev_deg = g[key + "_degen"][:2], d["degen"][1:3]
-        for th in (0.85, 1.65):                      # ConfigUSAC's default and the harness's (--USACdegenTh)
-            ref_dec = degenerate_decision(n, g[key + "_final"][5], ref_deg, th)
-            dev_dec = degenerate_decision(n, d["final"][5], dev_deg, th)
-            assert ref_dec == dev_dec, (key, name, th, ref_deg, dev_deg)
-        if name != "shortbase":                      # a short baseline is the case in between: either verdict, the same on both sides
-            assert degenerate_decision(n, d["final"][5], dev_deg) == (name != "general"), (key, name, dev_deg)
-        if name == "general":
-            continue
-        # the best rotation-only model: inlier count within 2 %, the same rotation, the same inlier set up to a few correspondences
-        assert abs(ref_deg[0] - dev_deg[0]) <= max(3, 0.02 * ref_deg[0]), (key, ref_deg, dev_deg)
-        Rr, Rd = g[key + "_R"].reshape(3, 3), d["R_degen"].reshape(3, 3)
-        assert np.abs(Rr - Rd).max() < 2e-4 and abs(np.linalg.det(Rd) - 1) < 1e-12, (key, np.abs(Rr - Rd).max())
-        assert (g[key + "_flags_rot"] != d["flags_rot"]).sum() <= max(4, 0.03 * ref_deg[0]), key
-        assert int(d["flags_rot"].sum()) == int(dev_deg[0]) and int(d["flags_nomot"].sum()) == int(dev_deg[1])
-        if name == "nomotion":
-            assert abs(ref_deg[1] - dev_deg[1]) <= max(3, 0.02 * ref_deg[1])
+    checks.check_degenerate_models_and_decision_at_the_end(runs)
 
 
 def test_parameters_and_results_entry(ctx):
@@ -217,3 +121,74 @@ def test_cpp_facade_decision_and_stereo_refine(tmp_path, scene, kw, expect):
         assert sr_rc == -1            # robustPoseEstimation's -2 reaches the caller as -1 (stereo_pose_refinement.cpp:974-977)
     else:
         assert have_R == 0 and have_mask == 0 and sr_rc == 0
+
+
+def test_edge_cases_terminate_with_defined_results(ctx):
+    """Few correspondences, repeated correspondences, correspondences that all coincide, almost no inliers, the full 8192: every call
+    returns, masks are consistent with their counts, the rotation is a rotation whenever one was stored."""
+    from matchinglib_poselib_amd import pose, synth
+
+    rng = np.random.default_rng(8)
+    cases = []
+    for n in (5, 6, 9, 20, 37):
+        p1, p2, R, t, truth, th = synth.pose_scene(n, 1.0, seed=200 + n, t_len=0.0)
+        cases.append((f"rotation_n{n}", p1, p2, th))
+    p1, p2, R, t, truth, th = synth.pose_scene(300, 0.7, seed=211, t_len=0.0, rot_deg=0.0)
+    cases.append(("nomotion_repeated", np.repeat(p1[:60], 5, axis=0), np.repeat(p2[:60], 5, axis=0), th))
+    cases.append(("one_point", np.tile(p1[:1], (64, 1)), np.tile(p1[:1], (64, 1)), th))
+    cases.append(("identical_views", p1.copy(), p1.copy(), th))
+    p1, p2, R, t, truth, th = synth.pose_scene(1000, 0.08, seed=212, t_len=0.0)
+    cases.append(("rotation_8_percent", p1, p2, th))
+    p1, p2, R, t, truth, th = synth.pose_scene(8192, 0.5, seed=213, t_len=0.0)
+    cases.append(("rotation_8192", p1, p2, th))
+    p1, p2, R, t, truth, th = synth.pose_scene(8192, 0.5, seed=214, t_len=0.0, rot_deg=0.0)
+    cases.append(("nomotion_8192", p1, p2, th))
+    for name, a, b, th in cases:
+        for chk in (1, 3):
+            d = pose.usac_essential(a, b, th, 5, check_degeneracy=chk, max_hyp=3000, ctx=ctx)
+            assert d["ok"], name
+            assert int(d["flags_rot"].sum()) == int(d["degen"][1]) and int(d["flags_nomot"].sum()) == int(d["degen"][2]), name
+            assert int(d["flags"].sum()) <= len(a) and d["final"][5] <= len(a), name
+            if d["degen"][1] > 2:
+                Rd = d["R_degen"].reshape(3, 3)
+                assert np.isfinite(Rd).all() and np.abs(Rd @ Rd.T - np.eye(3)).max() < 1e-9 and abs(np.linalg.det(Rd) - 1) < 1e-9, name
+        if name in ("rotation_8192", "nomotion_8192", "identical_views"):
+            assert d["degen"][1] > 0.4 * len(a) * (0.5 if "8192" in name else 0.7), (name, d["degen"])
+
+
+def test_device_equals_oracle_on_more_scenes(ctx, oracle):
+    """Scenes outside the fixture, device against the CPU oracle: identical through the first degeneracy test and through no-motion
+    upgrades; the same rotation-only model and verdict at the end."""
+    from matchinglib_poselib_amd import pose, synth
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import usac_compare
+
+    seen_nomot = 0
+    for n, frac, seed, kw in ((900, 0.55, 301, dict(t_len=0.0)), (3000, 0.4, 302, dict(t_len=0.0, rot_deg=2.0)), (700, 0.7, 303, dict(t_len=0.0, rot_deg=0.0)),
+                              (2500, 0.45, 304, dict(t_len=0.0, rot_deg=0.0)), (1200, 0.6, 305, {}), (5000, 0.5, 306, dict(t_len=0.0))):
+        p1, p2, R, t, truth, th = synth.pose_scene(n, frac, seed=seed, **kw)
+        for chk in (1, 3):
+            o = oracle.usac_essential_degen(p1, p2, th, 77, check_degeneracy=chk, event_cap=300000)
+            d = pose.usac_essential(p1, p2, th, 77, check_degeneracy=chk, event_cap=300000, ctx=ctx)
+            eo, ed = o["events"], d["events"]
+            i7 = checks.first_of(eo, 7)
+            first, _ = usac_compare.compare(eo[:i7 + 1], ed[:i7 + 1])
+            if first is not None:      # a sample without parallax before any test
+                assert kw and int(eo[first][0]) in (2, 5) and first < 80, (seed, first)
+                continue
+            i9 = checks.first_of(eo, 9)
+            if i9 is not None and eo[i9][2] == 1:
+                first, _ = usac_compare.compare(eo[:i9 + 1], ed[:i9 + 1])
+                assert first is None, (seed, first)
+                seen_nomot += 1
+            if not kw:
+                first, _ = usac_compare.compare(eo, ed)
+                assert first is None and np.array_equal(o["flags"], d["flags"]) and d["degen"][1] == 0
+                continue
+            assert abs(o["degen"][1] - d["degen"][1]) <= max(3, 0.02 * o["degen"][1]) and np.abs(o["R_degen"] - d["R_degen"]).max() < 2e-4, \
+                (seed, o["degen"], d["degen"])
+            for th_dec in (0.85, 1.65):
+                assert checks.degenerate_decision(n, o["final"][5], o["degen"][1:3], th_dec) == \
+                    checks.degenerate_decision(n, d["final"][5], d["degen"][1:3], th_dec)
+    assert seen_nomot >= 2

@@ -1,0 +1,49 @@
+"""The CPU oracle's restatement of USAC's degeneracy handling (oracle/usac_oracle.cpp, oracle_usac_essential_degen) against traces of
+the REFERENCE's USAC.h driven through the reference's OpenGV and PoseTools (oracle/_ref/usac_ref -> tests/golden/usac_degen_trace.npz).
+The same assertions as for the device path (tests/usac_degen_checks.py; what "equal" can mean on degenerate motion is explained in
+tests/test_gpu_usac_degeneracy.py).  The oracle's eigensolver is a properly converging minimiser of the same objective, so on the
+R -> R + t upgrade it parts from the reference's noise-driven iterates earlier than the device path does; the agreement bound there is on
+the essential matrices of the candidates both sides evaluated."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import usac_degen_checks as checks  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def runs(oracle):
+    return checks.collect(lambda p1, p2, th, seed, si, chk: oracle.usac_essential_degen(p1, p2, th, seed, check_degeneracy=chk, sorted_idx=si,
+                                                                                       event_cap=200000))
+
+
+def test_general_motion_nothing_found_and_identical(runs):
+    checks.check_general_motion_nothing_found_and_identical(runs)
+
+
+def test_first_degeneracy_test_is_identical(runs):
+    checks.check_first_degeneracy_test_is_identical(runs)
+
+
+def test_no_motion_upgrade_is_identical_candidate_by_candidate(runs):
+    checks.check_no_motion_upgrade_is_identical_candidate_by_candidate(runs)
+
+
+def test_rotation_upgrade_candidates_agree_where_both_converge(runs):
+    checks.check_rotation_upgrade_follows_until_the_eigensolver_noise_decides(runs, agree_tol=5e-2)
+
+
+def test_degenerate_models_and_decision_at_the_end(runs):
+    checks.check_degenerate_models_and_decision_at_the_end(runs)
+
+
+def test_without_the_tests_it_is_the_plain_run(oracle):
+    from matchinglib_poselib_amd import synth
+
+    p1, p2, R, t, truth, th = synth.pose_scene(400, 0.6, seed=9)
+    a = oracle.usac_essential(p1, p2, th, 3, event_cap=50000)
+    b = oracle.usac_essential_degen(p1, p2, th, 3, check_degeneracy=0, event_cap=50000)
+    assert np.array_equal(a["events"], b["events"]) and np.array_equal(a["flags"], b["flags"]) and b["degen"][0] == 0
