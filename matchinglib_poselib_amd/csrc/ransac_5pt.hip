@@ -3591,19 +3591,13 @@ int mlpl_usac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n
     int rc;
     if ((rc = usac_check_params(params, n, "mlpl_usac_essential"))) return rc;
     MLPL_HIP_TRY(hipSetDevice(ctx->device));
-    void *dp1, *dp2, *dmask;
+    void *dp1, *dp2;
     const size_t pb = (size_t)std::max(n, 1) * 16;
-    if ((rc = ws_get(ctx, WS_AUX0, pb, &dp1)) || (rc = ws_get(ctx, WS_AUX1, pb, &dp2)) || (rc = ws_get(ctx, WS_AUX2, (size_t)std::max(n, 1), &dmask)))
-        return rc;
+    if ((rc = ws_get(ctx, WS_AUX0, pb, &dp1)) || (rc = ws_get(ctx, WS_AUX1, pb, &dp2))) return rc;
     MLPL_HIP_TRY(hipMemcpyAsync(dp1, p1, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
     MLPL_HIP_TRY(hipMemcpyAsync(dp2, p2, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
-    rc = usac_essential_dev(ctx, (const double *)dp1, (const double *)dp2, n, params, E, (uint8_t *)dmask, results, ctx->stream);
-    if (rc) return rc;
-    if (mask) {
-        MLPL_HIP_TRY(hipMemcpyAsync(mask, dmask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-        MLPL_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
-    return MLPL_OK;
+    // the sequential part runs on the host and reads the correspondences there: it takes the caller's copies and returns the mask directly
+    return usac_essential_dev(ctx, (const double *)dp1, (const double *)dp2, n, params, E, nullptr, results, ctx->stream, p1, p2, mask);
 }
 
 int mlpl_usac_last_stats(mlpl_ctx *ctx, long long stats[8]) {

@@ -83,7 +83,8 @@ __global__ __launch_bounds__(64) void usac_check_kernel(const double4 *__restric
                                                         const double *__restrict__ p2, const int32_t *__restrict__ samples, int B,
                                                         const double *__restrict__ E_tab, const int32_t *__restrict__ n_models, UsacGeom g,
                                                         double thr, int32_t *__restrict__ out_nm, double *__restrict__ out_key,
-                                                        int32_t *__restrict__ out_valid, unsigned long long *__restrict__ out_rows) {
+                                                        int32_t *__restrict__ out_valid, unsigned long long *__restrict__ out_rows,
+                                                        double *__restrict__ out_E) {
     const int b = blockIdx.x / 10, slot = blockIdx.x - b * 10;
     const int lane = threadIdx.x;
     if (b >= B) return;
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(64) void usac_check_kernel(const double4 *__restric
     double E[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) E[k] = E_tab[((size_t)b * 10 + slot) * 9 + k];
+    if (lane < 9) out_E[((size_t)b * 10 + slot) * 9 + lane] = E_tab[((size_t)b * 10 + slot) * 9 + lane];  // the host's copy of the model
     if (lane == 0) {
         // order convention: ascending E(0,0) of the unit-Frobenius matrix whose largest-magnitude element is positive
         double big = 0, n2 = 0;
@@ -600,13 +602,15 @@ struct UsacRun {
         const size_t smp_bytes = (size_t)batch_cap * 5 * 4, lo_in_bytes = (size_t)kUsacLoReps * sizeof(UsacLoIn);
         dg_cap = dg_on ? (int)std::max<size_t>(10, std::min<size_t>(128, out_bytes / ((size_t)2 * words * 8))) : 0;
         const size_t dg_bytes = (size_t)dg_cap * sizeof(UsacDgModel);
-        if ((rc = pinned_get(ctx, out_bytes + smp_bytes + lo_in_bytes + dg_bytes + 320, &p))) return rc;
+        const size_t pool_bytes = ((size_t)n * 4 + 63) & ~(size_t)63;
+        if ((rc = pinned_get(ctx, out_bytes + smp_bytes + lo_in_bytes + pool_bytes + dg_bytes + 384, &p))) return rc;
         h_out = (char *)p;
         h_smp = (int32_t *)(h_out + ((out_bytes + 63) & ~(size_t)63));
         h_lo_in = (UsacLoIn *)((char *)h_smp + ((smp_bytes + 63) & ~(size_t)63));
+        int32_t *h_pool = (int32_t *)((char *)h_lo_in + ((lo_in_bytes + 63) & ~(size_t)63));
         void *alias = nullptr;
         if (dg_on) {
-            h_dg = (UsacDgModel *)((char *)h_lo_in + ((lo_in_bytes + 63) & ~(size_t)63));
+            h_dg = (UsacDgModel *)((char *)h_pool + pool_bytes);
             MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, h_dg, 0));
             d_dg = (UsacDgModel *)alias;
             pool_pos.resize(n);
@@ -620,13 +624,13 @@ struct UsacRun {
         MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, h_lo_in, 0));
         d_lo_in = (UsacLoIn *)alias;
         // the evaluation pool on the device: the permutation itself and the points gathered in its order
-        MLPL_HIP_TRY(hipMemcpyAsync(d_pool, pool.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        for (unsigned i = 0; i < n; ++i) h_pool[i] = (int32_t)pool[i];  // pinned: the copy is stream-ordered, nothing to wait for
+        MLPL_HIP_TRY(hipMemcpyAsync(d_pool, h_pool, (size_t)n * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(usac_pool_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_p1, d_p2, (const int32_t *)d_pool, (int)n, d_pts_pool);
         MLPL_HIP_TRY(hipGetLastError());
-        MLPL_HIP_TRY(hipStreamSynchronize(s));  // `pool` may be rewritten only after the copy (pageable source)
         return MLPL_OK;
     }
-    size_t batch_out_bytes(int B) const { return (size_t)B * 4 + 64 + (size_t)B * 10 * (8 + 4) + 64 + (size_t)B * 10 * words * 8; }
+    size_t batch_out_bytes(int B) const { return (size_t)B * 4 + 64 + (size_t)B * 10 * (8 + 4) + 64 + (size_t)B * 10 * words * 8 + 64 + (size_t)B * 720; }
     size_t lo_out_stride() const { return (sizeof(UsacLoOut) + (size_t)kUsacLoEvals * words * 8 + 63) & ~(size_t)63; }
 
     void uniform_sample(GlibcRand &r, unsigned data_size, unsigned sample_size, std::vector<unsigned> &sample) const {
@@ -811,18 +815,19 @@ struct UsacRun {
         int32_t *o_nm = (int32_t *)h_out_dev, *o_valid = (int32_t *)(h_out_dev + off_valid);
         double *o_key = (double *)(h_out_dev + off_key);
         unsigned long long *o_rows = (unsigned long long *)(h_out_dev + off_rows);
+        const size_t off_E = (off_rows + (size_t)B * 10 * words * 8 + 63) & ~(size_t)63;
         launch_solve5pt(ctx, B, s, d_p1, d_p2, (const int32_t *)d_smp, 0, B, d_recs);
         MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((B + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)d_recs, 0, B, d_Etab, d_nm,
                           (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
         hipLaunchKernelGGL(usac_check_kernel, dim3(B * 10), dim3(64), 0, s, (const double4 *)d_pts_pool, (int)n, words, d_p1, d_p2,
-                           (const int32_t *)d_smp, B, (const double *)d_Etab, (const int32_t *)d_nm, g, thr, o_nm, o_key, o_valid, o_rows);
+                           (const int32_t *)d_smp, B, (const double *)d_Etab, (const int32_t *)d_nm, g, thr, o_nm, o_key, o_valid, o_rows,
+                           (double *)(h_out_dev + off_E));
         MLPL_HIP_TRY(hipGetLastError());
-        MLPL_HIP_TRY(hipMemcpyAsync(h_Etab_host(B), d_Etab, (size_t)B * 720, hipMemcpyDeviceToHost, s));
         MLPL_HIP_TRY(hipStreamSynchronize(s));
         const int32_t *h_nm = (const int32_t *)h_out, *h_valid = (const int32_t *)(h_out + off_valid);
         const double *h_key = (const double *)(h_out + off_key);
         const uint64_t *h_rows = (const uint64_t *)(h_out + off_rows);
-        const double *hE = h_Etab_host(B);
+        const double *hE = (const double *)(h_out + off_E);
         for (int b = 0; b < B; ++b) {
             UsacSampleModels sm;
             const int nm = std::min(h_nm[b], 10);
@@ -841,11 +846,6 @@ struct UsacRun {
         }
         stats[0]++, stats[1] += B;
         return MLPL_OK;
-    }
-    std::vector<double> etab_host;
-    double *h_Etab_host(int B) {
-        if (etab_host.size() < (size_t)B * 90) etab_host.resize((size_t)kUsacBatch * 90);
-        return etab_host.data();
     }
 
     // evaluateModel's sequential test on a bit row (pool order)
@@ -1458,8 +1458,10 @@ struct UsacRun {
 
 }  // namespace
 
+// h_p1 / h_p2: the caller's host copies of the correspondences when it has them (else they are fetched); h_mask: host destination of the
+// inlier mask (d_mask is then not written)
 int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, const mlpl_usac_params *P, double *E, uint8_t *d_mask,
-                       double *results, hipStream_t s) {
+                       double *results, hipStream_t s, const double *h_p1 = nullptr, const double *h_p2 = nullptr, uint8_t *h_mask = nullptr) {
     UsacRun R;
     R.ctx = ctx, R.s = s, R.d_p1 = d_p1, R.d_p2 = d_p2, R.n = (unsigned)n;
     R.max_hyp = (unsigned)P->max_hyp, R.conf = P->conf, R.thr = P->th * P->th;
@@ -1471,10 +1473,14 @@ int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, in
     R.dg_on = P->check_degeneracy != 0;
     R.dg_losac = R.dg_on && (P->check_degeneracy & 2) != 0;
     if (R.dg_on) R.dg_thr = 1.0 - std::cos(std::atan(P->th_pixels / P->focal_length));  // EssentialMatEstimator.h:349
-    R.hp1.resize((size_t)2 * n), R.hp2.resize((size_t)2 * n);
-    MLPL_HIP_TRY(hipMemcpyAsync(R.hp1.data(), d_p1, (size_t)n * 16, hipMemcpyDeviceToHost, s));
-    MLPL_HIP_TRY(hipMemcpyAsync(R.hp2.data(), d_p2, (size_t)n * 16, hipMemcpyDeviceToHost, s));
-    MLPL_HIP_TRY(hipStreamSynchronize(s));
+    if (h_p1 && h_p2) {
+        R.hp1.assign(h_p1, h_p1 + (size_t)2 * n), R.hp2.assign(h_p2, h_p2 + (size_t)2 * n);
+    } else {
+        R.hp1.resize((size_t)2 * n), R.hp2.resize((size_t)2 * n);
+        MLPL_HIP_TRY(hipMemcpyAsync(R.hp1.data(), d_p1, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipMemcpyAsync(R.hp2.data(), d_p2, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipStreamSynchronize(s));
+    }
     R.rng.seed(P->seed);
     int rc;
     bool ok = false;
@@ -1518,7 +1524,9 @@ int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, in
         return MLPL_E_FAILED;
     }
     std::memcpy(E, R.final_model, 72);
-    if (d_mask) {
+    if (h_mask) {
+        std::memcpy(h_mask, R.flags.data(), (size_t)n);
+    } else if (d_mask) {
         void *hp;
         if ((rc = pinned_get(ctx, (size_t)n, &hp))) return rc;  // the batch blocks are no longer needed
         std::memcpy(hp, R.flags.data(), (size_t)n);
