@@ -1900,7 +1900,7 @@ struct Jacobi9Lds {
 
 // Eigen-decomposition of the symmetric 9x9 J.G by one wave: on return J.G is diagonal (the eigenvalues, unordered) and the columns
 // of J.Vv are the eigenvectors.  J.Vv must hold the identity on entry.
-__device__ __forceinline__ void jacobi9_wave(Jacobi9Lds &J, int lane) {
+__device__ __forceinline__ int jacobi9_wave(Jacobi9Lds &J, int lane) {  // returns the sweeps taken
     // Jacobi eigenvalue iteration on the symmetric 9x9 in the parallel (round-robin) ordering: the 9 indices plus one idle
     // slot form 5 disjoint pairs per round, 9 rounds visit all 36 pairs once (= one sweep).  Lanes 0..4 compute the rotations
     // of a round, then all lanes apply J^T G J and V J element-wise (disjoint rotations commute).
@@ -1908,12 +1908,15 @@ __device__ __forceinline__ void jacobi9_wave(Jacobi9Lds &J, int lane) {
     // round r, index 1 + (k - 1 - r) mod 9 (slot 0 keeps index 0; index 9 is the idle slot).
     double(*GG)[9][9] = reinterpret_cast<double(*)[9][9]>(&J.G[0][0]);    // GG[0] = G, GG[1] = Gn
     double(*VV)[9][9] = reinterpret_cast<double(*)[9][9]>(&J.Vv[0][0]);   // VV[0] = Vv, VV[1] = Vn
-    int cur = 0;
+    int cur = 0, sweeps = 0;
     // the (at most two) matrix elements this lane owns
     const int e0 = lane, e1 = lane + 64;
     const int a0 = e0 / 9, b0 = e0 - a0 * 9, a1 = e1 / 9, b1 = e1 - a1 * 9;
     const bool has1 = e1 < 81;
-    for (int sweep = 0; sweep < 60; ++sweep) {
+#ifndef MLPL_JACOBI_MAX_SWEEPS
+#define MLPL_JACOBI_MAX_SWEEPS 60
+#endif
+    for (int sweep = 0; sweep < MLPL_JACOBI_MAX_SWEEPS; ++sweep) {
         // off-diagonal mass against the diagonal (wave reduction; every lane gets the totals)
         double off = 0, diag = 0;
         {
@@ -1932,6 +1935,7 @@ __device__ __forceinline__ void jacobi9_wave(Jacobi9Lds &J, int lane) {
             diag += __shfl_xor(diag, d);
         }
         if (off <= kJacobiTol * diag) break;  // wave-uniform
+        ++sweeps;
         for (int round = 0; round < 9; ++round) {
             const double(*Gc)[9] = GG[cur];
             const double(*Vc)[9] = VV[cur];
@@ -1998,6 +2002,7 @@ __device__ __forceinline__ void jacobi9_wave(Jacobi9Lds &J, int lane) {
         }
         wave_sync();
     }
+    return sweeps;
 }
 
 // Indices of the nine eigenvalues in descending order, the first of equal values first (what a selection sort from the top gives).  The

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void usac_degen_rows_kernel(const double4 *__r
 struct UsacLoOut {          // per repetition, pinned host memory; followed by kUsacLoEvals bit rows of `words` words
     int32_t evals;          // evaluations performed (the chain stops when a 2 x threshold inlier set has < 5 members)
     int32_t cnt2;           // members of the 2 x threshold set after the first evaluation (the first refit's point count)
+    int32_t sweeps, fits;   // diagnostics: Jacobi sweeps and fits of the chain
     int32_t count[kUsacLoEvals];      // inliers at the threshold per evaluation
     int32_t fit_pts[kUsacLoEvals];    // points the model of evaluation e was fitted to (0 = the start model of a resumed chain)
     double F[kUsacLoEvals][9];        // the evaluated models, normalised coordinates (models_[0])
@@ -231,26 +232,53 @@ struct UsacLoLds {
     double red[8][45];
     double F[9], E[9];
     int scan[kUsacLoThreads / 64 + 1];
-    int total, K;
+    int total, K, sweeps;
 };
 
 // Fit of REFINE_WEIGHTS from the 45 accumulated products in L.red[0] (wave 0): smallest eigenvector of the covariance matrix, rank-2
 // projection (FTools::singulF), denormalisation.
-__device__ __forceinline__ void usac_fit_from_cov(UsacLoLds &L, const UsacGeom &g, int tid) {
+// `warm`: L.J.Vv holds the eigenvectors of the previous fit of this chain.  The covariance matrices of consecutive fits are close (same
+// scene, a slightly different inlier set / weights), so the iteration starts from V_prev^T G V_prev, which is nearly diagonal, and
+// accumulates its rotations onto V_prev: the same eigen-decomposition to the same tolerance in 2-3 sweeps instead of 8 (a column of V may
+// come out with the other sign, which no error or weight sees).
+__device__ __forceinline__ void usac_fit_from_cov(UsacLoLds &L, const UsacGeom &g, int tid, bool warm) {
     if (tid < 64) {
-        if (tid == 0) {
-            int t = 0;
-            for (int a = 0; a < 9; ++a)
-                for (int b = a; b < 9; ++b) {
-                    L.J.G[a][b] = L.red[0][t];
-                    L.J.G[b][a] = L.red[0][t];
-                    ++t;
+        if (!warm) {
+            if (tid == 0) {
+                int t = 0;
+                for (int a = 0; a < 9; ++a)
+                    for (int b = a; b < 9; ++b) {
+                        L.J.G[a][b] = L.red[0][t];
+                        L.J.G[b][a] = L.red[0][t];
+                        ++t;
+                    }
+            }
+            for (int e = tid; e < 81; e += 64) L.J.Vv[e / 9][e % 9] = (e / 9 == e % 9) ? 1.0 : 0.0;
+        } else {
+            // Gn = G V_prev (G read from the packed upper triangle), then G = V_prev^T Gn, upper triangle mirrored
+            for (int e = tid; e < 81; e += 64) {
+                const int a = e / 9, b = e - a * 9;
+                double acc = 0;
+                for (int k = 0; k < 9; ++k) {
+                    const int lo = a < k ? a : k, hi = a < k ? k : a;
+                    acc += L.red[0][lo * 9 - lo * (lo - 1) / 2 + (hi - lo)] * L.J.Vv[k][b];
                 }
+                L.J.Gn[a][b] = acc;
+            }
+            wave_sync();
+            for (int e = tid; e < 81; e += 64) {
+                const int a = e / 9, b = e - a * 9;
+                if (a > b) continue;
+                double acc = 0;
+                for (int k = 0; k < 9; ++k) acc += L.J.Vv[k][a] * L.J.Gn[k][b];
+                L.J.G[a][b] = acc;
+                L.J.G[b][a] = acc;
+            }
         }
-        for (int e = tid; e < 81; e += 64) L.J.Vv[e / 9][e % 9] = (e / 9 == e % 9) ? 1.0 : 0.0;
         wave_sync();
-        jacobi9_wave(L.J, tid);
+        const int sweeps = jacobi9_wave(L.J, tid);
         if (tid == 0) {
+            L.sweeps += sweeps;
             int m = 0;
             for (int a = 1; a < 9; ++a)
                 if (L.J.G[a][a] < L.J.G[m][m]) m = a;
@@ -302,9 +330,9 @@ __device__ __forceinline__ void usac_cov_add(double *acc, const double *a, const
 }
 
 __global__ __launch_bounds__(kUsacLoThreads) void usac_lo_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
-                                                                 const int32_t *__restrict__ pool, int n, int words, UsacGeom g, double thr,
+                                                                 const double4 *__restrict__ pts_pool, int n, int words, UsacGeom g, double thr,
                                                                  double lo_mult, const UsacLoIn *__restrict__ in, char *__restrict__ out_base,
-                                                                 size_t out_stride, double *__restrict__ err_scratch) {
+                                                                 size_t out_stride, double *__restrict__ err_scratch, int warm_start) {
     __shared__ UsacLoLds L;
     const int tid = threadIdx.x, rep = blockIdx.x;
     const UsacLoIn &I = in[rep];
@@ -316,6 +344,8 @@ __global__ __launch_bounds__(kUsacLoThreads) void usac_lo_kernel(const double *_
     const double step = (lo_mult * thr - thr) / kUsacLoSteps;
     int eval = 0;
     int fit_pts = 0;
+    bool have_fit = false;  // L.J.Vv holds the eigenvectors of an earlier fit of this chain
+    if (tid == 0) L.sweeps = 0;
 
     if (I.start_step < 0) {  // model of the 14-point sample, unit weights
         double acc[45];
@@ -329,7 +359,8 @@ __global__ __launch_bounds__(kUsacLoThreads) void usac_lo_kernel(const double *_
             usac_cov_add(acc, a, c, 1.0);
         }
         usac_reduce45(L, acc, tid);
-        usac_fit_from_cov(L, g, tid);
+        usac_fit_from_cov(L, g, tid, false);
+        have_fit = true;
         fit_pts = kUsacLoSample;
     } else {
         if (tid < 9) L.F[tid] = I.F[tid], L.E[tid] = I.E[tid];
@@ -363,12 +394,17 @@ __global__ __launch_bounds__(kUsacLoThreads) void usac_lo_kernel(const double *_
             O->fit_pts[eval] = fit_pts;
             for (int k = 0; k < 9; ++k) O->F[eval][k] = F[k], O->E[eval][k] = E[k];
         }
-        {
+        {   // the bit row in pool order: the same error from the points gathered in that order (coalesced; err[pool[j]] would be a
+            // dependent gather per word)
             unsigned long long *row = rows + (size_t)eval * words;
             const int lane = tid & 63;
             for (int w = tid >> 6; w < words; w += kUsacLoThreads / 64) {
                 const int j = w * 64 + lane;
-                const bool inl = j < n && err[pool[j]] < thr;
+                bool inl = false;
+                if (j < n) {
+                    const double4 p = pts_pool[j];
+                    inl = usac_sampson(E, p.x, p.y, p.z, p.w) < thr;
+                }
                 const unsigned long long bal = __ballot(inl);
                 if (lane == 0) row[w] = bal;
             }
@@ -430,11 +466,12 @@ __global__ __launch_bounds__(kUsacLoThreads) void usac_lo_kernel(const double *_
             usac_cov_add(acc, a, c, w);
         }
         usac_reduce45(L, acc, tid);
-        usac_fit_from_cov(L, g, tid);
+        usac_fit_from_cov(L, g, tid, have_fit && warm_start != 0);
+        have_fit = true;
         fit_pts = used;
         __syncthreads();
     }
-    if (tid == 0) O->evals = eval;
+    if (tid == 0) O->evals = eval, O->sweeps = L.sweeps;
 }
 
 struct UsacWald {
@@ -892,9 +929,9 @@ struct UsacRun {
 
     // ---- local optimisation ----
     int launch_lo(int reps_from, int reps_to) {  // h_lo_in[reps_from .. reps_to) are filled
-        hipLaunchKernelGGL(usac_lo_kernel, dim3(reps_to - reps_from), dim3(kUsacLoThreads), 0, s, d_p1, d_p2, (const int32_t *)d_pool, (int)n,
+        hipLaunchKernelGGL(usac_lo_kernel, dim3(reps_to - reps_from), dim3(kUsacLoThreads), 0, s, d_p1, d_p2, (const double4 *)d_pts_pool, (int)n,
                            words, g, thr, lo_mult, (const UsacLoIn *)(d_lo_in + reps_from), h_out_dev + (size_t)reps_from * lo_out_stride(),
-                           lo_out_stride(), d_err + (size_t)reps_from * n);
+                           lo_out_stride(), d_err + (size_t)reps_from * n, ctx->opt_usac_lo_warm_start);
         MLPL_HIP_TRY(hipGetLastError());
         MLPL_HIP_TRY(hipStreamSynchronize(s));
         stats[3]++;
@@ -929,6 +966,7 @@ struct UsacRun {
         for (int r = 0; r < kUsacLoReps; ++r) {
             // the chain of this repetition: evaluation record e of O holds the model evaluated there, its inlier count and its bit row
             const UsacLoOut *O = (const UsacLoOut *)(h_out + (size_t)r * stride);
+            stats[7] += O->sweeps;
             const uint64_t *rows = (const uint64_t *)((const char *)O + sizeof(UsacLoOut));
             int e = 0;
             unsigned tmp = 0, tested;

@@ -28,7 +28,7 @@ def main():
             st += d["stats"]
         st /= calls
         print(f"{name}: {1e3 * np.median(ts):.2f} ms per call (median of {calls}); per call: {st[0]:.1f} solver batches, {st[1]:.0f} samples solved, "
-              f"{st[2]:.0f} consumed, {st[3]:.1f} LO launches ({st[4]:.1f} resumes), {st[5]:.1f} degeneracy-test launches", flush=True)
+              f"{st[2]:.0f} consumed, {st[3]:.1f} LO launches ({st[4]:.1f} resumes), {st[5]:.1f} degeneracy-test launches, {st[7]:.0f} Jacobi sweeps in LO fits", flush=True)
 
 
 if __name__ == "__main__":
