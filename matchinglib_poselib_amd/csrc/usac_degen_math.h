@@ -8,7 +8,7 @@
 //   relative_pose/methods.cpp:57-86    twopt                 translation from two correspondences of known rotation
 //   relative_pose/methods.cpp:98-122   twopt_rotationOnly    Arun's rotation from two correspondences ("centred" on a third of their sum)
 //   relative_pose/methods.cpp:128-160  rotationOnly          Arun's rotation from n correspondences
-//   math/arun.cpp:33-56                arun                  R = V U^T of the cross-covariance, determinant forced to +1
+//   math/arun.cpp:33-56                arun                  R = V U^T of the cross-covariance (Eigen::JacobiSVD), determinant forced to +1
 //   relative_pose/methods.cpp:496-551 + modules/main.cpp:619-666 + modules/eigensolver/modules.cpp   eigensolver (Kneip & Lynen): rotation
 //                                      minimising the smallest eigenvalue of M(R) = sum (f1 x R f2)(f1 x R f2)^T, found by
 //                                      Levenberg-Marquardt on the gradient with a forward-difference Jacobian (Eigen's port of MINPACK
@@ -36,54 +36,94 @@ inline void matvec(const double *R, const double *v, double *o) {
     for (int r = 0; r < 3; ++r) o[r] = (R[3 * r] * v[0] + R[3 * r + 1] * v[1]) + R[3 * r + 2] * v[2];
 }
 
-// One-sided Jacobi SVD of a 3 x 3 matrix (row-major): A = U diag(S) V^T, S descending.  Columns of U that belong to a vanishing
-// singular value are not normalised (callers complete the frames themselves).
+// Eigen::JacobiSVD of a 3 x 3 matrix (row-major), as OpenGV's arun calls it (ComputeFullU | ComputeFullV): two-sided Jacobi on the pairs
+// (1,0), (2,0), (2,1) -- a rotation that symmetrises the 2 x 2 block, then the symmetric Jacobi rotation --, the signs of the singular
+// values moved into U, descending order by column swaps (Eigen/src/SVD/JacobiSVD.h; the same restatement as the device's svd3_eigen in
+// arrsac_impl.h and the oracle's, which tests/golden/eigen_svd3.npz pins against the Eigen the reference vendors).  It matters which
+// decomposition this is: for a cross-covariance of rank one or two (two correspondences) the rotation V U^T depends on the basis the
+// algorithm leaves in the null space.
+inline void svd3_pair(double *W, double *U, double *V, int p, int q, double &max_diag, bool &any) {
+    const double threshold = std::fmax(DBL_MIN, 2.0 * DBL_EPSILON * max_diag);
+    if (!(std::fabs(W[p * 3 + q]) > threshold || std::fabs(W[q * 3 + p]) > threshold)) return;
+    any = true;
+    double m00 = W[p * 3 + p], m01 = W[p * 3 + q], m10 = W[q * 3 + p], m11 = W[q * 3 + q];
+    double r1c = 1.0, r1s = 0.0;
+    const double t = m00 + m11, d = m10 - m01;
+    if (!(std::fabs(d) < DBL_MIN)) {
+        const double u = t / d, tmp = std::sqrt(1.0 + u * u);
+        r1s = 1.0 / tmp, r1c = u / tmp;
+    }
+    {
+        const double a0 = r1c * m00 + r1s * m10, a1 = r1c * m01 + r1s * m11, b1 = -r1s * m01 + r1c * m11;
+        m00 = a0, m01 = a1, m11 = b1;
+    }
+    double jrc = 1.0, jrs = 0.0;
+    const double deno = 2.0 * std::fabs(m01);
+    if (!(deno < DBL_MIN)) {
+        const double tau = (m00 - m11) / deno, w = std::sqrt(tau * tau + 1.0);
+        const double tt = tau > 0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+        const double sign_t = tt > 0 ? 1.0 : -1.0, nn = 1.0 / std::sqrt(tt * tt + 1.0);
+        jrc = nn, jrs = -sign_t * (m01 / std::fabs(m01)) * std::fabs(tt) * nn;
+    }
+    const double jlc = r1c * jrc + r1s * jrs, jls = -r1c * jrs + r1s * jrc;  // rot1 * jr^T
+    for (int i = 0; i < 3; ++i) {  // rows p, q of W turn with jl
+        const double x = W[p * 3 + i], y = W[q * 3 + i];
+        W[p * 3 + i] = jlc * x + jls * y, W[q * 3 + i] = -jls * x + jlc * y;
+    }
+    for (int i = 0; i < 3; ++i) {  // columns of U with jl^T, columns of W and V with jr
+        double x = U[i * 3 + p], y = U[i * 3 + q];
+        U[i * 3 + p] = jlc * x + jls * y, U[i * 3 + q] = -jls * x + jlc * y;
+        x = W[i * 3 + p], y = W[i * 3 + q];
+        W[i * 3 + p] = jrc * x - jrs * y, W[i * 3 + q] = jrs * x + jrc * y;
+        x = V[i * 3 + p], y = V[i * 3 + q];
+        V[i * 3 + p] = jrc * x - jrs * y, V[i * 3 + q] = jrs * x + jrc * y;
+    }
+    max_diag = std::fmax(max_diag, std::fmax(std::fabs(W[p * 3 + p]), std::fabs(W[q * 3 + q])));
+}
 inline void svd3(const double *A, double *U, double *S, double *V) {
-    double W[9], Vv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    std::memcpy(W, A, 72);
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        bool rotated = false;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                double al = 0, be = 0, ga = 0;
-                for (int i = 0; i < 3; ++i) al += W[3 * i + p] * W[3 * i + p], be += W[3 * i + q] * W[3 * i + q], ga += W[3 * i + p] * W[3 * i + q];
-                if (ga == 0.0 || std::fabs(ga) <= 1e-17 * std::sqrt(al * be)) continue;
-                rotated = true;
-                const double zeta = (be - al) / (2.0 * ga);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
-                for (int i = 0; i < 3; ++i) {
-                    const double wp = W[3 * i + p], wq = W[3 * i + q];
-                    W[3 * i + p] = c * wp - s * wq, W[3 * i + q] = s * wp + c * wq;
-                    const double vp = Vv[3 * i + p], vq = Vv[3 * i + q];
-                    Vv[3 * i + p] = c * vp - s * vq, Vv[3 * i + q] = s * vp + c * vq;
-                }
-            }
-        if (!rotated) break;
+    double W[9], scale = 0;
+    for (int i = 0; i < 9; ++i) scale = std::fmax(scale, std::fabs(A[i]));
+    if (scale == 0) scale = 1;
+    for (int i = 0; i < 9; ++i) W[i] = A[i] / scale, U[i] = V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    double max_diag = std::fmax(std::fabs(W[0]), std::fmax(std::fabs(W[4]), std::fabs(W[8])));
+    for (int guard = 0; guard < 100; ++guard) {
+        bool any = false;
+        svd3_pair(W, U, V, 1, 0, max_diag, any);
+        svd3_pair(W, U, V, 2, 0, max_diag, any);
+        svd3_pair(W, U, V, 2, 1, max_diag, any);
+        if (!any) break;
     }
-    double sv[3];
-    int order[3] = {0, 1, 2};
-    for (int k = 0; k < 3; ++k) sv[k] = std::sqrt(W[k] * W[k] + W[3 + k] * W[3 + k] + W[6 + k] * W[6 + k]);
-    std::stable_sort(order, order + 3, [&](int a, int b) { return sv[a] > sv[b]; });
-    for (int k = 0; k < 3; ++k) {
-        const int c = order[k];
-        S[k] = sv[c];
-        for (int i = 0; i < 3; ++i) {
-            U[3 * i + k] = sv[c] > 0 ? W[3 * i + c] / sv[c] : 0.0;
-            V[3 * i + k] = Vv[3 * i + c];
+    for (int i = 0; i < 3; ++i) {
+        const double a = W[i * 4];
+        S[i] = std::fabs(a) * scale;
+        if (a < 0)
+            for (int r = 0; r < 3; ++r) U[r * 3 + i] = -U[r * 3 + i];
+    }
+    auto swap_cols = [&](int a, int b) {
+        double tmp = S[a];
+        S[a] = S[b], S[b] = tmp;
+        for (int r = 0; r < 3; ++r) {
+            tmp = U[r * 3 + a], U[r * 3 + a] = U[r * 3 + b], U[r * 3 + b] = tmp;
+            tmp = V[r * 3 + a], V[r * 3 + a] = V[r * 3 + b], V[r * 3 + b] = tmp;
         }
-    }
+    };
+    // descending order, first maximum wins (Eigen: swap with the largest of the tail, stop at a zero)
+    if (S[1] > S[0] && S[1] >= S[2]) swap_cols(0, 1);
+    else if (S[2] > S[0] && S[2] > S[1]) swap_cols(0, 2);
+    if (S[0] != 0 && S[2] > S[1]) swap_cols(1, 2);
 }
 
-// arun: the rotation V diag(1, 1, det(V U^T)) U^T.  Built from the two leading singular pairs and the cross products that complete them
-// to right-handed frames, which is the same matrix and also covers a cross-covariance of rank two (two correspondences).
+// arun (math/arun.cpp:33-56): R = V U^T; when its determinant is negative, the third column of V is negated
 inline void arun(const double *H, double *R) {
     double U[9], S[3], V[9];
     svd3(H, U, S, V);
-    double u1[3] = {U[0], U[3], U[6]}, u2[3] = {U[1], U[4], U[7]}, v1[3] = {V[0], V[3], V[6]}, v2[3] = {V[1], V[4], V[7]}, u3[3], v3[3];
-    cross(u1, u2, u3), cross(v1, v2, v3);
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) R[3 * r + c] = v1[r] * u1[c] + v2[r] * u2[c] + v3[r] * u3[c];
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) R[3 * r + c] = V[3 * r] * U[3 * c] + V[3 * r + 1] * U[3 * c + 1] + V[3 * r + 2] * U[3 * c + 2];
+        const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+        if (!(det < 0)) break;
+        for (int r = 0; r < 3; ++r) V[3 * r + 2] = -V[3 * r + 2];
+    }
 }
 
 // Cross-covariance sum (f' - c')(f - c)^T over correspondences given as (f = vector of view "1" of the adapter, f' = of view "2")
