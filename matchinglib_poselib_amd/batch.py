@@ -41,12 +41,12 @@ def gather_records(local: np.ndarray, num_pairs: int, rank: int, world: int, dev
     buf = np.zeros(cap, RECORD_DTYPE)
     buf["pair_id"] = -1
     buf[: len(local)] = local
-    t = torch.from_numpy(buf.view(np.uint8).reshape(cap, RECORD_DTYPE.itemsize).copy())
-    if device is not None:
-        t = t.to(device)
     if world == 1:
-        allr = t.cpu().numpy()
+        allr = buf.view(np.uint8).reshape(cap, RECORD_DTYPE.itemsize)   # nothing to exchange
     else:
+        t = torch.from_numpy(buf.view(np.uint8).reshape(cap, RECORD_DTYPE.itemsize).copy())
+        if device is not None:
+            t = t.to(device)
         out = torch.empty((world * cap, RECORD_DTYPE.itemsize), dtype=torch.uint8, device=t.device)
         dist.all_gather_into_tensor(out, t, group=group)
         allr = out.cpu().numpy()
@@ -87,6 +87,11 @@ def gather_match_lists(local, num_pairs: int, rank: int, world: int, root: int =
 class _PairResult(C.Structure):
     _fields_ = [("n_matches", C.c_int32), ("n_inliers", C.c_int32), ("n_good", C.c_int32), ("status", C.c_int32), ("iters", C.c_int32),
                 ("pad", C.c_int32), ("E", C.c_double * 9), ("R", C.c_double * 9), ("t", C.c_double * 3)]
+
+
+_PAIR_RESULT_DTYPE = np.dtype([("n_matches", np.int32), ("n_inliers", np.int32), ("n_good", np.int32), ("status", np.int32), ("iters", np.int32),
+                               ("pad", np.int32), ("E", np.float64, (9,)), ("R", np.float64, (9,)), ("t", np.float64, (3,))])
+assert _PAIR_RESULT_DTYPE.itemsize == C.sizeof(_PairResult)
 
 
 def process_pair_on_device(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, th_pix: float = 0.8, max_iters: int = 1000,
@@ -144,16 +149,13 @@ def process_pairs_batched(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, seeds, t
                                            d_kp2.data_ptr(), k0, k1, float(th), int(max_iters), float(confidence), 1 if refit else 0, sd.ctypes.data,
                                            float(dist), C.addressof(res), matches_out.data_ptr() if matches_out is not None else None, st),
           "mlpl_pair_pose_batch_dev")
+    raw = np.frombuffer(res, _PAIR_RESULT_DTYPE, count=B)   # the library's result block, field by field (no per-pair Python)
     rec = np.zeros(B, RECORD_DTYPE)
     rec["pair_id"] = np.arange(B) if pair_ids is None else np.asarray(pair_ids)
-    for i in range(B):
-        r = res[i]
-        rec["n_matches"][i], rec["status"][i] = r.n_matches, r.status
-        if r.status == 0:
-            rec["n_inliers"][i] = r.n_inliers
-            rec["E"][i] = np.frombuffer(r.E, np.float64)
-            rec["R"][i] = np.frombuffer(r.R, np.float64)
-            rec["t"][i] = np.frombuffer(r.t, np.float64)
+    rec["n_matches"], rec["status"] = raw["n_matches"], raw["status"]
+    ok = raw["status"] == 0
+    for f in ("n_inliers", "E", "R", "t"):
+        rec[f][ok] = raw[f][ok]
     return rec
 
 
