@@ -156,6 +156,24 @@ def run(ctx, dev, cpu_baseline=True):
             ou = ora.usac_essential(p1, p2, th, 12345, sorted_idx=si)
             out[nm]["cpu_baseline"] = {"ms_per_call": (time.perf_counter() - tc) * 1e3, "cores": 1, "kind": "port", "sample": "the same call",
                                        "same_result": bool(np.array_equal(ou["flags"], ur["flags"]))}
+    # ---- USAC with ConfigUSAC's default degeneracy handling (DEGEN_USAC_INTERNAL; tests after new best models and local optimisations),
+    #      on the C3 scene and on a pure rotation of the same size ----
+    pr1, pr2, _, _, mask_r, th_r = synth.pose_scene(n, 0.5, seed=20260103, t_len=0.0)
+    for nm, (a1, a2, tha) in (("usac_degeneracy_tests_general", (p1, p2, th)), ("usac_degeneracy_tests_rotation", (pr1, pr2, th_r))):
+        uc = lambda: pose.usac_essential(a1, a2, tha, 12345, check_degeneracy=3, ctx=ctx)  # noqa: E731
+        ur = uc()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            uc()
+        dt = (time.perf_counter() - t0) / 10
+        out[nm] = {"metric": "one estimateEssentialOrPoseUSAC-shaped call with degeneracyCheck = DEGEN_USAC_INTERNAL (5000 correspondences)",
+                   "ms_per_call": dt * 1e3, "n_inliers": int(ur["final"][5]), "rotation_only_inliers": int(ur["degen"][1]),
+                   "no_motion_inliers": int(ur["degen"][2]), "degeneracy_test_launches": int(ur["stats"][5])}
+        if cpu_baseline:
+            tc = time.perf_counter()
+            ou = ora.usac_essential_degen(a1, a2, tha, 12345, check_degeneracy=3)
+            out[nm]["cpu_baseline"] = {"ms_per_call": (time.perf_counter() - tc) * 1e3, "cores": 1, "kind": "port", "sample": "the same call",
+                                       "rotation_only_inliers": int(ou["degen"][1])}
     # ---- C4: L2 ----
     q, tt = synth.sift_pair(4096, 4096, seed=20260104)
     dq = torch.from_numpy(q).to(dev)
