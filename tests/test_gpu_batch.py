@@ -200,3 +200,29 @@ def test_batched_correspondence_sets_equal_the_single_problem_entries(ctx, recov
         else:
             assert g["n_good"] == 0 and not g["R"].any()
         assert np.array_equal(mh[i, :n], m.cpu().numpy()), i
+
+
+def test_two_batched_calls_in_flight_give_the_same_records(ctx):
+    """batch.BatchLanes: the batch split over two library contexts / streams / host threads -- byte-identical records and match lists."""
+    import torch
+    from matchinglib_poselib_amd import batch, synth
+
+    dev = torch.device("cuda", 0)
+    sps = [synth.stereo_pair(1024, seed=900 + i, unmatched_frac=0.3) for i in range(5)]
+    K = sps[0]["K"]
+    B = 13
+    stk = [torch.from_numpy(np.stack([sps[i % 5][k] for i in range(B)])).to(dev) for k in ("desc1", "desc2", "kp1", "kp2")]
+    seeds = [7 + i for i in range(B)]
+    m1 = torch.zeros((B, 1024, 4), dtype=torch.int32, device=dev)
+    m2 = torch.zeros((B, 1024, 4), dtype=torch.int32, device=dev)
+    one = batch.process_pairs_batched(ctx, *stk, K, K, seeds, matches_out=m1)
+    lanes = batch.BatchLanes(0, lanes=2, first_ctx=ctx)
+    try:
+        two = lanes.process(*stk, K, K, seeds, matches_out=m2)
+        three = batch.BatchLanes(0, lanes=3).process(*stk, K, K, seeds)
+    finally:
+        lanes.close()
+    assert one.tobytes() == two.tobytes() == three.tobytes()
+    for b in range(B):
+        k = int(one["n_matches"][b])
+        assert torch.equal(m1[b, :k], m2[b, :k])
