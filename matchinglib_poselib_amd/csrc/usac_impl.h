@@ -32,6 +32,7 @@ namespace {
 constexpr int kUsacBatch = 128;
 constexpr int kUsacLoReps = 5, kUsacLoSample = 14, kUsacLoSteps = 4, kUsacLoEvals = 2 + kUsacLoSteps;
 constexpr int kUsacLoThreads = 512;
+constexpr int kUsacLoMaxRows = 512;  // rows of kUsacLoThreads correspondences a local-optimisation workgroup walks: n <= 262144
 
 struct UsacGeom {
     double T1[9], T2[9], T2t[9], T1i[9], T2ti[9];
@@ -230,9 +231,11 @@ struct UsacLoIn {           // per repetition
 struct UsacLoLds {
     Jacobi9Lds J;
     double red[8][45];
+    double stage[15][kUsacLoThreads];  // usac_reduce45
     double F[9], E[9];
     int scan[kUsacLoThreads / 64 + 1];
     int total, K, sweeps;
+    int rw[kUsacLoMaxRows * (kUsacLoThreads / 64)];  // members of the fit set per (row, wave), then their exclusive prefix in index order
 };
 
 // Fit of REFINE_WEIGHTS from the 45 accumulated products in L.red[0] (wave 0): smallest eigenvector of the covariance matrix, rank-2
@@ -296,23 +299,26 @@ __device__ __forceinline__ void usac_fit_from_cov(UsacLoLds &L, const UsacGeom &
     }
 }
 
-// block-wide sum of 45 per-thread accumulators into L.red[0]
+// block-wide sum of 45 per-thread accumulators into L.red[0]: in three slices of fifteen, a slice staged value-major in LDS (512
+// consecutive doubles per value), thirty-two threads per value add sixteen entries each and finish with five shuffle steps inside their
+// half wave.  (Six butterfly steps per value -- 540 ds_bpermute per wave and fit -- cost the kernel ~15 us per fit.)
 __device__ __forceinline__ void usac_reduce45(UsacLoLds &L, const double *acc, int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int v = tid >> 5, part = tid & 31;
 #pragma unroll
-    for (int k = 0; k < 45; ++k) {
-        double v = acc[k];
+    for (int c = 0; c < 3; ++c) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) L.red[wave][k] = v;
+        for (int k = 0; k < 15; ++k) L.stage[k][tid] = acc[15 * c + k];
+        __syncthreads();
+        double sacc = 0;
+        if (v < 15) {
+#pragma unroll
+            for (int e = 0; e < kUsacLoThreads / 32; ++e) sacc += L.stage[v][part + 32 * e];
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off);
+        if (v < 15 && part == 0) L.red[0][15 * c + v] = sacc;
+        __syncthreads();
     }
-    __syncthreads();
-    if (tid < 45) {
-        double s = 0;
-        for (int w = 0; w < kUsacLoThreads / 64; ++w) s += L.red[w][tid];
-        L.red[0][tid] = s;
-    }
-    __syncthreads();
 }
 
 __device__ __forceinline__ void usac_cov_add(double *acc, const double *a, const double *c, double w) {
@@ -339,8 +345,11 @@ __global__ __launch_bounds__(kUsacLoThreads) void usac_lo_kernel(const double *_
     UsacLoOut *O = reinterpret_cast<UsacLoOut *>(out_base + (size_t)rep * out_stride);
     unsigned long long *rows = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(O) + sizeof(UsacLoOut));
     double *err = err_scratch + (size_t)rep * n;
-    const int chunk = (n + kUsacLoThreads - 1) / kUsacLoThreads;
-    const int i0 = min(tid * chunk, n), i1 = min(i0 + chunk, n);
+    // correspondence i = row * 512 + thread: every pass over the correspondences is coalesced (a contiguous chunk per thread made each
+    // wave-wide load touch 64 cache lines, ~10 us per pass on the one CU a repetition runs on)
+    const int nrows = (n + kUsacLoThreads - 1) / kUsacLoThreads;
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int kWaves = kUsacLoThreads / 64;
     const double step = (lo_mult * thr - thr) / kUsacLoSteps;
     int eval = 0;
     int fit_pts = 0;
@@ -374,10 +383,13 @@ __global__ __launch_bounds__(kUsacLoThreads) void usac_lo_kernel(const double *_
         for (int k = 0; k < 9; ++k) E[k] = L.E[k], F[k] = L.F[k];
         // ---- evaluation: errors in point order, inlier count, bit row in pool order ----
         int cnt = 0;
-        for (int i = i0; i < i1; ++i) {
-            const double e = usac_sampson(E, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
-            err[i] = e;
-            cnt += e < thr ? 1 : 0;
+        for (int k = 0; k < nrows; ++k) {
+            const int i = k * kUsacLoThreads + tid;
+            if (i < n) {
+                const double e = usac_sampson(E, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+                err[i] = e;
+                cnt += e < thr ? 1 : 0;
+            }
         }
         {
             int v = cnt;
@@ -397,8 +409,7 @@ __global__ __launch_bounds__(kUsacLoThreads) void usac_lo_kernel(const double *_
         {   // the bit row in pool order: the same error from the points gathered in that order (coalesced; err[pool[j]] would be a
             // dependent gather per word)
             unsigned long long *row = rows + (size_t)eval * words;
-            const int lane = tid & 63;
-            for (int w = tid >> 6; w < words; w += kUsacLoThreads / 64) {
+            for (int w = wave; w < words; w += kWaves) {
                 const int j = w * 64 + lane;
                 bool inl = false;
                 if (j < n) {
@@ -415,30 +426,31 @@ __global__ __launch_bounds__(kUsacLoThreads) void usac_lo_kernel(const double *_
         // ---- the point set of the next fit: the first K members (ascending index) of {err < limit} ----
         const double limit = phase < 0 ? lo_mult * thr : (lo_mult * thr) - (phase + 1) * step;
         const int K = phase < 0 ? n : L.K;  // findInliers' own count for the first refit, evaluateModel's count afterwards
-        int mine = 0;
-        for (int i = i0; i < i1; ++i) mine += err[i] < limit ? 1 : 0;
-        int incl = mine;  // inclusive scan over the wave, then over the waves
-        {
-            const int lane = tid & 63;
+        for (int k = 0; k < nrows; ++k) {  // members of the set per (row, wave)
+            const int i = k * kUsacLoThreads + tid;
+            const unsigned long long b = __ballot(i < n && err[i] < limit);
+            if (lane == 0) L.rw[k * kWaves + wave] = __popcll(b);
+        }
+        __syncthreads();
+        if (tid < 64) {  // exclusive prefix of those counts in index order = (row, wave) order; the total
+            const int T = nrows * kWaves, per = (T + 63) / 64, b0 = min(tid * per, T), b1 = min(b0 + per, T);
+            int sum = 0;
+            for (int t = b0; t < b1; ++t) sum += L.rw[t];
+            int incl = sum;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const int o = __shfl_up(incl, off);
-                if (lane >= off) incl += o;
+                if (tid >= off) incl += o;
             }
-            if (lane == 63) L.scan[tid >> 6] = incl;
+            int run = incl - sum;
+            for (int t = b0; t < b1; ++t) {
+                const int v = L.rw[t];
+                L.rw[t] = run;
+                run += v;
+            }
+            if (tid == 63) L.total = incl;
         }
         __syncthreads();
-        if (tid == 0) {
-            int s = 0;
-            for (int w = 0; w < kUsacLoThreads / 64; ++w) {
-                const int v = L.scan[w];
-                L.scan[w] = s;
-                s += v;
-            }
-            L.total = s;
-        }
-        __syncthreads();
-        int rank = L.scan[tid >> 6] + incl - mine;
         const int used = min(L.total, K);
         if (phase < 0 && tid == 0) O->cnt2 = L.total;
         if (used < 5) {  // generateRefinedModel refuses (or, after the first evaluation, the repetition ends: temp_inliers < min sample)
@@ -449,9 +461,14 @@ __global__ __launch_bounds__(kUsacLoThreads) void usac_lo_kernel(const double *_
         double acc[45];
 #pragma unroll
         for (int k = 0; k < 45; ++k) acc[k] = 0;
-        for (int i = i0; i < i1; ++i) {
-            if (!(err[i] < limit)) continue;
-            if (rank++ >= K) break;
+        for (int k = 0; k < nrows; ++k) {
+            if (L.rw[k * kWaves + wave] >= K) break;  // wave-uniform: everything from here on is beyond the first K members
+            const int i = k * kUsacLoThreads + tid;
+            const bool member = i < n && err[i] < limit;
+            const unsigned long long b = __ballot(member);
+            if (!member) continue;
+            const int rank = L.rw[k * kWaves + wave] + __popcll(b & ((1ull << lane) - 1ull));
+            if (rank >= K) continue;
             double a[3], c[3];
             usac_normalise(g.T1, p1[2 * i], p1[2 * i + 1], a);
             usac_normalise(g.T2, p2[2 * i], p2[2 * i + 1], c);
@@ -617,6 +634,10 @@ struct UsacRun {
         for (unsigned i = 1; i < n; ++i) {  // std::random_shuffle (libstdc++): swap(i, rand() % (i + 1))
             const unsigned j = (unsigned)rng.next() % (i + 1);
             if (i != j) std::swap(pool[i], pool[j]);
+        }
+        if (n > (unsigned)kUsacLoMaxRows * kUsacLoThreads) {
+            set_error("mlpl_usac_essential: more than %d correspondences", kUsacLoMaxRows * kUsacLoThreads);
+            return MLPL_E_UNSUPPORTED;
         }
         flags.assign(n, 0);
         words = (int)((n + 63) / 64);
