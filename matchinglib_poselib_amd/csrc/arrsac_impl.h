@@ -434,6 +434,7 @@ __global__ __launch_bounds__(kArrRefineThreads) void arrsac_refine_kernel(const 
                                                              const double *__restrict__ E_init, double th, double *__restrict__ E_out,
                                                              int32_t *__restrict__ info) {
     __shared__ double red[kArrRefineThreads / 64][46];
+    __shared__ double stage[16][kArrRefineThreads];
     __shared__ Jacobi9Lds J;
     __shared__ double F3[9];
     __shared__ double s_err_old;
@@ -485,21 +486,26 @@ __global__ __launch_bounds__(kArrRefineThreads) void arrsac_refine_kernel(const 
                 for (int c = a; c < 9; ++c) acc[t++] += f2 * r[a] * r[c];
             acc[45] += f2;
         }
+        // block-wide sums: three slices of sixteen staged value-major in LDS, thirty-two threads per value add sixteen entries each and
+        // finish inside their half wave (six butterfly steps per value were 552 ds_bpermute per wave and round)
 #pragma unroll
-        for (int k = 0; k < 46; ++k) {
-            double v = acc[k];
+        for (int c0 = 0; c0 < 48; c0 += 16) {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if (lane == 0) red[wave][k] = v;
-        }
-        __syncthreads();
-        if (wave == 0) {
-            if (lane < 46) {
-                double sacc = 0;
-                for (int wv = 0; wv < kArrRefineThreads / 64; ++wv) sacc += red[wv][lane];
-                red[0][lane] = sacc;
+            for (int k = 0; k < 16; ++k)
+                if (c0 + k < 46) stage[k][tid] = acc[c0 + k];
+            __syncthreads();
+            const int v = tid >> 5, part = tid & 31;
+            double sacc = 0;
+            if (c0 + v < 46) {
+#pragma unroll
+                for (int q = 0; q < kArrRefineThreads / 32; ++q) sacc += stage[v][part + 32 * q];
             }
-            wave_sync();
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off);
+            if (c0 + v < 46 && part == 0) red[0][c0 + v] = sacc;
+            __syncthreads();
+        }
+        if (wave == 0) {
             const double wn2 = red[0][45];
             if (lane == 0) {
                 int t = 0;
