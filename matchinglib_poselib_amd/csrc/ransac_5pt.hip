@@ -37,6 +37,7 @@
 #include <climits>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>

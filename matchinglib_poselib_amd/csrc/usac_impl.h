@@ -1286,22 +1286,44 @@ struct UsacRun {
                 } else {
                     for (int j = 0; j < 3; ++j) cd.index[j] = (int)outlier_indices[smp[j]];
                     cd.index[3] = dg_sample_rot[0], cd.index[4] = dg_sample_rot[1];
-                    double f1[5][3], f2[5][3], R[9], t[3];
-                    for (int j = 0; j < 5; ++j) view1((unsigned)cd.index[j], f1[j]), view2((unsigned)cd.index[j], f2[j]);
-                    dgm::eigensolver(f1, f2, 5, dg_R, R, t);
-                    const double len = std::sqrt(t[0] * t[0] + (t[1] * t[1] + t[2] * t[2]));
-                    cd.skip = near_zero(len * 100);
-                    std::memset(cd.E, 0, 72);
+                    std::memset(cd.E, 0, 72);  // solved below, several candidates at a time
+                }
+                cd.after = r2;
+                cands.push_back(cd);
+            }
+            if (!nomot) {
+                // The eigensolver of a candidate (Levenberg-Marquardt on five correspondences, ~6 us) is independent of every other
+                // candidate: the batch is solved by a few host threads, each on its own slice.
+                auto solve_slice = [&](size_t c0, size_t c1) {
+                    for (size_t c = c0; c < c1; ++c) {
+                        Cand &cd = cands[c];
+                        double f1[5][3], f2[5][3], R[9], t[3];
+                        for (int j = 0; j < 5; ++j) view1((unsigned)cd.index[j], f1[j]), view2((unsigned)cd.index[j], f2[j]);
+                        dgm::eigensolver(f1, f2, 5, dg_R, R, t);
+                        const double len = std::sqrt(t[0] * t[0] + (t[1] * t[1] + t[2] * t[2]));
+                        cd.skip = near_zero(len * 100);
+                        if (!cd.skip) {
+                            for (int k = 0; k < 3; ++k) cd.t[k] = t[k] / len;
+                            dgm::e_from_rt(R, cd.t, cd.E);
+                        }
+                    }
+                };
+                const size_t nc = cands.size();
+                const unsigned hw = std::thread::hardware_concurrency();
+                const size_t workers = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 8), nc / 16);
+                if (workers >= 2) {
+                    std::vector<std::thread> pool;
+                    for (size_t w = 1; w < workers; ++w) pool.emplace_back(solve_slice, nc * w / workers, nc * (w + 1) / workers);
+                    solve_slice(0, nc / workers);
+                    for (auto &th : pool) th.join();
+                } else
+                    solve_slice(0, nc);
+                for (Cand &cd : cands)
                     if (!cd.skip) {
-                        for (int k = 0; k < 3; ++k) cd.t[k] = t[k] / len;
-                        dgm::e_from_rt(R, cd.t, cd.E);
                         h_dg[B].kind = 3;
                         std::memcpy(h_dg[B].m, cd.E, 72);
                         cd.model = B++;
                     }
-                }
-                cd.after = r2;
-                cands.push_back(cd);
             }
             const uint64_t *rows = nullptr;
             if (B > 0 && (rc = dg_rows(B, &rows))) return rc;
