@@ -14,8 +14,7 @@
 //                                      Levenberg-Marquardt on the gradient with a forward-difference Jacobian (Eigen's port of MINPACK
 //                                      lmdif: ftol 5e-5, xtol 10 eps, at most 100 evaluations), translation = eigenvector
 //   math/cayley.cpp                    the Cayley parameters
-// Stated deviation: the translation is the eigenvector of the SMALLEST eigenvalue of M.  OpenGV takes column 0 of Eigen::EigenSolver,
-// which orders nothing (oracle/ref_drivers/usac_ref.cpp, --eigvec-smallest).
+// The translation is the eigenvector OpenGV takes: column 0 of Eigen::EigenSolver's unordered decomposition (eigen_diag_order3 below).
 #pragma once
 #include <algorithm>
 #include <cfloat>
@@ -623,8 +622,149 @@ inline void sym_eig3(const double *Min, double *ev, double (*vec)[3]) {
     }
 }
 
+// ---- the order of Eigen::EigenSolver's eigenvalues on a 3 x 3 matrix ----------------------------------------------------------------
+// OpenGV takes the translation from COLUMN 0 of Eigen::EigenSolver's eigenvectors and its length from eigenvalues 1 and 2
+// (modules/main.cpp:646-659).  EigenSolver does not order its eigenvalues: on these symmetric matrices the smallest one -- the
+// eigenvector that would be the translation -- sits at position 0 in about a third of the cases.  Which position an eigenvalue gets is
+// a property of Eigen::RealSchur's iteration (Householder reduction to Hessenberg form, EISPACK hqr: Francis double-shift QR steps with
+// deflation from the bottom, Wilkinson / MATLAB exceptional shifts after 10 / 30 iterations, 2 x 2 blocks with real eigenvalues split by
+// a rotation), restated here for three rows.  Once the iteration has converged, entries at rounding-noise level decide what the next
+// reflector does, so the reflectors are formed and applied in Eigen's formulation and operation order; on identical input the diagonal
+// comes out in Eigen's order (probe against the Eigen the reference vendors: 60 000 of 60 000 matrices, values to 7e-16).
+// Householder reflector H = I - tau (1, ess)(1, ess)^T with H v = beta e1, and its application to a block, in the formulation (and
+// the operation order) of Eigen's makeHouseholder / applyHouseholderOnTheLeft / OnTheRight: entries at rounding-noise level decide
+// what the next reflector does once the iteration has converged, so the arithmetic has to be the same.
+struct Refl {
+    double ess[2], tau, beta;
+    int n;  // length of v
+};
+inline Refl make_reflector(const double *v, int n) {
+    Refl h;
+    h.n = n, h.ess[0] = h.ess[1] = 0;
+    double tail = 0;
+    for (int i = 1; i < n; ++i) tail += v[i] * v[i];
+    const double c0 = v[0];
+    if (tail == 0.0) {
+        h.tau = 0, h.beta = c0;
+    } else {
+        h.beta = std::sqrt(c0 * c0 + tail);
+        if (c0 >= 0) h.beta = -h.beta;
+        for (int i = 1; i < n; ++i) h.ess[i - 1] = v[i] / (c0 - h.beta);
+        h.tau = (h.beta - c0) / h.beta;
+    }
+    return h;
+}
+// rows r0 .. r0 + n - 1, columns c0 .. c1 - 1
+inline void apply_left(double T[3][3], const Refl &h, int r0, int c0, int c1) {
+    for (int j = c0; j < c1; ++j) {
+        double tmp = 0;
+        for (int i = 1; i < h.n; ++i) tmp = (i == 1) ? h.ess[0] * T[r0 + 1][j] : tmp + h.ess[i - 1] * T[r0 + i][j];
+        tmp += T[r0][j];
+        T[r0][j] -= h.tau * tmp;
+        for (int i = 1; i < h.n; ++i) T[r0 + i][j] -= (h.tau * h.ess[i - 1]) * tmp;
+    }
+}
+// columns k0 .. k0 + n - 1, rows r0 .. r1 - 1
+inline void apply_right(double T[3][3], const Refl &h, int k0, int r0, int r1) {
+    for (int i = r0; i < r1; ++i) {
+        double tmp = 0;
+        for (int j = 1; j < h.n; ++j) tmp = (j == 1) ? T[i][k0 + 1] * h.ess[0] : tmp + T[i][k0 + j] * h.ess[j - 1];
+        tmp += T[i][k0];
+        T[i][k0] -= h.tau * tmp;
+        for (int j = 1; j < h.n; ++j) T[i][k0 + j] -= (h.tau * tmp) * h.ess[j - 1];
+    }
+}
+inline void eigen_diag_order3(const double *M, double *d) {
+    double T[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) T[r][c] = M[3 * r + c];
+    {  // Hessenberg form (HessenbergDecomposition): the reflector of (T10, T20) on rows / columns 1, 2
+        const double v[2] = {T[1][0], T[2][0]};
+        const Refl h = make_reflector(v, 2);
+        T[1][0] = h.beta;
+        apply_left(T, h, 1, 1, 3);
+        apply_right(T, h, 1, 0, 3);
+        T[2][0] = 0.0;
+    }
+    int iu = 2, iter = 0, total = 0;
+    double exshift = 0;
+    double norm = 0;
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < (j + 2 < 3 ? j + 2 : 3); ++i) norm += std::fabs(T[i][j]);
+    if (norm != 0)
+        while (iu >= 0) {
+            int il = iu;
+            while (il > 0) {
+                double s = std::fabs(T[il - 1][il - 1]) + std::fabs(T[il][il]);
+                if (s == 0.0) s = norm;
+                if (std::fabs(T[il][il - 1]) < DBL_EPSILON * s) break;
+                il--;
+            }
+            if (il == iu) {
+                T[iu][iu] += exshift;
+                if (iu > 0) T[iu][iu - 1] = 0.0;
+                iu--;
+                iter = 0;
+            } else if (il == iu - 1) {
+                const double a = T[iu - 1][iu - 1], dd = T[iu][iu], b = T[iu - 1][iu], c = T[iu][iu - 1];
+                const double p = 0.5 * (a - dd), q = p * p + c * b;
+                T[iu][iu] += exshift, T[iu - 1][iu - 1] += exshift;
+                if (q >= 0) {  // two real eigenvalues: the rotation puts the eigenvalue of the eigenvector (p +- z, c) first
+                    const double z = std::sqrt(std::fabs(q)), mean = 0.5 * (a + dd) + exshift;
+                    if (p >= 0)
+                        T[iu - 1][iu - 1] = mean + z, T[iu][iu] = mean - z;
+                    else
+                        T[iu - 1][iu - 1] = mean - z, T[iu][iu] = mean + z;
+                    T[iu][iu - 1] = 0.0;
+                }
+                if (iu > 1) T[iu - 1][iu - 2] = 0.0;
+                iu -= 2;
+                iter = 0;
+            } else {  // iu = 2, il = 0: one Francis step on the whole matrix
+                double s0 = T[2][2], s1 = T[1][1], s2 = T[2][1] * T[1][2];
+                if (iter == 10) {
+                    exshift += s0;
+                    for (int i = 0; i <= iu; ++i) T[i][i] -= s0;
+                    const double s = std::fabs(T[2][1]) + std::fabs(T[1][0]);
+                    s0 = 0.75 * s, s1 = 0.75 * s, s2 = -0.4375 * s * s;
+                }
+                if (iter == 30) {
+                    double s = (s1 - s0) / 2.0;
+                    s = s * s + s2;
+                    if (s > 0) {
+                        s = std::sqrt(s);
+                        if (s1 < s0) s = -s;
+                        s = s + (s1 - s0) / 2.0;
+                        s = s0 - s2 / s;
+                        exshift += s;
+                        for (int i = 0; i <= iu; ++i) T[i][i] -= s;
+                        s0 = s1 = s2 = 0.964;
+                    }
+                }
+                ++iter, ++total;
+                if (total > 120) break;
+                const double Tmm = T[0][0], r = s0 - Tmm, s = s1 - Tmm;
+                const double v[3] = {(r * s - s2) / T[1][0] + T[0][1], T[1][1] - Tmm - r - s, T[2][1]};
+                const Refl h1 = make_reflector(v, 3);
+                if (h1.beta != 0.0) {
+                    apply_left(T, h1, 0, 0, 3);
+                    apply_right(T, h1, 0, 0, 3);
+                }
+                const double v2[2] = {T[1][0], T[2][0]};
+                const Refl h2 = make_reflector(v2, 2);
+                if (h2.beta != 0.0) {
+                    T[1][0] = h2.beta;
+                    apply_left(T, h2, 1, 1, 3);
+                    apply_right(T, h2, 1, 0, 3);
+                }
+                T[2][0] = 0.0;
+            }
+        }
+    d[0] = T[0][0], d[1] = T[1][1], d[2] = T[2][2];
+}
+
 // opengv::relative_pose::eigensolver on n correspondences (f1 = adapter view 1, f2 = view 2), starting from R_init.  t is not normalised:
-// its length is what OpenGV returns (the root sum of squares of the two other eigenvalues).
+// its length is what OpenGV returns (the root sum of squares of the eigenvalues at positions 1 and 2).
 inline void eigensolver(const double (*f1)[3], const double (*f2)[3], int n, const double *R_init, double *R, double *t) {
     EigSums Sx;
     eig_sums(f1, f2, n, Sx);
@@ -636,10 +776,14 @@ inline void eigensolver(const double (*f1)[3], const double (*f2)[3], int n, con
     const double scale = 1 + x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
     for (int k = 0; k < 9; ++k) R[k] = (1 / scale) * Rr[k];
     compose_M(Sx, Rr, nullptr, M);
-    double ev[3], vec[3][3];
-    sym_eig3(M, ev, vec);
-    const double mag = std::sqrt(ev[1] * ev[1] + ev[2] * ev[2]);
-    for (int k = 0; k < 3; ++k) t[k] = mag * vec[0][k];
+    double ev[3], vec[3][3], d[3];
+    sym_eig3(M, ev, vec);          // accurate eigenpairs ...
+    eigen_diag_order3(M, d);       // ... and the position Eigen::EigenSolver gives each eigenvalue
+    int k0 = 0;
+    for (int k = 1; k < 3; ++k)
+        if (std::fabs(ev[k] - d[0]) < std::fabs(ev[k0] - d[0])) k0 = k;
+    const double mag = std::sqrt(d[1] * d[1] + d[2] * d[2]);
+    for (int k = 0; k < 3; ++k) t[k] = mag * vec[k0][k];
     double f2r[3], flow[3];
     matvec(R, f2[0], f2r);
     for (int k = 0; k < 3; ++k) flow[k] = f1[0][k] - f2r[k];

@@ -205,6 +205,10 @@ int oracle_usac_essential_degen(const double *p1, const double *p2, int n, doubl
                                 uint8_t *inlier_flags, double *results, double *events, int event_cap, int *n_events, double *degen,
                                 uint8_t *flags_rot, uint8_t *flags_nomot);
 
+/* The eigenvalues of a 3 x 3 matrix (row-major) in the order Eigen::EigenSolver<Matrix3d> returns them (OpenGV's eigensolver takes its
+ * translation from position 0): Eigen::RealSchur restated; pinned by tests/golden/eigen_order3.npz. */
+void oracle_eigen_order3(const double *M, double *d);
+
 #ifdef __cplusplus
 }
 #endif

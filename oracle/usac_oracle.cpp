@@ -23,8 +23,8 @@
 // The degeneracy part is pinned by oracle/_ref/usac_ref with check_degeneracy (tests/golden/usac_degen_trace.npz).  Its eigensolver is
 // restated as what it computes, not how: a damped Newton iteration on the smallest eigenvalue of M(R) (Jacobi eigenvalues, central
 // differences) from the same start rotation.  OpenGV's own Levenberg-Marquardt follows the rounding noise of its forward-difference
-// Jacobian (tests/test_usac_degen_math.py), so no restatement can follow it step by step; translation = eigenvector of the smallest
-// eigenvalue (usac_ref --eigvec-smallest explains the deviation from OpenGV's column 0).
+// Jacobian (tests/test_usac_degen_math.py), so no restatement can follow it step by step; the translation is the eigenvector OpenGV
+// takes, column 0 of Eigen::EigenSolver's unordered decomposition (eigen_order3 below).
 //
 // Pinned by oracle/_ref/usac_ref: the reference's USAC.h + usac/utils + vendored OpenGV compiled in place, turn by turn
 // (tests/golden/usac_trace.npz).  What is restated from published algorithms rather than compiled from the reference: the smallest
@@ -54,6 +54,143 @@ struct WaldTest {
 unsigned to_uint(double v) {
     long long w = (v > -9.2233720368547758e18 && v < 9.2233720368547758e18) ? (long long)v : (long long)0x8000000000000000ull;
     return (unsigned)(unsigned long long)w;
+}
+
+// The position Eigen::EigenSolver<Matrix3d> gives each eigenvalue (Eigen::RealSchur: Hessenberg form, EISPACK hqr with deflation from the
+// bottom; thirdparty/opengv/third_party_notuse/Eigen/src/Eigenvalues/RealSchur.h:245-525, HessenbergDecomposition.h): OpenGV's eigensolver
+// takes its translation from position 0 (modules/main.cpp:646-659), which holds the smallest eigenvalue in about a third of the cases only.
+// Reflectors in Eigen's formulation and operation order: after convergence, rounding-level entries decide the next one.  Pinned by
+// tests/golden/eigen_order3.npz (oracle/_ref/eigen_svd3 eig).
+// Householder reflector H = I - tau (1, ess)(1, ess)^T with H v = beta e1, and its application to a block, in the formulation (and
+// the operation order) of Eigen's makeHouseholder / applyHouseholderOnTheLeft / OnTheRight: entries at rounding-noise level decide
+// what the next reflector does once the iteration has converged, so the arithmetic has to be the same.
+struct Refl {
+    double ess[2], tau, beta;
+    int n;  // length of v
+};
+inline Refl make_reflector(const double *v, int n) {
+    Refl h;
+    h.n = n, h.ess[0] = h.ess[1] = 0;
+    double tail = 0;
+    for (int i = 1; i < n; ++i) tail += v[i] * v[i];
+    const double c0 = v[0];
+    if (tail == 0.0) {
+        h.tau = 0, h.beta = c0;
+    } else {
+        h.beta = std::sqrt(c0 * c0 + tail);
+        if (c0 >= 0) h.beta = -h.beta;
+        for (int i = 1; i < n; ++i) h.ess[i - 1] = v[i] / (c0 - h.beta);
+        h.tau = (h.beta - c0) / h.beta;
+    }
+    return h;
+}
+// rows r0 .. r0 + n - 1, columns c0 .. c1 - 1
+inline void apply_left(double T[3][3], const Refl &h, int r0, int c0, int c1) {
+    for (int j = c0; j < c1; ++j) {
+        double tmp = 0;
+        for (int i = 1; i < h.n; ++i) tmp = (i == 1) ? h.ess[0] * T[r0 + 1][j] : tmp + h.ess[i - 1] * T[r0 + i][j];
+        tmp += T[r0][j];
+        T[r0][j] -= h.tau * tmp;
+        for (int i = 1; i < h.n; ++i) T[r0 + i][j] -= (h.tau * h.ess[i - 1]) * tmp;
+    }
+}
+// columns k0 .. k0 + n - 1, rows r0 .. r1 - 1
+inline void apply_right(double T[3][3], const Refl &h, int k0, int r0, int r1) {
+    for (int i = r0; i < r1; ++i) {
+        double tmp = 0;
+        for (int j = 1; j < h.n; ++j) tmp = (j == 1) ? T[i][k0 + 1] * h.ess[0] : tmp + T[i][k0 + j] * h.ess[j - 1];
+        tmp += T[i][k0];
+        T[i][k0] -= h.tau * tmp;
+        for (int j = 1; j < h.n; ++j) T[i][k0 + j] -= (h.tau * tmp) * h.ess[j - 1];
+    }
+}
+inline void eigen_order3(const double *M, double *d) {
+    double T[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) T[r][c] = M[3 * r + c];
+    {  // Hessenberg form (HessenbergDecomposition): the reflector of (T10, T20) on rows / columns 1, 2
+        const double v[2] = {T[1][0], T[2][0]};
+        const Refl h = make_reflector(v, 2);
+        T[1][0] = h.beta;
+        apply_left(T, h, 1, 1, 3);
+        apply_right(T, h, 1, 0, 3);
+        T[2][0] = 0.0;
+    }
+    int iu = 2, iter = 0, total = 0;
+    double exshift = 0;
+    double norm = 0;
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < (j + 2 < 3 ? j + 2 : 3); ++i) norm += std::fabs(T[i][j]);
+    if (norm != 0)
+        while (iu >= 0) {
+            int il = iu;
+            while (il > 0) {
+                double s = std::fabs(T[il - 1][il - 1]) + std::fabs(T[il][il]);
+                if (s == 0.0) s = norm;
+                if (std::fabs(T[il][il - 1]) < DBL_EPSILON * s) break;
+                il--;
+            }
+            if (il == iu) {
+                T[iu][iu] += exshift;
+                if (iu > 0) T[iu][iu - 1] = 0.0;
+                iu--;
+                iter = 0;
+            } else if (il == iu - 1) {
+                const double a = T[iu - 1][iu - 1], dd = T[iu][iu], b = T[iu - 1][iu], c = T[iu][iu - 1];
+                const double p = 0.5 * (a - dd), q = p * p + c * b;
+                T[iu][iu] += exshift, T[iu - 1][iu - 1] += exshift;
+                if (q >= 0) {  // two real eigenvalues: the rotation puts the eigenvalue of the eigenvector (p +- z, c) first
+                    const double z = std::sqrt(std::fabs(q)), mean = 0.5 * (a + dd) + exshift;
+                    if (p >= 0)
+                        T[iu - 1][iu - 1] = mean + z, T[iu][iu] = mean - z;
+                    else
+                        T[iu - 1][iu - 1] = mean - z, T[iu][iu] = mean + z;
+                    T[iu][iu - 1] = 0.0;
+                }
+                if (iu > 1) T[iu - 1][iu - 2] = 0.0;
+                iu -= 2;
+                iter = 0;
+            } else {  // iu = 2, il = 0: one Francis step on the whole matrix
+                double s0 = T[2][2], s1 = T[1][1], s2 = T[2][1] * T[1][2];
+                if (iter == 10) {
+                    exshift += s0;
+                    for (int i = 0; i <= iu; ++i) T[i][i] -= s0;
+                    const double s = std::fabs(T[2][1]) + std::fabs(T[1][0]);
+                    s0 = 0.75 * s, s1 = 0.75 * s, s2 = -0.4375 * s * s;
+                }
+                if (iter == 30) {
+                    double s = (s1 - s0) / 2.0;
+                    s = s * s + s2;
+                    if (s > 0) {
+                        s = std::sqrt(s);
+                        if (s1 < s0) s = -s;
+                        s = s + (s1 - s0) / 2.0;
+                        s = s0 - s2 / s;
+                        exshift += s;
+                        for (int i = 0; i <= iu; ++i) T[i][i] -= s;
+                        s0 = s1 = s2 = 0.964;
+                    }
+                }
+                ++iter, ++total;
+                if (total > 120) break;
+                const double Tmm = T[0][0], r = s0 - Tmm, s = s1 - Tmm;
+                const double v[3] = {(r * s - s2) / T[1][0] + T[0][1], T[1][1] - Tmm - r - s, T[2][1]};
+                const Refl h1 = make_reflector(v, 3);
+                if (h1.beta != 0.0) {
+                    apply_left(T, h1, 0, 0, 3);
+                    apply_right(T, h1, 0, 0, 3);
+                }
+                const double v2[2] = {T[1][0], T[2][0]};
+                const Refl h2 = make_reflector(v2, 2);
+                if (h2.beta != 0.0) {
+                    T[1][0] = h2.beta;
+                    apply_left(T, h2, 1, 1, 3);
+                    apply_right(T, h2, 1, 0, 3);
+                }
+                T[2][0] = 0.0;
+            }
+        }
+    d[0] = T[0][0], d[1] = T[1][1], d[2] = T[2][2];
 }
 
 struct Usac {
@@ -756,8 +893,13 @@ struct Usac {
         for (int k = 0; k < 9; ++k) R[k] = Rr[k] / scale;
         compose_M(idx, c, M);
         sym_eig3(M, w, V);
-        const double mag = sqrt(w[1] * w[1] + w[2] * w[2]);
-        for (int k = 0; k < 3; ++k) t[k] = mag * V[3 * k];
+        double d[3];
+        eigen_order3(M, d);  // OpenGV: column 0 of Eigen::EigenSolver, length from positions 1 and 2
+        int k0 = 0;
+        for (int k = 1; k < 3; ++k)
+            if (fabs(w[k] - d[0]) < fabs(w[k0] - d[0])) k0 = k;
+        const double mag = sqrt(d[1] * d[1] + d[2] * d[2]);
+        for (int k = 0; k < 3; ++k) t[k] = mag * V[3 * k + k0];
         const double *f1 = &v1[3 * idx[0]], *f2 = &v2[3 * idx[0]];
         double flow[3];
         for (int r = 0; r < 3; ++r) flow[r] = f1[r] - (R[3 * r] * f2[0] + R[3 * r + 1] * f2[1] + R[3 * r + 2] * f2[2]);
@@ -1164,3 +1306,6 @@ extern "C" int oracle_usac_essential_degen(const double *p1, const double *p2, i
         }
     return ok ? 1 : 0;
 }
+
+// Eigen::EigenSolver<Matrix3d>'s eigenvalue order on a 3 x 3 matrix (row-major), for tests (tests/golden/eigen_order3.npz)
+extern "C" void oracle_eigen_order3(const double *M, double *d) { eigen_order3(M, d); }

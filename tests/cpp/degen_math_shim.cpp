@@ -48,4 +48,5 @@ void shim_smallest_ev_gradient(const double *pts, const int *idx, int m, const d
     dgm::smallest_ev_gradient(S, cayley, grad);
 }
 void shim_e_from_rt(const double *R, const double *t, double *E) { dgm::e_from_rt(R, t, E); }
+void shim_eigen_diag_order3(const double *M, double *d) { dgm::eigen_diag_order3(M, d); }
 }

@@ -412,6 +412,44 @@ def degen_math_case():
     print("usac_degen_math: ok", os.path.getsize(os.path.join(HERE, "usac_degen_math.npz")), "bytes")
 
 
+def eigen_order_case():
+    """The ORDER of Eigen::EigenSolver<Matrix3d>'s eigenvalues (the Eigen the reference vendors, oracle/_ref/eigen_svd3 eig) on symmetric
+    matrices of the kind OpenGV's eigensolver decomposes -- sum of outer products of nearly coplanar vectors: one small eigenvalue, down
+    to exactly singular -- and on indefinite symmetric ones.  OpenGV takes column 0 as the translation."""
+    import struct
+    import subprocess
+    import tempfile
+
+    tool = os.path.join(ROOT, "oracle", "_ref", "eigen_svd3")
+    rng = np.random.default_rng(20260901)
+    Ms = []
+    for it in range(1500):
+        t = rng.normal(size=3)
+        t /= np.linalg.norm(t)
+        noise = (1e-1, 1e-3, 1e-6, 0.5, 1e-9, 0.0)[it % 6]
+        M = np.zeros((3, 3))
+        for _ in range(3 if it % 7 == 0 else 5):
+            v = rng.uniform(-1, 1, 3)
+            v = v - (v @ t) * t + noise * rng.uniform(-1, 1, 3)
+            v *= 1.0 if it % 5 == 0 else 0.05
+            M += np.outer(v, v)
+        if it % 11 == 0:
+            A = rng.uniform(-1, 1, (3, 3))
+            M = A + A.T
+        Ms.append(M)
+    Ms = np.array(Ms)
+    with tempfile.TemporaryDirectory() as d:
+        fi, fo = os.path.join(d, "i"), os.path.join(d, "o")
+        with open(fi, "wb") as f:
+            f.write(struct.pack("i", len(Ms)))
+            f.write(Ms.tobytes())
+        subprocess.run([tool, fi, fo, "eig"], check=True)
+        D = np.frombuffer(open(fo, "rb").read(), np.float64).reshape(-1, 3).copy()
+    first_is_smallest = int((np.argmin(D, axis=1) == 0).sum())
+    np.savez_compressed(os.path.join(HERE, "eigen_order3.npz"), M=Ms, D=D)
+    print(f"eigen_order3: ok {len(Ms)} matrices, smallest eigenvalue at position 0 in {first_is_smallest}")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "usac"):
@@ -420,6 +458,8 @@ if __name__ == "__main__":
         degen_math_case()
     if what in ("all", "eigen"):
         eigen_svd_case()
+    if what in ("all", "eigenorder"):
+        eigen_order_case()
     if what in ("all", "arrsac"):
         arrsac_case()
     if what in ("all", "nms"):

@@ -22,7 +22,7 @@ def shim():
         subprocess.run(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src], check=True)
     lib = C.CDLL(so)
     for name in ("shim_twopt_rotation", "shim_rotation_only", "shim_twopt_translation", "shim_eigensolver", "shim_smallest_ev_gradient",
-                 "shim_e_from_rt"):
+                 "shim_e_from_rt", "shim_eigen_diag_order3"):
         getattr(lib, name).restype = None
     return lib
 
@@ -101,7 +101,7 @@ def test_eigensolver_reaches_what_opengv_reaches(shim, golden, scene):
     that path happens to be.  So the comparison is on what matters downstream: the objective reached, and -- where both runs converge --
     the rotation and the translation direction (eigenvector of the smallest eigenvalue; see the module header for OpenGV's column 0)."""
     pts = np.ascontiguousarray(golden[f"{scene}_pts"])
-    close, n, obj_ratio = 0, 0, []
+    close, n, obj_ratio, same_t = 0, 0, [], []
     for k, idx in enumerate(golden[f"{scene}_fives"]):
         idx = np.ascontiguousarray(idx, np.int32)
         R0 = np.ascontiguousarray(golden[f"{scene}_Rs"][k])
@@ -119,12 +119,28 @@ def test_eigensolver_reaches_what_opengv_reaches(shim, golden, scene):
         n += 1
         if np.abs(Rm - Rr).max() < 1e-3:
             close += 1
-            # translation: parallel to the reference's eigenvector of the smallest eigenvalue
-            D, V = golden[f"{scene}_eigD"][k], golden[f"{scene}_eigV"][k].reshape(3, 3)
-            v = V[:, int(np.argmin(D))]
-            tn = t / np.linalg.norm(t)
-            if np.sort(D)[1] > 50 * max(np.sort(D)[0], 1e-14):   # a direction exists
-                assert abs(abs(tn @ v) - 1) < 1e-2, (k, tn, v, D)
+            # translation: OpenGV's own choice -- column 0 of Eigen::EigenSolver, whatever eigenvalue that is -- wherever the order of the
+            # eigenvalues is not decided by rounding noise (the two runs decompose matrices that differ by the distance of their rotations)
+            tr = golden[f"{scene}_eigT"][k]
+            if np.linalg.norm(tr) > 0 and np.linalg.norm(t) > 0:
+                same_t.append(abs((t / np.linalg.norm(t)) @ (tr / np.linalg.norm(tr))))
     med = float(np.median(obj_ratio))
     assert 0.2 < med < 5.0, med                 # neither implementation reaches systematically lower objectives
     assert close >= n // 3, (close, n)          # and a good share of the runs end at the same rotation
+    assert len(same_t) >= 8 and np.mean(np.array(same_t) > 1 - 1e-2) >= 0.8, same_t   # ... with the translation OpenGV takes
+
+
+def test_order_of_eigen_eigensolver_eigenvalues(shim):
+    """dgm::eigen_diag_order3 against Eigen::EigenSolver<Matrix3d> of the Eigen the reference vendors (tests/golden/eigen_order3.npz):
+    the same eigenvalue at every position on all 1500 matrices, including the ones where rounding noise decides the order."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "eigen_order3.npz"))
+    worst, first_small = 0.0, 0
+    for M, D in zip(g["M"], g["D"]):
+        M = np.ascontiguousarray(M)
+        d = np.zeros(3)
+        shim.shim_eigen_diag_order3(ptr(M), ptr(d))
+        scale = max(np.abs(D).max(), 1e-300)
+        worst = max(worst, np.abs(d - D).max() / scale)
+        first_small += int(np.argmin(D) == 0)
+    assert worst < 1e-12, worst
+    assert 0.2 < first_small / len(g["M"]) < 0.5      # what OpenGV relies on holds in about a third of the cases

@@ -77,7 +77,7 @@ def check_no_motion_upgrade_is_identical_candidate_by_candidate(runs):
     assert seen >= 4
 
 
-def check_rotation_upgrade_follows_until_the_eigensolver_noise_decides(runs, agree_tol=1e-3):
+def check_rotation_upgrade_follows_until_the_eigensolver_noise_decides(runs, agree_tol=1e-3, agree_share=0.5):
     """R -> R + t: candidates are the same correspondences (same stream), the models agree where the eigensolver converges, and the
     run stays identical at least up to the upgrade's first candidate."""
     seen, agree = 0, []
@@ -98,7 +98,10 @@ def check_rotation_upgrade_follows_until_the_eigensolver_noise_decides(runs, agr
         if len(ea):
             agree.append(np.median(np.abs(ea - eb).max(1)))
         seen += 1
-    assert seen >= 8 and np.median(agree) < agree_tol, (seen, agree)
+    # per run: the median difference of the candidates' models up to the point where the runs part; a run counts as agreeing below
+    # agree_tol (a few runs part after a handful of candidates on which the eigensolver's iteration or the order of Eigen's
+    # eigenvalues was decided by rounding noise)
+    assert seen >= 8 and np.mean(np.array(agree) < agree_tol) >= agree_share, (seen, agree)
 
 
 def degenerate_decision(n, n_inliers, degen, th=0.85):

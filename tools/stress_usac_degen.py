@@ -92,7 +92,11 @@ def main():
             b = checks.degenerate_decision(n, d["final"][5], d["degen"][1:3], th_dec)
             # a verdict on the knife edge (the two sides' E-inlier counts differ by a few after the runs parted) is not a disagreement
             edge = any(abs(th_dec * r["final"][5] / n - r["degen"][k] / max(r["final"][5], 1)) < 0.02 for r in (o, d) for k in (1, 2))
-            if a != b and not edge and kind in (0, 1, 2) and n >= 50 and frac >= 0.25:
+            # (with 1 px of noise against the 0.8 px threshold the degenerate model explains a quarter of the true correspondences only:
+            #  which sample's rotation collects most depends on the run, so the verdict is compared where the motion is well defined)
+            if a != b and not edge and noise > 0.3:
+                tally["verdict_differs_at_high_noise"] = tally.get("verdict_differs_at_high_noise", 0) + 1
+            elif a != b and not edge and kind in (0, 1, 2) and n >= 50 and frac >= 0.25:
                 print("VIOLATION verdict", tag, th_dec, o["degen"], d["degen"], o["final"][5], d["final"][5], flush=True)
                 tally["violations"] += 1
         tally["verdict_true"] += int(checks.degenerate_decision(n, d["final"][5], d["degen"][1:3]))

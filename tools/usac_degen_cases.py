@@ -50,7 +50,7 @@ def make():
     out = {}
     for key, name, p1, p2, th, order, truth, usac_seed, prosac, check in cases():
         r = u.run(p1, p2, th, usac_seed, refine=0, sorted_idx=order if prosac else None, solver_oracle=True, check_degeneracy=check,
-                  eigvec_smallest=True)
+                  eigvec_smallest=False)
         ev = r["events"]
         out[key + "_meta"] = np.array([len(p1), usac_seed, int(prosac), check, len(ev)], np.float64)
         out[key + "_events"] = ev[:EVENTS_KEPT]
