@@ -68,8 +68,9 @@ static bool g_solver_oracle = false;
 // --eigvec-smallest: OpenGV's eigensolver takes its translation from column 0 of Eigen::EigenSolver's eigenvectors
 // (modules/main.cpp:646-659) -- meant to be the eigenvector of the smallest eigenvalue, but EigenSolver orders nothing: on symmetric
 // matrices of this kind the smallest eigenvalue sits at position 0 in about a third of the cases (probe: 6178 / 7806 / 6016 of 20000).
-// With this flag the R -> R + t upgrade takes the eigenvector of the smallest eigenvalue from the same eigensolver output, which is
-// what oracle/ and the device path do (stated deviation); without it the reference's own choice.
+// With this flag the R -> R + t upgrade takes the eigenvector of the smallest eigenvalue from the same eigensolver output (a diagnostic:
+// what the solver was meant to do).  Without it -- the fixtures -- OpenGV's own choice, which oracle/ and the device path reproduce by
+// restating Eigen::RealSchur's eigenvalue order (oracle_eigen_order3, dgm::eigen_diag_order3; tests/golden/eigen_order3.npz).
 static bool g_eigvec_smallest = false;
 extern "C" int oracle_run5point(const double *q1, const double *q2, int n, double *E_out);
 static std::vector<double> g_events;  // 16 doubles per event

@@ -99,7 +99,7 @@ def test_eigensolver_reaches_what_opengv_reaches(shim, golden, scene):
     """OpenGV's Levenberg-Marquardt works on a forward-difference Jacobian with a step of 1.5e-8 |x|: its path follows the rounding noise
     of the build (the same sources at another optimisation level give other iterates), and its loose tolerance (5e-5) stops it wherever
     that path happens to be.  So the comparison is on what matters downstream: the objective reached, and -- where both runs converge --
-    the rotation and the translation direction (eigenvector of the smallest eigenvalue; see the module header for OpenGV's column 0)."""
+    the rotation and the translation direction (OpenGV's: column 0 of Eigen::EigenSolver, see test_order_of_eigen_eigensolver_eigenvalues)."""
     pts = np.ascontiguousarray(golden[f"{scene}_pts"])
     close, n, obj_ratio, same_t = 0, 0, [], []
     for k, idx in enumerate(golden[f"{scene}_fives"]):
