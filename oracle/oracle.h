@@ -19,6 +19,9 @@
  *     degeneracy handling (testSolutionDegeneracyRot / NoMot, upgradeDegenerateModel: oracle_usac_essential_degen), whose driver runs
  *     the restated estimator members over the reference's own OpenGV and PoseTools functions (tests/golden/usac_degen_trace.npz);
  *     oracle/ref_drivers/opengv_degen.cpp pins the 3 x 3 numerics one function at a time (tests/golden/usac_degen_math.npz).
+ *     Solver + control flow at once: `usac_ref --stewenius` runs the reference's DEFAULT estimator (POSE_STEWENIUS, OpenGV's
+ *     fivept_stewenius) and oracle_usac_essential -- with its own five-point solver -- follows it event by event in 21 of 24 runs
+ *     (tests/golden/usac_stewenius_trace.npz).
  *   - The arithmetic of cvflann::LinearIndex / cv::SVD / cv::solvePoly / cv::triangulatePoints lives in
  *     OpenCV 4.2.0 (pinned in ci/make_opencv.sh:6), which is NOT vendored under /root/reference and is
  *     not installed here; those steps restate the published algorithms and are "parity unpinned" at

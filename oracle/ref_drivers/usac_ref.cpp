@@ -27,7 +27,7 @@
 // association depends on the Eigen version and the alignment of the column -- rounding noise no restatement can reproduce.  The SET of
 // solutions does not depend on it.  `--native-order` keeps OpenGV's order (diagnostics).
 //
-// usage: usac_ref in.bin out.bin [--native-order] [--solver-oracle] [--eigvec-smallest]
+// usage: usac_ref in.bin out.bin [--native-order] [--solver-oracle] [--stewenius] [--eigvec-smallest]
 //   in.bin : int32 n, seed, refine (0 = REF_WEIGHTS, 6 = REF_NISTER), prosac (0/1), max_hyp, check_degeneracy (0, 1, 3 = also after local optimisations), reserved[2];
 //            double th, prosac_beta, sprt_delta, sprt_epsilon, sprt_mS, sprt_tM, conf, th_pixels / focal length;
 //            n * 4 doubles (x1,y1,x2,y2); if prosac: n uint32 sorted indices
@@ -65,6 +65,10 @@ static bool g_native_order = false;
 // the same solver.  (OpenGV's fivept_nister returns unconverged roots on a noticeable share of samples -- its Sturm brackets are
 // bound / (10 roots) wide and get five Newton steps -- so with it the traces part at the first such sample; see tests/test_oracle_usac.py.)
 static bool g_solver_oracle = false;
+// --stewenius: the minimal models come from OpenGV's fivept_stewenius as ConfigUSAC's (and the harness') default estimator POSE_STEWENIUS
+// takes them (EssentialMatEstimator.h:456-489) -- an eigenvalue solver, converged to rounding, unlike fivept_nister's bracketing; with the
+// order convention on top, the trace of this REFERENCE-SOLVER run is what tests/test_oracle_usac.py holds the oracle's own solver to.
+static bool g_stewenius = false;
 // --eigvec-smallest: OpenGV's eigensolver takes its translation from column 0 of Eigen::EigenSolver's eigenvectors
 // (modules/main.cpp:646-659) -- meant to be the eigenvector of the smallest eigenvalue, but EigenSolver orders nothing: on symmetric
 // matrices of this kind the smallest eigenvalue sits at position 0 in about a third of the cases (probe: 6178 / 7806 / 6016 of 20000).
@@ -131,6 +135,27 @@ class RefEssential : public USAC<RefEssential> {
         return (big < 0 ? -E(0, 0) : E(0, 0)) / nrm;
     }
     opengv::essentials_t five_point(const std::vector<int> &indices) {
+        if (g_stewenius) {  // ESTIM_STEWENIUS (:456-489): the solutions whose imaginary parts all pass nearZero(100 * imag), |.| < 1e-3
+            opengv::complexEssentials_t Ec = opengv::relative_pose::fivept_stewenius(*adapter_denorm, indices);
+            opengv::essentials_t out;
+            for (auto &Ei : Ec) {
+                bool imag = false;
+                for (int r = 0; r < 3 && !imag; r++)
+                    for (int c = 0; c < 3; c++) {
+                        const double d = 100 * Ei(r, c).imag();
+                        if (!(d < 1e-3 && d > -1e-3)) {
+                            imag = true;
+                            break;
+                        }
+                    }
+                if (imag) continue;
+                opengv::essential_t E;
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 3; c++) E(r, c) = Ei(r, c).real();
+                out.push_back(E);
+            }
+            return out;
+        }
         if (!g_solver_oracle) return opengv::relative_pose::fivept_nister(*adapter_denorm, indices);
         std::vector<double> q1(2 * indices.size()), q2(2 * indices.size());
         for (size_t i = 0; i < indices.size(); ++i) {
@@ -733,6 +758,7 @@ int main(int argc, char **argv) {
     for (int a = 3; a < argc; ++a)
         if (!std::strcmp(argv[a], "--native-order")) g_native_order = true;
         else if (!std::strcmp(argv[a], "--solver-oracle")) g_solver_oracle = true;
+        else if (!std::strcmp(argv[a], "--stewenius")) g_stewenius = true;
         else if (!std::strcmp(argv[a], "--eigvec-smallest")) g_eigvec_smallest = true;
     FILE *f = fopen(argv[1], "rb");
     if (!f) return 2;

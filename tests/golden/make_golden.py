@@ -355,6 +355,47 @@ def usac_case():
     print("usac_trace: ok", os.path.getsize(os.path.join(HERE, "usac_trace.npz")), "bytes")
 
 
+USAC_STEWENIUS_CASES = [(5000, 0.5, 20260103), (300, 0.5, 13), (1200, 0.9, 15), (8192, 0.25, 14), (800, 0.3, 11), (2000, 0.7, 12)]
+USAC_STEWENIUS_EVENTS_KEPT = 400
+
+
+def usac_stewenius_case():
+    """USAC with the reference's DEFAULT minimal solver: ConfigUSAC (pose_estim.h:99) and the harness (main.cpp:608, cfgUSAC 311220) select
+    POSE_STEWENIUS, i.e. OpenGV's fivept_stewenius filtered for real solutions (EssentialMatEstimator.h:456-489), with mS = 6 and
+    tM = 2736 on a process' first call (usac_estimations.cpp:323, 412, 422).  `usac_ref --stewenius` runs exactly that on the
+    reference-built USAC.h + OpenGV; only the order convention of a sample's solutions is put on top (Eigen::EigenSolver's order of ten
+    eigenvalues is not restated).  Unlike fivept_nister's bracketing the eigenvalue solver is converged to rounding, so these traces hold
+    the oracle's and the device's OWN five-point solver -- not a swapped-in one -- to the reference's, decision by decision.
+    agree = 0 marks runs that part at a refit where ccmath's svdu1v stops early (usac_case)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import oracle_lib
+    import usac_compare
+    import usac_ref_tool as u
+    ora = oracle_lib.load()
+    out = {"cases": np.array(USAC_STEWENIUS_CASES, np.float64)}
+    k = 0
+    for (n, frac, seed) in USAC_STEWENIUS_CASES:
+        p1, p2, th, truth, order = usac_scene(n, frac, seed)
+        for prosac in (0, 1):
+            for usac_seed in (12345, 7):
+                si = order if prosac else None
+                r = u.run(p1, p2, th, usac_seed, sorted_idx=si, stewenius=True, sprt_ms=6.0, sprt_tm=2736.0)
+                o = ora.usac_essential(p1, p2, th, usac_seed, sorted_idx=si, event_cap=200000, sprt_ms=6.0, sprt_tm=2736.0)
+                first, d = usac_compare.compare(r["events"], o["events"])
+                agree = int(first is None and np.array_equal(r["flags"], o["flags"]))
+                out[f"k{k}_meta"] = np.array([n, frac, seed, prosac, usac_seed, agree], np.float64)
+                out[f"k{k}_events"] = r["events"][:USAC_STEWENIUS_EVENTS_KEPT]
+                out[f"k{k}_n_events"] = np.array([len(r["events"])])
+                out[f"k{k}_final"], out[f"k{k}_E"], out[f"k{k}_flags"] = r["final"], r["E"], np.packbits(r["flags"])
+                print(f"usac stewenius case {k}: n {n} prosac {prosac} seed {usac_seed}: events {len(r['events'])} agree {agree} first {first} "
+                      f"inliers {int(r['final'][5])} hyps {int(r['final'][1])} {d}")
+                k += 1
+    out["n_cases"] = np.array([k])
+    np.savez_compressed(os.path.join(HERE, "usac_stewenius_trace.npz"), **out)
+    print("usac_stewenius_trace: ok", os.path.getsize(os.path.join(HERE, "usac_stewenius_trace.npz")), "bytes")
+
+
 def degen_math_case():
     """Fixture for the host numerics of USAC's degeneracy handling: the reference's vendored OpenGV (twopt_rotationOnly, rotationOnly,
     twopt, eigensolver) and PoseTools error functions compiled in place (oracle/_ref/opengv_degen) on three scenes -- pure rotation,
@@ -454,6 +495,8 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "usac"):
         usac_case()
+    if what in ("all", "usac_stewenius"):
+        usac_stewenius_case()
     if what in ("all", "degen"):
         degen_math_case()
     if what in ("all", "eigen"):

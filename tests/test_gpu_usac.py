@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gol
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
 import make_golden  # noqa: E402
 import usac_compare  # noqa: E402
-from test_oracle_usac import check_against_fixture, fixture_cases  # noqa: E402
+from test_oracle_usac import check_against_fixture, fixture_cases, stewenius_run  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -34,6 +34,21 @@ def test_device_follows_the_reference_built_traces(ctx, stepwise):
                 check_against_fixture(dev_run(ctx), g, k, n, frac, seed, prosac, usac_seed, e5_max=1e-4)
     finally:
         ctx.set_option("usac_lo_stepwise", 0)
+
+
+def test_device_follows_the_reference_running_its_default_stewenius_solver(ctx):
+    """tests/golden/usac_stewenius_trace.npz (`usac_ref --stewenius`: the reference-built USAC.h with ConfigUSAC's default estimator,
+    OpenGV's fivept_stewenius -- the reference's own solver).  The device serves POSE_STEWENIUS with its five-point kernels
+    (estimator = 2): same decisions event by event on the runs the oracle follows too."""
+    from matchinglib_poselib_amd import pose
+
+    run = stewenius_run(lambda *a, **k: pose.usac_essential(*a, estimator=2, ctx=ctx, **k))
+    checked = 0
+    for g, k, n, frac, seed, prosac, usac_seed, agree in fixture_cases("usac_stewenius_trace.npz"):
+        if agree:
+            check_against_fixture(run, g, k, n, frac, seed, prosac, usac_seed, e5_max=5e-3, kept=make_golden.USAC_STEWENIUS_EVENTS_KEPT)
+            checked += 1
+    assert checked >= 21
 
 
 def test_device_equals_oracle_turn_by_turn(ctx, oracle):

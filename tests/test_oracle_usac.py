@@ -15,20 +15,20 @@ import usac_compare  # noqa: E402
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def fixture_cases():
-    g = np.load(os.path.join(GOLD, "usac_trace.npz"))
+def fixture_cases(name="usac_trace.npz"):
+    g = np.load(os.path.join(GOLD, name))
     for k in range(int(g["n_cases"][0])):
         n, frac, seed, prosac, usac_seed, agree = g[f"k{k}_meta"]
         yield g, k, int(n), float(frac), int(seed), int(prosac), int(usac_seed), int(agree)
 
 
-def check_against_fixture(run, g, k, n, frac, seed, prosac, usac_seed, e_tol=1e-8, e5_max=1e-8):
+def check_against_fixture(run, g, k, n, frac, seed, prosac, usac_seed, e_tol=1e-8, e5_max=1e-8, kept=make_golden.USAC_EVENTS_KEPT):
     """run(p1, p2, th, usac_seed, sorted_idx, event_cap) -> dict(events, final, flags, E).  Asserts the reference's decisions.
     e5_max: bound on the largest difference of a MINIMAL model (the device polishes every 5-point solution on the cubic constraints; on
     the ~1 % of samples whose elimination is ill conditioned the CPU root path is off by up to 1e-5); 98 % within e_tol."""
     p1, p2, th, truth, order = make_golden.usac_scene(n, frac, seed)
     o = run(p1, p2, th, usac_seed, order if prosac else None, 200000)
-    ref_ev, kept = g[f"k{k}_events"], make_golden.USAC_EVENTS_KEPT
+    ref_ev = g[f"k{k}_events"]
     assert o["n_events"] == int(g[f"k{k}_n_events"][0])
     first, d = usac_compare.compare(ref_ev, o["events"][:kept])
     assert first is None, (k, first, ref_ev[first][:12] if first < len(ref_ev) else None, o["events"][first][:12])
@@ -92,6 +92,45 @@ def test_with_the_references_own_solver_the_results_agree(oracle):
         flags = np.unpackbits(g[f"k{k}_opengv_flags"])[:n]
         assert abs(o["final"][1] - gf[1]) <= max(2, 0.1 * gf[1]), (k, o["final"][1], gf[1])
         assert np.count_nonzero(flags != o["flags"]) <= max(3, 0.01 * n), (k, np.count_nonzero(flags != o["flags"]))
+
+
+def stewenius_run(f):
+    """POSE_STEWENIUS as estimateEssentialMatUsac configures it on a process' first call: mS = 6, tM = 2736 (usac_estimations.cpp:323, 412, 422)."""
+    return lambda p1, p2, th, s, si, cap: f(p1, p2, th, s, sorted_idx=si, event_cap=cap, sprt_ms=6.0, sprt_tm=2736.0)
+
+
+def test_oracle_follows_the_reference_running_its_default_stewenius_solver(oracle):
+    """tests/golden/usac_stewenius_trace.npz: the reference-built USAC.h with the reference's DEFAULT estimator, OpenGV's
+    fivept_stewenius (`usac_ref --stewenius`) -- the reference's own solver, nothing swapped in.  The oracle's five-point solver gives the
+    same real solutions (98 % of the minimal models within 1e-8; the ill-conditioned samples up to 5e-3) and the run takes the same
+    decisions, event by event, in 21 of the 24 runs."""
+    g0 = np.load(os.path.join(GOLD, "usac_stewenius_trace.npz"))
+    assert np.array_equal(g0["cases"], np.array(make_golden.USAC_STEWENIUS_CASES, np.float64))
+    cases = list(fixture_cases("usac_stewenius_trace.npz"))
+    assert len(cases) == 4 * len(make_golden.USAC_STEWENIUS_CASES) and sum(c[-1] for c in cases) >= len(cases) - 3
+    for g, k, n, frac, seed, prosac, usac_seed, agree in cases:
+        if agree:
+            check_against_fixture(stewenius_run(oracle.usac_essential), g, k, n, frac, seed, prosac, usac_seed, e5_max=5e-3,
+                                  kept=make_golden.USAC_STEWENIUS_EVENTS_KEPT)
+
+
+def test_stewenius_runs_that_part_do_so_at_a_named_place_and_end_alike(oracle):
+    """The three other runs: two part right after a refit where ccmath's svdu1v stops early (as in usac_trace.npz), one at a minimal
+    sample so ill conditioned that the two solvers' models differ by 1e-5 and the oriented-constraint verdict with them.  Same estimate
+    at the end: inlier counts within 1 %."""
+    seen = 0
+    for g, k, n, frac, seed, prosac, usac_seed, agree in fixture_cases("usac_stewenius_trace.npz"):
+        if agree:
+            continue
+        seen += 1
+        p1, p2, th, truth, order = make_golden.usac_scene(n, frac, seed)
+        o = stewenius_run(oracle.usac_essential)(p1, p2, th, usac_seed, order if prosac else None, 200000)
+        ref_ev = g[f"k{k}_events"]
+        first, _ = usac_compare.compare(ref_ev, o["events"][:len(ref_ev)])
+        if first is not None:     # inside the kept head: right after a refit
+            assert int(ref_ev[first - 1][0]) == 3 and int(ref_ev[first][0]) == 2, (k, first)
+        assert abs(int(o["final"][5]) - int(g[f"k{k}_final"][5])) <= max(2, 0.01 * g[f"k{k}_final"][5]), (k, o["final"][5], g[f"k{k}_final"][5])
+    assert seen == 3
 
 
 def test_live_against_the_reference_build(oracle):

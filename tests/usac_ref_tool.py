@@ -19,7 +19,7 @@ def available() -> bool:
 
 def run(p1, p2, th, seed, refine=0, sorted_idx=None, max_hyp=50000, prosac_beta=0.09, sprt_delta=0.05, sprt_epsilon=0.15,
         sprt_ms=8.5, sprt_tm=2314.0, conf=0.99, native_order=False, solver_oracle=False, check_degeneracy=False, th_pixels=0.8,
-        focal=800.0, eigvec_smallest=False):
+        focal=800.0, eigvec_smallest=False, stewenius=False):
     """Returns dict(events=(k,16) float64, final=(12,), E=(9,), flags=(n,) uint8, pool=(n,) int32); with check_degeneracy also
     degen=(4,) [inliers of the rotation, of "no motion", degeneracy type, 0], R_degen=(9,), flags_rot, flags_nomot=(n,) uint8."""
     n = len(p1)
@@ -33,7 +33,7 @@ def run(p1, p2, th, seed, refine=0, sorted_idx=None, max_hyp=50000, prosac_beta=
             if sorted_idx is not None:
                 f.write(np.ascontiguousarray(sorted_idx, np.uint32).tobytes())
         subprocess.run([TOOL, fi, fo] + (["--native-order"] if native_order else []) + (["--solver-oracle"] if solver_oracle else [])
-                       + (["--eigvec-smallest"] if eigvec_smallest else []),
+                       + (["--eigvec-smallest"] if eigvec_smallest else []) + (["--stewenius"] if stewenius else []),
                        check=True)
         raw = open(fo, "rb").read()
     ne = struct.unpack("i", raw[:4])[0]
