@@ -1428,12 +1428,15 @@ __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double
                 const f32x2 B2 = __builtin_elementwise_fma(E[1], X2, __builtin_elementwise_fma(E[4], Y2, E[7]));
                 const f32x2 D = __builtin_elementwise_fma(A, A, __builtin_elementwise_fma(B, B, __builtin_elementwise_fma(A2, A2, B2 * B2)));
                 const f32x2 N = S * S;
-                const f32x2 P = Q * D;
-                const f32x2 H = __builtin_elementwise_fma(C6, N + P, KM * KP);
-                const f32x2 diff = N - P;
-                const bool c0 = fabsf(diff.x) > H.x, c1 = fabsf(diff.y) > H.y;  // false for NaN / inf bands
-                cnt += (c0 && diff.x < 0.f) ? 1 : 0;
-                cnt += (c1 && diff.y < 0.f) ? 1 : 0;
+                // N32 -+ fl(qmax) D32 with ONE rounding each (the analysis above rounds the product first: at most an ulp of either
+                // quantity more, far inside the 1.02 / 1.01 slack of H)
+                const f32x2 diff = __builtin_elementwise_fma(-Q, D, N);
+                const f32x2 H = __builtin_elementwise_fma(C6, __builtin_elementwise_fma(Q, D, N), KM * KP);
+                // decided inlier: diff < -H; decided outlier: diff > H (H >= 0; every comparison is false for a NaN / inf band)
+                const bool in0 = diff.x < -H.x, in1 = diff.y < -H.y;
+                const bool c0 = in0 || diff.x > H.x, c1 = in1 || diff.y > H.y;
+                cnt += in0 ? 1 : 0;
+                cnt += in1 ? 1 : 0;
                 if (__builtin_expect(!(c0 && c1), 0)) {  // inside the band (or out of range): the fp64 predicate decides
                     const int i0 = base + 4 * (2 * q) + j, i1 = i0 + 4;
                     if (!c0) {

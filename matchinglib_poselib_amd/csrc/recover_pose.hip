@@ -71,6 +71,77 @@ __device__ __forceinline__ void jacobi_right_vectors(double (&G)[N][N], double (
     }
 }
 
+// The 4 x 4 triangulation systems: the same one-sided Jacobi iteration with the six column pairs of a sweep taken as three ROUNDS of two
+// disjoint pairs -- (0,1)(2,3), (0,2)(1,3), (0,3)(1,2) -- and no branch inside a round: a pair that is already orthogonal gets the identity
+// rotation (c = 1, s = 0 leave its columns bit for bit).  The two rotations of a round touch different columns, so their dependent
+// chains (three inner products, reciprocal, root, inverse root, two Newton steps) interleave in one lane; the cyclic order above left the
+// kernel waiting 60 % of its wave cycles (SQ_WAIT_ANY / SQ_WAVE_CYCLES, profiles/r03_pmc_summary.json) with one chain per lane.
+struct PlaneRot {
+    double c, s;
+    bool on;
+};
+__device__ __forceinline__ PlaneRot plane_rotation(double alpha, double beta, double gamma) {
+    const double eps = DBL_EPSILON * 2;
+    PlaneRot r;
+    r.on = !(gamma * gamma <= (eps * eps) * (alpha * beta) || gamma == 0.0);
+    const double zeta = (beta - alpha) * __builtin_amdgcn_rcp(2.0 * gamma);
+    const double az = fabs(zeta);
+    double t = __builtin_amdgcn_rcp(az + __builtin_amdgcn_sqrt(__builtin_fma(az, az, 1.0)));
+    t = zeta >= 0 ? t : -t;
+    if (!(az < 1e150)) t = 0.5 * __builtin_amdgcn_rcp(zeta);  // zeta^2 overflows: t = 1 / (2 zeta); any t of that size does (see above)
+    const double x1 = __builtin_fma(t, t, 1.0);
+    double c = __builtin_amdgcn_rsq(x1);
+    c = c * __builtin_fma(-0.5 * x1, c * c, 1.5);
+    c = c * __builtin_fma(-0.5 * x1, c * c, 1.5);
+    r.c = r.on ? c : 1.0;
+    r.s = r.on ? c * t : 0.0;
+    return r;
+}
+template <int P, int Q>
+__device__ __forceinline__ void pair_products(const double (&G)[4][4], double &alpha, double &beta, double &gamma) {
+    alpha = beta = gamma = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        alpha = __builtin_fma(G[i][P], G[i][P], alpha);  // (the library is built with -ffp-contract=off: the fused forms are spelled out
+        beta = __builtin_fma(G[i][Q], G[i][Q], beta);    //  where no bit pattern is pinned -- half the instructions of the iteration)
+        gamma = __builtin_fma(G[i][P], G[i][Q], gamma);
+    }
+}
+template <int P, int Q>
+__device__ __forceinline__ void turn_columns(double (&G)[4][4], double (&V)[4][4], PlaneRot r) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double gp = G[i][P], gq = G[i][Q];
+        G[i][P] = __builtin_fma(r.c, gp, -(r.s * gq));
+        G[i][Q] = __builtin_fma(r.s, gp, r.c * gq);
+        const double vp = V[i][P], vq = V[i][Q];
+        V[i][P] = __builtin_fma(r.c, vp, -(r.s * vq));
+        V[i][Q] = __builtin_fma(r.s, vp, r.c * vq);
+    }
+}
+template <int P0, int Q0, int P1, int Q1>
+__device__ __forceinline__ bool jacobi4_round(double (&G)[4][4], double (&V)[4][4]) {
+    double a0, b0, g0, a1, b1, g1;
+    pair_products<P0, Q0>(G, a0, b0, g0);
+    pair_products<P1, Q1>(G, a1, b1, g1);
+    const PlaneRot r0 = plane_rotation(a0, b0, g0), r1 = plane_rotation(a1, b1, g1);
+    turn_columns<P0, Q0>(G, V, r0);
+    turn_columns<P1, Q1>(G, V, r1);
+    return r0.on || r1.on;
+}
+__device__ __forceinline__ void jacobi4_right_vectors(double (&G)[4][4], double (&V)[4][4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = jacobi4_round<0, 1, 2, 3>(G, V);
+        rotated |= jacobi4_round<0, 2, 1, 3>(G, V);
+        rotated |= jacobi4_round<0, 3, 1, 2>(G, V);
+        if (!rotated) break;
+    }
+}
+
 __device__ __forceinline__ double det3(const double *M) {
     return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
 }
@@ -161,7 +232,7 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const double *__restri
             G[2][k] = x2 * Pc[8 + k] - Pc[k];
             G[3][k] = y2 * Pc[8 + k] - Pc[4 + k];
         }
-        jacobi_right_vectors<4>(G, V);
+        jacobi4_right_vectors(G, V);
         double w[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[j] = G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j] + G[3][j] * G[3][j];
@@ -254,77 +325,77 @@ __global__ void decompose_batch_kernel(const char *__restrict__ E_base, size_t E
     for (int i = 0; i < 3; ++i) out[66 + i] = tv[i];
 }
 
+constexpr int kTriPointsPerWave = 256;  // correspondences a wave of triangulate_batch_kernel compacts and walks
 __global__ __launch_bounds__(256) void triangulate_batch_kernel(const double *__restrict__ P_all, const double *__restrict__ p1,
                                                                 const double *__restrict__ p2, const int32_t *__restrict__ counts,
                                                                 const int32_t *__restrict__ active, int pair_stride, double dist,
                                                                 const uint8_t *__restrict__ mask_in /*[B][pair_stride]*/,
                                                                 uint8_t *__restrict__ mask_out /*[B][4][pair_stride]*/,
                                                                 int32_t *__restrict__ cand_counts /*[B][4]*/) {
-    __shared__ int wave_cnt[4];
-    __shared__ int todo[256];
+    // A correspondence outside the incoming mask cannot pass whatever its 3-D point is (the batch form returns no points): no SVD for it.
+    // About half of the correspondences are such (the RANSAC outliers), scattered over the lanes.  Every WAVE owns 256 consecutive
+    // correspondences: it compacts the ones to triangulate into its own list (ballot ranks, no workgroup barrier anywhere) and walks the
+    // list 64 at a time, so that all lanes are busy through the Jacobi sweeps but for the list's tail (as lane i = point i the kernel
+    // ran 467 us per 128 pairs with half of every wave idle; with a workgroup-wide list and two barriers, 350).
+    __shared__ int todo[4][kTriPointsPerWave];
     const int b = blockIdx.z, c = blockIdx.y;
     const int n = active[b] ? counts[b] : 0;
-    if ((int)(blockIdx.x * blockDim.x) >= n) return;  // block-uniform
-    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
-    // A correspondence outside the incoming mask cannot pass whatever its 3-D point is (the batch form returns no points): no SVD for it.
-    // About half of the correspondences are such (the RANSAC outliers), scattered over the lanes: the block first compacts the ones to
-    // triangulate into a list, so that its first waves run the SVD with every lane busy and the others leave at once (as lane i = point
-    // i the kernel ran 467 us per 128 pairs with half of every wave idle through the Jacobi sweeps).
-    const bool want = i0 < n && (!mask_in || mask_in[(size_t)b * pair_stride + i0]);
-    if (i0 < n && !want) mask_out[((size_t)b * 4 + c) * pair_stride + i0] = 0;
-    const unsigned long long wb = __ballot(want);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) wave_cnt[wv] = __popcll(wb);
-    __syncthreads();
-    int before = 0, total = 0;
+    const int base = (blockIdx.x * 4 + wv) * kTriPointsPerWave;
+    if (base >= n) return;  // wave-uniform
+    int total = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        before += (k < wv) ? wave_cnt[k] : 0;
-        total += wave_cnt[k];
+    for (int k = 0; k < kTriPointsPerWave / 64; ++k) {
+        const int i0 = base + k * 64 + lane;
+        const bool want = i0 < n && (!mask_in || mask_in[(size_t)b * pair_stride + i0]);
+        if (i0 < n && !want) mask_out[((size_t)b * 4 + c) * pair_stride + i0] = 0;
+        const unsigned long long wb = __ballot(want);
+        if (want) todo[wv][total + __popcll(wb & ((1ull << lane) - 1ull))] = i0;
+        total += __popcll(wb);
     }
-    if (want) todo[before + __popcll(wb & ((1ull << lane) - 1ull))] = i0;
-    __syncthreads();
-    bool good = false;
-    if ((int)threadIdx.x < total) {
-        const int i = todo[threadIdx.x];
-        const double *Pc = P_all + (size_t)b * 69 + c * 12;
-        const size_t at = ((size_t)b * pair_stride + i) * 2;
-        const double x1 = p1[at], y1 = p1[at + 1], x2 = p2[at], y2 = p2[at + 1];
-        double G[4][4], V[4][4];
-        const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the list is this wave's own: a wave-scope fence orders its LDS writes and reads
+    __builtin_amdgcn_wave_barrier();
+    const double *Pc = P_all + (size_t)b * 69 + c * 12;
+    int n_good = 0;
+    for (int at0 = 0; at0 < total; at0 += 64) {
+        bool good = false;
+        if (at0 + lane < total) {
+            const int i = todo[wv][at0 + lane];
+            const size_t at = ((size_t)b * pair_stride + i) * 2;
+            const double x1 = p1[at], y1 = p1[at + 1], x2 = p2[at], y2 = p2[at + 1];
+            double G[4][4], V[4][4];
+            const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            G[0][k] = x1 * P0[8 + k] - P0[k];
-            G[1][k] = y1 * P0[8 + k] - P0[4 + k];
-            G[2][k] = x2 * Pc[8 + k] - Pc[k];
-            G[3][k] = y2 * Pc[8 + k] - Pc[4 + k];
+            for (int k = 0; k < 4; ++k) {
+                G[0][k] = x1 * P0[8 + k] - P0[k];
+                G[1][k] = y1 * P0[8 + k] - P0[4 + k];
+                G[2][k] = x2 * Pc[8 + k] - Pc[k];
+                G[3][k] = y2 * Pc[8 + k] - Pc[4 + k];
+            }
+            jacobi4_right_vectors(G, V);
+            double w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j] + G[3][j] * G[3][j];
+            int m = 0;
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+                if (w[j] < w[m]) m = j;
+            double X[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) X[k] = (m == 0) ? V[k][0] : (m == 1 ? V[k][1] : (m == 2 ? V[k][2] : V[k][3]));
+            bool mk = (X[2] * X[3] > 0);
+            const double qz = Pc[8] * X[0] + Pc[9] * X[1] + Pc[10] * X[2] + Pc[11] * X[3];
+            mk = mk && (qz * X[3] > 0);
+            const double qzz = X[2] / X[3];
+            mk = mk && (qzz < dist);
+            uint8_t mv = mk ? 255 : 0;
+            if (mask_in) mv &= mask_in[(size_t)b * pair_stride + i];
+            mask_out[((size_t)b * 4 + c) * pair_stride + i] = mv;
+            good = (mv != 0);
         }
-        jacobi_right_vectors<4>(G, V);
-        double w[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j] + G[3][j] * G[3][j];
-        int m = 0;
-#pragma unroll
-        for (int j = 1; j < 4; ++j)
-            if (w[j] < w[m]) m = j;
-        double X[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) X[k] = (m == 0) ? V[k][0] : (m == 1 ? V[k][1] : (m == 2 ? V[k][2] : V[k][3]));
-        bool mk = (X[2] * X[3] > 0);
-        const double qz = Pc[8] * X[0] + Pc[9] * X[1] + Pc[10] * X[2] + Pc[11] * X[3];
-        mk = mk && (qz * X[3] > 0);
-        const double qzz = X[2] / X[3];
-        mk = mk && (qzz < dist);
-        uint8_t mv = mk ? 255 : 0;
-        if (mask_in) mv &= mask_in[(size_t)b * pair_stride + i];
-        mask_out[((size_t)b * 4 + c) * pair_stride + i] = mv;
-        good = (mv != 0);
+        n_good += __popcll(__ballot(good));
     }
-    __syncthreads();  // wave_cnt is reused below
-    const unsigned long long bal = __ballot(good);
-    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(bal);
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&cand_counts[b * 4 + c], wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
+    if (lane == 0 && n_good) atomicAdd(&cand_counts[b * 4 + c], n_good);
 }
 
 __global__ __launch_bounds__(256) void select_pose_batch_kernel(const double *__restrict__ P_all, const int32_t *__restrict__ cand_counts,
@@ -372,7 +443,7 @@ int launch_recover_pose_batch(const char *d_E_base, size_t E_stride, const doubl
                               hipStream_t s) {
     MLPL_HIP_TRY(hipMemsetAsync(d_cand_counts, 0, (size_t)B * 16, s));
     hipLaunchKernelGGL(decompose_batch_kernel, dim3(B), dim3(64), 0, s, d_E_base, E_stride, d_active, d_P);
-    hipLaunchKernelGGL(triangulate_batch_kernel, dim3((pair_stride + 255) / 256, 4, B), dim3(256), 0, s, (const double *)d_P, d_p1, d_p2, d_counts,
+    hipLaunchKernelGGL(triangulate_batch_kernel, dim3((pair_stride + 4 * kTriPointsPerWave - 1) / (4 * kTriPointsPerWave), 4, B), dim3(256), 0, s, (const double *)d_P, d_p1, d_p2, d_counts,
                        d_active, pair_stride, dist, (const uint8_t *)d_mask, d_cand_masks, d_cand_counts);
     hipLaunchKernelGGL(select_pose_batch_kernel, dim3(B), dim3(256), 0, s, (const double *)d_P, (const int32_t *)d_cand_counts, d_counts, d_active,
                        pair_stride, (const uint8_t *)d_cand_masks, d_mask, d_out);
