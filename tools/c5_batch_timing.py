@@ -26,7 +26,7 @@ for pb in (64, 32, 128):
         rec = batch.process_pairs_batched(ctx, st["desc1"], st["desc2"], st["kp1"], st["kp2"], K, K, seeds)
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
-    stats = np.zeros(4, np.int64)
+    stats = np.zeros(8, np.int64)   # mlpl_pair_batch_last_stats writes eight values
     ctx.lib.mlpl_pair_batch_last_stats(ctx.handle, stats.ctypes.data)
     print(f"pair_batch {pb}: {total} pairs, ms per pass {[round(t * 1e3, 2) for t in ts]}, best {total / min(ts):.0f} pairs/s = {min(ts) / total * 1e6:.1f} us/pair, "
           f"status ok {(rec['status'] == 0).sum()}, mean matches {rec['n_matches'].mean():.0f} inliers {rec['n_inliers'].mean():.0f}, stats {stats}", flush=True)
