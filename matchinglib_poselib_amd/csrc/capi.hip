@@ -123,6 +123,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_solver_wave3 = 1;
     ctx->opt_ransac_device_draw = 1;
     ctx->opt_usac_lo_warm_start = 1;
+    ctx->opt_usac_sprt_fast = 1;
     ctx->opt_l2_float_mfma = 1;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -201,6 +202,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "pair_batch_raw_cap") && (value == 0 || (value >= 64 && value <= (1 << 22)))) ctx->opt_pair_batch_raw_cap = value;
     else if (!std::strcmp(name, "usac_lo_stepwise") && (value == 0 || value == 1)) ctx->opt_usac_lo_stepwise = value;
     else if (!std::strcmp(name, "usac_lo_warm_start") && (value == 0 || value == 1)) ctx->opt_usac_lo_warm_start = value;
+    else if (!std::strcmp(name, "usac_sprt_fast") && (value == 0 || value == 1)) ctx->opt_usac_sprt_fast = value;
     else if (!std::strcmp(name, "ransac_host_table") && (value == 0 || value == 1)) ctx->opt_ransac_host_table = value;
     else if (!std::strcmp(name, "ransac_chunk") && value >= 0 && value <= 32768) ctx->opt_ransac_chunk = value;
     else {

@@ -529,6 +529,7 @@ struct UsacRun {
     unsigned n = 0, max_hyp = 50000;
     double conf = 0.99, thr = 0;
     bool prosac = false;
+    bool sprt_fast = true;  // option usac_sprt_fast (tests run both)
     unsigned prosac_max_samples = 1000, prosac_min_stop = 20;
     double prosac_beta = 0.09, prosac_non_rand_conf = 0.99;
     std::vector<unsigned> sorted_idx;
@@ -715,33 +716,61 @@ struct UsacRun {
             T_n_p = growth[i];
         }
         non_random.assign(n, 0);
-        double pn_i = 1.0;
-        for (unsigned nn = 6; nn <= n; ++nn) {
-            if (nn - 1 > 1000) {
-                non_random[nn - 1] = non_random[nn - 2];
-                continue;
-            }
-            std::vector<double> v(n, 0);
-            v[5] = prosac_beta * std::pow((double)1 - prosac_beta, (double)nn - 5 - 1) * (nn - 5);
-            pn_i = v[5];
-            for (unsigned i = 7; i <= nn; ++i) {
-                if (i == nn) {
-                    v[nn - 1] = std::pow((double)prosac_beta, (double)nn - 5);
-                    break;
+        // Non-randomness table (USAC.h initProsac): for every subset size nn <= 1001 the binomial terms v[5 .. nn-1] by a forward
+        // recurrence, then their tail sum from the top.  Entry nn depends on (nn, beta) only, and each recurrence is one serial chain of
+        // two multiplications per step -- ~500 000 dependent steps at n >= 1001, a millisecond on the host, as long as the rest of a PROSAC
+        // call.  Four sizes are therefore advanced side by side (four independent chains in flight); every chain performs the reference's
+        // operations in the reference's order (element-wise vector arithmetic is IEEE arithmetic per element), so the table is the same
+        // bit for bit.  (The reference also allocates and zeroes n doubles per nn; the buffer here is reused: every entry is written
+        // before the tail sum reads it.)
+        {
+            const unsigned top = std::min(n, 1001u);
+            constexpr int W = 4;
+            typedef double vecW __attribute__((vector_size(W * sizeof(double))));  // element-wise IEEE operations: same bits as scalar code
+            std::vector<vecW> vbuf((size_t)top + 1);                                // vbuf[i - 1][k]: term i of size nn0 + k
+            const double ratio_c = prosac_beta / (1 - prosac_beta);
+            for (unsigned nn0 = 6; nn0 <= top; nn0 += W) {
+                vecW pn, nnv;
+                unsigned nnk[W];
+                for (int k = 0; k < W; ++k) {  // sizes beyond `top` are computed along and dropped
+                    const unsigned nn = nn0 + k;
+                    nnk[k] = nn;
+                    nnv[k] = (double)nn;
+                    pn[k] = prosac_beta * std::pow((double)1 - prosac_beta, (double)nn - 5 - 1) * (nn - 5);
                 }
-                v[i - 1] = pn_i * (prosac_beta / (1 - prosac_beta)) * ((double)(nn - i) / (i - 5 + 1));
-                pn_i = v[i - 1];
+                vbuf[5] = pn;
+                // steps every size takes: i < nn0 (the integers nn - i and i - 4 are exact in double, so the quotient is the reference's)
+                for (unsigned i = 7; i < nn0; ++i) {
+                    const double di = (double)i, den = (double)(i - 5 + 1);
+                    pn = pn * ratio_c * ((nnv - di) / den);
+                    vbuf[i - 1] = pn;
+                }
+                // the last steps, size by size: term nn is beta^(nn - 5)
+                for (int k = 0; k < W; ++k) {
+                    const unsigned nn = nnk[k];
+                    if (nn > top) continue;
+                    double p = pn[k];
+                    for (unsigned i = std::max(7u, nn0); i <= nn; ++i) {
+                        if (i == nn) {
+                            vbuf[nn - 1][k] = std::pow((double)prosac_beta, (double)nn - 5);
+                            break;
+                        }
+                        vbuf[i - 1][k] = p * (prosac_beta / (1 - prosac_beta)) * ((double)(nn - i) / (i - 5 + 1));
+                        p = vbuf[i - 1][k];
+                    }
+                    double accp = 0.0;
+                    unsigned i_min = 0;
+                    for (unsigned i = nn; i >= 6; --i) {
+                        accp += vbuf[i - 1][k];
+                        if (accp < 1 - prosac_non_rand_conf)
+                            i_min = i;
+                        else
+                            break;
+                    }
+                    non_random[nn - 1] = i_min;
+                }
             }
-            double accp = 0.0;
-            unsigned i_min = 0;
-            for (unsigned i = nn; i >= 6; --i) {
-                accp += v[i - 1];
-                if (accp < 1 - prosac_non_rand_conf)
-                    i_min = i;
-                else
-                    break;
-            }
-            non_random[nn - 1] = i_min;
+            for (unsigned nn = top + 1; nn <= n; ++nn) non_random[nn - 1] = non_random[nn - 2];
         }
         maximality.assign(n, max_hyp);
         largest_size = 5, subset_size = 5, stop_len = n;
@@ -906,30 +935,88 @@ struct UsacRun {
         return MLPL_OK;
     }
 
-    // evaluateModel's sequential test on a bit row (pool order)
+    // evaluateModel's sequential test on a bit row (pool order): the likelihood ratio is multiplied point by point (inlier: delta / epsilon,
+    // outlier: (1 - delta) / (1 - epsilon)), clamped from below at 10 DBL_EPSILON, and the model is rejected the moment it exceeds A.
+    // The steps are one dependent chain (multiply, clamp, compare: ~2.5 ns each on the host), and a model that is NOT rejected walks all
+    // n correspondences -- 35 such walks per local optimisation, a third of a USAC call.  A walk therefore takes its first kSprtExact steps
+    // as the reference does (a bad model is rejected there) and then tries to PROVE that no later step can reject: per bit-row word, with
+    // ones / zeros counted by popcount, every intermediate ratio is at most max(U, floor) max(up, 1)^ones max(down, 1)^zeros for an upper
+    // bound U of the ratio at the word's start, and U advances to max(U up^ones down^zeros, floor max(up, 1)^ones max(down, 1)^zeros)
+    // (the clamp only ever raises the ratio to the floor; powers rounded up).  If every word stays below A the verdict is "accepted" with all
+    // n correspondences tested and the row's inlier count -- exactly what the step-by-step walk returns; if any word cannot be cleared
+    // the walk resumes step by step from the saved exact state.  Same verdicts, counts and pool positions by construction; the decision
+    // traces of tests/test_gpu_usac*.py compare all three with the reference-built runs.
+    static constexpr unsigned kSprtExact = 128;
+    struct SprtBounds {
+        double up = -1, down = -1;
+        double Pu[65], Pz[65], Gu[65], Gz[65];
+    } sb;
+    void sprt_bounds(double up, double down) {
+        if (sb.up == up && sb.down == down) return;
+        sb.up = up, sb.down = down;
+        const double gu = up > 1 ? up : 1.0, gz = down > 1 ? down : 1.0, slack = 1.0 + 0x1p-40;
+        double pu = 1, pz = 1, qu = 1, qz = 1;
+        for (int k = 0; k <= 64; ++k) {
+            sb.Pu[k] = pu * slack, sb.Pz[k] = pz * slack, sb.Gu[k] = qu * slack, sb.Gz[k] = qz * slack;
+            pu *= up, pz *= down, qu *= gu, qz *= gz;
+        }
+    }
     bool sprt_walk(const uint64_t *bits, unsigned *num_inl, unsigned *tested) {
         bool good = true;
         double lj, lj1 = 1.0;
         *num_inl = 0, *tested = 0;
         const double up = sprt_delta / sprt_epsilon, down = (1 - sprt_delta) / (1 - sprt_epsilon);
-        for (unsigned i = 0; i < n; ++i) {
-            if (pool_index > n - 1) pool_index = 0;
-            const unsigned j = pool_index;
-            ++pool_index;
-            const bool in = (bits[j >> 6] >> (j & 63)) & 1;
-            if (in) {
-                ++(*num_inl);
-                lj = lj1 * up;
-            } else
-                lj = lj1 * down;
-            if (lj <= DBL_EPSILON) lj = DBL_EPSILON * 10;
-            if (lj > sprt_A) {
-                good = false;
-                *tested = i + 1;
-                break;
+        unsigned i = 0;
+        auto steps = [&](unsigned end) {  // the reference's loop over [i, end)
+            for (; i < end; ++i) {
+                if (pool_index > n - 1) pool_index = 0;
+                const unsigned j = pool_index;
+                ++pool_index;
+                const bool in = (bits[j >> 6] >> (j & 63)) & 1;
+                if (in) {
+                    ++(*num_inl);
+                    lj = lj1 * up;
+                } else
+                    lj = lj1 * down;
+                if (lj <= DBL_EPSILON) lj = DBL_EPSILON * 10;
+                if (lj > sprt_A) {
+                    good = false;
+                    *tested = i + 1;
+                    return;
+                }
+                lj1 = lj;
             }
-            lj1 = lj;
+        };
+        steps(std::min(n, kSprtExact));
+        if (!good) return false;
+        if (i < n && sprt_fast) {
+            sprt_bounds(up, down);
+            const double floor_v = DBL_EPSILON * 10, slack = 1.0 + 0x1p-40, A_safe = sprt_A * (1.0 - 0x1p-30);
+            double U = lj1;
+            unsigned pi = pool_index, at = i, ones_rest = 0;
+            bool cleared = true;
+            while (at < n) {
+                if (pi > n - 1) pi = 0;
+                const unsigned off = pi & 63, len = std::min(std::min(64u - off, n - pi), n - at);
+                uint64_t w = bits[pi >> 6] >> off;
+                if (len < 64) w &= (1ull << len) - 1ull;
+                const unsigned ones = (unsigned)__builtin_popcountll(w), zeros = len - ones;
+                const double grow = sb.Gu[ones] * sb.Gz[zeros] * slack;
+                const double base = U > floor_v ? U : floor_v;
+                if (!(base * grow * slack < A_safe)) {  // also taken for NaN / inf parameters
+                    cleared = false;
+                    break;
+                }
+                const double through = U * sb.Pu[ones] * sb.Pz[zeros] * slack, from_floor = floor_v * grow;
+                U = (through > from_floor ? through : from_floor) * slack;
+                ones_rest += ones, pi += len, at += len;
+            }
+            if (cleared) {
+                *num_inl += ones_rest, *tested = n, pool_index = pi;
+                return true;
+            }
         }
+        steps(n);
         if (good) *tested = n;
         return good;
     }
@@ -1551,6 +1638,7 @@ int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, in
     R.prosac_beta = P->prosac_beta, R.sprt_delta = P->sprt_delta, R.sprt_epsilon = P->sprt_epsilon;
     R.sprt_mS = P->sprt_mS, R.sprt_tM = P->sprt_tM;
     R.lo_stepwise = ctx->opt_usac_lo_stepwise;
+    R.sprt_fast = ctx->opt_usac_sprt_fast != 0;
     R.dg_on = P->check_degeneracy != 0;
     R.dg_losac = R.dg_on && (P->check_degeneracy & 2) != 0;
     if (R.dg_on) R.dg_thr = 1.0 - std::cos(std::atan(P->th_pixels / P->focal_length));  // EssentialMatEstimator.h:349

@@ -51,6 +51,28 @@ def test_device_follows_the_reference_running_its_default_stewenius_solver(ctx):
     assert checked >= 21
 
 
+def test_sequential_test_finished_on_bounds_takes_the_same_decisions(ctx):
+    """Option usac_sprt_fast (default 1): a sequential test that survives its first 128 steps is finished word by word on upper bounds of the
+    likelihood ratio instead of step by step.  Same events (start position, inliers seen, points tested, verdict, SPRT parameters) and the
+    same result with the option off, on scenes from 64 to 8192 correspondences, uniform and PROSAC, with the degeneracy tests."""
+    from matchinglib_poselib_amd import pose
+
+    for sc in usac_compare.scenes():
+        for prosac, chk in ((False, 0), (True, 0), (False, 3)):
+            si = sc["order"] if prosac else None
+            runs = []
+            for fast in (1, 0):
+                ctx.set_option("usac_sprt_fast", fast)
+                try:
+                    runs.append(pose.usac_essential(sc["p1"], sc["p2"], sc["th"], 31337, sorted_idx=si, event_cap=120000, max_hyp=4000,
+                                                    check_degeneracy=chk, ctx=ctx))
+                finally:
+                    ctx.set_option("usac_sprt_fast", 1)
+            a, b = runs
+            assert a["n_events"] == b["n_events"] and np.array_equal(a["events"], b["events"]), sc["name"]
+            assert np.array_equal(a["final"], b["final"]) and np.array_equal(a["flags"], b["flags"]) and np.array_equal(a["E"], b["E"])
+
+
 def test_device_equals_oracle_turn_by_turn(ctx, oracle):
     """Ten more scenes incl. C3 (5000 correspondences, 50 % inliers) and 8192 correspondences at 25 %: identical decisions, models to 1e-8.
     A run may part from the oracle only at a sample whose solution COUNT differs (a double root on the 1e-10 imaginary-part line).
