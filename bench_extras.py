@@ -151,6 +151,13 @@ def run(ctx, dev, cpu_baseline=True):
         out[nm] = {"metric": "one estimateEssentialOrPoseUSAC-shaped call (POSE_NISTER, REF_WEIGHTS), host points in / E + mask out (5000 correspondences)",
                    "ms_per_call": dt * 1e3, "hypotheses": int(ur["final"][1]), "n_inliers": int(ur["final"][5]), "local_optimisations": int(ur["final"][7]),
                    "device_batches": int(ur["stats"][0]), "samples_solved": int(ur["stats"][1]), "lo_launches": int(ur["stats"][3])}
+        if si is not None:
+            # PROSAC's non-randomness table depends on (beta, confidence) only and the context keeps the last one: the calls above reuse it
+            # (ConfigUSAC::noAutomaticProsacParamters -- a fixed beta); with the automatic setting beta changes from call to call:
+            t0 = time.perf_counter()
+            for k in range(10):
+                pose.usac_essential(p1, p2, th, 12345, sorted_idx=si, prosac_beta=0.09 + 1e-9 * (k + 1), ctx=ctx)
+            out[nm]["ms_per_call_new_prosac_beta_every_call"] = (time.perf_counter() - t0) / 10 * 1e3
         if cpu_baseline:
             tc = time.perf_counter()
             ou = ora.usac_essential(p1, p2, th, 12345, sorted_idx=si)

@@ -158,6 +158,7 @@ void mlpl_ctx_destroy(mlpl_ctx *ctx) {
     if (ctx->l2_hint_host) (void)hipHostFree(ctx->l2_hint_host);
     delete[] ctx->ransac_T_host;
     std::free(ctx->last_usac_flags);
+    std::free(ctx->usac_prosac_tab);
     mlpl::free_rand_cache(ctx->rand_cache);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (int i = 0; i < 2; ++i)

@@ -139,6 +139,9 @@ struct mlpl_ctx {
     double last_usac_degen[16];                        // {tests on, inliers of the rotation, of "no motion", degeneracy type, R[9]}
     uint8_t *last_usac_flags;                          // malloc'ed, 2 * last_usac_flags_n bytes: inlier masks of the rotation / of "no motion"
     int last_usac_flags_n;
+    unsigned *usac_prosac_tab;                         // calloc'ed, 1001 entries: PROSAC's non-randomness table of the last (beta, confidence) (usac_impl.h init_prosac)
+    unsigned usac_prosac_tab_top;
+    double usac_prosac_tab_beta, usac_prosac_tab_conf;
     long long last_batch_stats[8];                     // mlpl_pair_pose_batch_dev: {RANSAC passes, pair slots over all passes, pairs redone on a host table, 0}
     int opt_pair_batch;                                // pairs per internal batch of mlpl_pair_pose_batch_dev (0 = 128)
     int opt_pair_batch_raw_cap;                        // tests: rand() values kept per pair for the device-side sampling (0 = 6.25 per iteration + 1024)
