@@ -2,7 +2,7 @@
 inlier ratios 0.1 .. 1; uniform and PROSAC sampling), device path against the CPU oracle.
     python tools/stress_usac_degen.py [seconds]          (GPU box)
 Per run: both sides must agree event by event up to and including the first degeneracy test unless they part earlier at a model of a
-sample without parallax (types 2 / 5); a no-motion upgrade must agree candidate by candidate; the verdict "degenerate" (both decision
+sample without parallax (types 2 / 5 / 6: its solutions, their number or the oriented-constraint verdict on one of them); a no-motion upgrade must agree candidate by candidate; the verdict "degenerate" (both decision
 thresholds in use) and the rotation-only model must agree at the end.  Prints the tally; exits non-zero on any violation."""
 from __future__ import annotations
 
@@ -69,7 +69,7 @@ def main():
                 tally["violations"] += 1
             continue
         if first is not None and first <= i7:
-            if int(eo[first][0]) in (1, 2, 3, 5) and kind != 0:
+            if int(eo[first][0]) in (1, 2, 3, 5, 6) and kind != 0:   # 6 / 2: the oriented-constraint verdict of such a model differs (either side)
                 tally["parted_before_test"] += 1
                 continue
             if kind == 0 and int(eo[first][0]) in (1, 5):   # a double root: the known category of the plain run
