@@ -73,6 +73,27 @@ def test_sequential_test_finished_on_bounds_takes_the_same_decisions(ctx):
             assert np.array_equal(a["final"], b["final"]) and np.array_equal(a["flags"], b["flags"]) and np.array_equal(a["E"], b["E"])
 
 
+def test_prosac_table_kept_by_the_context_gives_the_same_run(ctx):
+    """init_prosac's non-randomness table depends on (subset size, beta, confidence) only; the context keeps the last one.  A run that copies
+    it (same beta, fewer correspondences: a prefix of the kept table) equals the run of a fresh context event by event, and a run with
+    another beta -- which recomputes -- does too."""
+    import matchinglib_poselib_amd as mpa
+    from matchinglib_poselib_amd import pose
+
+    p1, p2, th, truth, order = make_golden.usac_scene(5000, 0.5, 20260103)
+    q1, q2, qth, qtruth, qorder = make_golden.usac_scene(300, 0.5, 13)
+    pose.usac_essential(p1, p2, th, 5, sorted_idx=order, ctx=ctx)                       # fills the table (1001 sizes, beta 0.09)
+    for beta in (0.09, 0.05, 0.09):
+        kept = pose.usac_essential(q1, q2, qth, 77, sorted_idx=qorder, prosac_beta=beta, event_cap=20000, ctx=ctx)
+        fresh_ctx = mpa.Context(0)
+        try:
+            fresh = pose.usac_essential(q1, q2, qth, 77, sorted_idx=qorder, prosac_beta=beta, event_cap=20000, ctx=fresh_ctx)
+        finally:
+            fresh_ctx.close()
+        assert kept["n_events"] == fresh["n_events"] and np.array_equal(kept["events"], fresh["events"]), beta
+        assert np.array_equal(kept["final"], fresh["final"]) and np.array_equal(kept["flags"], fresh["flags"])
+
+
 def test_device_equals_oracle_turn_by_turn(ctx, oracle):
     """Ten more scenes incl. C3 (5000 correspondences, 50 % inliers) and 8192 correspondences at 25 %: identical decisions, models to 1e-8.
     A run may part from the oracle only at a sample whose solution COUNT differs (a double root on the 1e-10 imaginary-part line).
