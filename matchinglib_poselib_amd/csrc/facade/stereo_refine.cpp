@@ -1201,6 +1201,11 @@ int StereoRefine::Impl::addNewCorrespondences(std::vector<cv::DMatch> &matches, 
     // the caller's pointers describe the matches of this call (tests/poselib-test/main.cpp:1944-1957); the by-value copies this function
     // works on are the same data and stay alive for the whole call, where the reference re-points cfg_usac.matches at them (:625-649)
     if (cfg.matches) cfg_usac.matches = &matches, cfg_usac.keypoints1 = &kp1, cfg_usac.keypoints2 = &kp2;
+    // ... and die with it: on every exit the member copy forgets them
+    struct Unpoint {
+        ConfigUSAC &c;
+        ~Unpoint() { c.matches = nullptr, c.keypoints1 = nullptr, c.keypoints2 = nullptr; }
+    } unpoint{cfg_usac};
     nr_corrs_new = matches.size();
     const int n0 = (int)nr_corrs_new;
     std::vector<float> a((size_t)n0 * 2), b((size_t)n0 * 2);
@@ -1233,6 +1238,14 @@ int StereoRefine::Impl::addNewCorrespondences(std::vector<cv::DMatch> &matches, 
     // (Remove_LensDist drops correspondences whose undistortion fails from the point vectors only; the reference keeps indexing
     // `matches` by position afterwards, so a drop misaligns its bookkeeping -- with n_left == n0, the normal case, nothing moves)
     const int n = n_left;
+    std::vector<cv::DMatch> matches_left;
+    if (n_left != n0 && cfg_usac.matches) {
+        // USAC asserts one match per correspondence (usac_estimations.cpp:316).  After a drop the reference's own bookkeeping pairs the
+        // surviving correspondences with the leading matches by position; the PROSAC order and the SPRT start values get the same view
+        // here instead of an assertion out of addNewCorrespondences (every other RobMethod carries on)
+        matches_left.assign(matches.begin(), matches.begin() + n_left);
+        cfg_usac.matches = &matches_left;
+    }
     points1new.resize((size_t)n);
     points2new.resize((size_t)n);
     p1new.resize((size_t)n * 2);

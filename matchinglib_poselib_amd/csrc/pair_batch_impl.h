@@ -348,11 +348,14 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
             ctx->last_batch_stats[5] += state[b].models_scored * (long long)h_counts[b];
             ctx->last_batch_stats[6] += state[b].iter;
         }
-    // the rare pairs whose iteration bound has to come from the host table: the single-pair pipeline on their inputs
+    // the rare pairs whose iteration bound has to come from the host table: the single-pair pipeline on their inputs.  The nested entries
+    // take the context's pinned block for their own records (their ReplayState lands where h_counts sits), so everything the loop needs
+    // from that block is copied out before the first of them runs.
+    const std::vector<int32_t> counts_copy(h_counts, h_counts + B);
     for (int b : redo) {
         if (points_mode) {  // the single-problem entries on this problem's correspondences
             mlpl_pair_result &o = out[b];
-            const int nb = h_counts[b];
+            const int nb = counts_copy[b];
             std::memset(&o, 0, sizeof(o));
             o.n_matches = nb;
             int ninl = 0, iters = 0;

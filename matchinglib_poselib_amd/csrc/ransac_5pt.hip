@@ -37,6 +37,7 @@
 #include <climits>
 #include <cmath>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <unordered_map>
 #include <unordered_set>
@@ -3571,7 +3572,12 @@ int mlpl_usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p
     int rc;
     if ((rc = usac_check_params(params, n, "mlpl_usac_essential_dev"))) return rc;
     MLPL_HIP_TRY(hipSetDevice(ctx->device));
-    return usac_essential_dev(ctx, d_p1, d_p2, n, params, E, d_mask, results, pick_stream(ctx, stream));
+    try {  // the host side of a run allocates (sample cache, bit rows): nothing may unwind through the C boundary
+        return usac_essential_dev(ctx, d_p1, d_p2, n, params, E, d_mask, results, pick_stream(ctx, stream));
+    } catch (const std::bad_alloc &) {
+        set_error("mlpl_usac_essential_dev: out of host memory");
+        return MLPL_E_NOMEM;
+    }
 }
 
 int mlpl_usac_last_degeneracy(mlpl_ctx *ctx, double info[16], uint8_t *flags_rot, uint8_t *flags_nomot, int n) {
@@ -3606,7 +3612,12 @@ int mlpl_usac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n
     MLPL_HIP_TRY(hipMemcpyAsync(dp1, p1, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
     MLPL_HIP_TRY(hipMemcpyAsync(dp2, p2, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
     // the sequential part runs on the host and reads the correspondences there: it takes the caller's copies and returns the mask directly
-    return usac_essential_dev(ctx, (const double *)dp1, (const double *)dp2, n, params, E, nullptr, results, ctx->stream, p1, p2, mask);
+    try {
+        return usac_essential_dev(ctx, (const double *)dp1, (const double *)dp2, n, params, E, nullptr, results, ctx->stream, p1, p2, mask);
+    } catch (const std::bad_alloc &) {
+        set_error("mlpl_usac_essential: out of host memory");
+        return MLPL_E_NOMEM;
+    }
 }
 
 int mlpl_usac_last_stats(mlpl_ctx *ctx, long long stats[8]) {

@@ -30,6 +30,7 @@
 namespace {
 
 constexpr int kUsacBatch = 128;
+constexpr size_t kUsacCacheBytes = (size_t)256 << 20;  // bound of the host-side sample cache of a run
 constexpr int kUsacLoReps = 5, kUsacLoSample = 14, kUsacLoSteps = 4, kUsacLoEvals = 2 + kUsacLoSteps;
 constexpr int kUsacLoThreads = 512;
 constexpr int kUsacLoMaxRows = 512;  // rows of kUsacLoThreads correspondences a local-optimisation workgroup walks: n <= 262144
@@ -559,6 +560,7 @@ struct UsacRun {
     std::vector<unsigned> growth, non_random, maximality;
     std::unordered_map<UsacKey, UsacSampleModels, UsacKeyHash> cache;
     double cache_thr = 0;
+    size_t cache_bytes = 0;  // bit rows held by the cache; bounded by kUsacCacheBytes (a run that never stops early would keep 50000 samples' rows)
     // results
     unsigned hyp_count = 0, model_count = 0, rejected_samples = 0, rejected_models = 0, best = 0, points_verified = 0, num_lo = 0;
     std::vector<uint8_t> flags;
@@ -940,6 +942,7 @@ struct UsacRun {
                 m.valid = h_valid[b * 10 + slot];
                 m.bits.assign(h_rows + ((size_t)b * 10 + slot) * words, h_rows + ((size_t)b * 10 + slot + 1) * words);
             }
+            cache_bytes += sizeof(UsacSampleModels) + (size_t)nm * words * 8;
             cache.emplace(keys[b], std::move(sm));
         }
         stats[0]++, stats[1] += B;
@@ -1507,7 +1510,7 @@ struct UsacRun {
                 thr *= 1.33;
             else if ((hyp_count == max3) && (best == 0))
                 thr *= 1.13;
-            if (thr != cache_thr) cache.clear(), cache_thr = thr;  // bit rows are per threshold
+            if (thr != cache_thr) cache.clear(), cache_bytes = 0, cache_thr = thr;  // bit rows are per threshold
             if (prosac)
                 prosac_sample(rng, subset_size, largest_size, stop_len, hyp_count, min_sample);
             else
@@ -1523,6 +1526,9 @@ struct UsacRun {
             for (int i = 0; i < 5; ++i) key.v[i] = min_sample[i];
             auto it = cache.find(key);
             if (it == cache.end()) {
+                // nothing refers to a cache entry here: a cache that has outgrown its bound is dropped whole (its entries are speculation and
+                // samples already consumed; a sample that recurs is solved again, with the same result)
+                if (cache_bytes > kUsacCacheBytes) cache.clear(), cache_bytes = 0;
                 // play the sampler forward under "no event" and solve what is coming in one batch
                 std::vector<UsacKey> batch(1, key);
                 std::unordered_set<UsacKey, UsacKeyHash> in_batch;

@@ -181,6 +181,24 @@ def test_batched_correspondence_sets_equal_the_single_problem_entries(ctx, recov
     masks = torch.zeros((40, stride), dtype=torch.uint8, device=dev)
     got = batch.ransac_pose_batched(ctx, d1, d2, sizes, seeds, ths, recover_pose=recover, masks_out=masks)
     mh = masks.cpu().numpy()
+    # the same batch with the raw rand() streams cut short: the small problems (many redraws) and the ones that need a second pass run out
+    # of stream and are redone through the single-problem entry -- several of ONE internal batch, one after the other (the nested calls
+    # reuse the context's pinned block: ADVICE r3), with the same records and masks
+    masks2 = torch.zeros((40, stride), dtype=torch.uint8, device=dev)
+    stats = np.zeros(8, np.int64)
+    ctx.set_option("pair_batch_raw_cap", 1700)
+    try:
+        got2 = batch.ransac_pose_batched(ctx, d1, d2, sizes, seeds, ths, recover_pose=recover, masks_out=masks2)
+    finally:
+        ctx.set_option("pair_batch_raw_cap", 0)
+    ctx.lib.mlpl_pair_batch_last_stats(ctx.handle, stats.ctypes.data)
+    assert stats[2] >= 2, stats
+    for g, h in zip(got, got2):
+        assert all(np.array_equal(np.asarray(g[k]), np.asarray(h[k])) for k in g), (g, h)
+    mh2 = masks2.cpu().numpy()
+    for i, n in enumerate(sizes):
+        if n >= 6 and got[i]["status"] == 0:
+            assert np.array_equal(mh2[i, :n], mh[i, :n]), i
     for i, n in enumerate(sizes):
         g = got[i]
         if n < 6:
