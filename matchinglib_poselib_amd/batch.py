@@ -199,16 +199,21 @@ class BatchLanes:
         self.streams = [torch.cuda.Stream(self.device) for _ in range(lanes)]
         self.pool = ThreadPoolExecutor(max_workers=lanes)
         self.lanes = lanes
+        self.last_lane_span = [(0.0, 0.0)] * lanes
 
     def _run(self, w, b, e, d_q, d_t, d_kp1, d_kp2, K0, K1, seeds, pair_ids, matches_out, kw):
         import torch
 
+        import time
+
+        t0 = time.perf_counter()
         torch.cuda.set_device(self.device)
         with torch.cuda.stream(self.streams[w]):
             r = process_pairs_batched(self.ctxs[w], d_q[b:e], d_t[b:e], d_kp1[b:e], d_kp2[b:e], K0, K1, seeds[b:e],
                                       pair_ids=None if pair_ids is None else pair_ids[b:e],
                                       matches_out=None if matches_out is None else matches_out[b:e], **kw)
             self.streams[w].synchronize()
+        self.last_lane_span[w] = (t0, time.perf_counter())   # when this lane's call started and ended (diagnostics: which lane stalled)
         return r
 
     def process(self, d_q, d_t, d_kp1, d_kp2, K0, K1, seeds, pair_ids=None, matches_out=None, **kw) -> np.ndarray:
