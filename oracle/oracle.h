@@ -98,6 +98,11 @@ int oracle_get_subset(oracle_glibc_rand *st, const double *p1, const double *p2,
 /* CvEMEstimator::run5Point (five-point.cpp:366-471).  q1,q2: n x 2 doubles (n>=5).
  * E_out: up to 10 row-major 3x3 matrices.  Returns the number of solutions. */
 int oracle_run5point(const double *q1, const double *q2, int n, double *E_out);
+/* The same solver on an n x 9 system given row by row (row i = s_i * (u2_i (x) u1_i), entry 3 a + b): OpenGV's fivept_nister /
+ * fivept_stewenius on n >= 5 unit bearing vectors (P/thirdparty/opengv/src/relative_pose/methods.cpp:183-268) and the reference's
+ * weighted forms (P/source/usac/utils/weightingEssential.cpp:62-148) build this system; the essential matrices are those of the four
+ * right singular vectors of the smallest singular values. */
+int oracle_run5point_rows(const double *rows, int n, double *E_out);
 /* The same plus diagnostics: c_out[11] = the degree-10 polynomial (ascending powers), roots_out[20] = solvePoly's roots as
  * (re, im) in root order, xy1z_out[10] = third component of the SVD::solveZ vector per root (NaN = rejected as complex). */
 int oracle_run5point_dbg(const double *q1, const double *q2, int n, double *E_out, double *c_out, double *roots_out,

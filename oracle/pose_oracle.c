@@ -376,6 +376,8 @@ void oracle_detpoly(const double *b, double *c) {
 /* The 10 x 20 constraint matrix in the reference's column order (getCoeffMat, five-point.cpp:603-824), EE[b * 9 + k]. */
 void oracle_coeff_matrix(const double *EE, double *A) { coeff_matrix(EE, A); }
 
+static int run5point_rows(double *Q, int n, double *E_out, double *c_out, double *roots_out, double *xy1z_out);
+
 static int run5point_impl(const double *q1, const double *q2, int n, double *E_out, double *c_out, double *roots_out,
                           double *xy1z_out) {
     if (n < 5) return 0;
@@ -394,9 +396,28 @@ static int run5point_impl(const double *q1, const double *q2, int n, double *E_o
         r[7] = y1;
         r[8] = 1.0;
     }
+    const int count = run5point_rows(Q, n, E_out, c_out, roots_out, xy1z_out);
+    free(Q);
+    return count;
+}
+
+/* The solver on an n x 9 system given row by row: row i = s_i * (u2_i (x) u1_i), entry 3 a + b = s_i u2_i[a] u1_i[b].  This is what
+ * OpenGV's fivept_nister / fivept_stewenius build from unit bearing vectors for n >= 5 correspondences
+ * (P/thirdparty/opengv/src/relative_pose/methods.cpp:183-268) and what the reference's weighted forms scale row by row
+ * (P/source/usac/utils/weightingEssential.cpp:62-148); the essential matrices are those of the four right singular vectors of the
+ * smallest singular values.  Q is overwritten. */
+int oracle_run5point_rows(const double *rows, int n, double *E_out) {
+    if (n < 5) return 0;
+    double *Q = (double *)malloc(sizeof(double) * (size_t)n * 9);
+    memcpy(Q, rows, sizeof(double) * (size_t)n * 9);
+    const int count = run5point_rows(Q, n, E_out, NULL, NULL, NULL);
+    free(Q);
+    return count;
+}
+
+static int run5point_rows(double *Q, int n, double *E_out, double *c_out, double *roots_out, double *xy1z_out) {
     double w[9], V[81];
     jacobi_svd_impl(Q, n, 9, w, V, NULL);
-    free(Q);
     /* EE = columns 5..8 of V (five-point.cpp:386-388); EE[b*9 + k] = V[k][5+b] */
     double EE[36];
     for (int b = 0; b < 4; ++b)

@@ -7,18 +7,26 @@
 // oracle/usac_oracle.cpp and the device path turn by turn (tests/golden/usac_trace.npz, generator tests/golden/make_golden.py).
 //
 // What is the reference's and what is ours.  The reference's problem class, EssentialMatEstimator (EssentialMatEstimator.h, 2447 lines),
-// cannot be compiled here: it includes OpenCV (cv::Mat members, poselib/pose_estim.h).  The class below is OUR restatement of the members
-// the POSE_NISTER path without degeneracy tests executes -- initProblem :189-352, generateMinimalSampleModels :384-398 + :505-520,
-// generateRefinedModel REFINE_WEIGHTS :540-599 / REFINE_NISTER :757-850, validateSample :1043-1078, validateModel :1085-1104,
-// evaluateModel :1110-1178, findWeights :2366-2390, storeModel :2436-2445 -- calling the reference's own FTools / MathTools / PoseTools /
-// OpenGV functions wherever the original does.  With `check_degeneracy` (in.bin ih[5]) the class also restates testSolutionDegeneracy
-// :1334-1362, testSolutionDegeneracyRot :1511-1663, testSolutionDegeneracyNoMot :1838-1911, upgradeDegenerateModel's pose branches
-// :2098-2361 and evaluateModelTrans :1264-1327 -- the configuration estimateEssentialMatUsac builds for a refinement other than the
-// 8-point ones (enableHDegen = false, enableUpgradeDegenPose = true, 8000 upgrade samples, usac_estimations.cpp:443-456) -- on the
-// reference's own opengv::relative_pose::{twopt_rotationOnly, rotationOnly, twopt, eigensolver}, opengv::triangulation::triangulate2 and
-// PoseTools::{getRotError, getNoMotError}.  Everything USAC<> does with them (solve(), the samplers, designSPRTTest, the SPRT
-// history, updateSPRTStopping, locallyOptimizeSolution, storeSolution, std::random_shuffle of the evaluation pool on the process-wide
-// rand() stream) is the reference's code, unmodified.  This file contains no reference source text.
+// cannot be compiled here: it includes OpenCV (cv::Mat members, poselib/pose_estim.h).  The class below is a TRANSCRIPTION of the members
+// the 5-point paths execute -- initProblem :189-352, generateMinimalSampleModels :384-398 + :456-520, generateRefinedModel
+// REFINE_WEIGHTS :540-599 / REFINE_STEWENIUS(_WEIGHTS) :640-755 / REFINE_NISTER(_WEIGHTS) :757-850, validateSample :1043-1078,
+// validateModel :1085-1104, evaluateModel :1110-1178, findWeights :2366-2428, storeModel :2436-2445 -- with the reference's statements
+// and, in many places, its identifiers (adapter_denorm, inverseSolution, p_hom, reprojection1/2 ...), calling the reference's own FTools
+// / MathTools / PoseTools / OpenGV functions wherever the original does.  With `check_degeneracy` (in.bin ih[5]) it also carries
+// testSolutionDegeneracy :1334-1362, testSolutionDegeneracyRot :1511-1663, testSolutionDegeneracyNoMot :1838-1911,
+// upgradeDegenerateModel's pose branches :2098-2361 and evaluateModelTrans :1264-1327 -- the configuration estimateEssentialMatUsac
+// builds for a refinement other than the 8-point ones (enableHDegen = false, enableUpgradeDegenPose = true, 8000 upgrade samples,
+// usac_estimations.cpp:443-456) -- on the reference's own opengv::relative_pose::{twopt_rotationOnly, rotationOnly, twopt,
+// eigensolver}, opengv::triangulation::triangulate2 and PoseTools::{getRotError, getNoMotError}.  Everything USAC<> does with them
+// (solve(), the samplers, designSPRTTest, the SPRT history, updateSPRTStopping, locallyOptimizeSolution, storeSolution,
+// std::random_shuffle of the evaluation pool on the process-wide rand() stream) is the reference's code, unmodified.  So: USAC.h,
+// usac/utils/*.cpp and OpenGV are genuinely the reference's; the problem class is a stand-in that pins the CONTROL FLOW, not itself
+// pinned by anything.  It lives under oracle/ (test infrastructure, built only in the build container) and nothing in the product uses it.
+// The weighted solvers fivept_nister_weight / fivept_stewenius_weight and computePseudoHuberWeight (P/source/usac/utils/
+// weightingEssential.cpp:56-206; that file includes BA_driver.h, which needs SBA and a generated export header: unbuildable here) and
+// poselib::costPseudoHuber (P/source/BA_driver.cpp:2639-2648) are transcribed below on the reference-built
+// opengv::relative_pose::modules::fivept_{nister,stewenius}_main; Eigen::BDCSVD, which they name, does not exist in the vendored Eigen
+// 3.2.0 -- JacobiSVD delivers the same four-dimensional right singular subspace, which is all the solvers read.
 //
 // ONE convention on top of OpenGV (shared with oracle/usac_oracle.cpp and the device path): the solutions of a minimal sample are
 // ordered by ascending E(0,0) after scaling each to unit Frobenius norm with its largest-magnitude element positive.  OpenGV's own order
@@ -28,7 +36,7 @@
 // solutions does not depend on it.  `--native-order` keeps OpenGV's order (diagnostics).
 //
 // usage: usac_ref in.bin out.bin [--native-order] [--solver-oracle] [--stewenius] [--eigvec-smallest]
-//   in.bin : int32 n, seed, refine (0 = REF_WEIGHTS, 6 = REF_NISTER), prosac (0/1), max_hyp, check_degeneracy (0, 1, 3 = also after local optimisations), reserved[2];
+//   in.bin : int32 n, seed, refine (poselib::RefineAlg: 0 = REF_WEIGHTS, 4 / 5 = REF_STEWENIUS(_WEIGHTS), 6 / 7 = REF_NISTER(_WEIGHTS)), prosac (0/1), max_hyp, check_degeneracy (0, 1, 3 = also after local optimisations), reserved[2];
 //            double th, prosac_beta, sprt_delta, sprt_epsilon, sprt_mS, sprt_tM, conf, th_pixels / focal length;
 //            n * 4 doubles (x1,y1,x2,y2); if prosac: n uint32 sorted indices
 //   out.bin: int32 n_events; n_events * 16 doubles (event records, see emit()); then the final record (see main)
@@ -58,6 +66,7 @@
 #include <opengv/relative_pose/methods.hpp>
 #include <opengv/triangulation/methods.hpp>
 #include <opengv/relative_pose/CentralRelativeAdapter.hpp>
+#include <opengv/relative_pose/modules/main.hpp>
 
 static bool g_native_order = false;
 // --solver-oracle: the minimal and the REFINE_NISTER models come from oracle_run5point (oracle/pose_oracle.c, linked in) instead of
@@ -77,6 +86,7 @@ static bool g_stewenius = false;
 // restating Eigen::RealSchur's eigenvalue order (oracle_eigen_order3, dgm::eigen_diag_order3; tests/golden/eigen_order3.npz).
 static bool g_eigvec_smallest = false;
 extern "C" int oracle_run5point(const double *q1, const double *q2, int n, double *E_out);
+extern "C" int oracle_run5point_rows(const double *rows, int n, double *E_out);
 static std::vector<double> g_events;  // 16 doubles per event
 
 class RefEssential : public USAC<RefEssential> {
@@ -174,6 +184,78 @@ class RefEssential : public USAC<RefEssential> {
         return out;
     }
 
+    static opengv::essentials_t real_solutions(const opengv::complexEssentials_t &Ec) {  // :671-696 (nearZero(100 * imag): |.| < 1e-3)
+        opengv::essentials_t out;
+        for (auto &Ei : Ec) {
+            bool imag = false;
+            for (int r = 0; r < 3 && !imag; r++)
+                for (int c = 0; c < 3; c++) {
+                    const double d = 100 * Ei(r, c).imag();
+                    if (!(d < 1e-3 && d > -1e-3)) {
+                        imag = true;
+                        break;
+                    }
+                }
+            if (imag) continue;
+            opengv::essential_t E;
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) E(r, c) = Ei(r, c).real();
+            out.push_back(E);
+        }
+        return out;
+    }
+    // the solutions generateRefinedModel chooses from: OpenGV's solver on all sample points (unit bearing vectors), for a re-weighted
+    // step of the _WEIGHTS forms the rows scaled by w_i / |w| (fivept_nister_weight / fivept_stewenius_weight)
+    opengv::essentials_t refine_solutions(const std::vector<unsigned int> &sample, unsigned numPoints, bool stewenius, bool use_weights,
+                                          const double *weights) {
+        Eigen::MatrixXd Q(numPoints, 9);
+        double weightnorm = 0;
+        if (use_weights) {
+            for (unsigned i = 0; i < numPoints; i++) weightnorm += std::pow(weights[i], 2);
+            weightnorm = std::sqrt(weightnorm);
+        }
+        for (unsigned i = 0; i < numPoints; i++) {
+            // "computing the inverse transformation, so we simply invert the input here"
+            opengv::bearingVector_t f = adapter_denorm->getBearingVector2(sample[i]);
+            opengv::bearingVector_t fprime = adapter_denorm->getBearingVector1(sample[i]);
+            Eigen::Matrix<double, 1, 9> row;
+            row << f[0] * fprime[0], f[1] * fprime[0], f[2] * fprime[0], f[0] * fprime[1], f[1] * fprime[1], f[2] * fprime[1], f[0] * fprime[2],
+                f[1] * fprime[2], f[2] * fprime[2];
+            if (use_weights) row *= weights[i] / weightnorm;
+            Q.row(i) = row;
+        }
+        opengv::essentials_t out;
+        if (g_solver_oracle) {
+            std::vector<double> rows((size_t)9 * numPoints);
+            for (unsigned i = 0; i < numPoints; ++i)
+                for (int k = 0; k < 9; ++k) rows[(size_t)9 * i + k] = Q(i, k);
+            double Es[90];
+            const int ns = oracle_run5point_rows(rows.data(), (int)numPoints, Es);
+            for (int k = 0; k < ns; ++k) {
+                opengv::essential_t E;
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) E(r, c) = Es[9 * k + 3 * r + c];
+                out.push_back(E);
+            }
+            return out;
+        }
+        if (!use_weights) {  // the reference calls OpenGV's own entry points here (:669, :791)
+            std::vector<int> indices;
+            for (unsigned i = 0; i < numPoints; ++i) indices.push_back((int)sample[i]);
+            if (stewenius) return real_solutions(opengv::relative_pose::fivept_stewenius(*adapter_denorm, indices));
+            return opengv::relative_pose::fivept_nister(*adapter_denorm, indices);
+        }
+        Eigen::JacobiSVD<Eigen::MatrixXd> SVD(Q, Eigen::ComputeFullV);
+        Eigen::Matrix<double, 9, 4> EE = SVD.matrixV().block(0, 5, 9, 4);
+        if (stewenius) {
+            opengv::complexEssentials_t complexEssentials;
+            opengv::relative_pose::modules::fivept_stewenius_main(EE, complexEssentials);
+            return real_solutions(complexEssentials);
+        }
+        opengv::relative_pose::modules::fivept_nister_main(EE, out);
+        return out;
+    }
+
     unsigned int generateMinimalSampleModels() override {
         std::vector<int> indices;
         for (unsigned i = 0; i < usac_min_sample_size_; ++i) indices.push_back((int)min_sample_[i]);
@@ -240,10 +322,11 @@ class RefEssential : public USAC<RefEssential> {
                     essentials[0](r, c) = models_[0][r * 3 + c];
                     essentials_denorm[0](r, c) = models_denorm_[0][r * 3 + c];
                 }
-        } else if (refineMethod == USACConfig::REFINE_NISTER) {
-            std::vector<int> indices;
-            for (unsigned i = 0; i < numPoints; ++i) indices.push_back((int)sample[i]);
-            opengv::essentials_t Es = five_point(indices);
+        } else if (refineMethod == USACConfig::REFINE_NISTER || refineMethod == USACConfig::REFINE_NISTER_WEIGHTS ||
+                   refineMethod == USACConfig::REFINE_STEWENIUS || refineMethod == USACConfig::REFINE_STEWENIUS_WEIGHTS) {
+            const bool stew = refineMethod == USACConfig::REFINE_STEWENIUS || refineMethod == USACConfig::REFINE_STEWENIUS_WEIGHTS;
+            const bool use_w = weighted && (refineMethod == USACConfig::REFINE_STEWENIUS_WEIGHTS || refineMethod == USACConfig::REFINE_NISTER_WEIGHTS);
+            opengv::essentials_t Es = refine_solutions(sample, numPoints, stew, use_w, weights);
             if (!g_native_order && Es.size() > 1) {  // the order convention decides ties of the error sums only
                 std::stable_sort(Es.begin(), Es.end(), [](const opengv::essential_t &a, const opengv::essential_t &b) { return order_key(a) < order_key(b); });
             }
@@ -714,6 +797,26 @@ class RefEssential : public USAC<RefEssential> {
     std::vector<double> degen_final_model_params_rot;
 
     void findWeights(unsigned int modelIndex, const std::vector<unsigned int> &inliers, unsigned int numInliers, double *weights) override {
+        if (refineMethod == USACConfig::REFINE_STEWENIUS_WEIGHTS || refineMethod == USACConfig::REFINE_NISTER_WEIGHTS) {  // :2404-2428
+            opengv::essential_t modele = essentials_denorm[modelIndex];
+            double pseudohuberth = std::sqrt(usac_inlier_threshold_) / 50.0;
+            for (unsigned i = 0; i < numInliers; ++i) {
+                opengv::bearingVector_t f = adapter_denorm->getBearingVector2(inliers[i]);
+                opengv::bearingVector_t fprime = adapter_denorm->getBearingVector1(inliers[i]);
+                // computePseudoHuberWeight(f, fprime, modele, pseudohuberth): SampsonL1_Eigen, then costPseudoHuber
+                Eigen::Vector3d xpE = fprime.transpose() * modele;
+                const double num = xpE.dot(f);
+                Eigen::Vector3d Ex1 = modele * f;
+                const double a = Ex1(0) * Ex1(0), b = Ex1(1) * Ex1(1), c = xpE(0) * xpE(0), d = xpE(1) * xpE(1);
+                const double denom1 = 1 / (std::sqrt(a + b + c + d) + 1e-8);
+                const double thresh = pseudohuberth, dd = num * denom1;
+                const double b_sq = thresh * thresh, d_abs = std::abs(dd) + 1e-12;
+                const double q = d_abs / thresh;
+                const double weight = std::sqrt(2 * b_sq * (std::sqrt(1 + q * q) - 1)) / d_abs;
+                weights[i] = denom1 * weight;
+            }
+            return;
+        }
         if (refineMethod != USACConfig::REFINE_WEIGHTS) return;
         const double *model = models_[modelIndex].data();
         for (unsigned i = 0; i < numInliers; ++i) {
@@ -815,7 +918,11 @@ int main(int argc, char **argv) {
     c_sprt.epsilon = dh[3];
     c_sprt.mS = dh[4];
     c_sprt.tM = dh[5];
-    c_ess.refineMethod = ih[2] == 6 ? USACConfig::REFINE_NISTER : USACConfig::REFINE_WEIGHTS;
+    c_ess.refineMethod = ih[2] == 6   ? USACConfig::REFINE_NISTER
+                         : ih[2] == 7 ? USACConfig::REFINE_NISTER_WEIGHTS
+                         : ih[2] == 4 ? USACConfig::REFINE_STEWENIUS
+                         : ih[2] == 5 ? USACConfig::REFINE_STEWENIUS_WEIGHTS
+                                      : USACConfig::REFINE_WEIGHTS;
     c_ess.used_estimator = USACConfig::ESTIM_NISTER;
     ConfigParamsEssential cfg(c_com, c_pro, c_sprt, c_lo, c_ess, false);
     std::unique_ptr<RefEssential> est(new RefEssential);

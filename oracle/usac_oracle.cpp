@@ -639,14 +639,33 @@ struct Usac {
             double t[9];
             mul3(t, T2t, F);
             mul3(models_denorm[0], t, T1);
-        } else {  // REFINE_NISTER: the solver on all sample points, the solution with the smallest error sum over the current inliers
-            std::vector<double> q1((size_t)2 * m), q2((size_t)2 * m);
+        } else {
+            // REFINE_NISTER / _STEWENIUS (6, 4) and their _WEIGHTS forms (7, 5), EssentialMatEstimator.h:640-850: OpenGV's five-point
+            // solver on ALL sample points -- unit bearing vectors of the denormalised points, row i = f2_i (x) f1_i
+            // (methods.cpp:183-268) -- and, for a re-weighted step of the _WEIGHTS forms, row i scaled by w_i / |w|
+            // (fivept_nister_weight / fivept_stewenius_weight, weightingEssential.cpp:62-148); then the solution with the smallest
+            // Sampson-error sum over the inliers of the best model so far, with the reference's early exit.  One exact solver serves
+            // Nister and Stewenius as it does for the minimal sample.
+            const bool use_w = weighted && (refine == 5 || refine == 7);
+            std::vector<double> rows((size_t)9 * m);
+            double wnorm = 0;
+            if (use_w) {
+                for (unsigned i = 0; i < m; ++i) wnorm += std::pow(weights[i], 2);
+                wnorm = std::sqrt(wnorm);
+            }
             for (unsigned i = 0; i < m; ++i) {
-                q1[2 * i] = p1[2 * sample[i]], q1[2 * i + 1] = p1[2 * sample[i] + 1];
-                q2[2 * i] = p2[2 * sample[i]], q2[2 * i + 1] = p2[2 * sample[i] + 1];
+                double f1[3], f2[3];
+                bearing(&pd[6 * sample[i]], f1), bearing(&pd[6 * sample[i] + 3], f2);
+                double *r = &rows[(size_t)9 * i];
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) r[3 * a + b] = f1[b] * f2[a];
+                if (use_w) {
+                    const double sc = weights[i] / wnorm;
+                    for (int k = 0; k < 9; ++k) r[k] *= sc;
+                }
             }
             double Es[90];
-            const int ns = oracle_run5point(q1.data(), q2.data(), (int)m, Es);
+            const int ns = oracle_run5point_rows(rows.data(), (int)m, Es);
             int take = 0;
             if (ns > 1) {
                 int order[10];
@@ -675,7 +694,32 @@ struct Usac {
         return ok;
     }
 
+    static void bearing(const double *pt, double *f) {  // (x, y, 1) / |.| (EssentialMatEstimator.h:273-279)
+        const double nrm = sqrt(pt[0] * pt[0] + (pt[1] * pt[1] + pt[2] * pt[2]));
+        f[0] = pt[0] / nrm, f[1] = pt[1] / nrm, f[2] = pt[2] / nrm;
+    }
+
     void find_weights(const std::vector<unsigned> &inl, unsigned cnt, double *weights) const {
+        if (refine == 5 || refine == 7) {
+            // findWeights, REFINE_STEWENIUS_WEIGHTS / REFINE_NISTER_WEIGHTS (:2404-2428): computePseudoHuberWeight
+            // (weightingEssential.cpp:190-206) of the denormalised model on unit bearing vectors, threshold sqrt(thr) / 50;
+            // costPseudoHuber is P/source/BA_driver.cpp:2639-2648
+            const double *E = models_denorm[0];
+            const double th = std::sqrt(thr) / 50.0, b_sq = th * th;
+            for (unsigned i = 0; i < cnt; ++i) {
+                double f[3], fp[3];
+                bearing(&pd[6 * inl[i]], f), bearing(&pd[6 * inl[i] + 3], fp);
+                double xpE[3], Ex1[2];
+                for (int c = 0; c < 3; ++c) xpE[c] = fp[0] * E[c] + fp[1] * E[3 + c] + fp[2] * E[6 + c];
+                const double num = xpE[0] * f[0] + xpE[1] * f[1] + xpE[2] * f[2];
+                for (int r = 0; r < 2; ++r) Ex1[r] = E[3 * r] * f[0] + E[3 * r + 1] * f[1] + E[3 * r + 2] * f[2];
+                const double denom1 = 1 / (std::sqrt(Ex1[0] * Ex1[0] + Ex1[1] * Ex1[1] + xpE[0] * xpE[0] + xpE[1] * xpE[1]) + 1e-8);
+                const double d_abs = std::abs(num * denom1) + 1e-12;
+                const double q = d_abs / th;
+                weights[i] = denom1 * (std::sqrt(2 * b_sq * (std::sqrt(1 + q * q) - 1)) / d_abs);
+            }
+            return;
+        }
         if (refine != 0) return;
         const double *m = models[0];
         for (unsigned i = 0; i < cnt; ++i) {

@@ -396,6 +396,57 @@ def usac_stewenius_case():
     print("usac_stewenius_trace: ok", os.path.getsize(os.path.join(HERE, "usac_stewenius_trace.npz")), "bytes")
 
 
+USAC_REFINE_CASES = [(5000, 0.5, 20260103), (300, 0.5, 13), (1200, 0.9, 15), (800, 0.3, 11), (2000, 0.7, 12), (150, 0.6, 16)]
+USAC_REFINE_EVENTS_KEPT = 300
+
+
+def usac_refine_case():
+    """USAC with the inner refinements of the 5-point family (poselib::RefineAlg 4..7; EssentialMatEstimator.h:640-850, findWeights
+    :2404-2428) -- ConfigUSAC's default is REF_STEWENIUS_WEIGHTS (5) with POSE_STEWENIUS (pose_estim.h:99-100).
+    refine 5 / 4 (Stewenius with / without the pseudo-Huber weights): `usac_ref --stewenius`, i.e. the reference-built USAC.h with
+    OpenGV's fivept_stewenius as the minimal AND the refinement solver (weighted rows through the reference-built
+    modules::fivept_stewenius_main), mS = 6, tM = 2736: nothing swapped in, only the order convention on top.  The oracle's own solver
+    follows these traces event by event in 48 of 48 runs.
+    refine 7 / 6 (Nister): OpenGV's fivept_nister returns unconverged roots on a share of its inputs (usac_case), so the event traces come
+    from `--solver-oracle` (control flow pinned, solver swapped) and the reference solver's own run contributes its final counts."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import oracle_lib
+    import usac_compare
+    import usac_ref_tool as u
+    ora = oracle_lib.load()
+    out = {"cases": np.array(USAC_REFINE_CASES, np.float64)}
+    k = 0
+    kw = dict(sprt_ms=6.0, sprt_tm=2736.0)
+    for refine in (5, 4, 7, 6):
+        for (n, frac, seed) in USAC_REFINE_CASES:
+            p1, p2, th, truth, order = usac_scene(n, frac, seed)
+            for prosac in (0, 1):
+                for usac_seed in (12345, 7):
+                    if refine in (4, 6) and usac_seed == 7:
+                        continue                      # the unweighted forms: half the runs
+                    si = order if prosac else None
+                    if refine in (4, 5):
+                        r = u.run(p1, p2, th, usac_seed, refine=refine, sorted_idx=si, stewenius=True, **kw)
+                    else:
+                        r = u.run(p1, p2, th, usac_seed, refine=refine, sorted_idx=si, solver_oracle=True, **kw)
+                        gres = u.run(p1, p2, th, usac_seed, refine=refine, sorted_idx=si, **kw)
+                        out[f"k{k}_opengv_final"], out[f"k{k}_opengv_flags"] = gres["final"], np.packbits(gres["flags"])
+                    o = ora.usac_essential(p1, p2, th, usac_seed, refine=refine, sorted_idx=si, event_cap=400000, **kw)
+                    first, d = usac_compare.compare(r["events"], o["events"])
+                    agree = int(first is None and np.array_equal(r["flags"], o["flags"]))
+                    out[f"k{k}_meta"] = np.array([n, frac, seed, prosac, usac_seed, agree, refine], np.float64)
+                    out[f"k{k}_events"] = r["events"][:USAC_REFINE_EVENTS_KEPT]
+                    out[f"k{k}_n_events"] = np.array([len(r["events"])])
+                    out[f"k{k}_final"], out[f"k{k}_E"], out[f"k{k}_flags"] = r["final"], r["E"], np.packbits(r["flags"])
+                    print(f"usac refine case {k}: refine {refine} n {n} prosac {prosac} seed {usac_seed}: events {len(r['events'])} agree {agree} "
+                          f"first {first} inliers {int(r['final'][5])} hyps {int(r['final'][1])} {d}")
+                    k += 1
+    out["n_cases"] = np.array([k])
+    np.savez_compressed(os.path.join(HERE, "usac_refine_trace.npz"), **out)
+    print("usac_refine_trace: ok", os.path.getsize(os.path.join(HERE, "usac_refine_trace.npz")), "bytes")
+
+
 def degen_math_case():
     """Fixture for the host numerics of USAC's degeneracy handling: the reference's vendored OpenGV (twopt_rotationOnly, rotationOnly,
     twopt, eigensolver) and PoseTools error functions compiled in place (oracle/_ref/opengv_degen) on three scenes -- pure rotation,
@@ -497,6 +548,8 @@ if __name__ == "__main__":
         usac_case()
     if what in ("all", "usac_stewenius"):
         usac_stewenius_case()
+    if what in ("all", "usac_refine"):
+        usac_refine_case()
     if what in ("all", "degen"):
         degen_math_case()
     if what in ("all", "eigen"):
