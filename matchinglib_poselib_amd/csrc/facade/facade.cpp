@@ -328,22 +328,46 @@ int estimateEssentialOrPoseUSAC(const cv::Mat &p1, const cv::Mat &p2, cv::Output
     (void)verbose;
     std::lock_guard<std::mutex> lock(g_usac_mutex);  // the history is process-wide: calls are serialised like the reference's statics imply
     UsacHistory &H = g_usac_hist;
-    int estimator;
+    // Options of ConfigUSAC that this library does not build are REFUSED with the reference's own message and -1 (what the reference
+    // returns for a configuration it does not support, pose_estim.cpp:1789-1797, 2001-2003), never served by another algorithm.
+    // MLPL_OPTIONS=usac_substitute (environment, read once) brings back the substitution of earlier rounds for callers that ask for it:
+    // POSE_EIG_KNEIP -> the 5-point solver, REF_8PT_PSEUDOHUBER / REF_EIG_KNEIP(_WEIGHTS) -> REF_WEIGHTS, DEGEN_QDEGSAC -> no check.
+    static const bool substitute = [] {
+        const char *o = std::getenv("MLPL_OPTIONS");
+        return o && std::strstr(o, "usac_substitute") != nullptr;
+    }();
+    int estimator, refine;
     switch (cfg.estimator) {
         case POSE_NISTER: estimator = 0; break;
         case POSE_STEWENIUS: estimator = 2; break;
         case POSE_EIG_KNEIP:
-            std::call_once(g_usac_notice[0], [] { std::cout << "USAC (MI355X hot-path library): Kneip's eigensolver is not built; the 5-point solver is used." << std::endl; });
+            if (!substitute) {
+                std::cout << "Estimator not supported!" << std::endl;  // (Kneip's eigensolver as the minimal solver is not built)
+                return -1;
+            }
+            std::call_once(g_usac_notice[0], [] { std::cout << "USAC (MI355X hot-path library, MLPL_OPTIONS=usac_substitute): Kneip's eigensolver is not built; the 5-point solver is used." << std::endl; });
             estimator = 0;
             break;
         default: std::cout << "Estimator not supported!" << std::endl; return -1;
     }
-    if ((int)cfg.refinealg < (int)REF_WEIGHTS || (int)cfg.refinealg > (int)REF_NISTER_WEIGHTS) {
-        std::cout << "Refinement algorithm not supported!" << std::endl;
-        return -1;
+    switch (cfg.refinealg) {
+        case REF_WEIGHTS: refine = 0; break;
+        case REF_STEWENIUS: refine = 4; break;
+        case REF_STEWENIUS_WEIGHTS: refine = 5; break;
+        case REF_NISTER: refine = 6; break;
+        case REF_NISTER_WEIGHTS: refine = 7; break;
+        case REF_8PT_PSEUDOHUBER:
+        case REF_EIG_KNEIP:
+        case REF_EIG_KNEIP_WEIGHTS:
+            if (!substitute) {
+                std::cout << "Refinement algorithm not supported!" << std::endl;  // (built: REF_WEIGHTS and the four 5-point refinements)
+                return -1;
+            }
+            std::call_once(g_usac_notice[1], [] { std::cout << "USAC (MI355X hot-path library, MLPL_OPTIONS=usac_substitute): this inner refinement is not built; REF_WEIGHTS is used." << std::endl; });
+            refine = 0;
+            break;
+        default: std::cout << "Refinement algorithm not supported!" << std::endl; return -1;
     }
-    if (cfg.refinealg != REF_WEIGHTS)
-        std::call_once(g_usac_notice[1], [] { std::cout << "USAC (MI355X hot-path library): of the inner refinement algorithms the 8-point fit with Torr weights (REF_WEIGHTS) is built; it is used." << std::endl; });
     CV_Assert(p1.cols == 2 && p2.cols == 2 && p1.rows == p2.rows && p1.type() == CV_64F && p2.type() == CV_64F);  // usac_estimations.cpp:315
     const int n = p1.rows;
     CV_Assert(!cfg.matches || cfg.matches->empty() || (size_t)n == cfg.matches->size());  // :316
@@ -394,16 +418,21 @@ int estimateEssentialOrPoseUSAC(const cv::Mat &p1, const cv::Mat &p2, cv::Output
         std::cout << "Mothod for checking degeneracy not available!" << std::endl;
         return -1;
     }
-    if (cfg.degeneracyCheck == DEGEN_QDEGSAC)
-        std::call_once(g_usac_notice[2], [] { std::cout << "USAC (MI355X hot-path library): QDEGSAC is not built; the estimation runs without a degeneracy check." << std::endl; });
-    const bool eight_point = cfg.refinealg == REF_WEIGHTS || cfg.refinealg == REF_8PT_PSEUDOHUBER;
+    if (cfg.degeneracyCheck == DEGEN_QDEGSAC) {
+        if (!substitute) {
+            std::cout << "Mothod for checking degeneracy not available!" << std::endl;  // (QDEGSAC is not built)
+            return -1;
+        }
+        std::call_once(g_usac_notice[2], [] { std::cout << "USAC (MI355X hot-path library, MLPL_OPTIONS=usac_substitute): QDEGSAC is not built; the estimation runs without a degeneracy check." << std::endl; });
+    }
+    const bool eight_point = refine == 0;
     if (cfg.degeneracyCheck == DEGEN_USAC_INTERNAL && eight_point)
         std::call_once(g_usac_notice[3], [] { std::cout << "USAC (MI355X hot-path library): the rotation-only / no-motion tests and the model upgrade are built; the homography test the reference adds for the 8-point refinements is not." << std::endl; });
 
     // estimateEssentialMatUsac (usac_estimations.cpp:283-470)
     mlpl_usac_params P;
     mlpl_usac_default_params(&P, th);
-    P.estimator = estimator, P.refine = 0;
+    P.estimator = estimator, P.refine = refine;
     P.seed = g_seed_fixed ? g_seed : (unsigned)std::time(nullptr);
     P.prosac_beta = prosac_beta, P.sprt_delta = sprt_delta, P.sprt_epsilon = sprt_epsilon;
     if (H.numhyps == 0 || H.modelcount == 0)

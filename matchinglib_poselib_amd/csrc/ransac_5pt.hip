@@ -2029,13 +2029,23 @@ __device__ __forceinline__ void order_desc9(const Jacobi9Lds &J, int *order) {
     }
 }
 
+// One workgroup (one wave) per system: blockIdx.x selects the system's parts (part_stride doubles apart) and its record.  `gate` (optional):
+// an int per system, gate_stride bytes apart -- a system whose gate is 0 is not solved and its record says "no models" (USAC's local
+// optimisation: chains whose step has no fit, usac_impl.h).
 __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restrict__ gram_part, int nparts,
-                                                         PolyRec *__restrict__ rec) {
+                                                         PolyRec *__restrict__ rec, size_t part_stride = 0,
+                                                         const char *__restrict__ gate = nullptr, size_t gate_stride = 0) {
     __shared__ SolveLds L;
     __shared__ Jacobi9Lds J;
     __shared__ double gsum[45];
     if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
     const int lane = threadIdx.x;
+    gram_part += (size_t)blockIdx.x * part_stride;
+    rec += blockIdx.x;
+    if (gate && *reinterpret_cast<const int32_t *>(gate + (size_t)blockIdx.x * gate_stride) == 0) {
+        if (lane == 0) rec->ok = 0.0;
+        return;
+    }
     if (lane < 45) {  // fixed summation order over the blocks: run-to-run deterministic
         double sacc = 0;
         for (int pblk = 0; pblk < nparts; ++pblk) sacc += gram_part[(size_t)pblk * 45 + lane];
@@ -3550,9 +3560,14 @@ static int usac_check_params(const mlpl_usac_params *P, int n, const char *who) 
         set_error("%s: bad degeneracy-test parameters", who);
         return MLPL_E_BAD_INPUT;
     }
-    if ((P->estimator != 0 && P->estimator != 2) || P->refine != 0) {
-        set_error("%s: estimator %d / refinement %d not built (POSE_NISTER, POSE_STEWENIUS with REF_WEIGHTS are)", who, P->estimator, P->refine);
+    if ((P->estimator != 0 && P->estimator != 2) || !(P->refine == 0 || (P->refine >= 4 && P->refine <= 7))) {
+        set_error("%s: estimator %d / refinement %d not built (POSE_NISTER, POSE_STEWENIUS with REF_WEIGHTS, REF_STEWENIUS(_WEIGHTS), REF_NISTER(_WEIGHTS) are)",
+                  who, P->estimator, P->refine);
         return MLPL_E_UNSUPPORTED;
+    }
+    if (P->refine != 0 && (P->check_degeneracy & 2)) {  // the reference tests after local optimisations only with the 8-point refinements
+        set_error("%s: check_degeneracy = 3 goes with the 8-point refinement only (usac_estimations.cpp:368-375)", who);
+        return MLPL_E_BAD_INPUT;
     }
     if (P->sorted_idx)
         for (int i = 0; i < n; ++i)

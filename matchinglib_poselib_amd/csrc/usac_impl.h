@@ -492,6 +492,375 @@ __global__ __launch_bounds__(kUsacLoThreads) void usac_lo_kernel(const double *_
     if (tid == 0) O->evals = eval, O->sweeps = L.sweeps;
 }
 
+// ---- local optimisation with the refinements of the 5-point family (poselib::RefineAlg REF_STEWENIUS(_WEIGHTS), REF_NISTER(_WEIGHTS)) ------
+// EssentialMatEstimator.h generateRefinedModel :640-850, findWeights :2404-2428; P/source/usac/utils/weightingEssential.cpp:56-206
+// (fivept_*_weight, computePseudoHuberWeight), P/source/BA_driver.cpp:2639-2648 (costPseudoHuber).  ConfigUSAC's own default is
+// REF_STEWENIUS_WEIGHTS (pose_estim.h:99-100).  A fit is OpenGV's five-point solver on ALL points of the set: unit bearing vectors, row
+// i = f2_i (x) f1_i, for a re-weighted step of the _WEIGHTS forms scaled by the pseudo-Huber weight of the current model -- the four
+// right singular vectors of the smallest singular values span the solver's input, i.e. the four smallest eigenvectors of the 9 x 9 Gram
+// matrix -- then, of its real solutions, the one with the smallest Sampson-error sum over the inliers of the best model so far (with the
+// reference's early exit).  One exact solver serves Nister and Stewenius as it does for the minimal sample (solve_from_basis +
+// roots_kernel_t).  A repetition is a CHAIN of launches with (block of correspondences, chain) as the grid, so that the per-correspondence
+// passes use the chip and several chains -- the five repetitions of a local optimisation, later the chains of many problems -- share
+// every launch:
+//   usac5_begin_kernel                      state; the 14-point sample's Gram matrix
+//   [refit_solve_kernel, roots_kernel_t, usac5_choose_kernel]            first model
+//   per phase (-1: refit on the 2 x threshold set, 0..3: re-weighted refits): usac5_eval_kernel (errors, inlier bits in pool order,
+//   per-block set counts), usac5_gram_kernel (the set's weighted Gram matrix in per-block parts), refit_solve_kernel (parts summed in
+//   block order -> Jacobi -> basis -> elimination), roots_kernel_t, usac5_choose_kernel; then the last usac5_eval_kernel.
+// As with REF_WEIGHTS the chain assumes that no sequential test inside it rejects; the host replays the reference's logic on the bit
+// rows and resumes a chain from the reference's state where one does.  The solution choice reads the inlier flags of the best model,
+// which a repetition that stores a new best changes: the host then re-runs the repetitions behind it with the new flags.
+constexpr int kLo5Threads = 256, kLo5MaxBlocks = 64;  // rows of 256 correspondences per block: n <= 64 * 16 * 256 (= the REF_WEIGHTS kernel's limit)
+
+struct UsacLo5State {  // device, one per chain
+    double E[9];       // current model (denormalised)
+    int32_t alive, step_fit, fit_pts, pad;
+    int32_t cnt_inl[kLo5MaxBlocks], cnt_mem[kLo5MaxBlocks];
+    int32_t hist_nm[kUsacLoEvals], hist_take[kUsacLoEvals];  // per fit of the chain (0 = the sample's): solutions found (-1: no fit), the one kept
+    double hist_E[kUsacLoEvals][10][9];
+};
+struct UsacLo5Out {    // pinned host memory, one per chain, followed by kUsacLoEvals bit rows of `words` words
+    int32_t evals, cnt2, first_fit, pad;  // first_fit: 1 = the sample's fit gave a model, 2 = it gave none (fresh chains)
+    int32_t fit_pts[kUsacLoEvals];        // points the model of evaluation e was fitted to
+    int32_t fit_state[kUsacLoEvals];      // the fit that follows evaluation e: 0 = none (fewer than 5 points), 1 = model, 2 = no solution
+    double E[kUsacLoEvals][9];            // the evaluated models (denormalised)
+};
+
+__device__ __forceinline__ void usac5_row(double x1, double y1, double x2, double y2, double *q) {
+    double f1[3], f2[3];
+    dg_bearing(x1, y1, f1);
+    dg_bearing(x2, y2, f2);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) q[3 * a + b] = f1[b] * f2[a];
+}
+// computePseudoHuberWeight(f, fprime, E, th): SampsonL1_Eigen on unit bearing vectors, costPseudoHuber of the distance, times 1 / denominator
+__device__ __forceinline__ double usac5_weight(const double *E, double x1, double y1, double x2, double y2, double th) {
+    double f[3], fp[3];
+    dg_bearing(x1, y1, f);
+    dg_bearing(x2, y2, fp);
+    double xpE[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xpE[c] = fp[0] * E[c] + fp[1] * E[3 + c] + fp[2] * E[6 + c];
+    const double num = xpE[0] * f[0] + xpE[1] * f[1] + xpE[2] * f[2];
+    const double e0 = E[0] * f[0] + E[1] * f[1] + E[2] * f[2], e1 = E[3] * f[0] + E[4] * f[1] + E[5] * f[2];
+    const double denom1 = 1 / (sqrt(e0 * e0 + e1 * e1 + xpE[0] * xpE[0] + xpE[1] * xpE[1]) + 1e-8);
+    const double d_abs = fabs(num * denom1) + 1e-12, q = d_abs / th;
+    return denom1 * (sqrt(2 * (th * th) * (sqrt(1 + q * q) - 1)) / d_abs);
+}
+
+// grid = chains, 64 threads.  in[c].start_step < 0: a fresh chain -- Gram matrix of its 14-point sample into part 0; else the chain
+// resumes with in[c].E as its model.
+__global__ __launch_bounds__(64) void usac5_begin_kernel(const double *__restrict__ p1, const double *__restrict__ p2, const UsacLoIn *__restrict__ in,
+                                                         UsacLo5State *__restrict__ st, double *__restrict__ gram_part, size_t part_stride,
+                                                         char *__restrict__ out_base, size_t out_stride) {
+    __shared__ double q[kUsacLoSample][9];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const UsacLoIn &I = in[c];
+    UsacLo5State &S = st[c];
+    UsacLo5Out *O = reinterpret_cast<UsacLo5Out *>(out_base + (size_t)c * out_stride);
+    if (lane == 0) {
+        S.alive = 1, S.step_fit = I.start_step < 0 ? 1 : 0, S.fit_pts = I.start_step < 0 ? kUsacLoSample : 0;
+        O->evals = 0, O->cnt2 = 0, O->first_fit = 0;
+    }
+    if (lane < kUsacLoEvals) O->fit_pts[lane] = 0, O->fit_state[lane] = 0, S.hist_nm[lane] = -1;
+    if (I.start_step >= 0) {
+        if (lane < 9) S.E[lane] = I.E[lane];
+        return;
+    }
+    if (lane < kUsacLoSample) {
+        const int i = I.sample[lane];
+        usac5_row(p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1], q[lane]);
+    }
+    wave_sync();
+    if (lane < 45) {
+        int a = 0, rem = lane;
+        while (rem >= 9 - a) rem -= 9 - a, ++a;
+        const int b = a + rem;
+        double sacc = 0;
+        for (int k = 0; k < kUsacLoSample; ++k) sacc += q[k][a] * q[k][b];
+        gram_part[(size_t)c * part_stride + lane] = sacc;
+    }
+}
+
+__device__ __forceinline__ double usac5_wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return v;
+}
+
+// The solution generateRefinedModel keeps (:697-752 / :793-848): lanes j < nm hold solution j (E, and its key in the order convention);
+// Sampson-error sums over the inliers of the best model so far in index order, every fourth index a check whether the smallest sum is
+// below 0.66 of the second smallest; then std::min_element over the sums in the convention's order.  One wave; returns the lane.
+__device__ __forceinline__ int usac5_pick(const double *E, double key, int nm, int lane, const double *__restrict__ p1,
+                                          const double *__restrict__ p2, int n, const uint8_t *__restrict__ flags) {
+    if (nm <= 1) return 0;
+    int pos = 0;  // position in the convention (ascending key, stable): it only breaks ties of the error sums
+    for (int k = 0; k < nm; ++k) {
+        const double kk = __shfl(key, k);
+        pos += (kk < key || (kk == key && k < lane)) ? 1 : 0;
+    }
+    double sum = 0;
+    bool done = false;
+    for (int i0 = 0; i0 < n && !done; i0 += 64) {
+        const int ii = i0 + lane;
+        unsigned long long mask = __ballot(ii < n && flags[ii] != 0);
+        while (mask) {
+            const int b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int i = i0 + b;
+            const double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
+            if (lane < nm) sum += usac_sampson(E, x1, y1, x2, y2);
+            if ((i > 3) && (i % 4 == 0)) {
+                const double v = lane < nm ? sum : INFINITY;
+                const double m1 = usac5_wave_min(v);
+                const unsigned long long at_min = __ballot(v == m1);
+                const int first = __ffsll((long long)at_min) - 1;
+                const double m2 = usac5_wave_min(lane == first ? INFINITY : v);
+                if (m1 < 0.66 * m2) {
+                    done = true;
+                    break;
+                }
+            }
+        }
+    }
+    const double v = lane < nm ? sum : INFINITY;
+    const double m1 = usac5_wave_min(v);
+    int cand = (lane < nm && v == m1) ? pos : 64;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off));
+    const unsigned long long who = __ballot(lane < nm && pos == cand);
+    return who ? __ffsll((long long)who) - 1 : 0;  // (all sums NaN: solution 0, which no test can tell from any other)
+}
+__device__ __forceinline__ double usac5_key(const double *E) {  // ascending E(0,0) of the unit-Frobenius matrix whose largest-magnitude element is positive
+    double big = 0, n2 = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (fabs(E[k]) > fabs(big)) big = E[k];
+        n2 += E[k] * E[k];
+    }
+    return (big < 0 ? -E[0] : E[0]) / sqrt(n2);
+}
+
+// grid = chains, 64 threads: of the solutions roots_kernel_t left for the chain's system, the one generateRefinedModel keeps.
+// `fit_eval` = index of the evaluation this fit follows, -1 for the sample's fit; `ends_chain`: a fit without a solution ends the
+// repetition (the sample's fit and the refit on the 2 x threshold set; in a re-weighted step the model stays).  The solutions and the
+// choice are kept per (chain, fit) for usac5_recheck_kernel.
+__global__ __launch_bounds__(64) void usac5_choose_kernel(const double *__restrict__ p1, const double *__restrict__ p2, int n,
+                                                          const uint8_t *__restrict__ flags, const double *__restrict__ E_tab,
+                                                          const int32_t *__restrict__ n_models, UsacLo5State *__restrict__ st,
+                                                          char *__restrict__ out_base, size_t out_stride, int fit_eval, int ends_chain) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    UsacLo5State &S = st[c];
+    UsacLo5Out *O = reinterpret_cast<UsacLo5Out *>(out_base + (size_t)c * out_stride);
+    const int fit = fit_eval + 1;
+    if (!S.alive || !S.step_fit) {
+        if (lane == 0) S.hist_nm[fit] = -1;
+        return;
+    }
+    const int nm = min(n_models[c], 10);
+    if (lane == 0) S.hist_nm[fit] = nm;
+    if (nm <= 0) {
+        if (lane == 0) {
+            if (fit_eval < 0) O->first_fit = 2;
+            else O->fit_state[fit_eval] = 2;
+            if (ends_chain) S.alive = 0;
+        }
+        return;
+    }
+    double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double key = INFINITY;
+    if (lane < nm) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            E[k] = E_tab[((size_t)c * 10 + lane) * 9 + k];
+            S.hist_E[fit][lane][k] = E[k];
+        }
+        key = usac5_key(E);
+    }
+    const int take = usac5_pick(E, key, nm, lane, p1, p2, n, flags);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const double v = __shfl(E[k], take);
+        if (lane == 0) S.E[k] = v;
+    }
+    if (lane == 0) {
+        S.hist_take[fit] = take;
+        if (fit_eval < 0) O->first_fit = 1;
+        else O->fit_state[fit_eval] = 1;
+    }
+}
+
+// grid = (kUsacLoEvals fits, chains), 64 threads.  The inlier flags of the best model have changed (an earlier repetition stored a new
+// best): would any choice of this chain have come out differently?  first_diff[c] = the first such fit, else kUsacLoEvals.
+__global__ __launch_bounds__(64) void usac5_recheck_kernel(const double *__restrict__ p1, const double *__restrict__ p2, int n,
+                                                           const uint8_t *__restrict__ flags, const UsacLo5State *__restrict__ st,
+                                                           int32_t *__restrict__ first_diff) {
+    const int fit = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+    const UsacLo5State &S = st[c];
+    const int nm = S.hist_nm[fit];
+    if (nm <= 1) return;
+    double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double key = INFINITY;
+    if (lane < nm) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) E[k] = S.hist_E[fit][lane][k];
+        key = usac5_key(E);
+    }
+    const int take = usac5_pick(E, key, nm, lane, p1, p2, n, flags);
+    if (lane == 0 && take != S.hist_take[fit]) atomicMin(&first_diff[c], fit);
+}
+
+// grid = (blocks, chains), 256 threads.  Evaluation `e` of the chain's model: errors in point order, per-block counts of the inliers and of
+// the members of {err < limit}, the inlier bit row in pool order.
+__global__ __launch_bounds__(kLo5Threads) void usac5_eval_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
+                                                                 const double4 *__restrict__ pts_pool, int n, int words, int rows_per_block,
+                                                                 double thr, double limit, UsacLo5State *__restrict__ st,
+                                                                 double *__restrict__ err_all, char *__restrict__ out_base, size_t out_stride, int e) {
+    __shared__ int red[2][kLo5Threads / 64];
+    const int c = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    UsacLo5State &S = st[c];
+    if (!S.alive) return;
+    UsacLo5Out *O = reinterpret_cast<UsacLo5Out *>(out_base + (size_t)c * out_stride);
+    unsigned long long *rows = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(O) + sizeof(UsacLo5Out));
+    double *err = err_all + (size_t)c * n;
+    double E[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) E[k] = S.E[k];
+    int inl = 0, mem = 0;
+    for (int r = 0; r < rows_per_block; ++r) {
+        const int i = (b * rows_per_block + r) * kLo5Threads + tid;
+        if (i < n) {
+            const double ev = usac_sampson(E, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+            err[i] = ev;
+            inl += ev < thr ? 1 : 0;
+            mem += ev < limit ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) inl += __shfl_xor(inl, off), mem += __shfl_xor(mem, off);
+    if (lane == 0) red[0][wave] = inl, red[1][wave] = mem;
+    __syncthreads();
+    if (tid == 0) {
+        int a = 0, m = 0;
+        for (int w = 0; w < kLo5Threads / 64; ++w) a += red[0][w], m += red[1][w];
+        S.cnt_inl[b] = a, S.cnt_mem[b] = m;
+        if (b == 0) {
+            O->evals = e + 1;
+            O->fit_pts[e] = S.fit_pts;
+            for (int k = 0; k < 9; ++k) O->E[e][k] = E[k];
+        }
+    }
+    unsigned long long *row = rows + (size_t)e * words;
+    for (int w = b * (kLo5Threads / 64) + wave; w < words; w += gridDim.x * (kLo5Threads / 64)) {
+        const int j = w * 64 + lane;
+        bool in = false;
+        if (j < n) {
+            const double4 p = pts_pool[j];
+            in = usac_sampson(E, p.x, p.y, p.z, p.w) < thr;
+        }
+        const unsigned long long bal = __ballot(in);
+        if (lane == 0) row[w] = bal;
+    }
+}
+
+// grid = (blocks, chains), 256 threads.  The fit set of this step: the first K members (ascending index) of {err < limit}, K = n for the
+// refit after the first evaluation (findInliers' own count), the inlier count of the evaluation afterwards (USAC.h:1027-1040).  Each
+// block adds the (weighted) rows of its members into its own 45-value part; a block without members writes zeros.
+__global__ __launch_bounds__(kLo5Threads) void usac5_gram_kernel(const double *__restrict__ p1, const double *__restrict__ p2, int n,
+                                                                 int rows_per_block, double limit, int first_refit, int weighted, double th_ph,
+                                                                 UsacLo5State *__restrict__ st, const double *__restrict__ err_all,
+                                                                 double *__restrict__ gram_part, size_t part_stride, char *__restrict__ out_base,
+                                                                 size_t out_stride, int e) {
+    __shared__ int cnt[16 * (kLo5Threads / 64) + 1];
+    __shared__ double red[kLo5Threads / 64][45];
+    const int c = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kWaves = kLo5Threads / 64;
+    UsacLo5State &S = st[c];
+    if (!S.alive) {
+        if (b == 0 && tid == 0) S.step_fit = 0;
+        return;
+    }
+    UsacLo5Out *O = reinterpret_cast<UsacLo5Out *>(out_base + (size_t)c * out_stride);
+    const double *err = err_all + (size_t)c * n;
+    int total = 0, K = 0, before = 0;
+    for (int k = 0; k < (int)gridDim.x; ++k) {
+        const int m = S.cnt_mem[k];
+        total += m, K += S.cnt_inl[k];
+        before += k < b ? m : 0;
+    }
+    if (first_refit) K = n;
+    const int used = min(total, K);
+    double *part = gram_part + (size_t)c * part_stride + (size_t)b * 45;
+    if (used < 5) {  // generateRefinedModel refuses; after the first evaluation the repetition ends
+        if (b == 0 && tid == 0) {
+            if (first_refit) O->cnt2 = total, S.alive = 0;
+            S.step_fit = 0;
+            O->fit_state[e] = 0;
+        }
+        return;
+    }
+    if (b == 0 && tid == 0) {
+        if (first_refit) O->cnt2 = total;
+        S.step_fit = 1, S.fit_pts = used;
+    }
+    double E[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) E[k] = S.E[k];
+    // members of this block per (row, wave) in index order, then their exclusive prefix
+    for (int r = 0; r < rows_per_block; ++r) {
+        const int i = (b * rows_per_block + r) * kLo5Threads + tid;
+        const unsigned long long bal = __ballot(i < n && err[i] < limit);
+        if (lane == 0) cnt[r * kWaves + wave] = __popcll(bal);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = before;
+        for (int t = 0; t < rows_per_block * kWaves; ++t) {
+            const int v = cnt[t];
+            cnt[t] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    double acc[45];
+#pragma unroll
+    for (int k = 0; k < 45; ++k) acc[k] = 0;
+    for (int r = 0; r < rows_per_block; ++r) {
+        if (cnt[r * kWaves + wave] >= K) break;  // wave-uniform
+        const int i = (b * rows_per_block + r) * kLo5Threads + tid;
+        const bool member = i < n && err[i] < limit;
+        const unsigned long long bal = __ballot(member);
+        if (!member) continue;
+        const int rank = cnt[r * kWaves + wave] + __popcll(bal & ((1ull << lane) - 1ull));
+        if (rank >= K) continue;
+        const double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
+        double q[9];
+        usac5_row(x1, y1, x2, y2, q);
+        if (weighted) {
+            const double w = usac5_weight(E, x1, y1, x2, y2, th_ph);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) q[k] *= w;
+        }
+        int t = 0;
+#pragma unroll
+        for (int x = 0; x < 9; ++x)
+#pragma unroll
+            for (int y = x; y < 9; ++y) acc[t++] += q[x] * q[y];
+    }
+#pragma unroll
+    for (int k = 0; k < 45; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid < 45) part[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
 struct UsacWald {
     double epsilon, delta, A;
     unsigned k;
@@ -550,6 +919,12 @@ struct UsacRun {
     int32_t *d_nm = nullptr;
     double *d_err = nullptr;
     UsacLoIn *h_lo_in = nullptr, *d_lo_in = nullptr;
+    int refine = 0;  // poselib::RefineAlg: 0 = REF_WEIGHTS (usac_lo_kernel), 4..7 = the 5-point family (usac5_* chains)
+    UsacLo5State *d_lo5_state = nullptr;
+    double *d_lo5_gram = nullptr;
+    uint8_t *d_lo5_flags = nullptr, *h_lo5_flags = nullptr;
+    int32_t *h_lo5_diff = nullptr, *d_lo5_diff = nullptr;
+    int lo5_blocks = 1, lo5_rows = 1;
     int batch_cap = kUsacBatch;
     // state
     std::vector<unsigned> min_sample, pool;
@@ -659,17 +1034,36 @@ struct UsacRun {
         d_nm = (int32_t *)(d_Etab + (size_t)batch_cap * 90);
         if ((rc = ws_get(ctx, WS_AUX6, (size_t)kUsacLoReps * n * 8 + 64, &p))) return rc;
         d_err = (double *)p;
-        const size_t out_bytes = std::max(batch_out_bytes(batch_cap), (size_t)kUsacLoReps * lo_out_stride());
+        const size_t out_bytes = std::max(batch_out_bytes(batch_cap), (size_t)kUsacLoReps * std::max(lo_out_stride(), lo5_out_stride()));
         const size_t smp_bytes = (size_t)batch_cap * 5 * 4, lo_in_bytes = (size_t)kUsacLoReps * sizeof(UsacLoIn);
+        const size_t lo5_pin_bytes = refine ? (((size_t)n + 63) & ~(size_t)63) + 64 : 0;  // flags staging + the recheck verdicts
+        if (refine) {
+            const int rows = (int)((n + kLo5Threads - 1) / kLo5Threads);
+            lo5_blocks = std::max(1, std::min(kLo5MaxBlocks, rows));
+            lo5_rows = (rows + lo5_blocks - 1) / lo5_blocks;
+            lo5_blocks = (rows + lo5_rows - 1) / lo5_rows;
+            const size_t st_bytes = ((size_t)kUsacLoReps * sizeof(UsacLo5State) + 255) & ~(size_t)255;
+            const size_t gram_bytes = ((size_t)kUsacLoReps * kLo5MaxBlocks * 45 * 8 + 255) & ~(size_t)255;
+            if ((rc = ws_get(ctx, WS_AUX7, st_bytes + gram_bytes + (size_t)n + 256, &p))) return rc;
+            d_lo5_state = (UsacLo5State *)p;
+            d_lo5_gram = (double *)((char *)p + st_bytes);
+            d_lo5_flags = (uint8_t *)p + st_bytes + gram_bytes;
+        }
         dg_cap = dg_on ? (int)std::max<size_t>(10, std::min<size_t>(128, out_bytes / ((size_t)2 * words * 8))) : 0;
         const size_t dg_bytes = (size_t)dg_cap * sizeof(UsacDgModel);
         const size_t pool_bytes = ((size_t)n * 4 + 63) & ~(size_t)63;
-        if ((rc = pinned_get(ctx, out_bytes + smp_bytes + lo_in_bytes + pool_bytes + dg_bytes + 384, &p))) return rc;
+        if ((rc = pinned_get(ctx, out_bytes + smp_bytes + lo_in_bytes + pool_bytes + dg_bytes + lo5_pin_bytes + 512, &p))) return rc;
         h_out = (char *)p;
         h_smp = (int32_t *)(h_out + ((out_bytes + 63) & ~(size_t)63));
         h_lo_in = (UsacLoIn *)((char *)h_smp + ((smp_bytes + 63) & ~(size_t)63));
         int32_t *h_pool = (int32_t *)((char *)h_lo_in + ((lo_in_bytes + 63) & ~(size_t)63));
         void *alias = nullptr;
+        if (refine) {
+            h_lo5_flags = (uint8_t *)h_pool + pool_bytes + ((dg_bytes + 63) & ~(size_t)63);
+            h_lo5_diff = (int32_t *)(h_lo5_flags + (((size_t)n + 63) & ~(size_t)63));
+            MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, h_lo5_diff, 0));
+            d_lo5_diff = (int32_t *)alias;
+        }
         if (dg_on) {
             h_dg = (UsacDgModel *)((char *)h_pool + pool_bytes);
             MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, h_dg, 0));
@@ -693,6 +1087,7 @@ struct UsacRun {
     }
     size_t batch_out_bytes(int B) const { return (size_t)B * 4 + 64 + (size_t)B * 10 * (8 + 4) + 64 + (size_t)B * 10 * words * 8 + 64 + (size_t)B * 720; }
     size_t lo_out_stride() const { return (sizeof(UsacLoOut) + (size_t)kUsacLoEvals * words * 8 + 63) & ~(size_t)63; }
+    size_t lo5_out_stride() const { return (sizeof(UsacLo5Out) + (size_t)kUsacLoEvals * words * 8 + 63) & ~(size_t)63; }
 
     void uniform_sample(GlibcRand &r, unsigned data_size, unsigned sample_size, std::vector<unsigned> &sample) const {
         unsigned count = 0;
@@ -1059,10 +1454,10 @@ struct UsacRun {
         stats[3]++;
         return MLPL_OK;
     }
-    void emit_refined(unsigned pts, bool weighted, const double *E) {
-        double v[13];
-        v[0] = hyp_count, v[1] = pts, v[2] = weighted ? 1 : 0, v[3] = 1;
-        std::memcpy(v + 4, E, 72);
+    void emit_refined(unsigned pts, bool weighted, const double *E, bool ok = true) {
+        double v[13] = {0};
+        v[0] = hyp_count, v[1] = pts, v[2] = weighted ? 1 : 0, v[3] = ok ? 1 : 0;
+        if (ok) std::memcpy(v + 4, E, 72);
         emit(3, v, 13);
     }
 
@@ -1131,6 +1526,137 @@ struct UsacRun {
         return MLPL_OK;
     }
 
+
+    // ---- local optimisation, refinements of the 5-point family (the usac5_* chains above) ----
+    // chains [c0, c1): their h_lo_in are filled, all start at `start_phase` (-1 = from the 14-point sample)
+    int lo5_run(int c0, int c1, int start_phase) {
+        const int C = c1 - c0;
+        const size_t stride = lo5_out_stride(), part_stride = (size_t)kLo5MaxBlocks * 45;
+        UsacLo5State *st = d_lo5_state + c0;
+        double *gram = d_lo5_gram + (size_t)c0 * part_stride, *err = d_err + (size_t)c0 * n, *Etab = d_Etab + (size_t)c0 * 90;
+        char *outp = h_out_dev + (size_t)c0 * stride;
+        PolyRec *recs = d_recs + c0;
+        int32_t *nm = d_nm + c0;
+        const char *gate = reinterpret_cast<const char *>(st) + offsetof(UsacLo5State, step_fit);
+        hipLaunchKernelGGL(usac5_begin_kernel, dim3(C), dim3(64), 0, s, d_p1, d_p2, (const UsacLoIn *)(d_lo_in + c0), st, gram, part_stride, outp, stride);
+        auto fit = [&](int nparts, int fit_eval, int ends) {
+            hipLaunchKernelGGL(refit_solve_kernel, dim3(C), dim3(64), 0, s, (const double *)gram, nparts, recs, part_stride, gate, sizeof(UsacLo5State));
+            MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((C + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)recs, 0, C, Etab, nm, (double *)nullptr,
+                              (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+            hipLaunchKernelGGL(usac5_choose_kernel, dim3(C), dim3(64), 0, s, d_p1, d_p2, (int)n, (const uint8_t *)d_lo5_flags, (const double *)Etab,
+                               (const int32_t *)nm, st, outp, stride, fit_eval, ends);
+        };
+        if (start_phase < 0) fit(1, -1, 1);
+        const double step = (lo_mult * thr - thr) / kUsacLoSteps, th_ph = sqrt(thr) / 50.0;
+        const bool weights = refine == 5 || refine == 7;
+        for (int phase = start_phase; phase <= kUsacLoSteps; ++phase) {
+            const int e = phase - start_phase;
+            const double limit = phase < 0 ? lo_mult * thr : (phase < kUsacLoSteps ? (lo_mult * thr) - (phase + 1) * step : 0.0);
+            hipLaunchKernelGGL(usac5_eval_kernel, dim3(lo5_blocks, C), dim3(kLo5Threads), 0, s, d_p1, d_p2, (const double4 *)d_pts_pool, (int)n, words,
+                               lo5_rows, thr, limit, st, err, outp, stride, e);
+            if (phase == kUsacLoSteps) break;
+            hipLaunchKernelGGL(usac5_gram_kernel, dim3(lo5_blocks, C), dim3(kLo5Threads), 0, s, d_p1, d_p2, (int)n, lo5_rows, limit, phase < 0 ? 1 : 0,
+                               (phase >= 0 && weights) ? 1 : 0, th_ph, st, (const double *)err, gram, part_stride, outp, stride, e);
+            fit(lo5_blocks, e, phase < 0 ? 1 : 0);
+        }
+        MLPL_HIP_TRY(hipGetLastError());
+        MLPL_HIP_TRY(hipStreamSynchronize(s));
+        stats[3]++;
+        return MLPL_OK;
+    }
+    int lo5_upload_flags() {  // the inlier flags of the best model, point order (pinned staging: the copy is stream-ordered)
+        std::memcpy(h_lo5_flags, flags.data(), n);
+        MLPL_HIP_TRY(hipMemcpyAsync(d_lo5_flags, h_lo5_flags, n, hipMemcpyHostToDevice, s));
+        return MLPL_OK;
+    }
+
+    // locallyOptimizeSolution (USAC.h:947-1073) over the usac5 chains
+    int local_optimization5(unsigned best_inliers, unsigned *out) {
+        *out = 0;
+        if (best_inliers < 2 * kUsacLoSample) return MLPL_OK;
+        std::vector<unsigned> orig(n), sample(kUsacLoSample);
+        unsigned c = 0;
+        for (unsigned i = 0; i < n; ++i)
+            if (flags[i]) orig[c++] = i;
+        unsigned lo_inliers = best_inliers;
+        ++num_lo;
+        for (int r = 0; r < kUsacLoReps; ++r) {
+            uniform_sample(rng, best_inliers, kUsacLoSample, sample);
+            h_lo_in[r].start_step = -1;
+            for (int j = 0; j < kUsacLoSample; ++j) h_lo_in[r].sample[j] = (int32_t)orig[sample[j]];
+        }
+        int rc;
+        if ((rc = lo5_upload_flags()) || (rc = lo5_run(0, kUsacLoReps, -1))) return rc;
+        const size_t stride = lo5_out_stride();
+        for (int r = 0; r < kUsacLoReps; ++r) {
+            const UsacLo5Out *O = (const UsacLo5Out *)(h_out + (size_t)r * stride);
+            const uint64_t *rows = (const uint64_t *)((const char *)O + sizeof(UsacLo5Out));
+            int e = 0;
+            unsigned tmp = 0, tested;
+            auto evaluate = [&]() {
+                const unsigned start = pool_index;
+                const bool good = sprt_walk(rows + (size_t)e * words, &tmp, &tested);
+                emit_eval(0, start, tmp, tested, good);
+                return good;
+            };
+            auto resume = [&](int step) {  // restart the chain at re-weighting step `step` with the model of record e
+                UsacLoIn &I = h_lo_in[r];
+                I.start_step = step;
+                std::memcpy(I.E, O->E[e], 72);
+                e = 0;
+                stats[4]++;
+                return lo5_run(r, r + 1, step);
+            };
+            if (O->first_fit != 1) {
+                emit_refined(kUsacLoSample, false, nullptr, false);
+                continue;
+            }
+            emit_refined(kUsacLoSample, false, O->E[0]);
+            if (!evaluate()) continue;
+            if ((unsigned)O->cnt2 < 5) continue;
+            if (O->fit_state[0] != 1) {
+                emit_refined((unsigned)O->cnt2, false, nullptr, false);
+                continue;
+            }
+            e = 1;
+            emit_refined((unsigned)O->cnt2, false, O->E[1]);
+            for (int j = 0; j < kUsacLoSteps; ++j) {
+                if (lo_stepwise && (rc = resume(j))) return rc;
+                if (!evaluate()) {
+                    if ((rc = resume(j + 1))) return rc;
+                    continue;
+                }
+                const int fs = O->fit_state[e];
+                ++e;
+                if (fs == 1) emit_refined((unsigned)O->fit_pts[e], true, O->E[e]);
+                else if (fs == 2) emit_refined(tmp, true, nullptr, false);
+            }
+            if (!evaluate()) continue;
+            if (tmp > lo_inliers) {
+                lo_inliers = tmp;
+                store_solution(0, lo_inliers, rows + (size_t)e * words, O->E[e]);
+                if (r + 1 < kUsacLoReps) {
+                    // the repetitions behind this one chose their solutions under the old flags: where a choice would now differ (rare:
+                    // the right solution's error sum is far below the others') the chain is run again
+                    if ((rc = lo5_upload_flags())) return rc;
+                    const int C = kUsacLoReps - (r + 1);
+                    for (int k = 0; k < C; ++k) h_lo5_diff[k] = kUsacLoEvals;
+                    hipLaunchKernelGGL(usac5_recheck_kernel, dim3(kUsacLoEvals, C), dim3(64), 0, s, d_p1, d_p2, (int)n, (const uint8_t *)d_lo5_flags,
+                                       (const UsacLo5State *)(d_lo5_state + r + 1), d_lo5_diff);
+                    MLPL_HIP_TRY(hipGetLastError());
+                    MLPL_HIP_TRY(hipStreamSynchronize(s));
+                    stats[5]++;
+                    for (int k = 0; k < C; ++k)
+                        if (h_lo5_diff[k] < kUsacLoEvals) {
+                            stats[6]++;
+                            if ((rc = lo5_run(r + 1 + k, r + 2 + k, -1))) return rc;
+                        }
+                }
+            }
+        }
+        *out = lo_inliers;
+        return MLPL_OK;
+    }
 
     // ---- degeneracy tests and model upgrade (ConfigUSAC::degeneracyCheck = DEGEN_USAC_INTERNAL) ---------------------------------------
     // EssentialMatEstimator.h: testSolutionDegeneracy :1334-1362, testSolutionDegeneracyRot :1511-1663, testSolutionDegeneracyNoMot
@@ -1613,7 +2139,7 @@ struct UsacRun {
             if (update_best) {
                 unsigned lo = 0;
                 // the cache entry `sm` may be invalidated by nothing below (no insertion during LO)
-                if ((rc = local_optimization(best, &lo))) return rc;
+                if ((rc = refine ? local_optimization5(best, &lo) : local_optimization(best, &lo))) return rc;
                 if (dg_losac) {  // USAC.h:540-556 (testDegeneracyLOSAC: the 8-point refinements)
                     bool degenerate = false, upgrade = false;
                     if ((rc = test_degeneracy(&degenerate, &upgrade))) return rc;
@@ -1655,6 +2181,7 @@ int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, in
     R.prosac_beta = P->prosac_beta, R.sprt_delta = P->sprt_delta, R.sprt_epsilon = P->sprt_epsilon;
     R.sprt_mS = P->sprt_mS, R.sprt_tM = P->sprt_tM;
     R.lo_stepwise = ctx->opt_usac_lo_stepwise;
+    R.refine = P->refine;
     R.sprt_fast = ctx->opt_usac_sprt_fast != 0;
     R.dg_on = P->check_degeneracy != 0;
     R.dg_losac = R.dg_on && (P->check_degeneracy & 2) != 0;

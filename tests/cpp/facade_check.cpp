@@ -198,6 +198,41 @@ int main(int argc, char **argv) {
         fwrite(rc2 == 0 ? (const void *)sr2.E_new.data : (const void *)zero, 8, 9, o);
         fwrite(&inl2, 4, 1, o);
     }
+    // a default-constructed ConfigUSAC (pose_estim.h:94-132: POSE_STEWENIUS, REF_STEWENIUS_WEIGHTS, DEGEN_USAC_INTERNAL, automatic SPRT
+    // start values) with the caller's matches / keypoints / image size filled in, as the harness does per image pair: it runs the
+    // algorithm it names.  Then the options this library does not build: each is refused with -1 like an unsupported configuration in
+    // the reference, never served by another algorithm.
+    {
+        poselib::resetUsacHistory();
+        poselib::ConfigUSAC cd;
+        cd.imgSize = cv::Size(640, 480);
+        cd.matches = &mm, cd.keypoints1 = &a, cd.keypoints2 = &b;
+        cd.nrMatchesVfcFiltered = (unsigned)(n / 2);
+        poselib::setRansacSeed(seed + 5);
+        cv::Mat Eu, inl;
+        bool degenerate = true;
+        int32_t rcu = poselib::estimateEssentialOrPoseUSAC(p1, p2, Eu, th, cd, degenerate, inl);
+        int32_t deg = degenerate ? 1 : 0;
+        fwrite(&rcu, 4, 1, o);
+        fwrite(&deg, 4, 1, o);
+        fwrite(rcu == 0 ? (const void *)Eu.data : (const void *)zero, 8, 9, o);
+        std::vector<uint8_t> mu((size_t)n, 0);
+        if (rcu == 0) std::memcpy(mu.data(), inl.data, (size_t)n);
+        fwrite(mu.data(), 1, (size_t)n, o);
+        int32_t refused[5];
+        for (int k = 0; k < 5; ++k) {
+            poselib::ConfigUSAC cr = cd;
+            if (k == 0) cr.estimator = poselib::PoseEstimator::POSE_EIG_KNEIP;
+            if (k == 1) cr.refinealg = poselib::RefineAlg::REF_8PT_PSEUDOHUBER;
+            if (k == 2) cr.refinealg = poselib::RefineAlg::REF_EIG_KNEIP;
+            if (k == 3) cr.refinealg = poselib::RefineAlg::REF_EIG_KNEIP_WEIGHTS;
+            if (k == 4) cr.degeneracyCheck = poselib::UsacChkDegenType::DEGEN_QDEGSAC;
+            cv::Mat Er;
+            bool dg = false;
+            refused[k] = poselib::estimateEssentialOrPoseUSAC(p1, p2, Er, th, cr, dg);
+        }
+        fwrite(refused, 4, 5, o);
+    }
     fclose(o);
     return 0;
 }

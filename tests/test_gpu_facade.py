@@ -145,3 +145,16 @@ def test_cpp_facade_end_to_end(oracle, tmp_path):
     assert inl2 == int(o6["flags"].sum())
     a6, b6 = E2 / np.linalg.norm(E2), o6["E"] / np.linalg.norm(o6["E"])
     assert min(np.abs(a6 - b6).max(), np.abs(a6 + b6).max()) < 1e-8
+    # a default-constructed ConfigUSAC: POSE_STEWENIUS + REF_STEWENIUS_WEIGHTS + DEGEN_USAC_INTERNAL on a process' first call (mS = 6,
+    # tM = 2736; the rotation-only / no-motion tests after every new best model) -- the algorithm the configuration names
+    rcd, degd = take(np.int32, 2)
+    Ed = take(np.float64, 9)
+    md = take(np.uint8, n)
+    o7 = oracle.usac_essential_degen(p1, p2, th, seed + 5, check_degeneracy=1, refine=5, sorted_idx=order, prosac_beta=delta0, sprt_delta=delta0,
+                                     sprt_epsilon=eps0, sprt_ms=6.0, sprt_tm=2736.0)
+    assert rcd == 0 and degd == 0 and o7["ok"]
+    assert np.array_equal(md, o7["flags"]), int((md != o7["flags"]).sum())
+    a7, b7 = Ed / np.linalg.norm(Ed), o7["E"] / np.linalg.norm(o7["E"])
+    assert min(np.abs(a7 - b7).max(), np.abs(a7 + b7).max()) < 1e-8
+    # ... and what is not built is refused, not substituted: POSE_EIG_KNEIP, REF_8PT_PSEUDOHUBER, REF_EIG_KNEIP(_WEIGHTS), DEGEN_QDEGSAC
+    assert take(np.int32, 5).tolist() == [-1] * 5

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gol
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
 import make_golden  # noqa: E402
 import usac_compare  # noqa: E402
-from test_oracle_usac import check_against_fixture, fixture_cases, stewenius_run  # noqa: E402
+from test_oracle_usac import check_against_fixture, fixture_cases, refine_fixture_cases, stewenius_run  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -152,9 +152,13 @@ def test_argument_checks_and_refusals(ctx):
     assert not pose.usac_essential(p1[:4], p2[:4], th, 1, ctx=ctx)["ok"]                                   # solve() refuses: < 5
     assert not pose.usac_essential(p1[:12], p2[:12], th, 1, sorted_idx=np.arange(12), ctx=ctx)["ok"]      # PROSAC: < 20
     assert pose.usac_essential(p1, p2, th, 1, estimator=2, ctx=ctx)["ok"]                                  # POSE_STEWENIUS: same solver
-    with pytest.raises(_lib.MlplError) as e:
-        pose.usac_essential(p1, p2, th, 1, refine=5, ctx=ctx)                                              # REF_STEWENIUS_WEIGHTS: not built
-    assert e.value.code == _lib.MLPL_E_UNSUPPORTED
+    for refine in (1, 2, 3, 8):                                                                            # REF_8PT_PSEUDOHUBER, REF_EIG_KNEIP(_WEIGHTS): not built
+        with pytest.raises(_lib.MlplError) as e:
+            pose.usac_essential(p1, p2, th, 1, refine=refine, ctx=ctx)
+        assert e.value.code == _lib.MLPL_E_UNSUPPORTED
+    assert pose.usac_essential(p1, p2, th, 1, refine=5, estimator=2, ctx=ctx)["ok"]                        # ConfigUSAC's defaults
+    with pytest.raises(_lib.MlplError):
+        pose.usac_essential(p1, p2, th, 1, refine=5, check_degeneracy=3, ctx=ctx)                          # tests after LO: 8-point refinements only
     with pytest.raises(_lib.MlplError):
         pose.usac_essential(p1, p2, th, 1, estimator=1, ctx=ctx)                                           # Kneip's eigensolver: not built
     with pytest.raises(_lib.MlplError):
@@ -174,3 +178,53 @@ def test_threshold_relaxation_after_half_the_budget(ctx, oracle):
     assert first is None and np.array_equal(o["final"][:8], d["final"][:8]) and np.array_equal(o["flags"], d["flags"])
     thr = np.unique(o["events"][o["events"][:, 0] == 2][:, 10])
     assert len(thr) >= 2                                                                                   # the relaxed threshold was in force
+
+
+@pytest.mark.parametrize("refine,stepwise", [(5, 0), (5, 1), (4, 0), (7, 0), (7, 1), (6, 0)])
+def test_device_follows_the_reference_with_the_five_point_refinements(ctx, refine, stepwise):
+    """tests/golden/usac_refine_trace.npz against the device path (usac5_* chains): REF_STEWENIUS_WEIGHTS (ConfigUSAC's default) and
+    REF_STEWENIUS on the reference-built USAC.h + OpenGV Stewenius traces, REF_NISTER(_WEIGHTS) on the control-flow traces; same
+    decisions event by event, refined models to 1e-8.  stepwise = 1: every step of a local-optimisation chain through the resume path."""
+    from matchinglib_poselib_amd import pose
+
+    ctx.set_option("usac_lo_stepwise", stepwise)
+    try:
+        run = stewenius_run(lambda *a, **k: pose.usac_essential(*a, estimator=2 if refine in (4, 5) else 0, refine=refine, ctx=ctx, **k))
+        checked = 0
+        for g, k, n, frac, seed, prosac, usac_seed, agree, rf in refine_fixture_cases():
+            if rf == refine and agree:
+                check_against_fixture(run, g, k, n, frac, seed, prosac, usac_seed, e5_max=5e-3, kept=make_golden.USAC_REFINE_EVENTS_KEPT)
+                checked += 1
+        assert checked >= 12
+    finally:
+        ctx.set_option("usac_lo_stepwise", 0)
+
+
+@pytest.mark.parametrize("refine", [5, 7, 4, 6])
+def test_device_equals_oracle_with_the_five_point_refinements(ctx, oracle, refine):
+    """Ten more scenes, uniform and PROSAC, with the degeneracy tests of DEGEN_USAC_INTERNAL on for half of them (check_degeneracy = 1:
+    what estimateEssentialMatUsac configures for these refinements): identical decisions, refined models to 1e-8, same masks."""
+    from matchinglib_poselib_amd import pose
+
+    parted = 0
+    for si_, sc in enumerate(usac_compare.scenes()):
+        for prosac in (False, True):
+            si = sc["order"] if prosac else None
+            chk = 1 if (si_ + prosac) % 2 else 0
+            kw = dict(sorted_idx=si, event_cap=120000, max_hyp=6000, refine=refine, sprt_ms=6.0, sprt_tm=2736.0)
+            if chk:
+                o = oracle.usac_essential_degen(sc["p1"], sc["p2"], sc["th"], 4242, check_degeneracy=1, **kw)
+            else:
+                o = oracle.usac_essential(sc["p1"], sc["p2"], sc["th"], 4242, **kw)
+            d = pose.usac_essential(sc["p1"], sc["p2"], sc["th"], 4242, check_degeneracy=chk, ctx=ctx, **kw)
+            first, diffs = usac_compare.compare(o["events"], d["events"])
+            if first is not None:   # only at a sample whose solution COUNT differs (a double root)
+                a, b = o["events"][first], d["events"][first]
+                assert int(a[0]) == 1 and int(b[0]) == 1 and np.array_equal(a[1:7], b[1:7]) and a[7] != b[7], (sc["name"], first, a[:9], b[:9])
+                parted += 1
+                continue
+            assert diffs["sprt"] < 1e-12 and diffs.get("E3", 0) < 1e-8 and diffs.get("E5_q98", 0) < 1e-8, (sc["name"], diffs)
+            assert np.array_equal(o["final"][:8], d["final"][:8]) and np.array_equal(o["flags"], d["flags"])
+            Eo, Ed = o["E"] / np.linalg.norm(o["E"]), d["E"] / np.linalg.norm(d["E"])
+            assert min(np.abs(Eo - Ed).max(), np.abs(Eo + Ed).max()) < 1e-8
+    assert parted <= 2
