@@ -104,11 +104,17 @@ bool estimateEssentialMat(cv::OutputArray E, cv::InputArray p1, cv::InputArray p
 // (cfg.automaticSprtInit; the history of the last 20 calls lives in function-local statics in the reference, and so it does here:
 // process-wide), local optimisation, SPRT-aware stopping -- on the MI355X (mlpl_usac_essential, include/mlpl_c.h).
 // Returns 0, -1 = configuration not supported, -2 = USAC failed.  E: 3 x 3, inliers: 1 x n CV_8U.
-// Built: PoseEstimator POSE_NISTER and POSE_STEWENIUS (one exact 5-point solver serves both), RefineAlg REF_WEIGHTS (8-point fit with
-// Torr weights: the harness default, tests/poselib-test/main.cpp cfgUSAC "311220"), UsacChkDegenType DEGEN_NO_CHECK.  What is NOT built
-// is served by what is, with one notice per process instead of a failure: the other inner refinement algorithms run REF_WEIGHTS,
-// POSE_EIG_KNEIP runs the 5-point solver, and DEGEN_USAC_INTERNAL / DEGEN_QDEGSAC run without degeneracy tests (isDegenerate = false,
-// R_degenerate / inliers_degenerate_R left empty; R and t are only ever filled by Kneip's eigensolver in the reference: left empty).
+// Built: PoseEstimator POSE_NISTER and POSE_STEWENIUS (one exact 5-point solver serves both); RefineAlg REF_WEIGHTS (8-point fit with
+// Torr weights: the harness default, tests/poselib-test/main.cpp cfgUSAC "311220") and the four 5-point refinements REF_STEWENIUS,
+// REF_STEWENIUS_WEIGHTS (ConfigUSAC's own default), REF_NISTER, REF_NISTER_WEIGHTS; UsacChkDegenType DEGEN_NO_CHECK and
+// DEGEN_USAC_INTERNAL -- the rotation-only / no-motion tests after every new best model (with REF_WEIGHTS also after every local
+// optimisation, usac_estimations.cpp:368-375), the upgrade of a degenerate model (no motion -> t, R -> R + t) and the verdict:
+// isDegenerate, R_degenerate and inliers_degenerate_R are filled as the reference fills them (pose_estim.cpp:2101-2133).  Of that check
+// only the homography test the reference adds for the 8-point refinements is missing (its upgrade branch has no defined behaviour,
+// EssentialMatEstimator.h:1958-2015).  R and t are only ever filled by Kneip's eigensolver in the reference: left empty.
+// NOT built, and REFUSED with the reference's message and -1 rather than served by another algorithm: POSE_EIG_KNEIP,
+// REF_8PT_PSEUDOHUBER, REF_EIG_KNEIP, REF_EIG_KNEIP_WEIGHTS, DEGEN_QDEGSAC.  (MLPL_OPTIONS=usac_substitute in the environment opts
+// into the substitution of earlier releases: Kneip -> 5-point solver, those refinements -> REF_WEIGHTS, QDEGSAC -> no check.)
 // The reference seeds srand(time(nullptr)) per call; setRansacSeed() fixes the seed here as for RANSAC.
 int estimateEssentialOrPoseUSAC(const cv::Mat &p1, const cv::Mat &p2, cv::OutputArray E, double th, ConfigUSAC &cfg, bool &isDegenerate,
                                 cv::OutputArray inliers = cv::noArray(), cv::OutputArray R_degenerate = cv::noArray(),

@@ -8,20 +8,21 @@
 // near-to-mean pose rating and the stability flags (:2817-3298), maxSkipPairs handling (:3300-3317).
 // Every robust estimation and every error evaluation runs on the MI355X (estimateEssentialMat / getPoseTriangPts / mlpl_get_inliers_strict).
 //
-// Not built (outside the hot path): USAC, homography alignment
-// (Halign), the linear refinement solvers (refineMethod / refineMethod_CorrPool: Nister/Stewenius/Kneip/8pt with weights) and bundle
-// adjustment (BART).  refineRTold IS built: the estimator's own refinement step plus poselib::robustEssentialRefine on the inliers
-// (:1460-1474), on the device.  Consequences of what is not built, all reported once on std::cout:
-//   * RobMethod must be "RANSAC", "LMEDS" or "ARRSAC"; "USAC" and Halign make addNewCorrespondences() return -1; autoTH (ARRSAC with
-//     poselib::AutoThEpi's threshold estimation, :1330-1342) is built;
+// Not built (outside the hot path): homography alignment (Halign), the linear refinement solvers
+// (refineMethod / refineMethod_CorrPool: Nister/Stewenius/Kneip/8pt with weights) and bundle adjustment (BART).  refineRTold IS built: the
+// estimator's own refinement step plus poselib::robustEssentialRefine on the inliers (:1460-1474), on the device.  Consequences, all
+// reported once on std::cout:
+//   * RobMethod is "USAC" (the reference's default; estimateEssentialOrPoseUSAC with the ConfigUSAC handed to addNewCorrespondences, a
+//     degenerate pair -> -2, :1355-1413), "RANSAC", "LMEDS" or "ARRSAC"; Halign makes addNewCorrespondences() return -1; autoTH (ARRSAC
+//     with poselib::AutoThEpi's threshold estimation, :1330-1342) is built;
 //   * refinement / BA options are ignored;
 //   * between robust estimations the pool pose is REFINED (checkPoolPoseRobust != 1, the reference's schedule :680-716) only with
 //     refineRTold_CorrPool, the refinement that is built (refinePoseFromPool :1767-2084 with robustEssentialRefine on the device);
 //     with the linear solvers selected the pool is re-estimated robustly on every frame (the reference's checkPoolPoseRobust = 1);
-//   * thinning an over-full pool (checkPoolSize) drops the lowest-weight correspondences; the reference first thins dense image regions
-//     by image morphology (cv::dilate / cv::erode on a density image), which is image-side work;
-//   * the radius search over the pool returns neighbours by ascending distance (the reference's nanoflann call leaves its dynamic
-//     kd-tree's traversal order).
+//   * thinning an over-full pool follows checkPoolSize (:2550-2816): a density image of the pool's left keypoints, elliptic dilate /
+//     erode with the reference's border handling, then the weights;
+//   * the radius search over the pool returns neighbours by ascending squared distance, as the reference's
+//     keyPointTreeInterface::radiusSearch does (nanoflannInterface.cpp:269-300); equal distances come by index.
 #pragma once
 #include <memory>
 #include <string>
@@ -32,8 +33,7 @@
 
 namespace poselib {
 
-// reference stereo_pose_refinement.h:100-176: every field, the reference's defaults (incl. RobMethod = "USAC", which this library
-// does not build: StereoRefine reports -1 for it, see addNewCorrespondences).
+// reference stereo_pose_refinement.h:100-176: every field, the reference's defaults (incl. RobMethod = "USAC").
 struct ConfigPoseEstimation {
     ConfigPoseEstimation()
         : dist0_8(nullptr),

@@ -284,9 +284,10 @@ int mlpl_debug_arrsac_trace(mlpl_ctx *ctx, int32_t *buf, int cap);
  * pose_estim.cpp:1737-2244) -> estimateEssentialMatUsac (source/usac/usac_estimations.cpp:283-735) -> USAC<EssentialMatEstimator>::solve
  * (include/usac/estimators/USAC.h:335-620, EssentialMatEstimator.h): PROSAC or uniform sampling, sample pre-validation, the oriented
  * epipolar constraint on every model, Wald's sequential test over a shuffled evaluation order with re-estimated delta / epsilon,
- * local optimisation (5 inner repetitions of a 14-point fit + 4 re-weighted refits, REF_WEIGHTS) on every new best model, and the
+ * local optimisation (5 inner repetitions of a 14-point fit + 4 re-weighted refits; `refine` below) on every new best model, and the
  * SPRT-aware stopping criterion.  The harness default estimator (tests/poselib-test/main.cpp:734).  Minimal solves, validity tests and
- * every error evaluation run on the device in speculative batches, the refits as one launch per local optimisation; the sequential
+ * every error evaluation run on the device in speculative batches, the refits as one launch (REF_WEIGHTS) or one chain of launches
+ * (5-point refinements) per local optimisation; the sequential
  * decisions are taken on the host.  params->check_degeneracy switches the degeneracy handling of
  * UsacChkDegenType::DEGEN_USAC_INTERNAL on: EssentialMatEstimator::testSolutionDegeneracyRot / NoMot and upgradeDegenerateModel
  * (EssentialMatEstimator.h:1334-1362, 1511-1663, 1838-1911, 2098-2361); results through mlpl_usac_last_degeneracy.  Not built: the
@@ -294,8 +295,13 @@ int mlpl_debug_arrsac_trace(mlpl_ctx *ctx, int32_t *buf, int cap);
  * reads a translation nothing has set), DEGEN_QDEGSAC.
  * The reference seeds srand(time(nullptr)) and shuffles its evaluation order on the process-wide stream; `seed` is that seed.
  * estimator: PoseEstimator value, 0 = POSE_NISTER, 2 = POSE_STEWENIUS (both are exact 5-point solvers with the same real solution set;
- * the device solver serves both, solutions ordered by the library's convention); refine: RefineAlg value, 0 = REF_WEIGHTS (8-point
- * fit with Torr weights).  Other values: MLPL_E_UNSUPPORTED.
+ * the device solver serves both, solutions ordered by the library's convention); refine: RefineAlg value of the local optimisation's
+ * fits (EssentialMatEstimator::generateRefinedModel :526-850, findWeights :2366-2428): 0 = REF_WEIGHTS (8-point fit with Torr weights),
+ * 4 = REF_STEWENIUS, 5 = REF_STEWENIUS_WEIGHTS (ConfigUSAC's default, pose_estim.h:99-100), 6 = REF_NISTER, 7 = REF_NISTER_WEIGHTS -- the
+ * five-point solver on all points of the fit set (unit bearing vectors; the _WEIGHTS forms scale the rows of a re-weighted step by the
+ * pseudo-Huber weights of P/source/usac/utils/weightingEssential.cpp:190-206), of its solutions the one with the smallest Sampson-error
+ * sum over the inliers of the best model so far.  Other values (REF_8PT_PSEUDOHUBER, REF_EIG_KNEIP(_WEIGHTS), POSE_EIG_KNEIP):
+ * MLPL_E_UNSUPPORTED.  check_degeneracy = 3 goes with refine = 0 only (usac_estimations.cpp:368-375).
  * results[12] = {1, hypotheses, models, samples rejected by pre-validation, models rejected by the oriented constraint, inliers of the
  * best model, correspondences verified, local optimisations, SPRT delta and epsilon the reference reports back (newest history entry,
  * usac_estimations.cpp:459-468 halves epsilon itself), delta and epsilon at the end}.  mask: n bytes, 1 = inlier of the returned model.
@@ -327,7 +333,8 @@ int mlpl_usac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n
 int mlpl_usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, const mlpl_usac_params *params, double E[9],
                             uint8_t *d_mask, double results[12], void *stream);
 /* Statistics of the last mlpl_usac_essential[_dev] call: {device batches, samples solved on the device, samples the control flow
- * consumed, local-optimisation launches, of which chain resumes, launches of the degeneracy tests, 0, 0}. */
+ * consumed, local-optimisation launches / chain runs, of which chain resumes, rechecks of the solution choices after a repetition
+ * stored a new best model (5-point refinements), chains re-run because a choice changed, Jacobi sweeps (REF_WEIGHTS)}. */
 int mlpl_usac_last_stats(mlpl_ctx *ctx, long long stats[8]);
 /* What the degeneracy tests of the last mlpl_usac_essential[_dev] call found -- the quantities estimateEssentialMatUsac hands to
  * estimateEssentialOrPoseUSAC (usac_estimations.cpp:564-636, 689-726; pose_estim.cpp:2044-2133 takes the decision "degenerate" from
