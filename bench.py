@@ -160,6 +160,10 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
     assert m.shape[0] == total
     first = m[0, : int(allrec["n_matches"][0])].cpu().numpy()
     assert (np.diff(first[:, 0]) > 0).all() and (first[:, 2] == -1).all(), "gathered match list of pair 0 is not a DMatch list"
+    if getattr(args, "dump_records", None):   # tests: the gathered records and the valid rows of every gathered match list
+        mh = m.cpu().numpy()
+        np.savez(args.dump_records, records=allrec.view(np.uint8), mode=np.array([0]),
+                 matches=np.concatenate([mh[i, : int(allrec["n_matches"][i])] for i in range(total)]))
     stats = np.zeros(8, np.int64)
     lib.mlpl_pair_batch_last_stats(ctx.handle, stats.ctypes.data)   # of the last single-call step: the rank's whole share
     prof = {}
@@ -273,6 +277,7 @@ def main():
     ap.add_argument("--c5-pairs", type=int, default=512)
     ap.add_argument("--c5-distinct", type=int, default=8, help="distinct synthetic inputs generated per rank (cycled over its shard)")
     ap.add_argument("--c5-steps", type=int, default=3, help="timed C5 batches of the extras block of the default (C2) line")
+    ap.add_argument("--dump-records", default=None, help="c5 workload, rank 0: write the gathered records and match lists of the last step to this .npz (tests)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -1,0 +1,38 @@
+"""N > 1 where a GPU exists: bench.py's C5 workload with TWO ranks (gloo, both on cuda:0 -- a rehearsal of the sharding, the all_gather
+of the records and the grouped send / recv of the match lists, not a scaling run) against the same batch on one rank: gathered records
+and match lists byte for byte.  The ranks are fresh child processes started by bench.py's own launcher (a process that never touched the
+GPU) under torch.distributed.run."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tmp_path, gpus):
+    out = os.path.join(str(tmp_path), f"rec{gpus}.npz")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", "c5", "--c5-pairs", "16", "--n", "2048", "--steps", "1",
+           "--warmup", "1", "--no-cpu-baseline", "--dump-records", out]
+    if gpus > 1:
+        cmd += ["--share-gpu", "--backend", "gloo"]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    return line, np.load(out)
+
+
+def test_two_ranks_give_the_one_rank_records_and_match_lists(tmp_path):
+    one_line, one = _run(tmp_path, 1)
+    two_line, two = _run(tmp_path, 2)
+    assert one_line["n_gpus"] == 1 and two_line["n_gpus"] == 2 and two_line["config"]["backend"] == "gloo"
+    assert two_line["config"]["pairs_total"] == 16 and two_line["config"]["pairs_this_rank"] == 8
+    assert one["records"].tobytes() == two["records"].tobytes()
+    assert one["matches"].shape == two["matches"].shape and one["matches"].tobytes() == two["matches"].tobytes()
+    assert len(one["matches"]) > 16 * 100
