@@ -64,7 +64,7 @@ def spawn_ranks(n):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), "--", os.path.abspath(__file__)] + sys.argv[1:]   # "--": the launcher's parser must not read bench.py's options (--n is a prefix of its --nnodes)
     return subprocess.run(cmd, env=env).returncode
 
 
