@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(tmp_path, gpus):
     out = os.path.join(str(tmp_path), f"rec{gpus}.npz")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", "c5", "--c5-pairs", "16", "--n", "2048", "--steps", "1",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", "c5", "--c5-pairs", "16", "--c5-distinct", "16", "--n", "2048", "--steps", "1",
            "--warmup", "1", "--no-cpu-baseline", "--dump-records", out]
     if gpus > 1:
         cmd += ["--share-gpu", "--backend", "gloo"]
