@@ -332,6 +332,21 @@ int mlpl_usac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n
                         uint8_t *mask, double results[12]);
 int mlpl_usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, const mlpl_usac_params *params, double E[9],
                             uint8_t *d_mask, double results[12], void *stream);
+/*
+ * A batch of USAC problems in one call -- the harness runs estimateEssentialOrPoseUSAC once per image pair (T/poselib-test/main.cpp:
+ * 1440-2072, RobMethod "USAC" is its default, :734); a rank's share of a batch of pairs is many such problems.  Problem b: correspondences
+ * d_p1 / d_p2 + b * stride * 2 doubles (device, camera coordinates), counts[b] <= stride of them (host), parameters params[b] (host; its own
+ * seed, thresholds, PROSAC order).  Every problem runs the sequential program of mlpl_usac_essential_dev on its own host thread, and the
+ * launches of all runs that stand at the same point of their control flow are merged into ONE launch per kernel (problem = grid
+ * dimension; csrc/batch_hub.h), 128 problems at a time.  Outputs per problem: status[b] (0; MLPL_E_FAILED = solve() refused; < 0 other
+ * errors, which also end the call), E + 9 b, results + 12 b, its inlier mask at d_masks + b * stride (device, optional), degen + 16 b
+ * (optional: what mlpl_usac_last_degeneracy's info[] returns), its decision trace at trace + b * trace_cap * 16 with trace_lens[b]
+ * records (optional, diagnostics).  Every output equals what mlpl_usac_essential_dev returns for that problem alone
+ * (tests/test_gpu_usac_batch.py: records and event traces of 64 problems).
+ */
+int mlpl_usac_essential_batch_dev(mlpl_ctx *ctx, int n_problems, const double *d_p1, const double *d_p2, int stride, const int32_t *counts,
+                                  const mlpl_usac_params *params, double *E, uint8_t *d_masks, double *results, int32_t *status, double *degen,
+                                  double *trace, int trace_cap, int32_t *trace_lens, void *stream);
 /* Statistics of the last mlpl_usac_essential[_dev] call: {device batches, samples solved on the device, samples the control flow
  * consumed, local-optimisation launches / chain runs, of which chain resumes, rechecks of the solution choices after a repetition
  * stored a new best model (5-point refinements), chains re-run because a choice changed, Jacobi sweeps (REF_WEIGHTS)}. */

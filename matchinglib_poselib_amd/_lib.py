@@ -98,6 +98,8 @@ _SIGNATURES = {
     "mlpl_usac_default_params": (None, [c_void_p, c_double]),
     "mlpl_usac_essential": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mlpl_usac_essential_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mlpl_usac_essential_batch_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "mlpl_usac_last_stats": (c_int, [c_void_p, c_void_p]),
     "mlpl_usac_last_degeneracy": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "mlpl_debug_usac_trace": (c_int, [c_void_p, c_void_p, c_int]),

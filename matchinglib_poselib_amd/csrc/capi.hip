@@ -58,6 +58,24 @@ int pinned_get(mlpl_ctx *ctx, size_t bytes, void **out) {
     return MLPL_OK;
 }
 
+int pinned_batch_get(mlpl_ctx *ctx, size_t bytes, void **out) {
+    if (ctx->pinned_batch_bytes < bytes) {
+        MLPL_HIP_TRY(hipDeviceSynchronize());
+        if (ctx->pinned_batch) MLPL_HIP_TRY(hipHostFree(ctx->pinned_batch));
+        ctx->pinned_batch = nullptr;
+        ctx->pinned_batch_bytes = 0;
+        const size_t want = bytes + bytes / 8 + 4096;
+        hipError_t e = hipHostMalloc(&ctx->pinned_batch, want, hipHostMallocMapped);
+        if (e != hipSuccess) {
+            set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            return MLPL_E_NOMEM;
+        }
+        ctx->pinned_batch_bytes = want;
+    }
+    *out = ctx->pinned_batch;
+    return MLPL_OK;
+}
+
 void prof_mark(mlpl_ctx *ctx, int id, int phase, hipStream_t s) {
     if (!ctx->prof_on) return;
     if (!ctx->prof_ev[id]) return;  // pools are created by mlpl_profile_enable, outside any timed region
@@ -155,6 +173,10 @@ void mlpl_ctx_destroy(mlpl_ctx *ctx) {
         delete[] ctx->prof_ev[k];
     }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pinned_batch) (void)hipHostFree(ctx->pinned_batch);
+    if (ctx->hub_items_host) (void)hipHostFree(ctx->hub_items_host);
+    if (ctx->hub_items_dev) (void)hipFree(ctx->hub_items_dev);
+    mlpl::hub_streams_free(ctx->hub_streams);
     if (ctx->l2_hint_host) (void)hipHostFree(ctx->l2_hint_host);
     delete[] ctx->ransac_T_host;
     std::free(ctx->last_usac_flags);

@@ -57,6 +57,7 @@ enum WsSlot {
     WS_F16_CAND,
     WS_BATCH_SMP, // mlpl_pair_pose_batch_dev: sample tables of a pass (drawn on the device), stream positions
     WS_RAND_RAW,  // raw rand() stream of the last RANSAC seed on the device + the control block of the device-side sampling
+    WS_BATCH_RUNS, // device blocks of the runs of a batched sequential estimator (USAC / ARRSAC), one slice per run
     WS_NUM_SLOTS
 };
 
@@ -83,6 +84,11 @@ struct mlpl_ctx {
     size_t ws_bytes[mlpl::WS_NUM_SLOTS];
     void *pinned;  // small pinned host scratch for async result readback
     size_t pinned_bytes;
+    void *pinned_batch;  // pinned, device-mapped block of the batched sequential estimators (one slice per run; csrc/usac_batch.h)
+    size_t pinned_batch_bytes;
+    void *hub_items_host, *hub_items_dev;  // item tables of the merged launches of a round (csrc/batch_hub.h)
+    size_t hub_items_cap;
+    void *hub_streams;   // helper streams / events of the hub (HubStreams, created on first use)
     int l2_mode;
     int opt_l2_mfma_waves;          // waves per workgroup of the L2 matrix-core kernel: 4, 8 or 0 = automatic
     int opt_l2_mfma_blocks_per_cu;  // its grid sizing target (0 = automatic)
@@ -164,6 +170,8 @@ namespace mlpl {
 // that can coexist in a call has its own slot (see the WsSlot comments and the call sites).
 int ws_get(mlpl_ctx *ctx, WsSlot slot, size_t bytes, void **out);
 int pinned_get(mlpl_ctx *ctx, size_t bytes, void **out);
+int pinned_batch_get(mlpl_ctx *ctx, size_t bytes, void **out);
+void hub_streams_free(void *p);
 
 constexpr int kProfMaxLaunches = 2048;
 // Records the start (phase 0) / stop (phase 1) event of one launch of kernel `id` on stream s when profiling is on.

@@ -34,10 +34,14 @@
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
+#include <type_traits>
 #include <climits>
 #include <cmath>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <string>
 #include <thread>
 #include <unordered_map>
 #include <unordered_set>
@@ -519,17 +523,17 @@ constexpr int kHypPerWave = 6;
 #define MLPL_SWEEP_CAP 32
 #endif
 template <bool kPolish>  // compile-time: the polished instance does not carry the Jacobi SVD's registers
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MLPL_ROOTS_WAVES, MLPL_ROOTS_WAVES))) void roots_kernel_t(const PolyRec *__restrict__ recs, int sample_offset, int n_samples,
-                                                   double *__restrict__ E_tab, int32_t *__restrict__ n_models,
-                                                   double *__restrict__ dense_E, int32_t *__restrict__ dense_id,
-                                                   int32_t *__restrict__ dense_total, int32_t *__restrict__ good_zero, int slot_stride = 0) {
+__device__ __forceinline__ void roots_body(const PolyRec *__restrict__ recs, int sample_offset, int n_samples,
+                                           double *__restrict__ E_tab, int32_t *__restrict__ n_models,
+                                           double *__restrict__ dense_E, int32_t *__restrict__ dense_id,
+                                           int32_t *__restrict__ dense_total, int32_t *__restrict__ good_zero, int slot_stride, const int vbx) {
     constexpr bool polish = kPolish;
     __shared__ double R[kHypPerWave][88];
     __shared__ double rr[64], ri[64];
     if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
     const int lane = threadIdx.x;
     const int h = lane / 10, r = lane - h * 10;
-    const int sample0 = sample_offset + blockIdx.x * kHypPerWave;
+    const int sample0 = sample_offset + vbx * kHypPerWave;
     if (slot_stride) {  // batched pass: a dense model list per slot (slot_stride is a multiple of kHypPerWave: a wave never straddles slots)
         const int a = sample0 / slot_stride;
         dense_total += a;
@@ -761,6 +765,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MLPL_ROOTS_W
     }
     if (h < kHypPerWave && r == 0 && sample < n_samples) n_models[sample] = cnt_h;
 }
+template <bool kPolish>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MLPL_ROOTS_WAVES, MLPL_ROOTS_WAVES))) void roots_kernel_t(const PolyRec *__restrict__ recs, int sample_offset, int n_samples,
+                                                   double *__restrict__ E_tab, int32_t *__restrict__ n_models,
+                                                   double *__restrict__ dense_E, int32_t *__restrict__ dense_id,
+                                                   int32_t *__restrict__ dense_total, int32_t *__restrict__ good_zero, int slot_stride = 0) {
+    roots_body<kPolish>(recs, sample_offset, n_samples, E_tab, n_models, dense_E, dense_id, dense_total, good_zero, slot_stride, blockIdx.x);
+}
 
 // launch helper: picks the instance by the context's solver_polish option
 #define MLPL_LAUNCH_ROOTS(polish_flag, grid, stream, ...)                                                        \
@@ -822,14 +833,14 @@ __device__ __forceinline__ void householder_basis(SolveLds &L, int lane) {
 
 }
 
-__global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
-                                                      const int32_t *__restrict__ samples, int sample_offset, int n_samples,
-                                                      PolyRec *__restrict__ recs /* indexed from sample_offset */,
-                                                      const PairSlot *__restrict__ ps = nullptr, int slot_stride = 0) {
+__device__ __forceinline__ void solve5pt_body(const double *__restrict__ p1, const double *__restrict__ p2,
+                                              const int32_t *__restrict__ samples, int sample_offset, int n_samples,
+                                              PolyRec *__restrict__ recs /* indexed from sample_offset */,
+                                              const PairSlot *__restrict__ ps, int slot_stride, const int vbx) {
     __shared__ SolveLds L;
     if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
     const int lane = threadIdx.x;
-    const int sample = sample_offset + blockIdx.x;
+    const int sample = sample_offset + vbx;
     if (sample >= n_samples) return;
     if (ps) {  // batched pass: hypotheses beyond the slot's count are padding -- no models
         const int a = sample / slot_stride;
@@ -849,6 +860,12 @@ __global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__
     wave_sync();
     householder_basis(L, lane);
     solve_from_basis(L, lane, recs + (sample - sample_offset));
+}
+__global__ __launch_bounds__(64) void solve5pt_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
+                                                      const int32_t *__restrict__ samples, int sample_offset, int n_samples,
+                                                      PolyRec *__restrict__ recs /* indexed from sample_offset */,
+                                                      const PairSlot *__restrict__ ps = nullptr, int slot_stride = 0) {
+    solve5pt_body(p1, p2, samples, sample_offset, n_samples, recs, ps, slot_stride, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -873,10 +890,10 @@ struct Solve3Lds {
     double W[kHypPerSolveWave][160];    // [0,60) rows 4..9 x columns 10..19 of the eliminated system, [60,99) B(z), [100,148) P0 * P1
 };
 
-__global__ __launch_bounds__(64) void solve5pt3_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
-                                                       const int32_t *__restrict__ samples, int sample_offset, int n_samples,
-                                                       PolyRec *__restrict__ recs /* indexed from sample_offset */,
-                                                       const PairSlot *__restrict__ ps = nullptr, int slot_stride = 0) {
+__device__ __forceinline__ void solve5pt3_body(const double *__restrict__ p1, const double *__restrict__ p2,
+                                               const int32_t *__restrict__ samples, int sample_offset, int n_samples,
+                                               PolyRec *__restrict__ recs /* indexed from sample_offset */,
+                                               const PairSlot *__restrict__ ps, int slot_stride, const int vbx) {
     __shared__ Solve3Lds L;
     if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
     const int lane = threadIdx.x;
@@ -884,7 +901,7 @@ __global__ __launch_bounds__(64) void solve5pt3_kernel(const double *__restrict_
     const bool mine = gl < kHypPerSolveWave;
     const int g = mine ? gl : kHypPerSolveWave - 1;  // lanes 60..63 follow group 2 (reads only)
     const int j = lane - gl * kSolveGroup;
-    const int sample = sample_offset + blockIdx.x * kHypPerSolveWave + g;
+    const int sample = sample_offset + vbx * kHypPerSolveWave + g;
     bool live = mine && sample < n_samples;
     if (live && ps) {  // batched pass: hypotheses beyond the slot's count are padding -- no models
         const int a = sample / slot_stride;
@@ -1107,6 +1124,12 @@ __global__ __launch_bounds__(64) void solve5pt3_kernel(const double *__restrict_
         }
     }
     if (live && j == 0) rec->ok = singular ? 0.0 : 1.0;
+}
+__global__ __launch_bounds__(64) void solve5pt3_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
+                                                       const int32_t *__restrict__ samples, int sample_offset, int n_samples,
+                                                       PolyRec *__restrict__ recs /* indexed from sample_offset */,
+                                                       const PairSlot *__restrict__ ps = nullptr, int slot_stride = 0) {
+    solve5pt3_body(p1, p2, samples, sample_offset, n_samples, recs, ps, slot_stride, blockIdx.x);
 }
 
 // the solver's first kernel: three hypotheses per wave (default) or the one-hypothesis wave (option solver_wave3 = 0)
@@ -2032,17 +2055,16 @@ __device__ __forceinline__ void order_desc9(const Jacobi9Lds &J, int *order) {
 // One workgroup (one wave) per system: blockIdx.x selects the system's parts (part_stride doubles apart) and its record.  `gate` (optional):
 // an int per system, gate_stride bytes apart -- a system whose gate is 0 is not solved and its record says "no models" (USAC's local
 // optimisation: chains whose step has no fit, usac_impl.h).
-__global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restrict__ gram_part, int nparts,
-                                                         PolyRec *__restrict__ rec, size_t part_stride = 0,
-                                                         const char *__restrict__ gate = nullptr, size_t gate_stride = 0) {
+__device__ __forceinline__ void refit_solve_body(const double *__restrict__ gram_part, int nparts, PolyRec *__restrict__ rec, size_t part_stride,
+                                                 const char *__restrict__ gate, size_t gate_stride, const int vbx) {
     __shared__ SolveLds L;
     __shared__ Jacobi9Lds J;
     __shared__ double gsum[45];
     if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
     const int lane = threadIdx.x;
-    gram_part += (size_t)blockIdx.x * part_stride;
-    rec += blockIdx.x;
-    if (gate && *reinterpret_cast<const int32_t *>(gate + (size_t)blockIdx.x * gate_stride) == 0) {
+    gram_part += (size_t)vbx * part_stride;
+    rec += vbx;
+    if (gate && *reinterpret_cast<const int32_t *>(gate + (size_t)vbx * gate_stride) == 0) {
         if (lane == 0) rec->ok = 0.0;
         return;
     }
@@ -2073,6 +2095,11 @@ __global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restric
     }
     wave_sync();
     solve_from_basis(L, lane, rec);
+}
+__global__ __launch_bounds__(64) void refit_solve_kernel(const double *__restrict__ gram_part, int nparts,
+                                                         PolyRec *__restrict__ rec, size_t part_stride = 0,
+                                                         const char *__restrict__ gate = nullptr, size_t gate_stride = 0) {
+    refit_solve_body(gram_part, nparts, rec, part_stride, gate, gate_stride, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2819,6 +2846,17 @@ static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
     return MLPL_OK;
 }
 
+#include "batch_hub.h"
+#include "hub_kernels.h"
+void hub_streams_free(void *p) {
+    HubStreams *h = static_cast<HubStreams *>(p);
+    if (!h) return;
+    for (int i = 0; i < kHubMaxGroups; ++i) {
+        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+        if (i && h->aux[i]) (void)hipStreamDestroy(h->aux[i]);
+    }
+    delete h;
+}
 #include "arrsac_impl.h"
 #include "usac_impl.h"
 #include "pair_batch_impl.h"
@@ -3631,6 +3669,34 @@ int mlpl_usac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int n
         return usac_essential_dev(ctx, (const double *)dp1, (const double *)dp2, n, params, E, nullptr, results, ctx->stream, p1, p2, mask);
     } catch (const std::bad_alloc &) {
         set_error("mlpl_usac_essential: out of host memory");
+        return MLPL_E_NOMEM;
+    }
+}
+
+int mlpl_usac_essential_batch_dev(mlpl_ctx *ctx, int n_problems, const double *d_p1, const double *d_p2, int stride, const int32_t *counts,
+                                  const mlpl_usac_params *params, double *E, uint8_t *d_masks, double *results, int32_t *status, double *degen,
+                                  double *trace, int trace_cap, int32_t *trace_lens, void *stream) {
+    if (!ctx || n_problems < 0 || !d_p1 || !d_p2 || stride < 1 || !counts || !params || !E || !results || !status) {
+        set_error("mlpl_usac_essential_batch_dev: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    int rc;
+    for (int b = 0; b < n_problems; ++b) {
+        if (counts[b] < 0 || counts[b] > stride) {
+            set_error("mlpl_usac_essential_batch_dev: problem %d has %d correspondences (stride %d)", b, counts[b], stride);
+            return MLPL_E_BAD_INPUT;
+        }
+        if ((rc = usac_check_params(&params[b], counts[b], "mlpl_usac_essential_batch_dev"))) return rc;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    UsacBatchTrace tr{trace, trace_cap, trace_lens};
+    if (trace && trace_lens)
+        for (int b = 0; b < n_problems; ++b) trace_lens[b] = 0;
+    try {
+        return usac_essential_batch_dev(ctx, n_problems, d_p1, d_p2, stride, counts, params, E, d_masks, results, status, degen, trace ? &tr : nullptr,
+                                        pick_stream(ctx, stream));
+    } catch (const std::bad_alloc &) {
+        set_error("mlpl_usac_essential_batch_dev: out of host memory");
         return MLPL_E_NOMEM;
     }
 }

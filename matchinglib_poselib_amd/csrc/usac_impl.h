@@ -72,22 +72,67 @@ __device__ __forceinline__ double usac_sampson(const double *m, double x1, doubl
     return r * r / (rxc * rxc + ryc * ryc + rx * rx + ry * ry);
 }
 
-__global__ void usac_pool_pack_kernel(const double *__restrict__ p1, const double *__restrict__ p2, const int32_t *__restrict__ pool, int n,
-                                      double4 *__restrict__ pts_pool) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+struct UsacPoolPackArgs {
+    KHdr hdr;
+    const double * p1;
+    const double * p2;
+    const int32_t * pool;
+    int n;
+    double4 * pts_pool;
+};
+__device__ __forceinline__ void usac_pool_pack_body(const UsacPoolPackArgs &A, const int vbx, const int vby) {
+    const double *__restrict__ p1 = A.p1;
+    const double *__restrict__ p2 = A.p2;
+    const int32_t *__restrict__ pool = A.pool;
+    const int n = A.n;
+    double4 *__restrict__ pts_pool = A.pts_pool;
+
+    const int j = vbx * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const int i = pool[j];
     pts_pool[j] = make_double4(p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
 }
+MLPL_HUB_KERNEL(HK_USAC_POOL_PACK, UsacPoolPackArgs, usac_pool_pack_body, 256);
 
 // One wave per (sample, solution slot).  out_* live in pinned, device-mapped host memory.
-__global__ __launch_bounds__(64) void usac_check_kernel(const double4 *__restrict__ pts_pool, int n, int words, const double *__restrict__ p1,
-                                                        const double *__restrict__ p2, const int32_t *__restrict__ samples, int B,
-                                                        const double *__restrict__ E_tab, const int32_t *__restrict__ n_models, UsacGeom g,
-                                                        double thr, int32_t *__restrict__ out_nm, double *__restrict__ out_key,
-                                                        int32_t *__restrict__ out_valid, unsigned long long *__restrict__ out_rows,
-                                                        double *__restrict__ out_E) {
-    const int b = blockIdx.x / 10, slot = blockIdx.x - b * 10;
+struct UsacCheckArgs {
+    KHdr hdr;
+    const double4 * pts_pool;
+    int n;
+    int words;
+    const double * p1;
+    const double * p2;
+    const int32_t * samples;
+    int B;
+    const double * E_tab;
+    const int32_t * n_models;
+    UsacGeom g;
+    double thr;
+    int32_t * out_nm;
+    double * out_key;
+    int32_t * out_valid;
+    unsigned long long * out_rows;
+    double * out_E;
+};
+__device__ __forceinline__ void usac_check_body(const UsacCheckArgs &A, const int vbx, const int vby) {
+    const double4 *__restrict__ pts_pool = A.pts_pool;
+    const int n = A.n;
+    const int words = A.words;
+    const double *__restrict__ p1 = A.p1;
+    const double *__restrict__ p2 = A.p2;
+    const int32_t *__restrict__ samples = A.samples;
+    const int B = A.B;
+    const double *__restrict__ E_tab = A.E_tab;
+    const int32_t *__restrict__ n_models = A.n_models;
+    const UsacGeom g = A.g;
+    const double thr = A.thr;
+    int32_t *__restrict__ out_nm = A.out_nm;
+    double *__restrict__ out_key = A.out_key;
+    int32_t *__restrict__ out_valid = A.out_valid;
+    unsigned long long *__restrict__ out_rows = A.out_rows;
+    double *__restrict__ out_E = A.out_E;
+
+    const int b = vbx / 10, slot = vbx - b * 10;
     const int lane = threadIdx.x;
     if (b >= B) return;
     const int nm = min(n_models[b], 10);
@@ -145,6 +190,7 @@ __global__ __launch_bounds__(64) void usac_check_kernel(const double4 *__restric
         if (lane == 0) row[w] = bal;
     }
 }
+MLPL_HUB_KERNEL(HK_USAC_CHECK, UsacCheckArgs, usac_check_body, 64);
 
 
 // ---- degeneracy tests: per-correspondence errors of a rotation / of "no motion" / of a translation / of an upgrade candidate ---------
@@ -163,12 +209,28 @@ __device__ __forceinline__ void dg_bearing(double x, double y, double *f) {
 __device__ __forceinline__ double dg_dot(const double *a, const double *b) { return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); }
 // One workgroup per model: bit rows in evaluation-pool order, rows[(model * 2 + 0) * words ..] = error < thr_pose (kinds 0..2) or
 // Sampson error < thr_inl (kind 3); rows[(model * 2 + 1) * words ..] = error < thr_inl (kind 2 only: what storeSolution reads).
-__global__ __launch_bounds__(256) void usac_degen_rows_kernel(const double4 *__restrict__ pts_pool, int n, int words,
-                                                              const UsacDgModel *__restrict__ models, double thr_pose, double thr_inl,
-                                                              unsigned long long *__restrict__ rows) {
-    const UsacDgModel M = models[blockIdx.x];
+struct UsacDgRowsArgs {
+    KHdr hdr;
+    const double4 * pts_pool;
+    int n;
+    int words;
+    const UsacDgModel * models;
+    double thr_pose;
+    double thr_inl;
+    unsigned long long * rows;
+};
+__device__ __forceinline__ void usac_degen_rows_body(const UsacDgRowsArgs &A, const int vbx, const int vby) {
+    const double4 *__restrict__ pts_pool = A.pts_pool;
+    const int n = A.n;
+    const int words = A.words;
+    const UsacDgModel *__restrict__ models = A.models;
+    const double thr_pose = A.thr_pose;
+    const double thr_inl = A.thr_inl;
+    unsigned long long *__restrict__ rows = A.rows;
+
+    const UsacDgModel M = models[vbx];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long *row_a = rows + ((size_t)blockIdx.x * 2) * words, *row_b = row_a + words;
+    unsigned long long *row_a = rows + ((size_t)vbx * 2) * words, *row_b = row_a + words;
     for (int w = wave; w < words; w += 4) {
         const int j = w * 64 + lane;
         bool in_a = false, in_b = false;
@@ -212,6 +274,7 @@ __global__ __launch_bounds__(256) void usac_degen_rows_kernel(const double4 *__r
         if (lane == 0) row_a[w] = ba, row_b[w] = bb;
     }
 }
+MLPL_HUB_KERNEL(HK_USAC_DG_ROWS, UsacDgRowsArgs, usac_degen_rows_body, 256);
 
 // ---- local optimisation ---------------------------------------------------------------------------------------------------------------
 struct UsacLoOut {          // per repetition, pinned host memory; followed by kUsacLoEvals bit rows of `words` words
@@ -336,12 +399,39 @@ __device__ __forceinline__ void usac_cov_add(double *acc, const double *a, const
         for (int y = x; y < 9; ++y) acc[t++] += q[x] * q[y];
 }
 
-__global__ __launch_bounds__(kUsacLoThreads) void usac_lo_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
-                                                                 const double4 *__restrict__ pts_pool, int n, int words, UsacGeom g, double thr,
-                                                                 double lo_mult, const UsacLoIn *__restrict__ in, char *__restrict__ out_base,
-                                                                 size_t out_stride, double *__restrict__ err_scratch, int warm_start) {
+struct UsacLoArgs {
+    KHdr hdr;
+    const double * p1;
+    const double * p2;
+    const double4 * pts_pool;
+    int n;
+    int words;
+    UsacGeom g;
+    double thr;
+    double lo_mult;
+    const UsacLoIn * in;
+    char * out_base;
+    size_t out_stride;
+    double * err_scratch;
+    int warm_start;
+};
+__device__ __forceinline__ void usac_lo_body(const UsacLoArgs &A, const int vbx, const int vby) {
+    const double *__restrict__ p1 = A.p1;
+    const double *__restrict__ p2 = A.p2;
+    const double4 *__restrict__ pts_pool = A.pts_pool;
+    const int n = A.n;
+    const int words = A.words;
+    const UsacGeom g = A.g;
+    const double thr = A.thr;
+    const double lo_mult = A.lo_mult;
+    const UsacLoIn *__restrict__ in = A.in;
+    char *__restrict__ out_base = A.out_base;
+    const size_t out_stride = A.out_stride;
+    double *__restrict__ err_scratch = A.err_scratch;
+    const int warm_start = A.warm_start;
+
     __shared__ UsacLoLds L;
-    const int tid = threadIdx.x, rep = blockIdx.x;
+    const int tid = threadIdx.x, rep = vbx;
     const UsacLoIn &I = in[rep];
     UsacLoOut *O = reinterpret_cast<UsacLoOut *>(out_base + (size_t)rep * out_stride);
     unsigned long long *rows = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(O) + sizeof(UsacLoOut));
@@ -491,6 +581,7 @@ __global__ __launch_bounds__(kUsacLoThreads) void usac_lo_kernel(const double *_
     }
     if (tid == 0) O->evals = eval, O->sweeps = L.sweeps;
 }
+MLPL_HUB_KERNEL(HK_USAC_LO, UsacLoArgs, usac_lo_body, kUsacLoThreads);
 
 // ---- local optimisation with the refinements of the 5-point family (poselib::RefineAlg REF_STEWENIUS(_WEIGHTS), REF_NISTER(_WEIGHTS)) ------
 // EssentialMatEstimator.h generateRefinedModel :640-850, findWeights :2404-2428; P/source/usac/utils/weightingEssential.cpp:56-206
@@ -553,11 +644,29 @@ __device__ __forceinline__ double usac5_weight(const double *E, double x1, doubl
 
 // grid = chains, 64 threads.  in[c].start_step < 0: a fresh chain -- Gram matrix of its 14-point sample into part 0; else the chain
 // resumes with in[c].E as its model.
-__global__ __launch_bounds__(64) void usac5_begin_kernel(const double *__restrict__ p1, const double *__restrict__ p2, const UsacLoIn *__restrict__ in,
-                                                         UsacLo5State *__restrict__ st, double *__restrict__ gram_part, size_t part_stride,
-                                                         char *__restrict__ out_base, size_t out_stride) {
+struct Usac5BeginArgs {
+    KHdr hdr;
+    const double * p1;
+    const double * p2;
+    const UsacLoIn * in;
+    UsacLo5State * st;
+    double * gram_part;
+    size_t part_stride;
+    char * out_base;
+    size_t out_stride;
+};
+__device__ __forceinline__ void usac5_begin_body(const Usac5BeginArgs &A, const int vbx, const int vby) {
+    const double *__restrict__ p1 = A.p1;
+    const double *__restrict__ p2 = A.p2;
+    const UsacLoIn *__restrict__ in = A.in;
+    UsacLo5State *__restrict__ st = A.st;
+    double *__restrict__ gram_part = A.gram_part;
+    const size_t part_stride = A.part_stride;
+    char *__restrict__ out_base = A.out_base;
+    const size_t out_stride = A.out_stride;
+
     __shared__ double q[kUsacLoSample][9];
-    const int c = blockIdx.x, lane = threadIdx.x;
+    const int c = vbx, lane = threadIdx.x;
     const UsacLoIn &I = in[c];
     UsacLo5State &S = st[c];
     UsacLo5Out *O = reinterpret_cast<UsacLo5Out *>(out_base + (size_t)c * out_stride);
@@ -584,6 +693,7 @@ __global__ __launch_bounds__(64) void usac5_begin_kernel(const double *__restric
         gram_part[(size_t)c * part_stride + lane] = sacc;
     }
 }
+MLPL_HUB_KERNEL(HK_USAC5_BEGIN, Usac5BeginArgs, usac5_begin_body, 64);
 
 __device__ __forceinline__ double usac5_wave_min(double v) {
 #pragma unroll
@@ -648,11 +758,34 @@ __device__ __forceinline__ double usac5_key(const double *E) {  // ascending E(0
 // `fit_eval` = index of the evaluation this fit follows, -1 for the sample's fit; `ends_chain`: a fit without a solution ends the
 // repetition (the sample's fit and the refit on the 2 x threshold set; in a re-weighted step the model stays).  The solutions and the
 // choice are kept per (chain, fit) for usac5_recheck_kernel.
-__global__ __launch_bounds__(64) void usac5_choose_kernel(const double *__restrict__ p1, const double *__restrict__ p2, int n,
-                                                          const uint8_t *__restrict__ flags, const double *__restrict__ E_tab,
-                                                          const int32_t *__restrict__ n_models, UsacLo5State *__restrict__ st,
-                                                          char *__restrict__ out_base, size_t out_stride, int fit_eval, int ends_chain) {
-    const int c = blockIdx.x, lane = threadIdx.x;
+struct Usac5ChooseArgs {
+    KHdr hdr;
+    const double * p1;
+    const double * p2;
+    int n;
+    const uint8_t * flags;
+    const double * E_tab;
+    const int32_t * n_models;
+    UsacLo5State * st;
+    char * out_base;
+    size_t out_stride;
+    int fit_eval;
+    int ends_chain;
+};
+__device__ __forceinline__ void usac5_choose_body(const Usac5ChooseArgs &A, const int vbx, const int vby) {
+    const double *__restrict__ p1 = A.p1;
+    const double *__restrict__ p2 = A.p2;
+    const int n = A.n;
+    const uint8_t *__restrict__ flags = A.flags;
+    const double *__restrict__ E_tab = A.E_tab;
+    const int32_t *__restrict__ n_models = A.n_models;
+    UsacLo5State *__restrict__ st = A.st;
+    char *__restrict__ out_base = A.out_base;
+    const size_t out_stride = A.out_stride;
+    const int fit_eval = A.fit_eval;
+    const int ends_chain = A.ends_chain;
+
+    const int c = vbx, lane = threadIdx.x;
     UsacLo5State &S = st[c];
     UsacLo5Out *O = reinterpret_cast<UsacLo5Out *>(out_base + (size_t)c * out_stride);
     const int fit = fit_eval + 1;
@@ -692,13 +825,28 @@ __global__ __launch_bounds__(64) void usac5_choose_kernel(const double *__restri
         else O->fit_state[fit_eval] = 1;
     }
 }
+MLPL_HUB_KERNEL(HK_USAC5_CHOOSE, Usac5ChooseArgs, usac5_choose_body, 64);
 
 // grid = (kUsacLoEvals fits, chains), 64 threads.  The inlier flags of the best model have changed (an earlier repetition stored a new
 // best): would any choice of this chain have come out differently?  first_diff[c] = the first such fit, else kUsacLoEvals.
-__global__ __launch_bounds__(64) void usac5_recheck_kernel(const double *__restrict__ p1, const double *__restrict__ p2, int n,
-                                                           const uint8_t *__restrict__ flags, const UsacLo5State *__restrict__ st,
-                                                           int32_t *__restrict__ first_diff) {
-    const int fit = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+struct Usac5RecheckArgs {
+    KHdr hdr;
+    const double * p1;
+    const double * p2;
+    int n;
+    const uint8_t * flags;
+    const UsacLo5State * st;
+    int32_t * first_diff;
+};
+__device__ __forceinline__ void usac5_recheck_body(const Usac5RecheckArgs &A, const int vbx, const int vby) {
+    const double *__restrict__ p1 = A.p1;
+    const double *__restrict__ p2 = A.p2;
+    const int n = A.n;
+    const uint8_t *__restrict__ flags = A.flags;
+    const UsacLo5State *__restrict__ st = A.st;
+    int32_t *__restrict__ first_diff = A.first_diff;
+
+    const int fit = vbx, c = vby, lane = threadIdx.x;
     const UsacLo5State &S = st[c];
     const int nm = S.hist_nm[fit];
     if (nm <= 1) return;
@@ -712,15 +860,43 @@ __global__ __launch_bounds__(64) void usac5_recheck_kernel(const double *__restr
     const int take = usac5_pick(E, key, nm, lane, p1, p2, n, flags);
     if (lane == 0 && take != S.hist_take[fit]) atomicMin(&first_diff[c], fit);
 }
+MLPL_HUB_KERNEL(HK_USAC5_RECHECK, Usac5RecheckArgs, usac5_recheck_body, 64);
 
 // grid = (blocks, chains), 256 threads.  Evaluation `e` of the chain's model: errors in point order, per-block counts of the inliers and of
 // the members of {err < limit}, the inlier bit row in pool order.
-__global__ __launch_bounds__(kLo5Threads) void usac5_eval_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
-                                                                 const double4 *__restrict__ pts_pool, int n, int words, int rows_per_block,
-                                                                 double thr, double limit, UsacLo5State *__restrict__ st,
-                                                                 double *__restrict__ err_all, char *__restrict__ out_base, size_t out_stride, int e) {
+struct Usac5EvalArgs {
+    KHdr hdr;
+    const double * p1;
+    const double * p2;
+    const double4 * pts_pool;
+    int n;
+    int words;
+    int rows_per_block;
+    double thr;
+    double limit;
+    UsacLo5State * st;
+    double * err_all;
+    char * out_base;
+    size_t out_stride;
+    int e;
+};
+__device__ __forceinline__ void usac5_eval_body(const Usac5EvalArgs &A, const int vbx, const int vby) {
+    const double *__restrict__ p1 = A.p1;
+    const double *__restrict__ p2 = A.p2;
+    const double4 *__restrict__ pts_pool = A.pts_pool;
+    const int n = A.n;
+    const int words = A.words;
+    const int rows_per_block = A.rows_per_block;
+    const double thr = A.thr;
+    const double limit = A.limit;
+    UsacLo5State *__restrict__ st = A.st;
+    double *__restrict__ err_all = A.err_all;
+    char *__restrict__ out_base = A.out_base;
+    const size_t out_stride = A.out_stride;
+    const int e = A.e;
+
     __shared__ int red[2][kLo5Threads / 64];
-    const int c = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = vby, b = vbx, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     UsacLo5State &S = st[c];
     if (!S.alive) return;
     UsacLo5Out *O = reinterpret_cast<UsacLo5Out *>(out_base + (size_t)c * out_stride);
@@ -754,7 +930,7 @@ __global__ __launch_bounds__(kLo5Threads) void usac5_eval_kernel(const double *_
         }
     }
     unsigned long long *row = rows + (size_t)e * words;
-    for (int w = b * (kLo5Threads / 64) + wave; w < words; w += gridDim.x * (kLo5Threads / 64)) {
+    for (int w = b * (kLo5Threads / 64) + wave; w < words; w += A.hdr.gx * (kLo5Threads / 64)) {
         const int j = w * 64 + lane;
         bool in = false;
         if (j < n) {
@@ -765,18 +941,49 @@ __global__ __launch_bounds__(kLo5Threads) void usac5_eval_kernel(const double *_
         if (lane == 0) row[w] = bal;
     }
 }
+MLPL_HUB_KERNEL(HK_USAC5_EVAL, Usac5EvalArgs, usac5_eval_body, kLo5Threads);
 
 // grid = (blocks, chains), 256 threads.  The fit set of this step: the first K members (ascending index) of {err < limit}, K = n for the
 // refit after the first evaluation (findInliers' own count), the inlier count of the evaluation afterwards (USAC.h:1027-1040).  Each
 // block adds the (weighted) rows of its members into its own 45-value part; a block without members writes zeros.
-__global__ __launch_bounds__(kLo5Threads) void usac5_gram_kernel(const double *__restrict__ p1, const double *__restrict__ p2, int n,
-                                                                 int rows_per_block, double limit, int first_refit, int weighted, double th_ph,
-                                                                 UsacLo5State *__restrict__ st, const double *__restrict__ err_all,
-                                                                 double *__restrict__ gram_part, size_t part_stride, char *__restrict__ out_base,
-                                                                 size_t out_stride, int e) {
+struct Usac5GramArgs {
+    KHdr hdr;
+    const double * p1;
+    const double * p2;
+    int n;
+    int rows_per_block;
+    double limit;
+    int first_refit;
+    int weighted;
+    double th_ph;
+    UsacLo5State * st;
+    const double * err_all;
+    double * gram_part;
+    size_t part_stride;
+    char * out_base;
+    size_t out_stride;
+    int e;
+};
+__device__ __forceinline__ void usac5_gram_body(const Usac5GramArgs &A, const int vbx, const int vby) {
+    const double *__restrict__ p1 = A.p1;
+    const double *__restrict__ p2 = A.p2;
+    const int n = A.n;
+    const int rows_per_block = A.rows_per_block;
+    const double limit = A.limit;
+    const int first_refit = A.first_refit;
+    const int weighted = A.weighted;
+    const double th_ph = A.th_ph;
+    UsacLo5State *__restrict__ st = A.st;
+    const double *__restrict__ err_all = A.err_all;
+    double *__restrict__ gram_part = A.gram_part;
+    const size_t part_stride = A.part_stride;
+    char *__restrict__ out_base = A.out_base;
+    const size_t out_stride = A.out_stride;
+    const int e = A.e;
+
     __shared__ int cnt[16 * (kLo5Threads / 64) + 1];
     __shared__ double red[kLo5Threads / 64][45];
-    const int c = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = vby, b = vbx, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kWaves = kLo5Threads / 64;
     UsacLo5State &S = st[c];
     if (!S.alive) {
@@ -786,7 +993,7 @@ __global__ __launch_bounds__(kLo5Threads) void usac5_gram_kernel(const double *_
     UsacLo5Out *O = reinterpret_cast<UsacLo5Out *>(out_base + (size_t)c * out_stride);
     const double *err = err_all + (size_t)c * n;
     int total = 0, K = 0, before = 0;
-    for (int k = 0; k < (int)gridDim.x; ++k) {
+    for (int k = 0; k < A.hdr.gx; ++k) {
         const int m = S.cnt_mem[k];
         total += m, K += S.cnt_inl[k];
         before += k < b ? m : 0;
@@ -860,6 +1067,7 @@ __global__ __launch_bounds__(kLo5Threads) void usac5_gram_kernel(const double *_
     __syncthreads();
     if (tid < 45) part[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
+MLPL_HUB_KERNEL(HK_USAC5_GRAM, Usac5GramArgs, usac5_gram_body, kLo5Threads);
 
 struct UsacWald {
     double epsilon, delta, A;
@@ -891,9 +1099,24 @@ unsigned usac_to_uint(double v) {  // (unsigned int) of a double as x86-64 compi
     return (unsigned)(unsigned long long)w;
 }
 
+inline std::mutex &usac_prosac_tab_mutex() {
+    static std::mutex m;
+    return m;
+}
+
+struct UsacBufs {  // a run's device / pinned buffers when the caller provides them (batched runs: one slice per run, usac_batch.h)
+    char *dev = nullptr;      // device block of dev_bytes(n, refine)
+    char *pin = nullptr;      // pinned, device-mapped block of pin_bytes(...)
+    char *pin_dev = nullptr;  // its device alias
+};
+
 struct UsacRun {
     mlpl_ctx *ctx;
     hipStream_t s;
+    Launcher L;                  // launches now (a run alone) or records for the hub (a run of a batch)
+    const UsacBufs *bufs = nullptr;
+    double *trace_buf = nullptr;  // decision trace of this run (batched runs: one buffer per run; else the context's)
+    int trace_cap = 0, trace_len = 0;
     const double *d_p1, *d_p2;
     std::vector<double> hp1, hp2;  // host copies (sample validation, normalisation)
     unsigned n = 0, max_hyp = 50000;
@@ -911,7 +1134,6 @@ struct UsacRun {
     int words = 0;
     // device / pinned buffers
     double4 *d_pts_pool = nullptr;
-    int32_t *d_pool = nullptr;
     int32_t *h_smp = nullptr, *d_smp = nullptr;  // pinned + its device alias
     char *h_out = nullptr, *h_out_dev = nullptr;
     PolyRec *d_recs = nullptr;
@@ -923,6 +1145,7 @@ struct UsacRun {
     UsacLo5State *d_lo5_state = nullptr;
     double *d_lo5_gram = nullptr;
     uint8_t *d_lo5_flags = nullptr, *h_lo5_flags = nullptr;
+    const uint8_t *d_lo5_flags_src = nullptr;  // device alias of h_lo5_flags
     int32_t *h_lo5_diff = nullptr, *d_lo5_diff = nullptr;
     int lo5_blocks = 1, lo5_rows = 1;
     int batch_cap = kUsacBatch;
@@ -944,14 +1167,14 @@ struct UsacRun {
     long long stats[8] = {0};  // [0] batches, [1] samples solved, [2] samples consumed, [3] LO launches, [4] LO resumes
 
     void emit(double type, const double *v, int nv) {
-        if (!ctx->usac_trace) return;
-        if (ctx->usac_trace_len < ctx->usac_trace_cap) {
-            double *r = ctx->usac_trace + (size_t)ctx->usac_trace_len * 16;
+        if (!trace_buf) return;
+        if (trace_len < trace_cap) {
+            double *r = trace_buf + (size_t)trace_len * 16;
             std::memset(r, 0, 128);
             r[0] = type;
             for (int i = 0; i < nv && i < 15; ++i) r[1 + i] = v[i];
         }
-        ctx->usac_trace_len++;
+        trace_len++;
     }
 
     static void mul3(double *c, const double *a, const double *b) {
@@ -1020,70 +1243,90 @@ struct UsacRun {
         flags.assign(n, 0);
         words = (int)((n + 63) / 64);
         best_bits.assign(words, 0);
-        // buffers
-        batch_cap = std::max(8, std::min(kUsacBatch, (int)((size_t)(6u << 20) / ((size_t)10 * words * 8))));
-        void *p;
-        int rc;
-        if ((rc = ws_get(ctx, WS_AUX3, (size_t)n * sizeof(double4) + (size_t)n * 4 + 64, &p))) return rc;
-        d_pts_pool = (double4 *)p;
-        d_pool = (int32_t *)(d_pts_pool + n);
-        if ((rc = ws_get(ctx, WS_PARTIAL, (size_t)batch_cap * sizeof(PolyRec), &p))) return rc;
-        d_recs = (PolyRec *)p;
-        if ((rc = ws_get(ctx, WS_AUX5, (size_t)batch_cap * 90 * 8 + (size_t)batch_cap * 4 + 64, &p))) return rc;
-        d_Etab = (double *)p;
-        d_nm = (int32_t *)(d_Etab + (size_t)batch_cap * 90);
-        if ((rc = ws_get(ctx, WS_AUX6, (size_t)kUsacLoReps * n * 8 + 64, &p))) return rc;
-        d_err = (double *)p;
-        const size_t out_bytes = std::max(batch_out_bytes(batch_cap), (size_t)kUsacLoReps * std::max(lo_out_stride(), lo5_out_stride()));
-        const size_t smp_bytes = (size_t)batch_cap * 5 * 4, lo_in_bytes = (size_t)kUsacLoReps * sizeof(UsacLoIn);
-        const size_t lo5_pin_bytes = refine ? (((size_t)n + 63) & ~(size_t)63) + 64 : 0;  // flags staging + the recheck verdicts
-        if (refine) {
-            const int rows = (int)((n + kLo5Threads - 1) / kLo5Threads);
-            lo5_blocks = std::max(1, std::min(kLo5MaxBlocks, rows));
-            lo5_rows = (rows + lo5_blocks - 1) / lo5_blocks;
-            lo5_blocks = (rows + lo5_rows - 1) / lo5_rows;
-            const size_t st_bytes = ((size_t)kUsacLoReps * sizeof(UsacLo5State) + 255) & ~(size_t)255;
-            const size_t gram_bytes = ((size_t)kUsacLoReps * kLo5MaxBlocks * 45 * 8 + 255) & ~(size_t)255;
-            if ((rc = ws_get(ctx, WS_AUX7, st_bytes + gram_bytes + (size_t)n + 256, &p))) return rc;
-            d_lo5_state = (UsacLo5State *)p;
-            d_lo5_gram = (double *)((char *)p + st_bytes);
-            d_lo5_flags = (uint8_t *)p + st_bytes + gram_bytes;
+        // buffers: one device block and one pinned, device-mapped block, laid out by usac_layout (a run alone takes them from the
+        // context, a run of a batch gets its slices from the batch driver)
+        const UsacLayout Y = usac_layout(n, refine, dg_on);
+        batch_cap = Y.batch_cap, dg_cap = Y.dg_cap, lo5_blocks = Y.lo5_blocks, lo5_rows = Y.lo5_rows;
+        char *dev, *pin, *pin_dev;
+        if (bufs) {
+            dev = bufs->dev, pin = bufs->pin, pin_dev = bufs->pin_dev;
+        } else {
+            void *p;
+            int rc;
+            if ((rc = ws_get(ctx, WS_AUX3, Y.dev_total, &p))) return rc;
+            dev = (char *)p;
+            if ((rc = pinned_get(ctx, Y.pin_total, &p))) return rc;
+            pin = (char *)p;
+            void *alias = nullptr;
+            MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, pin, 0));
+            pin_dev = (char *)alias;
         }
-        dg_cap = dg_on ? (int)std::max<size_t>(10, std::min<size_t>(128, out_bytes / ((size_t)2 * words * 8))) : 0;
-        const size_t dg_bytes = (size_t)dg_cap * sizeof(UsacDgModel);
-        const size_t pool_bytes = ((size_t)n * 4 + 63) & ~(size_t)63;
-        if ((rc = pinned_get(ctx, out_bytes + smp_bytes + lo_in_bytes + pool_bytes + dg_bytes + lo5_pin_bytes + 512, &p))) return rc;
-        h_out = (char *)p;
-        h_smp = (int32_t *)(h_out + ((out_bytes + 63) & ~(size_t)63));
-        h_lo_in = (UsacLoIn *)((char *)h_smp + ((smp_bytes + 63) & ~(size_t)63));
-        int32_t *h_pool = (int32_t *)((char *)h_lo_in + ((lo_in_bytes + 63) & ~(size_t)63));
-        void *alias = nullptr;
-        if (refine) {
-            h_lo5_flags = (uint8_t *)h_pool + pool_bytes + ((dg_bytes + 63) & ~(size_t)63);
-            h_lo5_diff = (int32_t *)(h_lo5_flags + (((size_t)n + 63) & ~(size_t)63));
-            MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, h_lo5_diff, 0));
-            d_lo5_diff = (int32_t *)alias;
-        }
+        d_pts_pool = (double4 *)(dev + Y.d_pts);
+        d_recs = (PolyRec *)(dev + Y.d_recs);
+        d_Etab = (double *)(dev + Y.d_Etab);
+        d_nm = (int32_t *)(dev + Y.d_nm);
+        d_err = (double *)(dev + Y.d_err);
+        d_lo5_state = (UsacLo5State *)(dev + Y.d_lo5_state);
+        d_lo5_gram = (double *)(dev + Y.d_lo5_gram);
+        d_lo5_flags = (uint8_t *)(dev + Y.d_lo5_flags);
+        h_out = pin + Y.p_out, h_out_dev = pin_dev + Y.p_out;
+        h_smp = (int32_t *)(pin + Y.p_smp), d_smp = (int32_t *)(pin_dev + Y.p_smp);
+        h_lo_in = (UsacLoIn *)(pin + Y.p_lo_in), d_lo_in = (UsacLoIn *)(pin_dev + Y.p_lo_in);
+        int32_t *h_pool = (int32_t *)(pin + Y.p_pool);
+        h_dg = (UsacDgModel *)(pin + Y.p_dg), d_dg = (UsacDgModel *)(pin_dev + Y.p_dg);
+        h_lo5_flags = (uint8_t *)(pin + Y.p_flags), d_lo5_flags_src = (const uint8_t *)(pin_dev + Y.p_flags);
+        h_lo5_diff = (int32_t *)(pin + Y.p_diff), d_lo5_diff = (int32_t *)(pin_dev + Y.p_diff);
         if (dg_on) {
-            h_dg = (UsacDgModel *)((char *)h_pool + pool_bytes);
-            MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, h_dg, 0));
-            d_dg = (UsacDgModel *)alias;
             pool_pos.resize(n);
             for (unsigned j = 0; j < n; ++j) pool_pos[pool[j]] = j;
             dg_in_rot.assign(n, 0), dg_out_rot.assign(n, 0), dg_in_nomot.assign(n, 0), dg_out_nomot.assign(n, 0);
         }
-        MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, h_out, 0));
-        h_out_dev = (char *)alias;
-        MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, h_smp, 0));
-        d_smp = (int32_t *)alias;
-        MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, h_lo_in, 0));
-        d_lo_in = (UsacLoIn *)alias;
-        // the evaluation pool on the device: the permutation itself and the points gathered in its order
-        for (unsigned i = 0; i < n; ++i) h_pool[i] = (int32_t)pool[i];  // pinned: the copy is stream-ordered, nothing to wait for
-        MLPL_HIP_TRY(hipMemcpyAsync(d_pool, h_pool, (size_t)n * 4, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(usac_pool_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_p1, d_p2, (const int32_t *)d_pool, (int)n, d_pts_pool);
-        MLPL_HIP_TRY(hipGetLastError());
+        // the evaluation pool: the points gathered in its order (the kernel reads the permutation from the mapped block)
+        for (unsigned i = 0; i < n; ++i) h_pool[i] = (int32_t)pool[i];
+        UsacPoolPackArgs pa{{(int)((n + 255) / 256), 1}, d_p1, d_p2, (const int32_t *)(pin_dev + Y.p_pool), (int)n, d_pts_pool};
+        L.launch(HK_USAC_POOL_PACK, pa);
         return MLPL_OK;
+    }
+    struct UsacLayout {
+        size_t d_pts, d_recs, d_Etab, d_nm, d_err, d_lo5_state, d_lo5_gram, d_lo5_flags, dev_total;
+        size_t p_out, p_smp, p_lo_in, p_pool, p_dg, p_flags, p_diff, pin_total;
+        int batch_cap, dg_cap, words, lo5_blocks, lo5_rows;
+    };
+    static UsacLayout usac_layout(unsigned n, int refine, bool dg) {
+        UsacLayout Y;
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const int words = (int)((n + 63) / 64);
+        Y.words = words;
+        Y.batch_cap = std::max(8, std::min(kUsacBatch, (int)((size_t)(6u << 20) / ((size_t)10 * words * 8))));
+        const int rows = (int)((n + kLo5Threads - 1) / kLo5Threads);
+        Y.lo5_blocks = std::max(1, std::min(kLo5MaxBlocks, rows));
+        Y.lo5_rows = std::max(1, (rows + Y.lo5_blocks - 1) / Y.lo5_blocks);
+        Y.lo5_blocks = std::max(1, (rows + Y.lo5_rows - 1) / Y.lo5_rows);
+        size_t o = 0;
+        Y.d_pts = o, o = up(o + (size_t)n * sizeof(double4));
+        Y.d_recs = o, o = up(o + (size_t)Y.batch_cap * sizeof(PolyRec));
+        Y.d_Etab = o, o = up(o + (size_t)Y.batch_cap * 90 * 8);
+        Y.d_nm = o, o = up(o + (size_t)Y.batch_cap * 4);
+        Y.d_err = o, o = up(o + (size_t)kUsacLoReps * n * 8);
+        Y.d_lo5_state = o, o = up(o + (refine ? (size_t)kUsacLoReps * sizeof(UsacLo5State) : 0));
+        Y.d_lo5_gram = o, o = up(o + (refine ? (size_t)kUsacLoReps * kLo5MaxBlocks * 45 * 8 : 0));
+        Y.d_lo5_flags = o, o = up(o + (refine ? (size_t)n + 16 : 0));
+        Y.dev_total = o + 256;
+        const size_t batch_out = (size_t)Y.batch_cap * 4 + 64 + (size_t)Y.batch_cap * 10 * (8 + 4) + 64 + (size_t)Y.batch_cap * 10 * words * 8 + 64 + (size_t)Y.batch_cap * 720;
+        const size_t lo_stride = (sizeof(UsacLoOut) + (size_t)kUsacLoEvals * words * 8 + 63) & ~(size_t)63;
+        const size_t lo5_stride = (sizeof(UsacLo5Out) + (size_t)kUsacLoEvals * words * 8 + 63) & ~(size_t)63;
+        const size_t out_bytes = std::max(batch_out, (size_t)kUsacLoReps * std::max(lo_stride, lo5_stride));
+        Y.dg_cap = dg ? (int)std::max<size_t>(10, std::min<size_t>(128, out_bytes / ((size_t)2 * words * 8))) : 0;
+        o = 0;
+        Y.p_out = o, o = up(o + out_bytes);
+        Y.p_smp = o, o = up(o + (size_t)Y.batch_cap * 5 * 4);
+        Y.p_lo_in = o, o = up(o + (size_t)kUsacLoReps * sizeof(UsacLoIn));
+        Y.p_pool = o, o = up(o + (size_t)n * 4);
+        Y.p_dg = o, o = up(o + (size_t)Y.dg_cap * sizeof(UsacDgModel));
+        Y.p_flags = o, o = up(o + (size_t)n + 16);   // the inlier flags of the best model (5-point refinements) / the final mask on its way to the device
+        Y.p_diff = o, o = up(o + 64);
+        Y.pin_total = o + 256;
+        return Y;
     }
     size_t batch_out_bytes(int B) const { return (size_t)B * 4 + 64 + (size_t)B * 10 * (8 + 4) + 64 + (size_t)B * 10 * words * 8 + 64 + (size_t)B * 720; }
     size_t lo_out_stride() const { return (sizeof(UsacLoOut) + (size_t)kUsacLoEvals * words * 8 + 63) & ~(size_t)63; }
@@ -1123,6 +1366,7 @@ struct UsacRun {
         // Entry nn of the table depends on (nn, beta, confidence) only: the context keeps the last table and a call with the same two
         // parameters (ConfigUSAC::noAutomaticProsacParamters: beta stays 0.09) copies it -- the same numbers, half a millisecond less.
         const unsigned top = std::min(n, 1001u);
+        std::lock_guard<std::mutex> tab_lock(usac_prosac_tab_mutex());  // the runs of a batch share the context's table
         if (ctx->usac_prosac_tab && ctx->usac_prosac_tab_top >= top && ctx->usac_prosac_tab_beta == prosac_beta &&
             ctx->usac_prosac_tab_conf == prosac_non_rand_conf) {
             for (unsigned nn = 6; nn <= top; ++nn) non_random[nn - 1] = ctx->usac_prosac_tab[nn - 1];
@@ -1311,14 +1555,12 @@ struct UsacRun {
         double *o_key = (double *)(h_out_dev + off_key);
         unsigned long long *o_rows = (unsigned long long *)(h_out_dev + off_rows);
         const size_t off_E = (off_rows + (size_t)B * 10 * words * 8 + 63) & ~(size_t)63;
-        launch_solve5pt(ctx, B, s, d_p1, d_p2, (const int32_t *)d_smp, 0, B, d_recs);
-        MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((B + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)d_recs, 0, B, d_Etab, d_nm,
-                          (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
-        hipLaunchKernelGGL(usac_check_kernel, dim3(B * 10), dim3(64), 0, s, (const double4 *)d_pts_pool, (int)n, words, d_p1, d_p2,
-                           (const int32_t *)d_smp, B, (const double *)d_Etab, (const int32_t *)d_nm, g, thr, o_nm, o_key, o_valid, o_rows,
-                           (double *)(h_out_dev + off_E));
-        MLPL_HIP_TRY(hipGetLastError());
-        MLPL_HIP_TRY(hipStreamSynchronize(s));
+        hub_launch_solver(L, ctx, B, d_p1, d_p2, (const int32_t *)d_smp, d_recs, d_Etab, d_nm);
+        UsacCheckArgs ca{{B * 10, 1}, (const double4 *)d_pts_pool, (int)n, words, d_p1, d_p2, (const int32_t *)d_smp, B, (const double *)d_Etab,
+                         (const int32_t *)d_nm, g, thr, o_nm, o_key, o_valid, o_rows, (double *)(h_out_dev + off_E)};
+        L.launch(HK_USAC_CHECK, ca);
+        int rcw;
+        if ((rcw = L.sync())) return rcw;
         const int32_t *h_nm = (const int32_t *)h_out, *h_valid = (const int32_t *)(h_out + off_valid);
         const double *h_key = (const double *)(h_out + off_key);
         const uint64_t *h_rows = (const uint64_t *)(h_out + off_rows);
@@ -1446,11 +1688,11 @@ struct UsacRun {
 
     // ---- local optimisation ----
     int launch_lo(int reps_from, int reps_to) {  // h_lo_in[reps_from .. reps_to) are filled
-        hipLaunchKernelGGL(usac_lo_kernel, dim3(reps_to - reps_from), dim3(kUsacLoThreads), 0, s, d_p1, d_p2, (const double4 *)d_pts_pool, (int)n,
-                           words, g, thr, lo_mult, (const UsacLoIn *)(d_lo_in + reps_from), h_out_dev + (size_t)reps_from * lo_out_stride(),
-                           lo_out_stride(), d_err + (size_t)reps_from * n, ctx->opt_usac_lo_warm_start);
-        MLPL_HIP_TRY(hipGetLastError());
-        MLPL_HIP_TRY(hipStreamSynchronize(s));
+        UsacLoArgs la{{reps_to - reps_from, 1}, d_p1, d_p2, (const double4 *)d_pts_pool, (int)n, words, g, thr, lo_mult, (const UsacLoIn *)(d_lo_in + reps_from),
+                      h_out_dev + (size_t)reps_from * lo_out_stride(), lo_out_stride(), d_err + (size_t)reps_from * n, ctx->opt_usac_lo_warm_start};
+        L.launch(HK_USAC_LO, la);
+        int rcw;
+        if ((rcw = L.sync())) return rcw;
         stats[3]++;
         return MLPL_OK;
     }
@@ -1538,13 +1780,15 @@ struct UsacRun {
         PolyRec *recs = d_recs + c0;
         int32_t *nm = d_nm + c0;
         const char *gate = reinterpret_cast<const char *>(st) + offsetof(UsacLo5State, step_fit);
-        hipLaunchKernelGGL(usac5_begin_kernel, dim3(C), dim3(64), 0, s, d_p1, d_p2, (const UsacLoIn *)(d_lo_in + c0), st, gram, part_stride, outp, stride);
+        Usac5BeginArgs ba{{C, 1}, d_p1, d_p2, (const UsacLoIn *)(d_lo_in + c0), st, gram, part_stride, outp, stride};
+        L.launch(HK_USAC5_BEGIN, ba);
         auto fit = [&](int nparts, int fit_eval, int ends) {
-            hipLaunchKernelGGL(refit_solve_kernel, dim3(C), dim3(64), 0, s, (const double *)gram, nparts, recs, part_stride, gate, sizeof(UsacLo5State));
-            MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((C + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)recs, 0, C, Etab, nm, (double *)nullptr,
-                              (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
-            hipLaunchKernelGGL(usac5_choose_kernel, dim3(C), dim3(64), 0, s, d_p1, d_p2, (int)n, (const uint8_t *)d_lo5_flags, (const double *)Etab,
-                               (const int32_t *)nm, st, outp, stride, fit_eval, ends);
+            RefitSolveArgs ra{{C, 1}, (const double *)gram, nparts, recs, part_stride, gate, sizeof(UsacLo5State)};
+            L.launch(HK_REFIT_SOLVE, ra);
+            RootsArgs ro{{(C + kHypPerWave - 1) / kHypPerWave, 1}, (const PolyRec *)recs, C, Etab, nm};
+            L.launch(ctx->opt_solver_polish ? HK_ROOTS_POLISH : HK_ROOTS_PLAIN, ro);
+            Usac5ChooseArgs ch{{C, 1}, d_p1, d_p2, (int)n, (const uint8_t *)d_lo5_flags, (const double *)Etab, (const int32_t *)nm, st, outp, stride, fit_eval, ends};
+            L.launch(HK_USAC5_CHOOSE, ch);
         };
         if (start_phase < 0) fit(1, -1, 1);
         const double step = (lo_mult * thr - thr) / kUsacLoSteps, th_ph = sqrt(thr) / 50.0;
@@ -1552,21 +1796,22 @@ struct UsacRun {
         for (int phase = start_phase; phase <= kUsacLoSteps; ++phase) {
             const int e = phase - start_phase;
             const double limit = phase < 0 ? lo_mult * thr : (phase < kUsacLoSteps ? (lo_mult * thr) - (phase + 1) * step : 0.0);
-            hipLaunchKernelGGL(usac5_eval_kernel, dim3(lo5_blocks, C), dim3(kLo5Threads), 0, s, d_p1, d_p2, (const double4 *)d_pts_pool, (int)n, words,
-                               lo5_rows, thr, limit, st, err, outp, stride, e);
+            Usac5EvalArgs ea{{lo5_blocks, C}, d_p1, d_p2, (const double4 *)d_pts_pool, (int)n, words, lo5_rows, thr, limit, st, err, outp, stride, e};
+            L.launch(HK_USAC5_EVAL, ea);
             if (phase == kUsacLoSteps) break;
-            hipLaunchKernelGGL(usac5_gram_kernel, dim3(lo5_blocks, C), dim3(kLo5Threads), 0, s, d_p1, d_p2, (int)n, lo5_rows, limit, phase < 0 ? 1 : 0,
-                               (phase >= 0 && weights) ? 1 : 0, th_ph, st, (const double *)err, gram, part_stride, outp, stride, e);
+            Usac5GramArgs ga{{lo5_blocks, C}, d_p1, d_p2, (int)n, lo5_rows, limit, phase < 0 ? 1 : 0, (phase >= 0 && weights) ? 1 : 0, th_ph, st,
+                             (const double *)err, gram, part_stride, outp, stride, e};
+            L.launch(HK_USAC5_GRAM, ga);
             fit(lo5_blocks, e, phase < 0 ? 1 : 0);
         }
-        MLPL_HIP_TRY(hipGetLastError());
-        MLPL_HIP_TRY(hipStreamSynchronize(s));
+        int rcw;
+        if ((rcw = L.sync())) return rcw;
         stats[3]++;
         return MLPL_OK;
     }
     int lo5_upload_flags() {  // the inlier flags of the best model, point order (pinned staging: the copy is stream-ordered)
         std::memcpy(h_lo5_flags, flags.data(), n);
-        MLPL_HIP_TRY(hipMemcpyAsync(d_lo5_flags, h_lo5_flags, n, hipMemcpyHostToDevice, s));
+        hub_copy_bytes(L, d_lo5_flags_src, d_lo5_flags, n);
         return MLPL_OK;
     }
 
@@ -1641,10 +1886,9 @@ struct UsacRun {
                     if ((rc = lo5_upload_flags())) return rc;
                     const int C = kUsacLoReps - (r + 1);
                     for (int k = 0; k < C; ++k) h_lo5_diff[k] = kUsacLoEvals;
-                    hipLaunchKernelGGL(usac5_recheck_kernel, dim3(kUsacLoEvals, C), dim3(64), 0, s, d_p1, d_p2, (int)n, (const uint8_t *)d_lo5_flags,
-                                       (const UsacLo5State *)(d_lo5_state + r + 1), d_lo5_diff);
-                    MLPL_HIP_TRY(hipGetLastError());
-                    MLPL_HIP_TRY(hipStreamSynchronize(s));
+                    Usac5RecheckArgs rk{{kUsacLoEvals, C}, d_p1, d_p2, (int)n, (const uint8_t *)d_lo5_flags, (const UsacLo5State *)(d_lo5_state + r + 1), d_lo5_diff};
+                    L.launch(HK_USAC5_RECHECK, rk);
+                    if ((rc = L.sync())) return rc;
                     stats[5]++;
                     for (int k = 0; k < C; ++k)
                         if (h_lo5_diff[k] < kUsacLoEvals) {
@@ -1691,10 +1935,10 @@ struct UsacRun {
     }
     // rows of h_dg[0 .. B): returns the pinned block, 2 rows of `words` words per model
     int dg_rows(int B, const uint64_t **rows) {
-        hipLaunchKernelGGL(usac_degen_rows_kernel, dim3(B), dim3(256), 0, s, (const double4 *)d_pts_pool, (int)n, words,
-                           (const UsacDgModel *)d_dg, dg_thr, thr, (unsigned long long *)h_out_dev);
-        MLPL_HIP_TRY(hipGetLastError());
-        MLPL_HIP_TRY(hipStreamSynchronize(s));
+        UsacDgRowsArgs da{{B, 1}, (const double4 *)d_pts_pool, (int)n, words, (const UsacDgModel *)d_dg, dg_thr, thr, (unsigned long long *)h_out_dev};
+        L.launch(HK_USAC_DG_ROWS, da);
+        int rcw;
+        if ((rcw = L.sync())) return rcw;
         *rows = (const uint64_t *)h_out;
         stats[5]++;
         return MLPL_OK;
@@ -2169,12 +2413,9 @@ struct UsacRun {
 
 }  // namespace
 
-// h_p1 / h_p2: the caller's host copies of the correspondences when it has them (else they are fetched); h_mask: host destination of the
-// inlier mask (d_mask is then not written)
-int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, const mlpl_usac_params *P, double *E, uint8_t *d_mask,
-                       double *results, hipStream_t s, const double *h_p1 = nullptr, const double *h_p2 = nullptr, uint8_t *h_mask = nullptr) {
-    UsacRun R;
-    R.ctx = ctx, R.s = s, R.d_p1 = d_p1, R.d_p2 = d_p2, R.n = (unsigned)n;
+// A run's configuration from the caller's parameters (estimateEssentialMatUsac, usac_estimations.cpp:283-470)
+static void usac_configure(UsacRun &R, mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, const mlpl_usac_params *P, hipStream_t s) {
+    R.ctx = ctx, R.s = s, R.L.s = s, R.d_p1 = d_p1, R.d_p2 = d_p2, R.n = (unsigned)n;
     R.max_hyp = (unsigned)P->max_hyp, R.conf = P->conf, R.thr = P->th * P->th;
     R.prosac = P->sorted_idx != nullptr;
     if (R.prosac) R.sorted_idx.assign(P->sorted_idx, P->sorted_idx + n);
@@ -2186,6 +2427,37 @@ int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, in
     R.dg_on = P->check_degeneracy != 0;
     R.dg_losac = R.dg_on && (P->check_degeneracy & 2) != 0;
     if (R.dg_on) R.dg_thr = 1.0 - std::cos(std::atan(P->th_pixels / P->focal_length));  // EssentialMatEstimator.h:349
+    R.rng.seed(P->seed);
+}
+static void usac_results(const UsacRun &R, bool ok, double *results) {
+    const double fin[12] = {ok ? 1.0 : 0.0,
+                            (double)R.hyp_count,
+                            (double)R.model_count,
+                            (double)R.rejected_samples,
+                            (double)R.rejected_models,
+                            (double)R.best,
+                            (double)R.points_verified,
+                            (double)R.num_lo,
+                            R.history.empty() ? 0.0 : R.history.back().delta,
+                            R.history.empty() ? 0.0 : R.history.back().epsilon,
+                            R.sprt_delta,
+                            R.sprt_epsilon};
+    std::memcpy(results, fin, sizeof(fin));
+}
+// the inlier mask of the run's model to device memory (through the run's pinned block; the run waits for the copy)
+static int usac_mask_to_device(UsacRun &R, uint8_t *d_mask) {
+    std::memcpy(R.h_lo5_flags, R.flags.data(), (size_t)R.n);
+    hub_copy_bytes(R.L, R.d_lo5_flags_src, d_mask, (size_t)R.n);
+    return R.L.sync();
+}
+
+// h_p1 / h_p2: the caller's host copies of the correspondences when it has them (else they are fetched); h_mask: host destination of the
+// inlier mask (d_mask is then not written)
+int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, const mlpl_usac_params *P, double *E, uint8_t *d_mask,
+                       double *results, hipStream_t s, const double *h_p1 = nullptr, const double *h_p2 = nullptr, uint8_t *h_mask = nullptr) {
+    UsacRun R;
+    usac_configure(R, ctx, d_p1, d_p2, n, P, s);
+    R.trace_buf = ctx->usac_trace, R.trace_cap = ctx->usac_trace_cap, R.trace_len = ctx->usac_trace_len;
     if (h_p1 && h_p2) {
         R.hp1.assign(h_p1, h_p1 + (size_t)2 * n), R.hp2.assign(h_p2, h_p2 + (size_t)2 * n);
     } else {
@@ -2194,13 +2466,13 @@ int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, in
         MLPL_HIP_TRY(hipMemcpyAsync(R.hp2.data(), d_p2, (size_t)n * 16, hipMemcpyDeviceToHost, s));
         MLPL_HIP_TRY(hipStreamSynchronize(s));
     }
-    R.rng.seed(P->seed);
     int rc;
     bool ok = false;
     if (n >= 5) {
         if ((rc = R.setup())) return rc;
         if ((rc = R.solve(&ok))) return rc;
     }
+    ctx->usac_trace_len = R.trace_len;
     std::memcpy(ctx->last_usac_stats, R.stats, sizeof(R.stats));
     {  // what estimateEssentialMatUsac reports of the degeneracy tests (usac_estimations.cpp:564-636, 689-726)
         double *d = ctx->last_usac_degen;
@@ -2217,21 +2489,7 @@ int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, in
             ctx->last_usac_flags_n = n;
         }
     }
-    if (results) {
-        const double fin[12] = {ok ? 1.0 : 0.0,
-                                (double)R.hyp_count,
-                                (double)R.model_count,
-                                (double)R.rejected_samples,
-                                (double)R.rejected_models,
-                                (double)R.best,
-                                (double)R.points_verified,
-                                (double)R.num_lo,
-                                R.history.empty() ? 0.0 : R.history.back().delta,
-                                R.history.empty() ? 0.0 : R.history.back().epsilon,
-                                R.sprt_delta,
-                                R.sprt_epsilon};
-        std::memcpy(results, fin, sizeof(fin));
-    }
+    if (results) usac_results(R, ok, results);
     if (!ok) {
         set_error("mlpl_usac_essential: too few correspondences (%d)", n);
         return MLPL_E_FAILED;
@@ -2240,11 +2498,117 @@ int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, in
     if (h_mask) {
         std::memcpy(h_mask, R.flags.data(), (size_t)n);
     } else if (d_mask) {
-        void *hp;
-        if ((rc = pinned_get(ctx, (size_t)n, &hp))) return rc;  // the batch blocks are no longer needed
-        std::memcpy(hp, R.flags.data(), (size_t)n);
-        MLPL_HIP_TRY(hipMemcpyAsync(d_mask, hp, (size_t)n, hipMemcpyHostToDevice, s));
-        MLPL_HIP_TRY(hipStreamSynchronize(s));
+        if ((rc = usac_mask_to_device(R, d_mask))) return rc;
+    }
+    return MLPL_OK;
+}
+
+// ---- a batch of USAC problems: every run a host thread, every launch merged over the runs (batch_hub.h) -----------------------------------
+// Problem b: correspondences d_p1 / d_p2 + b * stride * 2 (counts[b] of them), parameters params[b] (its seed, its PROSAC order, ...).
+// Outputs per problem: status (0, MLPL_E_FAILED = solve() refused, other < 0 = error), E, results[12], its inlier mask in d_masks + b *
+// stride (optional), degen (optional, 16 doubles as mlpl_usac_last_degeneracy), its decision trace (optional).  Every problem's outputs
+// are those of mlpl_usac_essential_dev on it alone: a run sees exactly its own launches' results, whatever ran beside them.
+constexpr int kUsacBatchRuns = 128;  // runs advancing together (threads of an internal batch)
+
+struct UsacBatchTrace {
+    double *buf;       // [B][cap][16]
+    int cap;
+    int32_t *lens;     // [B]
+};
+
+int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const double *d_p2, int stride, const int32_t *counts,
+                             const mlpl_usac_params *params, double *E, uint8_t *d_masks, double *results, int32_t *status, double *degen,
+                             const UsacBatchTrace *trace, hipStream_t s) {
+    if (B <= 0) return MLPL_OK;
+    int rc;
+    // the sequential parts read the correspondences on the host: one copy of the whole block through the batch's pinned memory
+    size_t max_dev = 0, max_pin = 0;
+    for (int b = 0; b < B; ++b) {
+        const UsacRun::UsacLayout Y = UsacRun::usac_layout((unsigned)std::max(counts[b], 1), params[b].refine, params[b].check_degeneracy != 0);
+        max_dev = std::max(max_dev, Y.dev_total), max_pin = std::max(max_pin, Y.pin_total);
+    }
+    const int runs_max = std::min(B, kUsacBatchRuns);
+    const size_t pts_bytes = ((size_t)B * stride * 16 + 255) & ~(size_t)255;
+    void *pblk, *dblk;
+    if ((rc = pinned_batch_get(ctx, 2 * pts_bytes + (size_t)runs_max * max_pin, &pblk))) return rc;
+    if ((rc = ws_get(ctx, WS_BATCH_RUNS, (size_t)runs_max * max_dev, &dblk))) return rc;
+    char *pin = (char *)pblk, *pin_dev = nullptr;
+    {
+        void *alias = nullptr;
+        MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, pin, 0));
+        pin_dev = (char *)alias;
+    }
+    double *h_p1 = (double *)pin, *h_p2 = (double *)(pin + pts_bytes);
+    MLPL_HIP_TRY(hipMemcpyAsync(h_p1, d_p1, (size_t)B * stride * 16, hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(h_p2, d_p2, (size_t)B * stride * 16, hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipStreamSynchronize(s));
+    char *run_pin = pin + 2 * pts_bytes, *run_pin_dev = pin_dev + 2 * pts_bytes;
+    long long rounds = 0, merged = 0;
+    int first_err = 0;
+    std::string first_msg;
+    for (int b0 = 0; b0 < B; b0 += kUsacBatchRuns) {
+        const int nb = std::min(kUsacBatchRuns, B - b0);
+        BatchHub hub(ctx, s, nb);
+        std::vector<UsacBufs> bufs((size_t)nb);
+        std::vector<std::string> msgs((size_t)nb);
+        std::vector<std::thread> threads;
+        threads.reserve((size_t)nb);
+        for (int k = 0; k < nb; ++k) {
+            bufs[k].dev = (char *)dblk + (size_t)k * max_dev;
+            bufs[k].pin = run_pin + (size_t)k * max_pin, bufs[k].pin_dev = run_pin_dev + (size_t)k * max_pin;
+            threads.emplace_back([&, k] {
+                const int b = b0 + k;
+                const int n = counts[b];
+                HubRun &hr = hub.run(k);
+                int r = MLPL_OK;
+                bool ok = false;
+                try {
+                    UsacRun R;
+                    usac_configure(R, ctx, d_p1 + (size_t)b * stride * 2, d_p2 + (size_t)b * stride * 2, n, &params[b], s);
+                    R.L.hub = &hub, R.L.run = &hr, R.bufs = &bufs[k];
+                    if (trace && trace->buf) R.trace_buf = trace->buf + (size_t)b * trace->cap * 16, R.trace_cap = trace->cap;
+                    R.hp1.assign(h_p1 + (size_t)b * stride * 2, h_p1 + (size_t)b * stride * 2 + (size_t)2 * std::max(n, 0));
+                    R.hp2.assign(h_p2 + (size_t)b * stride * 2, h_p2 + (size_t)b * stride * 2 + (size_t)2 * std::max(n, 0));
+                    if (n >= 5) {
+                        r = R.setup();
+                        if (!r) r = R.solve(&ok);
+                    }
+                    if (!r) {
+                        usac_results(R, ok, results + (size_t)b * 12);
+                        if (trace && trace->lens) trace->lens[b] = R.trace_len;
+                        if (degen) {
+                            double *d = degen + (size_t)b * 16;
+                            std::memset(d, 0, 128);
+                            d[0] = R.dg_on ? 1.0 : 0.0, d[1] = R.dg_cnt_rot, d[2] = R.dg_cnt_nomot, d[3] = R.dg_type;
+                            std::memcpy(d + 4, R.dg_R, 72);
+                        }
+                        if (ok) {
+                            std::memcpy(E + (size_t)b * 9, R.final_model, 72);
+                            if (d_masks) r = usac_mask_to_device(R, d_masks + (size_t)b * stride);
+                        } else
+                            r = MLPL_E_FAILED;
+                    }
+                } catch (const std::bad_alloc &) {
+                    r = MLPL_E_NOMEM;
+                    set_error("mlpl_usac_essential_batch_dev: out of host memory");
+                }
+                if (r && r != MLPL_E_FAILED) msgs[k] = mlpl_last_error();
+                status[b] = r;
+                hub.finish(hr);
+            });
+        }
+        const int hrc = hub.serve();
+        for (auto &t : threads) t.join();
+        rounds += hub.rounds(), merged += hub.merged_launches();
+        for (int k = 0; k < nb && !first_err; ++k)
+            if (status[b0 + k] && status[b0 + k] != MLPL_E_FAILED) first_err = status[b0 + k], first_msg = msgs[k];
+        if (hrc && !first_err) first_err = hrc;
+        if (first_err) break;
+    }
+    ctx->last_usac_stats[0] = rounds, ctx->last_usac_stats[1] = merged;
+    if (first_err) {
+        if (!first_msg.empty()) set_error("%s", first_msg.c_str());
+        return first_err;
     }
     return MLPL_OK;
 }

@@ -183,6 +183,54 @@ def usac_essential(p1, p2, th: float, seed: int, sorted_idx=None, max_hyp: int =
     return out
 
 
+def usac_essential_batch(d_p1, d_p2, counts, th: float, seeds, sorted_idx=None, max_hyp: int = 50000, conf: float = 0.99, prosac_beta: float = 0.09,
+                         sprt_delta: float = 0.05, sprt_epsilon: float = 0.15, sprt_ms: float = 8.5, sprt_tm: float = 2314.0, estimator: int = 0,
+                         refine: int = 0, event_cap: int = 0, check_degeneracy: int = 0, th_pixels: float = 0.8, focal_length: float = 800.0,
+                         masks_out=None, ctx: Optional[Context] = None) -> list:
+    """A batch of USAC problems in ONE library call (mlpl_usac_essential_batch_dev): d_p1, d_p2 float64 CUDA tensors [B, stride, 2],
+    counts[b] valid rows, seeds[b]; sorted_idx: None or a list of per-problem PROSAC orders (None entries = uniform sampling).  Returns one
+    dict per problem with the keys of usac_essential (ok, E, final, events, n_events, degen ...; flags only through masks_out, a uint8
+    CUDA tensor [B, stride])."""
+    import torch
+
+    ctx = ctx or default_context()
+    B, stride = d_p1.shape[0], d_p1.shape[1]
+    assert d_p1.is_cuda and d_p1.dtype == torch.float64 and d_p1.shape == d_p2.shape == (B, stride, 2) and d_p1.is_contiguous() and d_p2.is_contiguous()
+    cn = np.ascontiguousarray(counts, np.int32)
+    P = (UsacParams * B)()
+    keep = []
+    for b in range(B):
+        ctx.lib.mlpl_usac_default_params(C.addressof(P[b]), float(th))
+        P[b].conf, P[b].max_hyp, P[b].estimator, P[b].refine, P[b].seed = float(conf), int(max_hyp), int(estimator), int(refine), int(seeds[b]) & 0xFFFFFFFF
+        P[b].prosac_beta, P[b].sprt_delta, P[b].sprt_epsilon, P[b].sprt_mS, P[b].sprt_tM = float(prosac_beta), float(sprt_delta), float(sprt_epsilon), \
+            float(sprt_ms), float(sprt_tm)
+        P[b].check_degeneracy, P[b].th_pixels, P[b].focal_length = int(check_degeneracy), float(th_pixels), float(focal_length)
+        if sorted_idx is not None and sorted_idx[b] is not None:
+            si = np.ascontiguousarray(sorted_idx[b], np.uint32)
+            keep.append(si)
+            P[b].sorted_idx = si.ctypes.data
+    E, res, status, degen = np.zeros((B, 9)), np.zeros((B, 12)), np.zeros(B, np.int32), np.zeros((B, 16))
+    ev = np.zeros((B, max(event_cap, 1), 16))
+    lens = np.zeros(B, np.int32)
+    if masks_out is not None:
+        assert masks_out.is_cuda and masks_out.dtype == torch.uint8 and masks_out.shape == (B, stride) and masks_out.is_contiguous()
+    st = torch.cuda.current_stream(d_p1.device).cuda_stream
+    rc = ctx.lib.mlpl_usac_essential_batch_dev(ctx.handle, B, d_p1.data_ptr(), d_p2.data_ptr(), stride, cn.ctypes.data, C.addressof(P), E.ctypes.data,
+                                               masks_out.data_ptr() if masks_out is not None else None, res.ctypes.data, status.ctypes.data,
+                                               degen.ctypes.data, ev.ctypes.data if event_cap else None, int(event_cap), lens.ctypes.data if event_cap else None, st)
+    if rc != 0:
+        raise MlplError(rc, "mlpl_usac_essential_batch_dev", _lib.last_error())
+    stats = np.zeros(8, np.int64)
+    ctx.lib.mlpl_usac_last_stats(ctx.handle, stats.ctypes.data)
+    out = []
+    for b in range(B):
+        if status[b] not in (0, _lib.MLPL_E_FAILED):
+            raise MlplError(int(status[b]), "mlpl_usac_essential_batch_dev", f"problem {b}")
+        out.append(dict(ok=bool(status[b] == 0), E=E[b].copy(), final=res[b].copy(), events=ev[b, :min(int(lens[b]), event_cap)].copy(), n_events=int(lens[b]),
+                        degen=degen[b, :4].copy(), R_degen=degen[b, 4:13].copy(), stats=stats))
+    return out
+
+
 def arrsac_sample_models(p1, p2, idx, kind: int, thresh: float = 1e-3, ctx: Optional[Context] = None):
     """ARRSAC's estimators on one sample (modelest.cpp:111-178) -> (models [k,3,3] before the validity filter, valid flags [k])."""
     ctx = ctx or default_context()

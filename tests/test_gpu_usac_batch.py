@@ -1,0 +1,79 @@
+"""mlpl_usac_essential_batch_dev (csrc/batch_hub.h: every problem's sequential program on its own host thread, the launches of all runs merged
+into one launch per kernel) against mlpl_usac_essential problem by problem: results, masks and decision traces identical."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_golden  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _problems(B, rng):
+    sizes = [int(v) for v in rng.choice([64, 150, 300, 800, 1200, 2000, 3000, 5000], B)]
+    fr = rng.uniform(0.25, 0.9, B)
+    scenes = [make_golden.usac_scene(sizes[b], float(fr[b]), 500 + b) for b in range(B)]
+    return sizes, scenes
+
+
+@pytest.mark.parametrize("refine,estimator,degen", [(0, 0, 0), (5, 2, 1), (0, 0, 3), (7, 0, 0)])
+def test_batch_equals_the_single_problem_entry_on_64_problems(ctx, refine, estimator, degen):
+    """64 problems of 64 ... 5000 correspondences, 25-90 % inliers, uniform and PROSAC sampling mixed, each with its own seed; REF_WEIGHTS and
+    ConfigUSAC's defaults (POSE_STEWENIUS + REF_STEWENIUS_WEIGHTS + the degeneracy tests): per problem the same results[12], model, inlier
+    mask, degeneracy verdict and the same decision trace event by event as mlpl_usac_essential."""
+    import torch
+    from matchinglib_poselib_amd import pose
+
+    rng = np.random.default_rng(3 + refine)
+    B = 64
+    sizes, scenes = _problems(B, rng)
+    stride = max(sizes)
+    p1, p2 = np.zeros((B, stride, 2)), np.zeros((B, stride, 2))
+    th = scenes[0][2]
+    orders = []
+    for b, (a, c, t, truth, order) in enumerate(scenes):
+        p1[b, :sizes[b]], p2[b, :sizes[b]] = a, c
+        orders.append(order if b % 3 == 1 else None)
+    sizes[5] = 4            # solve() refuses
+    seeds = [9000 + 13 * b for b in range(B)]
+    dev = torch.device("cuda:0")
+    d1, d2 = torch.from_numpy(p1).to(dev), torch.from_numpy(p2).to(dev)
+    masks = torch.zeros((B, stride), dtype=torch.uint8, device=dev)
+    kw = dict(refine=refine, estimator=estimator, check_degeneracy=degen, max_hyp=3000, sprt_ms=6.0, sprt_tm=2736.0)
+    cap = 40000
+    got = pose.usac_essential_batch(d1, d2, sizes, th, seeds, sorted_idx=orders, event_cap=cap, masks_out=masks, ctx=ctx, **kw)
+    mh = masks.cpu().numpy()
+    for b in range(B):
+        n = sizes[b]
+        one = pose.usac_essential(p1[b, :n], p2[b, :n], th, seeds[b], sorted_idx=orders[b], event_cap=cap, ctx=ctx, **kw)
+        g = got[b]
+        assert g["ok"] == one["ok"], b
+        assert np.array_equal(g["final"], one["final"]), (b, g["final"], one["final"])
+        if not one["ok"]:
+            continue
+        assert np.array_equal(g["E"].view(np.uint64), one["E"].view(np.uint64)), b
+        assert np.array_equal(mh[b, :n], one["flags"]), b
+        assert g["n_events"] == one["n_events"] and g["n_events"] <= cap and np.array_equal(g["events"], one["events"]), b
+        if degen:
+            assert np.array_equal(g["degen"], one["degen"]) and np.array_equal(g["R_degen"], one["R_degen"]), b
+    assert got[0]["stats"][0] > 0 and got[0]["stats"][1] > 0      # rounds, merged launches
+
+
+def test_batch_of_one_and_of_more_than_an_internal_batch(ctx):
+    """B = 1, and B = 150 (two internal batches of runs): same as the single entry."""
+    import torch
+    from matchinglib_poselib_amd import pose
+
+    a, c, th, truth, order = make_golden.usac_scene(600, 0.6, 77)
+    dev = torch.device("cuda:0")
+    for B in (1, 150):
+        d1 = torch.from_numpy(np.repeat(a[None], B, 0).copy()).to(dev)
+        d2 = torch.from_numpy(np.repeat(c[None], B, 0).copy()).to(dev)
+        seeds = [40 + (b % 7) for b in range(B)]
+        got = pose.usac_essential_batch(d1, d2, [600] * B, th, seeds, refine=5, estimator=2, ctx=ctx)
+        ref = {s: pose.usac_essential(a, c, th, s, refine=5, estimator=2, ctx=ctx) for s in sorted(set(seeds))}
+        for b in range(B):
+            assert got[b]["ok"] and np.array_equal(got[b]["final"], ref[seeds[b]]["final"]) and np.array_equal(got[b]["E"], ref[seeds[b]]["E"]), (B, b)
