@@ -71,15 +71,23 @@ __device__ __forceinline__ void hub_refit_solve_body(const RefitSolveArgs &a, in
 }
 MLPL_HUB_KERNEL(HK_REFIT_SOLVE, RefitSolveArgs, hub_refit_solve_body, 64);
 
-struct CopyBytesArgs {  // n bytes from (device-visible) src to dst, 256 threads x 16 bytes per block; both 16-byte aligned, n padded by the caller's buffers
+struct CopyBytesArgs {  // n bytes from (device-visible, 16-byte aligned, padded) src to dst of ANY alignment; 256 threads x 16 bytes per block
     KHdr hdr;
     const uint4 *src;
-    uint4 *dst;
-    int n16;
+    uint8_t *dst;
+    int n;
 };
 __device__ __forceinline__ void hub_copy_bytes_body(const CopyBytesArgs &a, int bx, int) {
     const int i = bx * 256 + threadIdx.x;
-    if (i < a.n16) a.dst[i] = a.src[i];
+    if (i * 16 >= a.n) return;
+    const uint4 v = a.src[i];
+    uint8_t *d = a.dst + (size_t)i * 16;
+    if ((reinterpret_cast<uintptr_t>(d) & 15) == 0 && i * 16 + 16 <= a.n) {
+        *reinterpret_cast<uint4 *>(d) = v;
+        return;
+    }
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    for (int k = 0; k < 16 && i * 16 + k < a.n; ++k) d[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
 }
 MLPL_HUB_KERNEL(HK_COPY_BYTES, CopyBytesArgs, hub_copy_bytes_body, 256);
 
@@ -99,7 +107,7 @@ inline void hub_launch_solver(Launcher &L, mlpl_ctx *ctx, int count, const doubl
 }
 inline void hub_copy_bytes(Launcher &L, const void *src_dev_visible, void *dst, size_t bytes) {
     const int n16 = (int)((bytes + 15) / 16);
-    CopyBytesArgs ca{{(n16 + 255) / 256, 1}, (const uint4 *)src_dev_visible, (uint4 *)dst, n16};
+    CopyBytesArgs ca{{(n16 + 255) / 256, 1}, (const uint4 *)src_dev_visible, (uint8_t *)dst, (int)bytes};
     L.launch(HK_COPY_BYTES, ca);
 }
 
