@@ -74,10 +74,66 @@ struct HubLaunch {
     alignas(16) unsigned char args[kHubArgBytes];
 };
 
-struct HubStreams {  // helper streams of the hub: groups of one round run side by side (owned by the context)
+// The runs of a batch are host threads; creating 128 of them costs ~2.5 ms, a fifth of a batch: they are kept (blocked) between calls.
+class HubThreads {
+   public:
+    // run job(k) for k in [0, n) on n threads at once; returns at once (wait() joins the round)
+    void start(int n, std::function<void(int)> job) {
+        std::unique_lock<std::mutex> lk(m_);
+        while ((int)th_.size() < n) {
+            const int k = (int)th_.size();
+            th_.emplace_back([this, k] { loop(k); });
+        }
+        job_ = std::move(job);
+        active_ = n, pending_ = n;
+        ++gen_;
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [&] { return pending_ == 0; });
+    }
+    ~HubThreads() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            cv_.notify_all();
+        }
+        for (auto &t : th_) t.join();
+    }
+
+   private:
+    void loop(int k) {
+        unsigned long long seen = 0;
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_.wait(lk, [&] { return stop_ || (gen_ != seen && k < active_); });
+            if (stop_) return;
+            seen = gen_;
+            lk.unlock();
+            job_(k);
+            lk.lock();
+            if (--pending_ == 0) cv_done_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, cv_done_;
+    std::function<void(int)> job_;
+    unsigned long long gen_ = 0;
+    int active_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
+struct HubStreams {  // what the hub keeps between calls (owned by the context): helper streams -- groups of one round run side by side -- and the run threads
     hipEvent_t ev[kHubMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t aux[kHubMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
+    HubThreads threads;
 };
+inline HubStreams *hub_resources(mlpl_ctx *ctx) {
+    if (!ctx->hub_streams) ctx->hub_streams = new HubStreams();
+    return static_cast<HubStreams *>(ctx->hub_streams);
+}
 
 class BatchHub;
 struct HubRun {  // one run's side of the hub
@@ -114,13 +170,17 @@ class BatchHub {
         int first_rc = 0;
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
+            const auto t_wait = std::chrono::steady_clock::now();
             cv_hub_.wait(lk, [&] { return blocked_ + finished_ == (int)runs_.size(); });
+            host_us_ += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_wait).count();
             if (blocked_ == 0) break;
             std::vector<HubRun *> todo;
             for (auto &r : runs_)
                 if (r.blocked) todo.push_back(&r);
             lk.unlock();
+            const auto t_exec = std::chrono::steady_clock::now();
             const int rc = execute(todo);
+            device_us_ += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_exec).count();
             lk.lock();
             if (rc && !first_rc) first_rc = rc;
             for (HubRun *r : todo) {
@@ -137,6 +197,8 @@ class BatchHub {
     }
     long long rounds() const { return rounds_; }
     long long merged_launches() const { return merged_; }
+    long long host_us() const { return host_us_; }      // the hub waiting for the runs' host work (all runs blocked = a round can start)
+    long long device_us() const { return device_us_; }  // building, issuing and waiting for the merged launches
 
    private:
     int execute(const std::vector<HubRun *> &todo) {
@@ -198,11 +260,9 @@ class BatchHub {
         MLPL_HIP_TRY(hipMemcpyAsync(d_items_, h_items_, off, hipMemcpyHostToDevice, s_));
         // group gi runs on stream gi % kHubMaxGroups (0 = the caller's); the helper streams start behind the item copy and are joined at the end
         const int used = (int)std::min<size_t>(groups.size(), kHubMaxGroups);
-        HubStreams *hs = static_cast<HubStreams *>(ctx_->hub_streams);
+        HubStreams *hs = hub_resources(ctx_);
         if (used > 1) {
-            if (!hs) {
-                hs = new HubStreams();
-                ctx_->hub_streams = hs;
+            if (!hs->ev[0]) {
                 for (int i = 0; i < kHubMaxGroups; ++i) {
                     MLPL_HIP_TRY(hipEventCreateWithFlags(&hs->ev[i], hipEventDisableTiming));
                     if (i) MLPL_HIP_TRY(hipStreamCreateWithFlags(&hs->aux[i], hipStreamNonBlocking));
@@ -232,7 +292,7 @@ class BatchHub {
     std::mutex m_;
     std::condition_variable cv_hub_, cv_runs_;
     int blocked_ = 0, finished_ = 0;
-    long long rounds_ = 0, merged_ = 0;
+    long long rounds_ = 0, merged_ = 0, host_us_ = 0, device_us_ = 0;
 };
 
 // A run's view: launch now and wait on the stream (hub == nullptr), or record and wait on the hub.

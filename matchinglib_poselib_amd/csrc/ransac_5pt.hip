@@ -39,6 +39,7 @@
 #include <cmath>
 #include <cstring>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>

@@ -142,6 +142,7 @@ __device__ __forceinline__ void usac_check_body(const UsacCheckArgs &A, const in
 #pragma unroll
     for (int k = 0; k < 9; ++k) E[k] = E_tab[((size_t)b * 10 + slot) * 9 + k];
     if (lane < 9) out_E[((size_t)b * 10 + slot) * 9 + lane] = E_tab[((size_t)b * 10 + slot) * 9 + lane];  // the host's copy of the model
+    int valid_model = 0;
     if (lane == 0) {
         // order convention: ascending E(0,0) of the unit-Frobenius matrix whose largest-magnitude element is positive
         double big = 0, n2 = 0;
@@ -177,8 +178,13 @@ __device__ __forceinline__ void usac_check_body(const UsacCheckArgs &A, const in
             }
         }
         out_valid[b * 10 + slot] = ok;
+        valid_model = ok;
     }
+    // the control flow never evaluates a model the oriented constraint rejects (validateModel comes first, USAC.h:463-475): no row for it.
+    // The rows cross PCIe (pinned host memory): half the models of a batch are rejected here.
+    if (!__shfl(valid_model, 0)) return;
     unsigned long long *row = out_rows + ((size_t)b * 10 + slot) * words;
+    unsigned long long mine = 0;  // lane l collects word w0 + l: one coalesced 512-byte store per 64 words instead of 64 single stores
     for (int w = 0; w < words; ++w) {
         const int j = w * 64 + lane;
         bool in = false;
@@ -187,7 +193,11 @@ __device__ __forceinline__ void usac_check_body(const UsacCheckArgs &A, const in
             in = usac_sampson(E, p.x, p.y, p.z, p.w) < thr;
         }
         const unsigned long long bal = __ballot(in);
-        if (lane == 0) row[w] = bal;
+        if (lane == (w & 63)) mine = bal;
+        if ((w & 63) == 63 || w == words - 1) {
+            const int w0 = w & ~63;
+            if (w0 + lane <= w) row[w0 + lane] = mine;
+        }
     }
 }
 MLPL_HUB_KERNEL(HK_USAC_CHECK, UsacCheckArgs, usac_check_body, 64);
@@ -608,14 +618,16 @@ struct UsacLo5State {  // device, one per chain
     double E[9];       // current model (denormalised)
     int32_t alive, step_fit, fit_pts, pad;
     int32_t cnt_inl[kLo5MaxBlocks], cnt_mem[kLo5MaxBlocks];
-    int32_t hist_nm[kUsacLoEvals], hist_take[kUsacLoEvals];  // per fit of the chain (0 = the sample's): solutions found (-1: no fit), the one kept
-    double hist_E[kUsacLoEvals][10][9];
 };
 struct UsacLo5Out {    // pinned host memory, one per chain, followed by kUsacLoEvals bit rows of `words` words
     int32_t evals, cnt2, first_fit, pad;  // first_fit: 1 = the sample's fit gave a model, 2 = it gave none (fresh chains)
     int32_t fit_pts[kUsacLoEvals];        // points the model of evaluation e was fitted to
     int32_t fit_state[kUsacLoEvals];      // the fit that follows evaluation e: 0 = none (fewer than 5 points), 1 = model, 2 = no solution
     double E[kUsacLoEvals][9];            // the evaluated models (denormalised)
+    // per fit of the chain (0 = the sample's): solutions found (-1: no fit), the one kept, the solutions -- the host re-takes the choices
+    // when the flags of the best model change (UsacRun::lo5_pick_host)
+    int32_t hist_nm[kUsacLoEvals], hist_take[kUsacLoEvals];
+    double hist_E[kUsacLoEvals][10][9];
 };
 
 __device__ __forceinline__ void usac5_row(double x1, double y1, double x2, double y2, double *q) {
@@ -674,7 +686,7 @@ __device__ __forceinline__ void usac5_begin_body(const Usac5BeginArgs &A, const 
         S.alive = 1, S.step_fit = I.start_step < 0 ? 1 : 0, S.fit_pts = I.start_step < 0 ? kUsacLoSample : 0;
         O->evals = 0, O->cnt2 = 0, O->first_fit = 0;
     }
-    if (lane < kUsacLoEvals) O->fit_pts[lane] = 0, O->fit_state[lane] = 0, S.hist_nm[lane] = -1;
+    if (lane < kUsacLoEvals) O->fit_pts[lane] = 0, O->fit_state[lane] = 0, O->hist_nm[lane] = -1;
     if (I.start_step >= 0) {
         if (lane < 9) S.E[lane] = I.E[lane];
         return;
@@ -757,7 +769,7 @@ __device__ __forceinline__ double usac5_key(const double *E) {  // ascending E(0
 // grid = chains, 64 threads: of the solutions roots_kernel_t left for the chain's system, the one generateRefinedModel keeps.
 // `fit_eval` = index of the evaluation this fit follows, -1 for the sample's fit; `ends_chain`: a fit without a solution ends the
 // repetition (the sample's fit and the refit on the 2 x threshold set; in a re-weighted step the model stays).  The solutions and the
-// choice are kept per (chain, fit) for usac5_recheck_kernel.
+// choice are kept per (chain, fit) in the output block: the host re-takes the choices when the flags change (UsacRun::lo5_pick_host).
 struct Usac5ChooseArgs {
     KHdr hdr;
     const double * p1;
@@ -790,11 +802,11 @@ __device__ __forceinline__ void usac5_choose_body(const Usac5ChooseArgs &A, cons
     UsacLo5Out *O = reinterpret_cast<UsacLo5Out *>(out_base + (size_t)c * out_stride);
     const int fit = fit_eval + 1;
     if (!S.alive || !S.step_fit) {
-        if (lane == 0) S.hist_nm[fit] = -1;
+        if (lane == 0) O->hist_nm[fit] = -1;
         return;
     }
     const int nm = min(n_models[c], 10);
-    if (lane == 0) S.hist_nm[fit] = nm;
+    if (lane == 0) O->hist_nm[fit] = nm;
     if (nm <= 0) {
         if (lane == 0) {
             if (fit_eval < 0) O->first_fit = 2;
@@ -809,7 +821,7 @@ __device__ __forceinline__ void usac5_choose_body(const Usac5ChooseArgs &A, cons
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             E[k] = E_tab[((size_t)c * 10 + lane) * 9 + k];
-            S.hist_E[fit][lane][k] = E[k];
+            O->hist_E[fit][lane][k] = E[k];
         }
         key = usac5_key(E);
     }
@@ -820,47 +832,13 @@ __device__ __forceinline__ void usac5_choose_body(const Usac5ChooseArgs &A, cons
         if (lane == 0) S.E[k] = v;
     }
     if (lane == 0) {
-        S.hist_take[fit] = take;
+        O->hist_take[fit] = take;
         if (fit_eval < 0) O->first_fit = 1;
         else O->fit_state[fit_eval] = 1;
     }
 }
 MLPL_HUB_KERNEL(HK_USAC5_CHOOSE, Usac5ChooseArgs, usac5_choose_body, 64);
 
-// grid = (kUsacLoEvals fits, chains), 64 threads.  The inlier flags of the best model have changed (an earlier repetition stored a new
-// best): would any choice of this chain have come out differently?  first_diff[c] = the first such fit, else kUsacLoEvals.
-struct Usac5RecheckArgs {
-    KHdr hdr;
-    const double * p1;
-    const double * p2;
-    int n;
-    const uint8_t * flags;
-    const UsacLo5State * st;
-    int32_t * first_diff;
-};
-__device__ __forceinline__ void usac5_recheck_body(const Usac5RecheckArgs &A, const int vbx, const int vby) {
-    const double *__restrict__ p1 = A.p1;
-    const double *__restrict__ p2 = A.p2;
-    const int n = A.n;
-    const uint8_t *__restrict__ flags = A.flags;
-    const UsacLo5State *__restrict__ st = A.st;
-    int32_t *__restrict__ first_diff = A.first_diff;
-
-    const int fit = vbx, c = vby, lane = threadIdx.x;
-    const UsacLo5State &S = st[c];
-    const int nm = S.hist_nm[fit];
-    if (nm <= 1) return;
-    double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    double key = INFINITY;
-    if (lane < nm) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) E[k] = S.hist_E[fit][lane][k];
-        key = usac5_key(E);
-    }
-    const int take = usac5_pick(E, key, nm, lane, p1, p2, n, flags);
-    if (lane == 0 && take != S.hist_take[fit]) atomicMin(&first_diff[c], fit);
-}
-MLPL_HUB_KERNEL(HK_USAC5_RECHECK, Usac5RecheckArgs, usac5_recheck_body, 64);
 
 // grid = (blocks, chains), 256 threads.  Evaluation `e` of the chain's model: errors in point order, per-block counts of the inliers and of
 // the members of {err < limit}, the inlier bit row in pool order.
@@ -1577,7 +1555,7 @@ struct UsacRun {
                 UsacModel &m = sm.m[oi];
                 std::memcpy(m.E, hE + ((size_t)b * 10 + slot) * 9, 72);
                 m.valid = h_valid[b * 10 + slot];
-                m.bits.assign(h_rows + ((size_t)b * 10 + slot) * words, h_rows + ((size_t)b * 10 + slot + 1) * words);
+                if (m.valid) m.bits.assign(h_rows + ((size_t)b * 10 + slot) * words, h_rows + ((size_t)b * 10 + slot + 1) * words);  // (no row for a rejected model)
             }
             cache_bytes += sizeof(UsacSampleModels) + (size_t)nm * words * 8;
             cache.emplace(keys[b], std::move(sm));
@@ -1809,6 +1787,59 @@ struct UsacRun {
         stats[3]++;
         return MLPL_OK;
     }
+    // usac5_pick on the host: the same sums in the same order, the same early exit, the same tie rule
+    static double sampson_host(const double *m, double x1, double y1, double x2, double y2) {
+        const double rxc = m[0] * x2 + m[3] * y2 + m[6];
+        const double ryc = m[1] * x2 + m[4] * y2 + m[7];
+        const double rwc = m[2] * x2 + m[5] * y2 + m[8];
+        const double r = (x1 * rxc + y1 * ryc + rwc);
+        const double rx = m[0] * x1 + m[1] * y1 + m[2];
+        const double ry = m[3] * x1 + m[4] * y1 + m[5];
+        return r * r / (rxc * rxc + ryc * ryc + rx * rx + ry * ry);
+    }
+    int lo5_pick_host(const double (*Es)[9], int nm) const {
+        if (nm <= 1) return 0;
+        double key[10], sum[10];
+        int pos[10];
+        for (int j = 0; j < nm; ++j) {
+            double big = 0, n2 = 0;
+            for (int k = 0; k < 9; ++k) {
+                if (fabs(Es[j][k]) > fabs(big)) big = Es[j][k];
+                n2 += Es[j][k] * Es[j][k];
+            }
+            key[j] = (big < 0 ? -Es[j][0] : Es[j][0]) / sqrt(n2);
+            sum[j] = 0;
+        }
+        for (int j = 0; j < nm; ++j) {
+            pos[j] = 0;
+            for (int k = 0; k < nm; ++k) pos[j] += (key[k] < key[j] || (key[k] == key[j] && k < j)) ? 1 : 0;
+        }
+        auto two_smallest = [&](double &m1, double &m2) {
+            m1 = INFINITY;
+            int first = -1;
+            for (int j = 0; j < nm; ++j) m1 = fmin(m1, sum[j]);
+            for (int j = 0; j < nm && first < 0; ++j)
+                if (sum[j] == m1) first = j;
+            m2 = INFINITY;
+            for (int j = 0; j < nm; ++j)
+                if (j != first) m2 = fmin(m2, sum[j]);
+        };
+        for (unsigned i = 0; i < n; ++i) {
+            if (!flags[i]) continue;
+            for (int j = 0; j < nm; ++j) sum[j] += sampson_host(Es[j], hp1[2 * i], hp1[2 * i + 1], hp2[2 * i], hp2[2 * i + 1]);
+            if ((i > 3) && (i % 4 == 0)) {
+                double m1, m2;
+                two_smallest(m1, m2);
+                if (m1 < 0.66 * m2) break;
+            }
+        }
+        double m1, m2;
+        two_smallest(m1, m2);
+        int take = 0, best_pos = 64;
+        for (int j = 0; j < nm; ++j)
+            if (sum[j] == m1 && pos[j] < best_pos) best_pos = pos[j], take = j;
+        return take;
+    }
     int lo5_upload_flags() {  // the inlier flags of the best model, point order (pinned staging: the copy is stream-ordered)
         std::memcpy(h_lo5_flags, flags.data(), n);
         hub_copy_bytes(L, d_lo5_flags_src, d_lo5_flags, n);
@@ -1881,20 +1912,22 @@ struct UsacRun {
                 lo_inliers = tmp;
                 store_solution(0, lo_inliers, rows + (size_t)e * words, O->E[e]);
                 if (r + 1 < kUsacLoReps) {
-                    // the repetitions behind this one chose their solutions under the old flags: where a choice would now differ (rare:
-                    // the right solution's error sum is far below the others') the chain is run again
+                    // the repetitions behind this one chose their solutions under the old flags: the host re-takes every choice of
+                    // theirs on the solutions the chain recorded (usually a handful of error evaluations: the early exit), and a chain
+                    // whose choice would now differ is run again.  The device's flags follow (later resumes and re-runs read them).
                     if ((rc = lo5_upload_flags())) return rc;
-                    const int C = kUsacLoReps - (r + 1);
-                    for (int k = 0; k < C; ++k) h_lo5_diff[k] = kUsacLoEvals;
-                    Usac5RecheckArgs rk{{kUsacLoEvals, C}, d_p1, d_p2, (int)n, (const uint8_t *)d_lo5_flags, (const UsacLo5State *)(d_lo5_state + r + 1), d_lo5_diff};
-                    L.launch(HK_USAC5_RECHECK, rk);
-                    if ((rc = L.sync())) return rc;
                     stats[5]++;
-                    for (int k = 0; k < C; ++k)
-                        if (h_lo5_diff[k] < kUsacLoEvals) {
+                    for (int k = r + 1; k < kUsacLoReps; ++k) {
+                        const UsacLo5Out *Ok = (const UsacLo5Out *)(h_out + (size_t)k * stride);
+                        bool differs = false;
+                        for (int f = 0; f < kUsacLoEvals && !differs; ++f)
+                            if (Ok->hist_nm[f] > 1) differs = lo5_pick_host(Ok->hist_E[f], Ok->hist_nm[f]) != Ok->hist_take[f];
+                        if (differs) {
                             stats[6]++;
-                            if ((rc = lo5_run(r + 1 + k, r + 2 + k, -1))) return rc;
+                            h_lo_in[k].start_step = -1;
+                            if ((rc = lo5_run(k, k + 1, -1))) return rc;
                         }
+                    }
                 }
             }
         }
@@ -2543,20 +2576,23 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
     MLPL_HIP_TRY(hipMemcpyAsync(h_p2, d_p2, (size_t)B * stride * 16, hipMemcpyDeviceToHost, s));
     MLPL_HIP_TRY(hipStreamSynchronize(s));
     char *run_pin = pin + 2 * pts_bytes, *run_pin_dev = pin_dev + 2 * pts_bytes;
-    long long rounds = 0, merged = 0;
+    long long rounds = 0, merged = 0, host_us = 0, device_us = 0, spawn_us = 0;
+    const auto t_all = std::chrono::steady_clock::now();
     int first_err = 0;
     std::string first_msg;
     for (int b0 = 0; b0 < B; b0 += kUsacBatchRuns) {
         const int nb = std::min(kUsacBatchRuns, B - b0);
         BatchHub hub(ctx, s, nb);
+        const auto t_spawn = std::chrono::steady_clock::now();
         std::vector<UsacBufs> bufs((size_t)nb);
         std::vector<std::string> msgs((size_t)nb);
-        std::vector<std::thread> threads;
-        threads.reserve((size_t)nb);
         for (int k = 0; k < nb; ++k) {
             bufs[k].dev = (char *)dblk + (size_t)k * max_dev;
             bufs[k].pin = run_pin + (size_t)k * max_pin, bufs[k].pin_dev = run_pin_dev + (size_t)k * max_pin;
-            threads.emplace_back([&, k] {
+        }
+        HubThreads &pool = hub_resources(ctx)->threads;
+        pool.start(nb, [&](int k) {
+            {
                 const int b = b0 + k;
                 const int n = counts[b];
                 HubRun &hr = hub.run(k);
@@ -2595,17 +2631,20 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
                 if (r && r != MLPL_E_FAILED) msgs[k] = mlpl_last_error();
                 status[b] = r;
                 hub.finish(hr);
-            });
-        }
+            }
+        });
+        spawn_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_spawn).count();
         const int hrc = hub.serve();
-        for (auto &t : threads) t.join();
-        rounds += hub.rounds(), merged += hub.merged_launches();
+        pool.wait();
+        rounds += hub.rounds(), merged += hub.merged_launches(), host_us += hub.host_us(), device_us += hub.device_us();
         for (int k = 0; k < nb && !first_err; ++k)
             if (status[b0 + k] && status[b0 + k] != MLPL_E_FAILED) first_err = status[b0 + k], first_msg = msgs[k];
         if (hrc && !first_err) first_err = hrc;
         if (first_err) break;
     }
-    ctx->last_usac_stats[0] = rounds, ctx->last_usac_stats[1] = merged;
+    ctx->last_usac_stats[0] = rounds, ctx->last_usac_stats[1] = merged, ctx->last_usac_stats[2] = host_us, ctx->last_usac_stats[3] = device_us;
+    ctx->last_usac_stats[4] = spawn_us;
+    ctx->last_usac_stats[5] = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_all).count();
     if (first_err) {
         if (!first_msg.empty()) set_error("%s", first_msg.c_str());
         return first_err;
