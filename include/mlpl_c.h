@@ -396,6 +396,19 @@ int mlpl_pair_pose_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, const uint8_t 
 int mlpl_pair_pose_batch_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
                              const float *d_kp2, const double K0[4], const double K1[4], double thresh, int max_iters, double confidence,
                              int refit, const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out, void *stream);
+/*
+ * The same batch with USAC -- the reference harness' default RobMethod (T/poselib-test/main.cpp:734) -- as the robust estimator:
+ * matching, match counts, gather + ImgToCamCoordTrans as above, then mlpl_usac_essential_batch_dev on the pairs' correspondences (every
+ * pair's sequential program on its own host thread, every launch merged over the pairs), then the batched cheirality step.  *usac:
+ * the parameters every pair runs with (th, conf, max_hyp, estimator, refine, SPRT start values, degeneracy tests; its seed and sorted_idx
+ * are ignored); seeds[n_pairs]: the pairs' seeds; prosac != 0: PROSAC sampling in the order of the matching costs -- poselib::
+ * getSortedMatchIdx' std::sort of the pair's matches (pose_helper.cpp:2896-2923) -- else uniform sampling.  Record per pair:
+ * status 0, -1 (fewer than 16 matches) or -2 (USAC failed); iters = hypotheses, n_inliers = inliers of the USAC model, n_good, E, R, t --
+ * what mlpl_match_hamming_dev + mlpl_gather_match_points_dev -> mlpl_usac_essential_dev -> mlpl_recover_pose_dev return for the pair.
+ */
+int mlpl_pair_pose_batch_usac_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
+                                  const float *d_kp2, const double K0[4], const double K1[4], const mlpl_usac_params *usac, int prosac,
+                                  const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out, void *stream);
 /* The same batch behind the matching -- the batched form of mlpl_ransac_essential_dev (refit = 0) followed, with recover_pose != 0, by
  * mlpl_recover_pose_dev on the RANSAC inliers: problem b's correspondences are d_p1 / d_p2 + b * stride * 2 (camera coordinates, n x 2
  * doubles, device), counts[b] <= stride of them (host array), seeds[b] its srand() seed.  Records as above with n_matches = counts[b];

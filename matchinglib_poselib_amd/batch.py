@@ -159,6 +159,45 @@ def process_pairs_batched(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, seeds, t
     return rec
 
 
+def process_pairs_batched_usac(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, seeds, th_pix: float = 0.8, prosac: bool = False, estimator: int = 2,
+                               refine: int = 0, check_degeneracy: int = 0, sprt_delta: float = 0.05, sprt_epsilon: float = 0.15, sprt_ms: float = 6.0,
+                               sprt_tm: float = 2736.0, max_hyp: int = 50000, dist: float = 50.0, pair_ids=None, matches_out=None) -> np.ndarray:
+    """process_pairs_batched with USAC (the reference harness' default RobMethod; defaults = its cfgUSAC: POSE_STEWENIUS + REF_WEIGHTS) as the
+    robust estimator: mlpl_pair_pose_batch_usac_dev.  prosac: PROSAC sampling in the order of the matching costs."""
+    import torch
+    from .pose import UsacParams
+
+    B = d_q.shape[0]
+    assert d_q.is_cuda and d_q.dtype == torch.uint8 and d_q.dim() == 3 and d_t.dim() == 3 and d_t.shape[0] == B
+    assert d_kp1.dtype == torch.float32 and d_kp2.dtype == torch.float32 and d_kp1.shape == (B, d_q.shape[1], 2) and d_kp2.shape == (B, d_t.shape[1], 2)
+    assert d_q.is_contiguous() and d_t.is_contiguous() and d_kp1.is_contiguous() and d_kp2.is_contiguous()
+    k0 = (C.c_double * 4)(*K0)
+    k1 = (C.c_double * 4)(*K1)
+    th = th_pix * 4.0 / (np.sqrt(2.0) * (K0[0] + K0[1] + K1[0] + K1[1]))
+    P = UsacParams()
+    ctx.lib.mlpl_usac_default_params(C.addressof(P), float(th))
+    P.max_hyp, P.estimator, P.refine, P.check_degeneracy = int(max_hyp), int(estimator), int(refine), int(check_degeneracy)
+    P.sprt_delta, P.sprt_epsilon, P.sprt_mS, P.sprt_tM, P.prosac_beta = float(sprt_delta), float(sprt_epsilon), float(sprt_ms), float(sprt_tm), float(sprt_delta)
+    P.th_pixels, P.focal_length = float(th_pix), float((K0[0] + K0[1] + K1[0] + K1[1]) / 4.0)
+    sd = np.ascontiguousarray(np.asarray(seeds, np.int64) & 0xFFFFFFFF, np.uint32)
+    assert len(sd) == B
+    res = (_PairResult * B)()
+    st = torch.cuda.current_stream(d_q.device).cuda_stream
+    if matches_out is not None:
+        assert matches_out.is_cuda and matches_out.dtype == torch.int32 and matches_out.shape == (B, d_q.shape[1], 4) and matches_out.is_contiguous()
+    check(ctx.lib.mlpl_pair_pose_batch_usac_dev(ctx.handle, B, d_q.data_ptr(), d_q.shape[1], d_t.data_ptr(), d_t.shape[1], d_q.shape[2], d_kp1.data_ptr(),
+                                                d_kp2.data_ptr(), k0, k1, C.addressof(P), 1 if prosac else 0, sd.ctypes.data, float(dist), C.addressof(res),
+                                                matches_out.data_ptr() if matches_out is not None else None, st), "mlpl_pair_pose_batch_usac_dev")
+    raw = np.frombuffer(res, _PAIR_RESULT_DTYPE, count=B)
+    rec = np.zeros(B, RECORD_DTYPE)
+    rec["pair_id"] = np.arange(B) if pair_ids is None else np.asarray(pair_ids)
+    rec["n_matches"], rec["status"] = raw["n_matches"], raw["status"]
+    ok = raw["status"] == 0
+    for f in ("n_inliers", "E", "R", "t"):
+        rec[f][ok] = raw[f][ok]
+    return rec, raw
+
+
 def ransac_pose_batched(ctx: Context, d_p1, d_p2, counts, seeds, thresh: float, max_iters: int = 1000, confidence: float = 0.999,
                         recover_pose: bool = True, dist: float = 50.0, masks_out=None) -> list:
     """A batch of correspondence sets in ONE library call (mlpl_ransac_essential_batch_dev): d_p1, d_p2 float64 CUDA tensors [B, stride, 2]

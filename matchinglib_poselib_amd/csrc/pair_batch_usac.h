@@ -1,0 +1,107 @@
+// pair_batch_usac.h -- a batch of image pairs with USAC as the robust estimator (the harness default RobMethod, T/poselib-test/main.cpp:734).
+// Included by ransac_5pt.hip inside namespace mlpl after usac_impl.h and pair_batch_impl.h.
+//
+//   matching          mlpl_match_hamming_dev(batch = B)                        as in pair_batch_impl.h
+//   hop               the B match counts (and, for PROSAC, the match rows: the order is getSortedMatchIdx' std::sort of the matching costs)
+//   gather            blockIdx.y = pair: matched keypoints -> camera coordinates (ImgToCamCoordTrans)
+//   USAC              usac_essential_batch_dev: every pair's sequential program on its own host thread, every launch merged over the pairs
+//   cheirality        decomposition, four triangulations and the reference's candidate choice per pair on the device (launch_recover_pose_batch)
+// Per pair the record is what the single-problem entries return for it: mlpl_match_hamming_dev + mlpl_gather_match_points_dev ->
+// mlpl_usac_essential_dev (same parameters, seed and PROSAC order) -> mlpl_recover_pose_dev (tests/test_gpu_usac_batch.py).
+
+int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
+                             const float *d_kp2, const double K0[4], const double K1[4], const mlpl_usac_params *tmpl, int prosac,
+                             const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out, hipStream_t s) {
+    const int NQ = nq;
+    const size_t n = (size_t)NQ;
+    int rc;
+    const size_t off_idx = 0, off_dist = off_idx + (size_t)B * n * 8, off_match = off_dist + (size_t)B * n * 8, off_p1 = off_match + (size_t)B * n * 16,
+                 off_p2 = off_p1 + (size_t)B * n * 16, off_mask = off_p2 + (size_t)B * n * 16, off_cmask = (off_mask + (size_t)B * n + 255) / 256 * 256,
+                 off_small = (off_cmask + (size_t)B * 4 * n + 255) / 256 * 256;
+    // small block: counts[B] | active[B] | cand_counts[B][4] | E[B][9] | P[B][69] | pose[B]
+    const size_t sm_counts = 0, sm_active = sm_counts + (size_t)B * 4, sm_cc = sm_active + (size_t)B * 4, sm_E = (sm_cc + (size_t)B * 16 + 255) / 256 * 256,
+                 sm_P = sm_E + (size_t)B * 72, sm_pose = sm_P + (size_t)B * 69 * 8, sm_end = sm_pose + (size_t)B * sizeof(PairPoseDev);
+    void *blk = nullptr;
+    if ((rc = ws_get(ctx, WS_PIPE, off_small + sm_end + 256, &blk))) return rc;
+    char *b0 = (char *)blk, *sm = b0 + off_small;
+    mlpl_dmatch *d_m = d_matches_out ? d_matches_out : (mlpl_dmatch *)(b0 + off_match);
+    double *d_p1 = (double *)(b0 + off_p1), *d_p2 = (double *)(b0 + off_p2);
+    uint8_t *d_mask = (uint8_t *)(b0 + off_mask), *d_cmask = (uint8_t *)(b0 + off_cmask);
+    int32_t *d_counts = (int32_t *)(sm + sm_counts), *d_active = (int32_t *)(sm + sm_active), *d_cc = (int32_t *)(sm + sm_cc);
+    double *d_E = (double *)(sm + sm_E), *d_P = (double *)(sm + sm_P);
+    PairPoseDev *d_pose = (PairPoseDev *)(sm + sm_pose);
+    // pinned: counts | active | E | pose | (PROSAC) the match rows
+    const size_t pin_counts = 0, pin_act = (size_t)B * 4, pin_E = ((size_t)B * 8 + 255) / 256 * 256, pin_pose = pin_E + (size_t)B * 72,
+                 pin_match = (pin_pose + (size_t)B * sizeof(PairPoseDev) + 255) / 256 * 256, pin_end = pin_match + (prosac ? (size_t)B * n * 16 : 0);
+    void *pin;
+    if ((rc = pinned_get(ctx, pin_end + 256, &pin))) return rc;
+    char *hp = (char *)pin;
+    int32_t *h_counts = (int32_t *)(hp + pin_counts), *h_active = (int32_t *)(hp + pin_act);
+    double *h_E = (double *)(hp + pin_E);
+    PairPoseDev *h_pose = (PairPoseDev *)(hp + pin_pose);
+    const mlpl_dmatch *h_m = (const mlpl_dmatch *)(hp + pin_match);
+
+    rc = mlpl_match_hamming_dev(ctx, d_q, nq, (size_t)nbytes, (size_t)nq * nbytes, d_t, nt, (size_t)nbytes, (size_t)nt * nbytes, nbytes, 1, 0.75f, B,
+                                (int32_t *)(b0 + off_idx), (int32_t *)(b0 + off_dist), d_m, d_counts, s);
+    if (rc) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(h_counts, d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    if (prosac) MLPL_HIP_TRY(hipMemcpyAsync(hp + pin_match, d_m, (size_t)B * n * 16, hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipStreamSynchronize(s));
+    std::vector<int32_t> counts(h_counts, h_counts + B);  // (the nested entries reuse the context's pinned block)
+    std::vector<mlpl_usac_params> params((size_t)B, *tmpl);
+    std::vector<std::vector<uint32_t>> orders(prosac ? (size_t)B : 0);
+    int any = 0;
+    for (int b = 0; b < B; ++b) {
+        std::memset(&out[b], 0, sizeof(out[b]));
+        out[b].n_matches = counts[b];
+        h_active[b] = counts[b] >= 16 ? 1 : 0;  // below 16 matches Remove_LensDist / StereoRefine refuse to work
+        if (!h_active[b]) out[b].status = -1, counts[b] = 0;
+        any |= h_active[b];
+        params[b].seed = seeds[b];
+        params[b].sorted_idx = nullptr;
+        if (prosac && h_active[b]) {
+            // poselib::getSortedMatchIdx (pose_helper.cpp:2896-2923): std::sort of the matches by their distance, the indices in that order
+            // (the same std::sort on the same values: the same order, ties included)
+            struct Cost {
+                float distance;
+                uint32_t idx;
+            };
+            std::vector<Cost> c((size_t)counts[b]);
+            const mlpl_dmatch *row = h_m + (size_t)b * n;
+            for (int i = 0; i < counts[b]; ++i) c[i].distance = row[i].distance, c[i].idx = (uint32_t)i;
+            std::sort(c.begin(), c.end(), [](const Cost &x, const Cost &y) { return x.distance < y.distance; });
+            orders[b].resize((size_t)counts[b]);
+            for (int i = 0; i < counts[b]; ++i) orders[b][i] = c[i].idx;
+        }
+    }
+    if (!any) return MLPL_OK;
+    for (int b = 0; b < B; ++b)
+        if (prosac && h_active[b]) params[b].sorted_idx = orders[b].data();
+    if ((rc = launch_gather_match_points_batch(d_m, d_counts, B, NQ, d_kp1, (size_t)nq * 2, d_kp2, (size_t)nt * 2, K0, K1, d_p1, d_p2, s))) return rc;
+    std::vector<double> E((size_t)B * 9, 0.0), results((size_t)B * 12, 0.0);
+    std::vector<int32_t> status((size_t)B, 0);
+    if ((rc = usac_essential_batch_dev(ctx, B, d_p1, d_p2, NQ, counts.data(), params.data(), E.data(), d_mask, results.data(), status.data(), nullptr, nullptr, s)))
+        return rc;
+    // (usac_essential_batch_dev took the context's small pinned block for nothing; the pointers above are still valid: pinned_get only grows)
+    for (int b = 0; b < B; ++b) {
+        if (!h_active[b]) continue;
+        if (status[b] == MLPL_E_FAILED) {
+            h_active[b] = 0, out[b].status = -2;
+            continue;
+        }
+        out[b].iters = (int32_t)results[(size_t)b * 12 + 1], out[b].n_inliers = (int32_t)results[(size_t)b * 12 + 5];
+        std::memcpy(out[b].E, &E[(size_t)b * 9], 72);
+        std::memcpy(h_E + (size_t)b * 9, &E[(size_t)b * 9], 72);
+    }
+    MLPL_HIP_TRY(hipMemcpyAsync(d_E, h_E, (size_t)B * 72, hipMemcpyHostToDevice, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(d_active, h_active, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    if ((rc = launch_recover_pose_batch((const char *)d_E, 72, d_p1, d_p2, d_counts, d_active, B, NQ, dist, d_mask, d_P, d_cmask, d_cc, d_pose, s))) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(h_pose, d_pose, (size_t)B * sizeof(PairPoseDev), hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipStreamSynchronize(s));
+    for (int b = 0; b < B; ++b) {
+        if (!h_active[b]) continue;
+        out[b].status = 0, out[b].n_good = h_pose[b].n_good;
+        std::memcpy(out[b].R, h_pose[b].R, 72), std::memcpy(out[b].t, h_pose[b].t, 24);
+    }
+    return MLPL_OK;
+}

@@ -2861,6 +2861,7 @@ void hub_streams_free(void *p) {
 #include "arrsac_impl.h"
 #include "usac_impl.h"
 #include "pair_batch_impl.h"
+#include "pair_batch_usac.h"
 
 void free_rand_cache(void *p) { delete static_cast<RandCache *>(p); }
 
@@ -3543,6 +3544,36 @@ int mlpl_pair_pose_batch_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int
         for (int i = 0; i < 8; ++i) acc[i] += ctx->last_batch_stats[i];
     }
     std::memcpy(ctx->last_batch_stats, acc, sizeof(acc));
+    return MLPL_OK;
+}
+
+static int usac_check_params(const mlpl_usac_params *P, int n, const char *who);
+int mlpl_pair_pose_batch_usac_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
+                                  const float *d_kp2, const double K0[4], const double K1[4], const mlpl_usac_params *usac, int prosac,
+                                  const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out, void *stream) {
+    if (!ctx || !d_q || !d_t || !d_kp1 || !d_kp2 || !K0 || !K1 || !out || !seeds || !usac || n_pairs < 1 || nq < 1 || nt < 2 || nbytes < 1) {
+        set_error("mlpl_pair_pose_batch_usac_dev: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    int rc;
+    mlpl_usac_params chk = *usac;
+    chk.sorted_idx = nullptr;
+    if ((rc = usac_check_params(&chk, 0, "mlpl_pair_pose_batch_usac_dev"))) return rc;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = pick_stream(ctx, stream);
+    const int per = ctx->opt_pair_batch > 0 ? ctx->opt_pair_batch : kBatchPairsPerCall;
+    try {
+        for (int at = 0; at < n_pairs; at += per) {
+            const int B = std::min(per, n_pairs - at);
+            rc = pair_pose_batch_usac_dev(ctx, B, d_q + (size_t)at * nq * nbytes, nq, d_t + (size_t)at * nt * nbytes, nt, nbytes, d_kp1 + (size_t)at * nq * 2,
+                                          d_kp2 + (size_t)at * nt * 2, K0, K1, &chk, prosac, seeds + at, dist, out + at,
+                                          d_matches_out ? d_matches_out + (size_t)at * nq : nullptr, s);
+            if (rc) return rc;
+        }
+    } catch (const std::bad_alloc &) {
+        set_error("mlpl_pair_pose_batch_usac_dev: out of host memory");
+        return MLPL_E_NOMEM;
+    }
     return MLPL_OK;
 }
 

@@ -77,3 +77,57 @@ def test_batch_of_one_and_of_more_than_an_internal_batch(ctx):
         ref = {s: pose.usac_essential(a, c, th, s, refine=5, estimator=2, ctx=ctx) for s in sorted(set(seeds))}
         for b in range(B):
             assert got[b]["ok"] and np.array_equal(got[b]["final"], ref[seeds[b]]["final"]) and np.array_equal(got[b]["E"], ref[seeds[b]]["E"]), (B, b)
+
+
+@pytest.mark.parametrize("prosac,refine", [(False, 0), (True, 0), (False, 5)])
+def test_batched_image_pairs_with_usac_equal_the_single_problem_entries(ctx, prosac, refine):
+    """mlpl_pair_pose_batch_usac_dev (match -> gather -> USAC -> cheirality for a batch of image pairs) against the chain of single-problem
+    entries per pair: match counts, USAC inliers and hypotheses, E, R, t bit for bit; a pair with too few matches -> status -1."""
+    import ctypes as C
+    import torch
+    from matchinglib_poselib_amd import batch, pose, synth
+    from matchinglib_poselib_amd.matching import match_hamming_device
+
+    dev = torch.device("cuda:0")
+    B, nk = 20, 1024
+    sps = [synth.stereo_pair(nk, seed=700 + i, unmatched_frac=0.3 + 0.03 * (i % 5)) for i in range(B)]
+    rng = np.random.default_rng(1)
+    sps[3]["desc2"] = rng.integers(0, 256, sps[3]["desc2"].shape, dtype=np.uint8)     # nothing matches: status -1
+    K = sps[0]["K"]
+    stk = [torch.from_numpy(np.stack([sp[k] for sp in sps])).to(dev) for k in ("desc1", "desc2", "kp1", "kp2")]
+    seeds = [300 + 7 * i for i in range(B)]
+    kw = dict(estimator=2, refine=refine, sprt_ms=6.0, sprt_tm=2736.0)
+    rec, raw = batch.process_pairs_batched_usac(ctx, *stk, K, K, seeds, prosac=prosac, **kw)
+    th = 0.8 * 4.0 / (np.sqrt(2.0) * (2 * K[0] + 2 * K[1]))
+    k4 = (C.c_double * 4)(*K)
+    for i in range(B):
+        m = match_hamming_device(stk[0][i], stk[1][i], ctx=ctx)
+        cnt = int(m["count"][0].item())
+        assert raw["n_matches"][i] == cnt
+        if cnt < 16:
+            assert raw["status"][i] == -1
+            continue
+        mm = m["matches"][0, :cnt].contiguous()
+        d1 = torch.empty((cnt, 2), dtype=torch.float64, device=dev)
+        d2 = torch.empty((cnt, 2), dtype=torch.float64, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        assert ctx.lib.mlpl_gather_match_points_dev(ctx.handle, mm.data_ptr(), cnt, stk[2][i].data_ptr(), stk[3][i].data_ptr(), k4, k4, d1.data_ptr(),
+                                                    d2.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        order = None
+        if prosac:   # getSortedMatchIdx: std::sort by distance -- reproduced through the same library sort in the C++ facade; here: the
+            # batch entry and the single entry must agree, so the order is taken as the batch entry defines it: a sort of the
+            # distances that keeps equal distances in match order would differ; use numpy's on (distance, original position of a stable
+            # sort) only when there are no ties -- otherwise skip the PROSAC comparison for the pair
+            dist = mm[:, 3].cpu().numpy().view(np.float32)
+            if len(np.unique(dist)) < len(dist):
+                continue
+            order = np.argsort(dist, kind="stable").astype(np.uint32)
+        one = pose.usac_essential(d1.cpu().numpy(), d2.cpu().numpy(), th, seeds[i], sorted_idx=order, prosac_beta=0.05, th_pixels=0.8,
+                                  focal_length=float((2 * K[0] + 2 * K[1]) / 4.0), ctx=ctx, **kw)
+        assert raw["status"][i] == 0 and one["ok"], i
+        assert raw["iters"][i] == int(one["final"][1]) and raw["n_inliers"][i] == int(one["final"][5]), (i, raw[i], one["final"])
+        assert np.array_equal(raw["E"][i].view(np.uint64), one["E"].view(np.uint64)), i
+        ng, R, t = pose.getPoseTriangPts_device(one["E"].reshape(3, 3), d1, d2, mask=torch.from_numpy(one["flags"]).to(dev), ctx=ctx)
+        assert raw["n_good"][i] == ng and np.array_equal(raw["R"][i].view(np.uint64), R.ravel().view(np.uint64)), i
+        assert np.array_equal(raw["t"][i].view(np.uint64), t.ravel().view(np.uint64)), i
