@@ -370,4 +370,63 @@ def run(ctx, dev, cpu_baseline=True):
         c.close()
     out["arrsac_default_method_4_in_flight"] = {"metric": "the same call from 4 host threads with one library context each", "ms_per_call": dt4 * 1e3,
                                                 "value": 1.0 / dt4, "unit": "calls/s"}
+    # ---- C5 with the reference harness' DEFAULT estimator: USAC (T/poselib-test/main.cpp:734), 512 pairs in one call ----
+    out.update(c5_usac(ctx, dev, cpu_baseline))
     return out
+
+
+def c5_usac(ctx, dev, cpu_baseline=True, total=512, nk=8192, distinct=8, steps=3):
+    """512 stereo pairs x (8192-keypoint ORB match -> gather -> USAC (POSE_STEWENIUS + REF_WEIGHTS, the harness' cfgUSAC) -> cheirality) through
+    mlpl_pair_pose_batch_usac_dev: every pair's sequential USAC program on its own host thread, every launch merged over the pairs
+    (csrc/batch_hub.h).  PROSAC in the order of the matching costs (what estimateEssentialOrPoseUSAC does with cfg.matches) and uniform."""
+    import torch
+    from matchinglib_poselib_amd import batch, synth
+
+    sps = [synth.stereo_pair(nk, seed=20260200 + i, unmatched_frac=0.30 + 0.02 * (i % 8)) for i in range(distinct)]
+    K = sps[0]["K"]
+    stk = [torch.from_numpy(np.stack([sps[i % distinct][k] for i in range(total)])).to(dev) for k in ("desc1", "desc2", "kp1", "kp2")]
+    seeds = [100 + i for i in range(total)]
+    res = {}
+    for name, prosac, refine in (("c5_usac_batch_prosac", True, 0), ("c5_usac_batch_uniform", False, 0), ("c5_usac_batch_default_refinement_prosac", True, 5)):
+        kw = dict(prosac=prosac, refine=refine)
+        rec, raw = batch.process_pairs_batched_usac(ctx, *stk, K, K, seeds, **kw)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            rec, raw = batch.process_pairs_batched_usac(ctx, *stk, K, K, seeds, **kw)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        st = np.zeros(8, np.int64)
+        ctx.lib.mlpl_usac_last_stats(ctx.handle, st.ctypes.data)
+        assert (raw["status"] == 0).all()
+        res[name] = {"metric": "image-pairs/s (C5 with USAC: 8k ORB BF-Hamming match + USAC essential matrix + cheirality), one GPU, one call",
+                     "value": total / min(ts), "unit": "image-pairs/s", "ms_per_step": min(ts) * 1e3, "ms_steps": [round(t * 1e3, 2) for t in ts],
+                     "pairs": total, "sampling": "PROSAC by matching cost" if prosac else "uniform",
+                     "refinement": "REF_WEIGHTS (harness cfgUSAC)" if refine == 0 else "REF_STEWENIUS_WEIGHTS (ConfigUSAC's default)",
+                     "mean_matches": float(raw["n_matches"].mean()), "mean_inliers": float(raw["n_inliers"].mean()), "mean_hypotheses": float(raw["iters"].mean()),
+                     "hub_last_internal_call": {"rounds": int(st[0]), "merged_launches": int(st[1]), "hub_waiting_for_host_ms": st[2] / 1e3,
+                                                "device_ms": st[3] / 1e3}}
+        if cpu_baseline and name == "c5_usac_batch_uniform":
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
+            ora = oracle_lib.load()
+            ncpu = 2
+            tc = time.perf_counter()
+            for i in range(ncpu):
+                sp = sps[i % distinct]
+                rc, mm = ora.get_matches_linear(nk, nk, sp["desc1"], sp["desc2"])
+                a, b = sp["kp1"][mm["queryIdx"]], sp["kp2"][mm["trainIdx"]]
+                cam = lambda p: np.stack([((p[:, 0].astype(np.float64) - K[2]) / K[0]).astype(np.float32),  # noqa: E731
+                                          ((p[:, 1].astype(np.float64) - K[3]) / K[1]).astype(np.float32)], axis=1).astype(np.float64)
+                p1, p2 = cam(a), cam(b)
+                th = 0.8 * 4.0 / (np.sqrt(2.0) * (2 * K[0] + 2 * K[1]))
+                o = ora.usac_essential(p1, p2, th, seeds[i], sprt_ms=6.0, sprt_tm=2736.0)
+                good, R, t, Q, mk = ora.recover_pose(o["E"], p1, p2, 50.0, o["flags"])
+                assert len(mm) == raw["n_matches"][i] and int(o["final"][5]) == raw["n_inliers"][i] and int(o["final"][1]) == raw["iters"][i], "pair record differs from the CPU path"
+                assert np.abs(raw["R"][i].reshape(3, 3) - R).max() < 1e-6 and np.abs(raw["t"][i] - t.ravel()).max() < 1e-6
+            tc = time.perf_counter() - tc
+            res[name]["cpu_baseline"] = {"value": ncpu / tc, "unit": "image-pairs/s", "cores": 1, "kind": "port",
+                                         "sample": f"the first {ncpu} pairs through the oracle pipeline (LINEAR matching, USAC oracle, recoverPose), {tc:.1f} s; "
+                                                   "their records equal the batch's (counts and hypotheses exact, R, t to 1e-6)"}
+    return res

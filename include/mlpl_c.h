@@ -409,6 +409,9 @@ int mlpl_pair_pose_batch_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int
 int mlpl_pair_pose_batch_usac_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
                                   const float *d_kp2, const double K0[4], const double K1[4], const mlpl_usac_params *usac, int prosac,
                                   const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out, void *stream);
+/* poselib::getSortedMatchIdx (P/source/pose_helper.cpp:2896-2923) on a HOST match list: the indices of the matches in the order
+ * std::sort leaves them when comparing the distances -- the PROSAC order estimateEssentialOrPoseUSAC and the batch entry above use. */
+int mlpl_sorted_match_idx(const mlpl_dmatch *matches, int n, uint32_t *sorted_idx);
 /* The same batch behind the matching -- the batched form of mlpl_ransac_essential_dev (refit = 0) followed, with recover_pose != 0, by
  * mlpl_recover_pose_dev on the RANSAC inliers: problem b's correspondences are d_p1 / d_p2 + b * stride * 2 (camera coordinates, n x 2
  * doubles, device), counts[b] <= stride of them (host array), seeds[b] its srand() seed.  Records as above with n_matches = counts[b];

@@ -9,6 +9,19 @@
 // Per pair the record is what the single-problem entries return for it: mlpl_match_hamming_dev + mlpl_gather_match_points_dev ->
 // mlpl_usac_essential_dev (same parameters, seed and PROSAC order) -> mlpl_recover_pose_dev (tests/test_gpu_usac_batch.py).
 
+// poselib::getSortedMatchIdx (pose_helper.cpp:2896-2923): std::sort of the matches by their distance, the indices in that order (the same
+// std::sort on the same values: the same order, ties included)
+void sorted_match_idx(const mlpl_dmatch *matches, int count, uint32_t *out) {
+    struct Cost {
+        float distance;
+        uint32_t idx;
+    };
+    std::vector<Cost> c((size_t)count);
+    for (int i = 0; i < count; ++i) c[i].distance = matches[i].distance, c[i].idx = (uint32_t)i;
+    std::sort(c.begin(), c.end(), [](const Cost &x, const Cost &y) { return x.distance < y.distance; });
+    for (int i = 0; i < count; ++i) out[i] = c[i].idx;
+}
+
 int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
                              const float *d_kp2, const double K0[4], const double K1[4], const mlpl_usac_params *tmpl, int prosac,
                              const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out, hipStream_t s) {
@@ -60,18 +73,8 @@ int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, c
         params[b].seed = seeds[b];
         params[b].sorted_idx = nullptr;
         if (prosac && h_active[b]) {
-            // poselib::getSortedMatchIdx (pose_helper.cpp:2896-2923): std::sort of the matches by their distance, the indices in that order
-            // (the same std::sort on the same values: the same order, ties included)
-            struct Cost {
-                float distance;
-                uint32_t idx;
-            };
-            std::vector<Cost> c((size_t)counts[b]);
-            const mlpl_dmatch *row = h_m + (size_t)b * n;
-            for (int i = 0; i < counts[b]; ++i) c[i].distance = row[i].distance, c[i].idx = (uint32_t)i;
-            std::sort(c.begin(), c.end(), [](const Cost &x, const Cost &y) { return x.distance < y.distance; });
             orders[b].resize((size_t)counts[b]);
-            for (int i = 0; i < counts[b]; ++i) orders[b][i] = c[i].idx;
+            sorted_match_idx(h_m + (size_t)b * n, counts[b], orders[b].data());
         }
     }
     if (!any) return MLPL_OK;

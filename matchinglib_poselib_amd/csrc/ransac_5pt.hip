@@ -3547,6 +3547,17 @@ int mlpl_pair_pose_batch_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int
     return MLPL_OK;
 }
 
+int mlpl_sorted_match_idx(const mlpl_dmatch *matches, int n, uint32_t *sorted_idx) {
+    if ((!matches || !sorted_idx) && n > 0) return MLPL_E_BAD_INPUT;
+    if (n < 0) return MLPL_E_BAD_INPUT;
+    try {
+        sorted_match_idx(matches, n, sorted_idx);
+    } catch (const std::bad_alloc &) {
+        return MLPL_E_NOMEM;
+    }
+    return MLPL_OK;
+}
+
 static int usac_check_params(const mlpl_usac_params *P, int n, const char *who);
 int mlpl_pair_pose_batch_usac_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
                                   const float *d_kp2, const double K0[4], const double K1[4], const mlpl_usac_params *usac, int prosac,

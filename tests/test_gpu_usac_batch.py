@@ -115,14 +115,12 @@ def test_batched_image_pairs_with_usac_equal_the_single_problem_entries(ctx, pro
                                                     d2.data_ptr(), st) == 0
         torch.cuda.synchronize()
         order = None
-        if prosac:   # getSortedMatchIdx: std::sort by distance -- reproduced through the same library sort in the C++ facade; here: the
-            # batch entry and the single entry must agree, so the order is taken as the batch entry defines it: a sort of the
-            # distances that keeps equal distances in match order would differ; use numpy's on (distance, original position of a stable
-            # sort) only when there are no ties -- otherwise skip the PROSAC comparison for the pair
-            dist = mm[:, 3].cpu().numpy().view(np.float32)
-            if len(np.unique(dist)) < len(dist):
-                continue
-            order = np.argsort(dist, kind="stable").astype(np.uint32)
+        if prosac:   # poselib::getSortedMatchIdx: std::sort by the matching cost (integer Hamming distances: many ties)
+            mh = np.ascontiguousarray(mm.cpu().numpy())
+            order = np.zeros(cnt, np.uint32)
+            assert ctx.lib.mlpl_sorted_match_idx(mh.ctypes.data, cnt, order.ctypes.data) == 0
+            dist = mh[:, 3].view(np.float32)
+            assert sorted(order.tolist()) == list(range(cnt)) and (np.diff(dist[order]) >= 0).all() and len(np.unique(dist)) < cnt
         one = pose.usac_essential(d1.cpu().numpy(), d2.cpu().numpy(), th, seeds[i], sorted_idx=order, prosac_beta=0.05, th_pixels=0.8,
                                   focal_length=float((2 * K[0] + 2 * K[1]) / 4.0), ctx=ctx, **kw)
         assert raw["status"][i] == 0 and one["ok"], i
