@@ -72,12 +72,20 @@ int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, c
         any |= h_active[b];
         params[b].seed = seeds[b];
         params[b].sorted_idx = nullptr;
-        if (prosac && h_active[b]) {
-            orders[b].resize((size_t)counts[b]);
-            sorted_match_idx(h_m + (size_t)b * n, counts[b], orders[b].data());
-        }
     }
     if (!any) return MLPL_OK;
+    if (prosac) {  // the orders on the run threads, all pairs at once (a std::sort of 5000 costs takes 0.3 ms: 150 ms for 512 pairs on one thread)
+        HubThreads &pool = hub_resources(ctx)->threads;
+        const int T = std::min(B, 32);
+        pool.start(T, [&](int k) {
+            for (int b = k; b < B; b += T)
+                if (h_active[b]) {
+                    orders[b].resize((size_t)counts[b]);
+                    sorted_match_idx(h_m + (size_t)b * n, counts[b], orders[b].data());
+                }
+        });
+        pool.wait();
+    }
     for (int b = 0; b < B; ++b)
         if (prosac && h_active[b]) params[b].sorted_idx = orders[b].data();
     if ((rc = launch_gather_match_points_batch(d_m, d_counts, B, NQ, d_kp1, (size_t)nq * 2, d_kp2, (size_t)nt * 2, K0, K1, d_p1, d_p2, s))) return rc;

@@ -2572,9 +2572,13 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
         pin_dev = (char *)alias;
     }
     double *h_p1 = (double *)pin, *h_p2 = (double *)(pin + pts_bytes);
-    MLPL_HIP_TRY(hipMemcpyAsync(h_p1, d_p1, (size_t)B * stride * 16, hipMemcpyDeviceToHost, s));
-    MLPL_HIP_TRY(hipMemcpyAsync(h_p2, d_p2, (size_t)B * stride * 16, hipMemcpyDeviceToHost, s));
-    MLPL_HIP_TRY(hipStreamSynchronize(s));
+    {   // only the rows in use: counts[b] <= max_n of the stride rows of a problem
+        int max_n = 1;
+        for (int b = 0; b < B; ++b) max_n = std::max(max_n, counts[b]);
+        MLPL_HIP_TRY(hipMemcpy2DAsync(h_p1, (size_t)stride * 16, d_p1, (size_t)stride * 16, (size_t)max_n * 16, (size_t)B, hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipMemcpy2DAsync(h_p2, (size_t)stride * 16, d_p2, (size_t)stride * 16, (size_t)max_n * 16, (size_t)B, hipMemcpyDeviceToHost, s));
+        MLPL_HIP_TRY(hipStreamSynchronize(s));
+    }
     char *run_pin = pin + 2 * pts_bytes, *run_pin_dev = pin_dev + 2 * pts_bytes;
     long long rounds = 0, merged = 0, host_us = 0, device_us = 0, spawn_us = 0;
     const auto t_all = std::chrono::steady_clock::now();
