@@ -248,6 +248,15 @@ int mlpl_arrsac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int
                           double E[9], uint8_t *mask, int *n_inliers);
 int mlpl_arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thresh, int refine,
                               uint64_t rng_state[2], double E[9], uint8_t *d_mask, int *n_inliers, void *stream);
+/* A batch of ARRSAC problems in one call (estimateEssentialMat's default method, pose_estim.h:207): problem b = correspondences d_p1 / d_p2 +
+ * b * stride * 2 doubles (device), counts[b] in [6, stride] of them (host), its own pair of cv::RNG states rng_states[2 b], [2 b + 1] (host,
+ * in / out -- the reference's samplers draw from process-wide streams; here every problem owns a pair, so problems do not depend on each
+ * other).  Every problem runs the sequential program of mlpl_arrsac_essential_dev on its own host thread and the launches of all runs that
+ * stand at the same point of their control flow are merged into one launch per kernel (csrc/batch_hub.h), 128 problems at a time.
+ * Outputs per problem: status[b] (0; MLPL_E_FAILED; other < 0 end the call), E + 9 b, n_inliers[b] (optional), its inlier mask at d_masks +
+ * b * stride (device) -- what mlpl_arrsac_essential_dev returns for the problem alone with the same stream states. */
+int mlpl_arrsac_essential_batch_dev(mlpl_ctx *ctx, int n_problems, const double *d_p1, const double *d_p2, int stride, const int32_t *counts, double thresh,
+                                    int refine, uint64_t *rng_states, double *E, uint8_t *d_masks, int32_t *n_inliers, int32_t *status, void *stream);
 /*
  * poselib::robustEssentialRefine(points1, points2, E_init, E_refined, th, 0, true, ..., mask, 0) (pose_estim.h:225-228,
  * pose_estim.cpp:337-792) for the essential-matrix model without normalisation: iteratively re-weighted (pseudo-Huber on the Sampson

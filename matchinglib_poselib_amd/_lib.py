@@ -91,6 +91,8 @@ _SIGNATURES = {
     "mlpl_arrsac_essential": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mlpl_arrsac_essential_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p]),
+    "mlpl_arrsac_essential_batch_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_void_p]),
     "mlpl_arrsac_last_stats": (c_int, [c_void_p, c_void_p]),
     "mlpl_arrsac_sample_models": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "mlpl_robust_essential_refine": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p]),

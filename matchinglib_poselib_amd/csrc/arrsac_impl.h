@@ -204,16 +204,32 @@ __device__ __forceinline__ double arr_row_elem(const double *p, int a) {  // epi
     }
 }
 
-__global__ __launch_bounds__(64) void arrsac_sample_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
-                                                           const int32_t *__restrict__ smp, int n_samples, PolyRec *__restrict__ recs,
-                                                           double *__restrict__ direct_E, int32_t *__restrict__ direct_ok) {
+struct ArrSampleArgs {
+    KHdr hdr;
+    const double * p1;
+    const double * p2;
+    const int32_t * smp;
+    int n_samples;
+    PolyRec * recs;
+    double * direct_E;
+    int32_t * direct_ok;
+};
+__device__ __forceinline__ void arrsac_sample_body(const ArrSampleArgs &A, const int vbx, const int vby) {
+    const double *__restrict__ p1 = A.p1;
+    const double *__restrict__ p2 = A.p2;
+    const int32_t *__restrict__ smp = A.smp;
+    const int n_samples = A.n_samples;
+    PolyRec *__restrict__ recs = A.recs;
+    double *__restrict__ direct_E = A.direct_E;
+    int32_t *__restrict__ direct_ok = A.direct_ok;
+
     __shared__ SolveLds L;
     __shared__ Jacobi9Lds J;
     __shared__ double xn[kArrMaxSample][4];
     __shared__ double nrm[6];
     __shared__ int s_ok;
     if (blockDim.x != kSolverThreads) __builtin_trap();
-    const int lane = threadIdx.x, b = blockIdx.x;
+    const int lane = threadIdx.x, b = vbx;
     if (b >= n_samples) return;
     const int32_t *sm = smp + (size_t)b * kArrSmpStride;
     const int m = sm[0], kind = sm[15];
@@ -315,18 +331,49 @@ __global__ __launch_bounds__(64) void arrsac_sample_kernel(const double *__restr
         }
     }
 }
+MLPL_HUB_KERNEL(HK_ARR_SAMPLE, ArrSampleArgs, arrsac_sample_body, 64);
 
-__global__ __launch_bounds__(64) void arrsac_check_kernel(const double4 *__restrict__ pts, int flag_points, const double *__restrict__ p1,
-                                                          const double *__restrict__ p2, const int32_t *__restrict__ smp, int n_samples,
-                                                          double *__restrict__ E_tab, const int32_t *__restrict__ n_models,
-                                                          const double *__restrict__ direct_E, const int32_t *__restrict__ direct_ok,
-                                                          double thresh2, int32_t *__restrict__ out_nm, int32_t *__restrict__ out_valid,
-                                                          double *__restrict__ out_e00, unsigned long long *__restrict__ out_head,
-                                                          unsigned long long *__restrict__ flag_rows) {
+struct ArrCheckArgs {
+    KHdr hdr;
+    const double4 * pts;
+    int flag_points;
+    const double * p1;
+    const double * p2;
+    const int32_t * smp;
+    int n_samples;
+    double * E_tab;
+    const int32_t * n_models;
+    const double * direct_E;
+    const int32_t * direct_ok;
+    double thresh2;
+    int32_t * out_nm;
+    int32_t * out_valid;
+    double * out_e00;
+    unsigned long long * out_head;
+    unsigned long long * flag_rows;
+};
+__device__ __forceinline__ void arrsac_check_body(const ArrCheckArgs &A, const int vbx, const int vby) {
+    const double4 *__restrict__ pts = A.pts;
+    const int flag_points = A.flag_points;
+    const double *__restrict__ p1 = A.p1;
+    const double *__restrict__ p2 = A.p2;
+    const int32_t *__restrict__ smp = A.smp;
+    const int n_samples = A.n_samples;
+    double *__restrict__ E_tab = A.E_tab;
+    const int32_t *__restrict__ n_models = A.n_models;
+    const double *__restrict__ direct_E = A.direct_E;
+    const int32_t *__restrict__ direct_ok = A.direct_ok;
+    const double thresh2 = A.thresh2;
+    int32_t *__restrict__ out_nm = A.out_nm;
+    int32_t *__restrict__ out_valid = A.out_valid;
+    double *__restrict__ out_e00 = A.out_e00;
+    unsigned long long *__restrict__ out_head = A.out_head;
+    unsigned long long *__restrict__ flag_rows = A.flag_rows;
+
     __shared__ double q[1][4];  // the epipole and the singular-value verdict, lane 0 -> wave
     if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
     const int lane = threadIdx.x;
-    const int b = blockIdx.x / 10, slot = blockIdx.x - b * 10;
+    const int b = vbx / 10, slot = vbx - b * 10;
     if (b >= n_samples) return;
     const int32_t *sm = smp + (size_t)b * kArrSmpStride;
     const int m = sm[0], kind = sm[15];
@@ -386,25 +433,58 @@ __global__ __launch_bounds__(64) void arrsac_check_kernel(const double4 *__restr
     }
     if (lane == 0) out_e00[b * 10 + slot] = e[0];
 }
+MLPL_HUB_KERNEL(HK_ARR_CHECK, ArrCheckArgs, arrsac_check_body, 64);
 
 // Rows of the device-side model pool the host asks for (accepted hypotheses; models of the preemptive stage's generation branch):
 // out[i] = { E[9], bits[16] } of pool row rows[i].
-__global__ void arrsac_gather_kernel(const int32_t *__restrict__ rows, int n_rows, const double *__restrict__ E_pool,
-                                     const unsigned long long *__restrict__ F_pool, double *__restrict__ out) {
-    const int i = blockIdx.x, t = threadIdx.x;
+struct ArrGatherArgs {
+    KHdr hdr;
+    const int32_t * rows;
+    int n_rows;
+    const double * E_pool;
+    const unsigned long long * F_pool;
+    double * out;
+};
+__device__ __forceinline__ void arrsac_gather_body(const ArrGatherArgs &A, const int vbx, const int vby) {
+    const int32_t *__restrict__ rows = A.rows;
+    const int n_rows = A.n_rows;
+    const double *__restrict__ E_pool = A.E_pool;
+    const unsigned long long *__restrict__ F_pool = A.F_pool;
+    double *__restrict__ out = A.out;
+
+    const int i = vbx, t = threadIdx.x;
     if (i >= n_rows || t >= 9 + kArrFlagWords) return;
     const size_t row = (size_t)rows[i];
     double *o = out + (size_t)i * (9 + kArrFlagWords);
     if (t < 9) o[t] = E_pool[row * 9 + t];
     else reinterpret_cast<unsigned long long *>(o)[t] = F_pool[row * kArrFlagWords + (t - 9)];
 }
+MLPL_HUB_KERNEL(HK_ARR_GATHER, ArrGatherArgs, arrsac_gather_body, 32);
 
 // Inlier bits of pool models over ALL n correspondences (the preemptive stage beyond the first kArrFlagPoints: reached when the
 // hypothesis set keeps growing instead of halving, i.e. at inlier ratios above ~0.9): out[i] = words_full words for pool row rows[i].
-__global__ __launch_bounds__(64) void arrsac_extend_kernel(const int32_t *__restrict__ rows, int n_rows, const double4 *__restrict__ pts, int n,
-                                                           int words_full, const double *__restrict__ E_pool, double thresh2,
-                                                           unsigned long long *__restrict__ out) {
-    const int i = blockIdx.x, lane = threadIdx.x;
+struct ArrExtendArgs {
+    KHdr hdr;
+    const int32_t * rows;
+    int n_rows;
+    const double4 * pts;
+    int n;
+    int words_full;
+    const double * E_pool;
+    double thresh2;
+    unsigned long long * out;
+};
+__device__ __forceinline__ void arrsac_extend_body(const ArrExtendArgs &A, const int vbx, const int vby) {
+    const int32_t *__restrict__ rows = A.rows;
+    const int n_rows = A.n_rows;
+    const double4 *__restrict__ pts = A.pts;
+    const int n = A.n;
+    const int words_full = A.words_full;
+    const double *__restrict__ E_pool = A.E_pool;
+    const double thresh2 = A.thresh2;
+    unsigned long long *__restrict__ out = A.out;
+
+    const int i = vbx, lane = threadIdx.x;
     if (i >= n_rows) return;
     double e[9];
 #pragma unroll
@@ -420,6 +500,7 @@ __global__ __launch_bounds__(64) void arrsac_extend_kernel(const int32_t *__rest
         if (lane == 0) out[(size_t)i * words_full + w] = bal;
     }
 }
+MLPL_HUB_KERNEL(HK_ARR_EXTEND, ArrExtendArgs, arrsac_extend_body, 64);
 
 // robustEssentialRefine(inliers, E_init, th, iters = 0, makeClosestE = true) (pose_estim.cpp:337-792; model 0, no normalisation): up to
 // 50 rounds of { pseudo-Huber weights on the Sampson distance under the current matrix (pose_helper.cpp:115-143, BA_driver.cpp:2639-2648),
@@ -430,9 +511,25 @@ __global__ __launch_bounds__(64) void arrsac_extend_kernel(const int32_t *__rest
 // 512 threads: the 46 running sums of a thread need ~130 registers; at 1024 threads per workgroup (four waves per SIMD, 128 registers
 // each) the compiler spilled 213 of them and every round spent 60 us in scratch traffic.
 constexpr int kArrRefineThreads = 512;
-__global__ __launch_bounds__(kArrRefineThreads) void arrsac_refine_kernel(const double4 *__restrict__ pts, const uint8_t *__restrict__ mask, int n,
-                                                             const double *__restrict__ E_init, double th, double *__restrict__ E_out,
-                                                             int32_t *__restrict__ info) {
+struct ArrRefineArgs {
+    KHdr hdr;
+    const double4 * pts;
+    const uint8_t * mask;
+    int n;
+    const double * E_init;
+    double th;
+    double * E_out;
+    int32_t * info;
+};
+__device__ __forceinline__ void arrsac_refine_body(const ArrRefineArgs &A, const int vbx, const int vby) {
+    const double4 *__restrict__ pts = A.pts;
+    const uint8_t *__restrict__ mask = A.mask;
+    const int n = A.n;
+    const double *__restrict__ E_init = A.E_init;
+    const double th = A.th;
+    double *__restrict__ E_out = A.E_out;
+    int32_t *__restrict__ info = A.info;
+
     __shared__ double red[kArrRefineThreads / 64][46];
     __shared__ double stage[16][kArrRefineThreads];
     __shared__ Jacobi9Lds J;
@@ -550,6 +647,7 @@ __global__ __launch_bounds__(kArrRefineThreads) void arrsac_refine_kernel(const 
     // reference), as distinct from 2 = fewer than 50 correspondences ("too less points", written above)
     if (tid == 0) info[0] = j, info[1] = (s_stop == 3) ? 3 : (s_stop == 2 ? 1 : 0);
 }
+MLPL_HUB_KERNEL(HK_ARR_REFINE, ArrRefineArgs, arrsac_refine_body, kArrRefineThreads);
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // host side
@@ -607,9 +705,17 @@ struct ArrIds {  // ids of a sample's VALID models in the order of the conventio
     const int *end() const { return id + n; }
 };
 
+struct ArrBufs {  // a run's buffers when the caller provides them (batched runs: one slice per run)
+    char *dev = nullptr, *pin = nullptr, *pin_dev = nullptr;
+};
+
 struct ArrsacRun {
     mlpl_ctx *ctx;
     hipStream_t s;
+    Launcher L;                    // launches now (a run alone) or records for the hub (a run of a batch, batch_hub.h)
+    const ArrBufs *bufs = nullptr;
+    int32_t *trace_buf = nullptr;  // turn records of the first stage (this run's buffer)
+    int trace_cap = 0, trace_len = 0;
     const double *d_p1, *d_p2;
     const double4 *pts;
     int n, flag_points;
@@ -619,8 +725,10 @@ struct ArrsacRun {
     PolyRec *d_recs = nullptr;
     double *d_direct = nullptr;
     int32_t *d_direct_ok = nullptr, *d_nm5 = nullptr;
-    char *d_out = nullptr, *h_out = nullptr, *h_out_dev = nullptr;
+    char *h_out = nullptr, *h_out_dev = nullptr;
     int32_t *h_smp = nullptr;
+    double *d_final = nullptr;     // [0..8] best model, [9..17] refined, then 4 ints: inlier count, refinement info
+    double *h_final = nullptr, *h_final_dev = nullptr;
     // results
     std::vector<ArrModelHost> pool;
     std::vector<ArrFullRow> full_rows;
@@ -643,31 +751,61 @@ struct ArrsacRun {
         const size_t batch = (size_t)B * 4 + (size_t)B * 40 + (size_t)B * 80 + (size_t)B * 10 * kArrHeadWords * 8 + 64;
         return std::max(batch, (size_t)B * 10 * sizeof(ArrFullRow) + (size_t)B * 40);  // the same blocks carry gathered rows
     }
+    struct Layout {
+        size_t d_pts, d_recs, d_direct, d_final, d_Epool, d_Fpool, dev_total;
+        size_t p_out, p_smp, p_final, pin_total;
+    };
+    static Layout layout(int n) {
+        Layout Y;
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        size_t o = 0;
+        Y.d_pts = o, o = up(o + (size_t)std::max(n, 1) * sizeof(double4));
+        Y.d_recs = o, o = up(o + (size_t)kArrBatchCap * sizeof(PolyRec));
+        Y.d_direct = o, o = up(o + (size_t)kArrBatchCap * (72 + 8));
+        Y.d_final = o, o = up(o + 256);
+        Y.d_Epool = o, o = up(o + (size_t)kArrPoolSamples * 720);
+        Y.d_Fpool = o, o = up(o + (size_t)kArrPoolSamples * 10 * kArrFlagWords * 8);
+        Y.dev_total = o + 256;
+        o = 0;
+        Y.p_out = o, o = up(o + std::max(out_bytes(kArrBatchCap), (size_t)((std::max(n, 1) + 63) / 64) * 8 + 8192));
+        Y.p_smp = o, o = up(o + (size_t)kArrBatchCap * kArrSmpStride * 4);
+        Y.p_final = o, o = up(o + 256);
+        Y.pin_total = o + 256;
+        return Y;
+    }
 
+    // buffers + the packed correspondences (a run alone takes the blocks from the context)
     int alloc() {
-        void *p;
-        int rc;
-        if ((rc = ws_get(ctx, WS_PARTIAL, (size_t)kArrBatchCap * sizeof(PolyRec), &p))) return rc;
-        d_recs = (PolyRec *)p;
-        if ((rc = ws_get(ctx, WS_AUX6, (size_t)kArrBatchCap * (72 + 8), &p))) return rc;
-        d_direct = (double *)p;
+        const Layout Y = layout(n);
+        char *dev, *pin, *pin_dev;
+        if (bufs) {
+            dev = bufs->dev, pin = bufs->pin, pin_dev = bufs->pin_dev;
+        } else {
+            void *p;
+            int rc;
+            if ((rc = ws_get(ctx, WS_ARR_E, Y.dev_total, &p))) return rc;
+            dev = (char *)p;
+            if ((rc = pinned_get(ctx, Y.pin_total, &p))) return rc;
+            pin = (char *)p;
+            void *alias = nullptr;
+            MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, pin, 0));
+            pin_dev = (char *)alias;
+        }
+        double4 *d_pts = (double4 *)(dev + Y.d_pts);
+        d_recs = (PolyRec *)(dev + Y.d_recs);
+        d_direct = (double *)(dev + Y.d_direct);
         d_direct_ok = (int32_t *)(d_direct + (size_t)kArrBatchCap * 9);
         d_nm5 = d_direct_ok + kArrBatchCap;
-        if ((rc = ws_get(ctx, WS_AUX5, out_bytes(kArrBatchCap), &p))) return rc;
-        d_out = (char *)p;
-        if ((rc = pinned_get(ctx, out_bytes(kArrBatchCap) + (size_t)kArrBatchCap * kArrSmpStride * 4, &p))) return rc;
-        h_out = (char *)p;
-        h_smp = (int32_t *)(h_out + out_bytes(kArrBatchCap));
-        // the sample table is read by the kernels straight from the pinned (mapped) host block: 64 bytes per wave, no copy command
-        void *dev_alias = nullptr;
-        MLPL_HIP_TRY(hipHostGetDevicePointer(&dev_alias, h_smp, 0));
-        d_smp = (int32_t *)dev_alias;
-        MLPL_HIP_TRY(hipHostGetDevicePointer(&dev_alias, h_out, 0));
-        h_out_dev = (char *)dev_alias;
-        if ((rc = ws_get(ctx, WS_ARR_E, (size_t)kArrPoolSamples * 720, &p))) return rc;
-        d_Epool = (double *)p;
-        if ((rc = ws_get(ctx, WS_ARR_F, (size_t)kArrPoolSamples * 10 * kArrFlagWords * 8, &p))) return rc;
-        d_Fpool = (unsigned long long *)p;
+        d_final = (double *)(dev + Y.d_final);
+        d_Epool = (double *)(dev + Y.d_Epool);
+        d_Fpool = (unsigned long long *)(dev + Y.d_Fpool);
+        // the sample table and the small per-model results live in the pinned (mapped) host block: the kernels read / write them directly
+        h_out = pin + Y.p_out, h_out_dev = pin_dev + Y.p_out;
+        h_smp = (int32_t *)(pin + Y.p_smp), d_smp = (int32_t *)(pin_dev + Y.p_smp);
+        h_final = (double *)(pin + Y.p_final), h_final_dev = (double *)(pin_dev + Y.p_final);
+        PackPtsArgs pa{{(n + 255) / 256, 1}, d_p1, d_p2, n, d_pts};
+        L.launch(HK_PACK_POINTS, pa);
+        pts = d_pts;
         return MLPL_OK;
     }
 
@@ -690,15 +828,16 @@ struct ArrsacRun {
         unsigned long long *o_head = (unsigned long long *)(o_base + off_head);
         double *o_E = d_Epool + (size_t)pool_samples * 90;
         unsigned long long *o_rows = d_Fpool + (size_t)pool_samples * 10 * kArrFlagWords;
-        hipLaunchKernelGGL(arrsac_sample_kernel, dim3(B), dim3(64), 0, s, d_p1, d_p2, (const int32_t *)d_smp, B, d_recs, d_direct, d_direct_ok);
-        MLPL_LAUNCH_ROOTS(ctx->opt_solver_polish, dim3((B + kHypPerWave - 1) / kHypPerWave), s, (const PolyRec *)d_recs, 0, B, o_E, d_nm5,
-                          (double *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
-        hipLaunchKernelGGL(arrsac_check_kernel, dim3(B * 10), dim3(64), 0, s, pts, flag_points, d_p1, d_p2, (const int32_t *)d_smp, B, o_E,
-                           (const int32_t *)d_nm5, (const double *)d_direct, (const int32_t *)d_direct_ok, thresh2, o_nm, o_valid, o_e00, o_head,
-                           o_rows);
-        MLPL_HIP_TRY(hipGetLastError());
+        ArrSampleArgs sa{{B, 1}, d_p1, d_p2, (const int32_t *)d_smp, B, d_recs, d_direct, d_direct_ok};
+        L.launch(HK_ARR_SAMPLE, sa);
+        RootsArgs ra{{(B + kHypPerWave - 1) / kHypPerWave, 1}, (const PolyRec *)d_recs, B, o_E, d_nm5};
+        L.launch(ctx->opt_solver_polish ? HK_ROOTS_POLISH : HK_ROOTS_PLAIN, ra);
+        ArrCheckArgs ca{{B * 10, 1}, pts, flag_points, d_p1, d_p2, (const int32_t *)d_smp, B, o_E, (const int32_t *)d_nm5, (const double *)d_direct,
+                        (const int32_t *)d_direct_ok, thresh2, o_nm, o_valid, o_e00, o_head, o_rows};
+        L.launch(HK_ARR_CHECK, ca);
         (void)total;
-        MLPL_HIP_TRY(hipStreamSynchronize(s));  // kernel completion makes its system-scope writes visible
+        int rcw;
+        if ((rcw = L.sync())) return rcw;  // kernel completion makes its system-scope writes visible
         const int32_t *h_nm = (const int32_t *)h_out, *h_valid = (const int32_t *)(h_out + off_valid);
         const double *h_e00 = (const double *)(h_out + off_e00);
         const uint64_t *h_head = (const uint64_t *)(h_out + off_head);
@@ -737,19 +876,18 @@ struct ArrsacRun {
                 pool[id].full = -2;  // queued
                 need.push_back(id);
             }
-        for (size_t at = 0; at < need.size(); at += (size_t)kArrBatchCap * 10) {
-            const int cnt = (int)std::min(need.size() - at, (size_t)kArrBatchCap * 10);
+        const size_t per_full = (out_bytes(kArrBatchCap) - 4096) / (sizeof(ArrFullRow) + 4);
+        for (size_t at = 0; at < need.size(); at += per_full) {
+            const int cnt = (int)std::min(need.size() - at, per_full);
+            // the row list goes out and the gathered rows come back through the pinned (mapped) block: no copy commands
+            const size_t off_g = ((size_t)cnt * 4 + 255) & ~(size_t)255;
             int32_t *h_rows = (int32_t *)h_out;
             for (int i = 0; i < cnt; ++i) h_rows[i] = pool[need[at + i]].row;
-            int32_t *d_rows = (int32_t *)d_out;
-            double *d_g = (double *)(d_out + (((size_t)cnt * 4 + 7) & ~(size_t)7));
-            MLPL_HIP_TRY(hipMemcpyAsync(d_rows, h_rows, (size_t)cnt * 4, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(arrsac_gather_kernel, dim3(cnt), dim3(32), 0, s, (const int32_t *)d_rows, cnt, (const double *)d_Epool,
-                               (const unsigned long long *)d_Fpool, d_g);
-            MLPL_HIP_TRY(hipGetLastError());
-            MLPL_HIP_TRY(hipMemcpyAsync(h_out, d_g, (size_t)cnt * sizeof(ArrFullRow), hipMemcpyDeviceToHost, s));
-            MLPL_HIP_TRY(hipStreamSynchronize(s));
-            const ArrFullRow *g = (const ArrFullRow *)h_out;
+            ArrGatherArgs ga{{cnt, 1}, (const int32_t *)h_out_dev, cnt, (const double *)d_Epool, (const unsigned long long *)d_Fpool, (double *)(h_out_dev + off_g)};
+            L.launch(HK_ARR_GATHER, ga);
+            int rcw;
+            if ((rcw = L.sync())) return rcw;
+            const ArrFullRow *g = (const ArrFullRow *)(h_out + off_g);
             for (int i = 0; i < cnt; ++i) {
                 pool[need[at + i]].full = (int)full_rows.size();
                 full_rows.push_back(g[i]);
@@ -768,7 +906,7 @@ struct ArrsacRun {
             }
         if (need.empty()) return MLPL_OK;
         const int wf = (n + 63) / 64;
-        const size_t cap = out_bytes(kArrBatchCap);
+        const size_t cap = std::max(out_bytes(kArrBatchCap), (size_t)wf * 8 + 8192);  // = the pinned block's size (layout)
         const size_t per = std::max<size_t>(1, (cap - 4096) / ((size_t)wf * 8 + 4));
         if ((size_t)wf * 8 + 4096 > cap) {
             set_error("mlpl_arrsac_essential: %d correspondences exceed the staging block of the preemptive stage (internal capacity)", n);
@@ -776,17 +914,14 @@ struct ArrsacRun {
         }
         for (size_t at = 0; at < need.size(); at += per) {
             const int cnt = (int)std::min(need.size() - at, per);
+            const size_t off_g = ((size_t)cnt * 4 + 255) & ~(size_t)255;
             int32_t *h_rows = (int32_t *)h_out;
             for (int i = 0; i < cnt; ++i) h_rows[i] = pool[need[at + i]].row;
-            int32_t *d_rows = (int32_t *)d_out;
-            unsigned long long *d_g = (unsigned long long *)(d_out + (((size_t)cnt * 4 + 63) & ~(size_t)63));
-            MLPL_HIP_TRY(hipMemcpyAsync(d_rows, h_rows, (size_t)cnt * 4, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(arrsac_extend_kernel, dim3(cnt), dim3(64), 0, s, (const int32_t *)d_rows, cnt, pts, n, wf, (const double *)d_Epool,
-                               thresh2, d_g);
-            MLPL_HIP_TRY(hipGetLastError());
-            MLPL_HIP_TRY(hipMemcpyAsync(h_out, d_g, (size_t)cnt * wf * 8, hipMemcpyDeviceToHost, s));
-            MLPL_HIP_TRY(hipStreamSynchronize(s));
-            const uint64_t *g = (const uint64_t *)h_out;
+            ArrExtendArgs ea{{cnt, 1}, (const int32_t *)h_out_dev, cnt, pts, n, wf, (const double *)d_Epool, thresh2, (unsigned long long *)(h_out_dev + off_g)};
+            L.launch(HK_ARR_EXTEND, ea);
+            int rcw;
+            if ((rcw = L.sync())) return rcw;
+            const uint64_t *g = (const uint64_t *)(h_out + off_g);
             for (int i = 0; i < cnt; ++i) {
                 pool[need[at + i]].ext = (int)ext_rows.size();
                 ext_rows.emplace_back(g + (size_t)i * wf, g + (size_t)(i + 1) * wf);
@@ -899,14 +1034,14 @@ struct ArrsacRun {
     };
     // diagnostics (mlpl_debug_arrsac_trace): 20 ints per turn of the first stage
     void trace_turn(int k, int inner_turn, const ArrKey &key, int nvalid, const int *res) {
-        if (!ctx->arrsac_trace || ctx->arrsac_trace_len + 20 > ctx->arrsac_trace_cap) return;
-        int32_t *r = ctx->arrsac_trace + ctx->arrsac_trace_len;
+        if (!trace_buf || trace_len + 20 > trace_cap) return;
+        int32_t *r = trace_buf + trace_len;
         r[0] = k, r[1] = inner_turn, r[2] = key.size();
         for (int i = 0; i < 5; ++i) r[3 + i] = key.v[1 + i];
         r[8] = nvalid;
         for (int i = 0; i < 10; ++i) r[9 + i] = i < nvalid ? res[i] : -1;
         r[19] = (key.size() > 5 ? key.v[6] : 0) + 100 * (key.size() > 6 ? key.v[7] : 0);  // indices of the first stage are < 100
-        ctx->arrsac_trace_len += 20;
+        trace_len += 20;
     }
 
     // Arrsac::GenerateInitialHypothesisSet (arrsac.h:236-372)
@@ -1130,13 +1265,10 @@ struct ArrsacRun {
 int arrsac_sample_models(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, const int32_t *idx, int m, int kind, double thresh,
                          double *E_out, int32_t *n_models, uint8_t *valid, hipStream_t s) {
     ArrsacRun R;
-    R.ctx = ctx, R.s = s, R.d_p1 = d_p1, R.d_p2 = d_p2, R.n = n;
+    R.ctx = ctx, R.s = s, R.L.s = s, R.d_p1 = d_p1, R.d_p2 = d_p2, R.n = n;
     R.flag_points = std::min(n, ctx->opt_arrsac_flag_points ? ctx->opt_arrsac_flag_points : kArrFlagPoints);
     R.thresh2 = thresh * thresh;
     int rc;
-    double4 *pts = nullptr;
-    if ((rc = pack_points(ctx, d_p1, d_p2, n, &pts, s))) return rc;
-    R.pts = pts;
     if ((rc = R.alloc())) return rc;
     ArrKey key;
     key.reset(kind);
@@ -1150,25 +1282,18 @@ int arrsac_sample_models(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, 
     return MLPL_OK;
 }
 
-int arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thresh, int refine, uint64_t *rng_state,
-                         double *E, uint8_t *d_mask, int *n_inliers, hipStream_t s) {
-    ArrsacRun R;
-    R.ctx = ctx, R.s = s, R.d_p1 = d_p1, R.d_p2 = d_p2, R.n = n;
-    R.flag_points = std::min(n, ctx->opt_arrsac_flag_points ? ctx->opt_arrsac_flag_points : kArrFlagPoints);
+// One ARRSAC problem on a prepared run (Launcher, buffers, trace): estimate, findInliers with the winner, the reference's plausibility test,
+// the optional refinement.  Returns 0 / MLPL_E_FAILED / an error; rng_state is advanced only when the estimator itself ran through.
+static int arrsac_run_problem(ArrsacRun &R, double thresh, int refine, uint64_t *rng_state, double *E, uint8_t *d_mask, int *n_inliers, long long *stats12) {
+    const int n = R.n;
+    R.flag_points = std::min(n, R.ctx->opt_arrsac_flag_points ? R.ctx->opt_arrsac_flag_points : kArrFlagPoints);
     R.thresh2 = thresh * thresh;
     R.prosac_rng.state = rng_state[0], R.random_rng.state = rng_state[1];
     int rc;
-    double4 *pts = nullptr;
-    if ((rc = pack_points(ctx, d_p1, d_p2, n, &pts, s))) return rc;
-    R.pts = pts;
     if ((rc = R.alloc())) return rc;
-    void *p;
-    if ((rc = ws_get(ctx, WS_AUX7, 256, &p))) return rc;
-    double *d_E = (double *)p;           // [0..8] best model, [9..17] refined
-    int32_t *d_info = (int32_t *)(d_E + 18);  // [0] inlier count, [1..2] refinement info
     rc = MLPL_OK;
     const int best = R.estimate(&rc);
-    std::memcpy(ctx->last_arrsac_stats, R.stats, sizeof(ctx->last_arrsac_stats));
+    if (stats12) std::memcpy(stats12, R.stats, sizeof(R.stats));
     if (rc) return rc;  // an internal limit or a HIP error is not an estimator outcome: the caller's stream states stay where they were
     rng_state[0] = R.prosac_rng.state, rng_state[1] = R.random_rng.state;
     if (n_inliers) *n_inliers = 0;
@@ -1176,25 +1301,28 @@ int arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, 
         set_error("mlpl_arrsac_essential: no hypothesis passed the sequential test");
         return MLPL_E_FAILED;
     }
-    // findInliers with the best model (modelest.cpp:274), then the reference's plausibility test (:275-278)
-    // the winner's matrix is in the device pool already
-    MLPL_HIP_TRY(hipMemcpyAsync(d_E, R.d_Epool + (size_t)R.pool[best].row * 9, 72, hipMemcpyDeviceToDevice, s));
-    MLPL_HIP_TRY(hipMemsetAsync(d_info, 0, 16, s));
-    hipLaunchKernelGGL(inlier_mask_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const double4 *)pts, n, (const double *)d_E,
-                       R.thresh2, d_mask, d_info);
-    if (refine)  // the kernel itself returns the initial matrix below 50 inliers, as the reference does (modelest.cpp:304-309)
-        hipLaunchKernelGGL(arrsac_refine_kernel, dim3(1), dim3(kArrRefineThreads), 0, s, (const double4 *)pts, (const uint8_t *)d_mask, n,
-                           (const double *)d_E, thresh / 50.0, d_E + 9, d_info + 1);
-    MLPL_HIP_TRY(hipGetLastError());
-    void *hp;
-    if ((rc = pinned_get(ctx, 256, &hp))) return rc;
-    MLPL_HIP_TRY(hipMemcpyAsync(hp, d_E, 256, hipMemcpyDeviceToHost, s));
-    MLPL_HIP_TRY(hipStreamSynchronize(s));
-    const double *hE = (const double *)hp;
+    // findInliers with the best model (modelest.cpp:274), then the reference's plausibility test (:275-278).  The winner's matrix is in
+    // the device pool already: the count kernel reads it there; the refinement writes next to the counters; one small block comes back
+    // through the pinned (mapped) memory.
+    double *d_E = R.d_final;
+    int32_t *d_info = (int32_t *)(d_E + 18);  // [0] inlier count, [1..2] refinement info
+    std::memset(R.h_final, 0, 256);
+    hub_copy_bytes(R.L, R.h_final_dev, d_E, 256);  // zeroes the counters (stream-ordered in front of the count kernel)
+    MaskCountArgs ma{{(n + 255) / 256, 1}, R.pts, n, (const double *)(R.d_Epool + (size_t)R.pool[best].row * 9), R.thresh2, d_mask, d_info, d_E};
+    R.L.launch(HK_ARR_MASK_COUNT, ma);
+    if (refine) {  // the kernel itself returns the initial matrix below 50 inliers, as the reference does (modelest.cpp:304-309)
+        ArrRefineArgs ra{{1, 1}, R.pts, (const uint8_t *)d_mask, n, (const double *)(R.d_Epool + (size_t)R.pool[best].row * 9), thresh / 50.0, d_E + 9, d_info + 1};
+        R.L.launch(HK_ARR_REFINE, ra);
+    }
+    // best model + refined model + counters back: a copy kernel device -> mapped host
+    CopyBytesArgs cb{{1, 1}, (const uint4 *)d_E, (uint8_t *)R.h_final_dev, 256};
+    R.L.launch(HK_COPY_BYTES, cb);
+    if ((rc = R.L.sync())) return rc;
+    const double *hE = R.h_final;
     const int32_t *hinfo = (const int32_t *)(hE + 18);
     const int good = hinfo[0];
     if (n_inliers) *n_inliers = good;
-    ctx->last_arrsac_stats[11] = refine ? hinfo[2] : -1;
+    if (stats12) stats12[11] = refine ? hinfo[2] : -1;
     if ((good < 50 && n > 200) || good < 15) {
         set_error("mlpl_arrsac_essential: the best hypothesis has too few inliers (%d)", good);
         return MLPL_E_FAILED;
@@ -1202,5 +1330,89 @@ int arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, 
     // with `refine` the reference always takes the refined matrix (its acceptance test compares the unrefined model's inlier count
     // with itself, modelest.cpp:312-318) and keeps the unrefined model's mask
     std::memcpy(E, (refine && good >= 50) ? hE + 9 : hE, 72);
+    return MLPL_OK;
+}
+
+int arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thresh, int refine, uint64_t *rng_state,
+                         double *E, uint8_t *d_mask, int *n_inliers, hipStream_t s) {
+    ArrsacRun R;
+    R.ctx = ctx, R.s = s, R.L.s = s, R.d_p1 = d_p1, R.d_p2 = d_p2, R.n = n;
+    R.trace_buf = ctx->arrsac_trace, R.trace_cap = ctx->arrsac_trace_cap, R.trace_len = ctx->arrsac_trace_len;
+    const int rc = arrsac_run_problem(R, thresh, refine, rng_state, E, d_mask, n_inliers, ctx->last_arrsac_stats);
+    ctx->arrsac_trace_len = R.trace_len;
+    return rc;
+}
+
+// ---- a batch of ARRSAC problems: every run a host thread, every launch merged over the runs (batch_hub.h) -------------------------------
+// Problem b: correspondences d_p1 / d_p2 + b * stride * 2 (counts[b] of them), its own pair of cv::RNG states rng_states[2 b .. 2 b + 1]
+// (in / out: the reference's samplers draw from process-wide streams, the C ABI hands every problem its own).  Outputs per problem: status
+// (0, MLPL_E_FAILED, < 0 errors), E, n_inliers, its mask at d_masks + b * stride.  Every problem's outputs are those of
+// mlpl_arrsac_essential_dev on it alone.
+constexpr int kArrBatchRuns = 128;
+
+int arrsac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const double *d_p2, int stride, const int32_t *counts, double thresh,
+                               int refine, uint64_t *rng_states, double *E, uint8_t *d_masks, int32_t *n_inliers, int32_t *status, hipStream_t s) {
+    if (B <= 0) return MLPL_OK;
+    int rc;
+    size_t max_dev = 0, max_pin = 0;
+    for (int b = 0; b < B; ++b) {
+        const ArrsacRun::Layout Y = ArrsacRun::layout(counts[b]);
+        max_dev = std::max(max_dev, Y.dev_total), max_pin = std::max(max_pin, Y.pin_total);
+    }
+    const int runs_max = std::min(B, kArrBatchRuns);
+    void *pblk, *dblk;
+    if ((rc = pinned_batch_get(ctx, (size_t)runs_max * max_pin, &pblk))) return rc;
+    if ((rc = ws_get(ctx, WS_BATCH_RUNS, (size_t)runs_max * max_dev, &dblk))) return rc;
+    char *pin = (char *)pblk, *pin_dev = nullptr;
+    {
+        void *alias = nullptr;
+        MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, pin, 0));
+        pin_dev = (char *)alias;
+    }
+    int first_err = 0;
+    std::string first_msg;
+    long long rounds = 0, merged = 0;
+    for (int b0 = 0; b0 < B; b0 += kArrBatchRuns) {
+        const int nb = std::min(kArrBatchRuns, B - b0);
+        BatchHub hub(ctx, s, nb);
+        std::vector<ArrBufs> bufs((size_t)nb);
+        std::vector<std::string> msgs((size_t)nb);
+        for (int k = 0; k < nb; ++k) {
+            bufs[k].dev = (char *)dblk + (size_t)k * max_dev;
+            bufs[k].pin = pin + (size_t)k * max_pin, bufs[k].pin_dev = pin_dev + (size_t)k * max_pin;
+        }
+        HubThreads &pool = hub_resources(ctx)->threads;
+        pool.start(nb, [&](int k) {
+            const int b = b0 + k;
+            HubRun &hr = hub.run(k);
+            int r = MLPL_OK;
+            try {
+                ArrsacRun R;
+                R.ctx = ctx, R.s = s, R.L.s = s, R.L.hub = &hub, R.L.run = &hr, R.bufs = &bufs[k];
+                R.d_p1 = d_p1 + (size_t)b * stride * 2, R.d_p2 = d_p2 + (size_t)b * stride * 2, R.n = counts[b];
+                int ninl = 0;
+                r = arrsac_run_problem(R, thresh, refine, rng_states + 2 * (size_t)b, E + (size_t)b * 9, d_masks + (size_t)b * stride, &ninl, nullptr);
+                if (n_inliers) n_inliers[b] = ninl;
+            } catch (const std::bad_alloc &) {
+                r = MLPL_E_NOMEM;
+                set_error("mlpl_arrsac_essential_batch_dev: out of host memory");
+            }
+            if (r && r != MLPL_E_FAILED) msgs[k] = mlpl_last_error();
+            status[b] = r;
+            hub.finish(hr);
+        });
+        const int hrc = hub.serve();
+        pool.wait();
+        rounds += hub.rounds(), merged += hub.merged_launches();
+        for (int k = 0; k < nb && !first_err; ++k)
+            if (status[b0 + k] && status[b0 + k] != MLPL_E_FAILED) first_err = status[b0 + k], first_msg = msgs[k];
+        if (hrc && !first_err) first_err = hrc;
+        if (first_err) break;
+    }
+    ctx->last_arrsac_stats[8] = rounds, ctx->last_arrsac_stats[9] = merged;
+    if (first_err) {
+        if (!first_msg.empty()) set_error("%s", first_msg.c_str());
+        return first_err;
+    }
     return MLPL_OK;
 }

@@ -91,6 +91,45 @@ __device__ __forceinline__ void hub_copy_bytes_body(const CopyBytesArgs &a, int 
 }
 MLPL_HUB_KERNEL(HK_COPY_BYTES, CopyBytesArgs, hub_copy_bytes_body, 256);
 
+struct PackPtsArgs {  // (x1, y1, x2, y2) rows of the correspondences: what ARRSAC's kernels read
+    KHdr hdr;
+    const double *p1, *p2;
+    int n;
+    double4 *pts;
+};
+__device__ __forceinline__ void hub_pack_pts_body(const PackPtsArgs &a, int bx, int) {
+    const int i = bx * 256 + threadIdx.x;
+    if (i < a.n) a.pts[i] = make_double4(a.p1[2 * i], a.p1[2 * i + 1], a.p2[2 * i], a.p2[2 * i + 1]);
+}
+MLPL_HUB_KERNEL(HK_PACK_POINTS, PackPtsArgs, hub_pack_pts_body, 256);
+
+struct MaskCountArgs {  // inlier_mask_count_kernel: findInliers with one model; *count must be zero before (count_zero: block 0 of a launch BEFORE zeroes it)
+    KHdr hdr;
+    const double4 *pts;
+    int n;
+    const double *E;
+    double thresh2;
+    uint8_t *mask;
+    int32_t *count;
+    double *E_copy;  // optional: the model, for the host (9 doubles)
+};
+__device__ __forceinline__ void hub_mask_count_body(const MaskCountArgs &a, int bx, int) {
+    const int i = bx * 256 + threadIdx.x;
+    if (a.E_copy && bx == 0 && threadIdx.x < 9) a.E_copy[threadIdx.x] = a.E[threadIdx.x];
+    bool in = false;
+    if (i < a.n) {
+        double e[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) e[k] = a.E[k];
+        const double4 p = a.pts[i];
+        in = (double)sampson_err_f32(e, p.x, p.y, p.z, p.w) <= a.thresh2;
+        a.mask[i] = in ? 1 : 0;
+    }
+    const unsigned long long b = __ballot(in);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(a.count, __popcll(b));
+}
+MLPL_HUB_KERNEL(HK_ARR_MASK_COUNT, MaskCountArgs, hub_mask_count_body, 256);
+
 // the five-point solver + root kernels for `count` samples through a Launcher
 inline void hub_launch_solver(Launcher &L, mlpl_ctx *ctx, int count, const double *p1, const double *p2, const int32_t *samples, PolyRec *recs,
                               double *E_tab, int32_t *n_models) {

@@ -3451,6 +3451,27 @@ int mlpl_arrsac_essential(mlpl_ctx *ctx, const double *p1, const double *p2, int
     return rc;
 }
 
+int mlpl_arrsac_essential_batch_dev(mlpl_ctx *ctx, int n_problems, const double *d_p1, const double *d_p2, int stride, const int32_t *counts, double thresh,
+                                    int refine, uint64_t *rng_states, double *E, uint8_t *d_masks, int32_t *n_inliers, int32_t *status, void *stream) {
+    if (!ctx || n_problems < 0 || !d_p1 || !d_p2 || stride < 1 || !counts || !rng_states || !E || !d_masks || !status || !(thresh > 0)) {
+        set_error("mlpl_arrsac_essential_batch_dev: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    for (int b = 0; b < n_problems; ++b)
+        if (counts[b] < 6 || counts[b] > stride) {
+            set_error("mlpl_arrsac_essential_batch_dev: problem %d has %d correspondences (6 ... stride %d)", b, counts[b], stride);
+            return MLPL_E_BAD_INPUT;
+        }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    try {
+        return arrsac_essential_batch_dev(ctx, n_problems, d_p1, d_p2, stride, counts, thresh, refine, rng_states, E, d_masks, n_inliers, status,
+                                          pick_stream(ctx, stream));
+    } catch (const std::bad_alloc &) {
+        set_error("mlpl_arrsac_essential_batch_dev: out of host memory");
+        return MLPL_E_NOMEM;
+    }
+}
+
 int mlpl_arrsac_sample_models(mlpl_ctx *ctx, const double *p1, const double *p2, int n, const int32_t *idx, int m, int kind, double thresh,
                               double *E_out, int32_t *n_models, uint8_t *valid) {
     if (!ctx || !p1 || !p2 || !idx || !E_out || !n_models || !valid || n < 5 || m < 5 || m > kArrMaxSample || (kind != 0 && kind != 1) ||
@@ -3496,8 +3517,12 @@ int mlpl_robust_essential_refine(mlpl_ctx *ctx, const double *p1, const double *
     if ((rc = pack_points(ctx, (const double *)dp1, (const double *)dp2, n, &pts, s))) return rc;
     double *d_E = (double *)dE;
     int32_t *d_info = (int32_t *)(d_E + 18);
-    hipLaunchKernelGGL(arrsac_refine_kernel, dim3(1), dim3(kArrRefineThreads), 0, s, (const double4 *)pts, (const uint8_t *)dmask, n, (const double *)d_E, th,
-                       d_E + 9, d_info);
+    {
+        Launcher L;
+        L.s = s;
+        ArrRefineArgs ra{{1, 1}, (const double4 *)pts, (const uint8_t *)dmask, n, (const double *)d_E, th, d_E + 9, d_info};
+        L.launch(HK_ARR_REFINE, ra);
+    }
     MLPL_HIP_TRY(hipGetLastError());
     double h[20];
     MLPL_HIP_TRY(hipMemcpyAsync(h, d_E + 9, 88, hipMemcpyDeviceToHost, s));

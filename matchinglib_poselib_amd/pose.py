@@ -183,6 +183,30 @@ def usac_essential(p1, p2, th: float, seed: int, sorted_idx=None, max_hyp: int =
     return out
 
 
+def arrsac_essential_batch(d_p1, d_p2, counts, thresh: float, refine: bool = True, rng_states=None, masks_out=None, ctx: Optional[Context] = None) -> list:
+    """A batch of ARRSAC problems in ONE library call (mlpl_arrsac_essential_batch_dev): d_p1, d_p2 float64 CUDA tensors [B, stride, 2],
+    counts[b] valid rows; rng_states: uint64 [B, 2] (default: fresh streams for every problem), advanced in place.  Returns one dict per problem
+    (ok, E, n_inliers, rng_state); masks through masks_out (uint8 CUDA tensor [B, stride])."""
+    import torch
+
+    ctx = ctx or default_context()
+    B, stride = d_p1.shape[0], d_p1.shape[1]
+    assert d_p1.is_cuda and d_p1.dtype == torch.float64 and d_p1.shape == d_p2.shape == (B, stride, 2) and d_p1.is_contiguous() and d_p2.is_contiguous()
+    cn = np.ascontiguousarray(counts, np.int32)
+    st = np.tile(np.array(ARRSAC_RNG_FRESH, np.uint64), (B, 1)) if rng_states is None else rng_states
+    assert st.dtype == np.uint64 and st.shape == (B, 2) and st.flags.c_contiguous
+    if masks_out is None:
+        masks_out = torch.zeros((B, stride), dtype=torch.uint8, device=d_p1.device)
+    assert masks_out.is_cuda and masks_out.dtype == torch.uint8 and masks_out.shape == (B, stride) and masks_out.is_contiguous()
+    E, ninl, status = np.zeros((B, 9)), np.zeros(B, np.int32), np.zeros(B, np.int32)
+    rc = ctx.lib.mlpl_arrsac_essential_batch_dev(ctx.handle, B, d_p1.data_ptr(), d_p2.data_ptr(), stride, cn.ctypes.data, float(thresh), 1 if refine else 0,
+                                                 st.ctypes.data, E.ctypes.data, masks_out.data_ptr(), ninl.ctypes.data, status.ctypes.data,
+                                                 torch.cuda.current_stream(d_p1.device).cuda_stream)
+    if rc != 0:
+        raise MlplError(rc, "mlpl_arrsac_essential_batch_dev", _lib.last_error())
+    return [dict(ok=bool(status[b] == 0), E=E[b].copy(), n_inliers=int(ninl[b]), rng_state=st[b].copy()) for b in range(B)]
+
+
 def usac_essential_batch(d_p1, d_p2, counts, th: float, seeds, sorted_idx=None, max_hyp: int = 50000, conf: float = 0.99, prosac_beta: float = 0.09,
                          sprt_delta: float = 0.05, sprt_epsilon: float = 0.15, sprt_ms: float = 8.5, sprt_tm: float = 2314.0, estimator: int = 0,
                          refine: int = 0, event_cap: int = 0, check_degeneracy: int = 0, th_pixels: float = 0.8, focal_length: float = 800.0,
