@@ -418,6 +418,12 @@ int mlpl_pair_pose_batch_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int
 int mlpl_pair_pose_batch_usac_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
                                   const float *d_kp2, const double K0[4], const double K1[4], const mlpl_usac_params *usac, int prosac,
                                   const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out, void *stream);
+/* ... and with ARRSAC, estimateEssentialMat's default method (pose_estim.h:207; `refine` = robustEssentialRefine on the winner's inliers):
+ * mlpl_arrsac_essential_batch_dev on the pairs' correspondences.  rng_states[2 * n_pairs]: a pair of cv::RNG states per image pair (in / out).
+ * Record per pair: status 0 / -1 / -2 (ARRSAC failed), iters = 0, n_inliers = inliers of the unrefined winner, n_good, E, R, t. */
+int mlpl_pair_pose_batch_arrsac_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
+                                    const float *d_kp2, const double K0[4], const double K1[4], double thresh, int refine, uint64_t *rng_states, double dist,
+                                    mlpl_pair_result *out, mlpl_dmatch *d_matches_out, void *stream);
 /* poselib::getSortedMatchIdx (P/source/pose_helper.cpp:2896-2923) on a HOST match list: the indices of the matches in the order
  * std::sort leaves them when comparing the distances -- the PROSAC order estimateEssentialOrPoseUSAC and the batch entry above use. */
 int mlpl_sorted_match_idx(const mlpl_dmatch *matches, int n, uint32_t *sorted_idx);

@@ -122,6 +122,8 @@ _SIGNATURES = {
                                          c_int, c_double, c_int, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
     "mlpl_pair_pose_batch_usac_dev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                               c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
+    "mlpl_pair_pose_batch_arrsac_dev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int,
+                                                c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
     "mlpl_sorted_match_idx": (c_int, [c_void_p, c_int, c_void_p]),
     "mlpl_pair_batch_last_stats": (c_int, [c_void_p, c_void_p]),
     "mlpl_ransac_essential_batch_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_double, c_int, c_double, c_void_p, c_int, c_double,

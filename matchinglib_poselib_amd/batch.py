@@ -188,9 +188,39 @@ def process_pairs_batched_usac(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, see
     check(ctx.lib.mlpl_pair_pose_batch_usac_dev(ctx.handle, B, d_q.data_ptr(), d_q.shape[1], d_t.data_ptr(), d_t.shape[1], d_q.shape[2], d_kp1.data_ptr(),
                                                 d_kp2.data_ptr(), k0, k1, C.addressof(P), 1 if prosac else 0, sd.ctypes.data, float(dist), C.addressof(res),
                                                 matches_out.data_ptr() if matches_out is not None else None, st), "mlpl_pair_pose_batch_usac_dev")
-    raw = np.frombuffer(res, _PAIR_RESULT_DTYPE, count=B)
+    raw = np.frombuffer(res, _PAIR_RESULT_DTYPE, count=B).copy()
     rec = np.zeros(B, RECORD_DTYPE)
     rec["pair_id"] = np.arange(B) if pair_ids is None else np.asarray(pair_ids)
+    rec["n_matches"], rec["status"] = raw["n_matches"], raw["status"]
+    ok = raw["status"] == 0
+    for f in ("n_inliers", "E", "R", "t"):
+        rec[f][ok] = raw[f][ok]
+    return rec, raw
+
+
+def process_pairs_batched_arrsac(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, th_pix: float = 0.8, refine: bool = True, rng_states=None, dist: float = 50.0,
+                                 matches_out=None):
+    """process_pairs_batched with ARRSAC (estimateEssentialMat's default method) as the robust estimator: mlpl_pair_pose_batch_arrsac_dev.
+    rng_states: uint64 [B, 2], advanced in place (default: fresh cv::RNG streams for every pair).  Returns (records, raw result block)."""
+    import torch
+    from .pose import ARRSAC_RNG_FRESH
+
+    B = d_q.shape[0]
+    assert d_q.is_cuda and d_q.dtype == torch.uint8 and d_q.dim() == 3 and d_t.dim() == 3 and d_t.shape[0] == B
+    assert d_q.is_contiguous() and d_t.is_contiguous() and d_kp1.is_contiguous() and d_kp2.is_contiguous()
+    k0 = (C.c_double * 4)(*K0)
+    k1 = (C.c_double * 4)(*K1)
+    th = th_pix * 4.0 / (np.sqrt(2.0) * (K0[0] + K0[1] + K1[0] + K1[1]))
+    st = np.tile(np.array(ARRSAC_RNG_FRESH, np.uint64), (B, 1)) if rng_states is None else rng_states
+    assert st.dtype == np.uint64 and st.shape == (B, 2) and st.flags.c_contiguous
+    res = (_PairResult * B)()
+    stream = torch.cuda.current_stream(d_q.device).cuda_stream
+    check(ctx.lib.mlpl_pair_pose_batch_arrsac_dev(ctx.handle, B, d_q.data_ptr(), d_q.shape[1], d_t.data_ptr(), d_t.shape[1], d_q.shape[2], d_kp1.data_ptr(),
+                                                  d_kp2.data_ptr(), k0, k1, float(th), 1 if refine else 0, st.ctypes.data, float(dist), C.addressof(res),
+                                                  matches_out.data_ptr() if matches_out is not None else None, stream), "mlpl_pair_pose_batch_arrsac_dev")
+    raw = np.frombuffer(res, _PAIR_RESULT_DTYPE, count=B).copy()
+    rec = np.zeros(B, RECORD_DTYPE)
+    rec["pair_id"] = np.arange(B)
     rec["n_matches"], rec["status"] = raw["n_matches"], raw["status"]
     ok = raw["status"] == 0
     for f in ("n_inliers", "E", "R", "t"):

@@ -1356,7 +1356,7 @@ int arrsac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const d
     int rc;
     size_t max_dev = 0, max_pin = 0;
     for (int b = 0; b < B; ++b) {
-        const ArrsacRun::Layout Y = ArrsacRun::layout(counts[b]);
+        const ArrsacRun::Layout Y = ArrsacRun::layout(std::max(counts[b], 6));
         max_dev = std::max(max_dev, Y.dev_total), max_pin = std::max(max_pin, Y.pin_total);
     }
     const int runs_max = std::min(B, kArrBatchRuns);
@@ -1386,6 +1386,12 @@ int arrsac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const d
             const int b = b0 + k;
             HubRun &hr = hub.run(k);
             int r = MLPL_OK;
+            if (counts[b] < 6) {  // (a pair without enough matches in a batch of image pairs: nothing to estimate)
+                status[b] = MLPL_E_FAILED;
+                if (n_inliers) n_inliers[b] = 0;
+                hub.finish(hr);
+                return;
+            }
             try {
                 ArrsacRun R;
                 R.ctx = ctx, R.s = s, R.L.s = s, R.L.hub = &hub, R.L.run = &hr, R.bufs = &bufs[k];

@@ -22,9 +22,12 @@ void sorted_match_idx(const mlpl_dmatch *matches, int count, uint32_t *out) {
     for (int i = 0; i < count; ++i) out[i] = c[i].idx;
 }
 
+// tmpl != nullptr: USAC with these parameters (seeds[B], prosac); else ARRSAC (arr_thresh, arr_refine, arr_states[B][2] in / out)
 int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
                              const float *d_kp2, const double K0[4], const double K1[4], const mlpl_usac_params *tmpl, int prosac,
-                             const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out, hipStream_t s) {
+                             const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out, hipStream_t s,
+                             double arr_thresh = 0, int arr_refine = 0, uint64_t *arr_states = nullptr) {
+    if (!tmpl) prosac = 0;
     const int NQ = nq;
     const size_t n = (size_t)NQ;
     int rc;
@@ -61,7 +64,9 @@ int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, c
     if (prosac) MLPL_HIP_TRY(hipMemcpyAsync(hp + pin_match, d_m, (size_t)B * n * 16, hipMemcpyDeviceToHost, s));
     MLPL_HIP_TRY(hipStreamSynchronize(s));
     std::vector<int32_t> counts(h_counts, h_counts + B);  // (the nested entries reuse the context's pinned block)
-    std::vector<mlpl_usac_params> params((size_t)B, *tmpl);
+    mlpl_usac_params none;
+    std::memset(&none, 0, sizeof(none));
+    std::vector<mlpl_usac_params> params((size_t)B, tmpl ? *tmpl : none);
     std::vector<std::vector<uint32_t>> orders(prosac ? (size_t)B : 0);
     int any = 0;
     for (int b = 0; b < B; ++b) {
@@ -70,7 +75,7 @@ int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, c
         h_active[b] = counts[b] >= 16 ? 1 : 0;  // below 16 matches Remove_LensDist / StereoRefine refuse to work
         if (!h_active[b]) out[b].status = -1, counts[b] = 0;
         any |= h_active[b];
-        params[b].seed = seeds[b];
+        params[b].seed = seeds ? seeds[b] : 0u;
         params[b].sorted_idx = nullptr;
     }
     if (!any) return MLPL_OK;
@@ -91,8 +96,15 @@ int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, c
     if ((rc = launch_gather_match_points_batch(d_m, d_counts, B, NQ, d_kp1, (size_t)nq * 2, d_kp2, (size_t)nt * 2, K0, K1, d_p1, d_p2, s))) return rc;
     std::vector<double> E((size_t)B * 9, 0.0), results((size_t)B * 12, 0.0);
     std::vector<int32_t> status((size_t)B, 0);
-    if ((rc = usac_essential_batch_dev(ctx, B, d_p1, d_p2, NQ, counts.data(), params.data(), E.data(), d_mask, results.data(), status.data(), nullptr, nullptr, s)))
-        return rc;
+    if (tmpl) {
+        if ((rc = usac_essential_batch_dev(ctx, B, d_p1, d_p2, NQ, counts.data(), params.data(), E.data(), d_mask, results.data(), status.data(), nullptr, nullptr, s)))
+            return rc;
+    } else {
+        std::vector<int32_t> ninl((size_t)B, 0);
+        if ((rc = arrsac_essential_batch_dev(ctx, B, d_p1, d_p2, NQ, counts.data(), arr_thresh, arr_refine, arr_states, E.data(), d_mask, ninl.data(), status.data(), s)))
+            return rc;
+        for (int b = 0; b < B; ++b) results[(size_t)b * 12 + 1] = 0, results[(size_t)b * 12 + 5] = ninl[b];
+    }
     // (usac_essential_batch_dev took the context's small pinned block for nothing; the pointers above are still valid: pinned_get only grows)
     for (int b = 0; b < B; ++b) {
         if (!h_active[b]) continue;

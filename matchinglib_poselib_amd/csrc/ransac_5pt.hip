@@ -3613,6 +3613,31 @@ int mlpl_pair_pose_batch_usac_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q
     return MLPL_OK;
 }
 
+int mlpl_pair_pose_batch_arrsac_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
+                                    const float *d_kp2, const double K0[4], const double K1[4], double thresh, int refine, uint64_t *rng_states, double dist,
+                                    mlpl_pair_result *out, mlpl_dmatch *d_matches_out, void *stream) {
+    if (!ctx || !d_q || !d_t || !d_kp1 || !d_kp2 || !K0 || !K1 || !out || !rng_states || n_pairs < 1 || nq < 1 || nt < 2 || nbytes < 1 || !(thresh > 0)) {
+        set_error("mlpl_pair_pose_batch_arrsac_dev: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = pick_stream(ctx, stream);
+    const int per = ctx->opt_pair_batch > 0 ? ctx->opt_pair_batch : kBatchPairsPerCall;
+    try {
+        for (int at = 0; at < n_pairs; at += per) {
+            const int B = std::min(per, n_pairs - at);
+            const int rc = pair_pose_batch_usac_dev(ctx, B, d_q + (size_t)at * nq * nbytes, nq, d_t + (size_t)at * nt * nbytes, nt, nbytes,
+                                                    d_kp1 + (size_t)at * nq * 2, d_kp2 + (size_t)at * nt * 2, K0, K1, nullptr, 0, nullptr, dist, out + at,
+                                                    d_matches_out ? d_matches_out + (size_t)at * nq : nullptr, s, thresh, refine, rng_states + 2 * (size_t)at);
+            if (rc) return rc;
+        }
+    } catch (const std::bad_alloc &) {
+        set_error("mlpl_pair_pose_batch_arrsac_dev: out of host memory");
+        return MLPL_E_NOMEM;
+    }
+    return MLPL_OK;
+}
+
 int mlpl_ransac_essential_batch_dev(mlpl_ctx *ctx, int n_problems, const double *d_p1, const double *d_p2, int stride, const int32_t *counts, double thresh,
                                     int max_iters, double confidence, const uint32_t *seeds, int recover_pose, double dist, mlpl_pair_result *out,
                                     uint8_t *d_masks, void *stream) {
