@@ -1386,7 +1386,11 @@ __global__ __launch_bounds__(kThreads) void score_models_kernel(const double4 *_
 // makes N32 + p32 infinite: H = +inf or NaN and the comparison fails -> fp64 path.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int kThreads, int kTile>
+// MPL = models per lane.  With one model per lane the four waves of a SIMD group spend two fifths of their cycles waiting for the tile
+// reads (40 bytes of LDS per lane and pair of evaluations against 27 packed instructions: the LDS pipe is as busy as the vector pipe);
+// with MPL = 2 a lane applies every pair it reads to two models -- half the LDS traffic per evaluation, the same arithmetic per model in
+// the same order (same counts by construction: the per-model instruction sequence is unchanged).
+template <int kThreads, int kTile, int MPL = 1>
 __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
                                                                     const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
                                                                     int total_host, double thresh2, double qmax, int32_t *__restrict__ good,
@@ -1403,27 +1407,34 @@ __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double
     const double *__restrict__ kp64 = reinterpret_cast<const double *>(pts + n);
     const float *__restrict__ rec = reinterpret_cast<const float *>(kp64 + n);
     const int total = total_ptr ? *total_ptr : total_host;
-    if (blockIdx.x * (kThreads / 4) >= total) return;  // block-uniform
+    constexpr int kPerBlock = (kThreads / 4) * MPL;
+    if (blockIdx.x * kPerBlock >= total) return;  // block-uniform
     const int tid = threadIdx.x;
     const int j = tid & 3;
-    const int m = blockIdx.x * (kThreads / 4) + (tid >> 2);
-    const bool live = m < total;
-    double e[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) e[k] = live ? E_list[(size_t)m * 9 + k] : 0.0;
-    const double km = model_band(e, qmax);
-    double emax = 0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) emax = fmax(emax, fabs(e[k]));
+    const int m0 = blockIdx.x * kPerBlock + (tid >> 2) * MPL;
     const double u = 0x1p-24;
-    const double kms64 = 1.01 * fmax(fmax(65.0 * (8.01 * u * emax) * (8.01 * u * emax), 10.2 * u * qmax * emax * emax), km);
-    const bool in_range = emax >= 0x1p-40 && emax <= 0x1p20 && qmax >= 0x1p-60 && qmax <= 1.0 && km == km;
-    const float kms = in_range ? (float)kms64 * (1.0f + 0x1p-22f) : INFINITY;
-    f32x2 E[9];
+    bool live[MPL];
+    double e[MPL][9], km[MPL];
+    f32x2 E[MPL][9], KM[MPL];
+    int cnt[MPL];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) E[k] = f32x2{(float)e[k], (float)e[k]};
-    const f32x2 Q = {(float)qmax, (float)qmax}, KM = {kms, kms}, C6 = {0x1p-6f * 1.02f, 0x1p-6f * 1.02f};
-    int cnt = 0;
+    for (int mi = 0; mi < MPL; ++mi) {
+        live[mi] = m0 + mi < total;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) e[mi][k] = live[mi] ? E_list[(size_t)(m0 + mi) * 9 + k] : 0.0;
+        km[mi] = model_band(e[mi], qmax);
+        double emax = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) emax = fmax(emax, fabs(e[mi][k]));
+        const double kms64 = 1.01 * fmax(fmax(65.0 * (8.01 * u * emax) * (8.01 * u * emax), 10.2 * u * qmax * emax * emax), km[mi]);
+        const bool in_range = emax >= 0x1p-40 && emax <= 0x1p20 && qmax >= 0x1p-60 && qmax <= 1.0 && km[mi] == km[mi];
+        const float kms = in_range ? (float)kms64 * (1.0f + 0x1p-22f) : INFINITY;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) E[mi][k] = f32x2{(float)e[mi][k], (float)e[mi][k]};
+        KM[mi] = f32x2{kms, kms};
+        cnt[mi] = 0;
+    }
+    const f32x2 Q = {(float)qmax, (float)qmax}, C6 = {0x1p-6f * 1.02f, 0x1p-6f * 1.02f};
     for (int base = blockIdx.y * kTile; base < n; base += kTile * gridDim.y) {
         const int rows = min(kTile, n - base);
         __syncthreads();
@@ -1435,7 +1446,7 @@ __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double
             tile_k[slot * 2 + half] = r[4];
         }
         __syncthreads();
-        if (live) {
+        if (live[0]) {
             const int nk = (rows - j + 3) >> 2;  // correspondences of this lane's class in the tile: i = 4k + j, k < nk
             const int npairs = nk >> 1;
 #pragma unroll 2
@@ -1445,48 +1456,57 @@ __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double
                 const float4 v1 = *reinterpret_cast<const float4 *>(tile_xy + slot * 8 + 4);
                 const float2 kk = *reinterpret_cast<const float2 *>(tile_k + slot * 2);
                 const f32x2 X1 = {v0.x, v0.y}, Y1 = {v0.z, v0.w}, X2 = {v1.x, v1.y}, Y2 = {v1.z, v1.w}, KP = {kk.x, kk.y};
-                const f32x2 A = __builtin_elementwise_fma(E[0], X1, __builtin_elementwise_fma(E[1], Y1, E[2]));
-                const f32x2 B = __builtin_elementwise_fma(E[3], X1, __builtin_elementwise_fma(E[4], Y1, E[5]));
-                const f32x2 C = __builtin_elementwise_fma(E[6], X1, __builtin_elementwise_fma(E[7], Y1, E[8]));
-                const f32x2 S = __builtin_elementwise_fma(X2, A, __builtin_elementwise_fma(Y2, B, C));
-                const f32x2 A2 = __builtin_elementwise_fma(E[0], X2, __builtin_elementwise_fma(E[3], Y2, E[6]));
-                const f32x2 B2 = __builtin_elementwise_fma(E[1], X2, __builtin_elementwise_fma(E[4], Y2, E[7]));
-                const f32x2 D = __builtin_elementwise_fma(A, A, __builtin_elementwise_fma(B, B, __builtin_elementwise_fma(A2, A2, B2 * B2)));
-                const f32x2 N = S * S;
-                // N32 -+ fl(qmax) D32 with ONE rounding each (the analysis above rounds the product first: at most an ulp of either
-                // quantity more, far inside the 1.02 / 1.01 slack of H)
-                const f32x2 diff = __builtin_elementwise_fma(-Q, D, N);
-                const f32x2 H = __builtin_elementwise_fma(C6, __builtin_elementwise_fma(Q, D, N), KM * KP);
-                // decided inlier: diff < -H; decided outlier: diff > H (H >= 0; every comparison is false for a NaN / inf band)
-                const bool in0 = diff.x < -H.x, in1 = diff.y < -H.y;
-                const bool c0 = in0 || diff.x > H.x, c1 = in1 || diff.y > H.y;
-                cnt += in0 ? 1 : 0;
-                cnt += in1 ? 1 : 0;
-                if (__builtin_expect(!(c0 && c1), 0)) {  // inside the band (or out of range): the fp64 predicate decides
-                    const int i0 = base + 4 * (2 * q) + j, i1 = i0 + 4;
-                    if (!c0) {
-                        const double4 p = pts[i0];
-                        cnt += sampson_inlier_fma(e, km, p.x, p.y, p.z, p.w, kp64[i0], qmax, thresh2) ? 1 : 0;
-                    }
-                    if (!c1) {
-                        const double4 p = pts[i1];
-                        cnt += sampson_inlier_fma(e, km, p.x, p.y, p.z, p.w, kp64[i1], qmax, thresh2) ? 1 : 0;
+#pragma unroll
+                for (int mi = 0; mi < MPL; ++mi) {
+                    const f32x2 *Em = E[mi];
+                    const f32x2 A = __builtin_elementwise_fma(Em[0], X1, __builtin_elementwise_fma(Em[1], Y1, Em[2]));
+                    const f32x2 B = __builtin_elementwise_fma(Em[3], X1, __builtin_elementwise_fma(Em[4], Y1, Em[5]));
+                    const f32x2 C = __builtin_elementwise_fma(Em[6], X1, __builtin_elementwise_fma(Em[7], Y1, Em[8]));
+                    const f32x2 S = __builtin_elementwise_fma(X2, A, __builtin_elementwise_fma(Y2, B, C));
+                    const f32x2 A2 = __builtin_elementwise_fma(Em[0], X2, __builtin_elementwise_fma(Em[3], Y2, Em[6]));
+                    const f32x2 B2 = __builtin_elementwise_fma(Em[1], X2, __builtin_elementwise_fma(Em[4], Y2, Em[7]));
+                    const f32x2 D = __builtin_elementwise_fma(A, A, __builtin_elementwise_fma(B, B, __builtin_elementwise_fma(A2, A2, B2 * B2)));
+                    const f32x2 N = S * S;
+                    // N32 -+ fl(qmax) D32 with ONE rounding each (the analysis above rounds the product first: at most an ulp of either
+                    // quantity more, far inside the 1.02 / 1.01 slack of H)
+                    const f32x2 diff = __builtin_elementwise_fma(-Q, D, N);
+                    const f32x2 H = __builtin_elementwise_fma(C6, __builtin_elementwise_fma(Q, D, N), KM[mi] * KP);
+                    // decided inlier: diff < -H; decided outlier: diff > H (H >= 0; every comparison is false for a NaN / inf band)
+                    const bool in0 = diff.x < -H.x, in1 = diff.y < -H.y;
+                    const bool c0 = in0 || diff.x > H.x, c1 = in1 || diff.y > H.y;
+                    cnt[mi] += in0 ? 1 : 0;
+                    cnt[mi] += in1 ? 1 : 0;
+                    if (__builtin_expect(!(c0 && c1), 0)) {  // inside the band (or out of range): the fp64 predicate decides
+                        const int i0 = base + 4 * (2 * q) + j, i1 = i0 + 4;
+                        if (!c0) {
+                            const double4 p = pts[i0];
+                            cnt[mi] += sampson_inlier_fma(e[mi], km[mi], p.x, p.y, p.z, p.w, kp64[i0], qmax, thresh2) ? 1 : 0;
+                        }
+                        if (!c1) {
+                            const double4 p = pts[i1];
+                            cnt[mi] += sampson_inlier_fma(e[mi], km[mi], p.x, p.y, p.z, p.w, kp64[i1], qmax, thresh2) ? 1 : 0;
+                        }
                     }
                 }
             }
             if (nk & 1) {  // the unpaired last correspondence of the class: fp64
                 const int i0 = base + 4 * (nk - 1) + j;
                 const double4 p = pts[i0];
-                cnt += sampson_inlier_fma(e, km, p.x, p.y, p.z, p.w, kp64[i0], qmax, thresh2) ? 1 : 0;
+#pragma unroll
+                for (int mi = 0; mi < MPL; ++mi) cnt[mi] += sampson_inlier_fma(e[mi], km[mi], p.x, p.y, p.z, p.w, kp64[i0], qmax, thresh2) ? 1 : 0;
             }
         }
     }
-    cnt += __shfl_xor(cnt, 1);
-    cnt += __shfl_xor(cnt, 2);
-    if (live && j == 0) {
-        const int o = ids ? ids[m] : m;
-        if (gridDim.y > 1) atomicAdd(&good[o], cnt);
-        else good[o] = cnt;
+#pragma unroll
+    for (int mi = 0; mi < MPL; ++mi) {
+        int c = cnt[mi];
+        c += __shfl_xor(c, 1);
+        c += __shfl_xor(c, 2);
+        if (live[mi] && j == 0) {
+            const int o = ids ? ids[m0 + mi] : m0 + mi;
+            if (gridDim.y > 1) atomicAdd(&good[o], c);
+            else good[o] = c;
+        }
     }
 }
 
@@ -2748,7 +2768,7 @@ double inlier_bound(double thresh2) {
 constexpr int kScoreBlockMaxModels = 24576;
 static void launch_score(hipStream_t s, const double4 *pts, int n, const double *E_list, const int32_t *ids, const int32_t *total_ptr,
                          int total_host, int max_models, double thresh2, int32_t *good, double *esum, bool sums = true,
-                         double qmax = -1.0, int point_splits = 1, bool f32_filter = false) {
+                         double qmax = -1.0, int point_splits = 1, bool f32_filter = false, int mpl = 2) {
     if (max_models <= 0) return;
     const size_t lds = (size_t)((n + 3) / 4 * 4) * sizeof(float);
     const bool block = n <= kScoreBlockMaxN && max_models <= kScoreBlockMaxModels;
@@ -2772,7 +2792,10 @@ static void launch_score(hipStream_t s, const double4 *pts, int n, const double 
                                ids, total_ptr, total_host, thresh2, qmax, good, esum);
     } else {
         const dim3 grid((max_models + kScoreModels - 1) / kScoreModels, point_splits);
-        if (f32_filter)
+        if (f32_filter && mpl == 2)
+            hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile, 2>), dim3((max_models + 2 * kScoreModels - 1) / (2 * kScoreModels), point_splits),
+                               dim3(kScoreThreads), 0, s, pts, n, E_list, ids, total_ptr, total_host, thresh2, qmax, good);
+        else if (f32_filter)
             hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile>), grid, dim3(kScoreThreads), 0, s, pts, n, E_list, ids, total_ptr,
                                total_host, thresh2, qmax, good);
         else
@@ -2954,7 +2977,11 @@ static int score_models_impl(mlpl_ctx *ctx, const double *p1, const double *p2, 
     if ((rc = pack_points(ctx, (const double *)dp1, (const double *)dp2, n, &pts, s))) return rc;
     prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
     const double qmax = inlier_bound(thresh2);
-    if (shape == 1 && !err_sum && ctx->opt_ransac_f32_filter)
+    if (shape == 1 && !err_sum && ctx->opt_ransac_f32_filter && ctx->opt_ransac_count_mpl == 2)
+        hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile, 2>), dim3((n_models + 2 * kScoreModels - 1) / (2 * kScoreModels)), dim3(kScoreThreads), 0, s,
+                           (const double4 *)pts, n, (const double *)dE, (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, thresh2, qmax,
+                           (int32_t *)dgood);
+    else if (shape == 1 && !err_sum && ctx->opt_ransac_f32_filter)
         hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile>), dim3((n_models + kScoreModels - 1) / kScoreModels), dim3(kScoreThreads), 0, s,
                            (const double4 *)pts, n, (const double *)dE, (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, thresh2, qmax,
                            (int32_t *)dgood);
@@ -3169,7 +3196,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         }
         prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
         launch_score(s, (const double4 *)pts, n, (const double *)B.dense_E, (const int32_t *)B.dense_id, (const int32_t *)B.total, 0,
-                     cnt * 10, thresh2, B.good, B.esum, !lazy, qmax, point_splits, ctx->opt_ransac_f32_filter != 0);
+                     cnt * 10, thresh2, B.good, B.esum, !lazy, qmax, point_splits, ctx->opt_ransac_f32_filter != 0, ctx->opt_ransac_count_mpl);
         if (lazy) {
             // error sums only for the models that can still win (ties on the inlier count are decided by them)
             const bool sep = cnt > 2048;  // many hypotheses: per-hypothesis maxima in a grid-wide pass first
