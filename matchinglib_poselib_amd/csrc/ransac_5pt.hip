@@ -1386,10 +1386,13 @@ __global__ __launch_bounds__(kThreads) void score_models_kernel(const double4 *_
 // makes N32 + p32 infinite: H = +inf or NaN and the comparison fails -> fp64 path.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// MPL = models per lane.  With one model per lane the four waves of a SIMD group spend two fifths of their cycles waiting for the tile
-// reads (40 bytes of LDS per lane and pair of evaluations against 27 packed instructions: the LDS pipe is as busy as the vector pipe);
-// with MPL = 2 a lane applies every pair it reads to two models -- half the LDS traffic per evaluation, the same arithmetic per model in
-// the same order (same counts by construction: the per-model instruction sequence is unchanged).
+// MPL = models per lane (option ransac_count_mpl, default 1).  Round 4 measured the kernel's hot loop in the ISA: per pair of evaluations
+// 21 packed + 8 scalar-lane vector instructions (116 issue cycles per wave on a SIMD), i.e. the C3 counting pass is at ~0.67 of the VECTOR
+// ISSUE rate with 39 algorithmic FLOP per evaluation priced at 0.41 of the fp32 FLOP peak -- the gap between the two figures is instructions
+// that are not multiply-adds (comparisons, counts, the band), not waiting.  MPL = 2 (a lane applies every pair of correspondences it reads
+// from LDS to two models: half the LDS traffic per evaluation) needs 138 instead of 92 VGPRs, drops from four to two waves per SIMD and is
+// SLOWER: 0.34 against 0.27 ms at C3, 4.4 against 3.1 ms in the C5 step (tools/count_mpl_ab.py; same counts).  Kept as an instantiation for
+// the A/B, not used.
 template <int kThreads, int kTile, int MPL = 1>
 __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
                                                                     const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
@@ -1435,6 +1438,8 @@ __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double
         cnt[mi] = 0;
     }
     const f32x2 Q = {(float)qmax, (float)qmax}, C6 = {0x1p-6f * 1.02f, 0x1p-6f * 1.02f};
+    // (Measured and not kept, round 4: fetching the NEXT tile into registers while the current one is evaluated -- no change: with two
+    // workgroups per CU the other workgroup's evaluation already covers a tile's load latency.)
     for (int base = blockIdx.y * kTile; base < n; base += kTile * gridDim.y) {
         const int rows = min(kTile, n - base);
         __syncthreads();
@@ -2768,7 +2773,7 @@ double inlier_bound(double thresh2) {
 constexpr int kScoreBlockMaxModels = 24576;
 static void launch_score(hipStream_t s, const double4 *pts, int n, const double *E_list, const int32_t *ids, const int32_t *total_ptr,
                          int total_host, int max_models, double thresh2, int32_t *good, double *esum, bool sums = true,
-                         double qmax = -1.0, int point_splits = 1, bool f32_filter = false, int mpl = 2) {
+                         double qmax = -1.0, int point_splits = 1, bool f32_filter = false, int mpl = 1) {
     if (max_models <= 0) return;
     const size_t lds = (size_t)((n + 3) / 4 * 4) * sizeof(float);
     const bool block = n <= kScoreBlockMaxN && max_models <= kScoreBlockMaxModels;
