@@ -360,7 +360,8 @@ void launch_partial(int variant, int qpl, dim3 grid, hipStream_t s, const uint32
 
 int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_words, const uint32_t *tw, size_t t_batch_words,
                             int nq, int nt, int nw, int batch, int dshift, hipStream_t s, int *rps_out, int *nsplit_out,
-                            int *sps_out, int *tail_row0_out, const int32_t **split_tab_out, uint2 **part_out);
+                            int *sps_out, int *tail_row0_out, const int32_t **split_tab_out, uint2 **part_out, int k, float ratio,
+                            int32_t *d_idx, int32_t *d_dist, int32_t *d_group_counts, int *fused_out);
 
 int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_stride, size_t q_bstride,
                        const uint8_t *d_t, int nt, size_t t_stride, size_t t_bstride, int nbytes, int k, int batch,
@@ -419,11 +420,14 @@ int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_strid
         int rps = 0, nsplit = 0, sps = 1, tail_row0 = nt;
         const int32_t *split_tab = nullptr;
         uint2 *part = nullptr;
+        int fused = 0;
         int rc = launch_knn_hamming_mfma(ctx, qw, qbw, tw, tbw, nq, nt, nw, batch, dshift, s, &rps, &nsplit, &sps, &tail_row0, &split_tab,
-                                         &part);
+                                         &part, k, ratio, d_idx, d_dist, d_group_counts, &fused);
         if (rc) return rc;
-        const MergeTail tail{qw, tw, qbw, tbw, nw, tail_row0, nt - tail_row0, split_tab};
-        launch_merge(s, (const uint2 *)part, nq, nsplit, rps, dshift, k, ratio, batch, d_idx, d_dist, d_group_counts, sps, tail);
+        if (!fused) {  // (the static LDS-ring kernel merges its splits, evaluates the ratio predicate and counts by itself)
+            const MergeTail tail{qw, tw, qbw, tbw, nw, tail_row0, nt - tail_row0, split_tab};
+            launch_merge(s, (const uint2 *)part, nq, nsplit, rps, dshift, k, ratio, batch, d_idx, d_dist, d_group_counts, sps, tail);
+        }
         MLPL_HIP_TRY(hipGetLastError());
         return MLPL_OK;
     }

@@ -286,11 +286,23 @@ __global__ __launch_bounds__(256, (KS >= 8 ? 2 : 3)) void knn_hamming_mfma_kerne
 // visible.  Slot (it + 2) % 4 was last read in iteration it - 2, and a wave that has passed the barrier of iteration it - 1 knows that
 // every wave has finished iteration it - 2 (its MFMAs consumed those reads), so the copy cannot overtake a reader.
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Fused epilogue (`fuse.idx` != nullptr; QT = 2 or 4): the merge of the splits, the ratio predicate and the per-64-query pass counts -- the
+// work of knn_hamming_merge_kernel -- happen HERE.  One split: straight from the registers that hold the final top-2 (no partial table at
+// all).  Several splits: every workgroup writes its partial top-2 as before, then takes a ticket of its (image pair, query block); the
+// workgroup that draws the last ticket folds the splits' partials of its 128 * QT queries (64-bit (distance, global row) keys, as the
+// merge kernel) and resets the ticket counter.  Same outputs as the two-kernel path bit for bit (min over keys is order-independent).
+struct HammingFuse {
+    int32_t *idx, *dist, *group_counts;
+    int *tickets;   // [batch][qblocks], zero before the launch; left zero by the last workgroup
+    int k;
+    float ratio;
+};
+
 template <int QT, int PRIO>
 __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
     const uint32_t *__restrict__ qw, size_t q_batch_words, const uint4 *__restrict__ tfrag, size_t t_batch_u4, int nq, int nt,
     int rows_per_split, int nsplit, int dshift, int qblocks, int n_items, uint2 *__restrict__ part,
-    unsigned long long *__restrict__ stamps, const int32_t *__restrict__ split_tile0) {
+    unsigned long long *__restrict__ stamps, const int32_t *__restrict__ split_tile0, HammingFuse fuse) {
     constexpr int KS = 4, NB = 4;
     __shared__ __attribute__((aligned(16))) uint4 ring[NB][KS * 64];
     const int l = threadIdx.x & 63;
@@ -437,6 +449,7 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
     }
 
     const float frame = (float)(32 * (ntiles - 1));
+    int pass_acc = 0;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         uint32_t k[2];
@@ -459,7 +472,81 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
         k1 = umed3(k0, k1, o1);
         k0 = min(k0, o1);
         const int q = (qt0 + t) * 32 + (l & 31);
-        if (h == 0 && q < nq) part[((size_t)b * nsplit + split) * nq + q] = make_uint2(k0, k1);
+        if (fuse.idx && nsplit == 1) {  // the final top-2 of the query: outputs straight from the registers
+            const uint32_t lmask = (1u << dshift) - 1u;
+            bool pass = false;
+            if (h == 0 && q < nq) {
+                const size_t o = ((size_t)b * nq + q) * fuse.k;
+                const int d0 = k0 == 0xFFFFFFFFu ? -1 : (int)(k0 >> dshift);
+                fuse.idx[o] = k0 == 0xFFFFFFFFu ? -1 : (int)(row0 + (k0 & lmask));
+                fuse.dist[o] = d0;
+                if (fuse.k == 2) {
+                    const int d1 = k1 == 0xFFFFFFFFu ? -1 : (int)(k1 >> dshift);
+                    fuse.idx[o + 1] = k1 == 0xFFFFFFFFu ? -1 : (int)(row0 + (k1 & lmask));
+                    fuse.dist[o + 1] = d1;
+                    pass = (float)d0 < __fmul_rn(fuse.ratio, (float)d1);
+                } else {
+                    pass = true;
+                }
+            }
+            const int c = __popcll(__ballot(pass));
+            pass_acc = (t & 1) ? pass_acc + c : c;   // a group of 64 queries = tiles (t even, t + 1) of this wave (qt0 is a multiple of QT)
+            if (fuse.group_counts && (t & 1) && l == 0 && (qt0 + t - 1) * 32 < nq) fuse.group_counts[(size_t)b * ((nq + 63) >> 6) + ((qt0 + t) >> 1)] = pass_acc;
+        } else if (h == 0 && q < nq) {
+            part[((size_t)b * nsplit + split) * nq + q] = make_uint2(k0, k1);
+        }
+    }
+    if (fuse.idx && nsplit > 1) {
+        // the last workgroup of this (pair, query block) folds the splits
+        __shared__ int s_last;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int old = atomicAdd(&fuse.tickets[(size_t)b * qblocks + qb], 1);
+            s_last = old == nsplit - 1;
+            if (s_last) fuse.tickets[(size_t)b * qblocks + qb] = 0;
+        }
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            const uint32_t lmask = (1u << dshift) - 1u;
+            const int q_first = qb * 4 * QT * 32;
+#pragma unroll 1
+            for (int rr = 0; rr < (4 * QT * 32) / 256; ++rr) {
+                const int q = q_first + rr * 256 + (int)threadIdx.x;
+                unsigned long long b0 = ~0ull, b1 = ~0ull;
+                auto upd = [&](unsigned long long g) {
+                    const bool lt0 = g < b0, lt1 = g < b1;
+                    b1 = lt0 ? b0 : (lt1 ? g : b1);
+                    b0 = lt0 ? g : b0;
+                };
+                bool pass = false;
+                if (q < nq) {
+                    for (int sp = 0; sp < nsplit; ++sp) {
+                        const uint2 pv = part[((size_t)b * nsplit + sp) * nq + q];
+                        const unsigned long long base = split_tile0 ? 32ull * (unsigned long long)split_tile0[(size_t)b * (nsplit + 1) + sp]
+                                                                    : (unsigned long long)sp * rows_per_split;
+                        if (pv.x != 0xFFFFFFFFu) upd(((unsigned long long)(pv.x >> dshift) << 32) | (base + (pv.x & lmask)));
+                        if (pv.y != 0xFFFFFFFFu) upd(((unsigned long long)(pv.y >> dshift) << 32) | (base + (pv.y & lmask)));
+                    }
+                    const size_t o = ((size_t)b * nq + q) * fuse.k;
+                    const int d0 = (int32_t)(b0 >> 32);
+                    fuse.idx[o] = (int32_t)(b0 & 0xFFFFFFFFull);
+                    fuse.dist[o] = d0;
+                    if (fuse.k == 2) {
+                        const int d1 = (int32_t)(b1 >> 32);
+                        fuse.idx[o + 1] = (int32_t)(b1 & 0xFFFFFFFFull);
+                        fuse.dist[o + 1] = d1;
+                        pass = (float)d0 < __fmul_rn(fuse.ratio, (float)d1);
+                    } else {
+                        pass = true;
+                    }
+                }
+                const int c = __popcll(__ballot(pass));
+                const int q_wave = q_first + rr * 256 + (int)(threadIdx.x & ~63u);   // first query of this wave's 64
+                if (fuse.group_counts && l == 0 && q_wave < nq) fuse.group_counts[(size_t)b * ((nq + 63) >> 6) + (q_wave >> 6)] = c;
+            }
+        }
     }
     if (stamps && l == 0) {
         unsigned long long *o = stamps + ((size_t)item * 4 + w) * 4;
@@ -693,9 +780,13 @@ void launch_mfma(int qt, dim3 grid, hipStream_t s, const uint4 *qf, size_t qb, c
 }  // namespace
 
 // Called by launch_knn_hamming for descriptors of at most 64 bytes.  qw/tw: word rows (nw words per row, zero padded).
+// k, ratio, d_idx, d_dist, d_group_counts: the outputs of the merge step; when the kernel chosen can produce them itself (static LDS-ring
+// kernel, QT >= 2) *fused_out = 1 and the caller skips knn_hamming_merge_kernel.
 int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_words, const uint32_t *tw, size_t t_batch_words,
                             int nq, int nt, int nw, int batch, int dshift, hipStream_t s, int *rps_out, int *nsplit_out,
-                            int *sps_out, int *tail_row0_out, const int32_t **split_tab_out, uint2 **part_out) {
+                            int *sps_out, int *tail_row0_out, const int32_t **split_tab_out, uint2 **part_out, int k, float ratio,
+                            int32_t *d_idx, int32_t *d_dist, int32_t *d_group_counts, int *fused_out) {
+    *fused_out = 0;
     int ks = 1;
     while (ks * 2 < nw) ks *= 2;  // 64-bit K-steps: nw <= 2 -> 1, 4 -> 2, 8 -> 4, 16 -> 8
     if (nw > 16) {
@@ -848,6 +939,21 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
         stamps = (unsigned long long *)sp;
         ctx->dbg_stamp_items = (int)waves;
     }
+    HammingFuse fuse{nullptr, nullptr, nullptr, nullptr, k, ratio};
+    if (lds_ring && !dyn && qt >= 2 && d_idx && d_dist && ctx->opt_hamming_fused_merge) {
+        fuse.idx = d_idx, fuse.dist = d_dist, fuse.group_counts = d_group_counts;
+        if (nsplit > 1) {  // ticket counters of the (pair, query block)s: zero when (re)allocated, left zero by every launch
+            void *tp = nullptr;
+            const size_t tb = (size_t)batch * qblocks * sizeof(int);
+            if ((rc = ws_get(ctx, WS_COUNTERS, tb, &tp))) return rc;
+            if (ctx->hamming_tickets_ptr != tp || ctx->hamming_tickets_bytes < tb) {
+                MLPL_HIP_TRY(hipMemsetAsync(tp, 0, ctx->ws_bytes[WS_COUNTERS], s));
+                ctx->hamming_tickets_ptr = tp, ctx->hamming_tickets_bytes = ctx->ws_bytes[WS_COUNTERS];
+            }
+            fuse.tickets = (int *)tp;
+        }
+        *fused_out = 1;
+    }
     prof_mark(ctx, MLPL_PROF_KNN_HAMMING, 0, s);
     if (dyn) {
 #define MLPL_DYN_LAUNCH(QT_)                                                                                                          \
@@ -862,13 +968,13 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     do {                                                                                                                               \
         if (ctx->opt_hamming_mfma_prio == 2)                                                                                           \
             hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<QT_, 2>), grid, dim3(256), 0, s, qw, q_batch_words, (const uint4 *)tf, \
-                               t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab);               \
+                               t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab, fuse);         \
         else if (ctx->opt_hamming_mfma_prio)                                                                                           \
             hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<QT_, 1>), grid, dim3(256), 0, s, qw, q_batch_words, (const uint4 *)tf, \
-                               t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab);               \
+                               t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab, fuse);         \
         else                                                                                                                           \
             hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<QT_, 0>), grid, dim3(256), 0, s, qw, q_batch_words, (const uint4 *)tf, \
-                               t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab);               \
+                               t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab, fuse);         \
     } while (0)
         if (qt == 4) MLPL_RING_LAUNCH(4);
         else if (qt == 2) MLPL_RING_LAUNCH(2);

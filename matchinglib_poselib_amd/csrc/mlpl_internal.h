@@ -110,6 +110,9 @@ struct mlpl_ctx {
     int opt_hamming_mfma_weighted;  // 1 (default) = age-aware split sizes in the static LDS-ring kernel (4 workgroups per CU)
     long long split_tab_key;        // shape key of the split table currently in WS_COUNTERS
     void *split_tab_ptr;
+    int opt_hamming_fused_merge;    // 1 (default) = the static LDS-ring kernel merges its splits / evaluates the ratio predicate itself (no merge launch)
+    void *hamming_tickets_ptr;      // zeroed ticket counters of that merge (WS_COUNTERS) ...
+    size_t hamming_tickets_bytes;   // ... and how many bytes of them are known to be zero
     int opt_hamming_stamps;         // diagnostics: the matrix-core kernel records per-wave clock stamps (mlpl_debug_hamming_stamps)
     int dbg_stamp_items;
     int opt_ransac_chunk;           // hypotheses per device pass (0 = 32768)
