@@ -296,6 +296,7 @@ struct HammingFuse {
     int *tickets;   // [batch][qblocks], zero before the launch; left zero by the last workgroup
     int k;
     float ratio;
+    int dbg;  // experiments: 1 = no idx / dist stores, 2 = no count stores, 4 = skip the whole register path
 };
 
 template <int QT, int PRIO>
@@ -475,7 +476,8 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
         if (fuse.idx && nsplit == 1) {  // the final top-2 of the query: outputs straight from the registers
             const uint32_t lmask = (1u << dshift) - 1u;
             bool pass = false;
-            if (h == 0 && q < nq) {
+            if (fuse.dbg & 4) continue;
+            if (h == 0 && q < nq && !(fuse.dbg & 1)) {
                 const size_t o = ((size_t)b * nq + q) * fuse.k;
                 const int d0 = k0 == 0xFFFFFFFFu ? -1 : (int)(k0 >> dshift);
                 fuse.idx[o] = k0 == 0xFFFFFFFFu ? -1 : (int)(row0 + (k0 & lmask));
@@ -491,24 +493,31 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
             }
             const int c = __popcll(__ballot(pass));
             pass_acc = (t & 1) ? pass_acc + c : c;   // a group of 64 queries = tiles (t even, t + 1) of this wave (qt0 is a multiple of QT)
-            if (fuse.group_counts && (t & 1) && l == 0 && (qt0 + t - 1) * 32 < nq) fuse.group_counts[(size_t)b * ((nq + 63) >> 6) + ((qt0 + t) >> 1)] = pass_acc;
+            if (fuse.group_counts && !(fuse.dbg & 2) && (t & 1) && l == 0 && (qt0 + t - 1) * 32 < nq) fuse.group_counts[(size_t)b * ((nq + 63) >> 6) + ((qt0 + t) >> 1)] = pass_acc;
         } else if (h == 0 && q < nq) {
-            part[((size_t)b * nsplit + split) * nq + q] = make_uint2(k0, k1);
+            if (fuse.idx)  // read back by another workgroup of THIS launch: written through to the coherence point (see below)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(&part[((size_t)b * nsplit + split) * nq + q]),
+                                   (unsigned long long)k0 | ((unsigned long long)k1 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                part[((size_t)b * nsplit + split) * nq + q] = make_uint2(k0, k1);
         }
     }
     if (fuse.idx && nsplit > 1) {
-        // the last workgroup of this (pair, query block) folds the splits
+        // The last workgroup of this (pair, query block) folds the splits.  No fences: an agent-scope release / acquire pair writes back
+        // and INVALIDATES the XCD's L2 -- with a workgroup finishing every few microseconds the train fragments the other workgroups
+        // stream would never stay cached (measured: 431 -> 633 us per 64-pair launch).  Instead the partials themselves are relaxed
+        // agent-scope atomics (written through / read from the coherence point), every wave waits for its own stores to be acknowledged
+        // (vmcnt(0)) before the workgroup's barrier, and only then does thread 0 draw the ticket.
         __shared__ int s_last;
-        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int old = atomicAdd(&fuse.tickets[(size_t)b * qblocks + qb], 1);
+            const int old = __hip_atomic_fetch_add(&fuse.tickets[(size_t)b * qblocks + qb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = old == nsplit - 1;
-            if (s_last) fuse.tickets[(size_t)b * qblocks + qb] = 0;
+            if (s_last) __hip_atomic_store(&fuse.tickets[(size_t)b * qblocks + qb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (s_last) {
-            __threadfence();
             const uint32_t lmask = (1u << dshift) - 1u;
             const int q_first = qb * 4 * QT * 32;
 #pragma unroll 1
@@ -523,7 +532,9 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
                 bool pass = false;
                 if (q < nq) {
                     for (int sp = 0; sp < nsplit; ++sp) {
-                        const uint2 pv = part[((size_t)b * nsplit + sp) * nq + q];
+                        const unsigned long long pw = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(&part[((size_t)b * nsplit + sp) * nq + q]),
+                                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint2 pv = make_uint2((uint32_t)pw, (uint32_t)(pw >> 32));
                         const unsigned long long base = split_tile0 ? 32ull * (unsigned long long)split_tile0[(size_t)b * (nsplit + 1) + sp]
                                                                     : (unsigned long long)sp * rows_per_split;
                         if (pv.x != 0xFFFFFFFFu) upd(((unsigned long long)(pv.x >> dshift) << 32) | (base + (pv.x & lmask)));
@@ -939,8 +950,8 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
         stamps = (unsigned long long *)sp;
         ctx->dbg_stamp_items = (int)waves;
     }
-    HammingFuse fuse{nullptr, nullptr, nullptr, nullptr, k, ratio};
-    if (lds_ring && !dyn && qt >= 2 && d_idx && d_dist && ctx->opt_hamming_fused_merge) {
+    HammingFuse fuse{nullptr, nullptr, nullptr, nullptr, k, ratio, ctx->opt_hamming_fused_merge >> 4};
+    if (lds_ring && !dyn && qt >= 2 && d_idx && d_dist && (ctx->opt_hamming_fused_merge & 1)) {
         fuse.idx = d_idx, fuse.dist = d_dist, fuse.group_counts = d_group_counts;
         if (nsplit > 1) {  // ticket counters of the (pair, query block)s: zero when (re)allocated, left zero by every launch
             void *tp = nullptr;
