@@ -130,6 +130,8 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
             ts = time.perf_counter()
             step(mode)
             per_step.append((time.perf_counter() - ts) * 1e3)
+            if mode == "two_calls_in_flight":   # when each lane's call started and ended inside the step (which lane stalled, if one did)
+                state.setdefault("lane_spans", []).append([[round((a - ts) * 1e3, 2), round((b - ts) * 1e3, 2)] for a, b in lanes.last_lane_span])
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
@@ -182,6 +184,7 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
         "value": total * steps / elapsed, "unit": "image-pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "mode": best_mode, "ms_per_step_" + other_mode: timed[other_mode][0] / steps * 1e3,
         "ms_steps_rank0": {m: [round(x, 3) for x in timed[m][1]] for m in timed},
+        "lane_spans_ms_rank0": state.get("lane_spans"),
         "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None,
         "dtype": "fp4 MFMA (Hamming, exact) + f64 / packed f32 inside a rigorous band (solver, Sampson, cheirality)", "data": "synthetic",
