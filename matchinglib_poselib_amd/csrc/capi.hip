@@ -143,6 +143,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_solver_wave3 = 1;
     ctx->opt_ransac_device_draw = 1;
     ctx->opt_usac_lo_warm_start = 1;
+    ctx->opt_arrsac_refine_warm_start = 1;
     ctx->opt_usac_sprt_fast = 1;
     ctx->opt_l2_float_mfma = 1;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -218,6 +219,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "ransac_overlap") && (value == 0 || value == 1)) ctx->opt_ransac_overlap = value;
     else if (!std::strcmp(name, "rand_cache_max") && value >= 0) ctx->opt_rand_cache_max = value;
     else if (!std::strcmp(name, "ransac_f32_filter") && (value == 0 || value == 1)) ctx->opt_ransac_f32_filter = value;
+    else if (!std::strcmp(name, "arrsac_refine_warm_start") && (value == 0 || value == 1)) ctx->opt_arrsac_refine_warm_start = value;
     else if (!std::strcmp(name, "ransac_count_mpl") && (value == 1 || value == 2)) ctx->opt_ransac_count_mpl = value;
     else if (!std::strcmp(name, "ransac_event_cap") && value >= 0 && value <= 1024) ctx->opt_ransac_event_cap = value;
     else if (!std::strcmp(name, "solver_polish") && (value == 0 || value == 1)) ctx->opt_solver_polish = value;

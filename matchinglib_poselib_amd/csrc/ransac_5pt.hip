@@ -3552,7 +3552,7 @@ int mlpl_robust_essential_refine(mlpl_ctx *ctx, const double *p1, const double *
     {
         Launcher L;
         L.s = s;
-        ArrRefineArgs ra{{1, 1}, (const double4 *)pts, (const uint8_t *)dmask, n, (const double *)d_E, th, d_E + 9, d_info};
+        ArrRefineArgs ra{{1, 1}, (const double4 *)pts, (const uint8_t *)dmask, n, (const double *)d_E, th, d_E + 9, d_info, ctx->opt_arrsac_refine_warm_start};
         L.launch(HK_ARR_REFINE, ra);
     }
     MLPL_HIP_TRY(hipGetLastError());
