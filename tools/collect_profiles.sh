@@ -17,4 +17,8 @@ timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fe
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python $ARGS > "$OUT/pmc_write.log" 2>&1
 timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F16 SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/pmc_sq" -- python $ARGS > "$OUT/pmc_sq.log" 2>&1
 timeout -k 10 400 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_grbm" -- python $ARGS > "$OUT/pmc_grbm.log" 2>&1
-ls -R "$OUT" | head -40
+# 4. the C5 batch (both driving modes) and the sequential estimators under the kernel trace
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c5_trace" -- python bench.py --workload c5 --steps 6 --warmup 2 --no-cpu-baseline > "$OUT/c5_under_rocprof.json" 2> "$OUT/c5_trace.err"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/usac_trace" -- python tools/usac_profile_run.py 40 > "$OUT/usac_profile_run.txt" 2> "$OUT/usac_trace.err"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c5_usac_trace" -- python tools/c5_usac_timing.py 512 > "$OUT/c5_usac_under_rocprof.json" 2> "$OUT/c5_usac_trace.err"
+ls -R "$OUT" | head -60

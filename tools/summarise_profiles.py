@@ -105,3 +105,12 @@ json.dump(traffic, open(old, "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 for k, e in summary.items():
     print(k, {c: round(v["mean"], 1) for c, v in e.items() if isinstance(v, dict) and "mean" in v})
+
+# round 4 on: the C5 batch, the sequential estimators and C5 with USAC under the kernel trace
+for sub, name in (("c5_trace", "c5_kernel_stats.csv"), ("usac_trace", "usac_kernel_stats.csv"), ("c5_usac_trace", "c5_usac_kernel_stats.csv")):
+    f = one(f"{sub}/*/*kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(DST, f"{R}_{name}"))
+p = os.path.join(SRC, "usac_profile_run.txt")
+if os.path.exists(p):
+    open(os.path.join(DST, f"{R}_usac_profile_run.txt"), "w").write("".join(l for l in open(p) if not l.startswith(("W2", "E2", "/opt"))))

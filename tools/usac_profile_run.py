@@ -17,13 +17,15 @@ def main():
     from matchinglib_poselib_amd import pose, synth
 
     calls = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-    for name, kw in (("general", {}), ("rotation", dict(t_len=0.0))):
+    for name, kw, uk in (("general", {}, dict(check_degeneracy=3)), ("rotation", dict(t_len=0.0), dict(check_degeneracy=3)),
+                         ("general, ConfigUSAC's defaults (POSE_STEWENIUS, REF_STEWENIUS_WEIGHTS, DEGEN_USAC_INTERNAL)", {},
+                          dict(check_degeneracy=1, refine=5, estimator=2, sprt_ms=6.0, sprt_tm=2736.0))):
         p1, p2, R, t, truth, th = synth.pose_scene(5000, 0.5, seed=20260103, **kw)
-        pose.usac_essential(p1, p2, th, 1, check_degeneracy=3)   # warm-up: workspaces
+        pose.usac_essential(p1, p2, th, 1, **uk)   # warm-up: workspaces
         ts, st = [], np.zeros(8)
         for c in range(calls):
             t0 = time.perf_counter()
-            d = pose.usac_essential(p1, p2, th, 100 + c, check_degeneracy=3)
+            d = pose.usac_essential(p1, p2, th, 100 + c, **uk)
             ts.append(time.perf_counter() - t0)
             st += d["stats"]
         st /= calls
