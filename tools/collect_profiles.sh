@@ -21,4 +21,8 @@ timeout -k 10 400 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/p
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c5_trace" -- python bench.py --workload c5 --steps 6 --warmup 2 --no-cpu-baseline > "$OUT/c5_under_rocprof.json" 2> "$OUT/c5_trace.err"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/usac_trace" -- python tools/usac_profile_run.py 40 > "$OUT/usac_profile_run.txt" 2> "$OUT/usac_trace.err"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c5_usac_trace" -- python tools/c5_usac_timing.py 512 > "$OUT/c5_usac_under_rocprof.json" 2> "$OUT/c5_usac_trace.err"
-ls -R "$OUT" | head -60
+# 5. keep what tools/summarise_profiles.py reads (gpurun merges at most 64 MiB back): no databases, no per-dispatch traces of step 4
+find "$OUT" -name '*.db' -delete
+for d in c5_trace usac_trace c5_usac_trace; do find "$OUT/$d" -name '*kernel_trace.csv' -delete; done
+find "$OUT" -name '*agent_info.csv' -delete
+du -sh "$OUT" "$OUT"/*
