@@ -17,7 +17,6 @@ enum HubKernelId {
     HK_USAC_DG_ROWS,
     HK_USAC5_BEGIN,
     HK_USAC5_CHOOSE,
-    HK_USAC5_RECHECK,
     HK_USAC5_EVAL,
     HK_USAC5_GRAM,
     HK_ARR_SAMPLE,
@@ -65,9 +64,11 @@ struct RefitSolveArgs {
     size_t part_stride;
     const char *gate;
     size_t gate_stride;
+    char *warm;          // optional: 82 doubles per system, warm_stride bytes apart (refit_solve_body)
+    size_t warm_stride;
 };
 __device__ __forceinline__ void hub_refit_solve_body(const RefitSolveArgs &a, int bx, int) {
-    refit_solve_body(a.gram_part, a.nparts, a.rec, a.part_stride, a.gate, a.gate_stride, bx);
+    refit_solve_body(a.gram_part, a.nparts, a.rec, a.part_stride, a.gate, a.gate_stride, bx, a.warm, a.warm_stride);
 }
 MLPL_HUB_KERNEL(HK_REFIT_SOLVE, RefitSolveArgs, hub_refit_solve_body, 64);
 

@@ -424,7 +424,7 @@ int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_strid
         int rc = launch_knn_hamming_mfma(ctx, qw, qbw, tw, tbw, nq, nt, nw, batch, dshift, s, &rps, &nsplit, &sps, &tail_row0, &split_tab,
                                          &part, k, ratio, d_idx, d_dist, d_group_counts, &fused);
         if (rc) return rc;
-        if (!fused && !(ctx->opt_hamming_fused_merge & 128)) {  // (the static LDS-ring kernel merges its splits, evaluates the ratio predicate and counts by itself; 128: timing experiment, no merge at all)
+        if (!fused) {  // (the static LDS-ring kernel merges its splits, evaluates the ratio predicate and counts by itself)
             const MergeTail tail{qw, tw, qbw, tbw, nw, tail_row0, nt - tail_row0, split_tab};
             launch_merge(s, (const uint2 *)part, nq, nsplit, rps, dshift, k, ratio, batch, d_idx, d_dist, d_group_counts, sps, tail);
         }

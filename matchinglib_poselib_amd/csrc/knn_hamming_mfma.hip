@@ -296,7 +296,6 @@ struct HammingFuse {
     int *tickets;   // [batch][qblocks], zero before the launch; left zero by the last workgroup
     int k;
     float ratio;
-    int dbg;  // experiments: 1 = no idx / dist stores, 2 = no count stores, 4 = skip the whole register path
 };
 
 template <int QT, int PRIO>
@@ -476,8 +475,7 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
         if (fuse.idx && nsplit == 1) {  // the final top-2 of the query: outputs straight from the registers
             const uint32_t lmask = (1u << dshift) - 1u;
             bool pass = false;
-            if (fuse.dbg & 4) continue;
-            if (h == 0 && q < nq && !(fuse.dbg & 1)) {
+            if (h == 0 && q < nq) {
                 const size_t o = ((size_t)b * nq + q) * fuse.k;
                 const int d0 = k0 == 0xFFFFFFFFu ? -1 : (int)(k0 >> dshift);
                 fuse.idx[o] = k0 == 0xFFFFFFFFu ? -1 : (int)(row0 + (k0 & lmask));
@@ -493,7 +491,7 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
             }
             const int c = __popcll(__ballot(pass));
             pass_acc = (t & 1) ? pass_acc + c : c;   // a group of 64 queries = tiles (t even, t + 1) of this wave (qt0 is a multiple of QT)
-            if (fuse.group_counts && !(fuse.dbg & 2) && (t & 1) && l == 0 && (qt0 + t - 1) * 32 < nq) fuse.group_counts[(size_t)b * ((nq + 63) >> 6) + ((qt0 + t) >> 1)] = pass_acc;
+            if (fuse.group_counts && (t & 1) && l == 0 && (qt0 + t - 1) * 32 < nq) fuse.group_counts[(size_t)b * ((nq + 63) >> 6) + ((qt0 + t) >> 1)] = pass_acc;
         } else if (h == 0 && q < nq) {
             if (fuse.idx)  // read back by another workgroup of THIS launch: written through to the coherence point (see below)
                 __hip_atomic_store(reinterpret_cast<unsigned long long *>(&part[((size_t)b * nsplit + split) * nq + q]),
@@ -950,7 +948,7 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
         stamps = (unsigned long long *)sp;
         ctx->dbg_stamp_items = (int)waves;
     }
-    HammingFuse fuse{nullptr, nullptr, nullptr, nullptr, k, ratio, ctx->opt_hamming_fused_merge >> 4};
+    HammingFuse fuse{nullptr, nullptr, nullptr, nullptr, k, ratio};
     if (lds_ring && !dyn && qt >= 2 && d_idx && d_dist && (ctx->opt_hamming_fused_merge & 1)) {
         fuse.idx = d_idx, fuse.dist = d_dist, fuse.group_counts = d_group_counts;
         if (nsplit > 1) {  // ticket counters of the (pair, query block)s: zero when (re)allocated, left zero by every launch

@@ -2080,9 +2080,14 @@ __device__ __forceinline__ void order_desc9(const Jacobi9Lds &J, int *order) {
 
 // One workgroup (one wave) per system: blockIdx.x selects the system's parts (part_stride doubles apart) and its record.  `gate` (optional):
 // an int per system, gate_stride bytes apart -- a system whose gate is 0 is not solved and its record says "no models" (USAC's local
-// optimisation: chains whose step has no fit, usac_impl.h).
+// optimisation: chains whose step has no fit, usac_impl.h).  `warm` (optional): 82 doubles per system, warm_stride bytes apart; [0] != 0
+// says that [1..81] hold the eigenvectors V_prev of the system's previous fit: consecutive fits of a chain see nearly the same Gram
+// matrix, so the iteration starts from V_prev^T G V_prev (nearly diagonal) and accumulates onto V_prev -- the same decomposition to the
+// same tolerance in 2-4 sweeps instead of 7-8 (a basis vector may come out with the other sign; the solutions do not depend on it).  The
+// eigenvectors of this fit are left there for the next.
 __device__ __forceinline__ void refit_solve_body(const double *__restrict__ gram_part, int nparts, PolyRec *__restrict__ rec, size_t part_stride,
-                                                 const char *__restrict__ gate, size_t gate_stride, const int vbx) {
+                                                 const char *__restrict__ gate, size_t gate_stride, const int vbx, char *warm_base = nullptr,
+                                                 size_t warm_stride = 0) {
     __shared__ SolveLds L;
     __shared__ Jacobi9Lds J;
     __shared__ double gsum[45];
@@ -2094,24 +2099,54 @@ __device__ __forceinline__ void refit_solve_body(const double *__restrict__ gram
         if (lane == 0) rec->ok = 0.0;
         return;
     }
+    double *warm = warm_base ? reinterpret_cast<double *>(warm_base + (size_t)vbx * warm_stride) : nullptr;
+    const bool is_warm = warm && warm[0] != 0.0;  // wave-uniform
     if (lane < 45) {  // fixed summation order over the blocks: run-to-run deterministic
         double sacc = 0;
         for (int pblk = 0; pblk < nparts; ++pblk) sacc += gram_part[(size_t)pblk * 45 + lane];
         gsum[lane] = sacc;
     }
+    if (is_warm)
+        for (int e = lane; e < 81; e += 64) J.Vv[e / 9][e % 9] = warm[1 + e];
     wave_sync();
-    if (lane == 0) {
-        int t = 0;
-        for (int a = 0; a < 9; ++a)
-            for (int b = a; b < 9; ++b) {
-                J.G[a][b] = gsum[t];
-                J.G[b][a] = gsum[t];
-                ++t;
+    if (!is_warm) {
+        if (lane == 0) {
+            int t = 0;
+            for (int a = 0; a < 9; ++a)
+                for (int b = a; b < 9; ++b) {
+                    J.G[a][b] = gsum[t];
+                    J.G[b][a] = gsum[t];
+                    ++t;
+                }
+        }
+        for (int e = lane; e < 81; e += 64) J.Vv[e / 9][e % 9] = (e / 9 == e % 9) ? 1.0 : 0.0;
+    } else {
+        // Gn = G V_prev (G read from the packed upper triangle), then G = V_prev^T Gn, upper triangle mirrored
+        for (int e = lane; e < 81; e += 64) {
+            const int a = e / 9, b = e - a * 9;
+            double acc = 0;
+            for (int k = 0; k < 9; ++k) {
+                const int lo = a < k ? a : k, hi = a < k ? k : a;
+                acc += gsum[lo * 9 - lo * (lo - 1) / 2 + (hi - lo)] * J.Vv[k][b];
             }
+            J.Gn[a][b] = acc;
+        }
+        wave_sync();
+        for (int e = lane; e < 81; e += 64) {
+            const int a = e / 9, b = e - a * 9;
+            if (a > b) continue;
+            double acc = 0;
+            for (int k = 0; k < 9; ++k) acc += J.Vv[k][a] * J.Gn[k][b];
+            J.G[a][b] = acc;
+            J.G[b][a] = acc;
+        }
     }
-    for (int e = lane; e < 81; e += 64) J.Vv[e / 9][e % 9] = (e / 9 == e % 9) ? 1.0 : 0.0;
     wave_sync();
     jacobi9_wave(J, lane);
+    if (warm) {
+        for (int e = lane; e < 81; e += 64) warm[1 + e] = J.Vv[e / 9][e % 9];
+        if (lane == 0) warm[0] = 1.0;
+    }
     if (lane == 0) {
         // order eigenvalues descending; EE = eigenvectors of the 4 smallest, in descending order (five-point.cpp:388)
         int order[9];

@@ -618,6 +618,7 @@ struct UsacLo5State {  // device, one per chain
     double E[9];       // current model (denormalised)
     int32_t alive, step_fit, fit_pts, pad;
     int32_t cnt_inl[kLo5MaxBlocks], cnt_mem[kLo5MaxBlocks];
+    double warm[82];   // [0] != 0: [1..81] hold the eigenvectors of the chain's previous fit (refit_solve_body starts its iteration there)
 };
 struct UsacLo5Out {    // pinned host memory, one per chain, followed by kUsacLoEvals bit rows of `words` words
     int32_t evals, cnt2, first_fit, pad;  // first_fit: 1 = the sample's fit gave a model, 2 = it gave none (fresh chains)
@@ -684,6 +685,7 @@ __device__ __forceinline__ void usac5_begin_body(const Usac5BeginArgs &A, const 
     UsacLo5Out *O = reinterpret_cast<UsacLo5Out *>(out_base + (size_t)c * out_stride);
     if (lane == 0) {
         S.alive = 1, S.step_fit = I.start_step < 0 ? 1 : 0, S.fit_pts = I.start_step < 0 ? kUsacLoSample : 0;
+        S.warm[0] = 0.0;  // a chain's first fit after (re)start is a cold one
         O->evals = 0, O->cnt2 = 0, O->first_fit = 0;
     }
     if (lane < kUsacLoEvals) O->fit_pts[lane] = 0, O->fit_state[lane] = 0, O->hist_nm[lane] = -1;
@@ -715,38 +717,79 @@ __device__ __forceinline__ double usac5_wave_min(double v) {
 
 // The solution generateRefinedModel keeps (:697-752 / :793-848): lanes j < nm hold solution j (E, and its key in the order convention);
 // Sampson-error sums over the inliers of the best model so far in index order, every fourth index a check whether the smallest sum is
-// below 0.66 of the second smallest; then std::min_element over the sums in the convention's order.  One wave; returns the lane.
+// below 0.66 of the second smallest; then std::min_element over the sums in the convention's order.  One wave (the block); returns the lane.
+// The sums are one dependent chain per solution and the exit test couples the solutions, but neither needs the ERRORS in sequence: per
+// chunk of 64 indices the flagged ones are compacted, lane = correspondence evaluates its error under every solution (LDS), lane =
+// solution turns its row into running sums by adding in index order (the reference's additions, one after the other), and lane =
+// correspondence again evaluates the exit test on the running sums of its index; the first index whose test holds ends the loop with
+// the sums as they stood there.  Same sums, same exit, same choice as the one-index-at-a-time loop (lo5_pick_host keeps that form) at
+// one global-load latency per 64 indices instead of one per inlier: 81 -> ~5 us per choice in a merged launch, whose duration is its
+// slowest chain's.
+struct Usac5PickLds {
+    double err[10][64];  // [solution][compacted member]: errors, then running sums
+    double E[10][9];
+    int idx[64];
+};
 __device__ __forceinline__ int usac5_pick(const double *E, double key, int nm, int lane, const double *__restrict__ p1,
                                           const double *__restrict__ p2, int n, const uint8_t *__restrict__ flags) {
     if (nm <= 1) return 0;
+    __shared__ Usac5PickLds L;
     int pos = 0;  // position in the convention (ascending key, stable): it only breaks ties of the error sums
     for (int k = 0; k < nm; ++k) {
         const double kk = __shfl(key, k);
         pos += (kk < key || (kk == key && k < lane)) ? 1 : 0;
     }
+    if (lane < nm) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) L.E[lane][k] = E[k];
+    }
+    wave_sync();
     double sum = 0;
-    bool done = false;
-    for (int i0 = 0; i0 < n && !done; i0 += 64) {
+    for (int i0 = 0; i0 < n; i0 += 64) {
         const int ii = i0 + lane;
-        unsigned long long mask = __ballot(ii < n && flags[ii] != 0);
-        while (mask) {
-            const int b = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const int i = i0 + b;
-            const double x1 = p1[2 * i], y1 = p1[2 * i + 1], x2 = p2[2 * i], y2 = p2[2 * i + 1];
-            if (lane < nm) sum += usac_sampson(E, x1, y1, x2, y2);
-            if ((i > 3) && (i % 4 == 0)) {
-                const double v = lane < nm ? sum : INFINITY;
-                const double m1 = usac5_wave_min(v);
-                const unsigned long long at_min = __ballot(v == m1);
-                const int first = __ffsll((long long)at_min) - 1;
-                const double m2 = usac5_wave_min(lane == first ? INFINITY : v);
-                if (m1 < 0.66 * m2) {
-                    done = true;
-                    break;
-                }
+        const bool in_range = ii < n;
+        const uint8_t f = in_range ? flags[ii] : (uint8_t)0;
+        double x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+        if (in_range) x1 = p1[2 * ii], y1 = p1[2 * ii + 1], x2 = p2[2 * ii], y2 = p2[2 * ii + 1];
+        const unsigned long long mask = __ballot(f != 0);
+        if (!mask) continue;
+        const int cnt = __popcll(mask);
+        if (f != 0) {
+            const int r = __popcll(mask & ((1ull << lane) - 1ull));
+            L.idx[r] = ii;
+            for (int sidx = 0; sidx < nm; ++sidx) L.err[sidx][r] = usac_sampson(L.E[sidx], x1, y1, x2, y2);
+        }
+        wave_sync();
+        if (lane < nm) {
+            double run = sum;
+            for (int r = 0; r < cnt; ++r) {
+                run += L.err[lane][r];
+                L.err[lane][r] = run;
             }
         }
+        wave_sync();
+        bool hit = false;
+        if (lane < cnt) {
+            const int i = L.idx[lane];
+            if ((i > 3) && (i % 4 == 0)) {
+                // smallest sum, the first solution holding it, smallest of the others (a lane without a solution counts as +inf, as in
+                // the wave-wide form; fmin ignores a NaN sum as it did there)
+                double m1 = INFINITY;
+                for (int sidx = 0; sidx < nm; ++sidx) m1 = fmin(m1, L.err[sidx][lane]);
+                int first = nm;
+                for (int sidx = nm - 1; sidx >= 0; --sidx)
+                    if (L.err[sidx][lane] == m1) first = sidx;
+                double m2 = INFINITY;
+                for (int sidx = 0; sidx < nm; ++sidx)
+                    if (sidx != first) m2 = fmin(m2, L.err[sidx][lane]);
+                hit = m1 < 0.66 * m2;
+            }
+        }
+        const unsigned long long hits = __ballot(hit);
+        const int last = hits ? __ffsll((long long)hits) - 1 : cnt - 1;
+        if (lane < nm) sum = L.err[lane][last];
+        wave_sync();
+        if (hits) break;
     }
     const double v = lane < nm ? sum : INFINITY;
     const double m1 = usac5_wave_min(v);
@@ -1035,12 +1078,41 @@ __device__ __forceinline__ void usac5_gram_body(const Usac5GramArgs &A, const in
 #pragma unroll
             for (int y = x; y < 9; ++y) acc[t++] += q[x] * q[y];
     }
+    // wave-wide sums of the 45 accumulators by a transposing butterfly: at distance `off` a lane keeps one half of the values it still
+    // holds and hands the other half to its partner (23 + 12 + 6 + 3 + 2 + 1 = 47 exchanges instead of 45 x 6); afterwards lane l holds
+    // the total of value usac5_red_slot(l) -- a fixed order of additions, the same in every launch form
+    {
+        double buf[48];
 #pragma unroll
-    for (int k = 0; k < 45; ++k) {
-        double v = acc[k];
+        for (int k = 0; k < 48; ++k) buf[k] = k < 45 ? acc[k] : 0.0;
+        int len = 48;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) red[wave][k] = v;
+        for (int off = 32; off > 0; off >>= 1) {
+            const int half = len >> 1;  // 24, 12, 6, 3 -> then 3 is odd: handled below
+            if (len & 1) break;
+            const bool upper = (lane & off) != 0;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) {
+                if (k >= half) break;
+                const double send = upper ? buf[k] : buf[k + half];
+                const double keep = upper ? buf[k + half] : buf[k];
+                buf[k] = keep + __shfl_xor(send, off);
+            }
+            len = half;
+        }
+        // len == 3 after the distances 32, 16, 8, 4: lanes with equal (lane >> 2) hold partial sums of the same three values
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            buf[k] += __shfl_xor(buf[k], 2);
+            buf[k] += __shfl_xor(buf[k], 1);
+        }
+        // value index held by this lane group: bit 5 of the lane selects the upper 24 of 48, bit 4 the upper 12 of those, ...
+        if ((lane & 3) == 0) {
+            const int base = ((lane >> 5) & 1) * 24 + ((lane >> 4) & 1) * 12 + ((lane >> 3) & 1) * 6 + ((lane >> 2) & 1) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (base + k < 45) red[wave][base + k] = buf[k];
+        }
     }
     __syncthreads();
     if (tid < 45) part[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
@@ -1761,7 +1833,8 @@ struct UsacRun {
         Usac5BeginArgs ba{{C, 1}, d_p1, d_p2, (const UsacLoIn *)(d_lo_in + c0), st, gram, part_stride, outp, stride};
         L.launch(HK_USAC5_BEGIN, ba);
         auto fit = [&](int nparts, int fit_eval, int ends) {
-            RefitSolveArgs ra{{C, 1}, (const double *)gram, nparts, recs, part_stride, gate, sizeof(UsacLo5State)};
+            RefitSolveArgs ra{{C, 1}, (const double *)gram, nparts, recs, part_stride, gate, sizeof(UsacLo5State),
+                              ctx->opt_usac_lo_warm_start ? reinterpret_cast<char *>(st) + offsetof(UsacLo5State, warm) : nullptr, sizeof(UsacLo5State)};
             L.launch(HK_REFIT_SOLVE, ra);
             RootsArgs ro{{(C + kHypPerWave - 1) / kHypPerWave, 1}, (const PolyRec *)recs, C, Etab, nm};
             L.launch(ctx->opt_solver_polish ? HK_ROOTS_POLISH : HK_ROOTS_PLAIN, ro);

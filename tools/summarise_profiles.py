@@ -11,7 +11,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 SRC = os.path.join(ROOT, "gpurun_out", R)
-DST = os.path.join(ROOT, "profiles")
+DST = os.environ.get("MLPL_PROFILE_DST") or os.path.join(ROOT, "profiles")  # collect_profiles.sh summarises on the GPU box into gpurun_out/<round>_summary
+os.makedirs(DST, exist_ok=True)
 
 
 def short(name):
@@ -95,8 +96,9 @@ if kt:
         traffic["kernel_us_rocprof_trace"] = sum(d) / len(d) / 1e3
         traffic["kernel_launches_rocprof_trace"] = len(d)
 old = os.path.join(DST, "pmc_traffic.json")
-if os.path.exists(old):
-    prev = json.load(open(old))
+prev_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+if os.path.exists(prev_file):
+    prev = json.load(open(prev_file))
     for k in ("knn_hamming_partial_bytes_per_launch",):
         if k not in traffic and k in prev:
             traffic[k] = prev[k]
