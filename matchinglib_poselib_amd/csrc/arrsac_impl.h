@@ -1384,61 +1384,90 @@ int arrsac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const d
         const ArrsacRun::Layout Y = ArrsacRun::layout(std::max(counts[b], 6));
         max_dev = std::max(max_dev, Y.dev_total), max_pin = std::max(max_pin, Y.pin_total);
     }
-    const int runs_max = std::min(B, kArrBatchRuns);
+    // cohorts of <= kArrBatchRuns runs, two in flight (batch_hub.h kHubLanes): one cohort's host turns run beside the other's launches
+    const int cohort_max = ctx->opt_hub_cohort > 0 ? ctx->opt_hub_cohort : kArrBatchRuns;
+    const int lanes_wanted = ctx->opt_hub_lanes > 0 ? std::min(ctx->opt_hub_lanes, kHubLanes) : kHubLanes;
+    const int cohort = B >= 8 * lanes_wanted ? std::min(cohort_max, (B + lanes_wanted - 1) / lanes_wanted) : B;
+    const int n_cohorts = (B + cohort - 1) / cohort, lanes = std::min(lanes_wanted, n_cohorts);
     void *pblk, *dblk;
-    if ((rc = pinned_batch_get(ctx, (size_t)runs_max * max_pin, &pblk))) return rc;
-    if ((rc = ws_get(ctx, WS_BATCH_RUNS, (size_t)runs_max * max_dev, &dblk))) return rc;
+    if ((rc = pinned_batch_get(ctx, (size_t)lanes * cohort * max_pin, &pblk))) return rc;
+    if ((rc = ws_get(ctx, WS_BATCH_RUNS, (size_t)lanes * cohort * max_dev, &dblk))) return rc;
     char *pin = (char *)pblk, *pin_dev = nullptr;
     {
         void *alias = nullptr;
         MLPL_HIP_TRY(hipHostGetDevicePointer(&alias, pin, 0));
         pin_dev = (char *)alias;
     }
+    hipStream_t lane_stream[kHubLanes];
+    for (int l = 0; l < lanes; ++l)
+        if ((rc = hub_lane_stream(ctx, l, s, &lane_stream[l]))) return rc;
+    if (lanes > 1) MLPL_HIP_TRY(hipStreamSynchronize(s));  // the correspondences were produced on the caller's stream; a lane's own stream has no other ordering
+    struct LaneOut {
+        long long rounds = 0, merged = 0;
+        int first_err = 0;
+        std::string first_msg;
+    };
+    LaneOut lane_out[kHubLanes];
+    auto serve_lane = [&](int l) {
+        LaneOut &LO = lane_out[l];
+        const hipStream_t ls = lane_stream[l];
+        for (int c = l; c < n_cohorts; c += lanes) {
+            const int b0 = c * cohort, nb = std::min(cohort, B - b0);
+            BatchHub hub(ctx, ls, nb, l);
+            std::vector<ArrBufs> bufs((size_t)nb);
+            std::vector<std::string> msgs((size_t)nb);
+            for (int k = 0; k < nb; ++k) {
+                const size_t slot = (size_t)l * cohort + k;
+                bufs[k].dev = (char *)dblk + slot * max_dev;
+                bufs[k].pin = pin + slot * max_pin, bufs[k].pin_dev = pin_dev + slot * max_pin;
+            }
+            HubThreads &pool = hub_resources(ctx)->lane[l].threads;
+            pool.start(nb, [&](int k) {
+                const int b = b0 + k;
+                HubRun &hr = hub.run(k);
+                int r = MLPL_OK;
+                if (counts[b] < 6) {  // (a pair without enough matches in a batch of image pairs: nothing to estimate)
+                    status[b] = MLPL_E_FAILED;
+                    if (n_inliers) n_inliers[b] = 0;
+                    hub.finish(hr);
+                    return;
+                }
+                try {
+                    ArrsacRun R;
+                    R.ctx = ctx, R.s = ls, R.L.s = ls, R.L.hub = &hub, R.L.run = &hr, R.bufs = &bufs[k];
+                    R.d_p1 = d_p1 + (size_t)b * stride * 2, R.d_p2 = d_p2 + (size_t)b * stride * 2, R.n = counts[b];
+                    int ninl = 0;
+                    r = arrsac_run_problem(R, thresh, refine, rng_states + 2 * (size_t)b, E + (size_t)b * 9, d_masks + (size_t)b * stride, &ninl, nullptr);
+                    if (n_inliers) n_inliers[b] = ninl;
+                } catch (const std::bad_alloc &) {
+                    r = MLPL_E_NOMEM;
+                    set_error("mlpl_arrsac_essential_batch_dev: out of host memory");
+                }
+                if (r && r != MLPL_E_FAILED) msgs[k] = mlpl_last_error();
+                status[b] = r;
+                hub.finish(hr);
+            }, ctx->opt_hub_workers);
+            const int hrc = hub.serve();
+            pool.wait();
+            LO.rounds += hub.rounds(), LO.merged += hub.merged_launches();
+            for (int k = 0; k < nb && !LO.first_err; ++k)
+                if (status[b0 + k] && status[b0 + k] != MLPL_E_FAILED) LO.first_err = status[b0 + k], LO.first_msg = msgs[k];
+            if (hrc && !LO.first_err) LO.first_err = hrc;
+            if (LO.first_err) break;
+        }
+    };
+    {
+        std::vector<std::thread> others;
+        for (int l = 1; l < lanes; ++l) others.emplace_back(serve_lane, l);
+        serve_lane(0);
+        for (auto &t : others) t.join();
+    }
     int first_err = 0;
     std::string first_msg;
     long long rounds = 0, merged = 0;
-    for (int b0 = 0; b0 < B; b0 += kArrBatchRuns) {
-        const int nb = std::min(kArrBatchRuns, B - b0);
-        BatchHub hub(ctx, s, nb);
-        std::vector<ArrBufs> bufs((size_t)nb);
-        std::vector<std::string> msgs((size_t)nb);
-        for (int k = 0; k < nb; ++k) {
-            bufs[k].dev = (char *)dblk + (size_t)k * max_dev;
-            bufs[k].pin = pin + (size_t)k * max_pin, bufs[k].pin_dev = pin_dev + (size_t)k * max_pin;
-        }
-        HubThreads &pool = hub_resources(ctx)->threads;
-        pool.start(nb, [&](int k) {
-            const int b = b0 + k;
-            HubRun &hr = hub.run(k);
-            int r = MLPL_OK;
-            if (counts[b] < 6) {  // (a pair without enough matches in a batch of image pairs: nothing to estimate)
-                status[b] = MLPL_E_FAILED;
-                if (n_inliers) n_inliers[b] = 0;
-                hub.finish(hr);
-                return;
-            }
-            try {
-                ArrsacRun R;
-                R.ctx = ctx, R.s = s, R.L.s = s, R.L.hub = &hub, R.L.run = &hr, R.bufs = &bufs[k];
-                R.d_p1 = d_p1 + (size_t)b * stride * 2, R.d_p2 = d_p2 + (size_t)b * stride * 2, R.n = counts[b];
-                int ninl = 0;
-                r = arrsac_run_problem(R, thresh, refine, rng_states + 2 * (size_t)b, E + (size_t)b * 9, d_masks + (size_t)b * stride, &ninl, nullptr);
-                if (n_inliers) n_inliers[b] = ninl;
-            } catch (const std::bad_alloc &) {
-                r = MLPL_E_NOMEM;
-                set_error("mlpl_arrsac_essential_batch_dev: out of host memory");
-            }
-            if (r && r != MLPL_E_FAILED) msgs[k] = mlpl_last_error();
-            status[b] = r;
-            hub.finish(hr);
-        });
-        const int hrc = hub.serve();
-        pool.wait();
-        rounds += hub.rounds(), merged += hub.merged_launches();
-        for (int k = 0; k < nb && !first_err; ++k)
-            if (status[b0 + k] && status[b0 + k] != MLPL_E_FAILED) first_err = status[b0 + k], first_msg = msgs[k];
-        if (hrc && !first_err) first_err = hrc;
-        if (first_err) break;
+    for (int l = 0; l < lanes; ++l) {
+        rounds += lane_out[l].rounds, merged += lane_out[l].merged;
+        if (lane_out[l].first_err && !first_err) first_err = lane_out[l].first_err, first_msg = lane_out[l].first_msg;
     }
     ctx->last_arrsac_stats[8] = rounds, ctx->last_arrsac_stats[9] = merged;
     if (first_err) {

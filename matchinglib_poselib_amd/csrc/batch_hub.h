@@ -8,10 +8,11 @@
 //   * every kernel of those paths has the form  body(const Args &, block x, block y)  with two entry points generated from it: the
 //     single launch  k<<<grid>>>(Args)  and the merged launch  k_batch<<<(max grid x, max grid y, items)>>>(Args items[])  in which
 //     blockIdx.z selects the item (a run's launch) and blocks beyond an item's own grid return at once;
-//   * a run issues its launches through a Launcher.  Alone, the Launcher launches and waits as before.  In a batch every run is a host
-//     thread (its sequential code is unchanged: a thread is the run's stack), its Launcher RECORDS the launches of a chain, and its
-//     wait hands the list to the hub and blocks;
-//   * the hub -- the calling thread -- waits until every live run is blocked, groups the runs by the kernel sequence of their lists
+//   * a run issues its launches through a Launcher.  Alone, the Launcher launches and waits as before.  In a batch every run is a
+//     fiber on one of a few worker threads (its sequential code is unchanged: the fiber is the run's stack), its Launcher RECORDS the
+//     launches of a chain, and its wait hands the list to the hub and yields;
+//   * the hub -- the calling thread, or a lane's thread: up to four cohorts of runs are served side by side, so that one cohort's host
+//     turns run beside another's launches -- waits until every live run of its cohort is blocked, groups the runs by the kernel sequence of their lists
 //     (runs at the same point of their control flow have the same sequence), issues per group and position ONE merged launch, waits for
 //     the stream once and wakes everybody.  Host decisions of different runs execute in parallel on the host cores in between.
 // Results do not depend on the grouping: a run's launches see exactly the arguments it recorded, in its order.
@@ -74,18 +75,74 @@ struct HubLaunch {
     alignas(16) unsigned char args[kHubArgBytes];
 };
 
-// The runs of a batch are host threads; creating 128 of them costs ~2.5 ms, a fifth of a batch: they are kept (blocked) between calls.
+// ---- the runs of a batch: fibers on a few worker threads ---------------------------------------------------------------------------------
+// A run is a sequential program with its own stack that blocks 6-12 times per problem on the hub.  As one kernel thread per run (round 4's
+// first form) every such wait was a futex sleep and a wake-up of 128 threads at once: measured 60-90 us of CPU time per wait, i.e. more
+// than half of the 0.66 ms of host CPU a USAC run cost, and with 512 runs alive the batch ran into the CPU quota of its container (16
+// cores: calls of 17 ms stretched to 60-80 ms whenever the period's quota was spent).  So a run is a FIBER (ucontext: its own 1 MiB stack,
+// mapped once and kept): worker thread w of a pool owns the runs w, w + W, ... and switches into whichever of them can go on; a run that
+// waits for the hub switches back to its worker (two user-level context switches, no system call apart from glibc's signal-mask
+// bookkeeping), and a worker sleeps -- on the hub's generation word, one futex -- only when all of its runs wait.  A run's code does not
+// change: its stack is the fiber's.  A fiber stays on its worker, so thread-local state (the error text) behaves as before.
+inline long futex_wait_u32(const std::atomic<uint32_t> *w, uint32_t v) {
+    return syscall(SYS_futex, reinterpret_cast<const uint32_t *>(w), FUTEX_WAIT_PRIVATE, v, nullptr, nullptr, 0);
+}
+inline long futex_wake_u32(const std::atomic<uint32_t> *w, int n) {
+    return syscall(SYS_futex, reinterpret_cast<const uint32_t *>(w), FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0);
+}
+
+constexpr size_t kFiberStackBytes = 1u << 20;
+constexpr int kHubWorkersDefault = 16;  // worker threads of one pool (option hub_workers)
+
+class HubThreads;
+struct Fiber {
+    enum State { kIdle, kRunnable, kRunning, kWaiting, kDone };
+    ucontext_t uc;
+    ucontext_t *back = nullptr;  // the owning worker's scheduler context
+    char *stack = nullptr;
+    State state = kIdle;
+    int index = 0;
+    const std::atomic<uint32_t> *word = nullptr;  // kWaiting: resumable once *word != value
+    uint32_t value = 0;
+    HubThreads *pool = nullptr;
+};
+inline Fiber *&hub_current_fiber() {
+    static thread_local Fiber *f = nullptr;
+    return f;
+}
+// Block the caller until *word != value: a fiber yields to its worker, a plain thread sleeps on the word.
+inline void hub_block_until_changed(const std::atomic<uint32_t> *word, uint32_t value) {
+    Fiber *f = hub_current_fiber();
+    if (!f) {
+        while (word->load(std::memory_order_acquire) == value) futex_wait_u32(word, value);
+        return;
+    }
+    f->word = word, f->value = value, f->state = Fiber::kWaiting;
+    swapcontext(&f->uc, f->back);
+}
+
 class HubThreads {
    public:
-    // run job(k) for k in [0, n) on n threads at once; returns at once (wait() joins the round)
-    void start(int n, std::function<void(int)> job) {
+    // run job(k) for k in [0, n), every k as a fiber, on `workers` threads (0 = kHubWorkersDefault; at most n); returns at once (wait() joins)
+    void start(int n, std::function<void(int)> job, int workers = 0) {
         std::unique_lock<std::mutex> lk(m_);
-        while ((int)th_.size() < n) {
-            const int k = (int)th_.size();
-            th_.emplace_back([this, k] { loop(k); });
+        const int W = std::max(1, std::min(n, workers > 0 ? workers : kHubWorkersDefault));
+        while ((int)fibers_.size() < n) {
+            std::unique_ptr<Fiber> f(new Fiber());
+            void *st = mmap(nullptr, kFiberStackBytes + 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK | MAP_NORESERVE, -1, 0);
+            if (st == MAP_FAILED) throw std::bad_alloc();
+            mprotect(st, 4096, PROT_NONE);  // guard page below the stack
+            f->stack = static_cast<char *>(st) + 4096;
+            f->pool = this;
+            fibers_.push_back(std::move(f));
+        }
+        while ((int)workers_.size() < W) {
+            const int w = (int)workers_.size();
+            workers_.emplace_back(new Worker());
+            workers_.back()->th = std::thread([this, w] { loop(w); });
         }
         job_ = std::move(job);
-        active_ = n, pending_ = n;
+        n_ = n, active_ = W, pending_ = W;
         ++gen_;
         cv_.notify_all();
     }
@@ -99,99 +156,162 @@ class HubThreads {
             stop_ = true;
             cv_.notify_all();
         }
-        for (auto &t : th_) t.join();
+        for (auto &w : workers_) w->th.join();
+        for (auto &f : fibers_) munmap(f->stack - 4096, kFiberStackBytes + 4096);
     }
 
    private:
-    void loop(int k) {
+    struct Worker {
+        std::thread th;
+        ucontext_t sched;
+    };
+    static void entry(unsigned hi, unsigned lo) {
+        Fiber *f = reinterpret_cast<Fiber *>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+        f->pool->job_(f->index);
+        f->state = Fiber::kDone;
+    }  // returns through uc_link into the worker's scheduler
+    void serve_fibers(int w, int n, int W) {
+        ucontext_t &sched = workers_[(size_t)w]->sched;
+        for (int k = w; k < n; k += W) {
+            Fiber &f = *fibers_[(size_t)k];
+            getcontext(&f.uc);
+            f.uc.uc_stack.ss_sp = f.stack, f.uc.uc_stack.ss_size = kFiberStackBytes, f.uc.uc_link = &sched;
+            f.back = &sched, f.index = k, f.state = Fiber::kRunnable;
+            const uintptr_t p = reinterpret_cast<uintptr_t>(&f);
+            makecontext(&f.uc, reinterpret_cast<void (*)()>(&HubThreads::entry), 2, (unsigned)(p >> 32), (unsigned)(p & 0xffffffffu));
+        }
+        for (;;) {
+            bool progressed = false, live = false;
+            const Fiber *sleeper = nullptr;
+            for (int k = w; k < n; k += W) {
+                Fiber &f = *fibers_[(size_t)k];
+                if (f.state == Fiber::kDone) continue;
+                live = true;
+                if (f.state == Fiber::kWaiting && f.word->load(std::memory_order_acquire) == f.value) {
+                    if (!sleeper) sleeper = &f;
+                    continue;
+                }
+                f.state = Fiber::kRunning;
+                hub_current_fiber() = &f;
+                swapcontext(&sched, &f.uc);
+                hub_current_fiber() = nullptr;
+                progressed = true;
+            }
+            if (!live) return;
+            if (!progressed && sleeper) futex_wait_u32(sleeper->word, sleeper->value);  // (returns at once if the word has moved on)
+        }
+    }
+    void loop(int w) {
         unsigned long long seen = 0;
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
-            cv_.wait(lk, [&] { return stop_ || (gen_ != seen && k < active_); });
+            cv_.wait(lk, [&] { return stop_ || (gen_ != seen && w < active_); });
             if (stop_) return;
             seen = gen_;
+            const int n = n_, W = active_;
             lk.unlock();
-            job_(k);
+            serve_fibers(w, n, W);
             lk.lock();
             if (--pending_ == 0) cv_done_.notify_all();
         }
     }
-    std::vector<std::thread> th_;
+    std::vector<std::unique_ptr<Worker>> workers_;
+    std::vector<std::unique_ptr<Fiber>> fibers_;
     std::mutex m_;
     std::condition_variable cv_, cv_done_;
     std::function<void(int)> job_;
     unsigned long long gen_ = 0;
-    int active_ = 0, pending_ = 0;
+    int n_ = 0, active_ = 0, pending_ = 0;
     bool stop_ = false;
 };
 
-struct HubStreams {  // what the hub keeps between calls (owned by the context): helper streams -- groups of one round run side by side -- and the run threads
+constexpr int kHubLanes = 4;  // most cohorts of runs served side by side (option hub_lanes, default all four): while one cohort's launches execute, the others' runs do their host work
+
+struct HubLane {  // what one cohort's hub keeps between calls (owned by the context)
     hipEvent_t ev[kHubMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t aux[kHubMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
-    HubThreads threads;
+    hipStream_t aux[kHubMaxGroups] = {nullptr, nullptr, nullptr, nullptr};  // groups of one round run side by side ([0] unused: the hub's own stream)
+    hipStream_t own = nullptr;  // the stream of a lane > 0 (lane 0 serves on the caller's stream)
+    hipEvent_t done = nullptr;  // end of a round (created with hipEventBlockingSync: the lane's thread sleeps instead of spinning, option hub_blocking_sync)
+    void *items_host = nullptr, *items_dev = nullptr;  // item tables of the merged launches of a round
+    size_t items_cap = 0;
+    HubThreads threads;  // the cohort's run threads
+};
+struct HubStreams {
+    HubLane lane[kHubLanes];
+    HubThreads &threads = lane[0].threads;  // (helpers that only need a thread pool between rounds)
 };
 inline HubStreams *hub_resources(mlpl_ctx *ctx) {
     if (!ctx->hub_streams) ctx->hub_streams = new HubStreams();
     return static_cast<HubStreams *>(ctx->hub_streams);
+}
+// the stream lane `l` serves on: the caller's for lane 0, the lane's own otherwise (created on first use)
+inline int hub_lane_stream(mlpl_ctx *ctx, int l, hipStream_t caller, hipStream_t *out) {
+    if (l == 0) {
+        *out = caller;
+        return MLPL_OK;
+    }
+    HubLane &L = hub_resources(ctx)->lane[l];
+    if (!L.own) MLPL_HIP_TRY(hipStreamCreateWithFlags(&L.own, hipStreamNonBlocking));
+    *out = L.own;
+    return MLPL_OK;
 }
 
 class BatchHub;
 struct HubRun {  // one run's side of the hub
     std::vector<HubLaunch> list;
     bool blocked = false, finished = false;
-    unsigned long long served = 0;  // rounds this run's list was executed in
-    int rc = 0;                     // result of the round (a launch error)
+    int rc = 0;  // result of the round (a launch error)
 };
 
 class BatchHub {
    public:
-    BatchHub(mlpl_ctx *ctx, hipStream_t s, int runs) : ctx_(ctx), s_(s), runs_((size_t)runs) {}
+    BatchHub(mlpl_ctx *ctx, hipStream_t s, int runs, int lane = 0) : s_(s), lane_(&hub_resources(ctx)->lane[lane]), runs_((size_t)runs), pending_(runs), blocking_(ctx->opt_hub_blocking_sync != 0) {}
     HubRun &run(int i) { return runs_[(size_t)i]; }
     hipStream_t stream() const { return s_; }
 
-    // called by a run's thread: hand over the recorded launches, block until they have executed
+    // called by a run: hand over the recorded launches, block until they have executed.  pending_ counts the runs that are neither
+    // blocked nor finished; the run that brings it to zero wakes the hub; the hub's round ends by advancing gen_, which releases every
+    // run that blocked before it (no lock: a run's list / flags are published by its decrement of pending_ and read by the hub after it
+    // has seen zero).
     int wait(HubRun &r) {
-        std::unique_lock<std::mutex> lk(m_);
-        const unsigned long long target = r.served + 1;
+        const uint32_t g = gen_.load(std::memory_order_acquire);
         r.blocked = true;
-        ++blocked_;
-        cv_hub_.notify_one();
-        cv_runs_.wait(lk, [&] { return r.served >= target; });
+        if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) wake_hub();
+        hub_block_until_changed(&gen_, g);
         return r.rc;
     }
     void finish(HubRun &r) {
-        std::lock_guard<std::mutex> lk(m_);
         r.finished = true;
-        ++finished_;
-        cv_hub_.notify_one();
+        if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) wake_hub();
     }
     // called by the hub thread: serve rounds until every run has finished.  Returns the first error.
     int serve() {
         int first_rc = 0;
-        std::unique_lock<std::mutex> lk(m_);
         for (;;) {
             const auto t_wait = std::chrono::steady_clock::now();
-            cv_hub_.wait(lk, [&] { return blocked_ + finished_ == (int)runs_.size(); });
+            for (;;) {
+                const uint32_t w = hub_word_.load(std::memory_order_acquire);
+                if (pending_.load(std::memory_order_acquire) == 0) break;
+                futex_wait_u32(&hub_word_, w);
+            }
             host_us_ += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_wait).count();
-            if (blocked_ == 0) break;
             std::vector<HubRun *> todo;
             for (auto &r : runs_)
                 if (r.blocked) todo.push_back(&r);
-            lk.unlock();
+            if (todo.empty()) break;
             const auto t_exec = std::chrono::steady_clock::now();
             const int rc = execute(todo);
             device_us_ += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_exec).count();
-            lk.lock();
             if (rc && !first_rc) first_rc = rc;
             for (HubRun *r : todo) {
                 r->list.clear();
                 r->rc = rc;
                 r->blocked = false;
-                ++r->served;
             }
-            blocked_ = 0;
             ++rounds_;
-            cv_runs_.notify_all();
+            pending_.store((int)todo.size(), std::memory_order_release);  // they are about to run again
+            gen_.fetch_add(1, std::memory_order_release);
+            futex_wake_u32(&gen_, INT_MAX);
         }
         return first_rc;
     }
@@ -225,17 +345,17 @@ class BatchHub {
         size_t bytes = 0;
         for (auto &g : groups)
             for (size_t j = 0; j < g[0]->list.size(); ++j) bytes += ((size_t)hub_kernels()[g[0]->list[j].kid].arg_bytes * g.size() + 255) & ~(size_t)255;
-        if (bytes > ctx_->hub_items_cap) {  // the item tables live in the context: no allocation on the steady path
-            MLPL_HIP_TRY(hipDeviceSynchronize());
-            if (ctx_->hub_items_host) MLPL_HIP_TRY(hipHostFree(ctx_->hub_items_host));
-            if (ctx_->hub_items_dev) MLPL_HIP_TRY(hipFree(ctx_->hub_items_dev));
-            ctx_->hub_items_host = nullptr, ctx_->hub_items_dev = nullptr, ctx_->hub_items_cap = 0;
+        if (bytes > lane_->items_cap) {  // the item tables live in the context: no allocation on the steady path
+            MLPL_HIP_TRY(hipStreamSynchronize(s_));
+            if (lane_->items_host) MLPL_HIP_TRY(hipHostFree(lane_->items_host));
+            if (lane_->items_dev) MLPL_HIP_TRY(hipFree(lane_->items_dev));
+            lane_->items_host = nullptr, lane_->items_dev = nullptr, lane_->items_cap = 0;
             const size_t want = bytes * 2 + (1u << 20);
-            MLPL_HIP_TRY(hipHostMalloc(&ctx_->hub_items_host, want, hipHostMallocDefault));
-            MLPL_HIP_TRY(hipMalloc(&ctx_->hub_items_dev, want));
-            ctx_->hub_items_cap = want;
+            MLPL_HIP_TRY(hipHostMalloc(&lane_->items_host, want, hipHostMallocDefault));
+            MLPL_HIP_TRY(hipMalloc(&lane_->items_dev, want));
+            lane_->items_cap = want;
         }
-        unsigned char *h_items_ = static_cast<unsigned char *>(ctx_->hub_items_host), *d_items_ = static_cast<unsigned char *>(ctx_->hub_items_dev);
+        unsigned char *h_items_ = static_cast<unsigned char *>(lane_->items_host), *d_items_ = static_cast<unsigned char *>(lane_->items_dev);
         size_t off = 0;
         struct Plan {
             int kid, count, gx, gy, stream;
@@ -260,7 +380,7 @@ class BatchHub {
         MLPL_HIP_TRY(hipMemcpyAsync(d_items_, h_items_, off, hipMemcpyHostToDevice, s_));
         // group gi runs on stream gi % kHubMaxGroups (0 = the caller's); the helper streams start behind the item copy and are joined at the end
         const int used = (int)std::min<size_t>(groups.size(), kHubMaxGroups);
-        HubStreams *hs = hub_resources(ctx_);
+        HubLane *hs = lane_;
         if (used > 1) {
             if (!hs->ev[0]) {
                 for (int i = 0; i < kHubMaxGroups; ++i) {
@@ -281,17 +401,26 @@ class BatchHub {
             MLPL_HIP_TRY(hipEventRecord(hs->ev[i], hs->aux[i]));
             MLPL_HIP_TRY(hipStreamWaitEvent(s_, hs->ev[i], 0));
         }
-        MLPL_HIP_TRY(hipStreamSynchronize(s_));
+        if (blocking_) {
+            if (!lane_->done) MLPL_HIP_TRY(hipEventCreateWithFlags(&lane_->done, hipEventBlockingSync | hipEventDisableTiming));
+            MLPL_HIP_TRY(hipEventRecord(lane_->done, s_));
+            MLPL_HIP_TRY(hipEventSynchronize(lane_->done));
+        } else
+            MLPL_HIP_TRY(hipStreamSynchronize(s_));
         return MLPL_OK;
     }
 
    private:
-    mlpl_ctx *ctx_;
     hipStream_t s_;
+    HubLane *lane_;
     std::vector<HubRun> runs_;
-    std::mutex m_;
-    std::condition_variable cv_hub_, cv_runs_;
-    int blocked_ = 0, finished_ = 0;
+    void wake_hub() {
+        hub_word_.fetch_add(1, std::memory_order_release);
+        futex_wake_u32(&hub_word_, 1);
+    }
+    std::atomic<int> pending_;                      // runs neither blocked nor finished
+    bool blocking_;
+    std::atomic<uint32_t> gen_{0}, hub_word_{0};    // futex words: rounds served (the runs wait on it) / wake-ups of the hub
     long long rounds_ = 0, merged_ = 0, host_us_ = 0, device_us_ = 0;
 };
 

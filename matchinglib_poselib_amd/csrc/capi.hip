@@ -143,6 +143,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_solver_wave3 = 1;
     ctx->opt_ransac_device_draw = 1;
     ctx->opt_usac_lo_warm_start = 1;
+    ctx->opt_hub_blocking_sync = 1;
     ctx->opt_arrsac_refine_warm_start = 1;
     ctx->opt_usac_sprt_fast = 1;
     ctx->opt_l2_float_mfma = 1;
@@ -177,8 +178,6 @@ void mlpl_ctx_destroy(mlpl_ctx *ctx) {
     }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_batch) (void)hipHostFree(ctx->pinned_batch);
-    if (ctx->hub_items_host) (void)hipHostFree(ctx->hub_items_host);
-    if (ctx->hub_items_dev) (void)hipFree(ctx->hub_items_dev);
     mlpl::hub_streams_free(ctx->hub_streams);
     if (ctx->l2_hint_host) (void)hipHostFree(ctx->l2_hint_host);
     delete[] ctx->ransac_T_host;
@@ -228,6 +227,11 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "l2_float_mfma") && value >= 0 && value <= 2) ctx->opt_l2_float_mfma = value;
     else if (!std::strcmp(name, "arrsac_flag_points") && (value == 0 || (value >= 128 && value <= 1024 && value % 64 == 0))) ctx->opt_arrsac_flag_points = value;
     else if (!std::strcmp(name, "pair_batch") && value >= 0 && value <= 256) ctx->opt_pair_batch = value;
+    else if (!std::strcmp(name, "hub_lanes") && value >= 0 && value <= 4) ctx->opt_hub_lanes = value;
+    else if (!std::strcmp(name, "hub_blocking_sync") && (value == 0 || value == 1)) ctx->opt_hub_blocking_sync = value;
+    else if (!std::strcmp(name, "hub_workers") && value >= 0 && value <= 64) ctx->opt_hub_workers = value;
+    else if (!std::strcmp(name, "hub_cohort") && (value == 0 || (value >= 8 && value <= 512))) ctx->opt_hub_cohort = value;
+    else if (!std::strcmp(name, "pair_batch_seq") && value >= 0 && value <= 1024) ctx->opt_pair_batch_seq = value;
     else if (!std::strcmp(name, "pair_batch_raw_cap") && (value == 0 || (value >= 64 && value <= (1 << 22)))) ctx->opt_pair_batch_raw_cap = value;
     else if (!std::strcmp(name, "usac_lo_stepwise") && (value == 0 || value == 1)) ctx->opt_usac_lo_stepwise = value;
     else if (!std::strcmp(name, "usac_lo_warm_start") && (value == 0 || value == 1)) ctx->opt_usac_lo_warm_start = value;

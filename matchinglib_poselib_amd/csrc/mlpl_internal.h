@@ -86,9 +86,7 @@ struct mlpl_ctx {
     size_t pinned_bytes;
     void *pinned_batch;  // pinned, device-mapped block of the batched sequential estimators (one slice per run; csrc/usac_batch.h)
     size_t pinned_batch_bytes;
-    void *hub_items_host, *hub_items_dev;  // item tables of the merged launches of a round (csrc/batch_hub.h)
-    size_t hub_items_cap;
-    void *hub_streams;   // helper streams / events of the hub (HubStreams, created on first use)
+    void *hub_streams;   // what the launch hubs keep between calls (HubStreams, csrc/batch_hub.h: streams, events, item tables, run threads; created on first use)
     int l2_mode;
     int opt_l2_mfma_waves;          // waves per workgroup of the L2 matrix-core kernel: 4, 8 or 0 = automatic
     int opt_l2_mfma_blocks_per_cu;  // its grid sizing target (0 = automatic)
@@ -154,6 +152,11 @@ struct mlpl_ctx {
     double usac_prosac_tab_beta, usac_prosac_tab_conf;
     long long last_batch_stats[8];                     // mlpl_pair_pose_batch_dev: {RANSAC passes, pair slots over all passes, pairs redone on a host table, 0}
     int opt_pair_batch;                                // pairs per internal batch of mlpl_pair_pose_batch_dev (0 = 128)
+    int opt_pair_batch_seq;                            // ... of mlpl_pair_pose_batch_usac_dev / _arrsac_dev (0 = 512)
+    int opt_hub_lanes;                                 // cohorts in flight (0 = 4 = the most)
+    int opt_hub_blocking_sync;                         // 1: a lane's thread sleeps on an event at the end of a round instead of spinning in hipStreamSynchronize
+    int opt_hub_workers;                               // worker threads per cohort (0 = 16): the runs of a cohort are fibers on them
+    int opt_hub_cohort;                                // runs of a batched USAC / ARRSAC call that advance together (0 = 128; two such cohorts are in flight)
     int opt_pair_batch_raw_cap;                        // tests: rand() values kept per pair for the device-side sampling (0 = 6.25 per iteration + 1024)
     int opt_arrsac_flag_points;                        // tests: correspondences every ARRSAC model is tested on up front (0 = 1024)
     int opt_arrsac_refine_warm_start;                  // 1 (default): robustEssentialRefine's rounds start their Jacobi iteration from the previous round's eigenvectors

@@ -21,6 +21,8 @@ namespace {
 constexpr int kBatchFirstPass = 324;   // multiple of kHypPerWave; above the stopping point of pairs with >= ~45 % inliers at 0.999
 constexpr int kBatchPassMax = 1026;    // hypotheses per pair and pass (multiple of kHypPerWave)
 constexpr int kBatchPairsPerCall = 128;  // pairs per internal batch (workspace ~2.6 MB per pair)
+constexpr int kSeqBatchPairsPerCall = 512;  // ... of the entries with a sequential estimator (USAC, ARRSAC): their cohorts of runs (usac_impl.h) want the
+                                            // whole batch at hand (512 pairs: 24 ms at 256 per internal batch, 27 at 128); workspace ~0.7 MB per pair
 
 // getSubset (modelest.cpp:567-610) on the device: one wave per slot turns the pair's raw rand() stream into the slot's samples --
 // five draws `rand() % n` per sample, a draw that repeats an index of the sample is redrawn.  The stream position of sample i + 1

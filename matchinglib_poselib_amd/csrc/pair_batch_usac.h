@@ -81,14 +81,14 @@ int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, c
     if (!any) return MLPL_OK;
     if (prosac) {  // the orders on the run threads, all pairs at once (a std::sort of 5000 costs takes 0.3 ms: 150 ms for 512 pairs on one thread)
         HubThreads &pool = hub_resources(ctx)->threads;
-        const int T = std::min(B, 32);
+        const int T = std::min(B, 64);
         pool.start(T, [&](int k) {
             for (int b = k; b < B; b += T)
                 if (h_active[b]) {
                     orders[b].resize((size_t)counts[b]);
                     sorted_match_idx(h_m + (size_t)b * n, counts[b], orders[b].data());
                 }
-        });
+        }, 16);
         pool.wait();
     }
     for (int b = 0; b < B; ++b)

@@ -38,7 +38,16 @@
 #include <climits>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <climits>
 #include <condition_variable>
+#include <ctime>
+#include <memory>
+#include <linux/futex.h>
+#include <sys/mman.h>
+#include <sys/syscall.h>
+#include <ucontext.h>
+#include <unistd.h>
 #include <functional>
 #include <mutex>
 #include <new>
@@ -2915,9 +2924,15 @@ static int alloc_ransac(mlpl_ctx *ctx, int chunk, RansacBuffers &B) {
 void hub_streams_free(void *p) {
     HubStreams *h = static_cast<HubStreams *>(p);
     if (!h) return;
-    for (int i = 0; i < kHubMaxGroups; ++i) {
-        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
-        if (i && h->aux[i]) (void)hipStreamDestroy(h->aux[i]);
+    for (HubLane &L : h->lane) {
+        for (int i = 0; i < kHubMaxGroups; ++i) {
+            if (L.ev[i]) (void)hipEventDestroy(L.ev[i]);
+            if (i && L.aux[i]) (void)hipStreamDestroy(L.aux[i]);
+        }
+        if (L.own) (void)hipStreamDestroy(L.own);
+        if (L.done) (void)hipEventDestroy(L.done);
+        if (L.items_host) (void)hipHostFree(L.items_host);
+        if (L.items_dev) (void)hipFree(L.items_dev);
     }
     delete h;
 }
@@ -3664,7 +3679,7 @@ int mlpl_pair_pose_batch_usac_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q
     if ((rc = usac_check_params(&chk, 0, "mlpl_pair_pose_batch_usac_dev"))) return rc;
     MLPL_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = pick_stream(ctx, stream);
-    const int per = ctx->opt_pair_batch > 0 ? ctx->opt_pair_batch : kBatchPairsPerCall;
+    const int per = ctx->opt_pair_batch_seq > 0 ? ctx->opt_pair_batch_seq : kSeqBatchPairsPerCall;
     try {
         for (int at = 0; at < n_pairs; at += per) {
             const int B = std::min(per, n_pairs - at);
@@ -3689,7 +3704,7 @@ int mlpl_pair_pose_batch_arrsac_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d
     }
     MLPL_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = pick_stream(ctx, stream);
-    const int per = ctx->opt_pair_batch > 0 ? ctx->opt_pair_batch : kBatchPairsPerCall;
+    const int per = ctx->opt_pair_batch_seq > 0 ? ctx->opt_pair_batch_seq : kSeqBatchPairsPerCall;
     try {
         for (int at = 0; at < n_pairs; at += per) {
             const int B = std::min(per, n_pairs - at);

@@ -1137,7 +1137,26 @@ struct UsacKeyHash {
 struct UsacModel {  // one minimal model as the host holds it
     double E[9];
     int valid;
-    std::vector<uint64_t> bits;  // pool order
+    const uint64_t *bits;  // pool order; in the run's row arena (UsacRun::row_alloc), null for a rejected model
+};
+// Bit rows of the cached models: chunks that are kept and refilled when the cache is dropped (a heap allocation per model -- 250 per
+// batch of samples -- was a tenth of a run's host time).
+struct UsacRowArena {
+    static constexpr size_t kChunkWords = 1u << 16;
+    std::vector<std::unique_ptr<uint64_t[]>> chunks;
+    size_t chunk = 0, used = 0;
+    uint64_t *alloc(size_t words) {
+        if (words > kChunkWords) return nullptr;
+        if (chunks.empty() || used + words > kChunkWords) {
+            if (!chunks.empty()) ++chunk;
+            if (chunk >= chunks.size()) chunks.emplace_back(new uint64_t[kChunkWords]);
+            used = 0;
+        }
+        uint64_t *p = chunks[chunk].get() + used;
+        used += words;
+        return p;
+    }
+    void reset() { chunk = 0, used = 0; }
 };
 struct UsacSampleModels {
     int n = 0;
@@ -1208,6 +1227,7 @@ struct UsacRun {
     std::vector<unsigned> growth, non_random, maximality;
     std::unordered_map<UsacKey, UsacSampleModels, UsacKeyHash> cache;
     double cache_thr = 0;
+    UsacRowArena rows_arena;
     size_t cache_bytes = 0;  // bit rows held by the cache; bounded by kUsacCacheBytes (a run that never stops early would keep 50000 samples' rows)
     // results
     unsigned hyp_count = 0, model_count = 0, rejected_samples = 0, rejected_models = 0, best = 0, points_verified = 0, num_lo = 0;
@@ -1616,21 +1636,29 @@ struct UsacRun {
         const uint64_t *h_rows = (const uint64_t *)(h_out + off_rows);
         const double *hE = (const double *)(h_out + off_E);
         for (int b = 0; b < B; ++b) {
-            UsacSampleModels sm;
+            UsacSampleModels &sm = cache[keys[b]];  // (filled in place: the entry is a kilobyte)
             const int nm = std::min(h_nm[b], 10);
             int order[10];
-            for (int i = 0; i < nm; ++i) order[i] = i;
-            std::stable_sort(order, order + nm, [&](int x, int y) { return h_key[b * 10 + x] < h_key[b * 10 + y]; });
+            for (int i = 0; i < nm; ++i) {  // ascending key, equal keys in slot order (a stable insertion sort: no temporary buffer)
+                int j = i;
+                while (j > 0 && h_key[b * 10 + i] < h_key[b * 10 + order[j - 1]]) order[j] = order[j - 1], --j;
+                order[j] = i;
+            }
             sm.n = nm;
             for (int oi = 0; oi < nm; ++oi) {
                 const int slot = order[oi];
                 UsacModel &m = sm.m[oi];
                 std::memcpy(m.E, hE + ((size_t)b * 10 + slot) * 9, 72);
                 m.valid = h_valid[b * 10 + slot];
-                if (m.valid) m.bits.assign(h_rows + ((size_t)b * 10 + slot) * words, h_rows + ((size_t)b * 10 + slot + 1) * words);  // (no row for a rejected model)
+                m.bits = nullptr;
+                if (m.valid) {  // (no row for a rejected model)
+                    uint64_t *row = rows_arena.alloc((size_t)words);
+                    if (!row) return MLPL_E_INTERNAL;
+                    std::memcpy(row, h_rows + ((size_t)b * 10 + slot) * words, (size_t)words * 8);
+                    m.bits = row;
+                }
             }
             cache_bytes += sizeof(UsacSampleModels) + (size_t)nm * words * 8;
-            cache.emplace(keys[b], std::move(sm));
         }
         stats[0]++, stats[1] += B;
         return MLPL_OK;
@@ -2386,7 +2414,7 @@ struct UsacRun {
                 thr *= 1.33;
             else if ((hyp_count == max3) && (best == 0))
                 thr *= 1.13;
-            if (thr != cache_thr) cache.clear(), cache_bytes = 0, cache_thr = thr;  // bit rows are per threshold
+            if (thr != cache_thr) cache.clear(), rows_arena.reset(), cache_bytes = 0, cache_thr = thr;  // bit rows are per threshold
             if (prosac)
                 prosac_sample(rng, subset_size, largest_size, stop_len, hyp_count, min_sample);
             else
@@ -2404,7 +2432,7 @@ struct UsacRun {
             if (it == cache.end()) {
                 // nothing refers to a cache entry here: a cache that has outgrown its bound is dropped whole (its entries are speculation and
                 // samples already consumed; a sample that recurs is solved again, with the same result)
-                if (cache_bytes > kUsacCacheBytes) cache.clear(), cache_bytes = 0;
+                if (cache_bytes > kUsacCacheBytes) cache.clear(), rows_arena.reset(), cache_bytes = 0;
                 // play the sampler forward under "no event" and solve what is coming in one batch
                 std::vector<UsacKey> batch(1, key);
                 std::unordered_set<UsacKey, UsacKeyHash> in_batch;
@@ -2454,7 +2482,7 @@ struct UsacRun {
                 }
                 unsigned inl, tested;
                 const unsigned start = pool_index;
-                const bool good = sprt_walk(m.bits.data(), &inl, &tested);
+                const bool good = sprt_walk(m.bits, &inl, &tested);
                 emit_eval(i, start, inl, tested, good);
                 if (!good) {
                     points_verified += tested;
@@ -2473,7 +2501,7 @@ struct UsacRun {
                         sprt_epsilon = (double)best / n;
                         design_sprt();
                         update_sprt_stopping = true;
-                        store_solution(i, best, m.bits.data(), m.E);
+                        store_solution(i, best, m.bits, m.E);
                     }
                 }
             }
@@ -2614,7 +2642,8 @@ int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, in
 // Outputs per problem: status (0, MLPL_E_FAILED = solve() refused, other < 0 = error), E, results[12], its inlier mask in d_masks + b *
 // stride (optional), degen (optional, 16 doubles as mlpl_usac_last_degeneracy), its decision trace (optional).  Every problem's outputs
 // are those of mlpl_usac_essential_dev on it alone: a run sees exactly its own launches' results, whatever ran beside them.
-constexpr int kUsacBatchRuns = 128;  // runs advancing together (threads of an internal batch)
+constexpr int kUsacBatchRuns = 128;
+  // runs advancing together (threads of an internal batch)
 
 struct UsacBatchTrace {
     double *buf;       // [B][cap][16]
@@ -2633,11 +2662,16 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
         const UsacRun::UsacLayout Y = UsacRun::usac_layout((unsigned)std::max(counts[b], 1), params[b].refine, params[b].check_degeneracy != 0);
         max_dev = std::max(max_dev, Y.dev_total), max_pin = std::max(max_pin, Y.pin_total);
     }
-    const int runs_max = std::min(B, kUsacBatchRuns);
+    // Cohorts of <= kUsacBatchRuns runs, two of them in flight (batch_hub.h kHubLanes): while one cohort's merged launches execute, the
+    // other cohort's runs walk their bit rows on the host.  A batch that fits one cohort is split in two halves for the same reason.
+    const int cohort_max = ctx->opt_hub_cohort > 0 ? ctx->opt_hub_cohort : kUsacBatchRuns;
+    const int lanes_wanted = ctx->opt_hub_lanes > 0 ? std::min(ctx->opt_hub_lanes, kHubLanes) : kHubLanes;
+    const int cohort = B >= 8 * lanes_wanted ? std::min(cohort_max, (B + lanes_wanted - 1) / lanes_wanted) : B;
+    const int n_cohorts = (B + cohort - 1) / cohort, lanes = std::min(lanes_wanted, n_cohorts);
     const size_t pts_bytes = ((size_t)B * stride * 16 + 255) & ~(size_t)255;
     void *pblk, *dblk;
-    if ((rc = pinned_batch_get(ctx, 2 * pts_bytes + (size_t)runs_max * max_pin, &pblk))) return rc;
-    if ((rc = ws_get(ctx, WS_BATCH_RUNS, (size_t)runs_max * max_dev, &dblk))) return rc;
+    if ((rc = pinned_batch_get(ctx, 2 * pts_bytes + (size_t)lanes * cohort * max_pin, &pblk))) return rc;
+    if ((rc = ws_get(ctx, WS_BATCH_RUNS, (size_t)lanes * cohort * max_dev, &dblk))) return rc;
     char *pin = (char *)pblk, *pin_dev = nullptr;
     {
         void *alias = nullptr;
@@ -2650,26 +2684,35 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
         for (int b = 0; b < B; ++b) max_n = std::max(max_n, counts[b]);
         MLPL_HIP_TRY(hipMemcpy2DAsync(h_p1, (size_t)stride * 16, d_p1, (size_t)stride * 16, (size_t)max_n * 16, (size_t)B, hipMemcpyDeviceToHost, s));
         MLPL_HIP_TRY(hipMemcpy2DAsync(h_p2, (size_t)stride * 16, d_p2, (size_t)stride * 16, (size_t)max_n * 16, (size_t)B, hipMemcpyDeviceToHost, s));
-        MLPL_HIP_TRY(hipStreamSynchronize(s));
+        MLPL_HIP_TRY(hipStreamSynchronize(s));  // (also: everything the caller queued before is done -- the lanes' own streams need no other ordering)
     }
     char *run_pin = pin + 2 * pts_bytes, *run_pin_dev = pin_dev + 2 * pts_bytes;
-    long long rounds = 0, merged = 0, host_us = 0, device_us = 0, spawn_us = 0;
     const auto t_all = std::chrono::steady_clock::now();
-    int first_err = 0;
-    std::string first_msg;
-    for (int b0 = 0; b0 < B; b0 += kUsacBatchRuns) {
-        const int nb = std::min(kUsacBatchRuns, B - b0);
-        BatchHub hub(ctx, s, nb);
-        const auto t_spawn = std::chrono::steady_clock::now();
-        std::vector<UsacBufs> bufs((size_t)nb);
-        std::vector<std::string> msgs((size_t)nb);
-        for (int k = 0; k < nb; ++k) {
-            bufs[k].dev = (char *)dblk + (size_t)k * max_dev;
-            bufs[k].pin = run_pin + (size_t)k * max_pin, bufs[k].pin_dev = run_pin_dev + (size_t)k * max_pin;
-        }
-        HubThreads &pool = hub_resources(ctx)->threads;
-        pool.start(nb, [&](int k) {
-            {
+    struct LaneOut {
+        long long rounds = 0, merged = 0, host_us = 0, device_us = 0, spawn_us = 0;
+        int first_err = 0;
+        std::string first_msg;
+    };
+    LaneOut lane_out[kHubLanes];
+    hipStream_t lane_stream[kHubLanes];
+    for (int l = 0; l < lanes; ++l)
+        if ((rc = hub_lane_stream(ctx, l, s, &lane_stream[l]))) return rc;
+    auto serve_lane = [&](int l) {
+        LaneOut &LO = lane_out[l];
+        const hipStream_t ls = lane_stream[l];
+        for (int c = l; c < n_cohorts; c += lanes) {
+            const int b0 = c * cohort, nb = std::min(cohort, B - b0);
+            BatchHub hub(ctx, ls, nb, l);
+            const auto t_spawn = std::chrono::steady_clock::now();
+            std::vector<UsacBufs> bufs((size_t)nb);
+            std::vector<std::string> msgs((size_t)nb);
+            for (int k = 0; k < nb; ++k) {
+                const size_t slot = (size_t)l * cohort + k;
+                bufs[k].dev = (char *)dblk + slot * max_dev;
+                bufs[k].pin = run_pin + slot * max_pin, bufs[k].pin_dev = run_pin_dev + slot * max_pin;
+            }
+            HubThreads &pool = hub_resources(ctx)->lane[l].threads;
+            pool.start(nb, [&](int k) {
                 const int b = b0 + k;
                 const int n = counts[b];
                 HubRun &hr = hub.run(k);
@@ -2677,7 +2720,7 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
                 bool ok = false;
                 try {
                     UsacRun R;
-                    usac_configure(R, ctx, d_p1 + (size_t)b * stride * 2, d_p2 + (size_t)b * stride * 2, n, &params[b], s);
+                    usac_configure(R, ctx, d_p1 + (size_t)b * stride * 2, d_p2 + (size_t)b * stride * 2, n, &params[b], ls);
                     R.L.hub = &hub, R.L.run = &hr, R.bufs = &bufs[k];
                     if (trace && trace->buf) R.trace_buf = trace->buf + (size_t)b * trace->cap * 16, R.trace_cap = trace->cap;
                     R.hp1.assign(h_p1 + (size_t)b * stride * 2, h_p1 + (size_t)b * stride * 2 + (size_t)2 * std::max(n, 0));
@@ -2708,16 +2751,30 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
                 if (r && r != MLPL_E_FAILED) msgs[k] = mlpl_last_error();
                 status[b] = r;
                 hub.finish(hr);
-            }
-        });
-        spawn_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_spawn).count();
-        const int hrc = hub.serve();
-        pool.wait();
-        rounds += hub.rounds(), merged += hub.merged_launches(), host_us += hub.host_us(), device_us += hub.device_us();
-        for (int k = 0; k < nb && !first_err; ++k)
-            if (status[b0 + k] && status[b0 + k] != MLPL_E_FAILED) first_err = status[b0 + k], first_msg = msgs[k];
-        if (hrc && !first_err) first_err = hrc;
-        if (first_err) break;
+            }, ctx->opt_hub_workers);
+            LO.spawn_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_spawn).count();
+            const int hrc = hub.serve();
+            pool.wait();
+            LO.rounds += hub.rounds(), LO.merged += hub.merged_launches(), LO.host_us += hub.host_us(), LO.device_us += hub.device_us();
+            for (int k = 0; k < nb && !LO.first_err; ++k)
+                if (status[b0 + k] && status[b0 + k] != MLPL_E_FAILED) LO.first_err = status[b0 + k], LO.first_msg = msgs[k];
+            if (hrc && !LO.first_err) LO.first_err = hrc;
+            if (LO.first_err) break;
+        }
+    };
+    {
+        std::vector<std::thread> others;
+        for (int l = 1; l < lanes; ++l) others.emplace_back(serve_lane, l);
+        serve_lane(0);
+        for (auto &t : others) t.join();
+    }
+    long long rounds = 0, merged = 0, host_us = 0, device_us = 0, spawn_us = 0;
+    int first_err = 0;
+    std::string first_msg;
+    for (int l = 0; l < lanes; ++l) {
+        const LaneOut &LO = lane_out[l];
+        rounds += LO.rounds, merged += LO.merged, host_us += LO.host_us, device_us += LO.device_us, spawn_us += LO.spawn_us;
+        if (LO.first_err && !first_err) first_err = LO.first_err, first_msg = LO.first_msg;
     }
     ctx->last_usac_stats[0] = rounds, ctx->last_usac_stats[1] = merged, ctx->last_usac_stats[2] = host_us, ctx->last_usac_stats[3] = device_us;
     ctx->last_usac_stats[4] = spawn_us;

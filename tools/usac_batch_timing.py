@@ -11,8 +11,11 @@ import make_golden
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+OPTS = sys.argv[3:]   # name=value library options (hub_lanes=2 hub_cohort=128 ...)
 n = 5000
 ctx = mpa.Context(0)
+for o in OPTS:
+    ctx.set_option(o.split("=")[0], int(o.split("=")[1]))
 distinct = 16
 sc = [make_golden.usac_scene(n, 0.5, 20260103 + i) for i in range(distinct)]
 th = sc[0][2]
@@ -29,12 +32,14 @@ for refine, est in ((0, 0), (5, 2)):
         si = orders if prosac else None
         got = pose.usac_essential_batch(d1, d2, [n] * B, th, seeds, sorted_idx=si, masks_out=masks, **kw)
         ts = []
+        cpu0, wall0 = time.process_time(), time.perf_counter()
         for _ in range(reps):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             got = pose.usac_essential_batch(d1, d2, [n] * B, th, seeds, sorted_idx=si, masks_out=masks, **kw)
             torch.cuda.synchronize()
             ts.append((time.perf_counter() - t0) * 1e3)
+        cores = (time.process_time() - cpu0) / (time.perf_counter() - wall0)   # host cores the batched calls kept busy (all threads)
         k = min(B, 32)
         t0 = time.perf_counter()
         for b in range(k):
@@ -42,5 +47,5 @@ for refine, est in ((0, 0), (5, 2)):
         single = (time.perf_counter() - t0) * 1e3 / k
         inl = np.mean([g["final"][5] for g in got])
         hyp = np.mean([g["final"][1] for g in got])
-        print(f"B {B} refine {refine} prosac {prosac}: batch {min(ts):.2f} ms (runs {[round(t, 1) for t in ts]}) = {min(ts) / B * 1e3:.1f} us per problem; one at a time "
+        print(f"B {B} refine {refine} prosac {prosac}: batch {min(ts):.2f} ms (runs {[round(t, 1) for t in ts]}, {cores:.1f} host cores busy) = {min(ts) / B * 1e3:.1f} us per problem; one at a time "
               f"{single:.3f} ms per problem ({single * B:.0f} ms for B); mean hyps {hyp:.0f} inliers {inl:.0f}; rounds {got[0]['stats'][0]} merged launches {got[0]['stats'][1]} hub waiting for host us {got[0]['stats'][2]} device us {got[0]['stats'][3]} thread spawn us {got[0]['stats'][4]} runs total us {got[0]['stats'][5]}", flush=True)

@@ -12,6 +12,8 @@ import make_golden
 
 ctx = mpa.Context(0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+if len(sys.argv) > 2:   # A/B of the warm-started refits (option usac_lo_warm_start)
+    ctx.set_option("usac_lo_warm_start", int(sys.argv[2]))
 for (n, frac, seed) in ((5000, 0.5, 20260103), (2000, 0.7, 12), (8192, 0.25, 14)):
     p1, p2, th, truth, order = make_golden.usac_scene(n, frac, seed)
     for refine in (0, 5, 4, 7, 6):
