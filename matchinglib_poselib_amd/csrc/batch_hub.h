@@ -238,6 +238,7 @@ struct HubLane {  // what one cohort's hub keeps between calls (owned by the con
 };
 struct HubStreams {
     HubLane lane[kHubLanes];
+    hipStream_t copy = nullptr;  // device -> host copies that travel beside the lanes' work (the correspondences of a USAC batch)
     HubThreads &threads = lane[0].threads;  // (helpers that only need a thread pool between rounds)
 };
 inline HubStreams *hub_resources(mlpl_ctx *ctx) {

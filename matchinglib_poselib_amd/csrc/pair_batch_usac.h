@@ -2,7 +2,7 @@
 // Included by ransac_5pt.hip inside namespace mlpl after usac_impl.h and pair_batch_impl.h.
 //
 //   matching          mlpl_match_hamming_dev(batch = B)                        as in pair_batch_impl.h
-//   hop               the B match counts (and, for PROSAC, the match rows: the order is getSortedMatchIdx' std::sort of the matching costs)
+//   hop               the B match counts (and, for PROSAC, the matching costs: the order is getSortedMatchIdx' std::sort of them)
 //   gather            blockIdx.y = pair: matched keypoints -> camera coordinates (ImgToCamCoordTrans)
 //   USAC              usac_essential_batch_dev: every pair's sequential program on its own host thread, every launch merged over the pairs
 //   cheirality        decomposition, four triangulations and the reference's candidate choice per pair on the device (launch_recover_pose_batch)
@@ -20,6 +20,22 @@ void sorted_match_idx(const mlpl_dmatch *matches, int count, uint32_t *out) {
     for (int i = 0; i < count; ++i) c[i].distance = matches[i].distance, c[i].idx = (uint32_t)i;
     std::sort(c.begin(), c.end(), [](const Cost &x, const Cost &y) { return x.distance < y.distance; });
     for (int i = 0; i < count; ++i) out[i] = c[i].idx;
+}
+
+// the same on the bare costs (the batch entry fetches only those: 4 of a match's 16 bytes)
+void sorted_cost_idx(const float *cost, int count, uint32_t *out) {
+    struct Cost {
+        float distance;
+        uint32_t idx;
+    };
+    std::vector<Cost> c((size_t)count);
+    for (int i = 0; i < count; ++i) c[i].distance = cost[i], c[i].idx = (uint32_t)i;
+    std::sort(c.begin(), c.end(), [](const Cost &x, const Cost &y) { return x.distance < y.distance; });
+    for (int i = 0; i < count; ++i) out[i] = c[i].idx;
+}
+__global__ __launch_bounds__(256) void match_cost_kernel(const mlpl_dmatch *__restrict__ m, const int32_t *__restrict__ counts, int stride, float *__restrict__ out) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i < counts[b]) out[(size_t)b * stride + i] = m[(size_t)b * stride + i].distance;
 }
 
 // tmpl != nullptr: USAC with these parameters (seeds[B], prosac); else ARRSAC (arr_thresh, arr_refine, arr_states[B][2] in / out)
@@ -46,22 +62,27 @@ int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, c
     int32_t *d_counts = (int32_t *)(sm + sm_counts), *d_active = (int32_t *)(sm + sm_active), *d_cc = (int32_t *)(sm + sm_cc);
     double *d_E = (double *)(sm + sm_E), *d_P = (double *)(sm + sm_P);
     PairPoseDev *d_pose = (PairPoseDev *)(sm + sm_pose);
-    // pinned: counts | active | E | pose | (PROSAC) the match rows
+    // pinned: counts | active | E | pose | (PROSAC) the matching costs
     const size_t pin_counts = 0, pin_act = (size_t)B * 4, pin_E = ((size_t)B * 8 + 255) / 256 * 256, pin_pose = pin_E + (size_t)B * 72,
-                 pin_match = (pin_pose + (size_t)B * sizeof(PairPoseDev) + 255) / 256 * 256, pin_end = pin_match + (prosac ? (size_t)B * n * 16 : 0);
+                 pin_match = (pin_pose + (size_t)B * sizeof(PairPoseDev) + 255) / 256 * 256, pin_end = pin_match + (prosac ? (size_t)B * n * 4 : 0);
     void *pin;
     if ((rc = pinned_get(ctx, pin_end + 256, &pin))) return rc;
     char *hp = (char *)pin;
     int32_t *h_counts = (int32_t *)(hp + pin_counts), *h_active = (int32_t *)(hp + pin_act);
     double *h_E = (double *)(hp + pin_E);
     PairPoseDev *h_pose = (PairPoseDev *)(hp + pin_pose);
-    const mlpl_dmatch *h_m = (const mlpl_dmatch *)(hp + pin_match);
+    const float *h_cost = (const float *)(hp + pin_match);
 
     rc = mlpl_match_hamming_dev(ctx, d_q, nq, (size_t)nbytes, (size_t)nq * nbytes, d_t, nt, (size_t)nbytes, (size_t)nt * nbytes, nbytes, 1, 0.75f, B,
                                 (int32_t *)(b0 + off_idx), (int32_t *)(b0 + off_dist), d_m, d_counts, s);
     if (rc) return rc;
     MLPL_HIP_TRY(hipMemcpyAsync(h_counts, d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, s));
-    if (prosac) MLPL_HIP_TRY(hipMemcpyAsync(hp + pin_match, d_m, (size_t)B * n * 16, hipMemcpyDeviceToHost, s));
+    if (prosac) {  // the costs of the matches, through the (now free) table of nearest-neighbour indices
+        float *d_cost = (float *)(b0 + off_idx);
+        hipLaunchKernelGGL(match_cost_kernel, dim3((NQ + 255) / 256, B), dim3(256), 0, s, (const mlpl_dmatch *)d_m, (const int32_t *)d_counts, NQ, d_cost);
+        MLPL_HIP_TRY(hipGetLastError());
+        MLPL_HIP_TRY(hipMemcpyAsync(hp + pin_match, d_cost, (size_t)B * n * 4, hipMemcpyDeviceToHost, s));
+    }
     MLPL_HIP_TRY(hipStreamSynchronize(s));
     std::vector<int32_t> counts(h_counts, h_counts + B);  // (the nested entries reuse the context's pinned block)
     mlpl_usac_params none;
@@ -86,7 +107,7 @@ int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, c
             for (int b = k; b < B; b += T)
                 if (h_active[b]) {
                     orders[b].resize((size_t)counts[b]);
-                    sorted_match_idx(h_m + (size_t)b * n, counts[b], orders[b].data());
+                    sorted_cost_idx(h_cost + (size_t)b * n, counts[b], orders[b].data());
                 }
         }, 16);
         pool.wait();

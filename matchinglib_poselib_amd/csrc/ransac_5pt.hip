@@ -2934,6 +2934,7 @@ void hub_streams_free(void *p) {
         if (L.items_host) (void)hipHostFree(L.items_host);
         if (L.items_dev) (void)hipFree(L.items_dev);
     }
+    if (h->copy) (void)hipStreamDestroy(h->copy);
     delete h;
 }
 #include "arrsac_impl.h"

@@ -2679,12 +2679,29 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
         pin_dev = (char *)alias;
     }
     double *h_p1 = (double *)pin, *h_p2 = (double *)(pin + pts_bytes);
-    {   // only the rows in use: counts[b] <= max_n of the stride rows of a problem
-        int max_n = 1;
-        for (int b = 0; b < B; ++b) max_n = std::max(max_n, counts[b]);
-        MLPL_HIP_TRY(hipMemcpy2DAsync(h_p1, (size_t)stride * 16, d_p1, (size_t)stride * 16, (size_t)max_n * 16, (size_t)B, hipMemcpyDeviceToHost, s));
-        MLPL_HIP_TRY(hipMemcpy2DAsync(h_p2, (size_t)stride * 16, d_p2, (size_t)stride * 16, (size_t)max_n * 16, (size_t)B, hipMemcpyDeviceToHost, s));
-        MLPL_HIP_TRY(hipStreamSynchronize(s));  // (also: everything the caller queued before is done -- the lanes' own streams need no other ordering)
+    // The sequential parts read the correspondences on the host (normalisation, sample validation, the choices of the 5-point refinements,
+    // the degeneracy tests): they cross PCIe once, cohort by cohort on a stream of their own, so that the first cohort starts after its
+    // own slice has arrived (512 problems of 5000: 3.4 ms for all, 0.85 ms for the first quarter) and the rest travels beside its work.
+    MLPL_HIP_TRY(hipStreamSynchronize(s));  // everything the caller queued before is done: the lanes' own streams need no other ordering
+    HubStreams *hres = hub_resources(ctx);
+    if (!hres->copy) MLPL_HIP_TRY(hipStreamCreateWithFlags(&hres->copy, hipStreamNonBlocking));
+    std::vector<hipEvent_t> arrived((size_t)n_cohorts, nullptr);
+    struct EventsGuard {
+        std::vector<hipEvent_t> &ev;
+        ~EventsGuard() {
+            for (hipEvent_t e : ev)
+                if (e) (void)hipEventDestroy(e);
+        }
+    } events_guard{arrived};
+    for (int c = 0; c < n_cohorts; ++c) {
+        const int b0 = c * cohort, nb = std::min(cohort, B - b0);
+        int max_n = 1;  // only the rows in use: counts[b] <= max_n of the stride rows of a problem
+        for (int b = b0; b < b0 + nb; ++b) max_n = std::max(max_n, counts[b]);
+        const size_t at = (size_t)b0 * stride * 2;
+        MLPL_HIP_TRY(hipMemcpy2DAsync(h_p1 + at, (size_t)stride * 16, d_p1 + at, (size_t)stride * 16, (size_t)max_n * 16, (size_t)nb, hipMemcpyDeviceToHost, hres->copy));
+        MLPL_HIP_TRY(hipMemcpy2DAsync(h_p2 + at, (size_t)stride * 16, d_p2 + at, (size_t)stride * 16, (size_t)max_n * 16, (size_t)nb, hipMemcpyDeviceToHost, hres->copy));
+        MLPL_HIP_TRY(hipEventCreateWithFlags(&arrived[(size_t)c], hipEventDisableTiming));
+        MLPL_HIP_TRY(hipEventRecord(arrived[(size_t)c], hres->copy));
     }
     char *run_pin = pin + 2 * pts_bytes, *run_pin_dev = pin_dev + 2 * pts_bytes;
     const auto t_all = std::chrono::steady_clock::now();
@@ -2702,6 +2719,10 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
         const hipStream_t ls = lane_stream[l];
         for (int c = l; c < n_cohorts; c += lanes) {
             const int b0 = c * cohort, nb = std::min(cohort, B - b0);
+            if (hipEventSynchronize(arrived[(size_t)c]) != hipSuccess) {
+                LO.first_err = MLPL_E_INTERNAL, LO.first_msg = "mlpl_usac_essential_batch_dev: the copy of the correspondences failed";
+                break;
+            }
             BatchHub hub(ctx, ls, nb, l);
             const auto t_spawn = std::chrono::steady_clock::now();
             std::vector<UsacBufs> bufs((size_t)nb);
