@@ -251,7 +251,7 @@ int mlpl_arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
 /* A batch of ARRSAC problems in one call (estimateEssentialMat's default method, pose_estim.h:207): problem b = correspondences d_p1 / d_p2 +
  * b * stride * 2 doubles (device), counts[b] in [6, stride] of them (host), its own pair of cv::RNG states rng_states[2 b], [2 b + 1] (host,
  * in / out -- the reference's samplers draw from process-wide streams; here every problem owns a pair, so problems do not depend on each
- * other).  Every problem runs the sequential program of mlpl_arrsac_essential_dev on its own host thread and the launches of all runs that
+ * other).  Every problem runs the sequential program of mlpl_arrsac_essential_dev on its own stack (a fiber on a worker thread) and the launches of all runs that
  * stand at the same point of their control flow are merged into one launch per kernel (csrc/batch_hub.h), 128 problems at a time.
  * Outputs per problem: status[b] (0; MLPL_E_FAILED; other < 0 end the call), E + 9 b, n_inliers[b] (optional), its inlier mask at d_masks +
  * b * stride (device) -- what mlpl_arrsac_essential_dev returns for the problem alone with the same stream states. */
@@ -345,7 +345,7 @@ int mlpl_usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p
  * A batch of USAC problems in one call -- the harness runs estimateEssentialOrPoseUSAC once per image pair (T/poselib-test/main.cpp:
  * 1440-2072, RobMethod "USAC" is its default, :734); a rank's share of a batch of pairs is many such problems.  Problem b: correspondences
  * d_p1 / d_p2 + b * stride * 2 doubles (device, camera coordinates), counts[b] <= stride of them (host), parameters params[b] (host; its own
- * seed, thresholds, PROSAC order).  Every problem runs the sequential program of mlpl_usac_essential_dev on its own host thread, and the
+ * seed, thresholds, PROSAC order).  Every problem runs the sequential program of mlpl_usac_essential_dev on its own stack (a fiber on a worker thread), and the
  * launches of all runs that stand at the same point of their control flow are merged into ONE launch per kernel (problem = grid
  * dimension; csrc/batch_hub.h), 128 problems at a time.  Outputs per problem: status[b] (0; MLPL_E_FAILED = solve() refused; < 0 other
  * errors, which also end the call), E + 9 b, results + 12 b, its inlier mask at d_masks + b * stride (device, optional), degen + 16 b
@@ -408,7 +408,7 @@ int mlpl_pair_pose_batch_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int
 /*
  * The same batch with USAC -- the reference harness' default RobMethod (T/poselib-test/main.cpp:734) -- as the robust estimator:
  * matching, match counts, gather + ImgToCamCoordTrans as above, then mlpl_usac_essential_batch_dev on the pairs' correspondences (every
- * pair's sequential program on its own host thread, every launch merged over the pairs), then the batched cheirality step.  *usac:
+ * pair's sequential program on its own stack, every launch merged over the pairs), then the batched cheirality step.  *usac:
  * the parameters every pair runs with (th, conf, max_hyp, estimator, refine, SPRT start values, degeneracy tests; its seed and sorted_idx
  * are ignored); seeds[n_pairs]: the pairs' seeds; prosac != 0: PROSAC sampling in the order of the matching costs -- poselib::
  * getSortedMatchIdx' std::sort of the pair's matches (pose_helper.cpp:2896-2923) -- else uniform sampling.  Record per pair:

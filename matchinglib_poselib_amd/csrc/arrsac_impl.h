@@ -1368,7 +1368,7 @@ int arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, 
     return rc;
 }
 
-// ---- a batch of ARRSAC problems: every run a host thread, every launch merged over the runs (batch_hub.h) -------------------------------
+// ---- a batch of ARRSAC problems: every run a fiber on a worker thread, every launch merged over the runs (batch_hub.h) -------------------------------
 // Problem b: correspondences d_p1 / d_p2 + b * stride * 2 (counts[b] of them), its own pair of cv::RNG states rng_states[2 b .. 2 b + 1]
 // (in / out: the reference's samplers draw from process-wide streams, the C ABI hands every problem its own).  Outputs per problem: status
 // (0, MLPL_E_FAILED, < 0 errors), E, n_inliers, its mask at d_masks + b * stride.  Every problem's outputs are those of

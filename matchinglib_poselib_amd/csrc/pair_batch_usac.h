@@ -4,7 +4,7 @@
 //   matching          mlpl_match_hamming_dev(batch = B)                        as in pair_batch_impl.h
 //   hop               the B match counts (and, for PROSAC, the matching costs: the order is getSortedMatchIdx' std::sort of them)
 //   gather            blockIdx.y = pair: matched keypoints -> camera coordinates (ImgToCamCoordTrans)
-//   USAC              usac_essential_batch_dev: every pair's sequential program on its own host thread, every launch merged over the pairs
+//   USAC              usac_essential_batch_dev: every pair's sequential program on its own stack (a fiber), every launch merged over the pairs
 //   cheirality        decomposition, four triangulations and the reference's candidate choice per pair on the device (launch_recover_pose_batch)
 // Per pair the record is what the single-problem entries return for it: mlpl_match_hamming_dev + mlpl_gather_match_points_dev ->
 // mlpl_usac_essential_dev (same parameters, seed and PROSAC order) -> mlpl_recover_pose_dev (tests/test_gpu_usac_batch.py).

@@ -2637,7 +2637,7 @@ int usac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, in
     return MLPL_OK;
 }
 
-// ---- a batch of USAC problems: every run a host thread, every launch merged over the runs (batch_hub.h) -----------------------------------
+// ---- a batch of USAC problems: every run a fiber on a worker thread, every launch merged over the runs (batch_hub.h) -----------------------------------
 // Problem b: correspondences d_p1 / d_p2 + b * stride * 2 (counts[b] of them), parameters params[b] (its seed, its PROSAC order, ...).
 // Outputs per problem: status (0, MLPL_E_FAILED = solve() refused, other < 0 = error), E, results[12], its inlier mask in d_masks + b *
 // stride (optional), degen (optional, 16 doubles as mlpl_usac_last_degeneracy), its decision trace (optional).  Every problem's outputs
