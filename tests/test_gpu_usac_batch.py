@@ -1,5 +1,5 @@
-"""mlpl_usac_essential_batch_dev (csrc/batch_hub.h: every problem's sequential program on its own host thread, the launches of all runs merged
-into one launch per kernel) against mlpl_usac_essential problem by problem: results, masks and decision traces identical."""
+"""mlpl_usac_essential_batch_dev (csrc/batch_hub.h: every problem's sequential program on its own stack -- a fiber on a worker thread --,
+the launches of all runs merged into one launch per kernel, up to four cohorts of runs in flight) against mlpl_usac_essential problem by problem: results, masks and decision traces identical."""
 import os
 import sys
 
@@ -63,13 +63,14 @@ def test_batch_equals_the_single_problem_entry_on_64_problems(ctx, refine, estim
 
 
 def test_batch_of_one_and_of_more_than_an_internal_batch(ctx):
-    """B = 1, and B = 150 (two internal batches of runs): same as the single entry."""
+    """B = 1, 7 (one cohort), 33 (four ragged cohorts), 150, and 600 (five cohorts of 128 on four lanes: a lane serves two): same as
+    the single entry."""
     import torch
     from matchinglib_poselib_amd import pose
 
     a, c, th, truth, order = make_golden.usac_scene(600, 0.6, 77)
     dev = torch.device("cuda:0")
-    for B in (1, 150):
+    for B in (1, 7, 33, 150, 600):
         d1 = torch.from_numpy(np.repeat(a[None], B, 0).copy()).to(dev)
         d2 = torch.from_numpy(np.repeat(c[None], B, 0).copy()).to(dev)
         seeds = [40 + (b % 7) for b in range(B)]
@@ -129,3 +130,39 @@ def test_batched_image_pairs_with_usac_equal_the_single_problem_entries(ctx, pro
         ng, R, t = pose.getPoseTriangPts_device(one["E"].reshape(3, 3), d1, d2, mask=torch.from_numpy(one["flags"]).to(dev), ctx=ctx)
         assert raw["n_good"][i] == ng and np.array_equal(raw["R"][i].view(np.uint64), R.ravel().view(np.uint64)), i
         assert np.array_equal(raw["t"][i].view(np.uint64), t.ravel().view(np.uint64)), i
+
+
+@pytest.mark.parametrize("opts", [dict(hub_lanes=1), dict(hub_lanes=2, hub_workers=3), dict(hub_lanes=4, hub_cohort=8, hub_workers=1),
+                                  dict(hub_lanes=3, hub_cohort=16, hub_workers=64, hub_blocking_sync=0)])
+def test_results_do_not_depend_on_lanes_cohorts_or_workers(opts):
+    """How the runs are dealt to cohorts, lanes and worker threads is scheduling only: 40 problems under four settings of the options,
+    among them one worker for all runs of a cohort (every wait is a fiber switch on one thread) and more workers than runs."""
+    import torch
+    import matchinglib_poselib_amd as mpa
+    from matchinglib_poselib_amd import pose
+
+    rng = np.random.default_rng(11)
+    B = 40
+    sizes, scenes = _problems(B, rng)
+    stride = max(sizes)
+    p1, p2 = np.zeros((B, stride, 2)), np.zeros((B, stride, 2))
+    th = scenes[0][2]
+    for b, (a, c, t, truth, order) in enumerate(scenes):
+        p1[b, :sizes[b]], p2[b, :sizes[b]] = a, c
+    seeds = [77 + b for b in range(B)]
+    dev = torch.device("cuda:0")
+    d1, d2 = torch.from_numpy(p1).to(dev), torch.from_numpy(p2).to(dev)
+    kw = dict(refine=5, estimator=2, max_hyp=2000, sprt_ms=6.0, sprt_tm=2736.0)
+    base = mpa.Context(0)
+    want = pose.usac_essential_batch(d1, d2, sizes, th, seeds, event_cap=20000, ctx=base, **kw)
+    base.close()
+    c2 = mpa.Context(0)
+    for k, v in opts.items():
+        c2.set_option(k, v)
+    for _ in range(2):   # the second call reuses the kept fibers, workers and item tables
+        got = pose.usac_essential_batch(d1, d2, sizes, th, seeds, event_cap=20000, ctx=c2, **kw)
+        for b in range(B):
+            assert got[b]["ok"] == want[b]["ok"] and np.array_equal(got[b]["final"], want[b]["final"]), (opts, b)
+            assert np.array_equal(got[b]["E"].view(np.uint64), want[b]["E"].view(np.uint64)), (opts, b)
+            assert got[b]["n_events"] == want[b]["n_events"] and np.array_equal(got[b]["events"], want[b]["events"]), (opts, b)
+    c2.close()
