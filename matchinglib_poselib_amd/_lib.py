@@ -199,6 +199,12 @@ class Context:
             raise MlplError(rc, "mlpl_ctx_create", last_error())
         self._h = h
         self.device = int(device)
+        # MLPL_OPTIONS="name=value,...": the knobs of mlpl_set_option for every context of the process (the C++ facade reads the same
+        # variable); tools use it for A/B runs of unchanged scripts.  Words without "=" are the facade's own switches.
+        for kv in os.environ.get("MLPL_OPTIONS", "").split(","):
+            if "=" in kv:
+                k, v = kv.split("=", 1)
+                self.set_option(k.strip(), int(v))
 
     @property
     def handle(self):

@@ -536,9 +536,11 @@ __device__ __forceinline__ void arrsac_refine_body(const ArrRefineArgs &A, const
     __shared__ Jacobi9Lds J;
     __shared__ double F3[9];
     __shared__ double s_err_old;
+    __shared__ double s_xv[9], s_xprev[9], s_xlambda;  // smallest_eigvec9_wave: this round's vector, the previous round's (the next start)
+    __shared__ int s_x_have, s_jv_have;
     __shared__ int s_stop, s_cnt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_cnt = 0, s_stop = 0, s_err_old = 1e12;
+    if (tid == 0) s_cnt = 0, s_stop = 0, s_err_old = 1e12, s_x_have = 0, s_jv_have = 0;
     if (tid < 9) F3[tid] = E_init[tid];
     __syncthreads();
     {
@@ -608,54 +610,75 @@ __device__ __forceinline__ void arrsac_refine_body(const ArrRefineArgs &A, const
             // From the second round on the iteration starts from the previous round's eigenvectors (J.Vv): consecutive rounds re-weight the
             // same correspondences with a slightly different matrix, V_prev^T G V_prev is nearly diagonal and two or three sweeps finish
             // where a cold start needs eight (as usac_fit_from_cov does for the local optimisation's refits; ~35 -> ~12 us per round).
-            if (j == 0 || !A.warm_start) {
-                if (lane == 0) {
-                    int t = 0;
-                    for (int a = 0; a < 9; ++a)
-                        for (int c = a; c < 9; ++c) {
-                            const double v = red[0][t++] / wn2;
-                            J.G[a][c] = v;
-                            J.G[c][a] = v;
-                        }
-                }
-                for (int ee = lane; ee < 81; ee += 64) J.Vv[ee / 9][ee % 9] = (ee / 9 == ee % 9) ? 1.0 : 0.0;
-            } else {
-                for (int ee = lane; ee < 81; ee += 64) {  // Gn = G V_prev (G from the packed upper triangle, scaled)
-                    const int a = ee / 9, b = ee - a * 9;
-                    double sacc = 0;
-                    for (int k = 0; k < 9; ++k) {
-                        const int lo = a < k ? a : k, hi = a < k ? k : a;
-                        sacc += (red[0][lo * 9 - lo * (lo - 1) / 2 + (hi - lo)] / wn2) * J.Vv[k][b];
+            // First the inverse iteration for the one eigenvector the round needs (smallest_eigvec9_wave, ransac_5pt.hip; from the previous
+            // round's vector: ~2 us instead of ~35); a system it does not settle on takes the Jacobi path below.  (Its "second smallest
+            // eigenvalue below DBL_EPSILON" failure cannot pass unnoticed here: the iteration converges only when that eigenvalue is well
+            // above the shift 2^-44 trace, and the trace of the normalised matrix is at least 1.)
+            int steps = 0;
+            if (A.warm_start & 2) steps = smallest_eigvec9_wave(red[0], wn2, (j > 0 && s_x_have) ? s_xprev : nullptr, s_xv, &s_xlambda, lane);
+            if (steps == 0) {
+                const bool jwarm = j > 0 && (A.warm_start & 1) && s_jv_have;
+                if (!jwarm) {
+                    if (lane == 0) {
+                        int t = 0;
+                        for (int a = 0; a < 9; ++a)
+                            for (int c = a; c < 9; ++c) {
+                                const double v = red[0][t++] / wn2;
+                                J.G[a][c] = v;
+                                J.G[c][a] = v;
+                            }
                     }
-                    J.Gn[a][b] = sacc;
+                    for (int ee = lane; ee < 81; ee += 64) J.Vv[ee / 9][ee % 9] = (ee / 9 == ee % 9) ? 1.0 : 0.0;
+                } else {
+                    for (int ee = lane; ee < 81; ee += 64) {  // Gn = G V_prev (G from the packed upper triangle, scaled)
+                        const int a = ee / 9, b = ee - a * 9;
+                        double sacc = 0;
+                        for (int k = 0; k < 9; ++k) {
+                            const int lo = a < k ? a : k, hi = a < k ? k : a;
+                            sacc += (red[0][lo * 9 - lo * (lo - 1) / 2 + (hi - lo)] / wn2) * J.Vv[k][b];
+                        }
+                        J.Gn[a][b] = sacc;
+                    }
+                    wave_sync();
+                    for (int ee = lane; ee < 81; ee += 64) {  // G = V_prev^T Gn, upper triangle mirrored
+                        const int a = ee / 9, b = ee - a * 9;
+                        if (a > b) continue;
+                        double sacc = 0;
+                        for (int k = 0; k < 9; ++k) sacc += J.Vv[k][a] * J.Gn[k][b];
+                        J.G[a][b] = sacc;
+                        J.G[b][a] = sacc;
+                    }
                 }
                 wave_sync();
-                for (int ee = lane; ee < 81; ee += 64) {  // G = V_prev^T Gn, upper triangle mirrored
-                    const int a = ee / 9, b = ee - a * 9;
-                    if (a > b) continue;
-                    double sacc = 0;
-                    for (int k = 0; k < 9; ++k) sacc += J.Vv[k][a] * J.Gn[k][b];
-                    J.G[a][b] = sacc;
-                    J.G[b][a] = sacc;
-                }
+                jacobi9_wave(J, lane);
             }
             wave_sync();
-            jacobi9_wave(J, lane);
             if (lane == 0) {
-                int order[9];
-                order_desc9(J, order);
-                if (fabs(J.G[order[7]][order[7]]) < DBL_EPSILON) {
+                double F2[9], err = 0;
+                bool rank_deficient = false;
+                if (steps > 0) {
+                    for (int k = 0; k < 9; ++k) F2[k] = s_xv[k];
+                    err = s_xlambda;
+                } else {
+                    int order[9];
+                    order_desc9(J, order);
+                    rank_deficient = fabs(J.G[order[7]][order[7]]) < DBL_EPSILON;
+                    for (int k = 0; k < 9; ++k) F2[k] = J.Vv[k][order[8]];
+                    err = J.G[order[8]][order[8]];  // |A1 lastCol|^2 = the eigenvalue
+                    s_jv_have = 1;
+                }
+                for (int k = 0; k < 9; ++k) s_xprev[k] = F2[k];
+                s_x_have = 1;
+                if (rank_deficient) {
                     s_stop = 3;  // "Refinement failed!": the initial matrix is returned
                 } else {
-                    double F2[9], sv[3], U[9], V[9];
-                    for (int k = 0; k < 9; ++k) F2[k] = J.Vv[k][order[8]];
+                    double sv[3], U[9], V[9];
                     svd3_eigen(F2, sv, U, V);
                     if (!arr_is_zero(sv[2]) || sv[0] / sv[1] > 1.5 || sv[0] / sv[1] < 0.66 || !(sv[1] > 0)) {
                         s_stop = 2;  // "taking last valid E"
                     } else {
                         for (int r = 0; r < 3; ++r)
                             for (int c = 0; c < 3; ++c) F3[r * 3 + c] = U[r * 3] * sv[0] * V[c * 3] + U[r * 3 + 1] * sv[1] * V[c * 3 + 1];
-                        const double err = J.G[order[8]][order[8]];  // |A1 lastCol|^2 = the eigenvalue
                         const double diff = fabs(s_err_old - err);
                         if (j > 1 && (diff < min_diff || err < min_err)) s_stop = 1;
                         s_err_old = err;
@@ -1336,7 +1359,8 @@ static int arrsac_run_problem(ArrsacRun &R, double thresh, int refine, uint64_t 
     MaskCountArgs ma{{(n + 255) / 256, 1}, R.pts, n, (const double *)(R.d_Epool + (size_t)R.pool[best].row * 9), R.thresh2, d_mask, d_info, d_E};
     R.L.launch(HK_ARR_MASK_COUNT, ma);
     if (refine) {  // the kernel itself returns the initial matrix below 50 inliers, as the reference does (modelest.cpp:304-309)
-        ArrRefineArgs ra{{1, 1}, R.pts, (const uint8_t *)d_mask, n, (const double *)(R.d_Epool + (size_t)R.pool[best].row * 9), thresh / 50.0, d_E + 9, d_info + 1, R.ctx->opt_arrsac_refine_warm_start};
+        ArrRefineArgs ra{{1, 1}, R.pts, (const uint8_t *)d_mask, n, (const double *)(R.d_Epool + (size_t)R.pool[best].row * 9), thresh / 50.0, d_E + 9, d_info + 1,
+                         (R.ctx->opt_arrsac_refine_warm_start ? 1 : 0) | (R.ctx->opt_eig_inverse_iteration ? 2 : 0)};
         R.L.launch(HK_ARR_REFINE, ra);
     }
     // best model + refined model + counters back: a copy kernel device -> mapped host

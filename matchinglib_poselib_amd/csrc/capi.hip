@@ -144,6 +144,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_ransac_device_draw = 1;
     ctx->opt_usac_lo_warm_start = 1;
     ctx->opt_hub_blocking_sync = 1;
+    ctx->opt_eig_inverse_iteration = 1;
     ctx->opt_arrsac_refine_warm_start = 1;
     ctx->opt_usac_sprt_fast = 1;
     ctx->opt_l2_float_mfma = 1;
@@ -228,6 +229,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "arrsac_flag_points") && (value == 0 || (value >= 128 && value <= 1024 && value % 64 == 0))) ctx->opt_arrsac_flag_points = value;
     else if (!std::strcmp(name, "pair_batch") && value >= 0 && value <= 256) ctx->opt_pair_batch = value;
     else if (!std::strcmp(name, "hub_lanes") && value >= 0 && value <= 4) ctx->opt_hub_lanes = value;
+    else if (!std::strcmp(name, "eig_inverse_iteration") && (value == 0 || value == 1)) ctx->opt_eig_inverse_iteration = value;
     else if (!std::strcmp(name, "hub_blocking_sync") && (value == 0 || value == 1)) ctx->opt_hub_blocking_sync = value;
     else if (!std::strcmp(name, "hub_workers") && value >= 0 && value <= 64) ctx->opt_hub_workers = value;
     else if (!std::strcmp(name, "hub_cohort") && (value == 0 || (value >= 8 && value <= 512))) ctx->opt_hub_cohort = value;

@@ -154,6 +154,7 @@ struct mlpl_ctx {
     int opt_pair_batch;                                // pairs per internal batch of mlpl_pair_pose_batch_dev (0 = 128)
     int opt_pair_batch_seq;                            // ... of mlpl_pair_pose_batch_usac_dev / _arrsac_dev (0 = 512)
     int opt_hub_lanes;                                 // cohorts in flight (0 = 4 = the most)
+    int opt_eig_inverse_iteration;                     // 1 (default): the smallest eigenvector of the re-weighted 9 x 9 fits (USAC REF_WEIGHTS, robustEssentialRefine) by inverse iteration, Jacobi as the fallback
     int opt_hub_blocking_sync;                         // 1: a lane's thread sleeps on an event at the end of a round instead of spinning in hipStreamSynchronize
     int opt_hub_workers;                               // worker threads per cohort (0 = 16): the runs of a cohort are fibers on them
     int opt_hub_cohort;                                // runs of a batched USAC / ARRSAC call that advance together (0 = 128; two such cohorts are in flight)

@@ -2068,6 +2068,122 @@ __device__ __forceinline__ int jacobi9_wave(Jacobi9Lds &J, int lane) {  // retur
     return sweeps;
 }
 
+// ---- the eigenvector of the SMALLEST eigenvalue of a symmetric positive semi-definite 9 x 9, by inverse iteration ------------------------
+// The re-weighted 8-point fits (USAC's REF_WEIGHTS refits, robustEssentialRefine's rounds) need one eigenvector, not nine, and come in
+// chains whose previous member is an excellent start.  With A = G + delta I (delta = 2^-44 trace G: A is safely positive definite, same
+// eigenvectors) a Cholesky factor and a pair of triangular solves per step multiply the component along the smallest eigenvector by
+// (lambda_2 + delta) / (lambda_1 + delta) -- typically 10^2 ... 10^6 -- against all others: 3-6 steps from a warm start, ~0.4 us each,
+// where the Jacobi sweeps of jacobi9_wave take 25-40 us per decomposition.  Layout: lane i < 9 holds row i of A, of L and column i of L
+// in registers; a value crosses lanes by v_readlane (no LDS, no barrier); every loop is unrolled, every index static.
+// Returns the steps taken, or 0 when it has not converged in kInvIterMax steps (lambda_2 close to lambda_1: the caller falls back to
+// jacobi9_wave, as it does when the factorisation meets a non-positive pivot) -- so near-degenerate systems keep their old path.
+// Gp: the upper triangle of G, packed by rows (45 values, LDS or global), each divided by `divisor`; start: 9 values or null (cold start).
+// x_out (9 values) and *lambda_out (x^T G x) are written by lanes 0..8 / lane 0; the caller orders them with wave_sync().
+constexpr int kInvIterMax = 40;
+__device__ __forceinline__ double bcast_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int smallest_eigvec9_wave(const double *Gp, double divisor, const double *start, double *x_out, double *lambda_out, int lane) {
+    const int i = lane < 9 ? lane : 8;  // (the other lanes shadow lane 8: uniform control flow, nothing stored)
+    double g[9], a[9], l[9], c[9];
+    double trace = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int lo = i < k ? i : k, hi = i < k ? k : i;
+        g[k] = Gp[lo * 9 - lo * (lo - 1) / 2 + (hi - lo)] / divisor;
+        l[k] = 0, c[k] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        double d = 0;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) d = (i == m) ? g[m] : d;  // own diagonal entry
+        trace += bcast_f64(d, k);
+    }
+    if (!(trace > 0) || !(trace < 1e300)) return 0;
+    const double delta = trace * 0x1p-44;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a[k] = g[k] + ((i == k) ? delta : 0.0);
+    // Cholesky, column by column
+    double inv_d = 0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        double sdiag = a[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) sdiag -= l[k] * l[k];
+        const double sj = bcast_f64(sdiag, j);
+        if (!(sj > 0)) return 0;  // wave-uniform
+        const double dj = sqrt(sj), inv = 1.0 / dj;
+        double t = a[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) t -= l[k] * bcast_f64(l[k], j);
+        const double lij = t * inv;
+        l[j] = (i > j) ? lij : ((i == j) ? dj : 0.0);
+        inv_d = (i == j) ? inv : inv_d;
+#pragma unroll
+        for (int m = j + 1; m < 9; ++m) {
+            const double v = bcast_f64(lij, m);
+            c[m] = (i == j) ? v : c[m];
+        }
+    }
+    double x = start ? start[i] : (1.0 / 3.0);
+    {   // (a start that is not a unit vector: normalise; a zero / non-finite one: cold start)
+        double n2 = 0;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) n2 += bcast_f64(x * x, m);
+        x = (n2 > 0x1p-200 && n2 < 0x1p200) ? x / sqrt(n2) : (1.0 / 3.0);
+    }
+    double d_prev = 0;
+    int it = 0;
+    bool done = false;
+    for (; it < kInvIterMax && !done;) {
+        ++it;
+        double acc = 0, y = 0, z = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {  // L y = x
+            const double yj = bcast_f64((x - acc) * inv_d, j);
+            y = (i == j) ? yj : y;
+            acc += (i > j) ? l[j] * yj : 0.0;
+        }
+        acc = 0;
+#pragma unroll
+        for (int j = 8; j >= 0; --j) {  // L^T z = y
+            const double zj = bcast_f64((y - acc) * inv_d, j);
+            z = (i == j) ? zj : z;
+            acc += (i < j) ? c[j] * zj : 0.0;
+        }
+        double n2 = 0;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) n2 += bcast_f64(z * z, m);
+        if (!(n2 > 0) || !(n2 < 1e300)) return 0;
+        const double xn = z / sqrt(n2);
+        double d = 0;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) d = fmax(d, bcast_f64(fabs(xn - x), m));
+        x = xn;
+        // geometric convergence with ratio q = d / d_prev: what is still to come is ~ d q / (1 - q)
+        if (d <= 0x1p-51)
+            done = true;  // at rounding level
+        else if (it > 1 && d < d_prev) {
+            const double q = d / d_prev;
+            done = d * q / (1.0 - q) <= 0x1p-52;
+        }
+        d_prev = d;
+    }
+    if (!done) return 0;
+    // Rayleigh quotient with G itself
+    double gx = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gx += g[k] * bcast_f64(x, k);
+    double lam = 0;
+#pragma unroll
+    for (int m = 0; m < 9; ++m) lam += bcast_f64(x * gx, m);
+    if (lane < 9) x_out[lane] = x;
+    if (lane == 0) *lambda_out = lam;
+    return it;
+}
+
 // Indices of the nine eigenvalues in descending order, the first of equal values first (what a selection sort from the top gives).  The
 // diagonal is read once (nine loads in flight) and every index gets its position by counting in registers; as a selection sort over LDS
 // the 36 comparisons were 72 dependent round trips (~4 us on one lane).
@@ -3603,7 +3719,8 @@ int mlpl_robust_essential_refine(mlpl_ctx *ctx, const double *p1, const double *
     {
         Launcher L;
         L.s = s;
-        ArrRefineArgs ra{{1, 1}, (const double4 *)pts, (const uint8_t *)dmask, n, (const double *)d_E, th, d_E + 9, d_info, ctx->opt_arrsac_refine_warm_start};
+        ArrRefineArgs ra{{1, 1}, (const double4 *)pts, (const uint8_t *)dmask, n, (const double *)d_E, th, d_E + 9, d_info,
+                         (ctx->opt_arrsac_refine_warm_start ? 1 : 0) | (ctx->opt_eig_inverse_iteration ? 2 : 0)};
         L.launch(HK_ARR_REFINE, ra);
     }
     MLPL_HIP_TRY(hipGetLastError());

@@ -309,6 +309,8 @@ struct UsacLoLds {
     double F[9], E[9];
     int scan[kUsacLoThreads / 64 + 1];
     int total, K, sweeps;
+    double xv[9], xprev[9], xlambda;  // smallest_eigvec9_wave: this fit's vector, the previous fit's (the next start)
+    int x_have, jv_have;              // xprev holds a vector / J.Vv holds the eigenvectors of an earlier Jacobi run of this chain
     int rw[kUsacLoMaxRows * (kUsacLoThreads / 64)];  // members of the fit set per (row, wave), then their exclusive prefix in index order
 };
 
@@ -318,8 +320,30 @@ struct UsacLoLds {
 // scene, a slightly different inlier set / weights), so the iteration starts from V_prev^T G V_prev, which is nearly diagonal, and
 // accumulates its rotations onto V_prev: the same eigen-decomposition to the same tolerance in 2-3 sweeps instead of 8 (a column of V may
 // come out with the other sign, which no error or weight sees).
-__device__ __forceinline__ void usac_fit_from_cov(UsacLoLds &L, const UsacGeom &g, int tid, bool warm) {
+// `inv_iter`: first try smallest_eigvec9_wave (ransac_5pt.hip) from the previous fit's vector -- 3-6 steps of ~0.4 us where the Jacobi
+// iteration takes 25-40 us; systems it does not settle on (second-smallest eigenvalue close to the smallest) take the Jacobi path as before.
+__device__ __forceinline__ void usac_fit_from_cov(UsacLoLds &L, const UsacGeom &g, int tid, bool warm, bool inv_iter) {
     if (tid < 64) {
+        int steps = 0;
+        if (inv_iter) steps = smallest_eigvec9_wave(L.red[0], 1.0, (warm && L.x_have) ? L.xprev : nullptr, L.xv, &L.xlambda, tid);  // wave-uniform result
+        if (steps > 0) {
+            wave_sync();
+            if (tid == 0) {
+                double F[9], v[3], Fv[3];
+                for (int k = 0; k < 9; ++k) F[k] = L.xv[k], L.xprev[k] = L.xv[k];
+                L.x_have = 1;
+                null_vector_3x3(F, v);
+                for (int r = 0; r < 3; ++r) Fv[r] = F[3 * r] * v[0] + F[3 * r + 1] * v[1] + F[3 * r + 2] * v[2];
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) F[3 * r + c] -= Fv[r] * v[c];
+                double t[9], E[9];
+                usac_mul3(t, g.T2t, F);
+                usac_mul3(E, t, g.T1);
+                for (int k = 0; k < 9; ++k) L.F[k] = F[k], L.E[k] = E[k];
+            }
+            return;
+        }
+        warm = warm && L.jv_have;
         if (!warm) {
             if (tid == 0) {
                 int t = 0;
@@ -360,7 +384,8 @@ __device__ __forceinline__ void usac_fit_from_cov(UsacLoLds &L, const UsacGeom &
             for (int a = 1; a < 9; ++a)
                 if (L.J.G[a][a] < L.J.G[m][m]) m = a;
             double F[9], v[3], Fv[3];
-            for (int k = 0; k < 9; ++k) F[k] = L.J.Vv[k][m];
+            for (int k = 0; k < 9; ++k) F[k] = L.J.Vv[k][m], L.xprev[k] = F[k];
+            L.x_have = 1, L.jv_have = 1;
             null_vector_3x3(F, v);
             for (int r = 0; r < 3; ++r) Fv[r] = F[3 * r] * v[0] + F[3 * r + 1] * v[1] + F[3 * r + 2] * v[2];
             for (int r = 0; r < 3; ++r)
@@ -455,7 +480,7 @@ __device__ __forceinline__ void usac_lo_body(const UsacLoArgs &A, const int vbx,
     int eval = 0;
     int fit_pts = 0;
     bool have_fit = false;  // L.J.Vv holds the eigenvectors of an earlier fit of this chain
-    if (tid == 0) L.sweeps = 0;
+    if (tid == 0) L.sweeps = 0, L.x_have = 0, L.jv_have = 0;
 
     if (I.start_step < 0) {  // model of the 14-point sample, unit weights
         double acc[45];
@@ -469,7 +494,7 @@ __device__ __forceinline__ void usac_lo_body(const UsacLoArgs &A, const int vbx,
             usac_cov_add(acc, a, c, 1.0);
         }
         usac_reduce45(L, acc, tid);
-        usac_fit_from_cov(L, g, tid, false);
+        usac_fit_from_cov(L, g, tid, false, (warm_start & 2) != 0);
         have_fit = true;
         fit_pts = kUsacLoSample;
     } else {
@@ -584,7 +609,7 @@ __device__ __forceinline__ void usac_lo_body(const UsacLoArgs &A, const int vbx,
             usac_cov_add(acc, a, c, w);
         }
         usac_reduce45(L, acc, tid);
-        usac_fit_from_cov(L, g, tid, have_fit && warm_start != 0);
+        usac_fit_from_cov(L, g, tid, have_fit && (warm_start & 1) != 0, (warm_start & 2) != 0);
         have_fit = true;
         fit_pts = used;
         __syncthreads();
@@ -1767,7 +1792,8 @@ struct UsacRun {
     // ---- local optimisation ----
     int launch_lo(int reps_from, int reps_to) {  // h_lo_in[reps_from .. reps_to) are filled
         UsacLoArgs la{{reps_to - reps_from, 1}, d_p1, d_p2, (const double4 *)d_pts_pool, (int)n, words, g, thr, lo_mult, (const UsacLoIn *)(d_lo_in + reps_from),
-                      h_out_dev + (size_t)reps_from * lo_out_stride(), lo_out_stride(), d_err + (size_t)reps_from * n, ctx->opt_usac_lo_warm_start};
+                      h_out_dev + (size_t)reps_from * lo_out_stride(), lo_out_stride(), d_err + (size_t)reps_from * n,
+                      (ctx->opt_usac_lo_warm_start ? 1 : 0) | (ctx->opt_eig_inverse_iteration ? 2 : 0)};
         L.launch(HK_USAC_LO, la);
         int rcw;
         if ((rcw = L.sync())) return rcw;
