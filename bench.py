@@ -191,7 +191,7 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
         "config": {"workload": f"C5: {total} stereo pairs x ({args.n} ORB-256 keypoints per image: Hamming 2-NN + 0.75 ratio -> "
                                "ImgToCamCoordTrans gather -> RANSAC 1000 it / 0.999 -> getPoseTriangPts), one step = the whole batch",
                    "pairs_total": total, "pairs_this_rank": mine, "distinct_inputs_per_rank": distinct,
-                   "entry": "mlpl_pair_pose_batch_dev (pair = grid dimension; internal batches of 128 pairs); timed both with two calls in flight "
+                   "entry": "mlpl_pair_pose_batch_dev (pair = grid dimension; internal batches of 256 pairs); timed both with two calls in flight "
                             "per rank (batch.BatchLanes: two library contexts, half of the rank's share each) and one call at a time -- "
                             "`mode` names the faster one, which `value` is", "parallelism": f"shard{world}",
                    "world_size": world, "backend": args.backend if world > 1 else None,

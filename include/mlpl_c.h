@@ -398,7 +398,7 @@ int mlpl_pair_pose_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, const uint8_t 
  * A BATCH of image pairs through the same pipeline with the pair as a grid dimension of every launch (the reference harness loop over
  * image pairs, tests/poselib-test/main.cpp:1440-2072; BASELINE config 5): d_q / d_t / d_kp1 / d_kp2 hold n_pairs contiguous items
  * ([n_pairs][nq][nbytes], [n_pairs][nt][nbytes], [n_pairs][nq][2], [n_pairs][nt][2]), seeds[n_pairs] and out[n_pairs] are HOST arrays.
- * Every pair's record equals what mlpl_pair_pose_dev returns for it with the same seed.  Host hops per internal batch of 128 pairs
+ * Every pair's record equals what mlpl_pair_pose_dev returns for it with the same seed.  Host hops per internal batch of 256 pairs
  * (option "pair_batch"): the match counts, one per RANSAC pass (the first 324 iterations of every pair, then the rest for the pairs
  * the adaptive bound has not stopped), the results.  refit != 0 runs the pairs one by one through mlpl_pair_pose_dev.
  */

@@ -128,7 +128,7 @@ def process_pairs_batched(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, seeds, t
                           confidence: float = 0.999, refit: bool = False, dist: float = 50.0, pair_ids=None, matches_out=None) -> np.ndarray:
     """A batch of image pairs in ONE library call (mlpl_pair_pose_batch_dev): device tensors d_q [B, nq, nbytes] uint8, d_t [B, nt, nbytes],
     d_kp1 [B, nq, 2] float32, d_kp2 [B, nt, 2]; seeds: B RANSAC seeds.  The pair is a grid dimension of every launch -- no host threads, a
-    handful of host hops per 128 pairs -- and every record equals process_pair_on_device's for that pair.  matches_out: optional int32
+    handful of host hops per 256 pairs -- and every record equals process_pair_on_device's for that pair.  matches_out: optional int32
     CUDA tensor [B, nq, 4] that receives the match lists (cv::DMatch rows, n_matches valid per pair).  Returns B RECORD_DTYPE records."""
     import torch
 
@@ -254,7 +254,7 @@ def ransac_pose_batched(ctx: Context, d_p1, d_p2, counts, seeds, thresh: float, 
 
 class BatchLanes:
     """`lanes` (2) independent (library context, torch stream, host thread) triples on one GPU, each running mlpl_pair_pose_batch_dev on its
-    share of a batch.  A batched call has ~5 host hops per 128 pairs (match counts, one per RANSAC pass, the pose) during which its stream
+    share of a batch.  A batched call has ~5 host hops per 256 pairs (match counts, one per RANSAC pass, the pose) during which its stream
     is idle, and its solver kernels are latency-bound: a second call in flight fills both (512 pairs: 11.1 -> 9.8 ms; four lanes: 10.4).
     Records do not depend on the lane count: every pair's result is a function of its inputs and its seed."""
 

@@ -227,7 +227,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "ransac_device_draw") && (value == 0 || value == 1)) ctx->opt_ransac_device_draw = value;
     else if (!std::strcmp(name, "l2_float_mfma") && value >= 0 && value <= 2) ctx->opt_l2_float_mfma = value;
     else if (!std::strcmp(name, "arrsac_flag_points") && (value == 0 || (value >= 128 && value <= 1024 && value % 64 == 0))) ctx->opt_arrsac_flag_points = value;
-    else if (!std::strcmp(name, "pair_batch") && value >= 0 && value <= 256) ctx->opt_pair_batch = value;
+    else if (!std::strcmp(name, "pair_batch") && value >= 0 && value <= 1024) ctx->opt_pair_batch = value;
     else if (!std::strcmp(name, "hub_lanes") && value >= 0 && value <= 4) ctx->opt_hub_lanes = value;
     else if (!std::strcmp(name, "eig_inverse_iteration") && (value == 0 || value == 1)) ctx->opt_eig_inverse_iteration = value;
     else if (!std::strcmp(name, "hub_blocking_sync") && (value == 0 || value == 1)) ctx->opt_hub_blocking_sync = value;

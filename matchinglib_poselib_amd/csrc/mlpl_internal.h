@@ -151,7 +151,7 @@ struct mlpl_ctx {
     unsigned usac_prosac_tab_top;
     double usac_prosac_tab_beta, usac_prosac_tab_conf;
     long long last_batch_stats[8];                     // mlpl_pair_pose_batch_dev: {RANSAC passes, pair slots over all passes, pairs redone on a host table, 0}
-    int opt_pair_batch;                                // pairs per internal batch of mlpl_pair_pose_batch_dev (0 = 128)
+    int opt_pair_batch;                                // pairs per internal batch of mlpl_pair_pose_batch_dev (0 = 256)
     int opt_pair_batch_seq;                            // ... of mlpl_pair_pose_batch_usac_dev / _arrsac_dev (0 = 512)
     int opt_hub_lanes;                                 // cohorts in flight (0 = 4 = the most)
     int opt_eig_inverse_iteration;                     // 1 (default): the smallest eigenvector of the re-weighted 9 x 9 fits (USAC REF_WEIGHTS, robustEssentialRefine) by inverse iteration, Jacobi as the fallback

@@ -20,7 +20,7 @@ namespace {
 
 constexpr int kBatchFirstPass = 324;   // multiple of kHypPerWave; above the stopping point of pairs with >= ~45 % inliers at 0.999
 constexpr int kBatchPassMax = 1026;    // hypotheses per pair and pass (multiple of kHypPerWave)
-constexpr int kBatchPairsPerCall = 128;  // pairs per internal batch (workspace ~2.6 MB per pair)
+constexpr int kBatchPairsPerCall = 256;  // pairs per internal batch (workspace ~2.6 MB per pair; 512 pairs in one call: 10.5 ms at 128, 9.8-9.9 at 256, 10.0-10.2 at 512)
 constexpr int kSeqBatchPairsPerCall = 512;  // ... of the entries with a sequential estimator (USAC, ARRSAC): their cohorts of runs (usac_impl.h) want the
                                             // whole batch at hand (512 pairs: 24 ms at 256 per internal batch, 27 at 128); workspace ~0.7 MB per pair
 
