@@ -333,6 +333,41 @@ __device__ __forceinline__ void arrsac_sample_body(const ArrSampleArgs &A, const
 }
 MLPL_HUB_KERNEL(HK_ARR_SAMPLE, ArrSampleArgs, arrsac_sample_body, 64);
 
+// ValidModel for ONE model on ONE lane: valid_model_wave's arithmetic, the sample's points in a loop instead of across lanes (the same
+// operations per point, so the same verdict).  The 3 x 3 SVD is sequential code; one wave per model left 63 lanes idle for ~15 us, which a
+// single run hides behind nothing anyway but a batch of 128 runs pays 164 000 times per round (0.7 ms of a 1 ms round).
+__device__ __forceinline__ bool valid_model_lane(const double *E, const int32_t *sm, int m, const double *__restrict__ p1, const double *__restrict__ p2) {
+    double Et[9], sv[3], U[9], V[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Et[r * 3 + c] = E[c * 3 + r];
+    svd3_eigen(Et, sv, U, V);
+    const bool sv_ok = !(sv[0] / sv[1] > 1.2) && arr_is_zero(0.01 * sv[2] / sv[1]);
+    const double e2[3] = {V[2], V[5], V[8]};
+    bool anyP = false;
+    int fail = 0;
+    for (int t = 0; t < m; ++t) {
+        const int idx = sm[1 + t];
+        const double x1 = p1[2 * idx], y1 = p1[2 * idx + 1], x2 = p2[2 * idx], y2 = p2[2 * idx + 1];
+        const double l1[3] = {e2[1] - e2[2] * y2, e2[2] * x2 - e2[0], e2[0] * y2 - e2[1] * x2};
+        bool P = false, Q = false;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double l2 = E[j * 3] * x1 + E[j * 3 + 1] * y1 + E[j * 3 + 2];
+            const bool skip = arr_is_zero(0.1 * l1[j]) || arr_is_zero(0.1 * l2);
+            const double pr = l1[j] * l2;
+            P = P || (!skip && pr < 0);
+            Q = Q || (!skip && pr > 0);  // l1 * (-l2) < 0
+        }
+        anyP = anyP || P;
+        fail += Q ? 1 : 0;
+    }
+    return sv_ok && (!anyP || !((float)fail / (float)m >= 0.4f));
+}
+
+// Two launches per batch of samples: arrsac_valid (one LANE per model slot: sign convention, ValidModel) and arrsac_check (one WAVE per
+// valid model: its inlier bits).
 struct ArrCheckArgs {
     KHdr hdr;
     const double4 * pts;
@@ -351,41 +386,24 @@ struct ArrCheckArgs {
     double * out_e00;
     unsigned long long * out_head;
     unsigned long long * flag_rows;
+    int32_t * d_valid;  // [n_samples][10], device: arrsac_valid -> arrsac_check
 };
-__device__ __forceinline__ void arrsac_check_body(const ArrCheckArgs &A, const int vbx, const int vby) {
-    const double4 *__restrict__ pts = A.pts;
-    const int flag_points = A.flag_points;
-    const double *__restrict__ p1 = A.p1;
-    const double *__restrict__ p2 = A.p2;
-    const int32_t *__restrict__ smp = A.smp;
-    const int n_samples = A.n_samples;
-    double *__restrict__ E_tab = A.E_tab;
-    const int32_t *__restrict__ n_models = A.n_models;
-    const double *__restrict__ direct_E = A.direct_E;
-    const int32_t *__restrict__ direct_ok = A.direct_ok;
-    const double thresh2 = A.thresh2;
-    int32_t *__restrict__ out_nm = A.out_nm;
-    int32_t *__restrict__ out_valid = A.out_valid;
-    double *__restrict__ out_e00 = A.out_e00;
-    unsigned long long *__restrict__ out_head = A.out_head;
-    unsigned long long *__restrict__ flag_rows = A.flag_rows;
-
-    __shared__ double q[1][4];  // the epipole and the singular-value verdict, lane 0 -> wave
-    if (blockDim.x != kSolverThreads) __builtin_trap();  // wave_sync() is a one-wave ordering
-    const int lane = threadIdx.x;
-    const int b = vbx / 10, slot = vbx - b * 10;
-    if (b >= n_samples) return;
-    const int32_t *sm = smp + (size_t)b * kArrSmpStride;
+__device__ __forceinline__ void arrsac_valid_body(const ArrCheckArgs &A, const int vbx, const int vby) {
+    const int g = vbx * 64 + (int)threadIdx.x;  // model slot
+    const int b = g / 10, slot = g - b * 10;
+    if (b >= A.n_samples) return;
+    const int32_t *sm = A.smp + (size_t)b * kArrSmpStride;
     const int m = sm[0], kind = sm[15];
-    const int nm = kind ? direct_ok[b] : n_models[b];
-    if (slot == 0 && lane == 0) out_nm[b] = nm;
+    const int nm = kind ? A.direct_ok[b] : A.n_models[b];
+    if (slot == 0) A.out_nm[b] = nm;
     if (slot >= nm) {
-        if (lane == 0) out_valid[b * 10 + slot] = 0;
+        A.out_valid[b * 10 + slot] = 0;
+        A.d_valid[b * 10 + slot] = 0;
         return;
     }
     double e[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) e[k] = kind ? direct_E[(size_t)b * 9 + k] : E_tab[((size_t)b * 10 + slot) * 9 + k];
+    for (int k = 0; k < 9; ++k) e[k] = kind ? A.direct_E[(size_t)b * 9 + k] : A.E_tab[((size_t)b * 10 + slot) * 9 + k];
     if (!kind) {
         // sign convention of a 5-point solution: its element of largest magnitude is positive.  (The reference's sign comes from the
         // last null vector cv::SVD happens to return -- rounding noise decides it -- and ValidModel is not sign-symmetric.)
@@ -401,20 +419,28 @@ __device__ __forceinline__ void arrsac_check_body(const ArrCheckArgs &A, const i
             for (int k = 0; k < 9; ++k) e[k] = -e[k];
         }
     }
-    if (lane < 9) {
-        double v = e[0];
 #pragma unroll
-        for (int k = 1; k < 9; ++k) v = (lane == k) ? e[k] : v;
-        E_tab[((size_t)b * 10 + slot) * 9 + lane] = v;
-    }
-    double sx1 = 0, sy1 = 0, sx2 = 0, sy2 = 0;  // this lane's sample correspondence
-    if (lane < m) {
-        const int idx = sm[1 + lane];
-        sx1 = p1[2 * idx], sy1 = p1[2 * idx + 1], sx2 = p2[2 * idx], sy2 = p2[2 * idx + 1];
-    }
-    const bool valid = valid_model_wave(sx1, sy1, sx2, sy2, m, e, &q[0][0], lane);  // wave-uniform
-    if (lane == 0) out_valid[b * 10 + slot] = valid ? 1 : 0;
-    if (!valid) return;
+    for (int k = 0; k < 9; ++k) A.E_tab[((size_t)b * 10 + slot) * 9 + k] = e[k];
+    const bool valid = valid_model_lane(e, sm, m, A.p1, A.p2);
+    A.out_valid[b * 10 + slot] = valid ? 1 : 0;
+    A.d_valid[b * 10 + slot] = valid ? 1 : 0;
+    if (valid) A.out_e00[b * 10 + slot] = e[0];
+}
+MLPL_HUB_KERNEL(HK_ARR_VALID, ArrCheckArgs, arrsac_valid_body, 64);
+
+__device__ __forceinline__ void arrsac_check_body(const ArrCheckArgs &A, const int vbx, const int vby) {
+    const double4 *__restrict__ pts = A.pts;
+    const int flag_points = A.flag_points;
+    const double thresh2 = A.thresh2;
+    unsigned long long *__restrict__ out_head = A.out_head;
+    unsigned long long *__restrict__ flag_rows = A.flag_rows;
+    const int lane = threadIdx.x;
+    const int b = vbx / 10, slot = vbx - b * 10;
+    if (b >= A.n_samples) return;
+    if (!A.d_valid[b * 10 + slot]) return;  // wave-uniform
+    double e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = A.E_tab[((size_t)b * 10 + slot) * 9 + k];
     // the sixteen correspondences of this lane: all loads go out together (one after the other, each of the sixteen rounds waited
     // for its own: 4.4 us of a 13 us wave)
     double4 pp[kArrFlagWords];
@@ -431,7 +457,6 @@ __device__ __forceinline__ void arrsac_check_body(const ArrCheckArgs &A, const i
             if (w < kArrHeadWords) out_head[((size_t)b * 10 + slot) * kArrHeadWords + w] = bal;
         }
     }
-    if (lane == 0) out_e00[b * 10 + slot] = e[0];
 }
 MLPL_HUB_KERNEL(HK_ARR_CHECK, ArrCheckArgs, arrsac_check_body, 64);
 
@@ -772,7 +797,7 @@ struct ArrsacRun {
     int32_t *d_smp = nullptr;
     PolyRec *d_recs = nullptr;
     double *d_direct = nullptr;
-    int32_t *d_direct_ok = nullptr, *d_nm5 = nullptr;
+    int32_t *d_direct_ok = nullptr, *d_nm5 = nullptr, *d_valid = nullptr;
     char *h_out = nullptr, *h_out_dev = nullptr;
     int32_t *h_smp = nullptr;
     double *d_final = nullptr;     // [0..8] best model, [9..17] refined, then 4 ints: inlier count, refinement info
@@ -800,7 +825,7 @@ struct ArrsacRun {
         return std::max(batch, (size_t)B * 10 * sizeof(ArrFullRow) + (size_t)B * 40);  // the same blocks carry gathered rows
     }
     struct Layout {
-        size_t d_pts, d_recs, d_direct, d_final, d_Epool, d_Fpool, dev_total;
+        size_t d_pts, d_recs, d_direct, d_valid, d_final, d_Epool, d_Fpool, dev_total;
         size_t p_out, p_smp, p_final, pin_total;
     };
     static Layout layout(int n) {
@@ -810,6 +835,7 @@ struct ArrsacRun {
         Y.d_pts = o, o = up(o + (size_t)std::max(n, 1) * sizeof(double4));
         Y.d_recs = o, o = up(o + (size_t)kArrBatchCap * sizeof(PolyRec));
         Y.d_direct = o, o = up(o + (size_t)kArrBatchCap * (72 + 8));
+        Y.d_valid = o, o = up(o + (size_t)kArrBatchCap * 10 * 4);
         Y.d_final = o, o = up(o + 256);
         Y.d_Epool = o, o = up(o + (size_t)kArrPoolSamples * 720);
         Y.d_Fpool = o, o = up(o + (size_t)kArrPoolSamples * 10 * kArrFlagWords * 8);
@@ -844,6 +870,7 @@ struct ArrsacRun {
         d_direct = (double *)(dev + Y.d_direct);
         d_direct_ok = (int32_t *)(d_direct + (size_t)kArrBatchCap * 9);
         d_nm5 = d_direct_ok + kArrBatchCap;
+        d_valid = (int32_t *)(dev + Y.d_valid);
         d_final = (double *)(dev + Y.d_final);
         d_Epool = (double *)(dev + Y.d_Epool);
         d_Fpool = (unsigned long long *)(dev + Y.d_Fpool);
@@ -881,7 +908,10 @@ struct ArrsacRun {
         RootsArgs ra{{(B + kHypPerWave - 1) / kHypPerWave, 1}, (const PolyRec *)d_recs, B, o_E, d_nm5};
         L.launch(ctx->opt_solver_polish ? HK_ROOTS_POLISH : HK_ROOTS_PLAIN, ra);
         ArrCheckArgs ca{{B * 10, 1}, pts, flag_points, d_p1, d_p2, (const int32_t *)d_smp, B, o_E, (const int32_t *)d_nm5, (const double *)d_direct,
-                        (const int32_t *)d_direct_ok, thresh2, o_nm, o_valid, o_e00, o_head, o_rows};
+                        (const int32_t *)d_direct_ok, thresh2, o_nm, o_valid, o_e00, o_head, o_rows, d_valid};
+        ArrCheckArgs va = ca;
+        va.hdr.gx = (B * 10 + 63) / 64;
+        L.launch(HK_ARR_VALID, va);
         L.launch(HK_ARR_CHECK, ca);
         (void)total;
         int rcw;

@@ -20,6 +20,7 @@ enum HubKernelId {
     HK_USAC5_EVAL,
     HK_USAC5_GRAM,
     HK_ARR_SAMPLE,
+    HK_ARR_VALID,
     HK_ARR_CHECK,
     HK_ARR_GATHER,
     HK_ARR_EXTEND,
