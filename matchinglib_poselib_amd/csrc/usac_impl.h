@@ -72,6 +72,24 @@ __device__ __forceinline__ double usac_sampson(const double *m, double x1, doubl
     return r * r / (rxc * rxc + ryc * ryc + rx * rx + ry * ry);
 }
 
+// usac_sampson(...) < thr without the division wherever the answer does not depend on it.  With q = r^2 and D the denominator as the
+// reference computes them, the reference's verdict is RN(q / D) < thr.  RN is monotonic and within 2^-53 of q / D, and t = RN(thr D) is
+// within 2^-53 of thr D, so q < t (1 - 2^-50) implies RN(q / D) < thr and q > t (1 + 2^-50) implies RN(q / D) > thr; in between (one
+// evaluation in ~10^15), and whenever a comparison fails for a NaN or an infinity, the division itself decides.  The IEEE division is a
+// quarter of the instructions of an evaluation.
+__device__ __forceinline__ bool usac_sampson_less(const double *m, double x1, double y1, double x2, double y2, double thr) {
+    const double rxc = m[0] * x2 + m[3] * y2 + m[6];
+    const double ryc = m[1] * x2 + m[4] * y2 + m[7];
+    const double rwc = m[2] * x2 + m[5] * y2 + m[8];
+    const double r = (x1 * rxc + y1 * ryc + rwc);
+    const double rx = m[0] * x1 + m[1] * y1 + m[2];
+    const double ry = m[3] * x1 + m[4] * y1 + m[5];
+    const double q = r * r, D = rxc * rxc + ryc * ryc + rx * rx + ry * ry, t = thr * D;
+    if (q < t * (1.0 - 0x1p-50)) return true;
+    if (q > t * (1.0 + 0x1p-50)) return false;
+    return q / D < thr;
+}
+
 struct UsacPoolPackArgs {
     KHdr hdr;
     const double * p1;
@@ -190,7 +208,7 @@ __device__ __forceinline__ void usac_check_body(const UsacCheckArgs &A, const in
         bool in = false;
         if (j < n) {
             const double4 p = pts_pool[j];
-            in = usac_sampson(E, p.x, p.y, p.z, p.w) < thr;
+            in = usac_sampson_less(E, p.x, p.y, p.z, p.w, thr);
         }
         const unsigned long long bal = __ballot(in);
         if (lane == (w & 63)) mine = bal;
@@ -247,7 +265,7 @@ __device__ __forceinline__ void usac_degen_rows_body(const UsacDgRowsArgs &A, co
         if (j < n) {
             const double4 p = pts_pool[j];
             if (M.kind == 3) {
-                in_a = usac_sampson(M.m, p.x, p.y, p.z, p.w) < thr_inl;
+                in_a = usac_sampson_less(M.m, p.x, p.y, p.z, p.w, thr_inl);
             } else {
                 double f1[3], f2[3], err;
                 dg_bearing(p.z, p.w, f1);
@@ -540,7 +558,7 @@ __device__ __forceinline__ void usac_lo_body(const UsacLoArgs &A, const int vbx,
                 bool inl = false;
                 if (j < n) {
                     const double4 p = pts_pool[j];
-                    inl = usac_sampson(E, p.x, p.y, p.z, p.w) < thr;
+                    inl = usac_sampson_less(E, p.x, p.y, p.z, p.w, thr);
                 }
                 const unsigned long long bal = __ballot(inl);
                 if (lane == 0) row[w] = bal;
@@ -616,6 +634,10 @@ __device__ __forceinline__ void usac_lo_body(const UsacLoArgs &A, const int vbx,
     }
     if (tid == 0) O->evals = eval, O->sweeps = L.sweeps;
 }
+// Measured and not kept (round 4): the merged launch compiled for four waves per SIMD (128 VGPRs, staging cut to 48 KB so that two
+// workgroups share a compute unit -- at 256 VGPRs a workgroup owns its CU and the 640 workgroups of a cohort run in 2.5 rounds while nothing
+// else runs beside them): 295 spilled registers, 1.1 -> 3.2 ms per merged launch, 512 problems 13.6 -> 17.8 ms.  The 45 running sums per thread
+// are what the registers hold.
 MLPL_HUB_KERNEL(HK_USAC_LO, UsacLoArgs, usac_lo_body, kUsacLoThreads);
 
 // ---- local optimisation with the refinements of the 5-point family (poselib::RefineAlg REF_STEWENIUS(_WEIGHTS), REF_NISTER(_WEIGHTS)) ------
@@ -981,7 +1003,7 @@ __device__ __forceinline__ void usac5_eval_body(const Usac5EvalArgs &A, const in
         bool in = false;
         if (j < n) {
             const double4 p = pts_pool[j];
-            in = usac_sampson(E, p.x, p.y, p.z, p.w) < thr;
+            in = usac_sampson_less(E, p.x, p.y, p.z, p.w, thr);
         }
         const unsigned long long bal = __ballot(in);
         if (lane == 0) row[w] = bal;

@@ -26,8 +26,11 @@ dev = torch.device("cuda:0")
 d1, d2 = torch.from_numpy(p1).to(dev), torch.from_numpy(p2).to(dev)
 masks = torch.zeros((B, n), dtype=torch.uint8, device=dev)
 seeds = [1000 + b for b in range(B)]
+ONLY = os.environ.get("UBT_ONLY")   # "refine,prosac": one configuration only (for a kernel trace of it alone)
 for refine, est in ((0, 0), (5, 2)):
     for prosac in (0, 1):
+        if ONLY and ONLY != f"{refine},{prosac}":
+            continue
         kw = dict(refine=refine, estimator=est, sprt_ms=6.0, sprt_tm=2736.0, ctx=ctx)
         si = orders if prosac else None
         got = pose.usac_essential_batch(d1, d2, [n] * B, th, seeds, sorted_idx=si, masks_out=masks, **kw)
