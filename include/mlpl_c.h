@@ -77,6 +77,15 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  *     iteration-bound table T[g] on the host for every call (default 0: the device evaluates the few bounds it needs and the host
  *     verifies exactly those against its libm, falling back to the table when one differs); "ransac_event_cap" (tests) = capacity of
  *     the record-event list of the replay kernels.
+ *   Sequential estimators (round 4): "eig_inverse_iteration" (default 1) = the one eigenvector the re-weighted 9 x 9 fits need (USAC
+ *     REF_WEIGHTS, robustEssentialRefine) by inverse iteration, the Jacobi decomposition as fallback, 0 = Jacobi always;
+ *     "usac_lo_warm_start" / "arrsac_refine_warm_start" (default 1) = a chain's eigen-iterations start from its previous fit;
+ *     "usac_sprt_fast", "usac_lo_stepwise" (tests).  Batches of them: "hub_lanes" (cohorts of runs in flight, 0 = 4 = the most),
+ *     "hub_cohort" (runs per cohort, 0 = 128), "hub_workers" (worker threads per cohort, 0 = 16: the runs are fibers on them),
+ *     "hub_blocking_sync" (default 1: a cohort's thread sleeps at the end of a round instead of spinning), "pair_batch" /
+ *     "pair_batch_seq" (image pairs per internal batch of mlpl_pair_pose_batch_dev, 0 = 256 / of its USAC and ARRSAC forms, 0 = 512).
+ *     Hamming: "hamming_fused_merge" (default 1) = the LDS-ring kernel folds its train splits, evaluates the ratio predicate and counts
+ *     itself, 0 = separate merge launch; RANSAC: "ransac_count_mpl" 1|2 models per lane of the counting kernel (A/B, default 1).
  *   "solver_polish" (default 1) = every 5-point solution is polished by Gauss-Newton on the ten cubic constraints; 0 = the plain
  *     elimination + root path, which -- like the CPU code -- is off by up to 1e-5 on the ~0.5 % of samples whose eliminated block is ill
  *     conditioned.  This is the one option that changes results (towards the exact solution). */
