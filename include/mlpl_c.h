@@ -479,6 +479,10 @@ int mlpl_ransac_last_stats(mlpl_ctx *ctx, long long stats[2]);
  * >= 64 correspondences draw their samples on the device from the cached raw rand() stream): {calls redone with the host drawing the table
  * because a window / list / the stream ran out, 1 if the last call's samples were drawn on the device}. */
 int mlpl_debug_ransac_draw(mlpl_ctx *ctx, long long out[2]);
+/* The run scheduler of the batched sequential estimators by itself (csrc/batch_hub.h: fibers on worker threads, futex hand-over), no GPU
+ * and no context needed: n fibers on `workers` threads pass `rounds` times through the hand-over against a stand-in hub on the calling
+ * thread.  Returns n * rounds, or a negative value on bad arguments / a fiber that was not released exactly once per round. */
+long long mlpl_debug_fiber_selftest(int n, int workers, int rounds);
 
 /* Diagnostics: root-iteration (Ehrlich-Aberth) sweep statistics of the solver since the last call: {sum, solves, max, (enabled), sample
  * index of the max, solves with <= 8, 12, 16, 24, 32, 64, 128, 256, < 400, = 400 sweeps, 0}; enable != 0 turns the (atomic) bookkeeping on.

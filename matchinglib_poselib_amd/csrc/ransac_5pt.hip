@@ -3066,6 +3066,49 @@ using namespace mlpl;
 
 extern "C" {
 
+// The run scheduler of the launch hub by itself (no GPU, no context): n fibers on `workers` threads, each passing `rounds` times through
+// the hub's hand-over -- announce, block until the generation advances -- against a stand-in hub on the calling thread that releases a
+// round once every fiber has announced.  Returns the number of hand-overs completed (n * rounds when the scheduler works), -1 on bad
+// arguments.  tests/test_fiber_scheduler.py runs it without a GPU, also with far more fibers than workers and than host cores.
+long long mlpl_debug_fiber_selftest(int n, int workers, int rounds) {
+    if (n < 1 || n > 4096 || workers < 1 || workers > 256 || rounds < 1 || rounds > 100000) return -1;
+    HubThreads pool;
+    std::atomic<int> pending{n};
+    std::atomic<uint32_t> gen{0}, hub_word{0};
+    std::atomic<long long> done{0};
+    std::vector<int> order_seen((size_t)n, 0);
+    pool.start(n, [&](int k) {
+        volatile char pad[4096];  // (every fiber really has its own stack)
+        pad[0] = (char)k;
+        for (int r = 0; r < rounds; ++r) {
+            const uint32_t g = gen.load(std::memory_order_acquire);
+            if (pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                hub_word.fetch_add(1, std::memory_order_release);
+                futex_wake_u32(&hub_word, 1);
+            }
+            hub_block_until_changed(&gen, g);
+            if (gen.load(std::memory_order_acquire) != g + 1) return;  // released exactly once per round
+            ++order_seen[(size_t)k];
+            done.fetch_add(1, std::memory_order_relaxed);
+        }
+        (void)pad[0];
+    }, workers);
+    for (int r = 0; r < rounds; ++r) {
+        for (;;) {
+            const uint32_t w = hub_word.load(std::memory_order_acquire);
+            if (pending.load(std::memory_order_acquire) == 0) break;
+            futex_wait_u32(&hub_word, w);
+        }
+        pending.store(n, std::memory_order_release);
+        gen.fetch_add(1, std::memory_order_release);
+        futex_wake_u32(&gen, INT_MAX);
+    }
+    pool.wait();
+    for (int k = 0; k < n; ++k)
+        if (order_seen[(size_t)k] != rounds) return -2;
+    return done.load();
+}
+
 int mlpl_ransac_last_stats(mlpl_ctx *ctx, long long stats[2]) {
     if (!ctx || !stats) return MLPL_E_BAD_INPUT;
     stats[0] = ctx->last_ransac_iters;
