@@ -85,7 +85,7 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  *     "hub_blocking_sync" (default 1: a cohort's thread sleeps at the end of a round instead of spinning), "pair_batch" /
  *     "pair_batch_seq" (image pairs per internal batch of mlpl_pair_pose_batch_dev, 0 = 256 / of its USAC and ARRSAC forms, 0 = 512).
  *     Hamming: "hamming_fused_merge" (default 1) = the LDS-ring kernel folds its train splits, evaluates the ratio predicate and counts
- *     itself, 0 = separate merge launch; RANSAC: "ransac_count_mpl" 1|2 models per lane of the counting kernel (A/B, default 1).
+ *     itself, 0 = separate merge launch; RANSAC: "ransac_count_mpl" 1|2 models per lane of the counting kernel (A/B, default 2).
  *   "solver_polish" (default 1) = every 5-point solution is polished by Gauss-Newton on the ten cubic constraints; 0 = the plain
  *     elimination + root path, which -- like the CPU code -- is off by up to 1e-5 on the ~0.5 % of samples whose eliminated block is ill
  *     conditioned.  This is the one option that changes results (towards the exact solution). */

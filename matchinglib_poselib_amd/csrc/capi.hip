@@ -138,7 +138,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_ransac_lazy_sums = 1;
     ctx->opt_ransac_overlap = 1;
     ctx->opt_ransac_f32_filter = 1;
-    ctx->opt_ransac_count_mpl = 1;
+    ctx->opt_ransac_count_mpl = 2;
     ctx->opt_solver_polish = 1;
     ctx->opt_solver_wave3 = 1;
     ctx->opt_ransac_device_draw = 1;

@@ -1395,13 +1395,14 @@ __global__ __launch_bounds__(kThreads) void score_models_kernel(const double4 *_
 // makes N32 + p32 infinite: H = +inf or NaN and the comparison fails -> fp64 path.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// MPL = models per lane (option ransac_count_mpl, default 1).  Round 4 measured the kernel's hot loop in the ISA: per pair of evaluations
-// 21 packed + 8 scalar-lane vector instructions (116 issue cycles per wave on a SIMD), i.e. the C3 counting pass is at ~0.67 of the VECTOR
-// ISSUE rate with 39 algorithmic FLOP per evaluation priced at 0.41 of the fp32 FLOP peak -- the gap between the two figures is instructions
-// that are not multiply-adds (comparisons, counts, the band), not waiting.  MPL = 2 (a lane applies every pair of correspondences it reads
-// from LDS to two models: half the LDS traffic per evaluation) needs 138 instead of 92 VGPRs, drops from four to two waves per SIMD and is
-// SLOWER: 0.34 against 0.27 ms at C3, 4.4 against 3.1 ms in the C5 step (tools/count_mpl_ab.py; same counts).  Kept as an instantiation for
-// the A/B, not used.
+// MPL = models per lane (option ransac_count_mpl, default 2 for the large passes).  Round 4 measured the kernel's hot loop in the ISA: per pair
+// of evaluations 21 packed + 8 scalar-lane vector instructions (116 issue cycles per wave on a SIMD), i.e. the C3 counting pass is at ~0.67
+// of the VECTOR ISSUE rate with 39 algorithmic FLOP per evaluation priced at 0.41 of the fp32 FLOP peak -- the gap between the two figures
+// is instructions that are not multiply-adds (comparisons, counts, the band), not waiting.  MPL = 2 (a lane applies every pair of
+// correspondences it reads from LDS to two models: half the LDS traffic per evaluation) first needed 138 VGPRs, halved the waves per SIMD
+// and was slower (0.34 against 0.27 ms at C3); with the fp64 copy of the model no longer held across the loop (the rare undecided
+// evaluation reads it again) it needs 126, keeps four waves per SIMD and is 1-4 % faster (C3 0.283 against 0.285-0.309 ms, C5 counting
+// 3.22-3.27 against 3.36 ms per 512 pairs; tools/count_mpl_ab.py, same counts) -- the LDS reads were not what the loop waits for.
 template <int kThreads, int kTile, int MPL = 1>
 __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
                                                                     const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
@@ -1426,26 +1427,33 @@ __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double
     const int m0 = blockIdx.x * kPerBlock + (tid >> 2) * MPL;
     const double u = 0x1p-24;
     bool live[MPL];
-    double e[MPL][9], km[MPL];
     f32x2 E[MPL][9], KM[MPL];
     int cnt[MPL];
 #pragma unroll
     for (int mi = 0; mi < MPL; ++mi) {
         live[mi] = m0 + mi < total;
+        double e[9];  // (not kept: the fp64 predicate of the rare undecided evaluation reads the model again -- eighteen registers per model)
 #pragma unroll
-        for (int k = 0; k < 9; ++k) e[mi][k] = live[mi] ? E_list[(size_t)(m0 + mi) * 9 + k] : 0.0;
-        km[mi] = model_band(e[mi], qmax);
+        for (int k = 0; k < 9; ++k) e[k] = live[mi] ? E_list[(size_t)(m0 + mi) * 9 + k] : 0.0;
+        const double km = model_band(e, qmax);
         double emax = 0;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) emax = fmax(emax, fabs(e[mi][k]));
-        const double kms64 = 1.01 * fmax(fmax(65.0 * (8.01 * u * emax) * (8.01 * u * emax), 10.2 * u * qmax * emax * emax), km[mi]);
-        const bool in_range = emax >= 0x1p-40 && emax <= 0x1p20 && qmax >= 0x1p-60 && qmax <= 1.0 && km[mi] == km[mi];
+        for (int k = 0; k < 9; ++k) emax = fmax(emax, fabs(e[k]));
+        const double kms64 = 1.01 * fmax(fmax(65.0 * (8.01 * u * emax) * (8.01 * u * emax), 10.2 * u * qmax * emax * emax), km);
+        const bool in_range = emax >= 0x1p-40 && emax <= 0x1p20 && qmax >= 0x1p-60 && qmax <= 1.0 && km == km;
         const float kms = in_range ? (float)kms64 * (1.0f + 0x1p-22f) : INFINITY;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) E[mi][k] = f32x2{(float)e[mi][k], (float)e[mi][k]};
+        for (int k = 0; k < 9; ++k) E[mi][k] = f32x2{(float)e[k], (float)e[k]};
         KM[mi] = f32x2{kms, kms};
         cnt[mi] = 0;
     }
+    auto exact = [&](int mi, int i) {  // sampson_inlier_fma on correspondence i for model mi
+        double e[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) e[k] = E_list[(size_t)(m0 + mi) * 9 + k];
+        const double4 p = pts[i];
+        return sampson_inlier_fma(e, model_band(e, qmax), p.x, p.y, p.z, p.w, kp64[i], qmax, thresh2) ? 1 : 0;
+    };
     const f32x2 Q = {(float)qmax, (float)qmax}, C6 = {0x1p-6f * 1.02f, 0x1p-6f * 1.02f};
     // (Measured and not kept, round 4: fetching the NEXT tile into registers while the current one is evaluated -- no change: with two
     // workgroups per CU the other workgroup's evaluation already covers a tile's load latency.)
@@ -1492,22 +1500,16 @@ __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double
                     cnt[mi] += in1 ? 1 : 0;
                     if (__builtin_expect(!(c0 && c1), 0)) {  // inside the band (or out of range): the fp64 predicate decides
                         const int i0 = base + 4 * (2 * q) + j, i1 = i0 + 4;
-                        if (!c0) {
-                            const double4 p = pts[i0];
-                            cnt[mi] += sampson_inlier_fma(e[mi], km[mi], p.x, p.y, p.z, p.w, kp64[i0], qmax, thresh2) ? 1 : 0;
-                        }
-                        if (!c1) {
-                            const double4 p = pts[i1];
-                            cnt[mi] += sampson_inlier_fma(e[mi], km[mi], p.x, p.y, p.z, p.w, kp64[i1], qmax, thresh2) ? 1 : 0;
-                        }
+                        if (!c0) cnt[mi] += exact(mi, i0);
+                        if (!c1) cnt[mi] += exact(mi, i1);
                     }
                 }
             }
             if (nk & 1) {  // the unpaired last correspondence of the class: fp64
                 const int i0 = base + 4 * (nk - 1) + j;
-                const double4 p = pts[i0];
 #pragma unroll
-                for (int mi = 0; mi < MPL; ++mi) cnt[mi] += sampson_inlier_fma(e[mi], km[mi], p.x, p.y, p.z, p.w, kp64[i0], qmax, thresh2) ? 1 : 0;
+                for (int mi = 0; mi < MPL; ++mi)
+                    if (live[mi]) cnt[mi] += exact(mi, i0);
             }
         }
     }
