@@ -1465,6 +1465,10 @@ int arrsac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const d
     auto serve_lane = [&](int l) {
         LaneOut &LO = lane_out[l];
         const hipStream_t ls = lane_stream[l];
+        if (l > 0 && hipSetDevice(ctx->device) != hipSuccess) {  // a lane's own thread starts on device 0
+            LO.first_err = MLPL_E_INTERNAL, LO.first_msg = "batched estimator: hipSetDevice failed on a lane thread";
+            return;
+        }
         for (int c = l; c < n_cohorts; c += lanes) {
             const int b0 = c * cohort, nb = std::min(cohort, B - b0);
             BatchHub hub(ctx, ls, nb, l);
