@@ -1804,7 +1804,16 @@ struct UsacRun {
 
     void store_solution(unsigned mi, unsigned num_inl, const uint64_t *bits, const double *E) {
         best = num_inl;
-        for (unsigned j = 0; j < n; ++j) flags[pool[j]] = (uint8_t)((bits[j >> 6] >> (j & 63)) & 1);
+        std::memset(flags.data(), 0, n);  // the set bits only: half the scattered stores of a loop over all positions
+        for (int w = 0; w < words; ++w) {
+            uint64_t m = bits[w];
+            if (w == words - 1 && (n & 63)) m &= (1ull << (n & 63)) - 1ull;
+            while (m) {
+                const unsigned j = (unsigned)w * 64u + (unsigned)__builtin_ctzll(m);
+                m &= m - 1;
+                flags[pool[j]] = 1;
+            }
+        }
         best_bits.assign(bits, bits + words);
         std::memcpy(final_model, E, 72);
         double v[3] = {(double)hyp_count, (double)mi, (double)num_inl};
