@@ -468,3 +468,18 @@ def smoke_check(ctx, oracle) -> None:
     go, Ro, to, Qo, mo = oracle.recover_pose(o["E"], p1, p2, 50.0, o["mask"])
     assert n_good == go and np.abs(Rg - Ro).max() < 1e-6 and np.abs(tg.ravel() - to).max() < 1e-6
     print(f"smoke: RANSAC 5pt {g['iters']} iters -> {g['n_inliers']} inliers, pose within 1e-6 of the oracle")
+    # the sequential estimators as a batch (launch hub: fibers, merged launches, cohorts in flight): four USAC problems in one call, each
+    # against the oracle's run of it
+    import torch
+
+    seeds = [5, 6, 7, 8]
+    d1 = torch.from_numpy(np.repeat(p1[None], 4, 0).copy()).cuda()
+    d2 = torch.from_numpy(np.repeat(p2[None], 4, 0).copy()).cuda()
+    got = usac_essential_batch(d1, d2, [len(p1)] * 4, th, seeds, ctx=ctx)
+    for b, sd in enumerate(seeds):
+        ou = oracle.usac_essential(p1, p2, th, sd)
+        # (hypotheses, inliers, local optimisations; the model COUNT may differ by the solutions of a sample with a double root)
+        assert got[b]["ok"] and np.array_equal(got[b]["final"][[0, 1, 5, 7]], ou["final"][[0, 1, 5, 7]]), "batched USAC differs from the oracle"
+        du = min(np.abs(got[b]["E"] - ou["E"]).max(), np.abs(got[b]["E"] + ou["E"]).max())
+        assert du < 1e-8, f"batched USAC: essential matrix differs from the oracle by {du}"
+    print(f"smoke: USAC x 4 in one batched call -> {int(got[0]['final'][5])} inliers each; hypotheses, inliers, local optimisations and E equal to the oracle's")
