@@ -181,7 +181,7 @@ class HubThreads {
             makecontext(&f.uc, reinterpret_cast<void (*)()>(&HubThreads::entry), 2, (unsigned)(p >> 32), (unsigned)(p & 0xffffffffu));
         }
         for (;;) {
-            bool progressed = false, live = false;
+            bool progressed = false, live = false, one_word = true;
             const Fiber *sleeper = nullptr;
             for (int k = w; k < n; k += W) {
                 Fiber &f = *fibers_[(size_t)k];
@@ -189,6 +189,7 @@ class HubThreads {
                 live = true;
                 if (f.state == Fiber::kWaiting && f.word->load(std::memory_order_acquire) == f.value) {
                     if (!sleeper) sleeper = &f;
+                    else if (sleeper->word != f.word) one_word = false;
                     continue;
                 }
                 f.state = Fiber::kRunning;
@@ -198,7 +199,14 @@ class HubThreads {
                 progressed = true;
             }
             if (!live) return;
-            if (!progressed && sleeper) futex_wait_u32(sleeper->word, sleeper->value);  // (returns at once if the word has moved on)
+            if (!progressed && sleeper) {  // every live fiber waits (returns at once if the word has moved on)
+                if (one_word)
+                    futex_wait_u32(sleeper->word, sleeper->value);
+                else {  // (fibers of one pool waiting on different words -- not what the hub does: poll them all)
+                    const timespec ts{0, 50000};
+                    syscall(SYS_futex, reinterpret_cast<const uint32_t *>(sleeper->word), FUTEX_WAIT_PRIVATE, sleeper->value, &ts, nullptr, 0);
+                }
+            }
         }
     }
     void loop(int w) {
