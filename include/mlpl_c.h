@@ -483,6 +483,10 @@ int mlpl_debug_ransac_draw(mlpl_ctx *ctx, long long out[2]);
  * and no context needed: n fibers on `workers` threads pass `rounds` times through the hand-over against a stand-in hub on the calling
  * thread.  Returns n * rounds, or a negative value on bad arguments / a fiber that was not released exactly once per round. */
 long long mlpl_debug_fiber_selftest(int n, int workers, int rounds);
+/* The two eigen-solvers of the re-weighted 9 x 9 fits on `count` symmetric matrices G[count][81] (tests): out12[count][12] = {steps of the
+ * inverse iteration (0: it did not settle and the caller would take the Jacobi path), x^T G x, 0, x[9]}; jacobi10[count][10] = {smallest
+ * eigenvalue, its eigenvector} of the full Jacobi decomposition; start[count][9] (may be NULL) = start vectors of the inverse iteration. */
+int mlpl_debug_eig9(mlpl_ctx *ctx, const double *G, const double *start, int count, double *out12, double *jacobi10);
 
 /* Diagnostics: root-iteration (Ehrlich-Aberth) sweep statistics of the solver since the last call: {sum, solves, max, (enabled), sample
  * index of the max, solves with <= 8, 12, 16, 24, 32, 64, 128, 256, < 400, = 400 sweeps, 0}; enable != 0 turns the (atomic) bookkeeping on.

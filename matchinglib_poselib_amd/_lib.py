@@ -115,6 +115,7 @@ _SIGNATURES = {
     "mlpl_ransac_last_stats": (c_int, [c_void_p, c_void_p]),
     "mlpl_debug_ransac_draw": (c_int, [c_void_p, c_void_p]),
     "mlpl_debug_fiber_selftest": (C.c_longlong, [c_int, c_int, c_int]),
+    "mlpl_debug_eig9": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "mlpl_debug_dk_stats": (c_int, [c_void_p, c_int, c_void_p]),
     "mlpl_debug_hamming_stamps": (c_int, [c_void_p, c_void_p, c_int]),
     "mlpl_pair_pose_dev": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double,

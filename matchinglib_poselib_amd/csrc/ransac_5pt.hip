@@ -2189,6 +2189,40 @@ __device__ __forceinline__ int smallest_eigvec9_wave(const double *Gp, double di
     return it;
 }
 
+// tests: smallest_eigvec9_wave and jacobi9_wave on a batch of symmetric 9 x 9 matrices, one wave per matrix.  G: [count][81] row-major;
+// start: [count][9] or null; out: [count][12] = {steps (0 = not settled), lambda, 0, x[9]}; jac: [count][10] = {smallest eigenvalue, its vector}
+__global__ __launch_bounds__(64) void eig9_debug_kernel(const double *__restrict__ G, const double *__restrict__ start, int count, double *__restrict__ out,
+                                                        double *__restrict__ jac) {
+    __shared__ double gp[45], x[9], lam, st[9];
+    __shared__ Jacobi9Lds J;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= count) return;
+    if (lane < 45) {
+        int a = 0, rem = lane;
+        while (rem >= 9 - a) rem -= 9 - a, ++a;
+        gp[lane] = G[(size_t)b * 81 + a * 9 + (a + rem)];
+    }
+    if (lane < 9 && start) st[lane] = start[(size_t)b * 9 + lane];
+    for (int e = lane; e < 81; e += 64) {
+        J.G[e / 9][e % 9] = G[(size_t)b * 81 + e];
+        J.Vv[e / 9][e % 9] = (e / 9 == e % 9) ? 1.0 : 0.0;
+    }
+    if (lane == 0) lam = 0;
+    wave_sync();
+    const int steps = smallest_eigvec9_wave(gp, 1.0, start ? st : nullptr, x, &lam, lane);
+    wave_sync();
+    if (lane == 0) out[(size_t)b * 12] = steps, out[(size_t)b * 12 + 1] = lam, out[(size_t)b * 12 + 2] = 0;
+    if (lane < 9) out[(size_t)b * 12 + 3 + lane] = steps > 0 ? x[lane] : 0.0;
+    jacobi9_wave(J, lane);
+    if (lane == 0) {
+        int m = 0;
+        for (int a = 1; a < 9; ++a)
+            if (J.G[a][a] < J.G[m][m]) m = a;
+        jac[(size_t)b * 10] = J.G[m][m];
+        for (int k = 0; k < 9; ++k) jac[(size_t)b * 10 + 1 + k] = J.Vv[k][m];
+    }
+}
+
 // Indices of the nine eigenvalues in descending order, the first of equal values first (what a selection sort from the top gives).  The
 // diagonal is read once (nine loads in flight) and every index gets its position by counting in registers; as a selection sort over LDS
 // the 36 comparisons were 72 dependent round trips (~4 us on one lane).
@@ -3125,6 +3159,29 @@ int mlpl_debug_ransac_draw(mlpl_ctx *ctx, long long out[2]) {
     if (!ctx || !out) return MLPL_E_BAD_INPUT;
     out[0] = ctx->ransac_draw_fallbacks;
     out[1] = ctx->last_ransac_dev_draw;
+    return MLPL_OK;
+}
+
+int mlpl_debug_eig9(mlpl_ctx *ctx, const double *G, const double *start, int count, double *out12, double *jacobi10) {
+    if (!ctx || !G || !out12 || !jacobi10 || count < 1 || count > (1 << 20)) {
+        set_error("mlpl_debug_eig9: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    void *dG, *dS, *dO, *dJ;
+    int rc;
+    if ((rc = ws_get(ctx, WS_AUX0, (size_t)count * 81 * 8, &dG))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX1, (size_t)count * 9 * 8, &dS))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX5, (size_t)count * 12 * 8, &dO))) return rc;
+    if ((rc = ws_get(ctx, WS_AUX6, (size_t)count * 10 * 8, &dJ))) return rc;
+    MLPL_HIP_TRY(hipMemcpyAsync(dG, G, (size_t)count * 81 * 8, hipMemcpyHostToDevice, s));
+    if (start) MLPL_HIP_TRY(hipMemcpyAsync(dS, start, (size_t)count * 9 * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(eig9_debug_kernel, dim3(count), dim3(64), 0, s, (const double *)dG, start ? (const double *)dS : nullptr, count, (double *)dO, (double *)dJ);
+    MLPL_HIP_TRY(hipGetLastError());
+    MLPL_HIP_TRY(hipMemcpyAsync(out12, dO, (size_t)count * 12 * 8, hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipMemcpyAsync(jacobi10, dJ, (size_t)count * 10 * 8, hipMemcpyDeviceToHost, s));
+    MLPL_HIP_TRY(hipStreamSynchronize(s));
     return MLPL_OK;
 }
 
