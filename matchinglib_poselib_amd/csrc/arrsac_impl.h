@@ -213,6 +213,7 @@ struct ArrSampleArgs {
     PolyRec * recs;
     double * direct_E;
     int32_t * direct_ok;
+    int inverse_iteration;  // option eig_inverse_iteration
 };
 __device__ __forceinline__ void arrsac_sample_body(const ArrSampleArgs &A, const int vbx, const int vby) {
     const double *__restrict__ p1 = A.p1;
@@ -227,6 +228,7 @@ __device__ __forceinline__ void arrsac_sample_body(const ArrSampleArgs &A, const
     __shared__ Jacobi9Lds J;
     __shared__ double xn[kArrMaxSample][4];
     __shared__ double nrm[6];
+    __shared__ double s_gp[45], s_xv[9], s_xlam;  // smallest_eigvec9_wave (8-point fits)
     __shared__ int s_ok;
     if (blockDim.x != kSolverThreads) __builtin_trap();
     const int lane = threadIdx.x, b = vbx;
@@ -286,7 +288,22 @@ __device__ __forceinline__ void arrsac_sample_body(const ArrSampleArgs &A, const
         J.Vv[a][c] = (a == c) ? 1.0 : 0.0;
     }
     wave_sync();
-    jacobi9_wave(J, lane);
+    // The 8-point fit needs ONE eigenvector (the smallest eigenvalue's): inverse iteration first (smallest_eigvec9_wave, ransac_5pt.hip:
+    // ~3 us where the Jacobi decomposition of these fourteen-point systems takes ~50); a system it does not settle on -- among them every
+    // one whose second-smallest eigenvalue is below DBL_EPSILON, the reference's rank test: convergence needs that eigenvalue well above
+    // the shift 2^-44 trace -- takes the Jacobi path with the test as before.
+    int steps = 0;
+    if (kind == 1 && A.inverse_iteration) {
+        if (lane < 45) {
+            int a = 0, rem = lane;
+            while (rem >= 9 - a) rem -= 9 - a, ++a;
+            s_gp[lane] = J.G[a][a + rem];
+        }
+        wave_sync();
+        steps = smallest_eigvec9_wave(s_gp, 1.0, nullptr, s_xv, &s_xlam, lane);  // wave-uniform
+        wave_sync();
+    }
+    if (steps == 0) jacobi9_wave(J, lane);
     if (kind == 0) {
         if (lane == 0) {
             int order[9];
@@ -299,11 +316,11 @@ __device__ __forceinline__ void arrsac_sample_body(const ArrSampleArgs &A, const
         return;
     }
     if (lane == 0) {
-        int order[9];
-        order_desc9(J, order);
-        if (!(fabs(J.G[order[7]][order[7]]) < DBL_EPSILON)) {
+        int order[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (steps == 0) order_desc9(J, order);
+        if (steps > 0 || !(fabs(J.G[order[7]][order[7]]) < DBL_EPSILON)) {
             double F0[9], sv[3], U[9], V[9];
-            for (int k = 0; k < 9; ++k) F0[k] = J.Vv[k][order[8]];
+            for (int k = 0; k < 9; ++k) F0[k] = steps > 0 ? s_xv[k] : J.Vv[k][order[8]];
             svd3_eigen(F0, sv, U, V);
             for (int r = 0; r < 3; ++r)
                 for (int c = 0; c < 3; ++c) F0[r * 3 + c] = U[r * 3] * sv[0] * V[c * 3] + U[r * 3 + 1] * sv[1] * V[c * 3 + 1];
@@ -903,7 +920,7 @@ struct ArrsacRun {
         unsigned long long *o_head = (unsigned long long *)(o_base + off_head);
         double *o_E = d_Epool + (size_t)pool_samples * 90;
         unsigned long long *o_rows = d_Fpool + (size_t)pool_samples * 10 * kArrFlagWords;
-        ArrSampleArgs sa{{B, 1}, d_p1, d_p2, (const int32_t *)d_smp, B, d_recs, d_direct, d_direct_ok};
+        ArrSampleArgs sa{{B, 1}, d_p1, d_p2, (const int32_t *)d_smp, B, d_recs, d_direct, d_direct_ok, ctx->opt_eig_inverse_iteration};
         L.launch(HK_ARR_SAMPLE, sa);
         RootsArgs ra{{(B + kHypPerWave - 1) / kHypPerWave, 1}, (const PolyRec *)d_recs, B, o_E, d_nm5};
         L.launch(ctx->opt_solver_polish ? HK_ROOTS_POLISH : HK_ROOTS_PLAIN, ra);
