@@ -598,6 +598,15 @@ def main():
             cfg["c5_dominant_kernel_frac"] = c5["roofline"]["frac"]
             if c5.get("cpu_baseline"):
                 cfg["c5_cpu_image_pairs_per_s_1_core"] = c5["cpu_baseline"]["value"]
+        ex = rec.get("extras", {})
+        for name, key in (("c5_usac_batch_uniform", "c5_usac_uniform_ms_per_512_pairs"), ("c5_usac_batch_prosac", "c5_usac_prosac_ms_per_512_pairs"),
+                          ("c5_usac_batch_default_refinement_prosac", "c5_usac_default_refinement_ms_per_512_pairs")):
+            if isinstance(ex.get(name), dict) and "ms_per_step" in ex[name]:
+                cfg[key] = ex[name]["ms_per_step"]
+        for name, key in (("usac_uniform", "usac_call_ms"), ("arrsac_default_method", "arrsac_call_ms"), ("hamming_c2_single_pair", "hamming_single_pair_ms"),
+                          ("hamming_c2_8pairs_mfma_kernel", "hamming_8_pairs_ms")):
+            if isinstance(ex.get(name), dict) and "ms_per_call" in ex[name]:
+                cfg[key] = ex[name]["ms_per_call"]
         for k, v in (rec["roofline"].get("from_profiles") or {}).items():   # the same figures as scalars of `roofline`
             rec["roofline"]["from_profiles_" + k] = v
         print(json.dumps(rec), flush=True)
