@@ -98,15 +98,42 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
     state = {}
     use_rccl = args.backend == "nccl" or world == 1
 
-    lanes = batch.BatchLanes(local_rank, lanes=2, first_ctx=ctx)   # two batched calls in flight, half of the rank's share each
+    # The robust estimator of the pipeline: "ransac" = estimateEssentialMat(..., "RANSAC") at (1000, 0.999), mlpl_pair_pose_batch_dev;
+    # "usac" / "usac_prosac" = the harness' cfgUSAC (POSE_STEWENIUS + REF_WEIGHTS + SPRT + LO; T/poselib-test/main.cpp:734, 1135-1162), uniform /
+    # PROSAC sampling; "usac_default_refine" = ConfigUSAC's own default refinement REF_STEWENIUS_WEIGHTS (pose_estim.h:99-100), PROSAC;
+    # "arrsac" = estimateEssentialMat's default method (pose_estim.h:207) + robustEssentialRefine.  The sequential estimators run as
+    # fibers on a few host threads per rank behind one launch hub (csrc/batch_hub.h): the rank's host-thread budget is its share of the
+    # CPUs this process may run on.
+    est = getattr(args, "estimator", "ransac")
+    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    hub_workers = max(2, min(16, cpus // max(1, local_world) - 2))   # two threads of the share stay with the lane / Python threads
+    host_threads = {"cpus_visible": cpus, "local_world_size": local_world, "hub_workers_per_cohort": hub_workers if est != "ransac" else 0,
+                    "hub_lanes": 4 if est != "ransac" else 0, "batch_lanes": 2 if est == "ransac" else 0}
+    if est != "ransac":
+        ctx.set_option("hub_workers", hub_workers)
+    usac_kw = {"usac": dict(prosac=False, refine=0), "usac_prosac": dict(prosac=True, refine=0), "usac_default_refine": dict(prosac=True, refine=5)}.get(est)
+
+    lanes = batch.BatchLanes(local_rank, lanes=2, first_ctx=ctx) if est == "ransac" else None   # two batched calls in flight, half of the rank's share each
+
+    def one_call():
+        a = (stacked["desc1"], stacked["desc2"], stacked["kp1"], stacked["kp2"], K, K)
+        if est == "ransac":
+            return batch.process_pairs_batched(ctx, *a, seeds, pair_ids=ids, matches_out=d_matches[:mine])
+        if est == "arrsac":
+            r, raw = batch.process_pairs_batched_arrsac(ctx, *a, matches_out=d_matches[:mine])
+            r["pair_id"] = ids
+        else:
+            r, raw = batch.process_pairs_batched_usac(ctx, *a, seeds, pair_ids=ids, matches_out=d_matches[:mine], **usac_kw)
+        state["raw"] = raw
+        return r
 
     def step(mode):
         if mode == "two_calls_in_flight":
             recs = lanes.process(stacked["desc1"], stacked["desc2"], stacked["kp1"], stacked["kp2"], K, K, seeds, pair_ids=ids,
                                  matches_out=d_matches[:mine])
         else:
-            recs = batch.process_pairs_batched(ctx, stacked["desc1"], stacked["desc2"], stacked["kp1"], stacked["kp2"], K, K, seeds, pair_ids=ids,
-                                               matches_out=d_matches[:mine])
+            recs = one_call()
         state["rec"] = batch.gather_records(recs, total, rank, world, device=dev if use_rccl else None)
         state["matches"] = batch.gather_match_lists(d_matches if use_rccl else d_matches.cpu(), total, rank, world, root=0)
 
@@ -120,7 +147,7 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
     # both stay in the line so that a slow first step or a slow lane is visible in the record itself).
     lib = ctx.lib
     timed = {}
-    for mode in ("two_calls_in_flight", "one_call_at_a_time"):
+    for mode in (("two_calls_in_flight", "one_call_at_a_time") if est == "ransac" else ("one_call_at_a_time",)):
         for _ in range(max(warmup, 2)):
             step(mode)
         barrier()
@@ -140,7 +167,7 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
             el = float(tt.item())
         timed[mode] = (el, per_step)
     best_mode = min(timed, key=lambda m: timed[m][0])   # the same on every rank: the elapsed times are the maxima over the ranks
-    other_mode = [m for m in timed if m != best_mode][0]
+    other_mode = ([m for m in timed if m != best_mode] or [None])[0]
     elapsed = timed[best_mode][0]
     # Kernel durations: with two calls in flight the HIP events around a kernel also bracket what runs beside it, so the per-kernel
     # figures come from `prof_steps` further steps through ONE call at a time (not part of `elapsed`), every launch bracketed.
@@ -148,14 +175,14 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
     _lib.check(lib.mlpl_profile_reset(ctx.handle), "profile_reset")
     _lib.check(lib.mlpl_profile_enable(ctx.handle, 1 if prof_steps else 0), "profile_enable")
     for _ in range(prof_steps):
-        batch.process_pairs_batched(ctx, stacked["desc1"], stacked["desc2"], stacked["kp1"], stacked["kp2"], K, K, seeds, pair_ids=ids,
-                                    matches_out=d_matches[:mine])
+        one_call()
     torch.cuda.synchronize()
     _lib.check(lib.mlpl_profile_enable(ctx.handle, 0), "profile_enable")
     allrec = state["rec"]
     assert len(allrec) == total and (allrec["status"] == 0).all(), "a pair failed"
     if rank != 0:
-        lanes.close()
+        if lanes:
+            lanes.close()
         return None
     # the gathered match lists are the lists the poses were computed from
     m = state["matches"]
@@ -167,7 +194,14 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
         np.savez(args.dump_records, records=allrec.view(np.uint8), mode=np.array([0]),
                  matches=np.concatenate([mh[i, : int(allrec["n_matches"][i])] for i in range(total)]))
     stats = np.zeros(8, np.int64)
-    lib.mlpl_pair_batch_last_stats(ctx.handle, stats.ctypes.data)   # of the last single-call step: the rank's whole share
+    hub = None
+    if est == "ransac":
+        lib.mlpl_pair_batch_last_stats(ctx.handle, stats.ctypes.data)   # of the last single-call step: the rank's whole share
+    elif est != "arrsac":
+        hs = np.zeros(8, np.int64)
+        lib.mlpl_usac_last_stats(ctx.handle, hs.ctypes.data)
+        hub = {"rounds": int(hs[0]), "merged_launches": int(hs[1]), "hub_waiting_for_host_ms": hs[2] / 1e3, "device_ms": hs[3] / 1e3}
+        stats[6] = int(state["raw"]["iters"].sum())   # hypotheses of the rank's share
     prof = {}
     for name, kid in (("knn_hamming_mfma_lds_kernel<4, 0>", 0), ("solve5pt3_kernel + roots_kernel_t<true>", 2),
                       ("count_models_f32_kernel<512, 512>", 3), ("decompose / triangulate / select (batch)", 4)):
@@ -182,18 +216,26 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
     out = {
         "metric": "image-pairs/s (C5: stereo pairs x (8k ORB BF-Hamming match + 5-pt RANSAC + cheirality))",
         "value": total * steps / elapsed, "unit": "image-pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-        "ms_per_step": elapsed / steps * 1e3, "mode": best_mode, "ms_per_step_" + other_mode: timed[other_mode][0] / steps * 1e3,
+        "ms_per_step": elapsed / steps * 1e3, "mode": best_mode,
+        **({"ms_per_step_" + other_mode: timed[other_mode][0] / steps * 1e3} if other_mode else {}),
         "ms_steps_rank0": {m: [round(x, 3) for x in timed[m][1]] for m in timed},
         "lane_spans_ms_rank0": state.get("lane_spans"),
         "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None,
         "dtype": "fp4 MFMA (Hamming, exact) + f64 / packed f32 inside a rigorous band (solver, Sampson, cheirality)", "data": "synthetic",
         "config": {"workload": f"C5: {total} stereo pairs x ({args.n} ORB-256 keypoints per image: Hamming 2-NN + 0.75 ratio -> "
-                               "ImgToCamCoordTrans gather -> RANSAC 1000 it / 0.999 -> getPoseTriangPts), one step = the whole batch",
+                               "ImgToCamCoordTrans gather -> " + {"ransac": "RANSAC 1000 it / 0.999", "usac": "USAC (cfgUSAC, uniform sampling)",
+                                                                  "usac_prosac": "USAC (cfgUSAC, PROSAC by matching cost)",
+                                                                  "usac_default_refine": "USAC (REF_STEWENIUS_WEIGHTS, PROSAC)",
+                                                                  "arrsac": "ARRSAC + robustEssentialRefine"}[est] + " -> getPoseTriangPts), one step = the whole batch",
+                   "estimator": est, "host_threads": host_threads, "hub_last_internal_call": hub,
                    "pairs_total": total, "pairs_this_rank": mine, "distinct_inputs_per_rank": distinct,
-                   "entry": "mlpl_pair_pose_batch_dev (pair = grid dimension; internal batches of 256 pairs); timed both with two calls in flight "
-                            "per rank (batch.BatchLanes: two library contexts, half of the rank's share each) and one call at a time -- "
-                            "`mode` names the faster one, which `value` is", "parallelism": f"shard{world}",
+                   "entry": ("mlpl_pair_pose_batch_dev (pair = grid dimension; internal batches of 256 pairs); timed both with two calls in flight "
+                             "per rank (batch.BatchLanes: two library contexts, half of the rank's share each) and one call at a time -- "
+                             "`mode` names the faster one, which `value` is") if est == "ransac" else
+                            ("mlpl_pair_pose_batch_arrsac_dev" if est == "arrsac" else "mlpl_pair_pose_batch_usac_dev") +
+                            " (every pair's sequential estimator = a fiber behind the launch hub, launches merged over the pairs; one call per step)",
+                   "parallelism": f"shard{world}",
                    "world_size": world, "backend": args.backend if world > 1 else None,
                    "gathered_per_step": "184-byte records by all_gather + the padded match lists to rank 0 by grouped send / recv",
                    "mean_matches": float(allrec["n_matches"].mean()), "mean_inliers": float(allrec["n_inliers"].mean()),
@@ -237,17 +279,33 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
                                       ((p[:, 1].astype(np.float64) - K[3]) / K[1]).astype(np.float32)], axis=1).astype(np.float64)
             p1, p2 = cam(a), cam(b)
             th = 0.8 * 4.0 / (np.sqrt(2.0) * (2 * K[0] + 2 * K[1]))
-            o = ora.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, lesqu=False, seed=seeds[i])
-            good, R, t, Q, mk = ora.recover_pose(o["E"], p1, p2, 50.0, o["mask"])
+            if est == "ransac":
+                o = ora.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, lesqu=False, seed=seeds[i])
+                good, R, t, Q, mk = ora.recover_pose(o["E"], p1, p2, 50.0, o["mask"])
+                ninl = o["n_inliers"]
+            elif est == "arrsac":
+                o = ora.arrsac_essential(p1, p2, th, refine=True)
+                good, R, t, Q, mk = ora.recover_pose(o["E"], p1, p2, 50.0, o["mask"])
+                ninl = o["n_inliers"]
+            else:
+                order = None
+                if usac_kw["prosac"]:   # poselib::getSortedMatchIdx: std::sort by the matching cost (the library's own host helper: a sort, no GPU)
+                    order = np.zeros(len(mm), np.uint32)
+                    mmc = np.ascontiguousarray(mm)
+                    assert lib.mlpl_sorted_match_idx(mmc.ctypes.data, len(mm), order.ctypes.data) == 0
+                o = ora.usac_essential(p1, p2, th, seeds[i], refine=usac_kw["refine"], sorted_idx=order, prosac_beta=0.05, sprt_ms=6.0, sprt_tm=2736.0)
+                good, R, t, Q, mk = ora.recover_pose(o["E"], p1, p2, 50.0, o["flags"])
+                ninl = int(o["final"][5])
             if i < mine:   # the timed records are the CPU path's records
-                assert len(mm) == allrec["n_matches"][i] and o["n_inliers"] == allrec["n_inliers"][i], "pair record differs from the CPU path"
-                assert np.abs(allrec["R"][i].reshape(3, 3) - R).max() < 1e-6 and np.abs(allrec["t"][i] - t).max() < 1e-6
+                assert len(mm) == allrec["n_matches"][i] and ninl == allrec["n_inliers"][i], "pair record differs from the CPU path"
+                assert np.abs(allrec["R"][i].reshape(3, 3) - np.asarray(R).reshape(3, 3)).max() < 1e-6 and np.abs(allrec["t"][i] - np.asarray(t).ravel()).max() < 1e-6
         tc = time.perf_counter() - tc
         out["cpu_baseline"] = {"value": ncpu / tc, "unit": "image-pairs/s", "cores": 1, "kind": "port",
-                               "sample": f"the first {ncpu} pairs of the batch through the oracle pipeline (LINEAR matching, RANSAC 1000 / 0.999, "
+                               "sample": f"the first {ncpu} pairs of the batch through the oracle pipeline (LINEAR matching, {est} oracle, "
                                          f"recoverPose), {tc:.1f} s; their records equal the timed step's (counts exact, R, t to 1e-6)",
                                "host_cores_available": os.cpu_count()}
-    lanes.close()
+    if lanes:
+        lanes.close()
     return out
 
 
@@ -283,6 +341,13 @@ def main():
     ap.add_argument("--c5-distinct", type=int, default=8, help="distinct synthetic inputs generated per rank (cycled over its shard)")
     ap.add_argument("--c5-steps", type=int, default=3, help="timed C5 batches of the extras block of the default (C2) line")
     ap.add_argument("--dump-records", default=None, help="c5 workload, rank 0: write the gathered records and match lists of the last step to this .npz (tests)")
+    ap.add_argument("--steady-steps", type=int, default=200,
+                    help="steps of the steady_state measurement that follows the timed region when --steps < this (0 = none)")
+    ap.add_argument("--after-idle-launches", type=int, default=24,
+                    help="launches whose clock / duration are recorded after the GPU sat idle during the CPU baseline (0 = none)")
+    ap.add_argument("--hamming-train01", type=int, default=-1, help="encoding of the train operand of the matrix-core kernel: 1 = {0, +1}, 0 = +-1, -1 = library default")
+    ap.add_argument("--estimator", default="ransac", choices=["ransac", "usac", "usac_prosac", "usac_default_refine", "arrsac"],
+                    help="robust estimator of the C5 pipeline (--workload c5 and the c5 object of the default line)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -314,6 +379,9 @@ def main():
     ctx = mpa.Context(local_rank)
     lib = ctx.lib
     ctx.set_option("hamming_variant", args.hamming_variant)
+    if args.hamming_train01 >= 0:
+        ctx.set_option("hamming_train01", args.hamming_train01)
+    ctx.set_option("hamming_stamps", 2)   # one 32-byte clock record per launch of the matrix-core kernel (its first workgroup): the live shader clock
     if args.workload == "c5":
         if args.steps == 200 and args.warmup == 20:   # the defaults are sized for the C2 step; a C5 step is a whole batch
             args.steps, args.warmup = 5, 2
@@ -372,26 +440,57 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def read_clock(nlast):
+        """(GHz, first-workgroup lifetime in us, start in us since the first record) of the last `nlast` launches of the matrix-core kernel:
+        s_memtime (shader clock) and s_memrealtime (100 MHz) deltas of its work item 0, recorded by the kernel itself (hamming_stamps = 2)"""
+        buf = np.zeros((256, 4), np.uint64)
+        m = lib.mlpl_debug_hamming_clock(ctx.handle, buf.ctypes.data, int(min(nlast, 256)))
+        if m <= 0:
+            return np.zeros(0), np.zeros(0), np.zeros(0)
+        r = buf[:m].astype(np.float64)
+        return r[:, 0] / np.maximum(r[:, 1], 1.0) * 0.1, r[:, 1] / 100.0, (r[:, 2] - r[0, 2]) / 100.0
+
+    def timed_region(nsteps, per_step_events):
+        """EXACTLY nsteps steps between two barriers (+ device synchronisation); returns (wall seconds, max over ranks; kernel ms by HIP
+        events; launches bracketed; per-step GPU ms from one event per step on the launch stream; per-launch clock records)"""
+        _lib.check(lib.mlpl_profile_reset(ctx.handle), "profile_reset")
+        _lib.check(lib.mlpl_profile_enable(ctx.handle, 0 if args.no_kernel_events else max(1, args.kernel_event_every)), "profile_enable")
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)] if per_step_events else None
+        barrier()
+        t0 = time.perf_counter()
+        if evs:
+            evs[0].record()
+        for i in range(nsteps):
+            step()
+            if evs:
+                evs[i + 1].record()
+        barrier()
+        el = time.perf_counter() - t0
+        _lib.check(lib.mlpl_profile_enable(ctx.handle, 0), "profile_enable")
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        tot_ms, launches = C.c_double(0), C.c_int(0)
+        _lib.check(lib.mlpl_profile_read(ctx.handle, 0, C.byref(tot_ms), C.byref(launches)), "profile_read")
+        ms_steps = [evs[i].elapsed_time(evs[i + 1]) for i in range(nsteps)] if evs else None
+        return el, tot_ms.value / max(launches.value, 1), launches.value, ms_steps, read_clock(nsteps)
+
     for _ in range(args.warmup):
         step()
-    barrier()
-    _lib.check(lib.mlpl_profile_reset(ctx.handle), "profile_reset")
-    _lib.check(lib.mlpl_profile_enable(ctx.handle, 0 if args.no_kernel_events else max(1, args.kernel_event_every)), "profile_enable")
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    _lib.check(lib.mlpl_profile_enable(ctx.handle, 0), "profile_enable")
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, kern_ms, n_bracketed, ms_steps_gpu, clk_timed = timed_region(args.steps, True)
+    # steady state (VERDICT r4 #1b): the driver's protocol (20 steps after 5 warm-ups) times the first ~11 ms of GPU work after the input
+    # upload; the same step in a long run is measured right behind it, same buffers, same verification below.  `value` stays the former.
+    steady = None
+    if args.steady_steps > args.steps and args.steady_steps > 0:
+        st_el, st_kern, st_n, _, st_clk = timed_region(args.steady_steps, False)
+        steady = {"steps": args.steady_steps, "ms_per_step": st_el / args.steady_steps * 1e3, "kernel_ms_avg": st_kern, "launches_timed": st_n,
+                  "value": world * P * n * n * args.steady_steps / st_el,
+                  "clock_GHz_median": float(np.median(st_clk[0])) if len(st_clk[0]) else None}
 
-    tot_ms, launches = C.c_double(0), C.c_int(0)
-    _lib.check(lib.mlpl_profile_read(ctx.handle, 0, C.byref(tot_ms), C.byref(launches)), "profile_read")
-    kern_ms = tot_ms.value / max(launches.value, 1)
+    class _L:   # (the name the code below reads the number of bracketed launches from)
+        value = n_bracketed
+    launches = _L
 
     pairs_per_step_rank = P * n * n
     value = world * pairs_per_step_rank * args.steps / elapsed
@@ -448,10 +547,15 @@ def main():
                     prof = {k: tj[k] for k in ("mfma_busy_frac", "mfma_busy_how", "shader_clock_GHz_under_pmc", "kernel_us_rocprof_trace") if k in tj}
             except Exception:
                 traffic = None
+        def fmt(a, nd=3):   # a list of figures as ONE short string (the driver's parsed record keeps scalars and strings, <= 128 characters)
+            return " ".join((f"{x:.{nd}f}".lstrip("0") if 0 <= x < 1 else f"{x:.{nd}f}") for x in a)
+
+        clk_ghz, clk_dur_us, clk_start_us = clk_timed
         if mfma_path:
             flops = pairs_per_step_rank * FLOP_PER_PAIR          # algorithmic FLOP per launch of the dominant kernel
             achieved = flops / (kern_ms * 1e-3) / 1e12
             floor_ms = pairs_per_step_rank / MFMA_UNIT_PAIRS / N_SIMD * MFMA_UNIT_FLOOR_CYCLES / MFMA_CLOCK_HZ * 1e3
+            # key order: what a reader of the driver's `parsed` record needs first (it keeps a bounded number of keys, scalars / short strings)
             roofline = {
                 "kernel": kernel_name,
                 "bound": "mfma",
@@ -460,25 +564,37 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP4_MFMA_PEAK_TFLOPS,
                 "traffic": traffic,
-                "traffic_source": traffic_src,
-                "from_profiles": prof or None,
                 "kernel_ms_avg": kern_ms,
                 "launches_timed": launches.value,
-                "note": "the all-pairs Hamming table as a +-1 GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 x fp4, fp32 accumulate, "
+                # the protocol dependence in the record itself: GPU time of every timed step (one event per step on the launch stream) and
+                # the shader clock the kernel's first workgroup saw in every timed launch (s_memtime / s_memrealtime inside the kernel)
+                "ms_steps_gpu": fmt(ms_steps_gpu[:24]) if ms_steps_gpu else None,
+                "clock_GHz_steps": fmt(clk_ghz[-args.steps:][:24], 2) if len(clk_ghz) else None,
+                "clock_GHz_timed_median": float(np.median(clk_ghz[-args.steps:])) if len(clk_ghz) else None,
+                "steady_frac": (flops / (steady["kernel_ms_avg"] * 1e-3) / 1e12 / FP4_MFMA_PEAK_TFLOPS) if steady and steady["kernel_ms_avg"] > 0 else None,
+                "steady_kernel_ms_avg": steady["kernel_ms_avg"] if steady else None,
+                "steady_value": steady["value"] if steady else None,
+                "steady_ms_per_step": steady["ms_per_step"] if steady else None,
+                "steady_clock_GHz_median": steady["clock_GHz_median"] if steady else None,
+                "frac_of_mfma_plus_top2": floor_ms * MFMA_UNIT_WITH_TOP2_CYCLES / MFMA_UNIT_FLOOR_CYCLES / kern_ms,
+                "hbm_equiv_GBps": hbm_equiv,
+                "traffic_source": traffic_src,
+                "from_profiles": prof or None,
+                "note": "the all-pairs Hamming table as a GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 x fp4, fp32 accumulate, "
                         "exact): 2*256 FLOP per descriptor pair against the dense FP4 peak at the nominal 2.4 GHz.  Per 32x32 tile "
                         "the kernel issues 4 MFMAs and 22 VALU ops (running top-2), which do NOT overlap on a SIMD: "
                         "mfma_only_floor_ms is the measured cost of the MFMAs alone (141 cycles per tile per SIMD at 4 waves, "
                         "tools/hamming_unit_probe3.hip) at the ~1.9 GHz the chip holds on random descriptors, mfma_plus_top2_ms the "
-                        "measured cost of MFMAs + top-2 update with LDS-fed operands and no synchronisation (175 cycles)",
+                        "measured cost of MFMAs + top-2 update with LDS-fed operands and no synchronisation (175 cycles).  steady_* = the same "
+                        "step over --steady-steps further steps right behind the timed region",
                 "flop_per_pair": FLOP_PER_PAIR,
                 "mfma_only_floor_ms": floor_ms,
                 "mfma_plus_top2_ms": floor_ms * MFMA_UNIT_WITH_TOP2_CYCLES / MFMA_UNIT_FLOOR_CYCLES,
                 "frac_of_mfma_only_floor": floor_ms / kern_ms,
-                "frac_of_mfma_plus_top2": floor_ms * MFMA_UNIT_WITH_TOP2_CYCLES / MFMA_UNIT_FLOOR_CYCLES / kern_ms,
-                "hbm_equiv_GBps": hbm_equiv,
                 "hbm_equiv_frac": hbm_equiv / HBM_PEAK_GBS,
+                "first_workgroup_us_steps": fmt(clk_dur_us[-args.steps:][:24], 0) if len(clk_dur_us) else None,
             }
-            dtype = "fp4 (E2M1 +-1 per descriptor bit) MFMA, fp32 accumulate -- exact integer distances"
+            dtype = "fp4 (E2M1, one value per descriptor bit) MFMA, fp32 accumulate -- exact integer distances"
         else:
             roofline = {
                 "kernel": kernel_name,
@@ -491,6 +607,7 @@ def main():
                 "traffic_source": traffic_src,
                 "kernel_ms_avg": kern_ms,
                 "launches_timed": launches.value,
+                "ms_steps_gpu": fmt(ms_steps_gpu[:24]) if ms_steps_gpu else None,
                 "note": "streaming-equivalent bytes (64 B per descriptor pair, SURVEY 8(d)); operands are LDS/L2-"
                         "resident so the kernel is integer-VALU bound: valu_frac = measured instruction-issue floor of the xor/bcnt/"
                         "med3 mix (tools/valu_peak.hip) / kernel time",
@@ -513,26 +630,24 @@ def main():
             "vs_baseline": None,
             "dtype": dtype,
             "data": "synthetic",
+            # `config`: the scalars BASELINE.md section 4 quotes come FIRST (the driver's parsed record keeps the first ~24 keys, names cut
+            # at 40 characters, strings at 128); descriptive text and duplicates of top-level fields go last
             "config": {
                 "workload": f"C2: {n}x{n} ORB-256 BF-Hamming kNN=2 + 0.75 ratio + DMatch compaction, "
                             f"{P} image pair(s) per GPU per step",
-                "value_is": f"the BATCHED rate: {P} independent C2 image pairs per launch per GPU (a rank's share of BASELINE's 512-pair batch "
-                            "on 8 GPUs); value_8_pairs_per_launch is the launch shape rounds 1-2 reported, value_single_pair the same path "
-                            "with ONE pair per launch (the literal config 2, latency shape)",
+                "pairs_per_gpu": P,
                 "value_single_pair": (n * n / (single_ms * 1e-3)) if single_ms else None,
                 "ms_single_pair": single_ms,
-                "value_8_pairs_per_launch": (8 * n * n / (eight_ms * 1e-3)) if eight_ms else None,
                 "ms_8_pairs_per_launch": eight_ms,
-                "pairs_per_gpu": P,
-                "world_size": world,
-                "backend": args.backend if world > 1 else None,
-                "matches_first_pair": counts[0],
-                "parallelism": f"shard{world}",
-                "records_gathered_every_steps": G,
-                "hamming_kernel": kernel_name,
+                "steady_pairs_per_s": steady["value"] if steady else None,
+                "steady_kernel_ms": steady["kernel_ms_avg"] if steady else None,
+                "clock_GHz_timed_median": roofline.get("clock_GHz_timed_median"),
+                "clock_GHz_steady_median": steady["clock_GHz_median"] if steady else None,
             },
             "roofline": roofline,
+            "steady_state": steady,
         }
+        rec["config"]["hamming_train_operand"] = "{0,+1}" if ctx.get_option("hamming_train01") == 1 else "+-1"
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
@@ -563,6 +678,31 @@ def main():
             tb = time.perf_counter() - tb
             rec["cpu_best"] = {"value": n * n / tb, "unit": "descriptor-pairs/s", "cores": used, "kind": "port",
                                "sample": f"one full C2 pair, popcnt64 + OpenMP ({tb:.3f} s)"}
+        # After idle (VERDICT r4 #1a): the GPU has just sat idle for the seconds of the CPU baseline, as it does before the driver's run
+        # while the inputs are generated and uploaded.  The clock and duration of the first launches from that state, launch by launch,
+        # tell a clock / power ramp (clock rises or falls over the launches) from first-touch effects (only launch 0 is slow) and from a
+        # slow box (every figure low, steady state included).  Same buffers as the timed steps; not part of any reported rate.
+        if args.after_idle_launches > 0 and mfma_path:
+            if args.no_cpu_baseline:
+                time.sleep(2.0)
+            k = min(args.after_idle_launches, 200)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+            torch.cuda.synchronize()
+            evs[0].record()
+            for i in range(k):
+                match_hamming_device(d_q, d_t, ratio_test=True, ratio=0.75, ctx=ctx, out=outs[0][0], stream=stream)
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+            ai_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(k)]
+            ai_ghz, ai_dur, _ = read_clock(k)
+            rec["after_idle"] = {"launches": k, "ms_steps_gpu": [round(x, 4) for x in ai_ms], "clock_GHz": [round(float(x), 3) for x in ai_ghz],
+                                 "first_workgroup_us": [round(float(x), 1) for x in ai_dur],
+                                 "what": "the first launches after the GPU idled through the CPU baseline: GPU time per step (events) and the "
+                                         "shader clock inside each launch"}
+            rec["timed_region"] = {"ms_steps_gpu": [round(x, 4) for x in ms_steps_gpu], "clock_GHz": [round(float(x), 3) for x in clk_ghz[-args.steps:]],
+                                   "first_workgroup_us": [round(float(x), 1) for x in clk_dur_us[-args.steps:]]}
+            rec["roofline"]["after_idle_ms_steps_gpu"] = fmt(ai_ms[:24])
+            rec["roofline"]["after_idle_clock_GHz"] = fmt(ai_ghz[:24], 2)
         if not args.no_extras and world == 1:
             try:
                 import bench_extras
@@ -578,35 +718,55 @@ def main():
         # BASELINE's metric is "descriptor-pairs/s + RANSAC hyp/s; 1/2/4/8 GPU": the second half (C3) and the batch of config 5 are
         # TOP-LEVEL objects of the line, each with its own roofline and cpu_baseline, and their headline scalars are repeated in `config`
         # (a reader of the driver's `parsed` record, which keeps `config`, can check BASELINE.md section 4 from it alone)
-        cfg = rec["config"]
+        cfg = {}
         ransac = rec.get("extras", {}).pop("ransac_c3", None)
         if ransac is not None:
             rec["ransac"] = ransac
             cfg["ransac_c3_hyp_per_s"] = ransac["value"]
             cfg["ransac_c3_ms_per_call"] = ransac["ms_per_call"]
-            cfg["ransac_c3_count_kernel_frac_of_fp32_vector_peak"] = ransac["roofline"]["frac"]
-            cfg["ransac_c3_solver_kernels_frac_of_fp64_vector_peak"] = ransac["roofline"]["solver_frac_of_fp64_vector_peak"]
+            cfg["ransac_c3_count_frac_fp32_peak"] = ransac["roofline"]["frac"]
+            cfg["ransac_c3_solver_frac_fp64_peak"] = ransac["roofline"]["solver_frac_of_fp64_vector_peak"]
             if ransac.get("cpu_baseline"):
                 cfg["ransac_c3_cpu_hyp_per_s_1_core"] = ransac["cpu_baseline"]["value"]
+            if ransac.get("polish_changed_frac") is not None:
+                cfg["ransac_c3_polish_changed_frac"] = ransac["polish_changed_frac"]
         if c5 is not None:
             rec["c5"] = c5
             cfg["c5_image_pairs_per_s"] = c5["value"]
             cfg["c5_ms_per_step"] = c5["ms_per_step"]
+            cfg["c5_estimator"] = c5["config"]["estimator"]
             cfg["c5_mode"] = c5["mode"]
-            cfg["c5_ms_per_step_other_mode"] = [v for k, v in c5.items() if k.startswith("ms_per_step_")][0]
+            other = [v for k, v in c5.items() if k.startswith("ms_per_step_")]
+            cfg["c5_ms_per_step_other_mode"] = other[0] if other else None
             cfg["c5_dominant_kernel"] = c5["roofline"]["kernel"]
             cfg["c5_dominant_kernel_frac"] = c5["roofline"]["frac"]
             if c5.get("cpu_baseline"):
                 cfg["c5_cpu_image_pairs_per_s_1_core"] = c5["cpu_baseline"]["value"]
         ex = rec.get("extras", {})
-        for name, key in (("c5_usac_batch_uniform", "c5_usac_uniform_ms_per_512_pairs"), ("c5_usac_batch_prosac", "c5_usac_prosac_ms_per_512_pairs"),
-                          ("c5_usac_batch_default_refinement_prosac", "c5_usac_default_refinement_ms_per_512_pairs")):
+        for name, key in (("c5_usac_batch_uniform", "c5_usac_uniform_ms_per_512"), ("c5_usac_batch_prosac", "c5_usac_prosac_ms_per_512"),
+                          ("c5_usac_batch_default_refinement_prosac", "c5_usac_default_refine_ms_per_512")):
             if isinstance(ex.get(name), dict) and "ms_per_step" in ex[name]:
                 cfg[key] = ex[name]["ms_per_step"]
         for name, key in (("usac_uniform", "usac_call_ms"), ("arrsac_default_method", "arrsac_call_ms"), ("hamming_c2_single_pair", "hamming_single_pair_ms"),
                           ("hamming_c2_8pairs_mfma_kernel", "hamming_8_pairs_ms")):
             if isinstance(ex.get(name), dict) and "ms_per_call" in ex[name]:
                 cfg[key] = ex[name]["ms_per_call"]
+        # final key order of `config` (see the comment at its construction): 24 scalars first, the rest behind them
+        first = ["workload", "pairs_per_gpu", "value_single_pair", "ms_single_pair", "ms_8_pairs_per_launch", "steady_pairs_per_s", "steady_kernel_ms",
+                 "clock_GHz_timed_median", "clock_GHz_steady_median", "ransac_c3_hyp_per_s", "ransac_c3_ms_per_call", "ransac_c3_count_frac_fp32_peak",
+                 "ransac_c3_cpu_hyp_per_s_1_core", "c5_image_pairs_per_s", "c5_ms_per_step", "c5_estimator", "c5_cpu_image_pairs_per_s_1_core",
+                 "c5_usac_uniform_ms_per_512", "c5_usac_prosac_ms_per_512", "c5_usac_default_refine_ms_per_512", "usac_call_ms", "arrsac_call_ms",
+                 "c5_dominant_kernel_frac", "verified"]
+        merged = dict(rec["config"])
+        merged.update(cfg)
+        merged.update({"matches_first_pair": counts[0], "hamming_kernel": kernel_name, "world_size": world, "backend": args.backend if world > 1 else None,
+                       "parallelism": f"shard{world}", "records_gathered_every_steps": G,
+                       "value_8_pairs_per_launch": (8 * n * n / (eight_ms * 1e-3)) if eight_ms else None,
+                       "value_is": f"the BATCHED rate: {P} independent C2 image pairs per launch per GPU (a rank's share of BASELINE's 512-pair batch "
+                                   "on 8 GPUs) under the given --steps / --warmup; steady_* = the same step in a long run; value_single_pair = "
+                                   "ONE pair per launch (the literal config 2, latency shape)"})
+        rec["config"] = {k: merged[k] for k in first if k in merged}
+        rec["config"].update({k: v for k, v in merged.items() if k not in rec["config"]})
         for k, v in (rec["roofline"].get("from_profiles") or {}).items():   # the same figures as scalars of `roofline`
             rec["roofline"]["from_profiles_" + k] = v
         print(json.dumps(rec), flush=True)

@@ -66,7 +66,9 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  *     32-byte descriptors, 0 = register-prefetch kernel, 2 = dynamic train splits; "hamming_mfma_weighted" (default 1) = age-aware split
  *     sizes; "hamming_mfma_prio" 0|1|2 (diagnostics); "hamming_mfma_blocks_per_cu" and "hamming_mfma_qt" (query tiles per wave,
  *     0 = automatic) size the matrix-core grid; "hamming_qpl" queries per lane 1|2 and "hamming_blocks_per_cu" size the VALU grids;
- *     "hamming_stamps" 1 = per-wave / per-workgroup clock stamps (mlpl_debug_hamming_stamps).
+ *     "hamming_stamps" 1 = per-wave / per-workgroup clock stamps (mlpl_debug_hamming_stamps), 2 = one clock record per launch
+ *       (mlpl_debug_hamming_clock).  "hamming_train01" 1 = {0, +1} instead of +-1 train fragments in the matrix-core Hamming kernel
+ *       (same results; see knn_hamming_mfma.hip).
  *   L2: "l2_mfma_waves" 0|4|8 and "l2_mfma_blocks_per_cu" shape the int8 matrix-core kernel of the forced mode (see mlpl_set_l2_path);
  *     "l2_float_mfma" 0|1|2 decides when the fp16 candidate path serves non-integer float descriptors (mlpl_set_l2_path, mode 0).
  *   RANSAC: "ransac_device_draw" (default 1) = large passes draw their samples on the device (mlpl_debug_ransac_draw); "ransac_chunk" hypotheses per device pass (0 = 32768 = the maximum; the sequential best/niters rule is replayed across
@@ -90,6 +92,9 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  *     elimination + root path, which -- like the CPU code -- is off by up to 1e-5 on the ~0.5 % of samples whose eliminated block is ill
  *     conditioned.  This is the one option that changes results (towards the exact solution). */
 int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value);
+/* The current value of a tuning knob (the names mlpl_set_option takes; a subset: the Hamming knobs, "solver_polish", "ransac_count_mpl",
+ * "hub_workers", "hub_lanes").  Returns 0, MLPL_E_BAD_INPUT for a name it does not know. */
+int mlpl_get_option(mlpl_ctx *ctx, const char *name, int *value);
 
 /* ---- in-library kernel timing (for roofline accounting) ------------------------------------------------------
  * When enabled, the launches of the dominant kernel of each path are bracketed with hipEvents on the stream
@@ -503,6 +508,11 @@ int mlpl_debug_l2_flags(mlpl_ctx *ctx, int flags[4]);
  * real-time ticks, 32x32 tiles processed, start tick}; this copies up to max_items records of 4 x u64 of the LAST launch to `out`
  * and returns their number.  In-kernel clock = cycles / ticks * 100 MHz.  Not for production use. */
 int mlpl_debug_hamming_stamps(mlpl_ctx *ctx, unsigned long long *out, int max_items);
+/* Diagnostics: with option "hamming_stamps" = 2 every launch of the static LDS-ring Hamming kernel leaves ONE record {shader-clock
+ * cycles, 100 MHz ticks, start tick, launch number} of the lifetime of its first workgroup in a ring of 256 launches (one 32-byte store
+ * per launch; nothing else changes).  Copies the records of the last min(max_items, 256, launches so far) launches, oldest first, and
+ * returns their number (synchronises the device).  Shader clock of a launch = cycles / ticks * 100 MHz. */
+int mlpl_debug_hamming_clock(mlpl_ctx *ctx, unsigned long long *out, int max_items);
 
 /* ---- cheirality / pose recovery --------------------------------------------------------------------------
  * Replaces poselib::getPoseTriangPts (P/source/pose_estim.cpp:913-946) = recoverPose

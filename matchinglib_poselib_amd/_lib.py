@@ -49,6 +49,7 @@ _SIGNATURES = {
     "mlpl_ctx_device": (c_int, [c_void_p]),
     "mlpl_ctx_synchronize": (c_int, [c_void_p]),
     "mlpl_set_option": (c_int, [c_void_p, C.c_char_p, c_int]),
+    "mlpl_get_option": (c_int, [c_void_p, C.c_char_p, C.POINTER(c_int)]),
     "mlpl_profile_enable": (c_int, [c_void_p, c_int]),
     "mlpl_profile_reset": (c_int, [c_void_p]),
     "mlpl_profile_read": (c_int, [c_void_p, c_int, C.POINTER(c_double), C.POINTER(c_int)]),
@@ -118,6 +119,7 @@ _SIGNATURES = {
     "mlpl_debug_eig9": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "mlpl_debug_dk_stats": (c_int, [c_void_p, c_int, c_void_p]),
     "mlpl_debug_hamming_stamps": (c_int, [c_void_p, c_void_p, c_int]),
+    "mlpl_debug_hamming_clock": (c_int, [c_void_p, c_void_p, c_int]),
     "mlpl_pair_pose_dev": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
                                    c_int, c_double, c_int, c_u32, c_double, c_void_p, c_void_p]),
     "mlpl_pair_pose_batch_dev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
@@ -225,6 +227,12 @@ class Context:
     def set_option(self, name: str, value: int):
         """mlpl_set_option (include/mlpl_c.h): kernel selection / tuning knobs of this context."""
         check(self._lib.mlpl_set_option(self._h, name.encode(), int(value)), "mlpl_set_option")
+
+    def get_option(self, name: str) -> int:
+        """mlpl_get_option: the current value of a tuning knob."""
+        v = C.c_int(0)
+        check(self._lib.mlpl_get_option(self._h, name.encode(), C.byref(v)), "mlpl_get_option")
+        return v.value
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

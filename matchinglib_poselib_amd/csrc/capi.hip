@@ -210,7 +210,8 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "hamming_mfma_prio") && (value >= 0 && value <= 2)) ctx->opt_hamming_mfma_prio = value;
     else if (!std::strcmp(name, "hamming_mfma_weighted") && (value == 0 || value == 1)) ctx->opt_hamming_mfma_weighted = value;
     else if (!std::strcmp(name, "hamming_fused_merge") && (value == 0 || value == 1)) ctx->opt_hamming_fused_merge = value;
-    else if (!std::strcmp(name, "hamming_stamps") && (value == 0 || value == 1)) ctx->opt_hamming_stamps = value;
+    else if (!std::strcmp(name, "hamming_stamps") && (value >= 0 && value <= 2)) ctx->opt_hamming_stamps = value;
+    else if (!std::strcmp(name, "hamming_train01") && (value == 0 || value == 1)) ctx->opt_hamming_train01 = value;
     else if (!std::strcmp(name, "l2_mfma_waves") && (value == 0 || value == 4 || value == 8)) ctx->opt_l2_mfma_waves = value;
     else if (!std::strcmp(name, "l2_mfma_blocks_per_cu") && value >= 0 && value <= 16) ctx->opt_l2_mfma_blocks_per_cu = value;
     else if (!std::strcmp(name, "hamming_qpl") && (value == 1 || value == 2)) ctx->opt_hamming_qpl = value;
@@ -247,6 +248,25 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     return MLPL_OK;
 }
 
+int mlpl_get_option(mlpl_ctx *ctx, const char *name, int *value) {
+    if (!ctx || !name || !value) return MLPL_E_BAD_INPUT;
+    if (!std::strcmp(name, "hamming_variant")) *value = ctx->opt_hamming_variant;
+    else if (!std::strcmp(name, "hamming_mfma_qt")) *value = ctx->opt_hamming_mfma_qt;
+    else if (!std::strcmp(name, "hamming_mfma_lds")) *value = ctx->opt_hamming_mfma_lds;
+    else if (!std::strcmp(name, "hamming_fused_merge")) *value = ctx->opt_hamming_fused_merge;
+    else if (!std::strcmp(name, "hamming_train01")) *value = ctx->opt_hamming_train01;
+    else if (!std::strcmp(name, "hamming_stamps")) *value = ctx->opt_hamming_stamps;
+    else if (!std::strcmp(name, "solver_polish")) *value = ctx->opt_solver_polish;
+    else if (!std::strcmp(name, "ransac_count_mpl")) *value = ctx->opt_ransac_count_mpl;
+    else if (!std::strcmp(name, "hub_workers")) *value = ctx->opt_hub_workers;
+    else if (!std::strcmp(name, "hub_lanes")) *value = ctx->opt_hub_lanes;
+    else {
+        set_error("mlpl_get_option: unknown option: %s", name);
+        return MLPL_E_BAD_INPUT;
+    }
+    return MLPL_OK;
+}
+
 int mlpl_debug_hamming_stamps(mlpl_ctx *ctx, unsigned long long *out, int max_items) {
     if (!ctx || !out) return MLPL_E_BAD_INPUT;
     MLPL_HIP_TRY(hipSetDevice(ctx->device));
@@ -260,6 +280,22 @@ int mlpl_debug_hamming_stamps(mlpl_ctx *ctx, unsigned long long *out, int max_it
     }
     const int n = ctx->dbg_stamp_items < max_items ? ctx->dbg_stamp_items : max_items;
     if (n > 0 && ctx->ws[WS_DEBUG]) MLPL_HIP_TRY(hipMemcpy(out, ctx->ws[WS_DEBUG], (size_t)n * 32, hipMemcpyDeviceToHost));
+    return n;
+}
+
+int mlpl_debug_hamming_clock(mlpl_ctx *ctx, unsigned long long *out, int max_items) {
+    if (!ctx || !out || max_items < 0) return MLPL_E_BAD_INPUT;
+    MLPL_HIP_TRY(hipSetDevice(ctx->device));
+    MLPL_HIP_TRY(hipDeviceSynchronize());
+    const long long have = ctx->hamming_clock_launches < kClockRing ? ctx->hamming_clock_launches : kClockRing;
+    const int n = (int)(have < max_items ? have : max_items);
+    if (n <= 0 || !ctx->ws[WS_CLOCK]) return 0;
+    unsigned long long ring[kClockRing * 4];
+    MLPL_HIP_TRY(hipMemcpy(ring, ctx->ws[WS_CLOCK], sizeof(ring), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {  // oldest first
+        const long long launch = ctx->hamming_clock_launches - n + i;
+        std::memcpy(out + (size_t)i * 4, ring + (size_t)(launch % kClockRing) * 4, 32);
+    }
     return n;
 }
 

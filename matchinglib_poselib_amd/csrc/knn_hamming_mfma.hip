@@ -63,6 +63,17 @@ __device__ __forceinline__ uint32_t expand_byte(uint32_t x) {
     return 0xAAAAAAAAu ^ (t << 3);
 }
 
+// The {0, +1} form of the STREAMED (train) operand (option hamming_train01): bit 1 -> 0x2 (+1.0), bit 0 -> 0x0 (+0.0).  With the query
+// operand still +-1,  sum_k t_k q'_k = pop(t & q) - pop(t & ~q) = pop(q) - hamming(t, q):  for a fixed query (a lane's column) the
+// accumulator still orders the train rows by distance, all values are exact integers in [-256, 256], and half of the A operand's nibbles
+// are zero (fewer toggling multiplier inputs: the sustained matrix-core clock is data dependent).  The decode adds pop(q).
+__device__ __forceinline__ uint32_t expand_byte01(uint32_t x) {
+    uint32_t t = (x | (x << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    t = (t | (t << 3)) & 0x11111111u;
+    return t << 1;
+}
+
 // Rows of `nw` 32-bit words (word rows as the VALU path uses them) -> fragment order.  Lane (r = l & 31, h = l >> 5) of
 // K-step s holds word h * KS + s of row 32 * tile + r, i.e. each lane owns KS CONSECUTIVE words of its row (one 16-byte
 // load at KS = 4, and the wave reads one contiguous KiB); which 32 bits go to which K position is free as long as both
@@ -78,7 +89,7 @@ struct ExpandArgs {
 
 template <int KS>
 __global__ __launch_bounds__(256) void hamming_expand_kernel(ExpandArgs qa, ExpandArgs ta, int nw, int *__restrict__ counters,
-                                                             int counters_per_batch) {
+                                                             int counters_per_batch, int train01) {
     const ExpandArgs A = blockIdx.z ? ta : qa;
     const int b = blockIdx.y;
     if (counters && blockIdx.x == 0 && blockIdx.z == 0)  // chunk counters of the dynamic-split kernel that follows in the stream
@@ -111,8 +122,11 @@ __global__ __launch_bounds__(256) void hamming_expand_kernel(ExpandArgs qa, Expa
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 o = {expand_byte(v[s] & 255u), expand_byte((v[s] >> 8) & 255u), expand_byte((v[s] >> 16) & 255u),
-                         expand_byte(v[s] >> 24)};
+        u32x4 o = {expand_byte(v[s] & 255u), expand_byte((v[s] >> 8) & 255u), expand_byte((v[s] >> 16) & 255u),
+                   expand_byte(v[s] >> 24)};
+        if (train01)  // (only ever set for the train operand of the static LDS-ring kernel, which expands its queries itself)
+            o = u32x4{expand_byte01(v[s] & 255u), expand_byte01((v[s] >> 8) & 255u), expand_byte01((v[s] >> 16) & 255u),
+                      expand_byte01(v[s] >> 24)};
         __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(out + s * 64));
     }
 }
@@ -296,6 +310,11 @@ struct HammingFuse {
     int *tickets;   // [batch][qblocks], zero before the launch; left zero by the last workgroup
     int k;
     float ratio;
+    int train01;    // the train fragments are {0, +1} (hamming_expand_kernel train01): accumulator = pop(query) - distance
+    // Clock record of this launch (option hamming_stamps = 2; nullptr otherwise): thread 0 of work item 0 leaves {shader-clock cycles,
+    // 100 MHz ticks, start tick, launch number} of its workgroup's lifetime -- one 32-byte store per launch, the cost of the facility.
+    unsigned long long *clk;
+    unsigned long long launch_no;
 };
 
 template <int QT, int PRIO>
@@ -308,7 +327,7 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
     const int l = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned long long st_c = 0, st_r = 0;
-    if (stamps) {
+    if (stamps || fuse.clk) {
         st_c = __builtin_amdgcn_s_memtime();
         st_r = __builtin_amdgcn_s_memrealtime();
     }
@@ -326,11 +345,14 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
     // row: one 16-byte load per tile; the same word -> K-position rule as hamming_expand_kernel, which now runs for the train set only --
     // that one has to exist in fragment order in memory because it is streamed into LDS by DMA).  Rows >= nq read as zero bits.
     uint4 bq[QT][KS];
+    int qpop[QT];  // {0, +1} train operand (fuse.train01): the accumulator is pop(query) - distance; both lane halves' shares of the row
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int row = (qt0 + t) * 32 + (l & 31);
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (row < nq) v = *reinterpret_cast<const uint4 *>(qw + (size_t)b * q_batch_words + (size_t)row * (2 * KS) + (size_t)h * KS);
+        const int pc = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+        qpop[t] = pc + __shfl_xor(pc, 32);
         const uint32_t vs[KS] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int s = 0; s < KS; ++s)
@@ -460,7 +482,7 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
                 k[j] = 0xFFFFFFFFu;
             } else {
                 const float ip = rintf(mm[j]);
-                const int d = (64 * KS - (int)ip) >> 1;
+                const int d = fuse.train01 ? qpop[t] - (int)ip : (64 * KS - (int)ip) >> 1;
                 const int lrow = (int)(frame - (mm[j] - ip) * 16384.0f);
                 k[j] = ((uint32_t)d << dshift) | (uint32_t)lrow;
             }
@@ -565,6 +587,12 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
         const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
         o[2] = (unsigned long long)ntiles * QT | ((unsigned long long)(hw & 0xFFFFFu) << 32) | ((unsigned long long)(xcc & 15u) << 56);
         o[3] = st_r;
+    }
+    if (fuse.clk && item == 0 && threadIdx.x == 0) {
+        fuse.clk[0] = __builtin_amdgcn_s_memtime() - st_c;
+        fuse.clk[1] = __builtin_amdgcn_s_memrealtime() - st_r;
+        fuse.clk[2] = st_r;
+        fuse.clk[3] = fuse.launch_no;
     }
 }
 
@@ -868,14 +896,15 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     }
     // the static LDS-ring kernel expands its query operand itself (in registers): only the train set goes through the expansion kernel
     const bool expand_q = !(lds_ring && !dyn);
+    const int train01 = (lds_ring && !dyn && ctx->opt_hamming_train01) ? 1 : 0;  // {0, +1} train fragments: that kernel only (it has the raw query words)
     const ExpandArgs ta{tw, t_batch_words, nt, t_tiles, (uint4 *)tf};
     const ExpandArgs qa = expand_q ? ExpandArgs{qw, q_batch_words, nq, q_tiles_padded, (uint4 *)qf} : ta;  // blockIdx.z == 0
     const dim3 egrid((unsigned)(((expand_q ? std::max(q_tiles_padded, t_tiles) : t_tiles) * 64 + 255) / 256), batch, expand_q ? 2 : 1);
     switch (ks) {
-        case 1: hipLaunchKernelGGL(hamming_expand_kernel<1>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch); break;
-        case 2: hipLaunchKernelGGL(hamming_expand_kernel<2>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch); break;
-        case 4: hipLaunchKernelGGL(hamming_expand_kernel<4>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch); break;
-        default: hipLaunchKernelGGL(hamming_expand_kernel<8>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch); break;
+        case 1: hipLaunchKernelGGL(hamming_expand_kernel<1>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch, train01); break;
+        case 2: hipLaunchKernelGGL(hamming_expand_kernel<2>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch, train01); break;
+        case 4: hipLaunchKernelGGL(hamming_expand_kernel<4>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch, train01); break;
+        default: hipLaunchKernelGGL(hamming_expand_kernel<8>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch, train01); break;
     }
     // 1-D grid, remapped in the kernel (XCD-aware); padded so that every XCD gets the same number of workgroups
     const long long blocks = lds_ring ? items : (items + 3) / 4;
@@ -907,9 +936,10 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
             void *tabp = nullptr;
             if ((rc = ws_get(ctx, WS_SPLIT_TAB, 4096 * sizeof(int32_t), &tabp))) return rc;
             if (ctx->split_tab_key != key || ctx->split_tab_ptr != tabp) {
-                void *pin = nullptr;
-                if ((rc = pinned_get(ctx, 4096 * sizeof(int32_t), &pin))) return rc;
-                int32_t *h = (int32_t *)pin;  // staging: free again after the synchronous upload below
+                // staging in pageable memory of this call: the context's pinned block belongs to the entry point that called us (the pair
+                // batch entries keep pointers into it across the matching call, and pinned_get frees the block when it grows)
+                std::vector<int32_t> hv((size_t)batch * (nsplit + 1));
+                int32_t *h = hv.data();
                 for (int bb = 0; bb < batch; ++bb) {
                     double wsum = 0;
                     for (int sp = 0; sp < nsplit; ++sp) wsum += kRate[rank[(size_t)bb * nsplit + sp]];
@@ -930,7 +960,7 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
                 if (ok) {
                     MLPL_HIP_TRY(hipStreamSynchronize(s));  // the previous table may still be read by kernels in flight
                     MLPL_HIP_TRY(hipMemcpyAsync(tabp, h, (size_t)batch * (nsplit + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
-                    MLPL_HIP_TRY(hipStreamSynchronize(s));  // the staging memory is shared with other entry points
+                    MLPL_HIP_TRY(hipStreamSynchronize(s));  // the staging vector dies with this scope
                     ctx->split_tab_key = key;
                     ctx->split_tab_ptr = tabp;
                 }
@@ -940,7 +970,7 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     }
     unsigned long long *stamps = nullptr;
     ctx->dbg_stamp_items = 0;
-    if (ctx->opt_hamming_stamps) {
+    if (ctx->opt_hamming_stamps == 1) {
         void *sp = nullptr;
         const long long waves = lds_ring ? items * 4 : items;
         // per-wave records (4 x u64), then a per-tile clock trace of 48 u64 per wave (LDS-ring kernel, static splits)
@@ -949,7 +979,13 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
         stamps = (unsigned long long *)sp;
         ctx->dbg_stamp_items = (int)waves;
     }
-    HammingFuse fuse{nullptr, nullptr, nullptr, nullptr, k, ratio};
+    HammingFuse fuse{nullptr, nullptr, nullptr, nullptr, k, ratio, train01, nullptr, 0ull};
+    if (lds_ring && !dyn && ctx->opt_hamming_stamps == 2) {  // clock ring: one 32-byte record per launch, kClockRing launches deep
+        void *cp = nullptr;
+        if ((rc = ws_get(ctx, WS_CLOCK, (size_t)kClockRing * 32, &cp))) return rc;
+        fuse.clk = (unsigned long long *)cp + (size_t)(ctx->hamming_clock_launches % kClockRing) * 4;
+        fuse.launch_no = (unsigned long long)ctx->hamming_clock_launches++;
+    }
     // (one query tile per wave = a single image pair with sixteen splits: measured with the fused epilogue 26.8 us per pair against 21.2 with
     // the separate merge launch -- the last-arriving workgroup's fold of sixteen written-through partials is a serial tail on a 15 us kernel)
     if (lds_ring && !dyn && qt >= 2 && d_idx && d_dist && (ctx->opt_hamming_fused_merge & 1)) {
@@ -957,10 +993,10 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
         if (nsplit > 1) {  // ticket counters of the (pair, query block)s: zero when (re)allocated, left zero by every launch
             void *tp = nullptr;
             const size_t tb = (size_t)batch * qblocks * sizeof(int);
-            if ((rc = ws_get(ctx, WS_COUNTERS, tb, &tp))) return rc;
+            if ((rc = ws_get(ctx, WS_TICKETS, tb, &tp))) return rc;   // a slot of its own: nothing else writes it (not the dyn kernel's counters)
             if (ctx->hamming_tickets_ptr != tp || ctx->hamming_tickets_bytes < tb) {
-                MLPL_HIP_TRY(hipMemsetAsync(tp, 0, ctx->ws_bytes[WS_COUNTERS], s));
-                ctx->hamming_tickets_ptr = tp, ctx->hamming_tickets_bytes = ctx->ws_bytes[WS_COUNTERS];
+                MLPL_HIP_TRY(hipMemsetAsync(tp, 0, ctx->ws_bytes[WS_TICKETS], s));
+                ctx->hamming_tickets_ptr = tp, ctx->hamming_tickets_bytes = ctx->ws_bytes[WS_TICKETS];
             }
             fuse.tickets = (int *)tp;
         }

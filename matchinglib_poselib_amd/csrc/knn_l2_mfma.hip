@@ -194,7 +194,7 @@ int launch_knn_l2_mfma(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride,
     const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
     unsigned long long *stamps = nullptr;
     ctx->dbg_stamp_items = 0;
-    if (ctx->opt_hamming_stamps) {  // the same diagnostics switch as the Hamming kernels (mlpl_debug_hamming_stamps reads them back)
+    if (ctx->opt_hamming_stamps == 1) {  // the same diagnostics switch as the Hamming kernels (mlpl_debug_hamming_stamps reads them back)
         void *sp = nullptr;
         if ((rc = ws_get(ctx, WS_DEBUG, (size_t)total * 32, &sp))) return rc;
         stamps = (unsigned long long *)sp;

@@ -58,6 +58,8 @@ enum WsSlot {
     WS_BATCH_SMP, // mlpl_pair_pose_batch_dev: sample tables of a pass (drawn on the device), stream positions
     WS_RAND_RAW,  // raw rand() stream of the last RANSAC seed on the device + the control block of the device-side sampling
     WS_BATCH_RUNS, // device blocks of the runs of a batched sequential estimator (USAC / ARRSAC), one slice per run
+    WS_CLOCK,     // clock ring of the Hamming kernel (option hamming_stamps = 2): kClockRing records of 4 x u64
+    WS_TICKETS,   // ticket counters of the fused Hamming epilogue (zero between launches; knn_hamming_mfma.hip)
     WS_NUM_SLOTS
 };
 
@@ -109,9 +111,11 @@ struct mlpl_ctx {
     long long split_tab_key;        // shape key of the split table currently in WS_COUNTERS
     void *split_tab_ptr;
     int opt_hamming_fused_merge;    // 1 (default) = the static LDS-ring kernel merges its splits / evaluates the ratio predicate itself (no merge launch)
-    void *hamming_tickets_ptr;      // zeroed ticket counters of that merge (WS_COUNTERS) ...
+    void *hamming_tickets_ptr;      // zeroed ticket counters of that merge (WS_TICKETS) ...
     size_t hamming_tickets_bytes;   // ... and how many bytes of them are known to be zero
-    int opt_hamming_stamps;         // diagnostics: the matrix-core kernel records per-wave clock stamps (mlpl_debug_hamming_stamps)
+    int opt_hamming_stamps;         // diagnostics: 1 = the matrix-core kernel records per-wave clock stamps (mlpl_debug_hamming_stamps); 2 = one clock record per launch into a ring (mlpl_debug_hamming_clock)
+    long long hamming_clock_launches;   // launches recorded into the clock ring so far
+    int opt_hamming_train01;        // 1 = {0, +1} train fragments in the static LDS-ring kernel (accumulator = pop(query) - distance), 0 = +-1
     int dbg_stamp_items;
     int opt_ransac_chunk;           // hypotheses per device pass (0 = 32768)
     int opt_ransac_event_cap;       // tests: capacity of the record-event list of candidate / replay kernels (0 = 1024); forces their serial fallback
@@ -183,6 +187,7 @@ int pinned_batch_get(mlpl_ctx *ctx, size_t bytes, void **out);
 void hub_streams_free(void *p);
 
 constexpr int kProfMaxLaunches = 2048;
+constexpr int kClockRing = 256;  // launches the Hamming clock ring keeps
 // Records the start (phase 0) / stop (phase 1) event of one launch of kernel `id` on stream s when profiling is on.
 void prof_mark(mlpl_ctx *ctx, int id, int phase, hipStream_t s);
 

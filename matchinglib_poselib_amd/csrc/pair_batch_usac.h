@@ -65,6 +65,12 @@ int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, c
     // pinned: counts | active | E | pose | (PROSAC) the matching costs
     const size_t pin_counts = 0, pin_act = (size_t)B * 4, pin_E = ((size_t)B * 8 + 255) / 256 * 256, pin_pose = pin_E + (size_t)B * 72,
                  pin_match = (pin_pose + (size_t)B * sizeof(PairPoseDev) + 255) / 256 * 256, pin_end = pin_match + (prosac ? (size_t)B * n * 4 : 0);
+    rc = mlpl_match_hamming_dev(ctx, d_q, nq, (size_t)nbytes, (size_t)nq * nbytes, d_t, nt, (size_t)nbytes, (size_t)nt * nbytes, nbytes, 1, 0.75f, B,
+                                (int32_t *)(b0 + off_idx), (int32_t *)(b0 + off_dist), d_m, d_counts, s);
+    if (rc) return rc;
+    // The pinned block is taken AFTER the matching call and belongs to this entry until it returns: pinned_get frees and reallocates when
+    // it grows, so no pointer into it may live across a nested entry that asks for more (the matcher no longer touches it at all; the
+    // batched estimators below run on pinned_batch, their own block).
     void *pin;
     if ((rc = pinned_get(ctx, pin_end + 256, &pin))) return rc;
     char *hp = (char *)pin;
@@ -72,10 +78,6 @@ int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, c
     double *h_E = (double *)(hp + pin_E);
     PairPoseDev *h_pose = (PairPoseDev *)(hp + pin_pose);
     const float *h_cost = (const float *)(hp + pin_match);
-
-    rc = mlpl_match_hamming_dev(ctx, d_q, nq, (size_t)nbytes, (size_t)nq * nbytes, d_t, nt, (size_t)nbytes, (size_t)nt * nbytes, nbytes, 1, 0.75f, B,
-                                (int32_t *)(b0 + off_idx), (int32_t *)(b0 + off_dist), d_m, d_counts, s);
-    if (rc) return rc;
     MLPL_HIP_TRY(hipMemcpyAsync(h_counts, d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, s));
     if (prosac) {  // the costs of the matches, through the (now free) table of nearest-neighbour indices
         float *d_cost = (float *)(b0 + off_idx);
@@ -126,7 +128,10 @@ int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, c
             return rc;
         for (int b = 0; b < B; ++b) results[(size_t)b * 12 + 1] = 0, results[(size_t)b * 12 + 5] = ninl[b];
     }
-    // (usac_essential_batch_dev took the context's small pinned block for nothing; the pointers above are still valid: pinned_get only grows)
+    if (ctx->pinned != pin) {  // a nested entry must not have replaced the block these pointers look into
+        set_error("pair batch (USAC / ARRSAC): the context's pinned block was reallocated by a nested call");
+        return MLPL_E_INTERNAL;
+    }
     for (int b = 0; b < B; ++b) {
         if (!h_active[b]) continue;
         if (status[b] == MLPL_E_FAILED) {

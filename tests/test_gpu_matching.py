@@ -373,17 +373,24 @@ def test_l2_device_batched(ctx, oracle):
         assert np.array_equal(idx[b].cpu().numpy(), oi) and dist[b].cpu().numpy().tobytes() == od.tobytes(), b
 
 
-# (hamming_variant, hamming_mfma_qt)
+# (hamming_variant, hamming_mfma_qt[, hamming_train01: the other encoding of the train operand, -1 = the library default])
 HAMMING_VARIANTS = {
     "valu_lds_tiled": (0, 0), "valu_scalar_operand": (1, 0), "valu_one_wave_blocks": (2, 0),
     "mfma_fp4": (3, 0), "mfma_fp4_qt4": (3, 4), "mfma_fp4_qt2": (3, 2), "mfma_fp4_qt1": (3, 1),
+    "mfma_fp4_train01": (3, 0, 1), "mfma_fp4_qt2_train01": (3, 2, 1), "mfma_fp4_qt1_train01": (3, 1, 1), "mfma_fp4_qt4_train01": (3, 4, 1),
+    "mfma_fp4_train_pm1": (3, 0, 0), "mfma_fp4_qt2_train_pm1": (3, 2, 0),
 }
 HAMMING_DEFAULT = (3, 0)   # the library default: matrix-core kernel, automatic query tiles per wave
+HAMMING_TRAIN01_DEFAULT = None   # the library's default encoding of the train operand (1 = {0, +1}; 0 = +-1): read from the context
 
 
 def _set_hamming(ctx, cfg):
     ctx.set_option("hamming_variant", cfg[0])
     ctx.set_option("hamming_mfma_qt", cfg[1])
+    global HAMMING_TRAIN01_DEFAULT
+    if HAMMING_TRAIN01_DEFAULT is None:   # the library's default encoding of the train operand, read before the first change
+        HAMMING_TRAIN01_DEFAULT = ctx.get_option("hamming_train01")
+    ctx.set_option("hamming_train01", cfg[2] if len(cfg) > 2 else HAMMING_TRAIN01_DEFAULT)
 
 
 @pytest.mark.parametrize("variant", sorted(HAMMING_VARIANTS))
@@ -425,7 +432,7 @@ def test_hamming_every_kernel_variant_bit_exact(ctx, oracle, variant):
         _set_hamming(ctx, HAMMING_DEFAULT)
 
 
-@pytest.mark.parametrize("variant", ["mfma_fp4", "mfma_fp4_qt2"])
+@pytest.mark.parametrize("variant", ["mfma_fp4", "mfma_fp4_qt2", "mfma_fp4_train01", "mfma_fp4_train_pm1"])
 def test_c2_full_size_matrix_core_equals_valu(ctx, oracle, variant):
     """BASELINE C2 (8192 x 8192 x 256 bit): the matrix-core kernel against the VALU kernel (itself oracle-checked on samples)."""
     q, t = synth.orb_pair(8192, 8192, seed=20260102)
@@ -479,3 +486,20 @@ def test_hamming_property_random_shapes_and_ties(ctx, oracle):
 
     _set_hamming(ctx, HAMMING_DEFAULT)
     check()
+
+
+def test_hamming_fused_epilogue_survives_a_dynamic_split_call_between_two_fused_calls(ctx, oracle):
+    """the ticket counters of the fused split merge shared a workspace slot with the chunk counters of the dynamic-split
+    kernel (hamming_mfma_lds = 2), which leaves them non-zero.  A fused call with several splits, a dynamic-split call, a fused call again:
+    all three return the oracle's pairs."""
+    q, t = synth.orb_pair(2048, 6000, seed=4242)     # 64 query tiles: several train splits on 256 CUs
+    oi, od = oracle.knn_hamming(q[::16], t)
+    try:
+        for lds in (1, 2, 1, 2, 1):
+            ctx.set_option("hamming_mfma_lds", lds)
+            idx, dist = mpa.knn_hamming(q, t, ctx=ctx)
+            assert np.array_equal(idx[::16], oi) and np.array_equal(dist[::16], od), lds
+            err, m = mpa.getMatches([None] * 2048, [None] * 6000, q, t, matcher_name="LINEAR", ctx=ctx)
+            assert err == 0 and np.array_equal(m["trainIdx"], idx[m["queryIdx"], 0])
+    finally:
+        ctx.set_option("hamming_mfma_lds", 1)

@@ -34,6 +34,7 @@ while time.time() - t0 < budget:
     i0, d0 = mpa.knn_hamming(q, t, k=k, ctx=ctx)
     ctx.set_option("hamming_variant", 3)
     ctx.set_option("hamming_mfma_qt", int(rng.choice([0, 1, 2, 4])))
+    ctx.set_option("hamming_train01", int(rng.choice([0, 1])))   # both encodings of the train operand
     i3, d3 = mpa.knn_hamming(q, t, k=k, ctx=ctx)
     if not (np.array_equal(i0, i3) and np.array_equal(d0, d3)):
         print("MISMATCH", nq, nt, nbytes, k, alphabet, flush=True)
