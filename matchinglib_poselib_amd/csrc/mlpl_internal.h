@@ -120,6 +120,7 @@ struct mlpl_ctx {
     int opt_ransac_chunk;           // hypotheses per device pass (0 = 32768)
     int opt_ransac_event_cap;       // tests: capacity of the record-event list of candidate / replay kernels (0 = 1024); forces their serial fallback
     int opt_ransac_count_mpl;       // models per lane of the packed-fp32 counting kernel: 2 (default) or 1
+    int opt_ransac_count_defer;     // 1 (default) = the packed-fp32 counting kernel queues its undecided evaluations in LDS and decides them workgroup-wide (same counts)
     int opt_ransac_f32_filter;      // 1 (default) = the count-only scoring kernels pre-filter in packed fp32 inside a rigorous error band (same counts)
     int opt_ransac_overlap;         // 1 (default) = large passes run their root kernels on the helper stream
     int opt_ransac_lazy_sums;       // 1 (default) = division-free inlier counts + error sums only for models that can still win

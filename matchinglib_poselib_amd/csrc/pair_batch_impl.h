@@ -263,7 +263,12 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
         prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
         {
             const int point_splits = std::max(1, std::min(8, ((max_n + kScoreTile - 1) / kScoreTile) / 2));
-            if (ctx->opt_ransac_count_mpl == 2) {
+            if (ctx->opt_ransac_count_mpl == 2 && ctx->opt_ransac_count_defer) {
+                const dim3 grid((Hp * 10 + 2 * kScoreModels - 1) / (2 * kScoreModels), point_splits, A);
+                hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile, 2, true>), grid, dim3(kScoreThreads), 0, s, (const double4 *)nullptr, 0,
+                                   (const double *)d_denseE, (const int32_t *)d_dense_id, (const int32_t *)d_dense_total, 0, thresh2, qmax, d_good,
+                                   (const PairSlot *)d_slots, Hp);
+            } else if (ctx->opt_ransac_count_mpl == 2) {
                 const dim3 grid((Hp * 10 + 2 * kScoreModels - 1) / (2 * kScoreModels), point_splits, A);
                 hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile, 2>), grid, dim3(kScoreThreads), 0, s, (const double4 *)nullptr, 0,
                                    (const double *)d_denseE, (const int32_t *)d_dense_id, (const int32_t *)d_dense_total, 0, thresh2, qmax, d_good,

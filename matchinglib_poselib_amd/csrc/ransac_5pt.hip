@@ -1403,8 +1403,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // and was slower (0.34 against 0.27 ms at C3); with the fp64 copy of the model no longer held across the loop (the rare undecided
 // evaluation reads it again) it needs 126, keeps four waves per SIMD and is 1-4 % faster (C3 0.283 against 0.285-0.309 ms, C5 counting
 // 3.22-3.27 against 3.36 ms per 512 pairs; tools/count_mpl_ab.py, same counts) -- the LDS reads were not what the loop waits for.
-template <int kThreads, int kTile, int MPL = 1>
-__global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
+// DEFER (option ransac_count_defer, round 5; default).  Round 4 found that a build WITHOUT the fp64 path (wrong counts) runs the C3 pass in 0.25
+// instead of 0.33 ms although only ~3e-5 of the evaluations take that path: what it costs is its presence in the loop (registers, code, the
+// waits around it), not its executions.  Here the loop holds no fp64 code at all: an evaluation the band does not decide is QUEUED in LDS
+// as (model of the workgroup, correspondence) -- one LDS atomic and one LDS store on the undecided lanes -- and the queue is decided after
+// the tile loop by all threads of the workgroup, one entry per thread: the same predicate on the same operands, its verdict added to the
+// model's count through an LDS counter.  Same counts by construction (a sum of the same 0 / 1 verdicts).  A queue that overflows
+// (kDeferCap entries; a band that is infinite -- out-of-range scales -- queues everything) makes the workgroup recount its share in fp64
+// afterwards, outside the loop as well.
+constexpr int kDeferCap = 2048;
+template <int kThreads, int kTile, int MPL = 1, bool DEFER = false>
+__global__ __launch_bounds__(kThreads, (DEFER ? 4 : 1)) void count_models_f32_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
                                                                     const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
                                                                     int total_host, double thresh2, double qmax, int32_t *__restrict__ good,
                                                                     const PairSlot *__restrict__ ps = nullptr, int slot_stride = 0) {
@@ -1417,12 +1426,19 @@ __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double
     // (x1a,x1b, y1a,y1b, x2a,x2b, y2a,y2b) with two ds_read_b128 and (KPs_a, KPs_b) with one ds_read_b64
     __shared__ __attribute__((aligned(16))) float tile_xy[(kTile / 2) * 8];
     __shared__ __attribute__((aligned(8))) float tile_k[(kTile / 2) * 2];
+    constexpr int kPerBlock = (kThreads / 4) * MPL;
+    __shared__ uint32_t dq[DEFER ? kDeferCap : 1];        // (model of this workgroup) << 23 | correspondence
+    __shared__ int dq_n[2];                               // entries pushed (may exceed the capacity: overflow) | unused
+    __shared__ int dq_cnt[DEFER ? kPerBlock : 1];         // inliers the deferred evaluations add to the workgroup's models
     const double *__restrict__ kp64 = reinterpret_cast<const double *>(pts + n);
     const float *__restrict__ rec = reinterpret_cast<const float *>(kp64 + n);
     const int total = total_ptr ? *total_ptr : total_host;
-    constexpr int kPerBlock = (kThreads / 4) * MPL;
     if (blockIdx.x * kPerBlock >= total) return;  // block-uniform
     const int tid = threadIdx.x;
+    if constexpr (DEFER) {
+        for (int i = tid; i < kPerBlock; i += kThreads) dq_cnt[i] = 0;
+        if (tid < 2) dq_n[tid] = 0;   // (visible behind the first barrier of the tile loop, before anyone pushes)
+    }
     const int j = tid & 3;
     const int m0 = blockIdx.x * kPerBlock + (tid >> 2) * MPL;
     const double u = 0x1p-24;
@@ -1458,6 +1474,17 @@ __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double
         return sampson_inlier_fma(e, model_band(e, qmax), p.x, p.y, p.z, p.w, kp64[i], qmax, thresh2) ? 1 : 0;
     };
     const f32x2 Q = {(float)qmax, (float)qmax}, C6 = {0x1p-6f * 1.02f, 0x1p-6f * 1.02f};
+    // deferred evaluations: the push (lane-divergent, a few LDS instructions; the verdict comes later through dq_cnt)
+    const int ml0 = (tid >> 2) * MPL;  // first model of this lane within the workgroup
+    auto undecided = [&](int mi, int i) -> int {
+        if constexpr (DEFER) {
+            const int k = atomicAdd(&dq_n[0], 1);
+            if (k < kDeferCap) dq[k] = ((uint32_t)(ml0 + mi) << 23) | (uint32_t)i;   // (n < 2^23: the launcher's condition for this instance)
+            return 0;
+        } else {
+            return exact(mi, i);
+        }
+    };
     // (Measured and not kept, round 4: fetching the NEXT tile into registers while the current one is evaluated -- no change: with two
     // workgroups per CU the other workgroup's evaluation already covers a tile's load latency.)
     for (int base = blockIdx.y * kTile; base < n; base += kTile * gridDim.y) {
@@ -1501,10 +1528,10 @@ __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double
                     const bool c0 = in0 || diff.x > H.x, c1 = in1 || diff.y > H.y;
                     cnt[mi] += in0 ? 1 : 0;
                     cnt[mi] += in1 ? 1 : 0;
-                    if (__builtin_expect(!(c0 && c1), 0)) {  // inside the band (or out of range): the fp64 predicate decides
+                    if (__builtin_expect(live[mi] && !(c0 && c1), 0)) {  // inside the band (or out of range): the fp64 predicate decides
                         const int i0 = base + 4 * (2 * q) + j, i1 = i0 + 4;
-                        if (!c0) cnt[mi] += exact(mi, i0);
-                        if (!c1) cnt[mi] += exact(mi, i1);
+                        if (!c0) cnt[mi] += undecided(mi, i0);
+                        if (!c1) cnt[mi] += undecided(mi, i1);
                     }
                 }
             }
@@ -1512,9 +1539,35 @@ __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double
                 const int i0 = base + 4 * (nk - 1) + j;
 #pragma unroll
                 for (int mi = 0; mi < MPL; ++mi)
-                    if (live[mi]) cnt[mi] += exact(mi, i0);
+                    if (live[mi]) cnt[mi] += undecided(mi, i0);
             }
         }
+    }
+    if constexpr (DEFER) {
+        __syncthreads();
+        const int pushed = dq_n[0];
+        if (pushed <= kDeferCap) {  // the queue: one entry per thread, the fp64 predicate on the same operands
+            for (int k = tid; k < pushed; k += kThreads) {
+                const uint32_t e = dq[k];
+                const int ml = (int)(e >> 23), i = (int)(e & 0x7FFFFFu);
+                double ee[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) ee[q] = E_list[(size_t)(blockIdx.x * kPerBlock + ml) * 9 + q];
+                const double4 p = pts[i];
+                if (sampson_inlier_fma(ee, model_band(ee, qmax), p.x, p.y, p.z, p.w, kp64[i], qmax, thresh2)) atomicAdd(&dq_cnt[ml], 1);
+            }
+        } else {  // overflow (workgroup-uniform): this workgroup's share once more, every evaluation by the fp64 predicate
+#pragma unroll
+            for (int mi = 0; mi < MPL; ++mi) cnt[mi] = 0;
+            for (int base = blockIdx.y * kTile; base < n; base += kTile * gridDim.y) {
+                const int rows = min(kTile, n - base);
+                for (int i = base + j; i < base + rows; i += 4)
+#pragma unroll
+                    for (int mi = 0; mi < MPL; ++mi)
+                        if (live[mi]) cnt[mi] += exact(mi, i);
+            }
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int mi = 0; mi < MPL; ++mi) {
@@ -1522,6 +1575,7 @@ __global__ __launch_bounds__(kThreads) void count_models_f32_kernel(const double
         c += __shfl_xor(c, 1);
         c += __shfl_xor(c, 2);
         if (live[mi] && j == 0) {
+            if constexpr (DEFER) c += dq_cnt[ml0 + mi];
             const int o = ids ? ids[m0 + mi] : m0 + mi;
             if (gridDim.y > 1) atomicAdd(&good[o], c);
             else good[o] = c;
@@ -2972,7 +3026,7 @@ double inlier_bound(double thresh2) {
 constexpr int kScoreBlockMaxModels = 24576;
 static void launch_score(hipStream_t s, const double4 *pts, int n, const double *E_list, const int32_t *ids, const int32_t *total_ptr,
                          int total_host, int max_models, double thresh2, int32_t *good, double *esum, bool sums = true,
-                         double qmax = -1.0, int point_splits = 1, bool f32_filter = false, int mpl = 1) {
+                         double qmax = -1.0, int point_splits = 1, bool f32_filter = false, int mpl = 1, bool defer = false) {
     if (max_models <= 0) return;
     const size_t lds = (size_t)((n + 3) / 4 * 4) * sizeof(float);
     const bool block = n <= kScoreBlockMaxN && max_models <= kScoreBlockMaxModels;
@@ -2996,7 +3050,10 @@ static void launch_score(hipStream_t s, const double4 *pts, int n, const double 
                                ids, total_ptr, total_host, thresh2, qmax, good, esum);
     } else {
         const dim3 grid((max_models + kScoreModels - 1) / kScoreModels, point_splits);
-        if (f32_filter && mpl == 2)
+        if (f32_filter && mpl == 2 && defer && n < (1 << 23))
+            hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile, 2, true>), dim3((max_models + 2 * kScoreModels - 1) / (2 * kScoreModels), point_splits),
+                               dim3(kScoreThreads), 0, s, pts, n, E_list, ids, total_ptr, total_host, thresh2, qmax, good);
+        else if (f32_filter && mpl == 2)
             hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile, 2>), dim3((max_models + 2 * kScoreModels - 1) / (2 * kScoreModels), point_splits),
                                dim3(kScoreThreads), 0, s, pts, n, E_list, ids, total_ptr, total_host, thresh2, qmax, good);
         else if (f32_filter)
@@ -3254,7 +3311,11 @@ static int score_models_impl(mlpl_ctx *ctx, const double *p1, const double *p2, 
     if ((rc = pack_points(ctx, (const double *)dp1, (const double *)dp2, n, &pts, s))) return rc;
     prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
     const double qmax = inlier_bound(thresh2);
-    if (shape == 1 && !err_sum && ctx->opt_ransac_f32_filter && ctx->opt_ransac_count_mpl == 2)
+    if (shape == 1 && !err_sum && ctx->opt_ransac_f32_filter && ctx->opt_ransac_count_mpl == 2 && ctx->opt_ransac_count_defer && n < (1 << 23))
+        hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile, 2, true>), dim3((n_models + 2 * kScoreModels - 1) / (2 * kScoreModels)), dim3(kScoreThreads), 0, s,
+                           (const double4 *)pts, n, (const double *)dE, (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, thresh2, qmax,
+                           (int32_t *)dgood);
+    else if (shape == 1 && !err_sum && ctx->opt_ransac_f32_filter && ctx->opt_ransac_count_mpl == 2)
         hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile, 2>), dim3((n_models + 2 * kScoreModels - 1) / (2 * kScoreModels)), dim3(kScoreThreads), 0, s,
                            (const double4 *)pts, n, (const double *)dE, (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, thresh2, qmax,
                            (int32_t *)dgood);
@@ -3473,7 +3534,8 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         }
         prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
         launch_score(s, (const double4 *)pts, n, (const double *)B.dense_E, (const int32_t *)B.dense_id, (const int32_t *)B.total, 0,
-                     cnt * 10, thresh2, B.good, B.esum, !lazy, qmax, point_splits, ctx->opt_ransac_f32_filter != 0, ctx->opt_ransac_count_mpl);
+                     cnt * 10, thresh2, B.good, B.esum, !lazy, qmax, point_splits, ctx->opt_ransac_f32_filter != 0, ctx->opt_ransac_count_mpl,
+                     ctx->opt_ransac_count_defer != 0);
         if (lazy) {
             // error sums only for the models that can still win (ties on the inlier count are decided by them)
             const bool sep = cnt > 2048;  // many hypotheses: per-hypothesis maxima in a grid-wide pass first

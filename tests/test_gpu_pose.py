@@ -354,17 +354,51 @@ def test_fp32_prefilter_counts_at_every_scale(ctx, oracle, scale, escale):
         assert np.array_equal(got[1], want), (scale, escale, frac, got[1][:5], want[:5])
 
 
+@pytest.mark.parametrize("scale,escale", [(1.0, 1.0), (800.0, 1.0), (1.0, 1e-45), (1e13, 1.0)])
+def test_count_kernel_deferred_queue_equals_inline_and_the_cpu(ctx, oracle, scale, escale):
+    """Round 5: the counting kernel queues its undecided evaluations in LDS and decides them workgroup-wide (option ransac_count_defer,
+    default 1) instead of on the spot.  Same counts as the inline form and as the CPU arithmetic: odd and tiny model counts (an idle second
+    model of a lane), thresholds ON error values (many evaluations inside the band), scales at which the band is infinite (EVERY evaluation
+    undecided: the queue overflows and the inline path takes the rest) and a point count above one tile."""
+    p1, p2, R, t, mask, th = synth.pose_scene(2600, seed=321)
+    samples = oracle.sample_table(11, p1, p2, 40)
+    Es_all = np.concatenate([oracle.run5point(p1[s], p2[s]) for s in samples]) * escale
+    q1, q2 = p1 * scale, p2 * scale
+    for nm in (1, 3, 77, len(Es_all)):
+        Es = Es_all[:nm]
+        ref_err = np.stack([oracle.sampson_err(q1, q2, E).astype(np.float64) for E in Es])
+        finite = np.isfinite(ref_err)
+        t2s = [float(np.quantile(ref_err[finite], f)) for f in (0.2, 0.6)] if finite.any() else [1.0]
+        t2s += [float(v) for v in np.sort(ref_err[0][np.isfinite(ref_err[0])])[[5, 1300]]] if np.isfinite(ref_err[0]).sum() > 1400 else []
+        for t2 in t2s:
+            if not (t2 > 0 and np.isfinite(t2)):
+                continue
+            want = (ref_err <= t2).sum(axis=1)
+            got = {}
+            for d in (1, 0):
+                ctx.set_option("ransac_count_defer", d)
+                try:
+                    got[d] = pose.count_models(q1, q2, Es, t2, shape=1, ctx=ctx)
+                finally:
+                    ctx.set_option("ransac_count_defer", 1)
+            assert np.array_equal(got[1], got[0]), (scale, escale, nm, t2)
+            assert np.array_equal(got[1], want), (scale, escale, nm, t2, got[1][:5], want[:5])
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_ransac_with_and_without_the_fp32_prefilter(ctx, oracle, seed):
     p1, p2, R, t, mask, th = synth.pose_scene(4000, inlier_frac=0.35, seed=900 + seed)
     runs = []
-    for f in (1, 0):
+    for f, d in ((1, 1), (0, 1), (1, 0)):   # packed-fp32 filter with the deferred queue (default), pure fp64, filter with the inline fp64 path
         ctx.set_option("ransac_f32_filter", f)
+        ctx.set_option("ransac_count_defer", d)
         try:
             runs.append(pose.ransac_essential(p1, p2, th, confidence=0.999, max_iters=6000, refit=False, seed=seed, ctx=ctx))
         finally:
             ctx.set_option("ransac_f32_filter", 1)
-    a, b = runs
+            ctx.set_option("ransac_count_defer", 1)
+    a, b, c = runs
+    assert a["iters"] == c["iters"] and a["n_inliers"] == c["n_inliers"] and np.array_equal(a["E"], c["E"]) and np.array_equal(a["mask"], c["mask"])
     assert a["iters"] == b["iters"] and a["n_inliers"] == b["n_inliers"] and np.array_equal(a["E"], b["E"]) and np.array_equal(a["mask"], b["mask"])
     o = oracle.ransac_essential(p1, p2, th, confidence=0.999, max_iters=6000, lesqu=False, seed=seed)
     assert a["iters"] == o["iters"] and a["n_inliers"] == o["n_inliers"] and np.array_equal(a["mask"], o["mask"])

@@ -24,8 +24,9 @@ stk = [torch.from_numpy(np.stack([sps[i % 8][k] for i in range(total)])).to(dev)
 seeds = [100 + i for i in range(total)]
 ref = {}
 for rnd in range(2):
-    for mpl in (1, 2):
+    for mpl, defer in ((2, 0), (2, 1), (1, 0)):
         ctx.set_option("ransac_count_mpl", mpl)
+        ctx.set_option("ransac_count_defer", defer)
         call = lambda: pose.ransac_essential_device(d1, d2, th, confidence=1.0, max_iters=iters, refit=False, seed=12345, ctx=ctx, mask_out=dm)
         r = call(); torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -46,4 +47,4 @@ for rnd in range(2):
         batch.process_pairs_batched(ctx, *stk, K, K, seeds); torch.cuda.synchronize(); ctx.lib.mlpl_profile_enable(ctx.handle, 0)
         s5, s5n = prof(3)
         assert ref.setdefault("c5", rec.tobytes()) == rec.tobytes()
-        print(f"round {rnd} mpl {mpl}: C3 call {dt * 1e3:.3f} ms, counting pass {sc / 5:.3f} ms per call; C5 512 pairs {min(ts) * 1e3:.2f} ms (median {np.median(ts) * 1e3:.2f}), counting {s5:.3f} ms per step ({s5n} launches)", flush=True)
+        print(f"round {rnd} mpl {mpl} defer {defer}: C3 call {dt * 1e3:.3f} ms, counting pass {sc / 5:.3f} ms per call; C5 512 pairs {min(ts) * 1e3:.2f} ms (median {np.median(ts) * 1e3:.2f}), counting {s5:.3f} ms per step ({s5n} launches)", flush=True)

@@ -29,6 +29,7 @@ while time.time() - t0 < budget:
     t2 = float(th * th * 10 ** rng.uniform(-2, 2))
     good, esum = pose.score_models(p1, p2, E, np.sqrt(t2), ctx=ctx)
     t2 = float(np.sqrt(t2)) ** 2        # score_models squares its argument: use exactly that value
+    ctx.set_option("ransac_count_defer", int(rng.integers(0, 2)))   # the deferred queue of the counting kernel and its inline form
     for shape in (1, 2):
         c = pose.count_models(p1, p2, E, t2, shape=shape, ctx=ctx)
         if not np.array_equal(c, good):
