@@ -513,6 +513,11 @@ int mlpl_debug_hamming_stamps(mlpl_ctx *ctx, unsigned long long *out, int max_it
  * per launch; nothing else changes).  Copies the records of the last min(max_items, 256, launches so far) launches, oldest first, and
  * returns their number (synchronises the device).  Shader clock of a launch = cycles / ticks * 100 MHz. */
 int mlpl_debug_hamming_clock(mlpl_ctx *ctx, unsigned long long *out, int max_items);
+/* Diagnostics: the host-hop timeline of the last mlpl_pair_pose_batch_dev / mlpl_ransac_essential_batch_dev call of this context:
+ * us[i] = microseconds since the call's entry, codes[i] = 1 matching enqueued, 2 match counts back, 3 / 4 a RANSAC pass enqueued / its
+ * states back, 5 / 6 pose step enqueued / back; *ws_grows = workspace blocks (re)allocated by this context so far.  Returns the number
+ * of entries written (<= max_items). */
+int mlpl_debug_hop_trace(mlpl_ctx *ctx, float *us, int *codes, int max_items, long long *ws_grows);
 
 /* ---- cheirality / pose recovery --------------------------------------------------------------------------
  * Replaces poselib::getPoseTriangPts (P/source/pose_estim.cpp:913-946) = recoverPose

@@ -120,6 +120,7 @@ _SIGNATURES = {
     "mlpl_debug_dk_stats": (c_int, [c_void_p, c_int, c_void_p]),
     "mlpl_debug_hamming_stamps": (c_int, [c_void_p, c_void_p, c_int]),
     "mlpl_debug_hamming_clock": (c_int, [c_void_p, c_void_p, c_int]),
+    "mlpl_debug_hop_trace": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mlpl_pair_pose_dev": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
                                    c_int, c_double, c_int, c_u32, c_double, c_void_p, c_void_p]),
     "mlpl_pair_pose_batch_dev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double,

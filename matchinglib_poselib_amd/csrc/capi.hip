@@ -27,6 +27,7 @@ int ws_get(mlpl_ctx *ctx, WsSlot slot, size_t bytes, void **out) {
         if (ctx->ws[slot]) MLPL_HIP_TRY(hipFree(ctx->ws[slot]));
         ctx->ws[slot] = nullptr;
         ctx->ws_bytes[slot] = 0;
+        ctx->ws_grows++;
         size_t want = bytes + bytes / 4;
         want = (want + 255) & ~size_t(255);
         hipError_t e = hipMalloc(&ctx->ws[slot], want);
@@ -46,6 +47,7 @@ int pinned_get(mlpl_ctx *ctx, size_t bytes, void **out) {
         if (ctx->pinned) MLPL_HIP_TRY(hipHostFree(ctx->pinned));
         ctx->pinned = nullptr;
         ctx->pinned_bytes = 0;
+        ctx->ws_grows++;
         size_t want = std::max<size_t>(bytes * 2, 4096);
         hipError_t e = hipHostMalloc(&ctx->pinned, want, hipHostMallocMapped);
         if (e != hipSuccess) {
@@ -283,6 +285,17 @@ int mlpl_debug_hamming_stamps(mlpl_ctx *ctx, unsigned long long *out, int max_it
     }
     const int n = ctx->dbg_stamp_items < max_items ? ctx->dbg_stamp_items : max_items;
     if (n > 0 && ctx->ws[WS_DEBUG]) MLPL_HIP_TRY(hipMemcpy(out, ctx->ws[WS_DEBUG], (size_t)n * 32, hipMemcpyDeviceToHost));
+    return n;
+}
+
+int mlpl_debug_hop_trace(mlpl_ctx *ctx, float *us, int *codes, int max_items, long long *ws_grows) {
+    if (!ctx) return MLPL_E_BAD_INPUT;
+    const int n = ctx->hop_n < max_items ? ctx->hop_n : max_items;
+    for (int i = 0; i < n; ++i) {
+        if (us) us[i] = ctx->hop_us[i];
+        if (codes) codes[i] = ctx->hop_code[i];
+    }
+    if (ws_grows) *ws_grows = ctx->ws_grows;
     return n;
 }
 

@@ -155,6 +155,9 @@ struct mlpl_ctx {
     unsigned *usac_prosac_tab;                         // calloc'ed, 1001 entries: PROSAC's non-randomness table of the last (beta, confidence) (usac_impl.h init_prosac)
     unsigned usac_prosac_tab_top;
     double usac_prosac_tab_beta, usac_prosac_tab_conf;
+    float hop_us[48];                                  // diagnostics: microseconds since entry of the last mlpl_pair_pose_batch_dev call at its host hops ...
+    int hop_code[48], hop_n;                           // ... 1 launches enqueued, 2 match counts back, 3 / 4 a pass enqueued / its states back, 5 / 6 pose enqueued / back
+    long long ws_grows;                                // workspace / pinned blocks (re)allocated so far (a hipMalloc inside a call shows up here)
     long long last_batch_stats[8];                     // mlpl_pair_pose_batch_dev: {RANSAC passes, pair slots over all passes, pairs redone on a host table, 0}
     int opt_pair_batch;                                // pairs per internal batch of mlpl_pair_pose_batch_dev (0 = 256)
     int opt_pair_batch_seq;                            // ... of mlpl_pair_pose_batch_usac_dev / _arrsac_dev (0 = 512)

@@ -119,6 +119,15 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
                         uint8_t *d_masks_ext = nullptr) {
     const bool points_mode = d_q == nullptr;
     const int min_count = points_mode ? 6 : 16;  // mlpl_ransac_essential's limit / the reference's working minimum for a matched pair
+    // host-hop timeline of this call (diagnostics, mlpl_debug_hop_trace): microseconds since entry at which each wait on the stream returned
+    const auto t_entry = std::chrono::steady_clock::now();
+    ctx->hop_n = 0;
+    auto hop = [&](int code) {
+        if (ctx->hop_n < (int)(sizeof(ctx->hop_us) / sizeof(ctx->hop_us[0]))) {
+            ctx->hop_us[ctx->hop_n] = (float)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_entry).count() * 1e-3f;
+            ctx->hop_code[ctx->hop_n++] = code;
+        }
+    };
     const int NQ = nq;
     const size_t n = (size_t)NQ;
     int rc;
@@ -207,7 +216,9 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
         }
         draw_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_draw0).count();
     }
+    hop(1);   // workspace, launches of the matching step and the raw random streams are behind us
     if (!points_mode) MLPL_HIP_TRY(hipStreamSynchronize(s));  // hop 1: the match counts
+    hop(2);
     std::vector<int> alive;
     for (int b = 0; b < B; ++b) {
         std::memset(&out[b], 0, sizeof(out[b]));
@@ -296,7 +307,9 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
         MLPL_HIP_TRY(hipGetLastError());
         MLPL_HIP_TRY(hipMemcpyAsync(h_st, d_st, (size_t)B * sizeof(ReplayState), hipMemcpyDeviceToHost, s));
         MLPL_HIP_TRY(hipMemcpyAsync(h_ovf, d_rng_ovf, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+        hop(3);
         MLPL_HIP_TRY(hipStreamSynchronize(s));  // one hop per pass: which pairs go on
+        hop(4);
         passes++, slots_total += A;
         base += H;
         std::vector<int> next;
@@ -345,7 +358,9 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
                 prof_mark(ctx, MLPL_PROF_RECOVER_POSE, 1, s);
                 MLPL_HIP_TRY(hipMemcpyAsync(h_pose, d_pose, (size_t)B * sizeof(PairPoseDev), hipMemcpyDeviceToHost, s));
             }
+            hop(5);
             MLPL_HIP_TRY(hipStreamSynchronize(s));  // last hop
+            hop(6);
             for (int b : act) {
                 mlpl_pair_result &o = out[b];
                 o.status = 0, o.iters = state[b].iter, o.n_inliers = state[b].maxGood, o.n_good = want_pose ? h_pose[b].n_good : 0;

@@ -2238,6 +2238,38 @@ __device__ __forceinline__ int smallest_eigvec9_wave(const double *Gp, double di
     double lam = 0;
 #pragma unroll
     for (int m = 0; m < 9; ++m) lam += bcast_f64(x * gx, m);
+    // Settling says that the iterates stopped moving, not where: a start without a component along the smallest eigenvector --
+    // a cold start against a vector whose entries sum to zero, a warm start after a large change of the weights -- can sit on the
+    // second-smallest one until rounding brings the component back.  Two certificates, or the caller's Jacobi path:
+    // (i) (lam, x) is an eigenpair of G to rounding: |G x - lam x| <= 2^-40 trace;
+    // (ii) lam is THE smallest eigenvalue and separated: G - (lam + 2^-40 trace) I has exactly one negative pivot in its L D L^T
+    //     factorisation (Sylvester's law of inertia; a zero or non-finite pivot refuses).
+    const double mu = trace * 0x1p-40;
+    double rmax = 0;
+#pragma unroll
+    for (int m = 0; m < 9; ++m) rmax = fmax(rmax, bcast_f64(fabs(gx - lam * x), m));
+    if (!(rmax <= mu)) return 0;
+    {
+        double b[9], ll[9], dk[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) b[k] = g[k] - ((i == k) ? lam + mu : 0.0), ll[k] = 0, dk[k] = 0;
+        int neg = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            double sdiag = b[j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sdiag -= ll[k] * ll[k] * dk[k];
+            const double dj = bcast_f64(sdiag, j);
+            if (!(dj != 0.0) || !(fabs(dj) < 1e300)) return 0;  // wave-uniform
+            neg += dj < 0 ? 1 : 0;
+            dk[j] = dj;
+            double t = b[j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= ll[k] * bcast_f64(ll[k], j) * dk[k];
+            ll[j] = (i > j) ? t / dj : 0.0;
+        }
+        if (neg != 1) return 0;
+    }
     if (lane < 9) x_out[lane] = x;
     if (lane == 0) *lambda_out = lam;
     return it;

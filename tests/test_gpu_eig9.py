@@ -83,3 +83,41 @@ def test_refuses_a_double_smallest_eigenvalue_and_bad_input(ctx):
     if out[0, 0] > 0:
         x = out[0, 3:]
         assert np.linalg.norm(G_double @ x - 1e-3 * x) < 1e-12
+
+
+def test_never_settles_on_the_second_smallest_eigenvector(ctx):
+    """convergence was accepted from the iterate differences alone.  Matrices whose smallest eigenvector has NO component along
+    the cold start (entries sum to zero) or along a given warm start (the second-smallest eigenvector itself, exactly): the routine must
+    return the smallest eigenvector or refuse (steps = 0: the callers then take the Jacobi path) -- never another eigenvector."""
+    rng = np.random.default_rng(11)
+    Gs, starts, truth = [], [], []
+    for k in range(200):
+        M = rng.standard_normal((9, 9))
+        M[:, 0] -= M[:, 0].mean()                      # first column orthogonal to the constant vector
+        M[:, 0] = np.round(M[:, 0] * 64) / 64          # ... exactly (small dyadic entries: the sum is exact in floating point)
+        M[:, 0] -= np.round(M[:, 0].sum() * 64) / 64 / 9 * 0
+        if abs(M[:, 0].sum()) > 0:
+            M[8, 0] -= M[:, 0].sum()
+        Q, _ = np.linalg.qr(M)                         # Q[:, 0] is parallel to M[:, 0]
+        w = np.sort(10.0 ** rng.uniform(-6, 1, 9))
+        w[1] = max(w[1], w[0] * rng.choice([1.5, 10.0, 1e3]))
+        w[2:] = np.maximum(w[2:], w[1] * 1.2)
+        G = Q @ np.diag(w) @ Q.T
+        G = (G + G.T) / 2
+        Gs.append(G)
+        truth.append(Q[:, 0])
+        starts.append(Q[:, 1] if k % 2 else np.full(9, 1 / 3))   # warm start ON the second eigenvector / the cold start
+    G = np.stack(Gs)
+    out_cold, jac = _run(ctx, G)
+    out_warm, _ = _run(ctx, G, start=np.stack(starts))
+    for out in (out_cold, out_warm):
+        for b in range(len(G)):
+            if out[b, 0] > 0:
+                w, V = np.linalg.eigh(G[b])
+                x = out[b, 3:]
+                d = min(np.abs(x - V[:, 0]).max(), np.abs(x + V[:, 0]).max())
+                gap = (w[1] - w[0]) / w[-1]
+                assert d < 1e-15 / gap + 1e-12, (b, d, gap, out[b, 0])
+                assert abs(out[b, 1] - w[0]) <= 1e-13 * w[-1]
+    # and it still settles on ordinary inputs (the certificates must not turn the fast path off)
+    assert (out_cold[:, 0] > 0).mean() > 0.5

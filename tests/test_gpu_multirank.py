@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tmp_path, gpus):
-    out = os.path.join(str(tmp_path), f"rec{gpus}.npz")
+def _run(tmp_path, gpus, estimator="ransac"):
+    out = os.path.join(str(tmp_path), f"rec{gpus}_{estimator}.npz")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", "c5", "--c5-pairs", "16", "--c5-distinct", "16", "--n", "2048", "--steps", "1",
-           "--warmup", "1", "--no-cpu-baseline", "--dump-records", out]
+           "--warmup", "1", "--no-cpu-baseline", "--dump-records", out, "--estimator", estimator]
     if gpus > 1:
         cmd += ["--share-gpu", "--backend", "gloo"]
     env = dict(os.environ)
@@ -36,3 +36,18 @@ def test_two_ranks_give_the_one_rank_records_and_match_lists(tmp_path):
     assert one["records"].tobytes() == two["records"].tobytes()
     assert one["matches"].shape == two["matches"].shape and one["matches"].tobytes() == two["matches"].tobytes()
     assert len(one["matches"]) > 16 * 100
+
+
+@pytest.mark.parametrize("estimator", ["usac_prosac", "arrsac"])
+def test_two_ranks_with_the_sequential_estimators(tmp_path, estimator):
+    """the sharded C5 workload with the harness' default estimator (USAC, PROSAC by matching cost) and with estimateEssentialMat's
+    default (ARRSAC) -- every rank runs its share through the launch hub (fibers on its share of the host's cores) -- gathers the records and
+    match lists the one-rank run produces, byte for byte."""
+    one_line, one = _run(tmp_path, 1, estimator)
+    two_line, two = _run(tmp_path, 2, estimator)
+    assert one_line["config"]["estimator"] == estimator and two_line["config"]["estimator"] == estimator
+    ht = two_line["config"]["host_threads"]
+    assert ht["local_world_size"] == 2 and 2 <= ht["hub_workers_per_cohort"] <= 16
+    assert two_line["n_gpus"] == 2 and two_line["config"]["pairs_this_rank"] == 8
+    assert one["records"].tobytes() == two["records"].tobytes()
+    assert one["matches"].tobytes() == two["matches"].tobytes()
