@@ -147,6 +147,13 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
     # both stay in the line so that a slow first step or a slow lane is visible in the record itself).
     lib = ctx.lib
     timed = {}
+    # A step is ~10 ms of wall time with Python threads in the loop: a generation-2 garbage collection of this process' ~10^6 objects
+    # (torch, numpy) stalls every thread for 50-90 ms when it strikes (tools/lanes_tail_probe.py caught one: a 93 ms step among 9.4 ms ones).
+    # As a long-running service would, freeze what exists and keep the collector out of the timed steps.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     for mode in (("two_calls_in_flight", "one_call_at_a_time") if est == "ransac" else ("one_call_at_a_time",)):
         for _ in range(max(warmup, 2)):
             step(mode)
@@ -166,6 +173,7 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         timed[mode] = (el, per_step)
+    gc.enable()
     best_mode = min(timed, key=lambda m: timed[m][0])   # the same on every rank: the elapsed times are the maxima over the ranks
     other_mode = ([m for m in timed if m != best_mode] or [None])[0]
     elapsed = timed[best_mode][0]

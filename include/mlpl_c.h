@@ -419,6 +419,14 @@ int mlpl_pair_pose_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, const uint8_t 
 int mlpl_pair_pose_batch_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt, int nbytes, const float *d_kp1,
                              const float *d_kp2, const double K0[4], const double K1[4], double thresh, int max_iters, double confidence,
                              int refit, const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out, void *stream);
+/* mlpl_pair_pose_batch_dev (refit = 0) with `lanes` calls in flight on one GPU: lane l = (ctxs[l], streams[l]: a context and a stream of
+ * its own, same device) runs the l-th contiguous share of the batch on its own host thread inside this call, which returns when every
+ * lane has finished AND its stream is idle.  Inputs must be complete before the call (they were produced on another stream).
+ * lane_span_ms: NULL or 2 * lanes doubles {start, end} of each lane's call in milliseconds since entry (diagnostics). */
+int mlpl_pair_pose_batch_lanes_dev(mlpl_ctx *const *ctxs, void *const *streams, int lanes, int n_pairs, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt,
+                                   int nbytes, const float *d_kp1, const float *d_kp2, const double K0[4], const double K1[4], double thresh, int max_iters,
+                                   double confidence, const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out,
+                                   double *lane_span_ms);
 /*
  * The same batch with USAC -- the reference harness' default RobMethod (T/poselib-test/main.cpp:734) -- as the robust estimator:
  * matching, match counts, gather + ImgToCamCoordTrans as above, then mlpl_usac_essential_batch_dev on the pairs' correspondences (every

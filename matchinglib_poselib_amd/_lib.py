@@ -125,6 +125,8 @@ _SIGNATURES = {
                                    c_int, c_double, c_int, c_u32, c_double, c_void_p, c_void_p]),
     "mlpl_pair_pose_batch_dev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
                                          c_int, c_double, c_int, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
+    "mlpl_pair_pose_batch_lanes_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_double, c_int, c_double, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
     "mlpl_pair_pose_batch_usac_dev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                               c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
     "mlpl_pair_pose_batch_arrsac_dev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int,

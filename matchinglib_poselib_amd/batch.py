@@ -285,12 +285,48 @@ class BatchLanes:
         self.last_lane_span[w] = (t0, time.perf_counter())   # when this lane's call started and ended (diagnostics: which lane stalled)
         return r
 
-    def process(self, d_q, d_t, d_kp1, d_kp2, K0, K1, seeds, pair_ids=None, matches_out=None, **kw) -> np.ndarray:
-        """Same arguments and result as process_pairs_batched (without the context)."""
+    def process(self, d_q, d_t, d_kp1, d_kp2, K0, K1, seeds, pair_ids=None, matches_out=None, native: bool = True, th_pix: float = 0.8, max_iters: int = 1000,
+                confidence: float = 0.999, dist: float = 50.0, **kw) -> np.ndarray:
+        """Same arguments and result as process_pairs_batched (without the context).  native (default): ONE library call,
+        mlpl_pair_pose_batch_lanes_dev, whose lanes are threads inside the library -- no Python thread hand-off and no interpreter lock
+        between the lanes' calls; native = False: the lanes are Python threads (a ThreadPoolExecutor), each making its own call."""
         import torch
 
         B = d_q.shape[0]
         torch.cuda.current_stream(self.device).synchronize()  # inputs were produced on the caller's stream
+        if native and not kw:
+            assert d_q.is_cuda and d_q.dtype == torch.uint8 and d_q.dim() == 3 and d_t.dim() == 3 and d_t.shape[0] == B
+            assert d_kp1.dtype == torch.float32 and d_kp2.dtype == torch.float32 and d_kp1.shape == (B, d_q.shape[1], 2) and d_kp2.shape == (B, d_t.shape[1], 2)
+            assert d_q.is_contiguous() and d_t.is_contiguous() and d_kp1.is_contiguous() and d_kp2.is_contiguous()
+            if matches_out is not None:
+                assert matches_out.is_cuda and matches_out.dtype == torch.int32 and matches_out.shape == (B, d_q.shape[1], 4) and matches_out.is_contiguous()
+            L = self.lanes
+            ctxs = (C.c_void_p * L)(*[c.handle for c in self.ctxs])
+            strs = (C.c_void_p * L)(*[s.cuda_stream for s in self.streams])
+            k0, k1 = (C.c_double * 4)(*K0), (C.c_double * 4)(*K1)
+            th = th_pix * 4.0 / (np.sqrt(2.0) * (K0[0] + K0[1] + K1[0] + K1[1]))
+            sd = np.ascontiguousarray(np.asarray(seeds, np.int64) & 0xFFFFFFFF, np.uint32)
+            assert len(sd) == B
+            res = (_PairResult * B)()
+            spans = (C.c_double * (2 * L))()
+            check(self.ctxs[0].lib.mlpl_pair_pose_batch_lanes_dev(ctxs, strs, L, B, d_q.data_ptr(), d_q.shape[1], d_t.data_ptr(), d_t.shape[1], d_q.shape[2],
+                                                                  d_kp1.data_ptr(), d_kp2.data_ptr(), k0, k1, float(th), int(max_iters), float(confidence),
+                                                                  sd.ctypes.data, float(dist), C.addressof(res),
+                                                                  matches_out.data_ptr() if matches_out is not None else None, spans),
+                  "mlpl_pair_pose_batch_lanes_dev")
+            import time
+            now = time.perf_counter()
+            end = max(spans[2 * w + 1] for w in range(L))
+            self.last_lane_span = [(now - (end - spans[2 * w]) * 1e-3, now - (end - spans[2 * w + 1]) * 1e-3) for w in range(L)]
+            raw = np.frombuffer(res, _PAIR_RESULT_DTYPE, count=B)
+            rec = np.zeros(B, RECORD_DTYPE)
+            rec["pair_id"] = np.arange(B) if pair_ids is None else np.asarray(pair_ids)
+            rec["n_matches"], rec["status"] = raw["n_matches"], raw["status"]
+            ok = raw["status"] == 0
+            for f in ("n_inliers", "E", "R", "t"):
+                rec[f][ok] = raw[f][ok]
+            return rec
+        kw = dict(kw, th_pix=th_pix, max_iters=max_iters, confidence=confidence, dist=dist)
         lanes = max(1, min(self.lanes, B))
         bounds = [(B * w // lanes, B * (w + 1) // lanes) for w in range(lanes)]
         seeds = list(seeds)

@@ -3971,6 +3971,59 @@ int mlpl_pair_pose_batch_dev(mlpl_ctx *ctx, int n_pairs, const uint8_t *d_q, int
     return MLPL_OK;
 }
 
+// Two (or more) batched calls in flight on one GPU, inside the library: lane l = (ctxs[l], streams[l]) takes the l-th contiguous share of
+// the batch on a thread of its own (lane 0: the calling thread), so that one lane's host hops fall into the other's kernels.  The Python
+// form of this (batch.BatchLanes: a ThreadPoolExecutor) left 2-3 ms of thread hand-off and interpreter-lock waits in one step of ~25
+// (tools/lanes_tail_probe.py); here the caller makes ONE call and sleeps until every lane has returned.  Records do not depend on the
+// lane count: every pair's result is a function of its inputs and its seed.
+int mlpl_pair_pose_batch_lanes_dev(mlpl_ctx *const *ctxs, void *const *streams, int lanes, int n_pairs, const uint8_t *d_q, int nq, const uint8_t *d_t, int nt,
+                                   int nbytes, const float *d_kp1, const float *d_kp2, const double K0[4], const double K1[4], double thresh, int max_iters,
+                                   double confidence, const uint32_t *seeds, double dist, mlpl_pair_result *out, mlpl_dmatch *d_matches_out,
+                                   double *lane_span_ms) {
+    if (!ctxs || !streams || lanes < 1 || lanes > 8 || n_pairs < 1 || !seeds || !out) {
+        set_error("mlpl_pair_pose_batch_lanes_dev: bad arguments");
+        return MLPL_E_BAD_INPUT;
+    }
+    for (int l = 0; l < lanes; ++l)
+        if (!ctxs[l] || ctxs[l]->device != ctxs[0]->device) {
+            set_error("mlpl_pair_pose_batch_lanes_dev: every lane needs a context of the same device");
+            return MLPL_E_BAD_INPUT;
+        }
+    const int L = std::min(lanes, n_pairs);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<int> rcs((size_t)L, 0);
+    std::vector<std::string> msgs((size_t)L);
+    auto run_lane = [&](int l) {
+        const int b0 = (int)((long long)n_pairs * l / L), b1 = (int)((long long)n_pairs * (l + 1) / L);
+        const auto ts = std::chrono::steady_clock::now();
+        rcs[l] = b1 > b0 ? mlpl_pair_pose_batch_dev(ctxs[l], b1 - b0, d_q + (size_t)b0 * nq * nbytes, nq, d_t + (size_t)b0 * nt * nbytes, nt, nbytes,
+                                                    d_kp1 + (size_t)b0 * nq * 2, d_kp2 + (size_t)b0 * nt * 2, K0, K1, thresh, max_iters, confidence, 0, seeds + b0,
+                                                    dist, out + b0, d_matches_out ? d_matches_out + (size_t)b0 * nq : nullptr, streams[l])
+                         : MLPL_OK;
+        if (rcs[l]) msgs[l] = mlpl_last_error();  // (the error text is thread-local)
+        else if (hipStreamSynchronize(reinterpret_cast<hipStream_t>(streams[l])) != hipSuccess) rcs[l] = MLPL_E_HIP, msgs[l] = "lane stream synchronisation failed";
+        if (lane_span_ms) {
+            lane_span_ms[2 * l] = std::chrono::duration<double, std::milli>(ts - t0).count();
+            lane_span_ms[2 * l + 1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+    };
+    try {
+        std::vector<std::thread> others;
+        for (int l = 1; l < L; ++l) others.emplace_back(run_lane, l);
+        run_lane(0);
+        for (auto &t : others) t.join();
+    } catch (const std::exception &e) {
+        set_error("mlpl_pair_pose_batch_lanes_dev: %s", e.what());
+        return MLPL_E_INTERNAL;
+    }
+    for (int l = 0; l < L; ++l)
+        if (rcs[l]) {
+            set_error("%s", msgs[l].c_str());
+            return rcs[l];
+        }
+    return MLPL_OK;
+}
+
 int mlpl_sorted_match_idx(const mlpl_dmatch *matches, int n, uint32_t *sorted_idx) {
     if ((!matches || !sorted_idx) && n > 0) return MLPL_E_BAD_INPUT;
     if (n < 0) return MLPL_E_BAD_INPUT;

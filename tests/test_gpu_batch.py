@@ -235,12 +235,20 @@ def test_two_batched_calls_in_flight_give_the_same_records(ctx):
     m2 = torch.zeros((B, 1024, 4), dtype=torch.int32, device=dev)
     one = batch.process_pairs_batched(ctx, *stk, K, K, seeds, matches_out=m1)
     lanes = batch.BatchLanes(0, lanes=2, first_ctx=ctx)
+    m3 = torch.zeros((B, 1024, 4), dtype=torch.int32, device=dev)
     try:
-        two = lanes.process(*stk, K, K, seeds, matches_out=m2)
-        three = batch.BatchLanes(0, lanes=3).process(*stk, K, K, seeds)
+        two = lanes.process(*stk, K, K, seeds, matches_out=m2)                    # lanes inside the library (mlpl_pair_pose_batch_lanes_dev)
+        two_py = lanes.process(*stk, K, K, seeds, matches_out=m3, native=False)   # lanes as Python threads
+        l3 = batch.BatchLanes(0, lanes=3)
+        try:
+            three = l3.process(*stk, K, K, seeds)
+            one_pair = l3.process(*[t[:1] for t in stk], K, K, seeds[:1])         # fewer pairs than lanes
+        finally:
+            l3.close()
     finally:
         lanes.close()
-    assert one.tobytes() == two.tobytes() == three.tobytes()
+    assert one.tobytes() == two.tobytes() == three.tobytes() == two_py.tobytes() and one_pair.tobytes() == one[:1].tobytes()
+    assert all(b >= a for a, b in lanes.last_lane_span)
     for b in range(B):
         k = int(one["n_matches"][b])
-        assert torch.equal(m1[b, :k], m2[b, :k])
+        assert torch.equal(m1[b, :k], m2[b, :k]) and torch.equal(m1[b, :k], m3[b, :k])

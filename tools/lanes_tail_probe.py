@@ -11,6 +11,7 @@ from matchinglib_poselib_amd import batch, synth
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 total = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+native = (sys.argv[3] != "python") if len(sys.argv) > 3 else True   # lanes inside the library (default) or as Python threads
 n = 8192
 dev = torch.device("cuda:0")
 ctx = mpa.Context(0)
@@ -31,7 +32,7 @@ def hops(c):
 recs = []
 for k in range(steps + 3):
     t0 = time.perf_counter()
-    rec = lanes.process(st["desc1"], st["desc2"], st["kp1"], st["kp2"], K, K, seeds, matches_out=d_matches)
+    rec = lanes.process(st["desc1"], st["desc2"], st["kp1"], st["kp2"], K, K, seeds, matches_out=d_matches, native=native)
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
@@ -42,7 +43,7 @@ for k in range(steps + 3):
 ms = np.array([r["ms"] for r in recs])
 med = float(np.median(ms))
 slow = [r for r in recs if r["ms"] > 1.25 * med]
-print(json.dumps({"steps": steps, "median_ms": med, "p90_ms": float(np.percentile(ms, 90)), "max_ms": float(ms.max()), "slow_steps": len(slow),
+print(json.dumps({"lanes": "native" if native else "python", "steps": steps, "median_ms": med, "p90_ms": float(np.percentile(ms, 90)), "max_ms": float(ms.max()), "slow_steps": len(slow),
                   "all_ms": [round(float(x), 2) for x in ms]}))
 typ = min(recs, key=lambda r: abs(r["ms"] - med))
 print("typical:", json.dumps(typ))
