@@ -161,9 +161,10 @@ def process_pairs_batched(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, seeds, t
 
 def process_pairs_batched_usac(ctx: Context, d_q, d_t, d_kp1, d_kp2, K0, K1, seeds, th_pix: float = 0.8, prosac: bool = False, estimator: int = 2,
                                refine: int = 0, check_degeneracy: int = 0, sprt_delta: float = 0.05, sprt_epsilon: float = 0.15, sprt_ms: float = 6.0,
-                               sprt_tm: float = 2736.0, max_hyp: int = 50000, dist: float = 50.0, pair_ids=None, matches_out=None) -> np.ndarray:
+                               sprt_tm: float = 2736.0, max_hyp: int = 50000, dist: float = 50.0, pair_ids=None, matches_out=None) -> Tuple[np.ndarray, np.ndarray]:
     """process_pairs_batched with USAC (the reference harness' default RobMethod; defaults = its cfgUSAC: POSE_STEWENIUS + REF_WEIGHTS) as the
-    robust estimator: mlpl_pair_pose_batch_usac_dev.  prosac: PROSAC sampling in the order of the matching costs."""
+    robust estimator: mlpl_pair_pose_batch_usac_dev.  prosac: PROSAC sampling in the order of the matching costs.
+    Returns (records [B] RECORD_DTYPE, the library's raw result block [B]: n_matches, n_inliers, n_good, status, iters, E, R, t)."""
     import torch
     from .pose import UsacParams
 

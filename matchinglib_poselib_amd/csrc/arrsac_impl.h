@@ -1447,19 +1447,22 @@ int arrsac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, 
 constexpr int kArrBatchRuns = 128;
 
 int arrsac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const double *d_p2, int stride, const int32_t *counts, double thresh,
-                               int refine, uint64_t *rng_states, double *E, uint8_t *d_masks, int32_t *n_inliers, int32_t *status, hipStream_t s) {
+                               int refine, uint64_t *rng_states, double *E, uint8_t *d_masks, int32_t *n_inliers, int32_t *status, hipStream_t s,
+                               const CohortFeed *feed = nullptr) {
     if (B <= 0) return MLPL_OK;
     int rc;
     size_t max_dev = 0, max_pin = 0;
-    for (int b = 0; b < B; ++b) {
-        const ArrsacRun::Layout Y = ArrsacRun::layout(std::max(counts[b], 6));
+    for (int b = 0; b < (feed ? 1 : B); ++b) {  // (a feed delivers the counts later: blocks for `stride` correspondences)
+        const ArrsacRun::Layout Y = ArrsacRun::layout(std::max(feed ? stride : counts[b], 6));
         max_dev = std::max(max_dev, Y.dev_total), max_pin = std::max(max_pin, Y.pin_total);
     }
     // cohorts of <= kArrBatchRuns runs, two in flight (batch_hub.h kHubLanes): one cohort's host turns run beside the other's launches
-    const int cohort_max = ctx->opt_hub_cohort > 0 ? ctx->opt_hub_cohort : kArrBatchRuns;
-    const int lanes_wanted = ctx->opt_hub_lanes > 0 ? std::min(ctx->opt_hub_lanes, kHubLanes) : kHubLanes;
-    const int cohort = B >= 8 * lanes_wanted ? std::min(cohort_max, (B + lanes_wanted - 1) / lanes_wanted) : B;
-    const int n_cohorts = (B + cohort - 1) / cohort, lanes = std::min(lanes_wanted, n_cohorts);
+    int n_cohorts = 0, lanes = 0;
+    const int cohort = hub_cohort_size(ctx, B, kArrBatchRuns, &n_cohorts, &lanes);
+    if (feed && (feed->cohort != cohort || feed->n_cohorts != n_cohorts)) {
+        set_error("mlpl_arrsac_essential_batch_dev: the feed's cohorts are not the estimator's");
+        return MLPL_E_INTERNAL;
+    }
     void *pblk, *dblk;
     if ((rc = pinned_batch_get(ctx, (size_t)lanes * cohort * max_pin, &pblk))) return rc;
     if ((rc = ws_get(ctx, WS_BATCH_RUNS, (size_t)lanes * cohort * max_dev, &dblk))) return rc;
@@ -1472,7 +1475,7 @@ int arrsac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const d
     hipStream_t lane_stream[kHubLanes];
     for (int l = 0; l < lanes; ++l)
         if ((rc = hub_lane_stream(ctx, l, s, &lane_stream[l]))) return rc;
-    if (lanes > 1) MLPL_HIP_TRY(hipStreamSynchronize(s));  // the correspondences were produced on the caller's stream; a lane's own stream has no other ordering
+    if (lanes > 1 && !feed) MLPL_HIP_TRY(hipStreamSynchronize(s));  // the correspondences were produced on the caller's stream; a lane's own stream has no other ordering
     struct LaneOut {
         long long rounds = 0, merged = 0;
         int first_err = 0;
@@ -1488,6 +1491,14 @@ int arrsac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const d
         }
         for (int c = l; c < n_cohorts; c += lanes) {
             const int b0 = c * cohort, nb = std::min(cohort, B - b0);
+            if (feed) {  // the producer's event (everything this cohort reads on the device is behind it), then its host-side hand-over
+                int frc = hipEventSynchronize(feed->ready[c]) == hipSuccess ? MLPL_OK : MLPL_E_HIP;
+                if (!frc) frc = feed->on_ready(c, hub_resources(ctx)->lane[l].threads);
+                if (frc) {
+                    LO.first_err = frc, LO.first_msg = "mlpl_arrsac_essential_batch_dev: the hand-over of a cohort failed";
+                    break;
+                }
+            }
             BatchHub hub(ctx, ls, nb, l);
             std::vector<ArrBufs> bufs((size_t)nb);
             std::vector<std::string> msgs((size_t)nb);
@@ -1517,6 +1528,9 @@ int arrsac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const d
                 } catch (const std::bad_alloc &) {
                     r = MLPL_E_NOMEM;
                     set_error("mlpl_arrsac_essential_batch_dev: out of host memory");
+                } catch (...) {  // (anything else -- a length_error of a vector, say -- must not unwind off the fiber's makecontext frame)
+                    r = MLPL_E_INTERNAL;
+                    set_error("mlpl_arrsac_essential_batch_dev: a run ended with an unexpected C++ exception");
                 }
                 if (r && r != MLPL_E_FAILED) msgs[k] = mlpl_last_error();
                 status[b] = r;

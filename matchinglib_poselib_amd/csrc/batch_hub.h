@@ -131,7 +131,10 @@ class HubThreads {
             std::unique_ptr<Fiber> f(new Fiber());
             void *st = mmap(nullptr, kFiberStackBytes + 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK | MAP_NORESERVE, -1, 0);
             if (st == MAP_FAILED) throw std::bad_alloc();
-            mprotect(st, 4096, PROT_NONE);  // guard page below the stack
+            if (mprotect(st, 4096, PROT_NONE) != 0) {  // guard page below the stack
+                munmap(st, kFiberStackBytes + 4096);
+                throw std::bad_alloc();
+            }
             f->stack = static_cast<char *>(st) + 4096;
             f->pool = this;
             fibers_.push_back(std::move(f));
@@ -247,6 +250,8 @@ struct HubLane {  // what one cohort's hub keeps between calls (owned by the con
 struct HubStreams {
     HubLane lane[kHubLanes];
     hipStream_t copy = nullptr;  // device -> host copies that travel beside the lanes' work (the correspondences of a USAC batch)
+    hipStream_t feed = nullptr;  // the producer side of a cohort feed (the matching of later cohorts beside the estimators of earlier ones)
+    hipEvent_t feed_start = nullptr;
     HubThreads &threads = lane[0].threads;  // (helpers that only need a thread pool between rounds)
 };
 inline HubStreams *hub_resources(mlpl_ctx *ctx) {
@@ -264,6 +269,28 @@ inline int hub_lane_stream(mlpl_ctx *ctx, int l, hipStream_t caller, hipStream_t
     *out = L.own;
     return MLPL_OK;
 }
+
+// How a batched sequential estimator cuts its problems into cohorts (runs that advance together) and lanes (cohorts in flight); shared
+// by the estimators and by producers that feed them cohort by cohort (pair_batch_usac.h).
+inline int hub_cohort_size(const mlpl_ctx *ctx, int B, int cohort_default, int *n_cohorts_out, int *lanes_out) {
+    const int cohort_max = ctx->opt_hub_cohort > 0 ? ctx->opt_hub_cohort : cohort_default;
+    const int lanes_wanted = ctx->opt_hub_lanes > 0 ? std::min(ctx->opt_hub_lanes, kHubLanes) : kHubLanes;
+    const int cohort = B >= 8 * lanes_wanted ? std::min(cohort_max, (B + lanes_wanted - 1) / lanes_wanted) : B;
+    const int n_cohorts = (B + cohort - 1) / cohort;
+    if (n_cohorts_out) *n_cohorts_out = n_cohorts;
+    if (lanes_out) *lanes_out = std::min(lanes_wanted, n_cohorts);
+    return cohort;
+}
+// A producer that delivers the problems cohort by cohort (round 5: the image-pair entries match cohort c + 1 while the estimators of
+// cohort c run).  ready[c]: an event behind everything cohort c's problems need on the device; on_ready(c, lane): called by the lane's
+// thread once that event has completed, before the cohort's runs are built -- it fills the host-side inputs of problems
+// [c * cohort, ...) (counts[b], parameters); its pool argument is the lane's idle run-thread pool.  The estimator then sizes its
+// per-run blocks for `stride` correspondences, because the counts are not known up front.
+struct CohortFeed {
+    int cohort = 0, n_cohorts = 0;
+    const hipEvent_t *ready = nullptr;
+    std::function<int(int c, HubThreads &pool)> on_ready;
+};
 
 class BatchHub;
 struct HubRun {  // one run's side of the hub
@@ -391,11 +418,9 @@ class BatchHub {
         const int used = (int)std::min<size_t>(groups.size(), kHubMaxGroups);
         HubLane *hs = lane_;
         if (used > 1) {
-            if (!hs->ev[0]) {
-                for (int i = 0; i < kHubMaxGroups; ++i) {
-                    MLPL_HIP_TRY(hipEventCreateWithFlags(&hs->ev[i], hipEventDisableTiming));
-                    if (i) MLPL_HIP_TRY(hipStreamCreateWithFlags(&hs->aux[i], hipStreamNonBlocking));
-                }
+            for (int i = 0; i < kHubMaxGroups; ++i) {  // every handle on its own: a creation that failed once is tried again, never used as null
+                if (!hs->ev[i]) MLPL_HIP_TRY(hipEventCreateWithFlags(&hs->ev[i], hipEventDisableTiming));
+                if (i && !hs->aux[i]) MLPL_HIP_TRY(hipStreamCreateWithFlags(&hs->aux[i], hipStreamNonBlocking));
             }
             MLPL_HIP_TRY(hipEventRecord(hs->ev[0], s_));
             for (int i = 1; i < used; ++i) MLPL_HIP_TRY(hipStreamWaitEvent(hs->aux[i], hs->ev[0], 0));

@@ -142,6 +142,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_ransac_f32_filter = 1;
     ctx->opt_ransac_count_mpl = 2;
     ctx->opt_ransac_count_defer = 1;
+    ctx->opt_pair_batch_feed = 1;
     ctx->opt_solver_polish = 1;
     ctx->opt_solver_wave3 = 1;
     ctx->opt_ransac_device_draw = 1;
@@ -239,6 +240,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "hub_workers") && value >= 0 && value <= 64) ctx->opt_hub_workers = value;
     else if (!std::strcmp(name, "hub_cohort") && (value == 0 || (value >= 8 && value <= 512))) ctx->opt_hub_cohort = value;
     else if (!std::strcmp(name, "pair_batch_seq") && value >= 0 && value <= 1024) ctx->opt_pair_batch_seq = value;
+    else if (!std::strcmp(name, "pair_batch_feed") && (value == 0 || value == 1)) ctx->opt_pair_batch_feed = value;
     else if (!std::strcmp(name, "pair_batch_raw_cap") && (value == 0 || (value >= 64 && value <= (1 << 22)))) ctx->opt_pair_batch_raw_cap = value;
     else if (!std::strcmp(name, "usac_lo_stepwise") && (value == 0 || value == 1)) ctx->opt_usac_lo_stepwise = value;
     else if (!std::strcmp(name, "usac_lo_warm_start") && (value == 0 || value == 1)) ctx->opt_usac_lo_warm_start = value;

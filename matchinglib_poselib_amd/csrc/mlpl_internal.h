@@ -160,6 +160,7 @@ struct mlpl_ctx {
     long long ws_grows;                                // workspace / pinned blocks (re)allocated so far (a hipMalloc inside a call shows up here)
     long long last_batch_stats[8];                     // mlpl_pair_pose_batch_dev: {RANSAC passes, pair slots over all passes, pairs redone on a host table, 0}
     int opt_pair_batch;                                // pairs per internal batch of mlpl_pair_pose_batch_dev (0 = 256)
+    int opt_pair_batch_feed;                           // 1 (default): the USAC / ARRSAC pair entries match cohort c + 1 while the estimators of cohort c run (pair_batch_usac.h)
     int opt_pair_batch_seq;                            // ... of mlpl_pair_pose_batch_usac_dev / _arrsac_dev (0 = 512)
     int opt_hub_lanes;                                 // cohorts in flight (0 = 4 = the most)
     int opt_eig_inverse_iteration;                     // 1 (default): the smallest eigenvector of the re-weighted 9 x 9 fits (USAC REF_WEIGHTS, robustEssentialRefine) by inverse iteration, Jacobi as the fallback

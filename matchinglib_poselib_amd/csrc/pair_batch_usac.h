@@ -55,22 +55,19 @@ int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, c
                  sm_P = sm_E + (size_t)B * 72, sm_pose = sm_P + (size_t)B * 69 * 8, sm_end = sm_pose + (size_t)B * sizeof(PairPoseDev);
     void *blk = nullptr;
     if ((rc = ws_get(ctx, WS_PIPE, off_small + sm_end + 256, &blk))) return rc;
-    char *b0 = (char *)blk, *sm = b0 + off_small;
-    mlpl_dmatch *d_m = d_matches_out ? d_matches_out : (mlpl_dmatch *)(b0 + off_match);
-    double *d_p1 = (double *)(b0 + off_p1), *d_p2 = (double *)(b0 + off_p2);
-    uint8_t *d_mask = (uint8_t *)(b0 + off_mask), *d_cmask = (uint8_t *)(b0 + off_cmask);
+    char *base = (char *)blk, *sm = base + off_small;
+    mlpl_dmatch *d_m = d_matches_out ? d_matches_out : (mlpl_dmatch *)(base + off_match);
+    double *d_p1 = (double *)(base + off_p1), *d_p2 = (double *)(base + off_p2);
+    uint8_t *d_mask = (uint8_t *)(base + off_mask), *d_cmask = (uint8_t *)(base + off_cmask);
     int32_t *d_counts = (int32_t *)(sm + sm_counts), *d_active = (int32_t *)(sm + sm_active), *d_cc = (int32_t *)(sm + sm_cc);
     double *d_E = (double *)(sm + sm_E), *d_P = (double *)(sm + sm_P);
     PairPoseDev *d_pose = (PairPoseDev *)(sm + sm_pose);
     // pinned: counts | active | E | pose | (PROSAC) the matching costs
     const size_t pin_counts = 0, pin_act = (size_t)B * 4, pin_E = ((size_t)B * 8 + 255) / 256 * 256, pin_pose = pin_E + (size_t)B * 72,
                  pin_match = (pin_pose + (size_t)B * sizeof(PairPoseDev) + 255) / 256 * 256, pin_end = pin_match + (prosac ? (size_t)B * n * 4 : 0);
-    rc = mlpl_match_hamming_dev(ctx, d_q, nq, (size_t)nbytes, (size_t)nq * nbytes, d_t, nt, (size_t)nbytes, (size_t)nt * nbytes, nbytes, 1, 0.75f, B,
-                                (int32_t *)(b0 + off_idx), (int32_t *)(b0 + off_dist), d_m, d_counts, s);
-    if (rc) return rc;
-    // The pinned block is taken AFTER the matching call and belongs to this entry until it returns: pinned_get frees and reallocates when
-    // it grows, so no pointer into it may live across a nested entry that asks for more (the matcher no longer touches it at all; the
-    // batched estimators below run on pinned_batch, their own block).
+    // The pinned block belongs to this entry until it returns: pinned_get frees and reallocates when it grows, so no pointer into it may
+    // live across a nested entry that asks for more (the matcher does not touch it at all; the batched estimators below run on
+    // pinned_batch, their own block; checked again below).
     void *pin;
     if ((rc = pinned_get(ctx, pin_end + 256, &pin))) return rc;
     char *hp = (char *)pin;
@@ -78,53 +75,101 @@ int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, c
     double *h_E = (double *)(hp + pin_E);
     PairPoseDev *h_pose = (PairPoseDev *)(hp + pin_pose);
     const float *h_cost = (const float *)(hp + pin_match);
-    MLPL_HIP_TRY(hipMemcpyAsync(h_counts, d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, s));
-    if (prosac) {  // the costs of the matches, through the (now free) table of nearest-neighbour indices
-        float *d_cost = (float *)(b0 + off_idx);
-        hipLaunchKernelGGL(match_cost_kernel, dim3((NQ + 255) / 256, B), dim3(256), 0, s, (const mlpl_dmatch *)d_m, (const int32_t *)d_counts, NQ, d_cost);
-        MLPL_HIP_TRY(hipGetLastError());
-        MLPL_HIP_TRY(hipMemcpyAsync(hp + pin_match, d_cost, (size_t)B * n * 4, hipMemcpyDeviceToHost, s));
+
+    // ---- the producer side, cohort by cohort on the caller's stream, nothing waited for (round 5) ----------------------------------------
+    // The estimators advance in cohorts of <= 128 pairs on up to four lanes.  Until round 4 all B pairs were matched first (3 ms of
+    // matrix-core work during which no host thread had anything to do) and only then did the first estimator start (10+ ms of small
+    // dependent launches that leave most of the chip idle).  Now cohort c's matching, count read-back, cost read-back (PROSAC) and
+    // gather are enqueued with an event behind them, and a lane starts its cohort when THAT event has completed -- the matching of the
+    // later cohorts runs beside the estimators of the earlier ones.
+    int n_cohorts = 0, lanes_used = 0;
+    int cohort = hub_cohort_size(ctx, B, tmpl ? kUsacBatchRuns : kArrBatchRuns, &n_cohorts, &lanes_used);
+    const bool use_feed = ctx->opt_pair_batch_feed != 0 && n_cohorts > 1;
+    if (!use_feed) cohort = B, n_cohorts = 1;  // (option pair_batch_feed = 0, A/B: everything is matched first, then the estimators start -- round 4's order)
+    std::vector<hipEvent_t> ready((size_t)n_cohorts, nullptr);
+    struct EventsGuard {
+        std::vector<hipEvent_t> &ev;
+        ~EventsGuard() {
+            for (hipEvent_t e : ev)
+                if (e) (void)hipEventDestroy(e);
+        }
+    } ready_guard{ready};
+    // on a stream of its own, ordered behind the caller's: lane 0 of the estimators serves on the caller's stream, which must not queue
+    // behind the matching of the later cohorts
+    HubStreams *hres = hub_resources(ctx);
+    if (!hres->feed) MLPL_HIP_TRY(hipStreamCreateWithFlags(&hres->feed, hipStreamNonBlocking));
+    if (!hres->feed_start) MLPL_HIP_TRY(hipEventCreateWithFlags(&hres->feed_start, hipEventDisableTiming));
+    MLPL_HIP_TRY(hipEventRecord(hres->feed_start, s));
+    MLPL_HIP_TRY(hipStreamWaitEvent(hres->feed, hres->feed_start, 0));
+    const hipStream_t s_caller = s;
+    s = hres->feed;
+    for (int c = 0; c < n_cohorts; ++c) {
+        const int b0 = c * cohort, nb = std::min(cohort, B - b0);
+        rc = mlpl_match_hamming_dev(ctx, d_q + (size_t)b0 * nq * nbytes, nq, (size_t)nbytes, (size_t)nq * nbytes, d_t + (size_t)b0 * nt * nbytes, nt, (size_t)nbytes,
+                                    (size_t)nt * nbytes, nbytes, 1, 0.75f, nb, (int32_t *)(base + off_idx) + (size_t)b0 * n * 2, (int32_t *)(base + off_dist) + (size_t)b0 * n * 2, d_m + (size_t)b0 * n,
+                                    d_counts + b0, s);
+        if (rc) return rc;
+        MLPL_HIP_TRY(hipMemcpyAsync(h_counts + b0, d_counts + b0, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+        if (prosac) {  // the costs of the matches, through the (now free) table of nearest-neighbour indices of this cohort
+            float *d_cost = (float *)((int32_t *)(base + off_idx) + (size_t)b0 * n * 2);
+            hipLaunchKernelGGL(match_cost_kernel, dim3((NQ + 255) / 256, nb), dim3(256), 0, s, (const mlpl_dmatch *)(d_m + (size_t)b0 * n),
+                               (const int32_t *)(d_counts + b0), NQ, d_cost);
+            MLPL_HIP_TRY(hipGetLastError());
+            MLPL_HIP_TRY(hipMemcpyAsync(hp + pin_match + (size_t)b0 * n * 4, d_cost, (size_t)nb * n * 4, hipMemcpyDeviceToHost, s));
+        }
+        if ((rc = launch_gather_match_points_batch(d_m + (size_t)b0 * n, d_counts + b0, nb, NQ, d_kp1 + (size_t)b0 * nq * 2, (size_t)nq * 2, d_kp2 + (size_t)b0 * nt * 2,
+                                                   (size_t)nt * 2, K0, K1, d_p1 + (size_t)b0 * n * 2, d_p2 + (size_t)b0 * n * 2, s)))
+            return rc;
+        MLPL_HIP_TRY(hipEventCreateWithFlags(&ready[(size_t)c], hipEventDisableTiming | hipEventBlockingSync));
+        MLPL_HIP_TRY(hipEventRecord(ready[(size_t)c], s));
     }
-    MLPL_HIP_TRY(hipStreamSynchronize(s));
-    std::vector<int32_t> counts(h_counts, h_counts + B);  // (the nested entries reuse the context's pinned block)
+    s = s_caller;
+    // ---- the consumer side: what a lane does once its cohort's event has completed ---------------------------------------------------
+    std::vector<int32_t> counts((size_t)B, 0);
     mlpl_usac_params none;
     std::memset(&none, 0, sizeof(none));
     std::vector<mlpl_usac_params> params((size_t)B, tmpl ? *tmpl : none);
     std::vector<std::vector<uint32_t>> orders(prosac ? (size_t)B : 0);
-    int any = 0;
-    for (int b = 0; b < B; ++b) {
-        std::memset(&out[b], 0, sizeof(out[b]));
-        out[b].n_matches = counts[b];
-        h_active[b] = counts[b] >= 16 ? 1 : 0;  // below 16 matches Remove_LensDist / StereoRefine refuse to work
-        if (!h_active[b]) out[b].status = -1, counts[b] = 0;
-        any |= h_active[b];
-        params[b].seed = seeds ? seeds[b] : 0u;
-        params[b].sorted_idx = nullptr;
-    }
-    if (!any) return MLPL_OK;
-    if (prosac) {  // the orders on the run threads, all pairs at once (a std::sort of 5000 costs takes 0.3 ms: 150 ms for 512 pairs on one thread)
-        HubThreads &pool = hub_resources(ctx)->threads;
-        const int T = std::min(B, 64);
-        pool.start(T, [&](int k) {
-            for (int b = k; b < B; b += T)
-                if (h_active[b]) {
-                    orders[b].resize((size_t)counts[b]);
-                    sorted_cost_idx(h_cost + (size_t)b * n, counts[b], orders[b].data());
-                }
-        }, 16);
-        pool.wait();
-    }
-    for (int b = 0; b < B; ++b)
-        if (prosac && h_active[b]) params[b].sorted_idx = orders[b].data();
-    if ((rc = launch_gather_match_points_batch(d_m, d_counts, B, NQ, d_kp1, (size_t)nq * 2, d_kp2, (size_t)nt * 2, K0, K1, d_p1, d_p2, s))) return rc;
+    for (int b = 0; b < B; ++b) params[b].seed = seeds ? seeds[b] : 0u, params[b].sorted_idx = nullptr;
+    CohortFeed feed;
+    feed.cohort = cohort, feed.n_cohorts = n_cohorts, feed.ready = ready.data();
+    feed.on_ready = [&](int c, HubThreads &pool) -> int {
+        const int b0 = c * cohort, nb = std::min(cohort, B - b0);
+        for (int b = b0; b < b0 + nb; ++b) {
+            std::memset(&out[b], 0, sizeof(out[b]));
+            counts[b] = h_counts[b];
+            out[b].n_matches = counts[b];
+            h_active[b] = counts[b] >= 16 ? 1 : 0;  // below 16 matches Remove_LensDist / StereoRefine refuse to work
+            if (!h_active[b]) out[b].status = -1, counts[b] = 0;
+        }
+        if (prosac) {  // the orders on the lane's (idle) run threads (a std::sort of 5000 costs takes 0.3 ms)
+            const int T = std::min(nb, 64);
+            pool.start(T, [&, b0, nb, T](int k) {
+                for (int b = b0 + k; b < b0 + nb; b += T)
+                    if (h_active[b]) {
+                        orders[b].resize((size_t)counts[b]);
+                        sorted_cost_idx(h_cost + (size_t)b * n, counts[b], orders[b].data());
+                        params[b].sorted_idx = orders[b].data();
+                    }
+            }, 16);
+            pool.wait();
+        }
+        return MLPL_OK;
+    };
     std::vector<double> E((size_t)B * 9, 0.0), results((size_t)B * 12, 0.0);
     std::vector<int32_t> status((size_t)B, 0);
+    const CohortFeed *feed_arg = &feed;
+    if (!use_feed) {  // one hand-over for the whole batch, here; the estimators then see a batch with known counts
+        MLPL_HIP_TRY(hipEventSynchronize(ready[0]));
+        if ((rc = feed.on_ready(0, hres->threads))) return rc;
+        feed_arg = nullptr;
+    }
     if (tmpl) {
-        if ((rc = usac_essential_batch_dev(ctx, B, d_p1, d_p2, NQ, counts.data(), params.data(), E.data(), d_mask, results.data(), status.data(), nullptr, nullptr, s)))
+        if ((rc = usac_essential_batch_dev(ctx, B, d_p1, d_p2, NQ, counts.data(), params.data(), E.data(), d_mask, results.data(), status.data(), nullptr, nullptr, s, feed_arg)))
             return rc;
     } else {
         std::vector<int32_t> ninl((size_t)B, 0);
-        if ((rc = arrsac_essential_batch_dev(ctx, B, d_p1, d_p2, NQ, counts.data(), arr_thresh, arr_refine, arr_states, E.data(), d_mask, ninl.data(), status.data(), s)))
+        if ((rc = arrsac_essential_batch_dev(ctx, B, d_p1, d_p2, NQ, counts.data(), arr_thresh, arr_refine, arr_states, E.data(), d_mask, ninl.data(), status.data(), s, feed_arg)))
             return rc;
         for (int b = 0; b < B; ++b) results[(size_t)b * 12 + 1] = 0, results[(size_t)b * 12 + 5] = ninl[b];
     }

@@ -3179,6 +3179,8 @@ void hub_streams_free(void *p) {
         if (L.items_dev) (void)hipFree(L.items_dev);
     }
     if (h->copy) (void)hipStreamDestroy(h->copy);
+    if (h->feed) (void)hipStreamDestroy(h->feed);
+    if (h->feed_start) (void)hipEventDestroy(h->feed_start);
     delete h;
 }
 #include "arrsac_impl.h"

@@ -2710,21 +2710,23 @@ struct UsacBatchTrace {
 
 int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const double *d_p2, int stride, const int32_t *counts,
                              const mlpl_usac_params *params, double *E, uint8_t *d_masks, double *results, int32_t *status, double *degen,
-                             const UsacBatchTrace *trace, hipStream_t s) {
+                             const UsacBatchTrace *trace, hipStream_t s, const CohortFeed *feed = nullptr) {
     if (B <= 0) return MLPL_OK;
     int rc;
     // the sequential parts read the correspondences on the host: one copy of the whole block through the batch's pinned memory
     size_t max_dev = 0, max_pin = 0;
-    for (int b = 0; b < B; ++b) {
-        const UsacRun::UsacLayout Y = UsacRun::usac_layout((unsigned)std::max(counts[b], 1), params[b].refine, params[b].check_degeneracy != 0);
+    for (int b = 0; b < B; ++b) {  // (a feed delivers the counts later: blocks for `stride` correspondences)
+        const UsacRun::UsacLayout Y = UsacRun::usac_layout((unsigned)std::max(feed ? stride : counts[b], 1), params[b].refine, params[b].check_degeneracy != 0);
         max_dev = std::max(max_dev, Y.dev_total), max_pin = std::max(max_pin, Y.pin_total);
     }
     // Cohorts of <= kUsacBatchRuns runs, two of them in flight (batch_hub.h kHubLanes): while one cohort's merged launches execute, the
     // other cohort's runs walk their bit rows on the host.  A batch that fits one cohort is split in two halves for the same reason.
-    const int cohort_max = ctx->opt_hub_cohort > 0 ? ctx->opt_hub_cohort : kUsacBatchRuns;
-    const int lanes_wanted = ctx->opt_hub_lanes > 0 ? std::min(ctx->opt_hub_lanes, kHubLanes) : kHubLanes;
-    const int cohort = B >= 8 * lanes_wanted ? std::min(cohort_max, (B + lanes_wanted - 1) / lanes_wanted) : B;
-    const int n_cohorts = (B + cohort - 1) / cohort, lanes = std::min(lanes_wanted, n_cohorts);
+    int n_cohorts = 0, lanes = 0;
+    const int cohort = hub_cohort_size(ctx, B, kUsacBatchRuns, &n_cohorts, &lanes);
+    if (feed && (feed->cohort != cohort || feed->n_cohorts != n_cohorts)) {
+        set_error("mlpl_usac_essential_batch_dev: the feed's cohorts are not the estimator's");
+        return MLPL_E_INTERNAL;
+    }
     const size_t pts_bytes = ((size_t)B * stride * 16 + 255) & ~(size_t)255;
     void *pblk, *dblk;
     if ((rc = pinned_batch_get(ctx, 2 * pts_bytes + (size_t)lanes * cohort * max_pin, &pblk))) return rc;
@@ -2739,7 +2741,7 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
     // The sequential parts read the correspondences on the host (normalisation, sample validation, the choices of the 5-point refinements,
     // the degeneracy tests): they cross PCIe once, cohort by cohort on a stream of their own, so that the first cohort starts after its
     // own slice has arrived (512 problems of 5000: 3.4 ms for all, 0.85 ms for the first quarter) and the rest travels beside its work.
-    MLPL_HIP_TRY(hipStreamSynchronize(s));  // everything the caller queued before is done: the lanes' own streams need no other ordering
+    if (!feed) MLPL_HIP_TRY(hipStreamSynchronize(s));  // everything the caller queued before is done: the lanes' own streams need no other ordering
     HubStreams *hres = hub_resources(ctx);
     if (!hres->copy) MLPL_HIP_TRY(hipStreamCreateWithFlags(&hres->copy, hipStreamNonBlocking));
     std::vector<hipEvent_t> arrived((size_t)n_cohorts, nullptr);
@@ -2750,7 +2752,7 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
                 if (e) (void)hipEventDestroy(e);
         }
     } events_guard{arrived};
-    for (int c = 0; c < n_cohorts; ++c) {
+    for (int c = 0; c < n_cohorts && !feed; ++c) {
         const int b0 = c * cohort, nb = std::min(cohort, B - b0);
         int max_n = 1;  // only the rows in use: counts[b] <= max_n of the stride rows of a problem
         for (int b = b0; b < b0 + nb; ++b) max_n = std::max(max_n, counts[b]);
@@ -2780,7 +2782,23 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
         }
         for (int c = l; c < n_cohorts; c += lanes) {
             const int b0 = c * cohort, nb = std::min(cohort, B - b0);
-            if (hipEventSynchronize(arrived[(size_t)c]) != hipSuccess) {
+            if (feed) {  // the producer's event, its host-side hand-over (counts, orders), then this cohort's correspondences to the host
+                int frc = hipEventSynchronize(feed->ready[c]) == hipSuccess ? MLPL_OK : MLPL_E_HIP;
+                if (!frc) frc = feed->on_ready(c, hub_resources(ctx)->lane[l].threads);
+                if (!frc) {
+                    int max_n = 1;
+                    for (int b = b0; b < b0 + nb; ++b) max_n = std::max(max_n, counts[b]);
+                    const size_t at = (size_t)b0 * stride * 2;
+                    if (hipMemcpy2DAsync(h_p1 + at, (size_t)stride * 16, d_p1 + at, (size_t)stride * 16, (size_t)max_n * 16, (size_t)nb, hipMemcpyDeviceToHost, ls) != hipSuccess ||
+                        hipMemcpy2DAsync(h_p2 + at, (size_t)stride * 16, d_p2 + at, (size_t)stride * 16, (size_t)max_n * 16, (size_t)nb, hipMemcpyDeviceToHost, ls) != hipSuccess ||
+                        hipStreamSynchronize(ls) != hipSuccess)
+                        frc = MLPL_E_HIP;
+                }
+                if (frc) {
+                    LO.first_err = frc, LO.first_msg = "mlpl_usac_essential_batch_dev: the hand-over of a cohort failed";
+                    break;
+                }
+            } else if (hipEventSynchronize(arrived[(size_t)c]) != hipSuccess) {
                 LO.first_err = MLPL_E_INTERNAL, LO.first_msg = "mlpl_usac_essential_batch_dev: the copy of the correspondences failed";
                 break;
             }
@@ -2829,6 +2847,9 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
                 } catch (const std::bad_alloc &) {
                     r = MLPL_E_NOMEM;
                     set_error("mlpl_usac_essential_batch_dev: out of host memory");
+                } catch (...) {  // (anything else -- a length_error of a vector, say -- must not unwind off the fiber's makecontext frame)
+                    r = MLPL_E_INTERNAL;
+                    set_error("mlpl_usac_essential_batch_dev: a run ended with an unexpected C++ exception");
                 }
                 if (r && r != MLPL_E_FAILED) msgs[k] = mlpl_last_error();
                 status[b] = r;
