@@ -137,6 +137,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_hamming_mfma_weighted = 1;
     ctx->opt_hamming_mfma_prio = 0;
     ctx->opt_hamming_fused_merge = 1;
+    ctx->opt_hamming_merge_emit = 1;
     ctx->opt_ransac_lazy_sums = 1;
     ctx->opt_ransac_overlap = 1;
     ctx->opt_ransac_f32_filter = 1;
@@ -216,6 +217,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "hamming_fused_merge") && (value == 0 || value == 1)) ctx->opt_hamming_fused_merge = value;
     else if (!std::strcmp(name, "hamming_stamps") && (value >= 0 && value <= 2)) ctx->opt_hamming_stamps = value;
     else if (!std::strcmp(name, "hamming_train01") && (value == 0 || value == 1)) ctx->opt_hamming_train01 = value;
+    else if (!std::strcmp(name, "hamming_merge_emit") && (value == 0 || value == 1)) ctx->opt_hamming_merge_emit = value;
     else if (!std::strcmp(name, "l2_mfma_waves") && (value == 0 || value == 4 || value == 8)) ctx->opt_l2_mfma_waves = value;
     else if (!std::strcmp(name, "l2_mfma_blocks_per_cu") && value >= 0 && value <= 16) ctx->opt_l2_mfma_blocks_per_cu = value;
     else if (!std::strcmp(name, "hamming_qpl") && (value == 1 || value == 2)) ctx->opt_hamming_qpl = value;
@@ -261,6 +263,7 @@ int mlpl_get_option(mlpl_ctx *ctx, const char *name, int *value) {
     else if (!std::strcmp(name, "hamming_mfma_lds")) *value = ctx->opt_hamming_mfma_lds;
     else if (!std::strcmp(name, "hamming_fused_merge")) *value = ctx->opt_hamming_fused_merge;
     else if (!std::strcmp(name, "hamming_train01")) *value = ctx->opt_hamming_train01;
+    else if (!std::strcmp(name, "hamming_merge_emit")) *value = ctx->opt_hamming_merge_emit;
     else if (!std::strcmp(name, "hamming_stamps")) *value = ctx->opt_hamming_stamps;
     else if (!std::strcmp(name, "solver_polish")) *value = ctx->opt_solver_polish;
     else if (!std::strcmp(name, "ransac_count_mpl")) *value = ctx->opt_ransac_count_mpl;
@@ -426,9 +429,11 @@ int mlpl_match_hamming_dev(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_s
     const int ncnt = (nq + kCountGroup - 1) / kCountGroup;
     int rc = ws_get(ctx, WS_COUNT, (size_t)batch * std::max(ncnt, 1) * sizeof(int32_t), &gc);
     if (rc) return rc;
+    HammingEmitOut emit{d_out, d_n_out, 0};
     rc = launch_knn_hamming(ctx, d_q, nq, q_stride, q_batch_stride, d_t, nt, t_stride, t_batch_stride, nbytes, k, batch,
-                            d_idx, d_dist, s, ratio, (int32_t *)gc);
+                            d_idx, d_dist, s, ratio, (int32_t *)gc, &emit);
     if (rc) return rc;
+    if (emit.emitted) return MLPL_OK;  // (the latency shape: the merge kernel wrote the matches and their number)
     return launch_ratio_compact(ctx, d_idx, d_dist, 0, nq, k, batch, ratio, d_out, d_n_out, s, (int32_t *)gc);
 }
 

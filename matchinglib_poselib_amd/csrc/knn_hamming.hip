@@ -249,13 +249,27 @@ struct MergeTail {  // train rows [row0, row0 + n) to be folded in by the merge 
 // Also evaluates the ratio predicate and leaves the number of passing queries of this query group in group_counts (consumed by
 // ratio_write_kernel), so the fused getMatches path needs no separate counting pass.  LANES = 4 serves the usual handful of
 // splits (a quarter of the threads and shuffles of the 16-lane form), LANES = 16 many splits.
+// Emission inside the merge (round 5, the latency shape: ONE image pair per call).  When `out` is set the merge kernel also writes the
+// DMatch rows -- the work of ratio_write_kernel -- so the step has one launch less: a workgroup (64 queries) publishes its pass count as
+// (launch generation << 32 | count) in scan[pair][workgroup], sums the counts of the workgroups before it (spinning on entries that
+// still carry an older generation: they belong to workgroups with a smaller linear id, which were dispatched earlier) and writes its
+// matches at that offset in query order.  The launcher uses this only for grids that are resident all at once.  Same rows as the
+// two-kernel path (same predicate, same order).
+struct MergeEmit {
+    mlpl_dmatch *out;
+    int32_t *n_out;
+    unsigned long long *scan;
+    uint32_t gen;
+};
+
 template <int LANES>
 __global__ __launch_bounds__(kMergeGroup * LANES) void knn_hamming_merge_kernel(const uint2 *__restrict__ part, int nq, int nsplit,
                                                                                  int rows_per_split, int sps, int dshift, int k, float ratio,
                                                                                  int32_t *__restrict__ idx, int32_t *__restrict__ dist,
-                                                                                 int32_t *__restrict__ group_counts, MergeTail tail) {
+                                                                                 int32_t *__restrict__ group_counts, MergeTail tail, MergeEmit emit) {
     constexpr int kWaves = kMergeGroup * LANES / 64;
     __shared__ int wave_tot[kWaves];
+    __shared__ int wave_look[kWaves];
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const int sub = tid & (LANES - 1);
@@ -309,29 +323,60 @@ __global__ __launch_bounds__(kMergeGroup * LANES) void knn_hamming_merge_kernel(
             pass = true;
         }
     }
-    if (group_counts) {
+    if (group_counts || emit.out) {
         const unsigned long long bal = __ballot(pass);
         if ((tid & 63) == 0) wave_tot[tid >> 6] = __popcll(bal);
         __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
+        int tot = 0, wave_prefix = 0;
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) tot += wave_tot[w];
-            group_counts[(size_t)b * gridDim.x + blockIdx.x] = tot;
+        for (int w = 0; w < kWaves; ++w) {
+            if (w < (tid >> 6)) wave_prefix += wave_tot[w];
+            tot += wave_tot[w];
+        }
+        if (tid == 0 && group_counts) group_counts[(size_t)b * gridDim.x + blockIdx.x] = tot;
+        if (emit.out) {
+            unsigned long long *sc = emit.scan + (size_t)b * gridDim.x;
+            if (tid == 0)
+                __hip_atomic_store(&sc[blockIdx.x], ((unsigned long long)emit.gen << 32) | (unsigned long long)(uint32_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int look = 0;
+            for (int j = tid; j < (int)blockIdx.x; j += kMergeGroup * LANES) {
+                unsigned long long v = __hip_atomic_load(&sc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while ((uint32_t)(v >> 32) != emit.gen) {
+                    __builtin_amdgcn_s_sleep(2);
+                    v = __hip_atomic_load(&sc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                look += (int)(uint32_t)v;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) look += __shfl_xor(look, off);
+            if ((tid & 63) == 0) wave_look[tid >> 6] = look;
+            __syncthreads();
+            int base = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) base += wave_look[w];
+            if (pass) {  // (only lanes with sub == 0 pass; a wave's queries are in ascending order)
+                mlpl_dmatch m;
+                m.queryIdx = qi;
+                m.trainIdx = (int32_t)(b0 & 0xFFFFFFFFull);
+                m.imgIdx = -1;
+                m.distance = (float)(int32_t)(b0 >> 32);
+                emit.out[(size_t)b * nq + base + wave_prefix + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = m;
+            }
+            if (blockIdx.x == gridDim.x - 1 && tid == 0) emit.n_out[b] = base + tot;
         }
     }
 }
 
 static void launch_merge(hipStream_t s, const uint2 *part, int nq, int nsplit, int rps, int dshift, int k, float ratio, int batch,
                          int32_t *d_idx, int32_t *d_dist, int32_t *d_group_counts, int sps = 1,
-                         MergeTail tail = MergeTail{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr}) {
+                         MergeTail tail = MergeTail{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr}, MergeEmit emit = MergeEmit{nullptr, nullptr, nullptr, 0u}) {
     dim3 mgrid((nq + kMergeGroup - 1) / kMergeGroup, batch);
     if (nsplit <= 8)
         hipLaunchKernelGGL(knn_hamming_merge_kernel<4>, mgrid, dim3(kMergeGroup * 4), 0, s, part, nq, nsplit, rps, sps, dshift, k, ratio, d_idx,
-                           d_dist, d_group_counts, tail);
+                           d_dist, d_group_counts, tail, emit);
     else
         hipLaunchKernelGGL(knn_hamming_merge_kernel<16>, mgrid, dim3(kMergeGroup * 16), 0, s, part, nq, nsplit, rps, sps, dshift, k, ratio,
-                           d_idx, d_dist, d_group_counts, tail);
+                           d_idx, d_dist, d_group_counts, tail, emit);
 }
 
 template <int NW>
@@ -365,7 +410,8 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
 
 int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_stride, size_t q_bstride,
                        const uint8_t *d_t, int nt, size_t t_stride, size_t t_bstride, int nbytes, int k, int batch,
-                       int32_t *d_idx, int32_t *d_dist, hipStream_t s, float ratio, int32_t *d_group_counts) {
+                       int32_t *d_idx, int32_t *d_dist, hipStream_t s, float ratio, int32_t *d_group_counts, HammingEmitOut *emit_out) {
+    if (emit_out) emit_out->emitted = 0;
     if (!d_q || !d_t || !d_idx || !d_dist || nq < 0 || batch < 1 || batch > 65535 || (k != 1 && k != 2) || nt < k ||
         nbytes < 1 || nbytes > 256 || q_stride < (size_t)nbytes || t_stride < (size_t)nbytes) {
         set_error("knn_hamming: bad arguments (nq=%d nt=%d nbytes=%d k=%d batch=%d)", nq, nt, nbytes, k, batch);
@@ -426,7 +472,22 @@ int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_strid
         if (rc) return rc;
         if (!fused) {  // (the static LDS-ring kernel merges its splits, evaluates the ratio predicate and counts by itself)
             const MergeTail tail{qw, tw, qbw, tbw, nw, tail_row0, nt - tail_row0, split_tab};
-            launch_merge(s, (const uint2 *)part, nq, nsplit, rps, dshift, k, ratio, batch, d_idx, d_dist, d_group_counts, sps, tail);
+            MergeEmit emit{nullptr, nullptr, nullptr, 0u};
+            const long long mblocks = (long long)((nq + kMergeGroup - 1) / kMergeGroup) * batch;
+            // the merge also emits the DMatch rows when the caller wants them and the whole merge grid is resident at once (the latency
+            // shape: one or two image pairs; 1024-thread workgroups at 16 lanes per query: two per CU)
+            if (emit_out && emit_out->out && emit_out->n_out && ctx->opt_hamming_merge_emit && mblocks <= 2LL * ctx->num_cus) {
+                void *sp = nullptr;
+                const size_t sb = (size_t)mblocks * sizeof(unsigned long long);
+                if ((rc = ws_get(ctx, WS_SCAN, sb, &sp))) return rc;
+                if (ctx->hamming_scan_ptr != sp || ctx->hamming_scan_gen == 0xFFFFFFFFu) {  // new block (or the generation wraps): no stale generation in it
+                    MLPL_HIP_TRY(hipMemsetAsync(sp, 0, ctx->ws_bytes[WS_SCAN], s));
+                    ctx->hamming_scan_ptr = sp, ctx->hamming_scan_gen = 0;
+                }
+                emit = MergeEmit{emit_out->out, emit_out->n_out, (unsigned long long *)sp, ++ctx->hamming_scan_gen};
+                emit_out->emitted = 1;
+            }
+            launch_merge(s, (const uint2 *)part, nq, nsplit, rps, dshift, k, ratio, batch, d_idx, d_dist, d_group_counts, sps, tail, emit);
         }
         MLPL_HIP_TRY(hipGetLastError());
         return MLPL_OK;

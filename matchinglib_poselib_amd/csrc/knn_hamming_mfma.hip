@@ -341,25 +341,8 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
     const int qt0 = (qb * 4 + w) * QT;
     const int h = l >> 5;
 
-    // The query operand is expanded to fp4 HERE, once per wave, from the raw 32-byte descriptors (lane (r, h) owns words 4h..4h+3 of its
-    // row: one 16-byte load per tile; the same word -> K-position rule as hamming_expand_kernel, which now runs for the train set only --
-    // that one has to exist in fragment order in memory because it is streamed into LDS by DMA).  Rows >= nq read as zero bits.
-    uint4 bq[QT][KS];
-    int qpop[QT];  // {0, +1} train operand (fuse.train01): the accumulator is pop(query) - distance; both lane halves' shares of the row
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        const int row = (qt0 + t) * 32 + (l & 31);
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row < nq) v = *reinterpret_cast<const uint4 *>(qw + (size_t)b * q_batch_words + (size_t)row * (2 * KS) + (size_t)h * KS);
-        const int pc = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-        qpop[t] = pc + __shfl_xor(pc, 32);
-        const uint32_t vs[KS] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-            bq[t][s] = make_uint4(expand_byte(vs[s] & 255u), expand_byte((vs[s] >> 8) & 255u), expand_byte((vs[s] >> 16) & 255u),
-                                  expand_byte(vs[s] >> 24));
-    }
-
+    uint4 bq[QT][KS];   // the wave's query fragments (filled below, behind the first tile copies)
+    int qpop[QT];       // {0, +1} train operand (fuse.train01): the accumulator is pop(query) - distance; both lane halves' shares of the row
     v16f cinit;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) cinit[reg] = -(float)((reg & 3) + 8 * (reg >> 2) + 4 * h) * kEps;
@@ -425,6 +408,26 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
 
     copy_tile(0);
     if (ntiles > 1) copy_tile(1);
+    // (round 5: the first two tile copies are in flight BEFORE the query rows are fetched and expanded -- the two global latencies of a
+    // workgroup's prologue overlap instead of adding; vmcnt retires in issue order, so the query loads' own wait also covers these copies,
+    // which the first arrive() would wait for anyway)
+    // The query operand is expanded to fp4 HERE, once per wave, from the raw 32-byte descriptors (lane (r, h) owns words 4h..4h+3 of its
+    // row: one 16-byte load per tile; the same word -> K-position rule as hamming_expand_kernel, which now runs for the train set only --
+    // that one has to exist in fragment order in memory because it is streamed into LDS by DMA).  Rows >= nq read as zero bits.
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int row = (qt0 + t) * 32 + (l & 31);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row < nq) v = *reinterpret_cast<const uint4 *>(qw + (size_t)b * q_batch_words + (size_t)row * (2 * KS) + (size_t)h * KS);
+        const int pc = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+        qpop[t] = pc + __shfl_xor(pc, 32);
+        const uint32_t vs[KS] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            bq[t][s] = make_uint4(expand_byte(vs[s] & 255u), expand_byte((vs[s] >> 8) & 255u), expand_byte((vs[s] >> 16) & 255u),
+                                  expand_byte(vs[s] >> 24));
+    }
+
     // only the last tile of the train set can be ragged; it runs after the loop with its own C (rows >= nt start at -inf and stay there)
     const bool ragged = row0 + ntiles * 32 > nt;
     const int nfull = ragged ? ntiles - 1 : ntiles;

@@ -59,6 +59,7 @@ enum WsSlot {
     WS_RAND_RAW,  // raw rand() stream of the last RANSAC seed on the device + the control block of the device-side sampling
     WS_BATCH_RUNS, // device blocks of the runs of a batched sequential estimator (USAC / ARRSAC), one slice per run
     WS_CLOCK,     // clock ring of the Hamming kernel (option hamming_stamps = 2): kClockRing records of 4 x u64
+    WS_SCAN,      // pass counts of the merge workgroups when the merge kernel emits the matches itself (knn_hamming.hip MergeEmit)
     WS_TICKETS,   // ticket counters of the fused Hamming epilogue (zero between launches; knn_hamming_mfma.hip)
     WS_NUM_SLOTS
 };
@@ -115,6 +116,9 @@ struct mlpl_ctx {
     size_t hamming_tickets_bytes;   // ... and how many bytes of them are known to be zero
     int opt_hamming_stamps;         // diagnostics: 1 = the matrix-core kernel records per-wave clock stamps (mlpl_debug_hamming_stamps); 2 = one clock record per launch into a ring (mlpl_debug_hamming_clock)
     long long hamming_clock_launches;   // launches recorded into the clock ring so far
+    int opt_hamming_merge_emit;     // 1 (default) = one or two image pairs per call: the merge kernel writes the DMatch rows itself (no ratio_write launch)
+    void *hamming_scan_ptr;         // the WS_SCAN block the generation below counts for
+    uint32_t hamming_scan_gen;
     int opt_hamming_train01;        // 1 = {0, +1} train fragments in the static LDS-ring kernel (accumulator = pop(query) - distance), 0 = +-1
     int dbg_stamp_items;
     int opt_ransac_chunk;           // hypotheses per device pass (0 = 32768)
@@ -201,10 +205,17 @@ void prof_mark(mlpl_ctx *ctx, int id, int phase, hipStream_t s);
 inline hipStream_t pick_stream(mlpl_ctx *, void *stream) { return reinterpret_cast<hipStream_t>(stream); }
 
 // ---- kernel launchers (defined in the .hip files) ----
+// emit_out (optional): the caller wants the DMatch rows (out [batch][nq], n_out [batch]); *emitted = 1 when the Hamming path wrote them
+// itself (the merge kernel of the latency shape) and launch_ratio_compact is not needed.
+struct HammingEmitOut {
+    mlpl_dmatch *out;
+    int32_t *n_out;
+    int emitted;
+};
 int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_stride, size_t q_bstride,
                        const uint8_t *d_t, int nt, size_t t_stride, size_t t_bstride, int nbytes, int k, int batch,
                        int32_t *d_idx, int32_t *d_dist, hipStream_t s, float ratio = 0.75f,
-                       int32_t *d_group_counts = nullptr);
+                       int32_t *d_group_counts = nullptr, HammingEmitOut *emit_out = nullptr);
 int launch_knn_l2(mlpl_ctx *ctx, const float *d_q, int nq, size_t q_stride, size_t q_bstride, const float *d_t,
                   int nt, size_t t_stride, size_t t_bstride, int dim, int k, int batch, int32_t *d_idx,
                   float *d_dist, hipStream_t s, int nms_order = 0);

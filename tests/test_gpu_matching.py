@@ -503,3 +503,40 @@ def test_hamming_fused_epilogue_survives_a_dynamic_split_call_between_two_fused_
             assert err == 0 and np.array_equal(m["trainIdx"], idx[m["queryIdx"], 0])
     finally:
         ctx.set_option("hamming_mfma_lds", 1)
+
+
+@pytest.mark.parametrize("nq,nt,nbytes,B", [(8192, 8192, 32, 1), (1000, 5000, 32, 1), (100, 3000, 32, 1), (1, 40, 32, 1), (8191, 8200, 32, 1), (3000, 4000, 16, 1),
+                                           (4096, 4096, 32, 2), (2500, 300, 64, 1), (700, 900, 32, 5)])
+def test_matches_emitted_by_the_merge_kernel(ctx, oracle, nq, nt, nbytes, B):
+    """Round 5, the latency shape (one image pair per call): the merge kernel writes the DMatch rows itself (option hamming_merge_emit,
+    default 1: workgroups chain their pass counts through a generation-tagged table) instead of a ratio_write launch.  Same idx, dist,
+    count and match rows as with the option off and as the oracle; called repeatedly (the table's generation advances) and with shapes
+    that take other paths (several pairs, the fused epilogue, wide descriptors)."""
+    import torch
+    from matchinglib_poselib_amd.matching import match_hamming_device
+
+    qs, ts = zip(*[synth.orb_pair(nq, nt, nbytes=nbytes, seed=7000 + nq + nt + b) for b in range(B)])
+    q, t = torch.from_numpy(np.stack(qs)).cuda(), torch.from_numpy(np.stack(ts)).cuda()
+    outs = {}
+    try:
+        for emit in (1, 0, 1):
+            ctx.set_option("hamming_merge_emit", emit)
+            for rep in range(3):
+                o = match_hamming_device(q, t, ctx=ctx)
+                torch.cuda.synchronize()
+                cur = tuple(o[k].cpu().numpy().copy() for k in ("idx", "dist", "count"))
+                rows = [o["matches"][b, : int(cur[2][b])].cpu().numpy().copy() for b in range(B)]
+                if emit not in outs:
+                    outs[emit] = (cur, rows)
+                else:
+                    assert all(np.array_equal(a, c) for a, c in zip(outs[emit][0], cur)) and all(np.array_equal(a, c) for a, c in zip(outs[emit][1], rows))
+    finally:
+        ctx.set_option("hamming_merge_emit", 1)
+    assert all(np.array_equal(a, c) for a, c in zip(outs[1][0], outs[0][0])) and all(np.array_equal(a, c) for a, c in zip(outs[1][1], outs[0][1]))
+    for b in range(B):
+        oi, od = oracle.knn_hamming(qs[b], ts[b])
+        o = oracle.ratio_filter(oi, od)
+        m = outs[1][1][b]
+        assert np.array_equal(outs[1][0][0][b], oi) and np.array_equal(outs[1][0][1][b], od) and len(m) == len(o)
+        assert np.array_equal(m[:, 0], o["queryIdx"]) and np.array_equal(m[:, 1], o["trainIdx"]) and (m[:, 2] == -1).all()
+        assert np.array_equal(m[:, 3].view(np.float32), o["distance"])
