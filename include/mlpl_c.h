@@ -68,7 +68,8 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  *     0 = automatic) size the matrix-core grid; "hamming_qpl" queries per lane 1|2 and "hamming_blocks_per_cu" size the VALU grids;
  *     "hamming_stamps" 1 = per-wave / per-workgroup clock stamps (mlpl_debug_hamming_stamps), 2 = one clock record per launch
  *       (mlpl_debug_hamming_clock).  "hamming_train01" 1 = {0, +1} instead of +-1 train fragments in the matrix-core Hamming kernel
- *       (same results; see knn_hamming_mfma.hip).
+ *       (same results; see knn_hamming_mfma.hip; measured no faster, default 0).  "hamming_merge_emit" 1 = with one image pair per call the
+ *       merge kernel writes the DMatch rows itself (no ratio_write launch; measured no faster, default 0).
  *   L2: "l2_mfma_waves" 0|4|8 and "l2_mfma_blocks_per_cu" shape the int8 matrix-core kernel of the forced mode (see mlpl_set_l2_path);
  *     "l2_float_mfma" 0|1|2 decides when the fp16 candidate path serves non-integer float descriptors (mlpl_set_l2_path, mode 0).
  *   RANSAC: "ransac_device_draw" (default 1) = large passes draw their samples on the device (mlpl_debug_ransac_draw); "ransac_chunk" hypotheses per device pass (0 = 32768 = the maximum; the sequential best/niters rule is replayed across

@@ -137,7 +137,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_hamming_mfma_weighted = 1;
     ctx->opt_hamming_mfma_prio = 0;
     ctx->opt_hamming_fused_merge = 1;
-    ctx->opt_hamming_merge_emit = 1;
+    ctx->opt_hamming_merge_emit = 0;  // measured (tools/single_pair_probe.py): the launch it saves is what the chained look-back costs -- 21.2-22.2 against 20.8-21.4 us
     ctx->opt_ransac_lazy_sums = 1;
     ctx->opt_ransac_overlap = 1;
     ctx->opt_ransac_f32_filter = 1;

@@ -116,7 +116,7 @@ struct mlpl_ctx {
     size_t hamming_tickets_bytes;   // ... and how many bytes of them are known to be zero
     int opt_hamming_stamps;         // diagnostics: 1 = the matrix-core kernel records per-wave clock stamps (mlpl_debug_hamming_stamps); 2 = one clock record per launch into a ring (mlpl_debug_hamming_clock)
     long long hamming_clock_launches;   // launches recorded into the clock ring so far
-    int opt_hamming_merge_emit;     // 1 (default) = one or two image pairs per call: the merge kernel writes the DMatch rows itself (no ratio_write launch)
+    int opt_hamming_merge_emit;     // 1 = one image pair per call: the merge kernel writes the DMatch rows itself (no ratio_write launch); default 0: measured, no faster
     void *hamming_scan_ptr;         // the WS_SCAN block the generation below counts for
     uint32_t hamming_scan_gen;
     int opt_hamming_train01;        // 1 = {0, +1} train fragments in the static LDS-ring kernel (accumulator = pop(query) - distance), 0 = +-1
