@@ -48,7 +48,15 @@ def test_c3_with_refit_and_reference_confidence(ctx, oracle):
     g = pose.ransac_essential(p1, p2, th, confidence=0.999, max_iters=20000, refit=True, seed=12345, ctx=ctx)
     o = oracle.ransac_essential(p1, p2, th, confidence=0.999, max_iters=20000, lesqu=True, seed=12345)
     assert g["iters"] == o["iters"] and g["n_inliers"] == o["n_inliers"]
-    assert e_dist(g["E"], o["E"]) < 1e-7 and (g["mask"] != o["mask"]).sum() <= 2
+    assert e_dist(g["E"], o["E"]) < 1e-7
+    # The refit is a 9 x 9 eigen-problem on ~2500 inliers: device and oracle agree on its model to ~1e-8, not bit for bit, and the final mask is
+    # err(E_refit) <= th^2.  A correspondence may therefore differ ONLY if the oracle's own float error of it sits on the threshold: within
+    # the relative change a 1e-7 model difference can cause (VERDICT r4 #8a: assert THAT, not a flip count).
+    flips = np.nonzero(g["mask"] != o["mask"])[0]
+    if len(flips):
+        err = oracle.sampson_err(p1, p2, o["E"]).astype(np.float64)
+        t2 = th * th
+        assert len(flips) <= 4 and (np.abs(err[flips] - t2) <= 2e-5 * t2).all(), (flips, err[flips], t2)
 
 
 @pytest.mark.parametrize("iters", [2047, 2048, 2049, 4095, 4096, 4097, 8191])

@@ -75,7 +75,13 @@ def test_cpp_facade_end_to_end(oracle, tmp_path):
     o3 = oracle.lmeds_essential(p1, p2, confidence=0.999, max_iters=2000, seed=seed)
     assert okl == 1 and o3["ok"]
     assert min(np.abs(El - o3["E"]).max(), np.abs(El + o3["E"]).max()) < 1e-8
-    assert (ml != o3["mask"]).sum() <= 2
+    # LMedS' mask is err <= sigma^2 with sigma from the median error of the best model: device and oracle agree on that model to 1e-8, so a
+    # correspondence may differ only where the oracle's own error sits on ITS boundary (between its largest inlier and smallest outlier error)
+    flips = np.nonzero(ml != o3["mask"])[0]
+    if len(flips):
+        err = oracle.sampson_err(p1, p2, o3["E"]).astype(np.float64)
+        edge_in, edge_out = err[o3["mask"] != 0].max(), err[o3["mask"] == 0].min()
+        assert len(flips) <= 4 and all(min(abs(err[i] - edge_in), abs(err[i] - edge_out)) <= 2e-5 * edge_in for i in flips), (flips, err[flips], edge_in, edge_out)
 
     # the default method, ARRSAC with refinement, called twice in one process: the second call starts from the stream positions the
     # first one left (function-local static cv::RNGs in the reference)
