@@ -342,7 +342,6 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
     const int h = l >> 5;
 
     uint4 bq[QT][KS];   // the wave's query fragments (filled below, behind the first tile copies)
-    int qpop[QT];       // {0, +1} train operand (fuse.train01): the accumulator is pop(query) - distance; both lane halves' shares of the row
     v16f cinit;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) cinit[reg] = -(float)((reg & 3) + 8 * (reg >> 2) + 4 * h) * kEps;
@@ -419,8 +418,6 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
         const int row = (qt0 + t) * 32 + (l & 31);
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (row < nq) v = *reinterpret_cast<const uint4 *>(qw + (size_t)b * q_batch_words + (size_t)row * (2 * KS) + (size_t)h * KS);
-        const int pc = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-        qpop[t] = pc + __shfl_xor(pc, 32);
         const uint32_t vs[KS] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int s = 0; s < KS; ++s)
@@ -473,10 +470,25 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
         tile_body(nfull & (NB - 1), cinit);
     }
 
+    // (the epilogue's addresses are formed from copies of the lane and tile indices the compiler cannot see through: formed in the prologue
+    // they would have to live -- as spills: 128 registers are all in use -- across the main loop)
+    int le = l, qt0e = qt0;
+    asm volatile("" : "+v"(le), "+s"(qt0e));
+    const int he = le >> 5;
     const float frame = (float)(32 * (ntiles - 1));
     int pass_acc = 0;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
+        // {0, +1} train operand (fuse.train01): the accumulator is pop(query) - distance.  The query's popcount is formed HERE, from the raw
+        // words once more (both lane halves' shares of the row), so that the option costs the main loop no registers.
+        int qpop = 0;
+        if (fuse.train01) {
+            const int row = (qt0e + t) * 32 + (le & 31);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (row < nq) v = *reinterpret_cast<const uint4 *>(qw + (size_t)b * q_batch_words + (size_t)row * (2 * KS) + (size_t)he * KS);
+            const int pc = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+            qpop = pc + __shfl_xor(pc, 32);
+        }
         uint32_t k[2];
         const float mm[2] = {m1[t], m2[t]};
 #pragma unroll
@@ -485,7 +497,7 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
                 k[j] = 0xFFFFFFFFu;
             } else {
                 const float ip = rintf(mm[j]);
-                const int d = fuse.train01 ? qpop[t] - (int)ip : (64 * KS - (int)ip) >> 1;
+                const int d = fuse.train01 ? qpop - (int)ip : (64 * KS - (int)ip) >> 1;
                 const int lrow = (int)(frame - (mm[j] - ip) * 16384.0f);
                 k[j] = ((uint32_t)d << dshift) | (uint32_t)lrow;
             }
@@ -496,11 +508,11 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
         k0 = min(k0, o0);
         k1 = umed3(k0, k1, o1);
         k0 = min(k0, o1);
-        const int q = (qt0 + t) * 32 + (l & 31);
+        const int q = (qt0e + t) * 32 + (le & 31);
         if (fuse.idx && nsplit == 1) {  // the final top-2 of the query: outputs straight from the registers
             const uint32_t lmask = (1u << dshift) - 1u;
             bool pass = false;
-            if (h == 0 && q < nq) {
+            if (he == 0 && q < nq) {
                 const size_t o = ((size_t)b * nq + q) * fuse.k;
                 const int d0 = k0 == 0xFFFFFFFFu ? -1 : (int)(k0 >> dshift);
                 fuse.idx[o] = k0 == 0xFFFFFFFFu ? -1 : (int)(row0 + (k0 & lmask));
@@ -516,8 +528,8 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
             }
             const int c = __popcll(__ballot(pass));
             pass_acc = (t & 1) ? pass_acc + c : c;   // a group of 64 queries = tiles (t even, t + 1) of this wave (qt0 is a multiple of QT)
-            if (fuse.group_counts && (t & 1) && l == 0 && (qt0 + t - 1) * 32 < nq) fuse.group_counts[(size_t)b * ((nq + 63) >> 6) + ((qt0 + t) >> 1)] = pass_acc;
-        } else if (h == 0 && q < nq) {
+            if (fuse.group_counts && (t & 1) && le == 0 && (qt0e + t - 1) * 32 < nq) fuse.group_counts[(size_t)b * ((nq + 63) >> 6) + ((qt0e + t) >> 1)] = pass_acc;
+        } else if (he == 0 && q < nq) {
             if (fuse.idx)  // read back by another workgroup of THIS launch: written through to the coherence point (see below)
                 __hip_atomic_store(reinterpret_cast<unsigned long long *>(&part[((size_t)b * nsplit + split) * nq + q]),
                                    (unsigned long long)k0 | ((unsigned long long)k1 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -579,7 +591,7 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
                 }
                 const int c = __popcll(__ballot(pass));
                 const int q_wave = q_first + rr * 256 + (int)(threadIdx.x & ~63u);   // first query of this wave's 64
-                if (fuse.group_counts && l == 0 && q_wave < nq && rr * 256 + (int)(threadIdx.x & ~63u) < 4 * QT * 32) fuse.group_counts[(size_t)b * ((nq + 63) >> 6) + (q_wave >> 6)] = c;
+                if (fuse.group_counts && le == 0 && q_wave < nq && rr * 256 + (int)(threadIdx.x & ~63u) < 4 * QT * 32) fuse.group_counts[(size_t)b * ((nq + 63) >> 6) + (q_wave >> 6)] = c;
             }
         }
     }
