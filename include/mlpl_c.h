@@ -108,7 +108,8 @@ int mlpl_get_option(mlpl_ctx *ctx, const char *name, int *value);
 #define MLPL_PROF_SOLVE_5PT 2
 #define MLPL_PROF_SCORE 3
 #define MLPL_PROF_RECOVER_POSE 4
-#define MLPL_PROF_NUM 5
+#define MLPL_PROF_COUNT 5         /* the inlier-counting kernel of a RANSAC pass alone (MLPL_PROF_SCORE brackets the whole scoring pass: it, the candidate selection and the candidates' error sums) */
+#define MLPL_PROF_NUM 6
 int mlpl_profile_enable(mlpl_ctx *ctx, int on);
 int mlpl_profile_reset(mlpl_ctx *ctx);
 int mlpl_profile_read(mlpl_ctx *ctx, int kernel_id, double *total_ms, int *launches);

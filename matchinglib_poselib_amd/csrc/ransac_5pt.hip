@@ -3567,9 +3567,11 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
             }
         }
         prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
+        prof_mark(ctx, MLPL_PROF_COUNT, 0, s);
         launch_score(s, (const double4 *)pts, n, (const double *)B.dense_E, (const int32_t *)B.dense_id, (const int32_t *)B.total, 0,
                      cnt * 10, thresh2, B.good, B.esum, !lazy, qmax, point_splits, ctx->opt_ransac_f32_filter != 0, ctx->opt_ransac_count_mpl,
                      ctx->opt_ransac_count_defer != 0);
+        prof_mark(ctx, MLPL_PROF_COUNT, 1, s);
         if (lazy) {
             // error sums only for the models that can still win (ties on the inlier count are decided by them)
             const bool sep = cnt > 2048;  // many hypotheses: per-hypothesis maxima in a grid-wide pass first
