@@ -1427,6 +1427,7 @@ __global__ __launch_bounds__(kThreads, (DEFER ? 4 : 1)) void count_models_f32_ke
     __shared__ __attribute__((aligned(16))) float tile_xy[(kTile / 2) * 8];
     __shared__ __attribute__((aligned(8))) float tile_k[(kTile / 2) * 2];
     constexpr int kPerBlock = (kThreads / 4) * MPL;
+    __shared__ int tile_kmax_bits;                        // DEFER: the tile's largest per-point band constant (non-negative floats order as their bit patterns)
     __shared__ uint32_t dq[DEFER ? kDeferCap : 1];        // (model of this workgroup) << 23 | correspondence
     __shared__ int dq_n[2];                               // entries pushed (may exceed the capacity: overflow) | unused
     __shared__ int dq_cnt[DEFER ? kPerBlock : 1];         // inliers the deferred evaluations add to the workgroup's models
@@ -1490,24 +1491,49 @@ __global__ __launch_bounds__(kThreads, (DEFER ? 4 : 1)) void count_models_f32_ke
     for (int base = blockIdx.y * kTile; base < n; base += kTile * gridDim.y) {
         const int rows = min(kTile, n - base);
         __syncthreads();
+        if constexpr (DEFER) {
+            if (tid == 0) tile_kmax_bits = 0;
+            __syncthreads();
+        }
+        float kmax_mine = 0.f;
         for (int i = tid; i < rows; i += kThreads) {
             const float *r = rec + (size_t)(base + i) * 5;
             const int k = i >> 2, slot = ((k >> 1) * 4 + (i & 3)), half = k & 1;
             float *xy = tile_xy + slot * 8 + half;
             xy[0] = r[0], xy[2] = r[1], xy[4] = r[2], xy[6] = r[3];
-            tile_k[slot * 2 + half] = r[4];
+            if constexpr (DEFER) kmax_mine = (r[4] > kmax_mine || !(r[4] == r[4])) ? r[4] : kmax_mine;   // a NaN constant must win (it disables the fast path)
+            else tile_k[slot * 2 + half] = r[4];
+        }
+        if constexpr (DEFER) {
+            // One band constant per TILE instead of one per correspondence (round 5): H needs an upper bound of KMs * KPs, and KPs = 1.01 (pmag^2 +
+            // Pmax^2 + kp) varies by at most a factor ~2 over the correspondences (Pmax is the global maximum), so the tile's largest serves all
+            // of them -- one packed multiply and one LDS read less per pair of evaluations; the band grows only in its absolute term.
+            int kb = __float_as_int(kmax_mine);
+            kb = (kmax_mine == kmax_mine) ? kb : 0x7FC00000;   // NaN orders above +inf as a bit pattern
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) kb = max(kb, __shfl_xor(kb, off));
+            if ((tid & 63) == 0) atomicMax(&tile_kmax_bits, kb);
         }
         __syncthreads();
         if (live[0]) {
             const int nk = (rows - j + 3) >> 2;  // correspondences of this lane's class in the tile: i = 4k + j, k < nk
             const int npairs = nk >> 1;
-#pragma unroll 2
-            for (int q = 0; q < npairs; ++q) {
+            f32x2 KMKP[MPL];   // DEFER: the absolute term of the band for this tile, per model
+            if constexpr (DEFER) {
+                const float kt = __int_as_float(tile_kmax_bits);
+#pragma unroll
+                for (int mi = 0; mi < MPL; ++mi) KMKP[mi] = KM[mi] * f32x2{kt, kt} * f32x2{1.0f + 0x1p-22f, 1.0f + 0x1p-22f};   // (rounded up)
+            }
+            auto eval_pair = [&](const int q) {
                 const int slot = q * 4 + j;
                 const float4 v0 = *reinterpret_cast<const float4 *>(tile_xy + slot * 8);
                 const float4 v1 = *reinterpret_cast<const float4 *>(tile_xy + slot * 8 + 4);
-                const float2 kk = *reinterpret_cast<const float2 *>(tile_k + slot * 2);
-                const f32x2 X1 = {v0.x, v0.y}, Y1 = {v0.z, v0.w}, X2 = {v1.x, v1.y}, Y2 = {v1.z, v1.w}, KP = {kk.x, kk.y};
+                f32x2 KP = {0.f, 0.f};
+                if constexpr (!DEFER) {
+                    const float2 kk = *reinterpret_cast<const float2 *>(tile_k + slot * 2);
+                    KP = f32x2{kk.x, kk.y};
+                }
+                const f32x2 X1 = {v0.x, v0.y}, Y1 = {v0.z, v0.w}, X2 = {v1.x, v1.y}, Y2 = {v1.z, v1.w};
 #pragma unroll
                 for (int mi = 0; mi < MPL; ++mi) {
                     const f32x2 *Em = E[mi];
@@ -1522,18 +1548,40 @@ __global__ __launch_bounds__(kThreads, (DEFER ? 4 : 1)) void count_models_f32_ke
                     // N32 -+ fl(qmax) D32 with ONE rounding each (the analysis above rounds the product first: at most an ulp of either
                     // quantity more, far inside the 1.02 / 1.01 slack of H)
                     const f32x2 diff = __builtin_elementwise_fma(-Q, D, N);
-                    const f32x2 H = __builtin_elementwise_fma(C6, __builtin_elementwise_fma(Q, D, N), KM[mi] * KP);
+                    f32x2 H;
+                    if constexpr (DEFER) H = __builtin_elementwise_fma(C6, __builtin_elementwise_fma(Q, D, N), KMKP[mi]);
+                    else H = __builtin_elementwise_fma(C6, __builtin_elementwise_fma(Q, D, N), KM[mi] * KP);
                     // decided inlier: diff < -H; decided outlier: diff > H (H >= 0; every comparison is false for a NaN / inf band)
                     const bool in0 = diff.x < -H.x, in1 = diff.y < -H.y;
                     const bool c0 = in0 || diff.x > H.x, c1 = in1 || diff.y > H.y;
-                    cnt[mi] += in0 ? 1 : 0;
-                    cnt[mi] += in1 ? 1 : 0;
+                    if constexpr (DEFER) {
+                        // count += carry: one v_addc_co_u32 per comparison mask (the compiler's v_cndmask + v_cndmask + v_add3 is three for two)
+                        const unsigned long long b0 = __ballot(in0), b1 = __ballot(in1);
+                        unsigned long long co;
+                        asm("v_addc_co_u32 %0, %1, %0, 0, %2" : "+v"(cnt[mi]), "=s"(co) : "s"(b0));
+                        asm("v_addc_co_u32 %0, %1, %0, 0, %2" : "+v"(cnt[mi]), "=s"(co) : "s"(b1));
+                    } else {
+                        cnt[mi] += in0 ? 1 : 0;
+                        cnt[mi] += in1 ? 1 : 0;
+                    }
                     if (__builtin_expect(live[mi] && !(c0 && c1), 0)) {  // inside the band (or out of range): the fp64 predicate decides
                         const int i0 = base + 4 * (2 * q) + j, i1 = i0 + 4;
                         if (!c0) cnt[mi] += undecided(mi, i0);
                         if (!c1) cnt[mi] += undecided(mi, i1);
                     }
                 }
+            };
+            // two pairs per trip, by hand: the loop body holds wave-wide (convergent) operations, which the unroller will not leave a remainder for
+            if constexpr (DEFER) {
+                int q = 0;
+                for (; q + 2 <= npairs; q += 2) {
+                    eval_pair(q);
+                    eval_pair(q + 1);
+                }
+                if (q < npairs) eval_pair(q);
+            } else {
+#pragma unroll 2
+                for (int q = 0; q < npairs; ++q) eval_pair(q);
             }
             if (nk & 1) {  // the unpaired last correspondence of the class: fp64
                 const int i0 = base + 4 * (nk - 1) + j;
