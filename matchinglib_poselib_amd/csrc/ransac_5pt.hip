@@ -1571,7 +1571,9 @@ __global__ __launch_bounds__(kThreads, (DEFER ? 4 : 1)) void count_models_f32_ke
                     }
                 }
             };
-            // two pairs per trip, by hand: the loop body holds wave-wide (convergent) operations, which the unroller will not leave a remainder for
+            // two pairs per trip, by hand: the loop body holds wave-wide (convergent) operations, which the unroller will not leave a remainder for.
+            // (Measured and not kept, round 5: fetching the NEXT two pairs' operands from LDS before the current two are evaluated -- 126 registers
+            // instead of 102, C3 scoring pass 0.278 against 0.263 ms, C5 counting 2.95 against 2.77 ms: gpurun_out/r5/count_defer_ab4.log.)
             if constexpr (DEFER) {
                 int q = 0;
                 for (; q + 2 <= npairs; q += 2) {
