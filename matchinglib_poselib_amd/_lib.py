@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libmlpl_hip.so")
+_LIB_PATH = os.environ.get("MLPL_LIB_PATH") or os.path.join(_HERE, "lib", "libmlpl_hip.so")   # (MLPL_LIB_PATH: tools A/B two BUILDS of the library)
 
 MLPL_OK = 0
 MLPL_E_BAD_INPUT = -1

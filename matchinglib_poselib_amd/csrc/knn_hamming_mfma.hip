@@ -131,11 +131,22 @@ __global__ __launch_bounds__(256) void hamming_expand_kernel(ExpandArgs qa, Expa
     }
 }
 
+// Round 5: the UNSCALED form.  v_mfma_scale_f32_32x32x64_f8f6f4 is a two-part instruction (a scale-load prefix + the MFMA) that reads two
+// more registers; with unit scales it computes what v_mfma_f32_32x32x64_f8f6f4 computes without them.  The compiler selects the unscaled
+// opcode when both scale operands are the constant 0 (its encoding of "no scales").  Rounds 1-4 issued the scaled form with E8M0 0x7F
+// (2^0) in a register: 35 cycles per MFMA in the probes against the nominal 32.  MLPL_MFMA_SCALED=1 rebuilds the old form for the A/B.
+#ifndef MLPL_MFMA_SCALED
+#define MLPL_MFMA_SCALED 0
+#endif
 __device__ __forceinline__ v16f mfma_fp4(uint4 a, uint4 b, v16f c) {
     const v8i av = {(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
     const v8i bv = {(int)b.x, (int)b.y, (int)b.z, (int)b.w, 0, 0, 0, 0};
-    // cbsz = blgp = 4: fp4 operands (4 registers each); E8M0 scale 0x7F = 2^0 for both
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    // cbsz = blgp = 4: fp4 operands (4 registers each)
+#if MLPL_MFMA_SCALED
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);  // E8M0 scale 0x7F = 2^0 for both
+#else
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 4, 4, 0, 0, 0, 0);
+#endif
 }
 
 // KS K-steps of 64 bits, QT query tiles (32 queries each) per wave.  A wave's work item is (batch item, train split, query

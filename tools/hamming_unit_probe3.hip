@@ -13,7 +13,11 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ v16f mf(uint4 a, uint4 b, v16f c) {
     const v8i av = {(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
     const v8i bv = {(int)b.x, (int)b.y, (int)b.z, (int)b.w, 0, 0, 0, 0};
+#ifdef PROBE_SCALED   // rounds 1-4: the scaled form with unit scales in a register (a two-part instruction); default since round 5: the unscaled opcode
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+#else
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 4, 4, 0, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ void update(float &m1r, float &m2r, const v16f &acc) {
     float m1 = m1r + 0.001953125f, m2 = m2r + 0.001953125f;
