@@ -328,8 +328,11 @@ struct HammingFuse {
     unsigned long long launch_no;
 };
 
-template <int QT, int PRIO>
-__global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
+// NW (round 5) = waves per workgroup, 4 or 8: waves 0..3 copy one K-step of every tile each, ALL NW read it -- with 8 waves a tile is
+// fetched and a barrier passed once per eight units' worth of query tiles instead of four (tools/hamming_unit_probe3.hip `ringnw`: 167.9 ->
+// 159.1 cycles per unit per SIMD).  A workgroup then serves NW * QT query tiles of one (image pair, train split).
+template <int QT, int PRIO, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 4) void knn_hamming_mfma_lds_kernel(
     const uint32_t *__restrict__ qw, size_t q_batch_words, const uint4 *__restrict__ tfrag, size_t t_batch_u4, int nq, int nt,
     int rows_per_split, int nsplit, int dshift, int qblocks, int n_items, uint2 *__restrict__ part,
     unsigned long long *__restrict__ stamps, const int32_t *__restrict__ split_tile0, HammingFuse fuse) {
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
     const int qb = item % qblocks;
     const int split = (item / qblocks) % nsplit;
     const int b = item / (qblocks * nsplit);
-    const int qt0 = (qb * 4 + w) * QT;
+    const int qt0 = (qb * NW + w) * QT;
     const int h = l >> 5;
 
     uint4 bq[QT][KS];   // the wave's query fragments (filled below, behind the first tile copies)
@@ -375,6 +378,7 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
     const uint4 *tbase = tfrag + (size_t)b * t_batch_u4 + (size_t)tile0 * KS * 64 + (size_t)w * 64;  // wave-uniform
     if (PRIO == 2) tbase = tfrag + (size_t)w * 64;  // diagnostics: every workgroup streams the SAME tiles (wrong results, L1/L2-hot source)
     auto copy_tile = [&](int t_rel) {
+        if (NW > KS && w >= KS) return;  // (wave-uniform: the K-steps are copied by the first KS waves)
         __builtin_amdgcn_global_load_lds((const void *)(tbase + (size_t)t_rel * KS * 64 + l),
                                          (__attribute__((address_space(3))) void *)&ring[t_rel & (NB - 1)][w * 64], 16, 0, 0);
     };
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
     for (int it = 0; it < nfull; ++it) {
         rotate_prio();
         arrive(it);
-        if (stamps && l == 0 && it < 48) stamps[(size_t)n_items * 16 + ((size_t)item * 4 + w) * 48 + it] = __builtin_amdgcn_s_memtime();
+        if (stamps && l == 0 && it < 48) stamps[(size_t)n_items * NW * 4 + ((size_t)item * NW + w) * 48 + it] = __builtin_amdgcn_s_memtime();
         tile_body(it & (NB - 1), cinit);
     }
     if (ragged) {
@@ -565,11 +569,11 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
         __syncthreads();
         if (s_last) {
             const uint32_t lmask = (1u << dshift) - 1u;
-            const int q_first = qb * 4 * QT * 32;
+            const int q_first = qb * NW * QT * 32;
 #pragma unroll 1
-            for (int rr = 0; rr * 256 < 4 * QT * 32; ++rr) {  // (QT = 1: the first 128 threads)
-                const int ql = rr * 256 + (int)threadIdx.x;
-                const int q = ql < 4 * QT * 32 ? q_first + ql : nq;
+            for (int rr = 0; rr * (64 * NW) < NW * QT * 32; ++rr) {  // (QT = 1: the first half of the threads)
+                const int ql = rr * (64 * NW) + (int)threadIdx.x;
+                const int q = ql < NW * QT * 32 ? q_first + ql : nq;
                 unsigned long long b0 = ~0ull, b1 = ~0ull;
                 auto upd = [&](unsigned long long g) {
                     const bool lt0 = g < b0, lt1 = g < b1;
@@ -601,13 +605,13 @@ __global__ __launch_bounds__(256, 4) void knn_hamming_mfma_lds_kernel(
                     }
                 }
                 const int c = __popcll(__ballot(pass));
-                const int q_wave = q_first + rr * 256 + (int)(threadIdx.x & ~63u);   // first query of this wave's 64
-                if (fuse.group_counts && le == 0 && q_wave < nq && rr * 256 + (int)(threadIdx.x & ~63u) < 4 * QT * 32) fuse.group_counts[(size_t)b * ((nq + 63) >> 6) + (q_wave >> 6)] = c;
+                const int q_wave = q_first + rr * (64 * NW) + (int)(threadIdx.x & ~63u);   // first query of this wave's 64
+                if (fuse.group_counts && le == 0 && q_wave < nq && rr * (64 * NW) + (int)(threadIdx.x & ~63u) < NW * QT * 32) fuse.group_counts[(size_t)b * ((nq + 63) >> 6) + (q_wave >> 6)] = c;
             }
         }
     }
     if (stamps && l == 0) {
-        unsigned long long *o = stamps + ((size_t)item * 4 + w) * 4;
+        unsigned long long *o = stamps + ((size_t)item * NW + w) * 4;
         o[0] = __builtin_amdgcn_s_memtime() - st_c;
         o[1] = __builtin_amdgcn_s_memrealtime() - st_r;
         const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
@@ -864,16 +868,19 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     if (ctx->opt_hamming_mfma_qt > 0) qt = std::min(ctx->opt_hamming_mfma_qt, max_qt);
     while (ctx->opt_hamming_mfma_qt <= 0 && qt > 1 && (long long)((nqt + qt - 1) / qt) * batch < (long long)ctx->num_cus) qt >>= 1;
     const int qgroups = (nqt + qt - 1) / qt;  // wave-level work: one group of qt query tiles against one train split
-    const bool lds_ring = ks == 4 && ctx->opt_hamming_mfma_lds != 0;  // workgroup-level work: 4 query groups share the train tiles
+    const bool lds_ring = ks == 4 && ctx->opt_hamming_mfma_lds != 0;  // workgroup-level work: NW query groups share the train tiles
     const bool dyn = lds_ring && ctx->opt_hamming_mfma_lds == 2 && nt >= 32;  // ... and the train splits are drawn dynamically
-    const int qblocks = (qgroups + 3) / 4;
-    const int q_tiles_padded = lds_ring ? qblocks * 4 * qt : qgroups * qt;
+    // waves per workgroup of the static ring kernel (option hamming_mfma_waves: 0 = automatic, 4, 8): eight when every wave carries four query
+    // tiles (the throughput shape) -- a tile fetched and a barrier passed once per eight waves' units
+    const int nwv = (lds_ring && !dyn && qt == 4 && ctx->opt_hamming_mfma_waves != 4) ? (ctx->opt_hamming_mfma_waves == 16 ? 16 : 8) : 4;
+    const int qblocks = (qgroups + nwv - 1) / nwv;
+    const int q_tiles_padded = lds_ring ? qblocks * nwv * qt : qgroups * qt;
     const int t_tiles = (nt + 31) / 32;
 
     // train splits: ~4 * opt waves per CU in flight, whole tiles, bounded so that the re-based fraction stays exact
     const int bpc = lds_ring ? std::max(4, ctx->opt_hamming_mfma_blocks_per_cu) : std::max(1, ctx->opt_hamming_mfma_blocks_per_cu);
     const long long target_waves = 4LL * bpc * ctx->num_cus;
-    const long long wave_groups = lds_ring ? 4LL * qblocks : (long long)qgroups;
+    const long long wave_groups = lds_ring ? (long long)nwv * qblocks : (long long)qgroups;
     long long want = (target_waves + wave_groups * batch - 1) / (wave_groups * batch);
     int nsplit = (int)std::max<long long>(1, std::min<long long>(want, t_tiles));
     int rps = ((nt + nsplit - 1) / nsplit + 31) / 32 * 32;
@@ -942,7 +949,7 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     // (weights 1/cost) let the four finish together.  Correctness never depends on this: the table only moves split boundaries, and
     // it is used only when every query block of a (pair, split) has the same rank.
     const int32_t *split_tab = nullptr;
-    if (lds_ring && !dyn && ctx->opt_hamming_mfma_weighted && blocks == 4LL * ctx->num_cus && nsplit >= 4 && nsplit <= 256 &&
+    if (lds_ring && !dyn && nwv == 4 && ctx->opt_hamming_mfma_weighted && blocks == 4LL * ctx->num_cus && nsplit >= 4 && nsplit <= 256 &&
         batch * (nsplit + 1) <= 4096) {
         const int per_xcd = (int)(grid.x >> 3);
         std::vector<int> rank((size_t)batch * nsplit, -1);
@@ -998,7 +1005,7 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     ctx->dbg_stamp_items = 0;
     if (ctx->opt_hamming_stamps == 1) {
         void *sp = nullptr;
-        const long long waves = lds_ring ? items * 4 : items;
+        const long long waves = lds_ring ? items * nwv : items;
         // per-wave records (4 x u64), then a per-tile clock trace of 48 u64 per wave (LDS-ring kernel, static splits)
         if ((rc = ws_get(ctx, WS_DEBUG, (size_t)waves * (32 + 48 * 8), &sp))) return rc;
         MLPL_HIP_TRY(hipMemsetAsync(sp, 0, (size_t)waves * (32 + 48 * 8), s));
@@ -1050,7 +1057,13 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
             hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<QT_, 0>), grid, dim3(256), 0, s, qw, q_batch_words, (const uint4 *)tf, \
                                t_u4, nq, nt, rps, nsplit, dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab, fuse);         \
     } while (0)
-        if (qt == 4) MLPL_RING_LAUNCH(4);
+        if (qt == 4 && nwv == 16)
+            hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<4, 0, 16>), grid, dim3(1024), 0, s, qw, q_batch_words, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit,
+                               dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab, fuse);
+        else if (qt == 4 && nwv == 8)
+            hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<4, 0, 8>), grid, dim3(512), 0, s, qw, q_batch_words, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit,
+                               dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab, fuse);
+        else if (qt == 4) MLPL_RING_LAUNCH(4);
         else if (qt == 2) MLPL_RING_LAUNCH(2);
         else MLPL_RING_LAUNCH(1);
 #undef MLPL_RING_LAUNCH

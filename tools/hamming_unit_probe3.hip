@@ -424,6 +424,92 @@ void run_big(const uint4 *src, float *out) {
     hipFree(dc);
 }
 
+
+// Round 5: the ring with NW waves per workgroup (waves 0..3 copy one K-step each, all NW read the tile; one barrier per tile) at WPE waves per
+// SIMD: what a workgroup of 10 waves with two query tiles per wave (5 waves per SIMD) or of 8 / 16 waves would cost per unit.
+template <int QT, int NW, int WPE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void ringnw(const uint4 *__restrict__ src, float *out, int iters, long long *cyc) {
+    constexpr int NBS = 4;
+    __shared__ __attribute__((aligned(16))) uint4 ring[NBS][256];
+    for (int i = threadIdx.x; i < NBS * 256; i += 64 * NW) ring[i >> 8][i & 255] = src[i & 255];
+    __syncthreads();
+    const int l = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint4 b[QT][4];
+    for (int t = 0; t < QT; ++t)
+        for (int s = 0; s < 4; ++s) b[t][s] = src[l + 64 * (4 + 4 * t + s)];
+    v16f cinit;
+    for (int i = 0; i < 16; ++i) cinit[i] = -(float)i * (1.0f / 16384.0f);
+    float m1[QT], m2[QT];
+    for (int t = 0; t < QT; ++t) m1[t] = m2[t] = -1e30f;
+    const uint4 *tbase = src + (size_t)(w & 3) * 64;
+    auto copy_stage = [&](int st) {
+        if (w < 4)
+            __builtin_amdgcn_global_load_lds((const void *)(tbase + (size_t)((st & 7) * 256) + l),
+                                             (__attribute__((address_space(3))) void *)&ring[st & (NBS - 1)][w * 64], 16, 0, 0);
+    };
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4 *)&ring[0][0] + (uint32_t)l * 16u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    copy_stage(0);
+    copy_stage(1);
+    const long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int st = 0; st < iters; ++st) {
+        copy_stage(st + 2);
+        if (w < 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        u32x4 r[4];
+        const uint32_t addr = ring_lds + (uint32_t)(st & (NBS - 1)) * 4096u;
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                     : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(addr) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(r[0]));
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r[1]));
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(r[2]));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[3]));
+        uint4 a[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[s] = make_uint4(r[s].x, r[s].y, r[s].z, r[s].w);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            v16f acc = mf(a[0], b[t][0], cinit);
+#pragma unroll
+            for (int s = 1; s < 4; ++s) acc = mf(a[s], b[t][s], acc);
+            update(m1[t], m2[t], acc);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        const int wv = blockIdx.x * NW + (threadIdx.x >> 6);
+        cyc[4 * wv] = t1 - t0, cyc[4 * wv + 1] = r1 - r0, cyc[4 * wv + 2] = r0, cyc[4 * wv + 3] = r1;
+    }
+    float sres = 0.f;
+    for (int t = 0; t < QT; ++t) sres += m1[t] + m2[t];
+    out[(blockIdx.x * blockDim.x + threadIdx.x) & 16383] = sres;
+}
+template <int QT, int NW, int WPE>
+void run_ringnw(const uint4 *src, float *out) {
+    long long *dc;
+    const int blocks = 256 * WPE * 4 / NW, waves = blocks * NW, iters = 3000;
+    hipMalloc(&dc, waves * 32);
+    int nb = 0;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ringnw<QT, NW, WPE>, 64 * NW, 0);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((ringnw<QT, NW, WPE>), dim3(blocks), dim3(64 * NW), 0, 0, src, out, iters, dc);
+    std::vector<long long> h(waves * 4);
+    hipMemcpy(h.data(), dc, waves * 32, hipMemcpyDeviceToHost);
+    double cs = 0, rs = 0;
+    long long rmin = h[2], rmax = h[3];
+    for (int i = 0; i < waves; ++i) {
+        cs += h[4 * i], rs += h[4 * i + 1];
+        rmin = std::min(rmin, h[4 * i + 2]);
+        rmax = std::max(rmax, h[4 * i + 3]);
+    }
+    const double span_cycles = (double)(rmax - rmin) * (cs / rs);
+    printf("ringnw: QT=%d waves/workgroup=%d waves/SIMD=%d (occupancy API: %d blocks/CU): %.3f GHz -> %.1f cycles per unit per SIMD (AGGREGATE)\n", QT, NW, WPE, nb,
+           cs / rs * 0.1, span_cycles / (iters * (double)QT * WPE));
+    hipFree(dc);
+}
+
 int main() {
     uint4 *src;
     float *out;
@@ -448,6 +534,16 @@ int main() {
     run<1, 1, 8, 2, 0>(src, out);
     run_ring<4, 4, 1, 1>(src, out);
     run_big<4, 4>(src, out);
+    run_ringnw<4, 4, 4>(src, out);    // = the shipped shape
+    run_ringnw<4, 8, 4>(src, out);
+    run_ringnw<4, 16, 4>(src, out);
+    run_ringnw<2, 4, 5>(src, out);
+    run_ringnw<2, 10, 5>(src, out);
+    run_ringnw<2, 8, 4>(src, out);
+    run_ringnw<3, 4, 4>(src, out);
+    run_ringnw<3, 8, 4>(src, out);
+    run_ringnw<1, 8, 8>(src, out);
+    run_ringnw<1, 16, 8>(src, out);
     hipDeviceSynchronize();
     return 0;
 }
