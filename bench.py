@@ -37,12 +37,13 @@ FLOP_PER_PAIR = 2 * 256          # one +-1 multiply-add per descriptor bit: the 
 N_SIMD = 256 * 4
 # --- matrix-core kernel (default): per unit = one 32 x 32 distance tile = 1024 pairs the kernel issues 4 fp4 MFMAs and 22 VALU
 # ops (20 for the running top-2, 2 re-base adds).  tools/hamming_unit_probe3.hip (occupancy-controlled, AGGREGATE throughput = all
-# units / wall time, in-kernel shader clock): the 4 MFMAs alone cost 141 cycles per unit per SIMD at 4 waves (LDS-fed operands;
-# nominal 4 x 32 = 128), MFMA + top-2 update 175 (they do not overlap on a SIMD: the VALU work adds), at the ~1.9 GHz the chip
-# holds on random descriptors (2.3 GHz on zeros).  MFMA_UNIT_FLOOR_CYCLES is the measured MFMA-only figure.
+# units / wall time, in-kernel shader clock; round 5: the UNSCALED opcode): the 4 MFMAs alone cost 140 cycles per unit per SIMD at
+# 4 waves (LDS-fed operands; nominal 4 x 32 = 128), MFMA + top-2 update 159 with the LDS ring at 8 waves per workgroup (they do not
+# overlap fully on a SIMD: part of the VALU work adds), at the ~1.9 GHz the chip holds on random descriptors (2.3 GHz on zeros).
+# Rounds 2-4 (scaled opcode, 4-wave workgroups): 141 / 175.
 MFMA_UNIT_PAIRS = 1024
-MFMA_UNIT_FLOOR_CYCLES = 141.0
-MFMA_UNIT_WITH_TOP2_CYCLES = 175.0
+MFMA_UNIT_FLOOR_CYCLES = 140.0       # round 5, unscaled opcode: 139.8 (the scaled form of rounds 1-4: 140.8 -- the scale prefix costs in the MIXED stream)
+MFMA_UNIT_WITH_TOP2_CYCLES = 159.0   # round 5: 159.1 for 8-wave workgroups with the LDS ring (`ringnw`), = the stream without synchronisation (rounds 2-4, scaled: 175)
 MFMA_CLOCK_HZ = 1.9e9
 # --- VALU kernels (--hamming-variant 0/1/2): 8 v_xor + 8 v_bcnt(acc) + v_lshl_or + v_med3 + v_min per descriptor pair.
 # Issue cost per wave and train row from tools/valu_peak.hip (8 waves/SIMD, cycles per wave-instruction per SIMD at 2.4 GHz).
@@ -211,7 +212,7 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
         hub = {"rounds": int(hs[0]), "merged_launches": int(hs[1]), "hub_waiting_for_host_ms": hs[2] / 1e3, "device_ms": hs[3] / 1e3}
         stats[6] = int(state["raw"]["iters"].sum())   # hypotheses of the rank's share
     prof = {}
-    for name, kid in (("knn_hamming_mfma_lds_kernel<4, 0>", 0), ("solve5pt3_kernel + roots_kernel_t<true>", 2),
+    for name, kid in (("knn_hamming_mfma_lds_kernel<4, 0, 8>", 0), ("solve5pt3_kernel + roots_kernel_t<true>", 2),
                       ("count_models_f32_kernel<512, 512>", 3), ("decompose / triangulate / select (batch)", 4)):
         ms, cnt = C.c_double(0), C.c_int(0)
         lib.mlpl_profile_read(ctx.handle, kid, C.byref(ms), C.byref(cnt))
@@ -220,7 +221,7 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
     dom = max(per_step, key=per_step.get)
     evals = float(stats[5])  # Sampson evaluations of this rank's last step
     score_ms = per_step["count_models_f32_kernel<512, 512>"]
-    ham_ms = per_step["knn_hamming_mfma_lds_kernel<4, 0>"]
+    ham_ms = per_step["knn_hamming_mfma_lds_kernel<4, 0, 8>"]
     out = {
         "metric": "image-pairs/s (C5: stereo pairs x (8k ORB BF-Hamming match + 5-pt RANSAC + cheirality))",
         "value": total * steps / elapsed, "unit": "image-pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -538,7 +539,7 @@ def main():
         kern_ms = kern_ms if kern_ms > 0 else float('nan')
         hbm_equiv = pairs_per_step_rank * BYTES_PER_PAIR / (kern_ms * 1e-3) / 1e9   # north_star's "HBM-roofline GB/s" reading
         mfma_path = args.hamming_variant == 3
-        kernel_name = "knn_hamming_mfma_lds_kernel<4, 0>" if mfma_path else "knn_hamming_partial_kernel<8>"
+        kernel_name = "knn_hamming_mfma_lds_kernel<4, 0, 8>" if mfma_path else "knn_hamming_partial_kernel<8>"
         # traffic was measured with 8 pairs per launch: scale the per-launch figure to this run's launch size (it is per-pair work)
         traffic, traffic_src = None, None
         prof = {}   # counter-derived figures of the same launch shape from the committed profile (not measured in this run)
@@ -591,9 +592,9 @@ def main():
                 "note": "the all-pairs Hamming table as a GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 x fp4, fp32 accumulate, "
                         "exact): 2*256 FLOP per descriptor pair against the dense FP4 peak at the nominal 2.4 GHz.  Per 32x32 tile "
                         "the kernel issues 4 MFMAs and 22 VALU ops (running top-2), which do NOT overlap on a SIMD: "
-                        "mfma_only_floor_ms is the measured cost of the MFMAs alone (141 cycles per tile per SIMD at 4 waves, "
+                        "mfma_only_floor_ms is the measured cost of the MFMAs alone (140 cycles per tile per SIMD at 4 waves, "
                         "tools/hamming_unit_probe3.hip) at the ~1.9 GHz the chip holds on random descriptors, mfma_plus_top2_ms the "
-                        "measured cost of MFMAs + top-2 update with LDS-fed operands and no synchronisation (175 cycles).  steady_* = the same "
+                        "measured cost of MFMAs + top-2 update with the LDS ring at 8 waves per workgroup (159 cycles; the unscaled opcode).  steady_* = the same "
                         "step over --steady-steps further steps right behind the timed region",
                 "flop_per_pair": FLOP_PER_PAIR,
                 "mfma_only_floor_ms": floor_ms,

@@ -532,6 +532,9 @@ int main() {
     run<2, 1, 5, 2, 1>(src, out);
     run<1, 1, 8, 2, 1>(src, out);
     run<1, 1, 8, 2, 0>(src, out);
+    run<4, 2, 4, 2, 0>(src, out);   // two units' MFMA chains interleaved on two accumulators: MFMA only
+    run<4, 2, 4, 2, 1>(src, out);   // ... with the top-2 update
+    run<4, 2, 3, 2, 1>(src, out);   // ... at 3 waves per SIMD (168 registers)
     run_ring<4, 4, 1, 1>(src, out);
     run_big<4, 4>(src, out);
     run_ringnw<4, 4, 4>(src, out);    // = the shipped shape

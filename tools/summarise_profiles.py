@@ -44,7 +44,7 @@ for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm"):
     dur = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
-        if k.startswith(("knn_hamming_mfma_lds_kernel<4, 0>", "solve5pt", "roots_kernel_t<true>")):  # launched at several batch sizes (headline, 8-pair continuity, C5 extras): keep apart
+        if k.startswith(("knn_hamming_mfma_lds_kernel<4, 0", "solve5pt", "roots_kernel_t<true>")):  # launched at several batch sizes (headline, 8-pair continuity, C5 extras): keep apart
             k += " @grid " + r.get("Grid_Size", r.get("Grid_Size_X", "?"))
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -71,7 +71,7 @@ for k, e in summary.items():
         b = (2 * e["FETCH_SIZE"]["mean"] + e["WRITE_SIZE"]["mean"]) * 1024
         # the headline launch (8 pairs per launch): round 1 knn_hamming_mfma_kernel<4, 4>, since round 2 the LDS-ring kernel <4, 0>
         # (<1, 0> / <4, 1> are the single-pair extras launches)
-        if k.startswith("knn_hamming_mfma_lds_kernel<4, 0>") and k.endswith("@grid " + HEADLINE_GRID):
+        if k.startswith("knn_hamming_mfma_lds_kernel<4, 0") and k.endswith("@grid " + HEADLINE_GRID):
             traffic["knn_hamming_mfma_bytes_per_launch"] = b
             traffic["mfma_fetch_KiB_raw"] = e["FETCH_SIZE"]["mean"]
             traffic["mfma_write_KiB"] = e["WRITE_SIZE"]["mean"]
@@ -82,7 +82,7 @@ for k, e in summary.items():
 # matrix-core busy fraction of the headline launch: SQ_VALU_MFMA_BUSY_CYCLES over the SIMD-cycles of the launch (GRBM_GUI_ACTIVE sums the
 # eight XCDs' clocks; 1024 SIMDs), and the kernel's duration under `--kernel-trace` for the same grid
 for k, e in summary.items():
-    if k.startswith("knn_hamming_mfma_lds_kernel<4, 0>") and k.endswith("@grid " + HEADLINE_GRID):
+    if k.startswith("knn_hamming_mfma_lds_kernel<4, 0") and k.endswith("@grid " + HEADLINE_GRID):
         if "SQ_VALU_MFMA_BUSY_CYCLES" in e and "GRBM_GUI_ACTIVE" in e:
             cyc = e["GRBM_GUI_ACTIVE"]["mean"] / 8.0
             traffic["mfma_busy_frac"] = e["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (1024.0 * cyc)
@@ -91,7 +91,7 @@ for k, e in summary.items():
 kt = one("trace/*/*kernel_trace.csv")
 if kt:
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt))
-         if r["Kernel_Name"].find("knn_hamming_mfma_lds_kernel<4, 0>") >= 0 and r.get("Grid_Size_X", r.get("Grid_Size", "")) == HEADLINE_GRID]
+         if r["Kernel_Name"].find("knn_hamming_mfma_lds_kernel<4, 0") >= 0 and r.get("Grid_Size_X", r.get("Grid_Size", "")) == HEADLINE_GRID]
     if d:
         traffic["kernel_us_rocprof_trace"] = sum(d) / len(d) / 1e3
         traffic["kernel_launches_rocprof_trace"] = len(d)
