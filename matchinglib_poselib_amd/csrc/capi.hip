@@ -213,6 +213,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "hamming_mfma_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_mfma_blocks_per_cu = value;
     else if (!std::strcmp(name, "hamming_mfma_lds") && (value >= 0 && value <= 2)) ctx->opt_hamming_mfma_lds = value;
     else if (!std::strcmp(name, "hamming_mfma_prio") && (value >= 0 && value <= 2)) ctx->opt_hamming_mfma_prio = value;
+    else if (!std::strcmp(name, "hamming_mfma_prefetch") && (value == 0 || value == 2 || value == 4 || value == 6)) ctx->opt_hamming_mfma_prefetch = value;
     else if (!std::strcmp(name, "hamming_mfma_waves") && (value == 0 || value == 4 || value == 8 || value == 16)) ctx->opt_hamming_mfma_waves = value;
     else if (!std::strcmp(name, "hamming_mfma_weighted") && (value == 0 || value == 1)) ctx->opt_hamming_mfma_weighted = value;
     else if (!std::strcmp(name, "hamming_fused_merge") && (value == 0 || value == 1)) ctx->opt_hamming_fused_merge = value;

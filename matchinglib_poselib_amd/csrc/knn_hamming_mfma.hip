@@ -331,12 +331,14 @@ struct HammingFuse {
 // NW (round 5) = waves per workgroup, 4 or 8: waves 0..3 copy one K-step of every tile each, ALL NW read it -- with 8 waves a tile is
 // fetched and a barrier passed once per eight units' worth of query tiles instead of four (tools/hamming_unit_probe3.hip `ringnw`: 167.9 ->
 // 159.1 cycles per unit per SIMD).  A workgroup then serves NW * QT query tiles of one (image pair, train split).
-template <int QT, int PRIO, int NW = 4>
+// PD (round 5) = prefetch distance in tiles (2, 4 or 6): the copy of tile it + PD is issued in iteration it; the ring has NB >= PD + 2 slots.
+template <int QT, int PRIO, int NW = 4, int PD = 2>
 __global__ __launch_bounds__(64 * NW, 4) void knn_hamming_mfma_lds_kernel(
     const uint32_t *__restrict__ qw, size_t q_batch_words, const uint4 *__restrict__ tfrag, size_t t_batch_u4, int nq, int nt,
     int rows_per_split, int nsplit, int dshift, int qblocks, int n_items, uint2 *__restrict__ part,
     unsigned long long *__restrict__ stamps, const int32_t *__restrict__ split_tile0, HammingFuse fuse) {
-    constexpr int KS = 4, NB = 4;
+    constexpr int KS = 4, NB = PD == 2 ? 4 : 8;
+    static_assert(PD == 2 || PD == 4 || PD == 6, "prefetch distance");
     __shared__ __attribute__((aligned(16))) uint4 ring[NB][KS * 64];
     const int l = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -420,8 +422,9 @@ __global__ __launch_bounds__(64 * NW, 4) void knn_hamming_mfma_lds_kernel(
         }
     };
 
-    copy_tile(0);
-    if (ntiles > 1) copy_tile(1);
+#pragma unroll
+    for (int t = 0; t < PD; ++t)
+        if (t < ntiles) copy_tile(t);
     // (round 5: the first two tile copies are in flight BEFORE the query rows are fetched and expanded -- the two global latencies of a
     // workgroup's prologue overlap instead of adding; vmcnt retires in issue order, so the query loads' own wait also covers these copies,
     // which the first arrive() would wait for anyway)
@@ -444,14 +447,20 @@ __global__ __launch_bounds__(64 * NW, 4) void knn_hamming_mfma_lds_kernel(
     const bool ragged = row0 + ntiles * 32 > nt;
     const int nfull = ragged ? ntiles - 1 : ntiles;
     // own piece of tile `it` landed <=> at most the copies of the tiles after it are still in flight (LDS-DMA retires in issue order)
+    // (slot (it + PD) % NB was last read in iteration it + PD - NB <= it - 2, and a wave that has passed the barrier of iteration it - 1 knows
+    // that every wave has finished iteration it - 2)
     auto arrive = [&](int it) {
-        if (it + 2 < ntiles) {
-            copy_tile(it + 2);
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else if (it + 1 < ntiles) {
-            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        if (it + PD < ntiles) {
+            copy_tile(it + PD);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD) : "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ahead = ntiles - 1 - it;  // copies still allowed in flight: those of the tiles behind this one (< PD)
+            if (PD > 4 && ahead == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if (PD > 4 && ahead == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (PD > 2 && ahead == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (PD > 2 && ahead == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
     };
@@ -1059,6 +1068,12 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     } while (0)
         if (qt == 4 && nwv == 16)
             hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<4, 0, 16>), grid, dim3(1024), 0, s, qw, q_batch_words, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit,
+                               dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab, fuse);
+        else if (qt == 4 && nwv == 8 && ctx->opt_hamming_mfma_prefetch == 4)
+            hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<4, 0, 8, 4>), grid, dim3(512), 0, s, qw, q_batch_words, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit,
+                               dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab, fuse);
+        else if (qt == 4 && nwv == 8 && ctx->opt_hamming_mfma_prefetch == 6)
+            hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<4, 0, 8, 6>), grid, dim3(512), 0, s, qw, q_batch_words, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit,
                                dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab, fuse);
         else if (qt == 4 && nwv == 8)
             hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<4, 0, 8>), grid, dim3(512), 0, s, qw, q_batch_words, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit,
