@@ -70,6 +70,9 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  *       (mlpl_debug_hamming_clock).  "hamming_train01" 1 = {0, +1} instead of +-1 train fragments in the matrix-core Hamming kernel
  *       (same results; see knn_hamming_mfma.hip; measured no faster, default 0).  "hamming_merge_emit" 1 = with one image pair per call the
  *       merge kernel writes the DMatch rows itself (no ratio_write launch; measured no faster, default 0).
+ *       "hamming_split_rows" 0 (default) | 8192 | 4096 = cap on the train rows one workgroup scans (4096 = rounds 1-4: every 8192-row train
+ *       set was cut in two even with the chip full); "hamming_mfma_waves" 0 (automatic) | 4 | 8 | 16 waves per workgroup and
+ *       "hamming_mfma_prefetch" 0 | 2 | 4 | 6 tiles of prefetch distance in the LDS-ring kernel.
  *   L2: "l2_mfma_waves" 0|4|8 and "l2_mfma_blocks_per_cu" shape the int8 matrix-core kernel of the forced mode (see mlpl_set_l2_path);
  *     "l2_float_mfma" 0|1|2 decides when the fp16 candidate path serves non-integer float descriptors (mlpl_set_l2_path, mode 0).
  *   RANSAC: "ransac_device_draw" (default 1) = large passes draw their samples on the device (mlpl_debug_ransac_draw); "ransac_chunk" hypotheses per device pass (0 = 32768 = the maximum; the sequential best/niters rule is replayed across

@@ -214,6 +214,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "hamming_mfma_lds") && (value >= 0 && value <= 2)) ctx->opt_hamming_mfma_lds = value;
     else if (!std::strcmp(name, "hamming_mfma_prio") && (value >= 0 && value <= 2)) ctx->opt_hamming_mfma_prio = value;
     else if (!std::strcmp(name, "hamming_mfma_prefetch") && (value == 0 || value == 2 || value == 4 || value == 6)) ctx->opt_hamming_mfma_prefetch = value;
+    else if (!std::strcmp(name, "hamming_split_rows") && (value == 0 || value == 4096 || value == 8192)) ctx->opt_hamming_split_rows = value;
     else if (!std::strcmp(name, "hamming_mfma_waves") && (value == 0 || value == 4 || value == 8 || value == 16)) ctx->opt_hamming_mfma_waves = value;
     else if (!std::strcmp(name, "hamming_mfma_weighted") && (value == 0 || value == 1)) ctx->opt_hamming_mfma_weighted = value;
     else if (!std::strcmp(name, "hamming_fused_merge") && (value == 0 || value == 1)) ctx->opt_hamming_fused_merge = value;
@@ -267,6 +268,8 @@ int mlpl_get_option(mlpl_ctx *ctx, const char *name, int *value) {
     else if (!std::strcmp(name, "hamming_train01")) *value = ctx->opt_hamming_train01;
     else if (!std::strcmp(name, "hamming_merge_emit")) *value = ctx->opt_hamming_merge_emit;
     else if (!std::strcmp(name, "hamming_stamps")) *value = ctx->opt_hamming_stamps;
+    else if (!std::strcmp(name, "hamming_split_rows")) *value = ctx->opt_hamming_split_rows;
+    else if (!std::strcmp(name, "hamming_mfma_waves")) *value = ctx->opt_hamming_mfma_waves;
     else if (!std::strcmp(name, "solver_polish")) *value = ctx->opt_solver_polish;
     else if (!std::strcmp(name, "ransac_count_mpl")) *value = ctx->opt_ransac_count_mpl;
     else if (!std::strcmp(name, "ransac_count_defer")) *value = ctx->opt_ransac_count_defer;

@@ -37,7 +37,11 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr float kEps = 1.0f / 16384.0f;  // 2^-14: row weight in the accumulator
-constexpr int kMaxRowsPerSplit = 4096;   // keeps the re-based fraction below 1/4
+// Rows of one split.  A candidate's value is I - (row - frame) * 2^-14 with I = nbits - 2 d an integer of magnitude <= 512 and the frame the
+// first row of the tile being folded, so over a split of R rows the fraction lies in (-32 eps, R eps): R <= 8192 keeps it inside
+// (-1/2, 1/2) -- rint() recovers I -- and a multiple of 2^-14 below 512 is exact in fp32.  (Up to round 4 the cap was 4096, which cut every
+// 8192-row train set of a full batch in two although the chip was already full: partials, tickets and a fold for nothing.)
+constexpr int kMaxRowsPerSplit = 8192;
 
 __device__ __forceinline__ float fmax_raw(float a, float b) {
     float r;
@@ -467,7 +471,9 @@ __global__ __launch_bounds__(64 * NW, 4) void knn_hamming_mfma_lds_kernel(
     // Optional (PRIO, off by default): the hardware arbitrates oldest-first among equal priorities, so with identical work items the four
     // resident waves of a SIMD finish one after the other (28 -> 50 us measured).  Rotating s_setprio on a clock slice (2048 shader
     // cycles ~ 1 us) by (time + wave slot) makes them finish together (38 -> 50 us) -- but the launch is no shorter: the SIMD's
-    // throughput is the same either way.  Kept as a measured negative result and a diagnostic.
+    // throughput is the same either way.  Kept as a measured negative result and a diagnostic.  (Round 5, eight-wave workgroups, one split per
+    // 8192-row train set, i.e. exactly two workgroups resident per CU for the whole launch: unrotated the older workgroup finishes at 468k
+    // cycles and the younger at 697k; rotated both finish at ~740k -- 6 % MORE cycles.  Strict oldest-first is the better schedule.)
     const int wslot = (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3u);  // HW_ID.wave_id: slot within the SIMD
     auto rotate_prio = [&]() {
         if (PRIO != 1) return;
@@ -893,7 +899,8 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     long long want = (target_waves + wave_groups * batch - 1) / (wave_groups * batch);
     int nsplit = (int)std::max<long long>(1, std::min<long long>(want, t_tiles));
     int rps = ((nt + nsplit - 1) / nsplit + 31) / 32 * 32;
-    rps = std::min(rps, kMaxRowsPerSplit);
+    const int max_rps = ctx->opt_hamming_split_rows == 4096 ? 4096 : kMaxRowsPerSplit;
+    rps = std::min(rps, max_rps);
     nsplit = (nt + rps - 1) / rps;
     if (nsplit > 65535) {
         set_error("knn_hamming: train set too large (nt=%d)", nt);
@@ -993,11 +1000,11 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
                         int upto = (int)std::llround(t_tiles * acc_w / wsum);
                         upto = std::max(upto, acc_tiles + 1);                        // at least one tile per split
                         upto = std::min(upto, t_tiles - (nsplit - 1 - sp));          // and one left for every later split
-                        upto = std::min(upto, acc_tiles + kMaxRowsPerSplit / 32);    // exact re-basing bound
+                        upto = std::min(upto, acc_tiles + max_rps / 32);          // exact re-basing bound
                         acc_tiles = upto;
                     }
                     h[bb * (nsplit + 1) + nsplit] = t_tiles;
-                    if (t_tiles - h[bb * (nsplit + 1) + nsplit - 1] > kMaxRowsPerSplit / 32) ok = false;
+                    if (t_tiles - h[bb * (nsplit + 1) + nsplit - 1] > max_rps / 32) ok = false;
                 }
                 if (ok) {
                     MLPL_HIP_TRY(hipStreamSynchronize(s));  // the previous table may still be read by kernels in flight
@@ -1074,6 +1081,9 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
                                dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab, fuse);
         else if (qt == 4 && nwv == 8 && ctx->opt_hamming_mfma_prefetch == 6)
             hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<4, 0, 8, 6>), grid, dim3(512), 0, s, qw, q_batch_words, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit,
+                               dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab, fuse);
+        else if (qt == 4 && nwv == 8 && ctx->opt_hamming_mfma_prio == 1)
+            hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<4, 1, 8>), grid, dim3(512), 0, s, qw, q_batch_words, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit,
                                dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab, fuse);
         else if (qt == 4 && nwv == 8)
             hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<4, 0, 8>), grid, dim3(512), 0, s, qw, q_batch_words, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit,

@@ -108,6 +108,7 @@ struct mlpl_ctx {
     int opt_hamming_mfma_qt;             // query tiles per wave (0 = automatic, else 1, 2 or 4)
     int opt_hamming_mfma_lds;       // 32-byte descriptors: 2 (default) = LDS-ring kernel with dynamic train splits, 1 = LDS ring with static splits, 0 = register-prefetch kernel
     int opt_hamming_mfma_waves;     // waves per workgroup of the static LDS-ring kernel: 0 (default) = automatic (8 with four query tiles per wave, else 4), 4, 8
+    int opt_hamming_split_rows;     // cap on the train rows of one split: 0 (default) = 8192, the exactness bound of the row fraction; 4096 = the cap up to round 4
     int opt_hamming_mfma_prefetch;  // prefetch distance of the ring in tiles with 8-wave workgroups: 0 / 2 (default), 4, 6
     int opt_hamming_mfma_prio;      // 1 = the LDS-ring kernel rotates wave priorities on a clock slice (equal finish times per SIMD; measured: no faster). Default 0
     int opt_hamming_mfma_weighted;  // 1 (default) = age-aware split sizes in the static LDS-ring kernel (4 workgroups per CU)

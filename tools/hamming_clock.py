@@ -33,7 +33,7 @@ def run(ctx, P, n, bpc, qt, zero=False, secs=2.0, lds=1, prio=1, weighted=1):
     for _ in range(20):
         out = match_hamming_device(dq, dt, ctx=ctx, out=out)
     torch.cuda.synchronize()
-    buf = np.zeros((1 << 16, 4), np.uint64)
+    buf = np.zeros((1 << 17, 4), np.uint64)
     ctx.lib.mlpl_debug_hamming_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     m = ctx.lib.mlpl_debug_hamming_stamps(ctx.handle, buf.ctypes.data, len(buf))
     ctx.set_option("hamming_stamps", 0)
@@ -55,8 +55,8 @@ def run(ctx, P, n, bpc, qt, zero=False, secs=2.0, lds=1, prio=1, weighted=1):
     per_cu = np.bincount(np.unique(key, return_inverse=True)[1])
     skey = key * 4 + simd
     per_simd = np.bincount(np.unique(skey, return_inverse=True)[1])
-    print(f"   start pct [0,50,90,99,100] us: {np.percentile(start,[0,50,90,99,100]).round(1)}  dur pct: {np.percentile(dur,[0,50,90,100]).round(1)}  "
-          f"end pct: {np.percentile(end,[0,50,90,100]).round(1)}  CUs seen {ncu}, waves/CU min/max {per_cu.min()}/{per_cu.max()}, "
+    print(f"   start pct [0,50,90,99,100] us: {np.percentile(start,[0,50,90,99,100]).round(1)}  dur pct: {np.percentile(dur,[0,10,50,90,100]).round(1)}  "
+          f"end pct [0,10,25,50,75,90,100]: {np.percentile(end,[0,10,25,50,75,90,100]).round(1)}  CUs seen {ncu}, waves/CU min/max {per_cu.min()}/{per_cu.max()}, "
           f"waves/SIMD min/max {per_simd.min()}/{per_simd.max()} (SIMDs seen {len(per_simd)}), per-XCD waves {np.bincount(xcc).tolist()}")
     span = (s[:, 3].max() + s[:, 1].max() - s[:, 3].min()) / 100.0   # us, launch start -> last wave end (approx)
     units_total = P * (n // 32) ** 2
@@ -67,6 +67,8 @@ def run(ctx, P, n, bpc, qt, zero=False, secs=2.0, lds=1, prio=1, weighted=1):
 
 ctx = mpa.Context(0)
 CASES = [(8, 4, 0, 1, 0), (8, 4, 0, 1, 1), (1, 4, 0, 1, 0), (1, 4, 0, 1, 1), (4, 4, 0, 1, 0), (4, 4, 0, 1, 1)]
+if len(sys.argv) > 1 and sys.argv[1] == 'c64':  # the headline launch (64 pairs): where the waves start and end
+    CASES = [(64, 4, 0, 1, 1), (64, 4, 0, 1, 1)]
 if len(sys.argv) > 1 and sys.argv[1] == 'ab':  # same-box A/B of the 8-pair step: register-prefetch kernel (r1) vs LDS ring, twice
     CASES = [(8, 3, 0, 0, 0), (8, 4, 0, 1, 0), (8, 4, 0, 1, 1), (8, 3, 0, 0, 0), (8, 4, 0, 1, 1)]
 for P, bpc, qt, lds, wt in CASES:
