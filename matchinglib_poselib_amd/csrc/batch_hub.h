@@ -236,7 +236,9 @@ class HubThreads {
     bool stop_ = false;
 };
 
-constexpr int kHubLanes = 4;  // most cohorts of runs served side by side (option hub_lanes, default all four): while one cohort's launches execute, the others' runs do their host work
+constexpr int kHubLanes = 8;         // most cohorts of runs served side by side (option hub_lanes): while one cohort's launches execute, the others' runs do their host work
+constexpr int kHubLanesDefault = 4;  // ... and how many without the option (USAC with REF_WEIGHTS: six, hub_usac_lanes_default)
+inline int hub_usac_lanes_default(int refine) { return refine == 0 ? 6 : kHubLanesDefault; }
 
 struct HubLane {  // what one cohort's hub keeps between calls (owned by the context)
     hipEvent_t ev[kHubMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
@@ -272,9 +274,12 @@ inline int hub_lane_stream(mlpl_ctx *ctx, int l, hipStream_t caller, hipStream_t
 
 // How a batched sequential estimator cuts its problems into cohorts (runs that advance together) and lanes (cohorts in flight); shared
 // by the estimators and by producers that feed them cohort by cohort (pair_batch_usac.h).
-inline int hub_cohort_size(const mlpl_ctx *ctx, int B, int cohort_default, int *n_cohorts_out, int *lanes_out) {
+// lanes_default: the estimator's own choice without the option (measured, tools/c5_lanes_sweep.py, ms per 512 image pairs at 4 / 6 / 8 lanes: USAC with
+// REF_WEIGHTS 15.8 / 14.7-15.2 / 15.0 uniform, 17.7-20 / 16.4 / 16.5 PROSAC -- its rounds are half host work, which more cohorts overlap;
+// the usac5_* refinements 46.5 / 52-56 / 54 and ARRSAC 20.6 / 20.5 / 22.8 -- their rounds are chains of small launches that only get in each other's way)
+inline int hub_cohort_size(const mlpl_ctx *ctx, int B, int cohort_default, int *n_cohorts_out, int *lanes_out, int lanes_default = kHubLanesDefault) {
     const int cohort_max = ctx->opt_hub_cohort > 0 ? ctx->opt_hub_cohort : cohort_default;
-    const int lanes_wanted = ctx->opt_hub_lanes > 0 ? std::min(ctx->opt_hub_lanes, kHubLanes) : kHubLanes;
+    const int lanes_wanted = ctx->opt_hub_lanes > 0 ? std::min(ctx->opt_hub_lanes, kHubLanes) : std::min(lanes_default, kHubLanes);
     const int cohort = B >= 8 * lanes_wanted ? std::min(cohort_max, (B + lanes_wanted - 1) / lanes_wanted) : B;
     const int n_cohorts = (B + cohort - 1) / cohort;
     if (n_cohorts_out) *n_cohorts_out = n_cohorts;

@@ -148,6 +148,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_solver_wave3 = 1;
     ctx->opt_ransac_device_draw = 1;
     ctx->opt_usac_lo_warm_start = 1;
+    ctx->opt_usac_lo5_fused_fit = 1;
     ctx->opt_hub_blocking_sync = 1;
     ctx->opt_eig_inverse_iteration = 1;
     ctx->opt_arrsac_refine_warm_start = 1;
@@ -239,7 +240,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "l2_float_mfma") && value >= 0 && value <= 2) ctx->opt_l2_float_mfma = value;
     else if (!std::strcmp(name, "arrsac_flag_points") && (value == 0 || (value >= 128 && value <= 1024 && value % 64 == 0))) ctx->opt_arrsac_flag_points = value;
     else if (!std::strcmp(name, "pair_batch") && value >= 0 && value <= 1024) ctx->opt_pair_batch = value;
-    else if (!std::strcmp(name, "hub_lanes") && value >= 0 && value <= 4) ctx->opt_hub_lanes = value;
+    else if (!std::strcmp(name, "hub_lanes") && value >= 0 && value <= 8) ctx->opt_hub_lanes = value;
     else if (!std::strcmp(name, "eig_inverse_iteration") && (value == 0 || value == 1)) ctx->opt_eig_inverse_iteration = value;
     else if (!std::strcmp(name, "hub_blocking_sync") && (value == 0 || value == 1)) ctx->opt_hub_blocking_sync = value;
     else if (!std::strcmp(name, "hub_workers") && value >= 0 && value <= 64) ctx->opt_hub_workers = value;
@@ -249,6 +250,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "pair_batch_raw_cap") && (value == 0 || (value >= 64 && value <= (1 << 22)))) ctx->opt_pair_batch_raw_cap = value;
     else if (!std::strcmp(name, "usac_lo_stepwise") && (value == 0 || value == 1)) ctx->opt_usac_lo_stepwise = value;
     else if (!std::strcmp(name, "usac_lo_warm_start") && (value == 0 || value == 1)) ctx->opt_usac_lo_warm_start = value;
+    else if (!std::strcmp(name, "usac_lo5_fused_fit") && (value == 0 || value == 1)) ctx->opt_usac_lo5_fused_fit = value;
     else if (!std::strcmp(name, "usac_sprt_fast") && (value == 0 || value == 1)) ctx->opt_usac_sprt_fast = value;
     else if (!std::strcmp(name, "ransac_host_table") && (value == 0 || value == 1)) ctx->opt_ransac_host_table = value;
     else if (!std::strcmp(name, "ransac_chunk") && value >= 0 && value <= 32768) ctx->opt_ransac_chunk = value;

@@ -17,6 +17,7 @@ enum HubKernelId {
     HK_USAC_DG_ROWS,
     HK_USAC5_BEGIN,
     HK_USAC5_CHOOSE,
+    HK_USAC5_FIT,      // refit_solve_body + roots_body + usac5_choose_body of one chain in one wave
     HK_USAC5_EVAL,
     HK_USAC5_GRAM,
     HK_ARR_SAMPLE,

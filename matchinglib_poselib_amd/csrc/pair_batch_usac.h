@@ -83,7 +83,7 @@ int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, c
     // gather are enqueued with an event behind them, and a lane starts its cohort when THAT event has completed -- the matching of the
     // later cohorts runs beside the estimators of the earlier ones.
     int n_cohorts = 0, lanes_used = 0;
-    int cohort = hub_cohort_size(ctx, B, tmpl ? kUsacBatchRuns : kArrBatchRuns, &n_cohorts, &lanes_used);
+    int cohort = hub_cohort_size(ctx, B, tmpl ? kUsacBatchRuns : kArrBatchRuns, &n_cohorts, &lanes_used, tmpl ? hub_usac_lanes_default(tmpl->refine) : kHubLanesDefault);
     const bool use_feed = ctx->opt_pair_batch_feed != 0 && n_cohorts > 1;
     if (!use_feed) cohort = B, n_cohorts = 1;  // (option pair_batch_feed = 0, A/B: everything is matched first, then the estimators start -- round 4's order)
     std::vector<hipEvent_t> ready((size_t)n_cohorts, nullptr);
@@ -103,6 +103,12 @@ int pair_pose_batch_usac_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, c
     MLPL_HIP_TRY(hipStreamWaitEvent(hres->feed, hres->feed_start, 0));
     const hipStream_t s_caller = s;
     s = hres->feed;
+    // whatever way this entry is left, nothing of it is in flight on the feed stream afterwards: its copies land in the context's pinned
+    // block and its kernels write the WS_PIPE block, which the next entry may regrow (free) at once.  (On success the stream is idle.)
+    struct FeedDrain {
+        hipStream_t f;
+        ~FeedDrain() { (void)hipStreamSynchronize(f); }
+    } feed_drain{hres->feed};
     for (int c = 0; c < n_cohorts; ++c) {
         const int b0 = c * cohort, nb = std::min(cohort, B - b0);
         rc = mlpl_match_hamming_dev(ctx, d_q + (size_t)b0 * nq * nbytes, nq, (size_t)nbytes, (size_t)nq * nbytes, d_t + (size_t)b0 * nt * nbytes, nt, (size_t)nbytes,

@@ -929,6 +929,39 @@ __device__ __forceinline__ void usac5_choose_body(const Usac5ChooseArgs &A, cons
 }
 MLPL_HUB_KERNEL(HK_USAC5_CHOOSE, Usac5ChooseArgs, usac5_choose_body, 64);
 
+// A chain's whole fit in ONE launch (round 5): refit_solve_body -> roots_body -> usac5_choose_body of chain vbx, one after the
+// other in the chain's wave.  The three were launches of their own with one wave per chain (roots: six chains per wave), each waiting for
+// the one before; the data they hand over (the chain's PolyRec, its <= 10 solutions) is written and read back by the same wave.  The
+// arithmetic is that of the separate kernels, body for body (a hypothesis's lanes in roots_body never look at another hypothesis), so
+// the models, choices and traces are the same bit for bit (option usac_lo5_fused_fit = 0: the three launches, for A/B and tests).
+struct Usac5FitArgs {
+    KHdr hdr;
+    const double * gram_part;
+    int nparts;
+    PolyRec * recs;
+    size_t part_stride;
+    int warm_on;
+    int polish;
+    double * E_tab;
+    int32_t * n_models;
+    Usac5ChooseArgs ch;
+};
+__device__ __forceinline__ void usac5_fit_body(const Usac5FitArgs &A, const int vbx, const int vby) {
+    const int c = vbx;
+    char *stb = reinterpret_cast<char *>(A.ch.st);
+    refit_solve_body(A.gram_part, A.nparts, A.recs, A.part_stride, stb + offsetof(UsacLo5State, step_fit), sizeof(UsacLo5State), c,
+                     A.warm_on ? stb + offsetof(UsacLo5State, warm) : nullptr, sizeof(UsacLo5State));
+    // (the record and the solutions go through memory as between the launches: the wave's own stores, ordered before its loads)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    wave_sync();
+    if (A.polish) roots_body<true>(A.recs + c, 0, 1, A.E_tab + (size_t)c * 90, A.n_models + c, nullptr, nullptr, nullptr, nullptr, 0, 0);
+    else roots_body<false>(A.recs + c, 0, 1, A.E_tab + (size_t)c * 90, A.n_models + c, nullptr, nullptr, nullptr, nullptr, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    wave_sync();
+    usac5_choose_body(A.ch, c, vby);
+}
+MLPL_HUB_KERNEL(HK_USAC5_FIT, Usac5FitArgs, usac5_fit_body, 64);
+
 
 // grid = (blocks, chains), 256 threads.  Evaluation `e` of the chain's model: errors in point order, per-block counts of the inliers and of
 // the members of {err < limit}, the inlier bit row in pool order.
@@ -1918,6 +1951,12 @@ struct UsacRun {
         Usac5BeginArgs ba{{C, 1}, d_p1, d_p2, (const UsacLoIn *)(d_lo_in + c0), st, gram, part_stride, outp, stride};
         L.launch(HK_USAC5_BEGIN, ba);
         auto fit = [&](int nparts, int fit_eval, int ends) {
+            if (ctx->opt_usac_lo5_fused_fit) {
+                Usac5FitArgs fa{{C, 1}, (const double *)gram, nparts, recs, part_stride, ctx->opt_usac_lo_warm_start ? 1 : 0, ctx->opt_solver_polish ? 1 : 0, Etab, nm,
+                                Usac5ChooseArgs{{C, 1}, d_p1, d_p2, (int)n, (const uint8_t *)d_lo5_flags, (const double *)Etab, (const int32_t *)nm, st, outp, stride, fit_eval, ends}};
+                L.launch(HK_USAC5_FIT, fa);
+                return;
+            }
             RefitSolveArgs ra{{C, 1}, (const double *)gram, nparts, recs, part_stride, gate, sizeof(UsacLo5State),
                               ctx->opt_usac_lo_warm_start ? reinterpret_cast<char *>(st) + offsetof(UsacLo5State, warm) : nullptr, sizeof(UsacLo5State)};
             L.launch(HK_REFIT_SOLVE, ra);
@@ -2722,7 +2761,7 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
     // Cohorts of <= kUsacBatchRuns runs, two of them in flight (batch_hub.h kHubLanes): while one cohort's merged launches execute, the
     // other cohort's runs walk their bit rows on the host.  A batch that fits one cohort is split in two halves for the same reason.
     int n_cohorts = 0, lanes = 0;
-    const int cohort = hub_cohort_size(ctx, B, kUsacBatchRuns, &n_cohorts, &lanes);
+    const int cohort = hub_cohort_size(ctx, B, kUsacBatchRuns, &n_cohorts, &lanes, hub_usac_lanes_default(params[0].refine));
     if (feed && (feed->cohort != cohort || feed->n_cohorts != n_cohorts)) {
         set_error("mlpl_usac_essential_batch_dev: the feed's cohorts are not the estimator's");
         return MLPL_E_INTERNAL;
