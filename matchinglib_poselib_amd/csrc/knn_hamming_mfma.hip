@@ -473,7 +473,11 @@ __global__ __launch_bounds__(64 * NW, 4) void knn_hamming_mfma_lds_kernel(
     // cycles ~ 1 us) by (time + wave slot) makes them finish together (38 -> 50 us) -- but the launch is no shorter: the SIMD's
     // throughput is the same either way.  Kept as a measured negative result and a diagnostic.  (Round 5, eight-wave workgroups, one split per
     // 8192-row train set, i.e. exactly two workgroups resident per CU for the whole launch: unrotated the older workgroup finishes at 468k
-    // cycles and the younger at 697k; rotated both finish at ~740k -- 6 % MORE cycles.  Strict oldest-first is the better schedule.)
+    // cycles and the younger at 697k; rotated both finish at ~740k -- 6 % MORE cycles.  Strict oldest-first is the better schedule.
+    // Priority by a workgroup's OWN progress instead -- high and low alternating every 16 / 32 / 64 tiles, one s_setprio per segment, no clock
+    // read -- lets the younger workgroup catch up at every boundary: the older one then finishes at 288-306 us instead of 247 and the launch
+    // takes 375.2-376.6 us against 375.7 (gpurun_out/r5/prio_progress_ab.log).  So the half-occupied last third is NOT slower per unit: the
+    // SIMD delivers the same units per cycle with two resident waves as with four, and the staggered finish costs nothing.)
     const int wslot = (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3u);  // HW_ID.wave_id: slot within the SIMD
     auto rotate_prio = [&]() {
         if (PRIO != 1) return;
