@@ -589,9 +589,9 @@ def main():
                 "hbm_equiv_GBps": hbm_equiv,
                 "traffic_source": traffic_src,
                 "from_profiles": prof or None,
-                "note": "the all-pairs Hamming table as a GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 x fp4, fp32 accumulate, "
+                "note": "the all-pairs Hamming table as a GEMM on v_mfma_f32_32x32x64_f8f6f4 (fp4 x fp4, fp32 accumulate, "
                         "exact): 2*256 FLOP per descriptor pair against the dense FP4 peak at the nominal 2.4 GHz.  Per 32x32 tile "
-                        "the kernel issues 4 MFMAs and 22 VALU ops (running top-2), which do NOT overlap on a SIMD: "
+                        "the kernel issues 4 MFMAs and 22 VALU ops (running top-2), which overlap only partly on a SIMD: "
                         "mfma_only_floor_ms is the measured cost of the MFMAs alone (140 cycles per tile per SIMD at 4 waves, "
                         "tools/hamming_unit_probe3.hip) at the ~1.9 GHz the chip holds on random descriptors, mfma_plus_top2_ms the "
                         "measured cost of MFMAs + top-2 update with the LDS ring at 8 waves per workgroup (159 cycles; the unscaled opcode).  steady_* = the same "
