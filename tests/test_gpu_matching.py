@@ -540,3 +540,55 @@ def test_matches_emitted_by_the_merge_kernel(ctx, oracle, nq, nt, nbytes, B):
         assert np.array_equal(outs[1][0][0][b], oi) and np.array_equal(outs[1][0][1][b], od) and len(m) == len(o)
         assert np.array_equal(m[:, 0], o["queryIdx"]) and np.array_equal(m[:, 1], o["trainIdx"]) and (m[:, 2] == -1).all()
         assert np.array_equal(m[:, 3].view(np.float32), o["distance"])
+
+
+def test_hamming_one_split_of_8192_rows_is_exact(ctx, oracle):
+    """Round 5: with the chip full (64 pairs per call) an 8192-row train set is ONE split -- the row rides in the accumulator's fraction
+    as (row - frame) * 2^-14, which spans (-1/2, 1/2) over exactly 8192 rows.  Adversarial pairs for that bound: every train row at the same
+    distance (the winner is decided by the fraction alone, rows 0 and 1), the two best in the LAST two rows, a tie between the first and the
+    last row; the rest random.  Both split caps (option hamming_split_rows 8192 / 4096) give the same tables, equal to the oracle's."""
+    import torch
+    from matchinglib_poselib_amd.matching import match_hamming_device
+    B, n = 64, 8192
+    rng = np.random.default_rng(20261005)
+    qs, ts = [], []
+    for b in range(B):
+        q, t = synth.orb_pair(n, n, seed=7000 + b)
+        qs.append(q), ts.append(t)
+    q0 = rng.integers(0, 256, 32, dtype=np.uint8)
+
+    def flipped(k, salt):  # q0 with k distinct bits flipped
+        v = q0.copy()
+        for bit in np.random.default_rng(salt).choice(256, k, replace=False):
+            v[bit >> 3] ^= np.uint8(1 << (bit & 7))
+        return v
+    # pair 1: all train rows identical -> (0, 1) for every query
+    ts[1] = np.tile(flipped(9, 1), (n, 1))
+    # pair 2: identical queries; all rows at distance 8, row 8191 at 1, row 8190 at 2
+    qs[2] = np.tile(q0, (n, 1))
+    ts[2] = np.stack([flipped(8, 100 + i) for i in range(n)])
+    ts[2][n - 1], ts[2][n - 2] = flipped(1, 5), flipped(2, 6)
+    # pair 3: identical queries; rows 0 and 8191 tie at distance 3, everything else at 8
+    qs[3] = np.tile(q0, (n, 1))
+    ts[3] = np.stack([flipped(8, 9000 + i) for i in range(n)])
+    ts[3][0], ts[3][n - 1] = flipped(3, 7), flipped(3, 8)
+    dq, dt = torch.from_numpy(np.stack(qs)).cuda(), torch.from_numpy(np.stack(ts)).cuda()
+    res = {}
+    try:
+        for cap in (8192, 4096):
+            ctx.set_option("hamming_split_rows", cap)
+            out = match_hamming_device(dq, dt, ctx=ctx)
+            torch.cuda.synchronize()
+            res[cap] = (out["idx"].cpu().numpy().copy(), out["dist"].cpu().numpy().copy(), out["count"].cpu().numpy().copy())
+    finally:
+        ctx.set_option("hamming_split_rows", 0)
+    for a, b in zip(res[8192], res[4096]):
+        assert np.array_equal(a, b)
+    idx, dist, _ = res[8192]
+    assert (idx[1] == np.array([0, 1])).all() and (dist[1, :, 0] == dist[1, :, 1]).all()
+    assert (idx[2] == np.array([n - 1, n - 2])).all() and (dist[2] == np.array([1, 2])).all()
+    assert (idx[3] == np.array([0, n - 1])).all() and (dist[3] == np.array([3, 3])).all()
+    rows = rng.choice(n, 24, replace=False)
+    for b in (0, 1, 2, 3, 17, 63):
+        oi, od = oracle.knn_hamming(qs[b][rows], ts[b])
+        assert np.array_equal(idx[b][rows], oi) and np.array_equal(dist[b][rows], od), b

@@ -133,10 +133,13 @@ def test_batched_image_pairs_with_usac_equal_the_single_problem_entries(ctx, pro
 
 
 @pytest.mark.parametrize("opts", [dict(hub_lanes=1), dict(hub_lanes=2, hub_workers=3), dict(hub_lanes=4, hub_cohort=8, hub_workers=1),
-                                  dict(hub_lanes=3, hub_cohort=16, hub_workers=64, hub_blocking_sync=0)])
+                                  dict(hub_lanes=3, hub_cohort=16, hub_workers=64, hub_blocking_sync=0),
+                                  dict(hub_lanes=8, hub_cohort=8), dict(hub_lanes=6, usac_lo5_fused_fit=0), dict(usac_lo5_fused_fit=0)])
 def test_results_do_not_depend_on_lanes_cohorts_or_workers(opts):
-    """How the runs are dealt to cohorts, lanes and worker threads is scheduling only: 40 problems under four settings of the options,
-    among them one worker for all runs of a cohort (every wait is a fiber switch on one thread) and more workers than runs."""
+    """How the runs are dealt to cohorts, lanes and worker threads is scheduling only: 40 problems under several settings of the options,
+    among them one worker for all runs of a cohort (every wait is a fiber switch on one thread), more workers than runs, eight cohorts in
+    flight (round 5), and the fit of the 5-point refinement chains as three launches instead of one (usac_lo5_fused_fit = 0; the
+    default context runs the fused launch): same models, same decision traces."""
     import torch
     import matchinglib_poselib_amd as mpa
     from matchinglib_poselib_amd import pose
