@@ -1479,8 +1479,12 @@ __global__ __launch_bounds__(kThreads, (DEFER ? 4 : 1)) void count_models_f32_ke
     const int ml0 = (tid >> 2) * MPL;  // first model of this lane within the workgroup
     auto undecided = [&](int mi, int i) -> int {
         if constexpr (DEFER) {
-            const int k = atomicAdd(&dq_n[0], 1);
-            if (k < kDeferCap) dq[k] = ((uint32_t)(ml0 + mi) << 23) | (uint32_t)i;   // (n < 2^23: the launcher's condition for this instance)
+            // (a queue that has overflowed stays overflowed and is not counted further: with an infinite band EVERY evaluation comes here,
+            // up to 256 models x 2^23 correspondences per workgroup -- the counter must not wrap)
+            if (*reinterpret_cast<volatile int *>(&dq_n[0]) <= kDeferCap) {
+                const int k = atomicAdd(&dq_n[0], 1);
+                if (k < kDeferCap) dq[k] = ((uint32_t)(ml0 + mi) << 23) | (uint32_t)i;   // (n < 2^23: the launcher's condition for this instance)
+            }
             return 0;
         } else {
             return exact(mi, i);
@@ -4038,11 +4042,17 @@ int mlpl_pair_pose_batch_lanes_dev(mlpl_ctx *const *ctxs, void *const *streams, 
         set_error("mlpl_pair_pose_batch_lanes_dev: bad arguments");
         return MLPL_E_BAD_INPUT;
     }
-    for (int l = 0; l < lanes; ++l)
+    for (int l = 0; l < lanes; ++l) {
         if (!ctxs[l] || ctxs[l]->device != ctxs[0]->device) {
             set_error("mlpl_pair_pose_batch_lanes_dev: every lane needs a context of the same device");
             return MLPL_E_BAD_INPUT;
         }
+        for (int m = 0; m < l; ++m)
+            if (ctxs[m] == ctxs[l]) {  // a context serves one call at a time (its workspaces and pinned blocks are the call's)
+                set_error("mlpl_pair_pose_batch_lanes_dev: lanes %d and %d share a context", m, l);
+                return MLPL_E_BAD_INPUT;
+            }
+    }
     const int L = std::min(lanes, n_pairs);
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<int> rcs((size_t)L, 0);
@@ -4050,25 +4060,39 @@ int mlpl_pair_pose_batch_lanes_dev(mlpl_ctx *const *ctxs, void *const *streams, 
     auto run_lane = [&](int l) {
         const int b0 = (int)((long long)n_pairs * l / L), b1 = (int)((long long)n_pairs * (l + 1) / L);
         const auto ts = std::chrono::steady_clock::now();
-        rcs[l] = b1 > b0 ? mlpl_pair_pose_batch_dev(ctxs[l], b1 - b0, d_q + (size_t)b0 * nq * nbytes, nq, d_t + (size_t)b0 * nt * nbytes, nt, nbytes,
-                                                    d_kp1 + (size_t)b0 * nq * 2, d_kp2 + (size_t)b0 * nt * 2, K0, K1, thresh, max_iters, confidence, 0, seeds + b0,
-                                                    dist, out + b0, d_matches_out ? d_matches_out + (size_t)b0 * nq : nullptr, streams[l])
-                         : MLPL_OK;
-        if (rcs[l]) msgs[l] = mlpl_last_error();  // (the error text is thread-local)
-        else if (hipStreamSynchronize(reinterpret_cast<hipStream_t>(streams[l])) != hipSuccess) rcs[l] = MLPL_E_HIP, msgs[l] = "lane stream synchronisation failed";
+        try {
+            rcs[l] = b1 > b0 ? mlpl_pair_pose_batch_dev(ctxs[l], b1 - b0, d_q + (size_t)b0 * nq * nbytes, nq, d_t + (size_t)b0 * nt * nbytes, nt, nbytes,
+                                                        d_kp1 + (size_t)b0 * nq * 2, d_kp2 + (size_t)b0 * nt * 2, K0, K1, thresh, max_iters, confidence, 0, seeds + b0,
+                                                        dist, out + b0, d_matches_out ? d_matches_out + (size_t)b0 * nq : nullptr, streams[l])
+                             : MLPL_OK;
+            if (rcs[l]) msgs[l] = mlpl_last_error();  // (the error text is thread-local)
+            else if (hipStreamSynchronize(reinterpret_cast<hipStream_t>(streams[l])) != hipSuccess) rcs[l] = MLPL_E_HIP, msgs[l] = "lane stream synchronisation failed";
+        } catch (...) {  // (nothing may unwind off a lane's thread)
+            rcs[l] = MLPL_E_INTERNAL;
+            try { msgs[l] = "mlpl_pair_pose_batch_lanes_dev: a lane ended with a C++ exception"; } catch (...) {}
+        }
         if (lane_span_ms) {
             lane_span_ms[2 * l] = std::chrono::duration<double, std::milli>(ts - t0).count();
             lane_span_ms[2 * l + 1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
     };
-    try {
+    {
         std::vector<std::thread> others;
-        for (int l = 1; l < L; ++l) others.emplace_back(run_lane, l);
+        struct Join {  // whatever happens below, no joinable thread is destroyed
+            std::vector<std::thread> &t;
+            ~Join() {
+                for (auto &x : t)
+                    if (x.joinable()) x.join();
+            }
+        } join{others};
+        try {
+            others.reserve((size_t)L);
+            for (int l = 1; l < L; ++l) others.emplace_back(run_lane, l);
+        } catch (const std::exception &e) {  // a thread could not be started: the lanes that did start finish their shares, the call fails
+            set_error("mlpl_pair_pose_batch_lanes_dev: %s", e.what());
+            return MLPL_E_INTERNAL;
+        }
         run_lane(0);
-        for (auto &t : others) t.join();
-    } catch (const std::exception &e) {
-        set_error("mlpl_pair_pose_batch_lanes_dev: %s", e.what());
-        return MLPL_E_INTERNAL;
     }
     for (int l = 0; l < L; ++l)
         if (rcs[l]) {

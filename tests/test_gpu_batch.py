@@ -252,3 +252,29 @@ def test_two_batched_calls_in_flight_give_the_same_records(ctx):
     for b in range(B):
         k = int(one["n_matches"][b])
         assert torch.equal(m1[b, :k], m2[b, :k]) and torch.equal(m1[b, :k], m3[b, :k])
+
+
+def test_lanes_entry_refuses_a_context_shared_by_two_lanes(ctx):
+    """mlpl_pair_pose_batch_lanes_dev: a context serves one call at a time (its workspaces and pinned blocks belong to the call), so two lanes
+    on ONE context are refused with MLPL_E_BAD_INPUT and a message instead of racing."""
+    import ctypes as C
+
+    import torch
+    from matchinglib_poselib_amd import batch, synth
+
+    dev = torch.device("cuda", 0)
+    sp = synth.stereo_pair(512, seed=31, unmatched_frac=0.3)
+    B = 4
+    stk = [torch.from_numpy(np.stack([sp[k]] * B)).to(dev) for k in ("desc1", "desc2", "kp1", "kp2")]
+    K = sp["K"]
+    k0 = (C.c_double * 4)(*K)
+    ctxs = (C.c_void_p * 2)(ctx.handle, ctx.handle)
+    s0, s1 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    strs = (C.c_void_p * 2)(s0.cuda_stream, s1.cuda_stream)
+    sd = np.arange(B, dtype=np.uint32)
+    res = (batch._PairResult * B)()
+    th = 0.8 * 4.0 / (np.sqrt(2.0) * 2 * (K[0] + K[1]))
+    torch.cuda.synchronize()
+    rc = ctx.lib.mlpl_pair_pose_batch_lanes_dev(ctxs, strs, 2, B, stk[0].data_ptr(), 512, stk[1].data_ptr(), 512, 32, stk[2].data_ptr(), stk[3].data_ptr(),
+                                                k0, k0, float(th), 1000, 0.999, sd.ctypes.data, 50.0, C.addressof(res), None, None)
+    assert rc == -1 and b"share a context" in ctx.lib.mlpl_last_error()   # MLPL_E_BAD_INPUT
