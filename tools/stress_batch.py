@@ -33,8 +33,8 @@ while time.time() - t0 < budget:
     th = sc[0][2]
     d1, d2 = torch.from_numpy(p1).to(dev), torch.from_numpy(p2).to(dev)
     ctx = mpa.Context(0)
-    opts = dict(hub_lanes=int(rng.integers(1, 5)), hub_cohort=int(rng.choice([8, 16, 64, 128])), hub_workers=int(rng.choice([1, 2, 7, 16])),
-                hub_blocking_sync=int(rng.integers(0, 2)))
+    opts = dict(hub_lanes=int(rng.integers(0, 9)), hub_cohort=int(rng.choice([8, 16, 64, 128])), hub_workers=int(rng.choice([1, 2, 7, 16])),
+                hub_blocking_sync=int(rng.integers(0, 2)), usac_lo5_fused_fit=int(rng.integers(0, 2)))   # (round 5: up to 8 lanes, 0 = the estimator's default; the fused fit launch on / off)
     for k, v in opts.items():
         ctx.set_option(k, v)
     seeds = [int(v) for v in rng.integers(1, 1 << 30, B)]
