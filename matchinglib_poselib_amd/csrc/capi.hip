@@ -228,6 +228,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "hamming_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_blocks_per_cu = value;
     else if (!std::strcmp(name, "ransac_lazy_sums") && (value == 0 || value == 1)) ctx->opt_ransac_lazy_sums = value;
     else if (!std::strcmp(name, "ransac_overlap") && (value == 0 || value == 1)) ctx->opt_ransac_overlap = value;
+    else if (!std::strcmp(name, "ransac_dev_split") && value >= 0 && value <= 900) ctx->opt_ransac_dev_split = value;
     else if (!std::strcmp(name, "rand_cache_max") && value >= 0) ctx->opt_rand_cache_max = value;
     else if (!std::strcmp(name, "ransac_f32_filter") && (value == 0 || value == 1)) ctx->opt_ransac_f32_filter = value;
     else if (!std::strcmp(name, "arrsac_refine_warm_start") && (value == 0 || value == 1)) ctx->opt_arrsac_refine_warm_start = value;

@@ -130,6 +130,7 @@ struct mlpl_ctx {
     int opt_ransac_count_defer;     // 1 (default) = the packed-fp32 counting kernel queues its undecided evaluations in LDS and decides them workgroup-wide (same counts)
     int opt_ransac_f32_filter;      // 1 (default) = the count-only scoring kernels pre-filter in packed fp32 inside a rigorous error band (same counts)
     int opt_ransac_overlap;         // 1 (default) = large passes run their root kernels on the helper stream
+    int opt_ransac_dev_split;      // device-drawn passes above 8192 hypotheses: per mille of the pass in the first of two solver slices (0 = one slice)
     int opt_ransac_lazy_sums;       // 1 (default) = division-free inlier counts + error sums only for models that can still win
     int opt_solver_polish;          // 1 (default) = Gauss-Newton polish of every 5-point solution on the cubic constraints
     int opt_solver_wave3;           // 1 (default) = solve5pt3_kernel (three hypotheses per wave, matrices in registers); 0 = one per wave

@@ -3580,7 +3580,13 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         // the vector units and gains nothing from company -- DESIGN section 5).
         // (samples drawn on the device: nothing paces the solver, one elimination and one root launch -- 52 + 56 us for 20 000 hypotheses --
         //  beat the four overlapped slice pairs, whose small launches are latency-bound: 177 us)
-        const bool overlap = cnt > 4096 && ctx->opt_ransac_overlap != 0 && !dev_draw;
+        // Round 5 (option ransac_dev_split, per mille of the pass in its FIRST of two slices; 0 = one slice, the default): with the solver
+        // polish the root kernel of 20 000 hypotheses is 3334 waves for 3072 slots (89 us against the elimination's 59), which suggested two
+        // slices again -- the second slice's elimination beside the first slice's roots, no root launch overflowing the chip.  Measured
+        // (tools/c3_opt_ab.py, same process, alternating, identical results): one slice 0.483 ms per C3 call, 40 / 50 / 60 / 70 % in the
+        // first slice 0.508 / 0.500 / 0.500 / 0.511 ms.  Not enabled.
+        const int dev_split = (dev_draw && cnt > 8192 && ctx->opt_ransac_overlap != 0) ? ctx->opt_ransac_dev_split : 0;
+        const bool overlap = cnt > 4096 && ctx->opt_ransac_overlap != 0 && (!dev_draw || dev_split > 0);
         const int32_t *d_samples = d_samples_mapped;
         if (dev_draw) {
             const int window = (int)std::min<long long>((long long)((double)cnt * (5.0 + redraw)) + 256, INT32_MAX / 2);
@@ -3597,6 +3603,9 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
             if (cnt > 4096 && !dev_draw) {
                 const int last = std::min(2048, cnt / 8), mid = cnt - 1024 - last;
                 m = slice_no == 0 ? 1024 : slice_no == 1 ? mid / 2 : slice_no == 2 ? mid - mid / 2 : last;
+            } else if (dev_split > 0) {
+                const int first = std::max(6, std::min(cnt - 6, (int)((long long)cnt * dev_split / 1000) / 6 * 6));
+                m = slice_no == 0 ? first : cnt - first;
             }
             if (!dev_draw)
                 for (int i = off; i < off + m; ++i) draw_sample(rng, fmod_n, &h_samples[(size_t)i * 5]);
