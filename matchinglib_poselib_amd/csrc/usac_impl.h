@@ -638,6 +638,13 @@ __device__ __forceinline__ void usac_lo_body(const UsacLoArgs &A, const int vbx,
 // workgroups share a compute unit -- at 256 VGPRs a workgroup owns its CU and the 640 workgroups of a cohort run in 2.5 rounds while nothing
 // else runs beside them): 295 spilled registers, 1.1 -> 3.2 ms per merged launch, 512 problems 13.6 -> 17.8 ms.  The 45 running sums per thread
 // are what the registers hold.
+// Round 5, the same question without the spills: the covariance of a fit accumulated in TWO passes over the fit set (24 sums, then 21 -- the
+// products and each sum's order of additions unchanged, so the fits came out bit-identical: the records of 512 pairs had the same hash), the
+// staging cut to 32 KB, the model in scalar registers; compiled for 128 registers (still 111 spilled dwords, most of them in the one-wave
+// eigenvector code) and for 256.  Merged launch of a cohort of 86 runs (430 workgroups), same box, alternating builds: this kernel 747-749 us,
+// two passes at 256 registers 806-866 us, at 128 registers (two workgroups per compute unit) 807-940 us -- a second resident workgroup does not
+// raise a compute unit's throughput here, the repeated weights and products cost 10-15 %, and the C5 call took 15.0-15.6 ms with all three
+// (it is not bound by this kernel's throughput: tools/c5_opt_ab.py under rocprofv3, gpurun_out/r5/usac_lo_kernel_ab3.log).  Not kept.
 MLPL_HUB_KERNEL(HK_USAC_LO, UsacLoArgs, usac_lo_body, kUsacLoThreads);
 
 // ---- local optimisation with the refinements of the 5-point family (poselib::RefineAlg REF_STEWENIUS(_WEIGHTS), REF_NISTER(_WEIGHTS)) ------
@@ -1373,7 +1380,25 @@ struct UsacRun {
         }
     }
 
+    // host-time account of a run (debug: MLPL_USAC_PROF=1 prints the sums of a batch): TSC ticks per section; a run's waits for the device
+    // (during which its worker thread serves other runs) are taken out through sync_timed()
+    enum { PF_SETUP = 0, PF_BUILD, PF_BATCH_HOST, PF_WAIT, PF_LO, PF_SOLVE, PF_NUM };
+    uint64_t prof[PF_NUM] = {0, 0, 0, 0, 0, 0};
+    static uint64_t tsc() { return __builtin_ia32_rdtsc(); }
+    int sync_timed() {
+        const uint64_t t0 = tsc();
+        const int rc = L.sync();
+        prof[PF_WAIT] += tsc() - t0;
+        return rc;
+    }
+
     int setup() {
+        const uint64_t pf_t0 = tsc(), pf_w0 = prof[PF_WAIT];
+        struct PfSetup {
+            UsacRun &r;
+            uint64_t t0, w0;
+            ~PfSetup() { r.prof[PF_SETUP] += (tsc() - t0) - (r.prof[PF_WAIT] - w0); }
+        } pf_setup{*this, pf_t0, pf_w0};
         normalisation();
         min_sample.assign(5, 0);
         if (prosac) init_prosac();
@@ -1697,6 +1722,11 @@ struct UsacRun {
     int run_batch(const std::vector<UsacKey> &keys) {
         const int B = (int)keys.size();
         if (B == 0) return MLPL_OK;
+        struct PfBatch {
+            UsacRun &r;
+            uint64_t t0, w0;
+            ~PfBatch() { r.prof[PF_BATCH_HOST] += (tsc() - t0) - (r.prof[PF_WAIT] - w0); }
+        } pf_batch{*this, tsc(), prof[PF_WAIT]};
         for (int b = 0; b < B; ++b)
             for (int i = 0; i < 5; ++i) h_smp[b * 5 + i] = (int32_t)keys[b].v[i];
         const size_t off_key = ((size_t)B * 4 + 63) & ~(size_t)63, off_valid = off_key + (size_t)B * 80;
@@ -1710,7 +1740,7 @@ struct UsacRun {
                          (const int32_t *)d_nm, g, thr, o_nm, o_key, o_valid, o_rows, (double *)(h_out_dev + off_E)};
         L.launch(HK_USAC_CHECK, ca);
         int rcw;
-        if ((rcw = L.sync())) return rcw;
+        if ((rcw = sync_timed())) return rcw;
         const int32_t *h_nm = (const int32_t *)h_out, *h_valid = (const int32_t *)(h_out + off_valid);
         const double *h_key = (const double *)(h_out + off_key);
         const uint64_t *h_rows = (const uint64_t *)(h_out + off_rows);
@@ -1860,7 +1890,7 @@ struct UsacRun {
                       (ctx->opt_usac_lo_warm_start ? 1 : 0) | (ctx->opt_eig_inverse_iteration ? 2 : 0)};
         L.launch(HK_USAC_LO, la);
         int rcw;
-        if ((rcw = L.sync())) return rcw;
+        if ((rcw = sync_timed())) return rcw;
         stats[3]++;
         return MLPL_OK;
     }
@@ -1873,6 +1903,11 @@ struct UsacRun {
 
     // locallyOptimizeSolution (USAC.h:947-1073) over the device chains
     int local_optimization(unsigned best_inliers, unsigned *out) {
+        struct PfLo {
+            UsacRun &r;
+            uint64_t t0, w0;
+            ~PfLo() { r.prof[PF_LO] += (tsc() - t0) - (r.prof[PF_WAIT] - w0); }
+        } pf_lo{*this, tsc(), prof[PF_WAIT]};
         *out = 0;
         if (best_inliers < 2 * kUsacLoSample) return MLPL_OK;
         std::vector<unsigned> orig(n), sample(kUsacLoSample);
@@ -1980,7 +2015,7 @@ struct UsacRun {
             fit(lo5_blocks, e, phase < 0 ? 1 : 0);
         }
         int rcw;
-        if ((rcw = L.sync())) return rcw;
+        if ((rcw = sync_timed())) return rcw;
         stats[3]++;
         return MLPL_OK;
     }
@@ -2045,6 +2080,11 @@ struct UsacRun {
 
     // locallyOptimizeSolution (USAC.h:947-1073) over the usac5 chains
     int local_optimization5(unsigned best_inliers, unsigned *out) {
+        struct PfLo {
+            UsacRun &r;
+            uint64_t t0, w0;
+            ~PfLo() { r.prof[PF_LO] += (tsc() - t0) - (r.prof[PF_WAIT] - w0); }
+        } pf_lo{*this, tsc(), prof[PF_WAIT]};
         *out = 0;
         if (best_inliers < 2 * kUsacLoSample) return MLPL_OK;
         std::vector<unsigned> orig(n), sample(kUsacLoSample);
@@ -2168,7 +2208,7 @@ struct UsacRun {
         UsacDgRowsArgs da{{B, 1}, (const double4 *)d_pts_pool, (int)n, words, (const UsacDgModel *)d_dg, dg_thr, thr, (unsigned long long *)h_out_dev};
         L.launch(HK_USAC_DG_ROWS, da);
         int rcw;
-        if ((rcw = L.sync())) return rcw;
+        if ((rcw = sync_timed())) return rcw;
         *rows = (const uint64_t *)h_out;
         stats[5]++;
         return MLPL_OK;
@@ -2498,6 +2538,11 @@ struct UsacRun {
     }
 
     int solve(bool *ok) {
+        struct PfSolve {
+            UsacRun &r;
+            uint64_t t0, w0;
+            ~PfSolve() { r.prof[PF_SOLVE] += (tsc() - t0) - (r.prof[PF_WAIT] - w0); }
+        } pf_solve{*this, tsc(), prof[PF_WAIT]};
         unsigned adaptive = max_hyp;
         bool update_sprt_stopping = true;
         *ok = false;
@@ -2530,6 +2575,7 @@ struct UsacRun {
                 // samples already consumed; a sample that recurs is solved again, with the same result)
                 if (cache_bytes > kUsacCacheBytes) cache.clear(), rows_arena.reset(), cache_bytes = 0;
                 // play the sampler forward under "no event" and solve what is coming in one batch
+                const uint64_t pf_b0 = tsc();
                 std::vector<UsacKey> batch(1, key);
                 std::unordered_set<UsacKey, UsacKeyHash> in_batch;
                 in_batch.insert(key);
@@ -2549,6 +2595,7 @@ struct UsacRun {
                     for (int i = 0; i < 5; ++i) k2.v[i] = smp[i];
                     if (cache.find(k2) == cache.end() && in_batch.insert(k2).second) batch.push_back(k2);
                 }
+                prof[PF_BUILD] += tsc() - pf_b0;
                 if ((rc = run_batch(batch))) return rc;
                 it = cache.find(key);
             }
@@ -2803,6 +2850,7 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
     }
     char *run_pin = pin + 2 * pts_bytes, *run_pin_dev = pin_dev + 2 * pts_bytes;
     const auto t_all = std::chrono::steady_clock::now();
+    const uint64_t tsc_all0 = UsacRun::tsc();
     struct LaneOut {
         long long rounds = 0, merged = 0, host_us = 0, device_us = 0, spawn_us = 0;
         int first_err = 0;
@@ -2812,6 +2860,8 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
     hipStream_t lane_stream[kHubLanes];
     for (int l = 0; l < lanes; ++l)
         if ((rc = hub_lane_stream(ctx, l, s, &lane_stream[l]))) return rc;
+    std::atomic<uint64_t> prof_sum[UsacRun::PF_NUM];
+    for (auto &v : prof_sum) v.store(0);
     auto serve_lane = [&](int l) {
         LaneOut &LO = lane_out[l];
         const hipStream_t ls = lane_stream[l];
@@ -2868,6 +2918,7 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
                         r = R.setup();
                         if (!r) r = R.solve(&ok);
                     }
+                    for (int q = 0; q < UsacRun::PF_NUM; ++q) prof_sum[q].fetch_add(R.prof[q], std::memory_order_relaxed);
                     if (!r) {
                         usac_results(R, ok, results + (size_t)b * 12);
                         if (trace && trace->lens) trace->lens[b] = R.trace_len;
@@ -2921,6 +2972,13 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
     ctx->last_usac_stats[0] = rounds, ctx->last_usac_stats[1] = merged, ctx->last_usac_stats[2] = host_us, ctx->last_usac_stats[3] = device_us;
     ctx->last_usac_stats[4] = spawn_us;
     ctx->last_usac_stats[5] = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_all).count();
+    if (const char *pe = getenv("MLPL_USAC_PROF"); pe && *pe == '1') {  // debug: where the runs' host time goes (TSC ticks summed over the runs; waits excluded)
+        static const char *names[UsacRun::PF_NUM] = {"setup", "sampler play-forward", "batch hand-over (host)", "waiting for the device", "local optimisation (host)", "solve() total"};
+        const double ticks_per_us = (double)(UsacRun::tsc() - tsc_all0) / std::max<long long>(1, ctx->last_usac_stats[5]);
+        std::fprintf(stderr, "[mlpl usac prof] %d runs, %d lanes, call %.2f ms:", B, lanes, ctx->last_usac_stats[5] / 1e3);
+        for (int q = 0; q < UsacRun::PF_NUM; ++q) std::fprintf(stderr, " %s %.1f us per run;", names[q], (double)prof_sum[q].load() / ticks_per_us / B);
+        std::fprintf(stderr, "\n");
+    }
     if (first_err) {
         if (!first_msg.empty()) set_error("%s", first_msg.c_str());
         return first_err;

@@ -38,5 +38,5 @@ for name in want:
             ctx.lib.mlpl_usac_last_stats(ctx.handle, sa.ctypes.data)   # (lanes summed; ARRSAC keeps its own)
             st = {"rounds": int(sa[0]), "merged_launches": int(sa[1]), "hub_waiting_for_host_ms": sa[2] / 1e3, "device_ms": sa[3] / 1e3}
             print(json.dumps({"case": name, "round": rnd, opt: v, "ms_min": round(min(ts), 2), "ms_median": round(float(np.median(ts)), 2),
-                              "same_records": key == ref, "hub": st}), flush=True)
+                              "same_records": key == ref, "records_sha1": __import__("hashlib").sha1(key).hexdigest()[:12], "hub": st}), flush=True)
 ctx.close()
