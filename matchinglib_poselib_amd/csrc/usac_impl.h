@@ -2862,6 +2862,8 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
         if ((rc = hub_lane_stream(ctx, l, s, &lane_stream[l]))) return rc;
     std::atomic<uint64_t> prof_sum[UsacRun::PF_NUM];
     for (auto &v : prof_sum) v.store(0);
+    std::vector<double> cohort_ms((size_t)n_cohorts * 3, 0.0);  // debug (MLPL_USAC_PROF): when a cohort was handed over, when its runs started, when they had all finished
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count(); };
     auto serve_lane = [&](int l) {
         LaneOut &LO = lane_out[l];
         const hipStream_t ls = lane_stream[l];
@@ -2891,6 +2893,7 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
                 LO.first_err = MLPL_E_INTERNAL, LO.first_msg = "mlpl_usac_essential_batch_dev: the copy of the correspondences failed";
                 break;
             }
+            cohort_ms[(size_t)c * 3] = since();
             BatchHub hub(ctx, ls, nb, l);
             const auto t_spawn = std::chrono::steady_clock::now();
             std::vector<UsacBufs> bufs((size_t)nb);
@@ -2946,8 +2949,10 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
                 hub.finish(hr);
             }, ctx->opt_hub_workers);
             LO.spawn_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_spawn).count();
+            cohort_ms[(size_t)c * 3 + 1] = since();
             const int hrc = hub.serve();
             pool.wait();
+            cohort_ms[(size_t)c * 3 + 2] = since();
             LO.rounds += hub.rounds(), LO.merged += hub.merged_launches(), LO.host_us += hub.host_us(), LO.device_us += hub.device_us();
             for (int k = 0; k < nb && !LO.first_err; ++k)
                 if (status[b0 + k] && status[b0 + k] != MLPL_E_FAILED) LO.first_err = status[b0 + k], LO.first_msg = msgs[k];
@@ -2977,6 +2982,8 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
         const double ticks_per_us = (double)(UsacRun::tsc() - tsc_all0) / std::max<long long>(1, ctx->last_usac_stats[5]);
         std::fprintf(stderr, "[mlpl usac prof] %d runs, %d lanes, call %.2f ms:", B, lanes, ctx->last_usac_stats[5] / 1e3);
         for (int q = 0; q < UsacRun::PF_NUM; ++q) std::fprintf(stderr, " %s %.1f us per run;", names[q], (double)prof_sum[q].load() / ticks_per_us / B);
+        std::fprintf(stderr, " cohorts (handed over / runs started / all finished, ms):");
+        for (int c = 0; c < n_cohorts; ++c) std::fprintf(stderr, " [%.2f %.2f %.2f]", cohort_ms[(size_t)c * 3], cohort_ms[(size_t)c * 3 + 1], cohort_ms[(size_t)c * 3 + 2]);
         std::fprintf(stderr, "\n");
     }
     if (first_err) {
