@@ -203,6 +203,9 @@ __device__ __forceinline__ void usac_check_body(const UsacCheckArgs &A, const in
     if (!__shfl(valid_model, 0)) return;
     unsigned long long *row = out_rows + ((size_t)b * 10 + slot) * words;
     unsigned long long mine = 0;  // lane l collects word w0 + l: one coalesced 512-byte store per 64 words instead of 64 single stores
+    // (Round 5 probe: this loop run TWICE -- the arithmetic of every row doubled, its stores unchanged -- leaves the merged launch at 336-346 us
+    // against 303-340: the kernel is bound by its rows crossing PCIe, ~0.58 MB per run and ~295 MB per 512 image pairs, not by the predicate.
+    // A packed-fp32 pre-filter as in the RANSAC counting kernel would therefore buy nothing here.)
     for (int w = 0; w < words; ++w) {
         const int j = w * 64 + lane;
         bool in = false;
@@ -468,6 +471,21 @@ struct UsacLoArgs {
     double * err_scratch;
     int warm_start;
 };
+// -DMLPL_USAC_LO_STAMPS (a probe build, tools/README.md): thread 0 of every workgroup adds the shader-clock ticks it spent in each section of
+// the chain to a global table (sections: 0 sample fit, 1 evaluation, 2 bit row, 3 membership + prefix, 4 covariance sums, 5 reduction, 6 fit, 7 workgroups)
+#ifdef MLPL_USAC_LO_STAMPS
+__device__ unsigned long long g_usac_lo_stamps[8];
+#define LO_STAMP(sec)                                                                                  \
+    do {                                                                                               \
+        if (tid == 0) {                                                                                \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                              \
+            atomicAdd(&g_usac_lo_stamps[sec], now_ - lo_t_);                                           \
+            lo_t_ = now_;                                                                              \
+        }                                                                                              \
+    } while (0)
+#else
+#define LO_STAMP(sec) do { } while (0)
+#endif
 __device__ __forceinline__ void usac_lo_body(const UsacLoArgs &A, const int vbx, const int vby) {
     const double *__restrict__ p1 = A.p1;
     const double *__restrict__ p2 = A.p2;
@@ -499,6 +517,10 @@ __device__ __forceinline__ void usac_lo_body(const UsacLoArgs &A, const int vbx,
     int fit_pts = 0;
     bool have_fit = false;  // L.J.Vv holds the eigenvectors of an earlier fit of this chain
     if (tid == 0) L.sweeps = 0, L.x_have = 0, L.jv_have = 0;
+#ifdef MLPL_USAC_LO_STAMPS
+    unsigned long long lo_t_ = __builtin_amdgcn_s_memtime();
+    if (tid == 0) atomicAdd(&g_usac_lo_stamps[7], 1ull);
+#endif
 
     if (I.start_step < 0) {  // model of the 14-point sample, unit weights
         double acc[45];
@@ -519,6 +541,7 @@ __device__ __forceinline__ void usac_lo_body(const UsacLoArgs &A, const int vbx,
         if (tid < 9) L.F[tid] = I.F[tid], L.E[tid] = I.E[tid];
     }
     __syncthreads();
+    LO_STAMP(0);
 
     // phase -1: the evaluation after the sample model + refit on the 2 x threshold set; phases 0..3: re-weighted refits; then the last evaluation
     for (int phase = (I.start_step < 0 ? -1 : I.start_step); phase <= kUsacLoSteps; ++phase) {
@@ -542,6 +565,7 @@ __device__ __forceinline__ void usac_lo_body(const UsacLoArgs &A, const int vbx,
             if ((tid & 63) == 0) L.scan[tid >> 6] = v;
         }
         __syncthreads();
+        LO_STAMP(1);
         if (tid == 0) {
             int s = 0;
             for (int w = 0; w < kUsacLoThreads / 64; ++w) s += L.scan[w];
@@ -565,6 +589,7 @@ __device__ __forceinline__ void usac_lo_body(const UsacLoArgs &A, const int vbx,
             }
         }
         __syncthreads();
+        LO_STAMP(2);
         ++eval;
         if (phase == kUsacLoSteps) break;
         // ---- the point set of the next fit: the first K members (ascending index) of {err < limit} ----
@@ -595,6 +620,7 @@ __device__ __forceinline__ void usac_lo_body(const UsacLoArgs &A, const int vbx,
             if (tid == 63) L.total = incl;
         }
         __syncthreads();
+        LO_STAMP(3);
         const int used = min(L.total, K);
         if (phase < 0 && tid == 0) O->cnt2 = L.total;
         if (used < 5) {  // generateRefinedModel refuses (or, after the first evaluation, the repetition ends: temp_inliers < min sample)
@@ -626,11 +652,14 @@ __device__ __forceinline__ void usac_lo_body(const UsacLoArgs &A, const int vbx,
             }
             usac_cov_add(acc, a, c, w);
         }
+        LO_STAMP(4);
         usac_reduce45(L, acc, tid);
+        LO_STAMP(5);
         usac_fit_from_cov(L, g, tid, have_fit && (warm_start & 1) != 0, (warm_start & 2) != 0);
         have_fit = true;
         fit_pts = used;
         __syncthreads();
+        LO_STAMP(6);
     }
     if (tid == 0) O->evals = eval, O->sweeps = L.sweeps;
 }
@@ -2982,6 +3011,18 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
         const double ticks_per_us = (double)(UsacRun::tsc() - tsc_all0) / std::max<long long>(1, ctx->last_usac_stats[5]);
         std::fprintf(stderr, "[mlpl usac prof] %d runs, %d lanes, call %.2f ms:", B, lanes, ctx->last_usac_stats[5] / 1e3);
         for (int q = 0; q < UsacRun::PF_NUM; ++q) std::fprintf(stderr, " %s %.1f us per run;", names[q], (double)prof_sum[q].load() / ticks_per_us / B);
+#ifdef MLPL_USAC_LO_STAMPS
+        {
+            unsigned long long h[8];
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_usac_lo_stamps), sizeof(h)) == hipSuccess && h[7]) {
+                static const char *sec[7] = {"sample fit", "evaluation", "bit row", "membership + prefix", "covariance sums", "reduction", "fit"};
+                std::fprintf(stderr, " usac_lo, 100 MHz ticks per workgroup (%llu workgroups):", h[7]);
+                for (int q = 0; q < 7; ++q) std::fprintf(stderr, " %s %.1f;", sec[q], (double)h[q] / (double)h[7]);
+                const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_usac_lo_stamps), z, sizeof(z));
+            }
+        }
+#endif
         std::fprintf(stderr, " cohorts (handed over / runs started / all finished, ms):");
         for (int c = 0; c < n_cohorts; ++c) std::fprintf(stderr, " [%.2f %.2f %.2f]", cohort_ms[(size_t)c * 3], cohort_ms[(size_t)c * 3 + 1], cohort_ms[(size_t)c * 3 + 2]);
         std::fprintf(stderr, "\n");
