@@ -88,6 +88,7 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  *     "usac_lo_warm_start" / "arrsac_refine_warm_start" (default 1) = a chain's eigen-iterations start from its previous fit;
  *     "usac_sprt_fast", "usac_lo_stepwise" (tests).  Batches of them: "hub_lanes" (cohorts of runs in flight, 1..8; 0 = the estimator's own choice: six for USAC with REF_WEIGHTS, four otherwise),
  *     "usac_lo5_fused_fit" (default 1: a fit of the 5-point refinements' chains -- solve, roots, choice -- is one launch, 0 = three),
+ *     "usac_first_batch" (samples in a run's first speculative batch, 1..128; 0 = default = as later batches: up to 128),
  *     "hub_cohort" (runs per cohort, 0 = 128), "hub_workers" (worker threads per cohort, 0 = 16: the runs are fibers on them),
  *     "hub_blocking_sync" (default 1: a cohort's thread sleeps at the end of a round instead of spinning), "pair_batch" /
  *     "pair_batch_seq" (image pairs per internal batch of mlpl_pair_pose_batch_dev, 0 = 256 / of its USAC and ARRSAC forms, 0 = 512).

@@ -251,6 +251,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "pair_batch_raw_cap") && (value == 0 || (value >= 64 && value <= (1 << 22)))) ctx->opt_pair_batch_raw_cap = value;
     else if (!std::strcmp(name, "usac_lo_stepwise") && (value == 0 || value == 1)) ctx->opt_usac_lo_stepwise = value;
     else if (!std::strcmp(name, "usac_lo_warm_start") && (value == 0 || value == 1)) ctx->opt_usac_lo_warm_start = value;
+    else if (!std::strcmp(name, "usac_first_batch") && value >= 0 && value <= 128) ctx->opt_usac_first_batch = value;
     else if (!std::strcmp(name, "usac_lo5_fused_fit") && (value == 0 || value == 1)) ctx->opt_usac_lo5_fused_fit = value;
     else if (!std::strcmp(name, "usac_sprt_fast") && (value == 0 || value == 1)) ctx->opt_usac_sprt_fast = value;
     else if (!std::strcmp(name, "ransac_host_table") && (value == 0 || value == 1)) ctx->opt_ransac_host_table = value;

@@ -178,6 +178,7 @@ struct mlpl_ctx {
     int opt_pair_batch_raw_cap;                        // tests: rand() values kept per pair for the device-side sampling (0 = 6.25 per iteration + 1024)
     int opt_arrsac_flag_points;                        // tests: correspondences every ARRSAC model is tested on up front (0 = 1024)
     int opt_arrsac_refine_warm_start;                  // 1 (default): robustEssentialRefine's rounds start their Jacobi iteration from the previous round's eigenvectors
+    int opt_usac_first_batch;                          // samples in the first speculative batch of a USAC run (0 = as every batch: up to 128; measured, no robust gain from smaller ones)
     int opt_usac_lo5_fused_fit;                        // 1 (default): a fit of a usac5_* chain (solve -> roots -> choose) is one launch; 0 = three
     int opt_usac_lo_warm_start;                        // 1 (default): a refit of a local-optimisation chain starts its Jacobi iteration from the previous fit's eigenvectors
     int opt_usac_sprt_fast;         // 1 (default) = a sequential test that survives its first 128 steps is finished word by word on bounds (usac_impl.h sprt_walk)

@@ -2615,7 +2615,15 @@ struct UsacRun {
                 std::vector<unsigned> smp(5);
                 unsigned hyp = hyp_count;
                 const unsigned horizon = std::min(std::min(adaptive, max_hyp), best == 0 ? (hyp_count < max2 ? max2 - 1 : (hyp_count < max3 ? max3 - 1 : max_hyp)) : max_hyp);
-                while (hyp < horizon && (int)batch.size() < batch_cap) {
+                // Option usac_first_batch (default 0 = as every batch, up to 128): a run's FIRST speculative batch may be smaller -- the best
+                // model changes most often at the start, every event throws the rest of a batch away, and the rows of a batch cross PCIe (with
+                // 128, PROSAC consumes 83 of the 186 samples it solves per run; with 32 it solves 126).  Speculation only: results cannot depend
+                // on it.  Measured on two boxes, 512 image pairs, alternating (tools/c5_opt_ab.py usac_first_batch ...): uniform 14.8-15.3 ->
+                // 14.5-15.3 ms at 64, PROSAC 16.0-16.6 -> 15.4-16.6 ms at 32, ConfigUSAC's default refinement 45.4-46.7 -> 44.6-47.6 ms at 32:
+                // inside the spread between runs.  Not enabled.
+                const int first_cap = ctx->opt_usac_first_batch > 0 ? ctx->opt_usac_first_batch : batch_cap;
+                const int cap_now = stats[0] == 0 ? std::min(batch_cap, first_cap) : batch_cap;
+                while (hyp < horizon && (int)batch.size() < cap_now) {
                     ++hyp;
                     if (prosac)
                         prosac_sample(r2, sub, lar, stop_len, hyp, smp);
