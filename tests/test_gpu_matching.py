@@ -592,3 +592,36 @@ def test_hamming_one_split_of_8192_rows_is_exact(ctx, oracle):
     for b in (0, 1, 2, 3, 17, 63):
         oi, od = oracle.knn_hamming(qs[b][rows], ts[b])
         assert np.array_equal(idx[b][rows], oi) and np.array_equal(dist[b][rows], od), b
+
+
+@pytest.mark.parametrize("nbytes", [64, 16, 8, 61])
+def test_hamming_long_splits_other_descriptor_widths(ctx, nbytes):
+    """The 8192-row split bound for the matrix-core kernels of the OTHER descriptor widths (register-prefetch kernel, 1 / 2 / 8 K-steps; 64
+    bytes = integer parts up to +-512): a batch large enough that a whole 8192-row train set is one split, ties everywhere (a small
+    alphabet), matrix-core = VALU kernel on every pair, both split caps."""
+    import torch
+    from matchinglib_poselib_amd.matching import match_hamming_device
+    B, nq, nt = 32, 2048, 8192
+    rng = np.random.default_rng(500 + nbytes)
+    base = rng.integers(0, 256, (7, nbytes), dtype=np.uint8)
+    q = base[rng.integers(0, 7, (B, nq))]
+    t = base[rng.integers(0, 7, (B, nt))]
+    flip = rng.random(t.shape) < 0.02
+    t = np.where(flip, rng.integers(0, 256, t.shape, dtype=np.uint8), t)
+    t[3, :] = t[3, 0]                      # one pair with every train row equal: (0, 1) everywhere
+    dq, dt = torch.from_numpy(np.ascontiguousarray(q)).cuda(), torch.from_numpy(np.ascontiguousarray(t)).cuda()
+    res = {}
+    try:
+        for name, variant, cap in (("valu", 0, 0), ("mfma", 3, 0), ("mfma4096", 3, 4096)):
+            ctx.set_option("hamming_variant", variant)
+            ctx.set_option("hamming_split_rows", cap)
+            out = match_hamming_device(dq, dt, ctx=ctx)
+            torch.cuda.synchronize()
+            res[name] = [out[k].cpu().numpy().copy() for k in ("idx", "dist", "count")]
+    finally:
+        ctx.set_option("hamming_variant", 3)
+        ctx.set_option("hamming_split_rows", 0)
+    for name in ("mfma", "mfma4096"):
+        for a, b in zip(res["valu"], res[name]):
+            assert np.array_equal(a, b), (name, nbytes)
+    assert (res["mfma"][0][3] == np.array([0, 1])).all()
