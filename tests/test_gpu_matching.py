@@ -601,7 +601,7 @@ def test_hamming_long_splits_other_descriptor_widths(ctx, nbytes):
     alphabet), matrix-core = VALU kernel on every pair, both split caps."""
     import torch
     from matchinglib_poselib_amd.matching import match_hamming_device
-    B, nq, nt = 32, 2048, 8192
+    B, nq, nt = 64, 2048, 8192           # with hamming_mfma_blocks_per_cu = 1: 16 wave groups x 64 pairs = the 1024 waves wanted -> ONE split
     rng = np.random.default_rng(500 + nbytes)
     base = rng.integers(0, 256, (7, nbytes), dtype=np.uint8)
     q = base[rng.integers(0, 7, (B, nq))]
@@ -615,12 +615,14 @@ def test_hamming_long_splits_other_descriptor_widths(ctx, nbytes):
         for name, variant, cap in (("valu", 0, 0), ("mfma", 3, 0), ("mfma4096", 3, 4096)):
             ctx.set_option("hamming_variant", variant)
             ctx.set_option("hamming_split_rows", cap)
+            ctx.set_option("hamming_mfma_blocks_per_cu", 1)
             out = match_hamming_device(dq, dt, ctx=ctx)
             torch.cuda.synchronize()
             res[name] = [out[k].cpu().numpy().copy() for k in ("idx", "dist", "count")]
     finally:
         ctx.set_option("hamming_variant", 3)
         ctx.set_option("hamming_split_rows", 0)
+        ctx.set_option("hamming_mfma_blocks_per_cu", 3)   # the library default
     for name in ("mfma", "mfma4096"):
         for a, b in zip(res["valu"], res[name]):
             assert np.array_equal(a, b), (name, nbytes)
