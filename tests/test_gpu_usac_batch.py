@@ -169,3 +169,35 @@ def test_results_do_not_depend_on_lanes_cohorts_or_workers(opts):
             assert np.array_equal(got[b]["E"].view(np.uint64), want[b]["E"].view(np.uint64)), (opts, b)
             assert got[b]["n_events"] == want[b]["n_events"] and np.array_equal(got[b]["events"], want[b]["events"]), (opts, b)
     c2.close()
+
+
+def test_debug_account_of_a_batch_prints_and_changes_nothing():
+    """MLPL_USAC_PROF=1 (diagnostics: the runs' host time by section, their statistics, every cohort's times) prints one line per batched call
+    to stderr and leaves the results alone."""
+    import subprocess
+    code = r'''
+import os, sys, hashlib
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.getcwd(), "tests", "golden"))
+import make_golden
+import matchinglib_poselib_amd as mpa
+from matchinglib_poselib_amd import pose
+B = 12
+scenes = [make_golden.usac_scene(400, 0.6, 900 + b) for b in range(B)]
+p1 = np.stack([s[0] for s in scenes]); p2 = np.stack([s[1] for s in scenes])
+dev = torch.device("cuda:0")
+ctx = mpa.Context(0)
+got = pose.usac_essential_batch(torch.from_numpy(p1).to(dev), torch.from_numpy(p2).to(dev), [400] * B, scenes[0][2], [5 + b for b in range(B)],
+                                refine=5, estimator=2, max_hyp=2000, ctx=ctx)
+print(hashlib.sha1(b"".join(g["E"].tobytes() + g["final"].tobytes() for g in got)).hexdigest())
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for prof in ("0", "1"):
+        env = dict(os.environ, MLPL_USAC_PROF=prof)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append((r.stdout.strip().splitlines()[-1], r.stderr))
+    assert outs[0][0] == outs[1][0]
+    assert "[mlpl usac prof]" in outs[1][1] and "[mlpl usac prof]" not in outs[0][1]
+    assert "samples solved" in outs[1][1] and "cohorts" in outs[1][1]
