@@ -8,8 +8,10 @@ launch per kernel, inputs resident in HBM.  The single-pair (latency) figure is 
 the fixed-size per-pair result records (match counts) of every step (= a rank's 64-pair share of a C5 batch) are gathered by one
 asynchronous RCCL all_gather that overlaps the next step's kernels.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured live with HIP events inside the library,
-see mlpl_profile_*) and `cpu_baseline` (the oracle's single-thread LUT port timed on this host).
+Rank 0 prints, LAST, one JSON line shorter than 4 KB with `roofline` (dominant kernel, measured live with HIP events inside the library,
+see mlpl_profile_*) and `cpu_baseline` (the oracle's single-thread LUT port timed on this host).  Before it: one `bench_detail {...}` line
+(everything: extras, per-step arrays, notes; also written to bench_detail.json) and one `bench_secondary {...}` line (C3 RANSAC hyp/s and
+config 5, each with its own roofline and cpu_baseline) -- see bench_record.py.
 
 `python bench.py --gpus N` works by itself: when N > 1 and no torch.distributed environment is present, this process starts the N
 rank processes (python -m torch.distributed.run on 127.0.0.1) BEFORE it touches the GPU and relays their output; under an external
@@ -110,7 +112,9 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     hub_workers = max(2, min(16, cpus // max(1, local_world) - 2))   # two threads of the share stay with the lane / Python threads
     host_threads = {"cpus_visible": cpus, "local_world_size": local_world, "hub_workers_per_cohort": hub_workers if est != "ransac" else 0,
-                    "hub_lanes": 4 if est != "ransac" else 0, "batch_lanes": 2 if est == "ransac" else 0}
+                    "hub_lanes_option": ctx.get_option("hub_lanes") if est != "ransac" else 0,   # 0 = the estimator's own choice; the lanes a call used: hub_last_internal_call
+                    "batch_lanes": 2 if est == "ransac" else 0,
+                    "gc": "gc.freeze() + gc.disable() around the timed steps (a generation-2 collection stalls every thread for 50-90 ms)"}
     if est != "ransac":
         ctx.set_option("hub_workers", hub_workers)
     usac_kw = {"usac": dict(prosac=False, refine=0), "usac_prosac": dict(prosac=True, refine=0), "usac_default_refine": dict(prosac=True, refine=5)}.get(est)
@@ -209,7 +213,8 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
     elif est != "arrsac":
         hs = np.zeros(8, np.int64)
         lib.mlpl_usac_last_stats(ctx.handle, hs.ctypes.data)
-        hub = {"rounds": int(hs[0]), "merged_launches": int(hs[1]), "hub_waiting_for_host_ms": hs[2] / 1e3, "device_ms": hs[3] / 1e3}
+        hub = {"rounds": int(hs[0]), "merged_launches": int(hs[1]), "hub_waiting_for_host_ms": hs[2] / 1e3, "device_ms": hs[3] / 1e3,
+               "lanes_used": int(hs[6]), "cohorts": int(hs[7])}
         stats[6] = int(state["raw"]["iters"].sum())   # hypotheses of the rank's share
     prof = {}
     for name, kid in (("knn_hamming_mfma_lds_kernel<4, 0, 8>", 0), ("solve5pt3_kernel + roots_kernel_t<true>", 2),
@@ -231,7 +236,7 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
         "lane_spans_ms_rank0": state.get("lane_spans"),
         "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "fp4 MFMA (Hamming, exact) + f64 / packed f32 inside a rigorous band (solver, Sampson, cheirality)", "data": "synthetic",
+        "dtype": "fp4 MFMA (Hamming) + f64 / banded packed f32", "data": "synthetic",
         "config": {"workload": f"C5: {total} stereo pairs x ({args.n} ORB-256 keypoints per image: Hamming 2-NN + 0.75 ratio -> "
                                "ImgToCamCoordTrans gather -> " + {"ransac": "RANSAC 1000 it / 0.999", "usac": "USAC (cfgUSAC, uniform sampling)",
                                                                   "usac_prosac": "USAC (cfgUSAC, PROSAC by matching cost)",
@@ -321,7 +326,14 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
 def run_c5(args, rank, local_rank, world, dev, ctx):
     rec = measure_c5(args, rank, local_rank, world, dev, ctx, args.steps, args.warmup, not args.no_cpu_baseline)
     if rank == 0:
-        print(json.dumps(rec), flush=True)
+        import bench_record
+        rec["c5"] = {k: v for k, v in rec.items() if k != "c5"}   # the same object as the secondary line's `c5`
+        if world > 1:
+            rec["rccl_ranks_seen"] = RCCL_RANKS_SEEN.get("n")
+        bench_record.emit(rec, os.path.join(ROOT, "bench_detail.json"))
+
+
+RCCL_RANKS_SEEN = {}
 
 
 def main():
@@ -380,6 +392,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        # proof in the record that the collective library saw N ranks: the world size after init and one all_reduce of ones
+        ones = torch.ones(1, dtype=torch.int32, device=dev if args.backend == "nccl" else None)
+        dist.all_reduce(ones)
+        RCCL_RANKS_SEEN["n"] = {"world_size": dist.get_world_size(), "all_reduce_of_ones": int(ones.item()), "backend": dist.get_backend()}
+        assert RCCL_RANKS_SEEN["n"]["all_reduce_of_ones"] == world
 
     import matchinglib_poselib_amd as mpa
     from matchinglib_poselib_amd import _lib, synth
@@ -390,7 +407,8 @@ def main():
     ctx.set_option("hamming_variant", args.hamming_variant)
     if args.hamming_train01 >= 0:
         ctx.set_option("hamming_train01", args.hamming_train01)
-    ctx.set_option("hamming_stamps", 2)   # one 32-byte clock record per launch of the matrix-core kernel (its first workgroup): the live shader clock
+    # (the timed region and the steady-state pass run the PRODUCTION kernel: no clock stamps; a separate stamped pass behind them records
+    #  the shader clock -- hamming_stamps = 2 adds two clock reads and one 32-byte store to the kernel's first workgroup)
     if args.workload == "c5":
         if args.steps == 200 and args.warmup == 20:   # the defaults are sized for the C2 step; a C5 step is a whole batch
             args.steps, args.warmup = 5, 2
@@ -483,7 +501,13 @@ def main():
         tot_ms, launches = C.c_double(0), C.c_int(0)
         _lib.check(lib.mlpl_profile_read(ctx.handle, 0, C.byref(tot_ms), C.byref(launches)), "profile_read")
         ms_steps = [evs[i].elapsed_time(evs[i + 1]) for i in range(nsteps)] if evs else None
-        return el, tot_ms.value / max(launches.value, 1), launches.value, ms_steps, read_clock(nsteps)
+        return el, tot_ms.value / max(launches.value, 1), launches.value, ms_steps, (read_clock(nsteps) if stamped["on"] else (np.zeros(0),) * 3)
+
+    stamped = {"on": False}
+
+    def set_stamps(on):
+        ctx.set_option("hamming_stamps", 2 if on else 0)
+        stamped["on"] = bool(on)
 
     for _ in range(args.warmup):
         step()
@@ -492,10 +516,17 @@ def main():
     # upload; the same step in a long run is measured right behind it, same buffers, same verification below.  `value` stays the former.
     steady = None
     if args.steady_steps > args.steps and args.steady_steps > 0:
-        st_el, st_kern, st_n, _, st_clk = timed_region(args.steady_steps, False)
+        st_el, st_kern, st_n, _, _ = timed_region(args.steady_steps, False)
         steady = {"steps": args.steady_steps, "ms_per_step": st_el / args.steady_steps * 1e3, "kernel_ms_avg": st_kern, "launches_timed": st_n,
-                  "value": world * P * n * n * args.steady_steps / st_el,
-                  "clock_GHz_median": float(np.median(st_clk[0])) if len(st_clk[0]) else None}
+                  "value": world * P * n * n * args.steady_steps / st_el, "clock_GHz_median": None}
+        if args.hamming_variant == 3:
+            # the same steps once more WITH the per-launch clock record: the shader clock of the steady state, and the A/B that the stamp is free
+            set_stamps(True)
+            sk_el, sk_kern, sk_n, _, st_clk = timed_region(args.steady_steps, False)
+            set_stamps(False)
+            steady["clock_GHz_median"] = float(np.median(st_clk[0])) if len(st_clk[0]) else None
+            steady["stamped_pass"] = {"steps": args.steady_steps, "ms_per_step": sk_el / args.steady_steps * 1e3, "kernel_ms_avg": sk_kern,
+                                      "launches_timed": sk_n, "what": "hamming_stamps = 2 (one clock record per launch); the figures above are without it"}
 
     class _L:   # (the name the code below reads the number of bracketed launches from)
         value = n_bracketed
@@ -559,12 +590,11 @@ def main():
         def fmt(a, nd=3):   # a list of figures as ONE short string (the driver's parsed record keeps scalars and strings, <= 128 characters)
             return " ".join((f"{x:.{nd}f}".lstrip("0") if 0 <= x < 1 else f"{x:.{nd}f}") for x in a)
 
-        clk_ghz, clk_dur_us, clk_start_us = clk_timed
         if mfma_path:
             flops = pairs_per_step_rank * FLOP_PER_PAIR          # algorithmic FLOP per launch of the dominant kernel
             achieved = flops / (kern_ms * 1e-3) / 1e12
             floor_ms = pairs_per_step_rank / MFMA_UNIT_PAIRS / N_SIMD * MFMA_UNIT_FLOOR_CYCLES / MFMA_CLOCK_HZ * 1e3
-            # key order: what a reader of the driver's `parsed` record needs first (it keeps a bounded number of keys, scalars / short strings)
+            # the first ten keys are the final line's `roofline` (bench_record.ROOFLINE_KEYS); the rest stays in bench_detail
             roofline = {
                 "kernel": kernel_name,
                 "bound": "mfma",
@@ -575,11 +605,9 @@ def main():
                 "traffic": traffic,
                 "kernel_ms_avg": kern_ms,
                 "launches_timed": launches.value,
-                # the protocol dependence in the record itself: GPU time of every timed step (one event per step on the launch stream) and
-                # the shader clock the kernel's first workgroup saw in every timed launch (s_memtime / s_memrealtime inside the kernel)
+                "mfma_busy_frac": prof.get("mfma_busy_frac"),   # from profiles/pmc_traffic.json (same launch shape; counters are not read in this run)
+                # the protocol dependence in the record itself: GPU time of every timed step (one event per step on the launch stream)
                 "ms_steps_gpu": fmt(ms_steps_gpu[:24]) if ms_steps_gpu else None,
-                "clock_GHz_steps": fmt(clk_ghz[-args.steps:][:24], 2) if len(clk_ghz) else None,
-                "clock_GHz_timed_median": float(np.median(clk_ghz[-args.steps:])) if len(clk_ghz) else None,
                 "steady_frac": (flops / (steady["kernel_ms_avg"] * 1e-3) / 1e12 / FP4_MFMA_PEAK_TFLOPS) if steady and steady["kernel_ms_avg"] > 0 else None,
                 "steady_kernel_ms_avg": steady["kernel_ms_avg"] if steady else None,
                 "steady_value": steady["value"] if steady else None,
@@ -591,7 +619,7 @@ def main():
                 "from_profiles": prof or None,
                 "note": "the all-pairs Hamming table as a GEMM on v_mfma_f32_32x32x64_f8f6f4 (fp4 x fp4, fp32 accumulate, "
                         "exact): 2*256 FLOP per descriptor pair against the dense FP4 peak at the nominal 2.4 GHz.  Per 32x32 tile "
-                        "the kernel issues 4 MFMAs and 22 VALU ops (running top-2), which overlap only partly on a SIMD: "
+                        "the kernel issues 4 MFMAs and the VALU ops of the running top-2, which overlap only partly on a SIMD: "
                         "mfma_only_floor_ms is the measured cost of the MFMAs alone (140 cycles per tile per SIMD at 4 waves, "
                         "tools/hamming_unit_probe3.hip) at the ~1.9 GHz the chip holds on random descriptors, mfma_plus_top2_ms the "
                         "measured cost of MFMAs + top-2 update with the LDS ring at 8 waves per workgroup (159 cycles; the unscaled opcode).  steady_* = the same "
@@ -601,9 +629,8 @@ def main():
                 "mfma_plus_top2_ms": floor_ms * MFMA_UNIT_WITH_TOP2_CYCLES / MFMA_UNIT_FLOOR_CYCLES,
                 "frac_of_mfma_only_floor": floor_ms / kern_ms,
                 "hbm_equiv_frac": hbm_equiv / HBM_PEAK_GBS,
-                "first_workgroup_us_steps": fmt(clk_dur_us[-args.steps:][:24], 0) if len(clk_dur_us) else None,
             }
-            dtype = "fp4 (E2M1, one value per descriptor bit) MFMA, fp32 accumulate -- exact integer distances"
+            dtype = "fp4 (E2M1 MFMA, f32 accumulate: exact)"
         else:
             roofline = {
                 "kernel": kernel_name,
@@ -639,19 +666,20 @@ def main():
             "vs_baseline": None,
             "dtype": dtype,
             "data": "synthetic",
-            # `config`: the scalars BASELINE.md section 4 quotes come FIRST (the driver's parsed record keeps the first ~24 keys, names cut
-            # at 40 characters, strings at 128); descriptive text and duplicates of top-level fields go last
+            # `config`: bench_record.CONFIG_KEYS (<= 20 scalars) go to the final line, everything else stays in bench_detail
             "config": {
-                "workload": f"C2: {n}x{n} ORB-256 BF-Hamming kNN=2 + 0.75 ratio + DMatch compaction, "
-                            f"{P} image pair(s) per GPU per step",
+                "workload": f"C2: {n}x{n} ORB-256 BF-Hamming kNN=2 + 0.75 ratio + DMatch rows, {P} image pair(s) per GPU per step",
                 "pairs_per_gpu": P,
                 "value_single_pair": (n * n / (single_ms * 1e-3)) if single_ms else None,
                 "ms_single_pair": single_ms,
+                "value_8_pairs_per_launch": (8 * n * n / (eight_ms * 1e-3)) if eight_ms else None,
                 "ms_8_pairs_per_launch": eight_ms,
                 "steady_pairs_per_s": steady["value"] if steady else None,
+                "steady_frac": roofline.get("steady_frac"),
                 "steady_kernel_ms": steady["kernel_ms_avg"] if steady else None,
-                "clock_GHz_timed_median": roofline.get("clock_GHz_timed_median"),
                 "clock_GHz_steady_median": steady["clock_GHz_median"] if steady else None,
+                "solver_polish": ctx.get_option("solver_polish"),
+                "gc": "default (the C2 steps are one library call each; the C5 steps freeze + disable it, see c5.config.host_threads)",
             },
             "roofline": roofline,
             "steady_state": steady,
@@ -670,14 +698,14 @@ def main():
                 oi, od = ora.knn_hamming(qs[pp][:nqs], ts[pp])
                 tc += time.perf_counter() - t1
                 assert np.array_equal(gi_all[pp], oi) and np.array_equal(gd_all[pp], od), f"the timed step's (idx, dist) of pair {pp} differ from the CPU path"
-            rec["config"]["verified"] = (f"(idx, dist) of the last timed step, pairs 0..{npairs_cpu - 1}, queries 0..{nqs - 1}: bit-exact vs the CPU port")
+            rec["config"]["verified"] = f"(idx, dist) of the last timed step, pairs 0..{npairs_cpu - 1}, all queries: bit-exact vs the CPU port" if nqs == n else \
+                                        f"(idx, dist) of the last timed step, pairs 0..{npairs_cpu - 1}, queries 0..{nqs - 1}: bit-exact vs the CPU port"
             rec["cpu_baseline"] = {
                 "value": npairs_cpu * nqs * n / tc,
                 "unit": "descriptor-pairs/s",
                 "cores": 1,
                 "kind": "port",
-                "sample": f"{npairs_cpu} of the step's {P} C2 pairs, {nqs} of {n} queries x {n} train rows each (byte-LUT popcount, serial, "
-                          f"{tc:.2f} s)",
+                "sample": f"{npairs_cpu} of the step's {P} C2 pairs, {nqs} of {n} queries each; byte-LUT popcount, serial, {tc:.1f} s",
                 "host_cores_available": os.cpu_count(),
             }
             # BASELINE.md "CPU-best" tier: same results with hardware popcount + OpenMP on the host cores we may use
@@ -696,6 +724,7 @@ def main():
                 time.sleep(2.0)
             k = min(args.after_idle_launches, 200)
             evs = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+            set_stamps(True)
             torch.cuda.synchronize()
             evs[0].record()
             for i in range(k):
@@ -704,14 +733,13 @@ def main():
             torch.cuda.synchronize()
             ai_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(k)]
             ai_ghz, ai_dur, _ = read_clock(k)
+            set_stamps(False)
             rec["after_idle"] = {"launches": k, "ms_steps_gpu": [round(x, 4) for x in ai_ms], "clock_GHz": [round(float(x), 3) for x in ai_ghz],
                                  "first_workgroup_us": [round(float(x), 1) for x in ai_dur],
                                  "what": "the first launches after the GPU idled through the CPU baseline: GPU time per step (events) and the "
                                          "shader clock inside each launch"}
-            rec["timed_region"] = {"ms_steps_gpu": [round(x, 4) for x in ms_steps_gpu], "clock_GHz": [round(float(x), 3) for x in clk_ghz[-args.steps:]],
-                                   "first_workgroup_us": [round(float(x), 1) for x in clk_dur_us[-args.steps:]]}
-            rec["roofline"]["after_idle_ms_steps_gpu"] = fmt(ai_ms[:24])
-            rec["roofline"]["after_idle_clock_GHz"] = fmt(ai_ghz[:24], 2)
+            rec["timed_region"] = {"ms_steps_gpu": [round(x, 4) for x in ms_steps_gpu]}
+            rec["config"]["clock_GHz_stamped_median"] = float(np.median(ai_ghz)) if len(ai_ghz) else None   # of the after-idle launches
         if not args.no_extras and world == 1:
             try:
                 import bench_extras
@@ -760,25 +788,20 @@ def main():
                           ("hamming_c2_8pairs_mfma_kernel", "hamming_8_pairs_ms")):
             if isinstance(ex.get(name), dict) and "ms_per_call" in ex[name]:
                 cfg[key] = ex[name]["ms_per_call"]
-        # final key order of `config` (see the comment at its construction): 24 scalars first, the rest behind them
-        first = ["workload", "pairs_per_gpu", "value_single_pair", "ms_single_pair", "ms_8_pairs_per_launch", "steady_pairs_per_s", "steady_kernel_ms",
-                 "clock_GHz_timed_median", "clock_GHz_steady_median", "ransac_c3_hyp_per_s", "ransac_c3_ms_per_call", "ransac_c3_count_frac_fp32_peak",
-                 "ransac_c3_cpu_hyp_per_s_1_core", "c5_image_pairs_per_s", "c5_ms_per_step", "c5_estimator", "c5_cpu_image_pairs_per_s_1_core",
-                 "c5_usac_uniform_ms_per_512", "c5_usac_prosac_ms_per_512", "c5_usac_default_refine_ms_per_512", "usac_call_ms", "arrsac_call_ms",
-                 "c5_dominant_kernel_frac", "verified"]
+        import bench_record
         merged = dict(rec["config"])
         merged.update(cfg)
         merged.update({"matches_first_pair": counts[0], "hamming_kernel": kernel_name, "world_size": world, "backend": args.backend if world > 1 else None,
                        "parallelism": f"shard{world}", "records_gathered_every_steps": G,
-                       "value_8_pairs_per_launch": (8 * n * n / (eight_ms * 1e-3)) if eight_ms else None,
                        "value_is": f"the BATCHED rate: {P} independent C2 image pairs per launch per GPU (a rank's share of BASELINE's 512-pair batch "
                                    "on 8 GPUs) under the given --steps / --warmup; steady_* = the same step in a long run; value_single_pair = "
                                    "ONE pair per launch (the literal config 2, latency shape)"})
-        rec["config"] = {k: merged[k] for k in first if k in merged}
+        # the final line's keys first, in its order; everything else behind them (bench_detail only)
+        rec["config"] = {k: merged[k] for k in bench_record.CONFIG_KEYS if k in merged}
         rec["config"].update({k: v for k, v in merged.items() if k not in rec["config"]})
-        for k, v in (rec["roofline"].get("from_profiles") or {}).items():   # the same figures as scalars of `roofline`
-            rec["roofline"]["from_profiles_" + k] = v
-        print(json.dumps(rec), flush=True)
+        if world > 1:
+            rec["rccl_ranks_seen"] = RCCL_RANKS_SEEN.get("n")
+        bench_record.emit(rec, os.path.join(ROOT, "bench_detail.json"))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -60,7 +60,7 @@ void *mlpl_ctx_stream(mlpl_ctx *ctx);
 int mlpl_ctx_device(mlpl_ctx *ctx);
 int mlpl_ctx_synchronize(mlpl_ctx *ctx);
 
-/* Tuning knobs (performance only, never results -- except "solver_polish", see below):
+/* Tuning knobs (performance only, never results -- except the opt-in "solver_polish", see below):
  *   Hamming: "hamming_variant" 3 = fp4 matrix-core kernels (default; descriptors above 64 bytes fall back to 0), 0 = LDS-tiled VALU
  *     kernel, 1 = scalar-operand VALU kernel, 2 = one-wave-per-block VALU kernel; "hamming_mfma_lds" 1 (default) = LDS-ring kernel for
  *     32-byte descriptors, 0 = register-prefetch kernel, 2 = dynamic train splits; "hamming_mfma_weighted" (default 1) = age-aware split
@@ -94,9 +94,11 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  *     "pair_batch_seq" (image pairs per internal batch of mlpl_pair_pose_batch_dev, 0 = 256 / of its USAC and ARRSAC forms, 0 = 512).
  *     Hamming: "hamming_fused_merge" (default 1) = the LDS-ring kernel folds its train splits, evaluates the ratio predicate and counts
  *     itself, 0 = separate merge launch; RANSAC: "ransac_count_mpl" 1|2 models per lane of the counting kernel (A/B, default 2).
- *   "solver_polish" (default 1) = every 5-point solution is polished by Gauss-Newton on the ten cubic constraints; 0 = the plain
- *     elimination + root path, which -- like the CPU code -- is off by up to 1e-5 on the ~0.5 % of samples whose eliminated block is ill
- *     conditioned.  This is the one option that changes results (towards the exact solution). */
+ *   "solver_polish" (default 0) = 1: every 5-point solution is polished by Gauss-Newton on the ten cubic constraints.  The default (0)
+ *     is the plain elimination + root path, the reference's arithmetic (five-point.cpp:366-471): like the CPU code it is off the
+ *     constraints by up to 1e-5 on the ~0.5 % of samples whose eliminated block is ill conditioned, and with it every result equals
+ *     the CPU path's.  The polish is the one option that changes results (about 1.5 % of minimal samples move by more than 1e-9):
+ *     opt in with mlpl_set_option(ctx, "solver_polish", 1) or MLPL_OPTIONS=solver_polish=1. */
 int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value);
 /* The current value of a tuning knob (the names mlpl_set_option takes; a subset: the Hamming knobs, "solver_polish", "ransac_count_mpl",
  * "hub_workers", "hub_lanes").  Returns 0, MLPL_E_BAD_INPUT for a name it does not know. */
@@ -379,7 +381,10 @@ int mlpl_usac_essential_batch_dev(mlpl_ctx *ctx, int n_problems, const double *d
                                   double *trace, int trace_cap, int32_t *trace_lens, void *stream);
 /* Statistics of the last mlpl_usac_essential[_dev] call: {device batches, samples solved on the device, samples the control flow
  * consumed, local-optimisation launches / chain runs, of which chain resumes, rechecks of the solution choices after a repetition
- * stored a new best model (5-point refinements), chains re-run because a choice changed, Jacobi sweeps (REF_WEIGHTS)}. */
+ * stored a new best model (5-point refinements), chains re-run because a choice changed, Jacobi sweeps (REF_WEIGHTS)}.
+ * After a BATCHED call (mlpl_usac_essential_batch_dev, mlpl_pair_pose_batch_usac_dev): {hub rounds, merged launches, microseconds the hub
+ * waited for host work (summed over the lanes), microseconds of device work (summed), microseconds spent starting the runs, microseconds
+ * of the whole call, lanes (cohorts served side by side) the call used, cohorts}. */
 int mlpl_usac_last_stats(mlpl_ctx *ctx, long long stats[8]);
 /* What the degeneracy tests of the last mlpl_usac_essential[_dev] call found -- the quantities estimateEssentialMatUsac hands to
  * estimateEssentialOrPoseUSAC (usac_estimations.cpp:564-636, 689-726; pose_estim.cpp:2044-2133 takes the decision "degenerate" from

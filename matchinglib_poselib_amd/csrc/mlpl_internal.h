@@ -132,7 +132,7 @@ struct mlpl_ctx {
     int opt_ransac_overlap;         // 1 (default) = large passes run their root kernels on the helper stream
     int opt_ransac_dev_split;      // device-drawn passes above 8192 hypotheses: per mille of the pass in the first of two solver slices (0 = one slice)
     int opt_ransac_lazy_sums;       // 1 (default) = division-free inlier counts + error sums only for models that can still win
-    int opt_solver_polish;          // 1 (default) = Gauss-Newton polish of every 5-point solution on the cubic constraints
+    int opt_solver_polish;          // 0 (default) = the plain elimination + root path (the reference's arithmetic); 1 = opt-in Gauss-Newton polish of every 5-point solution on the cubic constraints
     int opt_solver_wave3;           // 1 (default) = solve5pt3_kernel (three hypotheses per wave, matrices in registers); 0 = one per wave
     int opt_ransac_host_table;      // 1 = always build the niters table on the host (default: evaluate on the device, verify)
     // cached table T[g] = cvRANSACUpdateNumIters1(conf, (n-g)/n, 5, inf) for the last (n, conf) (host libm values)
@@ -170,7 +170,7 @@ struct mlpl_ctx {
     int opt_pair_batch;                                // pairs per internal batch of mlpl_pair_pose_batch_dev (0 = 256)
     int opt_pair_batch_feed;                           // 1 (default): the USAC / ARRSAC pair entries match cohort c + 1 while the estimators of cohort c run (pair_batch_usac.h)
     int opt_pair_batch_seq;                            // ... of mlpl_pair_pose_batch_usac_dev / _arrsac_dev (0 = 512)
-    int opt_hub_lanes;                                 // cohorts in flight (0 = 4 = the most)
+    int opt_hub_lanes;                                 // cohorts in flight (0 = the estimator's own choice: six for USAC with REF_WEIGHTS, four otherwise; at most 8)
     int opt_eig_inverse_iteration;                     // 1 (default): the smallest eigenvector of the re-weighted 9 x 9 fits (USAC REF_WEIGHTS, robustEssentialRefine) by inverse iteration, Jacobi as the fallback
     int opt_hub_blocking_sync;                         // 1: a lane's thread sleeps on an event at the end of a round instead of spinning in hipStreamSynchronize
     int opt_hub_workers;                               // worker threads per cohort (0 = 16): the runs of a cohort are fibers on them

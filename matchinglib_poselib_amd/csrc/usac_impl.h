@@ -3017,6 +3017,7 @@ int usac_essential_batch_dev(mlpl_ctx *ctx, int B, const double *d_p1, const dou
     }
     ctx->last_usac_stats[0] = rounds, ctx->last_usac_stats[1] = merged, ctx->last_usac_stats[2] = host_us, ctx->last_usac_stats[3] = device_us;
     ctx->last_usac_stats[4] = spawn_us;
+    ctx->last_usac_stats[6] = lanes, ctx->last_usac_stats[7] = n_cohorts;   // the configuration the call actually ran with (bench.py records it)
     ctx->last_usac_stats[5] = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_all).count();
     if (const char *pe = getenv("MLPL_USAC_PROF"); pe && *pe == '1') {  // debug: where the runs' host time goes (TSC ticks summed over the runs; waits excluded)
         static const char *names[UsacRun::PF_NUM] = {"setup", "sampler play-forward", "batch hand-over (host)", "waiting for the device", "local optimisation (host)", "solve() total"};

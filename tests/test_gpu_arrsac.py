@@ -38,7 +38,7 @@ def test_arrsac_equals_the_sequential_oracle(ctx, oracle, n, frac, seed, polish)
                 # polished 5-point solutions sit on the essential-matrix constraints; the CPU path's own are off them by up to 1e-5
                 assert e_dist(g["E"], o["E"]) < (2e-5 if polish else 1e-7), e_dist(g["E"], o["E"])
     finally:
-        ctx.set_option("solver_polish", 1)
+        ctx.set_option("solver_polish", 0)
 
 
 def test_arrsac_fixture_on_the_device(ctx):
@@ -58,7 +58,7 @@ def test_arrsac_fixture_on_the_device(ctx):
             assert e_dist(r["E"], g[f"c{ci}_E"]) < 1e-7
             assert np.array_equal(buf[:ln].reshape(-1, 20)[:60], g[f"c{ci}_turns"])
     finally:
-        ctx.set_option("solver_polish", 1)
+        ctx.set_option("solver_polish", 0)
 
 
 def test_arrsac_streams_carry_over_and_default_method(ctx, oracle):
@@ -78,7 +78,7 @@ def test_arrsac_streams_carry_over_and_default_method(ctx, oracle):
         assert ok and o["ok"] and np.array_equal(mask, o["mask"]) and e_dist(E, o["E"]) < 1e-7
         assert np.array_equal(pose._arrsac_rng_state, o["rng_state"])
     finally:
-        ctx.set_option("solver_polish", 1)
+        ctx.set_option("solver_polish", 0)
 
 
 def test_arrsac_generation_in_the_preemptive_stage(ctx, oracle):
@@ -101,7 +101,7 @@ def test_arrsac_generation_in_the_preemptive_stage(ctx, oracle):
                 break
         assert hit >= 1, "no scene reached the generation branch"
     finally:
-        ctx.set_option("solver_polish", 1)
+        ctx.set_option("solver_polish", 0)
 
 
 def test_arrsac_bad_arguments_and_failure(ctx):
@@ -143,7 +143,7 @@ def test_arrsac_forty_scenes_on_one_stream_pair(ctx, oracle, polish):
                 assert e_dist(g["E"], o["E"]) < (2e-5 if polish else 1e-7), it
         assert exact >= 36, exact
     finally:
-        ctx.set_option("solver_polish", 1)
+        ctx.set_option("solver_polish", 0)
 
 
 def test_arrsac_device_variant_equals_host_api(ctx):
@@ -177,7 +177,7 @@ def test_arrsac_tiny_inputs(ctx, oracle, n):
         if g["ok"]:
             assert e_dist(g["E"], o["E"]) < 1e-7
     finally:
-        ctx.set_option("solver_polish", 1)
+        ctx.set_option("solver_polish", 0)
 
 
 def test_robust_essential_refine_on_the_device(ctx, oracle):
@@ -240,7 +240,7 @@ def test_arrsac_estimators_on_single_samples(ctx, oracle):
                 assert ok and len(Eg) == 1 and np.abs(Eg[0] - F).max() < 1e-8 * np.abs(F).max(), (m, trial)
                 assert vg[0] == oracle.valid_model(p1[idx], p2[idx], F)
     finally:
-        ctx.set_option("solver_polish", 1)
+        ctx.set_option("solver_polish", 0)
 
 
 def test_arrsac_preemptive_stage_past_the_up_front_rows(ctx, oracle):

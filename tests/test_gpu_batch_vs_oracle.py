@@ -111,7 +111,7 @@ def test_arrsac_batch_against_the_oracle(ctx, oracle, refine):
         if o["n_inliers"]:
             assert np.array_equal(mh[b, :n], o["mask"]), b
         if o["ok"]:
-            assert e_dist(g["E"], o["E"]) < 2e-5, (b, e_dist(g["E"], o["E"]))   # polished 5-point models: DESIGN 4.3
+            assert e_dist(g["E"], o["E"]) < 1e-7, (b, e_dist(g["E"], o["E"]))   # default options = the reference's arithmetic
     assert differing <= 1
 
 
@@ -181,10 +181,10 @@ def test_c5_unit_with_arrsac_at_8192_keypoints_against_the_oracle_pipeline(ctx, 
             skipped += 1
             continue
         assert o["ok"] and raw["status"][i] == 0 and o["n_inliers"] == raw["n_inliers"][i], (i, o["n_inliers"], raw[i])
-        assert e_dist(o["E"], raw["E"][i]) < 2e-5, i
+        assert e_dist(o["E"], raw["E"][i]) < 1e-7, i
         good, R, t, Q, mk = oracle.recover_pose(o["E"], p1, p2, 50.0, o["mask"])
         assert good == raw["n_good"][i], i
-        assert np.abs(raw["R"][i].reshape(3, 3) - R).max() < 1e-4 and np.abs(raw["t"][i] - np.asarray(t).ravel()).max() < 1e-4, i
+        assert np.abs(raw["R"][i].reshape(3, 3) - R).max() < 1e-6 and np.abs(raw["t"][i] - np.asarray(t).ravel()).max() < 1e-6, i   # north_star's bar
     assert skipped <= 1
 
 

@@ -94,7 +94,7 @@ def test_cpp_facade_end_to_end(oracle, tmp_path):
         assert oka == int(o4["ok"]) and sta.tolist() == st.tolist(), (call, oka, o4["ok"], sta, st)
         if oka:
             a, b = Ea / np.linalg.norm(Ea), o4["E"] / np.linalg.norm(o4["E"])
-            assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 2e-5
+            assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 1e-7
 
     # AutoThEpi::estimateEVarTH: the same loop over the CPU oracle, continuing the samplers' streams
     from stereo_refine_oracle import AutoThEpiOracle
@@ -106,7 +106,7 @@ def test_cpp_facade_end_to_end(oracle, tmp_path):
     rc_o, E_o, mask_o, th_o, ng_o = auto.estimate_e_var_th(p1, p2, th)
     assert rca == rc_o == 0 and nga == ng_o and abs(tha - th_o) < 1e-9 * th_o, (rca, rc_o, nga, ng_o, tha, th_o)
     a, b = Eat / np.linalg.norm(Eat), E_o / np.linalg.norm(E_o)
-    assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 2e-5
+    assert min(np.abs(a - b).max(), np.abs(a + b).max()) < 1e-7
 
     # estimateEssentialOrPoseUSAC: PROSAC in the order of the matching costs, delta from the convex hulls of the keypoints, epsilon from
     # the share of matches a flow filter kept; the second call starts from the delta / epsilon the first one handed back

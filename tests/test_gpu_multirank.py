@@ -24,8 +24,15 @@ def _run(tmp_path, gpus, estimator="ransac"):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    return line, np.load(out)
+    lines = r.stdout.splitlines()
+    final = lines[-1]                                   # what the driver parses: the LAST line, short, strict JSON
+    assert final.startswith("{") and len(final) < 4096, len(final)
+    head = json.loads(final)
+    assert head["n_gpus"] == gpus and head["config"]["workload"].startswith("C5") and head["roofline"]["frac"] > 0
+    if gpus > 1:   # the record itself proves the collective library saw every rank
+        assert head["rccl_ranks_seen"] == {"world_size": gpus, "all_reduce_of_ones": gpus, "backend": "gloo"}
+    detail = [ln for ln in lines if ln.startswith("bench_detail ")][-1]
+    return json.loads(detail[len("bench_detail "):]), np.load(out)
 
 
 def test_two_ranks_give_the_one_rank_records_and_match_lists(tmp_path):
