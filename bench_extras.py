@@ -89,19 +89,19 @@ def run(ctx, dev, cpu_baseline=True):
         "includes": "host sample table (glibc rand stream, pinned/mapped), solve + score + replay + mask kernels, one 200-byte "
                     "state readback",
     }
-    # Everything here runs at the library default, solver_polish = 0 (the reference's arithmetic).  The price tag of the OPT-IN polish: the same
-    # 20 000 minimal samples through mlpl_solve_5pt with the polish off (default) and on (untimed); a sample counts as changed when its model
-    # count differs or a model moves by more than 1e-9 (models are unit-norm).
+    # The solver's accuracy safeguard (solver_polish, default 1) as a number: the same 20 000 minimal samples through mlpl_solve_5pt with it on
+    # and off (untimed); a sample counts as changed when its model count differs or a model moves by more than 1e-9 (models are unit-norm).
+    # Which of the two is closer to the CPU path is measured by tools/polish_default_ab.py (profiles/r06_polish_default_ab.log): on.
     out["ransac_c3"]["solver_polish"] = ctx.get_option("solver_polish")
     try:
         rs = np.random.default_rng(12345)
         smp = np.stack([rs.choice(n, 5, replace=False) for _ in range(iters)]).astype(np.int32)
-        Eu, nmu = pose.solve_5pt(p1, p2, smp, ctx=ctx)
-        ctx.set_option("solver_polish", 1)
+        Ep, nmp = pose.solve_5pt(p1, p2, smp, ctx=ctx)
+        ctx.set_option("solver_polish", 0)
         try:
-            Ep, nmp = pose.solve_5pt(p1, p2, smp, ctx=ctx)
+            Eu, nmu = pose.solve_5pt(p1, p2, smp, ctx=ctx)
         finally:
-            ctx.set_option("solver_polish", 0)
+            ctx.set_option("solver_polish", 1)
         changed = nmp != nmu
         same = ~changed
         big = np.zeros(iters, bool)
@@ -111,7 +111,7 @@ def run(ctx, dev, cpu_baseline=True):
             big |= live & (dlt > 1e-9)
         out["ransac_c3"]["polish_changed_frac"] = float((changed | big).mean())
         out["ransac_c3"]["polish_changed"] = {"samples": iters, "model_count_differs": int(changed.sum()), "a_model_moves_more_than_1e-9": int(big.sum()),
-                                              "what": "what the opt-in solver_polish = 1 would change: 20 000 random minimal samples of the C3 scene through mlpl_solve_5pt, 0 (default) vs 1"}
+                                              "what": "20 000 random minimal samples of the C3 scene through mlpl_solve_5pt with solver_polish 1 (default) / 0"}
     except Exception as e:   # a diagnostic: never the reason a bench line is lost
         out["ransac_c3"]["polish_changed"] = {"error": repr(e)}
     if cpu_baseline:

@@ -144,7 +144,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_ransac_count_mpl = 2;
     ctx->opt_ransac_count_defer = 1;
     ctx->opt_pair_batch_feed = 1;
-    ctx->opt_solver_polish = 0;   // the reference's arithmetic is the default; 1 = opt-in Gauss-Newton polish (changes ~1.5 % of minimal samples)
+    ctx->opt_solver_polish = 1;   // the solver's accuracy safeguard stays on: measured CLOSER to the CPU path than the plain root path (tools/polish_default_ab.py)
     ctx->opt_solver_wave3 = 1;
     ctx->opt_ransac_device_draw = 1;
     ctx->opt_usac_lo_warm_start = 1;

@@ -9,6 +9,7 @@
 #include <cstdio>
 
 #include "mlpl_c.h"
+#include "mlpl_debug.h"
 
 namespace mlpl {
 
@@ -132,7 +133,7 @@ struct mlpl_ctx {
     int opt_ransac_overlap;         // 1 (default) = large passes run their root kernels on the helper stream
     int opt_ransac_dev_split;      // device-drawn passes above 8192 hypotheses: per mille of the pass in the first of two solver slices (0 = one slice)
     int opt_ransac_lazy_sums;       // 1 (default) = division-free inlier counts + error sums only for models that can still win
-    int opt_solver_polish;          // 0 (default) = the plain elimination + root path (the reference's arithmetic); 1 = opt-in Gauss-Newton polish of every 5-point solution on the cubic constraints
+    int opt_solver_polish;          // 1 (default) = every 5-point solution is finished by <= 4 Gauss-Newton steps on the cubic constraints (repairs the samples on which the DEVICE's elimination is ill conditioned); 0 = plain root path (A/B)
     int opt_solver_wave3;           // 1 (default) = solve5pt3_kernel (three hypotheses per wave, matrices in registers); 0 = one per wave
     int opt_ransac_host_table;      // 1 = always build the niters table on the host (default: evaluate on the device, verify)
     // cached table T[g] = cvRANSACUpdateNumIters1(conf, (n-g)/n, 5, inf) for the last (n, conf) (host libm values)

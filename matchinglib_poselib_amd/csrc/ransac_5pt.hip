@@ -1477,19 +1477,25 @@ __global__ __launch_bounds__(kThreads, (DEFER ? 4 : 1)) void count_models_f32_ke
     const f32x2 Q = {(float)qmax, (float)qmax}, C6 = {0x1p-6f * 1.02f, 0x1p-6f * 1.02f};
     // deferred evaluations: the push (lane-divergent, a few LDS instructions; the verdict comes later through dq_cnt)
     const int ml0 = (tid >> 2) * MPL;  // first model of this lane within the workgroup
-    auto undecided = [&](int mi, int i) -> int {
+    // `prov` = what the loop has already counted for this evaluation (DEFER: the sign bit of its fp32 difference, see below; 0 for the
+    // unpaired correspondence): the queue's verdict replaces it, i.e. adds (verdict - prov)
+    auto undecided = [&](int mi, int i, uint32_t prov = 0u) -> int {
         if constexpr (DEFER) {
             // (a queue that has overflowed stays overflowed and is not counted further: with an infinite band EVERY evaluation comes here,
             // up to 256 models x 2^23 correspondences per workgroup -- the counter must not wrap)
             if (*reinterpret_cast<volatile int *>(&dq_n[0]) <= kDeferCap) {
                 const int k = atomicAdd(&dq_n[0], 1);
-                if (k < kDeferCap) dq[k] = ((uint32_t)(ml0 + mi) << 23) | (uint32_t)i;   // (n < 2^23: the launcher's condition for this instance)
+                if (k < kDeferCap) dq[k] = (prov << 31) | ((uint32_t)(ml0 + mi) << 23) | (uint32_t)i;   // (n < 2^23, kPerBlock <= 256: the launcher's conditions for this instance)
             }
             return 0;
         } else {
             return exact(mi, i);
         }
     };
+    static_assert(!DEFER || kPerBlock <= 256, "queue entry: 8 bits of model, 23 of correspondence, 1 provisional verdict");
+    uint32_t sg[MPL];   // DEFER: sign bits of the fp32 differences of the last <= 32 evaluations per model (the newest in bit 0)
+#pragma unroll
+    for (int mi = 0; mi < MPL; ++mi) sg[mi] = 0u;
     // (Measured and not kept, round 4: fetching the NEXT tile into registers while the current one is evaluated -- no change: with two
     // workgroups per CU the other workgroup's evaluation already covers a tile's load latency.)
     for (int base = blockIdx.y * kTile; base < n; base += kTile * gridDim.y) {
@@ -1528,46 +1534,80 @@ __global__ __launch_bounds__(kThreads, (DEFER ? 4 : 1)) void count_models_f32_ke
 #pragma unroll
                 for (int mi = 0; mi < MPL; ++mi) KMKP[mi] = KM[mi] * f32x2{kt, kt} * f32x2{1.0f + 0x1p-22f, 1.0f + 0x1p-22f};   // (rounded up)
             }
-            auto eval_pair = [&](const int q) {
+            // the fp32 difference and band of one pair of correspondences (packed) under model mi
+            auto diff_band = [&](const int mi, const float4 &v0, const float4 &v1, const f32x2 KP, f32x2 &diff, f32x2 &H) {
+                const f32x2 X1 = {v0.x, v0.y}, Y1 = {v0.z, v0.w}, X2 = {v1.x, v1.y}, Y2 = {v1.z, v1.w};
+                const f32x2 *Em = E[mi];
+                const f32x2 A = __builtin_elementwise_fma(Em[0], X1, __builtin_elementwise_fma(Em[1], Y1, Em[2]));
+                const f32x2 B = __builtin_elementwise_fma(Em[3], X1, __builtin_elementwise_fma(Em[4], Y1, Em[5]));
+                const f32x2 C = __builtin_elementwise_fma(Em[6], X1, __builtin_elementwise_fma(Em[7], Y1, Em[8]));
+                const f32x2 S = __builtin_elementwise_fma(X2, A, __builtin_elementwise_fma(Y2, B, C));
+                const f32x2 A2 = __builtin_elementwise_fma(Em[0], X2, __builtin_elementwise_fma(Em[3], Y2, Em[6]));
+                const f32x2 B2 = __builtin_elementwise_fma(Em[1], X2, __builtin_elementwise_fma(Em[4], Y2, Em[7]));
+                const f32x2 D = __builtin_elementwise_fma(A, A, __builtin_elementwise_fma(B, B, __builtin_elementwise_fma(A2, A2, B2 * B2)));
+                const f32x2 N = S * S;
+                // N32 -+ fl(qmax) D32 with ONE rounding each (the analysis above rounds the product first: at most an ulp of either
+                // quantity more, far inside the 1.02 / 1.01 slack of H)
+                diff = __builtin_elementwise_fma(-Q, D, N);
+                if constexpr (DEFER) H = __builtin_elementwise_fma(C6, __builtin_elementwise_fma(Q, D, N), KMKP[mi]);
+                else H = __builtin_elementwise_fma(C6, __builtin_elementwise_fma(Q, D, N), KM[mi] * KP);
+            };
+            // DEFER (round 6): NP pairs x MPL models = NP * MPL independent chains are computed FIRST and ONE rare branch follows them (a branch
+            // between the chains kept the compiler from interleaving them: every dependent packed op waited out its predecessor).  The
+            // non-multiply-add instructions of an evaluation are ONE funnel shift and ONE comparison (were two comparisons and an
+            // add-with-carry): decided <=> |diff| > H, and a decided evaluation is an inlier exactly when diff is negative -- the SIGN BIT of
+            // diff is shifted into sg[mi] (v_alignbit_b32) for every evaluation and the bits are counted 32 at a time (v_bcnt) by the caller;
+            // an undecided evaluation is queued together with the bit that was counted for it, and the queue adds (verdict - bit).
+            // Same counts by construction.
+            auto eval_group = [&](const int q, auto np_tag) {
+                constexpr int NP = decltype(np_tag)::value;
+                f32x2 df[NP][MPL], Hh[NP][MPL];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int slot = (q + p) * 4 + j;
+                    const float4 v0 = *reinterpret_cast<const float4 *>(tile_xy + slot * 8);
+                    const float4 v1 = *reinterpret_cast<const float4 *>(tile_xy + slot * 8 + 4);
+#pragma unroll
+                    for (int mi = 0; mi < MPL; ++mi) diff_band(mi, v0, v1, f32x2{0.f, 0.f}, df[p][mi], Hh[p][mi]);
+                }
+                bool any_undecided = false;
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int mi = 0; mi < MPL; ++mi) {
+                        sg[mi] = __builtin_amdgcn_alignbit(sg[mi], __float_as_uint(df[p][mi].x), 31);
+                        sg[mi] = __builtin_amdgcn_alignbit(sg[mi], __float_as_uint(df[p][mi].y), 31);
+                        // (every comparison is false for a NaN / inf band: undecided)
+                        const bool c0 = __builtin_fabsf(df[p][mi].x) > Hh[p][mi].x, c1 = __builtin_fabsf(df[p][mi].y) > Hh[p][mi].y;
+                        any_undecided |= live[mi] && !(c0 && c1);
+                    }
+                if (__builtin_expect(any_undecided, 0)) {  // inside the band (or out of range): the fp64 predicate decides, later
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+#pragma unroll
+                        for (int mi = 0; mi < MPL; ++mi) {
+                            if (!live[mi]) continue;
+                            const int i0 = base + 4 * (2 * (q + p)) + j, i1 = i0 + 4;
+                            if (!(__builtin_fabsf(df[p][mi].x) > Hh[p][mi].x)) undecided(mi, i0, __float_as_uint(df[p][mi].x) >> 31);
+                            if (!(__builtin_fabsf(df[p][mi].y) > Hh[p][mi].y)) undecided(mi, i1, __float_as_uint(df[p][mi].y) >> 31);
+                        }
+                }
+            };
+            auto eval_pair = [&](const int q) {   // (!DEFER: the forms of rounds 3-4, for A/B)
                 const int slot = q * 4 + j;
                 const float4 v0 = *reinterpret_cast<const float4 *>(tile_xy + slot * 8);
                 const float4 v1 = *reinterpret_cast<const float4 *>(tile_xy + slot * 8 + 4);
-                f32x2 KP = {0.f, 0.f};
-                if constexpr (!DEFER) {
-                    const float2 kk = *reinterpret_cast<const float2 *>(tile_k + slot * 2);
-                    KP = f32x2{kk.x, kk.y};
-                }
-                const f32x2 X1 = {v0.x, v0.y}, Y1 = {v0.z, v0.w}, X2 = {v1.x, v1.y}, Y2 = {v1.z, v1.w};
+                const float2 kk = *reinterpret_cast<const float2 *>(tile_k + slot * 2);
+                const f32x2 KP = f32x2{kk.x, kk.y};
 #pragma unroll
                 for (int mi = 0; mi < MPL; ++mi) {
-                    const f32x2 *Em = E[mi];
-                    const f32x2 A = __builtin_elementwise_fma(Em[0], X1, __builtin_elementwise_fma(Em[1], Y1, Em[2]));
-                    const f32x2 B = __builtin_elementwise_fma(Em[3], X1, __builtin_elementwise_fma(Em[4], Y1, Em[5]));
-                    const f32x2 C = __builtin_elementwise_fma(Em[6], X1, __builtin_elementwise_fma(Em[7], Y1, Em[8]));
-                    const f32x2 S = __builtin_elementwise_fma(X2, A, __builtin_elementwise_fma(Y2, B, C));
-                    const f32x2 A2 = __builtin_elementwise_fma(Em[0], X2, __builtin_elementwise_fma(Em[3], Y2, Em[6]));
-                    const f32x2 B2 = __builtin_elementwise_fma(Em[1], X2, __builtin_elementwise_fma(Em[4], Y2, Em[7]));
-                    const f32x2 D = __builtin_elementwise_fma(A, A, __builtin_elementwise_fma(B, B, __builtin_elementwise_fma(A2, A2, B2 * B2)));
-                    const f32x2 N = S * S;
-                    // N32 -+ fl(qmax) D32 with ONE rounding each (the analysis above rounds the product first: at most an ulp of either
-                    // quantity more, far inside the 1.02 / 1.01 slack of H)
-                    const f32x2 diff = __builtin_elementwise_fma(-Q, D, N);
-                    f32x2 H;
-                    if constexpr (DEFER) H = __builtin_elementwise_fma(C6, __builtin_elementwise_fma(Q, D, N), KMKP[mi]);
-                    else H = __builtin_elementwise_fma(C6, __builtin_elementwise_fma(Q, D, N), KM[mi] * KP);
+                    f32x2 diff, H;
+                    diff_band(mi, v0, v1, KP, diff, H);
                     // decided inlier: diff < -H; decided outlier: diff > H (H >= 0; every comparison is false for a NaN / inf band)
                     const bool in0 = diff.x < -H.x, in1 = diff.y < -H.y;
                     const bool c0 = in0 || diff.x > H.x, c1 = in1 || diff.y > H.y;
-                    if constexpr (DEFER) {
-                        // count += carry: one v_addc_co_u32 per comparison mask (the compiler's v_cndmask + v_cndmask + v_add3 is three for two)
-                        const unsigned long long b0 = __ballot(in0), b1 = __ballot(in1);
-                        unsigned long long co;
-                        asm("v_addc_co_u32 %0, %1, %0, 0, %2" : "+v"(cnt[mi]), "=s"(co) : "s"(b0));
-                        asm("v_addc_co_u32 %0, %1, %0, 0, %2" : "+v"(cnt[mi]), "=s"(co) : "s"(b1));
-                    } else {
-                        cnt[mi] += in0 ? 1 : 0;
-                        cnt[mi] += in1 ? 1 : 0;
-                    }
+                    cnt[mi] += in0 ? 1 : 0;
+                    cnt[mi] += in1 ? 1 : 0;
                     if (__builtin_expect(live[mi] && !(c0 && c1), 0)) {  // inside the band (or out of range): the fp64 predicate decides
                         const int i0 = base + 4 * (2 * q) + j, i1 = i0 + 4;
                         if (!c0) cnt[mi] += undecided(mi, i0);
@@ -1579,12 +1619,18 @@ __global__ __launch_bounds__(kThreads, (DEFER ? 4 : 1)) void count_models_f32_ke
             // (Measured and not kept, round 5: fetching the NEXT two pairs' operands from LDS before the current two are evaluated -- 126 registers
             // instead of 102, C3 scoring pass 0.278 against 0.263 ms, C5 counting 2.95 against 2.77 ms: gpurun_out/r5/count_defer_ab4.log.)
             if constexpr (DEFER) {
-                int q = 0;
-                for (; q + 2 <= npairs; q += 2) {
-                    eval_pair(q);
-                    eval_pair(q + 1);
+                // blocks of 16 pairs = 32 evaluations per model: sg[mi] then holds exactly the block's sign bits (older ones have left through
+                // bit 31; a shorter last block is masked)
+                for (int qb = 0; qb < npairs; qb += 16) {
+                    const int qe = min(qb + 16, npairs);
+                    int q = qb;
+                    for (; q + 2 <= qe; q += 2) eval_group(q, std::integral_constant<int, 2>{});
+                    if (q < qe) eval_group(q, std::integral_constant<int, 1>{});
+                    const int r = 2 * (qe - qb);
+                    const uint32_t keep = r >= 32 ? 0xFFFFFFFFu : ((1u << r) - 1u);
+#pragma unroll
+                    for (int mi = 0; mi < MPL; ++mi) cnt[mi] += __popc(sg[mi] & keep);
                 }
-                if (q < npairs) eval_pair(q);
             } else {
 #pragma unroll 2
                 for (int q = 0; q < npairs; ++q) eval_pair(q);
@@ -1603,12 +1649,13 @@ __global__ __launch_bounds__(kThreads, (DEFER ? 4 : 1)) void count_models_f32_ke
         if (pushed <= kDeferCap) {  // the queue: one entry per thread, the fp64 predicate on the same operands
             for (int k = tid; k < pushed; k += kThreads) {
                 const uint32_t e = dq[k];
-                const int ml = (int)(e >> 23), i = (int)(e & 0x7FFFFFu);
+                const int ml = (int)((e >> 23) & 0xFFu), i = (int)(e & 0x7FFFFFu), prov = (int)(e >> 31);
                 double ee[9];
 #pragma unroll
                 for (int q = 0; q < 9; ++q) ee[q] = E_list[(size_t)(blockIdx.x * kPerBlock + ml) * 9 + q];
                 const double4 p = pts[i];
-                if (sampson_inlier_fma(ee, model_band(ee, qmax), p.x, p.y, p.z, p.w, kp64[i], qmax, thresh2)) atomicAdd(&dq_cnt[ml], 1);
+                const int fix = (sampson_inlier_fma(ee, model_band(ee, qmax), p.x, p.y, p.z, p.w, kp64[i], qmax, thresh2) ? 1 : 0) - prov;
+                if (fix) atomicAdd(&dq_cnt[ml], fix);
             }
         } else {  // overflow (workgroup-uniform): this workgroup's share once more, every evaluation by the fp64 predicate
 #pragma unroll

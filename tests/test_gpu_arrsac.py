@@ -35,17 +35,17 @@ def test_arrsac_equals_the_sequential_oracle(ctx, oracle, n, frac, seed, polish)
             if g["n_inliers"]:
                 assert np.array_equal(g["mask"], o["mask"])
             if g["ok"]:
-                # polished 5-point solutions sit on the essential-matrix constraints; the CPU path's own are off them by up to 1e-5
-                assert e_dist(g["E"], o["E"]) < (2e-5 if polish else 1e-7), e_dist(g["E"], o["E"])
+                assert e_dist(g["E"], o["E"]) < 1e-7, e_dist(g["E"], o["E"])   # with and without the solver's safeguard
     finally:
-        ctx.set_option("solver_polish", 0)
+        ctx.set_option("solver_polish", 1)
 
 
-def test_arrsac_fixture_on_the_device(ctx):
+@pytest.mark.parametrize("polish", [1, 0])
+def test_arrsac_fixture_on_the_device(ctx, polish):
     """The committed oracle fixture (tests/golden/arrsac_trace.npz): result, statistics, stream positions and the first 60 turns."""
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "arrsac_trace.npz"))
-    ctx.set_option("solver_polish", 0)
+    ctx.set_option("solver_polish", polish)
     try:
         for ci in range(len(g["cases"])):
             buf = np.zeros(20 * 4000, np.int32)
@@ -58,13 +58,14 @@ def test_arrsac_fixture_on_the_device(ctx):
             assert e_dist(r["E"], g[f"c{ci}_E"]) < 1e-7
             assert np.array_equal(buf[:ln].reshape(-1, 20)[:60], g[f"c{ci}_turns"])
     finally:
-        ctx.set_option("solver_polish", 0)
+        ctx.set_option("solver_polish", 1)
 
 
-def test_arrsac_streams_carry_over_and_default_method(ctx, oracle):
+@pytest.mark.parametrize("polish", [1, 0])
+def test_arrsac_streams_carry_over_and_default_method(ctx, oracle, polish):
     """Second call of a process = the reference's second call (static cv::RNGs); estimateEssentialMat's default method is ARRSAC."""
     p1, p2, R, t, truth, th = synth.pose_scene(1500, 0.5, seed=6)
-    ctx.set_option("solver_polish", 0)
+    ctx.set_option("solver_polish", polish)
     try:
         st_g, st_o = np.array(pose.ARRSAC_RNG_FRESH, np.uint64), np.array(pose.ARRSAC_RNG_FRESH, np.uint64)
         for call in range(3):
@@ -78,14 +79,15 @@ def test_arrsac_streams_carry_over_and_default_method(ctx, oracle):
         assert ok and o["ok"] and np.array_equal(mask, o["mask"]) and e_dist(E, o["E"]) < 1e-7
         assert np.array_equal(pose._arrsac_rng_state, o["rng_state"])
     finally:
-        ctx.set_option("solver_polish", 0)
+        ctx.set_option("solver_polish", 1)
 
 
-def test_arrsac_generation_in_the_preemptive_stage(ctx, oracle):
+@pytest.mark.parametrize("polish", [1, 0])
+def test_arrsac_generation_in_the_preemptive_stage(ctx, oracle, polish):
     """Scenes whose first block is almost all inliers make the preemptive stage generate more hypotheses (uniform sampler over ALL
     correspondences, sequential test over the first i+1): large device batches, scores that double-count, the n == 1 exit."""
     hit = 0
-    ctx.set_option("solver_polish", 0)
+    ctx.set_option("solver_polish", polish)
     try:
         for seed in range(40, 60):
             p1, p2, R, t, truth, th = synth.pose_scene(1200, 0.97, seed=seed)
@@ -101,7 +103,7 @@ def test_arrsac_generation_in_the_preemptive_stage(ctx, oracle):
                 break
         assert hit >= 1, "no scene reached the generation branch"
     finally:
-        ctx.set_option("solver_polish", 0)
+        ctx.set_option("solver_polish", 1)
 
 
 def test_arrsac_bad_arguments_and_failure(ctx):
@@ -140,10 +142,10 @@ def test_arrsac_forty_scenes_on_one_stream_pair(ctx, oracle, polish):
             assert gs[2:7] == os_[2:7] and abs(gs[0] - os_[0]) <= 2 and abs(gs[1] - os_[1]) <= 2, (it, gs, os_)
             exact += gs == os_
             if g["ok"]:
-                assert e_dist(g["E"], o["E"]) < (2e-5 if polish else 1e-7), it
+                assert e_dist(g["E"], o["E"]) < 1e-7, it
         assert exact >= 36, exact
     finally:
-        ctx.set_option("solver_polish", 0)
+        ctx.set_option("solver_polish", 1)
 
 
 def test_arrsac_device_variant_equals_host_api(ctx):
@@ -161,11 +163,12 @@ def test_arrsac_device_variant_equals_host_api(ctx):
 
 
 @pytest.mark.parametrize("n", [6, 7, 8, 10, 14, 20, 37])
-def test_arrsac_tiny_inputs(ctx, oracle, n):
+@pytest.mark.parametrize("polish", [1, 0])
+def test_arrsac_tiny_inputs(ctx, oracle, n, polish):
     """Fewer correspondences than one block: the first stage alone decides (arrsac.h:388-401); the result fails the final
     plausibility test below 15 inliers (modelest.cpp:275-278) -- both sides must say so alike."""
     p1, p2, R, t, truth, th = synth.pose_scene(n, 0.9, seed=500 + n)
-    ctx.set_option("solver_polish", 0)
+    ctx.set_option("solver_polish", polish)
     try:
         st = np.array(pose.ARRSAC_RNG_FRESH, np.uint64)
         g = pose.arrsac_essential(p1, p2, th, refine=True, rng_state=st, ctx=ctx)
@@ -177,7 +180,7 @@ def test_arrsac_tiny_inputs(ctx, oracle, n):
         if g["ok"]:
             assert e_dist(g["E"], o["E"]) < 1e-7
     finally:
-        ctx.set_option("solver_polish", 0)
+        ctx.set_option("solver_polish", 1)
 
 
 def test_robust_essential_refine_on_the_device(ctx, oracle):
@@ -201,7 +204,8 @@ def _cubic_residual(E):
     return max(np.abs(2 * E @ E.T @ E - np.trace(E @ E.T) * E).max(), abs(np.linalg.det(E)))
 
 
-def test_arrsac_estimators_on_single_samples(ctx, oracle):
+@pytest.mark.parametrize("polish", [1, 0])
+def test_arrsac_estimators_on_single_samples(ctx, oracle, polish):
     """The estimators ARRSAC's inner RANSAC uses, sample by sample: the 5-point solver on 6 and 7 correspondences (cv::SVD's four last
     right singular vectors of an m x 9 system there, the Gram matrix's four smallest eigenvectors here) and the 8-point fit on 8..14.
     Every oracle solution that IS an essential matrix (cubic constraints to 1e-9) must be reproduced; where the CPU elimination is ill
@@ -209,7 +213,7 @@ def test_arrsac_estimators_on_single_samples(ctx, oracle):
     while the device's stay on them -- those are counted, not compared."""
     p1, p2, R, t, truth, th = synth.pose_scene(400, 0.8, seed=91, noise_px=1.0)
     rng = np.random.default_rng(7)
-    ctx.set_option("solver_polish", 0)
+    ctx.set_option("solver_polish", polish)
     try:
         compared = off = 0
         for trial in range(60):
@@ -240,7 +244,7 @@ def test_arrsac_estimators_on_single_samples(ctx, oracle):
                 assert ok and len(Eg) == 1 and np.abs(Eg[0] - F).max() < 1e-8 * np.abs(F).max(), (m, trial)
                 assert vg[0] == oracle.valid_model(p1[idx], p2[idx], F)
     finally:
-        ctx.set_option("solver_polish", 0)
+        ctx.set_option("solver_polish", 1)
 
 
 def test_arrsac_preemptive_stage_past_the_up_front_rows(ctx, oracle):

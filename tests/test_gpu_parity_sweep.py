@@ -1,8 +1,6 @@
 """Seed sweeps at the REFERENCE's RANSAC settings (1000 iterations, confidence 0.999: findEssentialMat as estimateEssentialMat("RANSAC") drives
 it, pose_estim.cpp:870-873), with and without the least-squares refit, at the library's default options: iteration count, inlier count and
-mask identical to the CPU oracle on every seed.  The opt-in 5-point polish has its own test: every divergence is printed with the constraint
-residual of the oracle's model and must be explained by it (the CPU root path is off the essential-matrix constraints on ~1 % of samples,
-DESIGN 4.3)."""
+mask identical to the CPU oracle on every seed, E to 1e-7.  The same with the solver's safeguard off (A/B)."""
 import numpy as np
 import pytest
 
@@ -28,9 +26,9 @@ CASES = [(1500, 1000 + i, 50 + i) for i in range(120)] + [(5000, 20260103 + i, 1
 @pytest.mark.parametrize("refit", [False, True])
 def test_reference_settings_over_120_seeds(ctx, oracle, refit):
     """120 (scene, seed) pairs of C3 shape (50 % inliers, 0.3 px noise; 1500 correspondences so that the CPU side stays within a minute)
-    plus 6 at the full 5000, at the library's DEFAULT options (no option is touched: the plain root path, the CPU path's arithmetic):
-    identical (iterations, inliers, mask) on EVERY seed, E to 1e-7."""
-    assert ctx.get_option("solver_polish") == 0, "the library default must be the reference's arithmetic"
+    plus 6 at the full 5000, at the library's DEFAULT options (no option is touched): identical (iterations, inliers, mask) on EVERY
+    seed, E to 1e-7 (measured: 1.8e-9)."""
+    assert ctx.get_option("solver_polish") == 1
     diverged = []
     for n, scene_seed, seed in CASES:
         p1, p2, R, t, truth, th = synth.pose_scene(n, 0.5, seed=scene_seed)
@@ -45,7 +43,7 @@ def test_reference_settings_over_120_seeds(ctx, oracle, refit):
     for d in diverged:
         print("n %d scene %d seed %d: iters %d/%d inliers %d/%d mask flips %d" % d)
     if not refit:
-        assert not diverged, diverged                     # the plain root path IS the CPU path's arithmetic
+        assert not diverged, diverged                     # every run IS the CPU path's run
     else:
         # the refit solves an n-point system whose four smallest singular vectors come from different decompositions (Jacobi SVD of the
         # n x 9 matrix on the CPU, eigenvectors of the 9 x 9 Gram matrix on the device): a correspondence exactly at the threshold may
@@ -55,28 +53,20 @@ def test_reference_settings_over_120_seeds(ctx, oracle, refit):
             assert d[3] == d[4] and d[7] <= 2 and abs(d[5] - d[6]) <= 2, d
 
 
-def test_opt_in_polish_parts_only_where_the_cpu_model_is_off_the_constraints(ctx, oracle):
-    """The OPT-IN solver_polish = 1 (not the default): a run may part from the CPU path only where the CPU path's own winning (or a
-    competing) model is off the essential-matrix constraints; at most 5 % of the runs, each printed, the device's model on the constraints."""
-    diverged = []
-    ctx.set_option("solver_polish", 1)
+def test_plain_root_path_ab_over_the_same_seeds(ctx, oracle):
+    """A/B, solver_polish = 0 (the plain elimination + root path): the same 126 runs are identical to the CPU path's as well -- the safeguard
+    decides nothing at the level of a RANSAC run on these seeds; what it does decide is measured per model (tools/polish_default_ab.py,
+    tests/test_gpu_baseline_configs.py)."""
+    ctx.set_option("solver_polish", 0)
     try:
         for n, scene_seed, seed in CASES:
             p1, p2, R, t, truth, th = synth.pose_scene(n, 0.5, seed=scene_seed)
             o = oracle.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, lesqu=False, seed=seed)
             g = pose.ransac_essential(p1, p2, th, confidence=0.999, max_iters=1000, refit=False, seed=seed, ctx=ctx)
-            flips = int(np.count_nonzero(g["mask"] != o["mask"]))
-            if g["iters"] == o["iters"] and g["n_inliers"] == o["n_inliers"] and flips == 0:
-                assert e_dist(g["E"], o["E"]) < 1e-5
-                continue
-            diverged.append((n, scene_seed, seed, g["iters"], o["iters"], g["n_inliers"], o["n_inliers"], flips, constraint_residual(o["E"]), constraint_residual(g["E"])))
+            assert g["iters"] == o["iters"] and g["n_inliers"] == o["n_inliers"] and np.array_equal(g["mask"], o["mask"]), (n, scene_seed, seed)
+            assert e_dist(g["E"], o["E"]) < 1e-7
     finally:
-        ctx.set_option("solver_polish", 0)
-    for d in diverged:
-        print("polish 1: n %d scene %d seed %d: iters %d/%d inliers %d/%d mask flips %d, residual oracle %.2e device %.2e" % d)
-    assert len(diverged) <= 6, diverged
-    for d in diverged:
-        assert d[9] < 1e-12, d
+        ctx.set_option("solver_polish", 1)
 
 
 def test_refit_mask_flips_are_correspondences_at_the_threshold(ctx, oracle):

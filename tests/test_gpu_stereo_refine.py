@@ -195,8 +195,6 @@ def test_stereo_refine_sequence_matches_the_cpu_state_machine(oracle, tmp_path, 
             assert abs(st[k] - w[k]) <= (5 if (cpu_off or arrsac) else 0), (name, i, k, st, {k: w[k] for k in st})
             drift = max(drift, abs(st[k] - w[k]))
         tol = 1e-6 if not cpu_off else 1e-2
-        if arrsac and polish:
-            tol = 2e-5                         # polished 5-point hypotheses against the CPU path's unpolished ones
         if w["E"] is not None:
             unit = lambda a: a / np.linalg.norm(a)  # noqa: E731
             assert same_up_to_sign(unit(g["E"].reshape(3, 3)), unit(w["E"]), tol), (name, i)
