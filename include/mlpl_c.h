@@ -64,7 +64,7 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  *   Hamming: "hamming_variant" 3 = fp4 matrix-core kernels (default; descriptors above 64 bytes fall back to 0), 0 = LDS-tiled VALU
  *     kernel, 1 = scalar-operand VALU kernel, 2 = one-wave-per-block VALU kernel; "hamming_mfma_lds" 1 (default) = LDS-ring kernel for
  *     32-byte descriptors, 0 = register-prefetch kernel, 2 = dynamic train splits; "hamming_mfma_weighted" (default 1) = age-aware split
- *     sizes; "hamming_mfma_prio" 0|1|2 (diagnostics); "hamming_mfma_blocks_per_cu" and "hamming_mfma_qt" (query tiles per wave,
+ *     sizes; "hamming_mfma_prio" 0|1|2 (diagnostics) | 3 (wave-uniform skip of the running top-2 update: measured slower, round 6); "hamming_mfma_blocks_per_cu" and "hamming_mfma_qt" (query tiles per wave,
  *     0 = automatic) size the matrix-core grid; "hamming_qpl" queries per lane 1|2 and "hamming_blocks_per_cu" size the VALU grids;
  *     "hamming_stamps" 1 = per-wave / per-workgroup clock stamps (mlpl_debug_hamming_stamps), 2 = one clock record per launch
  *       (mlpl_debug_hamming_clock).  "hamming_train01" 1 = {0, +1} instead of +-1 train fragments in the matrix-core Hamming kernel

@@ -213,7 +213,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "hamming_mfma_qt") && (value == 0 || value == 1 || value == 2 || value == 4)) ctx->opt_hamming_mfma_qt = value;
     else if (!std::strcmp(name, "hamming_mfma_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_mfma_blocks_per_cu = value;
     else if (!std::strcmp(name, "hamming_mfma_lds") && (value >= 0 && value <= 2)) ctx->opt_hamming_mfma_lds = value;
-    else if (!std::strcmp(name, "hamming_mfma_prio") && (value >= 0 && value <= 2)) ctx->opt_hamming_mfma_prio = value;
+    else if (!std::strcmp(name, "hamming_mfma_prio") && (value >= 0 && value <= 3)) ctx->opt_hamming_mfma_prio = value;
     else if (!std::strcmp(name, "hamming_mfma_prefetch") && (value == 0 || value == 2 || value == 4 || value == 6)) ctx->opt_hamming_mfma_prefetch = value;
     else if (!std::strcmp(name, "hamming_split_rows") && (value == 0 || value == 4096 || value == 8192)) ctx->opt_hamming_split_rows = value;
     else if (!std::strcmp(name, "hamming_mfma_waves") && (value == 0 || value == 4 || value == 8 || value == 16)) ctx->opt_hamming_mfma_waves = value;

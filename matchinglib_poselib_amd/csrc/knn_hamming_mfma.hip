@@ -417,6 +417,16 @@ __global__ __launch_bounds__(64 * NW, 4) void knn_hamming_mfma_lds_kernel(
             m2[t] += 32.0f * kEps;
 #pragma unroll
             for (int reg = 0; reg < 16; reg += 4) {
+                if constexpr (PRIO == 3) {
+                    // Experiment (round 6; option hamming_mfma_prio = 3): wave-uniform skip.  A group of four rows changes a lane's
+                    // running pair only if its largest value beats the lane's m2; after the first eighth of a split fewer than half of the
+                    // groups do so in ANY lane.  3 ops (max3, max, compare) + a scalar branch instead of the 5-op update when none does.
+                    // MEASURED NEGATIVE (gpurun_out/r6/hamming_skip_ab*.log, profiles/README.md): same outputs, the shader clock RISES from
+                    // 1.84-1.97 to 2.06-2.17 GHz (less switching per cycle: the launch is power-limited), yet the kernel takes 0.376-0.383 ms
+                    // against 0.363-0.379 -- the four VCC round trips per unit cost more cycles than the skipped updates save.  Off.
+                    const float g = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(acc[reg], acc[reg + 1]), acc[reg + 2]), acc[reg + 3]);
+                    if (__builtin_amdgcn_ballot_w64(g > m2[t]) == 0) continue;
+                }
                 const float s0 = __builtin_amdgcn_fmed3f(m1[t], acc[reg], acc[reg + 1]);
                 const float t0 = __builtin_fmaxf(__builtin_fmaxf(m1[t], acc[reg]), acc[reg + 1]);
                 const float s1 = __builtin_amdgcn_fmed3f(t0, acc[reg + 2], acc[reg + 3]);
@@ -1085,6 +1095,9 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
                                dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab, fuse);
         else if (qt == 4 && nwv == 8 && ctx->opt_hamming_mfma_prefetch == 6)
             hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<4, 0, 8, 6>), grid, dim3(512), 0, s, qw, q_batch_words, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit,
+                               dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab, fuse);
+        else if (qt == 4 && nwv == 8 && ctx->opt_hamming_mfma_prio == 3)
+            hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<4, 3, 8>), grid, dim3(512), 0, s, qw, q_batch_words, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit,
                                dshift, qblocks, (int)items, (uint2 *)part, stamps, split_tab, fuse);
         else if (qt == 4 && nwv == 8 && ctx->opt_hamming_mfma_prio == 1)
             hipLaunchKernelGGL((knn_hamming_mfma_lds_kernel<4, 1, 8>), grid, dim3(512), 0, s, qw, q_batch_words, (const uint4 *)tf, t_u4, nq, nt, rps, nsplit,
