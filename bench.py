@@ -110,13 +110,15 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
     est = getattr(args, "estimator", "ransac")
     cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-    hub_workers = max(2, min(16, cpus // max(1, local_world) - 2))   # two threads of the share stay with the lane / Python threads
-    host_threads = {"cpus_visible": cpus, "local_world_size": local_world, "hub_workers_per_cohort": hub_workers if est != "ransac" else 0,
-                    "hub_lanes_option": ctx.get_option("hub_lanes") if est != "ransac" else 0,   # 0 = the estimator's own choice; the lanes a call used: hub_last_internal_call
-                    "batch_lanes": 2 if est == "ransac" else 0,
+    budget = batch.host_thread_budget(cpus, local_world, est)   # lanes x workers within the rank's share of the node's cores (batch.py)
+    host_threads = {"cpus_visible": cpus, "local_world_size": local_world, "hub_workers_per_cohort": budget["hub_workers"],
+                    "hub_lanes_option": budget["hub_lanes"],   # 0 = the estimator's own choice; the lanes a call used: hub_last_internal_call.lanes_used
+                    "batch_lanes": budget["batch_lanes"], "threads_bound": budget["threads"],
                     "gc": "gc.freeze() + gc.disable() around the timed steps (a generation-2 collection stalls every thread for 50-90 ms)"}
     if est != "ransac":
-        ctx.set_option("hub_workers", hub_workers)
+        ctx.set_option("hub_workers", budget["hub_workers"])
+        if budget["hub_lanes"]:
+            ctx.set_option("hub_lanes", budget["hub_lanes"])
     usac_kw = {"usac": dict(prosac=False, refine=0), "usac_prosac": dict(prosac=True, refine=0), "usac_default_refine": dict(prosac=True, refine=5)}.get(est)
 
     lanes = batch.BatchLanes(local_rank, lanes=2, first_ctx=ctx) if est == "ransac" else None   # two batched calls in flight, half of the rank's share each

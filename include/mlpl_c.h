@@ -69,7 +69,8 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  *     "hamming_stamps" 1 = per-wave / per-workgroup clock stamps (mlpl_debug_hamming_stamps), 2 = one clock record per launch
  *       (mlpl_debug_hamming_clock).  "hamming_train01" 1 = {0, +1} instead of +-1 train fragments in the matrix-core Hamming kernel
  *       (same results; see knn_hamming_mfma.hip; measured no faster, default 0).  "hamming_merge_emit" 1 = with one image pair per call the
- *       merge kernel writes the DMatch rows itself (no ratio_write launch; measured no faster, default 0).
+ *       merge kernel writes the DMatch rows itself (no ratio_write launch; measured no faster, default 0; TEST-ONLY: its chained look-back
+ *       assumes that the whole merge grid is resident, which other streams on the same device can break).
  *       "hamming_split_rows" 0 (default) | 8192 | 4096 = cap on the train rows one workgroup scans (4096 = rounds 1-4: every 8192-row train
  *       set was cut in two even with the chip full); "hamming_mfma_waves" 0 (automatic) | 4 | 8 | 16 waves per workgroup and
  *       "hamming_mfma_prefetch" 0 | 2 | 4 | 6 tiles of prefetch distance in the LDS-ring kernel.

@@ -31,26 +31,77 @@ def shard_capacity(num_pairs: int, world: int) -> int:
     return (num_pairs + world - 1) // world
 
 
+# Host-thread budget of one rank (VERDICT r5 #7a).  A rank that runs a batch of SEQUENTIAL estimators (USAC, ARRSAC) serves up to `lanes`
+# cohorts side by side, each with `hub_workers` worker threads its runs are fibers on (csrc/batch_hub.h); with RANSAC it drives two batched
+# calls from two Python threads (BatchLanes).  Most of those threads sleep on the device most of the time, so the rank may oversubscribe its
+# share of the node's cores -- by at most kThreadOversubscription -- but 8 ranks x (6 lanes x 16 workers) = 768 threads on a 64-core host
+# is not a plan.  Measured (gpurun_out/r5/c5_workers_ab.log): 8 workers per cohort instead of 16 cost 4-7 %, 32 or 64 gain nothing.
+kThreadOversubscription = 2
+kHubLanesDefault = {"usac": 6, "usac_prosac": 6, "usac_default_refine": 4, "arrsac": 4}   # csrc/batch_hub.h: hub_usac_lanes_default / kHubLanesDefault
+
+
+def host_thread_budget(cpus: int, local_world: int, estimator: str) -> dict:
+    """How many host threads a rank of `local_world` ranks on a node with `cpus` usable cores gives the estimator of its C5 share:
+    {"cpus_per_rank", "hub_lanes" (0 = leave the library's default), "hub_workers" (per cohort), "batch_lanes", "threads"} with
+    threads = everything the rank keeps runnable at once (lanes x workers + the lanes' own threads + the Python threads)."""
+    per_rank = max(1, cpus // max(1, local_world))
+    if estimator == "ransac":
+        return {"cpus_per_rank": per_rank, "hub_lanes": 0, "hub_workers": 0, "batch_lanes": 2, "threads": 3}
+    lanes = kHubLanesDefault[estimator]
+    bound = max(4, kThreadOversubscription * per_rank)           # runnable threads this rank may own
+    capped = lanes
+    while capped > 1 and capped * 2 + capped + 1 > bound:        # every lane needs its own thread and at least two workers
+        capped -= 1
+    workers = max(2, min(16, (bound - capped - 1) // capped))
+    return {"cpus_per_rank": per_rank, "hub_lanes": 0 if capped == lanes else capped, "hub_workers": workers, "batch_lanes": 0,
+            "threads": capped * workers + capped + 1}
+
+
+_gather_stage = {}   # (cap, world, device) -> (pinned host block, device block, device gather buffer, pinned host gather buffer)
+
+
 def gather_records(local: np.ndarray, num_pairs: int, rank: int, world: int, device=None, group=None) -> Optional[np.ndarray]:
     """All-gathers the ranks' record blocks (padded to equal size) and returns the num_pairs records in pair order on
-    every rank.  `device` = torch device the collective runs on (cuda for RCCL, cpu for gloo)."""
+    every rank.  `device` = torch device the collective runs on (cuda for RCCL, cpu / None for gloo).  On a GPU the blocks travel through
+    PERSISTENT pinned and device staging buffers (one asynchronous H2D, the all_gather on the device, one D2H, one synchronisation per
+    call; no allocation after the first call -- the records themselves are final only on the host, where the sequential replay of the
+    estimator ends: include/mlpl_c.h, mlpl_pair_pose_batch_dev)."""
     import torch
     import torch.distributed as dist
 
     cap = shard_capacity(num_pairs, world)
-    buf = np.zeros(cap, RECORD_DTYPE)
-    buf["pair_id"] = -1
-    buf[: len(local)] = local
+    isz = RECORD_DTYPE.itemsize
     if world == 1:
-        allr = buf.view(np.uint8).reshape(cap, RECORD_DTYPE.itemsize)   # nothing to exchange
+        buf = np.zeros(cap, RECORD_DTYPE)
+        buf["pair_id"] = -1
+        buf[: len(local)] = local
+        allr = buf.view(np.uint8).reshape(cap, isz)   # nothing to exchange
+    elif device is not None and torch.device(device).type == "cuda":
+        key = (cap, world, str(device))
+        st = _gather_stage.get(key)
+        if st is None:
+            st = (torch.empty((cap, isz), dtype=torch.uint8).pin_memory(), torch.empty((cap, isz), dtype=torch.uint8, device=device),
+                  torch.empty((world * cap, isz), dtype=torch.uint8, device=device), torch.empty((world * cap, isz), dtype=torch.uint8).pin_memory())
+            _gather_stage[key] = st
+        h_in, d_in, d_out, h_out = st
+        blk = h_in.numpy().view(RECORD_DTYPE).reshape(-1)
+        blk[:] = np.zeros((), RECORD_DTYPE)
+        blk["pair_id"] = -1
+        blk[: len(local)] = local
+        d_in.copy_(h_in, non_blocking=True)
+        dist.all_gather_into_tensor(d_out, d_in, group=group)
+        h_out.copy_(d_out, non_blocking=True)
+        torch.cuda.current_stream(device).synchronize()
+        allr = h_out.numpy()
     else:
-        t = torch.from_numpy(buf.view(np.uint8).reshape(cap, RECORD_DTYPE.itemsize).copy())
-        if device is not None:
-            t = t.to(device)
-        out = torch.empty((world * cap, RECORD_DTYPE.itemsize), dtype=torch.uint8, device=t.device)
+        buf = np.zeros(cap, RECORD_DTYPE)
+        buf["pair_id"] = -1
+        buf[: len(local)] = local
+        t = torch.from_numpy(buf.view(np.uint8).reshape(cap, isz).copy())
+        out = torch.empty((world * cap, isz), dtype=torch.uint8)
         dist.all_gather_into_tensor(out, t, group=group)
-        allr = out.cpu().numpy()
-    rec = np.ascontiguousarray(allr).view(RECORD_DTYPE).reshape(-1)
+        allr = out.numpy()
+    rec = np.ascontiguousarray(allr).view(RECORD_DTYPE).reshape(-1).copy()
     rec = rec[rec["pair_id"] >= 0]
     order = np.argsort(rec["pair_id"], kind="stable")
     rec = rec[order]

@@ -142,6 +142,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_ransac_overlap = 1;
     ctx->opt_ransac_f32_filter = 1;
     ctx->opt_ransac_count_mpl = 2;
+    ctx->opt_ransac_count_tiles = 2;
     ctx->opt_ransac_count_defer = 1;
     ctx->opt_pair_batch_feed = 1;
     ctx->opt_solver_polish = 1;   // the solver's accuracy safeguard stays on: measured CLOSER to the CPU path than the plain root path (tools/polish_default_ab.py)
@@ -233,6 +234,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "ransac_f32_filter") && (value == 0 || value == 1)) ctx->opt_ransac_f32_filter = value;
     else if (!std::strcmp(name, "arrsac_refine_warm_start") && (value == 0 || value == 1)) ctx->opt_arrsac_refine_warm_start = value;
     else if (!std::strcmp(name, "ransac_count_mpl") && (value == 1 || value == 2)) ctx->opt_ransac_count_mpl = value;
+    else if (!std::strcmp(name, "ransac_count_tiles") && (value == 1 || value == 2)) ctx->opt_ransac_count_tiles = value;
     else if (!std::strcmp(name, "ransac_count_defer") && (value == 0 || value == 1)) ctx->opt_ransac_count_defer = value;
     else if (!std::strcmp(name, "ransac_event_cap") && value >= 0 && value <= 1024) ctx->opt_ransac_event_cap = value;
     else if (!std::strcmp(name, "solver_polish") && (value == 0 || value == 1)) ctx->opt_solver_polish = value;
@@ -276,6 +278,7 @@ int mlpl_get_option(mlpl_ctx *ctx, const char *name, int *value) {
     else if (!std::strcmp(name, "hamming_mfma_waves")) *value = ctx->opt_hamming_mfma_waves;
     else if (!std::strcmp(name, "solver_polish")) *value = ctx->opt_solver_polish;
     else if (!std::strcmp(name, "ransac_count_mpl")) *value = ctx->opt_ransac_count_mpl;
+    else if (!std::strcmp(name, "ransac_count_tiles")) *value = ctx->opt_ransac_count_tiles;
     else if (!std::strcmp(name, "ransac_count_defer")) *value = ctx->opt_ransac_count_defer;
     else if (!std::strcmp(name, "hub_workers")) *value = ctx->opt_hub_workers;
     else if (!std::strcmp(name, "hub_lanes")) *value = ctx->opt_hub_lanes;

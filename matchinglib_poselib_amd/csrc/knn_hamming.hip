@@ -480,9 +480,11 @@ int launch_knn_hamming(mlpl_ctx *ctx, const uint8_t *d_q, int nq, size_t q_strid
                 void *sp = nullptr;
                 const size_t sb = (size_t)mblocks * sizeof(unsigned long long);
                 if ((rc = ws_get(ctx, WS_SCAN, sb, &sp))) return rc;
-                if (ctx->hamming_scan_ptr != sp || ctx->hamming_scan_gen == 0xFFFFFFFFu) {  // new block (or the generation wraps): no stale generation in it
+                // new block (or the generation wraps): no stale generation in it.  A block that was freed and re-allocated may come back at the SAME
+                // address: its size cannot -- a regrow only ever happens to a larger size -- so the size is part of the test.
+                if (ctx->hamming_scan_ptr != sp || ctx->hamming_scan_bytes != ctx->ws_bytes[WS_SCAN] || ctx->hamming_scan_gen == 0xFFFFFFFFu) {
                     MLPL_HIP_TRY(hipMemsetAsync(sp, 0, ctx->ws_bytes[WS_SCAN], s));
-                    ctx->hamming_scan_ptr = sp, ctx->hamming_scan_gen = 0;
+                    ctx->hamming_scan_ptr = sp, ctx->hamming_scan_bytes = ctx->ws_bytes[WS_SCAN], ctx->hamming_scan_gen = 0;
                 }
                 emit = MergeEmit{emit_out->out, emit_out->n_out, (unsigned long long *)sp, ++ctx->hamming_scan_gen};
                 emit_out->emitted = 1;

@@ -122,12 +122,14 @@ struct mlpl_ctx {
     long long hamming_clock_launches;   // launches recorded into the clock ring so far
     int opt_hamming_merge_emit;     // 1 = one image pair per call: the merge kernel writes the DMatch rows itself (no ratio_write launch); default 0: measured, no faster
     void *hamming_scan_ptr;         // the WS_SCAN block the generation below counts for
+    size_t hamming_scan_bytes;      // ... and its size when it was zeroed (a regrown block may return at the same address, never at the same size)
     uint32_t hamming_scan_gen;
     int opt_hamming_train01;        // 1 = {0, +1} train fragments in the static LDS-ring kernel (accumulator = pop(query) - distance), 0 = +-1
     int dbg_stamp_items;
     int opt_ransac_chunk;           // hypotheses per device pass (0 = 32768)
     int opt_ransac_event_cap;       // tests: capacity of the record-event list of candidate / replay kernels (0 = 1024); forces their serial fallback
     int opt_ransac_count_mpl;       // models per lane of the packed-fp32 counting kernel: 2 (default) or 1
+    int opt_ransac_count_tiles;     // 512-correspondence tiles one workgroup of the counting pass walks: 2 (rounds 3-5) or 1 (more, shorter workgroups: less idle tail)
     int opt_ransac_count_defer;     // 1 (default) = the packed-fp32 counting kernel queues its undecided evaluations in LDS and decides them workgroup-wide (same counts)
     int opt_ransac_f32_filter;      // 1 (default) = the count-only scoring kernels pre-filter in packed fp32 inside a rigorous error band (same counts)
     int opt_ransac_overlap;         // 1 (default) = large passes run their root kernels on the helper stream

@@ -3201,12 +3201,12 @@ static void launch_score(hipStream_t s, const double4 *pts, int n, const double 
 // Workgroups per model group of the count-only scoring pass (see score_models_kernel); with more than one the counts are ACCUMULATED
 // into a table the caller has zeroed (roots_kernel does that for the RANSAC pass).  launch_score(point_splits = 0) is the form for
 // callers with an unzeroed table: one workgroup per model.
-static int score_point_splits(int n, int max_models, bool sums) {
+static int score_point_splits(int n, int max_models, bool sums, int tiles_per_wg = 2) {
     if (sums) return 1;
     const int ntiles = (n + kScoreTile - 1) / kScoreTile;
     if (max_models <= kScoreBlockMaxModels)  // small passes: one 256-point tile per workgroup (occupancy is what hides the LDS latency)
         return std::max(1, std::min(32, (n + kScoreTileSmall - 1) / kScoreTileSmall));
-    return std::max(1, std::min(8, ntiles / 2));
+    return tiles_per_wg == 1 ? std::max(1, std::min(16, ntiles)) : std::max(1, std::min(8, ntiles / 2));
 }
 
 static int pack_points(mlpl_ctx *ctx, const double *d_p1, const double *d_p2, int n, double4 **d_pts, hipStream_t s,
@@ -3620,7 +3620,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         // per sample: a large pass runs in three slices (1024, up to 8192, the rest) so that the device starts after ~10 us of drawing
         // and always finds the next slice ready; up to 4096 hypotheses are one slice (two small solver launches would cost more than
         // the wait).
-        const int point_splits = score_point_splits(n, cnt * 10, !lazy);
+        const int point_splits = score_point_splits(n, cnt * 10, !lazy, ctx->opt_ransac_count_tiles);
         const int ev_cap = ctx->opt_ransac_event_cap > 0 ? std::min(ctx->opt_ransac_event_cap, kMaxScanEvents) : kMaxScanEvents;
         // Large passes: the root kernel of a slice goes to the helper stream, so it runs beside the elimination kernel of the next
         // slice (both are latency-bound at these sizes and leave most issue slots idle; unlike the counting kernel, which saturates
