@@ -18,7 +18,7 @@ ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic
 CONFIG_KEYS = ("workload", "pairs_per_gpu", "value_single_pair", "ms_single_pair", "value_8_pairs_per_launch", "steady_pairs_per_s", "steady_frac",
                "clock_GHz_steady_median", "clock_GHz_stamped_median", "ransac_c3_hyp_per_s", "ransac_c3_count_frac_fp32_peak",
                "ransac_c3_cpu_hyp_per_s_1_core", "c5_image_pairs_per_s", "c5_ms_per_step", "c5_estimator", "c5_cpu_image_pairs_per_s_1_core",
-               "c5_usac_uniform_ms_per_512", "c5_usac_default_refine_ms_per_512", "solver_polish", "verified")
+               "c5_usac_default_refine_ms_per_512", "settle_steps", "solver_polish", "verified")
 
 
 def _num(x, sig=6):

@@ -137,6 +137,7 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_hamming_mfma_weighted = 1;
     ctx->opt_hamming_mfma_prio = 0;
     ctx->opt_hamming_fused_merge = 1;
+    ctx->opt_hamming_expand_fine = 1;
     ctx->opt_hamming_merge_emit = 0;  // measured (tools/single_pair_probe.py): the launch it saves is what the chained look-back costs -- 21.2-22.2 against 20.8-21.4 us
     ctx->opt_ransac_lazy_sums = 1;
     ctx->opt_ransac_overlap = 1;
@@ -214,6 +215,7 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "hamming_mfma_qt") && (value == 0 || value == 1 || value == 2 || value == 4)) ctx->opt_hamming_mfma_qt = value;
     else if (!std::strcmp(name, "hamming_mfma_blocks_per_cu") && value >= 1 && value <= 64) ctx->opt_hamming_mfma_blocks_per_cu = value;
     else if (!std::strcmp(name, "hamming_mfma_lds") && (value >= 0 && value <= 2)) ctx->opt_hamming_mfma_lds = value;
+    else if (!std::strcmp(name, "hamming_expand_fine") && (value == 0 || value == 1)) ctx->opt_hamming_expand_fine = value;
     else if (!std::strcmp(name, "hamming_mfma_prio") && (value >= 0 && value <= 3)) ctx->opt_hamming_mfma_prio = value;
     else if (!std::strcmp(name, "hamming_mfma_prefetch") && (value == 0 || value == 2 || value == 4 || value == 6)) ctx->opt_hamming_mfma_prefetch = value;
     else if (!std::strcmp(name, "hamming_split_rows") && (value == 0 || value == 4096 || value == 8192)) ctx->opt_hamming_split_rows = value;

@@ -135,6 +135,23 @@ __global__ __launch_bounds__(256) void hamming_expand_kernel(ExpandArgs qa, Expa
     }
 }
 
+// The same expansion of a TRAIN set of 32-byte descriptors with one thread per (tile, K-step, lane) instead of per (tile, lane): for ONE
+// image pair hamming_expand_kernel<4> is 64 workgroups with 16 expansions per thread -- a quarter of the chip, one long thread each; this
+// form is one 256-thread workgroup per tile (256 for 8192 rows).  Same bytes at the same addresses.  (Round 6, the latency shape.)
+__global__ __launch_bounds__(256) void hamming_expand_fine_kernel(ExpandArgs A, int train01) {
+    constexpr int KS = 4;
+    const int b = blockIdx.y;
+    const int tile = blockIdx.x;   // gridDim.x == A.tiles
+    const int l = threadIdx.x & 63, st = threadIdx.x >> 6;
+    const int row = tile * 32 + (l & 31);
+    const int w = (l >> 5) * KS + st;
+    const uint32_t v = row < A.n ? A.src[(size_t)b * A.src_batch_words + (size_t)row * (2 * KS) + w] : 0u;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 o = {expand_byte(v & 255u), expand_byte((v >> 8) & 255u), expand_byte((v >> 16) & 255u), expand_byte(v >> 24)};
+    if (train01) o = u32x4{expand_byte01(v & 255u), expand_byte01((v >> 8) & 255u), expand_byte01((v >> 16) & 255u), expand_byte01(v >> 24)};
+    __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(A.dst + ((size_t)b * A.tiles + tile) * KS * 64 + st * 64 + l));
+}
+
 // Round 5: the UNSCALED form.  v_mfma_scale_f32_32x32x64_f8f6f4 is a two-part instruction (a scale-load prefix + the MFMA) that reads two
 // more registers; with unit scales it computes what v_mfma_f32_32x32x64_f8f6f4 computes without them.  The compiler selects the unscaled
 // opcode when both scale operands are the constant 0 (its encoding of "no scales").  Rounds 1-4 issued the scaled form with E8M0 0x7F
@@ -963,6 +980,10 @@ int launch_knn_hamming_mfma(mlpl_ctx *ctx, const uint32_t *qw, size_t q_batch_wo
     const ExpandArgs ta{tw, t_batch_words, nt, t_tiles, (uint4 *)tf};
     const ExpandArgs qa = expand_q ? ExpandArgs{qw, q_batch_words, nq, q_tiles_padded, (uint4 *)qf} : ta;  // blockIdx.z == 0
     const dim3 egrid((unsigned)(((expand_q ? std::max(q_tiles_padded, t_tiles) : t_tiles) * 64 + 255) / 256), batch, expand_q ? 2 : 1);
+    // (one thread per K-step when the launch is small: the single-pair latency shape)
+    if (!expand_q && ks == 4 && nw == 8 && !counters && (long long)t_tiles * batch <= 4LL * ctx->num_cus && ctx->opt_hamming_expand_fine) {
+        hipLaunchKernelGGL(hamming_expand_fine_kernel, dim3((unsigned)t_tiles, batch), dim3(256), 0, s, ta, train01);
+    } else
     switch (ks) {
         case 1: hipLaunchKernelGGL(hamming_expand_kernel<1>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch, train01); break;
         case 2: hipLaunchKernelGGL(hamming_expand_kernel<2>, egrid, dim3(256), 0, s, qa, ta, nw, counters, counters_per_batch, train01); break;

@@ -118,6 +118,7 @@ struct mlpl_ctx {
     int opt_hamming_fused_merge;    // 1 (default) = the static LDS-ring kernel merges its splits / evaluates the ratio predicate itself (no merge launch)
     void *hamming_tickets_ptr;      // zeroed ticket counters of that merge (WS_TICKETS) ...
     size_t hamming_tickets_bytes;   // ... and how many bytes of them are known to be zero
+    int opt_hamming_expand_fine;    // 1 (default) = small launches expand the train set with one thread per (tile, K-step, lane)
     int opt_hamming_stamps;         // diagnostics: 1 = the matrix-core kernel records per-wave clock stamps (mlpl_debug_hamming_stamps); 2 = one clock record per launch into a ring (mlpl_debug_hamming_clock)
     long long hamming_clock_launches;   // launches recorded into the clock ring so far
     int opt_hamming_merge_emit;     // 1 = one image pair per call: the merge kernel writes the DMatch rows itself (no ratio_write launch); default 0: measured, no faster

@@ -31,9 +31,14 @@ if ks:
 for name in ("bench_plain.json", "bench_under_rocprof.json"):
     p = os.path.join(SRC, name)
     if os.path.exists(p):
-        line = [x for x in open(p).read().splitlines() if x.startswith("{")]
-        if line:
+        text = open(p).read().splitlines()
+        line = [x for x in text if x.startswith("{")]
+        if line:   # the final line = what the driver parses
             json.dump(json.loads(line[-1]), open(os.path.join(DST, f"{R}_{name}"), "w"), indent=1)
+        for tag in ("bench_detail ", "bench_secondary "):   # round 6 on: the two lines in front of it
+            more = [x for x in text if x.startswith(tag)]
+            if more:
+                json.dump(json.loads(more[-1][len(tag):]), open(os.path.join(DST, f"{R}_{name}".replace(".json", "_" + tag.strip()[6:] + ".json")), "w"), indent=1)
 
 summary = {}
 for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm"):
