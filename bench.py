@@ -99,7 +99,7 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
     ids = list(range(begin, end))
     d_matches = torch.zeros((cap, args.n, 4), dtype=torch.int32, device=dev)
     state = {}
-    use_rccl = args.backend == "nccl" or world == 1
+    use_rccl = args.backend == "nccl" or not dist_on(world)
 
     # The robust estimator of the pipeline: "ransac" = estimateEssentialMat(..., "RANSAC") at (1000, 0.999), mlpl_pair_pose_batch_dev;
     # "usac" / "usac_prosac" = the harness' cfgUSAC (POSE_STEWENIUS + REF_WEIGHTS + SPRT + LO; T/poselib-test/main.cpp:734, 1135-1162), uniform /
@@ -141,11 +141,11 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
                                  matches_out=d_matches[:mine])
         else:
             recs = one_call()
-        state["rec"] = batch.gather_records(recs, total, rank, world, device=dev if use_rccl else None)
+        state["rec"] = batch.gather_records(recs, total, rank, world, device=dev if use_rccl else None, force_collective=FORCE_DIST["on"])
         state["matches"] = batch.gather_match_lists(d_matches if use_rccl else d_matches.cpu(), total, rank, world, root=0)
 
     def barrier():
-        if world > 1:
+        if dist_on(world):
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -175,7 +175,7 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
                 state.setdefault("lane_spans", []).append([[round((a - ts) * 1e3, 2), round((b - ts) * 1e3, 2)] for a, b in lanes.last_lane_span])
         barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if dist_on(world):
             tt = torch.tensor([el], dtype=torch.float64, device=dev if use_rccl else None)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
@@ -252,7 +252,7 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
                             ("mlpl_pair_pose_batch_arrsac_dev" if est == "arrsac" else "mlpl_pair_pose_batch_usac_dev") +
                             " (every pair's sequential estimator = a fiber behind the launch hub, launches merged over the pairs; one call per step)",
                    "parallelism": f"shard{world}",
-                   "world_size": world, "backend": args.backend if world > 1 else None,
+                   "world_size": world, "backend": args.backend if dist_on(world) else None,
                    "gathered_per_step": "184-byte records by all_gather + the padded match lists to rank 0 by grouped send / recv",
                    "mean_matches": float(allrec["n_matches"].mean()), "mean_inliers": float(allrec["n_inliers"].mean()),
                    "ransac_passes_rank0": int(stats[0]), "pair_slots_rank0": int(stats[1]), "iterations_rank0": int(stats[6]),
@@ -330,12 +330,17 @@ def run_c5(args, rank, local_rank, world, dev, ctx):
     if rank == 0:
         import bench_record
         rec["c5"] = {k: v for k, v in rec.items() if k != "c5"}   # the same object as the secondary line's `c5`
-        if world > 1:
+        if dist_on(world):
             rec["rccl_ranks_seen"] = RCCL_RANKS_SEEN.get("n")
         bench_record.emit(rec, os.path.join(ROOT, "bench_detail.json"))
 
 
 RCCL_RANKS_SEEN = {}
+FORCE_DIST = {"on": False}   # --force-dist: run every collective of the N > 1 path with ONE rank (rehearsal on a one-GPU box: the RCCL calls are real)
+
+
+def dist_on(world):
+    return world > 1 or FORCE_DIST["on"]
 
 
 def main():
@@ -354,6 +359,8 @@ def main():
                     help="bracket every Nth launch of the dominant kernel inside the timed region (two event records cost ~10 us)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal only: with --gpus 1, initialise the process group (world size 1) and run every collective of the N > 1 path")
     ap.add_argument("--gather-every", type=int, default=1, help="steps per record gather (N > 1): one step of 64 pairs = a C5 shard")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (RANSAC / L2) measurements")
     ap.add_argument("--hamming-variant", type=int, default=3,
@@ -388,11 +395,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus} (under an external launcher pass --gpus = its world size)"
+    FORCE_DIST["on"] = bool(args.force_dist)
+    if args.force_dist and "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if dist_on(world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -419,7 +432,7 @@ def main():
         if args.steps == 200 and args.warmup == 20:   # the defaults are sized for the C2 step; a C5 step is a whole batch
             args.steps, args.warmup = 5, 2
         run_c5(args, rank, local_rank, world, dev, ctx)
-        if world > 1:
+        if dist_on(world):
             dist.barrier()
             dist.destroy_process_group()
         ctx.close()
@@ -442,13 +455,13 @@ def main():
     first = match_hamming_device(d_q, d_t, ratio_test=True, ratio=0.75, ctx=ctx, stream=stream)   # allocates idx/dist/matches
     records = [torch.zeros((G * P,), dtype=torch.int32, device=dev) for _ in range(2)]
     outs = [[dict(first, count=records[b][g * P:(g + 1) * P]) for g in range(G)] for b in range(2)]
-    gathered = [torch.empty((world * G * P,), dtype=torch.int32, device=dev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty((world * G * P,), dtype=torch.int32, device=dev) for _ in range(2)] if dist_on(world) else None
     pending = [None, None]
     step_no = 0
     out = None
 
     def flush(b):
-        if world > 1:
+        if dist_on(world):
             pending[b] = dist.all_gather_into_tensor(gathered[b], records[b], async_op=True)
 
     def step():
@@ -469,7 +482,7 @@ def main():
             if pending[i] is not None:
                 pending[i].wait()
                 pending[i] = None
-        if world > 1:
+        if dist_on(world):
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -500,7 +513,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         _lib.check(lib.mlpl_profile_enable(ctx.handle, 0), "profile_enable")
-        if world > 1:
+        if dist_on(world):
             tt = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
@@ -570,7 +583,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             eight_ms = e0.elapsed_time(e1) / 50
-    if world > 1:  # every rank must hold every rank's records after the last gather
+    if dist_on(world):  # every rank must hold every rank's records after the last gather
         lastb = ((step_no - 1) // G) & 1
         g = gathered[lastb].cpu().numpy().reshape(world, G * P)
         mine = records[lastb].cpu().numpy()
@@ -801,7 +814,7 @@ def main():
         import bench_record
         merged = dict(rec["config"])
         merged.update(cfg)
-        merged.update({"matches_first_pair": counts[0], "hamming_kernel": kernel_name, "world_size": world, "backend": args.backend if world > 1 else None,
+        merged.update({"matches_first_pair": counts[0], "hamming_kernel": kernel_name, "world_size": world, "backend": args.backend if dist_on(world) else None,
                        "parallelism": f"shard{world}", "records_gathered_every_steps": G,
                        "value_is": f"the BATCHED rate: {P} independent C2 image pairs per launch per GPU (a rank's share of BASELINE's 512-pair batch "
                                    "on 8 GPUs) under the given --steps / --warmup; steady_* = the same step in a long run; value_single_pair = "
@@ -809,10 +822,10 @@ def main():
         # the final line's keys first, in its order; everything else behind them (bench_detail only)
         rec["config"] = {k: merged[k] for k in bench_record.CONFIG_KEYS if k in merged}
         rec["config"].update({k: v for k, v in merged.items() if k not in rec["config"]})
-        if world > 1:
+        if dist_on(world):
             rec["rccl_ranks_seen"] = RCCL_RANKS_SEEN.get("n")
         bench_record.emit(rec, os.path.join(ROOT, "bench_detail.json"))
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -60,7 +60,7 @@ def host_thread_budget(cpus: int, local_world: int, estimator: str) -> dict:
 _gather_stage = {}   # (cap, world, device) -> (pinned host block, device block, device gather buffer, pinned host gather buffer)
 
 
-def gather_records(local: np.ndarray, num_pairs: int, rank: int, world: int, device=None, group=None) -> Optional[np.ndarray]:
+def gather_records(local: np.ndarray, num_pairs: int, rank: int, world: int, device=None, group=None, force_collective: bool = False) -> Optional[np.ndarray]:
     """All-gathers the ranks' record blocks (padded to equal size) and returns the num_pairs records in pair order on
     every rank.  `device` = torch device the collective runs on (cuda for RCCL, cpu / None for gloo).  On a GPU the blocks travel through
     PERSISTENT pinned and device staging buffers (one asynchronous H2D, the all_gather on the device, one D2H, one synchronisation per
@@ -71,7 +71,7 @@ def gather_records(local: np.ndarray, num_pairs: int, rank: int, world: int, dev
 
     cap = shard_capacity(num_pairs, world)
     isz = RECORD_DTYPE.itemsize
-    if world == 1:
+    if world == 1 and not force_collective:   # (force_collective: rehearsal of the collective path with one rank)
         buf = np.zeros(cap, RECORD_DTYPE)
         buf["pair_id"] = -1
         buf[: len(local)] = local

@@ -58,3 +58,32 @@ def test_two_ranks_with_the_sequential_estimators(tmp_path, estimator):
     assert two_line["n_gpus"] == 2 and two_line["config"]["pairs_this_rank"] == 8
     assert one["records"].tobytes() == two["records"].tobytes()
     assert one["matches"].tobytes() == two["matches"].tobytes()
+
+
+@pytest.mark.parametrize("workload", ["c2", "c5"])
+def test_every_collective_of_the_n_gpu_path_runs_through_rccl_with_one_rank(tmp_path, workload):
+    """No box of the pool has two cards, so RCCL never sees N > 1 here -- but every collective CALL of the N > 1 path can run for real with a
+    world of one: `--force-dist` initialises the nccl process group on cuda:0 and takes every `N > 1` branch (the all_reduce of ones, the
+    asynchronous all_gather of the match counts per step, the staged all_gather of the records through pinned + device buffers, the
+    max-over-ranks reduction, the barriers).  The record must say so, and the C5 records must equal the plain one-rank run's."""
+    out = os.path.join(str(tmp_path), f"force_{workload}.npz")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--settle-steps", "0",
+            "--steady-steps", "0", "--after-idle-launches", "0"]
+    if workload == "c5":
+        base += ["--workload", "c5", "--c5-pairs", "16", "--c5-distinct", "16", "--n", "2048", "--dump-records", out]
+    else:
+        base += ["--no-extras", "--pairs-per-gpu", "8", "--n", "2048"]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(base + ["--force-dist"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    head = json.loads(r.stdout.splitlines()[-1])
+    assert head["rccl_ranks_seen"] == {"world_size": 1, "all_reduce_of_ones": 1, "backend": "nccl"}, head.get("rccl_ranks_seen")
+    assert head["n_gpus"] == 1 and head["value"] > 0
+    if workload == "c5":
+        forced = np.load(out)
+        plain_out = os.path.join(str(tmp_path), "plain.npz")
+        r2 = subprocess.run([a if a != out else plain_out for a in base], env=env, capture_output=True, text=True, timeout=600)
+        assert r2.returncode == 0, r2.stderr[-3000:]
+        plain = np.load(plain_out)
+        assert forced["records"].tobytes() == plain["records"].tobytes() and forced["matches"].tobytes() == plain["matches"].tobytes()
