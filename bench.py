@@ -564,14 +564,16 @@ def main():
     single_ms = eight_ms = None
     if rank == 0:
         o1 = match_hamming_device(d_q[:1], d_t[:1], ratio_test=True, ratio=0.75, ctx=ctx, stream=stream)
+        for _ in range(50):   # (the first calls of a new launch shape size its workspaces and split tables)
+            o1 = match_hamming_device(d_q[:1], d_t[:1], ratio_test=True, ratio=0.75, ctx=ctx, out=o1, stream=stream)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(50):
+        for _ in range(300):
             o1 = match_hamming_device(d_q[:1], d_t[:1], ratio_test=True, ratio=0.75, ctx=ctx, out=o1, stream=stream)
         e1.record()
         torch.cuda.synchronize()
-        single_ms = e0.elapsed_time(e1) / 50
+        single_ms = e0.elapsed_time(e1) / 300
         assert int(o1["count"][0].item()) == counts[0] or P == 0
         eight_ms = None
         if P >= 8:   # the launch shape of rounds 1-2 (8 pairs per launch), for continuity
