@@ -167,14 +167,14 @@ def measure_c5(args, rank, local_rank, world, dev, ctx, steps, warmup, cpu_basel
         stats[6] = int(state["raw"]["iters"].sum())   # hypotheses of the rank's share
     prof = {}
     for name, kid in (("knn_hamming_mfma_lds_kernel<4, 0, 8>", 0), ("solve5pt3_kernel + roots_kernel_t<true>", 2),
-                      ("count_models_f32_kernel<512, 512>", 3), ("decompose / triangulate / select (batch)", 4)):
+                      ("count_models_f32_kernel<256, 512, 2, true>", 3), ("decompose / triangulate / select (batch)", 4)):
         ms, cnt = C.c_double(0), C.c_int(0)
         lib.mlpl_profile_read(ctx.handle, kid, C.byref(ms), C.byref(cnt))
         prof[name] = (ms.value, cnt.value)
     per_step = {k: v[0] / max(prof_steps, 1) for k, v in prof.items()}
     dom = max(per_step, key=per_step.get)
     evals = float(stats[5])  # Sampson evaluations of this rank's last step
-    score_ms = per_step["count_models_f32_kernel<512, 512>"]
+    score_ms = per_step["count_models_f32_kernel<256, 512, 2, true>"]
     ham_ms = per_step["knn_hamming_mfma_lds_kernel<4, 0, 8>"]
     out = {
         "metric": "image-pairs/s (C5: stereo pairs x (8k ORB BF-Hamming match + 5-pt RANSAC + cheirality))",

@@ -69,7 +69,7 @@ def run(ctx, dev, cpu_baseline=True):
         "score_kernel_ms_per_call": score_ms,
         "count_kernel_ms_per_call": count_ms,
         "models_scored": models,
-        "roofline": {"kernel": "count_models_f32_kernel<512, 512, 2, true>", "bound": "valu-fp32",
+        "roofline": {"kernel": "count_models_f32_kernel<%d, 512, 2, true>" % ctx.get_option("ransac_count_threads"), "bound": "valu-fp32",
                      "achieved": 39.0 * n * models / (count_ms * 1e-3) / 1e12,
                      "peak": FP32_VALU_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": 39.0 * n * models / (count_ms * 1e-3) / FP32_VALU_PEAK,

@@ -94,7 +94,9 @@ int mlpl_ctx_synchronize(mlpl_ctx *ctx);
  *     "hub_blocking_sync" (default 1: a cohort's thread sleeps at the end of a round instead of spinning), "pair_batch" /
  *     "pair_batch_seq" (image pairs per internal batch of mlpl_pair_pose_batch_dev, 0 = 256 / of its USAC and ARRSAC forms, 0 = 512).
  *     Hamming: "hamming_fused_merge" (default 1) = the LDS-ring kernel folds its train splits, evaluates the ratio predicate and counts
- *     itself, 0 = separate merge launch; RANSAC: "ransac_count_mpl" 1|2 models per lane of the counting kernel (A/B, default 2).
+ *     itself, 0 = separate merge launch; RANSAC: "ransac_count_mpl" 1|2 models per lane of the counting kernel (A/B, default 2);
+ *     "ransac_count_threads" 256 (default since round 6: 4-wave workgroups at 96 VGPRs, five per CU) | 512; "ransac_count_tiles" 2 (default) | 1
+ *     tiles of 512 correspondences per counting workgroup.
  *   "solver_polish" (default 1) = every 5-point solution is finished by <= 4 Gauss-Newton steps on the ten cubic constraints (a step is
  *     kept only while the residual falls).  It is the accuracy safeguard of THIS solver, not a departure from the reference: the device's
  *     elimination (like the CPU code's, five-point.cpp:366-471, but on other samples) is ill conditioned on ~0.4 % of minimal samples and its

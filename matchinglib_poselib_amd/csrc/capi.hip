@@ -144,6 +144,8 @@ int mlpl_ctx_create(int device_ordinal, mlpl_ctx **out) {
     ctx->opt_ransac_f32_filter = 1;
     ctx->opt_ransac_count_mpl = 2;
     ctx->opt_ransac_count_tiles = 2;
+    ctx->opt_ransac_count_wpe = 5;
+    ctx->opt_ransac_count_threads = 256;   // round 6: 4-wave workgroups at 96 VGPRs, five per CU (C5 counting -6-8 %, C3 equal)
     ctx->opt_ransac_count_defer = 1;
     ctx->opt_pair_batch_feed = 1;
     ctx->opt_solver_polish = 1;   // the solver's accuracy safeguard stays on: measured CLOSER to the CPU path than the plain root path (tools/polish_default_ab.py)
@@ -237,6 +239,8 @@ int mlpl_set_option(mlpl_ctx *ctx, const char *name, int value) {
     else if (!std::strcmp(name, "arrsac_refine_warm_start") && (value == 0 || value == 1)) ctx->opt_arrsac_refine_warm_start = value;
     else if (!std::strcmp(name, "ransac_count_mpl") && (value == 1 || value == 2)) ctx->opt_ransac_count_mpl = value;
     else if (!std::strcmp(name, "ransac_count_tiles") && (value == 1 || value == 2)) ctx->opt_ransac_count_tiles = value;
+    else if (!std::strcmp(name, "ransac_count_threads") && (value == 256 || value == 512)) ctx->opt_ransac_count_threads = value;
+    else if (!std::strcmp(name, "ransac_count_wpe") && (value == 5 || value == 6)) ctx->opt_ransac_count_wpe = value;
     else if (!std::strcmp(name, "ransac_count_defer") && (value == 0 || value == 1)) ctx->opt_ransac_count_defer = value;
     else if (!std::strcmp(name, "ransac_event_cap") && value >= 0 && value <= 1024) ctx->opt_ransac_event_cap = value;
     else if (!std::strcmp(name, "solver_polish") && (value == 0 || value == 1)) ctx->opt_solver_polish = value;
@@ -280,6 +284,7 @@ int mlpl_get_option(mlpl_ctx *ctx, const char *name, int *value) {
     else if (!std::strcmp(name, "hamming_mfma_waves")) *value = ctx->opt_hamming_mfma_waves;
     else if (!std::strcmp(name, "solver_polish")) *value = ctx->opt_solver_polish;
     else if (!std::strcmp(name, "ransac_count_mpl")) *value = ctx->opt_ransac_count_mpl;
+    else if (!std::strcmp(name, "ransac_count_threads")) *value = ctx->opt_ransac_count_threads;
     else if (!std::strcmp(name, "ransac_count_tiles")) *value = ctx->opt_ransac_count_tiles;
     else if (!std::strcmp(name, "ransac_count_defer")) *value = ctx->opt_ransac_count_defer;
     else if (!std::strcmp(name, "hub_workers")) *value = ctx->opt_hub_workers;

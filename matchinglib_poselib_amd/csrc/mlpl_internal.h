@@ -130,6 +130,8 @@ struct mlpl_ctx {
     int opt_ransac_chunk;           // hypotheses per device pass (0 = 32768)
     int opt_ransac_event_cap;       // tests: capacity of the record-event list of candidate / replay kernels (0 = 1024); forces their serial fallback
     int opt_ransac_count_mpl;       // models per lane of the packed-fp32 counting kernel: 2 (default) or 1
+    int opt_ransac_count_threads;   // threads per workgroup of the counting kernel: 256 (default since round 6: 4 waves, 96 VGPRs, five workgroups per CU) or 512 (rounds 2-5: 8 waves, two per CU)
+    int opt_ransac_count_wpe;       // waves per SIMD the 256-thread counting kernel's registers are cut for: 5 (96 VGPRs) or 6 (80 VGPRs, a few spills outside the loop)
     int opt_ransac_count_tiles;     // 512-correspondence tiles one workgroup of the counting pass walks: 2 (rounds 3-5) or 1 (more, shorter workgroups: less idle tail)
     int opt_ransac_count_defer;     // 1 (default) = the packed-fp32 counting kernel queues its undecided evaluations in LDS and decides them workgroup-wide (same counts)
     int opt_ransac_f32_filter;      // 1 (default) = the count-only scoring kernels pre-filter in packed fp32 inside a rigorous error band (same counts)

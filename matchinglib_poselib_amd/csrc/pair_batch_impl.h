@@ -275,7 +275,17 @@ int pair_pose_batch_dev(mlpl_ctx *ctx, int B, const uint8_t *d_q, int nq, const 
         {
             const int ntiles_max = (max_n + kScoreTile - 1) / kScoreTile;
             const int point_splits = ctx->opt_ransac_count_tiles == 1 ? std::max(1, std::min(16, ntiles_max)) : std::max(1, std::min(8, ntiles_max / 2));
-            if (ctx->opt_ransac_count_mpl == 2 && ctx->opt_ransac_count_defer && max_n < (1 << 23)) {   // (the queue entry holds 23 bits of correspondence index)
+            if (ctx->opt_ransac_count_mpl == 2 && ctx->opt_ransac_count_defer && max_n < (1 << 23) && ctx->opt_ransac_count_threads == 256 && ctx->opt_ransac_count_wpe == 6) {
+                const dim3 grid((Hp * 10 + 127) / 128, point_splits, A);
+                hipLaunchKernelGGL((count_models_f32_kernel<256, kScoreTile, 2, true, 6>), grid, dim3(256), 0, s, (const double4 *)nullptr, 0,
+                                   (const double *)d_denseE, (const int32_t *)d_dense_id, (const int32_t *)d_dense_total, 0, thresh2, qmax, d_good,
+                                   (const PairSlot *)d_slots, Hp);
+            } else if (ctx->opt_ransac_count_mpl == 2 && ctx->opt_ransac_count_defer && max_n < (1 << 23) && ctx->opt_ransac_count_threads == 256) {
+                const dim3 grid((Hp * 10 + 127) / 128, point_splits, A);
+                hipLaunchKernelGGL((count_models_f32_kernel<256, kScoreTile, 2, true>), grid, dim3(256), 0, s, (const double4 *)nullptr, 0,
+                                   (const double *)d_denseE, (const int32_t *)d_dense_id, (const int32_t *)d_dense_total, 0, thresh2, qmax, d_good,
+                                   (const PairSlot *)d_slots, Hp);
+            } else if (ctx->opt_ransac_count_mpl == 2 && ctx->opt_ransac_count_defer && max_n < (1 << 23)) {   // (the queue entry holds 23 bits of correspondence index)
                 const dim3 grid((Hp * 10 + 2 * kScoreModels - 1) / (2 * kScoreModels), point_splits, A);
                 hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile, 2, true>), grid, dim3(kScoreThreads), 0, s, (const double4 *)nullptr, 0,
                                    (const double *)d_denseE, (const int32_t *)d_dense_id, (const int32_t *)d_dense_total, 0, thresh2, qmax, d_good,

@@ -1412,8 +1412,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // (kDeferCap entries; a band that is infinite -- out-of-range scales -- queues everything) makes the workgroup recount its share in fp64
 // afterwards, outside the loop as well.
 constexpr int kDeferCap = 2048;
-template <int kThreads, int kTile, int MPL = 1, bool DEFER = false>
-__global__ __launch_bounds__(kThreads, (DEFER ? 4 : 1)) void count_models_f32_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
+template <int kThreads, int kTile, int MPL = 1, bool DEFER = false, int WPE = 0>   // WPE: waves per SIMD the register budget is cut for (0 = by shape)
+__global__ __launch_bounds__(kThreads, (WPE ? WPE : (DEFER ? (kThreads == 256 ? 5 : 4) : 1))) void count_models_f32_kernel(const double4 *__restrict__ pts, int n, const double *__restrict__ E_list,
                                                                     const int32_t *__restrict__ ids, const int32_t *__restrict__ total_ptr,
                                                                     int total_host, double thresh2, double qmax, int32_t *__restrict__ good,
                                                                     const PairSlot *__restrict__ ps = nullptr, int slot_stride = 0) {
@@ -3159,7 +3159,7 @@ double inlier_bound(double thresh2) {
 constexpr int kScoreBlockMaxModels = 24576;
 static void launch_score(hipStream_t s, const double4 *pts, int n, const double *E_list, const int32_t *ids, const int32_t *total_ptr,
                          int total_host, int max_models, double thresh2, int32_t *good, double *esum, bool sums = true,
-                         double qmax = -1.0, int point_splits = 1, bool f32_filter = false, int mpl = 1, bool defer = false) {
+                         double qmax = -1.0, int point_splits = 1, bool f32_filter = false, int mpl = 1, bool defer = false, int count_threads = 512, int count_wpe = 5) {
     if (max_models <= 0) return;
     const size_t lds = (size_t)((n + 3) / 4 * 4) * sizeof(float);
     const bool block = n <= kScoreBlockMaxN && max_models <= kScoreBlockMaxModels;
@@ -3183,7 +3183,13 @@ static void launch_score(hipStream_t s, const double4 *pts, int n, const double 
                                ids, total_ptr, total_host, thresh2, qmax, good, esum);
     } else {
         const dim3 grid((max_models + kScoreModels - 1) / kScoreModels, point_splits);
-        if (f32_filter && mpl == 2 && defer && n < (1 << 23))
+        if (f32_filter && mpl == 2 && defer && n < (1 << 23) && count_threads == 256 && count_wpe == 6)   // A/B: 80 VGPRs, six 4-wave workgroups per CU
+            hipLaunchKernelGGL((count_models_f32_kernel<256, kScoreTile, 2, true, 6>), dim3((max_models + 127) / 128, point_splits),
+                               dim3(256), 0, s, pts, n, E_list, ids, total_ptr, total_host, thresh2, qmax, good);
+        else if (f32_filter && mpl == 2 && defer && n < (1 << 23) && count_threads == 256)   // round 6: 4-wave workgroups at 96 VGPRs, five per CU
+            hipLaunchKernelGGL((count_models_f32_kernel<256, kScoreTile, 2, true>), dim3((max_models + 127) / 128, point_splits),
+                               dim3(256), 0, s, pts, n, E_list, ids, total_ptr, total_host, thresh2, qmax, good);
+        else if (f32_filter && mpl == 2 && defer && n < (1 << 23))
             hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile, 2, true>), dim3((max_models + 2 * kScoreModels - 1) / (2 * kScoreModels), point_splits),
                                dim3(kScoreThreads), 0, s, pts, n, E_list, ids, total_ptr, total_host, thresh2, qmax, good);
         else if (f32_filter && mpl == 2)
@@ -3446,7 +3452,12 @@ static int score_models_impl(mlpl_ctx *ctx, const double *p1, const double *p2, 
     if ((rc = pack_points(ctx, (const double *)dp1, (const double *)dp2, n, &pts, s))) return rc;
     prof_mark(ctx, MLPL_PROF_SCORE, 0, s);
     const double qmax = inlier_bound(thresh2);
-    if (shape == 1 && !err_sum && ctx->opt_ransac_f32_filter && ctx->opt_ransac_count_mpl == 2 && ctx->opt_ransac_count_defer && n < (1 << 23))
+    if (shape == 1 && !err_sum && ctx->opt_ransac_f32_filter && ctx->opt_ransac_count_mpl == 2 && ctx->opt_ransac_count_defer && n < (1 << 23) &&
+        ctx->opt_ransac_count_threads == 256)
+        hipLaunchKernelGGL((count_models_f32_kernel<256, kScoreTile, 2, true>), dim3((n_models + 127) / 128), dim3(256), 0, s,
+                           (const double4 *)pts, n, (const double *)dE, (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, thresh2, qmax,
+                           (int32_t *)dgood);
+    else if (shape == 1 && !err_sum && ctx->opt_ransac_f32_filter && ctx->opt_ransac_count_mpl == 2 && ctx->opt_ransac_count_defer && n < (1 << 23))
         hipLaunchKernelGGL((count_models_f32_kernel<kScoreThreads, kScoreTile, 2, true>), dim3((n_models + 2 * kScoreModels - 1) / (2 * kScoreModels)), dim3(kScoreThreads), 0, s,
                            (const double4 *)pts, n, (const double *)dE, (const int32_t *)nullptr, (const int32_t *)nullptr, n_models, thresh2, qmax,
                            (int32_t *)dgood);
@@ -3680,7 +3691,7 @@ int mlpl_ransac_essential_dev(mlpl_ctx *ctx, const double *d_p1, const double *d
         prof_mark(ctx, MLPL_PROF_COUNT, 0, s);
         launch_score(s, (const double4 *)pts, n, (const double *)B.dense_E, (const int32_t *)B.dense_id, (const int32_t *)B.total, 0,
                      cnt * 10, thresh2, B.good, B.esum, !lazy, qmax, point_splits, ctx->opt_ransac_f32_filter != 0, ctx->opt_ransac_count_mpl,
-                     ctx->opt_ransac_count_defer != 0);
+                     ctx->opt_ransac_count_defer != 0, ctx->opt_ransac_count_threads, ctx->opt_ransac_count_wpe);
         prof_mark(ctx, MLPL_PROF_COUNT, 1, s);
         if (lazy) {
             // error sums only for the models that can still win (ties on the inlier count are decided by them)

@@ -30,6 +30,7 @@ while time.time() - t0 < budget:
     good, esum = pose.score_models(p1, p2, E, np.sqrt(t2), ctx=ctx)
     t2 = float(np.sqrt(t2)) ** 2        # score_models squares its argument: use exactly that value
     ctx.set_option("ransac_count_defer", int(rng.integers(0, 2)))   # the deferred queue of the counting kernel and its inline form
+    ctx.set_option("ransac_count_threads", int(rng.choice([256, 512])))   # 4-wave (default since round 6) and 8-wave workgroups
     for shape in (1, 2):
         c = pose.count_models(p1, p2, E, t2, shape=shape, ctx=ctx)
         if not np.array_equal(c, good):
