@@ -120,6 +120,7 @@ def main():
                     help="untimed steps BEFORE the --warmup steps: the power controller needs ~100-300 launches to settle after the GPU sat idle "
                          "through the input generation (clock 1.87 -> 1.50 -> 1.9 GHz); the metric is steady-state throughput, the transient is "
                          "reported separately (after_idle).  0 = rounds 1-5: warm-up steps only")
+    ap.add_argument("--step-events", type=int, default=1, help="1 = one HIP event per timed step (roofline.ms_steps_gpu); 0 = none inside the timed region")
     ap.add_argument("--after-idle-launches", type=int, default=24,
                     help="launches whose clock / duration are recorded after the GPU sat idle during the CPU baseline (0 = none)")
     ap.add_argument("--hamming-train01", type=int, default=-1, help="encoding of the train operand of the matrix-core kernel: 1 = {0, +1}, 0 = +-1, -1 = library default")
@@ -276,7 +277,7 @@ def main():
     barrier()
     for _ in range(args.warmup):
         step()
-    elapsed, kern_ms, n_bracketed, ms_steps_gpu, clk_timed = timed_region(args.steps, True)
+    elapsed, kern_ms, n_bracketed, ms_steps_gpu, clk_timed = timed_region(args.steps, bool(args.step_events))
     # steady state (VERDICT r4 #1b): the driver's protocol (20 steps after 5 warm-ups) times the first ~11 ms of GPU work after the input
     # upload; the same step in a long run is measured right behind it, same buffers, same verification below.  `value` stays the former.
     steady = None
@@ -506,7 +507,7 @@ def main():
                                  "first_workgroup_us": [round(float(x), 1) for x in ai_dur],
                                  "what": "the first launches after the GPU idled through the CPU baseline: GPU time per step (events) and the "
                                          "shader clock inside each launch"}
-            rec["timed_region"] = {"ms_steps_gpu": [round(x, 4) for x in ms_steps_gpu]}
+            rec["timed_region"] = {"ms_steps_gpu": [round(x, 4) for x in ms_steps_gpu] if ms_steps_gpu else None}
             rec["config"]["clock_GHz_stamped_median"] = float(np.median(ai_ghz)) if len(ai_ghz) else None   # of the after-idle launches
         if not args.no_extras and world == 1:
             try:
